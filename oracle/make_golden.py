@@ -1,0 +1,200 @@
+"""TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz from the REFERENCE's own code.
+
+Run in the build container (needs /root/reference):   python oracle/make_golden.py
+Every fixture is produced by executing the reference's unmodified modules on CPU through
+``oracle/ref_shim.py`` with seeded synthetic weights/inputs (oracle.wan_oracle.synth_*),
+so the files under tests/golden/ are outputs *of the reference*, not of our restatement.
+tests/test_oracle_vs_golden.py then pins oracle/wan_oracle.py to them; the -m gpu tests
+compare the HIP path with the oracle and, for the stored cases, with these files.
+
+Inputs are not stored -- they are re-derived from the seeds recorded in each file.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim, wan_oracle as O  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def f32(t):
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+def build_ref_model(ns, cfg: O.WanConfig, W, dtype):
+    """Construct the reference WanModel and load the synthetic checkpoint with the
+    reference's dtype locks (model.py:1330-1371): patch_embedding + head fp32."""
+    m = ns.M.WanModel(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads,
+                      num_layers=cfg.num_layers, in_dim=cfg.in_dim, out_dim=cfg.out_dim, text_dim=cfg.text_dim,
+                      freq_dim=cfg.freq_dim, eps=cfg.eps)
+    sd = {k: v.clone() for k, v in W.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all("modulation" not in k for k in missing), missing
+    m.apply_post_init_changes()          # modulation Parameter -> sub-module .weight (model.py:1291-1328)
+    m.eval()
+    if dtype != torch.float32:
+        for name, p in m.named_parameters():
+            if name.startswith(O.FP32_LOCKED):
+                continue
+            p.data = p.data.to(dtype)
+    return m
+
+
+def ref_forward(ns, m, x_list, t, ctx_list, y=None):
+    grid = x_list[0].shape[2:]
+    freqs = ns.P.get_rotary_pos_embed(grid)
+    with torch.no_grad():
+        return m([x.clone() for x in x_list], t=t, context=[c.clone() for c in ctx_list], y=y, freqs=freqs,
+                 pipeline=types.SimpleNamespace(_interrupt=False))
+
+
+def gen_ops(ns):
+    """Per-op goldens: RoPE tables, RMSNorm, RoPE apply, LayerNorm(+affine), sdpa."""
+    out = {}
+    cos, sin = ns.P.get_rotary_pos_embed((3, 8, 12))          # latent f,h,w -> grid (3,4,6)
+    out["rope_cos_3x4x6"], out["rope_sin_3x4x6"] = f32(cos), f32(sin)
+    g = torch.Generator().manual_seed(7)
+    L, H, D = 72, 2, 128
+    x = torch.randn(1, L, H * D, generator=g).to(torch.bfloat16)
+    w = (1 + 0.02 * torch.randn(H * D, generator=g)).to(torch.bfloat16)
+    n = ns.M.WanRMSNorm(H * D, eps=1e-6)
+    n.weight.data = w.clone()
+    q = n(x.clone())
+    out["rms_bf16"] = f32(q)
+    k = n(torch.flip(x, dims=[1]).clone())
+    qq, kk = ns.P.apply_rotary_emb([q.view(1, L, H, D).clone(), k.view(1, L, H, D).clone()], (cos, sin))
+    out["rope_q_bf16"], out["rope_k_bf16"] = f32(qq), f32(kk)
+    ln = ns.M.WanLayerNorm(H * D, 1e-6)
+    out["ln_bf16"] = f32(ln(x))
+    ln3 = ns.M.WanLayerNorm(H * D, 1e-6, elementwise_affine=True)
+    ln3.weight.data = w.clone(); ln3.bias.data = (0.01 * torch.randn(H * D, generator=g)).to(torch.bfloat16)
+    out["ln3_bias"] = f32(ln3.bias.data)
+    out["ln3_bf16"] = f32(ln3(x))
+    v = torch.randn(1, L, H, D, generator=g).to(torch.bfloat16)
+    out["sdpa_bf16"] = f32(ns.A.pay_attention([qq.clone(), kk.clone(), v.clone()]))
+    out["seed"] = np.array([7])
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **out)
+    print("ops.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_forward(ns, name, f, h, w, tval):
+    cfg = O.make_config(name)
+    out = {"shape": np.array([f, h, w]), "t": np.array([tval])}
+    lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
+    t = torch.tensor([tval], dtype=torch.int64)
+    # NOTE: only the reference's real bf16 plan is a valid golden.  Run "fp32 everywhere" the
+    # reference's WanRMSNorm aliases its input (`y = x.float()` is x itself for fp32, then
+    # `y.pow_(2)` squares x in place, model.py:165-166), a path the real pipeline never takes
+    # (q/k are always bf16: attention_dtype = self_attn.q.weight.dtype, model.py:614).
+    for tag, dtype in (("bf16", torch.bfloat16),):
+        W = O.synth_weights(cfg, dtype=dtype)
+        m = build_ref_model(ns, cfg, W, dtype)
+        cdt = dtype
+        r = ref_forward(ns, m, [lat, lat], t, [ctx.to(cdt), ctx_null.to(cdt)], y=y)
+        out[f"cond_{tag}"], out[f"uncond_{tag}"] = f32(r[0]), f32(r[1])
+        # one block in isolation (block 0) on a seeded hidden state
+        g = torch.Generator().manual_seed(11)
+        L = f * (h // 2) * (w // 2)
+        hid = torch.randn(1, L, cfg.dim, generator=g).to(dtype)
+        e0 = (0.5 * torch.randn(1, 6, cfg.dim, generator=g)).to(dtype)
+        cemb = (0.5 * torch.randn(1, 512, cfg.dim, generator=g)).to(dtype)
+        freqs = ns.P.get_rotary_pos_embed((f, h, w))
+        with torch.no_grad():
+            bo = m.blocks[0](hid.clone(), e=e0, grid_sizes=(f, h // 2, w // 2), freqs=freqs, context=cemb)
+        out[f"block0_{tag}"] = f32(bo)
+    np.savez_compressed(os.path.join(OUT, f"forward_{name}.npz"), **out)
+    print(f"forward_{name}.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_sched(ns):
+    out = {}
+    s = ns.U.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    for steps, shift in ((10, 5.0), (30, 12.0), (4, 3.0)):
+        s.set_timesteps(steps, device="cpu", shift=shift)
+        out[f"unipc_ts_{steps}_{shift}"] = s.timesteps.numpy().copy()
+        out[f"unipc_sig_{steps}_{shift}"] = s.sigmas.numpy().copy()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(1, 16, 2, 4, 4, generator=g)
+        trace = []
+        for i, t in enumerate(s.timesteps):
+            v = torch.randn(x.shape, generator=g) * 0.7 + 0.1 * x      # synthetic "model output"
+            x = s.step(v, t, x, return_dict=False)[0]
+            trace.append(f32(x))
+        out[f"unipc_trace_{steps}_{shift}"] = np.stack(trace)
+    e = ns.E.EulerScheduler(num_train_timesteps=1000, use_timestep_transform=True)
+    for steps, shift in ((10, 5.0), (4, 3.0)):
+        ts = e.set_timesteps(steps, device="cpu", shift=shift)
+        out[f"euler_ts_{steps}_{shift}"] = ts.numpy().copy()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(1, 16, 2, 4, 4, generator=g)
+        trace = []
+        for t in ts:
+            v = torch.randn(x.shape, generator=g) * 0.7 + 0.1 * x
+            x = e.step(v, t, x, return_dict=False)[0]
+            trace.append(f32(x))
+        out[f"euler_trace_{steps}_{shift}"] = np.stack(trace)
+    np.savez_compressed(os.path.join(OUT, "sched.npz"), **out)
+    print("sched.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_loop(ns):
+    """3-step t2v sampler loop, two experts, CFG, UniPC -- the loop body of
+    WanAny2V.generate (any2video.py:1470,1490-1501,1626-1634,1702-1722,1733) driven on the
+    reference's own WanModel + scheduler objects."""
+    cfg = O.make_config("tiny")
+    f, h, w = 2, 8, 8
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w, seed=5)
+    out = {"shape": np.array([f, h, w])}
+    for tag, dtype in (("bf16", torch.bfloat16),):
+        m_hi = build_ref_model(ns, cfg, O.synth_weights(cfg, seed=1234, dtype=dtype), dtype)
+        m_lo = build_ref_model(ns, cfg, O.synth_weights(cfg, seed=4321, dtype=dtype), dtype)
+        s = ns.U.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        s.set_timesteps(3, device="cpu", shift=5.0)
+        latents = lat.clone()
+        trans, g, switched = m_hi, 4.0, False
+        trace = []
+        for i, t in enumerate(s.timesteps):
+            if not switched and t <= 875:
+                trans, g, switched = m_lo, 3.0, True
+            cond, uncond = ref_forward(ns, trans, [latents, latents], torch.stack([t]),
+                                       [ctx.to(dtype), ctx_null.to(dtype)])
+            noise = uncond + g * (cond - uncond)
+            latents = s.step(noise, t, latents, return_dict=False)[0]
+            trace.append(f32(latents))
+        out[f"trace_{tag}"] = np.stack(trace)
+        out["timesteps"] = s.timesteps.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "loop_tiny.npz"), **out)
+    print("loop_tiny.npz", {k: v.shape for k, v in out.items()})
+
+
+def main():
+    torch.manual_seed(0)
+    os.makedirs(OUT, exist_ok=True)
+    ns = ref_shim.load()
+    which = sys.argv[1:] or ["ops", "forward", "sched", "loop", "vae"]
+    if "ops" in which:
+        gen_ops(ns)
+    if "forward" in which:
+        gen_forward(ns, "tiny", 3, 8, 12, 637)
+        gen_forward(ns, "tiny_i2v", 2, 8, 8, 912)
+    if "sched" in which:
+        gen_sched(ns)
+    if "loop" in which:
+        gen_loop(ns)
+    if "vae" in which:
+        try:
+            from oracle import make_golden_vae
+            make_golden_vae.main(ns, OUT)
+        except ImportError:
+            print("vae goldens: generator not present yet")
+
+
+if __name__ == "__main__":
+    main()
