@@ -1,0 +1,211 @@
+/*
+ * wanhip.h -- C ABI of libwanhip.so: the MI355X (gfx950) Wan 2.1/2.2 denoise hot path.
+ *
+ * The reference (deepbeepmeep/Wan2GP) has no FFI/operator registry on this path; its seams are
+ * Python call sites.  Every entry point below names the reference interface it
+ * replaces (file:line into /root/reference).  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (torch); the library never frees them
+ *   - bf16 tensors are raw uint16 storage, row-major, innermost dimension contiguous
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream)
+ *   - every function returns 0 on success, non-zero on error; wan_last_error() returns the
+ *     message for the calling thread.  Nothing here falls back to a CPU path.
+ *   - kernels reproduce the reference's bf16 rounding points (RMSNorm 2 roundings, RoPE 1,
+ *     LayerNorm 1 + modulate 2, Linear output 1, GELU 1, addcmul 1) so results track the
+ *     reference's eager bf16 path; accumulation is fp32 everywhere.
+ */
+#ifndef WANHIP_H
+#define WANHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t wan_bf16; /* raw bfloat16 bits */
+
+/* ---- library ------------------------------------------------------------------------- */
+const char* wan_last_error(void);
+int wan_version(void);               /* ABI version, bumps on any signature change */
+/* number of CUs of the current device (used by callers to size workspaces / report) */
+int wan_device_cus(void);
+
+/* ---- memory-bound fused ops ------------------------------------------------------------ */
+
+/* Fused full-width RMSNorm(q) [+ RMSNorm(k)] [+ 3-axis RoPE(q,k)], in place.
+ * Replaces WanRMSNorm.forward (models/wan/modules/model.py:160-175) applied to q and k
+ * (model.py:343-344, :253,:256) followed by apply_rotary_emb (posemb_layers.py:288-340,
+ * rotate :251-259) in WanSelfAttention.forward (model.py:345-350).
+ *   q, k   : [rows, d] bf16, d = H*128; k may be NULL (cross-attn q: norm only)
+ *   wq, wk : [d] bf16 RMSNorm weights
+ *   cos,sin: [L, 128] fp32 tables (get_rotary_pos_embed, posemb_layers.py:492); NULL = no RoPE
+ *   rows   : B*L token rows; token position = (row % L) + pos0  (pos0: first global token id
+ *            of this rank's shard under sequence parallelism) */
+int wan_rmsnorm_rope(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const wan_bf16* wk,
+                     const float* cos, const float* sin, int64_t rows, int64_t L, int64_t pos0,
+                     int d, float eps, void* stream);
+
+/* LayerNorm (no affine) + AdaLN modulate: out = bf16(bf16(LN(x) * bf16(1+scale)) + shift),
+ * scale = bf16(mod[scale_idx] + e[b][scale_idx]), shift likewise.
+ * Replaces norm1/norm2 + the two in-place ops of WanAttentionBlock.forward
+ * (model.py:632-638, :686-691).  x,out [B*L, d] bf16; mod [n_mod, d] bf16 (modulation.weight);
+ * e [B, n_mod, d] bf16 (e0); rows_per_batch = L. */
+int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e,
+                    int n_mod, int shift_idx, int scale_idx, int64_t rows, int64_t rows_per_batch,
+                    int d, float eps, void* stream);
+
+/* LayerNorm with affine (norm3): out = bf16(LN(x)*w + b).  Replaces WanLayerNorm.forward with
+ * elementwise_affine=True (model.py:199-212, used at :664). */
+int wan_ln_affine(const wan_bf16* x, wan_bf16* out, const wan_bf16* w, const wan_bf16* b,
+                  int64_t rows, int d, float eps, void* stream);
+
+/* Gated residual x = bf16(x + y * gate), gate = bf16(mod[idx] + e[b][idx]) (idx<0: gate = 1,
+ * i.e. x += y).  Replaces x.addcmul_(y, e[2]) / e[5] (model.py:658-660,:709-711) and the
+ * cross-attention `x += ...` (:668).  Also available fused as a GEMM epilogue. */
+int wan_gated_residual(wan_bf16* x, const wan_bf16* y, const wan_bf16* mod, const wan_bf16* e,
+                       int n_mod, int gate_idx, int64_t rows, int64_t rows_per_batch, int d,
+                       void* stream);
+
+/* ---- GEMM ------------------------------------------------------------------------------ */
+enum {
+  WAN_EPI_NONE = 0,       /* C = bf16(A W^T + bias)                                  nn.Linear     */
+  WAN_EPI_GELU_TANH = 1,  /* C = bf16(gelu_tanh(bf16(A W^T + bias)))   ffn[0]+ffn[1] model.py:552  */
+  WAN_EPI_GATE_RES = 2,   /* C = bf16(R + bf16(A W^T + bias) * gate)   o-proj/ffn2 + addcmul_      */
+  WAN_EPI_TRANSPOSED = 3  /* Ct[N, ldc] = bf16(A W^T + bias)^T : emits V^T for the attention kernel */
+};
+
+/* C[M,N] = epilogue(A[M,K] @ W[N,K]^T + bias[N]) on MFMA (bf16 in, fp32 accumulate).
+ * Replaces every nn.Linear on the block path: self_attn.q/k/v/o (model.py:322,337,406),
+ * cross_attn.q/k/v/o (:251-258,:444), ffn.0/ffn.2 (:703-705), text_embedding (:1856).
+ *   lda/ldc : row strides in elements (lda of A, ldc of C / residual R)
+ *   gate    : for WAN_EPI_GATE_RES: mod,e as in wan_gated_residual (gate_idx<0: gate=1)
+ *   K % 64 == 0 required; M, N arbitrary. */
+int wan_gemm_bf16(const wan_bf16* A, int64_t lda, const wan_bf16* W, const wan_bf16* bias,
+                  wan_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                  const wan_bf16* R, const wan_bf16* mod, const wan_bf16* e, int n_mod,
+                  int gate_idx, int64_t rows_per_batch, void* stream);
+
+/* ---- attention ------------------------------------------------------------------------- */
+
+/* Exact (non-causal, unmasked) flash attention, bf16 in/out, fp32 softmax/accumulate,
+ * head_dim 128, scale 1/sqrt(128).  Replaces pay_attention(qkv_list) -> sdpa_wrapper
+ * (shared/attention.py:360-373, :208-225) as called from model.py:264,385.
+ *   q  : [B, Lq, H, 128]   (row stride H*128)
+ *   k  : [Bk, Lk, H, 128]  Bk == B or 1 (broadcast, attention.py:415)
+ *   vt : [Bk, H*128, ldv]  V transposed (kv contiguous), columns [Lk, ldv) must be finite;
+ *        ldv % 64 == 0.  Produced directly by wan_gemm_bf16(WAN_EPI_TRANSPOSED) or by
+ *        wan_transpose_v for callers that hold V as [B, Lk, H, 128].
+ *   o  : [B, Lq, H, 128] */
+int wan_attention(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B,
+                  int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, void* stream);
+
+/* Same, with K / V^T given as `nseg` equal segments of Lk rows (one per sequence-parallel rank,
+ * as an all-gather leaves them: [seg][Bk][Lk][H*128] and [seg][Bk][H*128][ldv]); every
+ * segment's tail tile is masked.  Strides in elements. */
+int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B,
+                      int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg,
+                      int64_t k_seg_stride, int64_t vt_seg_stride, void* stream);
+
+/* vt[b, c, l] = v[b, l, c] for c < C, l < L; zero-fills l in [L, ldv). */
+int wan_transpose_v(const wan_bf16* v, wan_bf16* vt, int B, int64_t L, int64_t ldv, int C,
+                    void* stream);
+
+/* ---- fp32 edge ops of the DiT ------------------------------------------------------------ */
+
+/* patch_embedding: Conv3d k=s=(1,2,2) fp32 -> bf16 tokens [B, L, d] (model.py:1131,1631,1731).
+ *   x : [B, Cin, F, H, W] fp32 (y : optional [Cy, F, H, W] fp32 concatenated on the channel
+ *   axis for i2v2_2, model.py:1597-1600), w : [d, Cin+Cy, 1, 2, 2] fp32, bias [d] fp32 */
+int wan_patch_embed(const float* x, const float* y, const float* w, const float* bias,
+                    wan_bf16* out, int B, int Cin, int Cy, int F, int H, int W, int d,
+                    void* stream);
+
+/* Head: LN + 2-way modulate (fp32 modulation + bf16 e) + Linear(d -> 64) fp32 + unpatchify to
+ * [B, 16, F, H, W] fp32 (model.py:847-865, :2100-2126, :2096).
+ *   x [B, L, d] bf16; hmod [2, d] fp32; e [B, d] bf16; w [64, d] fp32; bias [64] fp32;
+ *   tmp [B*L, d] bf16 scratch. */
+int wan_head(const wan_bf16* x, const float* hmod, const wan_bf16* e, const float* w,
+             const float* bias, wan_bf16* tmp, float* out, int B, int F, int Hg, int Wg, int d,
+             float eps, void* stream);
+
+/* token-major head output [B, L, 64] fp32 -> [B, 16, F, 2*Hg, 2*Wg]  ('fhwpqrc->cfphqwr',
+ * model.py:2119-2121); used after the sequence-parallel gather of per-rank head outputs. */
+int wan_unpatchify(const float* in, float* out, int B, int F, int Hg, int Wg, void* stream);
+
+/* sinusoidal_embedding_1d(256, t) -> bf16 [n, dim] (model.py:32-42, :1816) */
+int wan_sinusoid(const float* t, wan_bf16* out, int n, int dim, void* stream);
+/* y = act(x) elementwise on bf16 (act: 1 = SiLU, used between the M=1 time MLP GEMVs) */
+int wan_act_bf16(const wan_bf16* x, wan_bf16* y, int64_t n, int act, void* stream);
+/* small-M Linear (GEMV): C[M,N] = bf16(A[M,K] W[N,K]^T + bias), M <= 16 (time MLP) */
+int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C, int M,
+                  int N, int K, void* stream);
+
+/* ---- sampler (fp32 latents) -------------------------------------------------------------- */
+
+/* out = sum_i coef[i] * in[i]  (n_in <= 6), fp32.  The flow-matching scheduler updates
+ * (fm_solvers_unipc.py:313-315 x0 = x - sigma*v, :350-480 UniP, :482-626 UniC;
+ * euler_scheduler.py:79) and CFG (any2video.py:1722) are all such combinations with host
+ * scalars; coefficients are computed on the host exactly as the reference does. */
+int wan_lincomb(float* out, int n_in, const float* const* in, const float* coef, int64_t n,
+                void* stream);
+
+/* noise_pred = uncond + guide_scale * (cond - uncond), evaluated in that order
+ * (classifier-free guidance combine, any2video.py:1722). */
+int wan_cfg_combine(float* out, const float* cond, const float* uncond, float guide_scale, int64_t n,
+                    void* stream);
+
+/* ---- whole-DiT context (weights resident in HBM) ----------------------------------------- */
+typedef struct wan_ctx wan_ctx;
+
+typedef struct {
+  int dim, ffn_dim, num_heads, num_layers, in_dim, out_dim, text_dim, freq_dim, text_len;
+  float eps;
+} wan_dit_config;
+
+/* Creates a DiT context.  Replaces the WanModel module object built in WanAny2V.__init__
+ * (any2video.py:187-224) minus mmgp's offload machinery: all weights stay resident. */
+int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out);
+void wan_dit_destroy(wan_ctx* ctx);
+/* Registers a (device) weight by checkpoint key (models/wan/convert_wan.py:19-76), e.g.
+ * "blocks.3.self_attn.q.weight".  dtype: 0 = bf16, 1 = fp32.  The pointer is borrowed. */
+int wan_dit_set_weight(wan_ctx* ctx, const char* name, const void* ptr, int dtype, int64_t numel);
+/* Bytes of scratch wan_dit_forward needs for S streams of B=1 and a (F,H,W) latent. */
+int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int H, int W, int seq_shards);
+/* interrupt/pause poll between blocks: return non-zero to abort (model.py:1995-1998) */
+typedef int (*wan_poll_fn)(void* user, int block_idx);
+
+/* Sequence-parallel hooks: the library calls back into the host runtime (torch.distributed /
+ * RCCL) to all-gather K and V^T shards; NULL = single GPU.  gather(user, which, send, recv,
+ * bytes_per_rank, stream): which 0 = K, 1 = V^T. */
+typedef int (*wan_gather_fn)(void* user, int which, const void* send, void* recv, int64_t bytes,
+                             void* stream);
+typedef struct {
+  int rank, world;          /* this rank, number of sequence shards */
+  int64_t tok0, tok_local;  /* first global token and number of local tokens */
+  wan_gather_fn gather;
+  void* user;
+} wan_sp_info;
+
+/* WanModel.forward for the t2v / i2v2_2 path (model.py:1485-2098): S streams (the joint CFG
+ * pass, any2video.py:1626-1634), each x_s [1, 16, F, H, W] fp32, t scalar, context_s
+ * [1, 512, text_dim] bf16, y optional [in_dim-16, F, H, W] fp32, cos/sin [L,128] fp32.
+ * outs[s] [1, 16, F, H, W] fp32.  Returns 1 if aborted by poll (reference returns [None]*n). */
+int wan_dit_forward(wan_ctx* ctx, int S, const float* const* x, float t, const wan_bf16* const* context,
+                    const float* y, const float* cos, const float* sin, float* const* outs, int F,
+                    int H, int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp,
+                    wan_poll_fn poll, void* poll_user, void* stream);
+
+/* ---- measurement hooks (bench.py) ----------------------------------------------------------
+ * wan_prof_enable(1): wan_dit_forward brackets each kernel class with HIP events recorded on the
+ * launch stream; wan_prof_collect sums the elapsed ms per class (0 self-attention, 1 cross-
+ * attention, 2 FFN GEMM pair, 3 fused RMSNorm+RoPE) and returns the bracket count. */
+int wan_prof_enable(int on);
+int wan_prof_collect(int cls, double* total_ms, int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WANHIP_H */

@@ -1,0 +1,302 @@
+"""-m gpu: every libwanhip op (through the C ABI) against the CPU oracle / golden fixtures.
+
+Tolerances (stated, per BASELINE north star "within a stated fp16 tolerance"):
+  * element-wise fused ops reproduce the reference's bf16 rounding points; the only freedom is
+    the fp32 reduction order, so results must equal the oracle up to 1 bf16 ulp (2^-8 relative,
+    we allow 2^-7) on at most 1% of the elements, everything else bit-equal.
+  * GEMM: fp32 accumulation in a different order -> <= 1 bf16 ulp of the exact result.
+  * attention: P is rounded to bf16 before PV (as torch's CPU flash kernel does): abs err
+    <= 1.5e-2 on O(1) outputs vs the fp32-exact softmax; mean abs err <= 2e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wan_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from wan2gp_amd import ops as _ops, lib
+    lib.load()
+    return _ops
+
+
+def cu(t):
+    return t.cuda().contiguous()
+
+
+def assert_bf16_close(got, ref, frac=0.01, ulps=2, what=""):
+    """got/ref: tensors holding bf16-representable values."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    diff = (got - ref).abs()
+    tol = ref.abs().clamp_min(1e-30) * (2.0 ** -8) * ulps + 1e-30
+    bad = diff > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements beyond {ulps} bf16 ulp, worst {diff.max().item()} at {np.unravel_index(int(diff.argmax()), diff.shape)}"
+    neq = (got != ref).float().mean().item()
+    assert neq <= frac, f"{what}: {neq * 100:.2f}% elements differ from the oracle (> {frac * 100}%)"
+
+
+# ---------------------------------------------------------------------------------------------
+def _ops_inputs():
+    g = torch.Generator().manual_seed(7)
+    L, H, D = 72, 2, 128
+    x = torch.randn(1, L, H * D, generator=g).to(BF)
+    w = (1 + 0.02 * torch.randn(H * D, generator=g)).to(BF)
+    b3 = (0.01 * torch.randn(H * D, generator=g)).to(BF)
+    v = torch.randn(1, L, H, D, generator=g).to(BF)
+    return x, w, b3, v
+
+
+def test_rmsnorm_rope_vs_reference_golden(ops):
+    gold = dict(np.load(os.path.join(G, "ops.npz")))
+    x, w, b3, v = _ops_inputs()
+    cos, sin = O.rope_tables((3, 4, 6))
+    q = cu(x.clone()); k = cu(torch.flip(x, dims=[1]).clone())
+    ops.rmsnorm_rope_(q, k, cu(w), cu(w), (cu(cos), cu(sin)))
+    assert_bf16_close(q.view(1, 72, 2, 128), torch.from_numpy(gold["rope_q_bf16"]), what="q")
+    assert_bf16_close(k.view(1, 72, 2, 128), torch.from_numpy(gold["rope_k_bf16"]), what="k")
+    # norm only (cross-attention q path)
+    q2 = cu(x.clone())
+    ops.rmsnorm_rope_(q2, None, cu(w), None, None)
+    assert_bf16_close(q2, torch.from_numpy(gold["rms_bf16"]), what="rms only")
+
+
+@pytest.mark.parametrize("d,H", [(1536, 12), (5120, 40), (256, 2)])
+def test_rmsnorm_rope_model_widths(ops, d, H):
+    g = torch.Generator().manual_seed(d)
+    B, f, hh, ww = 2, 2, 3, 5
+    L = f * hh * ww
+    cos, sin = O.rope_tables((f, hh, ww))
+    q = (torch.randn(B, L, d, generator=g) * 1.7).to(BF); k = torch.randn(B, L, d, generator=g).to(BF)
+    wq = (1 + 0.05 * torch.randn(d, generator=g)).to(BF); wk = (1 + 0.05 * torch.randn(d, generator=g)).to(BF)
+    rq = O.rope_apply(O.rms_norm(q, wq, 1e-6).view(B, L, H, 128), cos, sin)
+    rk = O.rope_apply(O.rms_norm(k, wk, 1e-6).view(B, L, H, 128), cos, sin)
+    gq, gk = cu(q.clone()), cu(k.clone())
+    ops.rmsnorm_rope_(gq, gk, cu(wq), cu(wk), (cu(cos), cu(sin)))
+    assert_bf16_close(gq.view(B, L, H, 128), rq, what="q")
+    assert_bf16_close(gk.view(B, L, H, 128), rk, what="k")
+    # sequence-parallel shard: rows [L/2, L) with pos0 = L/2 must equal the slice of the full result
+    half = L // 2
+    sq = cu(q[:1, half:].clone()); sk = cu(k[:1, half:].clone())
+    ops.rmsnorm_rope_(sq, sk, cu(wq), cu(wk), (cu(cos), cu(sin)), L=L - half, pos0=half)
+    assert torch.equal(sq.cpu(), gq[:1, half:].cpu()) and torch.equal(sk.cpu(), gk[:1, half:].cpu())
+
+
+@pytest.mark.parametrize("d", [256, 1536, 5120])
+def test_layernorm_family(ops, d):
+    g = torch.Generator().manual_seed(d + 1)
+    B, L = 2, 37
+    x = (torch.randn(B, L, d, generator=g) * 2 + 0.3).to(BF)
+    mod = (torch.randn(1, 6, d, generator=g) / d ** 0.5).to(BF)
+    e0 = (0.5 * torch.randn(B, 6, d, generator=g)).to(BF)
+    w = (1 + 0.05 * torch.randn(d, generator=g)).to(BF); b = (0.02 * torch.randn(d, generator=g)).to(BF)
+    for sh, sc in ((0, 1), (3, 4)):
+        ref = []
+        for bi in range(B):
+            e = (mod + e0[bi:bi + 1]).chunk(6, dim=1)
+            y = O.layer_norm(x[bi:bi + 1], 1e-6)
+            y = y * (1 + e[sc]); y = y + e[sh]
+            ref.append(y)
+        got = ops.ln_modulate(cu(x), cu(mod), cu(e0), sh, sc)
+        assert_bf16_close(got, torch.cat(ref), what=f"ln_modulate {sh},{sc}")
+    got = ops.ln_affine(cu(x), cu(w), cu(b))
+    assert_bf16_close(got, O.layer_norm(x, 1e-6, w, b), what="ln_affine")
+    y = torch.randn(B, L, d, generator=g).to(BF)
+    ref = torch.cat([torch.addcmul(x[bi:bi + 1], y[bi:bi + 1], (mod + e0[bi:bi + 1]).chunk(6, dim=1)[2]) for bi in range(B)])
+    xx = cu(x.clone())
+    ops.gated_residual_(xx, cu(y), cu(mod), cu(e0), 2)
+    assert_bf16_close(xx, ref, what="gated residual")
+    xx = cu(x.clone())
+    ops.gated_residual_(xx, cu(y))
+    assert_bf16_close(xx, x + y, what="plain residual")
+
+
+def test_layernorm_golden(ops):
+    gold = dict(np.load(os.path.join(G, "ops.npz")))
+    x, w, b3, v = _ops_inputs()
+    assert_bf16_close(ops.ln_affine(cu(x), cu(w), cu(b3)), torch.from_numpy(gold["ln3_bf16"]), what="ln3 golden")
+
+
+# ---------------------------------------------------------------------------------------------
+def _gemm_ref(x, w, b):
+    return (x.float() @ w.float().t() + b.float()).to(BF)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (72, 512, 256), (1, 256, 256), (517, 1536, 1536),
+                                   (130, 8960, 64), (257, 128, 8960)])
+def test_gemm_plain_and_gelu(ops, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = (0.1 * torch.randn(N, generator=g)).to(BF)
+    ref = _gemm_ref(x, w, b)
+    got = ops.linear(cu(x), cu(w), cu(b))
+    assert_bf16_close(got, ref, frac=0.05, what="gemm none")
+    got = ops.linear(cu(x), cu(w), cu(b), epilogue=1)
+    assert_bf16_close(got, torch.nn.functional.gelu(ref, approximate="tanh"), frac=0.05, ulps=3, what="gemm gelu")
+    got = ops.linear(cu(x), cu(w), None)
+    assert_bf16_close(got, _gemm_ref(x, w, torch.zeros(N)), frac=0.05, what="gemm no bias")
+
+
+@pytest.mark.parametrize("M,N,K,B", [(200, 256, 128, 2), (96, 1536, 256, 1)])
+def test_gemm_gate_residual(ops, M, N, K, B):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = (0.1 * torch.randn(N, generator=g)).to(BF)
+    r = torch.randn(M, N, generator=g).to(BF)
+    mod = (torch.randn(1, 6, N, generator=g) / N ** 0.5).to(BF); e0 = (0.5 * torch.randn(B, 6, N, generator=g)).to(BF)
+    y = _gemm_ref(x, w, b)
+    rpb = M // B
+    ref = torch.cat([torch.addcmul(r[i * rpb:(i + 1) * rpb], y[i * rpb:(i + 1) * rpb], (mod + e0[i:i + 1]).chunk(6, dim=1)[5][0])
+                     for i in range(B)])
+    rr = cu(r.clone())
+    got = ops.linear(cu(x), cu(w), cu(b), epilogue=2, residual=rr, mod=cu(mod), e=cu(e0), gate_idx=5, out=rr)
+    assert_bf16_close(got, ref, frac=0.05, what="gemm gate residual (in place)")
+    got = ops.linear(cu(x), cu(w), cu(b), epilogue=2, residual=cu(r), gate_idx=-1)
+    assert_bf16_close(got, r + y, frac=0.05, what="gemm plain residual")
+
+
+@pytest.mark.parametrize("M,N,K", [(72, 256, 256), (200, 256, 128), (4095, 1536, 256), (512, 256, 64)])
+def test_gemm_transposed_vt(ops, M, N, K):
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = (0.1 * torch.randn(N, generator=g)).to(BF)
+    vt = ops.linear(cu(x), cu(w), cu(b), epilogue=3)
+    ldv = vt.shape[1]
+    assert ldv % 64 == 0 and ldv >= M
+    assert_bf16_close(vt[:, :M], _gemm_ref(x, w, b).t(), frac=0.05, what="V^T")
+    assert (vt[:, M:] == 0).all(), "padding columns must stay zero"
+
+
+def test_gemm_rejects_bad_k(ops):
+    from wan2gp_amd.lib import WanHipError
+    x = torch.zeros(8, 96, dtype=BF).cuda(); w = torch.zeros(128, 96, dtype=BF).cuda()
+    with pytest.raises(WanHipError):
+        ops.linear(x, w, None)
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_check(ops, q, k, v, what, atol=1.5e-2):
+    ref = O.attention(q, k, v, exact=True).float()
+    vt = ops.transpose_v(cu(v))
+    got = ops.attention(cu(q), cu(k), vt).float().cpu()
+    assert torch.isfinite(got).all(), what
+    err = (got - ref).abs()
+    assert err.max().item() <= atol, f"{what}: max abs err {err.max().item()}"
+    assert err.mean().item() <= 2e-3, f"{what}: mean abs err {err.mean().item()}"
+    return got
+
+
+def test_attention_golden_sdpa(ops):
+    gold = dict(np.load(os.path.join(G, "ops.npz")))
+    x, w, b3, v = _ops_inputs()
+    cos, sin = O.rope_tables((3, 4, 6))
+    q = O.rope_apply(O.rms_norm(x, w, 1e-6).view(1, 72, 2, 128), cos, sin)
+    k = O.rope_apply(O.rms_norm(torch.flip(x, dims=[1]), w, 1e-6).view(1, 72, 2, 128), cos, sin)
+    got = _attn_check(ops, q, k, v, "golden")
+    ref = torch.from_numpy(gold["sdpa_bf16"])        # the reference's own sdpa output (bf16)
+    assert (got - ref).abs().max().item() <= 3e-2
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,Bk", [(1, 128, 64, 1, 1), (2, 200, 333, 3, 2), (2, 131, 512, 2, 1), (1, 64, 1, 2, 1),
+                                          (1, 1000, 1000, 2, 1), (1, 5, 7, 1, 1)])
+def test_attention_shapes(ops, B, Lq, Lk, H, Bk):
+    g = torch.Generator().manual_seed(Lq * 3 + Lk)
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF); k = torch.randn(Bk, Lk, H, 128, generator=g).to(BF)
+    v = torch.randn(Bk, Lk, H, 128, generator=g).to(BF)
+    _attn_check(ops, q, k, v, f"B{B} Lq{Lq} Lk{Lk} H{H} Bk{Bk}")
+
+
+def test_attention_forced_rescale(ops):
+    """cdna guide §5.4 rule 26: spike one key against the queries so the running max jumps at a
+    late tile; every accumulator must be rescaled exactly once."""
+    g = torch.Generator().manual_seed(99)
+    q = torch.randn(1, 64, 1, 128, generator=g).to(BF); k = torch.randn(1, 640, 1, 128, generator=g).to(BF)
+    v = torch.randn(1, 640, 1, 128, generator=g).to(BF)
+    k[0, 400] = (q[0, 3, 0].float() * 3.0).to(BF)      # huge score for q row 3 at kv 400 (tile 6)
+    k[0, 130] = (q[0, 17, 0].float() * 2.0).to(BF)
+    _attn_check(ops, q, k, v, "spiked")
+
+
+def test_attention_row_normalisation_and_linearity(ops):
+    """size-independent properties at a large size: V = 1 gives O = 1; O is linear in V."""
+    g = torch.Generator().manual_seed(5)
+    B, L, H = 1, 8192, 2
+    q = cu(torch.randn(B, L, H, 128, generator=g).to(BF)); k = cu(torch.randn(B, L, H, 128, generator=g).to(BF))
+    ones = torch.ones(B, L, H, 128, dtype=BF).cuda()
+    o = ops.attention(q, k, ops.transpose_v(ones)).float()
+    assert (o - 1).abs().max().item() <= 1e-2
+    v1 = cu(torch.randn(B, L, H, 128, generator=g).to(BF)); v2 = cu(torch.randn(B, L, H, 128, generator=g).to(BF))
+    o1 = ops.attention(q, k, ops.transpose_v(v1)).float(); o2 = ops.attention(q, k, ops.transpose_v(v2)).float()
+    o12 = ops.attention(q, k, ops.transpose_v((v1.float() + v2.float()).to(BF))).float()
+    assert (o12 - (o1 + o2)).abs().max().item() <= 3e-2
+
+
+def test_attention_segments_match_contiguous(ops):
+    """K/V split into 2 equal gathered segments (sequence-parallel layout) == contiguous K/V."""
+    g = torch.Generator().manual_seed(8)
+    S, Lq, Ll, H = 2, 96, 150, 2
+    q = torch.randn(S, Lq, H, 128, generator=g).to(BF)
+    k = torch.randn(2, S, Ll, H, 128, generator=g).to(BF)       # [seg][S][Ll]
+    v = torch.randn(2, S, Ll, H, 128, generator=g).to(BF)
+    kfull = torch.cat([k[0], k[1]], dim=1); vfull = torch.cat([v[0], v[1]], dim=1)
+    ref = O.attention(q, kfull, vfull, exact=True).float()
+    vt = torch.stack([ops.transpose_v(cu(v[0])), ops.transpose_v(cu(v[1]))])      # [seg][S][H*128][ldv]
+    ldv = vt.shape[-1]
+    got = ops.attention(cu(q), cu(k), vt.contiguous(), Lk=Ll, nseg=2, k_seg_stride=S * Ll * H * 128,
+                        vt_seg_stride=S * H * 128 * ldv, Bk=S).float().cpu()
+    assert (got - ref).abs().max().item() <= 1.5e-2
+
+
+def test_pay_attention_dropin_contract(ops):
+    g = torch.Generator().manual_seed(3)
+    q = cu(torch.randn(2, 70, 2, 128, generator=g).to(BF)); k = cu(torch.randn(1, 512, 2, 128, generator=g).to(BF))
+    v = cu(torch.randn(1, 512, 2, 128, generator=g).to(BF))
+    ref = O.attention(q.cpu(), k.cpu(), v.cpu(), exact=True).float()
+    lst = [q, k, v]
+    out = ops.pay_attention(lst, recycle_q=True)
+    assert lst == [] and out.dtype == BF and out.shape == q.shape          # list consumed (attention.py:403)
+    assert out.data_ptr() == q.data_ptr()                                  # recycle_q reuses q's storage
+    assert (out.float().cpu() - ref).abs().max().item() <= 1.5e-2
+    from wan2gp_amd.lib import WanHipError
+    with pytest.raises(WanHipError):
+        ops.pay_attention([q, k, v], causal=True)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v"])
+def test_patch_embed_and_head(ops, name):
+    cfg = O.make_config(name)
+    W = O.synth_weights(cfg)
+    f, h, w = 3, 8, 12
+    lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
+    xin = lat if y is None else torch.cat([lat, y.unsqueeze(0)], dim=1)
+    ref, grid = O.patch_embed(xin, W, cfg, BF)
+    got = ops.patch_embed(cu(lat), cu(W["patch_embedding.weight"]), cu(W["patch_embedding.bias"]), None if y is None else cu(y))
+    assert_bf16_close(got, ref, frac=0.02, what="patch_embed")
+    g = torch.Generator().manual_seed(2)
+    L = ref.shape[1]
+    hid = torch.randn(1, L, cfg.dim, generator=g).to(BF); e = (0.3 * torch.randn(1, cfg.dim, generator=g)).to(BF)
+    refh = O.unpatchify(O.head_forward(hid, e, W, cfg), grid, cfg).float()
+    goth = ops.head(cu(hid), cu(W["head.modulation"].reshape(2, -1)), cu(e), cu(W["head.head.weight"]), cu(W["head.head.bias"]), grid)
+    assert torch.allclose(goth.cpu(), refh, atol=2e-3, rtol=2e-3), (goth.cpu() - refh).abs().max()
+
+
+def test_lincomb_and_cfg(ops):
+    g = torch.Generator().manual_seed(1)
+    ts = [torch.randn(1, 16, 3, 10, 7, generator=g) for _ in range(4)]
+    cs = [0.3, -1.7, 2.0, 0.01]
+    ref = sum(c * t for c, t in zip(cs, ts))
+    got = ops.lincomb([cu(t) for t in ts], cs).cpu()
+    assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
+    ref = ts[1] + 4.0 * (ts[0] - ts[1])
+    assert torch.equal(ops.cfg_combine(cu(ts[0]), cu(ts[1]), 4.0).cpu(), ref)

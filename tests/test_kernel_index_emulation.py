@@ -1,0 +1,243 @@
+"""CPU emulation of the index algebra of the two MFMA kernels (no GPU needed).
+
+There is no GPU in the build container, so the staging permutations, XOR swizzles,
+fragment-read offsets, MFMA lane layouts and epilogue mappings of
+wan2gp_amd/csrc/gemm_bf16.hip and attention.hip are transliterated here lane by lane
+and executed with numpy against a plain matmul / softmax reference.  The MFMA lane
+layouts are the documented gfx950 ones (cdna guide §3):
+  16x16x32: A lane l -> row l&15, k (l>>4)*8+e ; B lane l -> col l&15, k (l>>4)*8+e ;
+            D lane l reg r -> row (l>>4)*4+r, col l&15
+  32x32x16: A lane l -> row l&31, k (l>>5)*8+e ; B lane l -> col l&31 ; D lane l reg r ->
+            row (r&3)+8*(r>>2)+4*(l>>5), col l&31
+Also checks the bank-conflict-freedom claims (MI355X_MICROARCH.md §LDS lane groups).
+"""
+import numpy as np
+import pytest
+
+B128_GROUPS = [  # ds_read_b128 lane groups (one LDS cycle each when conflict free)
+    list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+    list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+    [32 + x for x in (list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)))],
+    [32 + x for x in (list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)))],
+]
+
+
+def b128_conflict_free(byte_offsets):
+    """byte_offsets[lane] of a wave64 ds_read_b128; bank slot = (addr/16) mod 16 of a 256-B row."""
+    for g in B128_GROUPS:
+        slots = [(byte_offsets[l] // 16) % 16 for l in g]
+        if len(set(slots)) != len(slots):
+            return False
+    return True
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM (gemm_bf16.hip)
+# ----------------------------------------------------------------------------------------------
+def emulate_gemm_block(Y, X, y0, x0):
+    """One 128x128 output tile, returns dict {(yrow, xcol): value} written by the epilogue."""
+    YM, K = Y.shape
+    XN = X.shape[0]
+    BK = 64
+    out = {}
+    acc = np.zeros((256, 4, 4, 4), dtype=np.float64)  # [tid][yt][xt][r]
+    conflict_free = True
+    for k0 in range(0, K, BK):
+        ylds = np.zeros((128 * 64,), dtype=np.float64)  # element-addressed image (2 B per element)
+        xlds = np.zeros((128 * 64,), dtype=np.float64)
+        for tid in range(256):
+            for i in range(4):
+                q = i * 256 + tid
+                row, pch = q >> 3, q & 7
+                lch = pch ^ ((row >> 1) & 7)
+                yr = min(y0 + row, YM - 1)
+                slab, jj = row >> 6, row & 63
+                nt, ii = jj >> 4, jj & 15
+                xr = min(x0 + slab * 64 + (ii >> 2) * 16 + nt * 4 + (ii & 3), XN - 1)
+                # LDS-DMA: lane-linear destination q*16 bytes = q*8 elements
+                ylds[q * 8:q * 8 + 8] = Y[yr, k0 + lch * 8:k0 + lch * 8 + 8]
+                xlds[q * 8:q * 8 + 8] = X[xr, k0 + lch * 8:k0 + lch * 8 + 8]
+        for wave in range(4):
+            wy, wx = wave >> 1, wave & 1
+            for ks in range(2):
+                yf = np.zeros((64, 4, 8)); xf = np.zeros((64, 4, 8))
+                offs_y = np.zeros((4, 64), dtype=int); offs_x = np.zeros((4, 64), dtype=int)
+                for lane in range(64):
+                    frow, fch = lane & 15, lane >> 4
+                    for t in range(4):
+                        ry = wy * 64 + t * 16 + frow
+                        yo = (ry * 128 + ((fch ^ ((ry >> 1) & 7)) << 4)) ^ (ks << 6)
+                        rx = wx * 64 + t * 16 + frow
+                        xo = (rx * 128 + ((fch ^ ((rx >> 1) & 7)) << 4)) ^ (ks << 6)
+                        yf[lane, t] = ylds[yo // 2:yo // 2 + 8]
+                        xf[lane, t] = xlds[xo // 2:xo // 2 + 8]
+                        offs_y[t, lane] = yo; offs_x[t, lane] = xo
+                for t in range(4):
+                    conflict_free &= b128_conflict_free(offs_y[t]) and b128_conflict_free(offs_x[t])
+                # mfma_16x16x32(a = xf[b], b = yf[a]) : D[i][j] = sum_k A[i][k] B[k][j]
+                for a in range(4):
+                    for b in range(4):
+                        Am = np.zeros((16, 32)); Bm = np.zeros((32, 16))
+                        for lane in range(64):
+                            Am[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = xf[lane, b]
+                            Bm[(lane >> 4) * 8:(lane >> 4) * 8 + 8, lane & 15] = yf[lane, a]
+                        D = Am @ Bm
+                        for lane in range(64):
+                            for r in range(4):
+                                acc[wave * 64 + lane, a, b, r] += D[(lane >> 4) * 4 + r, lane & 15]
+    for tid in range(256):
+        lane, wave = tid & 63, tid >> 6
+        wy, wx = wave >> 1, wave & 1
+        xb = x0 + wx * 64 + (lane >> 4) * 16
+        for yt in range(4):
+            yr = y0 + wy * 64 + yt * 16 + (lane & 15)
+            if yr >= YM:
+                continue
+            for xt in range(4):
+                for r in range(4):
+                    xc = xb + xt * 4 + r
+                    if xc < XN:
+                        assert (yr, xc) not in out
+                        out[(yr, xc)] = acc[tid, yt, xt, r]
+    return out, conflict_free
+
+
+@pytest.mark.parametrize("YM,XN,K,y0,x0", [(128, 128, 128, 0, 0), (200, 144, 64, 128, 128), (70, 256, 64, 0, 128)])
+def test_gemm_index_algebra(YM, XN, K, y0, x0):
+    rng = np.random.default_rng(0)
+    Y = rng.integers(-4, 5, size=(YM, K)).astype(np.float64)
+    X = rng.integers(-4, 5, size=(XN, K)).astype(np.float64)
+    out, cf = emulate_gemm_block(Y, X, y0, x0)
+    ref = Y @ X.T
+    ny, nx = min(128, YM - y0), min(128, XN - x0)
+    assert len(out) == ny * nx                      # every in-range output written exactly once
+    for (yr, xc), v in out.items():
+        assert v == ref[yr, xc], (yr, xc)
+    assert cf, "fragment reads are not bank-conflict free"
+
+
+# ----------------------------------------------------------------------------------------------
+# attention (attention.hip)
+# ----------------------------------------------------------------------------------------------
+def emulate_attention_block(Q, K, V, qb, nseg=1):
+    """One block (128 q rows) of one head. Q [Lq,128], K [nseg*Lk,128] given as nseg segments of Lk rows,
+    V likewise. Returns O rows {q: vec128}."""
+    Lq = Q.shape[0]
+    Lk = K.shape[0] // nseg
+    ldv = ((Lk + 63) // 64) * 64
+    # V^T per segment, zero padded
+    Vt = np.zeros((nseg, 128, ldv))
+    for s in range(nseg):
+        Vt[s, :, :Lk] = V[s * Lk:(s + 1) * Lk].T
+    scale = 1.0 / np.sqrt(128.0)
+    tps = (Lk + 63) // 64
+    ntile = tps * nseg
+    res = {}
+    cf = True
+    for wave in range(4):
+        q0 = qb * 128 + wave * 32
+        qf = np.zeros((64, 8, 8))
+        for lane in range(64):
+            half, l31 = lane >> 5, lane & 31
+            qrow = min(q0 + l31, Lq - 1)
+            for ks in range(8):
+                qf[lane, ks] = Q[qrow, ks * 16 + half * 8:ks * 16 + half * 8 + 8]
+        accO = np.zeros((64, 4, 16))
+        m_run = np.full(64, -np.inf)
+        l_run = np.zeros(64)
+        for t in range(ntile):
+            seg = t // tps
+            kv0 = (t - seg * tps) * 64
+            klds = np.zeros(64 * 128); vlds = np.zeros(128 * 64)
+            for tid in range(256):
+                for i in range(4):
+                    s = i * 256 + tid
+                    r, pch = s >> 4, s & 15
+                    lch = pch ^ (r & 15)
+                    kvl = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+                    kr = min(kv0 + kvl, Lk - 1)
+                    klds[s * 8:s * 8 + 8] = K[seg * Lk + kr, lch * 8:lch * 8 + 8]
+                    r2, pch2 = s >> 3, s & 7
+                    lch2 = pch2 ^ ((r2 >> 1) & 7)
+                    vlds[s * 8:s * 8 + 8] = Vt[seg, r2, kv0 + lch2 * 8:kv0 + lch2 * 8 + 8]
+            accS = np.zeros((64, 2, 16))
+            for T in range(2):
+                for ks in range(8):
+                    Am = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+                    offs = np.zeros(64, dtype=int)
+                    for lane in range(64):
+                        half, l31 = lane >> 5, lane & 31
+                        r = T * 32 + l31
+                        off = (r * 256 + ((half ^ (r & 15)) << 4)) ^ (ks << 5)
+                        offs[lane] = off
+                        Am[l31, half * 8:half * 8 + 8] = klds[off // 2:off // 2 + 8]
+                        Bm[half * 8:half * 8 + 8, l31] = qf[lane, ks]
+                    cf &= b128_conflict_free(offs)
+                    D = Am @ Bm
+                    for lane in range(64):
+                        for r in range(16):
+                            accS[lane, T, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31]
+            tt = t % tps
+            if (tt + 1) * 64 > Lk:
+                for lane in range(64):
+                    half = lane >> 5
+                    for T in range(2):
+                        for r in range(16):
+                            kv = tt * 64 + T * 32 + (r & 7) + 8 * half + 16 * (r >> 3)
+                            if kv >= Lk:
+                                accS[lane, T, r] = -np.inf
+            mt = accS.reshape(64, 32).max(axis=1)
+            mt = np.maximum(mt, mt[np.arange(64) ^ 32])
+            m_new = np.maximum(m_run, mt)
+            alpha = np.exp((m_run - m_new) * scale)
+            p = np.exp(accS * scale - (m_new * scale)[:, None, None])
+            l_run = l_run * alpha + p.reshape(64, 32).sum(axis=1)
+            accO *= alpha[:, None, None]
+            m_run = m_new
+            for T in range(2):
+                for s in range(2):
+                    cx = (T * 4 + s * 2) << 4
+                    for dt in range(4):
+                        Am = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+                        offs = np.zeros(64, dtype=int)
+                        for lane in range(64):
+                            half, l31 = lane >> 5, lane & 31
+                            r = dt * 32 + l31
+                            off = (r * 128 + ((half ^ ((r >> 1) & 7)) << 4)) ^ cx
+                            offs[lane] = off
+                            Am[l31, half * 8:half * 8 + 8] = vlds[off // 2:off // 2 + 8]
+                            Bm[half * 8:half * 8 + 8, l31] = p[lane, T, s * 8:s * 8 + 8]
+                        cf &= b128_conflict_free(offs)
+                        D = Am @ Bm
+                        for lane in range(64):
+                            for r in range(16):
+                                accO[lane, dt, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31]
+        l_tot = l_run + l_run[np.arange(64) ^ 32]
+        # epilogue staging O[q][d]
+        ob = np.zeros((32, 128))
+        for lane in range(64):
+            half, l31 = lane >> 5, lane & 31
+            for dt in range(4):
+                for g in range(4):
+                    d = dt * 32 + g * 8 + half * 4
+                    ob[l31, d:d + 4] = accO[lane, dt, g * 4:g * 4 + 4] / l_tot[lane]
+        for r in range(32):
+            if q0 + r < Lq:
+                res[q0 + r] = ob[r]
+    return res, cf
+
+
+@pytest.mark.parametrize("Lq,Lk,nseg", [(128, 64, 1), (100, 200, 1), (64, 96, 2)])
+def test_attention_index_algebra(Lq, Lk, nseg):
+    rng = np.random.default_rng(1)
+    Q = rng.standard_normal((Lq, 128))
+    K = rng.standard_normal((Lk * nseg, 128))
+    V = rng.standard_normal((Lk * nseg, 128))
+    res, cf = emulate_attention_block(Q, K, V, 0, nseg)
+    S = (Q @ K.T) / np.sqrt(128.0)
+    P = np.exp(S - S.max(axis=1, keepdims=True))
+    ref = (P / P.sum(axis=1, keepdims=True)) @ V
+    assert sorted(res) == list(range(min(Lq, 128)))
+    for q, v in res.items():
+        np.testing.assert_allclose(v, ref[q], rtol=1e-9, atol=1e-9)
+    assert cf, "attention fragment reads are not bank-conflict free"

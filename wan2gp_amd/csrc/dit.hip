@@ -1,0 +1,402 @@
+// WanModel.forward (t2v / i2v2_2 path) as a resident-weights C++ driver over the HIP kernels.
+// Replaces models/wan/modules/model.py:1485-2098 (forward), :575-724 (block), with mmgp's weight
+// streaming deleted: every weight of both experts stays in HBM.  One call enqueues the whole
+// forward on the caller's stream; the only host interaction is the between-blocks poll
+// (model.py:1994-1998) and, under sequence parallelism, the K / V^T all-gather callback.
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+// ---- error state ---------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void wan_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* wan_last_error(void) { return g_err; }
+extern "C" int wan_version(void) { return 1; }
+extern "C" int wan_device_cus(void) {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  return n;
+}
+
+// internal (non-ABI) entry points from the other translation units
+int wan_patch_embed_range(const float* x, const float* y, const float* w, const float* bias, bf16_t* out, int B, int Cin,
+                          int Cy, int F, int H, int W, int d, int64_t tok0, int64_t ntok, void* stream);
+int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const float* w, const float* bias, bf16_t* tmp,
+                   float* out, int B, int F, int Hg, int Wg, int d, float eps, int64_t tok0, int64_t ntok,
+                   int token_major_out, int e_shared, void* stream);
+int wan_sinusoid_val(float t, bf16_t* out, int dim, void* stream);
+extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
+                                 int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
+                                 int64_t vt_seg_stride, void* stream);
+
+// ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ----
+// Off by default.  When enabled, wan_dit_forward brackets the launches of each class with a
+// hipEvent pair recorded on the caller's stream; wan_prof_collect() synchronises and sums them.
+enum { PROF_SELF_ATTN = 0, PROF_CROSS_ATTN = 1, PROF_GEMM = 2, PROF_ROWOPS = 3, PROF_NCLASS = 4 };
+struct ProfPair {
+  hipEvent_t a, b;
+  int cls;
+};
+static bool g_prof_on = false;
+static std::vector<ProfPair> g_prof;
+extern "C" int wan_prof_enable(int on) {
+  g_prof_on = on != 0;
+  for (auto& p : g_prof) {
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  g_prof.clear();
+  return 0;
+}
+extern "C" int wan_prof_collect(int cls, double* total_ms, int* count) {
+  WAN_REQUIRE(total_ms && count && cls >= 0 && cls < PROF_NCLASS, "wan_prof_collect: bad args");
+  double t = 0;
+  int n = 0;
+  for (auto& p : g_prof) {
+    if (p.cls != cls) continue;
+    WAN_CHECK_HIP(hipEventSynchronize(p.b));
+    float ms = 0;
+    WAN_CHECK_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+    t += ms;
+    ++n;
+  }
+  *total_ms = t;
+  *count = n;
+  return 0;
+}
+struct ProfScope {
+  bool on;
+  hipEvent_t b;
+  hipStream_t st;
+  ProfScope(int cls, hipStream_t s) : on(g_prof_on), st(s) {
+    if (!on) return;
+    ProfPair p;
+    p.cls = cls;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(p.a, st);
+    b = p.b;
+    g_prof.push_back(p);
+  }
+  ~ProfScope() {
+    if (on) (void)hipEventRecord(b, st);
+  }
+};
+
+struct Tensor {
+  const void* ptr;
+  int dtype;  // 0 bf16, 1 fp32
+  int64_t numel;
+};
+
+struct Lin {
+  const bf16_t* w = nullptr;
+  const bf16_t* b = nullptr;
+};
+struct Attn {
+  Lin q, k, v, o;
+  const bf16_t* nq = nullptr;
+  const bf16_t* nk = nullptr;
+};
+struct Layer {
+  const bf16_t* mod = nullptr;
+  Attn self, cross;
+  const bf16_t* n3w = nullptr;
+  const bf16_t* n3b = nullptr;
+  Lin f0, f2;
+};
+
+struct wan_ctx {
+  wan_dit_config cfg;
+  std::map<std::string, Tensor> weights;
+  bool resolved = false;
+  std::vector<Layer> layers;
+  const float* pe_w = nullptr;
+  const float* pe_b = nullptr;
+  Lin te0, te2, tm0, tm2, tp1;
+  const float* head_mod = nullptr;
+  const float* head_w = nullptr;
+  const float* head_b = nullptr;
+};
+
+extern "C" int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out) {
+  WAN_REQUIRE(cfg && out, "wan_dit_create: null argument");
+  WAN_REQUIRE(cfg->dim % cfg->num_heads == 0 && cfg->dim / cfg->num_heads == 128,
+              "wan_dit_create: head_dim must be 128 (dim=%d heads=%d)", cfg->dim, cfg->num_heads);
+  WAN_REQUIRE(cfg->dim % 64 == 0 && cfg->ffn_dim % 64 == 0 && cfg->text_dim % 64 == 0 && cfg->freq_dim % 8 == 0,
+              "wan_dit_create: dims must be multiples of 64");
+  WAN_REQUIRE(cfg->out_dim == 16 && cfg->in_dim >= 16, "wan_dit_create: out_dim must be 16 and in_dim >= 16");
+  wan_ctx* c = new wan_ctx();
+  c->cfg = *cfg;
+  *out = c;
+  return 0;
+}
+extern "C" void wan_dit_destroy(wan_ctx* ctx) { delete ctx; }
+
+extern "C" int wan_dit_set_weight(wan_ctx* ctx, const char* name, const void* ptr, int dtype, int64_t numel) {
+  WAN_REQUIRE(ctx && name && ptr, "wan_dit_set_weight: null argument");
+  WAN_REQUIRE(dtype == 0 || dtype == 1, "wan_dit_set_weight: dtype must be 0 (bf16) or 1 (fp32)");
+  WAN_REQUIRE((((uintptr_t)ptr) & 15) == 0, "wan_dit_set_weight: %s is not 16-byte aligned", name);
+  ctx->weights[name] = Tensor{ptr, dtype, numel};
+  ctx->resolved = false;
+  return 0;
+}
+
+static int get_w(wan_ctx* c, const std::string& name, int dtype, int64_t numel, const void** out) {
+  auto it = c->weights.find(name);
+  WAN_REQUIRE(it != c->weights.end(), "missing weight '%s'", name.c_str());
+  WAN_REQUIRE(it->second.dtype == dtype, "weight '%s' has dtype %d, expected %d (0=bf16,1=fp32; model.py:1330-1371)",
+              name.c_str(), it->second.dtype, dtype);
+  WAN_REQUIRE(it->second.numel == numel, "weight '%s' has %lld elements, expected %lld", name.c_str(),
+              (long long)it->second.numel, (long long)numel);
+  *out = it->second.ptr;
+  return 0;
+}
+#define GETB(field, name, n)                                        \
+  do {                                                              \
+    const void* _p;                                                 \
+    if (int _rc = get_w(c, name, 0, n, &_p)) return _rc;            \
+    field = (const bf16_t*)_p;                                      \
+  } while (0)
+#define GETF(field, name, n)                                        \
+  do {                                                              \
+    const void* _p;                                                 \
+    if (int _rc = get_w(c, name, 1, n, &_p)) return _rc;            \
+    field = (const float*)_p;                                       \
+  } while (0)
+
+static int get_lin(wan_ctx* c, Lin& l, const std::string& prefix, int64_t out_f, int64_t in_f) {
+  GETB(l.w, prefix + ".weight", out_f * in_f);
+  GETB(l.b, prefix + ".bias", out_f);
+  return 0;
+}
+
+static int resolve(wan_ctx* c) {
+  if (c->resolved) return 0;
+  const wan_dit_config& g = c->cfg;
+  const int64_t d = g.dim, f = g.ffn_dim;
+  GETF(c->pe_w, "patch_embedding.weight", d * g.in_dim * 4);
+  GETF(c->pe_b, "patch_embedding.bias", d);
+  if (int rc = get_lin(c, c->te0, "text_embedding.0", d, g.text_dim)) return rc;
+  if (int rc = get_lin(c, c->te2, "text_embedding.2", d, d)) return rc;
+  if (int rc = get_lin(c, c->tm0, "time_embedding.0", d, g.freq_dim)) return rc;
+  if (int rc = get_lin(c, c->tm2, "time_embedding.2", d, d)) return rc;
+  if (int rc = get_lin(c, c->tp1, "time_projection.1", 6 * d, d)) return rc;
+  GETF(c->head_mod, "head.modulation", 2 * d);
+  GETF(c->head_w, "head.head.weight", 64 * d);
+  GETF(c->head_b, "head.head.bias", 64);
+  c->layers.assign(g.num_layers, Layer());
+  for (int i = 0; i < g.num_layers; ++i) {
+    Layer& L = c->layers[i];
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    GETB(L.mod, p + "modulation", 6 * d);
+    for (int a = 0; a < 2; ++a) {
+      Attn& A = a == 0 ? L.self : L.cross;
+      const std::string ap = p + (a == 0 ? "self_attn." : "cross_attn.");
+      if (int rc = get_lin(c, A.q, ap + "q", d, d)) return rc;
+      if (int rc = get_lin(c, A.k, ap + "k", d, d)) return rc;
+      if (int rc = get_lin(c, A.v, ap + "v", d, d)) return rc;
+      if (int rc = get_lin(c, A.o, ap + "o", d, d)) return rc;
+      GETB(A.nq, ap + "norm_q.weight", d);
+      GETB(A.nk, ap + "norm_k.weight", d);
+    }
+    GETB(L.n3w, p + "norm3.weight", d);
+    GETB(L.n3b, p + "norm3.bias", d);
+    if (int rc = get_lin(c, L.f0, p + "ffn.0", f, d)) return rc;
+    if (int rc = get_lin(c, L.f2, p + "ffn.2", d, f)) return rc;
+  }
+  c->resolved = true;
+  return 0;
+}
+
+// ---- workspace carving -----------------------------------------------------------------------------
+struct Carve {
+  char* base;
+  int64_t off = 0;
+  explicit Carve(void* b) : base((char*)b) {}
+  template <typename T>
+  T* take(int64_t n) {
+    T* p = base ? (T*)(base + off) : nullptr;
+    off += ((n * (int64_t)sizeof(T) + 255) / 256) * 256;
+    return p;
+  }
+};
+
+struct Bufs {
+  bf16_t *x, *xm, *q, *k, *vt, *h, *ctx_h, *ctx_e, *ck, *cvt, *sinus, *e_h, *e, *e_s, *e0, *kfull, *vtfull;
+  int64_t Lp;
+};
+
+static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b) {
+  Carve c(ws);
+  const int64_t d = g.dim, rows = (int64_t)S * Ll;
+  const int64_t Lp = ((Ll + 63) / 64) * 64;
+  Bufs t;
+  t.Lp = Lp;
+  t.x = c.take<bf16_t>(rows * d);
+  t.xm = c.take<bf16_t>(rows * d);
+  t.q = c.take<bf16_t>(rows * d);
+  t.k = c.take<bf16_t>(rows * d);
+  t.vt = c.take<bf16_t>((int64_t)S * d * Lp);
+  t.h = c.take<bf16_t>(rows * g.ffn_dim);
+  t.ctx_h = c.take<bf16_t>((int64_t)S * g.text_len * d);
+  t.ctx_e = c.take<bf16_t>((int64_t)S * g.text_len * d);
+  t.ck = c.take<bf16_t>((int64_t)S * g.text_len * d);
+  t.cvt = c.take<bf16_t>((int64_t)S * d * g.text_len);
+  t.sinus = c.take<bf16_t>(g.freq_dim);
+  t.e_h = c.take<bf16_t>(d);
+  t.e = c.take<bf16_t>(d);
+  t.e_s = c.take<bf16_t>(d);
+  t.e0 = c.take<bf16_t>(6 * d);
+  if (world > 1) {
+    t.kfull = c.take<bf16_t>((int64_t)world * rows * d);
+    t.vtfull = c.take<bf16_t>((int64_t)world * S * d * Lp);
+  } else {
+    t.kfull = nullptr;
+    t.vtfull = nullptr;
+  }
+  if (b) *b = t;
+  return c.off;
+}
+
+extern "C" int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int H, int W, int seq_shards) {
+  if (!ctx || S < 1 || seq_shards < 1) return -1;
+  const int64_t L = (int64_t)F * (H / 2) * (W / 2);
+  if (L % seq_shards != 0) return -1;
+  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr);
+}
+
+#define RC(expr)             \
+  do {                       \
+    if (int _rc = (expr)) return _rc; \
+  } while (0)
+
+static int linear(const bf16_t* A, const Lin& l, bf16_t* C, int64_t M, int N, int K, int epi, void* st,
+                  const bf16_t* R = nullptr, const bf16_t* mod = nullptr, const bf16_t* e = nullptr, int gate = -1,
+                  int64_t rpb = 1, int64_t ldc = 0) {
+  return wan_gemm_bf16(A, K, l.w, l.b, C, ldc ? ldc : N, M, N, K, epi, R, mod, e, 6, gate, rpb, st);
+}
+
+extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
+                               const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
+                               int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
+                               void* poll_user, void* stream) {
+  WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
+  WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
+  WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
+  RC(resolve(c));
+  const wan_dit_config& g = c->cfg;
+  const int d = g.dim, ffn = g.ffn_dim, nh = g.num_heads, TL = g.text_len;
+  const int Hg = H / 2, Wg = W / 2;
+  const int64_t L = (int64_t)F * Hg * Wg;
+  const int world = sp ? sp->world : 1;
+  WAN_REQUIRE(world >= 1 && L % world == 0, "wan_dit_forward: L=%lld not divisible by %d sequence shards",
+              (long long)L, world);
+  const int64_t Ll = L / world;
+  const int64_t tok0 = sp ? sp->tok0 : 0;
+  WAN_REQUIRE(!sp || (sp->tok_local == Ll && sp->tok0 == (int64_t)sp->rank * Ll && (world == 1 || sp->gather)),
+              "wan_dit_forward: inconsistent sequence-parallel info");
+  WAN_REQUIRE((g.in_dim > 16) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > 16 (model.py:1597)");
+  Bufs b;
+  const int64_t need = carve_all(g, S, Ll, world, workspace, &b);
+  WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
+              (long long)workspace_bytes, (long long)need);
+  WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const int64_t rows = (int64_t)S * Ll;
+  const int64_t Lp = b.Lp;
+
+  // V^T padding columns must be finite for the PV MFMA (P = 0 there)
+  WAN_CHECK_HIP(hipMemsetAsync(b.vt, 0, (size_t)S * d * Lp * 2, st));
+
+  // ---- embeddings (model.py:1631,1731 ; :1815-1818 ; :1856) -----------------------------------------
+  for (int s = 0; s < S; ++s)
+    RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, 16, g.in_dim - 16, F, H, W, d,
+                             tok0, Ll, stream));
+  RC(wan_sinusoid_val(t, b.sinus, g.freq_dim, stream));
+  RC(wan_gemv_bf16(b.sinus, c->tm0.w, c->tm0.b, b.e_h, 1, d, g.freq_dim, stream));
+  RC(wan_act_bf16(b.e_h, b.e_h, d, 1, stream));
+  RC(wan_gemv_bf16(b.e_h, c->tm2.w, c->tm2.b, b.e, 1, d, d, stream));
+  RC(wan_act_bf16(b.e, b.e_s, d, 1, stream));
+  RC(wan_gemv_bf16(b.e_s, c->tp1.w, c->tp1.b, b.e0, 1, 6 * d, d, stream));
+  for (int s = 0; s < S; ++s) {
+    RC(linear(context[s], c->te0, b.ctx_h + (int64_t)s * TL * d, TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream));
+  }
+  RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream));
+
+  // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups
+  const int64_t rpb = rows;
+
+  for (int i = 0; i < g.num_layers; ++i) {
+    if (poll && poll(poll_user, i)) return 1;  // model.py:1995-1998
+    const Layer& Lw = c->layers[i];
+    // -- self attention (model.py:632-660) --
+    RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
+    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream));
+    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream));
+    for (int s = 0; s < S; ++s)
+      RC(wan_gemm_bf16(b.xm + (int64_t)s * Ll * d, d, Lw.self.v.w, Lw.self.v.b, b.vt + (int64_t)s * d * Lp, Lp, Ll, d, d,
+                       WAN_EPI_TRANSPOSED, nullptr, nullptr, nullptr, 0, -1, 1, stream));
+    {
+      ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
+      RC(wan_rmsnorm_rope(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, stream));
+    }
+    if (world > 1) {
+      if (sp->gather(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream)) {
+        wan_set_error("wan_dit_forward: K all-gather failed");
+        return 3;
+      }
+      if (sp->gather(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
+        wan_set_error("wan_dit_forward: V^T all-gather failed");
+        return 3;
+      }
+      ProfScope ps(PROF_SELF_ATTN, st);
+      RC(wan_attention_seg(b.q, b.kfull, b.vtfull, b.q, S, S, Ll, Ll, Lp, nh, world, rows * (int64_t)d,
+                           (int64_t)S * d * Lp, stream));
+    } else {
+      ProfScope ps(PROF_SELF_ATTN, st);
+      RC(wan_attention(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, stream));
+    }
+    RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb));
+    // -- cross attention (model.py:663-668, :245-265) --
+    RC(wan_ln_affine(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, stream));
+    RC(linear(b.xm, Lw.cross.q, b.q, rows, d, d, WAN_EPI_NONE, stream));
+    RC(wan_rmsnorm_rope(b.q, nullptr, Lw.cross.nq, nullptr, nullptr, nullptr, rows, Ll, 0, d, g.eps, stream));
+    RC(linear(b.ctx_e, Lw.cross.k, b.ck, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream));
+    RC(wan_rmsnorm_rope(b.ck, nullptr, Lw.cross.nk, nullptr, nullptr, nullptr, (int64_t)S * TL, TL, 0, d, g.eps, stream));
+    for (int s = 0; s < S; ++s)
+      RC(wan_gemm_bf16(b.ctx_e + (int64_t)s * TL * d, d, Lw.cross.v.w, Lw.cross.v.b, b.cvt + (int64_t)s * d * TL, TL, TL,
+                       d, d, WAN_EPI_TRANSPOSED, nullptr, nullptr, nullptr, 0, -1, 1, stream));
+    {
+      ProfScope ps(PROF_CROSS_ATTN, st);
+      RC(wan_attention(b.q, b.ck, b.cvt, b.q, S, S, Ll, TL, TL, nh, stream));
+    }
+    RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb));
+    // -- FFN (model.py:686-711) --
+    RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 3, 4, rows, rpb, d, g.eps, stream));
+    {
+      ProfScope ps(PROF_GEMM, st);  // the two FFN GEMMs: 4*rows*d*ffn FLOP
+      RC(linear(b.xm, Lw.f0, b.h, rows, ffn, d, WAN_EPI_GELU_TANH, stream));
+      RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb));
+    }
+  }
+
+  // ---- head + unpatchify (model.py:2068-2097) -------------------------------------------------------
+  for (int s = 0; s < S; ++s)
+    RC(wan_head_range(b.x + (int64_t)s * Ll * d, c->head_mod, b.e, c->head_w, c->head_b, b.xm, outs[s], 1, F, Hg, Wg, d,
+                      g.eps, tok0, Ll, world > 1 ? 1 : 0, 1, stream));
+  return 0;
+}

@@ -1,0 +1,188 @@
+// fp32 edge ops of the DiT: patch embedding (Conv3d k=s=(1,2,2) == a [L x Cin*4] x [Cin*4 x d]
+// GEMM, K = 64 or 144) and the output head (Linear d->64 in fp32 + unpatchify scatter).
+// Both are ~5e10 FLOP at 720p x 81f (0.001 of a forward) and run as plain LDS-tiled fp32 FMA
+// kernels; the reference keeps them in fp32 (model.py:1330-1371) so no MFMA bf16 path applies.
+#include "common.h"
+
+int wan_ln_modulate_head(const bf16_t* x, bf16_t* out, const float* hmod, const bf16_t* e, int64_t rows,
+                         int64_t rows_per_batch, int d, float eps, void* stream);
+
+#define PE_TOK 32
+// grid.x = ceil(ntok/32), block 256; token t (local) = tok0 + blockIdx.x*32 + i
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          const float* __restrict__ w, const float* __restrict__ bias,
+                                                          bf16_t* __restrict__ out, int Cin, int Cy, int F, int H, int W,
+                                                          int d, int64_t tok0, int64_t ntok, int64_t out_batch_stride,
+                                                          int64_t x_batch_stride) {
+  extern __shared__ float patch[];  // [PE_TOK][Kd]
+  const int Ct = Cin + Cy;
+  const int Kd = Ct * 4;
+  const int Hg = H / 2, Wg = W / 2;
+  const int b = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * PE_TOK;
+  const float* xb = x + (int64_t)b * x_batch_stride;
+  for (int i = threadIdx.x; i < PE_TOK * Kd; i += 256) {
+    const int tk = i / Kd, kk = i - tk * Kd;
+    const int64_t tl = t0 + tk;
+    float val = 0.f;
+    if (tl < ntok) {
+      const int64_t tg = tok0 + tl;
+      const int ww = (int)(tg % Wg);
+      const int hh = (int)((tg / Wg) % Hg);
+      const int f = (int)(tg / ((int64_t)Wg * Hg));
+      const int c = kk >> 2, qq = (kk >> 1) & 1, rr = kk & 1;
+      const int64_t sp = ((int64_t)f * H + (2 * hh + qq)) * W + (2 * ww + rr);
+      val = (c < Cin) ? xb[(int64_t)c * F * H * W + sp] : y[(int64_t)(c - Cin) * F * H * W + sp];
+    }
+    patch[i] = val;
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < d; n += 256) {
+    float acc[PE_TOK];
+    const float bn = bias[n];
+#pragma unroll
+    for (int tk = 0; tk < PE_TOK; ++tk) acc[tk] = bn;
+    const float* wr = w + (int64_t)n * Kd;
+    for (int kk = 0; kk < Kd; ++kk) {
+      const float wv = wr[kk];
+#pragma unroll
+      for (int tk = 0; tk < PE_TOK; ++tk) acc[tk] += patch[tk * Kd + kk] * wv;
+    }
+#pragma unroll
+    for (int tk = 0; tk < PE_TOK; ++tk) {
+      const int64_t tl = t0 + tk;
+      if (tl < ntok) out[(int64_t)b * out_batch_stride + tl * d + n] = f2bf(acc[tk]);
+    }
+  }
+}
+
+int wan_patch_embed_range(const float* x, const float* y, const float* w, const float* bias, bf16_t* out, int B, int Cin,
+                          int Cy, int F, int H, int W, int d, int64_t tok0, int64_t ntok, void* stream) {
+  WAN_REQUIRE(x && w && bias && out, "wan_patch_embed: null pointer");
+  WAN_REQUIRE(H % 2 == 0 && W % 2 == 0, "wan_patch_embed: H, W must be even (patch 1x2x2)");
+  WAN_REQUIRE(Cy == 0 || y != nullptr, "wan_patch_embed: y missing");
+  const int Kd = (Cin + Cy) * 4;
+  const size_t shm = (size_t)PE_TOK * Kd * sizeof(float);
+  WAN_REQUIRE(shm <= 64 * 1024, "wan_patch_embed: too many input channels");
+  if (ntok == 0) return 0;
+  dim3 grid((unsigned)((ntok + PE_TOK - 1) / PE_TOK), (unsigned)B);
+  hipLaunchKernelGGL(patch_embed_kernel, grid, dim3(256), shm, as_stream(stream), x, y, w, bias, out, Cin, Cy, F, H, W,
+                     d, tok0, ntok, ntok * (int64_t)d, (int64_t)Cin * F * H * W);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_patch_embed(const float* x, const float* y, const float* w, const float* bias, wan_bf16* out, int B,
+                               int Cin, int Cy, int F, int H, int W, int d, void* stream) {
+  return wan_patch_embed_range(x, y, w, bias, out, B, Cin, Cy, F, H, W, d, 0, (int64_t)F * (H / 2) * (W / 2), stream);
+}
+
+// ---- head GEMM: out64[tok][j] = bias[j] + sum_k xm[tok][k] * w[j][k]; 64 tokens x 64 outputs per block ----
+#define HD_KC 64
+__global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict__ xm, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int d,
+                                                        int F, int Hg, int Wg, int nout, int64_t tok0, int64_t ntok,
+                                                        int64_t rows_per_batch_local, int token_major_out) {
+  __shared__ float xs[64][HD_KC + 1];
+  __shared__ float ws[HD_KC][64 + 4];  // [k][j]
+  const int tid = threadIdx.x;
+  const int tk = tid >> 2, jq = tid & 3;
+  const int b = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * 64;
+  const bf16_t* xb = xm + (int64_t)b * rows_per_batch_local * d;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int k0 = 0; k0 < d; k0 += HD_KC) {
+    for (int i = tid; i < 64 * HD_KC; i += 256) {
+      const int r = i / HD_KC, c = i - r * HD_KC;
+      const int64_t tl = t0 + r;
+      xs[r][c] = (tl < ntok && k0 + c < d) ? bf2f(xb[tl * d + k0 + c]) : 0.f;
+      // w: r -> output j, c -> k
+      ws[c][r] = (r < nout && k0 + c < d) ? w[(int64_t)r * d + k0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int c = 0; c < HD_KC; ++c) {
+      const float xv = xs[tk][c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] += xv * ws[c][jq * 16 + j];
+    }
+    __syncthreads();
+  }
+  const int64_t tl = t0 + tk;
+  if (tl >= ntok) return;
+  if (token_major_out) {
+    // [B][ntok][64] (sequence-parallel: gathered by the host, unpatchified afterwards)
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (jq * 16 + j < nout) out[((int64_t)b * ntok + tl) * 64 + jq * 16 + j] = acc[j] + bias[jq * 16 + j];
+    return;
+  }
+  // unpatchify 'fhwpqrc->cfphqwr' (model.py:2119-2121): j = (q*2+r)*C + c, C = nout/4
+  const int C = nout / 4;
+  const int64_t tg = tok0 + tl;
+  const int ww = (int)(tg % Wg);
+  const int hh = (int)((tg / Wg) % Hg);
+  const int f = (int)(tg / ((int64_t)Wg * Hg));
+  const int H = Hg * 2, W = Wg * 2;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int jj = jq * 16 + j;
+    if (jj < nout) {
+      const int c = jj % C, qr = jj / C;
+      const int qq = qr >> 1, rr = qr & 1;
+      out[(((int64_t)b * C + c) * F + f) * H * W + (int64_t)(2 * hh + qq) * W + (2 * ww + rr)] = acc[j] + bias[jj];
+    }
+  }
+}
+
+// unpatchify from a token-major [B][L][64] fp32 buffer
+__global__ void unpatchify_kernel(const float* __restrict__ in, float* __restrict__ out, int F, int Hg, int Wg, int nout,
+                                  int64_t L) {
+  const int C = nout / 4;
+  const int64_t total = L * nout;
+  const int b = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tg = i / nout;
+    const int jj = (int)(i - tg * nout);
+    const int ww = (int)(tg % Wg);
+    const int hh = (int)((tg / Wg) % Hg);
+    const int f = (int)(tg / ((int64_t)Wg * Hg));
+    const int c = jj % C, qr = jj / C;
+    const int qq = qr >> 1, rr = qr & 1;
+    const int H = Hg * 2, W = Wg * 2;
+    out[(((int64_t)b * C + c) * F + f) * H * W + (int64_t)(2 * hh + qq) * W + (2 * ww + rr)] = in[(int64_t)b * total + i];
+  }
+}
+
+int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const float* w, const float* bias, bf16_t* tmp,
+                   float* out, int B, int F, int Hg, int Wg, int d, float eps, int64_t tok0, int64_t ntok,
+                   int token_major_out, int e_shared, void* stream) {
+  WAN_REQUIRE(x && hmod && e && w && bias && tmp && out, "wan_head: null pointer");
+  const int64_t rows = (int64_t)B * ntok;
+  // e_shared: one e [1,d] for every batch row (the streams of a joint CFG pass share t)
+  int rc = wan_ln_modulate_head(x, tmp, hmod, e, rows, e_shared ? (rows > 0 ? rows : 1) : ntok, d, eps, stream);
+  if (rc) return rc;
+  if (ntok == 0) return 0;
+  dim3 grid((unsigned)((ntok + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL(head_gemm_kernel, grid, dim3(256), 0, as_stream(stream), tmp, w, bias, out, d, F, Hg, Wg, 64, tok0,
+                     ntok, ntok, token_major_out);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_head(const wan_bf16* x, const float* hmod, const wan_bf16* e, const float* w, const float* bias,
+                        wan_bf16* tmp, float* out, int B, int F, int Hg, int Wg, int d, float eps, void* stream) {
+  return wan_head_range(x, hmod, e, w, bias, tmp, out, B, F, Hg, Wg, d, eps, 0, (int64_t)F * Hg * Wg, 0, 0, stream);
+}
+
+extern "C" int wan_unpatchify(const float* in, float* out, int B, int F, int Hg, int Wg, void* stream) {
+  WAN_REQUIRE(in && out, "wan_unpatchify: null pointer");
+  const int64_t L = (int64_t)F * Hg * Wg;
+  int blocks = (int)((L * 64 + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks, B), dim3(256), 0, as_stream(stream), in, out, F, Hg, Wg, 64, L);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,486 @@
+// Memory-bound fused row kernels of the Wan DiT block (gfx950, wave64).
+//
+// One 64-lane wave owns one token row; a row of d bf16 is held in registers as NCH chunks of
+// 8 bf16 per lane (16-byte coalesced loads: lane i reads chunk i, i+64, ...), statistics are
+// reduced with DPP/bpermute shuffles only (no LDS, no barrier), and the row is written back once.
+// HBM traffic = the algorithmic bytes (read + write of the row); cos/sin and the [d] vectors
+// are L2-resident.
+//
+// Rounding points follow the reference's eager bf16 graph (see include/wanhip.h).
+#include "common.h"
+
+#define ROWS_PER_BLOCK 4  // 4 waves of 64 lanes
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm(q,k) + RoPE  -- model.py:160-175, posemb_layers.py:251-269
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
+    bf16_t* __restrict__ q, bf16_t* __restrict__ k, const bf16_t* __restrict__ wq,
+    const bf16_t* __restrict__ wk, const float* __restrict__ cosT, const float* __restrict__ sinT,
+    int64_t rows, int64_t L, int64_t pos0, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (row >= rows) return;
+  bf16_t* x = (blockIdx.y == 0 ? q : k) + row * (int64_t)d;
+  const bf16_t* w = (blockIdx.y == 0 ? wq : wk);
+  const int nchunk = d >> 3;
+
+  float v[NCH][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      uint4 raw = *reinterpret_cast<const uint4*>(x + c * 8);
+      unpack8(raw, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+    }
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)d + eps);
+  const int64_t pos = (row % L) + pos0;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      uint4 wraw = *reinterpret_cast<const uint4*>(w + c * 8);
+      float wf[8];
+      unpack8(wraw, wf);
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[i][j] * r) * wf[j]);  // x *= rsqrt ; x *= weight
+      if (cosT != nullptr) {
+        const int hc = (c * 8) & 127;  // column inside the 128-wide head
+        const float4* cp = reinterpret_cast<const float4*>(cosT + pos * 128 + hc);
+        const float4* sp = reinterpret_cast<const float4*>(sinT + pos * 128 + hc);
+        float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+        float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          // x0' = x0*cos0 - x1*sin0 ; x1' = x1*cos1 + x0*sin1   (fp32, one rounding to bf16)
+          const float a = y[j], b = y[j + 1];
+          y[j] = __fmul_rn(a, cs[j]) - __fmul_rn(b, sn[j]);
+          y[j + 1] = __fmul_rn(b, cs[j + 1]) + __fmul_rn(a, sn[j + 1]);
+        }
+      }
+      *reinterpret_cast<uint4*>(x + c * 8) = pack8(y);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm family.  MODE 0: LN + modulate (norm1/norm2), MODE 1: LN affine (norm3),
+// MODE 2: LN + modulate with fp32 modulation table (head, model.py:856-862)
+// ------------------------------------------------------------------------------------------------
+template <int NCH, int MODE>
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const bf16_t* __restrict__ xin, bf16_t* __restrict__ out, const void* __restrict__ p0,
+    const bf16_t* __restrict__ p1, int n_mod, int shift_idx, int scale_idx, int64_t rows,
+    int64_t rows_per_batch, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+  if (row >= rows) return;
+  const bf16_t* x = xin + row * (int64_t)d;
+  bf16_t* o = out + row * (int64_t)d;
+  const int nchunk = d >> 3;
+
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      uint4 raw = *reinterpret_cast<const uint4*>(x + c * 8);
+      unpack8(raw, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = v[i][j] - mean;
+        ss += t * t;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+  const int64_t b = row / rows_per_batch;
+
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float y[8];
+      if (MODE == 1) {
+        const bf16_t* w = reinterpret_cast<const bf16_t*>(p0);
+        float wf[8], bfv[8];
+        unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wf);
+        unpack8(*reinterpret_cast<const uint4*>(p1 + c * 8), bfv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (v[i][j] - mean) * rstd * wf[j] + bfv[j];
+      } else if (MODE == 0) {
+        const bf16_t* mod = reinterpret_cast<const bf16_t*>(p0);
+        float msh[8], msc[8], esh[8], esc[8];
+        unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)shift_idx * d + c * 8), msh);
+        unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)scale_idx * d + c * 8), msc);
+        const bf16_t* eb = p1 + b * (int64_t)n_mod * d;
+        unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)shift_idx * d + c * 8), esh);
+        unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)scale_idx * d + c * 8), esc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float ln = rbf((v[i][j] - mean) * rstd);        // F.layer_norm -> bf16
+          const float sc = rbf(1.0f + rbf(msc[j] + esc[j]));    // 1 + e[scale]    (bf16 ops)
+          const float sh = rbf(msh[j] + esh[j]);                // e[shift]
+          y[j] = rbf(ln * sc) + sh;                             // x *= 1+scale ; x += shift
+        }
+      } else {
+        // head: modulation fp32 [2,d] + e bf16 [B,d] -> fp32; x bf16 updated in place twice
+        const float* hm = reinterpret_cast<const float*>(p0);
+        float ev[8];
+        unpack8(*reinterpret_cast<const uint4*>(p1 + b * (int64_t)d + c * 8), ev);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float ln = rbf((v[i][j] - mean) * rstd);
+          const float sc = 1.0f + (hm[(int64_t)scale_idx * d + c * 8 + j] + ev[j]);
+          const float sh = hm[(int64_t)shift_idx * d + c * 8 + j] + ev[j];
+          y[j] = rbf(ln * sc) + sh;
+        }
+      }
+      *reinterpret_cast<uint4*>(o + c * 8) = pack8(y);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gated residual  x = bf16(x + y*gate)   (addcmul_: fp32 internally, one rounding)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gated_residual_kernel(
+    bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ mod,
+    const bf16_t* __restrict__ e, int n_mod, int gate_idx, int64_t rows, int64_t rows_per_batch,
+    int d) {
+  const int nchunk = d >> 3;
+  const int64_t total = rows * nchunk;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / nchunk;
+    const int c = (int)(idx - row * nchunk);
+    float xv[8], yv[8], g[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + row * d + c * 8), xv);
+    unpack8(*reinterpret_cast<const uint4*>(y + row * d + c * 8), yv);
+    if (gate_idx >= 0) {
+      const int64_t b = row / rows_per_batch;
+      float m[8], ev[8];
+      unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)gate_idx * d + c * 8), m);
+      unpack8(*reinterpret_cast<const uint4*>(e + (b * n_mod + gate_idx) * (int64_t)d + c * 8), ev);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = rbf(m[j] + ev[j]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = xv[j] + yv[j] * g[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = xv[j] + yv[j];
+    }
+    *reinterpret_cast<uint4*>(x + row * d + c * 8) = pack8(xv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__global__ void sinusoid_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int n, int dim) {
+  // cat([cos(t * 10000^(-i/half)), sin(...)])   model.py:32-42
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * half) return;
+  const int r = idx / half, i = idx - r * half;
+  const float freq = powf(10000.0f, -((float)i / (float)half));
+  const float a = t[r] * freq;
+  out[(int64_t)r * dim + i] = f2bf(cosf(a));
+  out[(int64_t)r * dim + half + i] = f2bf(sinf(a));
+}
+
+__global__ void sinusoid_val_kernel(float tval, bf16_t* __restrict__ out, int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half) return;
+  const float freq = powf(10000.0f, -((float)i / (float)half));
+  const float a = tval * freq;
+  out[i] = f2bf(cosf(a));
+  out[half + i] = f2bf(sinf(a));
+}
+
+__global__ void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = bf2f(x[i]);
+    float r = v;
+    if (act == 1) r = v / (1.0f + expf(-v));  // SiLU
+    y[i] = f2bf(r);
+  }
+}
+
+// one wave per output column n (M <= 16 rows); W rows are K-contiguous -> 16-byte coalesced loads
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                   const bf16_t* __restrict__ bias, bf16_t* __restrict__ C,
+                                                   int M, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  for (int c = lane; c < (K >> 3); c += 64) {
+    float wv[8];
+    unpack8(*reinterpret_cast<const uint4*>(W + (int64_t)n * K + c * 8), wv);
+    for (int m = 0; m < M; ++m) {
+      float av[8];
+      unpack8(*reinterpret_cast<const uint4*>(A + (int64_t)m * K + c * 8), av);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[m] += av[j] * wv[j];
+    }
+  }
+  for (int m = 0; m < M; ++m) {
+    const float s = wave_sum(acc[m]);
+    if (lane == 0) C[(int64_t)m * N + n] = f2bf(s + (bias ? bf2f(bias[n]) : 0.f));
+  }
+}
+
+// out = sum_i coef[i]*in[i], fp32, float4-vectorised grid-stride
+struct LinCombArgs {
+  const float* in[6];
+  float coef[6];
+  int n_in;
+};
+__global__ __launch_bounds__(256) void lincomb_kernel(float* __restrict__ out, LinCombArgs a, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < a.n_in; ++j) {
+      const float4 v = reinterpret_cast<const float4*>(a.in[j])[i];
+      const float c = a.coef[j];
+      if (j == 0) {
+        acc.x = c * v.x; acc.y = c * v.y; acc.z = c * v.z; acc.w = c * v.w;
+      } else {
+        acc.x += c * v.x; acc.y += c * v.y; acc.z += c * v.z; acc.w += c * v.w;
+      }
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+  // tail
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (n4 << 2) + threadIdx.x;
+    float acc = 0.f;
+    for (int j = 0; j < a.n_in; ++j) acc = (j == 0) ? a.coef[j] * a.in[j][i] : acc + a.coef[j] * a.in[j][i];
+    out[i] = acc;
+  }
+}
+
+// noise_pred = uncond + g * (cond - uncond), same operation order as any2video.py:1722
+__global__ __launch_bounds__(256) void cfg_combine_kernel(float* __restrict__ out, const float* __restrict__ cond,
+                                                          const float* __restrict__ uncond, float g, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float u = uncond[i];
+    out[i] = u + __fmul_rn(g, cond[i] - u);
+  }
+}
+
+// vt[b, c, l] = v[b, l, c]; 64x64 tiles through LDS; zero-fill l in [L, ldv)
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, bf16_t* __restrict__ vt,
+                                                          int64_t L, int64_t ldv, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int b = blockIdx.z;
+  const int64_t l0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const bf16_t* src = v + (int64_t)b * L * C;
+  bf16_t* dst = vt + (int64_t)b * C * ldv;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, cc = i & 63;  // r: l offset, cc: c offset
+    const int64_t l = l0 + r;
+    const int c = c0 + cc;
+    tile[r][cc] = (l < L && c < C) ? src[l * C + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int cc = i >> 6, r = i & 63;
+    const int64_t l = l0 + r;
+    const int c = c0 + cc;
+    if (c < C && l < ldv) dst[(int64_t)c * ldv + l] = tile[r][cc];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static int pick_nch(int d) {
+  const int need = ((d >> 3) + 63) / 64;
+  const int opts[] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
+  for (int o : opts)
+    if (o >= need) return o;
+  return -1;
+}
+
+#define DISPATCH_NCH(nch, ...)                          \
+  switch (nch) {                                        \
+    case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;   \
+    case 2: { constexpr int NCH = 2; __VA_ARGS__; } break;   \
+    case 3: { constexpr int NCH = 3; __VA_ARGS__; } break;   \
+    case 4: { constexpr int NCH = 4; __VA_ARGS__; } break;   \
+    case 6: { constexpr int NCH = 6; __VA_ARGS__; } break;   \
+    case 8: { constexpr int NCH = 8; __VA_ARGS__; } break;   \
+    case 10: { constexpr int NCH = 10; __VA_ARGS__; } break; \
+    case 12: { constexpr int NCH = 12; __VA_ARGS__; } break; \
+    default: { constexpr int NCH = 16; __VA_ARGS__; } break; \
+  }
+
+extern "C" int wan_rmsnorm_rope(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const wan_bf16* wk,
+                                const float* cos, const float* sin, int64_t rows, int64_t L, int64_t pos0,
+                                int d, float eps, void* stream) {
+  WAN_REQUIRE(q && wq, "wan_rmsnorm_rope: q/wq null");
+  WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_rmsnorm_rope: d=%d must be a multiple of 8 and <= 8192", d);
+  WAN_REQUIRE((cos == nullptr) == (sin == nullptr), "wan_rmsnorm_rope: cos/sin must both be set or both null");
+  WAN_REQUIRE(cos == nullptr || d % 128 == 0, "wan_rmsnorm_rope: RoPE needs d %% 128 == 0 (head_dim 128)");
+  WAN_REQUIRE(k == nullptr || wk != nullptr, "wan_rmsnorm_rope: wk null");
+  if (rows == 0) return 0;
+  const int nch = pick_nch(d);
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), k ? 2 : 1);
+  DISPATCH_NCH(nch, hipLaunchKernelGGL(rmsnorm_rope_kernel<NCH>, grid, dim3(256), 0, as_stream(stream), q, k, wq,
+                                       wk, cos, sin, rows, L, pos0, d, eps));
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod,
+                               int shift_idx, int scale_idx, int64_t rows, int64_t rows_per_batch, int d, float eps,
+                               void* stream) {
+  WAN_REQUIRE(x && out && mod && e, "wan_ln_modulate: null pointer");
+  WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_ln_modulate: d=%d must be a multiple of 8 and <= 8192", d);
+  WAN_REQUIRE(shift_idx >= 0 && shift_idx < n_mod && scale_idx >= 0 && scale_idx < n_mod, "wan_ln_modulate: bad idx");
+  if (rows == 0) return 0;
+  const int nch = pick_nch(d);
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 0>), grid, dim3(256), 0, as_stream(stream), x, out,
+                                       (const void*)mod, e, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps));
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_ln_affine(const wan_bf16* x, wan_bf16* out, const wan_bf16* w, const wan_bf16* b, int64_t rows,
+                             int d, float eps, void* stream) {
+  WAN_REQUIRE(x && out && w && b, "wan_ln_affine: null pointer");
+  WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_ln_affine: d=%d must be a multiple of 8 and <= 8192", d);
+  if (rows == 0) return 0;
+  const int nch = pick_nch(d);
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 1>), grid, dim3(256), 0, as_stream(stream), x, out,
+                                       (const void*)w, b, 0, 0, 0, rows, rows, d, eps));
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// head LN+modulate (fp32 modulation): exposed to head.hip
+int wan_ln_modulate_head(const bf16_t* x, bf16_t* out, const float* hmod, const bf16_t* e, int64_t rows,
+                         int64_t rows_per_batch, int d, float eps, void* stream) {
+  if (rows == 0) return 0;
+  const int nch = pick_nch(d);
+  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 2>), grid, dim3(256), 0, as_stream(stream), x, out,
+                                       (const void*)hmod, e, 2, 0, 1, rows, rows_per_batch, d, eps));
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_gated_residual(wan_bf16* x, const wan_bf16* y, const wan_bf16* mod, const wan_bf16* e, int n_mod,
+                                  int gate_idx, int64_t rows, int64_t rows_per_batch, int d, void* stream) {
+  WAN_REQUIRE(x && y, "wan_gated_residual: null pointer");
+  WAN_REQUIRE(d % 8 == 0, "wan_gated_residual: d %% 8 != 0");
+  WAN_REQUIRE(gate_idx < 0 || (mod && e && gate_idx < n_mod), "wan_gated_residual: gate needs mod/e");
+  if (rows == 0) return 0;
+  const int64_t total = rows * (d >> 3);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gated_residual_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, mod, e, n_mod,
+                     gate_idx, rows, rows_per_batch, d);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_sinusoid(const float* t, wan_bf16* out, int n, int dim, void* stream) {
+  WAN_REQUIRE(t && out && dim % 2 == 0, "wan_sinusoid: bad args");
+  const int total = n * dim / 2;
+  hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), t, out, n, dim);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+int wan_sinusoid_val(float t, bf16_t* out, int dim, void* stream) {
+  hipLaunchKernelGGL(sinusoid_val_kernel, dim3((dim / 2 + 255) / 256), dim3(256), 0, as_stream(stream), t, out, dim);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_act_bf16(const wan_bf16* x, wan_bf16* y, int64_t n, int act, void* stream) {
+  WAN_REQUIRE(x && y, "wan_act_bf16: null pointer");
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(act_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, n, act);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C, int M, int N,
+                             int K, void* stream) {
+  WAN_REQUIRE(A && W && C, "wan_gemv_bf16: null pointer");
+  WAN_REQUIRE(M >= 1 && M <= 16 && K % 8 == 0, "wan_gemv_bf16: need 1<=M<=16 and K %% 8 == 0 (M=%d K=%d)", M, K);
+  hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, as_stream(stream), A, W, bias, C, M, N, K);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_lincomb(float* out, int n_in, const float* const* in, const float* coef, int64_t n, void* stream) {
+  WAN_REQUIRE(out && in && coef && n_in >= 1 && n_in <= 6, "wan_lincomb: bad args (n_in=%d)", n_in);
+  WAN_REQUIRE((((uintptr_t)out) & 15) == 0, "wan_lincomb: out must be 16-byte aligned");
+  LinCombArgs a;
+  a.n_in = n_in;
+  for (int i = 0; i < n_in; ++i) {
+    WAN_REQUIRE(in[i] && (((uintptr_t)in[i]) & 15) == 0, "wan_lincomb: in[%d] null or not 16-byte aligned", i);
+    a.in[i] = in[i];
+    a.coef[i] = coef[i];
+  }
+  if (n == 0) return 0;
+  int blocks = (int)(((n >> 2) + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(lincomb_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), out, a, n);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_cfg_combine(float* out, const float* cond, const float* uncond, float guide_scale, int64_t n,
+                               void* stream) {
+  WAN_REQUIRE(out && cond && uncond, "wan_cfg_combine: null pointer");
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), out, cond, uncond, guide_scale, n);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_transpose_v(const wan_bf16* v, wan_bf16* vt, int B, int64_t L, int64_t ldv, int C, void* stream) {
+  WAN_REQUIRE(v && vt && ldv >= L, "wan_transpose_v: bad args");
+  dim3 grid((unsigned)((ldv + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+  hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, as_stream(stream), v, vt, L, ldv, C);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}

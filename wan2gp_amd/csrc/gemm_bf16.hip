@@ -1,0 +1,256 @@
+// bf16 NT GEMM on MFMA for gfx950:  Out[y][x] = epilogue( sum_k Y[y][k] * X[x][k] + bias )
+//
+// Both operands are K-contiguous ("NT"), so every MFMA fragment is one 16-byte LDS read.
+//   normal     : Y = activations A [M,K], X = weights W [N,K]      -> C[M,N]
+//   transposed : Y = weights W [N,K],     X = activations A [M,K]  -> Ct[N,M]  (emits V^T)
+//
+// Tile 128(y) x 128(x) x 64(k), 256 threads = 4 waves in 2x2, each wave 64x64 = 4x4 MFMA
+// 16x16x32 tiles.  Global->LDS staging uses the LDS-DMA path (global_load_lds_dwordx4, 16 B per
+// lane, 1 KiB per wave-instruction) into a 2-deep ring; tile t+1 is in flight while tile t is
+// multiplied.
+//
+// LDS image: rows of 64 bf16 (128 B = 8 chunks of 16 B).  LDS-DMA writes lane-linearly, so the
+// bank-conflict swizzle is applied to the per-lane SOURCE address (cdna guide rule 21):
+//   physical chunk p of row r holds logical chunk p ^ ((r>>1)&7); readers apply the same XOR.
+// With 128-B rows two rows share one 256-B bank row, and ((r>>1)&7) makes the 16 rows of a
+// ds_read_b128 lane group land on 16 distinct 16-B slots (conflict-free, derivation in DESIGN.md).
+//
+// The X operand is the FIRST MFMA operand, so a lane's accumulator registers run along x.  X rows
+// are staged in a permuted order (LDS row nt*16+i <- x row (i>>2)*16 + nt*4 + (i&3) of the wave's
+// 64) so that the 16 accumulators a lane holds for one y row are 16 CONSECUTIVE x: the epilogue
+// reads bias/residual/gate and writes the output with 2 x 16-byte accesses per lane per row
+// (128 B contiguous per y row across the 4 lane groups) with no LDS transpose.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define STAGE_BYTES (BM * BK * 2)  // 16 KiB per operand per stage
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))  (torch GELU approximate='tanh')
+  const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
+  const float inner = kBeta * (x + kKappa * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+template <int EPI, bool BIAS_ROWS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
+    const bf16_t* __restrict__ Y, int64_t ldy, int64_t YM, const bf16_t* __restrict__ X, int64_t ldx,
+    int64_t XN, int K, bf16_t* __restrict__ Out, int64_t ldo, const bf16_t* __restrict__ bias,
+    const bf16_t* __restrict__ R, const bf16_t* __restrict__ mod, const bf16_t* __restrict__ e, int n_mod,
+    int gate_idx, int64_t rows_per_batch, int tiles_y, int tiles_x) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES];  // [stage][Y|X]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wy = wave >> 1, wx = wave & 1;
+
+  // ---- tile assignment: XCD-contiguous ids, then grouped (8 y-tiles per group) ordering -------
+  const int nwg = tiles_y * tiles_x;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  const int GROUP = 8;
+  const int per_group = GROUP * tiles_x;
+  const int gidx = wg / per_group;
+  const int first_y = gidx * GROUP;
+  const int gsz = min(tiles_y - first_y, GROUP);
+  const int in_g = wg - gidx * per_group;
+  const int ty = first_y + (in_g % gsz);
+  const int tx = in_g / gsz;
+  const int64_t y0 = (int64_t)ty * BM;
+  const int64_t x0 = (int64_t)tx * BN;
+
+  // ---- per-thread staging addresses (4 x 16 B per operand per stage) ---------------------------
+  const bf16_t* ysrc[4];
+  const bf16_t* xsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + tid;  // linear 16-B slot in the 16 KiB image
+    const int row = q >> 3, pch = q & 7;
+    const int lch = pch ^ ((row >> 1) & 7);
+    int64_t yr = y0 + row;
+    if (yr > YM - 1) yr = YM - 1;
+    ysrc[i] = Y + yr * ldy + lch * 8;
+    // X image row -> permuted x row inside the owning wave's 64-row slab
+    const int slab = row >> 6, jj = row & 63;
+    const int nt = jj >> 4, ii = jj & 15;
+    int64_t xr = x0 + slab * 64 + (ii >> 2) * 16 + nt * 4 + (ii & 3);
+    if (xr > XN - 1) xr = XN - 1;
+    xsrc[i] = X + xr * ldx + lch * 8;
+  }
+
+  auto stage = [&](int s, int k0) {
+    char* ybase = smem + s * 2 * STAGE_BYTES;
+    char* xbase = ybase + STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int woff = (i * 256 + wave * 64) * 16;  // wave-uniform LDS base; lanes land at +lane*16
+      glds16(ysrc[i] + k0, ybase + woff);
+      glds16(xsrc[i] + k0, xbase + woff);
+    }
+  };
+
+  f32x4 acc[4][4];  // [yt][xt]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bytes) inside a stage image, for ksub = 0; ksub = 1 flips chunk bit 2
+  const int frow = lane & 15, fch = lane >> 4;
+  int yoff[4], xoff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ry = wy * 64 + t * 16 + frow;
+    yoff[t] = ry * 128 + ((fch ^ ((ry >> 1) & 7)) << 4);
+    const int rx = wx * 64 + t * 16 + frow;
+    xoff[t] = rx * 128 + ((fch ^ ((rx >> 1) & 7)) << 4);
+  }
+
+  const int nk = K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+    const char* ybase = smem + (kt & 1) * 2 * STAGE_BYTES;
+    const char* xbase = ybase + STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      mfma_bf16x8 yf[4], xf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        yf[t] = *reinterpret_cast<const mfma_bf16x8*>(ybase + (yoff[t] ^ (ks << 6)));
+        xf[t] = *reinterpret_cast<const mfma_bf16x8*>(xbase + (xoff[t] ^ (ks << 6)));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[b], yf[a], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds, for y row (yt, lane&15), 16 consecutive x starting at xb ---------
+  const int64_t xb = x0 + wx * 64 + (lane >> 4) * 16;
+  float bcol[16];
+  if (!BIAS_ROWS) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bcol[j] = 0.f;
+    if (bias != nullptr && xb + 16 <= XN) {
+      unpack8(*reinterpret_cast<const uint4*>(bias + xb), bcol);
+      unpack8(*reinterpret_cast<const uint4*>(bias + xb + 8), bcol + 8);
+    }
+  }
+#pragma unroll
+  for (int yt = 0; yt < 4; ++yt) {
+    const int64_t yr = y0 + wy * 64 + yt * 16 + (lane & 15);
+    if (yr >= YM) continue;
+    float v[16];
+    const float brow = (BIAS_ROWS && bias != nullptr) ? bf2f(bias[yr]) : 0.f;
+#pragma unroll
+    for (int xt = 0; xt < 4; ++xt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float b = BIAS_ROWS ? brow : bcol[xt * 4 + r];
+        v[xt * 4 + r] = rbf(acc[yt][xt][r] + b);  // nn.Linear output is a bf16 tensor
+      }
+    bf16_t* optr = Out + yr * ldo + xb;
+    if (xb + 16 <= XN) {
+      if (EPI == WAN_EPI_GELU_TANH) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = gelu_tanh_f(v[j]);
+      } else if (EPI == WAN_EPI_GATE_RES) {
+        float rv[16];
+        const bf16_t* rptr = R + yr * ldo + xb;
+        unpack8(*reinterpret_cast<const uint4*>(rptr), rv);
+        unpack8(*reinterpret_cast<const uint4*>(rptr + 8), rv + 8);
+        if (gate_idx >= 0) {
+          const int64_t bidx = yr / rows_per_batch;
+          float mv[16], ev[16];
+          const bf16_t* mp = mod + (int64_t)gate_idx * XN + xb;
+          const bf16_t* ep = e + (bidx * n_mod + gate_idx) * XN + xb;
+          unpack8(*reinterpret_cast<const uint4*>(mp), mv);
+          unpack8(*reinterpret_cast<const uint4*>(mp + 8), mv + 8);
+          unpack8(*reinterpret_cast<const uint4*>(ep), ev);
+          unpack8(*reinterpret_cast<const uint4*>(ep + 8), ev + 8);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = rv[j] + v[j] * rbf(mv[j] + ev[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = rv[j] + v[j];
+        }
+      }
+      *reinterpret_cast<uint4*>(optr) = pack8(v);
+      *reinterpret_cast<uint4*>(optr + 8) = pack8(v + 8);
+    } else {
+      // ragged x edge (only the transposed/V^T form can hit this: x = tokens)
+      for (int j = 0; j < 16; ++j) {
+        if (xb + j < XN) {
+          float o = v[j];
+          if (!BIAS_ROWS && bias != nullptr) o = rbf(acc[yt][j >> 2][j & 3] + bf2f(bias[xb + j]));
+          if (EPI == WAN_EPI_GELU_TANH) o = gelu_tanh_f(o);
+          if (EPI == WAN_EPI_GATE_RES) {
+            float g = 1.f;
+            if (gate_idx >= 0)
+              g = rbf(bf2f(mod[(int64_t)gate_idx * XN + xb + j]) +
+                      bf2f(e[((yr / rows_per_batch) * n_mod + gate_idx) * XN + xb + j]));
+            o = bf2f(R[yr * ldo + xb + j]) + o * g;
+          }
+          optr[j] = f2bf(o);
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, bool BIAS_ROWS>
+static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K,
+                       bf16_t* Out, int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod,
+                       const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st) {
+  const int64_t ty = (YM + BM - 1) / BM, tx = (XN + BN - 1) / BN;
+  WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm_bf16: too many tiles");
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X,
+                     ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_gemm_bf16(const wan_bf16* A, int64_t lda, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C,
+                             int64_t ldc, int64_t M, int N, int K, int epilogue, const wan_bf16* R,
+                             const wan_bf16* mod, const wan_bf16* e, int n_mod, int gate_idx, int64_t rows_per_batch,
+                             void* stream) {
+  WAN_REQUIRE(A && W && C, "wan_gemm_bf16: null operand");
+  WAN_REQUIRE(K > 0 && K % BK == 0, "wan_gemm_bf16: K=%d must be a positive multiple of %d", K, BK);
+  WAN_REQUIRE(lda % 8 == 0 && ldc % 8 == 0, "wan_gemm_bf16: lda/ldc must be multiples of 8 elements (16 B)");
+  WAN_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0, "wan_gemm_bf16: pointers must be 16-B aligned");
+  if (M == 0 || N == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  switch (epilogue) {
+    case WAN_EPI_NONE:
+      WAN_REQUIRE(N % 16 == 0, "wan_gemm_bf16: N=%d must be a multiple of 16", N);
+      return launch_gemm<WAN_EPI_NONE, false>(A, lda, M, W, K, N, K, C, ldc, bias, nullptr, nullptr, nullptr, 0, -1, 1, st);
+    case WAN_EPI_GELU_TANH:
+      WAN_REQUIRE(N % 16 == 0, "wan_gemm_bf16: N=%d must be a multiple of 16", N);
+      return launch_gemm<WAN_EPI_GELU_TANH, false>(A, lda, M, W, K, N, K, C, ldc, bias, nullptr, nullptr, nullptr, 0, -1, 1, st);
+    case WAN_EPI_GATE_RES:
+      WAN_REQUIRE(N % 16 == 0, "wan_gemm_bf16: N=%d must be a multiple of 16", N);
+      WAN_REQUIRE(R != nullptr, "wan_gemm_bf16: GATE_RES needs the residual R");
+      WAN_REQUIRE(gate_idx < 0 || (mod && e && gate_idx < n_mod && rows_per_batch > 0), "wan_gemm_bf16: bad gate args");
+      return launch_gemm<WAN_EPI_GATE_RES, false>(A, lda, M, W, K, N, K, C, ldc, bias, R, mod, e, n_mod, gate_idx,
+                                                  rows_per_batch > 0 ? rows_per_batch : 1, st);
+    case WAN_EPI_TRANSPOSED:
+      // Ct[N, ldc]: roles swapped, bias runs along output rows
+      return launch_gemm<WAN_EPI_NONE, true>(W, K, N, A, lda, M, K, C, ldc, bias, nullptr, nullptr, nullptr, 0, -1, 1, st);
+    default:
+      WAN_REQUIRE(false, "wan_gemm_bf16: unknown epilogue %d", epilogue);
+  }
+  return 0;
+}

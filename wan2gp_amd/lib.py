@@ -1,0 +1,110 @@
+"""ctypes binding of libwanhip.so (the C ABI in include/wanhip.h).
+
+PyTorch is used only as the owner of device memory and streams: every call passes raw
+``data_ptr()`` values and the current HIP stream.  There is NO fallback: if the shared
+library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwanhip.so")
+
+EPI_NONE, EPI_GELU_TANH, EPI_GATE_RES, EPI_TRANSPOSED = 0, 1, 2, 3
+
+_lib = None
+
+
+class WanHipError(RuntimeError):
+    pass
+
+
+class DitConfig(ctypes.Structure):
+    _fields_ = [("dim", c_int), ("ffn_dim", c_int), ("num_heads", c_int), ("num_layers", c_int),
+                ("in_dim", c_int), ("out_dim", c_int), ("text_dim", c_int), ("freq_dim", c_int),
+                ("text_len", c_int), ("eps", c_float)]
+
+
+POLL_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int)
+GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p)
+
+
+class SpInfo(ctypes.Structure):
+    _fields_ = [("rank", c_int), ("world", c_int), ("tok0", c_int64), ("tok_local", c_int64),
+                ("gather", GATHER_FN), ("user", c_void_p)]
+
+
+# name -> (restype, argtypes); the single source of truth mirrored by tests/test_abi.py
+SIGNATURES = {
+    "wan_last_error": (c_char_p, []),
+    "wan_version": (c_int, []),
+    "wan_device_cus": (c_int, []),
+    "wan_rmsnorm_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                 c_int64, c_int, c_float, c_void_p]),
+    "wan_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
+                                c_int, c_float, c_void_p]),
+    "wan_ln_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "wan_gated_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int,
+                                   c_void_p]),
+    "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                              c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "wan_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
+                              c_int, c_void_p]),
+    "wan_attention_seg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
+                                  c_int, c_int, c_int64, c_int64, c_void_p]),
+    "wan_transpose_v": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "wan_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_int, c_void_p]),
+    "wan_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                         c_int, c_int, c_int, c_float, c_void_p]),
+    "wan_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_sinusoid": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "wan_act_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "wan_gemv_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "wan_lincomb": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_float), c_int64, c_void_p]),
+    "wan_cfg_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "wan_prof_enable": (c_int, [c_int]),
+    "wan_prof_collect": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
+    "wan_dit_create": (c_int, [POINTER(DitConfig), POINTER(c_void_p)]),
+    "wan_dit_destroy": (None, [c_void_p]),
+    "wan_dit_set_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int64]),
+    "wan_dit_workspace_bytes": (c_int64, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "wan_dit_forward": (c_int, [c_void_p, c_int, POINTER(c_void_p), c_float, POINTER(c_void_p), c_void_p, c_void_p,
+                                c_void_p, POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int64,
+                                POINTER(SpInfo), POLL_FN, c_void_p, c_void_p]),
+}
+
+
+def load():
+    """Loads libwanhip.so (no GPU needed to load); raises WanHipError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise WanHipError(
+            f"{LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C wan2gp_amd/csrc). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> a header symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().wan_last_error().decode("utf-8", "replace")
+        raise WanHipError(f"{what}: rc={rc}: {msg}")
+
+
+def ptr(t):
+    """data_ptr of a torch tensor (or None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,169 @@
+"""WanModelHIP -- drop-in for the reference `WanModel` on the t2v / i2v2_2 path.
+
+Mirrors models/wan/modules/model.py:891-2150: same constructor keywords for the plain
+DiT, same `forward(x, t, context, ..., y=, freqs=, pipeline=, callback=, x_id=, ...)`
+list-in / list-out contract (x list is *consumed*, model.py:1558-1559; outputs are fp32
+[B,16,F,H,W], :2093-2097; returns [None]*n when interrupted, :1997-1998; calls
+`callback(-1, None, False, True)` between blocks, :1995-1996).  All arithmetic runs in
+libwanhip (resident weights, no mmgp offload); variant conditioning kwargs that are not on
+the hot path raise NotImplementedError unless a `reference_module` is attached to delegate to.
+"""
+import ctypes
+from ctypes import c_void_p
+from typing import Dict, List, Optional
+
+import torch
+
+from . import lib as _L
+from .lib import DitConfig, POLL_FN, SpInfo, check, ptr, stream_ptr
+from .rope import get_rotary_pos_embed
+
+# checkpoint tensors the reference locks to fp32 (lock_layers_dtypes, model.py:1330-1371)
+FP32_PREFIXES = ("patch_embedding.", "head.")
+
+# non-None defaults of the variant keywords of WanModel.forward (model.py:1485-1543); a call that
+# leaves them at these values is the plain t2v / i2v2_2 path
+_VARIANT_DEFAULTS = {"vace_context_scale": [1.0], "causal_block_size": 1, "causal_attention": False,
+                     "ref_images_count": 0, "lynx_ip_scale": 0, "lynx_ref_scale": 0, "lynx_feature_extractor": False,
+                     "kiwi_ref_pad_first": False, "animate2_log_scale": 0.0, "animate2_kv_cache": "Disabled"}
+
+
+def _is_default(k, v):
+    if v is None:
+        return True
+    if torch.is_tensor(v):
+        return False
+    return k in _VARIANT_DEFAULTS and v == _VARIANT_DEFAULTS[k]
+
+
+class WanModelHIP:
+    def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, eps=1e-6, device="cuda",
+                 **unused):
+        if tuple(patch_size) != (1, 2, 2):
+            raise NotImplementedError("only patch_size (1,2,2) (all Wan 2.1/2.2 14B/1.3B models)")
+        if model_type not in ("t2v", "i2v2_2"):
+            raise NotImplementedError(f"model_type {model_type!r}: only t2v / i2v2_2 cross-attention (model.py:1149)")
+        self.model_type, self.dim, self.ffn_dim, self.num_heads, self.num_layers = model_type, dim, ffn_dim, num_heads, num_layers
+        self.in_dim, self.out_dim, self.text_dim, self.freq_dim, self.text_len, self.eps = in_dim, out_dim, text_dim, freq_dim, text_len, eps
+        self.patch_size = tuple(patch_size)
+        self.device = torch.device(device)
+        self.cache = None
+        self.reference_module = None      # optional: the reference nn.Module to delegate variant calls to
+        self.sp = None                    # optional sequence-parallel group (wan2gp_amd.sp.SequenceParallel)
+        self._weights: Dict[str, torch.Tensor] = {}
+        self._ws = None
+        cfg = DitConfig(dim, ffn_dim, num_heads, num_layers, in_dim, out_dim, text_dim, freq_dim, text_len, eps)
+        h = c_void_p()
+        check(_L.load().wan_dit_create(ctypes.byref(cfg), ctypes.byref(h)), "wan_dit_create")
+        self._ctx = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                _L.load().wan_dit_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """Checkpoint keys as in models/wan/convert_wan.py:19-76 (an optional
+        'model.diffusion_model.' prefix is stripped, model.py:913-941).  Tensors are moved to
+        HBM once and stay resident: bf16 everywhere except patch_embedding/head (fp32)."""
+        lib = _L.load()
+        for k, v in sd.items():
+            if k.startswith("model.diffusion_model."):
+                k = k[len("model.diffusion_model."):]
+            if k.endswith("modulation.weight"):           # post-init form (model.py:1291-1303)
+                k = k[: -len(".weight")]
+            want = torch.float32 if k.startswith(FP32_PREFIXES) else torch.bfloat16
+            t = v.detach().to(device=self.device, dtype=want).contiguous()
+            self._weights[k] = t
+            check(lib.wan_dit_set_weight(self._ctx, k.encode(), ptr(t), 1 if want == torch.float32 else 0, t.numel()),
+                  f"wan_dit_set_weight({k})")
+        return self
+
+    def apply_post_init_changes(self):  # reference API; nothing to adapt here
+        return self
+
+    def eval(self):
+        return self
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def _workspace(self, S, F, H, W, shards):
+        need = _L.load().wan_dit_workspace_bytes(self._ctx, S, F, H, W, shards)
+        if need < 0:
+            raise _L.WanHipError(f"wan_dit_workspace_bytes failed for S={S} latent={F}x{H}x{W} shards={shards}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, x, t, context, y=None, freqs=None, pipeline=None, current_step_no=0, real_step_no=0, x_id=0,
+                max_steps=0, callback=None, **variant_kwargs):
+        active = {k: v for k, v in variant_kwargs.items() if not _is_default(k, v)}
+        if active:
+            if self.reference_module is not None:
+                return self.reference_module(x, t, context, y=y, freqs=freqs, pipeline=pipeline,
+                                             current_step_no=current_step_no, real_step_no=real_step_no, x_id=x_id,
+                                             max_steps=max_steps, callback=callback, **variant_kwargs)
+            raise NotImplementedError(f"WanModelHIP.forward: variant arguments {sorted(active)} are outside the "
+                                      "MI355X hot path (t2v / i2v2_2); attach `reference_module` to delegate")
+        if self.cache is not None:
+            raise NotImplementedError("step-skipping caches (TeaCache/MagCache) change outputs and are not implemented")
+        x_list = list(x)
+        x.clear()                                           # model.py:1558-1559
+        S = len(x_list)
+        if any(xx.shape[0] != 1 for xx in x_list):
+            raise NotImplementedError("each stream must have batch 1 (the reference's joint CFG pass)")
+        _, C, F, H, W = x_list[0].shape
+        dev = self.device
+        xs = [xx.to(device=dev, dtype=torch.float32).contiguous() for xx in x_list]
+        ctxs = [c.to(device=dev, dtype=torch.bfloat16).contiguous() for c in context]
+        if any(c.shape[-2] != self.text_len or c.shape[0] != 1 for c in ctxs):
+            raise _L.WanHipError(f"context must be [1,{self.text_len},{self.text_dim}] per stream")
+        if t.numel() != 1:
+            raise NotImplementedError("per-frame / diffusion-forcing timesteps (model.py:1812) are not implemented")
+        tval = float(t.flatten()[0].item())
+        yy = None if y is None else y.to(device=dev, dtype=torch.float32).contiguous()
+        if freqs is None:
+            freqs = get_rotary_pos_embed((F, H, W))
+        cos, sin = (f.to(device=dev, dtype=torch.float32).contiguous() for f in freqs)
+
+        sp = self.sp
+        shards = 1 if sp is None else sp.world
+        ws = self._workspace(S, F, H, W, shards)
+        L = F * (H // 2) * (W // 2)
+        if sp is None:
+            outs = [torch.empty(1, self.out_dim, F, H, W, dtype=torch.float32, device=dev) for _ in range(S)]
+            sp_struct = None
+        else:
+            outs = [torch.empty(1, L // shards, 64, dtype=torch.float32, device=dev) for _ in range(S)]
+            sp.bind_workspace(ws)
+            sp_struct = ctypes.byref(sp.make_info(L))
+
+        def _poll(user, block_idx):
+            try:
+                if callback is not None:
+                    callback(-1, None, False, True)         # model.py:1995-1996
+                return 1 if (pipeline is not None and getattr(pipeline, "_interrupt", False)) else 0
+            except Exception:                                # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        poll = POLL_FN(_poll)
+        XP = (c_void_p * S)(*[a.data_ptr() for a in xs])
+        CP = (c_void_p * S)(*[a.data_ptr() for a in ctxs])
+        OP = (c_void_p * S)(*[a.data_ptr() for a in outs])
+        rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
+                                       ws.numel(), sp_struct, poll, None, stream_ptr())
+        if rc == 1:
+            return [None] * S                               # model.py:1997-1998
+        check(rc, "wan_dit_forward")
+        if sp is not None:
+            outs = [sp.gather_output(o, (F, H // 2, W // 2)) for o in outs]
+        return outs
+
+    __call__ = forward

@@ -1,0 +1,218 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per libwanhip entry point).
+
+These mirror the reference's operator call sites (names and argument meaning) so the
+parity tests read like the reference's code; they hold no arithmetic of their own.
+"""
+import ctypes
+from ctypes import c_float, c_void_p
+
+import torch
+
+from . import lib as _L
+from .lib import EPI_GATE_RES, EPI_GELU_TANH, EPI_NONE, EPI_TRANSPOSED, check, ptr, stream_ptr
+
+BF16 = torch.bfloat16
+
+
+def _req(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _L.WanHipError(f"{name} must be a CUDA(HIP) tensor -- libwanhip has no CPU path")
+    if t.dtype != dtype:
+        raise _L.WanHipError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _L.WanHipError(f"{name} must be contiguous")
+
+
+def rmsnorm_rope_(q, k, wq, wk, freqs=None, eps=1e-6, L=None, pos0=0):
+    """In-place WanRMSNorm(q)[, WanRMSNorm(k)][, apply_rotary_emb([q,k], freqs)].
+    q,k [B,L,d] or [B,L,H,128]; freqs = (cos,sin) [Ltot,128] fp32 or None.
+    (model.py:343-350; posemb_layers.py:288-340)"""
+    for t, n in ((q, "q"), (k, "k"), (wq, "wq"), (wk, "wk")):
+        _req(t, BF16, n)
+    d = wq.numel()
+    rows = q.numel() // d
+    if L is None:
+        L = q.shape[1]
+    cos = sin = None
+    if freqs is not None:
+        cos, sin = freqs
+        _req(cos, torch.float32, "cos"); _req(sin, torch.float32, "sin")
+    check(_L.load().wan_rmsnorm_rope(ptr(q), ptr(k), ptr(wq), ptr(wk), ptr(cos), ptr(sin), rows, L, pos0, d, eps,
+                                     stream_ptr()), "wan_rmsnorm_rope")
+    return q, k
+
+
+def ln_modulate(x, mod, e, shift_idx, scale_idx, eps=1e-6, out=None):
+    """LayerNorm(no affine) then `*= 1+e[scale]; += e[shift]` with e = mod + e0 (model.py:632-638)."""
+    _req(x, BF16, "x"); _req(mod, BF16, "mod"); _req(e, BF16, "e")
+    d = x.shape[-1]
+    n_mod = mod.numel() // d
+    rows = x.numel() // d
+    nb = e.numel() // (n_mod * d)
+    out = torch.empty_like(x) if out is None else out
+    check(_L.load().wan_ln_modulate(ptr(x), ptr(out), ptr(mod), ptr(e), n_mod, shift_idx, scale_idx, rows,
+                                    rows // nb, d, eps, stream_ptr()), "wan_ln_modulate")
+    return out
+
+
+def ln_affine(x, w, b, eps=1e-6, out=None):
+    """WanLayerNorm(elementwise_affine=True) (model.py:199-212, norm3)."""
+    for t, n in ((x, "x"), (w, "w"), (b, "b")):
+        _req(t, BF16, n)
+    d = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    check(_L.load().wan_ln_affine(ptr(x), ptr(out), ptr(w), ptr(b), x.numel() // d, d, eps, stream_ptr()),
+          "wan_ln_affine")
+    return out
+
+
+def gated_residual_(x, y, mod=None, e=None, gate_idx=-1):
+    """x.addcmul_(y, e[gate]) (model.py:658-660) or x += y when gate_idx < 0."""
+    _req(x, BF16, "x"); _req(y, BF16, "y"); _req(mod, BF16, "mod"); _req(e, BF16, "e")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    n_mod = mod.numel() // d if mod is not None else 0
+    nb = e.numel() // (n_mod * d) if e is not None else 1
+    check(_L.load().wan_gated_residual(ptr(x), ptr(y), ptr(mod), ptr(e), n_mod, gate_idx, rows, rows // nb, d,
+                                       stream_ptr()), "wan_gated_residual")
+    return x
+
+
+def linear(x, weight, bias=None, epilogue=EPI_NONE, residual=None, mod=None, e=None, gate_idx=-1, out=None,
+           ldc=None):
+    """nn.Linear on MFMA: bf16(x @ weight.T + bias) with an optional fused epilogue.
+    EPI_TRANSPOSED returns the [N, ldc] transposed result (V^T for attention)."""
+    _req(x, BF16, "x"); _req(weight, BF16, "weight"); _req(bias, BF16, "bias")
+    _req(residual, BF16, "residual"); _req(mod, BF16, "mod"); _req(e, BF16, "e")
+    N, K = weight.shape
+    M = x.numel() // K
+    if epilogue == EPI_TRANSPOSED:
+        ldc = ldc or ((M + 63) // 64) * 64
+        if out is None:
+            out = torch.zeros(N, ldc, dtype=BF16, device=x.device)
+    else:
+        ldc = N
+        if out is None:
+            out = torch.empty(*x.shape[:-1], N, dtype=BF16, device=x.device)
+    n_mod = mod.numel() // N if mod is not None else 0
+    nb = e.numel() // (n_mod * N) if (e is not None and n_mod) else 1
+    check(_L.load().wan_gemm_bf16(ptr(x), K, ptr(weight), ptr(bias), ptr(out), ldc, M, N, K, epilogue, ptr(residual),
+                                  ptr(mod), ptr(e), n_mod, gate_idx, max(M // nb, 1), stream_ptr()), "wan_gemm_bf16")
+    return out
+
+
+def transpose_v(v, ldv=None):
+    """[B,L,H,128] (or [B,L,C]) -> V^T [B, C, ldv] with zero padding."""
+    _req(v, BF16, "v")
+    B, L = v.shape[0], v.shape[1]
+    C = v.numel() // (B * L)
+    ldv = ldv or ((L + 63) // 64) * 64
+    vt = torch.empty(B, C, ldv, dtype=BF16, device=v.device)
+    check(_L.load().wan_transpose_v(ptr(v), ptr(vt), B, L, ldv, C, stream_ptr()), "wan_transpose_v")
+    return vt
+
+
+def attention(q, k, vt, Lk=None, out=None, nseg=1, k_seg_stride=0, vt_seg_stride=0, Bk=None):
+    """softmax(q k^T / sqrt(128)) v with v given transposed.  q [B,Lq,H,128], k [Bk,Lk,H,128], vt [Bk,H*128,ldv].
+    nseg > 1: k / vt hold `nseg` gathered segments ([seg][Bk][Lk][H*128], [seg][Bk][H*128][ldv]); pass Lk, Bk
+    and the segment strides (elements) explicitly."""
+    _req(q, BF16, "q"); _req(k, BF16, "k"); _req(vt, BF16, "vt")
+    B, Lq, H, D = q.shape
+    if D != 128:
+        raise _L.WanHipError("head_dim must be 128")
+    if Bk is None:
+        Bk = k.shape[0]
+    Lk = Lk if Lk is not None else k.shape[1]
+    ldv = vt.shape[-1]
+    out = torch.empty_like(q) if out is None else out
+    check(_L.load().wan_attention_seg(ptr(q), ptr(k), ptr(vt), ptr(out), B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride,
+                                      vt_seg_stride, stream_ptr()), "wan_attention")
+    return out
+
+
+def pay_attention(qkv_list, dropout_p=0., softmax_scale=None, causal=False, window_size=(-1, -1),
+                  deterministic=False, version=None, force_attention=None, attention_mask=None, recycle_q=False,
+                  q_lens=None, k_lens=None):
+    """Drop-in for shared/attention.py:360-373 `pay_attention` (attention mode "hip").
+    Same conventions: q,k,v [B,L,H,D] with D contiguous, the list is consumed (:403), k/v
+    batch 1 is broadcast (:415-416), the result has q's dtype (:563), recycle_q lets the
+    output reuse q's storage.  Unsupported options raise instead of silently approximating."""
+    if causal or attention_mask is not None or dropout_p != 0. or q_lens is not None or k_lens is not None \
+            or window_size != (-1, -1):
+        raise _L.WanHipError("pay_attention[hip]: only unmasked non-causal attention is implemented")
+    q, k, v = qkv_list
+    qkv_list.clear()
+    if softmax_scale is not None and abs(softmax_scale - q.shape[-1] ** -0.5) > 1e-9:
+        raise _L.WanHipError("pay_attention[hip]: only the default 1/sqrt(D) scale is implemented")
+    out_dtype = q.dtype
+    q = q.to(BF16).contiguous(); k = k.to(BF16).contiguous(); v = v.to(BF16).contiguous()
+    vt = transpose_v(v)
+    o = attention(q, k, vt, out=q if (recycle_q and out_dtype == BF16) else None)
+    return o.type(out_dtype)
+
+
+def patch_embed(x, w, bias, y=None):
+    """patch_embedding Conv3d(k=s=(1,2,2)) fp32 -> bf16 tokens [B,L,d] (model.py:1631,1731)."""
+    _req(x, torch.float32, "x"); _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias")
+    _req(y, torch.float32, "y")
+    B, Cin, F, H, W = x.shape
+    d = w.shape[0]
+    Cy = 0 if y is None else y.shape[0]
+    out = torch.empty(B, F * (H // 2) * (W // 2), d, dtype=BF16, device=x.device)
+    check(_L.load().wan_patch_embed(ptr(x), ptr(y), ptr(w), ptr(bias), ptr(out), B, Cin, Cy, F, H, W, d, stream_ptr()),
+          "wan_patch_embed")
+    return out
+
+
+def head(x, hmod, e, w, bias, grid, eps=1e-6):
+    """Head.forward + unpatchify -> fp32 [B,16,F,H,W] (model.py:847-865,2100-2126)."""
+    _req(x, BF16, "x"); _req(hmod, torch.float32, "hmod"); _req(e, BF16, "e")
+    _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias")
+    B, L, d = x.shape
+    F, Hg, Wg = grid
+    tmp = torch.empty_like(x)
+    out = torch.empty(B, 16, F, Hg * 2, Wg * 2, dtype=torch.float32, device=x.device)
+    check(_L.load().wan_head(ptr(x), ptr(hmod), ptr(e), ptr(w), ptr(bias), ptr(tmp), ptr(out), B, F, Hg, Wg, d, eps,
+                             stream_ptr()), "wan_head")
+    return out
+
+
+def unpatchify(tok, grid):
+    _req(tok, torch.float32, "tok")
+    B = tok.shape[0]
+    F, Hg, Wg = grid
+    out = torch.empty(B, 16, F, Hg * 2, Wg * 2, dtype=torch.float32, device=tok.device)
+    check(_L.load().wan_unpatchify(ptr(tok), ptr(out), B, F, Hg, Wg, stream_ptr()), "wan_unpatchify")
+    return out
+
+
+def lincomb(tensors, coefs, out=None):
+    """out = sum_i coefs[i] * tensors[i] on fp32 latents (scheduler / CFG arithmetic)."""
+    n = len(tensors)
+    for i, t in enumerate(tensors):
+        _req(t, torch.float32, f"in[{i}]")
+    out = torch.empty_like(tensors[0]) if out is None else out
+    P = (c_void_p * n)(*[t.data_ptr() for t in tensors])
+    C = (c_float * n)(*[float(c) for c in coefs])
+    check(_L.load().wan_lincomb(ptr(out), n, P, C, tensors[0].numel(), stream_ptr()), "wan_lincomb")
+    return out
+
+
+def gemv(x, weight, bias):
+    _req(x, BF16, "x"); _req(weight, BF16, "weight"); _req(bias, BF16, "bias")
+    N, K = weight.shape
+    M = x.numel() // K
+    out = torch.empty(M, N, dtype=BF16, device=x.device)
+    check(_L.load().wan_gemv_bf16(ptr(x), ptr(weight), ptr(bias), ptr(out), M, N, K, stream_ptr()), "wan_gemv_bf16")
+    return out
+
+
+def cfg_combine(cond, uncond, guide_scale, out=None):
+    """noise_pred = uncond + g * (cond - uncond)   (any2video.py:1722), fp32."""
+    _req(cond, torch.float32, "cond"); _req(uncond, torch.float32, "uncond")
+    out = torch.empty_like(cond) if out is None else out
+    check(_L.load().wan_cfg_combine(ptr(out), ptr(cond), ptr(uncond), float(guide_scale), cond.numel(), stream_ptr()),
+          "wan_cfg_combine")
+    return out

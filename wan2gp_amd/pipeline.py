@@ -1,0 +1,101 @@
+"""WanAny2VHIP -- the sampler loop of `WanAny2V.generate()` on resident HIP models.
+
+Mirrors models/wan/any2video.py for the t2v / i2v2.2 path:
+  scheduler build (:506-545) -> seed generator (:548-549) -> target_shape (:1166) ->
+  RoPE tables (:1192) -> noise (:1470) -> per-step expert/guidance switch (:1437-1443,
+  :1491-1492) -> joint CFG pass (:1626-1634) or two single passes (:1638-1643) ->
+  CFG combine (:1722) -> scheduler.step (:1733) -> callback (:1743-1750) ->
+  VAE decode to uint8 (:1763,:1784) -> {"x": ..., "latent_slice": None} (:1810-1826).
+Text encoding (UMT5) is outside the hot path: the caller passes the already encoded
+`context` / `context_null` ([1,512,4096], zero padded as :590 does), or a `text_encoder`
+callable.  Returns None when interrupted, like the reference.
+"""
+from typing import Callable, Optional
+
+import torch
+
+from .rope import get_rotary_pos_embed
+from .schedulers import EulerScheduler, FlowUniPCMultistepScheduler, cfg_combine
+
+
+class WanAny2VHIP:
+    def __init__(self, model, model2=None, vae=None, text_encoder: Optional[Callable] = None, device="cuda",
+                 num_train_timesteps=1000, vae_stride=(4, 8, 8), patch_size=(1, 2, 2)):
+        self.model, self.model2, self.vae, self.text_encoder = model, model2, vae, text_encoder
+        self.device = torch.device(device)
+        self.num_train_timesteps = num_train_timesteps
+        self.vae_stride, self.patch_size = vae_stride, patch_size
+        self._interrupt = False
+
+    def _scheduler(self, sample_solver, sampling_steps, shift):
+        if sample_solver == "euler":
+            s = EulerScheduler(num_train_timesteps=self.num_train_timesteps, use_timestep_transform=True)
+            s.set_timesteps(sampling_steps, device=self.device, shift=shift)
+        elif sample_solver in ("unipc", ""):
+            s = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                            use_dynamic_shifting=False)
+            s.set_timesteps(sampling_steps, device=self.device, shift=shift)
+        else:
+            raise NotImplementedError(f"Unsupported Scheduler {sample_solver} (hot path implements unipc, euler)")
+        return s, s.timesteps
+
+    def generate(self, input_prompt=None, n_prompt="", context=None, context_null=None, width=1280, height=720,
+                 frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
+                 guide2_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
+                 joint_pass=True, y=None, latents=None, VAE_tile_size=0, return_latents=False, **bbargs):
+        if batch_size != 1:
+            raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
+        if context is None:
+            if self.text_encoder is None or input_prompt is None:
+                raise ValueError("pass `context`/`context_null` ([1,512,4096] bf16) or a text_encoder + input_prompt")
+            context = self.text_encoder([input_prompt], self.device)[0]
+            context_null = self.text_encoder([n_prompt], self.device)[0]
+        dev = self.device
+        sample_scheduler, timesteps = self._scheduler(sample_solver, sampling_steps, shift)
+        seed_g = torch.Generator(device=dev)
+        seed_g.manual_seed(seed if seed >= 0 else torch.seed() % (2 ** 31))
+        lat_frames = (frame_num - 1) // self.vae_stride[0] + 1                       # any2video.py:647
+        target_shape = (16, lat_frames, height // self.vae_stride[1], width // self.vae_stride[2])   # :1166
+        freqs = get_rotary_pos_embed(target_shape[1:], device=dev)                   # :1192
+        if latents is None:
+            latents = torch.randn(batch_size, *target_shape, dtype=torch.float32, device=dev, generator=seed_g)  # :1470
+        else:
+            latents = latents.to(device=dev, dtype=torch.float32).clone()
+        any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
+        trans = self.model
+        guidance_switch_done = False
+        kwargs = {"freqs": freqs, "pipeline": self, "callback": callback, "y": y, "max_steps": len(timesteps)}
+        for i, t in enumerate(timesteps):
+            # update_guidance (:1437-1443): phase 2 begins once t <= switch_threshold
+            if guide_phases >= 2 and not guidance_switch_done and t <= switch_threshold:
+                if model_switch_phase == 1 and self.model2 is not None:
+                    trans = self.model2
+                guide_scale, guidance_switch_done = guide2_scale, True
+            timestep = torch.stack([t])
+            kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": i})
+            if guide_scale == 1 or not any_guidance:
+                ret = trans(x=[latents], context=[context], **kwargs)
+                if self._interrupt or ret[0] is None:
+                    return None
+                noise_pred = ret[0]
+            else:
+                if joint_pass:
+                    ret = trans(x=[latents, latents], context=[context, context_null], **kwargs)   # :1626-1634
+                    if self._interrupt or ret[0] is None:
+                        return None
+                else:
+                    ret = []
+                    for x_id, c in enumerate((context, context_null)):                             # :1638-1643
+                        r = trans(x=[latents], context=[c], x_id=x_id, **kwargs)[0]
+                        if self._interrupt or r is None:
+                            return None
+                        ret.append(r)
+                noise_pred = cfg_combine(ret[0], ret[1], float(guide_scale))                        # :1722
+            latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
+            if callback is not None:
+                callback(i, latents[0], False)
+        if return_latents or self.vae is None:
+            return {"x": None, "latents": latents, "latent_slice": None}
+        x0 = latents.unbind(0)                                                                     # :1763
+        videos = self.vae.decode_to_cpu_uint8(x0, VAE_tile_size)                                   # :1784
+        return {"x": videos[0], "latents": latents, "latent_slice": None}

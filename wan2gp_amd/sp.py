@@ -1,0 +1,76 @@
+"""Temporal sequence parallelism over RCCL / xGMI (new capability: the reference has no
+multi-GPU code on the Wan path).
+
+The token axis (f-major, so contiguous token ranges are temporal slabs) is split into
+`world` equal contiguous shards, one per GPU/process.  Everything in a DiT block except
+self-attention is token-local; per block each rank all-gathers K and V^T of the other shards
+(one `all_gather_into_tensor` each -- all-gather uses all 7 xGMI links of a rank concurrently,
+there is no all-reduce anywhere) and attends its local Q rows against the `world` gathered
+segments (wan_attention_seg).  Weights are replicated, latents are replicated (19 MB), every
+rank runs the identical scheduler arithmetic, so there is no broadcast either; the only other
+exchange is the all-gather of the head's token-major output once per forward.
+
+Host logic here is device-agnostic (`gloo` on CPU in tests, `nccl` == RCCL on GPUs).
+"""
+import ctypes
+from ctypes import c_void_p
+
+import torch
+import torch.distributed as dist
+
+from .lib import GATHER_FN, SpInfo
+
+
+def shard_range(L: int, rank: int, world: int):
+    """Equal contiguous token shards; L must divide evenly (75,600 / 147,600 / 32,760 all do for 2,4,8)."""
+    if L % world != 0:
+        raise ValueError(f"token count {L} is not divisible by {world} sequence shards")
+    n = L // world
+    return rank * n, n
+
+
+class SequenceParallel:
+    def __init__(self, rank: int, world: int, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self._ws = None
+        self._cb = None
+        self._info = None
+
+    # ---- collectives (torch.distributed; backend nccl == RCCL on ROCm) ---------------------------
+    def all_gather(self, send: torch.Tensor) -> torch.Tensor:
+        """[n, ...] per rank -> [world*n, ...] in rank order."""
+        out = torch.empty((self.world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(out, send.contiguous(), group=self.group)
+        return out
+
+    def bind_workspace(self, ws: torch.Tensor):
+        """The C++ forward hands raw pointers into the torch-owned workspace back to the gather
+        callback; they are mapped to views of `ws` so torch.distributed orders the collective
+        against the compute stream."""
+        self._ws = ws
+
+    def _gather_cb(self, user, which, send, recv, nbytes, stream):
+        try:
+            base = self._ws.data_ptr()
+            s_off, r_off = send - base, recv - base
+            sv = self._ws[s_off:s_off + nbytes]
+            rv = self._ws[r_off:r_off + nbytes * self.world]
+            dist.all_gather_into_tensor(rv, sv, group=self.group)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def make_info(self, L: int) -> SpInfo:
+        tok0, n = shard_range(L, self.rank, self.world)
+        if self._cb is None:
+            self._cb = GATHER_FN(self._gather_cb)      # keep the ctypes thunk alive
+        self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, None)
+        return self._info
+
+    def gather_output(self, tok_major: torch.Tensor, grid):
+        """[1, L/world, 64] fp32 per rank -> full [1,16,F,H,W] on every rank."""
+        from . import ops
+        full = self.all_gather(tok_major[0]).unsqueeze(0)
+        return ops.unpatchify(full.contiguous(), grid)
