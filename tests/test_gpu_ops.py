@@ -33,13 +33,19 @@ def cu(t):
     return t.cuda().contiguous()
 
 
-def assert_bf16_close(got, ref, frac=0.01, ulps=2, what=""):
-    """got/ref: tensors holding bf16-representable values."""
+def assert_bf16_close(got, ref, frac=0.01, ulps=2, what="", floor=None):
+    """got/ref: tensors holding bf16-representable values.  An element may differ from the oracle
+    by `ulps` bf16 ulps (1 ulp is 2^-8..2^-7 relative, we use 2^-7) of max(|ref|, floor): `floor`
+    is the magnitude of the terms that were summed to produce it (cancellation makes a 1-ulp
+    difference of an intermediate bf16 value look large relative to a small result); default
+    1e-3 of the largest |ref|."""
     got, ref = got.float().cpu(), ref.float().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert torch.isfinite(got).all(), f"{what}: non-finite output"
     diff = (got - ref).abs()
-    tol = ref.abs().clamp_min(1e-30) * (2.0 ** -8) * ulps + 1e-30
+    if floor is None:
+        floor = 1e-3 * ref.abs().max().item()
+    tol = torch.maximum(ref.abs(), torch.as_tensor(floor, dtype=torch.float32)) * (2.0 ** -7) * ulps
     bad = diff > tol
     assert not bad.any(), f"{what}: {int(bad.sum())} elements beyond {ulps} bf16 ulp, worst {diff.max().item()} at {np.unravel_index(int(diff.argmax()), diff.shape)}"
     neq = (got != ref).float().mean().item()
@@ -139,12 +145,13 @@ def test_gemm_plain_and_gelu(ops, M, N, K):
     x = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
     b = (0.1 * torch.randn(N, generator=g)).to(BF)
     ref = _gemm_ref(x, w, b)
+    fl = 0.25          # outputs are N(0,1)-scaled dot products: terms of magnitude ~1 cancel
     got = ops.linear(cu(x), cu(w), cu(b))
-    assert_bf16_close(got, ref, frac=0.05, what="gemm none")
+    assert_bf16_close(got, ref, frac=0.05, what="gemm none", floor=fl)
     got = ops.linear(cu(x), cu(w), cu(b), epilogue=1)
-    assert_bf16_close(got, torch.nn.functional.gelu(ref, approximate="tanh"), frac=0.05, ulps=3, what="gemm gelu")
+    assert_bf16_close(got, torch.nn.functional.gelu(ref, approximate="tanh"), frac=0.05, ulps=3, what="gemm gelu", floor=fl)
     got = ops.linear(cu(x), cu(w), None)
-    assert_bf16_close(got, _gemm_ref(x, w, torch.zeros(N)), frac=0.05, what="gemm no bias")
+    assert_bf16_close(got, _gemm_ref(x, w, torch.zeros(N)), frac=0.05, what="gemm no bias", floor=fl)
 
 
 @pytest.mark.parametrize("M,N,K,B", [(200, 256, 128, 2), (96, 1536, 256, 1)])
@@ -160,9 +167,9 @@ def test_gemm_gate_residual(ops, M, N, K, B):
                      for i in range(B)])
     rr = cu(r.clone())
     got = ops.linear(cu(x), cu(w), cu(b), epilogue=2, residual=rr, mod=cu(mod), e=cu(e0), gate_idx=5, out=rr)
-    assert_bf16_close(got, ref, frac=0.05, what="gemm gate residual (in place)")
+    assert_bf16_close(got, ref, frac=0.05, what="gemm gate residual (in place)", floor=(r.float().abs() + y.float().abs()))
     got = ops.linear(cu(x), cu(w), cu(b), epilogue=2, residual=cu(r), gate_idx=-1)
-    assert_bf16_close(got, r + y, frac=0.05, what="gemm plain residual")
+    assert_bf16_close(got, r + y, frac=0.05, what="gemm plain residual", floor=(r.float().abs() + y.float().abs()))
 
 
 @pytest.mark.parametrize("M,N,K", [(72, 256, 256), (200, 256, 128), (4095, 1536, 256), (512, 256, 64)])
@@ -173,7 +180,7 @@ def test_gemm_transposed_vt(ops, M, N, K):
     vt = ops.linear(cu(x), cu(w), cu(b), epilogue=3)
     ldv = vt.shape[1]
     assert ldv % 64 == 0 and ldv >= M
-    assert_bf16_close(vt[:, :M], _gemm_ref(x, w, b).t(), frac=0.05, what="V^T")
+    assert_bf16_close(vt[:, :M], _gemm_ref(x, w, b).t(), frac=0.05, what="V^T", floor=0.25)
     assert (vt[:, M:] == 0).all(), "padding columns must stay zero"
 
 
@@ -282,7 +289,7 @@ def test_patch_embed_and_head(ops, name):
     xin = lat if y is None else torch.cat([lat, y.unsqueeze(0)], dim=1)
     ref, grid = O.patch_embed(xin, W, cfg, BF)
     got = ops.patch_embed(cu(lat), cu(W["patch_embedding.weight"]), cu(W["patch_embedding.bias"]), None if y is None else cu(y))
-    assert_bf16_close(got, ref, frac=0.02, what="patch_embed")
+    assert_bf16_close(got, ref, frac=0.02, what="patch_embed", floor=0.05)
     g = torch.Generator().manual_seed(2)
     L = ref.shape[1]
     hid = torch.randn(1, L, cfg.dim, generator=g).to(BF); e = (0.3 * torch.randn(1, cfg.dim, generator=g)).to(BF)

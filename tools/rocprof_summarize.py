@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 CSV output (kernel trace and/or PMC passes) into a small JSON/markdown
+that can be committed under profiles/.   usage: rocprof_summarize.py <dir> <out.json> [label]"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.split("(")[0]
+    for k in ("attn_fwd_kernel", "gemm_bf16_kernel", "rmsnorm_rope_kernel", "layernorm_kernel", "gated_residual",
+              "patch_embed_kernel", "head_gemm_kernel", "gemv_kernel", "lincomb_kernel", "cfg_combine", "transpose_v"):
+        if k in name:
+            if k == "gemm_bf16_kernel":
+                import re
+                m = re.search(r"gemm_bf16_kernelILi(\d)ELb(\d)", name)
+                if m:
+                    return f"gemm_bf16_kernel<epi={m.group(1)},bias_rows={m.group(2)}>"
+            return k
+    return name[:60]
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    label = sys.argv[3] if len(sys.argv) > 3 else ""
+    res = {"label": label, "kernels": {}, "counters": {}}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        agg = defaultdict(lambda: [0, 0.0])
+        for row in csv.DictReader(open(f)):
+            n = short(row.get("Kernel_Name", ""))
+            dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+            agg[n][0] += 1
+            agg[n][1] += dur
+        tot = sum(v[1] for v in agg.values()) or 1.0
+        for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            res["kernels"][n] = {"calls": c, "total_ms": round(t, 3), "avg_ms": round(t / c, 4), "pct": round(100 * t / tot, 2)}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+        for row in csv.DictReader(open(f)):
+            n = short(row.get("Kernel_Name", ""))
+            a = agg[n][row["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+        for n, cs in agg.items():
+            for cn, (c, v) in cs.items():
+                res["counters"].setdefault(n, {})[cn] = {"dispatches": c, "avg": v / c, "sum": v}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: v for k, v in list(res["kernels"].items())[:12]}, indent=1))
+    for n, cs in res["counters"].items():
+        print(n, {k: round(v["avg"], 1) for k, v in cs.items()})
+
+
+if __name__ == "__main__":
+    main()
