@@ -1,0 +1,101 @@
+"""CPU, world_size 2, gloo: the host logic of temporal sequence parallelism (wan2gp_amd/sp.py) --
+token sharding, gather ordering, RoPE position offsets, segmented K/V attention, token-major output
+gather + unpatchify -- driven on the CPU oracle's arithmetic.  Every rank must reproduce the
+single-process oracle block/forward result for its shard."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wan_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wan2gp_amd.sp import SequenceParallel, shard_range
+        torch.set_num_threads(2)
+        sp = SequenceParallel(rank, world)
+        cfg = O.make_config("tiny")
+        W = O.synth_weights(cfg, dtype=torch.float32)
+        f, h, w = 2, 8, 8
+        lat, ctx, _, _ = O.synth_inputs(cfg, f, h, w)
+        grid = (f, h // 2, w // 2)
+        L = f * (h // 2) * (w // 2)
+        tok0, n = shard_range(L, rank, world)
+        assert (tok0, n) == (rank * L // world, L // world)
+        cos, sin = O.rope_tables(grid)
+        t = torch.tensor([500])
+        dt = torch.float32
+        # reference: single-process oracle
+        full_h, _ = O.patch_embed(lat, W, cfg, dt)
+        e, e0 = O.time_embed(t, W, cfg, dt)
+        cemb = O.text_embed(ctx.float(), W)
+        ref = full_h
+        for i in range(cfg.num_layers):
+            ref = O.block_forward(ref, e0, cemb, cos, sin, W, i, cfg, exact=True)
+        ref_out = O.unpatchify(O.head_forward(ref, e, W, cfg), grid, cfg)
+        # sharded: everything token-local except self-attention, which sees gathered K / V segments
+        x = full_h[:, tok0:tok0 + n]
+        for i in range(cfg.num_layers):
+            p = f"blocks.{i}."
+            ee = (W[p + "modulation"] + e0).chunk(6, dim=1)
+            xm = O.layer_norm(x, cfg.eps) * (1 + ee[1]) + ee[0]
+            sa = p + "self_attn."
+            qq = O.rms_norm(O._linear(xm, W, sa + "q"), W[sa + "norm_q.weight"], cfg.eps).view(1, n, cfg.num_heads, 128)
+            kk = O.rms_norm(O._linear(xm, W, sa + "k"), W[sa + "norm_k.weight"], cfg.eps).view(1, n, cfg.num_heads, 128)
+            vv = O._linear(xm, W, sa + "v").view(1, n, cfg.num_heads, 128)
+            qq = O.rope_apply(qq, cos[tok0:tok0 + n], sin[tok0:tok0 + n])       # pos0 = tok0
+            kk = O.rope_apply(kk, cos[tok0:tok0 + n], sin[tok0:tok0 + n])
+            kf = sp.all_gather(kk[0]).unsqueeze(0)                               # [world*n, H, 128] in rank order
+            vf = sp.all_gather(vv[0]).unsqueeze(0)
+            y = O._linear(O.attention(qq, kf, vf, exact=True).flatten(2), W, sa + "o")
+            x = torch.addcmul(x, y, ee[2])
+            y = O.layer_norm(x, cfg.eps, W[p + "norm3.weight"], W[p + "norm3.bias"])
+            x = x + O.cross_attention(y, cemb, W, p + "cross_attn.", cfg, True)
+            y = O.layer_norm(x, cfg.eps) * (1 + ee[4]) + ee[3]
+            y = O._linear(torch.nn.functional.gelu(O._linear(y, W, p + "ffn.0"), approximate="tanh"), W, p + "ffn.2")
+            x = torch.addcmul(x, y, ee[5])
+        assert torch.allclose(x, ref[:, tok0:tok0 + n], atol=1e-4, rtol=1e-4)
+        tok_major = O.head_forward(x, e, W, cfg)                                 # [1, n, 64]
+        full_tok = sp.all_gather(tok_major[0]).unsqueeze(0)                      # [1, L, 64]
+        out = O.unpatchify(full_tok, grid, cfg)
+        assert torch.allclose(out, ref_out, atol=1e-4, rtol=1e-4)
+        q.put((rank, "ok"))
+    except Exception as ex:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sequence_parallel_host_logic_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_shard_range_rejects_ragged():
+    from wan2gp_amd.sp import shard_range
+    assert shard_range(75600, 3, 8) == (3 * 9450, 9450)
+    assert shard_range(147600, 7, 8) == (7 * 18450, 18450)
+    with pytest.raises(ValueError):
+        shard_range(75601, 0, 8)

@@ -23,22 +23,32 @@
 // ds_read_b128 lane group hits 16 distinct 16-B slots.
 // Workgroup ids are remapped so that each XCD owns whole (batch, head) pairs: the 64 blocks
 // resident on an XCD stream the same K/V through that XCD's private L2.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
-#define QBLK 128       // q rows per block (4 waves x 32)
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float hw_f32x2;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {  // one v_cvt_pk_bf16_f32 (RNE)
+  hw_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
+}
 #define KVBLK 64
 #define K_STAGE (KVBLK * 256)        // 16 KiB: 64 rows x 128 d x 2 B
 #define V_STAGE (128 * KVBLK * 2)    // 16 KiB: 128 d rows x 64 kv x 2 B
-#define O_STRIDE 272                 // bytes per staged O row (256 + 16 pad)
 
 __device__ __forceinline__ void glds16a(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
+// FLAGS bit0: lean softmax (hardware v_cvt_pk_bf16_f32 packing, rescale O only when the running max
+//             moved), bit1: s_setprio(1) around the MFMA clusters.  NW = waves per block (4 or 8).
+template <int FLAGS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
                                                           const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O,
                                                           int B, int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H,
                                                           int nqb, float scale_log2e, int nseg, int64_t k_seg_stride,
@@ -66,6 +76,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   bf16_t* obase = O + ((int64_t)b * Lq) * rs + (int64_t)h * 128;
 
   // ---- Q fragments: B operand of S^T = K Q^T : lane holds Q[q=l31][ks*16 + half*8 .. +8] -------
+  constexpr int QBLK = NW * 32;  // q rows per block
+  constexpr bool LEAN = (FLAGS & 1) != 0;
+  constexpr bool PRIO = (FLAGS & 2) != 0;
+  constexpr int NLD = 1024 / (NW * 64);  // 16-B DMA slots per thread per 16 KiB image
   const int64_t q0 = (int64_t)qb * QBLK + wave * 32;
   int64_t qrow = q0 + l31;
   if (qrow > Lq - 1) qrow = Lq - 1;
@@ -76,11 +90,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
   // ---- staging addresses -----------------------------------------------------------------------
   // K image: LDS row r (0..63) <- kv_local = (r & ~12) | ((r&4)<<1) | ((r&8)>>1)  (swap bits 2,3)
-  int kk_row[4], kk_col[4];  // kv_local, element column
-  int vv_row[4], vv_col[4];  // d row, kv element column
+  int kk_row[NLD], kk_col[NLD];  // kv_local, element column
+  int vv_row[NLD], vv_col[NLD];  // d row, kv element column
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int s = i * 256 + tid;
+  for (int i = 0; i < NLD; ++i) {
+    const int s = i * (NW * 64) + tid;
     {
       const int r = s >> 4, pch = s & 15;
       const int lch = pch ^ (r & 15);
@@ -95,16 +109,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     }
   }
   const int tps = (int)((Lk + KVBLK - 1) / KVBLK);  // tiles per segment
-  auto stage = [&](int st, int t) {
-    const int seg = t / tps;
-    const int64_t kv0 = (int64_t)(t - seg * tps) * KVBLK;
+  auto stage = [&](int st, int seg, int tt) {
+    const int64_t kv0 = (int64_t)tt * KVBLK;
     const bf16_t* kseg = kbase + (int64_t)seg * k_seg_stride;
     const bf16_t* vseg = vbase + (int64_t)seg * vt_seg_stride;
     char* kb = smem + st * (K_STAGE + V_STAGE);
     char* vb = kb + K_STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int woff = (i * 256 + wave * 64) * 16;
+    for (int i = 0; i < NLD; ++i) {
+      const int woff = (i * (NW * 64) + wave * 64) * 16;
       int64_t kr = kv0 + kk_row[i];
       if (kr > Lk - 1) kr = Lk - 1;
       glds16a(kseg + kr * rs + kk_col[i], kb + woff);
@@ -137,16 +150,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   float l_run = 0.f;        // this lane's partial sum of exp
 
   const int ntile = tps * nseg;
-  stage(0, 0);
+  stage(0, 0, 0);
+  int tt = 0;                    // tile index inside the current segment (no per-tile division)
+  int pf_seg = 0, pf_tt = 0;     // (segment, tile) of the prefetched tile
   for (int t = 0; t < ntile; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 1 < ntile) stage((t + 1) & 1, t + 1);
+    if (t + 1 < ntile) {
+      if (++pf_tt == tps) { pf_tt = 0; ++pf_seg; }
+      stage((t + 1) & 1, pf_seg, pf_tt);
+    }
     const char* kb = smem + (t & 1) * (K_STAGE + V_STAGE);
     const char* vb = kb + K_STAGE;
 
     // ---- S^T = K Q^T ---------------------------------------------------------------------------
     f32x16 accS[2];
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
 #pragma unroll
@@ -157,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         accS[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], accS[T], 0, 0, 0);
       }
     }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
     // reg r of tile T, this half  <->  kv = t*64 + T*32 + (r&7) + 8*half + 16*(r>>3)
-    const int tt = t % tps;
     if ((int64_t)(tt + 1) * KVBLK > Lk) {
       const int64_t kv0 = (int64_t)tt * KVBLK;
 #pragma unroll
@@ -177,9 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, accS[T][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
     const float mb = m_new * scale_log2e;
-    m_run = m_new;
     float psum = 0.f;
     uint32_t pk[2][8];
 #pragma unroll
@@ -189,13 +206,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         const float p0 = __builtin_amdgcn_exp2f(accS[T][r] * scale_log2e - mb);
         const float p1 = __builtin_amdgcn_exp2f(accS[T][r + 1] * scale_log2e - mb);
         psum += p0 + p1;
-        pk[T][r >> 1] = pack2bf(p0, p1);
+        pk[T][r >> 1] = LEAN ? cvt_pk_bf16(p0, p1) : pack2bf(p0, p1);
       }
-    l_run = l_run * alpha + psum;
+    if (!LEAN || !__all(m_new == m_run)) {
+      // the running max moved for at least one q row of this wave: rescale O and l (exactly once,
+      // before this tile's P enters O); otherwise alpha == 1 for every lane and the pass is skipped
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      l_run *= alpha;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accO[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) accO[dt][r] *= alpha;
+    }
+    l_run += psum;
+    m_run = m_new;
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
 
     // ---- O^T += V^T P^T ---------------------------------------------------------------------------
 #pragma unroll
@@ -213,22 +238,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
           accO[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, accO[dt], 0, 0, 0);
         }
       }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    if (++tt == tps) tt = 0;
   }
 
   // ---- epilogue: normalise, stage O[q][d] through LDS, store whole 256-B rows -----------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   __syncthreads();  // all waves done with the K/V ring
-  char* ob = smem + wave * (32 * O_STRIDE);
+  // per-wave [32 q][128 d] bf16 image (8 KiB), 16-B chunks XOR-swizzled by the row (chunk ^= q&15)
+  char* ob = smem + wave * (32 * 256);
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       uint2 w;
-      w.x = pack2bf(accO[dt][g * 4 + 0] * inv, accO[dt][g * 4 + 1] * inv);
-      w.y = pack2bf(accO[dt][g * 4 + 2] * inv, accO[dt][g * 4 + 3] * inv);
-      const int d = dt * 32 + g * 8 + half * 4;
-      *reinterpret_cast<uint2*>(ob + l31 * O_STRIDE + d * 2) = w;
+      w.x = cvt_pk_bf16(accO[dt][g * 4 + 0] * inv, accO[dt][g * 4 + 1] * inv);
+      w.y = cvt_pk_bf16(accO[dt][g * 4 + 2] * inv, accO[dt][g * 4 + 3] * inv);
+      const int ch = (dt * 4 + g) ^ (l31 & 15);  // d = dt*32 + g*8 + half*4 .. +4
+      *reinterpret_cast<uint2*>(ob + l31 * 256 + ch * 16 + half * 8) = w;
     }
   __syncthreads();
 #pragma unroll
@@ -236,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int r = i * 4 + (lane >> 4), c = lane & 15;
     const int64_t qr = q0 + r;
     if (qr < Lq) {
-      const uint4 val = *reinterpret_cast<const uint4*>(ob + r * O_STRIDE + c * 16);
+      const uint4 val = *reinterpret_cast<const uint4*>(ob + r * 256 + ((c ^ (r & 15)) << 4));
       *reinterpret_cast<uint4*>(obase + qr * rs + c * 8) = val;
     }
   }
@@ -245,6 +273,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
                                  int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
                                  int64_t vt_seg_stride, void* stream);
+int wan_attention_pp_launch(int flags, int mode, int nw, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
+                            int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
+                            int64_t vt_seg_stride, float scale_log2e, hipStream_t stream);
 
 extern "C" int wan_attention(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
                              int64_t Lq, int64_t Lk, int64_t ldv, int H, void* stream) {
@@ -263,12 +294,47 @@ extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan
               (long long)ldv);
   WAN_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o) & 15) == 0,
               "wan_attention: pointers must be 16-byte aligned");
-  const int64_t nqb = (Lq + QBLK - 1) / QBLK;
+  const float scale_log2e = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
+  // kernel variant: default = lean softmax, 4 waves.  WAN_ATTN_VARIANT (tuning/A-B only):
+  //   "base" = first kernel, "lean", "lean_prio", "lean8" (8 waves / 256 q rows), "lean8_prio",
+  //   "pp"/"pp_prio" = the two-phase ping-pong schedule of attention_pp.hip (correct, slower: see DESIGN.md)
+  // measured on MI355X (profiles/r01_attn_variants.md): 8 waves sharing each K/V tile win for long
+  // KV (self-attention), 4-wave blocks win for short KV (cross-attention, Lk = 512)
+  // (v2 = static-stage loop body of attention_pp.hip MODE 0)
+  int variant = (Lk * (int64_t)nseg > 2048) ? 8 : 7;
+  if (Lk * (int64_t)H * 256 >= ((int64_t)1 << 32) || ldv * 256 >= ((int64_t)1 << 32)) variant = 3;  // 64-bit addressing kernel
+  {
+    const char* ev = getenv("WAN_ATTN_VARIANT");
+    if (ev) {
+      if (!strcmp(ev, "base")) variant = 0;
+      else if (!strcmp(ev, "lean")) variant = 1;
+      else if (!strcmp(ev, "lean_prio")) variant = 2;
+      else if (!strcmp(ev, "lean8")) variant = 3;
+      else if (!strcmp(ev, "lean8_prio")) variant = 4;
+      else if (!strcmp(ev, "pp")) variant = 5;
+      else if (!strcmp(ev, "pp_prio")) variant = 6;
+      else if (!strcmp(ev, "v2_4")) variant = 7;
+      else if (!strcmp(ev, "v2_8")) variant = 8;
+    }
+  }
+  if (variant >= 5)
+    return wan_attention_pp_launch(variant == 6 ? 1 : 0, variant <= 6 ? 1 : 0, variant == 7 ? 4 : 8, q, k, vt, o, B, Bk,
+                                   Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, scale_log2e, as_stream(stream));
+  const int nw = (variant >= 3) ? 8 : 4;
+  const int64_t nqb = (Lq + nw * 32 - 1) / (nw * 32);
   const int64_t total = nqb * H * B;
   WAN_REQUIRE(total < ((int64_t)1 << 31), "wan_attention: grid too large");
-  const float scale_log2e = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)total), dim3(256), 0, as_stream(stream), q, k, vt, o, B, Bk, Lq,
-                     Lk, ldv, H, (int)nqb, scale_log2e, nseg, k_seg_stride, vt_seg_stride);
+#define LAUNCH_ATTN(FL, NWV)                                                                                        \
+  hipLaunchKernelGGL((attn_fwd_kernel<FL, NWV>), dim3((unsigned)total), dim3(NWV * 64), 0, as_stream(stream), q, k, \
+                     vt, o, B, Bk, Lq, Lk, ldv, H, (int)nqb, scale_log2e, nseg, k_seg_stride, vt_seg_stride)
+  switch (variant) {
+    case 0: LAUNCH_ATTN(0, 4); break;
+    case 2: LAUNCH_ATTN(3, 4); break;
+    case 3: LAUNCH_ATTN(1, 8); break;
+    case 4: LAUNCH_ATTN(3, 8); break;
+    default: LAUNCH_ATTN(1, 4); break;
+  }
+#undef LAUNCH_ATTN
   WAN_LAUNCH_CHECK();
   return 0;
 }

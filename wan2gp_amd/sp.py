@@ -37,10 +37,22 @@ class SequenceParallel:
         self._info = None
 
     # ---- collectives (torch.distributed; backend nccl == RCCL on ROCm) ---------------------------
+    def _all_gather_into(self, out: torch.Tensor, send: torch.Tensor):
+        """out[world*n] <- concat over ranks of send[n] (flat views).  RCCL path: one
+        all_gather_into_tensor on device memory.  `gloo` (CPU tests, and the single-GPU functional
+        test where both ranks share one device) stages through host memory."""
+        if dist.get_backend(self.group) == "gloo":
+            src = send.detach().cpu().contiguous()
+            parts = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(parts, src, group=self.group)
+            out.copy_(torch.cat([p.reshape(-1) for p in parts]).view_as(out))
+        else:
+            dist.all_gather_into_tensor(out, send.contiguous(), group=self.group)
+
     def all_gather(self, send: torch.Tensor) -> torch.Tensor:
         """[n, ...] per rank -> [world*n, ...] in rank order."""
         out = torch.empty((self.world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
-        dist.all_gather_into_tensor(out, send.contiguous(), group=self.group)
+        self._all_gather_into(out, send)
         return out
 
     def bind_workspace(self, ws: torch.Tensor):
@@ -55,7 +67,7 @@ class SequenceParallel:
             s_off, r_off = send - base, recv - base
             sv = self._ws[s_off:s_off + nbytes]
             rv = self._ws[r_off:r_off + nbytes * self.world]
-            dist.all_gather_into_tensor(rv, sv, group=self.group)
+            self._all_gather_into(rv, sv)
             return 0
         except Exception:
             import traceback
