@@ -1,0 +1,30 @@
+"""Pins oracle/vae_oracle.py to the reference-generated VAE fixture (CPU, fp32, bit-exact)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import vae_oracle as VO
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_vae_param_count_matches_survey():
+    n = sum(int(np.prod(s)) for s in VO.vae_param_shapes().values())
+    assert abs(n - 126.9e6) < 0.1e6          # 127 M params
+
+
+def test_vae_decode_encode_match_reference():
+    g = dict(np.load(os.path.join(G, "vae_small.npz")))
+    W = VO.synth_vae_weights()
+    scale = VO.default_scale()
+    gen = torch.Generator().manual_seed(21)
+    z = torch.randn(1, 16, 3, 8, 8, generator=gen)
+    with torch.no_grad():
+        dec = VO.vae_decode(z, W, scale)
+        assert torch.equal(dec, torch.from_numpy(g["dec"]))
+        assert torch.equal(VO.float_to_uint8(dec), torch.from_numpy(g["dec_u8"]))
+        vid = (torch.rand(1, 3, 9, 64, 64, generator=gen) * 2 - 1)
+        vid[:, :, 1:] *= 0.5
+        enc = VO.vae_encode(vid, W, scale)
+        assert torch.equal(enc, torch.from_numpy(g["enc"]))
