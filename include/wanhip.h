@@ -198,6 +198,45 @@ int wan_dit_forward(wan_ctx* ctx, int S, const float* const* x, float t, const w
                     int H, int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp,
                     wan_poll_fn poll, void* poll_user, void* stream);
 
+/* ---- causal 3D VAE (fp16, channels-last [T,H,W,C], C % 32 == 0) ---------------------------------
+ * Replaces the torch ops of models/wan/modules/vae.py; the layer graph / cache bookkeeping of
+ * Encoder3d / Decoder3d / WanVAE_.encode / .decode stays on the host (wan2gp_amd/vae.py). */
+
+/* CausalConv3d (vae.py:43-82) / Conv2d of Resample (:124-141) as an implicit GEMM on MFMA.
+ *   x     : [Tin,Hin,Win,Cin] fp16;  cache: the layer's previous 2 input frames [2,Hin,Win,Cin] or NULL
+ *           (NULL = causal zero padding, first chunk)
+ *   w     : packed weights [Cout][Kp] fp16, K index = ((kt*KH+kh)*KW+kw)*Cin + c, Kp = K rounded up to 64
+ *   res   : optional residual [Tout,Hout,Wout,Cout] added after rounding the conv output to fp16
+ *   out   : fp16 output, or out_f32 (fp32, used for the 3-channel decoder head)
+ *   front : temporal context in front of output frame 0 (2: causal k=3; 1: stride-2 time_conv that
+ *           prepends the last cached frame, vae.py:205-206; 0: none);  st_t/st_s: strides
+ *   pad_s : spatial low-side zero padding (1 for 3x3 "same", 0 for 1x1 and the (0,1,0,1)-padded stride-2 conv)
+ *   ups   : 1 = the input is nearest-exact 2x upsampled on the fly (Upsample + Conv2d, vae.py:126-128)
+ *   interleave : 1 = time_conv epilogue: output channels [s*C2,(s+1)*C2) go to frame 2t+s (vae.py:186-189) */
+int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const uint16_t* w, const uint16_t* bias,
+                   const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int Hin, int Win, int Cin,
+                   int Tout, int Hout, int Wout, int Cout, int KT, int KH, int KW, int st_t, int st_s,
+                   int front, int pad_s, int ups, int interleave, void* stream);
+/* RMS_norm (F.normalize * sqrt(C) * gamma, vae.py:97-103) [+ SiLU], per pixel over C channels */
+int wan_vae_rmsnorm_silu(const uint16_t* x, uint16_t* out, const uint16_t* gamma, int64_t npix, int C,
+                         int silu, void* stream);
+/* fp16 GEMM for AttentionBlock (vae.py:294-315): C = scale * A W^T + bias (or its transpose) */
+int wan_gemm_f16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+                 uint16_t* C, int64_t ldc, int64_t M, int64_t N, int K, float scale, int transposed,
+                 void* stream);
+/* P[r,:L] = softmax(S[r,:L]); P[r,L:ld] = 0 */
+int wan_vae_softmax(const uint16_t* S, uint16_t* P, int64_t rows, int L, int64_t ld, void* stream);
+/* fp32 [C,thw] -> fp16 [thw,Cp] (zero padded channels), optional v*mul[c]+add[c] */
+int wan_vae_pack(const float* in, uint16_t* out, const float* mul, const float* add, int C, int Cp,
+                 int64_t thw, void* stream);
+/* fp16 [thw,Cs] -> fp32 [C,thw], optional (v-sub[c])*mul[c] */
+int wan_vae_unpack(const uint16_t* in, float* out, const float* sub, const float* mul, int C, int Cs,
+                   int64_t thw, void* stream);
+/* decoder head fp32 [T*hw,3] -> uint8 and/or fp32 [3,Ttot,hw] at frame t0; uint8 conversion is
+ * _vae_float_to_cpu_uint8 (vae.py:18-20): clamp, +1, *127.5, round-half-even, clamp */
+int wan_vae_to_video(const float* in, uint8_t* u8, float* f32, int T, int64_t hw, int Ttot, int t0,
+                     void* stream);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------
  * wan_prof_enable(1): wan_dit_forward brackets each kernel class with HIP events recorded on the
  * launch stream; wan_prof_collect sums the elapsed ms per class (0 self-attention, 1 cross-

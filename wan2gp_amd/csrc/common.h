@@ -46,6 +46,17 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
+// ---- fp16 <-> f32 (VAE path) ---------------------------------------------------------------------
+__device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+
+// element-type dispatch for kernels templated on the 16-bit storage type (bf16 DiT / fp16 VAE)
+template <bool F16> __device__ __forceinline__ float ld16(uint16_t v) { return F16 ? h2f(v) : bf2f(v); }
+template <bool F16> __device__ __forceinline__ uint16_t st16(float f) { return F16 ? f2h(f) : f2bf(f); }
+template <bool F16> __device__ __forceinline__ float rnd16(float f) { return ld16<F16>(st16<F16>(f)); }
+template <bool F16> __device__ __forceinline__ void unpack8t(const uint4& v, float* f);
+template <bool F16> __device__ __forceinline__ uint4 pack8t(const float* f);
+
 struct alignas(16) U4 {
   uint32_t x, y, z, w;
 };
@@ -60,6 +71,25 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   uint4 v;
   v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
   v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+template <> __device__ __forceinline__ void unpack8t<false>(const uint4& v, float* f) { unpack8(v, f); }
+template <> __device__ __forceinline__ uint4 pack8t<false>(const float* f) { return pack8(f); }
+template <> __device__ __forceinline__ void unpack8t<true>(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = h2f((uint16_t)(w[i] & 0xffffu));
+    f[2 * i + 1] = h2f((uint16_t)(w[i] >> 16));
+  }
+}
+template <> __device__ __forceinline__ uint4 pack8t<true>(const float* f) {
+  uint4 v;
+  v.x = (uint32_t)f2h(f[0]) | ((uint32_t)f2h(f[1]) << 16);
+  v.y = (uint32_t)f2h(f[2]) | ((uint32_t)f2h(f[3]) << 16);
+  v.z = (uint32_t)f2h(f[4]) | ((uint32_t)f2h(f[5]) << 16);
+  v.w = (uint32_t)f2h(f[6]) | ((uint32_t)f2h(f[7]) << 16);
   return v;
 }
 

@@ -23,6 +23,14 @@
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 mfma_f16x8;
+
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_f16x8, a), __builtin_bit_cast(mfma_f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
 
 #define BM 128
 #define BN 128
@@ -41,12 +49,14 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   return 0.5f * x * (1.0f + tanhf(inner));
 }
 
-template <int EPI, bool BIAS_ROWS>
+// F16 = false: bf16 storage (DiT);  F16 = true: fp16 storage (VAE) -- same tiles, MFMA f16 variant.
+// out_scale multiplies the fp32 accumulator before the bias (used for QK^T / sqrt(C) in the VAE).
+template <int EPI, bool BIAS_ROWS, bool F16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
     const bf16_t* __restrict__ Y, int64_t ldy, int64_t YM, const bf16_t* __restrict__ X, int64_t ldx,
     int64_t XN, int K, bf16_t* __restrict__ Out, int64_t ldo, const bf16_t* __restrict__ bias,
     const bf16_t* __restrict__ R, const bf16_t* __restrict__ mod, const bf16_t* __restrict__ e, int n_mod,
-    int gate_idx, int64_t rows_per_batch, int tiles_y, int tiles_x) {
+    int gate_idx, int64_t rows_per_batch, int tiles_y, int tiles_x, float out_scale) {
   __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES];  // [stage][Y|X]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -124,17 +134,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
     const char* xbase = ybase + STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      mfma_bf16x8 yf[4], xf[4];
+      uint4 yf[4], xf[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        yf[t] = *reinterpret_cast<const mfma_bf16x8*>(ybase + (yoff[t] ^ (ks << 6)));
-        xf[t] = *reinterpret_cast<const mfma_bf16x8*>(xbase + (xoff[t] ^ (ks << 6)));
+        yf[t] = *reinterpret_cast<const uint4*>(ybase + (yoff[t] ^ (ks << 6)));
+        xf[t] = *reinterpret_cast<const uint4*>(xbase + (xoff[t] ^ (ks << 6)));
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[b], yf[a], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16<F16>(xf[b], yf[a], acc[a][b]);
     }
   }
 
@@ -145,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
 #pragma unroll
     for (int j = 0; j < 16; ++j) bcol[j] = 0.f;
     if (bias != nullptr && xb + 16 <= XN) {
-      unpack8(*reinterpret_cast<const uint4*>(bias + xb), bcol);
-      unpack8(*reinterpret_cast<const uint4*>(bias + xb + 8), bcol + 8);
+      unpack8t<F16>(*reinterpret_cast<const uint4*>(bias + xb), bcol);
+      unpack8t<F16>(*reinterpret_cast<const uint4*>(bias + xb + 8), bcol + 8);
     }
   }
 #pragma unroll
@@ -154,13 +163,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
     const int64_t yr = y0 + wy * 64 + yt * 16 + (lane & 15);
     if (yr >= YM) continue;
     float v[16];
-    const float brow = (BIAS_ROWS && bias != nullptr) ? bf2f(bias[yr]) : 0.f;
+    const float brow = (BIAS_ROWS && bias != nullptr) ? ld16<F16>(bias[yr]) : 0.f;
 #pragma unroll
     for (int xt = 0; xt < 4; ++xt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float b = BIAS_ROWS ? brow : bcol[xt * 4 + r];
-        v[xt * 4 + r] = rbf(acc[yt][xt][r] + b);  // nn.Linear output is a bf16 tensor
+        v[xt * 4 + r] = rnd16<F16>(acc[yt][xt][r] * out_scale + b);  // nn.Linear output is a 16-bit tensor
       }
     bf16_t* optr = Out + yr * ldo + xb;
     if (xb + 16 <= XN) {
@@ -170,57 +179,78 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
       } else if (EPI == WAN_EPI_GATE_RES) {
         float rv[16];
         const bf16_t* rptr = R + yr * ldo + xb;
-        unpack8(*reinterpret_cast<const uint4*>(rptr), rv);
-        unpack8(*reinterpret_cast<const uint4*>(rptr + 8), rv + 8);
+        unpack8t<F16>(*reinterpret_cast<const uint4*>(rptr), rv);
+        unpack8t<F16>(*reinterpret_cast<const uint4*>(rptr + 8), rv + 8);
         if (gate_idx >= 0) {
           const int64_t bidx = yr / rows_per_batch;
           float mv[16], ev[16];
           const bf16_t* mp = mod + (int64_t)gate_idx * XN + xb;
           const bf16_t* ep = e + (bidx * n_mod + gate_idx) * XN + xb;
-          unpack8(*reinterpret_cast<const uint4*>(mp), mv);
-          unpack8(*reinterpret_cast<const uint4*>(mp + 8), mv + 8);
-          unpack8(*reinterpret_cast<const uint4*>(ep), ev);
-          unpack8(*reinterpret_cast<const uint4*>(ep + 8), ev + 8);
+          unpack8t<F16>(*reinterpret_cast<const uint4*>(mp), mv);
+          unpack8t<F16>(*reinterpret_cast<const uint4*>(mp + 8), mv + 8);
+          unpack8t<F16>(*reinterpret_cast<const uint4*>(ep), ev);
+          unpack8t<F16>(*reinterpret_cast<const uint4*>(ep + 8), ev + 8);
 #pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = rv[j] + v[j] * rbf(mv[j] + ev[j]);
+          for (int j = 0; j < 16; ++j) v[j] = rv[j] + v[j] * rnd16<F16>(mv[j] + ev[j]);
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j) v[j] = rv[j] + v[j];
         }
       }
-      *reinterpret_cast<uint4*>(optr) = pack8(v);
-      *reinterpret_cast<uint4*>(optr + 8) = pack8(v + 8);
+      *reinterpret_cast<uint4*>(optr) = pack8t<F16>(v);
+      *reinterpret_cast<uint4*>(optr + 8) = pack8t<F16>(v + 8);
     } else {
       // ragged x edge (only the transposed/V^T form can hit this: x = tokens)
       for (int j = 0; j < 16; ++j) {
         if (xb + j < XN) {
           float o = v[j];
-          if (!BIAS_ROWS && bias != nullptr) o = rbf(acc[yt][j >> 2][j & 3] + bf2f(bias[xb + j]));
+          if (!BIAS_ROWS && bias != nullptr) o = rnd16<F16>(acc[yt][j >> 2][j & 3] * out_scale + ld16<F16>(bias[xb + j]));
           if (EPI == WAN_EPI_GELU_TANH) o = gelu_tanh_f(o);
           if (EPI == WAN_EPI_GATE_RES) {
             float g = 1.f;
             if (gate_idx >= 0)
-              g = rbf(bf2f(mod[(int64_t)gate_idx * XN + xb + j]) +
-                      bf2f(e[((yr / rows_per_batch) * n_mod + gate_idx) * XN + xb + j]));
-            o = bf2f(R[yr * ldo + xb + j]) + o * g;
+              g = rnd16<F16>(ld16<F16>(mod[(int64_t)gate_idx * XN + xb + j]) +
+                             ld16<F16>(e[((yr / rows_per_batch) * n_mod + gate_idx) * XN + xb + j]));
+            o = ld16<F16>(R[yr * ldo + xb + j]) + o * g;
           }
-          optr[j] = f2bf(o);
+          optr[j] = st16<F16>(o);
         }
       }
     }
   }
 }
 
-template <int EPI, bool BIAS_ROWS>
+template <int EPI, bool BIAS_ROWS, bool F16 = false>
 static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K,
                        bf16_t* Out, int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod,
-                       const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st) {
+                       const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st,
+                       float out_scale = 1.0f) {
   const int64_t ty = (YM + BM - 1) / BM, tx = (XN + BN - 1) / BN;
-  WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm_bf16: too many tiles");
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X,
-                     ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx);
+  WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm: too many tiles");
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM,
+                     X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx,
+                     out_scale);
   WAN_LAUNCH_CHECK();
   return 0;
+}
+
+// fp16 GEMM for the VAE attention block: C[M,N] (ldc) = scale * A[M,K](lda) @ W[N,K](ldw)^T + bias, or its
+// transpose Ct[N, ldc] (transposed != 0).  K % 64 == 0; N % 16 == 0 unless transposed.
+extern "C" int wan_gemm_f16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
+                            uint16_t* C, int64_t ldc, int64_t M, int64_t N, int K, float scale, int transposed,
+                            void* stream) {
+  WAN_REQUIRE(A && W && C, "wan_gemm_f16: null operand");
+  WAN_REQUIRE(K > 0 && K % BK == 0, "wan_gemm_f16: K=%d must be a positive multiple of %d", K, BK);
+  WAN_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0, "wan_gemm_f16: leading dimensions must be multiples of 8");
+  WAN_REQUIRE((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0, "wan_gemm_f16: pointers must be 16-B aligned");
+  if (M == 0 || N == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  if (transposed)
+    return launch_gemm<WAN_EPI_NONE, true, true>(W, ldw, N, A, lda, M, K, C, ldc, bias, nullptr, nullptr, nullptr, 0, -1,
+                                                 1, st, scale);
+  WAN_REQUIRE(N % 16 == 0, "wan_gemm_f16: N=%lld must be a multiple of 16", (long long)N);
+  return launch_gemm<WAN_EPI_NONE, false, true>(A, lda, M, W, ldw, N, K, C, ldc, bias, nullptr, nullptr, nullptr, 0, -1, 1,
+                                                st, scale);
 }
 
 extern "C" int wan_gemm_bf16(const wan_bf16* A, int64_t lda, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C,

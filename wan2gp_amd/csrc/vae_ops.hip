@@ -1,0 +1,423 @@
+// Wan2.1 causal 3D VAE kernels for gfx950 (fp16 storage, fp32 accumulate, channels-last).
+// Replaces the torch ops of models/wan/modules/vae.py: CausalConv3d (:43-82) incl. the 2-frame
+// causal cache, Conv2d of Resample (:124-141) with the nearest-exact 2x upsample fused into the
+// gather (:105-111) or stride 2 + ZeroPad2d((0,1,0,1)), the time_conv channel->time interleave
+// (:186-189), RMS_norm + SiLU (:97-103, :246), the softmax of AttentionBlock (:303-308) and
+// _vae_float_to_cpu_uint8 (:18-20).
+//
+// Convolution = implicit GEMM on v_mfma_f32_16x16x32_f16 with the tile/LDS/epilogue structure of
+// gemm_bf16.hip: Out[pixel][cout] = sum_k A[pixel][k] * Wp[cout][k], K enumerated in UNITS of 32
+// input channels, unit u = tap * (Cin/32) + channel_block, tap = (kt*KH + kh)*KW + kw; a K-step
+// (64) is two units.  The A operand is never materialised: every 16-byte LDS-DMA piece (8
+// channels of one input pixel of one tap) is fetched straight from the channels-last activation
+// tensor [T,H,W,C]; out-of-range taps (spatial zero padding, the causal front before the first
+// frame) fetch from a 16-byte zero page, frames t < 0 come from the layer's 2-frame cache.
+// Activations are [T, H, W, C] fp16 with C % 32 == 0 (3- and 16-channel tensors are zero padded
+// to 32 channels by the layout kernels / weight packer).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 mfma_f16x8v;
+
+#define CBM 128
+#define CBN 128
+#define CSTAGE (CBM * 64 * 2)
+
+__device__ __forceinline__ void glds16v(const void* gsrc, void* ldst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+struct ConvP {
+  const uint16_t* x;
+  const uint16_t* cache;
+  const uint16_t* zero16;
+  const uint16_t* w;
+  const uint16_t* bias;
+  const uint16_t* res;
+  uint16_t* out;
+  float* out_f32;
+  int Tin, Hin, Win, Cin;
+  int Tout, Hout, Wout, Cout;
+  int KT, KH, KW;
+  int st_t, st_s, front, pad_s, ups;
+  int CB, U, nk, ncache, interleave;
+  int64_t M;
+  int tiles_y, tiles_x;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * CSTAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave >> 1, wx = wave & 1;
+
+  const int nwg = p.tiles_y * p.tiles_x;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  // x tiles (cout) fastest: the few cout tiles of one pixel tile run together and share the gathered pixels in L2
+  const int ty = wg / p.tiles_x, tx = wg - ty * p.tiles_x;
+  const int64_t y0 = (int64_t)ty * CBM;
+  const int x0 = tx * CBN;
+
+  const int HWo = p.Hout * p.Wout;
+  const int64_t frame_in = (int64_t)p.Hin * p.Win * p.Cin;
+  const int Heff = p.ups ? p.Hin * 2 : p.Hin, Weff = p.ups ? p.Win * 2 : p.Win;
+  const int Kp = p.nk * 64;
+
+  // per-slot constants
+  int s_to[4], s_ho[4], s_wo[4], s_usel[4], s_coff[4];
+  const uint16_t* xsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + tid;
+    const int row = q >> 3, pch = q & 7;
+    const int lch = pch ^ ((row >> 1) & 7);
+    int64_t pp = y0 + row;
+    if (pp > p.M - 1) pp = p.M - 1;
+    const int to = (int)(pp / HWo);
+    const int rem = (int)(pp - (int64_t)to * HWo);
+    s_to[i] = to;
+    s_ho[i] = rem / p.Wout;
+    s_wo[i] = rem - s_ho[i] * p.Wout;
+    s_usel[i] = lch >> 2;
+    s_coff[i] = (lch & 3) * 8;
+    const int slab = row >> 6, jj = row & 63;
+    const int nt = jj >> 4, ii = jj & 15;
+    int xr = x0 + slab * 64 + (ii >> 2) * 16 + nt * 4 + (ii & 3);
+    if (xr > p.Cout - 1) xr = p.Cout - 1;
+    xsrc[i] = p.w + (int64_t)xr * Kp + lch * 8;
+  }
+
+  auto stage = [&](int s, int ks) {
+    char* ybase = smem + s * 2 * CSTAGE;
+    char* xbase = ybase + CSTAGE;
+    // decode the two units of this K-step (wave-uniform scalars)
+    int ukt[2], ukh[2], ukw[2], ucb[2], uok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int u = 2 * ks + j;
+      uok[j] = u < p.U;
+      const int uu = uok[j] ? u : 0;
+      const int tap = uu / p.CB;
+      ucb[j] = uu - tap * p.CB;
+      ukw[j] = tap % p.KW;
+      const int t2 = tap / p.KW;
+      ukh[j] = t2 % p.KH;
+      ukt[j] = t2 / p.KH;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int woff = (i * 256 + wave * 64) * 16;
+      const int j = s_usel[i];
+      const int kt = j ? ukt[1] : ukt[0], kh = j ? ukh[1] : ukh[0], kw = j ? ukw[1] : ukw[0];
+      const int cb = j ? ucb[1] : ucb[0];
+      const bool ok_u = j ? uok[1] : uok[0];
+      const int ti = s_to[i] * p.st_t + kt - p.front;
+      int hi = s_ho[i] * p.st_s + kh - p.pad_s;
+      int wi = s_wo[i] * p.st_s + kw - p.pad_s;
+      const bool ok = ok_u && hi >= 0 && hi < Heff && wi >= 0 && wi < Weff && ti >= -p.ncache && ti < p.Tin;
+      if (p.ups) { hi >>= 1; wi >>= 1; }
+      const uint16_t* fb = (ti >= 0) ? p.x + (int64_t)ti * frame_in : p.cache + (int64_t)(2 + ti) * frame_in;
+      const uint16_t* src = ok ? fb + ((int64_t)hi * p.Win + wi) * p.Cin + cb * 32 + s_coff[i] : p.zero16;
+      glds16v(src, ybase + woff);
+      glds16v(xsrc[i] + ks * 64, xbase + woff);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fch = lane >> 4;
+  int yoff[4], xoff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ry = wy * 64 + t * 16 + frow;
+    yoff[t] = ry * 128 + ((fch ^ ((ry >> 1) & 7)) << 4);
+    const int rx = wx * 64 + t * 16 + frow;
+    xoff[t] = rx * 128 + ((fch ^ ((rx >> 1) & 7)) << 4);
+  }
+
+  stage(0, 0);
+  for (int kt = 0; kt < p.nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < p.nk) stage((kt + 1) & 1, kt + 1);
+    const char* ybase = smem + (kt & 1) * 2 * CSTAGE;
+    const char* xbase = ybase + CSTAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      mfma_f16x8v yf[4], xf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        yf[t] = *reinterpret_cast<const mfma_f16x8v*>(ybase + (yoff[t] ^ (ks << 6)));
+        xf[t] = *reinterpret_cast<const mfma_f16x8v*>(xbase + (xoff[t] ^ (ks << 6)));
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[b], yf[a], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------
+  const int xb = x0 + wx * 64 + (lane >> 4) * 16;
+  float bcol[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bcol[j] = 0.f;
+  const bool full = xb + 16 <= p.Cout;
+  if (p.bias != nullptr) {
+    if (full) {
+      unpack8t<true>(*reinterpret_cast<const uint4*>(p.bias + xb), bcol);
+      unpack8t<true>(*reinterpret_cast<const uint4*>(p.bias + xb + 8), bcol + 8);
+    } else {
+      for (int j = 0; j < 16; ++j)
+        if (xb + j < p.Cout) bcol[j] = h2f(p.bias[xb + j]);
+    }
+  }
+  const int C2 = p.Cout >> 1;
+#pragma unroll
+  for (int yt = 0; yt < 4; ++yt) {
+    const int64_t pp = y0 + wy * 64 + yt * 16 + (lane & 15);
+    if (pp >= p.M) continue;
+    float v[16];
+#pragma unroll
+    for (int xt = 0; xt < 4; ++xt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[xt * 4 + r] = acc[yt][xt][r] + bcol[xt * 4 + r];
+    if (full) {
+      int64_t oidx;
+      if (p.interleave) {
+        // time_conv output [T,H,W,2*C2] -> [2T,H,W,C2]: channel half s goes to frame 2t+s (vae.py:186-189)
+        const int to = (int)(pp / HWo);
+        const int rem = (int)(pp - (int64_t)to * HWo);
+        const int s = xb >= C2;
+        oidx = ((int64_t)(2 * to + s) * HWo + rem) * C2 + (xb - s * C2);
+      } else {
+        oidx = pp * p.Cout + xb;
+      }
+      if (p.res != nullptr) {
+        float rv[16];
+        unpack8t<true>(*reinterpret_cast<const uint4*>(p.res + oidx), rv);
+        unpack8t<true>(*reinterpret_cast<const uint4*>(p.res + oidx + 8), rv + 8);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = rnd16<true>(v[j]) + rv[j];  // conv output is fp16, then x + h
+      }
+      if (p.out_f32 != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) p.out_f32[oidx + j] = v[j];
+      } else {
+        *reinterpret_cast<uint4*>(p.out + oidx) = pack8t<true>(v);
+        *reinterpret_cast<uint4*>(p.out + oidx + 8) = pack8t<true>(v + 8);
+      }
+    } else {
+      for (int j = 0; j < 16; ++j) {
+        if (xb + j < p.Cout) {
+          const int64_t oidx = pp * p.Cout + xb + j;
+          float o = v[j];
+          if (p.res != nullptr) o = rnd16<true>(o) + h2f(p.res[oidx]);
+          if (p.out_f32 != nullptr) p.out_f32[oidx] = o;
+          else p.out[oidx] = f2h(o);
+        }
+      }
+    }
+  }
+}
+
+static uint16_t* g_zero_page = nullptr;
+static int ensure_zero_page(hipStream_t st) {
+  if (g_zero_page) return 0;
+  WAN_CHECK_HIP(hipMalloc((void**)&g_zero_page, 256));
+  WAN_CHECK_HIP(hipMemsetAsync(g_zero_page, 0, 256, st));
+  return 0;
+}
+
+extern "C" int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const uint16_t* w, const uint16_t* bias,
+                              const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int Hin, int Win, int Cin,
+                              int Tout, int Hout, int Wout, int Cout, int KT, int KH, int KW, int st_t, int st_s,
+                              int front, int pad_s, int ups, int interleave, void* stream) {
+  WAN_REQUIRE(x && w && (out || out_f32), "wan_vae_conv3d: null pointer");
+  WAN_REQUIRE(Cin % 32 == 0, "wan_vae_conv3d: Cin=%d must be a multiple of 32 (pad the activation/weights)", Cin);
+  WAN_REQUIRE(!interleave || (Cout % 32 == 0 && res == nullptr && out_f32 == nullptr), "wan_vae_conv3d: bad interleave use");
+  WAN_REQUIRE(front <= 2 && front >= 0, "wan_vae_conv3d: front must be 0..2");
+  hipStream_t st = as_stream(stream);
+  if (int rc = ensure_zero_page(st)) return rc;
+  ConvP p;
+  p.x = x; p.cache = cache ? cache : x; p.zero16 = g_zero_page; p.w = w; p.bias = bias; p.res = res; p.out = out;
+  p.out_f32 = out_f32;
+  p.Tin = Tin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Tout = Tout; p.Hout = Hout; p.Wout = Wout; p.Cout = Cout;
+  p.KT = KT; p.KH = KH; p.KW = KW; p.st_t = st_t; p.st_s = st_s; p.front = front; p.pad_s = pad_s; p.ups = ups;
+  p.CB = Cin / 32;
+  p.U = KT * KH * KW * p.CB;
+  p.nk = (p.U + 1) / 2;
+  p.ncache = cache ? 2 : 0;
+  p.interleave = interleave;
+  p.M = (int64_t)Tout * Hout * Wout;
+  if (p.M == 0) return 0;
+  p.tiles_y = (int)((p.M + CBM - 1) / CBM);
+  p.tiles_x = (Cout + CBN - 1) / CBN;
+  hipLaunchKernelGGL(conv3d_f16_kernel, dim3((unsigned)(p.tiles_y * p.tiles_x)), dim3(256), 0, st, p);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- RMS_norm (+ optional SiLU), channels-last: one thread per pixel, two passes over its C channels ----
+__global__ __launch_bounds__(256) void vae_rmsnorm_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ out,
+                                                          const uint16_t* __restrict__ gamma, int64_t npix, int C,
+                                                          int silu) {
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const uint16_t* xp = x + pix * C;
+  uint16_t* op = out + pix * C;
+  float ss = 0.f;
+  for (int c = 0; c < C; c += 8) {
+    float v[8];
+    unpack8t<true>(*reinterpret_cast<const uint4*>(xp + c), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+  }
+  // F.normalize: x / max(||x||, eps), eps = 1e-12; then * sqrt(C) * gamma
+  const float inv = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+  for (int c = 0; c < C; c += 8) {
+    float v[8], g[8];
+    unpack8t<true>(*reinterpret_cast<const uint4*>(xp + c), v);
+    unpack8t<true>(*reinterpret_cast<const uint4*>(gamma + c), g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = v[j] * inv * g[j];
+      if (silu) {
+        y = rnd16<true>(y);  // RMS_norm returns an fp16 tensor, SiLU then acts on it
+        y = y / (1.0f + __expf(-y));
+      }
+      v[j] = y;
+    }
+    *reinterpret_cast<uint4*>(op + c) = pack8t<true>(v);
+  }
+}
+
+extern "C" int wan_vae_rmsnorm_silu(const uint16_t* x, uint16_t* out, const uint16_t* gamma, int64_t npix, int C,
+                                    int silu, void* stream) {
+  WAN_REQUIRE(x && out && gamma && C % 8 == 0, "wan_vae_rmsnorm_silu: bad args");
+  if (npix == 0) return 0;
+  hipLaunchKernelGGL(vae_rmsnorm_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, as_stream(stream), x, out,
+                     gamma, npix, C, silu);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- row softmax for the VAE attention block: P[r, :L] = softmax(S[r, :L]), P[r, L:ld] = 0 -------------
+__global__ __launch_bounds__(256) void vae_softmax_kernel(const uint16_t* __restrict__ S, uint16_t* __restrict__ P,
+                                                          int L, int64_t ld) {
+  __shared__ float red[8];
+  const uint16_t* s = S + (int64_t)blockIdx.x * ld;
+  uint16_t* o = P + (int64_t)blockIdx.x * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < L; i += 256) m = fmaxf(m, h2f(s[i]));
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < L; i += 256) sum += __expf(h2f(s[i]) - m);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int i = threadIdx.x; i < ld; i += 256) o[i] = (i < L) ? f2h(__expf(h2f(s[i]) - m) * inv) : (uint16_t)0;
+}
+
+extern "C" int wan_vae_softmax(const uint16_t* S, uint16_t* P, int64_t rows, int L, int64_t ld, void* stream) {
+  WAN_REQUIRE(S && P && ld >= L, "wan_vae_softmax: bad args");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(vae_softmax_kernel, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), S, P, L, ld);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- layout / dtype edges ------------------------------------------------------------------------------
+// fp32 [C, T, H, W] -> fp16 channels-last [T, H, W, Cp] (channels >= C zero); optional per-channel affine
+// v = v * mul[c] + add[c]  (decode: z / scale[1] + scale[0], vae.py:631-635)
+__global__ void vae_pack_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, const float* __restrict__ mul,
+                                const float* __restrict__ add, int C, int Cp, int64_t thw) {
+  const int64_t total = thw * Cp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = i / Cp;
+    const int c = (int)(i - pix * Cp);
+    float v = 0.f;
+    if (c < C) {
+      v = in[(int64_t)c * thw + pix];
+      if (mul) v = v * mul[c] + add[c];
+    }
+    out[i] = f2h(v);
+  }
+}
+extern "C" int wan_vae_pack(const float* in, uint16_t* out, const float* mul, const float* add, int C, int Cp,
+                            int64_t thw, void* stream) {
+  WAN_REQUIRE(in && out && Cp >= C && (mul == nullptr) == (add == nullptr), "wan_vae_pack: bad args");
+  int blocks = (int)((thw * Cp + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(vae_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), in, out, mul, add, C, Cp, thw);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// fp16 channels-last [thw, Cs] (first C channels) -> fp32 [C, thw] with v = (v - sub[c]) * mul[c] (encode: mu
+// normalisation, vae.py:618-624) when sub != null
+__global__ void vae_unpack_kernel(const uint16_t* __restrict__ in, float* __restrict__ out, const float* __restrict__ sub,
+                                  const float* __restrict__ mul, int C, int Cs, int64_t thw) {
+  const int64_t total = thw * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / thw);
+    const int64_t pix = i - (int64_t)c * thw;
+    float v = h2f(in[pix * Cs + c]);
+    if (sub) v = (v - sub[c]) * mul[c];
+    out[i] = v;
+  }
+}
+extern "C" int wan_vae_unpack(const uint16_t* in, float* out, const float* sub, const float* mul, int C, int Cs,
+                              int64_t thw, void* stream) {
+  WAN_REQUIRE(in && out && Cs >= C, "wan_vae_unpack: bad args");
+  int blocks = (int)((thw * C + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(vae_unpack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), in, out, sub, mul, C, Cs, thw);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// decoder head output fp32 channels-last [T*H*W, 3] -> uint8 [3, Ttot, H, W] at frame offset t0
+// (clamp(-1,1) -> +1 -> *127.5 -> round-half-even -> clamp(0,255), vae.py:18-20), and/or fp32 [3,Ttot,H,W]
+__global__ void vae_to_video_kernel(const float* __restrict__ in, uint8_t* __restrict__ u8, float* __restrict__ f32,
+                                    int T, int64_t hw, int Ttot, int t0) {
+  const int64_t total = (int64_t)T * hw * 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / ((int64_t)T * hw));
+    const int64_t r = i - (int64_t)c * T * hw;
+    const int t = (int)(r / hw);
+    const int64_t px = r - (int64_t)t * hw;
+    const float v = in[((int64_t)t * hw + px) * 3 + c];
+    const int64_t o = ((int64_t)c * Ttot + t0 + t) * hw + px;
+    if (f32) f32[o] = v;
+    if (u8) {
+      float q = fminf(fmaxf(v, -1.0f), 1.0f);
+      q = (q + 1.0f) * 127.5f;
+      q = rintf(q);  // round half to even, like torch.round_
+      u8[o] = (uint8_t)fminf(fmaxf(q, 0.0f), 255.0f);
+    }
+  }
+}
+extern "C" int wan_vae_to_video(const float* in, uint8_t* u8, float* f32, int T, int64_t hw, int Ttot, int t0,
+                                void* stream) {
+  WAN_REQUIRE(in && (u8 || f32), "wan_vae_to_video: bad args");
+  int blocks = (int)(((int64_t)T * hw * 3 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(vae_to_video_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), in, u8, f32, T, hw, Ttot, t0);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}

@@ -64,6 +64,14 @@ SIGNATURES = {
     "wan_gemv_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wan_lincomb": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_float), c_int64, c_void_p]),
     "wan_cfg_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "wan_vae_conv3d": (c_int, [c_void_p] * 7 + [c_int] * 17 + [c_void_p]),
+    "wan_vae_rmsnorm_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "wan_gemm_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                             c_int, c_float, c_int, c_void_p]),
+    "wan_vae_softmax": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "wan_vae_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "wan_vae_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "wan_vae_to_video": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "wan_prof_enable": (c_int, [c_int]),
     "wan_prof_collect": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "wan_dit_create": (c_int, [POINTER(DitConfig), POINTER(c_void_p)]),

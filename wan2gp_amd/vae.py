@@ -1,0 +1,333 @@
+"""WanVAEHIP -- drop-in for the reference `WanVAE` (models/wan/modules/vae.py:935-1027).
+
+Same public surface: `encode(videos, tile_size, any_end_frame)`, `decode(zs, tile_size)`,
+`decode_to_cpu_uint8(zs, tile_size, ...)`, `.model.z_dim`, `.device`, `.dtype`, `.scale`,
+`get_VAE_tile_size`; lists in, lists out; latents normalised with the mean/std constants of
+vae.py:948-958.  The layer graph and the causal feature-cache bookkeeping of Encoder3d /
+Decoder3d / WanVAE_.encode / .decode (vae.py:318-662) run here on the host; every tensor op is a
+libwanhip kernel on fp16 channels-last activations [T,H,W,C] (vae_ops.hip): implicit-GEMM MFMA
+convolutions with the 2-frame cache, fused nearest-2x upsample, fused time interleave, fused
+residual add, RMS_norm+SiLU, the attention block as fp16 GEMMs + a row softmax, and the
+float->uint8 conversion.  Spatial tiling (tile_size > 0) exists in the reference only to fit
+small VRAM; with 288 GB of HBM the full frame is always decoded in one piece (the tile_size == 0
+path of vae.py:762-767), so tile_size is accepted and ignored.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import lib as _L
+from .lib import check, ptr, stream_ptr
+
+MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+        0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+       3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+F16 = torch.float16
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+class _Conv:
+    """A packed convolution: weights [Cout_p][Kp] fp16 with K = ((kt*KH+kh)*KW+kw)*Cin_p + c."""
+
+    def __init__(self, w, b, dev, cout_pad=None):
+        if w.dim() == 4:                       # Conv2d -> KT = 1
+            w = w.unsqueeze(2)
+        cout, cin, kt, kh, kw = w.shape
+        cin_p = _pad32(cin)
+        cout_p = cout_pad or cout
+        wp = torch.zeros(cout_p, kt, kh, kw, cin_p, dtype=torch.float32)
+        wp[:cout, ..., :cin] = w.detach().float().permute(0, 2, 3, 4, 1)
+        K = kt * kh * kw * cin_p
+        Kp = (K + 63) // 64 * 64
+        flat = torch.zeros(cout_p, Kp, dtype=torch.float32)
+        flat[:, :K] = wp.reshape(cout_p, K)
+        bb = torch.zeros(cout_p, dtype=torch.float32)
+        if b is not None:
+            bb[:cout] = b.detach().float()
+        self.w = flat.to(device=dev, dtype=F16).contiguous()
+        self.b = bb.to(device=dev, dtype=F16).contiguous()
+        self.cin, self.cout, self.k = cin_p, cout_p, (kt, kh, kw)
+
+
+class _VaeNet:
+    """Holds packed weights + the op helpers; one instance per WanVAEHIP."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], dev):
+        self.dev = dev
+        self.lib = _L.load()
+        self.convs: Dict[str, _Conv] = {}
+        self.gamma: Dict[str, torch.Tensor] = {}
+        for k, v in sd.items():
+            if k.endswith(".weight") and v.dim() in (4, 5):
+                name = k[: -len(".weight")]
+                pad = 32 if name == "conv2" else None          # latent 16 -> 32 channels for decoder.conv1
+                self.convs[name] = _Conv(v, sd.get(name + ".bias"), dev, cout_pad=pad)
+            elif k.endswith("gamma"):
+                self.gamma[k] = v.detach().reshape(-1).to(device=dev, dtype=F16).contiguous()
+        # attention blocks: keep the raw [3C, C] / [C, C] matrices for the GEMM path
+        self.attn = {}
+        for side in ("encoder.middle.1.", "decoder.middle.1."):
+            if side + "to_qkv.weight" in sd:
+                C = sd[side + "proj.weight"].shape[0]
+                self.attn[side] = dict(
+                    C=C,
+                    wqkv=sd[side + "to_qkv.weight"].detach().reshape(3 * C, C).to(device=dev, dtype=F16).contiguous(),
+                    bqkv=sd[side + "to_qkv.bias"].detach().to(device=dev, dtype=F16).contiguous())
+
+    # ---- ops ---------------------------------------------------------------------------------------
+    def conv(self, x, name, cache=None, res=None, out_f32=False, ups=False, interleave=False, st_t=1, st_s=1,
+             front=None, pad_s=None):
+        c = self.convs[name]
+        T, H, W, C = x.shape
+        assert C == c.cin, (name, C, c.cin)
+        kt, kh, kw = c.k
+        if front is None:
+            front = kt - 1                                   # causal: 2*padding[0] frames in front (vae.py:49-51)
+        if pad_s is None:
+            pad_s = kh // 2
+        Hin_eff, Win_eff = (2 * H, 2 * W) if ups else (H, W)
+        if st_s == 2:                                        # ZeroPad2d((0,1,0,1)) + stride 2 (vae.py:137-139)
+            Ho, Wo = (Hin_eff + 1 - kh) // 2 + 1, (Win_eff + 1 - kw) // 2 + 1
+        else:
+            Ho, Wo = Hin_eff, Win_eff
+        To = (T + front - kt) // st_t + 1
+        cout = c.cout
+        if interleave:
+            out = torch.empty(2 * To, Ho, Wo, cout // 2, dtype=F16, device=self.dev)
+        elif out_f32:
+            out = torch.empty(To, Ho, Wo, cout, dtype=torch.float32, device=self.dev)
+        else:
+            out = torch.empty(To, Ho, Wo, cout, dtype=F16, device=self.dev)
+        check(self.lib.wan_vae_conv3d(ptr(x), ptr(cache), ptr(c.w), ptr(c.b), ptr(res), None if out_f32 else ptr(out),
+                                      ptr(out) if out_f32 else None, T, H, W, C, To, Ho, Wo, cout, kt, kh, kw, st_t, st_s,
+                                      front, pad_s, 1 if ups else 0, 1 if interleave else 0, stream_ptr()),
+              f"wan_vae_conv3d({name})")
+        return out
+
+    def norm(self, x, gname, silu=True):
+        out = torch.empty_like(x)
+        C = x.shape[-1]
+        check(self.lib.wan_vae_rmsnorm_silu(ptr(x), ptr(out), ptr(self.gamma[gname]), x.numel() // C, C, 1 if silu else 0,
+                                            stream_ptr()), "wan_vae_rmsnorm_silu")
+        return out
+
+    def attention_block(self, x, p):
+        """AttentionBlock.forward (vae.py:294-315) per frame: tokens = h*w, one head of C channels."""
+        a = self.attn[p]
+        C = a["C"]
+        T, H, W, _ = x.shape
+        L = H * W
+        Lp = (L + 63) // 64 * 64
+        xn = self.norm(x, p + "norm.gamma", silu=False)
+        out = torch.empty_like(x)
+        lib = self.lib
+        if L % 16 != 0:
+            raise _L.WanHipError("VAE attention needs h*w % 16 == 0 at the lowest resolution")
+        scale = 1.0 / math.sqrt(C)
+        wv, bv = a["wqkv"][2 * C:], a["bqkv"][2 * C:]
+        for t in range(T):
+            xt = xn[t].reshape(L, C)
+            qk = torch.empty(L, 2 * C, dtype=F16, device=self.dev)               # [q | k] = x Wqk^T + b
+            check(lib.wan_gemm_f16(ptr(xt), C, ptr(a["wqkv"]), C, ptr(a["bqkv"]), ptr(qk), 2 * C, L, 2 * C, C, 1.0, 0,
+                                   stream_ptr()), "vae qk")
+            vt = torch.zeros(C, Lp, dtype=F16, device=self.dev)                   # V^T, zero padded columns
+            check(lib.wan_gemm_f16(ptr(xt), C, ptr(wv), C, ptr(bv), ptr(vt), Lp, L, C, C, 1.0, 1, stream_ptr()), "vae v^T")
+            S = torch.empty(L, Lp, dtype=F16, device=self.dev)                    # q k^T / sqrt(C)
+            check(lib.wan_gemm_f16(ptr(qk), 2 * C, ptr(qk[:, C:]), 2 * C, None, ptr(S), Lp, L, L, C, scale, 0,
+                                   stream_ptr()), "vae qk^T")
+            check(lib.wan_vae_softmax(ptr(S), ptr(S), L, L, Lp, stream_ptr()), "vae softmax")
+            o = torch.empty(L, C, dtype=F16, device=self.dev)
+            check(lib.wan_gemm_f16(ptr(S), Lp, ptr(vt), Lp, None, ptr(o), C, L, C, Lp, 1.0, 0, stream_ptr()), "vae pv")
+            out[t] = self.conv(o.view(1, H, W, C), p + "proj", res=x[t:t + 1].contiguous())[0]
+        return out
+
+
+def _cache_update(x, old):
+    """cache_x bookkeeping (vae.py:256-263): last 2 frames of [old ; x]."""
+    if x.shape[0] >= 2:
+        return x[-2:].clone()
+    if old is None:
+        return torch.cat([torch.zeros_like(x[-1:]), x[-1:]], 0)
+    return torch.cat([old[-1:], x[-1:]], 0)
+
+
+class WanVAEHIP:
+    CFG = dict(dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, temperal_downsample=[False, True, True])
+
+    def __init__(self, z_dim=16, vae_pth=None, dtype=torch.float16, device="cuda", state_dict=None, **unused):
+        self.dtype, self.device, self.z_dim = dtype, torch.device(device), z_dim
+        self.mean = torch.tensor(MEAN, dtype=torch.float32, device=self.device)
+        self.std = torch.tensor(STD, dtype=torch.float32, device=self.device)
+        self.scale = [self.mean, 1.0 / self.std]
+        self.model = self                                  # reference code reads vae.model.z_dim
+        self.upsampler_factor = 1
+        self.net = None
+        if state_dict is not None:
+            self.load_state_dict(state_dict)
+        elif vae_pth is not None:
+            from safetensors.torch import load_file
+            self.load_state_dict(load_file(vae_pth))
+
+    def load_state_dict(self, sd):
+        self.net = _VaeNet(sd, self.device)
+        return self
+
+    @staticmethod
+    def get_VAE_tile_size(vae_config, device_mem_capacity, mixed_precision, output_height=None, output_width=None):
+        return 0                                           # 288 GB: never tile (vae.py:970-1001 picks 0 for >= 24 GB)
+
+    # ---- layer graph (vae.py:338-369, 449-484) -------------------------------------------------------
+    def _res(self, x, p, cache, idx):
+        n = self.net
+        h = n.conv(x, p + "shortcut") if (p + "shortcut") in n.convs else x
+        y = x
+        for gi, ci in (("0", "2"), ("3", "6")):
+            y = n.norm(y, p + f"residual.{gi}.gamma")
+            cx = _cache_update(y, cache[idx[0]])
+            last = ci == "6"
+            y = n.conv(y, p + f"residual.{ci}", cache=cache[idx[0]], res=h if last else None)
+            cache[idx[0]] = cx
+            idx[0] += 1
+        return y
+
+    def _cached_conv(self, x, name, cache, idx, **kw):
+        cx = _cache_update(x, cache[idx[0]])
+        y = self.net.conv(x, name, cache=cache[idx[0]], **kw)
+        cache[idx[0]] = cx
+        idx[0] += 1
+        return y
+
+    def _decoder(self, x, cache, idx):
+        """Decoder3d.forward (vae.py:486-538) on one latent frame [1,h,w,32]."""
+        n = self.net
+        x = self._cached_conv(x, "decoder.conv1", cache, idx)
+        x = self._res(x, "decoder.middle.0.", cache, idx)
+        x = n.attention_block(x, "decoder.middle.1.")
+        x = self._res(x, "decoder.middle.2.", cache, idx)
+        li = 0
+        tus = self.CFG["temperal_downsample"][::-1]
+        for i in range(4):
+            for _ in range(3):
+                x = self._res(x, f"decoder.upsamples.{li}.", cache, idx); li += 1
+            if i != 3:
+                p = f"decoder.upsamples.{li}."
+                if tus[i]:                                   # upsample3d (vae.py:151-189)
+                    j = idx[0]
+                    if cache[j] is None:
+                        cache[j] = "Rep"
+                    else:
+                        prev = None if isinstance(cache[j], str) else cache[j]
+                        cx = _cache_update(x, prev)
+                        x = n.conv(x, p + "time_conv", cache=prev, interleave=True, pad_s=0)
+                        cache[j] = cx
+                    idx[0] += 1
+                x = n.conv(x, p + "resample.1", ups=True)    # nearest-exact 2x + Conv2d 3x3 (vae.py:126-128)
+                li += 1
+        x = n.norm(x, "decoder.head.0.gamma")
+        return self._cached_conv(x, "decoder.head.2", cache, idx, out_f32=True)
+
+    def _encoder(self, x, cache, idx):
+        """Encoder3d.forward (vae.py:371-428) on a chunk [t,H,W,32]."""
+        n = self.net
+        x = self._cached_conv(x, "encoder.conv1", cache, idx)
+        li = 0
+        tds = self.CFG["temperal_downsample"]
+        for i in range(4):
+            for _ in range(2):
+                x = self._res(x, f"encoder.downsamples.{li}.", cache, idx); li += 1
+            if i != 3:
+                p = f"encoder.downsamples.{li}."
+                x = n.conv(x, p + "resample.1", st_s=2, pad_s=0)          # ZeroPad2d((0,1,0,1)) + stride 2
+                if tds[i]:                                   # downsample3d (vae.py:195-211)
+                    j = idx[0]
+                    if cache[j] is None:
+                        cache[j] = x[-1:].clone()
+                    else:
+                        cx = x[-1:].clone()
+                        prev2 = torch.cat([torch.zeros_like(cache[j]), cache[j]], 0)   # kernel reads cache[1] = last frame
+                        x = n.conv(x, p + "time_conv", cache=prev2, st_t=2, front=1, pad_s=0)
+                        cache[j] = cx
+                    idx[0] += 1
+                li += 1
+        x = self._res(x, "encoder.middle.0.", cache, idx)
+        x = n.attention_block(x, "encoder.middle.1.")
+        x = self._res(x, "encoder.middle.2.", cache, idx)
+        x = n.norm(x, "encoder.head.0.gamma")
+        return self._cached_conv(x, "encoder.head.2", cache, idx)
+
+    def _n_cached(self, side):
+        return sum(1 for k, c in self.net.convs.items() if k.startswith(side) and (c.k[0] == 3))
+
+    # ---- WanVAE_.decode (vae.py:628-662) ----------------------------------------------------------------
+    def _decode_frames(self, z, want_u8, want_f32):
+        lib = self.net.lib
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()          # [16, t, h, w]
+        C, t, h, w = z.shape
+        zp = torch.empty(t, h, w, 32, dtype=F16, device=self.device)
+        inv_std = (1.0 / self.scale[1]).contiguous()                             # z / scale[1] + scale[0]
+        check(lib.wan_vae_pack(ptr(z), ptr(zp), ptr(inv_std), ptr(self.scale[0].contiguous()), C, 32, t * h * w,
+                               stream_ptr()), "wan_vae_pack")
+        x = self.net.conv(zp, "conv2")                                           # 1x1x1, 16 -> 16 (padded to 32)
+        T_out = (t - 1) * 4 + 1
+        H, W = h * 8, w * 8
+        u8 = torch.empty(3, T_out, H, W, dtype=torch.uint8, device=self.device) if want_u8 else None
+        f32 = torch.empty(3, T_out, H, W, dtype=torch.float32, device=self.device) if want_f32 else None
+        cache = [None] * self._n_cached("decoder.")
+        t0 = 0
+        for i in range(t):
+            y = self._decoder(x[i:i + 1], cache, [0])                            # fp32 [T_i, H, W, 3]
+            Ti = y.shape[0]
+            check(lib.wan_vae_to_video(ptr(y), ptr(u8), ptr(f32), Ti, H * W, T_out, t0, stream_ptr()), "wan_vae_to_video")
+            t0 += Ti
+        assert t0 == T_out, (t0, T_out)
+        return u8, f32
+
+    def decode(self, zs, tile_size=0, any_end_frame=False):
+        if any_end_frame:
+            raise NotImplementedError("any_end_frame decode is outside the hot path")
+        return [self._decode_frames(u, False, True)[1].clamp_(-1, 1) for u in zs]
+
+    def decode_to_cpu_uint8(self, zs, tile_size=0, target_frames=None, target_height=None, target_width=None,
+                            any_end_frame=False, frame_start=0):
+        if any_end_frame:
+            raise NotImplementedError("any_end_frame decode is outside the hot path")
+        outs = []
+        for u in zs:
+            u8 = self._decode_frames(u, True, False)[0]
+            T = u8.shape[1]
+            fs = min(max(0, int(frame_start or 0)), T)
+            te = T if target_frames is None else min(T, fs + int(target_frames))
+            hh = u8.shape[2] if target_height is None else min(int(target_height), u8.shape[2])
+            ww = u8.shape[3] if target_width is None else min(int(target_width), u8.shape[3])
+            outs.append(u8[:, fs:te, :hh, :ww].to("cpu"))
+        return outs
+
+    # ---- WanVAE_.encode (vae.py:586-625) ------------------------------------------------------------------
+    def encode(self, videos, tile_size=0, any_end_frame=False):
+        if any_end_frame:
+            raise NotImplementedError("any_end_frame encode is outside the hot path")
+        lib = self.net.lib
+        outs = []
+        for v in videos:
+            v = v.to(device=self.device, dtype=torch.float32).contiguous()       # [3, T, H, W]
+            C, T, H, W = v.shape
+            vp = torch.empty(T, H, W, 32, dtype=F16, device=self.device)
+            check(lib.wan_vae_pack(ptr(v), ptr(vp), None, None, C, 32, T * H * W, stream_ptr()), "wan_vae_pack")
+            cache = [None] * self._n_cached("encoder.")
+            chunks = []
+            for i in range(1 + (T - 1) // 4):
+                xc = vp[:1] if i == 0 else vp[1 + 4 * (i - 1):1 + 4 * i]
+                chunks.append(self._encoder(xc, cache, [0]))
+            enc = torch.cat(chunks, 0)                                           # [t, h, w, 32]
+            mu = self.net.conv(enc, "conv1")                                     # 1x1x1 32 -> 32; mu = first 16
+            t, h, w, _ = mu.shape
+            out = torch.empty(16, t, h, w, dtype=torch.float32, device=self.device)
+            check(lib.wan_vae_unpack(ptr(mu), ptr(out), ptr(self.scale[0].contiguous()), ptr(self.scale[1].contiguous()),
+                                     16, 32, t * h * w, stream_ptr()), "wan_vae_unpack")
+            outs.append(out)
+        return outs
