@@ -39,10 +39,28 @@ class WanAny2VHIP:
             raise NotImplementedError(f"Unsupported Scheduler {sample_solver} (hot path implements unipc, euler)")
         return s, s.timesteps
 
+    def build_i2v_conditioning(self, image_start, frame_num, height, width, VAE_tile_size=0):
+        """y = cat(mask[4,f,h,w], vae.encode(start image + zero frames)[16,f,h,w]) (any2video.py:739-774) and the
+        clean first latent frame that is re-injected every step (:776-783)."""
+        dev = self.device
+        img = image_start.to(device=dev, dtype=torch.float32)
+        if img.dim() == 3:
+            img = img.unsqueeze(1)                                                     # [3,1,H,W]
+        lat_h, lat_w = height // self.vae_stride[1], width // self.vae_stride[2]
+        enc = torch.cat([img, torch.zeros(3, frame_num - 1, height, width, device=dev)], dim=1)   # :739
+        lat_y = self.vae.encode([enc], VAE_tile_size)[0]                                           # :743
+        msk = torch.ones(1, frame_num, lat_h, lat_w, device=dev)                                   # :746-757
+        msk[:, 1:] = 0
+        msk = torch.cat([torch.repeat_interleave(msk[:, 0:1], repeats=4, dim=1), msk[:, 1:]], dim=1)
+        msk = msk.view(1, msk.shape[1] // 4, 4, lat_h, lat_w).transpose(1, 2)[0]
+        y = torch.cat([msk, lat_y.to(msk.dtype)])                                                  # :774
+        return y, lat_y[:, :1].clone().unsqueeze(0)
+
     def generate(self, input_prompt=None, n_prompt="", context=None, context_null=None, width=1280, height=720,
                  frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
                  guide2_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
-                 joint_pass=True, y=None, latents=None, VAE_tile_size=0, return_latents=False, **bbargs):
+                 joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
+                 **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -61,6 +79,12 @@ class WanAny2VHIP:
             latents = torch.randn(batch_size, *target_shape, dtype=torch.float32, device=dev, generator=seed_g)  # :1470
         else:
             latents = latents.to(device=dev, dtype=torch.float32).clone()
+        # ---- image2video conditioning (any2video.py:651-785, plain i2v2_2: one start image) -----------
+        ext_latents = None
+        if image_start is not None:
+            if self.vae is None:
+                raise ValueError("image_start needs a VAE to encode the conditioning video")
+            y, ext_latents = self.build_i2v_conditioning(image_start, frame_num, height, width, VAE_tile_size)
         any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
         trans = self.model
         guidance_switch_done = False
@@ -73,6 +97,10 @@ class WanAny2VHIP:
                 guide_scale, guidance_switch_done = guide2_scale, True
             timestep = torch.stack([t])
             kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": i})
+            if ext_latents is not None:                      # any2video.py:1517-1523: re-noise the known first latent
+                f = float(t) / 1000.0
+                n = ext_latents.shape[2]
+                latents[:, :, :n] = ext_latents * (1.0 - f) + torch.randn_like(ext_latents) * f
             if guide_scale == 1 or not any_guidance:
                 ret = trans(x=[latents], context=[context], **kwargs)
                 if self._interrupt or ret[0] is None:
@@ -94,6 +122,8 @@ class WanAny2VHIP:
             latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
             if callback is not None:
                 callback(i, latents[0], False)
+        if ext_latents is not None:
+            latents[:, :, :ext_latents.shape[2]] = ext_latents                                     # :1755-1756
         if return_latents or self.vae is None:
             return {"x": None, "latents": latents, "latent_slice": None}
         x0 = latents.unbind(0)                                                                     # :1763

@@ -147,6 +147,80 @@ class _VaeNet:
         return out
 
 
+def vae_param_shapes(dim=96, z=16, mult=(1, 2, 4, 4), nres=2, tds=(False, True, True)):
+    """state_dict key -> shape of the Wan2.1 VAE (WanVAE_(dim=96, z_dim=16, ...), vae.py:906-918); used to
+    build random-init weights for benchmarking and to validate checkpoints."""
+    p = {}
+
+    def res(pre, cin, cout):
+        p[pre + "residual.0.gamma"] = (cin, 1, 1, 1)
+        p[pre + "residual.2.weight"] = (cout, cin, 3, 3, 3); p[pre + "residual.2.bias"] = (cout,)
+        p[pre + "residual.3.gamma"] = (cout, 1, 1, 1)
+        p[pre + "residual.6.weight"] = (cout, cout, 3, 3, 3); p[pre + "residual.6.bias"] = (cout,)
+        if cin != cout:
+            p[pre + "shortcut.weight"] = (cout, cin, 1, 1, 1); p[pre + "shortcut.bias"] = (cout,)
+
+    def attn(pre, c):
+        p[pre + "norm.gamma"] = (c, 1, 1)
+        p[pre + "to_qkv.weight"] = (3 * c, c, 1, 1); p[pre + "to_qkv.bias"] = (3 * c,)
+        p[pre + "proj.weight"] = (c, c, 1, 1); p[pre + "proj.bias"] = (c,)
+
+    dims = [dim * u for u in (1,) + tuple(mult)]
+    p["encoder.conv1.weight"] = (dims[0], 3, 3, 3, 3); p["encoder.conv1.bias"] = (dims[0],)
+    li = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        for _ in range(nres):
+            res(f"encoder.downsamples.{li}.", cin, cout); li += 1
+            cin = cout
+        if i != len(mult) - 1:
+            p[f"encoder.downsamples.{li}.resample.1.weight"] = (cout, cout, 3, 3); p[f"encoder.downsamples.{li}.resample.1.bias"] = (cout,)
+            if tds[i]:
+                p[f"encoder.downsamples.{li}.time_conv.weight"] = (cout, cout, 3, 1, 1); p[f"encoder.downsamples.{li}.time_conv.bias"] = (cout,)
+            li += 1
+    c = dims[-1]
+    res("encoder.middle.0.", c, c); attn("encoder.middle.1.", c); res("encoder.middle.2.", c, c)
+    p["encoder.head.0.gamma"] = (c, 1, 1, 1)
+    p["encoder.head.2.weight"] = (2 * z, c, 3, 3, 3); p["encoder.head.2.bias"] = (2 * z,)
+    p["conv1.weight"] = (2 * z, 2 * z, 1, 1, 1); p["conv1.bias"] = (2 * z,)
+    p["conv2.weight"] = (z, z, 1, 1, 1); p["conv2.bias"] = (z,)
+    dd = [dim * u for u in (mult[-1],) + tuple(mult[::-1])]
+    tus = tuple(tds[::-1])
+    p["decoder.conv1.weight"] = (dd[0], z, 3, 3, 3); p["decoder.conv1.bias"] = (dd[0],)
+    res("decoder.middle.0.", dd[0], dd[0]); attn("decoder.middle.1.", dd[0]); res("decoder.middle.2.", dd[0], dd[0])
+    li = 0
+    for i, (cin, cout) in enumerate(zip(dd[:-1], dd[1:])):
+        if i in (1, 2, 3):
+            cin //= 2
+        for _ in range(nres + 1):
+            res(f"decoder.upsamples.{li}.", cin, cout); li += 1
+            cin = cout
+        if i != len(mult) - 1:
+            p[f"decoder.upsamples.{li}.resample.1.weight"] = (cout // 2, cout, 3, 3); p[f"decoder.upsamples.{li}.resample.1.bias"] = (cout // 2,)
+            if tus[i]:
+                p[f"decoder.upsamples.{li}.time_conv.weight"] = (2 * cout, cout, 3, 1, 1); p[f"decoder.upsamples.{li}.time_conv.bias"] = (2 * cout,)
+            li += 1
+    p["decoder.head.0.gamma"] = (dd[-1], 1, 1, 1)
+    p["decoder.head.2.weight"] = (3, dd[-1], 3, 3, 3); p["decoder.head.2.bias"] = (3,)
+    return p
+
+
+def random_vae_state_dict(seed=0):
+    """Random-init VAE weights of the reference architecture (benchmarking without checkpoints)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in vae_param_shapes().items():
+        if k.endswith("gamma"):
+            sd[k] = 1.0 + 0.05 * torch.randn(shp, generator=g)
+        elif k.endswith("bias"):
+            sd[k] = 0.02 * torch.randn(shp, generator=g)
+        else:
+            fan = 1
+            for d in shp[1:]:
+                fan *= d
+            sd[k] = torch.randn(shp, generator=g) * (1.2 / fan ** 0.5)
+    return sd
+
+
 def _cache_update(x, old):
     """cache_x bookkeeping (vae.py:256-263): last 2 frames of [old ; x]."""
     if x.shape[0] >= 2:
