@@ -210,7 +210,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "attn_pmc_traffic.json")
         if os.path.isfile(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload)
+                traffic = json.load(open(pmc)).get(args.workload, {}).get("traffic_bytes")
             except Exception:
                 traffic = None
         out = {

@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""VAE decode/encode timing at full size (tuning tool)."""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=81); ap.add_argument("--h", type=int, default=720); ap.add_argument("--w", type=int, default=1280)
+ap.add_argument("--encode", action="store_true")
+a = ap.parse_args()
+vae = WanVAEHIP(state_dict=random_vae_state_dict())
+t = (a.frames - 1) // 4 + 1
+z = torch.randn(16, t, a.h // 8, a.w // 8, device="cuda")
+res = {}
+for it in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    u8 = vae.decode_to_cpu_uint8([z], 0)[0]
+    torch.cuda.synchronize(); res[f"decode_s_{it}"] = time.perf_counter() - t0
+res["out"] = list(u8.shape)
+if a.encode:
+    vid = torch.rand(3, a.frames, a.h, a.w, device="cuda") * 2 - 1
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mu = vae.encode([vid])[0]
+    torch.cuda.synchronize(); res["encode_s"] = time.perf_counter() - t0
+res["max_mem_GB"] = torch.cuda.max_memory_allocated() / 1e9
+print(json.dumps(res))

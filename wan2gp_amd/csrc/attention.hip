@@ -301,7 +301,7 @@ extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan
   // measured on MI355X (profiles/r01_attn_variants.md): 8 waves sharing each K/V tile win for long
   // KV (self-attention), 4-wave blocks win for short KV (cross-attention, Lk = 512)
   // (v2 = static-stage loop body of attention_pp.hip MODE 0)
-  int variant = (Lk * (int64_t)nseg > 2048) ? 8 : 7;
+  int variant = (Lk * (int64_t)nseg > 2048) ? 10 : 7;  // v2r_8 (row sums on the matrix pipe) : v2_4
   if (Lk * (int64_t)H * 256 >= ((int64_t)1 << 32) || ldv * 256 >= ((int64_t)1 << 32)) variant = 3;  // 64-bit addressing kernel
   {
     const char* ev = getenv("WAN_ATTN_VARIANT");
@@ -315,11 +315,34 @@ extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan
       else if (!strcmp(ev, "pp_prio")) variant = 6;
       else if (!strcmp(ev, "v2_4")) variant = 7;
       else if (!strcmp(ev, "v2_8")) variant = 8;
+      else if (!strcmp(ev, "v3_8")) variant = 9;
+      else if (!strcmp(ev, "v2r_8")) variant = 10;   // v2 + row sums on the matrix pipe
+      else if (!strcmp(ev, "v4_8")) variant = 11;    // software-pipelined tiles, VALU row sums
+      else if (!strcmp(ev, "v4r_8")) variant = 12;   // software-pipelined tiles, MFMA row sums
+      else if (!strcmp(ev, "v4_4")) variant = 13;
+      else if (!strcmp(ev, "v4r_4")) variant = 14;
+      else if (!strcmp(ev, "v4_8s3")) variant = 15;  // pipelined + 3-stage ring
+      else if (!strncmp(ev, "abl", 3)) variant = 100 + atoi(ev + 3);  // timing ablations: abl8 / abl16 / abl32 / abl24 / abl48 / abl56
     }
   }
-  if (variant >= 5)
-    return wan_attention_pp_launch(variant == 6 ? 1 : 0, variant <= 6 ? 1 : 0, variant == 7 ? 4 : 8, q, k, vt, o, B, Bk,
-                                   Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, scale_log2e, as_stream(stream));
+  if (variant >= 5) {
+    int fl = 0, md = 0, nwv = 8;
+    switch (variant) {
+      case 5: case 6: md = 1; fl = 2; break;
+      case 7: nwv = 4; break;
+      case 8: break;
+      case 9: md = 2; fl = 2; break;
+      case 10: fl = 2; break;
+      case 11: fl = 4; break;
+      case 12: fl = 6; break;
+      case 13: fl = 4; nwv = 4; break;
+      case 14: fl = 6; nwv = 4; break;
+      case 15: fl = 4 | 2; md = 2; break;
+      default: if (variant >= 100) fl = variant - 100; break;
+    }
+    return wan_attention_pp_launch(fl, md, nwv, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride,
+                                   scale_log2e, as_stream(stream));
+  }
   const int nw = (variant >= 3) ? 8 : 4;
   const int64_t nqb = (Lq + nw * 32 - 1) / (nw * 32);
   const int64_t total = nqb * H * B;

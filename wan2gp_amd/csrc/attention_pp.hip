@@ -35,35 +35,68 @@ __device__ __forceinline__ void glds16p(const void* gsrc, void* ldst) {
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
 
+typedef __attribute__((address_space(3))) const char lds_cchar;
+typedef __attribute__((address_space(3))) const mfma_bf16x8 lds_frag;
+
 struct PPState {
   f32x16 accO[4];
+  f32x16 accL;  // row sums of P on the matrix pipe: accL = ones(32 x kv) * P^T, every row = l[q] (only [0] is read)
   uint32_t pk[2][8];
-  float m_run, l_run;
+  float m_run;
+  float l_run;  // per-lane partial row sum (used when the row sums are NOT taken on the matrix pipe)
 };
 
 // S^T = K Q^T for one 64-kv tile held in LDS stage ST, then the online-softmax update of `st`
-template <int ST, bool PRIO>
-__device__ __forceinline__ void qk_softmax(const char* smem, const int (&kaddr)[8], const mfma_bf16x8 (&qf)[8],
-                                           PPState& st, int64_t kv0, int64_t Lk, int half, float scale_log2e) {
+// LDS map (NST stages): K images at [ST*IMG), V^T images at [NST*IMG + ST*IMG): every fragment address is
+// a per-lane VGPR + an immediate < 64 KiB for NST <= 3.
+//
+// Schedule inside a tile (one wave).  hipcc left to itself issues each ds_read one MFMA ahead of its use
+// and waits lgkmcnt(0) before every MFMA (LDS latency > MFMA issue interval => ~3x the MFMA time per tile,
+// SQ_WAIT_ANY 31-44%).  The fragment reads are therefore batched explicitly and pinned with
+// sched_barrier(0) fences:
+//   [16 K reads] | [16 QK^T MFMAs] [8 V^T reads (T=0) issued under them] | [softmax VALU] |
+//   [8 V^T reads (T=1)] [8 PV MFMAs (T=0)] [8 PV MFMAs (T=1)]
+struct VFrags {
+  mfma_bf16x8 f[8];  // V^T fragments of kv sub-tile T=0: [s][dt]
+};
+
+template <int ST, bool PRIO, int NST, bool ROWSUM_MFMA = true, bool ABL_NOSM = false>
+__device__ __forceinline__ void qk_softmax(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
+                                           const mfma_bf16x8 (&qf)[8], PPState& st, VFrags& vf, int64_t kv0,
+                                           int64_t Lk, int half, float scale_log2e) {
   f32x16 accS[2];
+  mfma_bf16x8 kf[2][8];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      kf[T][ks] = *(lds_frag*)(smem + (ST * IMG + T * 8192) + kaddr[ks]);
+  __builtin_amdgcn_sched_barrier(0);
   if (PRIO) __builtin_amdgcn_s_setprio(1);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int T = 0; T < 2; ++T) {
+    accS[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T][0], qf[0], zero16, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) accS[T][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const mfma_bf16x8 kf = *reinterpret_cast<const mfma_bf16x8*>(smem + ST * 2 * IMG + T * 8192 + kaddr[ks]);
-      accS[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], accS[T], 0, 0, 0);
-    }
+    for (int ks = 1; ks < 8; ++ks) accS[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[T][ks], qf[ks], accS[T], 0, 0, 0);
   }
   if (PRIO) __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  if (ABL_NOSM) {  // timing ablation only (wrong results): no max / exp, just the bf16 packing
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) st.pk[T][r >> 1] = cvt_pk_bf16_pp(accS[T][r], accS[T][r + 1]);
+    return;
+  }
   if (kv0 + KVBLK > Lk) {  // ragged tail of a segment: reg r <-> kv = kv0 + T*32 + (r&7) + 8*half + 16*(r>>3)
+    asm volatile("" ::: "memory");  // keep this rare path a real (wave-uniform) branch: no if-conversion
+    const int lim = (int)(Lk - kv0) - 8 * half;
 #pragma unroll
     for (int T = 0; T < 2; ++T)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (kv0 + T * 32 + (r & 7) + 8 * half + 16 * (r >> 3) >= Lk) accS[T][r] = -INFINITY;
+        if (T * 32 + (r & 7) + 16 * (r >> 3) >= lim) accS[T][r] = -INFINITY;
   }
   float mt = accS[0][0];
 #pragma unroll
@@ -80,24 +113,40 @@ __device__ __forceinline__ void qk_softmax(const char* smem, const int (&kaddr)[
     for (int r = 0; r < 16; r += 2) {
       const float p0 = __builtin_amdgcn_exp2f(accS[T][r] * scale_log2e - mb);
       const float p1 = __builtin_amdgcn_exp2f(accS[T][r + 1] * scale_log2e - mb);
-      psum += p0 + p1;
+      if (!ROWSUM_MFMA) psum += p0 + p1;
       st.pk[T][r >> 1] = cvt_pk_bf16_pp(p0, p1);
     }
   if (!__all(m_new == st.m_run)) {  // running max moved: rescale O and l once, before P(t) enters O
     const float alpha = __builtin_amdgcn_exp2f((st.m_run - m_new) * scale_log2e);
-    st.l_run *= alpha;
+    if (ROWSUM_MFMA) st.accL[0] *= alpha; else st.l_run *= alpha;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) st.accO[dt][r] *= alpha;
   }
-  st.l_run += psum;
+  if (!ROWSUM_MFMA) st.l_run += psum;
   st.m_run = m_new;
 }
 
-// O^T += V^T P^T with V^T tile in LDS stage ST
-template <int ST>
-__device__ __forceinline__ void pv(const char* smem, const int (&vaddr)[4], PPState& st) {
+// O^T += V^T P^T with the V^T tile in LDS stage ST, plus the row sums l += ones * P^T on the matrix pipe (the
+// softmax VALU stream is the co-bottleneck: 4 extra MFMAs per tile replace 32 v_add_f32 per lane).
+template <int ST, int NST, bool PRELOADED, bool ROWSUM_MFMA = true>
+__device__ __forceinline__ void pv(lds_cchar* smem, const int (&vaddr)[4], PPState& st, VFrags& vf) {
+  mfma_bf16x8 vg[8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      vf.f[s * 4 + dt] = *(lds_frag*)(smem + (NST * IMG + ST * IMG + dt * 4096) + vaddr[s]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      vg[s * 4 + dt] = *(lds_frag*)(smem + (NST * IMG + ST * IMG + dt * 4096) + vaddr[2 + s]);
+  uint4 oraw;
+  oraw.x = oraw.y = oraw.z = oraw.w = 0x3f803f80u;  // bf16 1.0 x 8
+  const mfma_bf16x8 ones = __builtin_bit_cast(mfma_bf16x8, oraw);
 #pragma unroll
   for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -107,12 +156,146 @@ __device__ __forceinline__ void pv(const char* smem, const int (&vaddr)[4], PPSt
       praw.z = st.pk[T][s * 4 + 2]; praw.w = st.pk[T][s * 4 + 3];
       const mfma_bf16x8 pf = __builtin_bit_cast(mfma_bf16x8, praw);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const mfma_bf16x8 vf =
-            *reinterpret_cast<const mfma_bf16x8*>(smem + ST * 2 * IMG + IMG + dt * 4096 + vaddr[T * 2 + s]);
-        st.accO[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, st.accO[dt], 0, 0, 0);
-      }
+      for (int dt = 0; dt < 4; ++dt)
+        st.accO[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T == 0 ? vf.f[s * 4 + dt] : vg[s * 4 + dt], pf, st.accO[dt], 0, 0, 0);
+      if (ROWSUM_MFMA) st.accL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, st.accL, 0, 0, 0);
     }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- software-pipelined tile (non-tail tiles of MODE 0/2) -------------------------------------------------
+// The 64-kv tile is processed as two 32-kv online-softmax sub-steps whose VALU work is placed UNDER the
+// other sub-step's MFMAs inside one basic block (an in-order wave overlaps MFMA and VALU only when they are
+// interleaved in its instruction stream):
+//   B1: QK^T(T0)                        8 MFMA
+//   B2: QK^T(T1)  ||  softmax(T0)       8 MFMA + ~60 VALU     (+ V^T(T0) fragment reads)
+//   -- rare uniform branch: rescale O,l if the running max moved --
+//   B3: PV(T0)    ||  softmax(T1)       8(+2) MFMA + ~60 VALU (+ V^T(T1) fragment reads)
+//   -- rare uniform branch --
+//   B4: PV(T1)                          8(+2) MFMA
+// The cross-half row-max exchange uses v_permlane32_swap (VALU) instead of ds_bpermute so no LDS round trip
+// sits in the softmax chain.  sched_group_barrier pins the 1 MFMA : N VALU interleave.
+__device__ __forceinline__ float xhalf_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// max / exp / pack of one 32-kv sub-tile; returns alpha-needed flag via m_old/m_new in st
+template <bool ROWSUM_MFMA>
+__device__ __forceinline__ void softmax_half(const f32x16& accS, uint32_t (&pk)[8], float& m_run, float& m_prev,
+                                             float& lsum, float scale_log2e) {
+  float mt = fmaxf(accS[0], accS[1]);
+#pragma unroll
+  for (int r = 2; r < 16; ++r) mt = fmaxf(mt, accS[r]);
+  mt = xhalf_max(mt);
+  const float m_new = fmaxf(m_run, mt);
+  const float mb = m_new * scale_log2e;
+  float ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    const float p0 = __builtin_amdgcn_exp2f(accS[r] * scale_log2e - mb);
+    const float p1 = __builtin_amdgcn_exp2f(accS[r + 1] * scale_log2e - mb);
+    if (!ROWSUM_MFMA) ps += p0 + p1;
+    pk[r >> 1] = cvt_pk_bf16_pp(p0, p1);
+  }
+  if (!ROWSUM_MFMA) lsum = ps;
+  m_prev = m_run;
+  m_run = m_new;
+}
+
+template <bool ROWSUM_MFMA>
+__device__ __forceinline__ void rescale_if_moved(PPState& st, float m_prev, float scale_log2e) {
+  if (!__all(st.m_run == m_prev)) {
+    asm volatile("" ::: "memory");
+    const float alpha = __builtin_amdgcn_exp2f((m_prev - st.m_run) * scale_log2e);
+    if (ROWSUM_MFMA) st.accL[0] *= alpha; else st.l_run *= alpha;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st.accO[dt][r] *= alpha;
+  }
+}
+
+template <int ST, int NST, bool ROWSUM_MFMA>
+__device__ __forceinline__ void tile_fast(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
+                                          const mfma_bf16x8 (&qf)[8], PPState& st, float scale_log2e) {
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint4 oraw;
+  oraw.x = oraw.y = oraw.z = oraw.w = 0x3f803f80u;  // bf16 1.0 x 8
+  const mfma_bf16x8 ones = __builtin_bit_cast(mfma_bf16x8, oraw);
+  mfma_bf16x8 kf0[8], kf1[8], va0[4], va1[4], vb0[4], vb1[4];  // V^T fragments: [kv sub-tile a/b][k-step 0/1][dt]
+  f32x16 accS0, accS1;
+  float m_prev, ls0 = 0.f, ls1 = 0.f;
+  constexpr int KB = ST * IMG, VB = NST * IMG + ST * IMG;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kf0[ks] = *(lds_frag*)(smem + KB + kaddr[ks]);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- B1: QK^T(T0), K(T1) fragments in flight
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kf1[ks] = *(lds_frag*)(smem + (KB + 8192) + kaddr[ks]);
+  accS0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 8; ++ks) accS0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[ks], qf[ks], accS0, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- B2: QK^T(T1) || softmax(T0)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) va0[dt] = *(lds_frag*)(smem + (VB + dt * 4096) + vaddr[0]);
+  accS1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 8; ++ks) accS1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[ks], qf[ks], accS1, 0, 0, 0);
+  softmax_half<ROWSUM_MFMA>(accS0, st.pk[0], st.m_run, m_prev, ls0, scale_log2e);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // 8 VALU
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  rescale_if_moved<ROWSUM_MFMA>(st, m_prev, scale_log2e);
+  if (!ROWSUM_MFMA) st.l_run += ls0;
+  // ---- B3: PV(T0) || softmax(T1)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) va1[dt] = *(lds_frag*)(smem + (VB + dt * 4096) + vaddr[1]);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vb0[dt] = *(lds_frag*)(smem + (VB + dt * 4096) + vaddr[2]);
+  {
+    uint4 praw;
+    praw.x = st.pk[0][0]; praw.y = st.pk[0][1]; praw.z = st.pk[0][2]; praw.w = st.pk[0][3];
+    const mfma_bf16x8 pf = __builtin_bit_cast(mfma_bf16x8, praw);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st.accO[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0[dt], pf, st.accO[dt], 0, 0, 0);
+    if (ROWSUM_MFMA) st.accL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, st.accL, 0, 0, 0);
+    praw.x = st.pk[0][4]; praw.y = st.pk[0][5]; praw.z = st.pk[0][6]; praw.w = st.pk[0][7];
+    const mfma_bf16x8 pg = __builtin_bit_cast(mfma_bf16x8, praw);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st.accO[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1[dt], pg, st.accO[dt], 0, 0, 0);
+    if (ROWSUM_MFMA) st.accL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pg, st.accL, 0, 0, 0);
+  }
+  softmax_half<ROWSUM_MFMA>(accS1, st.pk[1], st.m_run, m_prev, ls1, scale_log2e);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  rescale_if_moved<ROWSUM_MFMA>(st, m_prev, scale_log2e);
+  if (!ROWSUM_MFMA) st.l_run += ls1;
+  // ---- B4: PV(T1)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vb1[dt] = *(lds_frag*)(smem + (VB + dt * 4096) + vaddr[3]);
+  {
+    uint4 praw;
+    praw.x = st.pk[1][0]; praw.y = st.pk[1][1]; praw.z = st.pk[1][2]; praw.w = st.pk[1][3];
+    const mfma_bf16x8 pf = __builtin_bit_cast(mfma_bf16x8, praw);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st.accO[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0[dt], pf, st.accO[dt], 0, 0, 0);
+    if (ROWSUM_MFMA) st.accL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, st.accL, 0, 0, 0);
+    praw.x = st.pk[1][4]; praw.y = st.pk[1][5]; praw.z = st.pk[1][6]; praw.w = st.pk[1][7];
+    const mfma_bf16x8 pg = __builtin_bit_cast(mfma_bf16x8, praw);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) st.accO[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1[dt], pg, st.accO[dt], 0, 0, 0);
+    if (ROWSUM_MFMA) st.accL = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pg, st.accL, 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // MODE 0: single-phase schedule (all waves: QK^T -> softmax -> PV per tile, one barrier per tile) with
@@ -125,7 +308,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp_kernel(const bf16_t* __res
                                                          float scale_log2e, int nseg, int64_t k_seg_stride,
                                                          int64_t vt_seg_stride) {
   constexpr bool PRIO = (FLAGS & 1) != 0;
-  __shared__ __attribute__((aligned(16))) char smem[4 * IMG];  // [stage0: K | V^T][stage1: K | V^T]
+  constexpr bool ROWSUM = (FLAGS & 2) != 0;     // row sums l on the matrix pipe (ones x P^T) instead of v_add
+  constexpr bool PIPELINED = (FLAGS & 4) != 0;  // software-pipelined tile_fast for full tiles (MODE 0/2)
+  constexpr bool ABL_NOSM = (FLAGS & 8) != 0, ABL_NODMA = (FLAGS & 16) != 0, ABL_NOBAR = (FLAGS & 32) != 0;  // timing ablations
+  constexpr int NST = (MODE == 2) ? 3 : 2;  // LDS ring depth
+  __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stage 0..NST-1][V^T stage 0..NST-1]
+  lds_cchar* lds = (lds_cchar*)smem;  // LDS-typed view: fragment reads become ds_read_b128 v, offset:imm
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp_kernel(const bf16_t* __res
     const char* base = reinterpret_cast<const char*>(kbase + (int64_t)seg * k_seg_stride + kv0 * rs);
     int64_t lim64 = Lk - 1 - kv0;
     const uint32_t lim = (uint32_t)(lim64 > 63 ? 63 : lim64);
-    char* dst = smem + ST * 2 * IMG;
+    char* dst = smem + ST * IMG;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
       const uint32_t r = krow[i] < lim ? krow[i] : lim;  // clamp rows past the end of the segment
@@ -191,9 +379,42 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp_kernel(const bf16_t* __res
     const int seg = (nseg == 1) ? 0 : t / tps;
     const int64_t kv0 = (int64_t)(t - seg * tps) * KVBLK;
     const char* base = reinterpret_cast<const char*>(vbase + (int64_t)seg * vt_seg_stride + kv0);
-    char* dst = smem + ST * 2 * IMG + IMG;
+    char* dst = smem + NST * IMG + ST * IMG;
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) glds16p(base + vofs[i], dst + (i * (NW * 64) + wave * 64) * 16);
+  };
+
+  // MODE 0/2: K and V^T of a tile are issued together, walking running (uniform) source pointers: no
+  // per-tile multiplies or divisions.
+  int dma_tt = 0, dma_seg = 0;
+  const char* dma_k = reinterpret_cast<const char*>(kbase);
+  const char* dma_v = reinterpret_cast<const char*>(vbase);
+  auto issue_next = [&](int ST) {
+    uint32_t lim = 63;
+    if (dma_tt == tps - 1) lim = (uint32_t)(Lk - 1 - (int64_t)dma_tt * KVBLK);  // ragged tail: clamp rows
+    char* kd = smem + ST * IMG;
+    char* vd = smem + NST * IMG + ST * IMG;
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) {
+      const uint32_t r = krow[i] < lim ? krow[i] : lim;
+      glds16p(dma_k + (r * rs2 + kcol[i]), kd + (i * (NW * 64) + wave * 64) * 16);
+      glds16p(dma_v + vofs[i], vd + (i * (NW * 64) + wave * 64) * 16);
+    }
+    if (++dma_tt == tps) {
+      dma_tt = 0;
+      ++dma_seg;
+      dma_k = reinterpret_cast<const char*>(kbase + (int64_t)dma_seg * k_seg_stride);
+      dma_v = reinterpret_cast<const char*>(vbase + (int64_t)dma_seg * vt_seg_stride);
+    } else {
+      dma_k += (int64_t)KVBLK * rs2;
+      dma_v += KVBLK * 2;
+    }
+  };
+  int cur_tt = 0;  // tile index inside the current segment of the tile being consumed
+  auto next_kv0 = [&]() {
+    const int64_t kv0 = (int64_t)cur_tt * KVBLK;
+    if (++cur_tt == tps) cur_tt = 0;
+    return kv0;
   };
 
   // ---- LDS fragment addresses: per-lane VGPR + compile-time immediates -----------------------------
@@ -212,13 +433,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp_kernel(const bf16_t* __res
   for (int T = 0; T < 2; ++T)
 #pragma unroll
     for (int r = 0; r < 8; ++r) st.pk[T][r] = 0u;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) st.accL[r] = 0.f;
   st.m_run = -INFINITY;
   st.l_run = 0.f;
+  VFrags vf, vscratch;  // vscratch: the ping-pong mode reads (and discards) V^T early; see pv<..., false>
 
   auto kv0_of = [&](int t) { return (int64_t)((nseg == 1) ? t : t % tps) * KVBLK; };
 
-  issueK(0, 0);
-  issueV(0, 0);
+  if (MODE == 1) {
+    issueK(0, 0);
+    issueV(0, 0);
+  } else {
+    issue_next(0);
+  }
 
   // The two groups run separate loops (identical barrier counts; s_barrier only counts arrivals), so
   // each loop body is a straight-line [phase | barrier | phase | barrier] stream for the allocator.
@@ -235,50 +463,83 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp_kernel(const bf16_t* __res
   asm volatile("" ::: "memory");                                                   \
   if ((t) + 1 < ntile) issueV(((t) + 1) & 1, (t) + 1);
 
+  // one tile from LDS stage STG: pipelined fast path for full tiles, sequential path for a segment's ragged tail
+#define COMPUTE_TILE(STG)                                                                                   \
+  {                                                                                                         \
+    const int64_t kv0_ = next_kv0();                                                                        \
+    if (PIPELINED && kv0_ + KVBLK <= Lk) {                                                                  \
+      tile_fast<STG, NST, ROWSUM>(lds, kaddr, vaddr, qf, st, scale_log2e);                                  \
+    } else {                                                                                                \
+      qk_softmax<STG, PRIO, NST, ROWSUM, ABL_NOSM>(lds, kaddr, vaddr, qf, st, vf, kv0_, Lk, half, scale_log2e); \
+      pv<STG, NST, true, ROWSUM>(lds, vaddr, st, vf);                                                       \
+    }                                                                                                       \
+  }
   if (MODE == 0) {
     // single phase: tile t+1 (K and V^T) is in flight while tile t is consumed
     for (int t = 0; t < ntile; t += 2) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (!ABL_NOBAR) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (t + 1 < ntile) { issueK(1, t + 1); issueV(1, t + 1); }
-      qk_softmax<0, PRIO>(smem, kaddr, qf, st, kv0_of(t), Lk, half, scale_log2e);
-      pv<0>(smem, vaddr, st);
+      if (t + 1 < ntile && !(ABL_NODMA && t > 0)) issue_next(1);
+      COMPUTE_TILE(0);
       if (t + 1 < ntile) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!ABL_NOBAR) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < ntile) { issueK(0, t + 2); issueV(0, t + 2); }
-        qk_softmax<1, PRIO>(smem, kaddr, qf, st, kv0_of(t + 1), Lk, half, scale_log2e);
-        pv<1>(smem, vaddr, st);
+        if (t + 2 < ntile && !ABL_NODMA) issue_next(0);
+        COMPUTE_TILE(1);
       }
     }
+  } else if (MODE == 2) {
+    // single phase, 3-deep ring: tiles t+1 and t+2 are in flight while tile t is consumed; the wait before
+    // the barrier is COUNTED (the younger tile's 2*NSLOT pieces per lane stay in flight across it)
+    if (1 < ntile) issue_next(1);
+#define V3_STEP(J)                                                                                     \
+  if (t + (J) < ntile) {                                                                               \
+    const int tt = t + (J);                                                                            \
+    if (tt + 1 < ntile) {                                                                              \
+      if (NSLOT == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                      \
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                 \
+    } else {                                                                                           \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+    }                                                                                                  \
+    __builtin_amdgcn_s_barrier();                                                                      \
+    asm volatile("" ::: "memory");                                                                     \
+    if (tt + 2 < ntile) issue_next(((J) + 2) % 3);                                                     \
+    COMPUTE_TILE(J)                                                                                    \
+  }
+    for (int t = 0; t < ntile; t += 3) {
+      V3_STEP(0)
+      V3_STEP(1)
+      V3_STEP(2)
+    }
+#undef V3_STEP
   } else if (grp == 0) {
     // G0: P1 = QK^T(t)+softmax(t), P2 = PV(t)
     for (int t = 0; t <= ntile; t += 2) {
       PP_BAR1(t);
-      if (t < ntile) qk_softmax<0, PRIO>(smem, kaddr, qf, st, kv0_of(t), Lk, half, scale_log2e);
+      if (t < ntile) qk_softmax<0, PRIO, NST, ROWSUM>(lds, kaddr, vaddr, qf, st, vscratch, kv0_of(t), Lk, half, scale_log2e);
       PP_BAR2(t);
-      if (t < ntile) pv<0>(smem, vaddr, st);
+      if (t < ntile) pv<0, NST, false, ROWSUM>(lds, vaddr, st, vf);
       if (t + 1 <= ntile) {
         PP_BAR1(t + 1);
-        if (t + 1 < ntile) qk_softmax<1, PRIO>(smem, kaddr, qf, st, kv0_of(t + 1), Lk, half, scale_log2e);
+        if (t + 1 < ntile) qk_softmax<1, PRIO, NST, ROWSUM>(lds, kaddr, vaddr, qf, st, vscratch, kv0_of(t + 1), Lk, half, scale_log2e);
         PP_BAR2(t + 1);
-        if (t + 1 < ntile) pv<1>(smem, vaddr, st);
+        if (t + 1 < ntile) pv<1, NST, false, ROWSUM>(lds, vaddr, st, vf);
       }
     }
   } else {
     // G1: P1 = PV(t-1), P2 = QK^T(t)+softmax(t)
     for (int t = 0; t <= ntile; t += 2) {
       PP_BAR1(t);
-      if (t >= 1) pv<1>(smem, vaddr, st);
+      if (t >= 1) pv<1, NST, false, ROWSUM>(lds, vaddr, st, vf);
       PP_BAR2(t);
-      if (t < ntile) qk_softmax<0, PRIO>(smem, kaddr, qf, st, kv0_of(t), Lk, half, scale_log2e);
+      if (t < ntile) qk_softmax<0, PRIO, NST, ROWSUM>(lds, kaddr, vaddr, qf, st, vscratch, kv0_of(t), Lk, half, scale_log2e);
       if (t + 1 <= ntile) {
         PP_BAR1(t + 1);
-        pv<0>(smem, vaddr, st);
+        pv<0, NST, false, ROWSUM>(lds, vaddr, st, vf);
         PP_BAR2(t + 1);
-        if (t + 1 < ntile) qk_softmax<1, PRIO>(smem, kaddr, qf, st, kv0_of(t + 1), Lk, half, scale_log2e);
+        if (t + 1 < ntile) qk_softmax<1, PRIO, NST, ROWSUM>(lds, kaddr, vaddr, qf, st, vscratch, kv0_of(t + 1), Lk, half, scale_log2e);
       }
     }
   }
@@ -286,8 +547,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp_kernel(const bf16_t* __res
 #undef PP_BAR2
 
   // ---- epilogue ----------------------------------------------------------------------------------------
-  const float l_tot = st.l_run + __shfl_xor(st.l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
+  // ROWSUM: accL[0] = sum over ALL kv of P[q][kv] (the MFMA contracts both halves' kv), q = lane&31;
+  // otherwise the two halves hold partial sums
+  const float inv = 1.0f / (ROWSUM ? st.accL[0] : st.l_run + __shfl_xor(st.l_run, 32, 64));
   __syncthreads();
   char* ob = smem + wave * (32 * 256);
 #pragma unroll
@@ -318,20 +580,41 @@ int wan_attention_pp_launch(int flags, int mode, int nw, const bf16_t* q, const 
                             int64_t vt_seg_stride, float scale_log2e, hipStream_t stream) {
   WAN_REQUIRE(Lk * (int64_t)H * 256 < ((int64_t)1 << 32) && ldv * 256 < ((int64_t)1 << 32),
               "wan_attention: K/V^T extent exceeds the 32-bit DMA offsets of this kernel");
-  WAN_REQUIRE((mode == 0 && (nw == 4 || nw == 8)) || (mode == 1 && nw == 8), "wan_attention: bad kernel variant");
+  WAN_REQUIRE((mode == 0 && (nw == 4 || nw == 8)) || ((mode == 1 || mode == 2) && nw == 8), "wan_attention: bad kernel variant");
   const int64_t nqb = (Lq + nw * 32 - 1) / (nw * 32);
   const int64_t total = nqb * H * B;
   WAN_REQUIRE(total < ((int64_t)1 << 31), "wan_attention: grid too large");
 #define PP_LAUNCH(FL, MD, NWV)                                                                                      \
   hipLaunchKernelGGL((attn_pp_kernel<FL, MD, NWV>), dim3((unsigned)total), dim3(NWV * 64), 0, stream, q, k, vt, o, B, \
                      Bk, Lq, Lk, ldv, H, (int)nqb, scale_log2e, nseg, k_seg_stride, vt_seg_stride)
-  const int pr = flags & 1;
+  // flags: bit0 setprio, bit1 row sums on the matrix pipe, bit2 software-pipelined tiles
   if (mode == 1) {
-    if (pr) PP_LAUNCH(1, 1, 8); else PP_LAUNCH(0, 1, 8);
+    PP_LAUNCH(2, 1, 8);
+  } else if (mode == 2) {
+    if (flags & 4) PP_LAUNCH(6, 2, 8); else PP_LAUNCH(2, 2, 8);
+  } else if (nw == 8 && (flags & 56)) {  // timing ablations (tools/bench_attn.py only)
+    switch (flags & 56) {
+      case 8: PP_LAUNCH(8, 0, 8); break;
+      case 16: PP_LAUNCH(16, 0, 8); break;
+      case 32: PP_LAUNCH(32, 0, 8); break;
+      case 24: PP_LAUNCH(24, 0, 8); break;
+      case 48: PP_LAUNCH(48, 0, 8); break;
+      default: PP_LAUNCH(56, 0, 8); break;
+    }
   } else if (nw == 8) {
-    if (pr) PP_LAUNCH(1, 0, 8); else PP_LAUNCH(0, 0, 8);
+    switch (flags & 6) {
+      case 6: PP_LAUNCH(6, 0, 8); break;
+      case 4: PP_LAUNCH(4, 0, 8); break;
+      case 2: PP_LAUNCH(2, 0, 8); break;
+      default: PP_LAUNCH(0, 0, 8); break;
+    }
   } else {
-    if (pr) PP_LAUNCH(1, 0, 4); else PP_LAUNCH(0, 0, 4);
+    switch (flags & 6) {
+      case 6: PP_LAUNCH(6, 0, 4); break;
+      case 4: PP_LAUNCH(4, 0, 4); break;
+      case 2: PP_LAUNCH(2, 0, 4); break;
+      default: PP_LAUNCH(0, 0, 4); break;
+    }
   }
 #undef PP_LAUNCH
   WAN_LAUNCH_CHECK();
