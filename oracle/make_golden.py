@@ -144,6 +144,40 @@ def gen_sched(ns):
     print("sched.npz", {k: v.shape for k, v in out.items()})
 
 
+def gen_sched2(ns):
+    """dpm++ / causvid / lcm schedulers exactly as WanAny2V.generate builds them (any2video.py:513-545)."""
+    out = {}
+
+    def run(name, sched, timesteps, stepfn):
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(1, 16, 2, 4, 4, generator=g)
+        trace = []
+        for t in timesteps:
+            v = torch.randn(x.shape, generator=g) * 0.7 + 0.1 * x
+            x = stepfn(v, t, x)
+            trace.append(f32(x))
+        out[name + "_trace"] = np.stack(trace)
+        out[name + "_ts"] = np.asarray(timesteps.numpy() if torch.is_tensor(timesteps) else timesteps).copy()
+
+    for steps, shift in ((10, 5.0), (4, 3.0), (20, 12.0)):
+        s = ns.D.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+        ts, _ = ns.D.retrieve_timesteps(s, device="cpu", sigmas=ns.D.get_sampling_sigmas(steps, shift))
+        run(f"dpm_{steps}_{shift}", s, ts, lambda v, t, x: s.step(v, t, x, return_dict=False)[0])
+        out[f"dpm_{steps}_{shift}_sig"] = s.sigmas.numpy().copy()
+    for steps, shift in ((9, 7.0), (4, 5.0)):
+        s = ns.FM.FlowMatchScheduler(num_inference_steps=steps, shift=shift, sigma_min=0, extra_one_step=True)
+        ts = torch.tensor([1000, 934, 862, 756, 603, 410, 250, 140, 74])[:steps]
+        s.timesteps = ts
+        s.sigmas = torch.cat([s.timesteps / 1000, torch.tensor([0.])])
+        run(f"causvid_{steps}_{shift}", s, ts, lambda v, t, x: s.step(v, t, x)[0])
+    for steps, shift in ((4, 5.0), (8, 3.0)):
+        s = ns.LCM.LCMScheduler(num_train_timesteps=1000, num_inference_steps=min(steps, 8), shift=shift)
+        s.set_timesteps(steps, device="cpu", shift=shift)
+        run(f"lcm_{steps}_{shift}", s, s.timesteps, lambda v, t, x: s.step(v, t, x)[0])
+    np.savez_compressed(os.path.join(OUT, "sched2.npz"), **out)
+    print("sched2.npz", {k: v.shape for k, v in out.items()})
+
+
 def gen_loop(ns):
     """3-step t2v sampler loop, two experts, CFG, UniPC -- the loop body of
     WanAny2V.generate (any2video.py:1470,1490-1501,1626-1634,1702-1722,1733) driven on the
@@ -178,7 +212,7 @@ def main():
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
     ns = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "forward", "sched", "loop", "vae"]
+    which = sys.argv[1:] or ["ops", "forward", "sched", "sched2", "loop", "vae"]
     if "ops" in which:
         gen_ops(ns)
     if "forward" in which:
@@ -186,6 +220,8 @@ def main():
         gen_forward(ns, "tiny_i2v", 2, 8, 8, 912)
     if "sched" in which:
         gen_sched(ns)
+    if "sched2" in which:
+        gen_sched2(ns)
     if "loop" in which:
         gen_loop(ns)
     if "vae" in which:

@@ -137,6 +137,9 @@ def load():
     ns.V = _load("ref_vae", "models/wan/modules/vae.py")
     ns.U = _load("ref_unipc", "shared/utils/fm_solvers_unipc.py")
     ns.E = _load("ref_euler", "shared/utils/euler_scheduler.py")
+    ns.D = _load("ref_dpm", "shared/utils/fm_solvers.py")
+    ns.FM = _load("ref_flowmatch", "shared/utils/basic_flowmatch.py")
+    ns.LCM = _load("ref_lcm", "shared/utils/lcm_scheduler.py")
     import shared.attention as A  # the real file (namespace package `shared`)
     ns.A = A
     off.shared_state["_attention"] = "sdpa"

@@ -461,6 +461,96 @@ class EulerOracle:
         return sample - model_output * (dt_raw.item() / self.N)
 
 
+class DpmppOracle:
+    """FlowDPMSolverMultistepScheduler restated for the configuration generate() builds (any2video.py:524-533):
+    order 2, dpmsolver++, midpoint, flow_prediction, lower_order_final, final sigma 0 --
+    fm_solvers.py:22-27 (get_sampling_sigmas), :226-291 (set_timesteps), :341-395 (x0 = x - sigma*v),
+    :415-468 (first order), :486-557 (second order), :706-797 (step)."""
+
+    def __init__(self, num_train_timesteps=1000):
+        self.N = num_train_timesteps
+
+    def set_timesteps(self, sampling_steps: int, shift: float):
+        sigma = np.linspace(1, 0, sampling_steps + 1)[:sampling_steps]
+        sigma = shift * sigma / (1 + (shift - 1) * sigma)            # get_sampling_sigmas
+        sigmas = 1.0 * sigma / (1 + (1.0 - 1) * sigma)               # set_timesteps(sigmas=..) with config.shift = 1
+        timesteps = sigmas * self.N
+        self.sigmas = torch.from_numpy(np.concatenate([sigmas, [0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(timesteps).to(dtype=torch.int64)
+        self.model_outputs = [None, None]
+        self.lower_order_nums = 0
+        self.step_index = 0
+        return self.timesteps
+
+    @staticmethod
+    def _lam(sigma):
+        return torch.log(1 - sigma) - torch.log(sigma)
+
+    def step(self, model_output, sample):
+        i, sig, n = self.step_index, self.sigmas, len(self.timesteps)
+        lower_order_final = i == n - 1                                # final_sigmas_type == "zero"
+        lower_order_second = (i == n - 2) and n < 15
+        m = sample - sig[i] * model_output
+        self.model_outputs = [self.model_outputs[1], m]
+        sample = sample.to(torch.float32)
+        sigma_t, sigma_s0 = sig[i + 1], sig[i]
+        alpha_t = 1 - sigma_t
+        h = self._lam(sigma_t) - self._lam(sigma_s0)
+        if self.lower_order_nums < 1 or lower_order_final:
+            prev = (sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * m
+        else:
+            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
+            h_0 = self._lam(sigma_s0) - self._lam(sig[i - 1])
+            r0 = h_0 / h
+            D0, D1 = m0, (1.0 / r0) * (m0 - m1)
+            prev = ((sigma_t / sigma_s0) * sample - (alpha_t * (torch.exp(-h) - 1.0)) * D0
+                    - 0.5 * (alpha_t * (torch.exp(-h) - 1.0)) * D1)
+        if self.lower_order_nums < 2:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return prev.to(model_output.dtype)
+
+
+class FlowMatchOracle:
+    """FlowMatchScheduler (causvid) restated -- basic_flowmatch.py:20-54 as generate() uses it
+    (any2video.py:513-517: shift, sigma_min=0, extra_one_step=True, fixed timestep table)."""
+
+    def __init__(self, num_inference_steps, shift, sigma_min=0.0, extra_one_step=True, num_train_timesteps=1000):
+        sig = torch.linspace(1.0, sigma_min, num_inference_steps + 1)[:-1] if extra_one_step else \
+            torch.linspace(1.0, sigma_min, num_inference_steps)
+        self.sigmas = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = self.sigmas * num_train_timesteps
+
+    def step(self, model_output, timestep, sample):
+        tid = torch.argmin((self.timesteps - timestep).abs(), dim=0)
+        sigma = self.sigmas[tid].reshape(-1, 1, 1, 1)
+        sigma_ = 0 if tid + 1 >= len(self.timesteps) else self.sigmas[tid + 1].reshape(-1, 1, 1, 1)
+        return sample + model_output * (sigma_ - sigma)
+
+
+class LcmOracle:
+    """LCMScheduler restated -- lcm_scheduler.py:26-76."""
+
+    def __init__(self, num_train_timesteps=1000):
+        self.N = num_train_timesteps
+
+    def set_timesteps(self, num_inference_steps, shift):
+        n = min(num_inference_steps, 8)
+        t = torch.linspace(0, 1, n + 1, dtype=torch.float32)
+        sigma_min = 0.003 / 1.002
+        sig = sigma_min + (1.0 - sigma_min) * (1 - t)
+        self.sigmas = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = self.sigmas[:-1] * self.N
+        self.step_index = 0
+        return self.timesteps
+
+    def step(self, model_output, sample):
+        i = self.step_index
+        nxt = self.sigmas[i + 1] if i + 1 < len(self.sigmas) else torch.zeros(())
+        self.step_index += 1
+        return sample + model_output * (nxt - self.sigmas[i])
+
+
 def cfg_combine(cond: torch.Tensor, uncond: torch.Tensor, guide_scale: float) -> torch.Tensor:
     """any2video.py:1722: noise_pred = uncond + g * (cond - uncond)."""
     return uncond + guide_scale * (cond - uncond)

@@ -128,6 +128,47 @@ def test_euler_vs_reference_golden(steps, shift):
         x = torch.from_numpy(ref[i])
 
 
+def _follow(ref, stepfn, timesteps, atol):
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 2, 4, 4, generator=gen)
+    for i, tv in enumerate(timesteps):
+        v = torch.randn(x.shape, generator=gen) * 0.7 + 0.1 * x
+        got = stepfn(v.cuda(), tv, x.cuda()).cpu()
+        x = torch.from_numpy(ref[i])                                   # follow the reference trajectory
+        assert torch.allclose(got, x, atol=atol, rtol=atol), (i, (got - x).abs().max())
+
+
+@pytest.mark.parametrize("steps,shift", [(10, 5.0), (4, 3.0), (20, 12.0)])
+def test_dpmpp_vs_reference_golden(steps, shift):
+    from wan2gp_amd.schedulers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
+    g = load("sched2.npz")
+    s = FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    ts, _ = retrieve_timesteps(s, device="cuda", sigmas=get_sampling_sigmas(steps, shift))
+    assert np.array_equal(ts.cpu().numpy(), g[f"dpm_{steps}_{shift}_ts"])
+    assert np.array_equal(s.sigmas.numpy(), g[f"dpm_{steps}_{shift}_sig"])
+    _follow(g[f"dpm_{steps}_{shift}_trace"], lambda v, t, x: s.step(v, t, x, return_dict=False)[0], ts, 2e-5)
+
+
+@pytest.mark.parametrize("steps,shift", [(9, 7.0), (4, 5.0)])
+def test_causvid_vs_reference_golden(steps, shift):
+    from wan2gp_amd.schedulers import FlowMatchScheduler
+    g = load("sched2.npz")
+    s = FlowMatchScheduler(num_inference_steps=steps, shift=shift, sigma_min=0, extra_one_step=True)
+    s.timesteps = torch.tensor([1000, 934, 862, 756, 603, 410, 250, 140, 74])[:steps].cuda()
+    s.sigmas = torch.cat([s.timesteps / 1000, torch.tensor([0.], device="cuda")])
+    _follow(g[f"causvid_{steps}_{shift}_trace"], lambda v, t, x: s.step(v, t, x)[0], s.timesteps, 1e-6)
+
+
+@pytest.mark.parametrize("steps,shift", [(4, 5.0), (8, 3.0)])
+def test_lcm_vs_reference_golden(steps, shift):
+    from wan2gp_amd.schedulers import LCMScheduler
+    g = load("sched2.npz")
+    s = LCMScheduler(num_train_timesteps=1000, num_inference_steps=min(steps, 8), shift=shift)
+    s.set_timesteps(steps, device="cuda", shift=shift)
+    assert np.array_equal(s.timesteps.cpu().numpy(), g[f"lcm_{steps}_{shift}_ts"])
+    _follow(g[f"lcm_{steps}_{shift}_trace"], lambda v, t, x: s.step(v, t, x)[0], s.timesteps, 1e-6)
+
+
 def test_sampler_loop_vs_reference_golden():
     """3 UniPC steps, CFG 4 -> 3, expert switch at t <= 875 (any2video.py:1437-1443)."""
     from wan2gp_amd.pipeline import WanAny2VHIP

@@ -145,3 +145,49 @@ def test_sampler_loop_matches_reference(tag, dtype):
         else:
             rel = (trace[i] - t(ref[i])).norm() / t(ref[i]).norm()
             assert rel < 3e-2, (i, rel)
+
+
+@pytest.mark.parametrize("steps,shift", [(10, 5.0), (4, 3.0), (20, 12.0)])
+def test_dpmpp_matches_reference(steps, shift):
+    g = load("sched2.npz")
+    s = O.DpmppOracle()
+    ts = s.set_timesteps(steps, shift)
+    assert np.array_equal(ts.numpy(), g[f"dpm_{steps}_{shift}_ts"])
+    assert np.array_equal(s.sigmas.numpy(), g[f"dpm_{steps}_{shift}_sig"])
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 2, 4, 4, generator=gen)
+    ref = g[f"dpm_{steps}_{shift}_trace"]
+    for i in range(steps):
+        v = torch.randn(x.shape, generator=gen) * 0.7 + 0.1 * x
+        x = s.step(v, x)
+        assert torch.allclose(x, t(ref[i]), atol=1e-6, rtol=1e-6), i
+
+
+@pytest.mark.parametrize("steps,shift", [(9, 7.0), (4, 5.0)])
+def test_causvid_matches_reference(steps, shift):
+    g = load("sched2.npz")
+    s = O.FlowMatchOracle(steps, shift)
+    s.timesteps = torch.tensor([1000, 934, 862, 756, 603, 410, 250, 140, 74])[:steps]
+    s.sigmas = torch.cat([s.timesteps / 1000, torch.tensor([0.])])
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 2, 4, 4, generator=gen)
+    ref = g[f"causvid_{steps}_{shift}_trace"]
+    for i, tv in enumerate(s.timesteps):
+        v = torch.randn(x.shape, generator=gen) * 0.7 + 0.1 * x
+        x = s.step(v, tv, x)
+        assert torch.equal(x, t(ref[i])), i
+
+
+@pytest.mark.parametrize("steps,shift", [(4, 5.0), (8, 3.0)])
+def test_lcm_matches_reference(steps, shift):
+    g = load("sched2.npz")
+    s = O.LcmOracle()
+    ts = s.set_timesteps(steps, shift)
+    assert np.array_equal(ts.numpy(), g[f"lcm_{steps}_{shift}_ts"])
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 2, 4, 4, generator=gen)
+    ref = g[f"lcm_{steps}_{shift}_trace"]
+    for i in range(len(ts)):
+        v = torch.randn(x.shape, generator=gen) * 0.7 + 0.1 * x
+        x = s.step(v, x)
+        assert torch.equal(x, t(ref[i])), i

@@ -15,7 +15,8 @@ from typing import Callable, Optional
 import torch
 
 from .rope import get_rotary_pos_embed
-from .schedulers import EulerScheduler, FlowUniPCMultistepScheduler, cfg_combine
+from .schedulers import (EulerScheduler, FlowDPMSolverMultistepScheduler, FlowMatchScheduler, FlowUniPCMultistepScheduler,
+                         LCMScheduler, cfg_combine, get_sampling_sigmas, retrieve_timesteps)
 
 
 class WanAny2VHIP:
@@ -35,8 +36,20 @@ class WanAny2VHIP:
             s = FlowUniPCMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
                                             use_dynamic_shifting=False)
             s.set_timesteps(sampling_steps, device=self.device, shift=shift)
+        elif sample_solver == "dpm++":                                              # any2video.py:524-533
+            s = FlowDPMSolverMultistepScheduler(num_train_timesteps=self.num_train_timesteps, shift=1,
+                                                use_dynamic_shifting=False)
+            retrieve_timesteps(s, device=self.device, sigmas=get_sampling_sigmas(sampling_steps, shift))
+        elif sample_solver == "causvid":                                            # :513-517
+            s = FlowMatchScheduler(num_inference_steps=sampling_steps, shift=shift, sigma_min=0, extra_one_step=True)
+            s.timesteps = torch.tensor([1000, 934, 862, 756, 603, 410, 250, 140, 74])[:sampling_steps].to(self.device)
+            s.sigmas = torch.cat([s.timesteps / 1000, torch.tensor([0.], device=self.device)])
+        elif sample_solver == "lcm":                                                # :534-543
+            n = min(sampling_steps, 8)
+            s = LCMScheduler(num_train_timesteps=self.num_train_timesteps, num_inference_steps=n, shift=shift)
+            s.set_timesteps(n, device=self.device, shift=shift)
         else:
-            raise NotImplementedError(f"Unsupported Scheduler {sample_solver} (hot path implements unipc, euler)")
+            raise NotImplementedError(f"Unsupported Scheduler {sample_solver}")
         return s, s.timesteps
 
     def build_i2v_conditioning(self, image_start, frame_num, height, width, VAE_tile_size=0):
@@ -119,7 +132,10 @@ class WanAny2VHIP:
                             return None
                         ret.append(r)
                 noise_pred = cfg_combine(ret[0], ret[1], float(guide_scale))                        # :1722
-            latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
+            if isinstance(sample_scheduler, FlowMatchScheduler):                                    # :1463-1467
+                latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents)[0]
+            else:
+                latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
             if callback is not None:
                 callback(i, latents[0], False)
         if ext_latents is not None:

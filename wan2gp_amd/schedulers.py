@@ -207,3 +207,162 @@ class EulerScheduler:
 def cfg_combine(cond, uncond, guide_scale):
     """noise_pred = uncond + g * (cond - uncond)   (any2video.py:1722)"""
     return ops.cfg_combine(cond, uncond, guide_scale)
+
+
+# ---- the remaining samplers WanAny2V.generate() can build (any2video.py:513-545) ---------------------------
+def get_sampling_sigmas(sampling_steps, shift):
+    """fm_solvers.py:22-27."""
+    sigma = np.linspace(1, 0, sampling_steps + 1)[:sampling_steps]
+    return shift * sigma / (1 + (shift - 1) * sigma)
+
+
+def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):
+    """fm_solvers.py:29-72 (the `sigmas=` / plain forms generate() uses)."""
+    if timesteps is not None:
+        raise NotImplementedError("custom timestep schedules are not used on the Wan path")
+    if sigmas is not None:
+        scheduler.set_timesteps(sigmas=sigmas, device=device, **kwargs)
+    else:
+        scheduler.set_timesteps(num_inference_steps, device=device, **kwargs)
+    return scheduler.timesteps, len(scheduler.timesteps)
+
+
+class FlowDPMSolverMultistepScheduler:
+    """`dpm++`: shared/utils/fm_solvers.py FlowDPMSolverMultistepScheduler in the configuration generate() builds
+    (order 2, dpmsolver++, midpoint, flow_prediction, lower_order_final, final sigma zero).  Scalar algebra on the
+    host as the reference (:455-468, :529-557); each update is one fused wan_lincomb over the fp32 latents."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, solver_order=2, prediction_type="flow_prediction", shift=1.0,
+                 use_dynamic_shifting=False, algorithm_type="dpmsolver++", solver_type="midpoint",
+                 lower_order_final=True, euler_at_final=False, final_sigmas_type="zero", **unused):
+        if (solver_order, prediction_type, algorithm_type, solver_type, final_sigmas_type, use_dynamic_shifting) != \
+                (2, "flow_prediction", "dpmsolver++", "midpoint", "zero", False):
+            raise NotImplementedError("only the configuration WanAny2V.generate() uses is implemented")
+        self.num_train_timesteps, self.shift = num_train_timesteps, shift
+        self.lower_order_final, self.euler_at_final = lower_order_final, euler_at_final
+        alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
+        sig = torch.from_numpy(1.0 - alphas).to(dtype=torch.float32)
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        self.sigma_min, self.sigma_max = sig[-1].item(), sig[0].item()
+        self.num_inference_steps = None
+        self._step_index = None
+
+    def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None, shift=None):
+        if sigmas is None:
+            sigmas = np.linspace(self.sigma_max, self.sigma_min, num_inference_steps + 1).copy()[:-1]
+        if shift is None:
+            shift = self.shift
+        sigmas = shift * sigmas / (1 + (shift - 1) * sigmas)
+        timesteps = sigmas * self.num_train_timesteps
+        self.sigmas = torch.from_numpy(np.concatenate([sigmas, [0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(timesteps).to(device=device, dtype=torch.int64)
+        self._timesteps_host = self.timesteps.cpu()
+        self.num_inference_steps = len(timesteps)
+        self.model_outputs = [None, None]
+        self.lower_order_nums = 0
+        self._step_index = None
+
+    @staticmethod
+    def _lam(sigma):
+        return torch.log(1 - sigma) - torch.log(sigma)
+
+    def step(self, model_output, timestep, sample, generator=None, variance_noise=None, return_dict=True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self._step_index is None:
+            tv = int(timestep) if not torch.is_tensor(timestep) else int(timestep.item())
+            idx = (self._timesteps_host == tv).nonzero()
+            self._step_index = idx[1 if len(idx) > 1 else 0].item()
+        i, sig, n = self._step_index, self.sigmas, len(self.timesteps)
+        lower_order_final = i == n - 1                      # final_sigmas_type == "zero" (:745-748)
+        model_output = model_output.to(torch.float32).contiguous()
+        sample = sample.to(torch.float32).contiguous()
+        m0 = ops.lincomb([sample, model_output], [1.0, -float(sig[i])])           # x0 = x - sigma*v (:385-386)
+        self.model_outputs = [self.model_outputs[1], m0]
+        sigma_t, sigma_s0 = sig[i + 1], sig[i]
+        alpha_t = 1 - sigma_t
+        h = self._lam(sigma_t) - self._lam(sigma_s0)
+        c_x = sigma_t / sigma_s0
+        c_d0 = -(alpha_t * (torch.exp(-h) - 1.0))
+        if self.lower_order_nums < 1 or lower_order_final:                          # first order (:455-468)
+            prev = ops.lincomb([sample, m0], [float(c_x), float(c_d0)])
+        else:                                                                       # second order midpoint (:529-553)
+            m1 = self.model_outputs[-2]
+            r0 = (self._lam(sigma_s0) - self._lam(sig[i - 1])) / h
+            c_d1 = 0.5 * c_d0 * (1.0 / r0)                                          # on D1 = (1/r0)(m0 - m1)
+            prev = ops.lincomb([sample, m0, m1], [float(c_x), float(c_d0 + c_d1), float(-c_d1)])
+        if self.lower_order_nums < 2:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        return (prev,) if not return_dict else SchedulerOutput(prev)
+
+    def scale_model_input(self, sample, *a, **k):
+        return sample
+
+
+class FlowMatchScheduler:
+    """`causvid`: shared/utils/basic_flowmatch.py:8-54.  generate() overwrites `.timesteps` / `.sigmas` with its fixed
+    table after construction (any2video.py:515-517); that works here the same way."""
+    is_stateful = False
+
+    def __init__(self, num_inference_steps=100, num_train_timesteps=1000, shift=3.0, sigma_max=1.0,
+                 sigma_min=0.003 / 1.002, inverse_timesteps=False, extra_one_step=False, reverse_sigmas=False):
+        if inverse_timesteps or reverse_sigmas:
+            raise NotImplementedError("training-only options")
+        self.num_train_timesteps, self.shift = num_train_timesteps, shift
+        self.sigma_max, self.sigma_min, self.extra_one_step = sigma_max, sigma_min, extra_one_step
+        self.set_timesteps(num_inference_steps)
+
+    def set_timesteps(self, num_inference_steps=100, denoising_strength=1.0, training=False):
+        start = self.sigma_min + (self.sigma_max - self.sigma_min) * denoising_strength
+        if self.extra_one_step:
+            sig = torch.linspace(start, self.sigma_min, num_inference_steps + 1)[:-1]
+        else:
+            sig = torch.linspace(start, self.sigma_min, num_inference_steps)
+        self.sigmas = self.shift * sig / (1 + (self.shift - 1) * sig)
+        self.timesteps = self.sigmas * self.num_train_timesteps
+
+    def step(self, model_output, timestep, sample, to_final=False, **kwargs):
+        ts = self.timesteps.detach().float().cpu()
+        sg = self.sigmas.detach().float().cpu()
+        tv = float(timestep.flatten()[0].item()) if torch.is_tensor(timestep) else float(timestep)
+        tid = int(torch.argmin((ts - tv).abs()).item())
+        sigma = sg[tid]
+        sigma_ = 0.0 if (to_final or tid + 1 >= len(ts)) else sg[tid + 1]
+        coef = float(torch.as_tensor(sigma_, dtype=torch.float32) - sigma)
+        return [ops.lincomb([sample.to(torch.float32).contiguous(), model_output.to(torch.float32).contiguous()], [1.0, coef])]
+
+
+class LCMScheduler:
+    """`lcm`: shared/utils/lcm_scheduler.py:11-99."""
+
+    def __init__(self, num_train_timesteps=1000, num_inference_steps=4, shift=1.0):
+        self.num_train_timesteps, self.num_inference_steps, self.shift = num_train_timesteps, num_inference_steps, shift
+        self._step_index = None
+
+    def set_timesteps(self, num_inference_steps, device=None, shift=None, **kwargs):
+        self.num_inference_steps = min(num_inference_steps, 8)
+        shift = self.shift if shift is None else shift
+        t = torch.linspace(0, 1, self.num_inference_steps + 1, dtype=torch.float32)
+        sigma_min = 0.003 / 1.002
+        sig = sigma_min + (1.0 - sigma_min) * (1 - t)
+        self.sigmas = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = self.sigmas[:-1] * self.num_train_timesteps
+        self._sig_host, self._ts_host = self.sigmas.clone(), self.timesteps.clone()
+        if device is not None:
+            self.timesteps = self.timesteps.to(device)
+            self.sigmas = self.sigmas.to(device)
+        self._step_index = None
+
+    def step(self, model_output, timestep, sample, **kwargs):
+        if self._step_index is None:
+            tv = float(timestep.flatten()[0].item()) if torch.is_tensor(timestep) else float(timestep)
+            idx = (self._ts_host == tv).nonzero()
+            self._step_index = idx[0].item() if len(idx) > 0 else int(torch.argmin((self._ts_host - tv).abs()).item())
+        i = self._step_index
+        nxt = self._sig_host[i + 1] if i + 1 < len(self._sig_host) else torch.zeros(())
+        coef = float(nxt - self._sig_host[i])
+        self._step_index += 1
+        return SchedulerOutput(ops.lincomb([sample.to(torch.float32).contiguous(),
+                                            model_output.to(torch.float32).contiguous()], [1.0, coef]))
