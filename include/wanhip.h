@@ -178,14 +178,21 @@ int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int H, int W, 
 typedef int (*wan_poll_fn)(void* user, int block_idx);
 
 /* Sequence-parallel hooks: the library calls back into the host runtime (torch.distributed /
- * RCCL) to all-gather K and V^T shards; NULL = single GPU.  gather(user, which, send, recv,
- * bytes_per_rank, stream): which 0 = K, 1 = V^T. */
-typedef int (*wan_gather_fn)(void* user, int which, const void* send, void* recv, int64_t bytes,
-                             void* stream);
+ * RCCL) to all-gather the K and V^T shards; NULL = single GPU.
+ *   gather_begin(user, which, send, recv, bytes_per_rank, stream): start the all-gather of `send`
+ *       into recv[world][bytes]; which 0 = K, 1 = V^T.  May return before the collective has run
+ *       (RCCL: enqueued on a side stream behind everything already on `stream`).
+ *   gather_wait(user, which, stream): make `stream` wait for that collective.
+ * wan_dit_forward issues the V^T gather right after the V projection so that it overlaps the Q/K
+ * projections and the RMSNorm+RoPE kernel; both waits sit immediately before the attention launch. */
+typedef int (*wan_gather_begin_fn)(void* user, int which, const void* send, void* recv, int64_t bytes,
+                                   void* stream);
+typedef int (*wan_gather_wait_fn)(void* user, int which, void* stream);
 typedef struct {
   int rank, world;          /* this rank, number of sequence shards */
   int64_t tok0, tok_local;  /* first global token and number of local tokens */
-  wan_gather_fn gather;
+  wan_gather_begin_fn gather_begin;
+  wan_gather_wait_fn gather_wait;
   void* user;
 } wan_sp_info;
 

@@ -1,0 +1,6 @@
+#!/bin/bash
+set -u
+mkdir -p gpurun_out
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tee gpurun_out/pytest_gpu.log | tail -15

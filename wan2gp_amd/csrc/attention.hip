@@ -322,6 +322,9 @@ extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan
       else if (!strcmp(ev, "v4_4")) variant = 13;
       else if (!strcmp(ev, "v4r_4")) variant = 14;
       else if (!strcmp(ev, "v4_8s3")) variant = 15;  // pipelined + 3-stage ring
+      else if (!strcmp(ev, "v5_8")) variant = 16;    // hand-placed interleave, VALU row sums
+      else if (!strcmp(ev, "v5r_8")) variant = 17;   // hand-placed interleave, MFMA row sums
+      else if (!strcmp(ev, "v5_4")) variant = 18;
       else if (!strncmp(ev, "abl", 3)) variant = 100 + atoi(ev + 3);  // timing ablations: abl8 / abl16 / abl32 / abl24 / abl48 / abl56
     }
   }
@@ -338,6 +341,9 @@ extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan
       case 13: fl = 4; nwv = 4; break;
       case 14: fl = 6; nwv = 4; break;
       case 15: fl = 4 | 2; md = 2; break;
+      case 16: fl = 64; break;
+      case 17: fl = 66; break;
+      case 18: fl = 64; nwv = 4; break;
       default: if (variant >= 100) fl = variant - 100; break;
     }
     return wan_attention_pp_launch(fl, md, nwv, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride,

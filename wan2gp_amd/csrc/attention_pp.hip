@@ -298,6 +298,129 @@ __device__ __forceinline__ void tile_fast(lds_cchar* smem, const int (&kaddr)[8]
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- tile_fast2: the same sub-tile pipeline with a HAND-PLACED interleave ---------------------------------
+// hipcc's scheduler did not honour the sched_group_barrier pattern of tile_fast (it clustered the 8 MFMAs in
+// front of the softmax VALU), so here every MFMA is followed by one small softmax chunk and the order is
+// pinned with sched_barrier(0) after each item:  M max M xhalf M exp M exp M exp M exp M M
+#define SB() __builtin_amdgcn_sched_barrier(0)
+struct SmxState {
+  float mt, mb, m_prev, lsum;
+};
+__device__ __forceinline__ void smx_max(const f32x16& a, SmxState& x) {
+  float m = fmaxf(a[0], a[1]);
+#pragma unroll
+  for (int r = 2; r < 16; ++r) m = fmaxf(m, a[r]);
+  x.mt = m;
+}
+__device__ __forceinline__ void smx_xhalf(SmxState& x, float& m_run, float c) {
+  const float m_new = fmaxf(m_run, xhalf_max(x.mt));
+  x.m_prev = m_run;
+  m_run = m_new;
+  x.mb = m_new * c;
+  x.lsum = 0.f;
+}
+template <int R0, bool ROWSUM_MFMA>
+__device__ __forceinline__ void smx_exp4(const f32x16& a, uint32_t (&pk)[8], SmxState& x, float c) {
+  const float p0 = __builtin_amdgcn_exp2f(a[R0] * c - x.mb), p1 = __builtin_amdgcn_exp2f(a[R0 + 1] * c - x.mb);
+  const float p2 = __builtin_amdgcn_exp2f(a[R0 + 2] * c - x.mb), p3 = __builtin_amdgcn_exp2f(a[R0 + 3] * c - x.mb);
+  if (!ROWSUM_MFMA) x.lsum += (p0 + p1) + (p2 + p3);
+  pk[R0 >> 1] = cvt_pk_bf16_pp(p0, p1);
+  pk[(R0 >> 1) + 1] = cvt_pk_bf16_pp(p2, p3);
+}
+
+template <int ST, int NST, bool ROWSUM_MFMA>
+__device__ __forceinline__ void tile_fast2(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
+                                           const mfma_bf16x8 (&qf)[8], PPState& st, float c) {
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint4 oraw;
+  oraw.x = oraw.y = oraw.z = oraw.w = 0x3f803f80u;
+  const mfma_bf16x8 ones = __builtin_bit_cast(mfma_bf16x8, oraw);
+  mfma_bf16x8 kf0[8], kf1[8], va0[4], va1[4], vb0[4], vb1[4];
+  f32x16 s0, s1;
+  SmxState x0, x1;
+  constexpr int KB = ST * IMG, VB = NST * IMG + ST * IMG;
+#define MF(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kf0[ks] = *(lds_frag*)(smem + KB + kaddr[ks]);
+  SB();
+  // B1: QK^T(T0); K(T1) fragment reads issued underneath
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) kf1[ks] = *(lds_frag*)(smem + (KB + 8192) + kaddr[ks]);
+  s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+  for (int ks = 1; ks < 8; ++ks) MF(s0, kf0[ks], qf[ks]);
+  SB();
+  // B2: QK^T(T1) with softmax(T0) chunks between the MFMAs
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) va0[dt] = *(lds_frag*)(smem + (VB + dt * 4096) + vaddr[0]);
+  s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[0], qf[0], zero16, 0, 0, 0); SB();
+  smx_max(s0, x0); SB();
+  MF(s1, kf1[1], qf[1]); SB();
+  smx_xhalf(x0, st.m_run, c); SB();
+  MF(s1, kf1[2], qf[2]); SB();
+  smx_exp4<0, ROWSUM_MFMA>(s0, st.pk[0], x0, c); SB();
+  MF(s1, kf1[3], qf[3]); SB();
+  smx_exp4<4, ROWSUM_MFMA>(s0, st.pk[0], x0, c); SB();
+  MF(s1, kf1[4], qf[4]); SB();
+  smx_exp4<8, ROWSUM_MFMA>(s0, st.pk[0], x0, c); SB();
+  MF(s1, kf1[5], qf[5]); SB();
+  smx_exp4<12, ROWSUM_MFMA>(s0, st.pk[0], x0, c); SB();
+  MF(s1, kf1[6], qf[6]);
+  MF(s1, kf1[7], qf[7]); SB();
+  rescale_if_moved<ROWSUM_MFMA>(st, x0.m_prev, c);
+  if (!ROWSUM_MFMA) st.l_run += x0.lsum;
+  // B3: PV(T0) with softmax(T1) chunks between the MFMAs
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) va1[dt] = *(lds_frag*)(smem + (VB + dt * 4096) + vaddr[1]);
+  {
+    uint4 pr;
+    pr.x = st.pk[0][0]; pr.y = st.pk[0][1]; pr.z = st.pk[0][2]; pr.w = st.pk[0][3];
+    const mfma_bf16x8 pf = __builtin_bit_cast(mfma_bf16x8, pr);
+    pr.x = st.pk[0][4]; pr.y = st.pk[0][5]; pr.z = st.pk[0][6]; pr.w = st.pk[0][7];
+    const mfma_bf16x8 pg = __builtin_bit_cast(mfma_bf16x8, pr);
+    MF(st.accO[0], va0[0], pf); SB();
+    smx_max(s1, x1); SB();
+    MF(st.accO[1], va0[1], pf); SB();
+    smx_xhalf(x1, st.m_run, c); SB();
+    MF(st.accO[2], va0[2], pf); SB();
+    smx_exp4<0, ROWSUM_MFMA>(s1, st.pk[1], x1, c); SB();
+    MF(st.accO[3], va0[3], pf); SB();
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vb0[dt] = *(lds_frag*)(smem + (VB + dt * 4096) + vaddr[2]);  // va0 is dead now
+    smx_exp4<4, ROWSUM_MFMA>(s1, st.pk[1], x1, c); SB();
+    MF(st.accO[0], va1[0], pg); SB();
+    smx_exp4<8, ROWSUM_MFMA>(s1, st.pk[1], x1, c); SB();
+    MF(st.accO[1], va1[1], pg); SB();
+    smx_exp4<12, ROWSUM_MFMA>(s1, st.pk[1], x1, c); SB();
+    MF(st.accO[2], va1[2], pg);
+    MF(st.accO[3], va1[3], pg);
+    if (ROWSUM_MFMA) { MF(st.accL, ones, pf); MF(st.accL, ones, pg); }
+    SB();
+  }
+  // NOTE: PV(T0) used the max as of sub-tile T0; the T1 rescale below multiplies O (which now includes P0 V0,
+  // exponentiated against m after T0) by exp2((m_T0 - m_T1) c): exactly once, before P1 V1 is added.
+  rescale_if_moved<ROWSUM_MFMA>(st, x1.m_prev, c);
+  if (!ROWSUM_MFMA) st.l_run += x1.lsum;
+  // B4: PV(T1)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) vb1[dt] = *(lds_frag*)(smem + (VB + dt * 4096) + vaddr[3]);
+  {
+    uint4 pr;
+    pr.x = st.pk[1][0]; pr.y = st.pk[1][1]; pr.z = st.pk[1][2]; pr.w = st.pk[1][3];
+    const mfma_bf16x8 pf = __builtin_bit_cast(mfma_bf16x8, pr);
+    pr.x = st.pk[1][4]; pr.y = st.pk[1][5]; pr.z = st.pk[1][6]; pr.w = st.pk[1][7];
+    const mfma_bf16x8 pg = __builtin_bit_cast(mfma_bf16x8, pr);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) MF(st.accO[dt], vb0[dt], pf);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) MF(st.accO[dt], vb1[dt], pg);
+    if (ROWSUM_MFMA) { MF(st.accL, ones, pf); MF(st.accL, ones, pg); }
+  }
+  SB();
+#undef MF
+}
+#undef SB
+
 // MODE 0: single-phase schedule (all waves: QK^T -> softmax -> PV per tile, one barrier per tile) with
 //         the static-stage / precomputed-address / 32-bit-DMA-offset loop body ("v2" of attention.hip)
 // MODE 1: two-phase ping-pong schedule described above (NW must be 8)
@@ -310,6 +433,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp_kernel(const bf16_t* __res
   constexpr bool PRIO = (FLAGS & 1) != 0;
   constexpr bool ROWSUM = (FLAGS & 2) != 0;     // row sums l on the matrix pipe (ones x P^T) instead of v_add
   constexpr bool PIPELINED = (FLAGS & 4) != 0;  // software-pipelined tile_fast for full tiles (MODE 0/2)
+  constexpr bool HANDSCHED = (FLAGS & 64) != 0;  // tile_fast2 (hand-placed MFMA/softmax interleave)
   constexpr bool ABL_NOSM = (FLAGS & 8) != 0, ABL_NODMA = (FLAGS & 16) != 0, ABL_NOBAR = (FLAGS & 32) != 0;  // timing ablations
   constexpr int NST = (MODE == 2) ? 3 : 2;  // LDS ring depth
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stage 0..NST-1][V^T stage 0..NST-1]
@@ -467,7 +591,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_pp_kernel(const bf16_t* __res
 #define COMPUTE_TILE(STG)                                                                                   \
   {                                                                                                         \
     const int64_t kv0_ = next_kv0();                                                                        \
-    if (PIPELINED && kv0_ + KVBLK <= Lk) {                                                                  \
+    if (HANDSCHED && kv0_ + KVBLK <= Lk) {                                                                  \
+      tile_fast2<STG, NST, ROWSUM>(lds, kaddr, vaddr, qf, st, scale_log2e);                                 \
+    } else if (PIPELINED && kv0_ + KVBLK <= Lk) {                                                           \
       tile_fast<STG, NST, ROWSUM>(lds, kaddr, vaddr, qf, st, scale_log2e);                                  \
     } else {                                                                                                \
       qk_softmax<STG, PRIO, NST, ROWSUM, ABL_NOSM>(lds, kaddr, vaddr, qf, st, vf, kv0_, Lk, half, scale_log2e); \
@@ -592,6 +718,9 @@ int wan_attention_pp_launch(int flags, int mode, int nw, const bf16_t* q, const 
     PP_LAUNCH(2, 1, 8);
   } else if (mode == 2) {
     if (flags & 4) PP_LAUNCH(6, 2, 8); else PP_LAUNCH(2, 2, 8);
+  } else if (flags & 64) {
+    if (nw == 8) { if (flags & 2) PP_LAUNCH(66, 0, 8); else PP_LAUNCH(64, 0, 8); }
+    else { if (flags & 2) PP_LAUNCH(66, 0, 4); else PP_LAUNCH(64, 0, 4); }
   } else if (nw == 8 && (flags & 56)) {  // timing ablations (tools/bench_attn.py only)
     switch (flags & 56) {
       case 8: PP_LAUNCH(8, 0, 8); break;

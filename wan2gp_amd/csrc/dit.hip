@@ -307,7 +307,8 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
               (long long)L, world);
   const int64_t Ll = L / world;
   const int64_t tok0 = sp ? sp->tok0 : 0;
-  WAN_REQUIRE(!sp || (sp->tok_local == Ll && sp->tok0 == (int64_t)sp->rank * Ll && (world == 1 || sp->gather)),
+  WAN_REQUIRE(!sp || (sp->tok_local == Ll && sp->tok0 == (int64_t)sp->rank * Ll &&
+                      (world == 1 || (sp->gather_begin && sp->gather_wait))),
               "wan_dit_forward: inconsistent sequence-parallel info");
   WAN_REQUIRE((g.in_dim > 16) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > 16 (model.py:1597)");
   Bufs b;
@@ -345,22 +346,24 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
     const Layer& Lw = c->layers[i];
     // -- self attention (model.py:632-660) --
     RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
-    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream));
-    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream));
+    // V^T first: under sequence parallelism its all-gather then overlaps the Q/K projections + RMSNorm/RoPE
     for (int s = 0; s < S; ++s)
       RC(wan_gemm_bf16(b.xm + (int64_t)s * Ll * d, d, Lw.self.v.w, Lw.self.v.b, b.vt + (int64_t)s * d * Lp, Lp, Ll, d, d,
                        WAN_EPI_TRANSPOSED, nullptr, nullptr, nullptr, 0, -1, 1, stream));
+    if (world > 1 && sp->gather_begin(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
+      wan_set_error("wan_dit_forward: V^T all-gather failed");
+      return 3;
+    }
+    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream));
+    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream));
     {
       ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
       RC(wan_rmsnorm_rope(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, stream));
     }
     if (world > 1) {
-      if (sp->gather(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream)) {
-        wan_set_error("wan_dit_forward: K all-gather failed");
-        return 3;
-      }
-      if (sp->gather(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
-        wan_set_error("wan_dit_forward: V^T all-gather failed");
+      if (sp->gather_begin(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream) ||
+          sp->gather_wait(sp->user, 1, stream) || sp->gather_wait(sp->user, 0, stream)) {
+        wan_set_error("wan_dit_forward: K / V^T all-gather failed");
         return 3;
       }
       ProfScope ps(PROF_SELF_ATTN, st);

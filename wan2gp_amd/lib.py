@@ -28,11 +28,12 @@ class DitConfig(ctypes.Structure):
 
 POLL_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int)
 GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p)
+GATHER_WAIT_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p)
 
 
 class SpInfo(ctypes.Structure):
     _fields_ = [("rank", c_int), ("world", c_int), ("tok0", c_int64), ("tok_local", c_int64),
-                ("gather", GATHER_FN), ("user", c_void_p)]
+                ("gather_begin", GATHER_FN), ("gather_wait", GATHER_WAIT_FN), ("user", c_void_p)]
 
 
 # name -> (restype, argtypes); the single source of truth mirrored by tests/test_abi.py

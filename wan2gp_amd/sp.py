@@ -18,7 +18,7 @@ from ctypes import c_void_p
 import torch
 import torch.distributed as dist
 
-from .lib import GATHER_FN, SpInfo
+from .lib import GATHER_FN, GATHER_WAIT_FN, SpInfo
 
 
 def shard_range(L: int, rank: int, world: int):
@@ -34,7 +34,9 @@ class SequenceParallel:
         self.rank, self.world, self.group = rank, world, group
         self._ws = None
         self._cb = None
+        self._cbw = None
         self._info = None
+        self._pending = {}          # which -> async Work handle of the in-flight all-gather
 
     # ---- collectives (torch.distributed; backend nccl == RCCL on ROCm) ---------------------------
     def _all_gather_into(self, out: torch.Tensor, send: torch.Tensor):
@@ -61,13 +63,30 @@ class SequenceParallel:
         against the compute stream."""
         self._ws = ws
 
-    def _gather_cb(self, user, which, send, recv, nbytes, stream):
+    def _gather_begin_cb(self, user, which, send, recv, nbytes, stream):
+        """Start the all-gather of a workspace region.  RCCL: async on the communicator's stream, ordered behind
+        the work already enqueued on the compute stream; the compute stream keeps going (overlap)."""
         try:
             base = self._ws.data_ptr()
             s_off, r_off = send - base, recv - base
             sv = self._ws[s_off:s_off + nbytes]
             rv = self._ws[r_off:r_off + nbytes * self.world]
-            self._all_gather_into(rv, sv)
+            if dist.get_backend(self.group) == "gloo":
+                self._all_gather_into(rv, sv)          # host-staged, synchronous
+                self._pending[which] = None
+            else:
+                self._pending[which] = dist.all_gather_into_tensor(rv, sv, group=self.group, async_op=True)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _gather_wait_cb(self, user, which, stream):
+        try:
+            w = self._pending.pop(which, None)
+            if w is not None:
+                w.wait()                               # current stream waits for the collective's completion event
             return 0
         except Exception:
             import traceback
@@ -77,8 +96,9 @@ class SequenceParallel:
     def make_info(self, L: int) -> SpInfo:
         tok0, n = shard_range(L, self.rank, self.world)
         if self._cb is None:
-            self._cb = GATHER_FN(self._gather_cb)      # keep the ctypes thunk alive
-        self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, None)
+            self._cb = GATHER_FN(self._gather_begin_cb)      # keep the ctypes thunks alive
+            self._cbw = GATHER_WAIT_FN(self._gather_wait_cb)
+        self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, None)
         return self._info
 
     def gather_output(self, tok_major: torch.Tensor, grid):
