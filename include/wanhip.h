@@ -48,6 +48,14 @@ int wan_device_cus(void);
 int wan_rmsnorm_rope(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const wan_bf16* wk,
                      const float* cos, const float* sin, int64_t rows, int64_t L, int64_t pos0,
                      int d, float eps, void* stream);
+/* Same, with q multiplied by q_scale in fp32 in front of its single bf16 rounding (k is untouched).
+ * With q_scale = wan_attention_qscale() the result feeds wan_attention_prescaled: the softmax scale of
+ * flash_attention (shared/attention.py:399 ff., softmax_scale = 1/sqrt(head_dim)) and the exp -> exp2
+ * base change are folded into q, so the attention kernel's score tile comes out of the matrix pipe ready
+ * for exp2.  q then carries ONE rounding, of q*scale instead of q (same relative error). */
+int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const wan_bf16* wk,
+                            const float* cos, const float* sin, int64_t rows, int64_t L, int64_t pos0,
+                            int d, float eps, float q_scale, void* stream);
 
 /* LayerNorm (no affine) + AdaLN modulate: out = bf16(bf16(LN(x) * bf16(1+scale)) + shift),
  * scale = bf16(mod[scale_idx] + e[b][scale_idx]), shift likewise.
@@ -109,6 +117,14 @@ int wan_attention(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_
 int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B,
                       int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg,
                       int64_t k_seg_stride, int64_t vt_seg_stride, void* stream);
+/* wan_attention_seg for a q that already holds q * wan_attention_qscale() (see wan_rmsnorm_rope_scaled):
+ * runs the issue-balanced 4x64 kernel (csrc/attention_w64q.hip) without its in-kernel pre-scaling pass. */
+int wan_attention_prescaled(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B,
+                            int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg,
+                            int64_t k_seg_stride, int64_t vt_seg_stride, void* stream);
+/* (1/sqrt(128)) * log2(e): the factor wan_attention_prescaled expects folded into q */
+float wan_attention_qscale(void);
+
 
 /* vt[b, c, l] = v[b, l, c] for c < C, l < L; zero-fills l in [L, ldv). */
 int wan_transpose_v(const wan_bf16* v, wan_bf16* vt, int B, int64_t L, int64_t ldv, int C,

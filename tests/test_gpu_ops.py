@@ -264,6 +264,80 @@ def test_attention_segments_match_contiguous(ops):
     assert (got - ref).abs().max().item() <= 1.5e-2
 
 
+# ---- pre-scaled attention path (wan_rmsnorm_rope_scaled -> wan_attention_prescaled, csrc/attention_w64q.hip) --------
+def _prescaled_ref(qs, k, v):
+    """Exact attention for a q that already holds q * scale * log2(e): P = 2^(qs k^T - rowmax) (fp32)."""
+    B, Lq, H, _ = qs.shape
+    kk = k.float().expand(B, -1, -1, -1) if k.shape[0] != B else k.float()
+    vv = v.float().expand(B, -1, -1, -1) if v.shape[0] != B else v.float()
+    s = torch.einsum("bqhd,bkhd->bhqk", qs.float().double(), kk.double())
+    p = torch.exp2(s - s.amax(dim=-1, keepdim=True))
+    o = torch.einsum("bhqk,bkhd->bqhd", p / p.sum(dim=-1, keepdim=True), vv.double())
+    return o.float()
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,Bk", [(1, 128, 64, 1, 1), (2, 200, 333, 3, 2), (2, 131, 512, 2, 1), (1, 64, 1, 2, 1),
+                                          (1, 1000, 1000, 2, 1), (1, 5, 7, 1, 1), (1, 300, 4160, 1, 1)])
+def test_attention_prescaled_shapes(ops, B, Lq, Lk, H, Bk):
+    """Same rounding points as the kernel (q*scale rounded to bf16 once): tolerance as for the exact-scale kernels.
+    Against the true oracle (scale applied to fp32 scores) the extra q rounding may move an output by one bf16 ulp:
+    tolerance 2 bf16 ulps of max(|ref|, 1)."""
+    g = torch.Generator().manual_seed(Lq * 3 + Lk)
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF); k = torch.randn(Bk, Lk, H, 128, generator=g).to(BF)
+    v = torch.randn(Bk, Lk, H, 128, generator=g).to(BF)
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True).float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - _prescaled_ref(qs, k, v)).abs()
+    assert err.max().item() <= 1.5e-2 and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+    assert_bf16_close(got, O.attention(q, k, v, exact=True), frac=1.0, ulps=2, what="vs oracle", floor=1.0)
+
+
+def test_attention_prescaled_forced_rescale_and_segments(ops):
+    """Lazy reference max: a late spike far above the threshold must rescale O and l exactly once; a row whose scores are
+    all very negative must not underflow; 2 gathered kv segments == contiguous."""
+    g = torch.Generator().manual_seed(99)
+    q = torch.randn(1, 64, 1, 128, generator=g).to(BF); k = torch.randn(1, 640, 1, 128, generator=g).to(BF)
+    v = torch.randn(1, 640, 1, 128, generator=g).to(BF)
+    k[0, 400] = (q[0, 3, 0].float() * 3.0).to(BF)
+    k[0, 130] = (q[0, 17, 0].float() * 2.0).to(BF)
+    q[0, 9] = (-4.0 * k[0, :, 0].float().mean(dim=0)).to(BF) - q[0, 9]        # a row with a distinctly shifted score range
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    vt = ops.transpose_v(cu(v))
+    got = ops.attention(cu(qs), cu(k), vt, q_prescaled=True).float().cpu()
+    err = (got - _prescaled_ref(qs, k, v)).abs()
+    assert torch.isfinite(got).all() and err.max().item() <= 1.5e-2, err.max().item()
+    S, Ll, H = 1, 320, 1
+    k2 = k.view(2, S, Ll, H, 128); v2 = v.view(2, S, Ll, H, 128)
+    vt2 = torch.stack([ops.transpose_v(cu(v2[0])), ops.transpose_v(cu(v2[1]))]).contiguous()
+    got2 = ops.attention(cu(qs), cu(k2.contiguous()), vt2, Lk=Ll, nseg=2, k_seg_stride=S * Ll * H * 128,
+                         vt_seg_stride=S * H * 128 * vt2.shape[-1], Bk=S, q_prescaled=True).float().cpu()
+    assert (got2 - _prescaled_ref(qs, k, v)).abs().max().item() <= 1.5e-2
+
+
+def test_rmsnorm_rope_scaled(ops):
+    """q_scale is applied in fp32 in front of q's single bf16 rounding; k is untouched."""
+    g = torch.Generator().manual_seed(5)
+    B, f, hh, ww, d, H = 1, 2, 3, 4, 256, 2
+    L = f * hh * ww
+    cos, sin = O.rope_tables((f, hh, ww))
+    q = (torch.randn(B, L, d, generator=g) * 1.3).to(BF); k = torch.randn(B, L, d, generator=g).to(BF)
+    wq = (1 + 0.05 * torch.randn(d, generator=g)).to(BF); wk = (1 + 0.05 * torch.randn(d, generator=g)).to(BF)
+    c = ops.attention_qscale()
+    assert abs(c - 128 ** -0.5 * 1.4426950408889634) < 1e-7
+    g0, k0 = cu(q.clone()), cu(k.clone())
+    ops.rmsnorm_rope_(g0, k0, cu(wq), cu(wk), (cu(cos), cu(sin)))
+    g1, k1 = cu(q.clone()), cu(k.clone())
+    ops.rmsnorm_rope_(g1, k1, cu(wq), cu(wk), (cu(cos), cu(sin)), q_scale=c)
+    assert torch.equal(k0.cpu(), k1.cpu())
+    # unrounded reference: fp32 RoPE of the bf16-rounded norm output (the kernel's rounding points), times c
+    xn = O.rms_norm(q, wq, 1e-6).view(B, L, H, 128).float()
+    cs, sn = cos.view(1, L, 1, 128), sin.view(1, L, 1, 128)
+    rot = torch.stack([-xn[..., 1::2], xn[..., ::2]], dim=-1).flatten(-2)
+    exact = (xn * cs + rot * sn) * c
+    assert_bf16_close(g1.view(B, L, H, 128), exact.to(BF), frac=0.02, ulps=1, what="scaled q")
+
+
 def test_pay_attention_dropin_contract(ops):
     g = torch.Generator().manual_seed(3)
     q = cu(torch.randn(2, 70, 2, 128, generator=g).to(BF)); k = cu(torch.randn(1, 512, 2, 128, generator=g).to(BF))

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--variants", default="base,lean,lean_prio,lean8,lean8_prio")
+    ap.add_argument("--stamps", default="", help="variant that writes s_memtime stamps into O (w64t): print slot cycle deltas")
     a = ap.parse_args()
     Lk = a.Lk or a.L
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -28,6 +29,13 @@ def main():
     v = torch.randn(a.B, Lk, a.H, 128, device="cuda", generator=g).to(torch.bfloat16)
     vt = ops.transpose_v(v)
     variants = a.variants.split(",")
+    for sv in (a.stamps.split(",") if a.stamps else []):
+        os.environ["WAN_ATTN_VARIANT"] = sv
+        for _ in range(2):
+            o = ops.attention(q.clone(), k, vt)
+            torch.cuda.synchronize()
+            st = o.view(-1)[:24].view(torch.int64).cpu().tolist()
+            print("stamps", sv, "deltas(top->barrier, A, B, C, D):", [st[i + 1] - st[i] for i in range(5)], "tile:", st[5] - st[0])
     flops = 4.0 * a.B * a.H * a.L * Lk * 128
     outs, times = {}, {vn: [] for vn in variants}
     for vn in variants:

@@ -276,15 +276,39 @@ extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan
 int wan_attention_pp_launch(int flags, int mode, int nw, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
                             int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
                             int64_t vt_seg_stride, float scale_log2e, hipStream_t stream);
+int wan_attention_w64_launch(int flags, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
+                             int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
+                             int64_t vt_seg_stride, float scale_log2e, hipStream_t stream);
+int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
+                             int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
+                             int64_t vt_seg_stride, float scale_log2e, hipStream_t stream);
 
 extern "C" int wan_attention(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
                              int64_t Lq, int64_t Lk, int64_t ldv, int H, void* stream) {
   return wan_attention_seg(q, k, vt, o, B, Bk, Lq, Lk, ldv, H, 1, 0, 0, stream);
 }
 
+static int attention_dispatch(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
+                              int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
+                              int64_t vt_seg_stride, bool q_prescaled, void* stream);
+
 extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
                                  int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
                                  int64_t vt_seg_stride, void* stream) {
+  return attention_dispatch(q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, false, stream);
+}
+
+extern "C" int wan_attention_prescaled(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B,
+                                       int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg,
+                                       int64_t k_seg_stride, int64_t vt_seg_stride, void* stream) {
+  return attention_dispatch(q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, true, stream);
+}
+
+extern "C" float wan_attention_qscale(void) { return 0.08838834764831845f * 1.4426950408889634f; }
+
+static int attention_dispatch(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
+                              int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
+                              int64_t vt_seg_stride, bool q_prescaled, void* stream) {
   WAN_REQUIRE(q && k && vt && o, "wan_attention: null pointer");
   WAN_REQUIRE(nseg >= 1, "wan_attention: nseg must be >= 1");
   WAN_REQUIRE(B >= 1 && (Bk == B || Bk == 1), "wan_attention: Bk must be B or 1 (B=%d Bk=%d)", B, Bk);
@@ -301,7 +325,7 @@ extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan
   // measured on MI355X (profiles/r01_attn_variants.md): 8 waves sharing each K/V tile win for long
   // KV (self-attention), 4-wave blocks win for short KV (cross-attention, Lk = 512)
   // (v2 = static-stage loop body of attention_pp.hip MODE 0)
-  int variant = (Lk * (int64_t)nseg > 2048) ? 10 : 7;  // v2r_8 (row sums on the matrix pipe) : v2_4
+  int variant = (Lk * (int64_t)nseg > 2048) ? 20 : 7;  // w64 (4 waves x 64 q rows, exact softmax scaling) : v2_4
   if (Lk * (int64_t)H * 256 >= ((int64_t)1 << 32) || ldv * 256 >= ((int64_t)1 << 32)) variant = 3;  // 64-bit addressing kernel
   {
     const char* ev = getenv("WAN_ATTN_VARIANT");
@@ -325,9 +349,26 @@ extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan
       else if (!strcmp(ev, "v5_8")) variant = 16;    // hand-placed interleave, VALU row sums
       else if (!strcmp(ev, "v5r_8")) variant = 17;   // hand-placed interleave, MFMA row sums
       else if (!strcmp(ev, "v5_4")) variant = 18;
+      else if (!strcmp(ev, "w64")) variant = 20;     // attention_w64.hip: 4 waves x 64 q rows, VALU row sums
+      else if (!strcmp(ev, "w64r")) variant = 21;    // ... MFMA row sums
+      else if (!strcmp(ev, "w64t")) variant = 24;    // ... w64 + s_memtime stamps (tools/bench_attn.py --stamps)
+      else if (!strcmp(ev, "w64q")) variant = 28;    // attention_w64q.hip: issue-balanced 4 x 64 kernel (lazy max in the MFMA C operand)
+      else if (!strcmp(ev, "w64qt")) variant = 29;   // ... + s_memtime stamps
       else if (!strncmp(ev, "abl", 3)) variant = 100 + atoi(ev + 3);  // timing ablations: abl8 / abl16 / abl32 / abl24 / abl48 / abl56
     }
   }
+  if (q_prescaled) {  // only the w64q kernel takes a pre-scaled q
+    WAN_REQUIRE(Lk * (int64_t)H * 256 < ((int64_t)1 << 32) && ldv * 256 < ((int64_t)1 << 32),
+                "wan_attention_prescaled: K/V^T extent exceeds the 32-bit DMA offsets of the w64q kernel");
+    return wan_attention_w64q_launch((variant == 29 ? 1 : 0) | 2, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride,
+                                     vt_seg_stride, scale_log2e, as_stream(stream));
+  }
+  if (variant >= 28 && variant <= 29)
+    return wan_attention_w64q_launch(variant - 28, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride,
+                                     scale_log2e, as_stream(stream));
+  if (variant >= 20 && variant <= 24)
+    return wan_attention_w64_launch(variant - 20, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride,
+                                    scale_log2e, as_stream(stream));
   if (variant >= 5) {
     int fl = 0, md = 0, nwv = 8;
     switch (variant) {

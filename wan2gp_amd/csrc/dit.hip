@@ -341,6 +341,12 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
   // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups
   const int64_t rpb = rows;
 
+  // Self-attention: fold softmax scale * log2(e) into q inside the fused RMSNorm+RoPE kernel (in front of q's single
+  // bf16 rounding) and run the pre-scaled attention kernel.  WAN_DIT_EXACT_QSCALE=1 keeps the scale on the fp32 scores
+  // (reference rounding points; slower kernel).
+  static const bool exact_env = [] { const char* e = getenv("WAN_DIT_EXACT_QSCALE"); return e && e[0] == '1'; }();
+  const bool fold_qscale = !exact_env && Ll * (int64_t)nh * 256 < ((int64_t)1 << 32) && Lp * 256 < ((int64_t)1 << 32);
+
   for (int i = 0; i < g.num_layers; ++i) {
     if (poll && poll(poll_user, i)) return 1;  // model.py:1995-1998
     const Layer& Lw = c->layers[i];
@@ -358,7 +364,8 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
     RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream));
     {
       ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
-      RC(wan_rmsnorm_rope(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, stream));
+      RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps,
+                                 fold_qscale ? wan_attention_qscale() : 1.0f, stream));
     }
     if (world > 1) {
       if (sp->gather_begin(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream) ||
@@ -367,11 +374,11 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
         return 3;
       }
       ProfScope ps(PROF_SELF_ATTN, st);
-      RC(wan_attention_seg(b.q, b.kfull, b.vtfull, b.q, S, S, Ll, Ll, Lp, nh, world, rows * (int64_t)d,
-                           (int64_t)S * d * Lp, stream));
+      RC((fold_qscale ? wan_attention_prescaled : wan_attention_seg)(b.q, b.kfull, b.vtfull, b.q, S, S, Ll, Ll, Lp, nh, world,
+                                                                   rows * (int64_t)d, (int64_t)S * d * Lp, stream));
     } else {
       ProfScope ps(PROF_SELF_ATTN, st);
-      RC(wan_attention(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, stream));
+      RC((fold_qscale ? wan_attention_prescaled : wan_attention_seg)(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, stream));
     }
     RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb));
     // -- cross attention (model.py:663-668, :245-265) --

@@ -18,11 +18,12 @@ template <int NCH>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
     bf16_t* __restrict__ q, bf16_t* __restrict__ k, const bf16_t* __restrict__ wq,
     const bf16_t* __restrict__ wk, const float* __restrict__ cosT, const float* __restrict__ sinT,
-    int64_t rows, int64_t L, int64_t pos0, int d, float eps) {
+    int64_t rows, int64_t L, int64_t pos0, int d, float eps, float q_scale) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
   if (row >= rows) return;
+  const float oscale = (blockIdx.y == 0) ? q_scale : 1.0f;  // q only: fp32 scale folded in front of the ONE bf16 rounding
   bf16_t* x = (blockIdx.y == 0 ? q : k) + row * (int64_t)d;
   const bf16_t* w = (blockIdx.y == 0 ? wq : wk);
   const int nchunk = d >> 3;
@@ -66,6 +67,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
           y[j] = __fmul_rn(a, cs[j]) - __fmul_rn(b, sn[j]);
           y[j + 1] = __fmul_rn(b, cs[j + 1]) + __fmul_rn(a, sn[j + 1]);
         }
+      }
+      if (oscale != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] *= oscale;
       }
       *reinterpret_cast<uint4*>(x + c * 8) = pack8(y);
     }
@@ -345,6 +350,12 @@ static int pick_nch(int d) {
 extern "C" int wan_rmsnorm_rope(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const wan_bf16* wk,
                                 const float* cos, const float* sin, int64_t rows, int64_t L, int64_t pos0,
                                 int d, float eps, void* stream) {
+  return wan_rmsnorm_rope_scaled(q, k, wq, wk, cos, sin, rows, L, pos0, d, eps, 1.0f, stream);
+}
+
+extern "C" int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const wan_bf16* wk,
+                                       const float* cos, const float* sin, int64_t rows, int64_t L, int64_t pos0,
+                                       int d, float eps, float q_scale, void* stream) {
   WAN_REQUIRE(q && wq, "wan_rmsnorm_rope: q/wq null");
   WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_rmsnorm_rope: d=%d must be a multiple of 8 and <= 8192", d);
   WAN_REQUIRE((cos == nullptr) == (sin == nullptr), "wan_rmsnorm_rope: cos/sin must both be set or both null");
@@ -354,7 +365,7 @@ extern "C" int wan_rmsnorm_rope(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, co
   const int nch = pick_nch(d);
   dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), k ? 2 : 1);
   DISPATCH_NCH(nch, hipLaunchKernelGGL(rmsnorm_rope_kernel<NCH>, grid, dim3(256), 0, as_stream(stream), q, k, wq,
-                                       wk, cos, sin, rows, L, pos0, d, eps));
+                                       wk, cos, sin, rows, L, pos0, d, eps, q_scale));
   WAN_LAUNCH_CHECK();
   return 0;
 }

@@ -43,6 +43,8 @@ SIGNATURES = {
     "wan_device_cus": (c_int, []),
     "wan_rmsnorm_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                  c_int64, c_int, c_float, c_void_p]),
+    "wan_rmsnorm_rope_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                        c_int64, c_int, c_float, c_float, c_void_p]),
     "wan_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                                 c_int, c_float, c_void_p]),
     "wan_ln_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
@@ -54,6 +56,9 @@ SIGNATURES = {
                               c_int, c_void_p]),
     "wan_attention_seg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
                                   c_int, c_int, c_int64, c_int64, c_void_p]),
+    "wan_attention_prescaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
+                                        c_int, c_int, c_int64, c_int64, c_void_p]),
+    "wan_attention_qscale": (c_float, []),
     "wan_transpose_v": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "wan_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_int, c_void_p]),

@@ -25,10 +25,11 @@ def _req(t, dtype, name):
         raise _L.WanHipError(f"{name} must be contiguous")
 
 
-def rmsnorm_rope_(q, k, wq, wk, freqs=None, eps=1e-6, L=None, pos0=0):
+def rmsnorm_rope_(q, k, wq, wk, freqs=None, eps=1e-6, L=None, pos0=0, q_scale=1.0):
     """In-place WanRMSNorm(q)[, WanRMSNorm(k)][, apply_rotary_emb([q,k], freqs)].
     q,k [B,L,d] or [B,L,H,128]; freqs = (cos,sin) [Ltot,128] fp32 or None.
-    (model.py:343-350; posemb_layers.py:288-340)"""
+    (model.py:343-350; posemb_layers.py:288-340).  q_scale: fp32 factor folded into q in front of its bf16
+    rounding (attention_qscale() for attention(..., q_prescaled=True))."""
     for t, n in ((q, "q"), (k, "k"), (wq, "wq"), (wk, "wk")):
         _req(t, BF16, n)
     d = wq.numel()
@@ -39,9 +40,14 @@ def rmsnorm_rope_(q, k, wq, wk, freqs=None, eps=1e-6, L=None, pos0=0):
     if freqs is not None:
         cos, sin = freqs
         _req(cos, torch.float32, "cos"); _req(sin, torch.float32, "sin")
-    check(_L.load().wan_rmsnorm_rope(ptr(q), ptr(k), ptr(wq), ptr(wk), ptr(cos), ptr(sin), rows, L, pos0, d, eps,
-                                     stream_ptr()), "wan_rmsnorm_rope")
+    check(_L.load().wan_rmsnorm_rope_scaled(ptr(q), ptr(k), ptr(wq), ptr(wk), ptr(cos), ptr(sin), rows, L, pos0, d, eps,
+                                            float(q_scale), stream_ptr()), "wan_rmsnorm_rope")
     return q, k
+
+
+def attention_qscale():
+    """(1/sqrt(128)) * log2(e): the factor attention(..., q_prescaled=True) expects folded into q."""
+    return float(_L.load().wan_attention_qscale())
 
 
 def ln_modulate(x, mod, e, shift_idx, scale_idx, eps=1e-6, out=None):
@@ -114,10 +120,10 @@ def transpose_v(v, ldv=None):
     return vt
 
 
-def attention(q, k, vt, Lk=None, out=None, nseg=1, k_seg_stride=0, vt_seg_stride=0, Bk=None):
+def attention(q, k, vt, Lk=None, out=None, nseg=1, k_seg_stride=0, vt_seg_stride=0, Bk=None, q_prescaled=False):
     """softmax(q k^T / sqrt(128)) v with v given transposed.  q [B,Lq,H,128], k [Bk,Lk,H,128], vt [Bk,H*128,ldv].
     nseg > 1: k / vt hold `nseg` gathered segments ([seg][Bk][Lk][H*128], [seg][Bk][H*128][ldv]); pass Lk, Bk
-    and the segment strides (elements) explicitly."""
+    and the segment strides (elements) explicitly.  q_prescaled: q already holds q * attention_qscale()."""
     _req(q, BF16, "q"); _req(k, BF16, "k"); _req(vt, BF16, "vt")
     B, Lq, H, D = q.shape
     if D != 128:
@@ -127,8 +133,9 @@ def attention(q, k, vt, Lk=None, out=None, nseg=1, k_seg_stride=0, vt_seg_stride
     Lk = Lk if Lk is not None else k.shape[1]
     ldv = vt.shape[-1]
     out = torch.empty_like(q) if out is None else out
-    check(_L.load().wan_attention_seg(ptr(q), ptr(k), ptr(vt), ptr(out), B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride,
-                                      vt_seg_stride, stream_ptr()), "wan_attention")
+    fn = _L.load().wan_attention_prescaled if q_prescaled else _L.load().wan_attention_seg
+    check(fn(ptr(q), ptr(k), ptr(vt), ptr(out), B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, stream_ptr()),
+          "wan_attention")
     return out
 
 
