@@ -34,8 +34,12 @@ def main():
         for _ in range(2):
             o = ops.attention(q.clone(), k, vt)
             torch.cuda.synchronize()
-            st = o.view(-1)[:24].view(torch.int64).cpu().tolist()
-            print("stamps", sv, "deltas(top->barrier, A, B, C, D):", [st[i + 1] - st[i] for i in range(5)], "tile:", st[5] - st[0])
+            st = o.view(-1)[:80].view(torch.int64).cpu().tolist()
+            if sv == "w64ft":   # fine stamps: [top, after barrier, tile start, then after gaps 3,7,...,67]
+                print("stamps", sv, "top->barrier", st[1] - st[0], "per 4 gaps:", [st[i + 1] - st[i] for i in range(2, 19)],
+                      "tile:", st[19] - st[0])
+            else:
+                print("stamps", sv, "deltas(top->barrier, A, B, C, D):", [st[i + 1] - st[i] for i in range(5)], "tile:", st[5] - st[0])
     flops = 4.0 * a.B * a.H * a.L * Lk * 128
     outs, times = {}, {vn: [] for vn in variants}
     for vn in variants:

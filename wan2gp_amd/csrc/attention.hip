@@ -354,15 +354,21 @@ static int attention_dispatch(const wan_bf16* q, const wan_bf16* k, const wan_bf
       else if (!strcmp(ev, "w64t")) variant = 24;    // ... w64 + s_memtime stamps (tools/bench_attn.py --stamps)
       else if (!strcmp(ev, "w64q")) variant = 28;    // attention_w64q.hip: issue-balanced 4 x 64 kernel (lazy max in the MFMA C operand)
       else if (!strcmp(ev, "w64qt")) variant = 29;   // ... + s_memtime stamps
+      else if (!strcmp(ev, "w64f")) variant = 32;    // ... flat one-exp-per-gap schedule
+      else if (!strcmp(ev, "w64ft")) variant = 33;
       else if (!strncmp(ev, "abl", 3)) variant = 100 + atoi(ev + 3);  // timing ablations: abl8 / abl16 / abl32 / abl24 / abl48 / abl56
     }
   }
-  if (q_prescaled) {  // only the w64q kernel takes a pre-scaled q
+  if (q_prescaled) {  // only the w64q kernel takes a pre-scaled q; flat schedule unless WAN_ATTN_VARIANT=w64q / w64qt
     WAN_REQUIRE(Lk * (int64_t)H * 256 < ((int64_t)1 << 32) && ldv * 256 < ((int64_t)1 << 32),
                 "wan_attention_prescaled: K/V^T extent exceeds the 32-bit DMA offsets of the w64q kernel");
-    return wan_attention_w64q_launch((variant == 29 ? 1 : 0) | 2, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride,
-                                     vt_seg_stride, scale_log2e, as_stream(stream));
+    const int fl = 2 | ((variant == 28 || variant == 29) ? 0 : 4) | ((variant == 29 || variant == 33) ? 1 : 0);
+    return wan_attention_w64q_launch(fl, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, scale_log2e,
+                                     as_stream(stream));
   }
+  if (variant >= 32 && variant <= 33)
+    return wan_attention_w64q_launch((variant - 32) | 4, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride,
+                                     scale_log2e, as_stream(stream));
   if (variant >= 28 && variant <= 29)
     return wan_attention_w64q_launch(variant - 28, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride,
                                      scale_log2e, as_stream(stream));

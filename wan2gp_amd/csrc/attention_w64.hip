@@ -40,7 +40,7 @@ struct QBlock {      // one 32-row q-block of the wave
 // reg r of s[T] <-> kv = kv0 + T*32 + (r&7) + 8*half + 16*(r>>3); the lane's q row is lane&31.
 // kv_rem = Lk - kv0 (valid kv rows left in the segment, counted from this tile's first row)
 __device__ __forceinline__ void smx_mask_tail(QBlock& q, int kv_rem, int half) {
-  if (kv_rem < KVBLK) {
+  if (__builtin_expect(kv_rem < KVBLK, 0)) {
     asm volatile("" ::: "memory");  // keep this rare path a real (wave-uniform) branch
     const int lim = kv_rem - 8 * half;
 #pragma unroll
@@ -80,7 +80,7 @@ __device__ __forceinline__ void smx_exp4(QBlock& q, float c) {
 }
 template <bool ROWSUM>
 __device__ __forceinline__ void rescale_if_moved(QBlock& q, float c) {
-  if (!__all(q.m_run == q.m_prev)) {  // running max moved: rescale O and l once, before P(t) enters O
+  if (__builtin_expect(!__all(q.m_run == q.m_prev), 0)) {  // running max moved: rescale O and l once, before P(t) enters O
     asm volatile("" ::: "memory");
     // opaque AGPR re-definitions on both sides keep the accumulator <-> VGPR copies INSIDE this rare branch (without
     // them the allocator hoists 128 v_accvgpr_read to the top of every tile)
@@ -310,21 +310,7 @@ __global__ __launch_bounds__(256) void attn_w64_kernel(const bf16_t* __restrict_
   const int tps = (Lk32 + KVBLK - 1) / KVBLK;
   const int ntile = tps * nseg;
   Dma dma;
-  dma.k = dma.k0 = reinterpret_cast<const char*>(kbase);
-  dma.v = dma.v0 = reinterpret_cast<const char*>(vbase);
-  dma.kseg = k_seg_stride * 2;
-  dma.vseg = vt_seg_stride * 2;
-  dma.tt = 0; dma.seg = 0; dma.tps = tps; dma.left = ntile;
-  dma.tail_lim = Lk32 - 1 - (tps - 1) * KVBLK;
-  dma.rs2 = (uint32_t)(rs * 2);
-  dma.ldv2 = (uint32_t)(ldv * 2);
-  {
-    const uint32_t kr0 = (uint32_t)(tid >> 4);
-    dma.krow0 = (kr0 & 3u) | ((kr0 & 4u) << 1) | ((kr0 & 8u) >> 1);
-    dma.kcol = (uint32_t)(((tid & 15) ^ (int)kr0) << 4);
-    dma.vofs0 = (uint32_t)(tid >> 3) * dma.ldv2 + (uint32_t)(((tid & 7) ^ ((tid >> 4) & 7)) << 4);
-  }
-  dma.wave = wave;
+  dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave);
   int cur_tt = 0;
   auto next_kv_rem = [&]() {  // valid kv rows from the start of the tile being consumed to the end of its segment
     const int rem = Lk32 - cur_tt * KVBLK;

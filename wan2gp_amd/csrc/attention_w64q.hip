@@ -47,6 +47,9 @@ struct QB {          // one 32-row q-block of the wave
   float l_run;       // this lane's share of the row sum (relative to m_ref)
   float mt;          // row max being reduced
   float pe0, pe1;    // exp2 of the pair whose sum / pack is still pending
+  float cur0, ps;    // flat schedule: first exp2 of the pair in progress; sum of the pending pair
+  float tmax;        // flat schedule: row max of S' found by chunk 4 ...
+  bool need;         // ... and its wave-uniform verdict, consumed by chunk 5 one MFMA later (a branch on a fresh VALU compare stalls)
 };
 
 // O^T += V^T P^T with the V^T fragment in the accumulator file
@@ -61,7 +64,11 @@ __device__ __forceinline__ void pv_mfma(f32x16& acc, const mfma_bf16x8& v, const
 __device__ __forceinline__ void qk_stepq(QB& x, const mfma_bf16x8 (&kf)[2][8], const mfma_bf16x8 (&qf)[8],
                                          const mfma_bf16x8& kones, int i) {
   if (i < 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(x.s[i]) : "v"(kones), "v"(x.mfrag));
+#ifdef W64Q_KF_AGPR
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x.s[i & 1]) : "a"(kf[i & 1][(i - 2) >> 1]), "a"(qf[(i - 2) >> 1]));
+#else
   else mfma_qk(x.s[i & 1], kf[i & 1][(i - 2) >> 1], qf[(i - 2) >> 1]);
+#endif
 }
 __device__ __forceinline__ void set_mref(QB& q, float nm, int half) {
   q.nm = nm;
@@ -93,8 +100,8 @@ __device__ __forceinline__ float max8(const f32x16& s, int r0, float m, bool wit
 }
 // reg r of s[T] <-> kv = kv0 + T*32 + (r&7) + 8*half + 16*(r>>3); kv_rem = valid kv rows from the tile's first row
 __device__ __forceinline__ void mask_tail(QB& q, int kv_rem, int half) {
-  if (kv_rem < KVBLK) {
-    asm volatile("" ::: "memory");  // keep this rare path a real (wave-uniform) branch
+  if (__builtin_expect(kv_rem < KVBLK, 0)) {
+    asm volatile("" ::: "memory");  // keep this rare path a real (wave-uniform) branch, out of line
     int lim = kv_rem - 8 * half;
     asm volatile("" : "+v"(lim));  // opaque inside the branch: the 32 compares below must not be hoisted into the hot path
 #pragma unroll
@@ -107,6 +114,34 @@ __device__ __forceinline__ void mask_tail(QB& q, int kv_rem, int half) {
   }
 }
 
+// the rare path of the lazy reference max: move m_ref to absorb tp = max(t, 0) (t on the first tile), rescale O and l
+__device__ __forceinline__ void move_mref(QB& q, float t, int half, bool first) {
+  asm volatile("" ::: "memory");
+  const float tp = first ? t : fmaxf(t, 0.f);
+  const float nm_new = q.nm - tp;
+  const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-tp);  // O and l are still zero on the first tile
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q.s[T][r] -= tp;
+  set_mref(q, nm_new, half);
+  q.l_run *= alpha;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {  // one O tile at a time: 16 temporaries, and the accumulator <-> VGPR copies stay in here
+    asm volatile("" : "+a"(q.accO[dt]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) q.accO[dt][r] *= alpha;
+    asm volatile("" : "+a"(q.accO[dt]));
+  }
+  asm volatile("" : "+v"(q.nm), "+v"(q.mfrag), "+v"(q.s[0]), "+v"(q.s[1]));
+}
+__device__ __forceinline__ float row_tmax(const QB& q) {  // max of S' = s - m_ref over the row's 64 kv of this tile
+  float t;
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q.mt), __float_as_uint(q.mt), false, false);
+  asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
+  return t;
+}
+
 // softmax chunk idx of q-block q (see the header).  Every chunk ends in an opaque asm use of what it produced: that
 // pins it between the two asm MFMAs around it (LLVM would otherwise sink it into the block of its consumer).
 __device__ __forceinline__ void chunk(QB& q, int idx, int kv_rem, int half, bool first) {
@@ -115,32 +150,8 @@ __device__ __forceinline__ void chunk(QB& q, int idx, int kv_rem, int half, bool
     q.mt = max8(q.s[idx >> 1], (idx & 1) * 8, q.mt, idx != 0);
     asm volatile("" : "+v"(q.mt));
   } else if (idx == 4) {
-    float t;  // max of S' = s - m_ref over the row's 64 kv of this tile
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q.mt), __float_as_uint(q.mt), false, false);
-      asm("v_max_f32 %0, %1, %2" : "=v"(t) : "v"(__uint_as_float(sw[0])), "v"(__uint_as_float(sw[1])));
-    }
-    if (first || __any(t > LAZY_THR)) {
-      asm volatile("" ::: "memory");
-      // move the reference: the first tile sets it to the row max, later tiles only raise it
-      const float tp = first ? t : fmaxf(t, 0.f);
-      const float nm_new = q.nm - tp;
-      const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-tp);  // O and l are still zero on the first tile
-#pragma unroll
-      for (int T = 0; T < 2; ++T)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q.s[T][r] -= tp;
-      set_mref(q, nm_new, half);
-      q.l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {  // one O tile at a time: 16 temporaries, and the accumulator <-> VGPR copies stay in here
-        asm volatile("" : "+a"(q.accO[dt]));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q.accO[dt][r] *= alpha;
-        asm volatile("" : "+a"(q.accO[dt]));
-      }
-      asm volatile("" : "+v"(q.nm), "+v"(q.mfrag), "+v"(q.s[0]), "+v"(q.s[1]));
-    }
+    const float t = row_tmax(q);
+    if (__builtin_expect(first || __any(t > LAZY_THR), 0)) move_mref(q, t, half, first);  // cold: out of line
   } else {
     const int j = idx - 5;  // pair whose exp2 is issued here (0..15); pair j-1 is summed and packed
     float n0 = 0.f, n1 = 0.f;
@@ -218,6 +229,123 @@ __device__ __forceinline__ void tile_w64q(lds_cchar* smem, const int (&kaddr)[8]
 #undef STAMP
 }
 
+// ---- flat schedule ("w64f") -------------------------------------------------------------------------------------
+// Same data flow, finer placement: ONE v_exp_f32 per MFMA gap (2 exps + 3 other VALU in one gap cost ~47 cycles against
+// the MFMA's 32; 1 exp + 1-2 others fit).  The tile is 68 gaps (A 0..17, B 18..33, C 34..51, D 52..67); each q-block's
+// softmax is a run of 38 single-gap chunks:
+//   0-3 row max (quarters)   4 cross-half max + threshold test (+ rare rescale)
+//   5+k (k = 0..31) exp2 of score k, plus for the PREVIOUS pair j = k/2 - 1:  k even: ps = p0 + p1, pack;  k odd: l += ps
+//   37  sum / pack / l += of pair 15
+// q-block a runs its chunks at gaps 23..60 of its own tile, q-block b at gaps 59..67 and 0..28 of the next tile: the two
+// exp streams (a: gaps 28..59, b: 64..67 + 0..27) never overlap.  P pairs are packed >= 2 gaps before the PV MFMA that
+// reads them (a: pair j at gap 30+2j, PV k-step c at 52+4c; b: pair j at 66+2j (mod 68), PV k-step c at 18+4c).
+// LDS reads are spread (1 KB x 4 waves per read: bursts saturate the LDS pipe): V^T(t) fragment f at gap 20+2f, the K
+// fragments in the order the QK^T MFMAs need them, 8 at the even gaps 52..66 and 8 at gaps 0..7 of the next tile.
+constexpr int FLAT_A0 = 23;  // first chunk gap of q-block a
+constexpr int FLAT_B0 = 59;  // first chunk gap of q-block b
+__device__ __forceinline__ void chunkf(QB& q, int c, int kv_rem, int half, bool first) {
+  if (c < 4) {
+    chunk(q, c, kv_rem, half, first);
+  } else if (c == 4) {
+    q.tmax = row_tmax(q);
+    q.need = first || __any(q.tmax > LAZY_THR);
+    asm volatile("" : "+v"(q.tmax));
+  } else if (c < 37) {
+    const int k = c - 5;
+    if (c == 5 && __builtin_expect(q.need, 0)) move_mref(q, q.tmax, half, first);  // cold: out of line
+    const float e = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
+    if ((k & 1) == 0) {
+      if (k >= 2) {
+        const int j = (k >> 1) - 1;
+        q.ps = q.pe0 + q.pe1;
+        q.pk[j >> 2][j & 3] = cvt_pk(q.pe0, q.pe1);
+        asm volatile("" : "+v"(q.pk[j >> 2]), "+v"(q.ps));
+      }
+      q.cur0 = e;
+      asm volatile("" : "+v"(q.cur0));
+    } else {
+      if (k >= 3) {
+        q.l_run += q.ps;
+        asm volatile("" : "+v"(q.l_run));
+      }
+      q.pe0 = q.cur0;
+      q.pe1 = e;
+      asm volatile("" : "+v"(q.pe0), "+v"(q.pe1));
+    }
+  } else {
+    q.ps = q.pe0 + q.pe1;
+    q.pk[3][3] = cvt_pk(q.pe0, q.pe1);
+    q.l_run += q.ps;
+    asm volatile("" : "+v"(q.pk[3]), "+v"(q.l_run));
+  }
+}
+
+template <int ST, bool TIMING>
+__device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
+                                          const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
+                                          mfma_bf16x8 (&vf)[4][4], const mfma_bf16x8& kones, QB& a, QB& b, int kv_rem,
+                                          int half, bool first, char* smem_rw, Dma& dma, uint64_t* stamp, bool rec) {
+  constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + 2) % NST;
+#define STAMP(K) do { if (TIMING && rec) stamp[K] = __builtin_amdgcn_s_memtime(); } while (0)
+  // the non-MFMA work of global gap G
+#define FLAT_GAP(G)                                                                                              \
+  do {                                                                                                           \
+    if ((G) <= 28) chunkf(b, (G) + 9, kv_rem, half, false);           /* q-block b, tile t-1: chunks 9..37 */     \
+    if ((G) >= FLAT_A0 && (G) <= FLAT_A0 + 37) chunkf(a, (G) - FLAT_A0, kv_rem, half, first);                     \
+    if ((G) >= FLAT_B0) chunkf(b, (G) - FLAT_B0, kv_rem, half, first);  /* q-block b, tile t: chunks 0..8 */      \
+    if ((G) >= 20 && (G) <= 50 && (((G) - 20) & 1) == 0) {              /* V^T(t) fragment f at gap 20 + 2f */     \
+      const int f = ((G) - 20) >> 1;                                                                              \
+      vf[f >> 2][f & 3] = *(lds_frag*)(smem + (VB + (f & 3) * 4096) + vaddr[f >> 2]);                             \
+    }                                                                                                            \
+    if ((G) >= 52 && (((G) - 52) & 1) == 0) {                           /* K(t+1), need order, first 8 */         \
+      const int r = ((G) - 52) >> 1, f = (r & 1) * 8 + (r >> 1);                                                  \
+      kf[f >> 3][f & 7] = *(lds_frag*)(smem + (KN + (f >> 3) * 8192) + kaddr[f & 7]);                             \
+    }                                                                                                            \
+    if ((G) <= 7) {                                                     /* K(t) read 8..15: this tile's stage */  \
+      const int r = 8 + (G), f = (r & 1) * 8 + (r >> 1);                                                          \
+      kf[f >> 3][f & 7] = *(lds_frag*)(smem + (ST * IMG + (f >> 3) * 8192) + kaddr[f & 7]);                       \
+    }                                                                                                            \
+    if ((G) >= 3 && (G) <= 17 && (((G) - 3) & 1) == 0) {                                                          \
+      const int pc = ((G) - 3) >> 1;                                    /* DMA pieces K0 V0 K1 V1 ... */          \
+      dma_piece_i<DST>(smem_rw, dma, (pc & 1) * 4 + (pc >> 1));                                                   \
+    }                                                                                                            \
+    if (TIMING && rec && ((G) & 3) == 3) stamp[3 + ((G) >> 2)] = __builtin_amdgcn_s_memtime();                    \
+  } while (0)
+  if (TIMING && rec) stamp[2] = __builtin_amdgcn_s_memtime();
+  // ---- A: S_a = -m_a + K Q_a^T (18 MFMAs)
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    qk_stepq(a, kf, qfa, kones, i); SB();
+    FLAT_GAP(i);
+    SB();
+  }
+  dma_advance(dma);
+  SB();
+  // ---- B: O_b += V^T(t-1) P_b(t-1)^T
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    pv_mfma(b.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, b.pk[i >> 2]), i >> 2); SB();
+    FLAT_GAP(18 + i);
+    SB();
+  }
+  // ---- C: S_b = -m_b + K Q_b^T (18 MFMAs)
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    qk_stepq(b, kf, qfb, kones, i); SB();
+    FLAT_GAP(34 + i);
+    SB();
+  }
+  // ---- D: O_a += V^T(t) P_a(t)^T
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    pv_mfma(a.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, a.pk[i >> 2]), i >> 2); SB();
+    FLAT_GAP(52 + i);
+    SB();
+  }
+#undef FLAT_GAP
+#undef STAMP
+}
+
 // 8 bf16 -> * c -> 8 bf16 (round to nearest even)
 __device__ __forceinline__ mfma_bf16x8 prescale8(const uint4 raw, float c) {
   uint4 o;
@@ -232,6 +360,7 @@ __device__ __forceinline__ mfma_bf16x8 prescale8(const uint4 raw, float c) {
 
 // FLAGS bit0: s_memtime stamps of tile 300 of workgroup 0 -> first 48 B of O (tuning aid)
 //       bit1: q already holds q * scale * log2(e) (wan_rmsnorm_rope_scaled): skip the pre-scaling pass
+//       bit2: flat one-exp-per-gap schedule (tile_w64f) instead of the half-slot chunks (tile_w64q)
 template <int FLAGS>
 __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int B, int Bk,
@@ -239,7 +368,8 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
                                                        int nseg, int64_t k_seg_stride, int64_t vt_seg_stride) {
   constexpr bool TIMING = (FLAGS & 1) != 0;
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
-  uint64_t stamp[6] = {0, 0, 0, 0, 0, 0};
+  constexpr bool FLAT = (FLAGS & 4) != 0;  // one-exp-per-gap schedule (tile_w64f)
+  uint64_t stamp[20] = {};
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stage 0..2][V^T stage 0..2] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
   const int tid = threadIdx.x;
@@ -285,21 +415,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   const int tps = (Lk32 + KVBLK - 1) / KVBLK;
   const int ntile = tps * nseg;
   Dma dma;
-  dma.k = dma.k0 = reinterpret_cast<const char*>(kbase);
-  dma.v = dma.v0 = reinterpret_cast<const char*>(vbase);
-  dma.kseg = k_seg_stride * 2;
-  dma.vseg = vt_seg_stride * 2;
-  dma.tt = 0; dma.seg = 0; dma.tps = tps; dma.left = ntile;
-  dma.tail_lim = Lk32 - 1 - (tps - 1) * KVBLK;
-  dma.rs2 = (uint32_t)(rs * 2);
-  dma.ldv2 = (uint32_t)(ldv * 2);
-  {
-    const uint32_t kr0 = (uint32_t)(tid >> 4);
-    dma.krow0 = (kr0 & 3u) | ((kr0 & 4u) << 1) | ((kr0 & 8u) >> 1);
-    dma.kcol = (uint32_t)(((tid & 15) ^ (int)kr0) << 4);
-    dma.vofs0 = (uint32_t)(tid >> 3) * dma.ldv2 + (uint32_t)(((tid & 7) ^ ((tid >> 4) & 7)) << 4);
-  }
-  dma.wave = wave;
+  dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave);
   int cur_tt = 0;
   auto next_kv_rem = [&]() {  // valid kv rows from the start of the tile being consumed to the end of its segment
     const int rem = Lk32 - cur_tt * KVBLK;
@@ -333,6 +449,9 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   }
   qa.l_run = qbk.l_run = 0.f;
   qa.pe0 = qa.pe1 = qbk.pe0 = qbk.pe1 = 0.f;
+  qa.cur0 = qa.ps = qbk.cur0 = qbk.ps = 0.f;
+  qa.tmax = qbk.tmax = 0.f;
+  qa.need = qbk.need = false;
   qa.mt = qbk.mt = 0.f;
   // q-block b starts half a tile behind: its first "chunks 10..21" / PV_b run on an all-masked dummy tile (P = 0)
   {
@@ -366,7 +485,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 
   int kv_rem_prev = KVBLK;
 #define W64Q_STEP(J)                                                                                         \
-  if (t + (J) < ntile) {                                                                                     \
+  if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
     const bool rec = TIMING && (t + (J) == 300);                                                             \
     if (TIMING && rec) stamp[0] = __builtin_amdgcn_s_memtime();                                              \
     if (t + (J) > 0) {                                                                                       \
@@ -376,8 +495,10 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
     }                                                                                                        \
     if (TIMING && rec) stamp[1] = __builtin_amdgcn_s_memtime();                                              \
     const int kv_rem = next_kv_rem();                                                                        \
-    tile_w64q<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, kones, qa, qbk, kv_rem_prev, kv_rem, half, t + (J) == 0, \
-                         t + (J) == 1, smem, dma, stamp, rec);                                               \
+    if (FLAT) tile_w64f<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, kones, qa, qbk, kv_rem, half, t + (J) == 0, smem, \
+                                   dma, stamp, rec);                                                         \
+    else tile_w64q<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, kones, qa, qbk, kv_rem_prev, kv_rem, half,  \
+                              t + (J) == 0, t + (J) == 1, smem, dma, stamp, rec);                            \
     kv_rem_prev = kv_rem;                                                                                    \
   }
   for (int t = 0; t < ntile; t += 3) {
@@ -387,8 +508,13 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   }
 #undef W64Q_STEP
   // drain: q-block b's last tile
+  if (FLAT) {
 #pragma unroll
-  for (int idx = 10; idx < 22; ++idx) chunk(qbk, idx, kv_rem_prev, half, ntile == 1);
+    for (int c = 9; c < 38; ++c) chunkf(qbk, c, kv_rem_prev, half, false);
+  } else {
+#pragma unroll
+    for (int idx = 10; idx < 22; ++idx) chunk(qbk, idx, kv_rem_prev, half, ntile == 1);
+  }
   asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
   for (int i = 0; i < 16; ++i) pv_mfma(qbk.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, qbk.pk[i >> 2]), i >> 2);
@@ -428,13 +554,13 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   if (TIMING && blockIdx.x == 0 && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
 #pragma unroll
-    for (int k6 = 0; k6 < 6; ++k6) reinterpret_cast<uint64_t*>(O)[k6] = stamp[k6];
+    for (int k6 = 0; k6 < 20; ++k6) reinterpret_cast<uint64_t*>(O)[k6] = stamp[k6];
   }
 }
 
 }  // namespace
 
-// called from attention.hip's dispatcher.  flags bit0: s_memtime stamps (tuning aid); bit1: q is pre-scaled
+// called from attention.hip's dispatcher.  flags bit0: s_memtime stamps (tuning aid); bit1: q is pre-scaled; bit2: flat schedule
 int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
                               int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
                               int64_t vt_seg_stride, float scale_log2e, hipStream_t stream) {
@@ -446,11 +572,15 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
 #define W64Q_LAUNCH(FL)                                                                                              \
   hipLaunchKernelGGL((attn_w64q_kernel<FL>), dim3((unsigned)total), dim3(256), 0, stream, q, k, vt, o, B, Bk, Lq, Lk, \
                      ldv, H, (int)nqb, scale_log2e, nseg, k_seg_stride, vt_seg_stride)
-  switch (flags & 3) {
+  switch (flags & 7) {
     case 0: W64Q_LAUNCH(0); break;
     case 1: W64Q_LAUNCH(1); break;
     case 2: W64Q_LAUNCH(2); break;
-    default: W64Q_LAUNCH(3); break;
+    case 3: W64Q_LAUNCH(3); break;
+    case 4: W64Q_LAUNCH(4); break;
+    case 5: W64Q_LAUNCH(5); break;
+    case 6: W64Q_LAUNCH(6); break;
+    default: W64Q_LAUNCH(7); break;
   }
 #undef W64Q_LAUNCH
   WAN_LAUNCH_CHECK();

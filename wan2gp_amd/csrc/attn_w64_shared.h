@@ -51,61 +51,82 @@ __device__ __forceinline__ void mfma_qk(f32x16& d, const mfma_bf16x8& k, const m
 
 // LDS-DMA stream of one wave: walks the K / V^T tiles of all kv segments in order, one 16-B piece per lane per
 // call.  piece s = i*256 + tid (i = 0..3) of an image.  K: row 16 i + (tid>>4) (bits 2<->3 swapped inside the low
-// nibble), 16-B chunk (tid&15) ^ (row&15); V^T: row 32 i + (tid>>3), chunk (tid&7) ^ ((row>>1)&7).  The swizzles do
-// not depend on i, so the per-lane plan is three VGPRs (krow0, kcol, vofs0) and everything else is uniform.
+// nibble), 16-B chunk (tid&15) ^ (row&15); V^T: row 32 i + (tid>>3), chunk (tid&7) ^ ((row>>1)&7).
+// Issued as `buffer_load_dwordx4 v_off, s[desc], 0 offen lds`: the per-lane offsets of the 8 pieces are loop-invariant
+// VGPRs, the tile position lives in the descriptor base (3 SALU per tile), and the K descriptor's num_records ends at
+// the segment's last valid row, so rows of a ragged tail tile read as zeros (hardware range check) -- no per-piece
+// address arithmetic, no clamping, no branch.
 struct Dma {
   const char* k;   // K rows of the next tile to fetch (uniform)
   const char* v;   // V^T columns of the next tile
-  const char* k0;  // segment 0 bases and segment strides (bytes)
-  const char* v0;
+  const char* kseg0;  // base of the current segment, and the segment strides (bytes)
+  const char* vseg0;
   int64_t kseg, vseg;
-  int tt, seg, tps, left;  // tile inside the segment, segment, tiles per segment, tiles not yet fetched
-  int tail_lim;            // last valid row of a segment's last tile (63 when Lk % 64 == 0)
+  int tt, tps, left;  // tile inside the segment, tiles per segment, tiles not yet fetched
+  uint32_t klen, klen0;    // valid K bytes from d.k to the end of the segment ((rows-1)*pitch + 256); at a segment start
   uint32_t rs2, ldv2;      // K / V^T row pitch in bytes
-  uint32_t krow0, kcol, vofs0;
+  uint32_t kofs[4], vofs[4];
   int wave;
 };
-// piece I = 0..3: K, 4..7: V^T, into ring stage ST
-template <int I, int ST>
-__device__ __forceinline__ void dma_piece(char* smem, const Dma& d) {
-  if (I < 4) {
-    const uint32_t lim = (d.tt == d.tps - 1) ? (uint32_t)d.tail_lim : 63u;  // ragged tail: clamp rows to the last valid one
-    const uint32_t r = d.krow0 + 16u * I;
-    glds16(d.k + ((r < lim ? r : lim) * d.rs2 + d.kcol), smem + ST * IMG + d.wave * 1024 + I * 4096);
-  } else {
-    glds16(d.v + (size_t)(I - 4) * 32u * d.ldv2 + d.vofs0, smem + NST * IMG + ST * IMG + d.wave * 1024 + (I - 4) * 4096);
+__device__ __forceinline__ void dma_init(Dma& d, const void* kbase, const void* vbase, int64_t kseg_bytes, int64_t vseg_bytes,
+                                         int Lk, int nseg, uint32_t rs2, uint32_t ldv2, int tid, int wave) {
+  d.k = d.kseg0 = reinterpret_cast<const char*>(kbase);
+  d.v = d.vseg0 = reinterpret_cast<const char*>(vbase);
+  d.kseg = kseg_bytes;
+  d.vseg = vseg_bytes;
+  d.tps = (Lk + KVBLK - 1) / KVBLK;
+  d.tt = 0; d.left = d.tps * nseg;
+  d.klen = d.klen0 = (uint32_t)(Lk - 1) * rs2 + 256u;
+  d.rs2 = rs2;
+  d.ldv2 = ldv2;
+  const uint32_t kr0 = (uint32_t)(tid >> 4);
+  const uint32_t krow0 = (kr0 & 3u) | ((kr0 & 4u) << 1) | ((kr0 & 8u) >> 1);
+  const uint32_t kcol = (uint32_t)(((tid & 15) ^ (int)kr0) << 4);
+  const uint32_t vofs0 = (uint32_t)(tid >> 3) * ldv2 + (uint32_t)(((tid & 7) ^ ((tid >> 4) & 7)) << 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    d.kofs[i] = (krow0 + 16u * i) * rs2 + kcol;
+    d.vofs[i] = vofs0 + 32u * i * ldv2;
   }
+  d.wave = wave;
 }
-// step to the next tile; after the last tile the stream stays put (later fetches re-read it into a dead stage)
-__device__ __forceinline__ void dma_advance(Dma& d) {
-  if (d.left > 1) {
-    --d.left;
-    if (++d.tt == d.tps) {
-      d.tt = 0;
-      ++d.seg;
-      d.k = d.k0 + d.seg * d.kseg;
-      d.v = d.v0 + d.seg * d.vseg;
-    } else {
-      d.k += (int64_t)KVBLK * d.rs2;
-      d.v += KVBLK * 2;
-    }
-  }
-}
-// same with the piece index as an (unrolled, hence constant) loop variable
+// piece I = 0..3: K, 4..7: V^T, into ring stage ST (I is a template argument or an unrolled loop variable)
 template <int ST>
 __device__ __forceinline__ void dma_piece_i(char* smem, const Dma& d, int I) {
+  typedef __attribute__((address_space(3))) void lds_void;
   if (I < 4) {
-    const uint32_t lim = (d.tt == d.tps - 1) ? (uint32_t)d.tail_lim : 63u;
-    const uint32_t r = d.krow0 + 16u * I;
-    glds16(d.k + ((r < lim ? r : lim) * d.rs2 + d.kcol), smem + ST * IMG + d.wave * 1024 + I * 4096);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(d.k), 0, d.klen, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + ST * IMG + d.wave * 1024 + I * 4096), 16, d.kofs[I], 0, 0, 0);
   } else {
-    glds16(d.v + (size_t)(I - 4) * 32u * d.ldv2 + d.vofs0, smem + NST * IMG + ST * IMG + d.wave * 1024 + (I - 4) * 4096);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(d.v), 0, 0xffffffffu, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + NST * IMG + ST * IMG + d.wave * 1024 + (I - 4) * 4096), 16,
+                                             d.vofs[I - 4], 0, 0, 0);
   }
+}
+template <int I, int ST>
+__device__ __forceinline__ void dma_piece(char* smem, const Dma& d) {
+  dma_piece_i<ST>(smem, d, I);
+}
+// step to the next tile; after the last tile the stream stays put (later fetches re-read it into a dead stage).
+// Branch-free (scalar selects): a taken branch in the tile loop costs ~100 cycles of instruction fetch.
+__device__ __forceinline__ void dma_advance(Dma& d) {
+  const bool adv = d.left > 1;
+  const bool sw = adv && (d.tt + 1 == d.tps);  // move to the next kv segment
+  const bool stp = adv && !sw;                 // next tile of the same segment
+  d.left -= adv ? 1 : 0;
+  d.tt = sw ? 0 : d.tt + (stp ? 1 : 0);
+  d.kseg0 = sw ? d.kseg0 + d.kseg : d.kseg0;
+  d.vseg0 = sw ? d.vseg0 + d.vseg : d.vseg0;
+  const char* kstep = d.k + (int64_t)KVBLK * d.rs2;
+  const char* vstep = d.v + KVBLK * 2;
+  d.k = sw ? d.kseg0 : (stp ? kstep : d.k);
+  d.v = sw ? d.vseg0 : (stp ? vstep : d.v);
+  d.klen = sw ? d.klen0 : (stp ? d.klen - (uint32_t)KVBLK * d.rs2 : d.klen);
 }
 template <int ST>
 __device__ __forceinline__ void dma_tile(char* smem, Dma& d) {
-  dma_piece<0, ST>(smem, d); dma_piece<1, ST>(smem, d); dma_piece<2, ST>(smem, d); dma_piece<3, ST>(smem, d);
-  dma_piece<4, ST>(smem, d); dma_piece<5, ST>(smem, d); dma_piece<6, ST>(smem, d); dma_piece<7, ST>(smem, d);
+#pragma unroll
+  for (int I = 0; I < 8; ++I) dma_piece_i<ST>(smem, d, I);
   dma_advance(d);
 }
 
