@@ -4,10 +4,12 @@
 //   normal     : Y = activations A [M,K], X = weights W [N,K]      -> C[M,N]
 //   transposed : Y = weights W [N,K],     X = activations A [M,K]  -> Ct[N,M]  (emits V^T)
 //
-// Tile 128(y) x 128(x) x 64(k), 256 threads = 4 waves in 2x2, each wave 64x64 = 4x4 MFMA
-// 16x16x32 tiles.  Global->LDS staging uses the LDS-DMA path (global_load_lds_dwordx4, 16 B per
-// lane, 1 KiB per wave-instruction) into a 2-deep ring; tile t+1 is in flight while tile t is
-// multiplied.
+// Two tile shapes, each wave 64x64 = 4x4 MFMA 16x16x32 tiles:
+//   WY = 2: 128(y) x 128(x) x 64(k), 4 waves in 2x2, two workgroups per CU, 2-deep LDS ring (small problems)
+//   WY = 4: 256(y) x 128(x) x 64(k), 8 waves in 4x2, one workgroup per CU, 3-deep LDS ring with counted vmcnt (k-tiles
+//           t+1 and t+2 in flight).  Correct but 20 % slower than WY = 2 on the Wan shapes (see launch_gemm): kept
+//           behind WAN_GEMM_TILE=256.
+// Global->LDS staging uses the LDS-DMA path (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave-instruction).
 //
 // LDS image: rows of 64 bf16 (128 B = 8 chunks of 16 B).  LDS-DMA writes lane-linearly, so the
 // bank-conflict swizzle is applied to the per-lane SOURCE address (cdna guide rule 21):
@@ -20,6 +22,8 @@
 // 64) so that the 16 accumulators a lane holds for one y row are 16 CONSECUTIVE x: the epilogue
 // reads bias/residual/gate and writes the output with 2 x 16-byte accesses per lane per row
 // (128 B contiguous per y row across the 4 lane groups) with no LDS transpose.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
@@ -32,10 +36,9 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c)
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
 }
 
-#define BM 128
 #define BN 128
 #define BK 64
-#define STAGE_BYTES (BM * BK * 2)  // 16 KiB per operand per stage
+#define XSTAGE_BYTES (BN * BK * 2)  // 16 KiB: X operand per stage
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -51,13 +54,19 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 
 // F16 = false: bf16 storage (DiT);  F16 = true: fp16 storage (VAE) -- same tiles, MFMA f16 variant.
 // out_scale multiplies the fp32 accumulator before the bias (used for QK^T / sqrt(C) in the VAE).
-template <int EPI, bool BIAS_ROWS, bool F16>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
+template <int EPI, bool BIAS_ROWS, bool F16, int WY>
+__global__ __launch_bounds__(WY * 128, WY == 2 ? 2 : 1) void gemm_bf16_kernel(
     const bf16_t* __restrict__ Y, int64_t ldy, int64_t YM, const bf16_t* __restrict__ X, int64_t ldx,
     int64_t XN, int K, bf16_t* __restrict__ Out, int64_t ldo, const bf16_t* __restrict__ bias,
     const bf16_t* __restrict__ R, const bf16_t* __restrict__ mod, const bf16_t* __restrict__ e, int n_mod,
     int gate_idx, int64_t rows_per_batch, int tiles_y, int tiles_x, float out_scale) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * STAGE_BYTES];  // [stage][Y|X]
+  constexpr int BM = WY * 64;                   // y rows per workgroup tile
+  constexpr int NTHR = WY * 128;
+  constexpr int NSTG = (WY == 4) ? 3 : 2;       // LDS ring depth
+  constexpr int YSTAGE_BYTES = BM * BK * 2;
+  constexpr int STAGE_ALL = YSTAGE_BYTES + XSTAGE_BYTES;
+  constexpr int XS = 1024 / NTHR;               // X staging slots per thread (Y: always 4)
+  __shared__ __attribute__((aligned(16))) char smem[NSTG * STAGE_ALL];  // [stage][Y|X]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -79,15 +88,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
 
   // ---- per-thread staging addresses (4 x 16 B per operand per stage) ---------------------------
   const bf16_t* ysrc[4];
-  const bf16_t* xsrc[4];
+  const bf16_t* xsrc[XS];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int q = i * 256 + tid;  // linear 16-B slot in the 16 KiB image
+    const int q = i * NTHR + tid;  // linear 16-B slot in the Y image
     const int row = q >> 3, pch = q & 7;
     const int lch = pch ^ ((row >> 1) & 7);
     int64_t yr = y0 + row;
     if (yr > YM - 1) yr = YM - 1;
     ysrc[i] = Y + yr * ldy + lch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < XS; ++i) {
+    const int q = i * NTHR + tid;  // linear 16-B slot in the 16 KiB X image
+    const int row = q >> 3, pch = q & 7;
+    const int lch = pch ^ ((row >> 1) & 7);
     // X image row -> permuted x row inside the owning wave's 64-row slab
     const int slab = row >> 6, jj = row & 63;
     const int nt = jj >> 4, ii = jj & 15;
@@ -97,14 +112,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
   }
 
   auto stage = [&](int s, int k0) {
-    char* ybase = smem + s * 2 * STAGE_BYTES;
-    char* xbase = ybase + STAGE_BYTES;
+    char* ybase = smem + s * STAGE_ALL;
+    char* xbase = ybase + YSTAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int woff = (i * 256 + wave * 64) * 16;  // wave-uniform LDS base; lanes land at +lane*16
-      glds16(ysrc[i] + k0, ybase + woff);
-      glds16(xsrc[i] + k0, xbase + woff);
-    }
+    for (int i = 0; i < 4; ++i) glds16(ysrc[i] + k0, ybase + (i * NTHR + wave * 64) * 16);  // wave-uniform LDS base; lanes land at +lane*16
+#pragma unroll
+    for (int i = 0; i < XS; ++i) glds16(xsrc[i] + k0, xbase + (i * NTHR + wave * 64) * 16);
   };
 
   f32x4 acc[4][4];  // [yt][xt]
@@ -125,13 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
   }
 
   const int nk = K / BK;
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
-    const char* ybase = smem + (kt & 1) * 2 * STAGE_BYTES;
-    const char* xbase = ybase + STAGE_BYTES;
+  auto compute = [&](const char* ybase, const char* xbase) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       uint4 yf[4], xf[4];
@@ -144,6 +151,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16<F16>(xf[b], yf[a], acc[a][b]);
+    }
+  };
+  stage(0, 0);
+  if (NSTG == 3) {
+    if (nk > 1) stage(1, BK);
+    int st = 0;  // ring slot of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed once at most the youngest tile's 4 + XS pieces per lane are still in flight
+      if (kt + 1 < nk) {
+        if (XS == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (kt + 2 < nk) stage(st == 0 ? 2 : st - 1, (kt + 2) * BK);  // slot of tile kt-1: every wave is past it
+      const char* ybase = smem + st * STAGE_ALL;
+      compute(ybase, ybase + YSTAGE_BYTES);
+      st = (st == 2) ? 0 : st + 1;
+    }
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+      const char* ybase = smem + (kt & 1) * STAGE_ALL;
+      compute(ybase, ybase + YSTAGE_BYTES);
     }
   }
 
@@ -225,11 +258,25 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
                        bf16_t* Out, int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod,
                        const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st,
                        float out_scale = 1.0f) {
-  const int64_t ty = (YM + BM - 1) / BM, tx = (XN + BN - 1) / BN;
-  WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm: too many tiles");
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM,
-                     X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx,
-                     out_scale);
+  const int64_t tx = (XN + BN - 1) / BN;
+  // Measured on MI355X (M=151200, Wan 14B shapes): 128-row tiles 790-920 TF, 256-row tiles 620-690 TF -- two independent
+  // 4-wave workgroups per CU cover each other's barrier / DMA-issue bubbles, one 8-wave workgroup cannot.  The 256-row
+  // variant stays selectable (WAN_GEMM_TILE=256) for tuning.
+  static const int forced = [] { const char* e = getenv("WAN_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const bool big = forced == 256;
+  if (big) {
+    const int64_t ty = (YM + 255) / 256;
+    WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm: too many tiles");
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16, 4>), dim3((unsigned)(ty * tx)), dim3(512), 0, st, Y, ldy, YM,
+                       X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx,
+                       out_scale);
+  } else {
+    const int64_t ty = (YM + 127) / 128;
+    WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm: too many tiles");
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16, 2>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM,
+                       X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx,
+                       out_scale);
+  }
   WAN_LAUNCH_CHECK();
   return 0;
 }
