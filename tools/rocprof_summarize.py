@@ -10,8 +10,9 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "", 1) if name.startswith("void (anonymous") else name
     name = name.split("(")[0]
-    for k in ("attn_fwd_kernel", "gemm_bf16_kernel", "rmsnorm_rope_kernel", "layernorm_kernel", "gated_residual",
+    for k in ("attn_w64q_kernel", "attn_w64_kernel", "attn_pp_kernel", "attn_fwd_kernel", "gemm_bf16_kernel", "rmsnorm_rope_kernel", "layernorm_kernel", "gated_residual",
               "patch_embed_kernel", "head_gemm_kernel", "gemv_kernel", "lincomb_kernel", "cfg_combine", "transpose_v"):
         if k in name:
             if k == "gemm_bf16_kernel":
