@@ -23,6 +23,7 @@
 // reads bias/residual/gate and writes the output with 2 x 16-byte accesses per lane per row
 // (128 B contiguous per y row across the 4 lane groups) with no LDS transpose.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -45,11 +46,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
                                    (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
 
+// torch GELU(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x / (1 + exp(-2u))
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715x^3)))  (torch GELU approximate='tanh')
-  const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
-  const float inner = kBeta * (x + kKappa * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(inner));
+  const float c = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2 sqrt(2/pi) log2(e)
+  const float t = __builtin_fmaf(x * x, 0.044715f, 1.0f);
+  const float ex = __builtin_amdgcn_exp2f(x * t * c);
+  return x * __builtin_amdgcn_rcpf(1.0f + ex);
 }
 
 // F16 = false: bf16 storage (DiT);  F16 = true: fp16 storage (VAE) -- same tiles, MFMA f16 variant.
@@ -253,12 +255,25 @@ __global__ __launch_bounds__(WY * 128, WY == 2 ? 2 : 1) void gemm_bf16_kernel(
   }
 }
 
+// second-generation kernel (gemm32.hip); returns -1 when the problem does not fit it
+template <int EPI, bool BIAS_ROWS, bool F16>
+int wan_gemm32_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                   int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
+                   int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
+
 template <int EPI, bool BIAS_ROWS, bool F16 = false>
 static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K,
                        bf16_t* Out, int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod,
                        const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st,
                        float out_scale = 1.0f) {
   const int64_t tx = (XN + BN - 1) / BN;
+  // large problems: 256x128x32 tiles on 32x32x16 MFMAs (gemm32.hip); WAN_GEMM_KERNEL=v1 keeps this file's kernel
+  static const bool use_v1 = [] { const char* e = getenv("WAN_GEMM_KERNEL"); return e && !strcmp(e, "v1"); }();
+  if (!use_v1 && YM >= 512 && XN >= 128) {
+    const int rc = wan_gemm32_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
+                                                       rows_per_batch, st, out_scale);
+    if (rc >= 0) return rc;
+  }
   // Measured on MI355X (M=151200, Wan 14B shapes): 128-row tiles 790-920 TF, 256-row tiles 620-690 TF -- two independent
   // 4-wave workgroups per CU cover each other's barrier / DMA-issue bubbles, one 8-wave workgroup cannot.  The 256-row
   // variant stays selectable (WAN_GEMM_TILE=256) for tuning.
