@@ -257,9 +257,15 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(const bf16_t* __restrict
     if (!BIAS_ROWS) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) bcol[j] = 0.f;
-      if (bias != nullptr && xb + 16 <= XN) {
-        unpack8t<F16>(*reinterpret_cast<const uint4*>(bias + xb), bcol);
-        unpack8t<F16>(*reinterpret_cast<const uint4*>(bias + xb + 8), bcol + 8);
+      if (bias != nullptr) {
+        if (xb + 16 <= XN) {
+          unpack8t<F16>(*reinterpret_cast<const uint4*>(bias + xb), bcol);
+          unpack8t<F16>(*reinterpret_cast<const uint4*>(bias + xb + 8), bcol + 8);
+        } else {  // ragged x edge
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (xb + j < XN) bcol[j] = ld16<F16>(bias[xb + j]);
+        }
       }
     }
 #pragma unroll
@@ -268,9 +274,10 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(const bf16_t* __restrict
       if (yr >= YM) continue;
       float v[16];
       const float brow = (BIAS_ROWS && bias != nullptr) ? ld16<F16>(bias[yr]) : 0.f;
+      const f32x16 av = acc[yt][xt];
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        v[r] = rnd16<F16>(acc[yt][xt][r] * out_scale + (BIAS_ROWS ? brow : bcol[r]));  // nn.Linear output is a 16-bit tensor
+        v[r] = rnd16<F16>(av[r] * out_scale + (BIAS_ROWS ? brow : bcol[r]));  // nn.Linear output is a 16-bit tensor
       bf16_t* optr = Out + yr * ldo + xb;
       if (xb + 16 <= XN) {
         if (EPI == WAN_EPI_GELU_TANH) {
@@ -299,23 +306,12 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(const bf16_t* __restrict
         }
         *reinterpret_cast<uint4*>(optr) = pack8t<F16>(v);
         *reinterpret_cast<uint4*>(optr + 8) = pack8t<F16>(v + 8);
-      } else {
-        // ragged x edge (only the transposed / V^T form can hit this: x = tokens)
-        for (int j = 0; j < 16; ++j) {
-          if (xb + j < XN) {
-            float o = v[j];
-            if (!BIAS_ROWS && bias != nullptr) o = rnd16<F16>(acc[yt][xt][j] * out_scale + ld16<F16>(bias[xb + j]));
-            if (EPI == WAN_EPI_GELU_TANH) o = g32_gelu_tanh(o);
-            if (EPI == WAN_EPI_GATE_RES) {
-              float g = 1.f;
-              if (gate_idx >= 0)
-                g = rnd16<F16>(ld16<F16>(mod[(int64_t)gate_idx * XN + xb + j]) +
-                               ld16<F16>(e[((yr / rows_per_batch) * n_mod + gate_idx) * XN + xb + j]));
-              o = ld16<F16>(R[yr * ldo + xb + j]) + o * g;
-            }
-            optr[j] = st16<F16>(o);
-          }
-        }
+      } else if (EPI == WAN_EPI_NONE) {
+        // ragged x edge: only the transposed / V^T form (x = tokens, EPI NONE) can hit it -- the launcher requires
+        // N % 16 == 0 for every other epilogue.  Fully unrolled: no runtime index into v[].
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (xb + j < XN) optr[j] = st16<F16>(v[j]);
       }
     }
   }

@@ -261,6 +261,12 @@ int wan_gemm32_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, in
                    int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                    int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
+// third-generation kernel (gemm256.hip): 256x256 tiles, one wave per SIMD, accumulators in the accumulator file
+template <int EPI, bool BIAS_ROWS, bool F16>
+int wan_gemm256_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                    int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
+                    int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
+
 template <int EPI, bool BIAS_ROWS, bool F16 = false>
 static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K,
                        bf16_t* Out, int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod,
@@ -268,7 +274,16 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
                        float out_scale = 1.0f) {
   const int64_t tx = (XN + BN - 1) / BN;
   // large problems: 256x128x32 tiles on 32x32x16 MFMAs (gemm32.hip); WAN_GEMM_KERNEL=v1 keeps this file's kernel
-  static const bool use_v1 = [] { const char* e = getenv("WAN_GEMM_KERNEL"); return e && !strcmp(e, "v1"); }();
+  static const int gen = [] { const char* e = getenv("WAN_GEMM_KERNEL"); return !e ? 3 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v2") ? 2 : !strcmp(e, "v3f") ? 4 : 3; }();
+  const bool use_v1 = gen == 1;
+  // Measured (M = 151200, TFLOP/s, gemm256 vs gemm32): qkvo 1004 vs 946, V^T 948 vs 910, ffn1+GELU 877 vs 914, ffn2+gate
+  // 757 vs 929 -- with one wave per SIMD nothing covers a heavy epilogue, so the 256x256 kernel takes the plain
+  // bias epilogues only.  v3f (tests): the 256x256 kernel whatever the problem size / epilogue.
+  if (gen == 4 || (gen == 3 && EPI == WAN_EPI_NONE && ((YM + 255) / 256) * ((XN + 255) / 256) >= 256)) {  // enough 256x256 tiles to fill the 256 CUs
+    const int rc = wan_gemm256_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
+                                                        rows_per_batch, st, out_scale);
+    if (rc >= 0) return rc;
+  }
   if (!use_v1 && YM >= 512 && XN >= 128) {
     const int rc = wan_gemm32_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
                                                        rows_per_batch, st, out_scale);
