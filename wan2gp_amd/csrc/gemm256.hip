@@ -10,8 +10,11 @@
 //   * 0.5 fragment reads and 0.25 DMA pieces per MFMA, placed BETWEEN the MFMAs (one DMA piece per 4 MFMAs, one
 //     ds_read_b128 per 2) with the order pinned by sched_barrier(0): there is no VALU work in the main loop at all, so the
 //     ~4 free issue slots under each 32-cycle MFMA carry them;
-//   * 3-deep LDS ring (96 KB), one s_waitcnt vmcnt(0) + s_barrier per k-tile (32 MFMAs = 1024 cycles per wave), tile t+1
-//     visible when tile t starts so its first fragments are read under tile t's last MFMAs; k loop unrolled by 3.
+//   * 4-deep LDS ring (128 KB), one counted s_waitcnt vmcnt(8) + s_barrier per k-tile (32 MFMAs = 1024 cycles per wave):
+//     tile t+1 is visible when tile t starts (its first fragments are read under tile t's last MFMAs) while tiles t+2
+//     and t+3 are in flight -- with ONE tile (32 KB) in flight the kernel ran at one k-tile per ~2070 cycles = the
+//     memory latency (tools/probes/dma_probe: the DMA instruction itself costs ~4 cycles when the memory system keeps
+//     up; the 70 cycles per piece seen in the GEMMs are queue back-pressure); k loop unrolled by 4.
 // LDS images, swizzle and the X-row permutation that makes a lane's 16 accumulators 16 consecutive x are those of
 // gemm32.hip (rows of 32 k = 64 B, physical chunk p of row r holds logical chunk p ^ ((r>>2)&3)).
 #include <stdlib.h>
@@ -29,7 +32,10 @@ typedef __attribute__((address_space(3))) const g256_u4 g256_lds_u4;
 constexpr int G_BM = 256, G_BN = 256, G_BK = 32;
 constexpr int G_YST = G_BM * G_BK * 2;  // 16 KiB: Y image per stage
 constexpr int G_XST = G_BN * G_BK * 2;  // 16 KiB: X image per stage
-constexpr int G_NST = 3;
+#ifndef G256_NST
+#define G256_NST 4
+#endif
+constexpr int G_NST = G256_NST;  // LDS ring depth: tiles t+2 .. t+NST-1 in flight
 constexpr int G_XBASE = G_NST * G_YST;  // LDS: [Y st0][Y st1][Y st2][X st0][X st1][X st2]
 
 __device__ __forceinline__ float g256_gelu_tanh(float x) {
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
                                                        const bf16_t* __restrict__ R, const bf16_t* __restrict__ mod,
                                                        const bf16_t* __restrict__ e, int n_mod, int gate_idx,
                                                        int64_t rows_per_batch, int tiles_y, int tiles_x, float out_scale) {
-  __shared__ __attribute__((aligned(16))) char smem[G_NST * (G_YST + G_XST)];  // 96 KiB
+  __shared__ __attribute__((aligned(16))) char smem[G_NST * (G_YST + G_XST)];  // 128 KiB
   g256_lds_cchar* lds = (g256_lds_cchar*)smem;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -160,45 +166,51 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
   const int nk = K / G_BK;
   stage(0);
   stage(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stage(2);
+  if (G_NST == 5) stage(3);
+  if (G_NST == 5) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tiles 0 and 1 landed, the younger ones may be in flight
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   G256Frags f0, f1;
 #pragma unroll
   for (int r = 0; r < 8; ++r) load_frag(f0, 0, 0, r);
   // k-tile kt in ring slot J, 32 MFMAs.  MFMA m of a k-step multiplies (y tile m>>2, x tile m&3); after MFMA 0,4,8,12 one
-  // DMA piece of tile kt+2 (ring slot (J+2)%3, free since this tile's barrier), after the other of the first 12 one
-  // fragment read: k-step 0 reads k-step 1's fragments, k-step 1 reads the next tile's k-step 0 fragments (slot (J+1)%3).
+  // DMA piece of tile kt+3 (ring slot (J+3)%4, free since this tile's barrier), after the other of the first 12 one
+  // fragment read: k-step 0 reads k-step 1's fragments, k-step 1 reads the next tile's k-step 0 fragments (slot (J+1)%4).
 #define G256_SB() __builtin_amdgcn_sched_barrier(0)
 #define G256_STEP(J)                                                                                   \
   if (__builtin_expect(kt + (J) < nk, 1)) {                                                            \
     if (kt + (J) > 0) {                                                                                \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile kt+J+1 landed (issued a tile ago) */    \
+      if (G_NST == 5) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                \
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* tile kt+J+1 landed; younger pieces may fly */ \
       __builtin_amdgcn_s_barrier();                                                                    \
       asm volatile("" ::: "memory");                                                                   \
     }                                                                                                  \
     _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                                   \
       mfma256<F16>(acc[m >> 2][m & 3], f0.x[m & 3], f0.y[m >> 2]); G256_SB();                          \
-      if ((m & 3) == 0) dma_piece(((J) + 2) % 3, m >> 2);                                              \
+      if ((m & 3) == 0) dma_piece(((J) + G_NST - 1) % G_NST, m >> 2);                                              \
       else if (m - (m >> 2) - 1 < 8) load_frag(f1, (J), 1, m - (m >> 2) - 1);                          \
       G256_SB();                                                                                       \
     }                                                                                                  \
     _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                                   \
       mfma256<F16>(acc[m >> 2][m & 3], f1.x[m & 3], f1.y[m >> 2]); G256_SB();                          \
-      if ((m & 3) == 0) dma_piece(((J) + 2) % 3, 4 + (m >> 2));                                        \
-      else if (m - (m >> 2) - 1 < 8) load_frag(f0, ((J) + 1) % 3, 0, m - (m >> 2) - 1);                \
+      if ((m & 3) == 0) dma_piece(((J) + G_NST - 1) % G_NST, 4 + (m >> 2));                                        \
+      else if (m - (m >> 2) - 1 < 8) load_frag(f0, ((J) + 1) % G_NST, 0, m - (m >> 2) - 1);                \
       G256_SB();                                                                                       \
     }                                                                                                  \
     advance();                                                                                         \
   }
-  for (int kt = 0; kt < nk; kt += 3) {
+  for (int kt = 0; kt < nk; kt += G_NST) {
     G256_STEP(0)
     G256_STEP(1)
     G256_STEP(2)
+    G256_STEP(3)
+    if (G_NST == 5) { G256_STEP(4) }
   }
 #undef G256_STEP
 #undef G256_SB
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMAs -> accumulator reads of the epilogue
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA; last asm MFMAs -> accumulator reads of the epilogue
 
   // ---- epilogue: lane holds, for y row (yt, l31), the 16 consecutive x  xb .. xb+15 of x tile xt ----------------------
 #pragma unroll
