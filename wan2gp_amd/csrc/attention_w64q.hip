@@ -31,6 +31,12 @@
 #include <stdlib.h>
 #include <string.h>
 
+// Ring depth 3: tile t+1 visible when tile t starts, tile t+2 in flight.  Depth 4 (two tiles in flight; build with
+// -DW64_NST=4) was measured neutral here (1246 vs 1250 TFLOP/s): at ~11 B/clk/CU the K/V stream is not latency-bound,
+// unlike the GEMMs (gemm256.hip gained 13 % from the same change).
+#ifndef W64_NST
+#define W64_NST 3
+#endif
 #include "attn_w64_shared.h"
 
 namespace {
@@ -179,7 +185,7 @@ __device__ __forceinline__ void tile_w64q(lds_cchar* smem, const int (&kaddr)[8]
                                           mfma_bf16x8 (&vf)[4][4], const mfma_bf16x8& kones, QB& a, QB& b, int kv_rem_prev,
                                           int kv_rem, int half, bool first, bool first_prev, char* smem_rw, Dma& dma,
                                           uint64_t* stamp, bool rec) {
-  constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + 2) % NST;
+  constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
 #define STAMP(K) do { if (TIMING && rec) stamp[K] = __builtin_amdgcn_s_memtime(); } while (0)
   // ---- A: S_a = -m_a + K Q_a^T (18 MFMAs)  ||  softmax b(t-1) chunks 10..21  ||  DMA of tile t+2
 #pragma unroll
@@ -285,7 +291,7 @@ __device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8]
                                           const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
                                           mfma_bf16x8 (&vf)[4][4], const mfma_bf16x8& kones, QB& a, QB& b, int kv_rem,
                                           int half, bool first, char* smem_rw, Dma& dma, uint64_t* stamp, bool rec) {
-  constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + 2) % NST;
+  constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
 #define STAMP(K) do { if (TIMING && rec) stamp[K] = __builtin_amdgcn_s_memtime(); } while (0)
   // the non-MFMA work of global gap G
 #define FLAT_GAP(G)                                                                                              \
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
   constexpr bool FLAT = (FLAGS & 4) != 0;  // one-exp-per-gap schedule (tile_w64f)
   uint64_t stamp[20] = {};
-  __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stage 0..2][V^T stage 0..2] = 96 KB
+  __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stages][V^T stages] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -474,7 +480,12 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 
   dma_tile<0>(smem, dma);
   dma_tile<1>(smem, dma);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (NST == 4) {
+    dma_tile<2>(smem, dma);
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // tiles 0, 1 landed; tile 2's 8 pieces may be in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   mfma_bf16x8 kf[2][8];
@@ -489,7 +500,8 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
     const bool rec = TIMING && (t + (J) == 300);                                                             \
     if (TIMING && rec) stamp[0] = __builtin_amdgcn_s_memtime();                                              \
     if (t + (J) > 0) {                                                                                       \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+      if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* tile t+J+1 landed; the next one's 8 pieces may fly */ \
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
       __builtin_amdgcn_s_barrier();                                                                          \
       asm volatile("" ::: "memory");                                                                         \
     }                                                                                                        \
@@ -501,10 +513,11 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
                               t + (J) == 0, t + (J) == 1, smem, dma, stamp, rec);                            \
     kv_rem_prev = kv_rem;                                                                                    \
   }
-  for (int t = 0; t < ntile; t += 3) {
+  for (int t = 0; t < ntile; t += NST) {
     W64Q_STEP(0)
     W64Q_STEP(1)
     W64Q_STEP(2)
+    if (NST == 4) { W64Q_STEP(3) }
   }
 #undef W64Q_STEP
   // drain: q-block b's last tile

@@ -14,7 +14,10 @@ typedef __attribute__((address_space(3))) const mfma_bf16x8 lds_frag;
 
 constexpr int KVBLK = 64;
 constexpr int IMG = 16384;  // bytes per K or V^T image
-constexpr int NST = 3;      // LDS ring depth
+#ifndef W64_NST
+#define W64_NST 3
+#endif
+constexpr int NST = W64_NST;  // LDS ring depth (the including kernel may set W64_NST)
 
 __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
   hw_f32x2 v = {lo, hi};
