@@ -10,7 +10,7 @@ ap.add_argument("--M", type=int, default=151200)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--variants", default="")
 a = ap.parse_args()
-shapes = [("qkvo", a.M, 5120, 5120, 0), ("ffn1+gelu", a.M, 13824, 5120, 1), ("ffn2+gate", a.M, 5120, 13824, 2), ("vT", a.M // 2, 5120, 5120, 3)]
+shapes = [("qkvo", a.M, 5120, 5120, 0), ("o+gate", a.M, 5120, 5120, 2), ("ffn1+gelu", a.M, 13824, 5120, 1), ("ffn2+gate", a.M, 5120, 13824, 2), ("vT", a.M // 2, 5120, 5120, 3)]
 g = torch.Generator(device="cuda").manual_seed(0)
 res = {}
 variants = a.variants.split(",") if a.variants else [""]

@@ -276,10 +276,9 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
   // large problems: 256x128x32 tiles on 32x32x16 MFMAs (gemm32.hip); WAN_GEMM_KERNEL=v1 keeps this file's kernel
   static const int gen = [] { const char* e = getenv("WAN_GEMM_KERNEL"); return !e ? 3 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v2") ? 2 : !strcmp(e, "v3f") ? 4 : 3; }();
   const bool use_v1 = gen == 1;
-  // Measured (M = 151200, TFLOP/s, gemm256 vs gemm32): qkvo 1004 vs 946, V^T 948 vs 910, ffn1+GELU 877 vs 914, ffn2+gate
-  // 757 vs 929 -- with one wave per SIMD nothing covers a heavy epilogue, so the 256x256 kernel takes the plain
-  // bias epilogues only.  v3f (tests): the 256x256 kernel whatever the problem size / epilogue.
-  if (gen == 4 || (gen == 3 && EPI == WAN_EPI_NONE && ((YM + 255) / 256) * ((XN + 255) / 256) >= 256)) {  // enough 256x256 tiles to fill the 256 CUs
+  // Measured (M = 151200, TFLOP/s, gemm256 with its 4-deep ring vs gemm32): qkvo 1106 vs 946, o+gate 902 vs 869,
+  // ffn1+GELU 1040 vs 918, ffn2+gate 1060 vs 925, V^T 1089 vs 910.  v3f (tests): gemm256 whatever the problem size.
+  if (gen == 4 || (gen == 3 && ((YM + 255) / 256) * ((XN + 255) / 256) >= 256)) {
     const int rc = wan_gemm256_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
                                                         rows_per_batch, st, out_scale);
     if (rc >= 0) return rc;
