@@ -10,5 +10,6 @@ out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
     ops.linear(x, w, b, out=out)
     torch.cuda.synchronize()
-    st = out[0, :24].view(torch.int64).cpu().tolist()
-    print("gemm32 stamps: top->vmcnt", st[1] - st[0], "barrier", st[2] - st[1], "dma issue", st[3] - st[2], "kstep0", st[4] - st[3], "kstep1", st[5] - st[4], "tile", st[5] - st[0])
+    st = out[0, :20].view(torch.int64).cpu().tolist()
+    print("gemm256 stamps (k-tile 60, wave 0): vmcnt wait", st[1] - st[0], "barrier", st[2] - st[1], "k-step 0 (16 MFMA + 4 DMA + 8 reads)", st[3] - st[2],
+          "k-step 1", st[4] - st[3], "tile", st[4] - st[0])

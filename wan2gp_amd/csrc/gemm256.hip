@@ -178,21 +178,31 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
   // k-tile kt in ring slot J, 32 MFMAs.  MFMA m of a k-step multiplies (y tile m>>2, x tile m&3); after MFMA 0,4,8,12 one
   // DMA piece of tile kt+3 (ring slot (J+3)%4, free since this tile's barrier), after the other of the first 12 one
   // fragment read: k-step 0 reads k-step 1's fragments, k-step 1 reads the next tile's k-step 0 fragments (slot (J+1)%4).
+#ifdef G256_TIMING
+  uint64_t stamp[5] = {};
+#define G256_STAMP(I, J) if (kt + (J) == 60) stamp[I] = __builtin_amdgcn_s_memtime();
+#else
+#define G256_STAMP(I, J)
+#endif
 #define G256_SB() __builtin_amdgcn_sched_barrier(0)
 #define G256_STEP(J)                                                                                   \
   if (__builtin_expect(kt + (J) < nk, 1)) {                                                            \
+    G256_STAMP(0, J)                                                                                   \
     if (kt + (J) > 0) {                                                                                \
       if (G_NST == 5) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                \
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* tile kt+J+1 landed; younger pieces may fly */ \
+      G256_STAMP(1, J)                                                                                 \
       __builtin_amdgcn_s_barrier();                                                                    \
       asm volatile("" ::: "memory");                                                                   \
     }                                                                                                  \
+    G256_STAMP(2, J)                                                                                   \
     _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                                   \
       mfma256<F16>(acc[m >> 2][m & 3], f0.x[m & 3], f0.y[m >> 2]); G256_SB();                          \
       if ((m & 3) == 0) dma_piece(((J) + G_NST - 1) % G_NST, m >> 2);                                              \
       else if (m - (m >> 2) - 1 < 8) load_frag(f1, (J), 1, m - (m >> 2) - 1);                          \
       G256_SB();                                                                                       \
     }                                                                                                  \
+    G256_STAMP(3, J)                                                                                   \
     _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                                   \
       mfma256<F16>(acc[m >> 2][m & 3], f1.x[m & 3], f1.y[m >> 2]); G256_SB();                          \
       if ((m & 3) == 0) dma_piece(((J) + G_NST - 1) % G_NST, 4 + (m >> 2));                                        \
@@ -200,6 +210,7 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
       G256_SB();                                                                                       \
     }                                                                                                  \
     advance();                                                                                         \
+    G256_STAMP(4, J)                                                                                   \
   }
   for (int kt = 0; kt < nk; kt += G_NST) {
     G256_STEP(0)
@@ -210,6 +221,13 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
   }
 #undef G256_STEP
 #undef G256_SB
+#ifdef G256_TIMING
+  if (blockIdx.x == 0 && tid == 0) {  // tuning aid: s_memtime stamps of k-tile 60 -> row 0 of tile (0,0), whose epilogue is skipped
+    uint64_t* dbg = reinterpret_cast<uint64_t*>(Out);
+    for (int i = 0; i < 5; ++i) dbg[i] = stamp[i];
+  }
+  if (blockIdx.x == 0) return;
+#endif
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA; last asm MFMAs -> accumulator reads of the epilogue
 
   // ---- epilogue: lane holds, for y row (yt, l31), the 16 consecutive x  xb .. xb+15 of x tile xt ----------------------
