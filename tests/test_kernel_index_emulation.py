@@ -241,3 +241,159 @@ def test_attention_index_algebra(Lq, Lk, nseg):
     for q, v in res.items():
         np.testing.assert_allclose(v, ref[q], rtol=1e-9, atol=1e-9)
     assert cf, "attention fragment reads are not bank-conflict free"
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM generations 2 / 3 (gemm32.hip, gemm256.hip): 32x32x16 MFMA, 64-byte LDS rows
+# ----------------------------------------------------------------------------------------------
+def _pi(rho):
+    """LDS row rho of a 32-row x tile holds x row pi(rho) (gemm32.hip / gemm256.hip staging permutation)."""
+    return 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3)
+
+
+def emulate_gemm256_wave(Y, X, wy, wx, wave_rows_x, k0):
+    """One k-step pair (BK = 32) of one wave of gemm256 (wave_rows_x = 128) or gemm32 (64): stages the two LDS images
+    exactly as the DMA plan does, reads the fragments with the kernel's addresses and returns
+    (acc[yt][xt][lane][r], conflict_free).  Y/X are float arrays [rows, K]."""
+    nxt = wave_rows_x // 32
+    xrows = 2 * wave_rows_x                      # x rows of the workgroup tile
+    ylds = np.zeros(256 * 32)                    # element-addressed images, 32 elements (64 B) per row
+    xlds = np.zeros(xrows * 32)
+    for q in range(256 * 4):                     # Y image: 1024 16-B slots
+        row, pch = q >> 2, q & 3
+        lch = pch ^ ((row >> 2) & 3)
+        ylds[q * 8:q * 8 + 8] = Y[row, k0 + lch * 8:k0 + lch * 8 + 8]
+    for q in range(xrows * 4):
+        row, pch = q >> 2, q & 3
+        lch = pch ^ ((row >> 2) & 3)
+        slab, rem = divmod(row, wave_rows_x)
+        xt, rho = rem >> 5, rem & 31
+        xr = slab * wave_rows_x + xt * 32 + _pi(rho)
+        xlds[q * 8:q * 8 + 8] = X[xr, k0 + lch * 8:k0 + lch * 8 + 8]
+    acc = np.zeros((4, nxt, 64, 16))
+    ok = True
+    for ks in range(2):
+        yfr = np.zeros((4, 64, 8)); xfr = np.zeros((nxt, 64, 8))
+        yoffs = np.zeros((4, 64), dtype=int); xoffs = np.zeros((nxt, 64), dtype=int)
+        for lane in range(64):
+            l31, half = lane & 31, lane >> 5
+            sw = (l31 >> 2) & 3
+            ya = (wy * 128 + l31) * 64 + ((half ^ sw) << 4)
+            xa = (wx * wave_rows_x + l31) * 64 + ((half ^ sw) << 4)
+            for t in range(4):
+                off = t * 2048 + (ya ^ (ks << 5))
+                yoffs[t, lane] = off
+                yfr[t, lane] = ylds[off // 2:off // 2 + 8]
+            for t in range(nxt):
+                off = t * 2048 + (xa ^ (ks << 5))
+                xoffs[t, lane] = off
+                xfr[t, lane] = xlds[off // 2:off // 2 + 8]
+        for t in range(4):
+            ok &= b128_conflict_free(list(yoffs[t]))
+        for t in range(nxt):
+            ok &= b128_conflict_free(list(xoffs[t]))
+        # MFMA 32x32x16: D[i][j] += sum_k A[i][k] B[k][j]; A = X fragment (i = lane&31), B = Y fragment (j = lane&31),
+        # k = 8*(lane>>5) + e;  D lane (j, h) reg r <-> row i = (r&3) + 8*(r>>2) + 4*h
+        for a in range(4):
+            for b in range(nxt):
+                A = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+                for lane in range(64):
+                    A[lane & 31, 8 * (lane >> 5):8 * (lane >> 5) + 8] = xfr[b, lane]
+                    Bm[8 * (lane >> 5):8 * (lane >> 5) + 8, lane & 31] = yfr[a, lane]
+                D = A @ Bm
+                for lane in range(64):
+                    for r in range(16):
+                        acc[a, b, lane, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31]
+    return acc, ok
+
+
+@pytest.mark.parametrize("wave_rows_x", [128, 64])
+def test_gemm32_gemm256_index_algebra(wave_rows_x):
+    """The lane that the epilogue treats as (y row, 16 consecutive x starting at 16*half) really holds those products,
+    and every fragment read is LDS-bank-conflict free."""
+    rng = np.random.default_rng(3)
+    K = 32
+    Y = rng.standard_normal((256, K)); X = rng.standard_normal((2 * wave_rows_x, K))
+    ref = Y @ X.T
+    for wy in range(2):
+        for wx in range(2):
+            acc, ok = emulate_gemm256_wave(Y, X, wy, wx, wave_rows_x, 0)
+            assert ok, "bank conflict in a fragment read"
+            for yt in range(4):
+                for xt in range(wave_rows_x // 32):
+                    for lane in range(64):
+                        yr = wy * 128 + yt * 32 + (lane & 31)
+                        xb = wx * wave_rows_x + xt * 32 + 16 * (lane >> 5)
+                        np.testing.assert_allclose(acc[yt, xt, lane], ref[yr, xb:xb + 16], rtol=1e-12, atol=1e-12)
+
+
+def test_x_row_permutation_is_a_bijection():
+    assert sorted(_pi(r) for r in range(32)) == list(range(32))
+
+
+# ----------------------------------------------------------------------------------------------
+# attention_w64q.hip: exact 3-term bf16 split of -m_ref, and the flat schedule's static invariants
+# ----------------------------------------------------------------------------------------------
+def _bf16_rne(x):
+    """float32 -> bf16 (round to nearest even) -> float32, numpy."""
+    b = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((b + 0x7FFF + ((b >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def test_mref_three_term_bf16_split_is_exact():
+    """set_mref(): hi = bf16(nm), mid = bf16(nm - hi), lo = bf16(nm - hi - mid); hi + mid + lo == nm exactly in fp32
+    (what the S-initialising MFMA [1 1 1 0..] x [hi; mid; lo; 0..] adds up)."""
+    rng = np.random.default_rng(11)
+    nm = np.concatenate([rng.standard_normal(20000).astype(np.float32) * np.float32(37.0),
+                         np.float32([0.0, -0.0, 1.0, -1e-3, 123.456, -88.125, 3e-5, -2.5e4])])
+    hi = _bf16_rne(nm)
+    r1 = (nm - hi).astype(np.float32)
+    mid = _bf16_rne(r1)
+    r2 = (r1 - mid).astype(np.float32)
+    lo = _bf16_rne(r2)
+    assert np.array_equal(lo, r2), "third term must capture the residual exactly"
+    total = ((hi.astype(np.float64) + mid.astype(np.float64)) + lo.astype(np.float64))
+    assert np.array_equal(total.astype(np.float32), nm)
+    assert np.array_equal(total, nm.astype(np.float64))
+
+
+def _flat_constants():
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "wan2gp_amd", "csrc", "attention_w64q.hip")).read()
+    a0 = int(re.search(r"constexpr int FLAT_A0 = (\d+);", src).group(1))
+    b0 = int(re.search(r"constexpr int FLAT_B0 = (\d+);", src).group(1))
+    return a0, b0
+
+
+def test_flat_schedule_invariants():
+    """Static checks of attention_w64q.hip's 68-gap tile (A 0..17 incl. 2 init MFMAs, B 18..33, C 34..51, D 52..67):
+    chunk c of q-block a runs at gap A0+c of its tile, of q-block b at gap B0+c (wrapping into the next tile);
+    chunks 0..3 row max, 4 test, 5+k exp2 of score k (k = 0..31), pair j packed in chunk 5+2j+2 (pair 15: chunk 37)."""
+    A0, B0 = _flat_constants()
+    exp_a = {A0 + 5 + k for k in range(32)}
+    exp_b = {(B0 + 5 + k) % 68 for k in range(32)}
+    assert max(exp_a) <= 67, "q-block a's chunks must stay inside its own tile"
+    assert not (exp_a & exp_b), "at most one v_exp_f32 per MFMA gap"
+    # first readers of S come >= 3 MFMAs after the slot that produced it (asm MFMAs are not hazard-padded)
+    assert A0 >= 17 + 3 and B0 >= 51 + 3
+    pack_a = [A0 + 5 + 2 * j + 2 for j in range(16)]
+    pack_b = [B0 + 5 + 2 * j + 2 for j in range(16)]           # absolute gaps; PV_b runs at 68 + 18 + i
+    for c4 in range(4):
+        need = max(pack_a[4 * c4:4 * c4 + 4])
+        assert need + 2 <= 52 + 4 * c4, f"P_a k-step {c4} packed at gap {need}, PV_a reads it at {52 + 4 * c4}"
+        need = max(pack_b[4 * c4:4 * c4 + 4])
+        assert need + 2 <= 68 + 18 + 4 * c4, f"P_b k-step {c4} packed at gap {need}, PV_b reads it at {86 + 4 * c4}"
+    # S tiles are overwritten by the next QK^T slot only after their last exp2
+    assert max(exp_a) < 68 + 0 and (B0 + 5 + 31) < 68 + 34
+    # q-block b's chunks that run in the next tile are exactly 9..37 (the kernel's `G <= 28 -> chunk G + 9`)
+    assert 68 - B0 == 9
+    # V^T(t) fragment f is read at gap 20+2f: after PV_b(t-1) used the old one (gap 18+f), before PV_a(t) needs it (52+f)
+    for f in range(16):
+        g = 20 + 2 * f
+        assert 18 + f < g and g + 2 <= 52 + f
+    # K fragments in need order: read r at gap 52+2r (r < 8) of the previous tile or gap r-8 of this tile, used by MFMA 2+r
+    for r in range(16):
+        g = (52 + 2 * r - 68) if r < 8 else (r - 8)
+        assert g + 2 <= 2 + r
