@@ -163,6 +163,43 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
     else f.x[r - 4] = *(g256_lds_u4*)(lds + (s * G_XST + (r - 4) * 2048) + (xaddr0 ^ (ks << 5)));
   };
 
+  // ---- gated-residual epilogue operands: loaded one x tile ahead ---------------------------------------------------------
+  // One wave per SIMD: nothing covers the latency of these loads if they are issued where they are used (measured:
+  // the o / ffn2 projections lost 10-30 % to it, depending on the box's memory latency).
+  uint4 rraw[2][4][2], eraw[2][4][2], mraw[2][2];  // [x tile parity][y tile][half]; requested one x tile ahead
+  uint32_t brow_idx[4];                            // batch (stream) of each of the lane's four y rows, for the gate lookup
+  if (EPI == WAN_EPI_GATE_RES) {
+#pragma unroll
+    for (int yt = 0; yt < 4; ++yt) {
+      const int64_t yr = y0 + wy * 128 + yt * 32 + l31;
+      brow_idx[yt] = (uint32_t)(yr < YM ? yr : YM - 1) / (uint32_t)rows_per_batch;
+    }
+  }
+  auto epi_loads = [&](int xt) {  // xt is a compile-time constant at every call site
+    if (EPI != WAN_EPI_GATE_RES) return;
+    const int64_t xb = x0 + wx * 128 + xt * 32 + half * 16;
+    if (xb + 16 > XN) return;
+    const int pb = xt & 1;
+    if (gate_idx >= 0) {
+      const bf16_t* mp = mod + (int64_t)gate_idx * XN + xb;
+      mraw[pb][0] = *reinterpret_cast<const uint4*>(mp);
+      mraw[pb][1] = *reinterpret_cast<const uint4*>(mp + 8);
+    }
+#pragma unroll
+    for (int yt = 0; yt < 4; ++yt) {
+      int64_t yr = y0 + wy * 128 + yt * 32 + l31;
+      if (yr > YM - 1) yr = YM - 1;
+      const bf16_t* rptr = R + yr * ldo + xb;
+      rraw[pb][yt][0] = *reinterpret_cast<const uint4*>(rptr);
+      rraw[pb][yt][1] = *reinterpret_cast<const uint4*>(rptr + 8);
+      if (gate_idx >= 0) {
+        const bf16_t* ep = e + ((int64_t)brow_idx[yt] * n_mod + gate_idx) * XN + xb;
+        eraw[pb][yt][0] = *reinterpret_cast<const uint4*>(ep);
+        eraw[pb][yt][1] = *reinterpret_cast<const uint4*>(ep + 8);
+      }
+    }
+  };
+
   const int nk = K / G_BK;
   stage(0);
   stage(1);
@@ -221,6 +258,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
   }
 #undef G256_STEP
 #undef G256_SB
+  epi_loads(0);  // x tile 0's operands: requested before the accumulators are drained (kept out of the main loop: live
+                 // across it they were spilled to scratch, which exposes their latency at the start instead)
 #ifdef G256_TIMING
   if (blockIdx.x == 0 && tid == 0) {  // tuning aid: s_memtime stamps of k-tile 60 -> row 0 of tile (0,0), whose epilogue is skipped
     uint64_t* dbg = reinterpret_cast<uint64_t*>(Out);
@@ -231,17 +270,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA; last asm MFMAs -> accumulator reads of the epilogue
 
   // ---- epilogue: lane holds, for y row (yt, l31), the 16 consecutive x  xb .. xb+15 of x tile xt ----------------------
-  // One wave per SIMD: nothing else covers the latency of the residual / gate loads, so all of an x tile's loads are
-  // issued before the first of its four 16-wide groups is computed, and the batch index is a 32-bit division per row
-  // (4 per lane), not a 64-bit one per group.
-  uint32_t brow_idx[4];  // batch (stream) of each of the lane's four y rows, for the gate lookup
-  if (EPI == WAN_EPI_GATE_RES) {
-#pragma unroll
-    for (int yt = 0; yt < 4; ++yt) {
-      const int64_t yr = y0 + wy * 128 + yt * 32 + l31;
-      brow_idx[yt] = (uint32_t)(yr < YM ? yr : YM - 1) / (uint32_t)rows_per_batch;
-    }
-  }
+  // The residual / gate operands of x tile xt were requested one tile ahead (epi_loads); the batch index is a 32-bit
+  // division per row (4 per lane), not a 64-bit one per group.
 #pragma unroll
   for (int xt = 0; xt < 4; ++xt) {
     const int64_t xb = x0 + wx * 128 + xt * 32 + half * 16;
@@ -261,28 +291,8 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
         }
       }
     }
-    // loads of this x tile: residual rows, the gate's modulation (per x) and e rows (per x and batch)
-    uint4 rraw[4][2], eraw[4][2], mraw[2];
-    if (EPI == WAN_EPI_GATE_RES && full) {
-      if (gate_idx >= 0) {
-        const bf16_t* mp = mod + (int64_t)gate_idx * XN + xb;
-        mraw[0] = *reinterpret_cast<const uint4*>(mp);
-        mraw[1] = *reinterpret_cast<const uint4*>(mp + 8);
-      }
-#pragma unroll
-      for (int yt = 0; yt < 4; ++yt) {
-        int64_t yr = y0 + wy * 128 + yt * 32 + l31;
-        if (yr > YM - 1) yr = YM - 1;
-        const bf16_t* rptr = R + yr * ldo + xb;
-        rraw[yt][0] = *reinterpret_cast<const uint4*>(rptr);
-        rraw[yt][1] = *reinterpret_cast<const uint4*>(rptr + 8);
-        if (gate_idx >= 0) {
-          const bf16_t* ep = e + ((int64_t)brow_idx[yt] * n_mod + gate_idx) * XN + xb;
-          eraw[yt][0] = *reinterpret_cast<const uint4*>(ep);
-          eraw[yt][1] = *reinterpret_cast<const uint4*>(ep + 8);
-        }
-      }
-    }
+    const int pb = xt & 1;
+    if (xt + 1 < 4) epi_loads(xt + 1);  // next x tile's operands fly while this one is computed
 #pragma unroll
     for (int yt = 0; yt < 4; ++yt) {
       const int64_t yr = y0 + wy * 128 + yt * 32 + l31;
@@ -300,14 +310,14 @@ __global__ __launch_bounds__(256) void gemm256_kernel(const bf16_t* __restrict__
           for (int j = 0; j < 16; ++j) v[j] = g256_gelu_tanh(v[j]);
         } else if (EPI == WAN_EPI_GATE_RES) {
           float rv[16];
-          unpack8t<F16>(rraw[yt][0], rv);
-          unpack8t<F16>(rraw[yt][1], rv + 8);
+          unpack8t<F16>(rraw[pb][yt][0], rv);
+          unpack8t<F16>(rraw[pb][yt][1], rv + 8);
           if (gate_idx >= 0) {
             float mv[16], ev[16];
-            unpack8t<F16>(mraw[0], mv);
-            unpack8t<F16>(mraw[1], mv + 8);
-            unpack8t<F16>(eraw[yt][0], ev);
-            unpack8t<F16>(eraw[yt][1], ev + 8);
+            unpack8t<F16>(mraw[pb][0], mv);
+            unpack8t<F16>(mraw[pb][1], mv + 8);
+            unpack8t<F16>(eraw[pb][yt][0], ev);
+            unpack8t<F16>(eraw[pb][yt][1], ev + 8);
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = rv[j] + v[j] * rnd16<F16>(mv[j] + ev[j]);
           } else {
