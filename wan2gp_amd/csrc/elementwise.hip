@@ -42,7 +42,18 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
   }
   ss = wave_sum(ss);
   const float r = rsqrtf(ss / (float)d + eps);
-  const int64_t pos = (row % L) + pos0;
+  const int64_t pos = (int64_t)((uint32_t)row % (uint32_t)L) + pos0;  // rows < 2^31 (launcher): 32-bit modulo, a 64-bit one costs ~100 VALU per lane
+  // the lane's column inside the 128-wide head is the same for all of its chunks (c = lane + 64 i, 64*8 = 0 mod 128):
+  // ONE cos / sin fetch per row instead of one per chunk (the kernel was VMEM-issue bound: 6 loads per 16 B of data)
+  float cs[8], sn[8];
+  if (cosT != nullptr) {
+    const int hc = (lane * 8) & 127;
+    const float4* cp = reinterpret_cast<const float4*>(cosT + pos * 128 + hc);
+    const float4* sp = reinterpret_cast<const float4*>(sinT + pos * 128 + hc);
+    const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+    cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+    sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+  }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
@@ -54,12 +65,6 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[i][j] * r) * wf[j]);  // x *= rsqrt ; x *= weight
       if (cosT != nullptr) {
-        const int hc = (c * 8) & 127;  // column inside the 128-wide head
-        const float4* cp = reinterpret_cast<const float4*>(cosT + pos * 128 + hc);
-        const float4* sp = reinterpret_cast<const float4*>(sinT + pos * 128 + hc);
-        float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
-        float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
           // x0' = x0*cos0 - x1*sin0 ; x1' = x1*cos1 + x0*sin1   (fp32, one rounding to bf16)
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     }
   }
   const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
-  const int64_t b = row / rows_per_batch;
+  const int64_t b = (int64_t)((uint32_t)row / (uint32_t)rows_per_batch);  // 32-bit: a 64-bit division costs ~100 VALU per lane
 
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void gated_residual_kernel(
     unpack8(*reinterpret_cast<const uint4*>(x + row * d + c * 8), xv);
     unpack8(*reinterpret_cast<const uint4*>(y + row * d + c * 8), yv);
     if (gate_idx >= 0) {
-      const int64_t b = row / rows_per_batch;
+      const int64_t b = (int64_t)((uint32_t)row / (uint32_t)rows_per_batch);  // 32-bit: a 64-bit division costs ~100 VALU per lane
       float m[8], ev[8];
       unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)gate_idx * d + c * 8), m);
       unpack8(*reinterpret_cast<const uint4*>(e + (b * n_mod + gate_idx) * (int64_t)d + c * 8), ev);
@@ -361,6 +366,7 @@ extern "C" int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16*
   WAN_REQUIRE((cos == nullptr) == (sin == nullptr), "wan_rmsnorm_rope: cos/sin must both be set or both null");
   WAN_REQUIRE(cos == nullptr || d % 128 == 0, "wan_rmsnorm_rope: RoPE needs d %% 128 == 0 (head_dim 128)");
   WAN_REQUIRE(k == nullptr || wk != nullptr, "wan_rmsnorm_rope: wk null");
+  WAN_REQUIRE(rows < ((int64_t)1 << 31) && L > 0 && L < ((int64_t)1 << 31), "wan_rmsnorm_rope: rows / L must fit 31 bits");
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
   dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), k ? 2 : 1);
@@ -376,6 +382,8 @@ extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16*
   WAN_REQUIRE(x && out && mod && e, "wan_ln_modulate: null pointer");
   WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_ln_modulate: d=%d must be a multiple of 8 and <= 8192", d);
   WAN_REQUIRE(shift_idx >= 0 && shift_idx < n_mod && scale_idx >= 0 && scale_idx < n_mod, "wan_ln_modulate: bad idx");
+  WAN_REQUIRE(rows < ((int64_t)1 << 31) && rows_per_batch > 0 && rows_per_batch < ((int64_t)1 << 31),
+              "wan_ln_modulate: rows / rows_per_batch must fit 31 bits");
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
   dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
