@@ -184,6 +184,32 @@ def test_gemm_transposed_vt(ops, M, N, K):
     assert (vt[:, M:] == 0).all(), "padding columns must stay zero"
 
 
+def test_gemm_256x256_kernel_default_path(ops):
+    """>= 256 tiles of 256x256 select gemm256.hip (one wave per SIMD, accumulators in the accumulator file) without any
+    environment override: ragged M (the last y tile has 37 rows), every epilogue, two batches for the gate, and the
+    transposed V^T form with a ragged token count.  References as in the small-shape tests."""
+    g = torch.Generator().manual_seed(256)
+    M, N, K, B = 16 * 256 + 37 + 1, 4096, 128, 2        # 17 x 16 = 272 tiles; M even so that rows split into 2 batches
+    x = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = (0.1 * torch.randn(N, generator=g)).to(BF)
+    y = _gemm_ref(x, w, b)
+    assert_bf16_close(ops.linear(cu(x), cu(w), cu(b)), y, frac=0.05, what="gemm256 none", floor=0.25)
+    assert_bf16_close(ops.linear(cu(x), cu(w), cu(b), epilogue=1), torch.nn.functional.gelu(y, approximate="tanh"), frac=0.05,
+                      ulps=3, what="gemm256 gelu", floor=0.25)
+    r = torch.randn(M, N, generator=g).to(BF)
+    mod = (torch.randn(1, 6, N, generator=g) / N ** 0.5).to(BF); e0 = (0.5 * torch.randn(B, 6, N, generator=g)).to(BF)
+    rpb = M // B
+    ref = torch.cat([torch.addcmul(r[i * rpb:(i + 1) * rpb], y[i * rpb:(i + 1) * rpb], (mod + e0[i:i + 1]).chunk(6, dim=1)[5][0])
+                     for i in range(B)])
+    rr = cu(r.clone())
+    got = ops.linear(cu(x), cu(w), cu(b), epilogue=2, residual=rr, mod=cu(mod), e=cu(e0), gate_idx=5, out=rr)
+    assert_bf16_close(got, ref, frac=0.05, what="gemm256 gate residual (in place)", floor=(r.float().abs() + y.float().abs()))
+    # transposed: weights are the y operand (4096 rows = 16 y tiles), tokens the x operand (ragged: 4134 = 16 x tiles + 38)
+    vt = ops.linear(cu(x), cu(w), cu(b), epilogue=3)
+    assert_bf16_close(vt[:, :M], y.t(), frac=0.05, what="gemm256 V^T", floor=0.25)
+    assert (vt[:, M:] == 0).all(), "padding columns must stay zero"
+
+
 def test_gemm_rejects_bad_k(ops):
     from wan2gp_amd.lib import WanHipError
     x = torch.zeros(8, 96, dtype=BF).cuda(); w = torch.zeros(128, 96, dtype=BF).cuda()
