@@ -159,6 +159,19 @@ int wan_act_bf16(const wan_bf16* x, wan_bf16* y, int64_t n, int act, void* strea
 int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C, int M,
                   int N, int K, void* stream);
 
+/* ---- UMT5 text encoder (models/wan/modules/t5.py) ------------------------------ */
+/* T5Attention core (t5.py:109-131) for head_dim 64: out = softmax_fp32(bf16(q k^T) + pos_bias, masked) v.
+ * NO 1/sqrt(d) scaling.  q, k, v, out: [B, L, H*64] bf16 (the Linear outputs viewed per head).
+ * relbias: [H, 2L-1] bf16 with relbias[h][j - i + L - 1] = T5RelativeEmbedding bias of key j for query i
+ * (t5.py:232-263 evaluated once per distinct relative position).  mask: [B, L] int32, 0 = padding key
+ * (masked_fill_(mask == 0, finfo.min), t5.py:119-123) or NULL.  L <= 1024.
+ * The Linear layers of the encoder are wan_gemm_bf16 (bias = NULL), T5LayerNorm is wan_rmsnorm_rope(q, NULL, w, ...)
+ * without RoPE (same two roundings, t5.py:66-71), residual adds are the WAN_EPI_GATE_RES epilogue with gate_idx -1. */
+int wan_t5_attention(const wan_bf16* q, const wan_bf16* k, const wan_bf16* v, const wan_bf16* relbias,
+                     const int32_t* mask, wan_bf16* out, int B, int L, int H, void* stream);
+/* out = bf16(a * b) elementwise (T5FeedForward: fc1(x) * gate(x), t5.py:149); n % 8 == 0 */
+int wan_mul_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
+
 /* ---- sampler (fp32 latents) -------------------------------------------------------------- */
 
 /* out = sum_i coef[i] * in[i]  (n_in <= 6), fp32.  The flow-matching scheduler updates

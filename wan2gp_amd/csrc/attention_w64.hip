@@ -131,7 +131,6 @@ __device__ __forceinline__ void tile_w64(lds_cchar* smem, const int (&kaddr)[8],
                                          QBlock& a, QBlock& b, int kv_rem, int half, float c, char* smem_rw, Dma& dma,
                                          uint64_t* stamp = nullptr, bool rec = false) {
 #define STAMP(K) do { if (TIMING && rec) stamp[K] = __builtin_amdgcn_s_memtime(); } while (0)
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   uint4 oraw;
   oraw.x = oraw.y = oraw.z = oraw.w = 0x3f803f80u;  // bf16 1.0 x 8
   const mfma_bf16x8 ones = __builtin_bit_cast(mfma_bf16x8, oraw);
@@ -291,7 +290,6 @@ __global__ __launch_bounds__(256) void attn_w64_kernel(const bf16_t* __restrict_
   const bf16_t* vbase = Vt + ((int64_t)bk * H * 128 + (int64_t)h * 128) * ldv;
   bf16_t* obase = O + ((int64_t)b * Lq) * rs + (int64_t)h * 128;
 
-  constexpr int NSLOT = 4;  // 16-B DMA pieces per lane per image (1024 pieces / 256 lanes)
   const int64_t q0 = (int64_t)qb * 256 + wave * 64;
   mfma_bf16x8 qfa[8], qfb[8];
   {

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(const bf16_t* __restrict
 #endif
 #define G32_STEP(J)                                                                          \
   if (__builtin_expect(kt + (J) < nk, 1)) {                                                  \
-    constexpr int J0 = (J);                                                                  \
+    constexpr int J0 = (J); (void)J0;                                                        \
     G32_STAMP(0)                                                                             \
     if (kt + (J) > 0) {                                                                      \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile kt+J+1 landed (issued a tile ago) */ \

@@ -160,6 +160,28 @@ def pay_attention(qkv_list, dropout_p=0., softmax_scale=None, causal=False, wind
     return o.type(out_dtype)
 
 
+def t5_attention(q, k, v, relbias, mask=None, out=None):
+    """T5Attention core (models/wan/modules/t5.py:109-131), head_dim 64, no scaling.  q,k,v [B,L,H*64] bf16;
+    relbias [H, 2L-1] bf16 (relbias[h][j-i+L-1]); mask [B,L] int32 (0 = padding key) or None."""
+    _req(q, BF16, "q"); _req(k, BF16, "k"); _req(v, BF16, "v"); _req(relbias, BF16, "relbias")
+    B, L, C = q.shape
+    H = C // 64
+    if mask is not None:
+        _req(mask, torch.int32, "mask")
+    out = torch.empty_like(q) if out is None else out
+    check(_L.load().wan_t5_attention(ptr(q), ptr(k), ptr(v), ptr(relbias), ptr(mask), ptr(out), B, L, H, stream_ptr()),
+          "wan_t5_attention")
+    return out
+
+
+def mul(a, b, out=None):
+    """bf16(a * b) elementwise (T5FeedForward gate product, t5.py:149)."""
+    _req(a, BF16, "a"); _req(b, BF16, "b")
+    out = torch.empty_like(a) if out is None else out
+    check(_L.load().wan_mul_bf16(ptr(a), ptr(b), ptr(out), a.numel(), stream_ptr()), "wan_mul_bf16")
+    return out
+
+
 def patch_embed(x, w, bias, y=None):
     """patch_embedding Conv3d(k=s=(1,2,2)) fp32 -> bf16 tokens [B,L,d] (model.py:1631,1731)."""
     _req(x, torch.float32, "x"); _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias")
