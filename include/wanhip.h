@@ -172,6 +172,21 @@ int wan_t5_attention(const wan_bf16* q, const wan_bf16* k, const wan_bf16* v, co
 /* out = bf16(a * b) elementwise (T5FeedForward: fc1(x) * gate(x), t5.py:149); n % 8 == 0 */
 int wan_mul_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
 
+/* ---- checkpoint load: LoRA merge + qint8 dequantisation -------------------------- */
+/* The reference hands LoRA files to mmgp.offload.load_loras_into_model / activate_loras (wgp.py:6922-6931,
+ * shared/utils/loras_mutipliers.py:143-148), whose patched Linear.forward adds m*(alpha/r)*(x A^T) B^T per call.  Resident
+ * weights are merged instead: acc (fp32 scratch [N,K], zeroed by the caller) collects every adapter's delta, then the
+ * bf16 weight takes one rounding.
+ *   wan_lora_accumulate:   acc += scale * lora_B[N,r] @ lora_A[r,K]      (scale = multiplier * alpha / r)
+ *   wan_axpy_f32:          acc += alpha * x                              (`.diff` / `.diff_b` full deltas)
+ *   wan_add_f32_into_bf16: w = bf16(float(w) + acc)  elementwise
+ *   wan_dequant_i8:        out[n,k] = bf16(float(data[n,k]) * scale[n])  (optimum-quanto qint8 `_data` / `_scale`,
+ *                          the `quanto_*_int8` checkpoints of any2video.py:187-224) */
+int wan_lora_accumulate(float* acc, const float* lora_B, const float* lora_A, float scale, int N, int K, int r, void* stream);
+int wan_axpy_f32(float* acc, const float* x, float alpha, int64_t n, void* stream);
+int wan_add_f32_into_bf16(wan_bf16* w, const float* acc, int64_t n, void* stream);
+int wan_dequant_i8(const int8_t* data, const float* scale, wan_bf16* out, int64_t N, int64_t K, void* stream);
+
 /* ---- sampler (fp32 latents) -------------------------------------------------------------- */
 
 /* out = sum_i coef[i] * in[i]  (n_in <= 6), fp32.  The flow-matching scheduler updates

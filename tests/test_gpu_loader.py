@@ -1,0 +1,263 @@
+"""GPU parity of the checkpoint / LoRA row, through the C ABI.
+
+  * wan_lora_accumulate / wan_axpy_f32 / wan_add_f32_into_bf16: the merged weight must be a correct bf16 rounding of the
+    float64 value W + sum m_i (alpha_i/r_i) B_i A_i (+ diffs) -- half a bf16 ulp plus 2^-20 of the summed terms' magnitude for the fp32 accumulation
+    (oracle/loader_oracle.py; "parity unpinned": mmgp is not in the reference tree).
+  * merged model == run-time adapter form y = xW^T + m s (xA^T)B^T within bf16 GEMM tolerance.
+  * wan_dequant_i8 bit-exact; safetensors file -> WanModelHIP bit-identical forward to a direct load_state_dict.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loader_oracle as LO
+from oracle import wan_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def cu(t):
+    return t.cuda().contiguous()
+
+
+@pytest.mark.parametrize("N,K,r", [(64, 64, 16), (100, 72, 4), (257, 130, 33), (1536, 1536, 64), (8, 8, 1), (5120, 1024, 128)])
+def test_lora_accumulate_vs_float64(N, K, r):
+    from wan2gp_amd import ops
+    g = torch.Generator().manual_seed(N + K + r)
+    B, A = torch.randn(N, r, generator=g), torch.randn(r, K, generator=g)
+    acc0 = torch.randn(N, K, generator=g)
+    got = ops.lora_accumulate(cu(acc0.clone()), cu(B), cu(A), 0.37).cpu()
+    ref = acc0.double() + 0.37 * (B.double() @ A.double())
+    mag = acc0.abs().double() + 0.37 * (B.abs().double() @ A.abs().double())
+    assert ((got.double() - ref).abs() <= 2.0 ** -20 * mag * (r ** 0.5 + 2)).all()
+
+
+def _fake_model(W):
+    return types.SimpleNamespace(_weights={k: cu(v) for k, v in W.items()}, device=torch.device("cuda"))
+
+
+def _adapters(g, shapes, r=8):
+    """Two stacked LoRA files over `shapes` = {module: (N, K)}: file 0 has alpha, file 1 has none + diff / diff_b."""
+    f0, f1 = {}, {}
+    for mod, (N, K) in shapes.items():
+        f0[f"diffusion_model.{mod}.lora_A.weight"] = torch.randn(r, K, generator=g) * 0.1
+        f0[f"diffusion_model.{mod}.lora_B.weight"] = torch.randn(N, r, generator=g) * 0.1
+        f0[f"diffusion_model.{mod}.alpha"] = torch.tensor(4.0)
+        f1[f"{mod}.lora_down.weight"] = (torch.randn(2 * r, K, generator=g) * 0.05).half()
+        f1[f"{mod}.lora_up.weight"] = (torch.randn(N, 2 * r, generator=g) * 0.05).half()
+    first = next(iter(shapes))
+    f1[f"{first}.diff"] = torch.randn(*shapes[first], generator=g) * 0.01
+    f1[f"{first}.diff_b"] = torch.randn(shapes[first][0], generator=g) * 0.01
+    return f0, f1
+
+
+def _oracle_adapters(files, mod):
+    out = []
+    for f in files:
+        ad = {}
+        for k, v in f.items():
+            k = k.replace("diffusion_model.", "")
+            if not k.startswith(mod + "."):
+                continue
+            suf = k[len(mod) + 1:]
+            slot = {"lora_A.weight": "A", "lora_down.weight": "A", "lora_B.weight": "B", "lora_up.weight": "B", "alpha": "alpha",
+                    "diff": "diff", "diff_b": "diff_b"}[suf]
+            ad[slot] = float(v) if slot == "alpha" else v.float()
+        out.append(ad)
+    return out
+
+
+def test_merged_loras_roundings_remerge_unload():
+    from wan2gp_amd.lora import MergedLoras
+    g = torch.Generator().manual_seed(3)
+    shapes = {"blocks.0.self_attn.q": (128, 128), "blocks.0.ffn.0": (320, 128), "blocks.1.ffn.2": (128, 320)}
+    W = {}
+    for mod, (N, K) in shapes.items():
+        W[mod + ".weight"] = (torch.randn(N, K, generator=g) * K ** -0.5).to(BF)
+        W[mod + ".bias"] = (torch.randn(N, generator=g) * 0.1).to(BF)
+    model = _fake_model(W)
+    files = _adapters(g, shapes)
+    ml = MergedLoras(model)
+    for f in files:
+        ml.add(f, normalized=True)
+    assert ml.errors == []
+
+    def check(mults):
+        for mod in shapes:
+            ads = _oracle_adapters(files, mod)
+            w0, b0 = W[mod + ".weight"], W[mod + ".bias"]
+            exact = LO.merged_weight_exact(w0, ads, mults)
+            mag = float(w0.abs().max()) + float((exact - w0.double()).abs().max())
+            assert LO.bf16_round_ok(model._weights[mod + ".weight"].cpu(), exact, mag).all(), (mod, mults)
+            exb = LO.merged_bias_exact(b0, ads, mults)
+            assert LO.bf16_round_ok(model._weights[mod + ".bias"].cpu(), exb, float(b0.abs().max()) + 0.1).all(), (mod, mults)
+
+    ml.set_multipliers([1.0, 0.5]); check([1.0, 0.5])
+    snap = {k: v.clone() for k, v in model._weights.items()}
+    ml.set_multipliers([0.0, 1.25]); check([0.0, 1.25])                 # phase switch: re-merged from the pristine base
+    ml.set_multipliers([1.0, 0.5])                                      # and back: bit-identical, no drift
+    assert all(torch.equal(model._weights[k], snap[k]) for k in snap)
+    ml.set_multipliers([0.0, 0.0])
+    assert all(torch.equal(model._weights[k].cpu(), W[k]) for k in W)
+    ml.set_multipliers([1.0]); check([1.0, 0.0])                        # short list: missing multipliers are 0
+    ml.unload()
+    assert all(torch.equal(model._weights[k].cpu(), W[k]) for k in W)
+
+
+def test_merged_equals_runtime_adapter_form():
+    """y = x W'^T + b' on the GEMM kernel vs the run-time LoRA formula in float64."""
+    from wan2gp_amd import ops
+    from wan2gp_amd.lora import MergedLoras
+    g = torch.Generator().manual_seed(9)
+    N, K, M = 256, 128, 192
+    shapes = {"blocks.0.ffn.0": (N, K)}
+    W = {"blocks.0.ffn.0.weight": (torch.randn(N, K, generator=g) * K ** -0.5).to(BF), "blocks.0.ffn.0.bias": (torch.randn(N, generator=g) * 0.1).to(BF)}
+    model = _fake_model(W)
+    files = _adapters(g, shapes)
+    ml = MergedLoras(model)
+    for f in files:
+        ml.add(f, normalized=True)
+    mults = [0.8, 1.0]
+    ml.set_multipliers(mults)
+    x = torch.randn(M, K, generator=g).to(BF)
+    y = ops.linear(cu(x), model._weights["blocks.0.ffn.0.weight"], model._weights["blocks.0.ffn.0.bias"]).float().cpu()
+    ref = LO.runtime_lora_linear(x, W["blocks.0.ffn.0.weight"], W["blocks.0.ffn.0.bias"], _oracle_adapters(files, "blocks.0.ffn.0"), mults)
+    base = LO.runtime_lora_linear(x, W["blocks.0.ffn.0.weight"], W["blocks.0.ffn.0.bias"], [], [])
+    err = (y.double() - ref).norm() / ref.norm()
+    assert err < 6e-3, err                                             # bf16 weights + bf16 output rounding
+    assert (ref - base).norm() / ref.norm() > 0.05                      # the adapters actually moved the output
+
+
+def test_shape_mismatch_and_fp32_locked_are_reported_not_merged():
+    from wan2gp_amd.lora import MergedLoras
+    W = {"blocks.0.ffn.0.weight": torch.zeros(16, 8, dtype=BF), "head.head.weight": torch.zeros(8, 8)}
+    model = _fake_model(W)
+    ml = MergedLoras(model)
+    ml.add({"blocks.0.ffn.0.lora_A.weight": torch.ones(2, 9), "blocks.0.ffn.0.lora_B.weight": torch.ones(16, 2),
+            "head.head.lora_A.weight": torch.ones(2, 8), "head.head.lora_B.weight": torch.ones(8, 2),
+            "blocks.9.ffn.0.lora_A.weight": torch.ones(2, 8), "blocks.9.ffn.0.lora_B.weight": torch.ones(16, 2)}, normalized=True)
+    assert len(ml.errors) == 3
+    ml.set_multipliers([1.0])
+    assert all(float(v.float().abs().sum()) == 0.0 for v in model._weights.values())
+
+
+@pytest.mark.parametrize("N,K", [(7, 5), (256, 384), (1536, 8960)])
+def test_dequant_i8_bit_exact(N, K):
+    from wan2gp_amd import ops
+    g = torch.Generator().manual_seed(N)
+    data = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8)
+    scale = torch.rand(N, generator=g) * 0.01 + 1e-4
+    got = ops.dequant_i8(cu(data), cu(scale)).cpu()
+    assert torch.equal(got, LO.dequant_i8(data, scale))
+
+
+def _forward(m, cfg):
+    lat, ctx, _, _ = O.synth_inputs(cfg, 3, 8, 8, seed=2)
+    return m([lat.cuda()], t=torch.tensor([500]), context=[ctx.cuda()])[0].cpu()
+
+
+def test_checkpoint_files_to_resident_model(tmp_path):
+    """Wan-named file with the ComfyUI prefix, a Diffusers-named file and a quanto-int8 file all load into WanModelHIP;
+    the first two give a forward bit-identical to load_state_dict of the same tensors."""
+    from safetensors.torch import save_file
+    from wan2gp_amd.checkpoint import load_wan_checkpoint
+    from wan2gp_amd.model import WanModelHIP
+    cfg = O.make_config("tiny")
+    W = O.synth_weights(cfg, seed=5)
+    mk = lambda: WanModelHIP(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads,
+                             num_layers=cfg.num_layers, in_dim=cfg.in_dim)
+    ref = _forward(mk().load_state_dict(W), cfg)
+
+    p1 = str(tmp_path / "wan_mbf16.safetensors")
+    save_file({"model.diffusion_model." + k: v.contiguous() for k, v in W.items()} | {"vae.decoder.x": torch.zeros(2)}, p1)
+    assert torch.equal(_forward(load_wan_checkpoint(mk(), p1), cfg), ref)
+
+    inv = {"self_attn.q": "attn1.to_q", "self_attn.k": "attn1.to_k", "self_attn.v": "attn1.to_v", "self_attn.o": "attn1.to_out.0",
+           "self_attn.norm_q": "attn1.norm_q", "self_attn.norm_k": "attn1.norm_k",
+           "cross_attn.q": "attn2.to_q", "cross_attn.k": "attn2.to_k", "cross_attn.v": "attn2.to_v", "cross_attn.o": "attn2.to_out.0",
+           "cross_attn.norm_q": "attn2.norm_q", "cross_attn.norm_k": "attn2.norm_k",
+           "ffn.0": "ffn.net.0.proj", "ffn.2": "ffn.net.2", "norm3": "norm2", "modulation": "scale_shift_table"}
+    top = {"text_embedding.0": "condition_embedder.text_embedder.linear_1", "text_embedding.2": "condition_embedder.text_embedder.linear_2",
+           "time_embedding.0": "condition_embedder.time_embedder.linear_1", "time_embedding.2": "condition_embedder.time_embedder.linear_2",
+           "time_projection.1": "condition_embedder.time_proj", "head.head": "proj_out"}
+    D = {}
+    for k, v in W.items():
+        if k == "head.modulation":
+            D["scale_shift_table"] = v
+            continue
+        parts = k.split(".")
+        if parts[0] == "blocks":
+            rest = ".".join(parts[2:])
+            for a, b in inv.items():
+                if rest == a or rest.startswith(a + "."):
+                    rest = b + rest[len(a):]
+                    break
+            D[f"blocks.{parts[1]}.{rest}"] = v
+        else:
+            for a, b in top.items():
+                if k.startswith(a + "."):
+                    k = b + k[len(a):]
+                    break
+            D[k] = v
+    assert set(D) != set(W)
+    p2 = str(tmp_path / "diffusers.safetensors")
+    save_file({k: v.contiguous() for k, v in D.items()}, p2)
+    assert torch.equal(_forward(load_wan_checkpoint(mk(), p2), cfg), ref)
+
+    # quanto qint8: per-row symmetric quantisation of every block Linear weight
+    Q, Wq = {}, {}
+    for k, v in W.items():
+        if k.startswith("blocks.") and k.endswith(".weight") and v.dim() == 2 and v.dtype == BF:
+            scale = (v.float().abs().amax(dim=1, keepdim=True) / 127).clamp_min(1e-8)
+            data = torch.round(v.float() / scale).clamp(-128, 127).to(torch.int8)
+            Q[k + "._data"], Q[k + "._scale"] = data, scale.to(BF)
+            Q[k[: -len("weight")] + "input_scale"] = torch.ones(())
+            Wq[k] = LO.dequant_i8(data, scale.to(BF))
+        else:
+            Q[k] = Wq[k] = v
+    p3 = str(tmp_path / "quanto_bf16_int8.safetensors")
+    save_file({k: v.contiguous() for k, v in Q.items()}, p3)
+    assert torch.equal(_forward(load_wan_checkpoint(mk(), p3), cfg), _forward(mk().load_state_dict(Wq), cfg))
+
+
+def test_pipeline_applies_per_phase_multipliers():
+    """Two experts, the Lightning-style string "1;0 0;1" (profiles/wan_2_2/*.json): expert 1 runs phase 1 with adapter 0,
+    expert 2 runs phase 2 with adapter 1 -- identical to experts whose weights were merged statically."""
+    from wan2gp_amd.lora import load_loras_into_model, parse_loras_multipliers
+    from wan2gp_amd.model import WanModelHIP
+    from wan2gp_amd.pipeline import WanAny2VHIP
+    cfg = O.make_config("tiny")
+    g = torch.Generator().manual_seed(1)
+    mk = lambda seed: WanModelHIP(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads,
+                                  num_layers=cfg.num_layers, in_dim=cfg.in_dim).load_state_dict(O.synth_weights(cfg, seed=seed))
+    d, f = cfg.dim, cfg.ffn_dim
+    files = []
+    for _ in range(2):
+        sd = {}
+        for mod, (N, K) in {"blocks.0.self_attn.q": (d, d), "blocks.1.ffn.0": (f, d), "blocks.1.cross_attn.o": (d, d)}.items():
+            sd[f"diffusion_model.{mod}.lora_A.weight"] = torch.randn(8, K, generator=g) * 0.2
+            sd[f"diffusion_model.{mod}.lora_B.weight"] = torch.randn(N, 8, generator=g) * 0.2
+        files.append(sd)
+    _, ctx, ctx_null, _ = O.synth_inputs(cfg, 3, 8, 8, seed=2)
+    run = lambda pipe, **kw: pipe.generate(context=ctx.cuda(), context_null=ctx_null.cuda(), width=64, height=64, frame_num=9,
+                                           sampling_steps=4, guide_scale=3.0, guide2_scale=2.0, guide_phases=2, switch_threshold=800,
+                                           seed=7, return_latents=True, **kw)["latents"].cpu()
+    # dynamic: both adapters loaded into both experts, multipliers chosen per step
+    m1, m2 = mk(5), mk(6)
+    for m in (m1, m2):
+        assert load_loras_into_model(m, [dict(f_) for f_ in files]).errors == []
+    _, slists, err = parse_loras_multipliers("1;0 0;1", 2, 4, nb_phases=2)
+    assert err == ""
+    dyn = run(WanAny2VHIP(m1, m2), loras_slists=slists)
+    assert m1.loras.merged == [1.0, 0.0] and m2.loras.merged == [0.0, 1.0]
+    # static: each expert merged once with its phase's multipliers
+    s1, s2 = mk(5), mk(6)
+    load_loras_into_model(s1, [dict(f_) for f_ in files], multipliers=[1.0, 0.0])
+    load_loras_into_model(s2, [dict(f_) for f_ in files], multipliers=[0.0, 1.0])
+    sta = run(WanAny2VHIP(s1, s2))
+    plain = run(WanAny2VHIP(mk(5), mk(6)))
+    assert torch.equal(dyn, sta)
+    assert (dyn - plain).norm() / plain.norm() > 1e-3

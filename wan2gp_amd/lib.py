@@ -62,6 +62,10 @@ SIGNATURES = {
     "wan_transpose_v": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "wan_t5_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wan_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_lora_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
+    "wan_axpy_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "wan_add_f32_into_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_dequant_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "wan_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_int, c_void_p]),
     "wan_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

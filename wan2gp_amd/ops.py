@@ -182,6 +182,46 @@ def mul(a, b, out=None):
     return out
 
 
+def lora_accumulate(acc, lora_B, lora_A, scale):
+    """acc[N,K] (fp32) += scale * lora_B[N,r] @ lora_A[r,K] (fp32 operands)."""
+    F32 = torch.float32
+    _req(acc, F32, "acc"); _req(lora_B, F32, "lora_B"); _req(lora_A, F32, "lora_A")
+    N, K = acc.shape
+    r = lora_A.shape[0]
+    if tuple(lora_B.shape) != (N, r) or tuple(lora_A.shape) != (r, K):
+        raise _L.WanHipError(f"lora_accumulate: B {list(lora_B.shape)} @ A {list(lora_A.shape)} does not give {[N, K]}")
+    check(_L.load().wan_lora_accumulate(ptr(acc), ptr(lora_B), ptr(lora_A), float(scale), N, K, r, stream_ptr()), "wan_lora_accumulate")
+    return acc
+
+
+def axpy_f32(acc, x, alpha):
+    _req(acc, torch.float32, "acc"); _req(x, torch.float32, "x")
+    if acc.numel() != x.numel():
+        raise _L.WanHipError("axpy_f32: size mismatch")
+    check(_L.load().wan_axpy_f32(ptr(acc), ptr(x), float(alpha), acc.numel(), stream_ptr()), "wan_axpy_f32")
+    return acc
+
+
+def add_f32_into_bf16_(w, acc):
+    """w = bf16(float(w) + acc) in place: the single rounding of a LoRA merge."""
+    _req(w, BF16, "w"); _req(acc, torch.float32, "acc")
+    if acc.numel() != w.numel():
+        raise _L.WanHipError("add_f32_into_bf16_: size mismatch")
+    check(_L.load().wan_add_f32_into_bf16(ptr(w), ptr(acc), w.numel(), stream_ptr()), "wan_add_f32_into_bf16")
+    return w
+
+
+def dequant_i8(data, scale):
+    """bf16(float(data[n,k]) * scale[n]): optimum-quanto qint8 weight -> resident bf16."""
+    _req(data, torch.int8, "data"); _req(scale, torch.float32, "scale")
+    N, K = data.shape
+    if scale.numel() != N:
+        raise _L.WanHipError("dequant_i8: one scale per output row expected")
+    out = torch.empty(N, K, dtype=BF16, device=data.device)
+    check(_L.load().wan_dequant_i8(ptr(data), ptr(scale), ptr(out), N, K, stream_ptr()), "wan_dequant_i8")
+    return out
+
+
 def patch_embed(x, w, bias, y=None):
     """patch_embedding Conv3d(k=s=(1,2,2)) fp32 -> bf16 tokens [B,L,d] (model.py:1631,1731)."""
     _req(x, torch.float32, "x"); _req(w, torch.float32, "w"); _req(bias, torch.float32, "bias")

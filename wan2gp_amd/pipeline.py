@@ -73,7 +73,7 @@ class WanAny2VHIP:
                  frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
                  guide2_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
-                 **bbargs):
+                 loras_slists=None, switch2_threshold=0, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -101,6 +101,13 @@ class WanAny2VHIP:
         any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
         trans = self.model
         guidance_switch_done = False
+        # LoRA multipliers per step (any2video.py:1431-1445, :1493): the reference re-selects the active multipliers on
+        # every step (offload.set_step_no_for_lora); merged adapters are re-merged only when a step's multipliers change
+        if loras_slists is not None:
+            from .lora import get_model_switch_steps
+            phase_switch_step, phase_switch_step2, _ = get_model_switch_steps(
+                [float(t) for t in timesteps], guide_phases, 0 if self.model2 is None else model_switch_phase, switch_threshold,
+                switch2_threshold)
         kwargs = {"freqs": freqs, "pipeline": self, "callback": callback, "y": y, "max_steps": len(timesteps)}
         for i, t in enumerate(timesteps):
             # update_guidance (:1437-1443): phase 2 begins once t <= switch_threshold
@@ -110,6 +117,8 @@ class WanAny2VHIP:
                 guide_scale, guidance_switch_done = guide2_scale, True
             timestep = torch.stack([t])
             kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": i})
+            if loras_slists is not None and getattr(trans, "loras", None) is not None:
+                trans.loras.set_step(loras_slists, len(timesteps), i, phase_switch_step, phase_switch_step2)
             if ext_latents is not None:                      # any2video.py:1517-1523: re-noise the known first latent
                 f = float(t) / 1000.0
                 n = ext_latents.shape[2]
