@@ -184,12 +184,14 @@ def test_gemm_transposed_vt(ops, M, N, K):
     assert (vt[:, M:] == 0).all(), "padding columns must stay zero"
 
 
-def test_gemm_256x256_kernel_default_path(ops):
-    """>= 256 tiles of 256x256 select gemm256.hip (one wave per SIMD, accumulators in the accumulator file) without any
-    environment override: ragged M (the last y tile has 37 rows), every epilogue, two batches for the gate, and the
-    transposed V^T form with a ragged token count.  References as in the small-shape tests."""
-    g = torch.Generator().manual_seed(256)
-    M, N, K, B = 16 * 256 + 37 + 1, 4096, 128, 2        # 17 x 16 = 272 tiles; M even so that rows split into 2 batches
+@pytest.mark.parametrize("K", [128, 64, 448, 704])
+def test_gemm_256x256_kernel_default_path(ops, K):
+    """>= 256 tiles of 256x256 select gemm256k.hip (one wave per SIMD, accumulators in the accumulator file, k-tiles of 64
+    in a ring of five 32-KB units) without any environment override: ragged M (the last y tile has 37 rows), every
+    epilogue, two batches for the gate, and the transposed V^T form with a ragged token count; K = 1, 2, 7 and 11 k-tiles
+    (prologue-only, clamped streams, ring wrap-around).  References as in the small-shape tests."""
+    g = torch.Generator().manual_seed(256 + K)
+    M, N, B = 16 * 256 + 37 + 1, 4096, 2                # 17 x 16 = 272 tiles; M even so that rows split into 2 batches
     x = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
     b = (0.1 * torch.randn(N, generator=g)).to(BF)
     y = _gemm_ref(x, w, b)

@@ -397,3 +397,96 @@ def test_flat_schedule_invariants():
     for r in range(16):
         g = (52 + 2 * r - 68) if r < 8 else (r - 8)
         assert g + 2 <= 2 + r
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# gemm256k.hip (BK = 64, five 32-KB units): DMA plan <-> fragment addresses, bank conflicts, ring schedule
+# ---------------------------------------------------------------------------------------------------------------------
+def _g256k_unit_image():
+    """slot q (16 B) of a unit image -> (row, logical chunk), as the DMA plan of gemm256k.hip fills it."""
+    img = {}
+    for i in range(8):
+        for tid in range(256):
+            q = i * 256 + tid
+            row, pch = q >> 3, q & 7
+            assert q * 16 == (i * 256 + (tid >> 6) * 64 + (tid & 63)) * 16          # piece i of wave w, lane order
+            img[q * 16] = (row, pch ^ ((row >> 1) & 7))
+    return img
+
+
+def test_gemm256k_fragment_addresses_hit_the_right_chunks():
+    img = _g256k_unit_image()
+    assert sorted(img.values()) == [(r, c) for r in range(256) for c in range(8)]       # every (row, chunk) exactly once
+    # every instruction's 8 lanes of a row cover the row's whole 128-B line
+    for i in range(8):
+        for wave in range(4):
+            rows = {}
+            for lane in range(64):
+                row, lch = img[(i * 256 + wave * 64 + lane) * 16]
+                rows.setdefault(row, set()).add(lch)
+            assert len(rows) == 8 and all(v == set(range(8)) for v in rows.values())
+    for w in range(2):                     # wy (or wx)
+        for l31 in range(32):
+            for half in range(2):
+                sw = (l31 >> 1) & 7
+                addr0 = (w * 128 + l31) * 128 + ((half ^ sw) << 4)
+                for r in range(4):
+                    for ks in range(4):
+                        addr = r * 4096 + (addr0 ^ (ks << 5))
+                        assert img[addr] == (w * 128 + r * 32 + l31, 2 * ks + half)
+
+
+def test_gemm256k_ds_read_b128_is_conflict_free():
+    """The 16 lanes a ds_read_b128 services in one LDS cycle (MI355X_MICROARCH.md LDS table) must cover 64 distinct banks."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for ks in range(4):
+        for g in groups:
+            banks = set()
+            for lane in g:
+                l31, half = lane & 31, lane >> 5
+                addr = l31 * 128 + (((half ^ ((l31 >> 1) & 7)) << 4) ^ (ks << 5))
+                for d in range(4):
+                    banks.add((addr // 4 + d) % 64)
+            assert len(banks) == 64
+
+
+def test_gemm256k_ring_schedule():
+    """Event simulation of the five-unit ring: every unit is written only after its previous tenant's last read and
+    is complete (by the vmcnt rule) before its first read; 8 pieces per wave may still fly at every sync point."""
+    nk = 23
+    unit_of = lambda kind, S: 2 * S + (1 if kind == "X" else 0)
+    slot_of = lambda u: u % 5
+    issue_order = []                      # (unit) in per-wave issue order, 8 pieces each
+    events = []                           # (time, what, unit): times in MFMA units
+    for S in (0, 1):
+        for kind in ("Y", "X"):
+            issue_order.append(unit_of(kind, S)); events.append((-1, "issue", unit_of(kind, S)))
+    landed_at_sync = {}
+    for S in range(nk):
+        t0 = S * 64
+        J = S % 5
+        SY, SX, NY, NX, DY, DX = (2 * J) % 5, (2 * J + 1) % 5, (2 * J + 2) % 5, (2 * J + 3) % 5, (2 * J + 4) % 5, (2 * J) % 5
+        assert (SY, SX) == (slot_of(unit_of("Y", S)), slot_of(unit_of("X", S)))
+        assert (NY, NX) == (slot_of(unit_of("Y", S + 1)), slot_of(unit_of("X", S + 1)))
+        assert DY == slot_of(unit_of("Y", S + 2)) and DX == slot_of(unit_of("X", S + 2))
+        # k-steps 0, 1: Y_{S+2}; reads of stage S (k-steps 1..3 fragments) during k-steps 0..2
+        issue_order.append(unit_of("Y", S + 2)); events.append((t0 + 0, "issue", unit_of("Y", S + 2)))
+        for kind in ("Y", "X"):
+            events.append((t0 + 40, "lastread", unit_of(kind, S)))       # last fragment read of stage S: k-step 2, MFMA 7
+        # sync point P_S at t0 + 48: vmcnt(8) -> everything but the last 8 pieces (one unit) has landed
+        landed_at_sync[S] = set(issue_order[:-1])
+        assert unit_of("X", S + 1) in landed_at_sync[S] and unit_of("Y", S + 1) in landed_at_sync[S]
+        events.append((t0 + 48, "firstread", unit_of("Y", S + 1))); events.append((t0 + 48, "firstread", unit_of("X", S + 1)))
+        issue_order.append(unit_of("X", S + 2)); events.append((t0 + 48, "issue", unit_of("X", S + 2)))
+    # a unit may be issued into a slot only after the previous tenant (unit - 5) was read for the last time
+    last_read = {u: t for t, w, u in events if w == "lastread"}
+    for t, w, u in events:
+        if w == "issue" and u - 5 >= 0:
+            assert last_read[u - 5] < t + 1e-9 and (t - last_read[u - 5]) >= 8, (u, t)      # separated by the barrier at P
+    # latency budgets (MFMAs between the LAST piece's issue and the sync point that needs the unit)
+    first_read = {u: t for t, w, u in events if w == "firstread"}
+    for t, w, u in events:
+        if w == "issue" and t >= 0 and u in first_read:
+            span = 32 if u % 2 == 0 else 16                     # Y pieces spread over 2 k-steps, X pieces over 1
+            assert first_read[u] - (t + span) >= (48 if u % 2 else 64)

@@ -32,19 +32,18 @@ void wan_set_error(const char* fmt, ...);
 
 // ---- bf16 <-> f32 -----------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved (matches torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-// round a float through bf16 (value of the bf16 the reference would have stored)
-__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
-
+// round-to-nearest-even through the hardware converter (v_cvt_pk_bf16_f32: one instruction per PAIR; the integer
+// add-and-shift form it replaces cost ~6 VALU operations per element and made the GEMM epilogues VALU-bound: 33k cycles to
+// drain a 256x256 tile).  Bit-identical to torch's float->bfloat16 for every non-NaN input; NaNs come out quiet.
+typedef float wan_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wan_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  wan_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wan_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
+// round a float through bf16 (value of the bf16 the reference would have stored)
+__device__ __forceinline__ float rbf(float f) { return __uint_as_float(pack2bf(f, 0.f) << 16); }
 
 // ---- fp16 <-> f32 (VAE path) ---------------------------------------------------------------------
 __device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }

@@ -266,6 +266,10 @@ template <int EPI, bool BIAS_ROWS, bool F16>
 int wan_gemm256_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                     int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                     int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
+template <int EPI, bool BIAS_ROWS, bool F16>
+int wan_gemm256k_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                    int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
+                    int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
 template <int EPI, bool BIAS_ROWS, bool F16 = false>
 static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K,
@@ -274,11 +278,21 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
                        float out_scale = 1.0f) {
   const int64_t tx = (XN + BN - 1) / BN;
   // large problems: 256x128x32 tiles on 32x32x16 MFMAs (gemm32.hip); WAN_GEMM_KERNEL=v1 keeps this file's kernel
-  static const int gen = [] { const char* e = getenv("WAN_GEMM_KERNEL"); return !e ? 3 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v2") ? 2 : !strcmp(e, "v3f") ? 4 : 3; }();
+  // v4 (default): gemm256k.hip, full-line (BK = 64) fetches; v3: gemm256.hip (BK = 32); *f: whatever the problem size (tests)
+  static const int gen = [] {
+    const char* e = getenv("WAN_GEMM_KERNEL");
+    return !e ? 5 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v2") ? 2 : !strcmp(e, "v3") ? 3 : !strcmp(e, "v3f") ? 4 : !strcmp(e, "v4f") ? 6 : 5;
+  }();
   const bool use_v1 = gen == 1;
   // Measured (M = 151200, TFLOP/s, gemm256 with its 4-deep ring vs gemm32): qkvo 1106 vs 946, o+gate 902 vs 869,
   // ffn1+GELU 1040 vs 918, ffn2+gate 1060 vs 925, V^T 1089 vs 910.  v3f (tests): gemm256 whatever the problem size.
-  if (gen == 4 || (gen == 3 && ((YM + 255) / 256) * ((XN + 255) / 256) >= 256)) {
+  const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= 256;
+  if (gen == 6 || (gen == 5 && many_tiles)) {
+    const int rc = wan_gemm256k_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
+                                                         rows_per_batch, st, out_scale);
+    if (rc >= 0) return rc;
+  }
+  if (gen == 4 || gen == 6 || (gen >= 3 && many_tiles)) {
     const int rc = wan_gemm256_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
                                                         rows_per_batch, st, out_scale);
     if (rc >= 0) return rc;
