@@ -12,9 +12,14 @@ from collections import defaultdict
 def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "", 1) if name.startswith("void (anonymous") else name
     name = name.split("(")[0]
-    for k in ("attn_w64q_kernel", "attn_w64_kernel", "attn_pp_kernel", "attn_fwd_kernel", "gemm_bf16_kernel", "rmsnorm_rope_kernel", "layernorm_kernel", "gated_residual",
+    for k in ("gemm256k_kernel", "gemm256_kernel", "gemm32_kernel", "attn_w64q_kernel", "attn_w64_kernel", "attn_pp_kernel", "attn_fwd_kernel", "gemm_bf16_kernel", "rmsnorm_rope_kernel", "layernorm_kernel", "gated_residual",
               "patch_embed_kernel", "head_gemm_kernel", "gemv_kernel", "lincomb_kernel", "cfg_combine", "transpose_v"):
         if k in name:
+            if k in ("gemm256k_kernel", "gemm256_kernel", "gemm32_kernel"):
+                import re
+                m = re.search(k + r"ILi(\d)ELb(\d)", name)
+                if m:
+                    return f"{k}<epi={m.group(1)},bias_rows={m.group(2)}>"
             if k == "gemm_bf16_kernel":
                 import re
                 m = re.search(r"gemm_bf16_kernelILi(\d)ELb(\d)", name)
