@@ -150,6 +150,11 @@ int wan_head(const wan_bf16* x, const float* hmod, const wan_bf16* e, const floa
 /* token-major head output [B, L, 64] fp32 -> [B, 16, F, 2*Hg, 2*Wg]  ('fhwpqrc->cfphqwr',
  * model.py:2119-2121); used after the sequence-parallel gather of per-rank head outputs. */
 int wan_unpatchify(const float* in, float* out, int B, int F, int Hg, int Wg, void* stream);
+/* The same two for latents of out_dim = nout / 4 channels (48 for the ti2v 5B model, models/wan/configs/ti2v_2_2.json:
+ * w [nout, d], bias [nout], out [B, nout/4, F, 2*Hg, 2*Wg], token-major input [B, L, nout]). */
+int wan_head_n(const wan_bf16* x, const float* hmod, const wan_bf16* e, const float* w, const float* bias, wan_bf16* tmp,
+               float* out, int B, int F, int Hg, int Wg, int d, float eps, int nout, void* stream);
+int wan_unpatchify_n(const float* in, float* out, int B, int F, int Hg, int Wg, int nout, void* stream);
 
 /* sinusoidal_embedding_1d(256, t) -> bf16 [n, dim] (model.py:32-42, :1816) */
 int wan_sinusoid(const float* t, wan_bf16* out, int n, int dim, void* stream);
@@ -158,6 +163,21 @@ int wan_act_bf16(const wan_bf16* x, wan_bf16* y, int64_t n, int act, void* strea
 /* small-M Linear (GEMV): C[M,N] = bf16(A[M,K] W[N,K]^T + bias), M <= 16 (time MLP) */
 int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C, int M,
                   int N, int K, void* stream);
+
+/* ---- Wan2.2 VAE additions (models/wan/modules/vae2_2.py) -------------------------- */
+/* The 5B ti2v VAE (z 48, stride (4,16,16)) reuses wan_vae_conv3d / wan_vae_rmsnorm_silu / wan_gemm_f16 / wan_vae_softmax and
+ * wan_vae_pack / wan_vae_unpack; fp16 channels-last activations [T,H,W,C].  New data movement:
+ *   wan_vae22_patchify:    video fp32 [3,T,H,W] -> [T,H/2,W/2,Cp] fp16, channel (c*2+r)*2+q = pixel (2h+q, 2w+r)
+ *                          (patchify, vae2_2.py:299-315), channels 12..Cp-1 zero
+ *   wan_vae22_to_video:    decoder head output fp32 [Ti,h,w,12] -> video [3,Ttot,2h,2w] at frame t0, as uint8
+ *                          (_vae_float_to_cpu_uint8, vae.py:18-20) and/or fp32 (unpatchify, vae2_2.py:318-332)
+ *   wan_vae22_avgdown_add: io[To,H/fs,W/fs,Co] += AvgDown3D(x[T,H,W,C]) (vae2_2.py:354-386, :466-471); To = ceil(T/ft)
+ *   wan_vae22_dupup_add:   io[T*ft-(first_chunk?ft-1:0),H*fs,W*fs,Co] += DupUp3D(x[T,H,W,C]) (vae2_2.py:409-431, :508-516) */
+int wan_vae22_patchify(const float* video, uint16_t* out, int T, int H, int W, int Cp, void* stream);
+int wan_vae22_to_video(const float* y, uint8_t* u8, float* f32, int Ti, int h, int w, int Ttot, int t0, void* stream);
+int wan_vae22_avgdown_add(const uint16_t* x, uint16_t* io, int T, int H, int W, int C, int Co, int ft, int fs, void* stream);
+int wan_vae22_dupup_add(const uint16_t* x, uint16_t* io, int T, int H, int W, int C, int Co, int ft, int fs, int first_chunk,
+                        void* stream);
 
 /* ---- UMT5 text encoder (models/wan/modules/t5.py) ------------------------------ */
 /* T5Attention core (t5.py:109-131) for head_dim 64: out = softmax_fp32(bf16(q k^T) + pos_bias, masked) v.
@@ -242,7 +262,7 @@ typedef struct {
 
 /* WanModel.forward for the t2v / i2v2_2 path (model.py:1485-2098): S streams (the joint CFG
  * pass, any2video.py:1626-1634), each x_s [1, 16, F, H, W] fp32, t scalar, context_s
- * [1, 512, text_dim] bf16, y optional [in_dim-16, F, H, W] fp32, cos/sin [L,128] fp32.
+ * [1, 512, text_dim] bf16, y optional [in_dim-out_dim, F, H, W] fp32 (x streams are [1, out_dim, F, H, W]), cos/sin [L,128] fp32.
  * outs[s] [1, 16, F, H, W] fp32.  Returns 1 if aborted by poll (reference returns [None]*n). */
 int wan_dit_forward(wan_ctx* ctx, int S, const float* const* x, float t, const wan_bf16* const* context,
                     const float* y, const float* cos, const float* sin, float* const* outs, int F,

@@ -218,6 +218,7 @@ def main():
     if "forward" in which:
         gen_forward(ns, "tiny", 3, 8, 12, 637)
         gen_forward(ns, "tiny_i2v", 2, 8, 8, 912)
+        gen_forward(ns, "tiny_ti2v", 2, 6, 10, 455)
     if "sched" in which:
         gen_sched(ns)
     if "sched2" in which:

@@ -62,6 +62,9 @@ CONFIGS = {
     "tiny": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2),
     "tiny_i2v": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, in_dim=36, model_type="i2v2_2"),
     "small": dict(dim=512, ffn_dim=1536, num_heads=4, num_layers=3),
+    # Wan2.2 ti2v 5B (models/wan/configs/ti2v_2_2.json): 48-channel latents of the Wan2.2 VAE in and out, no y
+    "ti2v_5B": dict(dim=3072, ffn_dim=14336, num_heads=24, num_layers=30, in_dim=48, out_dim=48, model_type="ti2v2_2"),
+    "tiny_ti2v": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, in_dim=48, out_dim=48, model_type="ti2v2_2"),
 }
 
 
@@ -595,7 +598,7 @@ def sample_loop(W_hi, cfg: WanConfig, latents: torch.Tensor, ctx: torch.Tensor, 
 def synth_inputs(cfg: WanConfig, f: int, h: int, w: int, seed: int = 42, text_tokens: int = 77,
                  batch: int = 1):
     g = torch.Generator().manual_seed(seed)
-    lat = torch.randn(batch, 16, f, h, w, generator=g)
+    lat = torch.randn(batch, cfg.out_dim, f, h, w, generator=g)
     ctx = (torch.randn(batch, cfg.text_len, cfg.text_dim, generator=g) * 0.5)
     ctx[:, text_tokens:] = 0                      # zero padding, any2video.py:590
     ctx_null = (torch.randn(batch, cfg.text_len, cfg.text_dim, generator=g) * 0.5)

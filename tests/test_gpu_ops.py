@@ -382,7 +382,7 @@ def test_pay_attention_dropin_contract(ops):
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v"])
 def test_patch_embed_and_head(ops, name):
     cfg = O.make_config(name)
     W = O.synth_weights(cfg)

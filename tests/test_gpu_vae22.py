@@ -1,0 +1,162 @@
+"""-m gpu: the Wan2.2 (5B ti2v) VAE on HIP against oracle/vae22_oracle.py (pinned bit-exactly to the reference's own
+vae2_2.py modules by tests/test_vae22_oracle_vs_golden.py) and the reference-generated fixture tests/golden/vae22_small.npz.
+
+Tolerances as for the Wan2.1 VAE (tests/test_gpu_vae.py): fp16 activations + fp32 accumulation vs the fp32 reference.
+Data-movement kernels: bit-exact on fp16-representable inputs, except the averaged shortcut (fp32 sum order, one fp16
+rounding: <= 1e-3 relative).  End to end on the INTEGER pixels: max |delta| <= 2 LSB, >= 90 % of the bytes identical,
+mean |delta| <= 0.1 LSB; encode |err| <= 1e-2 max|ref| + 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vae22_oracle as V2
+
+pytestmark = pytest.mark.gpu
+G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "vae22_small.npz")))
+F16 = torch.float16
+
+
+def cl(x):
+    """[1,C,T,H,W] fp32 -> channels-last fp16 [T,H,W,C] on the GPU."""
+    return x[0].permute(1, 2, 3, 0).contiguous().to(F16).cuda()
+
+
+def uncl(y):
+    return y.float().cpu().permute(3, 0, 1, 2).unsqueeze(0)
+
+
+def h(x):
+    return x.to(F16).float()
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from wan2gp_amd import lib as L
+    return L
+
+
+def test_patchify_and_to_video(lib):
+    from wan2gp_amd.lib import check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(1)
+    vid = h(torch.rand(1, 3, 5, 12, 20, generator=g) * 2 - 1)
+    out = torch.full((5, 6, 10, 32), 7.0, dtype=F16, device="cuda")
+    check(lib.load().wan_vae22_patchify(ptr(vid[0].cuda().contiguous()), ptr(out), 5, 12, 20, 32, stream_ptr()), "patchify")
+    got = uncl(out)
+    assert torch.equal(got[:, :12], V2.patchify(vid, 2)) and (got[:, 12:] == 0).all()
+    # decoder head output [Ti, h, w, 12] -> frames t0.. of a [3, Ttot, 2h, 2w] video, fp32 and uint8
+    y = torch.randn(1, 12, 3, 6, 10, generator=g) * 0.8
+    f32 = torch.zeros(3, 7, 12, 20, device="cuda"); u8 = torch.zeros(3, 7, 12, 20, dtype=torch.uint8, device="cuda")
+    ycl = y[0].permute(1, 2, 3, 0).contiguous().cuda()
+    check(lib.load().wan_vae22_to_video(ptr(ycl), ptr(u8), ptr(f32), 3, 6, 10, 7, 2, stream_ptr()), "to_video")
+    ref = V2.unpatchify(y, 2)[0]
+    assert torch.equal(f32.cpu()[:, 2:5], ref) and (f32.cpu()[:, :2] == 0).all() and (f32.cpu()[:, 5:] == 0).all()
+    assert torch.equal(u8.cpu()[:, 2:5], V2.float_to_uint8(ref))
+    from wan2gp_amd.lib import WanHipError
+    with pytest.raises(WanHipError):
+        check(lib.load().wan_vae22_patchify(ptr(vid[0].cuda()), ptr(out), 5, 11, 20, 32, stream_ptr()), "patchify odd H")
+    with pytest.raises(WanHipError):
+        check(lib.load().wan_vae22_to_video(ptr(ycl), ptr(u8), ptr(f32), 3, 6, 10, 7, 5, stream_ptr()), "to_video overflow")
+
+
+@pytest.mark.parametrize("C,Co,ft,fs,T", [(32, 64, 2, 2, 4), (32, 64, 2, 2, 1), (64, 128, 1, 2, 3), (64, 64, 1, 1, 2), (32, 64, 2, 2, 3)])
+def test_avgdown_add(lib, C, Co, ft, fs, T):
+    from wan2gp_amd.lib import check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(C + T)
+    x = h(torch.randn(1, C, T, 6, 8, generator=g))
+    sc = V2.avg_down3d(x, Co, ft, fs)
+    main = h(torch.randn(sc.shape, generator=g))
+    io = cl(main)
+    check(lib.load().wan_vae22_avgdown_add(ptr(cl(x)), ptr(io), T, 6, 8, C, Co, ft, fs, stream_ptr()), "avgdown")
+    ref = main + sc
+    assert (uncl(io) - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("C,Co,ft,fs,T,first", [(64, 32, 2, 2, 2, False), (64, 32, 2, 2, 1, True), (128, 64, 1, 2, 3, False), (64, 32, 2, 2, 3, True)])
+def test_dupup_add(lib, C, Co, ft, fs, T, first):
+    from wan2gp_amd.lib import check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(C + T)
+    x = h(torch.randn(1, C, T, 3, 5, generator=g))
+    sc = V2.dup_up3d(x, Co, ft, fs, first)
+    main = h(torch.randn(sc.shape, generator=g))
+    io = cl(main)
+    check(lib.load().wan_vae22_dupup_add(ptr(cl(x)), ptr(io), T, 3, 5, C, Co, ft, fs, 1 if first else 0, stream_ptr()), "dupup")
+    assert torch.equal(uncl(io), h(main + sc))
+
+
+@pytest.fixture(scope="module")
+def vae():
+    from wan2gp_amd.vae22 import Wan22VAEHIP
+    cfg = V2.SMALL
+    return Wan22VAEHIP(z_dim=cfg["z_dim"], c_dim=cfg["dim"], dec_dim=cfg["dec_dim"], state_dict=V2.synth_vae22_weights(cfg=cfg), device="cuda")
+
+
+def _inputs():
+    gen = torch.Generator().manual_seed(int(G["seed"][0]))
+    z = torch.randn(1, V2.SMALL["z_dim"], 3, 4, 4, generator=gen)
+    vid = torch.rand(1, 3, 9, 64, 64, generator=gen) * 2 - 1
+    vid[:, :, 1:] *= 0.5
+    return z, vid
+
+
+def test_decode_to_uint8_vs_reference_golden(vae):
+    z, _ = _inputs()
+    u8 = vae.decode_to_cpu_uint8([z[0]], 0)[0]
+    ref = torch.from_numpy(G["dec_u8"])[0]
+    assert u8.dtype == torch.uint8 and u8.shape == ref.shape and u8.device.type == "cpu"
+    d = (u8.int() - ref.int()).abs()
+    frac_same = (d == 0).float().mean().item()
+    print(f"VAE2.2 uint8: identical {frac_same * 100:.2f}%  max delta {int(d.max())}  mean delta {d.float().mean().item():.4f}")
+    assert int(d.max()) <= 2 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
+    dec = vae.decode([z[0]], 0)[0].cpu()
+    refd = torch.from_numpy(G["dec"])[0].clamp(-1, 1)
+    assert (dec - refd).abs().max().item() <= 1.5e-2
+
+
+def test_encode_vs_reference_golden(vae):
+    _, vid = _inputs()
+    mu = vae.encode([vid[0]])[0].cpu()
+    ref = torch.from_numpy(G["enc"])[0]
+    assert mu.shape == ref.shape and mu.dtype == torch.float32
+    err = (mu - ref).abs().max().item()
+    print(f"VAE2.2 encode: max abs err {err:.4e} (|ref| max {ref.abs().max().item():.3f})")
+    assert err <= 1e-2 * ref.abs().max().item() + 1e-3
+
+
+@pytest.fixture(scope="module")
+def full_vae():
+    from wan2gp_amd.vae22 import Wan22VAEHIP
+    W = V2.synth_vae22_weights(seed=3, cfg=V2.CFG)
+    return Wan22VAEHIP(state_dict=W, device="cuda"), W
+
+
+def test_full_geometry_roundtrip_shapes(full_vae):
+    """The real 5B geometry (z 48, dim 160 / 256, random weights): 1+4 frames at 64x128 -> latents [48, 2, 4, 8] -> 5 frames."""
+    vae, W = full_vae
+    g = torch.Generator().manual_seed(7)
+    vid = torch.rand(3, 5, 64, 128, generator=g) * 2 - 1
+    mu = vae.encode([vid])[0]
+    assert tuple(mu.shape) == (48, 2, 4, 8) and torch.isfinite(mu).all()
+    ref = V2.vae22_encode(vid.unsqueeze(0), W, V2.default_scale(), V2.CFG)[0]
+    assert (mu.cpu() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-3
+    u8 = vae.decode_to_cpu_uint8([mu], 0)[0]
+    assert tuple(u8.shape) == (3, 5, 64, 128)
+
+
+def test_ti2v_pipeline_48_channel_latents(full_vae):
+    """ti2v 5B wiring (models/wan/configs/ti2v_2_2.json; any2video.py:144-147): a 48-channel DiT (tiny depth / width) sampling
+    latents at stride (4,16,16) that the Wan2.2 VAE decodes to uint8 frames."""
+    from oracle import wan_oracle as O
+    from wan2gp_amd.model import WanModelHIP
+    from wan2gp_amd.pipeline import WanAny2VHIP
+    vae, _ = full_vae
+    cfg = O.make_config("tiny_ti2v")
+    m = WanModelHIP(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers,
+                    in_dim=cfg.in_dim, out_dim=cfg.out_dim).load_state_dict(O.synth_weights(cfg, seed=8))
+    _, ctx, ctx_null, _ = O.synth_inputs(cfg, 2, 8, 8, seed=2)
+    pipe = WanAny2VHIP(m, vae=vae, vae_stride=(4, 16, 16))
+    out = pipe.generate(context=ctx.cuda(), context_null=ctx_null.cuda(), width=128, height=128, frame_num=5, sampling_steps=2,
+                        guide_scale=3.0, seed=3)
+    assert tuple(out["latents"].shape) == (1, 48, 2, 8, 8) and torch.isfinite(out["latents"]).all()
+    assert out["x"].dtype == torch.uint8 and tuple(out["x"].shape) == (3, 5, 128, 128)

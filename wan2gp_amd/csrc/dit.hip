@@ -34,7 +34,7 @@ int wan_patch_embed_range(const float* x, const float* y, const float* w, const 
                           int Cy, int F, int H, int W, int d, int64_t tok0, int64_t ntok, void* stream);
 int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const float* w, const float* bias, bf16_t* tmp,
                    float* out, int B, int F, int Hg, int Wg, int d, float eps, int64_t tok0, int64_t ntok,
-                   int token_major_out, int e_shared, void* stream);
+                   int token_major_out, int e_shared, int nout, void* stream);
 int wan_sinusoid_val(float t, bf16_t* out, int dim, void* stream);
 extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
                                  int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
@@ -138,7 +138,9 @@ extern "C" int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out) {
               "wan_dit_create: head_dim must be 128 (dim=%d heads=%d)", cfg->dim, cfg->num_heads);
   WAN_REQUIRE(cfg->dim % 64 == 0 && cfg->ffn_dim % 64 == 0 && cfg->text_dim % 64 == 0 && cfg->freq_dim % 8 == 0,
               "wan_dit_create: dims must be multiples of 64");
-  WAN_REQUIRE(cfg->out_dim == 16 && cfg->in_dim >= 16, "wan_dit_create: out_dim must be 16 and in_dim >= 16");
+  // latents have out_dim channels (16; 48 for the ti2v 5B model, configs/ti2v_2_2.json); in_dim - out_dim more come from y
+  WAN_REQUIRE(cfg->out_dim >= 4 && cfg->out_dim % 4 == 0 && cfg->out_dim <= 256 && cfg->in_dim >= cfg->out_dim,
+              "wan_dit_create: out_dim=%d must be a multiple of 4 in [4, 256] and in_dim=%d >= out_dim", cfg->out_dim, cfg->in_dim);
   wan_ctx* c = new wan_ctx();
   c->cfg = *cfg;
   *out = c;
@@ -196,8 +198,8 @@ static int resolve(wan_ctx* c) {
   if (int rc = get_lin(c, c->tm2, "time_embedding.2", d, d)) return rc;
   if (int rc = get_lin(c, c->tp1, "time_projection.1", 6 * d, d)) return rc;
   GETF(c->head_mod, "head.modulation", 2 * d);
-  GETF(c->head_w, "head.head.weight", 64 * d);
-  GETF(c->head_b, "head.head.bias", 64);
+  GETF(c->head_w, "head.head.weight", (int64_t)4 * g.out_dim * d);
+  GETF(c->head_b, "head.head.bias", 4 * g.out_dim);
   c->layers.assign(g.num_layers, Layer());
   for (int i = 0; i < g.num_layers; ++i) {
     Layer& L = c->layers[i];
@@ -310,7 +312,7 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
   WAN_REQUIRE(!sp || (sp->tok_local == Ll && sp->tok0 == (int64_t)sp->rank * Ll &&
                       (world == 1 || (sp->gather_begin && sp->gather_wait))),
               "wan_dit_forward: inconsistent sequence-parallel info");
-  WAN_REQUIRE((g.in_dim > 16) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > 16 (model.py:1597)");
+  WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
   Bufs b;
   const int64_t need = carve_all(g, S, Ll, world, workspace, &b);
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
@@ -325,7 +327,7 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
 
   // ---- embeddings (model.py:1631,1731 ; :1815-1818 ; :1856) -----------------------------------------
   for (int s = 0; s < S; ++s)
-    RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, 16, g.in_dim - 16, F, H, W, d,
+    RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, g.out_dim, g.in_dim - g.out_dim, F, H, W, d,
                              tok0, Ll, stream));
   RC(wan_sinusoid_val(t, b.sinus, g.freq_dim, stream));
   RC(wan_gemv_bf16(b.sinus, c->tm0.w, c->tm0.b, b.e_h, 1, d, g.freq_dim, stream));
@@ -407,6 +409,6 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
   // ---- head + unpatchify (model.py:2068-2097) -------------------------------------------------------
   for (int s = 0; s < S; ++s)
     RC(wan_head_range(b.x + (int64_t)s * Ll * d, c->head_mod, b.e, c->head_w, c->head_b, b.xm, outs[s], 1, F, Hg, Wg, d,
-                      g.eps, tok0, Ll, world > 1 ? 1 : 0, 1, stream));
+                      g.eps, tok0, Ll, world > 1 ? 1 : 0, 1, 4 * g.out_dim, stream));
   return 0;
 }

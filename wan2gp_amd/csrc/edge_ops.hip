@@ -77,7 +77,8 @@ extern "C" int wan_patch_embed(const float* x, const float* y, const float* w, c
   return wan_patch_embed_range(x, y, w, bias, out, B, Cin, Cy, F, H, W, d, 0, (int64_t)F * (H / 2) * (W / 2), stream);
 }
 
-// ---- head GEMM: out64[tok][j] = bias[j] + sum_k xm[tok][k] * w[j][k]; 64 tokens x 64 outputs per block ----
+// ---- head GEMM: out[tok][j] = bias[j] + sum_k xm[tok][k] * w[j][k]; 64 tokens x 64 outputs per block, grid.z covers
+// nout = 4 * out_dim outputs in chunks of 64 (64 for the 16-channel latents, 192 for the 48-channel ti2v 5B model) ----
 #define HD_KC 64
 __global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict__ xm, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out, int d,
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict
   const int tid = threadIdx.x;
   const int tk = tid >> 2, jq = tid & 3;
   const int b = blockIdx.y;
+  const int j0 = blockIdx.z * 64;
   const int64_t t0 = (int64_t)blockIdx.x * 64;
   const bf16_t* xb = xm + (int64_t)b * rows_per_batch_local * d;
   float acc[16];
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict
       const int64_t tl = t0 + r;
       xs[r][c] = (tl < ntok && k0 + c < d) ? bf2f(xb[tl * d + k0 + c]) : 0.f;
       // w: r -> output j, c -> k
-      ws[c][r] = (r < nout && k0 + c < d) ? w[(int64_t)r * d + k0 + c] : 0.f;
+      ws[c][r] = (j0 + r < nout && k0 + c < d) ? w[(int64_t)(j0 + r) * d + k0 + c] : 0.f;
     }
     __syncthreads();
 #pragma unroll 8
@@ -113,10 +115,10 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict
   const int64_t tl = t0 + tk;
   if (tl >= ntok) return;
   if (token_major_out) {
-    // [B][ntok][64] (sequence-parallel: gathered by the host, unpatchified afterwards)
+    // [B][ntok][nout] (sequence-parallel: gathered by the host, unpatchified afterwards)
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      if (jq * 16 + j < nout) out[((int64_t)b * ntok + tl) * 64 + jq * 16 + j] = acc[j] + bias[jq * 16 + j];
+      if (j0 + jq * 16 + j < nout) out[((int64_t)b * ntok + tl) * nout + j0 + jq * 16 + j] = acc[j] + bias[j0 + jq * 16 + j];
     return;
   }
   // unpatchify 'fhwpqrc->cfphqwr' (model.py:2119-2121): j = (q*2+r)*C + c, C = nout/4
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict
   const int H = Hg * 2, W = Wg * 2;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int jj = jq * 16 + j;
+    const int jj = j0 + jq * 16 + j;
     if (jj < nout) {
       const int c = jj % C, qr = jj / C;
       const int qq = qr >> 1, rr = qr & 1;
@@ -158,15 +160,16 @@ __global__ void unpatchify_kernel(const float* __restrict__ in, float* __restric
 
 int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const float* w, const float* bias, bf16_t* tmp,
                    float* out, int B, int F, int Hg, int Wg, int d, float eps, int64_t tok0, int64_t ntok,
-                   int token_major_out, int e_shared, void* stream) {
+                   int token_major_out, int e_shared, int nout, void* stream) {
   WAN_REQUIRE(x && hmod && e && w && bias && tmp && out, "wan_head: null pointer");
+  WAN_REQUIRE(nout >= 4 && nout % 4 == 0 && nout <= 1024, "wan_head: nout=%d must be 4 * out_dim", nout);
   const int64_t rows = (int64_t)B * ntok;
   // e_shared: one e [1,d] for every batch row (the streams of a joint CFG pass share t)
   int rc = wan_ln_modulate_head(x, tmp, hmod, e, rows, e_shared ? (rows > 0 ? rows : 1) : ntok, d, eps, stream);
   if (rc) return rc;
   if (ntok == 0) return 0;
-  dim3 grid((unsigned)((ntok + 63) / 64), (unsigned)B);
-  hipLaunchKernelGGL(head_gemm_kernel, grid, dim3(256), 0, as_stream(stream), tmp, w, bias, out, d, F, Hg, Wg, 64, tok0,
+  dim3 grid((unsigned)((ntok + 63) / 64), (unsigned)B, (unsigned)((nout + 63) / 64));
+  hipLaunchKernelGGL(head_gemm_kernel, grid, dim3(256), 0, as_stream(stream), tmp, w, bias, out, d, F, Hg, Wg, nout, tok0,
                      ntok, ntok, token_major_out);
   WAN_LAUNCH_CHECK();
   return 0;
@@ -174,15 +177,28 @@ int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const fl
 
 extern "C" int wan_head(const wan_bf16* x, const float* hmod, const wan_bf16* e, const float* w, const float* bias,
                         wan_bf16* tmp, float* out, int B, int F, int Hg, int Wg, int d, float eps, void* stream) {
-  return wan_head_range(x, hmod, e, w, bias, tmp, out, B, F, Hg, Wg, d, eps, 0, (int64_t)F * Hg * Wg, 0, 0, stream);
+  return wan_head_range(x, hmod, e, w, bias, tmp, out, B, F, Hg, Wg, d, eps, 0, (int64_t)F * Hg * Wg, 0, 0, 64, stream);
 }
 
-extern "C" int wan_unpatchify(const float* in, float* out, int B, int F, int Hg, int Wg, void* stream) {
+extern "C" int wan_head_n(const wan_bf16* x, const float* hmod, const wan_bf16* e, const float* w, const float* bias,
+                          wan_bf16* tmp, float* out, int B, int F, int Hg, int Wg, int d, float eps, int nout, void* stream) {
+  return wan_head_range(x, hmod, e, w, bias, tmp, out, B, F, Hg, Wg, d, eps, 0, (int64_t)F * Hg * Wg, 0, 0, nout, stream);
+}
+
+static int unpatchify_n(const float* in, float* out, int B, int F, int Hg, int Wg, int nout, void* stream) {
   WAN_REQUIRE(in && out, "wan_unpatchify: null pointer");
+  WAN_REQUIRE(nout >= 4 && nout % 4 == 0, "wan_unpatchify: nout=%d must be 4 * out_dim", nout);
   const int64_t L = (int64_t)F * Hg * Wg;
-  int blocks = (int)((L * 64 + 255) / 256);
+  int blocks = (int)((L * nout + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks, B), dim3(256), 0, as_stream(stream), in, out, F, Hg, Wg, 64, L);
+  if (blocks < 1) return 0;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks, B), dim3(256), 0, as_stream(stream), in, out, F, Hg, Wg, nout, L);
   WAN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int wan_unpatchify(const float* in, float* out, int B, int F, int Hg, int Wg, void* stream) {
+  return unpatchify_n(in, out, B, F, Hg, Wg, 64, stream);
+}
+extern "C" int wan_unpatchify_n(const float* in, float* out, int B, int F, int Hg, int Wg, int nout, void* stream) {
+  return unpatchify_n(in, out, B, F, Hg, Wg, nout, stream);
 }

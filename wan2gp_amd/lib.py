@@ -62,6 +62,10 @@ SIGNATURES = {
     "wan_transpose_v": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "wan_t5_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wan_mul_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_vae22_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_vae22_to_video": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_vae22_avgdown_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_vae22_dupup_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_lora_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "wan_axpy_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "wan_add_f32_into_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
@@ -71,6 +75,9 @@ SIGNATURES = {
     "wan_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                          c_int, c_int, c_int, c_float, c_void_p]),
     "wan_unpatchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_unpatchify_n": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_head_n": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                           c_int, c_float, c_int, c_void_p]),
     "wan_sinusoid": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "wan_act_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "wan_gemv_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -42,8 +42,8 @@ class WanModelHIP:
                  **unused):
         if tuple(patch_size) != (1, 2, 2):
             raise NotImplementedError("only patch_size (1,2,2) (all Wan 2.1/2.2 14B/1.3B models)")
-        if model_type not in ("t2v", "i2v2_2"):
-            raise NotImplementedError(f"model_type {model_type!r}: only t2v / i2v2_2 cross-attention (model.py:1149)")
+        if model_type not in ("t2v", "i2v2_2", "ti2v2_2"):
+            raise NotImplementedError(f"model_type {model_type!r}: only the t2v_cross_attn types t2v / i2v2_2 / ti2v2_2 (model.py:1149)")
         self.model_type, self.dim, self.ffn_dim, self.num_heads, self.num_layers = model_type, dim, ffn_dim, num_heads, num_layers
         self.in_dim, self.out_dim, self.text_dim, self.freq_dim, self.text_len, self.eps = in_dim, out_dim, text_dim, freq_dim, text_len, eps
         self.patch_size = tuple(patch_size)
@@ -118,6 +118,8 @@ class WanModelHIP:
         if any(xx.shape[0] != 1 for xx in x_list):
             raise NotImplementedError("each stream must have batch 1 (the reference's joint CFG pass)")
         _, C, F, H, W = x_list[0].shape
+        if C != self.out_dim:
+            raise _L.WanHipError(f"latent streams must have {self.out_dim} channels, got {C}")
         dev = self.device
         xs = [xx.to(device=dev, dtype=torch.float32).contiguous() for xx in x_list]
         ctxs = [c.to(device=dev, dtype=torch.bfloat16).contiguous() for c in context]
@@ -139,7 +141,7 @@ class WanModelHIP:
             outs = [torch.empty(1, self.out_dim, F, H, W, dtype=torch.float32, device=dev) for _ in range(S)]
             sp_struct = None
         else:
-            outs = [torch.empty(1, L // shards, 64, dtype=torch.float32, device=dev) for _ in range(S)]
+            outs = [torch.empty(1, L // shards, 4 * self.out_dim, dtype=torch.float32, device=dev) for _ in range(S)]
             sp.bind_workspace(ws)
             sp_struct = ctypes.byref(sp.make_info(L))
 

@@ -242,18 +242,19 @@ def head(x, hmod, e, w, bias, grid, eps=1e-6):
     B, L, d = x.shape
     F, Hg, Wg = grid
     tmp = torch.empty_like(x)
-    out = torch.empty(B, 16, F, Hg * 2, Wg * 2, dtype=torch.float32, device=x.device)
-    check(_L.load().wan_head(ptr(x), ptr(hmod), ptr(e), ptr(w), ptr(bias), ptr(tmp), ptr(out), B, F, Hg, Wg, d, eps,
-                             stream_ptr()), "wan_head")
+    nout = w.shape[0]                                                      # 4 * out_dim: 64, or 192 for the ti2v 5B model
+    out = torch.empty(B, nout // 4, F, Hg * 2, Wg * 2, dtype=torch.float32, device=x.device)
+    check(_L.load().wan_head_n(ptr(x), ptr(hmod), ptr(e), ptr(w), ptr(bias), ptr(tmp), ptr(out), B, F, Hg, Wg, d, eps, nout,
+                               stream_ptr()), "wan_head")
     return out
 
 
 def unpatchify(tok, grid):
     _req(tok, torch.float32, "tok")
-    B = tok.shape[0]
+    B, nout = tok.shape[0], tok.shape[-1]
     F, Hg, Wg = grid
-    out = torch.empty(B, 16, F, Hg * 2, Wg * 2, dtype=torch.float32, device=tok.device)
-    check(_L.load().wan_unpatchify(ptr(tok), ptr(out), B, F, Hg, Wg, stream_ptr()), "wan_unpatchify")
+    out = torch.empty(B, nout // 4, F, Hg * 2, Wg * 2, dtype=torch.float32, device=tok.device)
+    check(_L.load().wan_unpatchify_n(ptr(tok), ptr(out), B, F, Hg, Wg, nout, stream_ptr()), "wan_unpatchify")
     return out
 
 

@@ -86,7 +86,8 @@ class WanAny2VHIP:
         seed_g = torch.Generator(device=dev)
         seed_g.manual_seed(seed if seed >= 0 else torch.seed() % (2 ** 31))
         lat_frames = (frame_num - 1) // self.vae_stride[0] + 1                       # any2video.py:647
-        target_shape = (16, lat_frames, height // self.vae_stride[1], width // self.vae_stride[2])   # :1166
+        target_shape = (getattr(self.model, "out_dim", 16), lat_frames, height // self.vae_stride[1],
+                        width // self.vae_stride[2])                                   # :1166 (48 channels, stride 16 for ti2v 5B)
         freqs = get_rotary_pos_embed(target_shape[1:], device=dev)                   # :1192
         if latents is None:
             latents = torch.randn(batch_size, *target_shape, dtype=torch.float32, device=dev, generator=seed_g)  # :1470

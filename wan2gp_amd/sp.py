@@ -102,7 +102,7 @@ class SequenceParallel:
         return self._info
 
     def gather_output(self, tok_major: torch.Tensor, grid):
-        """[1, L/world, 64] fp32 per rank -> full [1,16,F,H,W] on every rank."""
+        """[1, L/world, 4*out_dim] fp32 per rank -> full [1,out_dim,F,H,W] on every rank."""
         from . import ops
         full = self.all_gather(tok_major[0]).unsqueeze(0)
         return ops.unpatchify(full.contiguous(), grid)

@@ -65,7 +65,7 @@ class _VaeNet:
         for k, v in sd.items():
             if k.endswith(".weight") and v.dim() in (4, 5):
                 name = k[: -len(".weight")]
-                pad = 32 if name == "conv2" else None          # latent 16 -> 32 channels for decoder.conv1
+                pad = _pad32(v.shape[0]) if name == "conv2" else None    # latent 16 -> 32 (48 -> 64) channels for decoder.conv1
                 self.convs[name] = _Conv(v, sd.get(name + ".bias"), dev, cout_pad=pad)
             elif k.endswith("gamma"):
                 self.gamma[k] = v.detach().reshape(-1).to(device=dev, dtype=F16).contiguous()
