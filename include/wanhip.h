@@ -191,6 +191,10 @@ int wan_t5_attention(const wan_bf16* q, const wan_bf16* k, const wan_bf16* v, co
                      const int32_t* mask, wan_bf16* out, int B, int L, int H, void* stream);
 /* out = bf16(a * b) elementwise (T5FeedForward: fc1(x) * gate(x), t5.py:149); n % 8 == 0 */
 int wan_mul_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
+/* out = bf16(a + b), out = bf16(a - b); operands may alias out.  The residual bookkeeping of the step-skipping caches
+ * (model.py:1967-1971: x += previous_residual; :2044-2062: previous_residual = x - ori). */
+int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
+int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
 
 /* ---- checkpoint load: LoRA merge + qint8 dequantisation -------------------------- */
 /* The reference hands LoRA files to mmgp.offload.load_loras_into_model / activate_loras (wgp.py:6922-6931,
@@ -268,6 +272,16 @@ int wan_dit_forward(wan_ctx* ctx, int S, const float* const* x, float t, const w
                     const float* y, const float* cos, const float* sin, float* const* outs, int F,
                     int H, int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp,
                     wan_poll_fn poll, void* poll_user, void* stream);
+/* wan_dit_forward with the reference's step-skipping caches (TeaCache / MagCache, model.py:1373-1482 thresholds,
+ * :1914-2064 skip logic; the decisions are host code): should_calc [S] (NULL = all), residual [S] bf16 buffers of
+ * tokens_local * dim elements (NULL entries = stream not cached).  A computing stream with a buffer leaves
+ * residual = x_after_blocks - x_after_patch_embed there; a skipped stream gets x = patch_embed(x) + residual and goes
+ * straight to the head. */
+int wan_dit_forward_skip(wan_ctx* ctx, int S, const float* const* x, float t, const wan_bf16* const* context,
+                    const float* y, const float* cos, const float* sin, float* const* outs, int F,
+                    int H, int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp,
+                    wan_poll_fn poll, void* poll_user, const int* should_calc, wan_bf16* const* residual,
+                         void* stream);
 
 /* ---- causal 3D VAE (fp16, channels-last [T,H,W,C], C % 32 == 0) ---------------------------------
  * Replaces the torch ops of models/wan/modules/vae.py; the layer graph / cache bookkeeping of

@@ -1,0 +1,134 @@
+"""-m gpu: TeaCache / MagCache on the resident HIP model against
+tests/golden/skipcache_tiny.npz -- the REFERENCE's own WanModel with `.cache` set, 8 steps, three scenarios
+(oracle/make_golden_skipcache.py).  Decisions must equal the reference's exactly; outputs within the forward tolerance of
+tests/test_gpu_model.py (relative L2 <= 2.5e-2 against the reference's bf16 result) on computed AND skipped steps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wan_oracle as O
+from oracle.make_golden_skipcache import MAG_RATIOS, STEPS, TEA_COEF, inputs
+
+pytestmark = pytest.mark.gpu
+G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "skipcache_tiny.npz")))
+CFG = O.make_config("tiny")
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), torch.as_tensor(b).float()
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def model():
+    from wan2gp_amd.model import WanModelHIP
+    m = WanModelHIP(model_type=CFG.model_type, dim=CFG.dim, ffn_dim=CFG.ffn_dim, num_heads=CFG.num_heads, num_layers=CFG.num_layers,
+                    in_dim=CFG.in_dim)
+    return m.load_state_dict(O.synth_weights(CFG, seed=4321))
+
+
+def mk(kind):
+    from wan2gp_amd.skipcache import SkipStepsCache, reset_for_generation
+    c = SkipStepsCache(cache_type=kind, multiplier=2.0, start_step=1, num_steps=STEPS, skipped_steps=0, previous_residual=None,
+                       previous_modulated_input=None)
+    if kind == "mag":
+        c.update({"magcache_thresh": 0, "magcache_K": 2, "def_mag_ratios": list(MAG_RATIOS)})
+    else:
+        c.update({"coefficients": list(TEA_COEF), "rel_l1_thresh": 0, "accumulated_rel_l1_distance": 0})
+    reset_for_generation(c, 2)
+    return c
+
+
+def test_magcache_joint_pass_vs_reference(model):
+    lats, ts, ctx, ctx_null = inputs(CFG)
+    c = model.cache = mk("mag")
+    try:
+        assert model.compute_magcache_threshold(c.start_step, ts, c.multiplier) == pytest.approx(float(G["mag_thresh"][0]), abs=1e-12)
+        worst = 0.0
+        for i in range(STEPS):
+            outs = model([lats[i].cuda(), lats[i].cuda()], t=torch.stack([ts[i]]), context=[ctx.cuda(), ctx_null.cuda()], real_step_no=i,
+                         current_step_no=i)
+            assert [int(s == 0) for s in c.accumulated_steps] == G["magj_flags"][i].tolist(), i
+            for k in range(2):
+                worst = max(worst, rel(outs[k], G[f"magj_{i}_{k}"]))
+        print(f"MagCache joint: skipped {c.skipped_steps}/{STEPS}, worst rel err {worst:.4f}")
+        assert c.skipped_steps == int(G["magj_skipped"][0]) and worst <= 2.5e-2
+    finally:
+        model.cache = None
+
+
+def test_magcache_single_passes_vs_reference(model):
+    lats, ts, ctx, ctx_null = inputs(CFG)
+    c = model.cache = mk("mag")
+    try:
+        model.compute_magcache_threshold(c.start_step, ts, c.multiplier)
+        worst = 0.0
+        for i in range(STEPS):
+            for x_id, cc in enumerate((ctx, ctx_null)):
+                out = model([lats[i].cuda()], t=torch.stack([ts[i]]), context=[cc.cuda()], real_step_no=i, current_step_no=i, x_id=x_id)[0]
+                assert int(c.accumulated_steps[x_id] == 0) == int(G["mags_flags"][i][x_id])
+                worst = max(worst, rel(out, G[f"mags_{i}_{x_id}"]))
+        assert worst <= 2.5e-2, worst
+    finally:
+        model.cache = None
+
+
+def test_teacache_joint_pass_vs_reference(model):
+    lats, ts, ctx, ctx_null = inputs(CFG)
+    c = model.cache = mk("tea")
+    try:
+        assert model.compute_teacache_threshold(c.start_step, ts, c.multiplier) == pytest.approx(float(G["tea_thresh"][0]), abs=1e-12)
+        worst, flags = 0.0, []
+        for i in range(STEPS):
+            outs = model([lats[i].cuda(), lats[i].cuda()], t=torch.stack([ts[i]]), context=[ctx.cuda(), ctx_null.cuda()], real_step_no=i,
+                         current_step_no=i)
+            flags.append(int(c.should_calc))
+            for k in range(2):
+                worst = max(worst, rel(outs[k], G[f"teaj_{i}_{k}"]))
+        print(f"TeaCache joint: flags {flags}, worst rel err {worst:.4f}")
+        assert flags == G["teaj_flags"].tolist() and c.skipped_steps == int(G["teaj_skipped"][0]) and worst <= 2.5e-2
+    finally:
+        model.cache = None
+
+
+def test_skip_reapplies_the_stored_residual(model):
+    """Same inputs computed, then skipped: patch_embed(x) + (x_after - x_before) must give the computed output back up to
+    the two bf16 roundings of the residual round trip; a skipped stream without a stored residual is an error."""
+    from wan2gp_amd.lib import WanHipError
+    from wan2gp_amd.skipcache import SkipStepsCache
+    lats, ts, ctx, ctx_null = inputs(CFG)
+    t = torch.stack([ts[3]])
+    plain = model([lats[3].cuda()], t=t, context=[ctx.cuda()])[0]
+    c = model.cache = SkipStepsCache(cache_type="mag", start_step=0, one_for_all=False, magcache_K=4, magcache_thresh=10.0, skipped_steps=0,
+                                     mag_ratios=np.ones(64), accumulated_err=[0.0, 0.0], accumulated_steps=[0, 0],
+                                     accumulated_ratio=[1.0, 1.0], previous_residual=None)
+    try:
+        with pytest.raises(WanHipError):
+            model([lats[3].cuda()], t=t, context=[ctx.cuda()], real_step_no=1)          # would skip, nothing stored yet
+        c.accumulated_err, c.accumulated_steps, c.accumulated_ratio = [0.0, 0.0], [0, 0], [1.0, 1.0]
+        a = model([lats[3].cuda()], t=t, context=[ctx.cuda()], real_step_no=0)[0]    # computes, stores the residual
+        assert torch.equal(a, plain)
+        b = model([lats[3].cuda()], t=t, context=[ctx.cuda()], real_step_no=1)[0]    # skips
+        assert c.skipped_steps == 2 and rel(b, a.cpu()) < 1e-2 and not torch.equal(a, b)
+    finally:
+        model.cache = None
+
+
+def test_generate_with_magcache(model):
+    from wan2gp_amd.pipeline import WanAny2VHIP
+    _, _, ctx, ctx_null = inputs(CFG)
+    pipe = WanAny2VHIP(model)
+    run = lambda: pipe.generate(context=ctx.cuda(), context_null=ctx_null.cuda(), width=64, height=64, frame_num=5, sampling_steps=8,
+                                guide_scale=3.0, seed=11, return_latents=True)["latents"].cpu()
+    base = run()
+    c = model.cache = mk("mag")
+    try:
+        fast = run()
+        assert c.skipped_steps > 0 and torch.isfinite(fast).all()
+        d = ((fast - base).norm() / base.norm()).item()
+        print(f"generate with MagCache x{c.multiplier}: skipped {c.skipped_steps}/8, latents differ by {d:.3f} (relative)")
+        assert 0 < d < 0.5
+    finally:
+        model.cache = None

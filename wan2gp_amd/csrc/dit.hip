@@ -292,10 +292,17 @@ static int linear(const bf16_t* A, const Lin& l, bf16_t* C, int64_t M, int N, in
   return wan_gemm_bf16(A, K, l.w, l.b, C, ldc ? ldc : N, M, N, K, epi, R, mod, e, 6, gate, rpb, st);
 }
 
-extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
-                               const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
-                               int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
-                               void* poll_user, void* stream) {
+extern "C" int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
+extern "C" int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
+
+// should_calc / residual: the step-skipping caches of the reference (TeaCache / MagCache, model.py:1914-2064).  Stream s
+// with residual[s] != NULL either runs the block chain and leaves residual[s] = x_after_blocks - x_after_patch_embed
+// (should_calc[s] != 0), or skips the chain and adds the stored residual to its freshly embedded tokens.  The decision is
+// host logic (wan2gp_amd/skipcache.py); both arrays NULL = the plain forward.
+static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
+                            const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
+                            int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
+                            void* poll_user, const int* should_calc, wan_bf16* const* residual, void* stream) {
   WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
   WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
@@ -349,6 +356,26 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
   static const bool exact_env = [] { const char* e = getenv("WAN_DIT_EXACT_QSCALE"); return e && e[0] == '1'; }();
   const bool fold_qscale = !exact_env && Ll * (int64_t)nh * 256 < ((int64_t)1 << 32) && Lp * 256 < ((int64_t)1 << 32);
 
+  // ---- step-skipping: park x_before in the residual buffer, or add the stored residual and skip (model.py:1967-1990) ----
+  const int64_t sn = Ll * (int64_t)d;
+  auto calc = [&](int s) { return should_calc == nullptr || should_calc[s] != 0; };
+  for (int s = 0; s < S; ++s) {
+    if (residual == nullptr || residual[s] == nullptr) {
+      WAN_REQUIRE(calc(s), "wan_dit_forward: stream %d is skipped but has no residual buffer", s);
+      continue;
+    }
+    if (calc(s)) WAN_CHECK_HIP(hipMemcpyAsync(residual[s], b.x + s * sn, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
+    else RC(wan_add_bf16(b.x + s * sn, residual[s], b.x + s * sn, sn, stream));
+  }
+
+  // the block chain over streams [s0, s0 + Sn): every scratch buffer is used from its base, only the token stream and the
+  // text context are offset (maximal runs of computing streams; all of them in the plain forward)
+  auto run_blocks = [&](const int s0, const int Sn) -> int {
+  const int S = Sn;
+  const int64_t rows = (int64_t)Sn * Ll, rpb = rows;
+  struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull; } b2 = {
+      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull};
+  auto& b = b2;
   for (int i = 0; i < g.num_layers; ++i) {
     if (poll && poll(poll_user, i)) return 1;  // model.py:1995-1998
     const Layer& Lw = c->layers[i];
@@ -405,10 +432,38 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
       RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb));
     }
   }
+  return 0;
+  };
+  for (int s0 = 0; s0 < S;) {
+    if (!calc(s0)) { ++s0; continue; }
+    int Sn = 1;
+    while (s0 + Sn < S && calc(s0 + Sn)) ++Sn;
+    if (int rc = run_blocks(s0, Sn)) return rc;
+    s0 += Sn;
+  }
+  for (int s = 0; s < S; ++s)
+    if (residual != nullptr && residual[s] != nullptr && calc(s))
+      RC(wan_sub_bf16(b.x + s * sn, residual[s], residual[s], sn, stream));  // previous_residual = x - ori (model.py:2044-2062)
 
   // ---- head + unpatchify (model.py:2068-2097) -------------------------------------------------------
   for (int s = 0; s < S; ++s)
     RC(wan_head_range(b.x + (int64_t)s * Ll * d, c->head_mod, b.e, c->head_w, c->head_b, b.xm, outs[s], 1, F, Hg, Wg, d,
                       g.eps, tok0, Ll, world > 1 ? 1 : 0, 1, 4 * g.out_dim, stream));
   return 0;
+}
+
+extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
+                               const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
+                               int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
+                               void* poll_user, void* stream) {
+  return dit_forward_impl(c, S, x, t, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
+                          nullptr, nullptr, stream);
+}
+
+extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
+                                    const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
+                                    int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
+                                    void* poll_user, const int* should_calc, wan_bf16* const* residual, void* stream) {
+  return dit_forward_impl(c, S, x, t, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
+                          should_calc, residual, stream);
 }

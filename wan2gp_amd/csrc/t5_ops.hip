@@ -88,13 +88,16 @@ __global__ __launch_bounds__(256) void t5_attention_kernel(const bf16_t* __restr
   }
 }
 
-__global__ void mul_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ o, int64_t n8) {
+// OP: 0 = a * b, 1 = a + b, 2 = a - b; fp32 arithmetic on the bf16 values, one rounding (what torch does for bf16 tensors).
+// a, b and o may alias element for element (no __restrict__).
+template <int OP>
+__global__ void binary_bf16_kernel(const bf16_t* a, const bf16_t* b, bf16_t* o, int64_t n8) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
     float x[8], y[8];
     unpack8(*reinterpret_cast<const uint4*>(a + i * 8), x);
     unpack8(*reinterpret_cast<const uint4*>(b + i * 8), y);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] *= y[j];
+    for (int j = 0; j < 8; ++j) x[j] = OP == 0 ? x[j] * y[j] : OP == 1 ? x[j] + y[j] : x[j] - y[j];
     *reinterpret_cast<uint4*>(o + i * 8) = pack8(x);
   }
 }
@@ -110,14 +113,25 @@ extern "C" int wan_t5_attention(const wan_bf16* q, const wan_bf16* k, const wan_
   return 0;
 }
 
-extern "C" int wan_mul_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream) {
-  WAN_REQUIRE(a && b && out, "wan_mul_bf16: null pointer");
-  WAN_REQUIRE(n % 8 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0), "wan_mul_bf16: n %% 8 and 16-byte alignment required");
+template <int OP>
+static int binary_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream, const char* what) {
+  WAN_REQUIRE(a && b && out, "%s: null pointer", what);
+  WAN_REQUIRE(n % 8 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0), "%s: n %% 8 and 16-byte alignment required", what);
   if (n == 0) return 0;
   const int64_t n8 = n / 8;
   int blocks = (int)((n8 + 255) / 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(mul_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a, b, out, n8);
+  hipLaunchKernelGGL(binary_bf16_kernel<OP>, dim3(blocks), dim3(256), 0, as_stream(stream), a, b, out, n8);
   WAN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int wan_mul_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream) {
+  return binary_bf16<0>(a, b, out, n, stream, "wan_mul_bf16");
+}
+// residual bookkeeping of the step-skipping caches (model.py:1967-1971, :2044-2062): x += residual, residual = x - ori
+extern "C" int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream) {
+  return binary_bf16<1>(a, b, out, n, stream, "wan_add_bf16");
+}
+extern "C" int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream) {
+  return binary_bf16<2>(a, b, out, n, stream, "wan_sub_bf16");
 }

@@ -66,6 +66,8 @@ SIGNATURES = {
     "wan_vae22_to_video": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_vae22_avgdown_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_vae22_dupup_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_sub_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_lora_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),
     "wan_axpy_f32": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "wan_add_f32_into_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
@@ -100,6 +102,9 @@ SIGNATURES = {
     "wan_dit_forward": (c_int, [c_void_p, c_int, POINTER(c_void_p), c_float, POINTER(c_void_p), c_void_p, c_void_p,
                                 c_void_p, POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int64,
                                 POINTER(SpInfo), POLL_FN, c_void_p, c_void_p]),
+    "wan_dit_forward_skip": (c_int, [c_void_p, c_int, POINTER(c_void_p), c_float, POINTER(c_void_p), c_void_p, c_void_p,
+                                c_void_p, POINTER(c_void_p), c_int, c_int, c_int, c_void_p, c_int64,
+                                POINTER(SpInfo), POLL_FN, c_void_p, POINTER(c_int), POINTER(c_void_p), c_void_p]),
 }
 
 

@@ -84,6 +84,24 @@ class WanModelHIP:
                   f"wan_dit_set_weight({k})")
         return self
 
+    # ---- step-skipping caches (model.py:1373-1482) --------------------------------------------------------
+    def time_embedding(self, tval):
+        """e = time_embedding(sinusoidal_embedding_1d(freq_dim, t)) as bf16 [1, dim] (model.py:1815-1817): the same three
+        kernels wan_dit_forward runs."""
+        from . import ops
+        w = self._weights
+        s = ops.sinusoid(torch.tensor([float(tval)], dtype=torch.float32, device=self.device), self.freq_dim)
+        h = ops.silu(ops.gemv(s, w["time_embedding.0.weight"], w["time_embedding.0.bias"]))
+        return ops.gemv(h, w["time_embedding.2.weight"], w["time_embedding.2.bias"])
+
+    def compute_teacache_threshold(self, start_step, timesteps=None, speed_factor=0):
+        from . import skipcache
+        return skipcache.compute_teacache_threshold(self.cache, start_step, [self.time_embedding(float(t)) for t in timesteps], speed_factor)
+
+    def compute_magcache_threshold(self, start_step, timesteps=None, speed_factor=0):
+        from . import skipcache
+        return skipcache.compute_magcache_threshold(self.cache, start_step, timesteps, speed_factor)
+
     def apply_post_init_changes(self):  # reference API; nothing to adapt here
         return self
 
@@ -110,8 +128,6 @@ class WanModelHIP:
                                              max_steps=max_steps, callback=callback, **variant_kwargs)
             raise NotImplementedError(f"WanModelHIP.forward: variant arguments {sorted(active)} are outside the "
                                       "MI355X hot path (t2v / i2v2_2); attach `reference_module` to delegate")
-        if self.cache is not None:
-            raise NotImplementedError("step-skipping caches (TeaCache/MagCache) change outputs and are not implemented")
         x_list = list(x)
         x.clear()                                           # model.py:1558-1559
         S = len(x_list)
@@ -159,8 +175,33 @@ class WanModelHIP:
         XP = (c_void_p * S)(*[a.data_ptr() for a in xs])
         CP = (c_void_p * S)(*[a.data_ptr() for a in ctxs])
         OP = (c_void_p * S)(*[a.data_ptr() for a in outs])
-        rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
-                                       ws.numel(), sp_struct, poll, None, stream_ptr())
+        cache = self.cache
+        if cache is None:
+            rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
+                                           ws.numel(), sp_struct, poll, None, stream_ptr())
+        else:
+            # TeaCache / MagCache (model.py:1914-2064): host decision, residual bookkeeping inside wan_dit_forward_skip
+            from . import skipcache
+            e = self.time_embedding(tval) if (cache.cache_type == "tea" and x_id == 0) else None
+            flags = skipcache.decide(cache, S, x_id, real_step_no, e)
+            if getattr(cache, "previous_residual", None) is None:
+                cache.previous_residual = [None] * S
+            slots = list(range(S)) if S > 1 else [x_id]
+            n_res = (L // shards) * self.dim
+            bufs = []
+            for sl, calc in zip(slots, flags):
+                while len(cache.previous_residual) <= sl:
+                    cache.previous_residual.append(None)
+                r = cache.previous_residual[sl]
+                if r is None or r.numel() != n_res or not r.is_cuda:
+                    if not calc:
+                        raise _L.WanHipError(f"step-skipping cache: stream {sl} is skipped at step {real_step_no} without a stored residual")
+                    r = cache.previous_residual[sl] = torch.empty(n_res, dtype=torch.bfloat16, device=dev)
+                bufs.append(r)
+            FL = (ctypes.c_int * S)(*[1 if f else 0 for f in flags])
+            RP = (c_void_p * S)(*[r.data_ptr() for r in bufs])
+            rc = _L.load().wan_dit_forward_skip(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
+                                                ws.numel(), sp_struct, poll, None, FL, RP, stream_ptr())
         if rc == 1:
             return [None] * S                               # model.py:1997-1998
         check(rc, "wan_dit_forward")

@@ -279,6 +279,21 @@ def gemv(x, weight, bias):
     return out
 
 
+def sinusoid(t, dim):
+    """sinusoidal_embedding_1d(dim, t) -> bf16 [n, dim] (model.py:32-42)."""
+    _req(t, torch.float32, "t")
+    out = torch.empty(t.numel(), dim, dtype=BF16, device=t.device)
+    check(_L.load().wan_sinusoid(ptr(t), ptr(out), t.numel(), dim, stream_ptr()), "wan_sinusoid")
+    return out
+
+
+def silu(x):
+    _req(x, BF16, "x")
+    out = torch.empty_like(x)
+    check(_L.load().wan_act_bf16(ptr(x), ptr(out), x.numel(), 1, stream_ptr()), "wan_act_bf16")
+    return out
+
+
 def cfg_combine(cond, uncond, guide_scale, out=None):
     """noise_pred = uncond + g * (cond - uncond)   (any2video.py:1722), fp32."""
     _req(cond, torch.float32, "cond"); _req(uncond, torch.float32, "uncond")

@@ -109,6 +109,18 @@ class WanAny2VHIP:
             phase_switch_step, phase_switch_step2, _ = get_model_switch_steps(
                 [float(t) for t in timesteps], guide_phases, 0 if self.model2 is None else model_switch_phase, switch_threshold,
                 switch2_threshold)
+        # step-skipping caches (any2video.py:1398-1408): reset, then pick the threshold that meets cache.multiplier
+        for m in (self.model, self.model2):
+            cache = getattr(m, "cache", None) if m is not None else None
+            if cache is not None:
+                from . import skipcache
+                skipcache.reset_for_generation(cache, 2)
+                cache.num_steps = len(timesteps)
+                cache.previous_modulated_input = None
+                if cache.cache_type == "tea":
+                    m.compute_teacache_threshold(cache.start_step, timesteps, cache.multiplier)
+                else:
+                    m.compute_magcache_threshold(cache.start_step, timesteps, cache.multiplier)
         kwargs = {"freqs": freqs, "pipeline": self, "callback": callback, "y": y, "max_steps": len(timesteps)}
         for i, t in enumerate(timesteps):
             # update_guidance (:1437-1443): phase 2 begins once t <= switch_threshold
