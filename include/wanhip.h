@@ -158,7 +158,7 @@ int wan_unpatchify_n(const float* in, float* out, int B, int F, int Hg, int Wg, 
 
 /* sinusoidal_embedding_1d(256, t) -> bf16 [n, dim] (model.py:32-42, :1816) */
 int wan_sinusoid(const float* t, wan_bf16* out, int n, int dim, void* stream);
-/* y = act(x) elementwise on bf16 (act: 1 = SiLU, used between the M=1 time MLP GEMVs) */
+/* y = act(x) elementwise on bf16 (act: 1 = SiLU, used between the M=1 time MLP GEMVs; 2 = GELU(erf), img_emb) */
 int wan_act_bf16(const wan_bf16* x, wan_bf16* y, int64_t n, int act, void* stream);
 /* small-M Linear (GEMV): C[M,N] = bf16(A[M,K] W[N,K]^T + bias), M <= 16 (time MLP) */
 int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C, int M,
@@ -272,6 +272,13 @@ int wan_dit_forward(wan_ctx* ctx, int S, const float* const* x, float t, const w
                     const float* y, const float* cos, const float* sin, float* const* outs, int F,
                     int H, int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp,
                     wan_poll_fn poll, void* poll_user, void* stream);
+/* Wan2.1 i2v (model_type 'i2v': checkpoints with img_emb.* and cross_attn.k_img / v_img / norm_k_img): projects the CLIP
+ * vision features clip_fea [257, 1280] bf16 through img_emb (MLPProj, model.py:868-889, :1858-1859) and keeps the 257 image
+ * tokens for the k_img / v_img branch of every block's cross-attention (WanI2VCrossAttention, model.py:448-499).  Must be
+ * called before wan_dit_forward for such a model (the reference asserts clip_fea is not None, model.py:1547); the result
+ * is kept in the context until the next call (the features do not depend on the step). */
+int wan_dit_set_clip(wan_ctx* ctx, const wan_bf16* clip_fea, void* stream);
+
 /* wan_dit_forward with the reference's step-skipping caches (TeaCache / MagCache, model.py:1373-1482 thresholds,
  * :1914-2064 skip logic; the decisions are host code): should_calc [S] (NULL = all), residual [S] bf16 buffers of
  * tokens_local * dim elements (NULL entries = stream not cached).  A computing stream with a buffer leaves

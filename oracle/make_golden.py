@@ -47,12 +47,13 @@ def build_ref_model(ns, cfg: O.WanConfig, W, dtype):
     return m
 
 
-def ref_forward(ns, m, x_list, t, ctx_list, y=None):
+def ref_forward(ns, m, x_list, t, ctx_list, y=None, clip_fea=None):
     grid = x_list[0].shape[2:]
     freqs = ns.P.get_rotary_pos_embed(grid)
+    kw = {} if clip_fea is None else {"clip_fea": clip_fea.clone()}
     with torch.no_grad():
         return m([x.clone() for x in x_list], t=t, context=[c.clone() for c in ctx_list], y=y, freqs=freqs,
-                 pipeline=types.SimpleNamespace(_interrupt=False))
+                 pipeline=types.SimpleNamespace(_interrupt=False), **kw)
 
 
 def gen_ops(ns):
@@ -88,6 +89,7 @@ def gen_forward(ns, name, f, h, w, tval):
     cfg = O.make_config(name)
     out = {"shape": np.array([f, h, w]), "t": np.array([tval])}
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
+    clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None
     t = torch.tensor([tval], dtype=torch.int64)
     # NOTE: only the reference's real bf16 plan is a valid golden.  Run "fp32 everywhere" the
     # reference's WanRMSNorm aliases its input (`y = x.float()` is x itself for fp32, then
@@ -97,14 +99,14 @@ def gen_forward(ns, name, f, h, w, tval):
         W = O.synth_weights(cfg, dtype=dtype)
         m = build_ref_model(ns, cfg, W, dtype)
         cdt = dtype
-        r = ref_forward(ns, m, [lat, lat], t, [ctx.to(cdt), ctx_null.to(cdt)], y=y)
+        r = ref_forward(ns, m, [lat, lat], t, [ctx.to(cdt), ctx_null.to(cdt)], y=y, clip_fea=clip)
         out[f"cond_{tag}"], out[f"uncond_{tag}"] = f32(r[0]), f32(r[1])
         # one block in isolation (block 0) on a seeded hidden state
         g = torch.Generator().manual_seed(11)
         L = f * (h // 2) * (w // 2)
         hid = torch.randn(1, L, cfg.dim, generator=g).to(dtype)
         e0 = (0.5 * torch.randn(1, 6, cfg.dim, generator=g)).to(dtype)
-        cemb = (0.5 * torch.randn(1, 512, cfg.dim, generator=g)).to(dtype)
+        cemb = (0.5 * torch.randn(1, 512 + (O.CLIP_TOKENS if cfg.model_type == "i2v" else 0), cfg.dim, generator=g)).to(dtype)
         freqs = ns.P.get_rotary_pos_embed((f, h, w))
         with torch.no_grad():
             bo = m.blocks[0](hid.clone(), e=e0, grid_sizes=(f, h // 2, w // 2), freqs=freqs, context=cemb)
@@ -219,6 +221,7 @@ def main():
         gen_forward(ns, "tiny", 3, 8, 12, 637)
         gen_forward(ns, "tiny_i2v", 2, 8, 8, 912)
         gen_forward(ns, "tiny_ti2v", 2, 6, 10, 455)
+        gen_forward(ns, "tiny_i2v21", 2, 8, 8, 731)
     if "sched" in which:
         gen_sched(ns)
     if "sched2" in which:

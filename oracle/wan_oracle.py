@@ -65,7 +65,11 @@ CONFIGS = {
     # Wan2.2 ti2v 5B (models/wan/configs/ti2v_2_2.json): 48-channel latents of the Wan2.2 VAE in and out, no y
     "ti2v_5B": dict(dim=3072, ffn_dim=14336, num_heads=24, num_layers=30, in_dim=48, out_dim=48, model_type="ti2v2_2"),
     "tiny_ti2v": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, in_dim=48, out_dim=48, model_type="ti2v2_2"),
+    # Wan2.1 i2v: CLIP image tokens through img_emb + the k_img / v_img cross-attention branch (model.py:448-499, :868-889)
+    "i2v_14B": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, model_type="i2v"),
+    "tiny_i2v21": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, in_dim=36, model_type="i2v"),
 }
+CLIP_TOKENS, CLIP_DIM = 257, 1280
 
 
 def make_config(name: str) -> WanConfig:
@@ -96,6 +100,16 @@ def param_shapes(cfg: WanConfig) -> Dict[str, Tuple[int, ...]]:
         p[b + "norm3.weight"] = (d,); p[b + "norm3.bias"] = (d,)
         p[b + "ffn.0.weight"] = (f, d); p[b + "ffn.0.bias"] = (f,)
         p[b + "ffn.2.weight"] = (d, f); p[b + "ffn.2.bias"] = (d,)
+    if cfg.model_type == "i2v":                                # WanI2VCrossAttention (:448-464) + MLPProj (:868-876)
+        for i in range(cfg.num_layers):
+            b = f"blocks.{i}.cross_attn."
+            p[b + "k_img.weight"] = (d, d); p[b + "k_img.bias"] = (d,)
+            p[b + "v_img.weight"] = (d, d); p[b + "v_img.bias"] = (d,)
+            p[b + "norm_k_img.weight"] = (d,)
+        p["img_emb.proj.0.weight"] = (CLIP_DIM,); p["img_emb.proj.0.bias"] = (CLIP_DIM,)
+        p["img_emb.proj.1.weight"] = (CLIP_DIM, CLIP_DIM); p["img_emb.proj.1.bias"] = (CLIP_DIM,)
+        p["img_emb.proj.3.weight"] = (d, CLIP_DIM); p["img_emb.proj.3.bias"] = (d,)
+        p["img_emb.proj.4.weight"] = (d,); p["img_emb.proj.4.bias"] = (d,)
     p["head.modulation"] = (1, 2, d)
     p["head.head.weight"] = (cfg.out_dim * math.prod(cfg.patch_size), d)
     p["head.head.bias"] = (cfg.out_dim * math.prod(cfg.patch_size),)
@@ -115,7 +129,7 @@ def synth_weights(cfg: WanConfig, seed: int = 1234, dtype=torch.bfloat16) -> Dic
     for k, shp in param_shapes(cfg).items():
         if k.endswith("modulation"):
             w = torch.randn(shp, generator=g) / cfg.dim ** 0.5
-        elif "norm" in k and k.endswith("weight"):
+        elif ("norm" in k or k in ("img_emb.proj.0.weight", "img_emb.proj.4.weight")) and k.endswith("weight"):
             w = 1.0 + 0.02 * torch.randn(shp, generator=g)
         elif k.endswith("bias"):
             w = 0.01 * torch.randn(shp, generator=g)
@@ -261,10 +275,26 @@ def self_attention(x, W, p, cfg: WanConfig, cos, sin, exact):
 def cross_attention(x, ctx, W, p, cfg: WanConfig, exact):
     b, n, d = x.shape[0], cfg.num_heads, cfg.head_dim
     q = rms_norm(_linear(x, W, p + "q"), W[p + "norm_q.weight"], cfg.eps).view(b, -1, n, d)
+    ctx_img = None
+    if cfg.model_type == "i2v":                                # WanI2VCrossAttention.forward (model.py:466-499)
+        ctx_img, ctx = ctx[:, :CLIP_TOKENS], ctx[:, CLIP_TOKENS:]
     k = rms_norm(_linear(ctx, W, p + "k"), W[p + "norm_k.weight"], cfg.eps).view(ctx.shape[0], -1, n, d)
     v = _linear(ctx, W, p + "v").view(ctx.shape[0], -1, n, d)
-    o = attention(q, k, v, exact)
-    return _linear(o.flatten(2, 3), W, p + "o")
+    o = attention(q, k, v, exact).flatten(2, 3)
+    if ctx_img is not None:
+        k_img = rms_norm(_linear(ctx_img, W, p + "k_img"), W[p + "norm_k_img.weight"], cfg.eps).view(ctx_img.shape[0], -1, n, d)
+        v_img = _linear(ctx_img, W, p + "v_img").view(ctx_img.shape[0], -1, n, d)
+        o = o + attention(q, k_img, v_img, exact).flatten(2, 3)        # x += img_x (:493)
+    return _linear(o, W, p + "o")
+
+
+def img_emb(clip_fea, W):
+    """MLPProj.forward (model.py:868-889, no flf position embedding): LayerNorm(1280) -> Linear -> GELU(erf) -> Linear ->
+    LayerNorm(dim); torch.nn.LayerNorm's default eps 1e-5."""
+    x = F.layer_norm(clip_fea, (clip_fea.shape[-1],), W["img_emb.proj.0.weight"], W["img_emb.proj.0.bias"], 1e-5)
+    x = F.gelu(_linear(x, W, "img_emb.proj.1"))
+    x = _linear(x, W, "img_emb.proj.3")
+    return F.layer_norm(x, (x.shape[-1],), W["img_emb.proj.4.weight"], W["img_emb.proj.4.bias"], 1e-5)
 
 
 def block_forward(x, e0, ctx, cos, sin, W, i: int, cfg: WanConfig, exact: bool = False):
@@ -321,7 +351,7 @@ def unpatchify(x, grid, cfg: WanConfig):
 # --------------------------------------------------------------------------------------
 def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[torch.Tensor],
                 W, cfg: WanConfig, y: Optional[torch.Tensor] = None, freqs=None,
-                dtype=torch.bfloat16, exact: bool = False, return_hidden: bool = False):
+                dtype=torch.bfloat16, exact: bool = False, return_hidden: bool = False, clip_fea: Optional[torch.Tensor] = None):
     """x_list: S tensors [B,16,F,H,W] fp32; t [1]; context_list: S tensors [B,512,4096].
     Returns S fp32 tensors [B,16,F,H,W] (model.py:2093-2097)."""
     hs = []
@@ -337,6 +367,9 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
     cos, sin = freqs if freqs is not None else rope_tables(grid)
     e, e0 = time_embed(t, W, cfg, dtype)
     ctxs = [text_embed(c.to(dtype), W) for c in context_list]
+    if clip_fea is not None:                                # model.py:1858-1869: [clip tokens ; text tokens]
+        cc = img_emb(clip_fea.to(dtype), W)
+        ctxs = [torch.cat([cc, c], dim=1) for c in ctxs]
     for i in range(cfg.num_layers):                         # model.py:1993-2036
         for s in range(len(hs)):
             hs[s] = block_forward(hs[s], e0, ctxs[s], cos, sin, W, i, cfg, exact)
@@ -608,3 +641,9 @@ def synth_inputs(cfg: WanConfig, f: int, h: int, w: int, seed: int = 42, text_to
         msk = (torch.rand(4, f, h, w, generator=g) > 0.5).float()
         y = torch.cat([msk, torch.randn(16, f, h, w, generator=g)], dim=0)
     return lat, ctx.to(torch.bfloat16), ctx_null.to(torch.bfloat16), y
+
+
+def synth_clip_fea(seed: int = 9):
+    """CLIP ViT-H penultimate features as `clip_fea` [1, 257, 1280] bf16 (any2video.py feeds clip.visual output)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(1, CLIP_TOKENS, CLIP_DIM, generator=g).to(torch.bfloat16)

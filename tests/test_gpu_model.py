@@ -38,7 +38,7 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21"])
 def test_forward_vs_reference_golden(name):
     g = load(f"forward_{name}.npz")
     f, h, w = [int(v) for v in g["shape"]]
@@ -47,10 +47,13 @@ def test_forward_vs_reference_golden(name):
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
     t = torch.tensor([int(g["t"][0])], dtype=torch.int64)
     xs = [lat.cuda(), lat.cuda()]
-    outs = m(xs, t=t, context=[ctx.cuda(), ctx_null.cuda()], y=None if y is None else y.cuda())
+    clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None     # Wan2.1 i2v: CLIP tokens + k_img / v_img branch
+    kw = {} if clip is None else {"clip_fea": clip.cuda()}
+    outs = m(xs, t=t, context=[ctx.cuda(), ctx_null.cuda()], y=None if y is None else y.cuda(), **kw)
     assert xs == []                                                    # list consumed (model.py:1558-1559)
     W32 = O.synth_weights(cfg, dtype=torch.float32)
-    anchor = O.dit_forward([lat, lat], t, [ctx.float(), ctx_null.float()], W32, cfg, y=y, dtype=torch.float32, exact=True)
+    anchor = O.dit_forward([lat, lat], t, [ctx.float(), ctx_null.float()], W32, cfg, y=y, dtype=torch.float32, exact=True,
+                           clip_fea=None if clip is None else clip.float())
     for o, key, a in zip(outs, ("cond_bf16", "uncond_bf16"), anchor):
         assert o.dtype == torch.float32 and tuple(o.shape) == (1, cfg.out_dim, f, h, w)
         ref = torch.from_numpy(g[key])
@@ -193,3 +196,22 @@ def test_sampler_loop_vs_reference_golden():
         print(f"loop step {i}: rel err vs reference {e:.4e}")
         assert e <= 4e-2, (i, e)
     assert torch.isfinite(out["latents"]).all()
+
+
+def test_i2v21_requires_clip_features_and_changes_with_them():
+    """model.py:1547 asserts clip_fea and y for model_type 'i2v'; the CLIP branch must actually contribute."""
+    from wan2gp_amd.lib import WanHipError
+    cfg = O.make_config("tiny_i2v21")
+    m, W = build(cfg)
+    lat, ctx, _, y = O.synth_inputs(cfg, 2, 8, 8)
+    t = torch.tensor([500])
+    with pytest.raises(WanHipError):
+        m([lat.cuda()], t=t, context=[ctx.cuda()], y=y.cuda())
+    a = m([lat.cuda()], t=t, context=[ctx.cuda()], y=y.cuda(), clip_fea=O.synth_clip_fea(1).cuda())[0]
+    b = m([lat.cuda()], t=t, context=[ctx.cuda()], y=y.cuda(), clip_fea=O.synth_clip_fea(2).cuda())[0]
+    assert torch.isfinite(a).all() and rel(a.cpu(), b.cpu()) > 1e-4
+    cfg2 = O.make_config("tiny")
+    m2, _ = build(cfg2)
+    lat2, ctx2, _, _ = O.synth_inputs(cfg2, 2, 8, 8)
+    with pytest.raises(NotImplementedError):
+        m2([lat2.cuda()], t=t, context=[ctx2.cuda()], clip_fea=O.synth_clip_fea(1).cuda())      # t2v model: variant kwarg

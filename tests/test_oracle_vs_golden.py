@@ -56,7 +56,7 @@ def test_rmsnorm_rope_ln_sdpa_bit_exact():
     assert (ex - t(g["sdpa_bf16"])).abs().max() < 2e-2
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21"])
 @pytest.mark.parametrize("tag,dtype", [("bf16", torch.bfloat16), ("fp32", torch.float32)])
 def test_forward_matches_reference(name, tag, dtype):
     g = load(f"forward_{name}.npz")
@@ -65,7 +65,8 @@ def test_forward_matches_reference(name, tag, dtype):
     W = O.synth_weights(cfg, dtype=dtype)
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
     tt = torch.tensor([int(g["t"][0])], dtype=torch.int64)
-    cond, uncond = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, y=y, dtype=dtype)
+    clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None          # Wan2.1 i2v: CLIP tokens (model.py:1858-1869)
+    cond, uncond = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, y=y, dtype=dtype, clip_fea=clip)
     if dtype == torch.bfloat16:
         assert torch.equal(cond, t(g["cond_bf16"])) and torch.equal(uncond, t(g["uncond_bf16"]))
     else:
@@ -80,7 +81,7 @@ def test_forward_matches_reference(name, tag, dtype):
     L = f * (h // 2) * (w // 2)
     hid = torch.randn(1, L, cfg.dim, generator=gen).to(dtype)
     e0 = (0.5 * torch.randn(1, 6, cfg.dim, generator=gen)).to(dtype)
-    cemb = (0.5 * torch.randn(1, 512, cfg.dim, generator=gen)).to(dtype)
+    cemb = (0.5 * torch.randn(1, 512 + (O.CLIP_TOKENS if cfg.model_type == "i2v" else 0), cfg.dim, generator=gen)).to(dtype)
     cos, sin = O.rope_tables((f, h // 2, w // 2))
     bo = O.block_forward(hid, e0, cemb, cos, sin, W, 0, cfg)
     if dtype == torch.bfloat16:

@@ -114,6 +114,8 @@ struct Attn {
 struct Layer {
   const bf16_t* mod = nullptr;
   Attn self, cross;
+  Lin kimg, vimg;                 // Wan2.1 i2v: WanI2VCrossAttention.k_img / v_img (model.py:460-463)
+  const bf16_t* nkimg = nullptr;  //             norm_k_img
   const bf16_t* n3w = nullptr;
   const bf16_t* n3b = nullptr;
   Lin f0, f2;
@@ -130,7 +132,15 @@ struct wan_ctx {
   const float* head_mod = nullptr;
   const float* head_w = nullptr;
   const float* head_b = nullptr;
+  // Wan2.1 i2v (model_type 'i2v'): img_emb = MLPProj(1280, dim) (model.py:868-889) and the projected CLIP tokens
+  bool has_img = false;
+  const bf16_t *ie_ln0w = nullptr, *ie_ln0b = nullptr, *ie_ln4w = nullptr, *ie_ln4b = nullptr;
+  Lin ie1, ie3;
+  bf16_t* clip_ctx = nullptr;   // [257, dim], owned; filled by wan_dit_set_clip
+  bf16_t* clip_tmp = nullptr;   // 2 x [257, 1280] scratch, owned
+  bool clip_set = false;
 };
+constexpr int CLIP_TOK = 257, CLIP_DIM = 1280, CLIP_LDV = 320;
 
 extern "C" int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out) {
   WAN_REQUIRE(cfg && out, "wan_dit_create: null argument");
@@ -146,7 +156,13 @@ extern "C" int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out) {
   *out = c;
   return 0;
 }
-extern "C" void wan_dit_destroy(wan_ctx* ctx) { delete ctx; }
+extern "C" void wan_dit_destroy(wan_ctx* ctx) {
+  if (ctx) {
+    if (ctx->clip_ctx) (void)hipFree(ctx->clip_ctx);
+    if (ctx->clip_tmp) (void)hipFree(ctx->clip_tmp);
+  }
+  delete ctx;
+}
 
 extern "C" int wan_dit_set_weight(wan_ctx* ctx, const char* name, const void* ptr, int dtype, int64_t numel) {
   WAN_REQUIRE(ctx && name && ptr, "wan_dit_set_weight: null argument");
@@ -220,6 +236,23 @@ static int resolve(wan_ctx* c) {
     if (int rc = get_lin(c, L.f0, p + "ffn.0", f, d)) return rc;
     if (int rc = get_lin(c, L.f2, p + "ffn.2", d, f)) return rc;
   }
+  // Wan2.1 i2v checkpoints carry the CLIP branch (img_emb + per-block k_img / v_img / norm_k_img)
+  c->has_img = c->weights.count("img_emb.proj.1.weight") != 0;
+  if (c->has_img) {
+    GETB(c->ie_ln0w, "img_emb.proj.0.weight", CLIP_DIM);
+    GETB(c->ie_ln0b, "img_emb.proj.0.bias", CLIP_DIM);
+    if (int rc = get_lin(c, c->ie1, "img_emb.proj.1", CLIP_DIM, CLIP_DIM)) return rc;
+    if (int rc = get_lin(c, c->ie3, "img_emb.proj.3", d, CLIP_DIM)) return rc;
+    GETB(c->ie_ln4w, "img_emb.proj.4.weight", d);
+    GETB(c->ie_ln4b, "img_emb.proj.4.bias", d);
+    for (int i = 0; i < g.num_layers; ++i) {
+      Layer& L = c->layers[i];
+      const std::string ap = "blocks." + std::to_string(i) + ".cross_attn.";
+      if (int rc = get_lin(c, L.kimg, ap + "k_img", d, d)) return rc;
+      if (int rc = get_lin(c, L.vimg, ap + "v_img", d, d)) return rc;
+      GETB(L.nkimg, ap + "norm_k_img.weight", d);
+    }
+  }
   c->resolved = true;
   return 0;
 }
@@ -238,7 +271,7 @@ struct Carve {
 };
 
 struct Bufs {
-  bf16_t *x, *xm, *q, *k, *vt, *h, *ctx_h, *ctx_e, *ck, *cvt, *sinus, *e_h, *e, *e_s, *e0, *kfull, *vtfull;
+  bf16_t *x, *xm, *q, *k, *vt, *h, *ctx_h, *ctx_e, *ck, *cvt, *sinus, *e_h, *e, *e_s, *e0, *kfull, *vtfull, *ckimg, *cvtimg;
   int64_t Lp;
 };
 
@@ -263,6 +296,8 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.e = c.take<bf16_t>(d);
   t.e_s = c.take<bf16_t>(d);
   t.e0 = c.take<bf16_t>(6 * d);
+  t.ckimg = c.take<bf16_t>((int64_t)CLIP_TOK * d);      // i2v CLIP branch: K_img [257, d] and V_img^T [d, 320] (3.3 + 3.3 MB at 14B)
+  t.cvtimg = c.take<bf16_t>((int64_t)d * CLIP_LDV);
   if (world > 1) {
     t.kfull = c.take<bf16_t>((int64_t)world * rows * d);
     t.vtfull = c.take<bf16_t>((int64_t)world * S * d * Lp);
@@ -295,6 +330,28 @@ static int linear(const bf16_t* A, const Lin& l, bf16_t* C, int64_t M, int N, in
 extern "C" int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
 extern "C" int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
 
+// context_clip = img_emb(clip_fea) (model.py:1858-1859; MLPProj :868-889): LayerNorm(1280) -> Linear -> GELU(erf) -> Linear ->
+// LayerNorm(dim), eps 1e-5 (torch.nn.LayerNorm).  The CLIP features do not change during a generation, so this runs once
+// per call of wan_dit_set_clip instead of once per forward; the result stays in a buffer owned by the context.
+extern "C" int wan_dit_set_clip(wan_ctx* c, const wan_bf16* clip_fea, void* stream) {
+  WAN_REQUIRE(c && clip_fea, "wan_dit_set_clip: null argument");
+  RC(resolve(c));
+  WAN_REQUIRE(c->has_img, "wan_dit_set_clip: the loaded checkpoint has no img_emb / k_img / v_img weights (not a Wan2.1 i2v model)");
+  const int d = c->cfg.dim;
+  if (!c->clip_ctx) WAN_CHECK_HIP(hipMalloc((void**)&c->clip_ctx, (size_t)CLIP_TOK * d * 2));
+  if (!c->clip_tmp) WAN_CHECK_HIP(hipMalloc((void**)&c->clip_tmp, (size_t)2 * CLIP_TOK * CLIP_DIM * 2 + (size_t)CLIP_TOK * d * 2));
+  bf16_t* t1 = c->clip_tmp;
+  bf16_t* t2 = t1 + (int64_t)CLIP_TOK * CLIP_DIM;
+  bf16_t* t3 = t2 + (int64_t)CLIP_TOK * CLIP_DIM;
+  RC(wan_ln_affine(clip_fea, t1, c->ie_ln0w, c->ie_ln0b, CLIP_TOK, CLIP_DIM, 1e-5f, stream));
+  RC(linear(t1, c->ie1, t2, CLIP_TOK, CLIP_DIM, CLIP_DIM, WAN_EPI_NONE, stream));
+  RC(wan_act_bf16(t2, t2, (int64_t)CLIP_TOK * CLIP_DIM, 2, stream));
+  RC(linear(t2, c->ie3, t3, CLIP_TOK, d, CLIP_DIM, WAN_EPI_NONE, stream));
+  RC(wan_ln_affine(t3, c->clip_ctx, c->ie_ln4w, c->ie_ln4b, CLIP_TOK, d, 1e-5f, stream));
+  c->clip_set = true;
+  return 0;
+}
+
 // should_calc / residual: the step-skipping caches of the reference (TeaCache / MagCache, model.py:1914-2064).  Stream s
 // with residual[s] != NULL either runs the block chain and leaves residual[s] = x_after_blocks - x_after_patch_embed
 // (should_calc[s] != 0), or skips the chain and adds the stored residual to its freshly embedded tokens.  The decision is
@@ -320,6 +377,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
                       (world == 1 || (sp->gather_begin && sp->gather_wait))),
               "wan_dit_forward: inconsistent sequence-parallel info");
   WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
+  WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
   Bufs b;
   const int64_t need = carve_all(g, S, Ll, world, workspace, &b);
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
@@ -331,6 +389,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
 
   // V^T padding columns must be finite for the PV MFMA (P = 0 there)
   WAN_CHECK_HIP(hipMemsetAsync(b.vt, 0, (size_t)S * d * Lp * 2, st));
+  if (c->has_img) WAN_CHECK_HIP(hipMemsetAsync(b.cvtimg, 0, (size_t)d * CLIP_LDV * 2, st));
 
   // ---- embeddings (model.py:1631,1731 ; :1815-1818 ; :1856) -----------------------------------------
   for (int s = 0; s < S; ++s)
@@ -373,8 +432,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   auto run_blocks = [&](const int s0, const int Sn) -> int {
   const int S = Sn;
   const int64_t rows = (int64_t)Sn * Ll, rpb = rows;
-  struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull; } b2 = {
-      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull};
+  struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; } b2 = {
+      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg};
   auto& b = b2;
   for (int i = 0; i < g.num_layers; ++i) {
     if (poll && poll(poll_user, i)) return 1;  // model.py:1995-1998
@@ -419,9 +478,20 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     for (int s = 0; s < S; ++s)
       RC(wan_gemm_bf16(b.ctx_e + (int64_t)s * TL * d, d, Lw.cross.v.w, Lw.cross.v.b, b.cvt + (int64_t)s * d * TL, TL, TL,
                        d, d, WAN_EPI_TRANSPOSED, nullptr, nullptr, nullptr, 0, -1, 1, stream));
-    {
+    if (!c->has_img) {
       ProfScope ps(PROF_CROSS_ATTN, st);
       RC(wan_attention(b.q, b.ck, b.cvt, b.q, S, S, Ll, TL, TL, nh, stream));
+    } else {
+      // WanI2VCrossAttention (model.py:466-499): the same q attends the text tokens and the 257 CLIP tokens (K_img / V_img
+      // shared by every stream), the two bf16 results are added, then o.  xm is free here: it takes the text result.
+      RC(linear(c->clip_ctx, Lw.kimg, b.ckimg, CLIP_TOK, d, d, WAN_EPI_NONE, stream));
+      RC(wan_rmsnorm_rope(b.ckimg, nullptr, Lw.nkimg, nullptr, nullptr, nullptr, CLIP_TOK, CLIP_TOK, 0, d, g.eps, stream));
+      RC(wan_gemm_bf16(c->clip_ctx, d, Lw.vimg.w, Lw.vimg.b, b.cvtimg, CLIP_LDV, CLIP_TOK, d, d, WAN_EPI_TRANSPOSED, nullptr,
+                       nullptr, nullptr, 0, -1, 1, stream));
+      ProfScope ps(PROF_CROSS_ATTN, st);
+      RC(wan_attention(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TL, TL, nh, stream));
+      RC(wan_attention(b.q, b.ckimg, b.cvtimg, b.q, S, 1, Ll, CLIP_TOK, CLIP_LDV, nh, stream));
+      RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }
     RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb));
     // -- FFN (model.py:686-711) --

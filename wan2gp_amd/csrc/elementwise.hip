@@ -235,6 +235,7 @@ __global__ void act_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
     const float v = bf2f(x[i]);
     float r = v;
     if (act == 1) r = v / (1.0f + expf(-v));  // SiLU
+    else if (act == 2) r = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // GELU (erf), torch.nn.GELU() of MLPProj (model.py:875)
     y[i] = f2bf(r);
   }
 }

@@ -66,6 +66,7 @@ SIGNATURES = {
     "wan_vae22_to_video": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_vae22_avgdown_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_vae22_dupup_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_dit_set_clip": (c_int, [c_void_p, c_void_p, c_void_p]),
     "wan_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_sub_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_lora_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p]),

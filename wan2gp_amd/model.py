@@ -42,8 +42,9 @@ class WanModelHIP:
                  **unused):
         if tuple(patch_size) != (1, 2, 2):
             raise NotImplementedError("only patch_size (1,2,2) (all Wan 2.1/2.2 14B/1.3B models)")
-        if model_type not in ("t2v", "i2v2_2", "ti2v2_2"):
-            raise NotImplementedError(f"model_type {model_type!r}: only the t2v_cross_attn types t2v / i2v2_2 / ti2v2_2 (model.py:1149)")
+        if model_type not in ("t2v", "i2v2_2", "ti2v2_2", "i2v"):
+            raise NotImplementedError(f"model_type {model_type!r}: t2v / i2v2_2 / ti2v2_2 (t2v_cross_attn) and i2v (Wan2.1 "
+                                      "i2v_cross_attn with CLIP tokens) are implemented (model.py:1149)")
         self.model_type, self.dim, self.ffn_dim, self.num_heads, self.num_layers = model_type, dim, ffn_dim, num_heads, num_layers
         self.in_dim, self.out_dim, self.text_dim, self.freq_dim, self.text_len, self.eps = in_dim, out_dim, text_dim, freq_dim, text_len, eps
         self.patch_size = tuple(patch_size)
@@ -119,8 +120,19 @@ class WanModelHIP:
         return self._ws
 
     def forward(self, x, t, context, y=None, freqs=None, pipeline=None, current_step_no=0, real_step_no=0, x_id=0,
-                max_steps=0, callback=None, **variant_kwargs):
+                max_steps=0, callback=None, clip_fea=None, **variant_kwargs):
         active = {k: v for k, v in variant_kwargs.items() if not _is_default(k, v)}
+        if self.model_type == "i2v":
+            if clip_fea is None or y is None:
+                raise _L.WanHipError("model_type 'i2v' needs clip_fea [1,257,1280] and y (model.py:1547)")
+            cf = clip_fea.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            if cf.numel() != 257 * 1280:
+                raise _L.WanHipError(f"clip_fea must be [1,257,1280], got {list(clip_fea.shape)}")
+            # img_emb(clip_fea): three small GEMMs + two LayerNorms on 257 tokens -- redone per call like the reference does
+            # (a pointer-keyed cache would be fooled by the allocator handing the same address to a different tensor)
+            check(_L.load().wan_dit_set_clip(self._ctx, ptr(cf), stream_ptr()), "wan_dit_set_clip")
+        elif clip_fea is not None:
+            active["clip_fea"] = clip_fea
         if active:
             if self.reference_module is not None:
                 return self.reference_module(x, t, context, y=y, freqs=freqs, pipeline=pipeline,
