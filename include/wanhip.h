@@ -195,6 +195,8 @@ int wan_mul_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n,
  * (model.py:1967-1971: x += previous_residual; :2044-2062: previous_residual = x - ori). */
 int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
 int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
+/* out = bf16(x + alpha * y) (torch's x.add_(y, alpha=alpha) on bf16: the scaled VACE hint, model.py:713-719); x may alias out */
+int wan_axpy_bf16(const wan_bf16* x, const wan_bf16* y, float alpha, wan_bf16* out, int64_t n, void* stream);
 
 /* ---- checkpoint load: LoRA merge + qint8 dequantisation -------------------------- */
 /* The reference hands LoRA files to mmgp.offload.load_loras_into_model / activate_loras (wgp.py:6922-6931,
@@ -272,6 +274,37 @@ int wan_dit_forward(wan_ctx* ctx, int S, const float* const* x, float t, const w
                     const float* y, const float* cos, const float* sin, float* const* outs, int F,
                     int H, int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp,
                     wan_poll_fn poll, void* poll_user, void* stream);
+/* Every argument of a forward in one struct (the positional entry points above/below are wrappers around it):
+ * wan_dit_forward's arguments, the step-skipping pair of wan_dit_forward_skip, and VACE (model.py:790-828, :1905-1912):
+ * vace_context [vace_in_dim, F, H, W] fp32 holding bf16-representable values (the reference feeds the bf16 conv
+ * vace_patch_embedding with u.to(weight.dtype)), vace_scale = vace_context_scale[0]; NULL = no VACE. */
+typedef struct {
+  int S;
+  const float* const* x;
+  float t;
+  const wan_bf16* const* context;
+  const float* y;
+  const float* cos;
+  const float* sin;
+  float* const* outs;
+  int F, H, W;
+  void* workspace;
+  int64_t workspace_bytes;
+  const wan_sp_info* sp;
+  wan_poll_fn poll;
+  void* poll_user;
+  const int* should_calc;
+  wan_bf16* const* residual;
+  const float* vace_context;
+  float vace_scale;
+} wan_dit_args;
+int wan_dit_forward_ex(wan_ctx* ctx, const wan_dit_args* args, void* stream);
+/* VACE: main-block indices that carry a context block (WanModel(vace_layers=...), model.py:1178-1183; 0,5,...,35 for the
+ * 14B VACE model).  Weights: vace_blocks.N.* (a block's keys + before_proj for N = 0 + after_proj), and
+ * vace_patch_embedding.weight / .bias registered as fp32 copies of the bf16 parameters.  Call before the first forward /
+ * wan_dit_workspace_bytes. */
+int wan_dit_set_vace_layers(wan_ctx* ctx, const int* layers, int n);
+
 /* Wan2.1 i2v (model_type 'i2v': checkpoints with img_emb.* and cross_attn.k_img / v_img / norm_k_img): projects the CLIP
  * vision features clip_fea [257, 1280] bf16 through img_emb (MLPProj, model.py:868-889, :1858-1859) and keeps the 257 image
  * tokens for the k_img / v_img branch of every block's cross-attention (WanI2VCrossAttention, model.py:448-499).  Must be

@@ -32,7 +32,8 @@ def build_ref_model(ns, cfg: O.WanConfig, W, dtype):
     reference's dtype locks (model.py:1330-1371): patch_embedding + head fp32."""
     m = ns.M.WanModel(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads,
                       num_layers=cfg.num_layers, in_dim=cfg.in_dim, out_dim=cfg.out_dim, text_dim=cfg.text_dim,
-                      freq_dim=cfg.freq_dim, eps=cfg.eps)
+                      freq_dim=cfg.freq_dim, eps=cfg.eps,
+                      **({} if cfg.vace_layers is None else {"vace_layers": list(cfg.vace_layers), "vace_in_dim": cfg.vace_in_dim}))
     sd = {k: v.clone() for k, v in W.items()}
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected
@@ -47,10 +48,12 @@ def build_ref_model(ns, cfg: O.WanConfig, W, dtype):
     return m
 
 
-def ref_forward(ns, m, x_list, t, ctx_list, y=None, clip_fea=None):
+def ref_forward(ns, m, x_list, t, ctx_list, y=None, clip_fea=None, vace=None, vace_scale=1.0):
     grid = x_list[0].shape[2:]
     freqs = ns.P.get_rotary_pos_embed(grid)
     kw = {} if clip_fea is None else {"clip_fea": clip_fea.clone()}
+    if vace is not None:
+        kw.update({"vace_context": [vace.clone()], "vace_context_scale": [vace_scale]})
     with torch.no_grad():
         return m([x.clone() for x in x_list], t=t, context=[c.clone() for c in ctx_list], y=y, freqs=freqs,
                  pipeline=types.SimpleNamespace(_interrupt=False), **kw)
@@ -90,6 +93,7 @@ def gen_forward(ns, name, f, h, w, tval):
     out = {"shape": np.array([f, h, w]), "t": np.array([tval])}
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
     clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None
+    vace = O.synth_vace_context(cfg, f, h, w) if cfg.vace_layers is not None else None
     t = torch.tensor([tval], dtype=torch.int64)
     # NOTE: only the reference's real bf16 plan is a valid golden.  Run "fp32 everywhere" the
     # reference's WanRMSNorm aliases its input (`y = x.float()` is x itself for fp32, then
@@ -99,8 +103,11 @@ def gen_forward(ns, name, f, h, w, tval):
         W = O.synth_weights(cfg, dtype=dtype)
         m = build_ref_model(ns, cfg, W, dtype)
         cdt = dtype
-        r = ref_forward(ns, m, [lat, lat], t, [ctx.to(cdt), ctx_null.to(cdt)], y=y, clip_fea=clip)
+        r = ref_forward(ns, m, [lat, lat], t, [ctx.to(cdt), ctx_null.to(cdt)], y=y, clip_fea=clip, vace=vace)
         out[f"cond_{tag}"], out[f"uncond_{tag}"] = f32(r[0]), f32(r[1])
+        if vace is not None:                                    # a second run with a fractional context scale (x.add_(hint, alpha))
+            r = ref_forward(ns, m, [lat, lat], t, [ctx.to(cdt), ctx_null.to(cdt)], y=y, vace=vace, vace_scale=0.6)
+            out[f"cond_s06_{tag}"], out[f"uncond_s06_{tag}"] = f32(r[0]), f32(r[1])
         # one block in isolation (block 0) on a seeded hidden state
         g = torch.Generator().manual_seed(11)
         L = f * (h // 2) * (w // 2)
@@ -222,6 +229,7 @@ def main():
         gen_forward(ns, "tiny_i2v", 2, 8, 8, 912)
         gen_forward(ns, "tiny_ti2v", 2, 6, 10, 455)
         gen_forward(ns, "tiny_i2v21", 2, 8, 8, 731)
+        gen_forward(ns, "tiny_vace", 2, 8, 8, 588)
     if "sched" in which:
         gen_sched(ns)
     if "sched2" in which:

@@ -48,6 +48,8 @@ class WanConfig:
     eps: float = 1e-6
     patch_size: Tuple[int, int, int] = (1, 2, 2)
     model_type: str = "t2v"
+    vace_layers: Optional[Tuple[int, ...]] = None   # VACE: main-block indices that carry a context block (model.py:1178-1206)
+    vace_in_dim: int = 96
 
     @property
     def head_dim(self):
@@ -68,6 +70,9 @@ CONFIGS = {
     # Wan2.1 i2v: CLIP image tokens through img_emb + the k_img / v_img cross-attention branch (model.py:448-499, :868-889)
     "i2v_14B": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, model_type="i2v"),
     "tiny_i2v21": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, in_dim=36, model_type="i2v"),
+    # VACE (Wan2.1 VACE 14B: vace_layers 0,5,...,35; 1.3B: every second block): context blocks feeding hints into the main blocks
+    "vace_14B": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, vace_layers=tuple(range(0, 40, 5))),
+    "tiny_vace": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=3, vace_layers=(0, 2)),
 }
 CLIP_TOKENS, CLIP_DIM = 257, 1280
 
@@ -100,6 +105,22 @@ def param_shapes(cfg: WanConfig) -> Dict[str, Tuple[int, ...]]:
         p[b + "norm3.weight"] = (d,); p[b + "norm3.bias"] = (d,)
         p[b + "ffn.0.weight"] = (f, d); p[b + "ffn.0.bias"] = (f,)
         p[b + "ffn.2.weight"] = (d, f); p[b + "ffn.2.bias"] = (d,)
+    if cfg.vace_layers is not None:                            # VaceWanAttentionBlock (:790-828), vace_patch_embedding (:1203-1206)
+        for n in range(len(cfg.vace_layers)):
+            b = f"vace_blocks.{n}."
+            p[b + "modulation"] = (1, 6, d)
+            for a in ("self_attn", "cross_attn"):
+                for l in ("q", "k", "v", "o"):
+                    p[b + f"{a}.{l}.weight"] = (d, d); p[b + f"{a}.{l}.bias"] = (d,)
+                p[b + f"{a}.norm_q.weight"] = (d,); p[b + f"{a}.norm_k.weight"] = (d,)
+            p[b + "norm3.weight"] = (d,); p[b + "norm3.bias"] = (d,)
+            p[b + "ffn.0.weight"] = (f, d); p[b + "ffn.0.bias"] = (f,)
+            p[b + "ffn.2.weight"] = (d, f); p[b + "ffn.2.bias"] = (d,)
+            if n == 0:
+                p[b + "before_proj.weight"] = (d, d); p[b + "before_proj.bias"] = (d,)
+            p[b + "after_proj.weight"] = (d, d); p[b + "after_proj.bias"] = (d,)
+        p["vace_patch_embedding.weight"] = (d, cfg.vace_in_dim, *cfg.patch_size)
+        p["vace_patch_embedding.bias"] = (d,)
     if cfg.model_type == "i2v":                                # WanI2VCrossAttention (:448-464) + MLPProj (:868-876)
         for i in range(cfg.num_layers):
             b = f"blocks.{i}.cross_attn."
@@ -297,11 +318,11 @@ def img_emb(clip_fea, W):
     return F.layer_norm(x, (x.shape[-1],), W["img_emb.proj.4.weight"], W["img_emb.proj.4.bias"], 1e-5)
 
 
-def block_forward(x, e0, ctx, cos, sin, W, i: int, cfg: WanConfig, exact: bool = False):
+def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = False):
     """WanAttentionBlock.forward, t2v path (model.py:631-711).  x [B,L,dim] in the
     residual dtype, e0 [1,6,dim] (latent_frames = e.shape[0] = 1, so the reshape at
-    :635/:658/:688 is a no-op broadcast)."""
-    p = f"blocks.{i}."
+    :635/:658/:688 is a no-op broadcast).  i: block index, or a key prefix (VACE context blocks)."""
+    p = i if isinstance(i, str) else f"blocks.{i}."
     e = (W[p + "modulation"] + e0).chunk(6, dim=1)            # :632   6 x [1,1,dim]
     x_mod = layer_norm(x, cfg.eps)                             # :634
     x_mod = x_mod * (1 + e[1]); x_mod = x_mod + e[0]           # :636-637 (two roundings)
@@ -318,6 +339,16 @@ def block_forward(x, e0, ctx, cos, sin, W, i: int, cfg: WanConfig, exact: bool =
     y = torch.cat(outs, 0).view(shp)
     x = torch.addcmul(x, y, e[5])                              # :710
     return x
+
+
+def vace_block_forward(c, x, e0, ctx, cos, sin, W, n: int, cfg: WanConfig, exact: bool = False):
+    """VaceWanAttentionBlock.forward (model.py:816-828) as called from the main block (:617-629): returns (c, c_skip)."""
+    p = f"vace_blocks.{n}."
+    if n == 0:
+        c = _linear(c, W, p + "before_proj")
+        c = c + x                                            # c += x
+    c = block_forward(c, e0, ctx, cos, sin, W, p, cfg, exact)
+    return c, _linear(c, W, p + "after_proj")
 
 
 # --------------------------------------------------------------------------------------
@@ -351,7 +382,8 @@ def unpatchify(x, grid, cfg: WanConfig):
 # --------------------------------------------------------------------------------------
 def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[torch.Tensor],
                 W, cfg: WanConfig, y: Optional[torch.Tensor] = None, freqs=None,
-                dtype=torch.bfloat16, exact: bool = False, return_hidden: bool = False, clip_fea: Optional[torch.Tensor] = None):
+                dtype=torch.bfloat16, exact: bool = False, return_hidden: bool = False, clip_fea: Optional[torch.Tensor] = None,
+                vace_context: Optional[torch.Tensor] = None, vace_scale: float = 1.0):
     """x_list: S tensors [B,16,F,H,W] fp32; t [1]; context_list: S tensors [B,512,4096].
     Returns S fp32 tensors [B,16,F,H,W] (model.py:2093-2097)."""
     hs = []
@@ -370,9 +402,20 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
     if clip_fea is not None:                                # model.py:1858-1869: [clip tokens ; text tokens]
         cc = img_emb(clip_fea.to(dtype), W)
         ctxs = [torch.cat([cc, c], dim=1) for c in ctxs]
+    hints = None
+    if vace_context is not None:                            # model.py:1908-1912: one hint stream per x, all from the same embedding
+        w = W["vace_patch_embedding.weight"]
+        c0 = F.conv3d(vace_context.to(w.dtype).unsqueeze(0), w, W["vace_patch_embedding.bias"], stride=cfg.patch_size)
+        c0 = c0.flatten(2).transpose(1, 2)
+        hints = [c0.clone() for _ in hs]
     for i in range(cfg.num_layers):                         # model.py:1993-2036
         for s in range(len(hs)):
+            skip = None
+            if hints is not None and i in cfg.vace_layers and vace_scale != 0:
+                hints[s], skip = vace_block_forward(hints[s], hs[s], e0, ctxs[s], cos, sin, W, cfg.vace_layers.index(i), cfg, exact)
             hs[s] = block_forward(hs[s], e0, ctxs[s], cos, sin, W, i, cfg, exact)
+            if skip is not None:                            # model.py:713-719: x.add_(hint[, alpha=scale])
+                hs[s] = hs[s] + skip if vace_scale == 1 else torch.add(hs[s], skip, alpha=vace_scale)
     if return_hidden:
         return hs
     outs = []
@@ -647,3 +690,9 @@ def synth_clip_fea(seed: int = 9):
     """CLIP ViT-H penultimate features as `clip_fea` [1, 257, 1280] bf16 (any2video.py feeds clip.visual output)."""
     g = torch.Generator().manual_seed(seed)
     return torch.randn(1, CLIP_TOKENS, CLIP_DIM, generator=g).to(torch.bfloat16)
+
+
+def synth_vace_context(cfg: WanConfig, f: int, h: int, w: int, seed: int = 13):
+    """[vace_in_dim, F, H, W]: the masked-video / mask latents VACE conditions on (any2video.py vace_encode_*)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(cfg.vace_in_dim, f, h, w, generator=g)

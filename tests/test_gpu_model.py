@@ -29,7 +29,8 @@ def build(cfg, seed=1234):
     from wan2gp_amd.model import WanModelHIP
     W = O.synth_weights(cfg, seed=seed)
     m = WanModelHIP(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads,
-                    num_layers=cfg.num_layers, in_dim=cfg.in_dim, out_dim=cfg.out_dim)
+                    num_layers=cfg.num_layers, in_dim=cfg.in_dim, out_dim=cfg.out_dim,
+                    **({} if cfg.vace_layers is None else {"vace_layers": list(cfg.vace_layers), "vace_in_dim": cfg.vace_in_dim}))
     m.load_state_dict(W)
     return m, W
 
@@ -38,7 +39,7 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21", "tiny_vace"])
 def test_forward_vs_reference_golden(name):
     g = load(f"forward_{name}.npz")
     f, h, w = [int(v) for v in g["shape"]]
@@ -49,11 +50,14 @@ def test_forward_vs_reference_golden(name):
     xs = [lat.cuda(), lat.cuda()]
     clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None     # Wan2.1 i2v: CLIP tokens + k_img / v_img branch
     kw = {} if clip is None else {"clip_fea": clip.cuda()}
+    vace = O.synth_vace_context(cfg, f, h, w) if cfg.vace_layers is not None else None     # VACE context blocks
+    if vace is not None:
+        kw.update({"vace_context": [vace.cuda()], "vace_context_scale": [1.0]})
     outs = m(xs, t=t, context=[ctx.cuda(), ctx_null.cuda()], y=None if y is None else y.cuda(), **kw)
     assert xs == []                                                    # list consumed (model.py:1558-1559)
     W32 = O.synth_weights(cfg, dtype=torch.float32)
     anchor = O.dit_forward([lat, lat], t, [ctx.float(), ctx_null.float()], W32, cfg, y=y, dtype=torch.float32, exact=True,
-                           clip_fea=None if clip is None else clip.float())
+                           clip_fea=None if clip is None else clip.float(), vace_context=vace)
     for o, key, a in zip(outs, ("cond_bf16", "uncond_bf16"), anchor):
         assert o.dtype == torch.float32 and tuple(o.shape) == (1, cfg.out_dim, f, h, w)
         ref = torch.from_numpy(g[key])
@@ -215,3 +219,25 @@ def test_i2v21_requires_clip_features_and_changes_with_them():
     lat2, ctx2, _, _ = O.synth_inputs(cfg2, 2, 8, 8)
     with pytest.raises(NotImplementedError):
         m2([lat2.cuda()], t=t, context=[ctx2.cuda()], clip_fea=O.synth_clip_fea(1).cuda())      # t2v model: variant kwarg
+
+
+def test_vace_scale_and_plain_paths():
+    """vace_context_scale 0.6 (x.add_(hint, alpha)) against the reference golden; scale 0 and no context equal the plain
+    forward of the same weights; a model without VACE blocks rejects the keyword."""
+    g = load("forward_tiny_vace.npz")
+    f, h, w = [int(v) for v in g["shape"]]
+    cfg = O.make_config("tiny_vace")
+    m, W = build(cfg)
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    t = torch.tensor([int(g["t"][0])], dtype=torch.int64)
+    vace = O.synth_vace_context(cfg, f, h, w)
+    run = lambda **kw: m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()], **kw)
+    o6 = run(vace_context=[vace.cuda()], vace_context_scale=[0.6])
+    assert rel(o6[0].cpu(), torch.from_numpy(g["cond_s06_bf16"])) <= 2.5e-2 and rel(o6[1].cpu(), torch.from_numpy(g["uncond_s06_bf16"])) <= 2.5e-2
+    o1 = run(vace_context=[vace.cuda()])
+    assert rel(o1[0].cpu(), torch.from_numpy(g["cond_bf16"])) <= 2.5e-2 and rel(o6[0].cpu(), o1[0].cpu()) > 1e-3
+    plain, zero = run(), run(vace_context=[vace.cuda()], vace_context_scale=[0.0])
+    assert torch.equal(plain[0], zero[0]) and torch.equal(plain[1], zero[1]) and rel(plain[0].cpu(), o1[0].cpu()) > 1e-3
+    m2, _ = build(O.make_config("tiny"))
+    with pytest.raises(NotImplementedError):
+        m2([lat.cuda()], t=t, context=[ctx.cuda()], vace_context=[vace.cuda()])

@@ -56,7 +56,7 @@ def test_rmsnorm_rope_ln_sdpa_bit_exact():
     assert (ex - t(g["sdpa_bf16"])).abs().max() < 2e-2
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21", "tiny_vace"])
 @pytest.mark.parametrize("tag,dtype", [("bf16", torch.bfloat16), ("fp32", torch.float32)])
 def test_forward_matches_reference(name, tag, dtype):
     g = load(f"forward_{name}.npz")
@@ -66,7 +66,13 @@ def test_forward_matches_reference(name, tag, dtype):
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
     tt = torch.tensor([int(g["t"][0])], dtype=torch.int64)
     clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None          # Wan2.1 i2v: CLIP tokens (model.py:1858-1869)
-    cond, uncond = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, y=y, dtype=dtype, clip_fea=clip)
+    vace = O.synth_vace_context(cfg, f, h, w) if cfg.vace_layers is not None else None     # VACE context blocks (model.py:790-828)
+    cond, uncond = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, y=y, dtype=dtype, clip_fea=clip,
+                                 vace_context=vace)
+    if vace is not None and dtype == torch.bfloat16:                 # fractional context scale: x.add_(hint, alpha=0.6)
+        c6, u6 = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, dtype=dtype, vace_context=vace, vace_scale=0.6)
+        assert torch.equal(c6, t(g["cond_s06_bf16"])) and torch.equal(u6, t(g["uncond_s06_bf16"]))
+        assert not torch.equal(c6, cond)
     if dtype == torch.bfloat16:
         assert torch.equal(cond, t(g["cond_bf16"])) and torch.equal(uncond, t(g["uncond_bf16"]))
     else:

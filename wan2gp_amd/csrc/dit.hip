@@ -116,6 +116,7 @@ struct Layer {
   Attn self, cross;
   Lin kimg, vimg;                 // Wan2.1 i2v: WanI2VCrossAttention.k_img / v_img (model.py:460-463)
   const bf16_t* nkimg = nullptr;  //             norm_k_img
+  Lin before, after;              // VACE context block: before_proj (block 0 only) / after_proj (model.py:805-812)
   const bf16_t* n3w = nullptr;
   const bf16_t* n3b = nullptr;
   Lin f0, f2;
@@ -136,6 +137,13 @@ struct wan_ctx {
   bool has_img = false;
   const bf16_t *ie_ln0w = nullptr, *ie_ln0b = nullptr, *ie_ln4w = nullptr, *ie_ln4b = nullptr;
   Lin ie1, ie3;
+  // VACE (model.py:790-828, :1178-1206): context blocks attached to the main blocks listed in vace_layers
+  std::vector<int> vace_layers;   // main-block index of context block n
+  std::vector<int> vace_at;       // main-block index -> n or -1
+  std::vector<Layer> vlayers;
+  const float* vpe_w = nullptr;   // vace_patch_embedding as fp32 copies of the bf16 parameters
+  const float* vpe_b = nullptr;
+  int vace_in_dim = 0;
   bf16_t* clip_ctx = nullptr;   // [257, dim], owned; filled by wan_dit_set_clip
   bf16_t* clip_tmp = nullptr;   // 2 x [257, 1280] scratch, owned
   bool clip_set = false;
@@ -202,6 +210,26 @@ static int get_lin(wan_ctx* c, Lin& l, const std::string& prefix, int64_t out_f,
   return 0;
 }
 
+static int load_layer(wan_ctx* c, Layer& L, const std::string& p) {
+  const int64_t d = c->cfg.dim, f = c->cfg.ffn_dim;
+  GETB(L.mod, p + "modulation", 6 * d);
+  for (int a = 0; a < 2; ++a) {
+    Attn& A = a == 0 ? L.self : L.cross;
+    const std::string ap = p + (a == 0 ? "self_attn." : "cross_attn.");
+    if (int rc = get_lin(c, A.q, ap + "q", d, d)) return rc;
+    if (int rc = get_lin(c, A.k, ap + "k", d, d)) return rc;
+    if (int rc = get_lin(c, A.v, ap + "v", d, d)) return rc;
+    if (int rc = get_lin(c, A.o, ap + "o", d, d)) return rc;
+    GETB(A.nq, ap + "norm_q.weight", d);
+    GETB(A.nk, ap + "norm_k.weight", d);
+  }
+  GETB(L.n3w, p + "norm3.weight", d);
+  GETB(L.n3b, p + "norm3.bias", d);
+  if (int rc = get_lin(c, L.f0, p + "ffn.0", f, d)) return rc;
+  if (int rc = get_lin(c, L.f2, p + "ffn.2", d, f)) return rc;
+  return 0;
+}
+
 static int resolve(wan_ctx* c) {
   if (c->resolved) return 0;
   const wan_dit_config& g = c->cfg;
@@ -217,24 +245,26 @@ static int resolve(wan_ctx* c) {
   GETF(c->head_w, "head.head.weight", (int64_t)4 * g.out_dim * d);
   GETF(c->head_b, "head.head.bias", 4 * g.out_dim);
   c->layers.assign(g.num_layers, Layer());
-  for (int i = 0; i < g.num_layers; ++i) {
-    Layer& L = c->layers[i];
-    const std::string p = "blocks." + std::to_string(i) + ".";
-    GETB(L.mod, p + "modulation", 6 * d);
-    for (int a = 0; a < 2; ++a) {
-      Attn& A = a == 0 ? L.self : L.cross;
-      const std::string ap = p + (a == 0 ? "self_attn." : "cross_attn.");
-      if (int rc = get_lin(c, A.q, ap + "q", d, d)) return rc;
-      if (int rc = get_lin(c, A.k, ap + "k", d, d)) return rc;
-      if (int rc = get_lin(c, A.v, ap + "v", d, d)) return rc;
-      if (int rc = get_lin(c, A.o, ap + "o", d, d)) return rc;
-      GETB(A.nq, ap + "norm_q.weight", d);
-      GETB(A.nk, ap + "norm_k.weight", d);
-    }
-    GETB(L.n3w, p + "norm3.weight", d);
-    GETB(L.n3b, p + "norm3.bias", d);
-    if (int rc = get_lin(c, L.f0, p + "ffn.0", f, d)) return rc;
-    if (int rc = get_lin(c, L.f2, p + "ffn.2", d, f)) return rc;
+  for (int i = 0; i < g.num_layers; ++i)
+    if (int rc = load_layer(c, c->layers[i], "blocks." + std::to_string(i) + ".")) return rc;
+  // VACE context blocks: the same block structure under vace_blocks.N. plus the two projections
+  c->vlayers.assign(c->vace_layers.size(), Layer());
+  c->vace_at.assign(g.num_layers, -1);
+  for (size_t n = 0; n < c->vace_layers.size(); ++n) {
+    const std::string p = "vace_blocks." + std::to_string(n) + ".";
+    if (int rc = load_layer(c, c->vlayers[n], p)) return rc;
+    if (n == 0)
+      if (int rc = get_lin(c, c->vlayers[n].before, p + "before_proj", d, d)) return rc;
+    if (int rc = get_lin(c, c->vlayers[n].after, p + "after_proj", d, d)) return rc;
+    c->vace_at[c->vace_layers[n]] = (int)n;
+  }
+  if (!c->vace_layers.empty()) {
+    auto it = c->weights.find("vace_patch_embedding.weight");
+    WAN_REQUIRE(it != c->weights.end() && it->second.dtype == 1 && it->second.numel % (d * 4) == 0,
+                "VACE: 'vace_patch_embedding.weight' must be registered as fp32 [dim, vace_in_dim, 1, 2, 2]");
+    c->vace_in_dim = (int)(it->second.numel / (d * 4));
+    c->vpe_w = (const float*)it->second.ptr;
+    GETF(c->vpe_b, "vace_patch_embedding.bias", d);
   }
   // Wan2.1 i2v checkpoints carry the CLIP branch (img_emb + per-block k_img / v_img / norm_k_img)
   c->has_img = c->weights.count("img_emb.proj.1.weight") != 0;
@@ -271,11 +301,11 @@ struct Carve {
 };
 
 struct Bufs {
-  bf16_t *x, *xm, *q, *k, *vt, *h, *ctx_h, *ctx_e, *ck, *cvt, *sinus, *e_h, *e, *e_s, *e0, *kfull, *vtfull, *ckimg, *cvtimg;
+  bf16_t *x, *xm, *q, *k, *vt, *h, *ctx_h, *ctx_e, *ck, *cvt, *sinus, *e_h, *e, *e_s, *e0, *kfull, *vtfull, *ckimg, *cvtimg, *vc, *vskip;
   int64_t Lp;
 };
 
-static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b) {
+static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, bool vace = false) {
   Carve c(ws);
   const int64_t d = g.dim, rows = (int64_t)S * Ll;
   const int64_t Lp = ((Ll + 63) / 64) * 64;
@@ -298,6 +328,8 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.e0 = c.take<bf16_t>(6 * d);
   t.ckimg = c.take<bf16_t>((int64_t)CLIP_TOK * d);      // i2v CLIP branch: K_img [257, d] and V_img^T [d, 320] (3.3 + 3.3 MB at 14B)
   t.cvtimg = c.take<bf16_t>((int64_t)d * CLIP_LDV);
+  t.vc = vace ? c.take<bf16_t>(rows * d) : nullptr;      // VACE: the hint token streams and the projected hint of one block
+  t.vskip = vace ? c.take<bf16_t>(rows * d) : nullptr;
   if (world > 1) {
     t.kfull = c.take<bf16_t>((int64_t)world * rows * d);
     t.vtfull = c.take<bf16_t>((int64_t)world * S * d * Lp);
@@ -313,7 +345,7 @@ extern "C" int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int
   if (!ctx || S < 1 || seq_shards < 1) return -1;
   const int64_t L = (int64_t)F * (H / 2) * (W / 2);
   if (L % seq_shards != 0) return -1;
-  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr);
+  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, !ctx->vace_layers.empty());
 }
 
 #define RC(expr)             \
@@ -329,6 +361,7 @@ static int linear(const bf16_t* A, const Lin& l, bf16_t* C, int64_t M, int N, in
 
 extern "C" int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
 extern "C" int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
+extern "C" int wan_axpy_bf16(const wan_bf16* x, const wan_bf16* y, float alpha, wan_bf16* out, int64_t n, void* stream);
 
 // context_clip = img_emb(clip_fea) (model.py:1858-1859; MLPProj :868-889): LayerNorm(1280) -> Linear -> GELU(erf) -> Linear ->
 // LayerNorm(dim), eps 1e-5 (torch.nn.LayerNorm).  The CLIP features do not change during a generation, so this runs once
@@ -359,7 +392,8 @@ extern "C" int wan_dit_set_clip(wan_ctx* c, const wan_bf16* clip_fea, void* stre
 static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
                             const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
                             int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
-                            void* poll_user, const int* should_calc, wan_bf16* const* residual, void* stream) {
+                            void* poll_user, const int* should_calc, wan_bf16* const* residual, const float* vace_context,
+                            float vace_scale, void* stream) {
   WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
   WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
@@ -379,7 +413,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
   WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
   Bufs b;
-  const int64_t need = carve_all(g, S, Ll, world, workspace, &b);
+  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, !c->vace_layers.empty());
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
               (long long)workspace_bytes, (long long)need);
   WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
@@ -427,6 +461,17 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     else RC(wan_add_bf16(b.x + s * sn, residual[s], b.x + s * sn, sn, stream));
   }
 
+  // ---- VACE: c = vace_patch_embedding(vace_context) for every stream (model.py:1908-1912) ------------------------------------
+  const bool vace = vace_context != nullptr && vace_scale != 0.f;
+  if (vace_context != nullptr) {
+    WAN_REQUIRE(!c->vace_layers.empty(), "wan_dit_forward: vace_context given but the model has no VACE blocks (wan_dit_set_vace_layers)");
+    if (vace) {
+      RC(wan_patch_embed_range(vace_context, nullptr, c->vpe_w, c->vpe_b, b.vc, 1, c->vace_in_dim, 0, F, H, W, d, tok0, Ll, stream));
+      for (int s = 1; s < S; ++s)
+        WAN_CHECK_HIP(hipMemcpyAsync(b.vc + s * sn, b.vc, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
+    }
+  }
+
   // the block chain over streams [s0, s0 + Sn): every scratch buffer is used from its base, only the token stream and the
   // text context are offset (maximal runs of computing streams; all of them in the plain forward)
   auto run_blocks = [&](const int s0, const int Sn) -> int {
@@ -434,10 +479,12 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   const int64_t rows = (int64_t)Sn * Ll, rpb = rows;
   struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; } b2 = {
       b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg};
+  bf16_t* const x_main = b.x + s0 * sn;
+  bf16_t* vc = vace ? b.vc + s0 * sn : nullptr;      // hint streams of this run; vskip doubles as the swap buffer of before_proj
+  bf16_t* vskip = vace ? b.vskip : nullptr;
   auto& b = b2;
-  for (int i = 0; i < g.num_layers; ++i) {
-    if (poll && poll(poll_user, i)) return 1;  // model.py:1995-1998
-    const Layer& Lw = c->layers[i];
+  // one WanAttentionBlock (model.py:575-724) on the token streams at b.x, with the weights Lw
+  auto run_layer = [&](const Layer& Lw) -> int {
     // -- self attention (model.py:632-660) --
     RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
     // V^T first: under sequence parallelism its all-gather then overlaps the Q/K projections + RMSNorm/RoPE
@@ -501,6 +548,26 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(linear(b.xm, Lw.f0, b.h, rows, ffn, d, WAN_EPI_GELU_TANH, stream));
       RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb));
     }
+    return 0;
+  };
+  for (int i = 0; i < g.num_layers; ++i) {
+    if (poll && poll(poll_user, i)) return 1;  // model.py:1995-1998
+    const int n = vace ? c->vace_at[i] : -1;
+    if (n >= 0) {
+      // VaceWanAttentionBlock.forward (model.py:816-828), called at the top of main block i (:617-629): the context block
+      // runs the same layer code on the hint streams, with the main streams' e0 / text context / RoPE.
+      const Layer& Vw = c->vlayers[n];
+      if (n == 0) {  // c = before_proj(c) + x
+        RC(linear(vc, Vw.before, vskip, rows, d, d, WAN_EPI_GATE_RES, stream, x_main, nullptr, nullptr, -1, rpb));
+        bf16_t* t2 = vc; vc = vskip; vskip = t2;
+      }
+      b.x = vc;
+      RC(run_layer(Vw));
+      b.x = x_main;
+      RC(linear(vc, Vw.after, vskip, rows, d, d, WAN_EPI_NONE, stream));  // c_skip = after_proj(c)
+    }
+    RC(run_layer(c->layers[i]));
+    if (n >= 0) RC(wan_axpy_bf16(b.x, vskip, vace_scale, b.x, rows * (int64_t)d, stream));  // x.add_(hint[, alpha=scale]) (:713-719)
   }
   return 0;
   };
@@ -527,7 +594,7 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
                                int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                void* poll_user, void* stream) {
   return dit_forward_impl(c, S, x, t, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
-                          nullptr, nullptr, stream);
+                          nullptr, nullptr, nullptr, 1.0f, stream);
 }
 
 extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
@@ -535,5 +602,23 @@ extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, fl
                                     int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                     void* poll_user, const int* should_calc, wan_bf16* const* residual, void* stream) {
   return dit_forward_impl(c, S, x, t, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
-                          should_calc, residual, stream);
+                          should_calc, residual, nullptr, 1.0f, stream);
+}
+
+extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* stream) {
+  WAN_REQUIRE(c && a, "wan_dit_forward_ex: null argument");
+  return dit_forward_impl(c, a->S, a->x, a->t, a->context, a->y, a->cos, a->sin, a->outs, a->F, a->H, a->W, a->workspace,
+                          a->workspace_bytes, a->sp, a->poll, a->poll_user, a->should_calc, a->residual, a->vace_context,
+                          a->vace_scale, stream);
+}
+
+extern "C" int wan_dit_set_vace_layers(wan_ctx* c, const int* layers, int n) {
+  WAN_REQUIRE(c && (n == 0 || layers), "wan_dit_set_vace_layers: null argument");
+  WAN_REQUIRE(n >= 0 && n <= c->cfg.num_layers, "wan_dit_set_vace_layers: %d context blocks for %d layers", n, c->cfg.num_layers);
+  for (int i = 0; i < n; ++i)
+    WAN_REQUIRE(layers[i] >= 0 && layers[i] < c->cfg.num_layers && (i == 0 ? layers[0] == 0 : layers[i] > layers[i - 1]),
+                "wan_dit_set_vace_layers: layers must start at 0 and increase (model.py:1182)");
+  c->vace_layers.assign(layers, layers + n);
+  c->resolved = false;
+  return 0;
 }

@@ -113,6 +113,30 @@ extern "C" int wan_t5_attention(const wan_bf16* q, const wan_bf16* k, const wan_
   return 0;
 }
 
+// out = bf16(x + alpha * y): torch's `x.add_(y, alpha=alpha)` on bf16 tensors (fp32 product, fp32 sum, one rounding;
+// __fmul_rn / __fadd_rn keep the compiler from contracting the two into an FMA).  x and out may alias.
+__global__ void axpy_bf16_kernel(const bf16_t* x, const bf16_t* __restrict__ y, float alpha, bf16_t* o, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[8], b[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + i * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(y + i * 8), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = __fadd_rn(a[j], __fmul_rn(alpha, b[j]));
+    *reinterpret_cast<uint4*>(o + i * 8) = pack8(a);
+  }
+}
+extern "C" int wan_axpy_bf16(const wan_bf16* x, const wan_bf16* y, float alpha, wan_bf16* out, int64_t n, void* stream) {
+  WAN_REQUIRE(x && y && out, "wan_axpy_bf16: null pointer");
+  WAN_REQUIRE(n % 8 == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)out) & 15) == 0), "wan_axpy_bf16: n %% 8 and 16-byte alignment required");
+  if (n == 0) return 0;
+  const int64_t n8 = n / 8;
+  int blocks = (int)((n8 + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(axpy_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, alpha, out, n8);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int OP>
 static int binary_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream, const char* what) {
   WAN_REQUIRE(a && b && out, "%s: null pointer", what);

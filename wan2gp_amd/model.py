@@ -39,7 +39,7 @@ def _is_default(k, v):
 class WanModelHIP:
     def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
                  freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, eps=1e-6, device="cuda",
-                 **unused):
+                 vace_layers=None, vace_in_dim=None, **unused):
         if tuple(patch_size) != (1, 2, 2):
             raise NotImplementedError("only patch_size (1,2,2) (all Wan 2.1/2.2 14B/1.3B models)")
         if model_type not in ("t2v", "i2v2_2", "ti2v2_2", "i2v"):
@@ -58,6 +58,12 @@ class WanModelHIP:
         h = c_void_p()
         check(_L.load().wan_dit_create(ctypes.byref(cfg), ctypes.byref(h)), "wan_dit_create")
         self._ctx = h
+        # VACE (model.py:1178-1206): context blocks attached to the main blocks `vace_layers`
+        self.vace_layers = None if vace_layers is None else [int(v) for v in vace_layers]
+        self.vace_in_dim = (in_dim if vace_in_dim is None else vace_in_dim) if vace_layers is not None else None
+        if self.vace_layers is not None:
+            arr = (ctypes.c_int * len(self.vace_layers))(*self.vace_layers)
+            check(_L.load().wan_dit_set_vace_layers(self._ctx, arr, len(self.vace_layers)), "wan_dit_set_vace_layers")
 
     def __del__(self):
         try:
@@ -79,6 +85,13 @@ class WanModelHIP:
             if k.endswith("modulation.weight"):           # post-init form (model.py:1291-1303)
                 k = k[: -len(".weight")]
             want = torch.float32 if k.startswith(FP32_PREFIXES) else torch.bfloat16
+            if k.startswith("vace_patch_embedding."):
+                # a bf16 Conv3d in the reference (lock_layers_dtypes, model.py:1351-1355); the fp32 patch-embed kernel gets
+                # fp32 copies of the bf16 values: identical products, fp32 accumulation, one bf16 rounding of the result
+                t = v.detach().to(device=self.device, dtype=torch.bfloat16).to(torch.float32).contiguous()
+                self._weights[k] = t
+                check(lib.wan_dit_set_weight(self._ctx, k.encode(), ptr(t), 1, t.numel()), f"wan_dit_set_weight({k})")
+                continue
             t = v.detach().to(device=self.device, dtype=want).contiguous()
             self._weights[k] = t
             check(lib.wan_dit_set_weight(self._ctx, k.encode(), ptr(t), 1 if want == torch.float32 else 0, t.numel()),
@@ -120,8 +133,18 @@ class WanModelHIP:
         return self._ws
 
     def forward(self, x, t, context, y=None, freqs=None, pipeline=None, current_step_no=0, real_step_no=0, x_id=0,
-                max_steps=0, callback=None, clip_fea=None, **variant_kwargs):
+                max_steps=0, callback=None, clip_fea=None, vace_context=None, vace_context_scale=None, **variant_kwargs):
         active = {k: v for k, v in variant_kwargs.items() if not _is_default(k, v)}
+        vace_t, vace_scale = None, 1.0
+        if vace_context is not None:
+            if self.vace_layers is None:
+                active["vace_context"] = vace_context
+            else:
+                if len(vace_context) != 1:
+                    raise NotImplementedError("one VACE context per call (vace_context=[tensor]); multi-context mixing is not implemented")
+                scales = [1.0] if vace_context_scale is None else list(vace_context_scale)
+                vace_scale = float(scales[0])
+                vace_t = vace_context[0].to(device=self.device, dtype=torch.bfloat16).to(torch.float32).contiguous()   # u.to(weight.dtype)
         if self.model_type == "i2v":
             if clip_fea is None or y is None:
                 raise _L.WanHipError("model_type 'i2v' needs clip_fea [1,257,1280] and y (model.py:1547)")
@@ -188,7 +211,16 @@ class WanModelHIP:
         CP = (c_void_p * S)(*[a.data_ptr() for a in ctxs])
         OP = (c_void_p * S)(*[a.data_ptr() for a in outs])
         cache = self.cache
-        if cache is None:
+        if vace_t is not None:
+            if tuple(vace_t.shape) != (self.vace_in_dim, F, H, W):
+                raise _L.WanHipError(f"vace_context must be [{self.vace_in_dim},{F},{H},{W}], got {list(vace_t.shape)}")
+            if cache is not None:
+                raise NotImplementedError("VACE together with a step-skipping cache")
+            a = _L.DitArgs(S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws), ws.numel(),
+                           None if sp_struct is None else ctypes.cast(sp_struct, c_void_p), ctypes.cast(poll, c_void_p), None, None, None,
+                           ptr(vace_t), vace_scale)
+            rc = _L.load().wan_dit_forward_ex(self._ctx, ctypes.byref(a), stream_ptr())
+        elif cache is None:
             rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
                                            ws.numel(), sp_struct, poll, None, stream_ptr())
         else:
