@@ -233,7 +233,7 @@ static int load_layer(wan_ctx* c, Layer& L, const std::string& p) {
 static int resolve(wan_ctx* c) {
   if (c->resolved) return 0;
   const wan_dit_config& g = c->cfg;
-  const int64_t d = g.dim, f = g.ffn_dim;
+  const int64_t d = g.dim;
   GETF(c->pe_w, "patch_embedding.weight", d * g.in_dim * 4);
   GETF(c->pe_b, "patch_embedding.bias", d);
   if (int rc = get_lin(c, c->te0, "text_embedding.0", d, g.text_dim)) return rc;
@@ -440,8 +440,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   }
   RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream));
 
-  // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups
-  const int64_t rpb = rows;
+  // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups (rpb = rows in run_blocks)
 
   // Self-attention: fold softmax scale * log2(e) into q inside the fused RMSNorm+RoPE kernel (in front of q's single
   // bf16 rounding) and run the pre-scaled attention kernel.  WAN_DIT_EXACT_QSCALE=1 keeps the scale on the fp32 scores
