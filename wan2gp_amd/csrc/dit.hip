@@ -418,7 +418,6 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
               (long long)workspace_bytes, (long long)need);
   WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
   hipStream_t st = as_stream(stream);
-  const int64_t rows = (int64_t)S * Ll;
   const int64_t Lp = b.Lp;
 
   // V^T padding columns must be finite for the PV MFMA (P = 0 there)
