@@ -490,3 +490,39 @@ def test_gemm256k_ring_schedule():
         if w == "issue" and t >= 0 and u in first_read:
             span = 32 if u % 2 == 0 else 16                     # Y pieces spread over 2 k-steps, X pieces over 1
             assert first_read[u] - (t + span) >= (48 if u % 2 else 64)
+
+
+def test_gemm256k_epilogue_park_and_readback():
+    """Phase 1 of the gemm256k epilogue parks acc[yt][xt] (lane = (l31, half): row yt*32+l31, 16 columns xt*32+half*16..)
+    in the wave's LDS region with rows of 272 B; phase 2 reads 4 rows x 256 B per instruction (lane -> row 4i + lane/16,
+    16-B chunk lane%16).  Every element of the 128x128 sub-tile must be written once and read once, at the right place,
+    and a ds_write_b128 service group (16 lanes) must cover all 64 banks."""
+    EROW = 272
+    park = {}
+    for xt in range(4):
+        for yt in range(4):
+            for lane in range(64):
+                l31, half = lane & 31, lane >> 5
+                for part in range(2):                      # two 16-B stores of 8 columns each
+                    addr = (yt * 32 + l31) * EROW + (xt * 32 + half * 16) * 2 + part * 16
+                    assert addr % 16 == 0 and addr not in park
+                    park[addr] = (yt * 32 + l31, xt * 32 + half * 16 + part * 8)
+    assert len(park) == 128 * 16 and max(park) + 16 <= 128 * EROW <= 160 * 1024 // 4
+    seen = set()
+    for i in range(32):
+        rows_of_instr = set()
+        for lane in range(64):
+            prow, pchunk = lane >> 4, lane & 15
+            addr = (i * 4 + prow) * EROW + pchunk * 16
+            row, col = park[addr]
+            assert row == 4 * i + prow and col == pchunk * 8          # global row y0+wy*128+row, column x0+wx*128+col
+            seen.add((row, col)); rows_of_instr.add(row)
+        assert len(rows_of_instr) == 4
+    assert len(seen) == 128 * 16
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    for g in groups:                                        # ds_write_b128 of lanes on consecutive rows (one half, one part)
+        banks = set()
+        for l31 in g:
+            for dword in range(4):
+                banks.add(((l31 * EROW) // 4 + dword) % 64)
+        assert len(banks) == 64
