@@ -1,5 +1,5 @@
-"""s_memtime stamps of one stage of gemm256k.hip (tuning aid): needs wan2gp_amd/libwanhip_timing.so, i.e. the library
-linked with gemm256k.hip compiled with -DG256K_TIMING (stage 30 of tile (0,0), wave 0; that tile's epilogue is skipped)."""
+"""s_memtime stamps of one stage of gemm256k.hip (tuning aid): needs wan2gp_amd/libwanhip_timing.so (`make -C wan2gp_amd/csrc timing`),
+i.e. the library linked with gemm256k.hip compiled with -DG256K_TIMING (stage 30 of tile (0,0), wave 0; that tile's epilogue is skipped)."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from wan2gp_amd import lib
