@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the host logic of temporal sequence parallelism (wan2gp_amd/sp.py) --
+"""CPU, world_size 2 and 4, gloo: the host logic of temporal sequence parallelism (wan2gp_amd/sp.py) --
 token sharding, gather ordering, RoPE position offsets, segmented K/V attention, token-major output
 gather + unpatchify -- driven on the CPU oracle's arithmetic.  Every rank must reproduce the
 single-process oracle block/forward result for its shard."""
@@ -79,11 +79,14 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sequence_parallel_host_logic_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_sequence_parallel_host_logic(world):
+    """world 2 (the driver's smallest multi-GPU point) and 4 (L = 32 tokens -> 8 per rank): rank-ordered gathers, RoPE
+    offsets and the token-major output gather do not depend on the shard count."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
