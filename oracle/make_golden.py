@@ -230,6 +230,7 @@ def main():
         gen_forward(ns, "tiny_ti2v", 2, 6, 10, 455)
         gen_forward(ns, "tiny_i2v21", 2, 8, 8, 731)
         gen_forward(ns, "tiny_vace", 2, 8, 8, 588)
+        gen_forward(ns, "small", 3, 10, 14, 412)            # 4 heads, 3 layers, ragged token count L = 105
     if "sched" in which:
         gen_sched(ns)
     if "sched2" in which:

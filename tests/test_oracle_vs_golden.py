@@ -56,7 +56,7 @@ def test_rmsnorm_rope_ln_sdpa_bit_exact():
     assert (ex - t(g["sdpa_bf16"])).abs().max() < 2e-2
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21", "tiny_vace"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21", "tiny_vace", "small"])
 @pytest.mark.parametrize("tag,dtype", [("bf16", torch.bfloat16), ("fp32", torch.float32)])
 def test_forward_matches_reference(name, tag, dtype):
     g = load(f"forward_{name}.npz")
