@@ -64,6 +64,8 @@ def gen_ops(ns):
     out = {}
     cos, sin = ns.P.get_rotary_pos_embed((3, 8, 12))          # latent f,h,w -> grid (3,4,6)
     out["rope_cos_3x4x6"], out["rope_sin_3x4x6"] = f32(cos), f32(sin)
+    rc, rs = ns.P.get_rotary_pos_embed((33, 4, 6), enable_RIFLEx=True)        # long video: RIFLEx on the time axis
+    out["riflex_cos_33x2x3"], out["riflex_sin_33x2x3"] = f32(rc), f32(rs)
     g = torch.Generator().manual_seed(7)
     L, H, D = 72, 2, 128
     x = torch.randn(1, L, H * D, generator=g).to(torch.bfloat16)

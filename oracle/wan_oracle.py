@@ -169,7 +169,7 @@ def synth_weights(cfg: WanConfig, seed: int = 1234, dtype=torch.bfloat16) -> Dic
 ROPE_DIM_LIST = (44, 42, 42)  # posemb_layers.py:356 (t, h, w) for head_dim 128
 
 
-def rope_tables(grid: Sequence[int], theta: float = 10000.0) -> Tuple[torch.Tensor, torch.Tensor]:
+def rope_tables(grid: Sequence[int], theta: float = 10000.0, riflex: bool = False, riflex_k: int = 6) -> Tuple[torch.Tensor, torch.Tensor]:
     """cos/sin [L,128] fp32 for a token grid (f, h/2, w/2), f-major token order.
     Follows get_rotary_pos_embed -> get_nd_rotary_pos_embed -> get_1d_rotary_pos_embed:
     positions are integer grid indices in fp32 (USE_FP32_ROPE_FREQS=True, :6),
@@ -179,9 +179,11 @@ def rope_tables(grid: Sequence[int], theta: float = 10000.0) -> Tuple[torch.Tens
     axes = torch.meshgrid(torch.arange(f, dtype=torch.float32), torch.arange(h, dtype=torch.float32),
                           torch.arange(w, dtype=torch.float32), indexing="ij")
     cos_parts, sin_parts = [], []
-    for dim_axis, pos in zip(ROPE_DIM_LIST, axes):
+    for ax, (dim_axis, pos) in enumerate(zip(ROPE_DIM_LIST, axes)):
         pos = pos.reshape(-1)
         freqs = 1.0 / (theta ** (torch.arange(0, dim_axis, 2, dtype=torch.float32)[: dim_axis // 2] / dim_axis))
+        if ax == 0 and riflex:                              # get_1d_rotary_pos_embed_riflex (posemb_layers.py:70-76), L_test = f
+            freqs[riflex_k - 1] = 0.9 * 2 * torch.pi / f
         ang = torch.outer(pos, freqs)
         cos_parts.append(ang.cos().repeat_interleave(2, dim=1))
         sin_parts.append(ang.sin().repeat_interleave(2, dim=1))

@@ -36,6 +36,20 @@ def _ops_inputs():
     return x, w, b3, v
 
 
+def test_riflex_rope_tables_bit_exact_oracle_and_product():
+    """RIFLEx (long videos, posemb_layers.py:35-85, :417-419): the oracle and the product's host function both reproduce the
+    reference's tables exactly; the plain tables are untouched by the flag's code path."""
+    from wan2gp_amd.rope import get_rotary_pos_embed
+    g = load("ops.npz")
+    cos, sin = O.rope_tables((33, 2, 3), riflex=True)
+    assert torch.equal(cos, t(g["riflex_cos_33x2x3"])) and torch.equal(sin, t(g["riflex_sin_33x2x3"]))
+    pc, ps = get_rotary_pos_embed((33, 4, 6), enable_RIFLEx=True)
+    assert torch.equal(pc, t(g["riflex_cos_33x2x3"])) and torch.equal(ps, t(g["riflex_sin_33x2x3"]))
+    pc, ps = get_rotary_pos_embed((3, 8, 12))
+    assert torch.equal(pc, t(g["rope_cos_3x4x6"])) and torch.equal(ps, t(g["rope_sin_3x4x6"]))
+    assert not torch.equal(O.rope_tables((33, 2, 3))[0], cos)
+
+
 def test_rmsnorm_rope_ln_sdpa_bit_exact():
     g = load("ops.npz")
     x, w, b3, v = _ops_inputs()

@@ -73,7 +73,7 @@ class WanAny2VHIP:
                  frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
                  guide2_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
-                 loras_slists=None, switch2_threshold=0, **bbargs):
+                 loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -88,7 +88,7 @@ class WanAny2VHIP:
         lat_frames = (frame_num - 1) // self.vae_stride[0] + 1                       # any2video.py:647
         target_shape = (getattr(self.model, "out_dim", 16), lat_frames, height // self.vae_stride[1],
                         width // self.vae_stride[2])                                   # :1166 (48 channels, stride 16 for ti2v 5B)
-        freqs = get_rotary_pos_embed(target_shape[1:], device=dev)                   # :1192
+        freqs = get_rotary_pos_embed(target_shape[1:], enable_RIFLEx=bool(enable_RIFLEx), device=dev)   # :1192
         if latents is None:
             latents = torch.randn(batch_size, *target_shape, dtype=torch.float32, device=dev, generator=seed_g)  # :1470
         else:
