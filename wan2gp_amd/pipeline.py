@@ -73,7 +73,8 @@ class WanAny2VHIP:
                  frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
                  guide2_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
-                 loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, **bbargs):
+                 loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
+                 **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -102,6 +103,7 @@ class WanAny2VHIP:
         any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
         trans = self.model
         guidance_switch_done = False
+        text_momentum = None
         # LoRA multipliers per step (any2video.py:1431-1445, :1493): the reference re-selects the active multipliers on
         # every step (offload.set_step_no_for_lora); merged adapters are re-merged only when a step's multipliers change
         if loras_slists is not None:
@@ -153,7 +155,15 @@ class WanAny2VHIP:
                         if self._interrupt or r is None:
                             return None
                         ret.append(r)
-                noise_pred = cfg_combine(ret[0], ret[1], float(guide_scale))                        # :1722
+                if apg_switch != 0 or cfg_star_switch:
+                    # adaptive projected guidance / CFG-Zero* (any2video.py:1703-1721; momentum -0.75, norm threshold 55, :1476-1478)
+                    from . import guidance
+                    if apg_switch != 0 and text_momentum is None:
+                        text_momentum = guidance.MomentumBuffer(-0.75)
+                    noise_pred = guidance.combine(ret[0], ret[1], float(guide_scale), i, apg_switch, cfg_star_switch, cfg_zero_step,
+                                                  text_momentum, 55)
+                else:
+                    noise_pred = cfg_combine(ret[0], ret[1], float(guide_scale))                    # :1722
             if isinstance(sample_scheduler, FlowMatchScheduler):                                    # :1463-1467
                 latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents)[0]
             else:
