@@ -1,0 +1,134 @@
+"""CPU: the control flow of `WanAny2VHIP.generate` (mirror of models/wan/any2video.py:1490-1750) with the two HIP entry points
+it touches outside the model -- `ops.lincomb` (scheduler updates) and `ops.cfg_combine` -- replaced by torch one-liners IN THE
+TEST and a fake DiT that records its calls.  No arithmetic claim is made here (the kernels are checked by the -m gpu suite);
+what is checked is the host logic around them: which expert runs which step, which keyword arguments it receives, when the
+step-skipping cache / LoRA multipliers / guidance variants / RIFLEx tables are engaged, for every solver."""
+import types
+
+import pytest
+import torch
+
+from wan2gp_amd import ops, pipeline, schedulers
+from wan2gp_amd.pipeline import WanAny2VHIP
+
+
+class FakeDiT:
+    """Stands in for WanModelHIP: consumes the x list, returns one fp32 prediction per stream, records the call."""
+
+    def __init__(self, tag, out_dim=16):
+        self.tag, self.out_dim, self.calls, self.cache, self.loras = tag, out_dim, [], None, None
+        self.device = torch.device("cpu")
+
+    def __call__(self, x, t, context, **kw):
+        xs = list(x)
+        x.clear()
+        self.calls.append(dict(tag=self.tag, t=float(t), n=len(xs), step=kw.get("current_step_no"), x_id=kw.get("x_id", 0),
+                               freqs=kw["freqs"], y=kw.get("y")))
+        g = torch.Generator().manual_seed(int(float(t)) + len(self.calls))
+        return [0.1 * torch.randn(u.shape, generator=g) + 0.05 * i for i, u in enumerate(xs)]
+
+    # step-skipping cache API used by generate()
+    def compute_magcache_threshold(self, start_step, timesteps=None, speed_factor=0):
+        from wan2gp_amd import skipcache
+        self.thresholds = ("mag", start_step, len(timesteps), speed_factor)
+        return skipcache.compute_magcache_threshold(self.cache, start_step, timesteps, speed_factor)
+
+
+@pytest.fixture(autouse=True)
+def torch_stubs(monkeypatch):
+    def lincomb(tensors, coefs, out=None):
+        r = sum(float(c) * t_.float() for c, t_ in zip(coefs, tensors))
+        return r if out is None else out.copy_(r)
+    monkeypatch.setattr(ops, "lincomb", lincomb)
+    monkeypatch.setattr(ops, "cfg_combine", lambda c, u, g, out=None: u + g * (c - u))
+    yield
+
+
+def run(pipe, **kw):
+    ctx = torch.zeros(1, 512, 4096, dtype=torch.bfloat16)
+    args = dict(context=ctx, context_null=ctx, width=64, height=64, frame_num=9, sampling_steps=6, guide_scale=4.0, seed=5,
+                return_latents=True)
+    args.update(kw)
+    return pipe.generate(**args)
+
+
+@pytest.mark.parametrize("solver", ["unipc", "euler", "dpm++", "causvid", "lcm"])
+def test_every_solver_drives_the_model_once_per_step(solver):
+    m = FakeDiT("A")
+    steps = 4 if solver == "lcm" else 6
+    out = run(WanAny2VHIP(m, device="cpu"), sample_solver=solver, sampling_steps=steps)
+    assert torch.isfinite(out["latents"]).all() and tuple(out["latents"].shape) == (1, 16, 3, 8, 8)
+    assert len(m.calls) >= min(steps, 3) and all(c["n"] == 2 for c in m.calls)                  # joint CFG pass
+    assert [c["step"] for c in m.calls] == list(range(len(m.calls)))
+    ts = [c["t"] for c in m.calls]
+    assert ts == sorted(ts, reverse=True)
+
+
+def test_two_experts_switch_at_the_threshold_and_guidance_scale_follows():
+    a, b = FakeDiT("A"), FakeDiT("B")
+    seen = []
+    orig = ops.cfg_combine
+    ops.cfg_combine = lambda c, u, g, out=None: (seen.append(g), orig(c, u, g))[1]
+    try:
+        run(WanAny2VHIP(a, b, device="cpu"), guide2_scale=2.5, guide_phases=2, switch_threshold=800, model_switch_phase=1)
+    finally:
+        ops.cfg_combine = orig
+    assert a.calls and b.calls and all(c["t"] > 800 for c in a.calls) and all(c["t"] <= 800 for c in b.calls)
+    assert seen == [4.0] * len(a.calls) + [2.5] * len(b.calls)
+    assert len(a.calls) + len(b.calls) == 6
+
+
+def test_single_passes_when_joint_pass_is_off_and_no_cfg_at_scale_one():
+    m = FakeDiT("A")
+    run(WanAny2VHIP(m, device="cpu"), joint_pass=False)
+    assert all(c["n"] == 1 for c in m.calls) and [c["x_id"] for c in m.calls[:4]] == [0, 1, 0, 1] and len(m.calls) == 12
+    m = FakeDiT("A")
+    run(WanAny2VHIP(m, device="cpu"), guide_scale=1.0)
+    assert len(m.calls) == 6 and all(c["n"] == 1 for c in m.calls)
+
+
+def test_guidance_variants_and_riflex_are_engaged(monkeypatch):
+    from wan2gp_amd import guidance
+    used = []
+    real = guidance.combine
+    monkeypatch.setattr(guidance, "combine", lambda *a, **k: (used.append(a[3:7]), real(*a, **k))[1])
+    m = FakeDiT("A")
+    run(WanAny2VHIP(m, device="cpu"), cfg_star_switch=1, cfg_zero_step=1)
+    assert [u[0] for u in used] == list(range(6)) and all(u[1] == 0 and u[2] == 1 and u[3] == 1 for u in used)
+    used.clear()
+    run(WanAny2VHIP(FakeDiT("A"), device="cpu"), apg_switch=1)
+    assert len(used) == 6 and all(u[1] == 1 for u in used)
+    plain = FakeDiT("A"); run(WanAny2VHIP(plain, device="cpu"))
+    rif = FakeDiT("A"); run(WanAny2VHIP(rif, device="cpu"), enable_RIFLEx=True)
+    assert not torch.equal(plain.calls[0]["freqs"][0], rif.calls[0]["freqs"][0])
+
+
+def test_magcache_is_reset_and_thresholded_before_the_loop():
+    from wan2gp_amd.skipcache import SkipStepsCache
+    m = FakeDiT("A")
+    m.cache = SkipStepsCache(cache_type="mag", multiplier=2.0, start_step=1, magcache_K=2, magcache_thresh=0,
+                             def_mag_ratios=[0.99] * 10, skipped_steps=7, previous_residual="stale")
+    run(WanAny2VHIP(m, device="cpu"))
+    c = m.cache
+    assert m.thresholds == ("mag", 1, 6, 2.0) and c.num_steps == 6 and c.previous_residual == [None, None]
+    assert c.skipped_steps == 0 and len(c.mag_ratios) == 12 and c.accumulated_steps == [0, 0] and c.one_for_all is False
+
+
+def test_lora_multipliers_follow_the_phase_of_each_expert():
+    from wan2gp_amd.lora import parse_loras_multipliers
+
+    class Rec:
+        def __init__(self):
+            self.steps = []
+
+        def set_step(self, slists, n, step_no, s1, s2):
+            from wan2gp_amd.lora import step_multipliers
+            self.steps.append((step_no, step_multipliers(slists, n, step_no, s1, s2)))
+    a, b = FakeDiT("A"), FakeDiT("B")
+    a.loras, b.loras = Rec(), Rec()
+    _, slists, err = parse_loras_multipliers("1;0 0;1", 2, 6, nb_phases=2)
+    assert err == ""
+    run(WanAny2VHIP(a, b, device="cpu"), guide_phases=2, switch_threshold=800, loras_slists=slists)
+    assert a.loras.steps and all(m == [1.0, 0.0] for _, m in a.loras.steps)
+    assert b.loras.steps and all(m == [0.0, 1.0] for _, m in b.loras.steps)
+    assert [s for s, _ in a.loras.steps + b.loras.steps] == list(range(6))
