@@ -158,11 +158,14 @@ class WanModelHIP:
             active["clip_fea"] = clip_fea
         if active:
             if self.reference_module is not None:
+                extra = {k: v for k, v in (("clip_fea", clip_fea), ("vace_context", vace_context),
+                                           ("vace_context_scale", vace_context_scale)) if v is not None}
                 return self.reference_module(x, t, context, y=y, freqs=freqs, pipeline=pipeline,
                                              current_step_no=current_step_no, real_step_no=real_step_no, x_id=x_id,
-                                             max_steps=max_steps, callback=callback, **variant_kwargs)
-            raise NotImplementedError(f"WanModelHIP.forward: variant arguments {sorted(active)} are outside the "
-                                      "MI355X hot path (t2v / i2v2_2); attach `reference_module` to delegate")
+                                             max_steps=max_steps, callback=callback, **extra, **variant_kwargs)
+            raise NotImplementedError(f"WanModelHIP.forward: variant arguments {sorted(active)} are outside what this model "
+                                      "instance implements (t2v / i2v2_2 / ti2v2_2, i2v with clip_fea, VACE with vace_layers); "
+                                      "attach `reference_module` to delegate")
         x_list = list(x)
         x.clear()                                           # model.py:1558-1559
         S = len(x_list)
