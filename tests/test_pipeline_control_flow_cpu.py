@@ -132,3 +132,19 @@ def test_lora_multipliers_follow_the_phase_of_each_expert():
     assert a.loras.steps and all(m == [1.0, 0.0] for _, m in a.loras.steps)
     assert b.loras.steps and all(m == [0.0, 1.0] for _, m in b.loras.steps)
     assert [s for s, _ in a.loras.steps + b.loras.steps] == list(range(6))
+
+
+def test_vace_control_video_reaches_the_model_as_context():
+    from oracle.make_golden_vace_context import FakeVAE, inputs
+
+    class VaceDiT(FakeDiT):
+        def __call__(self, x, t, context, vace_context=None, vace_context_scale=None, **kw):
+            self.vace = (None if vace_context is None else [tuple(z.shape) for z in vace_context], vace_context_scale)
+            return super().__call__(x, t, context, **kw)
+    frames, mask, _ = inputs()
+    m = VaceDiT("A")
+    run(WanAny2VHIP(m, vae=FakeVAE(), device="cpu"), width=48, height=32, input_frames=frames, input_masks=mask, context_scale=[0.8])
+    assert m.vace == ([(96, 3, 4, 6)], [0.8]) and len(m.calls) == 6
+    m = VaceDiT("A")
+    run(WanAny2VHIP(m, vae=FakeVAE(), device="cpu"))
+    assert m.vace == (None, None)

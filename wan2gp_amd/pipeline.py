@@ -69,12 +69,57 @@ class WanAny2VHIP:
         y = torch.cat([msk, lat_y.to(msk.dtype)])                                                  # :774
         return y, lat_y[:, :1].clone().unsqueeze(0)
 
+    # ---- VACE context (any2video.py:270-331, :1128-1147) ---------------------------------------------------------------------
+    def vace_encode_frames(self, frames, ref_images, masks=None, tile_size=0):
+        """`WanAny2V.vace_encode_frames`: VAE latents of the control video, split by the mask into an inactive (kept) and a
+        reactive (to be generated) half -> 32 channels; reference images, if any, are prepended as extra latent frames."""
+        ref_images = [ref_images] * len(frames)
+        if masks is None:
+            latents = self.vae.encode(frames, tile_size=tile_size)
+        else:
+            inactive = self.vae.encode([i * (1 - m) + 0 * m for i, m in zip(frames, masks)], tile_size=tile_size)
+            reactive = self.vae.encode([i * m + 0 * (1 - m) for i, m in zip(frames, masks)], tile_size=tile_size)
+            latents = [torch.cat((u, c), dim=0) for u, c in zip(inactive, reactive)]
+        out = []
+        for latent, refs in zip(latents, ref_images):
+            if refs is not None:
+                ref_latent = self.vae.encode(refs, tile_size=tile_size)
+                if masks is not None:
+                    ref_latent = [torch.cat((u, torch.zeros_like(u)), dim=0) for u in ref_latent]
+                assert all(x.shape[1] == 1 for x in ref_latent)
+                latent = torch.cat([*ref_latent, latent], dim=1)
+            out.append(latent)
+        return out
+
+    def vace_encode_masks(self, masks, ref_images=None):
+        """`WanAny2V.vace_encode_masks`: the pixel mask folded 8x8 into 64 channels at latent resolution, nearest-exact
+        resampled in time to the latent frame count; zero frames in front for reference images."""
+        ref_images = [ref_images] * len(masks)
+        st, sh, sw = self.vae_stride
+        out = []
+        for mask, refs in zip(masks, ref_images):
+            _, depth, height, width = mask.shape
+            new_depth = int((depth + 3) // st)
+            height, width = 2 * (int(height) // (sh * 2)), 2 * (int(width) // (sw * 2))
+            m = mask[0].view(depth, height, sh, width, sh).permute(2, 4, 0, 1, 3).reshape(sh * sw, depth, height, width)
+            m = torch.nn.functional.interpolate(m.unsqueeze(0), size=(new_depth, height, width), mode="nearest-exact").squeeze(0)
+            if refs is not None:
+                m = torch.cat((torch.zeros(m.shape[0], len(refs), *m.shape[-2:], dtype=m.dtype, device=m.device), m), dim=1)
+            out.append(m)
+        return out
+
+    def vace_context(self, input_frames, input_masks, input_ref_images=None, tile_size=0):
+        """z = [cat(z0, m0)] as built at any2video.py:1136-1146 (no background reference mask): [96, F, H, W] per control video."""
+        z0 = self.vace_encode_frames(input_frames, input_ref_images, masks=input_masks, tile_size=tile_size)
+        m0 = self.vace_encode_masks(input_masks, input_ref_images)
+        return [torch.cat([zz, mm.to(zz.dtype)], dim=0) for zz, mm in zip(z0, m0)]
+
     def generate(self, input_prompt=None, n_prompt="", context=None, context_null=None, width=1280, height=720,
                  frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
                  guide2_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
-                 **bbargs):
+                 input_frames=None, input_masks=None, context_scale=None, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -100,6 +145,12 @@ class WanAny2VHIP:
             if self.vae is None:
                 raise ValueError("image_start needs a VAE to encode the conditioning video")
             y, ext_latents = self.build_i2v_conditioning(image_start, frame_num, height, width, VAE_tile_size)
+        vace_kwargs = {}
+        if input_frames is not None:                         # VACE control video + mask (any2video.py:1128-1147), no reference images
+            if self.vae is None or input_masks is None:
+                raise ValueError("VACE needs a VAE, input_frames [3,T,H,W] and input_masks [1,T,H,W]")
+            z = self.vace_context([input_frames.to(dev)], [input_masks.to(dev)], None, VAE_tile_size)
+            vace_kwargs = {"vace_context": z, "vace_context_scale": context_scale if context_scale is not None else [1.0] * len(z)}
         any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
         trans = self.model
         guidance_switch_done = False
@@ -123,7 +174,7 @@ class WanAny2VHIP:
                     m.compute_teacache_threshold(cache.start_step, timesteps, cache.multiplier)
                 else:
                     m.compute_magcache_threshold(cache.start_step, timesteps, cache.multiplier)
-        kwargs = {"freqs": freqs, "pipeline": self, "callback": callback, "y": y, "max_steps": len(timesteps)}
+        kwargs = {"freqs": freqs, "pipeline": self, "callback": callback, "y": y, "max_steps": len(timesteps), **vace_kwargs}
         for i, t in enumerate(timesteps):
             # update_guidance (:1437-1443): phase 2 begins once t <= switch_threshold
             if guide_phases >= 2 and not guidance_switch_done and t <= switch_threshold:
