@@ -148,3 +148,30 @@ def test_vace_control_video_reaches_the_model_as_context():
     m = VaceDiT("A")
     run(WanAny2VHIP(m, vae=FakeVAE(), device="cpu"))
     assert m.vace == (None, None)
+
+
+def test_sub_parallel_windows_run_every_step_on_overlapping_latent_windows():
+    """frame_num 41 -> 11 latent frames; window 17 px-frames / overlap 5 -> 5 / 2 latent frames -> windows (0,5) (3,8) (6,11):
+    three forwards per step, each on its window plus one anchor frame, with the RoPE rows of exactly those frames; the
+    step-skipping cache is parked for the run and restored afterwards (any2video.py:1392-1397, :1448-1462)."""
+    from wan2gp_amd.skipcache import SkipStepsCache
+    m = FakeDiT("A")
+    cache = m.cache = SkipStepsCache(cache_type="mag", multiplier=2.0, start_step=1, magcache_K=2, magcache_thresh=0, def_mag_ratios=[0.99] * 10,
+                                     previous_residual="x", previous_modulated_input="y")
+    seen = []
+    orig = m.__class__.__call__
+
+    def spy(self, x, t, context, **kw):
+        seen.append((x[0].shape[2], kw["freqs"][0].shape[0], self.cache))
+        return orig(self, x, t, context, **kw)
+    m.__class__ = type("Spy", (FakeDiT,), {"__call__": spy})
+    out = run(WanAny2VHIP(m, device="cpu"), frame_num=41, sampling_steps=3, sub_parallel_window_size=17, sub_parallel_window_overlap=5)
+    assert tuple(out["latents"].shape) == (1, 16, 11, 8, 8) and torch.isfinite(out["latents"]).all()
+    tok = 4 * 4
+    assert [s[:2] for s in seen] == [(5, 5 * tok), (6, 6 * tok), (6, 6 * tok)] * 3           # anchor frame in front of windows 2 and 3
+    assert all(s[2] is None for s in seen)                                                   # cache parked while windows run
+    assert m.cache is cache and cache.previous_residual is None and cache.previous_modulated_input is None
+    # a window that covers the clip is no window at all
+    m2 = FakeDiT("A")
+    run(WanAny2VHIP(m2, device="cpu"), frame_num=9, sampling_steps=2, sub_parallel_window_size=81)
+    assert len(m2.calls) == 2

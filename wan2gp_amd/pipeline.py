@@ -119,7 +119,8 @@ class WanAny2VHIP:
                  guide2_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
-                 input_frames=None, input_masks=None, context_scale=None, **bbargs):
+                 input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
+                 **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -162,6 +163,25 @@ class WanAny2VHIP:
             phase_switch_step, phase_switch_step2, _ = get_model_switch_steps(
                 [float(t) for t in timesteps], guide_phases, 0 if self.model2 is None else model_switch_phase, switch_threshold,
                 switch2_threshold)
+        # sub-parallel temporal windows (any2video.py:1199-1223, :1392-1397): per-step forwards on overlapping windows of latent
+        # frames; step-skipping caches are parked while they are active (their residuals have the full clip's token count)
+        from . import subparallel
+        sub_win, sub_overlap = subparallel.window_latent_counts(sub_parallel_window_size, sub_parallel_window_overlap, lat_frames,
+                                                                self.vae_stride[0])
+        sub_windows = subparallel.build_windows(lat_frames, sub_win, sub_overlap)
+        parked = []
+        if sub_windows is not None:
+            for m in (self.model, self.model2):
+                if m is not None and getattr(m, "cache", None) is not None:
+                    parked.append((m, m.cache))
+                    m.cache = None
+
+        def restore_caches():                                # clear() (any2video.py:1448-1462)
+            for m, c in parked:
+                c.previous_residual = None
+                c.previous_modulated_input = None
+                m.cache = c
+            return None
         # step-skipping caches (any2video.py:1398-1408): reset, then pick the threshold that meets cache.multiplier
         for m in (self.model, self.model2):
             cache = getattr(m, "cache", None) if m is not None else None
@@ -189,38 +209,46 @@ class WanAny2VHIP:
                 f = float(t) / 1000.0
                 n = ext_latents.shape[2]
                 latents[:, :, :n] = ext_latents * (1.0 - f) + torch.randn_like(ext_latents) * f
-            if guide_scale == 1 or not any_guidance:
-                ret = trans(x=[latents], context=[context], **kwargs)
-                if self._interrupt or ret[0] is None:
-                    return None
-                noise_pred = ret[0]
-            else:
+            def denoise_with_cfg(lat):                       # denoise_with_cfg_fn, plain two-stream branch (any2video.py:1610-1722)
+                nonlocal text_momentum
+                if guide_scale == 1 or not any_guidance:
+                    ret = trans(x=[lat], context=[context], **kwargs)
+                    return None if (self._interrupt or ret[0] is None) else ret[0]
                 if joint_pass:
-                    ret = trans(x=[latents, latents], context=[context, context_null], **kwargs)   # :1626-1634
+                    ret = trans(x=[lat, lat], context=[context, context_null], **kwargs)              # :1626-1634
                     if self._interrupt or ret[0] is None:
                         return None
                 else:
                     ret = []
-                    for x_id, c in enumerate((context, context_null)):                             # :1638-1643
-                        r = trans(x=[latents], context=[c], x_id=x_id, **kwargs)[0]
+                    for x_id, c in enumerate((context, context_null)):                               # :1638-1643
+                        r = trans(x=[lat], context=[c], x_id=x_id, **kwargs)[0]
                         if self._interrupt or r is None:
                             return None
                         ret.append(r)
                 if apg_switch != 0 or cfg_star_switch:
-                    # adaptive projected guidance / CFG-Zero* (any2video.py:1703-1721; momentum -0.75, norm threshold 55, :1476-1478)
+                    # adaptive projected guidance / CFG-Zero* (:1703-1721; momentum -0.75, norm threshold 55, :1476-1478)
                     from . import guidance
                     if apg_switch != 0 and text_momentum is None:
                         text_momentum = guidance.MomentumBuffer(-0.75)
-                    noise_pred = guidance.combine(ret[0], ret[1], float(guide_scale), i, apg_switch, cfg_star_switch, cfg_zero_step,
-                                                  text_momentum, 55)
-                else:
-                    noise_pred = cfg_combine(ret[0], ret[1], float(guide_scale))                    # :1722
+                    return guidance.combine(ret[0], ret[1], float(guide_scale), i, apg_switch, cfg_star_switch, cfg_zero_step,
+                                            text_momentum, 55)
+                return cfg_combine(ret[0], ret[1], float(guide_scale))                              # :1722
+
+            if sub_windows is not None:                      # any2video.py:1724: one forward per temporal window, blended
+                from . import subparallel
+                noise_pred = subparallel.denoise(latents, denoise_with_cfg, sub_windows, sub_overlap, kwargs,
+                                                 (target_shape[2] // self.patch_size[1]) * (target_shape[3] // self.patch_size[2]))
+            else:
+                noise_pred = denoise_with_cfg(latents)
+            if noise_pred is None:
+                return restore_caches()
             if isinstance(sample_scheduler, FlowMatchScheduler):                                    # :1463-1467
                 latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents)[0]
             else:
                 latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
             if callback is not None:
                 callback(i, latents[0], False)
+        restore_caches()
         if ext_latents is not None:
             latents[:, :, :ext_latents.shape[2]] = ext_latents                                     # :1755-1756
         if return_latents or self.vae is None:
