@@ -52,22 +52,32 @@ class WanAny2VHIP:
             raise NotImplementedError(f"Unsupported Scheduler {sample_solver}")
         return s, s.timesteps
 
-    def build_i2v_conditioning(self, image_start, frame_num, height, width, VAE_tile_size=0):
-        """y = cat(mask[4,f,h,w], vae.encode(start image + zero frames)[16,f,h,w]) (any2video.py:739-774) and the
-        clean first latent frame that is re-injected every step (:776-783)."""
+    def build_i2v_conditioning(self, image_start, frame_num, height, width, VAE_tile_size=0, motion_amplitude=1.0):
+        """y = cat(mask[4,f,h,w], vae.encode(known frames + zero frames)[16,f,h,w]) (any2video.py:699-774) and the clean
+        latents of the known frames that are re-injected every step (:775-782).  `image_start`: one image [3,H,W] or a
+        prefix video [3,P,H,W] to continue (control_video, :671-680); `motion_amplitude` > 1 stretches the latent
+        differences to the first frame (:761-770)."""
         dev = self.device
-        img = image_start.to(device=dev, dtype=torch.float32)
-        if img.dim() == 3:
-            img = img.unsqueeze(1)                                                     # [3,1,H,W]
+        video = image_start.to(device=dev, dtype=torch.float32)
+        if video.dim() == 3:
+            video = video.unsqueeze(1)                                                 # [3,1,H,W]
+        P = video.shape[1]
         lat_h, lat_w = height // self.vae_stride[1], width // self.vae_stride[2]
-        enc = torch.cat([img, torch.zeros(3, frame_num - 1, height, width, device=dev)], dim=1)   # :739
+        enc = torch.cat([video, torch.zeros(3, frame_num - P, height, width, device=dev)], dim=1)  # :739
         lat_y = self.vae.encode([enc], VAE_tile_size)[0]                                           # :743
         msk = torch.ones(1, frame_num, lat_h, lat_w, device=dev)                                   # :746-757
-        msk[:, 1:] = 0
+        msk[:, P:] = 0
         msk = torch.cat([torch.repeat_interleave(msk[:, 0:1], repeats=4, dim=1), msk[:, 1:]], dim=1)
         msk = msk.view(1, msk.shape[1] // 4, 4, lat_h, lat_w).transpose(1, 2)[0]
+        if motion_amplitude > 1:                                                                   # :761-770
+            base = lat_y[:, :1]
+            diff = lat_y[:, P:] - base
+            mean = diff.mean(dim=(0, 2, 3), keepdim=True)
+            scaled = torch.clamp(base + (diff - mean) * motion_amplitude + mean, -6, 6)
+            lat_y = torch.cat([lat_y[:, :P], scaled], dim=1)
         y = torch.cat([msk, lat_y.to(msk.dtype)])                                                  # :774
-        return y, lat_y[:, :1].clone().unsqueeze(0)
+        n_known = int(1 + (P - 1) // 4)                                                            # :775
+        return y, lat_y[:, :n_known].clone().unsqueeze(0)
 
     # ---- VACE context (any2video.py:270-331, :1128-1147) ---------------------------------------------------------------------
     def vace_encode_frames(self, frames, ref_images, masks=None, tile_size=0):
@@ -145,7 +155,7 @@ class WanAny2VHIP:
         if image_start is not None:
             if self.vae is None:
                 raise ValueError("image_start needs a VAE to encode the conditioning video")
-            y, ext_latents = self.build_i2v_conditioning(image_start, frame_num, height, width, VAE_tile_size)
+            y, ext_latents = self.build_i2v_conditioning(image_start, frame_num, height, width, VAE_tile_size, motion_amplitude)
         vace_kwargs = {}
         if input_frames is not None:                         # VACE control video + mask (any2video.py:1128-1147), no reference images
             if self.vae is None or input_masks is None:
