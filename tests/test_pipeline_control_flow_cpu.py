@@ -175,3 +175,21 @@ def test_sub_parallel_windows_run_every_step_on_overlapping_latent_windows():
     m2 = FakeDiT("A")
     run(WanAny2VHIP(m2, device="cpu"), frame_num=9, sampling_steps=2, sub_parallel_window_size=81)
     assert len(m2.calls) == 2
+
+
+def test_three_guidance_phases_switch_expert_at_the_second_boundary():
+    """guide_phases 3, model_switch_phase 2 (any2video.py:1437-1443, :1491-1492): expert 1 keeps running through phase 2 with
+    guide2_scale, expert 2 takes over at switch2_threshold with guide3_scale."""
+    a, b = FakeDiT("A"), FakeDiT("B")
+    seen = []
+    orig = ops.cfg_combine
+    ops.cfg_combine = lambda c, u, g, out=None: (seen.append(g), orig(c, u, g))[1]
+    try:
+        run(WanAny2VHIP(a, b, device="cpu"), sampling_steps=8, guide2_scale=3.0, guide3_scale=2.0, guide_phases=3, switch_threshold=900,
+            switch2_threshold=600, model_switch_phase=2)
+    finally:
+        ops.cfg_combine = orig
+    ta, tb = [c["t"] for c in a.calls], [c["t"] for c in b.calls]
+    assert ta and tb and min(ta) > 600 and max(tb) <= 600 and len(ta) + len(tb) == 8
+    n1 = sum(1 for t in ta if t > 900)
+    assert seen == [4.0] * n1 + [3.0] * (len(ta) - n1) + [2.0] * len(tb) and 0 < n1 < len(ta)

@@ -126,7 +126,7 @@ class WanAny2VHIP:
 
     def generate(self, input_prompt=None, n_prompt="", context=None, context_null=None, width=1280, height=720,
                  frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
-                 guide2_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
+                 guide2_scale=5.0, guide3_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
@@ -164,7 +164,7 @@ class WanAny2VHIP:
             vace_kwargs = {"vace_context": z, "vace_context_scale": context_scale if context_scale is not None else [1.0] * len(z)}
         any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
         trans = self.model
-        guidance_switch_done = False
+        guidance_switch_done = guidance_switch2_done = False
         text_momentum = None
         # LoRA multipliers per step (any2video.py:1431-1445, :1493): the reference re-selects the active multipliers on
         # every step (offload.set_step_no_for_lora); merged adapters are re-merged only when a step's multipliers change
@@ -211,6 +211,10 @@ class WanAny2VHIP:
                 if model_switch_phase == 1 and self.model2 is not None:
                     trans = self.model2
                 guide_scale, guidance_switch_done = guide2_scale, True
+            if guide_phases >= 3 and not guidance_switch2_done and t <= switch2_threshold:          # phase 3 (:1492)
+                if model_switch_phase == 2 and self.model2 is not None:
+                    trans = self.model2
+                guide_scale, guidance_switch2_done = guide3_scale, True
             timestep = torch.stack([t])
             kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": i})
             if loras_slists is not None and getattr(trans, "loras", None) is not None:
