@@ -193,3 +193,22 @@ def test_three_guidance_phases_switch_expert_at_the_second_boundary():
     assert ta and tb and min(ta) > 600 and max(tb) <= 600 and len(ta) + len(tb) == 8
     n1 = sum(1 for t in ta if t > 900)
     assert seen == [4.0] * n1 + [3.0] * (len(ta) - n1) + [2.0] * len(tb) and 0 < n1 < len(ta)
+
+
+def test_i2v_start_image_conditions_every_step_and_is_restored_at_the_end():
+    """image_start: y = [mask ; VAE latents] reaches every forward, the known first latent is re-noised before each step and
+    written back clean after the last one (any2video.py:699-782, :1517-1523, :1755-1756)."""
+    from oracle.make_golden_i2v_cond import FakeVAE
+    m = FakeDiT("A")
+    pipe = WanAny2VHIP(m, vae=FakeVAE(), device="cpu")
+    img = torch.rand(3, 32, 48) * 2 - 1
+    out = run(pipe, width=48, height=32, frame_num=9, sampling_steps=3, image_start=img)
+    assert all(c["y"] is not None and tuple(c["y"].shape) == (20, 3, 4, 6) for c in m.calls) and len(m.calls) == 3
+    y, ext = pipe.build_i2v_conditioning(img, 9, 32, 48)
+    assert torch.equal(m.calls[0]["y"], y) and torch.equal(out["latents"][:, :, :1], ext)
+    # prefix video of 5 frames: two known latent frames
+    vid = torch.rand(3, 5, 32, 48) * 2 - 1
+    out = run(WanAny2VHIP(FakeDiT("A"), vae=FakeVAE(), device="cpu"), width=48, height=32, frame_num=13, sampling_steps=2, image_start=vid,
+              motion_amplitude=1.3)
+    _, ext = pipe.build_i2v_conditioning(vid, 13, 32, 48, 0, 1.3)
+    assert ext.shape[2] == 2 and torch.equal(out["latents"][:, :, :2], ext)

@@ -130,7 +130,7 @@ class WanAny2VHIP:
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
-                 **bbargs):
+                 motion_amplitude=1.0, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
