@@ -107,6 +107,11 @@ def gen_forward(ns, name, f, h, w, tval):
         cdt = dtype
         r = ref_forward(ns, m, [lat, lat], t, [ctx.to(cdt), ctx_null.to(cdt)], y=y, clip_fea=clip, vace=vace)
         out[f"cond_{tag}"], out[f"uncond_{tag}"] = f32(r[0]), f32(r[1])
+        if name == "tiny_ti2v":                                 # per-frame timesteps: ti2v timestep injection (any2video.py:1496-1499)
+            tf = torch.full((f,), tval, dtype=torch.int64)
+            tf[:1] = 0
+            r = ref_forward(ns, m, [lat, lat], tf, [ctx.to(cdt), ctx_null.to(cdt)])
+            out[f"cond_tframe_{tag}"], out[f"uncond_tframe_{tag}"] = f32(r[0]), f32(r[1])
         if vace is not None:                                    # a second run with a fractional context scale (x.add_(hint, alpha))
             r = ref_forward(ns, m, [lat, lat], t, [ctx.to(cdt), ctx_null.to(cdt)], y=y, vace=vace, vace_scale=0.6)
             out[f"cond_s06_{tag}"], out[f"uncond_s06_{tag}"] = f32(r[0]), f32(r[1])

@@ -325,21 +325,24 @@ def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = Fals
     residual dtype, e0 [1,6,dim] (latent_frames = e.shape[0] = 1, so the reshape at
     :635/:658/:688 is a no-op broadcast).  i: block index, or a key prefix (VACE context blocks)."""
     p = i if isinstance(i, str) else f"blocks.{i}."
-    e = (W[p + "modulation"] + e0).chunk(6, dim=1)            # :632   6 x [1,1,dim]
-    x_mod = layer_norm(x, cfg.eps)                             # :634
-    x_mod = x_mod * (1 + e[1]); x_mod = x_mod + e[0]           # :636-637 (two roundings)
+    nf = e0.shape[0]                                           # latent_frames (:631): > 1 with per-frame timesteps (ti2v injection,
+    rs = (lambda v: v.reshape(v.shape[0], nf, -1, v.shape[-1])) if nf > 1 else (lambda v: v)      # diffusion forcing): reshape_latent
+    un = (lambda v: v.reshape(v.shape[0], -1, v.shape[-1])) if nf > 1 else (lambda v: v)          # / restore_latent_shape (:45-49)
+    e = (W[p + "modulation"] + e0).chunk(6, dim=1)            # :632   6 x [nf,1,dim]
+    x_mod = rs(layer_norm(x, cfg.eps))                         # :634-635
+    x_mod = x_mod * (1 + e[1]); x_mod = un(x_mod + e[0])       # :636-638 (two roundings)
     y = self_attention(x_mod, W, p + "self_attn.", cfg, cos, sin, exact)   # :653
-    x = torch.addcmul(x, y, e[2])                              # :659
+    x = un(torch.addcmul(rs(x), rs(y), e[2]))                  # :658-660
     y = layer_norm(x, cfg.eps, W[p + "norm3.weight"], W[p + "norm3.bias"])  # :664
     x = x + cross_attention(y, ctx, W, p + "cross_attn.", cfg, exact)       # :668
-    y = layer_norm(x, cfg.eps)                                 # :686
-    y = y * (1 + e[4]); y = y + e[3]                           # :689-690
+    y = rs(layer_norm(x, cfg.eps))                             # :686-688
+    y = y * (1 + e[4]); y = un(y + e[3])                       # :689-691
     shp = y.shape                                              # :698-707 three row chunks
     y2 = y.reshape(-1, shp[-1])
     outs = [_linear(F.gelu(_linear(c, W, p + "ffn.0"), approximate="tanh"), W, p + "ffn.2")
             for c in torch.split(y2, int(y2.shape[0] / 2.7))]
     y = torch.cat(outs, 0).view(shp)
-    x = torch.addcmul(x, y, e[5])                              # :710
+    x = un(torch.addcmul(rs(x), rs(y), e[5]))                  # :708-711
     return x
 
 
@@ -358,12 +361,17 @@ def vace_block_forward(c, x, e0, ctx, cos, sin, W, n: int, cfg: WanConfig, exact
 # --------------------------------------------------------------------------------------
 def head_forward(x, e, W, cfg: WanConfig):
     dtype = x.dtype
+    nf = e.shape[0]                                                 # latent_frames (model.py:856)
     em = (W["head.modulation"] + e.unsqueeze(1)).chunk(2, dim=1)   # fp32 (+ bf16 e -> fp32)
     x = layer_norm(x, cfg.eps).to(dtype)
+    if nf > 1:
+        x = x.reshape(x.shape[0], nf, -1, x.shape[-1])
     x = x * (1 + em[1])     # `x *= (1+e[1])` in place on the bf16 tensor -> rounds to bf16 ...
     x = x.to(dtype)
     x = x + em[0]
     x = x.to(dtype)         # ... and `x += e[0]` likewise (model.py:860-861)
+    if nf > 1:
+        x = x.reshape(x.shape[0], -1, x.shape[-1])
     x = x.to(W["head.head.weight"].dtype)
     return F.linear(x, W["head.head.weight"], W["head.head.bias"])
 

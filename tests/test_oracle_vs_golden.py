@@ -87,6 +87,11 @@ def test_forward_matches_reference(name, tag, dtype):
         c6, u6 = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, dtype=dtype, vace_context=vace, vace_scale=0.6)
         assert torch.equal(c6, t(g["cond_s06_bf16"])) and torch.equal(u6, t(g["uncond_s06_bf16"]))
         assert not torch.equal(c6, cond)
+    if name == "tiny_ti2v" and dtype == torch.bfloat16:              # per-frame timesteps (first latent frame at t = 0)
+        tf = torch.full((f,), int(g["t"][0]), dtype=torch.int64)
+        tf[:1] = 0
+        c2, u2 = O.dit_forward([lat, lat], tf, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, dtype=dtype)
+        assert torch.equal(c2, t(g["cond_tframe_bf16"])) and torch.equal(u2, t(g["uncond_tframe_bf16"])) and not torch.equal(c2, cond)
     if dtype == torch.bfloat16:
         assert torch.equal(cond, t(g["cond_bf16"])) and torch.equal(uncond, t(g["uncond_bf16"]))
     else:
