@@ -1,0 +1,91 @@
+"""Build-time guard for the two hot kernels: the properties their performance rests on are visible in the gfx950 ISA hipcc
+emits, so they are asserted here (CPU, cross-compile only, ~30 s):
+  * gemm256k: 256 accumulators in the accumulator file, no scratch in any instantiation (a spill there costs the epilogue its
+    prefetch), 160 KB of LDS, and the main loop's instruction mix per stage -- 64 MFMAs, 32
+    ds_read_b128, 16 LDS-DMA pieces, one counted wait + barrier;
+  * attention w64q: no scratch, accumulators in the accumulator file, one v_exp_f32 per score element and packed bf16
+    conversions (no software rounding) in the steady-state segments."""
+import collections
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+
+
+def asm_of(name, tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    src = os.path.join(ROOT, "wan2gp_amd", "csrc", name + ".hip")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-ffp-contract=on",
+                    "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", src, "-o", str(out)], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def kernels(asm, stem):
+    """name -> (body ops, metadata dict) for every kernel whose mangled name contains `stem`."""
+    res = {}
+    for m in re.finditer(r"^(_Z\S*" + stem + r"\S*):", asm, re.M):
+        name = m.group(1)
+        end = asm.index("s_endpgm", m.end())
+        ops = [l.split()[0] for l in (x.strip() for x in asm[m.end():end].split("\n")) if l and not l.startswith((";", ".")) and not l.endswith(":")]
+        tail = asm[end:end + 6000]
+        meta = {k: int(v) for k, v in re.findall(r"; (NumVgprs|NumAgprs|ScratchSize|LDSByteSize): (\d+)", tail)}
+        res[name] = (ops, meta)
+    return res
+
+
+@pytest.fixture(scope="module")
+def gemm(tmp_path_factory):
+    return kernels(asm_of("gemm256k", tmp_path_factory), "gemm256k_kernel")
+
+
+@pytest.fixture(scope="module")
+def attn(tmp_path_factory):
+    return kernels(asm_of("attention_w64q", tmp_path_factory), "attn_w64q_kernel")
+
+
+def test_gemm256k_registers_lds_and_no_scratch(gemm):
+    assert len(gemm) == 6                                            # NONE / GELU / GATE_RES, bias rows, fp16 variants
+    for name, (ops, meta) in gemm.items():
+        assert meta["ScratchSize"] == 0, name
+        assert meta["NumAgprs"] >= 252 and meta["LDSByteSize"] == 160 * 1024, (name, meta)
+
+
+def test_gemm256k_main_loop_instruction_mix(gemm):
+    name = next(n for n in gemm if "ILi0ELb0ELb0E" in n)            # EPI NONE, column bias, bf16
+    ops = gemm[name][0]
+    mf = [i for i, o in enumerate(ops) if o.startswith("v_mfma_f32_32x32x16")]
+    assert len(mf) == 5 * 64                                         # loop unrolled over the five ring positions
+    br = [i for i, o in enumerate(ops) if o.startswith(("s_cbranch", "s_branch"))]
+    stages = []
+    prev = 0
+    for b in br + [len(ops)]:
+        if sum(1 for i in mf if prev <= i < b) == 64:
+            stages.append(collections.Counter(ops[prev:b]))
+        prev = b
+    assert len(stages) == 5
+    for j, c in enumerate(stages):
+        if j == 0:                                                   # the first segment also holds the tail of the prologue
+            assert c["ds_read_b128"] >= 32 and c["buffer_load_dwordx4"] >= 16
+            continue
+        assert c["ds_read_b128"] == 32 and c["buffer_load_dwordx4"] == 16 and c["s_barrier"] == 1
+        valu = sum(v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma"))
+        assert valu <= 24, valu                                      # address adds only: nothing competes with the MFMAs for issue slots
+        assert not any(k.startswith("scratch_") for k in c)
+
+
+def test_attention_w64q_no_scratch_and_hardware_conversions(attn):
+    assert len(attn) == 8
+    for name, (ops, meta) in attn.items():
+        assert meta["ScratchSize"] == 0 and meta["NumAgprs"] >= 128, (name, meta)
+    name = next(n for n in attn if "ILi6E" in n)                     # PRESCALED | FLAT: the DiT's self-attention
+    c = collections.Counter(attn[name][0])
+    assert c["v_exp_f32_e32"] >= 64 and c["v_cvt_pk_bf16_f32"] >= 32
+    mf = sum(v for k, v in c.items() if k.startswith("v_mfma"))
+    assert mf >= 136                                                  # 68 per KV tile, two unrolled ring positions at least
