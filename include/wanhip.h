@@ -10,8 +10,10 @@
  *   - all pointers are DEVICE pointers owned by the caller (torch); the library never frees them
  *   - bf16 tensors are raw uint16 storage, row-major, innermost dimension contiguous
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream)
- *   - every function returns 0 on success, non-zero on error; wan_last_error() returns the
- *     message for the calling thread.  Nothing here falls back to a CPU path.
+ *   - every function returns 0 on success, non-zero on error (1 = rejected arguments, 2 = HIP runtime error,
+ *     3 = a host callback failed, WAN_ABORTED = the interrupt poll asked to stop -- not an error: the reference
+ *     returns [None]*n there); wan_last_error() returns the message for the calling thread.  Nothing here falls
+ *     back to a CPU path.
  *   - kernels reproduce the reference's bf16 rounding points (RMSNorm 2 roundings, RoPE 1,
  *     LayerNorm 1 + modulate 2, Linear output 1, GELU 1, addcmul 1) so results track the
  *     reference's eager bf16 path; accumulation is fp32 everywhere.
@@ -27,6 +29,7 @@ extern "C" {
 #endif
 
 typedef uint16_t wan_bf16; /* raw bfloat16 bits */
+#define WAN_ABORTED 100   /* wan_dit_forward*: stopped by the between-blocks poll (model.py:1997-1998) */
 
 /* ---- library ------------------------------------------------------------------------- */
 const char* wan_last_error(void);
@@ -269,7 +272,7 @@ typedef struct {
 /* WanModel.forward for the t2v / i2v2_2 path (model.py:1485-2098): S streams (the joint CFG
  * pass, any2video.py:1626-1634), each x_s [1, 16, F, H, W] fp32, t scalar, context_s
  * [1, 512, text_dim] bf16, y optional [in_dim-out_dim, F, H, W] fp32 (x streams are [1, out_dim, F, H, W]), cos/sin [L,128] fp32.
- * outs[s] [1, 16, F, H, W] fp32.  Returns 1 if aborted by poll (reference returns [None]*n). */
+ * outs[s] [1, 16, F, H, W] fp32.  Returns WAN_ABORTED if stopped by poll (reference returns [None]*n). */
 int wan_dit_forward(wan_ctx* ctx, int S, const float* const* x, float t, const wan_bf16* const* context,
                     const float* y, const float* cos, const float* sin, float* const* outs, int F,
                     int H, int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp,

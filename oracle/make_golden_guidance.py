@@ -26,6 +26,21 @@ def lift(path, names):
     return ns
 
 
+def lift_cfg_branch(ns):
+    """The plain two-stream branch of denoise_with_cfg_fn (any2video.py:1702-1722: `noise_pred_cond, noise_pred_uncond =
+    ret_values` ... `noise_pred = noise_pred_uncond + guide_scale * (noise_pred_text - noise_pred_uncond)`), lifted by its
+    first / last statement, dedented and wrapped in a function of the names it reads.  Statements untouched."""
+    import textwrap
+    lines = open(os.path.join(REF, "models/wan/any2video.py")).read().split("\n")
+    i0 = next(i for i, l in enumerate(lines) if l.strip() == "noise_pred_cond, noise_pred_uncond = ret_values")
+    i1 = next(i for i in range(i0, len(lines)) if lines[i].strip().startswith("noise_pred = noise_pred_uncond + guide_scale * (noise_pred_text - noise_pred_uncond)"))
+    body = textwrap.dedent("\n".join(lines[i0:i1 + 1]))
+    src = ("def cfg_branch(ret_values, guide_scale, i, apg_switch, cfg_star_switch, cfg_zero_step, batch_size, text_momentumbuffer, apg_norm_threshold):\n"
+           + textwrap.indent(body, "    ") + "\n    return noise_pred\n")
+    exec(compile(src, "any2video.py[%d:%d]" % (i0 + 1, i1 + 1), "exec"), ns)
+    return ns["cfg_branch"]
+
+
 def main():
     a = lift("models/wan/any2video.py", ["optimized_scale"])
     m = lift("models/wan/multitalk/multitalk_utils.py", ["MomentumBuffer", "project", "adaptive_projected_guidance"])
@@ -41,6 +56,13 @@ def main():
             out[f"cond_{i}"], out[f"uncond_{i}"] = c.numpy(), u.numpy()
             out[f"apg_{i}"] = m["adaptive_projected_guidance"](c - u, c, momentum_buffer=buf, norm_threshold=55).numpy()
         out["apg_nomom_eta"] = m["adaptive_projected_guidance"](steps[1][0] - steps[1][1], steps[1][0], eta=0.3, norm_threshold=0).numpy()
+    # CFG-Zero*: the branch itself, executed (steps <= cfg_zero_step and later ones); it scales its uncond argument in place
+    ns = dict(a); ns.update(m)
+    branch = lift_cfg_branch(ns)
+    c0, u0 = steps[0]
+    out["cfgzero_early"] = branch((c0.clone(), u0.clone()), 4.0, 2, 0, 1, 5, 1, None, 55).numpy()
+    out["cfgzero_late"] = branch((c0.clone(), u0.clone()), 4.0, 9, 0, 1, 5, 1, None, 55).numpy()
+    out["cfg_plain"] = branch((c0.clone(), u0.clone()), 4.0, 9, 0, 0, 5, 1, None, 55).numpy()
     par, orth = m["project"](steps[0][1], steps[0][0])
     out["proj_par"], out["proj_orth"] = par.numpy(), orth.numpy()
     np.savez_compressed(OUT, **out)

@@ -393,9 +393,10 @@ def unpatchify(x, grid, cfg: WanConfig):
 def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[torch.Tensor],
                 W, cfg: WanConfig, y: Optional[torch.Tensor] = None, freqs=None,
                 dtype=torch.bfloat16, exact: bool = False, return_hidden: bool = False, clip_fea: Optional[torch.Tensor] = None,
-                vace_context: Optional[torch.Tensor] = None, vace_scale: float = 1.0):
+                vace_context: Optional[torch.Tensor] = None, vace_scale: float = 1.0, probe=None):
     """x_list: S tensors [B,16,F,H,W] fp32; t [1]; context_list: S tensors [B,512,4096].
-    Returns S fp32 tensors [B,16,F,H,W] (model.py:2093-2097)."""
+    Returns S fp32 tensors [B,16,F,H,W] (model.py:2093-2097).
+    probe(i, s, hidden): called with stream s's token stream after block i (error-growth tables)."""
     hs = []
     grid = None
     for x in x_list:
@@ -426,6 +427,8 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
             hs[s] = block_forward(hs[s], e0, ctxs[s], cos, sin, W, i, cfg, exact)
             if skip is not None:                            # model.py:713-719: x.add_(hint[, alpha=scale])
                 hs[s] = hs[s] + skip if vace_scale == 1 else torch.add(hs[s], skip, alpha=vace_scale)
+            if probe is not None:
+                probe(i, s, hs[s])
     if return_hidden:
         return hs
     outs = []
@@ -648,7 +651,7 @@ def cfg_combine(cond: torch.Tensor, uncond: torch.Tensor, guide_scale: float) ->
 def sample_loop(W_hi, cfg: WanConfig, latents: torch.Tensor, ctx: torch.Tensor, ctx_null: torch.Tensor,
                 steps: int, shift: float, guide_scale: float, W_lo=None, switch_threshold: float = 0.0,
                 guide2_scale: Optional[float] = None, y=None, dtype=torch.bfloat16, exact=False,
-                solver: str = "unipc"):
+                solver: str = "unipc", on_step=None):
     """The t2v/i2v loop body of WanAny2V.generate (any2video.py:1470,1490-1501,
     1626-1634,1702-1722,1733): joint-pass CFG pair, expert switch at t <= switch_threshold
     (:1437-1443), scheduler step on fp32 latents.  Returns (latents, per-step latents)."""
@@ -675,6 +678,8 @@ def sample_loop(W_hi, cfg: WanConfig, latents: torch.Tensor, ctx: torch.Tensor, 
             noise = cfg_combine(cond, uncond, g)
         latents = sch.step(noise, latents) if solver == "unipc" else sch.step(noise, t, latents)
         trace.append(latents.clone())
+        if on_step is not None:
+            on_step(len(trace) - 1, latents)
     return latents, trace
 
 

@@ -1,0 +1,302 @@
+"""-m gpu: parity AT THE BASELINE CONFIGS (BASELINE.json `configs`, SURVEY.md section 8 shape table), through the C ABI.
+
+  config 1  Wan2.1 t2v 1.3B (dim 1536 / 12 heads / ffn 8960 / 30 layers), latent 16x5x40x64, L = 3,200:
+            * one joint CFG forward against the REFERENCE's own bf16 output (tests/golden/cfg1_forward.npz, produced by
+              oracle/make_golden_cfg1.py from /root/reference) and the fp32 anchor, with a per-layer error-growth table;
+            * the 10-step CFG UniPC loop, free running, against the reference's trajectory (tests/golden/cfg1_loop.npz),
+              with a per-step error-growth table.
+  config 3/5 one 14B-dim block (d 5120, 40 heads, ffn 13824) as a 1-layer model, CFG pair, L = 2,048 and 4,096, against
+            the CPU oracle (bf16 plan) and its fp32 anchor.
+  config 3  the shipped self-attention kernel (wan_attention_prescaled -> attn_w64q_kernel) at the bench shape
+            B=2, H=40, L=75,600: sampled q rows against an fp64 softmax computed on the GPU.
+  config 4  the same kernel at L = 147,600 (32-bit offset limits), and as one rank of world 8 sees it (8 gathered kv
+            segments of 18,450 rows), plus the workspace / shard arithmetic of that configuration.
+  config 3  gemm256k_kernel at the exact Wan shapes (M = 151,200; K, N in {5120, 13824}; every epilogue): sampled rows
+            against an fp64 matmul.
+
+Tolerances (stated):
+  forward / block:  err_hip <= 1.5 * err_ref + 2e-3 with err_x = |x - fp32 anchor| / |fp32 anchor| (the HIP path is no
+                    further from the exact graph than the reference's own bf16 run), and |hip - ref| / |ref| <= 2.5e-2
+                    (tests/test_gpu_model.py uses the same bar at toy dims).
+  per-layer table:  printed + written to gpurun_out/parity/ (committed under profiles/); every layer obeys the same
+                    1.5x + 2e-3 bar on the probed token rows.
+  10-step loop:     free running, so bf16 noise compounds: per step err_hip <= 2 * err_ref + 5e-3, final latents
+                    |hip - ref| / |ref| <= 2 * err_ref_final + 5e-3.
+  attention:        |err| <= 1.5e-2 abs, mean <= 2e-3 vs the fp64 softmax of the same (pre-scaled, bf16) q -- the
+                    tolerance of tests/test_gpu_ops.py at small shapes (P is rounded to bf16 before PV).
+  GEMM:             <= 2 bf16 ulp of max(|exact|, magnitude of the summed terms).
+"""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wan_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+def _report(name, obj):
+    """Tables go to stdout (pytest -s) and to gpurun_out/parity/<name>.json (merged back by gpurun; committed under profiles/)."""
+    d = os.path.join(ROOT, "gpurun_out", "parity")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+
+
+def _hip_model(cfg, W):
+    from wan2gp_amd.model import WanModelHIP
+    m = WanModelHIP(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads,
+                    num_layers=cfg.num_layers, in_dim=cfg.in_dim, out_dim=cfg.out_dim)
+    m.load_state_dict(W)
+    return m
+
+
+@pytest.fixture(scope="module")
+def cfg1():
+    """The full 1.3B model with the seeded synthetic checkpoint the goldens were produced with."""
+    cfg = O.make_config("t2v_1.3B")
+    t0 = time.time()
+    W = O.synth_weights(cfg)
+    m = _hip_model(cfg, W)
+    del W
+    print(f"[cfg1] 1.3B synthetic checkpoint resident in {time.time() - t0:.1f}s")
+    return cfg, m
+
+
+def test_cfg1_forward_vs_reference_golden(cfg1):
+    cfg, m = cfg1
+    g = dict(np.load(os.path.join(G, "cfg1_forward.npz")))
+    f, h, w = [int(v) for v in g["shape"]]
+    L = f * (h // 2) * (w // 2)
+    assert (cfg.dim, cfg.num_heads, cfg.ffn_dim, cfg.num_layers, L) == (1536, 12, 8960, 30, 3200)
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    t = torch.tensor([int(g["t"][0])], dtype=torch.int64)
+    rows = torch.from_numpy(g["probe_rows"]).long()
+    # hidden state of the cond stream after block i-1, read at the between-blocks poll of block i (model.py:1995-1996)
+    layers_hip = []
+
+    def cb(*a):
+        torch.cuda.synchronize()
+        layers_hip.append(m.debug_token_stream(2, L)[0, rows.cuda()].float().cpu())
+    outs = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()], callback=cb)
+    torch.cuda.synchronize()
+    layers_hip = layers_hip[1:]                                      # entry 0 = the embedded tokens (before block 0)
+    assert len(layers_hip) == cfg.num_layers - 1
+    lay_ref = torch.from_numpy(g["layers_bf16"]).view(BF).float()    # [30, rows, 1536] reference bf16
+    lay_a = torch.from_numpy(g["layers_fp32"])                      # fp32 anchor
+    table = []
+    for i, hh in enumerate(layers_hip):
+        er, eh, d = rel(lay_ref[i], lay_a[i]), rel(hh, lay_a[i]), rel(hh, lay_ref[i])
+        table.append({"layer": i, "err_ref": er, "err_hip": eh, "hip_vs_ref": d})
+    print("\n[cfg1 forward] per-layer error growth on %d probed token rows (cond stream), vs the fp32 anchor:" % len(rows))
+    for r in table:
+        print("  layer %2d  err_ref %.3e  err_hip %.3e  hip-vs-ref %.3e" % (r["layer"], r["err_ref"], r["err_hip"], r["hip_vs_ref"]))
+    res = {"layers": table, "outputs": {}}
+    for o, key in zip(outs, ("cond", "uncond")):
+        assert o.dtype == torch.float32 and tuple(o.shape) == (1, 16, f, h, w)
+        ref, a = torch.from_numpy(g[key + "_bf16"]), torch.from_numpy(g[key + "_fp32"])
+        er, eh, d = rel(ref, a), rel(o.cpu(), a), rel(o.cpu(), ref)
+        res["outputs"][key] = {"err_ref": er, "err_hip": eh, "hip_vs_ref": d}
+        print(f"[cfg1 forward] {key}: err_ref={er:.4e} err_hip={eh:.4e} hip-vs-ref={d:.4e}")
+    _report("cfg1_forward", res)
+    for r in table:
+        assert r["err_hip"] <= 1.5 * r["err_ref"] + 2e-3, r
+    for key, r in res["outputs"].items():
+        assert r["err_hip"] <= 1.5 * r["err_ref"] + 2e-3, (key, r)
+        assert r["hip_vs_ref"] <= 2.5e-2, (key, r)
+
+
+def test_cfg1_ten_step_loop_vs_reference_golden(cfg1):
+    """BASELINE configs[0] end to end on the DiT side: noise -> 10 x (joint CFG pass, combine, UniPC step)."""
+    from wan2gp_amd.pipeline import WanAny2VHIP
+    cfg, m = cfg1
+    g = dict(np.load(os.path.join(G, "cfg1_loop.npz")))
+    f, h, w = [int(v) for v in g["shape"]]
+    steps, shift, guide, sub = int(g["steps"][0]), float(g["shift"][0]), float(g["guide"][0]), int(g["sub"][0])
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    trace = []
+    pipe = WanAny2VHIP(m, device="cuda")
+    out = pipe.generate(context=ctx.cuda(), context_null=ctx_null.cuda(), width=w * 8, height=h * 8, frame_num=(f - 1) * 4 + 1,
+                        shift=shift, sample_solver="unipc", sampling_steps=steps, guide_scale=guide, latents=lat,
+                        return_latents=True, callback=lambda i, x, *a: trace.append(x.detach().float().cpu().reshape(-1)[::sub].clone())
+                        if i >= 0 else None)
+    assert len(trace) == steps
+    table = []
+    for i in range(steps):
+        ref, a = torch.from_numpy(g["sub_bf16"][i]), torch.from_numpy(g["sub_fp32"][i])
+        table.append({"step": i, "t": int(g["timesteps"][i]), "err_ref": rel(ref, a), "err_hip": rel(trace[i], a),
+                      "hip_vs_ref": rel(trace[i], ref)})
+    print("\n[cfg1 loop] per-step error growth (free running, every %d-th latent element), vs the fp32 anchor:" % sub)
+    for r in table:
+        print("  step %d (t=%3d)  err_ref %.3e  err_hip %.3e  hip-vs-ref %.3e" % (r["step"], r["t"], r["err_ref"], r["err_hip"], r["hip_vs_ref"]))
+    fin = out["latents"].cpu()
+    fr, fa = torch.from_numpy(g["final_bf16"]), torch.from_numpy(g["final_fp32"])
+    final = {"err_ref": rel(fr, fa), "err_hip": rel(fin, fa), "hip_vs_ref": rel(fin, fr)}
+    print(f"[cfg1 loop] final latents: err_ref={final['err_ref']:.4e} err_hip={final['err_hip']:.4e} hip-vs-ref={final['hip_vs_ref']:.4e}")
+    _report("cfg1_loop", {"steps": table, "final": final})
+    for r in table:
+        assert r["err_hip"] <= 2 * r["err_ref"] + 5e-3, r
+    assert final["hip_vs_ref"] <= 2 * final["err_ref"] + 5e-3, final
+
+
+@pytest.mark.parametrize("grid", [(4, 32, 64), (4, 64, 64)], ids=["L2048", "L4096"])
+def test_14B_block_cfg_pair_vs_oracle(grid):
+    """One WanAttentionBlock at the 14B dims (a 1-layer model: patch embed -> block -> head), CFG pair."""
+    f, h, w = grid
+    cfg = O.WanConfig(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1)
+    W32 = O.synth_weights(cfg, seed=2024, dtype=torch.float32)              # bf16-representable masters
+    W = {k: (v if k.startswith(O.FP32_LOCKED) else v.to(BF)) for k, v in W32.items()}
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w, seed=11)
+    t = torch.tensor([533], dtype=torch.int64)
+    m = _hip_model(cfg, W)
+    outs = [o.cpu() for o in m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])]
+    del m
+    t0 = time.time()
+    ref = O.dit_forward([lat, lat], t, [ctx, ctx_null], W, cfg, dtype=BF)
+    t1 = time.time()
+    anchor = O.dit_forward([lat, lat], t, [ctx.float(), ctx_null.float()], W32, cfg, dtype=torch.float32, exact=True)
+    print(f"\n[14B block L={f * h * w // 4}] oracle bf16 {t1 - t0:.1f}s, fp32 anchor {time.time() - t1:.1f}s on {torch.get_num_threads()} threads")
+    res = {}
+    for o, r, a, key in zip(outs, ref, anchor, ("cond", "uncond")):
+        er, eh, d = rel(r, a), rel(o, a), rel(o, r)
+        res[key] = {"err_ref": er, "err_hip": eh, "hip_vs_ref": d}
+        print(f"[14B block L={f * h * w // 4}] {key}: err_ref={er:.4e} err_hip={eh:.4e} hip-vs-ref={d:.4e}")
+    _report(f"block14B_L{f * h * w // 4}", res)
+    for key, r in res.items():
+        assert r["err_hip"] <= 1.5 * r["err_ref"] + 2e-3, (key, r)
+        assert r["hip_vs_ref"] <= 2.5e-2, (key, r)
+
+
+# ---- the shipped self-attention kernel at the bench / config-4 shapes ---------------------------------------------------
+def _attn_sampled_check(q, k, vt, got, pairs, n_rows, nseg=1, what=""):
+    """q [B,Lq,H,128] pre-scaled bf16, k [nseg,B,Lk,H,128], vt [nseg,B,H*128,ldv]; fp64 softmax on sampled rows."""
+    B, Lq, H, _ = q.shape
+    Lk = k.shape[2]
+    gen = torch.Generator().manual_seed(1)
+    worst, mean_acc, n = 0.0, 0.0, 0
+    for (b, hd) in pairs:
+        rows = torch.cat([torch.randperm(Lq - 40, generator=gen)[: n_rows - 40], torch.arange(Lq - 40, Lq)]).cuda()
+        kk = torch.cat([k[s, b, :, hd, :] for s in range(nseg)]).double()                       # [nseg*Lk, 128]
+        vv = torch.cat([vt[s, b, hd * 128:(hd + 1) * 128, :Lk] for s in range(nseg)], dim=1).double()   # [128, nseg*Lk]
+        s_ = q[b, rows, hd, :].double() @ kk.t()
+        p = torch.exp2(s_ - s_.amax(dim=-1, keepdim=True))
+        o = (p / p.sum(dim=-1, keepdim=True)) @ vv.t()
+        err = (got[b, rows, hd, :].double() - o).abs()
+        worst = max(worst, err.max().item()); mean_acc += err.mean().item(); n += 1
+    print(f"[attention {what}] {n} (stream, head) pairs x {n_rows} rows: max abs err {worst:.3e}, mean {mean_acc / n:.3e}")
+    assert worst <= 1.5e-2 and mean_acc / n <= 2e-3, (what, worst, mean_acc / n)
+    return {"max_abs_err": worst, "mean_abs_err": mean_acc / n, "pairs": n, "rows": n_rows}
+
+
+def _rand_qkv(B, Lq, Lk, H, nseg, seed):
+    from wan2gp_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = (torch.randn(B, Lq, H, 128, device="cuda", generator=g) * ops.attention_qscale()).to(BF)   # q * scale * log2 e, one rounding
+    k = torch.randn(nseg, B, Lk, H, 128, device="cuda", generator=g).to(BF)
+    ldv = (Lk + 63) // 64 * 64
+    vt = torch.zeros(nseg, B, H * 128, ldv, device="cuda", dtype=BF)
+    vt[..., :Lk] = torch.randn(nseg, B, H * 128, Lk, device="cuda", generator=g).to(BF)
+    return q, k, vt, ldv
+
+
+@pytest.mark.parametrize("B,L", [(2, 75600), (1, 147600)], ids=["cfg3_B2_H40_L75600", "cfg4_B1_H40_L147600"])
+def test_attention_prescaled_at_bench_shape(B, L):
+    from wan2gp_amd import ops
+    H = 40
+    q, k, vt, ldv = _rand_qkv(B, L, L, H, 1, seed=L)
+    got = ops.attention(q, k[0], vt[0], q_prescaled=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    pairs = [(0, 0), (0, 17), (B - 1, 39), (B - 1, 8)]
+    r = _attn_sampled_check(q, k, vt, got, pairs, 512, what=f"B={B} H={H} L={L}")
+    _report(f"attn_w64q_B{B}_L{L}", r)
+
+
+def test_cfg4_world8_rank_dryrun():
+    """BASELINE configs[3] (720p x 161f, L = 147,600) as ONE rank of a world of 8 sees it: shard arithmetic, workspace size
+    and 32-bit offset limits of wan_dit_forward, and the self-attention launch of that rank -- its 18,450 q rows against 8
+    gathered kv segments -- against the fp64 softmax of the concatenated segments."""
+    from wan2gp_amd import lib as L_, ops
+    from wan2gp_amd.model import WanModelHIP
+    from wan2gp_amd.sp import shard_range
+    F, Hl, Wl, world, H, d = 41, 90, 160, 8, 40, 5120
+    L = F * (Hl // 2) * (Wl // 2)
+    assert L == 147600 and L % world == 0
+    Ll = L // world
+    assert [shard_range(L, r, world) for r in (0, 7)] == [(0, Ll), (7 * Ll, 8 * Ll)]
+    m = WanModelHIP(dim=d, ffn_dim=13824, num_heads=H, num_layers=40)
+    need = L_.load().wan_dit_workspace_bytes(m._ctx, 2, F, Hl, Wl, world)
+    Lp = (Ll + 63) // 64 * 64
+    gathered = world * 2 * Ll * d * 2 + world * 2 * d * Lp * 2          # K and V^T of every rank, both CFG streams
+    assert gathered < need < 40e9, (need, gathered)
+    assert Ll * H * 256 < 2 ** 32 and Lp * 256 < 2 ** 32              # the DMA descriptors' 32-bit offsets (dit.hip fold_qscale guard)
+    print(f"\n[cfg4 world 8] L={L} tokens/rank={Ll} workspace/rank={need / 1e9:.2f} GB (gathered K,V^T {gathered / 1e9:.2f} GB)")
+    q, k, vt, ldv = _rand_qkv(2, Ll, Ll, H, world, seed=4)
+    got = ops.attention(q, k, vt, Lk=Ll, nseg=world, k_seg_stride=2 * Ll * H * 128, vt_seg_stride=2 * H * 128 * ldv, Bk=2,
+                        q_prescaled=True)
+    torch.cuda.synchronize()
+    r = _attn_sampled_check(q, k, vt, got, [(0, 3), (1, 39)], 256, nseg=world, what=f"rank view: Lq={Ll}, 8 x {Ll} kv")
+    _report("attn_w64q_cfg4_world8_rank", dict(r, workspace_bytes=int(need)))
+
+
+# ---- gemm256k at the Wan shapes ------------------------------------------------------------------------------------------
+def _bf16_close_rows(got, exact, floor, ulps=2, what=""):
+    diff = (got.double() - exact).abs()
+    tol = torch.maximum(exact.abs(), floor) * (2.0 ** -7) * ulps
+    bad = diff > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} beyond {ulps} bf16 ulp, worst {(diff / tol).max().item():.2f}x"
+    return (diff / tol).max().item()
+
+
+@pytest.mark.parametrize("K,N,epi", [(5120, 5120, 0), (5120, 5120, 2), (5120, 13824, 1), (13824, 5120, 2), (5120, 5120, 3)],
+                         ids=["qkv_none", "o_gate_res", "ffn1_gelu", "ffn2_gate_res", "v_transposed"])
+def test_gemm256k_at_wan_shapes(K, N, epi):
+    """M = 2 x 75,600 token rows (both CFG streams), the exact shapes of a 14B block.  Sampled rows (first / last tile,
+    the stream boundary, random) against an fp64 matmul on the GPU."""
+    from wan2gp_amd import ops
+    S, L = 2, 75600
+    M = S * L if epi != 3 else L                                        # V^T is produced per stream
+    g = torch.Generator(device="cuda").manual_seed(K + N + epi)
+    x = torch.randn(M, K, device="cuda", generator=g).to(BF)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(BF)
+    b = (0.1 * torch.randn(N, device="cuda", generator=g)).to(BF)
+    gen = torch.Generator().manual_seed(3)
+    rows = torch.cat([torch.arange(0, 8), torch.arange(M - 8, M), torch.arange(L - 4, L + 4) % M,
+                      torch.randperm(M, generator=gen)[:360]]).cuda()
+    acc = x[rows].double() @ w.double().t() + b.double()                # exact pre-rounding value
+    y = acc.float().to(BF).double()                                     # the Linear output is a bf16 tensor
+    one = torch.tensor(1.0, dtype=torch.float64, device="cuda")
+    if epi == 0:
+        got = ops.linear(x, w, b)
+        worst = _bf16_close_rows(got[rows], acc, 0.25 * one, what="none")
+    elif epi == 1:
+        got = ops.linear(x, w, b, epilogue=1)
+        ref = torch.nn.functional.gelu(y.float(), approximate="tanh").double()
+        worst = _bf16_close_rows(got[rows], ref, 0.25 * one, ulps=3, what="gelu")
+    elif epi == 2:
+        r = torch.randn(M, N, device="cuda", generator=g).to(BF)
+        mod = (torch.randn(1, 6, N, device="cuda", generator=g) / N ** 0.5).to(BF)
+        e0 = (0.5 * torch.randn(1, 6, N, device="cuda", generator=g)).to(BF)       # the CFG streams share t, hence e0
+        gate = (mod + e0)[0, 5].double()
+        ref = r[rows].double() + y * gate
+        got = ops.linear(x, w, b, epilogue=2, residual=r.clone(), mod=mod, e=e0, gate_idx=5)
+        worst = _bf16_close_rows(got[rows], ref, r[rows].double().abs() + (y * gate).abs(), what="gate residual")
+    else:
+        vt = ops.linear(x, w, b, epilogue=3)
+        assert vt.shape[1] % 64 == 0 and (vt[:, M:] == 0).all()
+        worst = _bf16_close_rows(vt[:, rows].t(), acc, 0.25 * one, what="V^T")
+    print(f"\n[gemm256k M={M} N={N} K={K} epi={epi}] worst error = {worst:.2f} x tolerance on {len(rows)} sampled rows")

@@ -32,8 +32,12 @@ def test_combine_branches():
     c, u = t("cond_0"), t("uncond_0")
     plain = G.combine(c, u, 4.0, 7)
     assert torch.equal(plain, u + 4.0 * (c - u))
-    assert torch.equal(G.combine(c, u, 4.0, 2, cfg_star_switch=1, cfg_zero_step=5), c * 0.)
+    # CFG-Zero*: goldens are the reference's own branch (any2video.py:1702-1722) executed on these inputs.  For steps
+    # <= cfg_zero_step the reference's zeroed prediction is overwritten by the plain CFG line (unscaled uncond).
+    assert torch.equal(G.combine(c, u, 4.0, 2, cfg_star_switch=1, cfg_zero_step=5), t("cfgzero_early"))
+    assert torch.equal(t("cfgzero_early"), t("cfg_plain")) and torch.equal(plain, G.combine(c, u, 4.0, 9))
+    assert torch.equal(G.combine(c, u, 4.0, 9, cfg_star_switch=1, cfg_zero_step=5), t("cfgzero_late"))
     a = t("alpha").view(1, 1, 1, 1)
-    assert torch.equal(G.combine(c, u, 4.0, 9, cfg_star_switch=1, cfg_zero_step=5), u * a + 4.0 * (c - u * a))
+    assert torch.equal(t("cfgzero_late"), u * a + 4.0 * (c - u * a))
     buf = G.MomentumBuffer(-0.75)
     assert torch.equal(G.combine(c, u, 4.0, 0, apg_switch=1, momentum_buffer=buf), c + 3.0 * t("apg_0"))

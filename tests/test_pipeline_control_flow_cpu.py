@@ -212,3 +212,66 @@ def test_i2v_start_image_conditions_every_step_and_is_restored_at_the_end():
               motion_amplitude=1.3)
     _, ext = pipe.build_i2v_conditioning(vid, 13, 32, 48, 0, 1.3)
     assert ext.shape[2] == 2 and torch.equal(out["latents"][:, :, :2], ext)
+
+
+# ---- round-2 advisor items ---------------------------------------------------------------------------------------------------
+def test_text_encoder_output_is_padded_like_the_reference():
+    """any2video.py:587-593: the UMT5 wrapper returns unpadded [n_tokens, 4096]; generate() zero-pads to text_len rows and
+    adds the batch axis before the DiT sees it."""
+    seen = []
+
+    class Dit(FakeDiT):
+        text_len = 512
+
+        def __call__(self, x, t, context, **kw):
+            seen.append([tuple(c.shape) for c in context] + [c.dtype for c in context] + [float(c[0, 100:].abs().sum()) for c in context])
+            return super().__call__(x, t, context, **kw)
+    enc_calls = []
+
+    def encoder(prompts, device):
+        enc_calls.append(list(prompts))
+        n = 7 if prompts[0] else 1
+        return [torch.ones(n, 4096)]                          # fp32, unpadded, like T5EncoderModel.__call__ (t5.py:709-716)
+    pipe = WanAny2VHIP(Dit("A"), device="cpu", text_encoder=encoder)
+    out = pipe.generate(input_prompt="a cat", n_prompt="", width=64, height=64, frame_num=9, sampling_steps=2, guide_scale=4.0,
+                        seed=1, return_latents=True)
+    assert out is not None and enc_calls == [["a cat"], [""]]
+    assert seen[0] == [(1, 512, 4096), (1, 512, 4096), torch.bfloat16, torch.bfloat16, 0.0, 0.0]
+
+
+def test_shared_cache_object_is_configured_once_from_model():
+    """wgp.py hands ONE cache object to both experts; the reference configures it once, from self.model (any2video.py:1396-1406)."""
+    from wan2gp_amd.skipcache import SkipStepsCache
+    a, b = FakeDiT("A"), FakeDiT("B")
+    a.cache = b.cache = SkipStepsCache(cache_type="mag", multiplier=2.0, start_step=1, magcache_K=2, magcache_thresh=0,
+                                       def_mag_ratios=[0.99] * 10, previous_residual=None)
+    run(WanAny2VHIP(a, b, device="cpu"), guide_phases=2, switch_threshold=800, model_switch_phase=1)
+    assert hasattr(a, "thresholds") and not hasattr(b, "thresholds")
+
+
+def test_parked_caches_come_back_when_a_forward_raises():
+    class Boom(FakeDiT):
+        def __call__(self, x, t, context, **kw):
+            raise RuntimeError("kernel failure")
+    m = Boom("A")
+    m.cache = types.SimpleNamespace(cache_type="mag", previous_residual=[1], previous_modulated_input=2)
+    with pytest.raises(RuntimeError):
+        run(WanAny2VHIP(m, device="cpu"), frame_num=17, sub_parallel_window_size=9, sub_parallel_window_overlap=1)
+    assert m.cache is not None and m.cache.previous_residual is None
+
+
+def test_clip_fea_reaches_the_model_and_i2v21_requires_it():
+    got = []
+
+    class Dit(FakeDiT):
+        model_type = "i2v"
+
+        def __call__(self, x, t, context, **kw):
+            got.append(kw.get("clip_fea"))
+            return super().__call__(x, t, context, **kw)
+    pipe = WanAny2VHIP(Dit("A"), device="cpu")
+    with pytest.raises(ValueError, match="clip_fea"):
+        run(pipe, y=torch.zeros(20, 3, 8, 8))
+    cf = torch.zeros(1, 257, 1280)
+    run(pipe, y=torch.zeros(20, 3, 8, 8), clip_fea=cf, sampling_steps=2)
+    assert got and all(g is cf for g in got)

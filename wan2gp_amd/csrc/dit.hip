@@ -549,7 +549,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     return 0;
   };
   for (int i = 0; i < g.num_layers; ++i) {
-    if (poll && poll(poll_user, i)) return 1;  // model.py:1995-1998
+    if (poll && poll(poll_user, i)) return WAN_ABORTED;  // model.py:1995-1998
     const int n = vace ? c->vace_at[i] : -1;
     if (n >= 0) {
       // VaceWanAttentionBlock.forward (model.py:816-828), called at the top of main block i (:617-629): the context block

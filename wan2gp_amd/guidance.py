@@ -54,7 +54,9 @@ def combine(cond, uncond, guide_scale, step_no, apg_switch=0, cfg_star_switch=0,
     if cfg_star_switch:
         b = cond.shape[0]
         alpha = optimized_scale(cond.view(b, -1), uncond.view(b, -1)).view(b, 1, 1, 1)
-        if step_no <= cfg_zero_step:
-            return cond * 0.
-        uncond = uncond * alpha                  # the reference scales uncond in place, then falls through to plain CFG
+        # any2video.py:1717-1722: for step_no <= cfg_zero_step the reference computes `noise_pred = text * 0.` and then
+        # OVERWRITES it with the plain CFG line below (which is not nested under the `if`), with an unscaled uncond; later
+        # steps scale uncond by alpha in place and fall through to the same line.
+        if step_no > cfg_zero_step:
+            uncond = uncond * alpha
     return uncond + guide_scale * (cond - uncond)

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwanhip.so")
 
 EPI_NONE, EPI_GELU_TANH, EPI_GATE_RES, EPI_TRANSPOSED = 0, 1, 2, 3
+WAN_ABORTED = 100     # wan_dit_forward*: stopped by the interrupt poll (include/wanhip.h)
 
 _lib = None
 

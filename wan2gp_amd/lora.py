@@ -249,9 +249,11 @@ _SUFFIXES = ((".lora_A.weight", "A"), (".lora_B.weight", "B"), (".lora_down.weig
              (".alpha", "alpha"), (".diff_b", "diff_b"), (".diff", "diff"))
 
 
-def group_adapter(sd: Dict[str, torch.Tensor]):
+def group_adapter(sd: Dict[str, torch.Tensor], errors: Optional[List[str]] = None):
     """{module name: {"A": [r,K], "B": [N,r], "alpha": float | None, "diff": [N,K] | None, "diff_b": [N] | None}} from
-    normalised keys `[diffusion_model.]<module>.lora_A.weight` ... (the layout load_loras_into_model consumes)."""
+    normalised keys `[diffusion_model.]<module>.lora_A.weight` ... (the layout load_loras_into_model consumes).
+    With `errors` (a list) problems are appended there and the offending key / module is skipped -- the reference
+    collects per-key problems in `_loras_errors` and keeps loading; without it they raise."""
     mods: Dict[str, dict] = {}
     for k, v in sd.items():
         for p in _PREFIXES:
@@ -263,12 +265,22 @@ def group_adapter(sd: Dict[str, torch.Tensor]):
                 mods.setdefault(k[: -len(suf)], {})[slot] = float(v) if slot == "alpha" else v
                 break
         else:
-            raise WanHipError(f"LoRA key {k!r}: unknown suffix (expected lora_A/lora_B/lora_down/lora_up/alpha/diff/diff_b)")
-    for name, m in mods.items():
+            msg = f"LoRA key {k!r}: unknown suffix (expected lora_A/lora_B/lora_down/lora_up/alpha/diff/diff_b)"
+            if errors is None:
+                raise WanHipError(msg)
+            errors.append(msg)
+    for name in list(mods):
+        m = mods[name]
+        msg = None
         if ("A" in m) != ("B" in m):
-            raise WanHipError(f"LoRA module {name!r}: lora_A without lora_B (or the reverse)")
-        if "A" in m and m["A"].shape[0] != m["B"].shape[1]:
-            raise WanHipError(f"LoRA module {name!r}: rank mismatch A {list(m['A'].shape)} / B {list(m['B'].shape)}")
+            msg = f"LoRA module {name!r}: lora_A without lora_B (or the reverse)"
+        elif "A" in m and m["A"].shape[0] != m["B"].shape[1]:
+            msg = f"LoRA module {name!r}: rank mismatch A {list(m['A'].shape)} / B {list(m['B'].shape)}"
+        if msg is not None:
+            if errors is None:
+                raise WanHipError(msg)
+            errors.append(msg)
+            del mods[name]
     return mods
 
 
@@ -300,7 +312,7 @@ class MergedLoras:
         """One LoRA file (state dict).  Returns its index; multipliers are applied by `set_multipliers`."""
         if not normalized:
             sd = normalize_lora_keys(dict(sd), base_model_type, i2v_class, getattr(self.model, "vace_layers", None))
-        mods = group_adapter(sd)
+        mods = group_adapter(sd, self.errors)
         dev = self.model.device
         for name, m in mods.items():
             for slot in ("A", "B", "diff", "diff_b"):

@@ -122,6 +122,13 @@ class WanModelHIP:
     def eval(self):
         return self
 
+    def debug_token_stream(self, S, L):
+        """View of the bf16 token streams [S, L_local, dim] inside the forward workspace (first region carved by
+        wan_dit_workspace_bytes).  Valid between blocks (inside `callback`) after a torch.cuda.synchronize(): the
+        per-layer error-growth tables of tests/test_gpu_baseline_configs.py read it."""
+        n = S * L * self.dim
+        return self._ws[: n * 2].view(torch.bfloat16).view(S, L, self.dim)
+
     # ---- forward ---------------------------------------------------------------------------------
     def _workspace(self, S, F, H, W, shards):
         need = _L.load().wan_dit_workspace_bytes(self._ctx, S, F, H, W, shards)
@@ -249,7 +256,7 @@ class WanModelHIP:
             RP = (c_void_p * S)(*[r.data_ptr() for r in bufs])
             rc = _L.load().wan_dit_forward_skip(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
                                                 ws.numel(), sp_struct, poll, None, FL, RP, stream_ptr())
-        if rc == 1:
+        if rc == _L.WAN_ABORTED:
             return [None] * S                               # model.py:1997-1998
         check(rc, "wan_dit_forward")
         if sp is not None:

@@ -130,14 +130,23 @@ class WanAny2VHIP:
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
-                 motion_amplitude=1.0, **bbargs):
+                 motion_amplitude=1.0, clip_fea=None, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
             if self.text_encoder is None or input_prompt is None:
                 raise ValueError("pass `context`/`context_null` ([1,512,4096] bf16) or a text_encoder + input_prompt")
-            context = self.text_encoder([input_prompt], self.device)[0]
-            context_null = self.text_encoder([n_prompt], self.device)[0]
+            # any2video.py:587-593: the encoder returns unpadded [n_tokens, 4096]; zero-pad to text_len and add the batch axis
+            text_len = getattr(self.model, "text_len", 512)
+
+            def _encode(prompt):
+                c = self.text_encoder([prompt], self.device)[0].to(torch.bfloat16)
+                return torch.cat([c, c.new_zeros(text_len - c.size(0), c.size(1))]).unsqueeze(0)
+            context = _encode(input_prompt)
+            context_null = _encode(n_prompt)
+        if getattr(self.model, "model_type", None) == "i2v" and clip_fea is None:
+            raise ValueError("a Wan2.1 i2v model (model_type 'i2v') needs clip_fea [1,257,1280]: the CLIP vision features of the "
+                             "start image (any2video.py:721-729)")
         dev = self.device
         sample_scheduler, timesteps = self._scheduler(sample_solver, sampling_steps, shift)
         seed_g = torch.Generator(device=dev)
@@ -193,9 +202,13 @@ class WanAny2VHIP:
                 m.cache = c
             return None
         # step-skipping caches (any2video.py:1398-1408): reset, then pick the threshold that meets cache.multiplier
+        # The reference configures only self.model.cache (any2video.py:1396-1406; wgp.py hands the SAME object to both
+        # experts): one reset, threshold from model's time embedding.  A distinct cache object on model2 gets its own setup.
+        seen = []
         for m in (self.model, self.model2):
             cache = getattr(m, "cache", None) if m is not None else None
-            if cache is not None:
+            if cache is not None and not any(cache is c for c in seen):
+                seen.append(cache)
                 from . import skipcache
                 skipcache.reset_for_generation(cache, 2)
                 cache.num_steps = len(timesteps)
@@ -205,64 +218,68 @@ class WanAny2VHIP:
                 else:
                     m.compute_magcache_threshold(cache.start_step, timesteps, cache.multiplier)
         kwargs = {"freqs": freqs, "pipeline": self, "callback": callback, "y": y, "max_steps": len(timesteps), **vace_kwargs}
-        for i, t in enumerate(timesteps):
-            # update_guidance (:1437-1443): phase 2 begins once t <= switch_threshold
-            if guide_phases >= 2 and not guidance_switch_done and t <= switch_threshold:
-                if model_switch_phase == 1 and self.model2 is not None:
-                    trans = self.model2
-                guide_scale, guidance_switch_done = guide2_scale, True
-            if guide_phases >= 3 and not guidance_switch2_done and t <= switch2_threshold:          # phase 3 (:1492)
-                if model_switch_phase == 2 and self.model2 is not None:
-                    trans = self.model2
-                guide_scale, guidance_switch2_done = guide3_scale, True
-            timestep = torch.stack([t])
-            kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": i})
-            if loras_slists is not None and getattr(trans, "loras", None) is not None:
-                trans.loras.set_step(loras_slists, len(timesteps), i, phase_switch_step, phase_switch_step2)
-            if ext_latents is not None:                      # any2video.py:1517-1523: re-noise the known first latent
-                f = float(t) / 1000.0
-                n = ext_latents.shape[2]
-                latents[:, :, :n] = ext_latents * (1.0 - f) + torch.randn_like(ext_latents) * f
-            def denoise_with_cfg(lat):                       # denoise_with_cfg_fn, plain two-stream branch (any2video.py:1610-1722)
-                nonlocal text_momentum
-                if guide_scale == 1 or not any_guidance:
-                    ret = trans(x=[lat], context=[context], **kwargs)
-                    return None if (self._interrupt or ret[0] is None) else ret[0]
-                if joint_pass:
-                    ret = trans(x=[lat, lat], context=[context, context_null], **kwargs)              # :1626-1634
-                    if self._interrupt or ret[0] is None:
-                        return None
-                else:
-                    ret = []
-                    for x_id, c in enumerate((context, context_null)):                               # :1638-1643
-                        r = trans(x=[lat], context=[c], x_id=x_id, **kwargs)[0]
-                        if self._interrupt or r is None:
+        if clip_fea is not None:
+            kwargs["clip_fea"] = clip_fea
+        try:
+            for i, t in enumerate(timesteps):
+                # update_guidance (:1437-1443): phase 2 begins once t <= switch_threshold
+                if guide_phases >= 2 and not guidance_switch_done and t <= switch_threshold:
+                    if model_switch_phase == 1 and self.model2 is not None:
+                        trans = self.model2
+                    guide_scale, guidance_switch_done = guide2_scale, True
+                if guide_phases >= 3 and not guidance_switch2_done and t <= switch2_threshold:          # phase 3 (:1492)
+                    if model_switch_phase == 2 and self.model2 is not None:
+                        trans = self.model2
+                    guide_scale, guidance_switch2_done = guide3_scale, True
+                timestep = torch.stack([t])
+                kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": i})
+                if loras_slists is not None and getattr(trans, "loras", None) is not None:
+                    trans.loras.set_step(loras_slists, len(timesteps), i, phase_switch_step, phase_switch_step2)
+                if ext_latents is not None:                      # any2video.py:1517-1523: re-noise the known first latent
+                    f = float(t) / 1000.0
+                    n = ext_latents.shape[2]
+                    latents[:, :, :n] = ext_latents * (1.0 - f) + torch.randn_like(ext_latents) * f
+                def denoise_with_cfg(lat):                       # denoise_with_cfg_fn, plain two-stream branch (any2video.py:1610-1722)
+                    nonlocal text_momentum
+                    if guide_scale == 1 or not any_guidance:
+                        ret = trans(x=[lat], context=[context], **kwargs)
+                        return None if (self._interrupt or ret[0] is None) else ret[0]
+                    if joint_pass:
+                        ret = trans(x=[lat, lat], context=[context, context_null], **kwargs)              # :1626-1634
+                        if self._interrupt or ret[0] is None:
                             return None
-                        ret.append(r)
-                if apg_switch != 0 or cfg_star_switch:
-                    # adaptive projected guidance / CFG-Zero* (:1703-1721; momentum -0.75, norm threshold 55, :1476-1478)
-                    from . import guidance
-                    if apg_switch != 0 and text_momentum is None:
-                        text_momentum = guidance.MomentumBuffer(-0.75)
-                    return guidance.combine(ret[0], ret[1], float(guide_scale), i, apg_switch, cfg_star_switch, cfg_zero_step,
-                                            text_momentum, 55)
-                return cfg_combine(ret[0], ret[1], float(guide_scale))                              # :1722
+                    else:
+                        ret = []
+                        for x_id, c in enumerate((context, context_null)):                               # :1638-1643
+                            r = trans(x=[lat], context=[c], x_id=x_id, **kwargs)[0]
+                            if self._interrupt or r is None:
+                                return None
+                            ret.append(r)
+                    if apg_switch != 0 or cfg_star_switch:
+                        # adaptive projected guidance / CFG-Zero* (:1703-1721; momentum -0.75, norm threshold 55, :1476-1478)
+                        from . import guidance
+                        if apg_switch != 0 and text_momentum is None:
+                            text_momentum = guidance.MomentumBuffer(-0.75)
+                        return guidance.combine(ret[0], ret[1], float(guide_scale), i, apg_switch, cfg_star_switch, cfg_zero_step,
+                                                text_momentum, 55)
+                    return cfg_combine(ret[0], ret[1], float(guide_scale))                              # :1722
 
-            if sub_windows is not None:                      # any2video.py:1724: one forward per temporal window, blended
-                from . import subparallel
-                noise_pred = subparallel.denoise(latents, denoise_with_cfg, sub_windows, sub_overlap, kwargs,
-                                                 (target_shape[2] // self.patch_size[1]) * (target_shape[3] // self.patch_size[2]))
-            else:
-                noise_pred = denoise_with_cfg(latents)
-            if noise_pred is None:
-                return restore_caches()
-            if isinstance(sample_scheduler, FlowMatchScheduler):                                    # :1463-1467
-                latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents)[0]
-            else:
-                latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
-            if callback is not None:
-                callback(i, latents[0], False)
-        restore_caches()
+                if sub_windows is not None:                      # any2video.py:1724: one forward per temporal window, blended
+                    from . import subparallel
+                    noise_pred = subparallel.denoise(latents, denoise_with_cfg, sub_windows, sub_overlap, kwargs,
+                                                     (target_shape[2] // self.patch_size[1]) * (target_shape[3] // self.patch_size[2]))
+                else:
+                    noise_pred = denoise_with_cfg(latents)
+                if noise_pred is None:
+                    return None
+                if isinstance(sample_scheduler, FlowMatchScheduler):                                    # :1463-1467
+                    latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents)[0]
+                else:
+                    latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
+                if callback is not None:
+                    callback(i, latents[0], False)
+        finally:
+            restore_caches()                                 # also when a forward raises: parked caches must come back
         if ext_latents is not None:
             latents[:, :, :ext_latents.shape[2]] = ext_latents                                     # :1755-1756
         if return_latents or self.vae is None:
