@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""bench.py -- denoise-steps/s of the Wan DiT hot path on MI355X (BASELINE.json metric).
+"""bench.py -- denoise-steps/s (+ end-to-end s/video) of the Wan DiT hot path on MI355X (BASELINE.json metric).
 
 One "step" = one iteration of the sampler loop at any2video.py:1490: a joint CFG pass
 (2 x WanModel.forward: cond + uncond), the CFG combine and one UniPC scheduler step, on
@@ -8,19 +8,30 @@ synthetic random latents / context / random-init weights of the named architectu
 region.  Default workload = BASELINE.json configs[2]: Wan2.2 t2v 14B (both experts resident),
 720p x 81 frames (latent 16x21x90x160, L = 75,600 tokens), bf16.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 14B-720p|1.3B-480p|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 14B-720p|1.3B-480p|i2v-14B-720p|tiny]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the token axis is sharded
-across ranks (temporal sequence parallelism) -- total work fixed -> "strong".
-Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU over RCCL; the token axis is sharded across ranks (temporal sequence parallelism,
+SURVEY.md section 8e) -- total work fixed -> "strong".  Launched by `torch.distributed.run` (the driver's way) the ranks
+are already there; launched as plain `python bench.py --gpus N` this process re-executes itself under
+torch.distributed.run with N ranks on 127.0.0.1.  Prints ONE JSON line on rank 0.
+
+Besides the contract fields the line carries
+  roofline      the dominant kernel (self-attention): algorithmic FLOP per launch / its average duration measured with HIP
+                events on the launch stream inside the timed region
+  e2e           end-to-end seconds per video: noise -> steps -> causal 3D VAE decode -> uint8 on the host, (a) measured
+                over the W+K steps this run executed and (b) composed for the 30-step default from the measured step time
+                plus the VAE decode / host copy measured in this run (text encoding excluded: the context is synthetic)
+  secondary     (N = 1) BASELINE configs[1], Wan2.1 t2v 1.3B 480x832x81f: a full generate() -- 30 steps + VAE decode
+  cpu_baseline  the oracle (CPU restatement of the reference, kind "port") on the host cores: BASELINE configs[0], one real
+                CFG step of the 1.3B model at L = 3,200 -- baseline only
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -29,11 +40,15 @@ WORKLOADS = {
     # name: (config, latent f,h,w, description)
     "14B-720p": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), (21, 90, 160),
                  "Wan2.2 t2v 14B 720x1280x81f (L=75600), CFG joint pass, UniPC, both experts resident"),
+    "i2v-14B-720p": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, model_type="i2v2_2"), (21, 90, 160),
+                     "Wan2.2 i2v 14B 720x1280x81f (L=75600, in_dim 36), CFG joint pass, UniPC, both experts resident, "
+                     "VAE encode of the conditioning video + decode in the e2e figure"),
     "1.3B-480p": (dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30), (21, 60, 104),
                   "Wan2.1 t2v 1.3B 480x832x81f (L=32760), CFG joint pass, UniPC"),
     "tiny": (dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2), (3, 16, 16), "plumbing check"),
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+VIDEO_STEPS = 30            # UI default sampling steps (defaults/t2v_2_2.json)
 
 
 def forward_flops(cfg, L, text_len=512):
@@ -45,13 +60,14 @@ def forward_flops(cfg, L, text_len=512):
 def random_weights(model, cfg, seed):
     """Random-init weights of the named architecture, generated directly in HBM."""
     import math
+    import torch
     g = torch.Generator(device="cuda").manual_seed(seed)
-    d, f = cfg["dim"], cfg["ffn_dim"]
+    d, f, cin = cfg["dim"], cfg["ffn_dim"], cfg.get("in_dim", 16)
 
     def rn(*shape, std=0.02, dtype=torch.bfloat16, mean=0.0):
         return (torch.randn(*shape, generator=g, device="cuda", dtype=torch.float32) * std + mean).to(dtype)
 
-    sd = {"patch_embedding.weight": rn(d, 16, 1, 2, 2, dtype=torch.float32), "patch_embedding.bias": rn(d, std=0.01, dtype=torch.float32),
+    sd = {"patch_embedding.weight": rn(d, cin, 1, 2, 2, dtype=torch.float32), "patch_embedding.bias": rn(d, std=0.01, dtype=torch.float32),
           "text_embedding.0.weight": rn(d, 4096), "text_embedding.0.bias": rn(d, std=0.01),
           "text_embedding.2.weight": rn(d, d), "text_embedding.2.bias": rn(d, std=0.01),
           "time_embedding.0.weight": rn(d, 256), "time_embedding.0.bias": rn(d, std=0.01),
@@ -73,33 +89,45 @@ def random_weights(model, cfg, seed):
     return model
 
 
-def cpu_baseline(cfg, L_full, n_layers):
-    """The oracle (CPU restatement of the reference, kind 'port') timed on the host cores on a
-    bounded sample: ONE 14B-config transformer block, CFG pair, at L=2048 tokens, scaled to a
-    full denoise step by the FLOP ratio.  Baseline only."""
+def cpu_baseline(flops_step_main):
+    """The oracle (CPU restatement of the reference, kind 'port', bit-exact to the reference on tests/golden/cfg1_forward.npz)
+    on the host cores: BASELINE configs[0] -- Wan2.1 t2v 1.3B, latent 16x5x40x64 (L = 3,200) -- ONE real CFG step (joint
+    cond + uncond forward of all 30 layers, CFG combine, UniPC step), all cores.  The 14B-720p figure
+    next to it is a FLOP-ratio extrapolation and labelled as such.  Baseline only."""
+    import torch
     from oracle import wan_oracle as O
-    ocfg = O.WanConfig(dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"], num_layers=1)
-    W = O.synth_weights(ocfg)
-    f, hh, ww = 4, 16, 32
-    Ls = f * hh * ww
-    g = torch.Generator().manual_seed(0)
-    hid = [torch.randn(1, Ls, ocfg.dim, generator=g).to(torch.bfloat16) for _ in range(2)]
-    e0 = (0.5 * torch.randn(1, 6, ocfg.dim, generator=g)).to(torch.bfloat16)
-    ctx = (0.5 * torch.randn(1, 512, ocfg.dim, generator=g)).to(torch.bfloat16)
-    cos, sin = O.rope_tables((f, hh, ww))
-    cores = torch.get_num_threads()
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.make_config("t2v_1.3B")
+    f, h, w = 5, 40, 64
+    t0 = time.perf_counter()
+    W = O.synth_weights(cfg)
+    t_w = time.perf_counter() - t0
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    sch = O.UniPCOracle()
+    ts = sch.set_timesteps(10, 5.0)
+    freqs = O.rope_tables((f, h // 2, w // 2))
     with torch.no_grad():
-        O.block_forward(hid[0][:, :256], e0, ctx, cos[:256], sin[:256], W, 0, ocfg)     # warm-up
+        O.dit_forward([lat[:, :, :1, :8, :8]], torch.stack([ts[0]]), [ctx], W, cfg)                 # warm-up: thread pool, kernels
         t0 = time.perf_counter()
-        for s in range(2):
-            O.block_forward(hid[s], e0, ctx, cos, sin, W, 0, ocfg)
+        cond, uncond = O.dit_forward([lat, lat], torch.stack([ts[0]]), [ctx, ctx_null], W, cfg, freqs=freqs)
+        sch.step(O.cfg_combine(cond, uncond, 5.0), lat)
         dt = time.perf_counter() - t0
-    fl_sample = 2 * forward_flops(dict(cfg, num_layers=1), Ls)
-    fl_step = 2 * forward_flops(cfg, L_full)
-    est = dt * fl_step / fl_sample
-    return {"value": 1.0 / est, "unit": "denoise-steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 of {n_layers} blocks, CFG pair, L={Ls} of {L_full} tokens: {dt:.2f} s measured "
-                      f"({fl_sample / dt / 1e12:.3f} TFLOP/s), scaled by FLOP ratio {fl_step / fl_sample:.0f}x"}
+    L = f * (h // 2) * (w // 2)
+    fl = 2 * forward_flops(dict(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_layers=cfg.num_layers), L)
+    return {"value": 1.0 / dt, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"BASELINE configs[0]: Wan2.1 t2v 1.3B 320x512x17f (L={L}), one full CFG step (2 forwards x 30 layers + "
+                      f"combine + UniPC) in the reference's bf16 plan: {dt:.2f} s measured ({fl / dt / 1e12:.3f} TFLOP/s); "
+                      f"synthetic checkpoint built in {t_w:.0f} s (untimed)",
+            "extrapolated_main_workload_steps_per_s": fl / dt / flops_step_main,
+            "extrapolation": f"FLOP ratio {flops_step_main / fl:.0f}x to the main workload (not measured; BASELINE.md section 3)"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -109,31 +137,47 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("WAN_BENCH_WORKLOAD", "14B-720p"), choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the VAE decode / end-to-end block")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU, RCCL, rendezvous on 127.0.0.1)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
+    import torch
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() < world and world > 1:
+        sys.exit(f"bench.py: {world} ranks need {world} GPUs on this node, found {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"          # RCCL sees every rank
+        chk = torch.ones(1, device="cuda")
+        dist.all_reduce(chk)
+        assert int(chk.item()) == world, "RCCL all-reduce did not see every rank"
 
     from wan2gp_amd import lib as L_
     from wan2gp_amd.model import WanModelHIP
-    from wan2gp_amd.pipeline import WanAny2VHIP
     from wan2gp_amd.rope import get_rotary_pos_embed
     from wan2gp_amd.schedulers import FlowUniPCMultistepScheduler, cfg_combine
 
     cfg, (f, h, w), desc = WORKLOADS[args.workload]
+    mcfg = {k: v for k, v in cfg.items()}
     L = f * (h // 2) * (w // 2)
-    two_experts = args.workload == "14B-720p"
-    model = random_weights(WanModelHIP(**cfg), cfg, 1234)
-    model2 = random_weights(WanModelHIP(**cfg), cfg, 4321) if two_experts else None
+    two_experts = args.workload in ("14B-720p", "i2v-14B-720p")
+    i2v = cfg.get("in_dim", 16) == 36
+    model = random_weights(WanModelHIP(**mcfg), cfg, 1234)
+    model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321) if two_experts else None
     if world > 1:
         from wan2gp_amd.sp import SequenceParallel
         sp = SequenceParallel(rank, world)
@@ -141,45 +185,87 @@ def main():
         if model2 is not None:
             model2.sp = sp
 
+    vae = None
+    want_e2e = not args.no_e2e and rank == 0 and args.workload != "tiny"
+    if want_e2e or i2v:
+        from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
+        vae = WanVAEHIP(state_dict=random_vae_state_dict())
+
     g = torch.Generator(device="cuda").manual_seed(42)
-    latents = torch.randn(1, 16, f, h, w, device="cuda", generator=g)
     ctx = (torch.randn(1, 512, 4096, device="cuda", generator=g) * 0.5).to(torch.bfloat16); ctx[:, 77:] = 0
     ctx_null = (torch.randn(1, 512, 4096, device="cuda", generator=g) * 0.5).to(torch.bfloat16); ctx_null[:, 8:] = 0
     freqs = get_rotary_pos_embed((f, h, w), device="cuda")
     sched = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
     total_steps = args.steps + args.warmup
-    sched.set_timesteps(max(30, total_steps), device="cuda", shift=12.0)
+    sched.set_timesteps(max(VIDEO_STEPS, total_steps), device="cuda", shift=12.0)
     guide, switch_threshold = 4.0, 875
     lib = L_.load()
 
-    def one_step(i, lat):
-        t = sched.timesteps[i]
-        trans = model2 if (model2 is not None and int(t) <= switch_threshold) else model
-        cond, uncond = trans([lat, lat], t=torch.stack([t]), context=[ctx, ctx_null], freqs=freqs)
-        noise = cfg_combine(cond, uncond, guide if trans is model else 3.0)
-        return sched.step(noise, t, lat)[0]
-
-    def barrier():
+    def sync():
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    # ---- the video starts here: (i2v: VAE-encode the conditioning clip,) noise ---------------------------------------------
+    sync()
+    t_video0 = time.perf_counter()
+    y, enc_s = None, None
+    if i2v:
+        # any2video.py:739-774: start image + zero frames -> VAE encode -> y = cat(mask[4], latents[16]); every rank encodes
+        te = time.perf_counter()
+        img = torch.rand(3, 1, h * 8, w * 8, device="cuda", generator=g) * 2 - 1
+        clip = torch.cat([img, torch.zeros(3, (f - 1) * 4, h * 8, w * 8, device="cuda")], dim=1)
+        lat_y = vae.encode([clip])[0]
+        msk = torch.zeros(4, f, h, w, device="cuda"); msk[:, 0] = 1
+        y = torch.cat([msk, lat_y])
+        del clip
+        torch.cuda.synchronize()
+        enc_s = time.perf_counter() - te
+    latents = torch.randn(1, 16, f, h, w, device="cuda", generator=g)
+
+    def one_step(i, lat):
+        t = sched.timesteps[i]
+        trans = model2 if (model2 is not None and int(t) <= switch_threshold) else model
+        cond, uncond = trans([lat, lat], t=torch.stack([t]), context=[ctx, ctx_null], freqs=freqs, y=y)
+        noise = cfg_combine(cond, uncond, guide if trans is model else 3.0)
+        return sched.step(noise, t, lat)[0]
+
     lat = latents
     for i in range(args.warmup):
         lat = one_step(i, lat)
-    barrier()
+    sync()
     lib.wan_prof_enable(1)
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         lat = one_step(i, lat)
-    barrier()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(lat).all(), "non-finite latents"
+
+    # ---- ... and ends here: causal 3D VAE decode -> uint8 on the host (rank 0; latents are replicated) --------------------------
+    e2e = None
+    if want_e2e:
+        td = time.perf_counter()
+        video = vae.decode_to_cpu_uint8([lat[0]], 0)[0]
+        torch.cuda.synchronize()
+        t_end = time.perf_counter()
+        dec_s = t_end - td
+        assert video.dtype == torch.uint8 and tuple(video.shape) == (3, (f - 1) * 4 + 1, h * 8, w * 8) and not video.is_cuda
+        step_s = dt / args.steps
+        e2e = {"unit": "s/video", "video": [3, (f - 1) * 4 + 1, h * 8, w * 8],
+               "measured_s": t_end - t_video0, "measured_sampling_steps": total_steps,
+               "measured_note": "noise -> W+K sampler steps (the first includes one-time workspace allocation) -> VAE decode -> uint8 "
+                                "on the host, wall clock of this run; text encoding excluded (synthetic context)",
+               "vae_decode_to_host_s": dec_s, "vae_encode_s": enc_s,
+               "composed_s_at_%d_steps" % VIDEO_STEPS: VIDEO_STEPS * step_s + dec_s + (enc_s or 0.0),
+               "composed_note": "%d x the step time of the timed region + the VAE times measured in this run" % VIDEO_STEPS}
+    if world > 1:
+        torch.distributed.barrier()
 
     import ctypes
     prof = {}
@@ -208,13 +294,13 @@ def main():
             kern["cross_attn_TFLOPs"] = 4.0 * S * Ll * 512 * d / (m4 / n4 * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "attn_pmc_traffic.json")
-        if os.path.isfile(pmc):
+        if os.path.isfile(pmc) and world == 1:
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("traffic_bytes")
+                traffic = json.load(open(pmc)).get(args.workload.replace("i2v-", ""), {}).get("traffic_bytes")
             except Exception:
                 traffic = None
         out = {
-            "metric": "denoise-steps/s", "value": args.steps / dt, "unit": "steps/s", "n_gpus": world,
+            "metric": "denoise-steps/s", "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "world": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
@@ -226,11 +312,54 @@ def main():
                          "flop_per_launch": attn_flops, "other_kernels": kern},
             "step_TFLOPs": 2 * forward_flops(cfg, L) / (dt / args.steps) / 1e12,
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, L, cfg["num_layers"])
+        if e2e is not None:
+            out["e2e"] = e2e
+        if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
+            out["secondary"] = secondary_1p3b(vae)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(2 * forward_flops(cfg, L))
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def secondary_1p3b(vae):
+    """BASELINE configs[1] on the same code: Wan2.1 t2v 1.3B 480x832x81f through WanAny2VHIP.generate() -- noise, 30 CFG
+    UniPC steps, VAE decode, uint8 frames on the host -- timed as a whole and per step."""
+    import torch
+    from wan2gp_amd.model import WanModelHIP
+    from wan2gp_amd.pipeline import WanAny2VHIP
+    cfg, (f, h, w), desc = WORKLOADS["1.3B-480p"]
+    m = random_weights(WanModelHIP(**cfg), cfg, 99)
+    if vae is None:
+        from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
+        vae = WanVAEHIP(state_dict=random_vae_state_dict())
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ctx = (torch.randn(1, 512, 4096, device="cuda", generator=g) * 0.5).to(torch.bfloat16); ctx[:, 77:] = 0
+    ctx_null = torch.zeros_like(ctx)
+    pipe = WanAny2VHIP(m, vae=vae, device="cuda")
+    stamps = []
+
+    def cb(i, *a):
+        if i >= 0:
+            torch.cuda.synchronize()
+            stamps.append(time.perf_counter())
+    kw = dict(context=ctx, context_null=ctx_null, width=w * 8, height=h * 8, frame_num=(f - 1) * 4 + 1, shift=5.0,
+              sample_solver="unipc", guide_scale=5.0, seed=3)
+    pipe.generate(sampling_steps=2, **kw)                                   # warm-up: workspace, VAE buffers
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = pipe.generate(sampling_steps=VIDEO_STEPS, callback=cb, **kw)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    assert out["x"].dtype == torch.uint8 and tuple(out["x"].shape) == (3, 81, h * 8, w * 8)
+    step_ms = (stamps[-1] - stamps[4]) / (len(stamps) - 5) * 1e3
+    L = f * (h // 2) * (w // 2)
+    return {"workload": desc, "metric": "denoise-steps/s", "value": 1e3 / step_ms, "ms_per_step": step_ms,
+            "sampling_steps": VIDEO_STEPS, "e2e_s_per_video": total, "vae_decode_to_host_s": total - (stamps[-1] - t0),
+            "step_TFLOPs": 2 * forward_flops(cfg, L) / (step_ms * 1e-3) / 1e12,
+            "note": "full generate(): noise -> 30 CFG steps -> VAE decode -> uint8 on host; step time = mean of steps 5..29"}
 
 
 if __name__ == "__main__":

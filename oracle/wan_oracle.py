@@ -140,7 +140,7 @@ def param_shapes(cfg: WanConfig) -> Dict[str, Tuple[int, ...]]:
 FP32_LOCKED = ("patch_embedding.", "head.")  # model.py:1331 (lock_layers_dtypes layer_list)
 
 
-def synth_weights(cfg: WanConfig, seed: int = 1234, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+def synth_weights(cfg: WanConfig, seed: int = 1234, dtype=torch.bfloat16, max_layers: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """Seeded synthetic checkpoint. fp32 master values are drawn first, then cast per the
     reference's dtype lock (patch_embedding/head fp32, rest `dtype`), so the bf16 and fp32
     plans share the *same* (bf16-representable) weights: the master is rounded through
@@ -148,6 +148,8 @@ def synth_weights(cfg: WanConfig, seed: int = 1234, dtype=torch.bfloat16) -> Dic
     g = torch.Generator().manual_seed(seed)
     out = {}
     for k, shp in param_shapes(cfg).items():
+        if max_layers is not None and k.startswith(f"blocks.{max_layers}."):
+            break       # a PREFIX of the checkpoint (embeddings + the first blocks, same values; no head): cheap partial checks
         if k.endswith("modulation"):
             w = torch.randn(shp, generator=g) / cfg.dim ** 0.5
         elif ("norm" in k or k in ("img_emb.proj.0.weight", "img_emb.proj.4.weight")) and k.endswith("weight"):
