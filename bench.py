@@ -96,7 +96,7 @@ def cpu_baseline(flops_step_main):
     next to it is a FLOP-ratio extrapolation and labelled as such.  Baseline only."""
     import torch
     from oracle import wan_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch's default intra-op pool = the physical cores (os.cpu_count() would add the SMT siblings: slower, not faster)
     cfg = O.make_config("t2v_1.3B")
     f, h, w = 5, 40, 64
     t0 = time.perf_counter()
@@ -120,6 +120,12 @@ def cpu_baseline(flops_step_main):
                       f"synthetic checkpoint built in {t_w:.0f} s (untimed)",
             "extrapolated_main_workload_steps_per_s": fl / dt / flops_step_main,
             "extrapolation": f"FLOP ratio {flops_step_main / fl:.0f}x to the main workload (not measured; BASELINE.md section 3)"}
+
+
+def log(msg):
+    """Progress on stderr (stdout carries exactly one JSON line)."""
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def free_port():
@@ -176,6 +182,7 @@ def main():
     L = f * (h // 2) * (w // 2)
     two_experts = args.workload in ("14B-720p", "i2v-14B-720p")
     i2v = cfg.get("in_dim", 16) == 36
+    log(f"workload {args.workload}: building random-init weights")
     model = random_weights(WanModelHIP(**mcfg), cfg, 1234)
     model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321) if two_experts else None
     if world > 1:
@@ -232,6 +239,7 @@ def main():
         return sched.step(noise, t, lat)[0]
 
     lat = latents
+    log(f"{args.warmup} warm-up + {args.steps} timed steps")
     for i in range(args.warmup):
         lat = one_step(i, lat)
     sync()
@@ -248,6 +256,7 @@ def main():
     assert torch.isfinite(lat).all(), "non-finite latents"
 
     # ---- ... and ends here: causal 3D VAE decode -> uint8 on the host (rank 0; latents are replicated) --------------------------
+    log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
     e2e = None
     if want_e2e:
         td = time.perf_counter()
@@ -315,9 +324,12 @@ def main():
         if e2e is not None:
             out["e2e"] = e2e
         if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
+            log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
             out["secondary"] = secondary_1p3b(vae)
         if not args.no_cpu_baseline and world == 1:
+            log("cpu_baseline: config-1 oracle step on the host cores")
             out["cpu_baseline"] = cpu_baseline(2 * forward_flops(cfg, L))
+        log("done")
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

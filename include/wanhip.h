@@ -121,10 +121,22 @@ int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, 
                       int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg,
                       int64_t k_seg_stride, int64_t vt_seg_stride, void* stream);
 /* wan_attention_seg for a q that already holds q * wan_attention_qscale() (see wan_rmsnorm_rope_scaled):
- * runs the issue-balanced 4x64 kernel (csrc/attention_w64q.hip) without its in-kernel pre-scaling pass. */
+ * runs the 4x64 kernel (csrc/attention_w64q.hip) without its in-kernel pre-scaling pass.  A K / V^T segment must stay
+ * inside the kernels' 32-bit DMA offsets: Lk * H * 256 < 2^32 (419,430 rows at 40 heads). */
 int wan_attention_prescaled(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B,
                             int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg,
                             int64_t k_seg_stride, int64_t vt_seg_stride, void* stream);
+/* The same kernel with caller-owned scratch for its K pre-pass: kmax_scratch = wan_attention_scratch_words(B, Bk, Lq, H)
+ * 4-byte words of device memory (overwritten; NULL = no pre-pass).  The pre-pass leaves max |k_h|^2 per (batch, head) in
+ * the first Bk*H floats; where |q~_row| * max|k_h| <= 96 (log2 units: no softmax term can overflow or go subnormal) for a
+ * whole 256-row workgroup, that workgroup skips the running-max bookkeeping altogether (softmax is shift-invariant; bf16 /
+ * fp32 carry P with relative precision); the others are flagged in the rest of the scratch and run the lazy-max loop in a
+ * second launch.  wan_attention / _seg / _prescaled do the same with a library-owned scratch ring.  q_prescaled != 0:
+ * q already holds q * wan_attention_qscale(). */
+int64_t wan_attention_scratch_words(int B, int Bk, int64_t Lq, int H);
+int wan_attention_bounded(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
+                          int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
+                          int64_t vt_seg_stride, int q_prescaled, float* kmax_scratch, void* stream);
 /* (1/sqrt(128)) * log2(e): the factor wan_attention_prescaled expects folded into q */
 float wan_attention_qscale(void);
 

@@ -237,7 +237,7 @@ def test_cfg4_world8_rank_dryrun():
     L = F * (Hl // 2) * (Wl // 2)
     assert L == 147600 and L % world == 0
     Ll = L // world
-    assert [shard_range(L, r, world) for r in (0, 7)] == [(0, Ll), (7 * Ll, 8 * Ll)]
+    assert [shard_range(L, r, world) for r in (0, 7)] == [(0, Ll), (7 * Ll, Ll)]          # (first token, count)
     m = WanModelHIP(dim=d, ffn_dim=13824, num_heads=H, num_layers=40)
     need = L_.load().wan_dit_workspace_bytes(m._ctx, 2, F, Hl, Wl, world)
     Lp = (Ll + 63) // 64 * 64

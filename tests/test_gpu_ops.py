@@ -409,3 +409,54 @@ def test_lincomb_and_cfg(ops):
     assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
     ref = ts[1] + 4.0 * (ts[0] - ts[1])
     assert torch.equal(ops.cfg_combine(cu(ts[0]), cu(ts[1]), 4.0).cpu(), ref)
+
+
+# ---- the two tile loops of attn_w64q_kernel: bounded softmax (K pre-pass proves |s| <= 96 log2 units) / lazy-max tracking ----
+@pytest.mark.parametrize("B,Lq,Lk,H,Bk", [(1, 300, 4160, 2, 1), (2, 520, 2200, 3, 2), (1, 64, 2049, 1, 1)])
+def test_attention_bounded_and_tracking_loops_agree_with_fp64(ops, B, Lq, Lk, H, Bk):
+    """The same inputs through (a) the bounded loop (caller scratch), (b) the library-scratch entry, (c) the tracking loop
+    (no pre-pass): each within the attention tolerance of the fp64 softmax, and the scratch holds max |k_h|^2 afterwards."""
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF); k = torch.randn(Bk, Lk, H, 128, generator=g).to(BF)
+    v = torch.randn(Bk, Lk, H, 128, generator=g).to(BF)
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    ref = _prescaled_ref(qs, k, v)
+    vt = ops.transpose_v(cu(v))
+    scratch = torch.full((ops.attention_scratch_words(B, Bk, Lq, H),), -1.0, device="cuda")
+    assert scratch.numel() == Bk * H + (Lq + 255) // 256 * H * B
+    outs = {"bounded": ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch),
+            "library scratch": ops.attention(cu(qs), cu(k), vt, q_prescaled=True),
+            "tracking": ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=False)}
+    kn = (k.float() ** 2).sum(-1).amax(dim=1).reshape(-1)                       # [Bk*H]
+    assert torch.allclose(scratch[:Bk * H].cpu(), kn, rtol=1e-5), (scratch.cpu(), kn)
+    assert (scratch[Bk * H:].view(torch.int32) == 0).all()                     # no workgroup had to fall back to the tracking loop
+    for name, o in outs.items():
+        err = (o.float().cpu() - ref).abs()
+        assert torch.isfinite(o.float()).all() and err.max().item() <= 1.5e-2 and err.mean().item() <= 2e-3, (name, err.max().item())
+    # unscaled q through the generic entry (in-kernel pre-scaling) takes the same kernel for long KV
+    o = ops.attention(cu(q), cu(k), vt).float().cpu()
+    assert (o - O.attention(q, k, v, exact=True).float()).abs().max().item() <= 1.5e-2
+
+
+def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
+    """Rows whose Cauchy-Schwarz bound |q~| * max|k| exceeds 96 log2 units must take the tracking loop -- per 256-row
+    workgroup: here q rows 256..511 are scaled 80x (scores up to +-1800 log2 units, far beyond fp32's exponent range if
+    exponentiated unshifted), the other workgroups stay bounded.  Both must match the fp64 softmax."""
+    g = torch.Generator().manual_seed(77)
+    B, Lq, Lk, H = 1, 700, 2300, 2
+    q = torch.randn(B, Lq, H, 128, generator=g); k = torch.randn(B, Lk, H, 128, generator=g).to(BF)
+    v = torch.randn(B, Lk, H, 128, generator=g).to(BF)
+    q[:, 256:512] *= 80.0
+    qs = (q * ops.attention_qscale()).to(BF)
+    scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
+    got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
+    assert scratch[B * H:].view(torch.int32).view(B * H, -1).cpu().tolist() == [[0, 1, 0]] * (B * H)   # q-block 1 of every head fell back
+    ref = _prescaled_ref(qs, k, v)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert err.max().item() <= 1.5e-2, err.max().item()
+    # and a K so large that every workgroup is out of bounds
+    k2 = (k.float() * 70).to(BF)
+    got2 = ops.attention(cu(qs), cu(k2), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
+    assert (scratch[B * H:].view(torch.int32) == 1).all()
+    assert torch.isfinite(got2).all() and (got2 - _prescaled_ref(qs, k2, v)).abs().max().item() <= 1.5e-2

@@ -1,42 +1,30 @@
-// Flash attention forward for gfx950, "4 x 64, issue-balanced" kernel: the structure of attention_w64.hip (4 waves =
-// one wave per SIMD, 64 q rows per wave as two 32-row q-blocks a and b, 3-deep LDS-DMA ring, asm MFMAs with pinned
-// register files) rebuilt around the SIMD's ISSUE budget.
+// Flash attention forward for gfx950, the "4 x 64" kernel: 4 waves = one wave per SIMD, 64 q rows per wave as two 32-row
+// q-blocks a and b, the whole 512-entry register file per wave, 3-deep LDS-DMA ring, asm MFMAs with pinned register
+// files -- built around the SIMD's ISSUE budget.
 //
-// Measured on MI355X (tools/probes/mfma_valu_probe.hip, s_memtime stamps of attention_w64.hip): a wave hides ~4 plain
-// VALU instructions under each 32-cycle v_mfma_f32_32x32x16_bf16; every further VALU costs ~4.6 cycles, v_exp_f32 ~8.5.
-// The classic online softmax needs ~4.7 VALU issue slots per score (fma, exp = 2 slots, max, add, 1/2 cvt_pk): 300+
-// slots per 64-MFMA tile against a budget of 256, and they cluster in half of the tile.  Hence:
-//   1. Q is pre-multiplied by scale*log2(e) once (bf16), and the running reference max m_ref enters through the
-//      matrix pipe: each S sub-tile starts with one extra MFMA  S := [1 1 1 0..](kv x 16) * [hi; mid; lo; 0..](16 x q)
-//      where hi + mid + lo = -m_ref exactly (three bf16 terms carry an fp32; a constant A fragment and a 4-register B
-//      fragment that is rewritten only when m_ref moves), so that
-//      S' = K Q~^T - m_ref  comes out ready for exp2 -- no per-score fma / subtract in the softmax stream, at the
-//      price of 4 MFMAs per 64.
-//   2. lazy max: m_ref is the row max of the first tile and afterwards only moves when a tile's max exceeds it by
-//      more than 2^THR (P <= 2^THR, exact in bf16/fp32); the O / l rescale is a rare wave-uniform branch.
-//   3. q-block b runs half a tile behind q-block a, so each of the tile's four 16-MFMA slots carries one half of one
-//      block's softmax, in chunks of <= 5 instructions per MFMA gap, staggered (exp of pair j next to add/pack of pair
-//      j-1) so that no instruction waits on the one before it.
-//   4. V^T fragments live in the accumulator file ("a" operands, filled by ds_read_b128 directly); K fragments, S, P
-//      and the -m_ref tuples in arch VGPRs.
-//
-//   A(t): S_a(t)  = K(t) Q_a^T - m_a   || softmax b(t-1) chunks 10..21 || LDS-DMA of tile t+2
-//   B(t): O_b    += V^T(t-1) P_b^T     || softmax a(t)   chunks 0..9
-//   C(t): S_b(t)  = K(t) Q_b^T - m_b   || softmax a(t)   chunks 10..21 || V^T(t) fragment reads
-//   D(t): O_a    += V^T(t) P_a^T       || softmax b(t)   chunks 0..9   || K(t+1) fragment reads
-//   chunks: 0-3 row max (quarters), 4 cross-half max + threshold test (+ rare rescale), 5 exp(pair 0),
-//           6..20 exp(pair j) + sum/pack(pair j-1), 21 sum/pack(pair 15).
-// Math, HBM layouts and LDS images are those of attention.hip (S^T = K Q^T, O^T = V^T P^T, V transposed in HBM, K rows
+// Measured on MI355X (tools/probes/mfma_valu_probe.hip, s_memtime stamps): a wave hides ~4 plain VALU instructions under
+// each 32-cycle v_mfma_f32_32x32x16_bf16; every further VALU costs ~4.6 cycles, v_exp_f32 ~8.5.  The classic online
+// softmax needs ~4.7 VALU issue slots per score (fma, exp = 2 slots, max, add, 1/2 cvt_pk): 300+ slots per 64-MFMA tile
+// against a budget of 256.  Hence, in both tile loops:
+//   * Q is pre-multiplied by scale*log2(e) once (bf16): scores come out of the matrix pipe ready for exp2;
+//   * q-block b runs half a tile behind q-block a and every MFMA gap carries exactly one v_exp_f32 ("flat" schedule);
+//   * V^T fragments live in the accumulator file ("a" operands, filled by ds_read_b128 directly); K fragments, S and P
+//     in arch VGPRs.
+// BOUNDED loop (tile_w64n; the hot one): a pre-pass over K (attn_kmax_kernel) gives max |k_h|^2 per (batch, head); when
+//   |Q~_row| * max|k_h| <= 96 for every row of the workgroup no score can leave [-96, 96] log2 units, so P = 2^s is
+//   exponentiated UNSHIFTED -- no running max, no rescale, 64 MFMAs per tile (see the comment at tile_w64n).
+// TRACKING loop (tile_w64f; any input): lazy reference max.  m_ref is the row max of the first tile and afterwards only
+//   moves when a tile's max exceeds it by more than 2^THR (P <= 2^THR, exact in bf16 / fp32); the O / l rescale is a rare
+//   wave-uniform branch.  -m_ref enters through the matrix pipe: each S sub-tile starts with one extra MFMA
+//   S := [1 1 1 0..](kv x 16) * [hi; mid; lo; 0..](16 x q) with hi + mid + lo = -m_ref exactly (three bf16 terms carry an
+//   fp32), 4 extra MFMAs per 64, no per-score subtract.
+// Math, HBM layouts and LDS images: attention.hip's header (S^T = K Q^T, O^T = V^T P^T, V transposed in HBM, K rows
 // bit-2/3 swapped, XOR-swizzled lane-linear LDS-DMA images).
 #include <stdlib.h>
 #include <string.h>
 
-// Ring depth 3: tile t+1 visible when tile t starts, tile t+2 in flight.  Depth 4 (two tiles in flight; build with
-// -DW64_NST=4) was measured neutral here (1246 vs 1250 TFLOP/s): at ~11 B/clk/CU the K/V stream is not latency-bound,
-// unlike the GEMMs (gemm256.hip gained 13 % from the same change).
-#ifndef W64_NST
-#define W64_NST 3
-#endif
+// Ring depth 3: tile t+1 visible when tile t starts, tile t+2 in flight (a depth of 4 was measured neutral: at ~11 B/clk/CU
+// the K/V stream is not latency-bound, unlike the GEMMs).
 #include "attn_w64_shared.h"
 
 namespace {
@@ -56,25 +44,19 @@ struct QB {          // one 32-row q-block of the wave
   float cur0, ps;    // flat schedule: first exp2 of the pair in progress; sum of the pending pair
   float tmax;        // flat schedule: row max of S' found by chunk 4 ...
   bool need;         // ... and its wave-uniform verdict, consumed by chunk 5 one MFMA later (a branch on a fresh VALU compare stalls)
+  hw_f32x2 pe2;      // bounded path: the exp2 pair whose sum / pack is pending (an aligned register pair: v_pk_add_f32 operand)
+  hw_f32x2 l2;       // bounded path: this lane's share of the row sum, even / odd scores
 };
 
 // O^T += V^T P^T with the V^T fragment in the accumulator file
-#ifndef W64Q_VF_AGPR_KSTEPS
-#define W64Q_VF_AGPR_KSTEPS 4  // V^T fragments of k-steps < this live in the accumulator file, the rest in arch VGPRs
-#endif
-__device__ __forceinline__ void pv_mfma(f32x16& acc, const mfma_bf16x8& v, const mfma_bf16x8& p, int c4) {
-  if (c4 < W64Q_VF_AGPR_KSTEPS) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(v), "v"(p));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(v), "v"(p));
+__device__ __forceinline__ void pv_mfma(f32x16& acc, const mfma_bf16x8& v, const mfma_bf16x8& p) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(v), "v"(p));
 }
 // i = 0, 1: S sub-tile i := -m_ref (ones x mfrag);  i = 2..17: k-step (i-2)>>1 of sub-tile i&1
 __device__ __forceinline__ void qk_stepq(QB& x, const mfma_bf16x8 (&kf)[2][8], const mfma_bf16x8 (&qf)[8],
                                          const mfma_bf16x8& kones, int i) {
   if (i < 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(x.s[i]) : "v"(kones), "v"(x.mfrag));
-#ifdef W64Q_KF_AGPR
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(x.s[i & 1]) : "a"(kf[i & 1][(i - 2) >> 1]), "a"(qf[(i - 2) >> 1]));
-#else
   else mfma_qk(x.s[i & 1], kf[i & 1][(i - 2) >> 1], qf[(i - 2) >> 1]);
-#endif
 }
 __device__ __forceinline__ void set_mref(QB& q, float nm, int half) {
   q.nm = nm;
@@ -148,91 +130,12 @@ __device__ __forceinline__ float row_tmax(const QB& q) {  // max of S' = s - m_r
   return t;
 }
 
-// softmax chunk idx of q-block q (see the header).  Every chunk ends in an opaque asm use of what it produced: that
-// pins it between the two asm MFMAs around it (LLVM would otherwise sink it into the block of its consumer).
+// row-max chunks 0..3 of q-block q (quarters of the tile's 32 scores per lane).  Every chunk ends in an opaque asm use of what
+// it produced: that pins it between the two asm MFMAs around it (LLVM would otherwise sink it into the block of its consumer).
 __device__ __forceinline__ void chunk(QB& q, int idx, int kv_rem, int half, bool first) {
-  if (idx < 4) {
-    if (idx == 0) mask_tail(q, kv_rem, half);
-    q.mt = max8(q.s[idx >> 1], (idx & 1) * 8, q.mt, idx != 0);
-    asm volatile("" : "+v"(q.mt));
-  } else if (idx == 4) {
-    const float t = row_tmax(q);
-    if (__builtin_expect(first || __any(t > LAZY_THR), 0)) move_mref(q, t, half, first);  // cold: out of line
-  } else {
-    const int j = idx - 5;  // pair whose exp2 is issued here (0..15); pair j-1 is summed and packed
-    float n0 = 0.f, n1 = 0.f;
-    if (j < 16) {
-      n0 = __builtin_amdgcn_exp2f(q.s[j >> 3][(j & 7) * 2]);
-      n1 = __builtin_amdgcn_exp2f(q.s[j >> 3][(j & 7) * 2 + 1]);
-    }
-    if (j > 0) {
-      const int jp = j - 1;
-      q.l_run += q.pe0 + q.pe1;
-      q.pk[jp >> 2][jp & 3] = cvt_pk(q.pe0, q.pe1);
-      asm volatile("" : "+v"(q.pk[jp >> 2]), "+v"(q.l_run));
-    }
-    if (j < 16) {
-      q.pe0 = n0;
-      q.pe1 = n1;
-      asm volatile("" : "+v"(q.pe0), "+v"(q.pe1));
-    }
-  }
-}
-
-template <int ST, bool TIMING>
-__device__ __forceinline__ void tile_w64q(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
-                                          const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
-                                          mfma_bf16x8 (&vf)[4][4], const mfma_bf16x8& kones, QB& a, QB& b, int kv_rem_prev,
-                                          int kv_rem, int half, bool first, bool first_prev, char* smem_rw, Dma& dma,
-                                          uint64_t* stamp, bool rec) {
-  constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
-#define STAMP(K) do { if (TIMING && rec) stamp[K] = __builtin_amdgcn_s_memtime(); } while (0)
-  // ---- A: S_a = -m_a + K Q_a^T (18 MFMAs)  ||  softmax b(t-1) chunks 10..21  ||  DMA of tile t+2
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    qk_stepq(a, kf, qfa, kones, i); SB();
-    if (i < 12) chunk(b, 10 + i, kv_rem_prev, half, first_prev);
-    if (i >= 10) dma_piece_i<DST>(smem_rw, dma, ((i - 10) & 1) * 4 + ((i - 10) >> 1));  // K0 V0 K1 V1 ...
-    SB();
-  }
-  dma_advance(dma);
-  SB();
-  STAMP(2);
-  // ---- B: O_b += V^T(t-1) P_b(t-1)^T  ||  softmax a(t) chunks 0..9
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    pv_mfma(b.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, b.pk[i >> 2]), i >> 2); SB();
-    if (i >= 2 && i <= 11) chunk(a, i - 2, kv_rem, half, first);
-    SB();
-  }
-  STAMP(3);
-  // ---- C: S_b = -m_b + K Q_b^T (18 MFMAs)  ||  softmax a(t) chunks 10..21  ||  V^T(t) fragments (two per gap)
-#pragma unroll
-  for (int i = 0; i < 18; ++i) {
-    qk_stepq(b, kf, qfb, kones, i); SB();
-    if (i < 12) chunk(a, 10 + i, kv_rem, half, first);
-    if (i >= 2 && i < 10) {
-      const int x0 = (i - 2) * 2, x1 = x0 + 1;
-      vf[x0 >> 2][x0 & 3] = *(lds_frag*)(smem + (VB + (x0 & 3) * 4096) + vaddr[x0 >> 2]);
-      vf[x1 >> 2][x1 & 3] = *(lds_frag*)(smem + (VB + (x1 & 3) * 4096) + vaddr[x1 >> 2]);
-    }
-    SB();
-  }
-  STAMP(4);
-  // ---- D: O_a += V^T(t) P_a(t)^T  ||  softmax b(t) chunks 0..9  ||  K(t+1) fragments
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    pv_mfma(a.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, a.pk[i >> 2]), i >> 2); SB();
-    if (i < 8) {
-      const int x0 = i * 2, x1 = x0 + 1;
-      kf[x0 >> 3][x0 & 7] = *(lds_frag*)(smem + (KN + (x0 >> 3) * 8192) + kaddr[x0 & 7]);
-      kf[x1 >> 3][x1 & 7] = *(lds_frag*)(smem + (KN + (x1 >> 3) * 8192) + kaddr[x1 & 7]);
-    }
-    if (i >= 2 && i <= 11) chunk(b, i - 2, kv_rem, half, first);
-    SB();
-  }
-  STAMP(5);
-#undef STAMP
+  if (idx == 0) mask_tail(q, kv_rem, half);
+  q.mt = max8(q.s[idx >> 1], (idx & 1) * 8, q.mt, idx != 0);
+  asm volatile("" : "+v"(q.mt));
 }
 
 // ---- flat schedule ("w64f") -------------------------------------------------------------------------------------
@@ -330,7 +233,7 @@ __device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8]
   // ---- B: O_b += V^T(t-1) P_b(t-1)^T
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    pv_mfma(b.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, b.pk[i >> 2]), i >> 2); SB();
+    pv_mfma(b.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, b.pk[i >> 2])); SB();
     FLAT_GAP(18 + i);
     SB();
   }
@@ -344,12 +247,131 @@ __device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8]
   // ---- D: O_a += V^T(t) P_a(t)^T
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    pv_mfma(a.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, a.pk[i >> 2]), i >> 2); SB();
+    pv_mfma(a.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, a.pk[i >> 2])); SB();
     FLAT_GAP(52 + i);
     SB();
   }
 #undef FLAT_GAP
 #undef STAMP
+}
+
+
+// ---- bounded schedule ("w64n"): no running max at all ----------------------------------------------------------------
+// A pre-pass (attn_kmax_kernel) leaves max_k |k_h|^2 per (batch, head).  With Q~ = q * scale * log2(e) every score obeys
+// |s| <= |Q~_row| * max|k_h| (Cauchy-Schwarz); when that bound is <= BOUND_LOG2 for every row of the workgroup,
+// P = 2^s can neither overflow nor go subnormal (2^-96 .. 2^96; row sums < 2^96 * 2^18, O likewise: fp32 range), and since
+// bf16 / fp32 carry P with a RELATIVE precision the result is the one the max-subtracting kernel computes, minus its
+// bookkeeping: no row max (16 v_max3 + cross-half swap + compare per q-block and tile), no threshold branch, no -m_ref
+// MFMAs (the S sub-tiles start from the inline constant 0) -- 64 MFMAs per tile and, per score, one v_exp_f32, half a
+// v_cvt_pk_bf16_f32 and half a v_pk_add_f32: ~190 issue slots against a budget of 4 x 64.  Anything beyond the bound
+// (scores that could exceed +-96 in log2 units = +-66 nats) runs the tracking loop below, unchanged.
+//   64 gaps: A 0..15 (S_a), B 16..31 (PV_b of tile t-1), C 32..47 (S_b), D 48..63 (PV_a).
+//   q-block a: exp2 of score k at gap 19 + k (19..50), tail (sum / pack of pair 15) at 51;
+//   q-block b: exp2 of score k at gap (51 + k) mod 64: 51..63 and 0..18 of the next tile, tail at 19  -> one v_exp_f32 in
+//   every gap; pair j is packed at the gap of score 2j + 2, >= 2 gaps before the PV MFMA that reads it
+//   (a: pair j at 21 + 2j, PV k-step c at 48 + 4c;  b: pair j at (53 + 2j) mod 64, PV k-step c at 16 + 4c of the next tile).
+//   LDS reads: V^T(t) fragment f at gap 18 + 2f (PV_b's MFMA f, its last reader, issued at 16 + f); K(t+1) fragments in
+//   need order, 8 at the odd gaps 49..63 and 8 at gaps 0..7 of the next tile; DMA pieces of tile t+2 at the odd gaps 9..23.
+constexpr float BOUND_LOG2 = 96.0f;
+__device__ __forceinline__ void expn(QB& q, int k, int kv_rem, int half) {
+  if (k == 0) mask_tail(q, kv_rem, half);  // cold: only a segment's ragged last tile (zero-filled K rows -> s = 0 -> -inf)
+  if ((k & 1) == 0) {
+    if (k >= 2) {
+      const int j = (k >> 1) - 1;
+      q.pk[j >> 2][j & 3] = cvt_pk(q.pe2[0], q.pe2[1]);
+      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(q.l2) : "v"(q.pe2));
+      asm volatile("" : "+v"(q.pk[j >> 2]));
+    }
+    q.pe2[0] = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
+  } else {
+    q.pe2[1] = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
+  }
+  asm volatile("" : "+v"(q.pe2));
+}
+__device__ __forceinline__ void exptail(QB& q) {
+  q.pk[3][3] = cvt_pk(q.pe2[0], q.pe2[1]);
+  asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(q.l2) : "v"(q.pe2));
+  asm volatile("" : "+v"(q.pk[3]));
+}
+// S sub-tile i&1, k-step i>>1 (i = 0..15); k-step 0 starts from the inline constant 0
+__device__ __forceinline__ void qk_stepn(QB& x, const mfma_bf16x8 (&kf)[2][8], const mfma_bf16x8 (&qf)[8], int i) {
+  if ((i >> 1) == 0) mfma_qk0(x.s[i & 1], kf[i & 1][0], qf[0]);
+  else mfma_qk(x.s[i & 1], kf[i & 1][i >> 1], qf[i >> 1]);
+}
+
+template <int ST, bool TIMING>
+__device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
+                                          const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
+                                          mfma_bf16x8 (&vf)[4][4], QB& a, QB& b, int kv_rem, int half, char* smem_rw,
+                                          Dma& dma, uint64_t* stamp, bool rec) {
+  constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
+#define BND_GAP(G)                                                                                               \
+  do {                                                                                                           \
+    if ((G) <= 18) expn(b, (G) + 13, kv_rem, half);                     /* q-block b, tile t-1: scores 13..31 */    \
+    if ((G) == 19) exptail(b);                                                                                    \
+    if ((G) >= 19 && (G) <= 50) expn(a, (G) - 19, kv_rem, half);        /* q-block a, tile t */                     \
+    if ((G) == 51) exptail(a);                                                                                    \
+    if ((G) >= 51) expn(b, (G) - 51, kv_rem, half);                     /* q-block b, tile t: scores 0..12 */       \
+    if ((G) >= 18 && (G) <= 48 && (((G) - 18) & 1) == 0) {              /* V^T(t) fragment f at gap 18 + 2f */      \
+      const int f = ((G) - 18) >> 1;                                                                              \
+      vf[f >> 2][f & 3] = *(lds_frag*)(smem + (VB + (f & 3) * 4096) + vaddr[f >> 2]);                             \
+    }                                                                                                            \
+    if ((G) >= 49 && (((G) - 49) & 1) == 0) {                           /* K(t+1), need order, first 8 */          \
+      const int r = ((G) - 49) >> 1, f = (r & 1) * 8 + (r >> 1);                                                  \
+      kf[f >> 3][f & 7] = *(lds_frag*)(smem + (KN + (f >> 3) * 8192) + kaddr[f & 7]);                             \
+    }                                                                                                            \
+    if ((G) <= 7) {                                                     /* K(t) read 8..15: this tile's stage */   \
+      const int r = 8 + (G), f = (r & 1) * 8 + (r >> 1);                                                          \
+      kf[f >> 3][f & 7] = *(lds_frag*)(smem + (ST * IMG + (f >> 3) * 8192) + kaddr[f & 7]);                       \
+    }                                                                                                            \
+    if ((G) >= 9 && (G) <= 23 && (((G) - 9) & 1) == 0) {                                                          \
+      const int pc = ((G) - 9) >> 1;                                    /* DMA pieces K0 V0 K1 V1 ... */           \
+      dma_piece_i<DST>(smem_rw, dma, (pc & 1) * 4 + (pc >> 1));                                                   \
+    }                                                                                                            \
+    if (TIMING && rec && ((G) & 3) == 3) stamp[3 + ((G) >> 2)] = __builtin_amdgcn_s_memtime();                    \
+  } while (0)
+  if (TIMING && rec) stamp[2] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // ---- A: S_a = K Q_a^T
+    qk_stepn(a, kf, qfa, i); SB();
+    BND_GAP(i);
+    SB();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // ---- B: O_b += V^T(t-1) P_b(t-1)^T
+    pv_mfma(b.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, b.pk[i >> 2])); SB();
+    BND_GAP(16 + i);
+    SB();
+  }
+  dma_advance(dma);
+  SB();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // ---- C: S_b = K Q_b^T
+    qk_stepn(b, kf, qfb, i); SB();
+    BND_GAP(32 + i);
+    SB();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // ---- D: O_a += V^T(t) P_a(t)^T
+    pv_mfma(a.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, a.pk[i >> 2])); SB();
+    BND_GAP(48 + i);
+    SB();
+  }
+#undef BND_GAP
+}
+
+// sum of squares of the 8 bf16 of one fragment
+__device__ __forceinline__ float sumsq8(const mfma_bf16x8& f) {
+  const uint4 w = __builtin_bit_cast(uint4, f);
+  const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+    s = __builtin_fmaf(lo, lo, s);
+    s = __builtin_fmaf(hi, hi, s);
+  }
+  return s;
 }
 
 // 8 bf16 -> * c -> 8 bf16 (round to nearest even)
@@ -364,17 +386,21 @@ __device__ __forceinline__ mfma_bf16x8 prescale8(const uint4 raw, float c) {
   return __builtin_bit_cast(mfma_bf16x8, o);
 }
 
-// FLAGS bit0: s_memtime stamps of tile 300 of workgroup 0 -> first 48 B of O (tuning aid)
+// FLAGS bit0: s_memtime stamps of tile 300 of workgroup 0 -> first 160 B of O (tuning aid; only built with -DW64Q_TIMING)
 //       bit1: q already holds q * scale * log2(e) (wan_rmsnorm_rope_scaled): skip the pre-scaling pass
-//       bit2: flat one-exp-per-gap schedule (tile_w64f) instead of the half-slot chunks (tile_w64q)
+//       bit2: BOUNDED instantiation.  The two tile loops are two instantiations of this kernel (in one body the register
+//             allocator needs 256 VGPRs + scratch; apart 202 / 226, no scratch), launched back to back: the bounded one
+//             first -- a workgroup whose rows fail the bound sets wg_flags[id] and returns before touching LDS -- then
+//             the tracking one, whose workgroups return at once unless their flag is set (wg_flags == NULL: all run).
 template <int FLAGS>
 __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int B, int Bk,
                                                        int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e,
-                                                       int nseg, int64_t k_seg_stride, int64_t vt_seg_stride) {
+                                                       int nseg, int64_t k_seg_stride, int64_t vt_seg_stride,
+                                                       const float* __restrict__ kmax2, int* __restrict__ wg_flags) {
   constexpr bool TIMING = (FLAGS & 1) != 0;
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
-  constexpr bool FLAT = (FLAGS & 4) != 0;  // one-exp-per-gap schedule (tile_w64f)
+  constexpr bool BND = (FLAGS & 4) != 0;
   uint64_t stamp[20] = {};
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stages][V^T stages] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
@@ -386,6 +412,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 
   const int total = nqb * H * B;
   const int v = xcd_remap(blockIdx.x, total);
+  if (!BND && wg_flags != nullptr && wg_flags[v] == 0) return;  // the bounded launch did this workgroup
   const int pair = v / nqb;
   const int qb = v - pair * nqb;
   const int b = pair / H, h = pair - b * H;
@@ -399,6 +426,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 
   const int64_t q0 = (int64_t)qb * 256 + wave * 64;
   mfma_bf16x8 qfa[8], qfb[8];  // Q~ = bf16(q * scale * log2 e)
+  float ssa = 0.f, ssb = 0.f;  // |Q~_row|^2, this lane's 64 of the row's 128 channels
   {
     int64_t ra = q0 + l31, rb = q0 + 32 + l31;
     if (ra > Lq - 1) ra = Lq - 1;
@@ -409,10 +437,24 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
       const uint4 wb = *reinterpret_cast<const uint4*>(qbase + rb * rs + ks * 16 + half * 8);
       qfa[ks] = PRESCALED ? __builtin_bit_cast(mfma_bf16x8, wa) : prescale8(wa, scale_log2e);
       qfb[ks] = PRESCALED ? __builtin_bit_cast(mfma_bf16x8, wb) : prescale8(wb, scale_log2e);
+      ssa += sumsq8(qfa[ks]);
+      ssb += sumsq8(qfb[ks]);
       // make each fragment ONE accumulator-file tuple from here on (otherwise the allocator keeps scattered master copies
       // and assembles the operand tuple with v_accvgpr_mov before every MFMA)
       asm volatile("" : "+a"(qfa[ks]));
       asm volatile("" : "+a"(qfb[ks]));
+    }
+  }
+
+  // ---- bounded softmax?  every row of the workgroup must satisfy |Q~_row| * max|k_h| <= BOUND_LOG2 (workgroup-uniform, so
+  // that the four waves run the same loop; both loops issue the same DMA pieces and barriers per tile)
+  if (BND) {
+    const float km = kmax2[bk * H + h];
+    const float sa = ssa + __shfl_xor(ssa, 32, 64), sb = ssb + __shfl_xor(ssb, 32, 64);
+    const bool ok = (sa * km <= BOUND_LOG2 * BOUND_LOG2) && (sb * km <= BOUND_LOG2 * BOUND_LOG2);  // false for NaN
+    if (__syncthreads_and(ok ? 1 : 0) == 0) {
+      if (tid == 0) wg_flags[v] = 1;
+      return;
     }
   }
 
@@ -454,6 +496,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
     asm volatile("" : "+v"(kones));
   }
   qa.l_run = qbk.l_run = 0.f;
+  qa.pe2 = qbk.pe2 = qa.l2 = qbk.l2 = hw_f32x2{0.f, 0.f};
   qa.pe0 = qa.pe1 = qbk.pe0 = qbk.pe1 = 0.f;
   qa.cur0 = qa.ps = qbk.cur0 = qbk.ps = 0.f;
   qa.tmax = qbk.tmax = 0.f;
@@ -480,12 +523,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 
   dma_tile<0>(smem, dma);
   dma_tile<1>(smem, dma);
-  if (NST == 4) {
-    dma_tile<2>(smem, dma);
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");  // tiles 0, 1 landed; tile 2's 8 pieces may be in flight
-  } else {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   mfma_bf16x8 kf[2][8];
@@ -495,42 +533,57 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
     for (int ks = 0; ks < 8; ++ks) kf[T][ks] = *(lds_frag*)(lds + T * 8192 + kaddr[ks]);
 
   int kv_rem_prev = KVBLK;
-#define W64Q_STEP(J)                                                                                         \
-  if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
+#define W64Q_TOP(J)                                                                                          \
     const bool rec = TIMING && (t + (J) == 300);                                                             \
     if (TIMING && rec) stamp[0] = __builtin_amdgcn_s_memtime();                                              \
     if (t + (J) > 0) {                                                                                       \
-      if (NST == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* tile t+J+1 landed; the next one's 8 pieces may fly */ \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile t+J+1 landed */                               \
       __builtin_amdgcn_s_barrier();                                                                          \
       asm volatile("" ::: "memory");                                                                         \
     }                                                                                                        \
     if (TIMING && rec) stamp[1] = __builtin_amdgcn_s_memtime();                                              \
-    const int kv_rem = next_kv_rem();                                                                        \
-    if (FLAT) tile_w64f<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, kones, qa, qbk, kv_rem, half, t + (J) == 0, smem, \
-                                   dma, stamp, rec);                                                         \
-    else tile_w64q<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, kones, qa, qbk, kv_rem_prev, kv_rem, half,  \
-                              t + (J) == 0, t + (J) == 1, smem, dma, stamp, rec);                            \
+    const int kv_rem = next_kv_rem();
+  if (BND) {
+#define W64N_STEP(J)                                                                                         \
+  if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
+    W64Q_TOP(J)                                                                                              \
+    tile_w64n<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, qa, qbk, kv_rem, half, smem, dma, stamp, rec);  \
     kv_rem_prev = kv_rem;                                                                                    \
   }
-  for (int t = 0; t < ntile; t += NST) {
-    W64Q_STEP(0)
-    W64Q_STEP(1)
-    W64Q_STEP(2)
-    if (NST == 4) { W64Q_STEP(3) }
+    for (int t = 0; t < ntile; t += NST) {
+      W64N_STEP(0)
+      W64N_STEP(1)
+      W64N_STEP(2)
+    }
+#undef W64N_STEP
+    // drain: q-block b's last tile
+#pragma unroll
+    for (int k = 13; k < 32; ++k) expn(qbk, k, kv_rem_prev, half);
+    exptail(qbk);
+    qa.l_run = qa.l2[0] + qa.l2[1];
+    qbk.l_run = qbk.l2[0] + qbk.l2[1];
+  } else {
+#define W64Q_STEP(J)                                                                                         \
+  if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
+    W64Q_TOP(J)                                                                                              \
+    tile_w64f<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, kones, qa, qbk, kv_rem, half, t + (J) == 0, smem, dma, stamp,  \
+                         rec);                                                                               \
+    kv_rem_prev = kv_rem;                                                                                    \
   }
+    for (int t = 0; t < ntile; t += NST) {
+      W64Q_STEP(0)
+      W64Q_STEP(1)
+      W64Q_STEP(2)
+    }
 #undef W64Q_STEP
-  // drain: q-block b's last tile
-  if (FLAT) {
+    // drain: q-block b's last tile
 #pragma unroll
     for (int c = 9; c < 38; ++c) chunkf(qbk, c, kv_rem_prev, half, false);
-  } else {
-#pragma unroll
-    for (int idx = 10; idx < 22; ++idx) chunk(qbk, idx, kv_rem_prev, half, ntile == 1);
   }
+#undef W64Q_TOP
   asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < 16; ++i) pv_mfma(qbk.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, qbk.pk[i >> 2]), i >> 2);
+  for (int i = 0; i < 16; ++i) pv_mfma(qbk.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, qbk.pk[i >> 2]));
 
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA lands before O staging reuses LDS; last PV MFMAs -> accumulator reads
   // ---- epilogue: normalise, stage the wave's 64 x 128 O tile through LDS, store whole rows -------------------
@@ -571,30 +624,84 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   }
 }
 
+// max_k |k_h|^2 per (batch, head), over every kv row of every segment: one workgroup per (1024-row slab, batch x head,
+// segment); 16 lanes read one row's 256-byte head slice, reduce it with 4 shuffles; squares are >= 0, so their float bits
+// order like unsigned integers and one atomicMax per workgroup finishes the job (out is zeroed by the launcher).
+// 1.5 GB at 14B-720p: ~0.4 ms in front of a 180 ms attention launch.
+constexpr int KMAX_ROWS = 1024;
+__global__ __launch_bounds__(256) void attn_kmax_kernel(const bf16_t* __restrict__ Kg, float* __restrict__ out, int Bk, int64_t Lk,
+                                                       int H, int64_t k_seg_stride) {
+  const int bh = blockIdx.y, bk = bh / H, h = bh - bk * H;
+  const int grp = threadIdx.x >> 4, ln = threadIdx.x & 15;
+  const int64_t rs = (int64_t)H * 128;
+  const bf16_t* base = Kg + (int64_t)blockIdx.z * k_seg_stride + ((int64_t)bk * Lk) * rs + (int64_t)h * 128 + ln * 8;
+  const int64_t r0 = (int64_t)blockIdx.x * KMAX_ROWS;
+  float m = 0.f;
+  for (int64_t r = r0 + grp; r < r0 + KMAX_ROWS && r < Lk; r += 16) {
+    const uint4 w = *reinterpret_cast<const uint4*>(base + r * rs);
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+      s = __builtin_fmaf(lo, lo, s);
+      s = __builtin_fmaf(hi, hi, s);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    m = fmaxf(m, s);  // +inf survives (-> tracking loop); a NaN in K makes every output NaN in either loop
+  }
+  m = wave_max(m);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float mm = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    atomicMax(reinterpret_cast<unsigned int*>(out + bh), __float_as_uint(mm));
+  }
+}
+
 }  // namespace
 
-// called from attention.hip's dispatcher.  flags bit0: s_memtime stamps (tuning aid); bit1: q is pre-scaled; bit2: flat schedule
+// called from attention.hip's dispatcher.  flags bit1: q is pre-scaled.  kmax_scratch: wan_attention_scratch_words() 4-byte
+// words (the K pre-pass maxima + one flag per workgroup), or NULL (tracking loop only)
 int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
                               int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
-                              int64_t vt_seg_stride, float scale_log2e, hipStream_t stream) {
+                              int64_t vt_seg_stride, float scale_log2e, float* kmax_scratch, hipStream_t stream) {
   WAN_REQUIRE(Lk * (int64_t)H * 256 < ((int64_t)1 << 32) && ldv * 256 < ((int64_t)1 << 32),
               "wan_attention: K/V^T extent exceeds the 32-bit DMA offsets of this kernel");
   const int64_t nqb = (Lq + 255) / 256;
   const int64_t total = nqb * H * B;
   WAN_REQUIRE(total < ((int64_t)1 << 31), "wan_attention: grid too large");
+  int* wg_flags = nullptr;
+  if (kmax_scratch != nullptr) {
+    // pre-pass: max over the kv rows (all segments) of |k_h|^2 per (batch, head) -> the bounded-softmax test of the kernel;
+    // the workgroup flags follow the maxima in the scratch
+    wg_flags = reinterpret_cast<int*>(kmax_scratch + (size_t)Bk * H);
+    WAN_CHECK_HIP(hipMemsetAsync(kmax_scratch, 0, ((size_t)Bk * H + (size_t)total) * 4, stream));
+    const int rblocks = (int)((Lk + KMAX_ROWS - 1) / KMAX_ROWS);
+    hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(Bk * H), (unsigned)nseg), dim3(256), 0, stream, k,
+                       kmax_scratch, Bk, Lk, H, k_seg_stride);
+    WAN_LAUNCH_CHECK();
+  }
 #define W64Q_LAUNCH(FL)                                                                                              \
   hipLaunchKernelGGL((attn_w64q_kernel<FL>), dim3((unsigned)total), dim3(256), 0, stream, q, k, vt, o, B, Bk, Lq, Lk, \
-                     ldv, H, (int)nqb, scale_log2e, nseg, k_seg_stride, vt_seg_stride)
-  switch (flags & 7) {
-    case 0: W64Q_LAUNCH(0); break;
-    case 1: W64Q_LAUNCH(1); break;
-    case 2: W64Q_LAUNCH(2); break;
-    case 3: W64Q_LAUNCH(3); break;
-    case 4: W64Q_LAUNCH(4); break;
-    case 5: W64Q_LAUNCH(5); break;
-    case 6: W64Q_LAUNCH(6); break;
-    default: W64Q_LAUNCH(7); break;
+                     ldv, H, (int)nqb, scale_log2e, nseg, k_seg_stride, vt_seg_stride, (const float*)kmax_scratch, wg_flags)
+  const bool pre = (flags & 2) != 0;
+#ifdef W64Q_TIMING
+  static const bool stamps = [] { const char* e = getenv("WAN_ATTN_STAMPS"); return e && e[0] == '1'; }();
+  if (stamps) {  // stamps of the loop that runs: bounded if there is a pre-pass, else tracking
+    if (kmax_scratch != nullptr) { if (pre) W64Q_LAUNCH(7); else W64Q_LAUNCH(5); }
+    else { if (pre) W64Q_LAUNCH(3); else W64Q_LAUNCH(1); }
+    WAN_LAUNCH_CHECK();
+    return 0;
   }
+#endif
+  if (kmax_scratch != nullptr) {
+    if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4);
+    WAN_LAUNCH_CHECK();
+  }
+  if (pre) W64Q_LAUNCH(2); else W64Q_LAUNCH(0);
 #undef W64Q_LAUNCH
   WAN_LAUNCH_CHECK();
   return 0;

@@ -1,4 +1,4 @@
-// Shared pieces of the "4 waves x 64 q rows" attention kernels (attention_w64.hip, attention_w64q.hip): fragment
+// Shared pieces of the "4 waves x 64 q rows" attention kernel (attention_w64q.hip): fragment
 // types, the inline-asm MFMAs that pin operands to the VGPR / accumulator files, and the per-wave LDS-DMA stream.
 #pragma once
 #include "common.h"
@@ -14,10 +14,7 @@ typedef __attribute__((address_space(3))) const mfma_bf16x8 lds_frag;
 
 constexpr int KVBLK = 64;
 constexpr int IMG = 16384;  // bytes per K or V^T image
-#ifndef W64_NST
-#define W64_NST 3
-#endif
-constexpr int NST = W64_NST;  // LDS ring depth (the including kernel may set W64_NST)
+constexpr int NST = 3;  // LDS ring depth
 
 __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
   hw_f32x2 v = {lo, hi};

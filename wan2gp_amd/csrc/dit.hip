@@ -36,9 +36,6 @@ int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const fl
                    float* out, int B, int F, int Hg, int Wg, int d, float eps, int64_t tok0, int64_t ntok,
                    int token_major_out, int e_shared, int nout, void* stream);
 int wan_sinusoid_val(float t, bf16_t* out, int dim, void* stream);
-extern "C" int wan_attention_seg(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
-                                 int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
-                                 int64_t vt_seg_stride, void* stream);
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ----
 // Off by default.  When enabled, wan_dit_forward brackets the launches of each class with a
@@ -302,6 +299,7 @@ struct Carve {
 
 struct Bufs {
   bf16_t *x, *xm, *q, *k, *vt, *h, *ctx_h, *ctx_e, *ck, *cvt, *sinus, *e_h, *e, *e_s, *e0, *kfull, *vtfull, *ckimg, *cvtimg, *vc, *vskip;
+  float* kmax;  // scratch of the self-attention K pre-pass (wan_attention_bounded): wan_attention_scratch_words(S, S, Ll, heads)
   int64_t Lp;
 };
 
@@ -326,6 +324,7 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.e = c.take<bf16_t>(d);
   t.e_s = c.take<bf16_t>(d);
   t.e0 = c.take<bf16_t>(6 * d);
+  t.kmax = c.take<float>(wan_attention_scratch_words(S, S, Ll, g.num_heads));
   t.ckimg = c.take<bf16_t>((int64_t)CLIP_TOK * d);      // i2v CLIP branch: K_img [257, d] and V_img^T [d, 320] (3.3 + 3.3 MB at 14B)
   t.cvtimg = c.take<bf16_t>((int64_t)d * CLIP_LDV);
   t.vc = vace ? c.take<bf16_t>(rows * d) : nullptr;      // VACE: the hint token streams and the projected hint of one block
@@ -441,11 +440,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
 
   // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups (rpb = rows in run_blocks)
 
-  // Self-attention: fold softmax scale * log2(e) into q inside the fused RMSNorm+RoPE kernel (in front of q's single
-  // bf16 rounding) and run the pre-scaled attention kernel.  WAN_DIT_EXACT_QSCALE=1 keeps the scale on the fp32 scores
-  // (reference rounding points; slower kernel).
-  static const bool exact_env = [] { const char* e = getenv("WAN_DIT_EXACT_QSCALE"); return e && e[0] == '1'; }();
-  const bool fold_qscale = !exact_env && Ll * (int64_t)nh * 256 < ((int64_t)1 << 32) && Lp * 256 < ((int64_t)1 << 32);
+  // Self-attention: softmax scale * log2(e) is folded into q inside the fused RMSNorm+RoPE kernel (in front of q's single
+  // bf16 rounding); the attention kernel's score tiles then come out of the matrix pipe ready for exp2.
 
   // ---- step-skipping: park x_before in the residual buffer, or add the stored residual and skip (model.py:1967-1990) ----
   const int64_t sn = Ll * (int64_t)d;
@@ -475,8 +471,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   auto run_blocks = [&](const int s0, const int Sn) -> int {
   const int S = Sn;
   const int64_t rows = (int64_t)Sn * Ll, rpb = rows;
-  struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; } b2 = {
-      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg};
+  struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; } b2 = {
+      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax};
   bf16_t* const x_main = b.x + s0 * sn;
   bf16_t* vc = vace ? b.vc + s0 * sn : nullptr;      // hint streams of this run; vskip doubles as the swap buffer of before_proj
   bf16_t* vskip = vace ? b.vskip : nullptr;
@@ -497,8 +493,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream));
     {
       ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
-      RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps,
-                                 fold_qscale ? wan_attention_qscale() : 1.0f, stream));
+      RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(),
+                                 stream));
     }
     if (world > 1) {
       if (sp->gather_begin(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream) ||
@@ -507,11 +503,11 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
         return 3;
       }
       ProfScope ps(PROF_SELF_ATTN, st);
-      RC((fold_qscale ? wan_attention_prescaled : wan_attention_seg)(b.q, b.kfull, b.vtfull, b.q, S, S, Ll, Ll, Lp, nh, world,
-                                                                   rows * (int64_t)d, (int64_t)S * d * Lp, stream));
+      RC(wan_attention_bounded(b.q, b.kfull, b.vtfull, b.q, S, S, Ll, Ll, Lp, nh, world, rows * (int64_t)d, (int64_t)S * d * Lp, 1,
+                               b.kmax, stream));
     } else {
       ProfScope ps(PROF_SELF_ATTN, st);
-      RC((fold_qscale ? wan_attention_prescaled : wan_attention_seg)(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, stream));
+      RC(wan_attention_bounded(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, 1, b.kmax, stream));
     }
     RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb));
     // -- cross attention (model.py:663-668, :245-265) --

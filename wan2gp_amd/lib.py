@@ -68,6 +68,9 @@ SIGNATURES = {
                                   c_int, c_int, c_int64, c_int64, c_void_p]),
     "wan_attention_prescaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
                                         c_int, c_int, c_int64, c_int64, c_void_p]),
+    "wan_attention_bounded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
+                                      c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "wan_attention_scratch_words": (c_int64, [c_int, c_int, c_int64, c_int]),
     "wan_attention_qscale": (c_float, []),
     "wan_transpose_v": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "wan_t5_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -45,6 +45,11 @@ def rmsnorm_rope_(q, k, wq, wk, freqs=None, eps=1e-6, L=None, pos0=0, q_scale=1.
     return q, k
 
 
+def attention_scratch_words(B, Bk, Lq, H):
+    """4-byte words of scratch attention(..., kmax_scratch=) needs: Bk*H maxima + one flag per 256-row workgroup."""
+    return int(_L.load().wan_attention_scratch_words(B, Bk, Lq, H))
+
+
 def attention_qscale():
     """(1/sqrt(128)) * log2(e): the factor attention(..., q_prescaled=True) expects folded into q."""
     return float(_L.load().wan_attention_qscale())
@@ -120,10 +125,13 @@ def transpose_v(v, ldv=None):
     return vt
 
 
-def attention(q, k, vt, Lk=None, out=None, nseg=1, k_seg_stride=0, vt_seg_stride=0, Bk=None, q_prescaled=False):
+def attention(q, k, vt, Lk=None, out=None, nseg=1, k_seg_stride=0, vt_seg_stride=0, Bk=None, q_prescaled=False,
+              kmax_scratch=None):
     """softmax(q k^T / sqrt(128)) v with v given transposed.  q [B,Lq,H,128], k [Bk,Lk,H,128], vt [Bk,H*128,ldv].
     nseg > 1: k / vt hold `nseg` gathered segments ([seg][Bk][Lk][H*128], [seg][Bk][H*128][ldv]); pass Lk, Bk
-    and the segment strides (elements) explicitly.  q_prescaled: q already holds q * attention_qscale()."""
+    and the segment strides (elements) explicitly.  q_prescaled: q already holds q * attention_qscale().
+    kmax_scratch: fp32 device scratch of attention_scratch_words(B, Bk, Lq, H) elements for the K pre-pass
+    (wan_attention_bounded); False = no pre-pass (the kernel's lazy-max loop); None = the library's own scratch."""
     _req(q, BF16, "q"); _req(k, BF16, "k"); _req(vt, BF16, "vt")
     B, Lq, H, D = q.shape
     if D != 128:
@@ -133,6 +141,18 @@ def attention(q, k, vt, Lk=None, out=None, nseg=1, k_seg_stride=0, vt_seg_stride
     Lk = Lk if Lk is not None else k.shape[1]
     ldv = vt.shape[-1]
     out = torch.empty_like(q) if out is None else out
+    if kmax_scratch is not None:
+        if kmax_scratch is False:
+            km = None
+        else:
+            _req(kmax_scratch, torch.float32, "kmax_scratch")
+            need = attention_scratch_words(B, Bk, Lq, H)
+            if kmax_scratch.numel() < need:
+                raise _L.WanHipError(f"kmax_scratch needs {need} 4-byte words")
+            km = kmax_scratch
+        check(_L.load().wan_attention_bounded(ptr(q), ptr(k), ptr(vt), ptr(out), B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride,
+                                              vt_seg_stride, 1 if q_prescaled else 0, ptr(km), stream_ptr()), "wan_attention_bounded")
+        return out
     fn = _L.load().wan_attention_prescaled if q_prescaled else _L.load().wan_attention_seg
     check(fn(ptr(q), ptr(k), ptr(vt), ptr(out), B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, stream_ptr()),
           "wan_attention")
