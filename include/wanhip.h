@@ -100,6 +100,24 @@ int wan_gemm_bf16(const wan_bf16* A, int64_t lda, const wan_bf16* W, const wan_b
                   const wan_bf16* R, const wan_bf16* mod, const wan_bf16* e, int n_mod,
                   int gate_idx, int64_t rows_per_batch, void* stream);
 
+/* ---- scaled-fp8 Linear (fp8 checkpoints; BASELINE configs[4]) ---------------------------------------------------------
+ * Replaces ScaledFP8WeightTensor._linear_scaled (shared/qtypes/scaled_fp8.py:324-380), the plan the reference runs for
+ * `<name>.weight` float8_e4m3fn + `<name>.scale_weight` checkpoints (QLinearScaledFP8, :490-637) on a GPU with an fp8
+ * matrix unit.  OCP e4m3fn bytes; both operands fp8, fp32 accumulation on v_mfma_f32_32x32x64_f8f6f4.
+ *
+ * wan_fp8_quantize: _quantize_activation (:162-169) -- per-tensor dynamic scale.  x [n] bf16 -> out [n] fp8 bytes;
+ *   ws[0] <- scale_a = absmax / 448 (1 if the tensor is all zero), ws[1] = scratch (2 floats of device memory);
+ *   q = fp8( clamp( bf16( x / bf16(scale_a) ), -448, 448 ) ), round-to-nearest-even.  n % 8 == 0.
+ * wan_gemm_fp8: C[M,N] = epilogue( (A[M,K] W[N,K]^T) * scale_a * w_scale + bias ), A / W fp8, C bf16.
+ *   scale_a: DEVICE pointer to the activation scale (ws of wan_fp8_quantize); w_scale: device fp32, w_scale_n = 1 (per
+ *   tensor: scale and bias applied in fp32, one bf16 rounding -- torch._scaled_mm) or N (per output row: bf16(acc * scale_a),
+ *   then `*= bf16(w_scale[n])`, then `+= bias`, one rounding each, :368-378).  epilogue / R / mod / e / gate as in
+ *   wan_gemm_bf16.  K % 128 == 0, lda % 16 == 0. */
+int wan_fp8_quantize(const wan_bf16* x, uint8_t* out, float* ws, int64_t n, void* stream);
+int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, const float* w_scale, int w_scale_n,
+                 const wan_bf16* bias, wan_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue, const wan_bf16* R,
+                 const wan_bf16* mod, const wan_bf16* e, int n_mod, int gate_idx, int64_t rows_per_batch, void* stream);
+
 /* ---- attention ------------------------------------------------------------------------- */
 
 /* Exact (non-causal, unmasked) flash attention, bf16 in/out, fp32 softmax/accumulate,

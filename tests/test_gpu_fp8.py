@@ -1,0 +1,102 @@
+"""-m gpu: the scaled-fp8 Linear (wan_fp8_quantize + wan_gemm_fp8, csrc/gemm_fp8.hip) against the reference's own results
+(tests/golden/fp8_linear.npz: shared/qtypes/scaled_fp8.py executed on CPU) and the bit-exact-pinned oracle/fp8_oracle.py.
+
+Tolerances: activation quantisation is integer work on bf16 inputs -- fp8 bytes and the scale must be EQUAL.  The product is
+a sum of exact fp8 x fp8 terms in fp32: only the summation order differs from torch._scaled_mm, so the bf16 output may differ
+by one ulp on a few elements (<= 2 bf16 ulp of max(|ref|, magnitude floor), <= 5 % of the elements unequal)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fp8_oracle as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+G = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "fp8_linear.npz")))
+SHAPES = {"per_tensor_bias": (70, 256), "per_row_bias": (70, 256), "per_row_col_nobias": (33, 128), "batched_3d_per_row": (2, 40, 192),
+          "zero_input": (16, 64)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from wan2gp_amd import ops as _ops, lib
+    lib.load()
+    return _ops
+
+
+def bf(a):
+    return torch.from_numpy(a.copy()).view(BF)
+
+
+def close(got, ref, floor, ulps=2, frac=0.05, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape and torch.isfinite(got).all(), what
+    diff = (got - ref).abs()
+    tol = torch.maximum(ref.abs(), torch.as_tensor(floor, dtype=torch.float32)) * 2.0 ** -7 * ulps
+    assert not (diff > tol).any(), f"{what}: {int((diff > tol).sum())} beyond {ulps} ulp, worst {(diff / tol).max().item():.2f}x"
+    assert (got != ref).float().mean().item() <= frac, f"{what}: {(got != ref).float().mean().item() * 100:.1f}% elements differ"
+
+
+@pytest.mark.parametrize("name", sorted(SHAPES))
+def test_quantize_activation_is_bit_exact(ops, name):
+    x = bf(G[name + "/x"]).reshape(SHAPES[name]).cuda()
+    if x.numel() % 8:
+        pytest.skip("n % 8")
+    q, ws = ops.fp8_quantize(x)
+    assert float(ws[0].cpu()) == float(G[name + "/scale_a"])
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy().reshape(-1), G[name + "/x_fp8"].reshape(-1))
+
+
+@pytest.mark.parametrize("name", ["per_tensor_bias", "per_row_bias", "per_row_col_nobias", "batched_3d_per_row", "zero_input"])
+def test_linear_scaled_vs_reference_golden(ops, name):
+    x = bf(G[name + "/x"]).reshape(SHAPES[name])
+    K = x.shape[-1]
+    if K % 128:
+        pytest.skip("K % 128: the reference falls back to the dequantised plan below the MFMA's k-tile as well (K % 16)")
+    w = torch.from_numpy(G[name + "/w"].copy()).view(torch.float8_e4m3fn)
+    scale = torch.from_numpy(G[name + "/scale"].copy())
+    bias = bf(G[name + "/bias"]) if name + "/bias" in G else None
+    got = ops.linear_fp8(x.cuda(), w.cuda(), scale.reshape(-1).cuda(), None if bias is None else bias.cuda())
+    ref = bf(G[name + "/out_scaled"]).reshape(*x.shape[:-1], w.shape[0])
+    close(got, ref, floor=0.25, what=name)
+
+
+@pytest.mark.parametrize("per_row", [True, False])
+def test_fp8_gemm_every_epilogue_at_tile_scale(ops, per_row):
+    """17 x 16 = 272 tiles of 256x256, ragged M (the last y tile has 38 rows), K = 7 k-tiles of 128 (ring wrap-around),
+    per-row and per-tensor weight scales, all four epilogues; oracle = oracle/fp8_oracle.py (bit-exact to the reference)."""
+    g = torch.Generator().manual_seed(17 + per_row)
+    M, N, K, B = 16 * 256 + 38, 4096, 896, 2
+    x = (torch.randn(M, K, generator=g) * 1.3).to(BF)
+    wq, ws = F.quantize_weight(torch.randn(N, K, generator=g) / K ** 0.5, per_row=per_row)
+    b = (0.1 * torch.randn(N, generator=g)).to(BF)
+    y = F.linear_scaled(x, wq, ws, b)
+    xc, wc, sc, bc = x.cuda(), wq.cuda(), ws.reshape(-1).cuda(), b.cuda()
+    xq = ops.fp8_quantize(xc)                                                   # one quantisation shared by every Linear of this input
+    close(ops.linear_fp8(xc, wc, sc, bc, x_fp8=xq), y, 0.25, what="none")
+    close(ops.linear_fp8(xc, wc, sc, bc, epilogue=1, x_fp8=xq), torch.nn.functional.gelu(y, approximate="tanh"), 0.25, ulps=3, what="gelu")
+    r = torch.randn(M, N, generator=g).to(BF)
+    mod = (torch.randn(1, 6, N, generator=g) / N ** 0.5).to(BF); e0 = (0.5 * torch.randn(B, 6, N, generator=g)).to(BF)
+    rpb = M // B
+    ref = torch.cat([torch.addcmul(r[i * rpb:(i + 1) * rpb], y[i * rpb:(i + 1) * rpb], (mod + e0[i:i + 1]).chunk(6, dim=1)[5][0])
+                     for i in range(B)])
+    got = ops.linear_fp8(xc, wc, sc, bc, epilogue=2, residual=r.cuda(), mod=mod.cuda(), e=e0.cuda(), gate_idx=5, x_fp8=xq)
+    close(got, ref, r.float().abs() + y.float().abs(), what="gate residual")
+    vt = ops.linear_fp8(xc, wc, sc, bc, epilogue=3, x_fp8=xq)
+    assert vt.shape[1] % 64 == 0 and (vt[:, M:] == 0).all()
+    close(vt[:, :M], y.t(), 0.25, what="V^T")
+    # small M (the time-embedding / text Linears of an fp8 checkpoint): one ragged tile row
+    close(ops.linear_fp8(xc[:5].contiguous(), wc, sc, bc), F.linear_scaled(x[:5], wq, ws, b), 0.25, what="M=5")
+
+
+def test_fp8_plan_accuracy_vs_dequantised_weights(ops):
+    """Context for whole-model comparisons: the fp8 x fp8 plan sits ~2.7e-2 from the dequantised-weight bf16 Linear."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(512, 1024, generator=g).to(BF)
+    wq, ws = F.quantize_weight(torch.randn(768, 1024, generator=g) / 32)
+    got = ops.linear_fp8(x.cuda(), wq.cuda(), ws.cuda()).float().cpu()
+    fb = F.linear_fallback(x, wq, ws).float()
+    r = ((got - fb).norm() / fb.norm()).item()
+    assert 1e-2 < r < 5e-2, r

@@ -44,8 +44,9 @@ struct QB {          // one 32-row q-block of the wave
   float cur0, ps;    // flat schedule: first exp2 of the pair in progress; sum of the pending pair
   float tmax;        // flat schedule: row max of S' found by chunk 4 ...
   bool need;         // ... and its wave-uniform verdict, consumed by chunk 5 one MFMA later (a branch on a fresh VALU compare stalls)
-  hw_f32x2 pe2;      // bounded path: the exp2 pair whose sum / pack is pending (an aligned register pair: v_pk_add_f32 operand)
-  hw_f32x2 l2;       // bounded path: this lane's share of the row sum, even / odd scores
+  float p0, p1;      // bounded path: the exp2 pair whose sum / pack is pending
+  float l0, l1;      // bounded path: this lane's share of the row sum, even / odd scores (scalars, summed with asm v_add_f32:
+                     // on a 2-vector hipcc SLP-packs the two adds into v_pk_add_f32, an anti-lever beside MFMAs)
 };
 
 // O^T += V^T P^T with the V^T fragment in the accumulator file
@@ -270,28 +271,37 @@ __device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8]
 //   q-block b: exp2 of score k at gap (51 + k) mod 64: 51..63 and 0..18 of the next tile, tail at 19  -> one v_exp_f32 in
 //   every gap; pair j is packed at the gap of score 2j + 2, >= 2 gaps before the PV MFMA that reads it
 //   (a: pair j at 21 + 2j, PV k-step c at 48 + 4c;  b: pair j at (53 + 2j) mod 64, PV k-step c at 16 + 4c of the next tile).
-//   LDS reads: V^T(t) fragment f at gap 18 + 2f (PV_b's MFMA f, its last reader, issued at 16 + f); K(t+1) fragments in
-//   need order, 8 at the odd gaps 49..63 and 8 at gaps 0..7 of the next tile; DMA pieces of tile t+2 at the odd gaps 9..23.
+//   LDS reads on the odd gaps (the lighter ones): V^T(t) fragment f at gap 17 + 2f (PV_b's MFMA f, its last reader, issued at
+//   16 + f); K(t+1) fragments in need order, 8 at the odd gaps 49..63 and 8 at gaps 0..7 of the next tile; DMA pieces of tile
+//   t+2 at the even gaps 8..22 (SCHED 0) or the odd gaps 9..23 (SCHED 1).
 constexpr float BOUND_LOG2 = 96.0f;
+// exp2 of score k (0..31) of q-block q, plus the bookkeeping of the PREVIOUS pair split over the two gaps of this pair:
+//   k even: pack pair k/2 - 1, l.x += its first element, then pe2.x := exp2(s_k)   (cvt + add + exp: 5 issue slots with exp = 3)
+//   k odd : l.y += the previous pair's second element, then pe2.y := exp2(s_k)      (add + exp: 4, room for one ds_read)
+// Plain v_add_f32: packed-f32 VALU (v_pk_add_f32) beside MFMAs is an anti-lever (+13 cycles each: measured 2x on this loop).
+__device__ __forceinline__ void vadd(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
 __device__ __forceinline__ void expn(QB& q, int k, int kv_rem, int half) {
   if (k == 0) mask_tail(q, kv_rem, half);  // cold: only a segment's ragged last tile (zero-filled K rows -> s = 0 -> -inf)
   if ((k & 1) == 0) {
     if (k >= 2) {
       const int j = (k >> 1) - 1;
-      q.pk[j >> 2][j & 3] = cvt_pk(q.pe2[0], q.pe2[1]);
-      asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(q.l2) : "v"(q.pe2));
+      q.pk[j >> 2][j & 3] = cvt_pk(q.p0, q.p1);
       asm volatile("" : "+v"(q.pk[j >> 2]));
+      vadd(q.l0, q.p0);
     }
-    q.pe2[0] = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
+    q.p0 = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
+    asm volatile("" : "+v"(q.p0));
   } else {
-    q.pe2[1] = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
+    if (k >= 3) vadd(q.l1, q.p1);
+    q.p1 = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
+    asm volatile("" : "+v"(q.p1));
   }
-  asm volatile("" : "+v"(q.pe2));
 }
-__device__ __forceinline__ void exptail(QB& q) {
-  q.pk[3][3] = cvt_pk(q.pe2[0], q.pe2[1]);
-  asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(q.l2) : "v"(q.pe2));
+__device__ __forceinline__ void exptail(QB& q) {  // pair 15: pack, both sums
+  q.pk[3][3] = cvt_pk(q.p0, q.p1);
   asm volatile("" : "+v"(q.pk[3]));
+  vadd(q.l0, q.p0);
+  vadd(q.l1, q.p1);
 }
 // S sub-tile i&1, k-step i>>1 (i = 0..15); k-step 0 starts from the inline constant 0
 __device__ __forceinline__ void qk_stepn(QB& x, const mfma_bf16x8 (&kf)[2][8], const mfma_bf16x8 (&qf)[8], int i) {
@@ -299,7 +309,7 @@ __device__ __forceinline__ void qk_stepn(QB& x, const mfma_bf16x8 (&kf)[2][8], c
   else mfma_qk(x.s[i & 1], kf[i & 1][i >> 1], qf[i >> 1]);
 }
 
-template <int ST, bool TIMING>
+template <int ST, bool TIMING, int SCHED>
 __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
                                           const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
                                           mfma_bf16x8 (&vf)[4][4], QB& a, QB& b, int kv_rem, int half, char* smem_rw,
@@ -312,8 +322,8 @@ __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8]
     if ((G) >= 19 && (G) <= 50) expn(a, (G) - 19, kv_rem, half);        /* q-block a, tile t */                     \
     if ((G) == 51) exptail(a);                                                                                    \
     if ((G) >= 51) expn(b, (G) - 51, kv_rem, half);                     /* q-block b, tile t: scores 0..12 */       \
-    if ((G) >= 18 && (G) <= 48 && (((G) - 18) & 1) == 0) {              /* V^T(t) fragment f at gap 18 + 2f */      \
-      const int f = ((G) - 18) >> 1;                                                                              \
+    if ((G) >= 17 && (G) <= 47 && (((G) - 17) & 1) == 0) {              /* V^T(t) fragment f at gap 17 + 2f */      \
+      const int f = ((G) - 17) >> 1;                                                                              \
       vf[f >> 2][f & 3] = *(lds_frag*)(smem + (VB + (f & 3) * 4096) + vaddr[f >> 2]);                             \
     }                                                                                                            \
     if ((G) >= 49 && (((G) - 49) & 1) == 0) {                           /* K(t+1), need order, first 8 */          \
@@ -324,8 +334,8 @@ __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8]
       const int r = 8 + (G), f = (r & 1) * 8 + (r >> 1);                                                          \
       kf[f >> 3][f & 7] = *(lds_frag*)(smem + (ST * IMG + (f >> 3) * 8192) + kaddr[f & 7]);                       \
     }                                                                                                            \
-    if ((G) >= 9 && (G) <= 23 && (((G) - 9) & 1) == 0) {                                                          \
-      const int pc = ((G) - 9) >> 1;                                    /* DMA pieces K0 V0 K1 V1 ... */           \
+    if ((G) >= 8 + SCHED && (G) <= 22 + SCHED && (((G) - 8 - SCHED) & 1) == 0) {                                  \
+      const int pc = ((G) - 8 - SCHED) >> 1;                            /* DMA pieces K0 V0 K1 V1 ... */           \
       dma_piece_i<DST>(smem_rw, dma, (pc & 1) * 4 + (pc >> 1));                                                   \
     }                                                                                                            \
     if (TIMING && rec && ((G) & 3) == 3) stamp[3 + ((G) >> 2)] = __builtin_amdgcn_s_memtime();                    \
@@ -401,6 +411,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   constexpr bool TIMING = (FLAGS & 1) != 0;
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
   constexpr bool BND = (FLAGS & 4) != 0;
+  constexpr int SCHED = (FLAGS >> 3) & 1;  // tuning: placement of the DMA pieces in the bounded loop
   uint64_t stamp[20] = {};
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stages][V^T stages] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
     asm volatile("" : "+v"(kones));
   }
   qa.l_run = qbk.l_run = 0.f;
-  qa.pe2 = qbk.pe2 = qa.l2 = qbk.l2 = hw_f32x2{0.f, 0.f};
+  qa.p0 = qa.p1 = qbk.p0 = qbk.p1 = qa.l0 = qa.l1 = qbk.l0 = qbk.l1 = 0.f;
   qa.pe0 = qa.pe1 = qbk.pe0 = qbk.pe1 = 0.f;
   qa.cur0 = qa.ps = qbk.cur0 = qbk.ps = 0.f;
   qa.tmax = qbk.tmax = 0.f;
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 #define W64N_STEP(J)                                                                                         \
   if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
     W64Q_TOP(J)                                                                                              \
-    tile_w64n<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, qa, qbk, kv_rem, half, smem, dma, stamp, rec);  \
+    tile_w64n<J, TIMING, SCHED>(lds, kaddr, vaddr, qfa, qfb, kf, vf, qa, qbk, kv_rem, half, smem, dma, stamp, rec); \
     kv_rem_prev = kv_rem;                                                                                    \
   }
     for (int t = 0; t < ntile; t += NST) {
@@ -560,8 +571,8 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int k = 13; k < 32; ++k) expn(qbk, k, kv_rem_prev, half);
     exptail(qbk);
-    qa.l_run = qa.l2[0] + qa.l2[1];
-    qbk.l_run = qbk.l2[0] + qbk.l2[1];
+    qa.l_run = qa.l0 + qa.l1;
+    qbk.l_run = qbk.l0 + qbk.l1;
   } else {
 #define W64Q_STEP(J)                                                                                         \
   if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
@@ -698,7 +709,9 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   }
 #endif
   if (kmax_scratch != nullptr) {
-    if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4);
+    static const bool sched1 = [] { const char* e = getenv("WAN_ATTN_SCHED"); return e && e[0] == '1'; }();
+    if (sched1) { if (pre) W64Q_LAUNCH(14); else W64Q_LAUNCH(12); }
+    else { if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4); }
     WAN_LAUNCH_CHECK();
   }
   if (pre) W64Q_LAUNCH(2); else W64Q_LAUNCH(0);

@@ -62,6 +62,9 @@ SIGNATURES = {
                                    c_void_p]),
     "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                               c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "wan_fp8_quantize": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                             c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "wan_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
                               c_int, c_void_p]),
     "wan_attention_seg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,

@@ -114,6 +114,44 @@ def linear(x, weight, bias=None, epilogue=EPI_NONE, residual=None, mod=None, e=N
     return out
 
 
+def fp8_quantize(x):
+    """_quantize_activation (shared/qtypes/scaled_fp8.py:162-169): x bf16 -> (float8_e4m3fn tensor of x's shape, ws) where
+    ws is a 2-float device tensor whose first element is scale_a = absmax / 448."""
+    _req(x, BF16, "x")
+    out = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    ws = torch.empty(2, dtype=torch.float32, device=x.device)
+    check(_L.load().wan_fp8_quantize(ptr(x), ptr(out), ptr(ws), x.numel(), stream_ptr()), "wan_fp8_quantize")
+    return out, ws
+
+
+def linear_fp8(x, weight_fp8, weight_scale, bias=None, epilogue=EPI_NONE, residual=None, mod=None, e=None, gate_idx=-1,
+               out=None, ldc=None, x_fp8=None):
+    """ScaledFP8WeightTensor._linear_scaled (scaled_fp8.py:324-380) with an optional fused epilogue: x [..., K] bf16 is
+    quantised per tensor (or pass x_fp8 = fp8_quantize(x) to share it between Linears of the same input), weight_fp8 [N, K]
+    float8_e4m3fn, weight_scale fp32 scalar or [N] / [N, 1]."""
+    _req(weight_fp8, torch.float8_e4m3fn, "weight_fp8"); _req(weight_scale, torch.float32, "weight_scale")
+    _req(bias, BF16, "bias"); _req(residual, BF16, "residual"); _req(mod, BF16, "mod"); _req(e, BF16, "e")
+    N, K = weight_fp8.shape
+    if weight_scale.numel() not in (1, N):
+        raise _L.WanHipError(f"weight_scale must have 1 or {N} elements")
+    xq, ws = fp8_quantize(x) if x_fp8 is None else x_fp8
+    M = xq.numel() // K
+    if epilogue == EPI_TRANSPOSED:
+        ldc = ldc or ((M + 63) // 64) * 64
+        if out is None:
+            out = torch.zeros(N, ldc, dtype=BF16, device=xq.device)
+    else:
+        ldc = N
+        if out is None:
+            out = torch.empty(*xq.shape[:-1], N, dtype=BF16, device=xq.device)
+    n_mod = mod.numel() // N if mod is not None else 0
+    nb = e.numel() // (n_mod * N) if (e is not None and n_mod) else 1
+    check(_L.load().wan_gemm_fp8(ptr(xq), K, ptr(ws), ptr(weight_fp8), ptr(weight_scale), weight_scale.numel(), ptr(bias), ptr(out),
+                                 ldc, M, N, K, epilogue, ptr(residual), ptr(mod), ptr(e), n_mod, gate_idx, max(M // nb, 1),
+                                 stream_ptr()), "wan_gemm_fp8")
+    return out
+
+
 def transpose_v(v, ldv=None):
     """[B,L,H,128] (or [B,L,C]) -> V^T [B, C, ldv] with zero padding."""
     _req(v, BF16, "v")
