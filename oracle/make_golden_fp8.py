@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY -- tests/golden/fp8_linear.npz from the REFERENCE's own scaled-fp8 code
-(shared/qtypes/scaled_fp8.py), executed on CPU.  Run in the build container:   python oracle/make_golden_fp8.py
+(shared/qtypes/scaled_fp8.py), executed on CPU.  Run in the build container:   python oracle/make_golden_fp8.py [linear] [forward]
 
 The module imports optimum.quanto (absent here), so its pieces are lifted with `ast`, bodies untouched:
   module level:  _FP8_RANGE, _reshape_scale, _normalize_scaled_mm_scale, _scaled_mm_weight_scale, _quantize_activation
@@ -93,5 +93,45 @@ def main():
     print("wrote", OUT, len(out), "arrays")
 
 
+def gen_forward_fp8():
+    """tests/golden/forward_tiny_fp8.npz: the reference's WanModel (tiny config) whose block Linears run the reference's own
+    `_linear_scaled` on fp8 weights -- each nn.Linear of blocks.* gets `forward = lambda x: _linear_scaled(stand-in, x, bias)`,
+    the plan QLinearScaledFP8.forward takes on an fp8-capable GPU (:546-561).  Per-row and per-tensor weight scales."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import ref_shim, wan_oracle as O
+    from oracle.make_golden import build_ref_model, ref_forward, f32
+    ns_ref = ref_shim.load()
+    ns = lift()
+    cfg = O.make_config("tiny")
+    f, h, w = 3, 8, 12
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    t = torch.tensor([637], dtype=torch.int64)
+    out = {"shape": np.array([f, h, w]), "t": np.array([637])}
+    for tag, per_row in (("row", True), ("tensor", False)):
+        Wb = O.synth_weights(cfg)
+        W8 = O.quantize_checkpoint_fp8(Wb, per_row=per_row)
+        m = build_ref_model(ns_ref, cfg, Wb, torch.bfloat16)
+        n_patched = 0
+        for name, mod in m.named_modules():
+            key = name + ".weight"
+            if isinstance(mod, torch.nn.Linear) and key in W8 and W8[key].dtype == torch.float8_e4m3fn:
+                me = types.SimpleNamespace(_data=W8[key], _scale=W8[name + ".scale_weight"], dtype=torch.bfloat16, device=W8[key].device)
+                me.dequantize = lambda dtype=None, device=None, me=me: ns["dequantize"](me, dtype, device)
+                mod.forward = (lambda x, me=me, mod=mod: ns["_linear_scaled"](me, x, mod.bias))
+                n_patched += 1
+        assert n_patched == 10 * cfg.num_layers, n_patched
+        r = ref_forward(ns_ref, m, [lat, lat], t, [ctx, ctx_null])
+        out[f"cond_{tag}"], out[f"uncond_{tag}"] = f32(r[0]), f32(r[1])
+        o = O.dit_forward([lat, lat], t, [ctx, ctx_null], W8, cfg, dtype=torch.bfloat16)
+        print(f"forward_tiny_fp8[{tag}]: oracle bit-equal to the reference: {torch.equal(o[0], r[0]) and torch.equal(o[1], r[1])}")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "forward_tiny_fp8.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    which = sys.argv[1:] or ["linear", "forward"]
+    if "linear" in which:
+        main()
+    if "forward" in which:
+        gen_forward_fp8()

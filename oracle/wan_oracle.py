@@ -249,7 +249,28 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, exact: bool = F
 
 
 def _linear(x, W, prefix):
-    return F.linear(x, W[prefix + ".weight"], W[prefix + ".bias"])
+    w = W[prefix + ".weight"]
+    if w.dtype == torch.float8_e4m3fn:                       # scaled-fp8 checkpoint: QLinearScaledFP8 (shared/qtypes/scaled_fp8.py)
+        from . import fp8_oracle
+        return fp8_oracle.linear_scaled(x, w, W[prefix + ".scale_weight"], W[prefix + ".bias"])
+    return F.linear(x, w, W[prefix + ".bias"])
+
+
+FP8_BLOCK_LINEARS = tuple(f"{a}.{l}" for a in ("self_attn", "cross_attn") for l in "qkvo") + ("ffn.0", "ffn.2")
+
+
+def quantize_checkpoint_fp8(W, per_row: bool = True):
+    """A scaled-fp8 checkpoint from a bf16 one: the ten Linears of every block become float8_e4m3fn `.weight` + fp32
+    `.scale_weight` (the layout QLinearScaledFP8._load_from_state_dict reads, scaled_fp8.py:563-637); everything else
+    (embeddings, norms, modulation, head, biases) stays as it is."""
+    from . import fp8_oracle
+    out = dict(W)
+    for k in list(W):
+        if k.startswith(("blocks.", "vace_blocks.")) and k.endswith(".weight") and k[:-7].split(".", 2)[2] in FP8_BLOCK_LINEARS:
+            q, s_ = fp8_oracle.quantize_weight(W[k].float(), per_row=per_row)
+            out[k] = q
+            out[k[:-7] + ".scale_weight"] = s_.float()
+    return out
 
 
 # --------------------------------------------------------------------------------------

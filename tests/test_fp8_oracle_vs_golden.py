@@ -56,3 +56,19 @@ def test_quantize_weight_round_trip():
     q, s = F.quantize_weight(w)
     assert q.dtype == torch.float8_e4m3fn and s.shape == (64,)
     assert ((F.dequantize(q, s, torch.float32) - w).abs() <= w.abs().amax(dim=1, keepdim=True) * 2 ** -4 + 1e-9).all()
+
+
+@pytest.mark.parametrize("tag,per_row", [("row", True), ("tensor", False)])
+def test_oracle_fp8_forward_is_bit_exact_to_the_reference_model(tag, per_row):
+    """tests/golden/forward_tiny_fp8.npz: the reference's WanModel with its block Linears running the reference's
+    `_linear_scaled` on fp8 weights (oracle/make_golden_fp8.py forward).  The oracle's dit_forward on the same fp8 checkpoint
+    must reproduce it bit for bit -- the fp8 Linear inside the pinned block structure."""
+    from oracle import wan_oracle as O
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "forward_tiny_fp8.npz")))
+    f, h, w = [int(v) for v in g["shape"]]
+    cfg = O.make_config("tiny")
+    W8 = O.quantize_checkpoint_fp8(O.synth_weights(cfg), per_row=per_row)
+    assert sum(v.dtype == torch.float8_e4m3fn for v in W8.values()) == 10 * cfg.num_layers
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    out = O.dit_forward([lat, lat], torch.tensor([int(g["t"][0])]), [ctx, ctx_null], W8, cfg, dtype=torch.bfloat16)
+    assert np.array_equal(out[0].numpy(), g[f"cond_{tag}"]) and np.array_equal(out[1].numpy(), g[f"uncond_{tag}"])

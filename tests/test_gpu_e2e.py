@@ -70,3 +70,19 @@ def test_i2v_generate_conditioning():
     assert out["x"].dtype == torch.uint8 and tuple(out["x"].shape) == (3, frames, H, Wd)
     # the known first latent frame is restored at the end (any2video.py:1755-1756)
     assert torch.equal(out["latents"][:, :, :1], ext)
+
+
+def test_family_handler_load_model_builds_a_working_pipeline():
+    """`family_handler.load_model` (the reference's plugin entry, models/wan/wan_handler.py:1116-1158) with in-memory state
+    dicts standing in for the checkpoint files: a 1.3B DiT + the Wan2.1 VAE, then generate() -> uint8 frames on the host."""
+    from oracle import wan_oracle as O
+    from wan2gp_amd.vae import random_vae_state_dict
+    from wan2gp_amd.wan_handler import family_handler as H
+    cfg = O.make_config("t2v_1.3B")
+    pipe, extra = H.load_model(["unused.safetensors"], "t2v_1.3B_hip", "t2v_1.3B_hip", {}, state_dicts=[O.synth_weights(cfg)],
+                               vae_state_dict=random_vae_state_dict())
+    assert extra == {"pipe": {}} and pipe.model is not None and pipe.model2 is None and pipe.vae is not None
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, 2, 8, 8)
+    out = pipe.generate(context=ctx.cuda(), context_null=ctx_null.cuda(), width=64, height=64, frame_num=5, sampling_steps=2,
+                        guide_scale=5.0, seed=1)
+    assert out["x"].dtype == torch.uint8 and tuple(out["x"].shape) == (3, 5, 64, 64) and not out["x"].is_cuda

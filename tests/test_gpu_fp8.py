@@ -75,18 +75,21 @@ def test_fp8_gemm_every_epilogue_at_tile_scale(ops, per_row):
     y = F.linear_scaled(x, wq, ws, b)
     xc, wc, sc, bc = x.cuda(), wq.cuda(), ws.reshape(-1).cuda(), b.cuda()
     xq = ops.fp8_quantize(xc)                                                   # one quantisation shared by every Linear of this input
-    close(ops.linear_fp8(xc, wc, sc, bc, x_fp8=xq), y, 0.25, what="none")
-    close(ops.linear_fp8(xc, wc, sc, bc, epilogue=1, x_fp8=xq), torch.nn.functional.gelu(y, approximate="tanh"), 0.25, ulps=3, what="gelu")
+    # per-row scale: the output goes through three bf16 roundings (product, * scale, + bias): a last-bit difference of the fp32
+    # sum can move the FIRST by one ulp, which is then carried through -- the magnitude floor is that of the pre-bias value
+    fl = (y.float() - b.float()).abs() + b.float().abs() + 0.25
+    close(ops.linear_fp8(xc, wc, sc, bc, x_fp8=xq), y, fl, what="none")
+    close(ops.linear_fp8(xc, wc, sc, bc, epilogue=1, x_fp8=xq), torch.nn.functional.gelu(y, approximate="tanh"), fl, ulps=3, what="gelu")
     r = torch.randn(M, N, generator=g).to(BF)
     mod = (torch.randn(1, 6, N, generator=g) / N ** 0.5).to(BF); e0 = (0.5 * torch.randn(B, 6, N, generator=g)).to(BF)
     rpb = M // B
     ref = torch.cat([torch.addcmul(r[i * rpb:(i + 1) * rpb], y[i * rpb:(i + 1) * rpb], (mod + e0[i:i + 1]).chunk(6, dim=1)[5][0])
                      for i in range(B)])
     got = ops.linear_fp8(xc, wc, sc, bc, epilogue=2, residual=r.cuda(), mod=mod.cuda(), e=e0.cuda(), gate_idx=5, x_fp8=xq)
-    close(got, ref, r.float().abs() + y.float().abs(), what="gate residual")
+    close(got, ref, r.float().abs() + fl, what="gate residual")
     vt = ops.linear_fp8(xc, wc, sc, bc, epilogue=3, x_fp8=xq)
     assert vt.shape[1] % 64 == 0 and (vt[:, M:] == 0).all()
-    close(vt[:, :M], y.t(), 0.25, what="V^T")
+    close(vt[:, :M], y.t(), fl.t(), what="V^T")
     # small M (the time-embedding / text Linears of an fp8 checkpoint): one ragged tile row
     close(ops.linear_fp8(xc[:5].contiguous(), wc, sc, bc), F.linear_scaled(x[:5], wq, ws, b), 0.25, what="M=5")
 
@@ -100,3 +103,31 @@ def test_fp8_plan_accuracy_vs_dequantised_weights(ops):
     fb = F.linear_fallback(x, wq, ws).float()
     r = ((got - fb).norm() / fb.norm()).item()
     assert 1e-2 < r < 5e-2, r
+
+
+@pytest.mark.parametrize("tag,per_row", [("row", True), ("tensor", False)])
+def test_fp8_checkpoint_forward_vs_reference_golden(tag, per_row):
+    """WanModelHIP loaded with a scaled-fp8 checkpoint (fp8 block Linears + scale_weight, everything else bf16 / fp32) against
+    tests/golden/forward_tiny_fp8.npz = the reference's WanModel running the reference's `_linear_scaled` (bit-exactly
+    reproduced by the oracle on CPU).  The HIP path differs from it by fp32 summation order only, but a last-bit difference
+    in front of an e4m3 quantisation (3 mantissa bits) is amplified to that format's step: the distance is expected at the
+    scale of the fp8 plan's own noise (~1e-2), far below its distance to the bf16 checkpoint's output."""
+    from oracle import wan_oracle as O
+    from wan2gp_amd.model import WanModelHIP
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "forward_tiny_fp8.npz")))
+    f, h, w = [int(v) for v in g["shape"]]
+    cfg = O.make_config("tiny")
+    Wb = O.synth_weights(cfg)
+    W8 = O.quantize_checkpoint_fp8(Wb, per_row=per_row)
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    t = torch.tensor([int(g["t"][0])])
+    m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers).load_state_dict(W8)
+    outs = [o.cpu() for o in m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])]
+    mb = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers).load_state_dict(Wb)
+    outs_bf16 = [o.cpu() for o in mb([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])]
+    for o, ob, key in zip(outs, outs_bf16, (f"cond_{tag}", f"uncond_{tag}")):
+        ref = torch.from_numpy(g[key])
+        d = ((o - ref).norm() / ref.norm()).item()
+        dq = ((ob - ref).norm() / ref.norm()).item()
+        print(f"[fp8 forward {key}] hip-fp8 vs reference-fp8 {d:.3e}; bf16 checkpoint vs reference-fp8 {dq:.3e}")
+        assert torch.isfinite(o).all() and d <= 2.5e-2 and d < dq, (d, dq)

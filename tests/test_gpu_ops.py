@@ -220,13 +220,22 @@ def test_gemm_rejects_bad_k(ops):
 
 
 # ---------------------------------------------------------------------------------------------
+def attn_ok(got, ref, atol=1.5e-2):
+    """The attention tolerance of this file: |err| <= 1.5e-2, or one coarse bf16 ulp (2^-7 |ref|) where |ref| >= 2."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return bool(torch.isfinite(got).all() and ((got - ref).abs() <= torch.clamp(ref.abs() * 2.0 ** -7, min=atol)).all())
+
+
 def _attn_check(ops, q, k, v, what, atol=1.5e-2):
+    """|err| <= 1.5e-2 for outputs below 2 in magnitude; one coarse bf16 ulp (2^-7 |ref|) above: every entry point now runs the
+    4x64 kernel, whose q carries the softmax scale in its bf16 rounding (q * c rounded instead of q), which can move an output
+    by one bf16 ulp -- 0.0156 for |o| in [2, 4)."""
     ref = O.attention(q, k, v, exact=True).float()
     vt = ops.transpose_v(cu(v))
     got = ops.attention(cu(q), cu(k), vt).float().cpu()
     assert torch.isfinite(got).all(), what
     err = (got - ref).abs()
-    assert err.max().item() <= atol, f"{what}: max abs err {err.max().item()}"
+    assert (err <= torch.clamp(ref.abs() * 2.0 ** -7, min=atol)).all(), f"{what}: max abs err {err.max().item()}"
     assert err.mean().item() <= 2e-3, f"{what}: mean abs err {err.mean().item()}"
     return got
 
@@ -289,7 +298,7 @@ def test_attention_segments_match_contiguous(ops):
     ldv = vt.shape[-1]
     got = ops.attention(cu(q), cu(k), vt.contiguous(), Lk=Ll, nseg=2, k_seg_stride=S * Ll * H * 128,
                         vt_seg_stride=S * H * 128 * ldv, Bk=S).float().cpu()
-    assert (got - ref).abs().max().item() <= 1.5e-2
+    assert attn_ok(got, ref), (got - ref).abs().max().item()
 
 
 # ---- pre-scaled attention path (wan_rmsnorm_rope_scaled -> wan_attention_prescaled, csrc/attention_w64q.hip) --------
@@ -316,8 +325,9 @@ def test_attention_prescaled_shapes(ops, B, Lq, Lk, H, Bk):
     qs = (q.float() * ops.attention_qscale()).to(BF)
     got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True).float().cpu()
     assert torch.isfinite(got).all()
-    err = (got - _prescaled_ref(qs, k, v)).abs()
-    assert err.max().item() <= 1.5e-2 and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+    ref = _prescaled_ref(qs, k, v)
+    err = (got - ref).abs()
+    assert (err <= torch.clamp(ref.abs() * 2.0 ** -7, min=1.5e-2)).all() and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
     assert_bf16_close(got, O.attention(q, k, v, exact=True), frac=1.0, ulps=2, what="vs oracle", floor=1.0)
 
 
@@ -334,13 +344,13 @@ def test_attention_prescaled_forced_rescale_and_segments(ops):
     vt = ops.transpose_v(cu(v))
     got = ops.attention(cu(qs), cu(k), vt, q_prescaled=True).float().cpu()
     err = (got - _prescaled_ref(qs, k, v)).abs()
-    assert torch.isfinite(got).all() and err.max().item() <= 1.5e-2, err.max().item()
+    assert attn_ok(got, _prescaled_ref(qs, k, v)), err.max().item()
     S, Ll, H = 1, 320, 1
     k2 = k.view(2, S, Ll, H, 128); v2 = v.view(2, S, Ll, H, 128)
     vt2 = torch.stack([ops.transpose_v(cu(v2[0])), ops.transpose_v(cu(v2[1]))]).contiguous()
     got2 = ops.attention(cu(qs), cu(k2.contiguous()), vt2, Lk=Ll, nseg=2, k_seg_stride=S * Ll * H * 128,
                          vt_seg_stride=S * H * 128 * vt2.shape[-1], Bk=S, q_prescaled=True).float().cpu()
-    assert (got2 - _prescaled_ref(qs, k, v)).abs().max().item() <= 1.5e-2
+    assert attn_ok(got2, _prescaled_ref(qs, k, v))
 
 
 def test_rmsnorm_rope_scaled(ops):
@@ -375,7 +385,7 @@ def test_pay_attention_dropin_contract(ops):
     out = ops.pay_attention(lst, recycle_q=True)
     assert lst == [] and out.dtype == BF and out.shape == q.shape          # list consumed (attention.py:403)
     assert out.data_ptr() == q.data_ptr()                                  # recycle_q reuses q's storage
-    assert (out.float().cpu() - ref).abs().max().item() <= 1.5e-2
+    assert attn_ok(out, ref)
     from wan2gp_amd.lib import WanHipError
     with pytest.raises(WanHipError):
         ops.pay_attention([q, k, v], causal=True)
@@ -432,10 +442,10 @@ def test_attention_bounded_and_tracking_loops_agree_with_fp64(ops, B, Lq, Lk, H,
     assert (scratch[Bk * H:].view(torch.int32) == 0).all()                     # no workgroup had to fall back to the tracking loop
     for name, o in outs.items():
         err = (o.float().cpu() - ref).abs()
-        assert torch.isfinite(o.float()).all() and err.max().item() <= 1.5e-2 and err.mean().item() <= 2e-3, (name, err.max().item())
+        assert attn_ok(o, ref) and err.mean().item() <= 2e-3, (name, err.max().item())
     # unscaled q through the generic entry (in-kernel pre-scaling) takes the same kernel for long KV
     o = ops.attention(cu(q), cu(k), vt).float().cpu()
-    assert (o - O.attention(q, k, v, exact=True).float()).abs().max().item() <= 1.5e-2
+    assert attn_ok(o, O.attention(q, k, v, exact=True))
 
 
 def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
@@ -454,9 +464,9 @@ def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
     ref = _prescaled_ref(qs, k, v)
     assert torch.isfinite(got).all()
     err = (got - ref).abs()
-    assert err.max().item() <= 1.5e-2, err.max().item()
+    assert attn_ok(got, ref), err.max().item()
     # and a K so large that every workgroup is out of bounds
     k2 = (k.float() * 70).to(BF)
     got2 = ops.attention(cu(qs), cu(k2), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
     assert (scratch[B * H:].view(torch.int32) == 1).all()
-    assert torch.isfinite(got2).all() and (got2 - _prescaled_ref(qs, k2, v)).abs().max().item() <= 1.5e-2
+    assert attn_ok(got2, _prescaled_ref(qs, k2, v))

@@ -81,7 +81,7 @@ def test_gemm256k_main_loop_instruction_mix(gemm):
 
 
 def test_attention_w64q_no_scratch_and_hardware_conversions(attn):
-    assert len(attn) == 4                                            # {bounded, tracking} x {q pre-scaled, pre-scaling pass}
+    assert len(attn) in (4, 6)                                       # {bounded, tracking} x {q pre-scaled, pre-scaling pass} (+ 2 while a DMA-placement variant is being A/B-ed)
     for name, (ops, meta) in attn.items():
         assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256 and meta["LDSByteSize"] <= 96 * 1024 + 256, (name, meta)
     # tracking loop (FLAGS 2): 68 MFMAs per KV tile (4 carry -m_ref), one v_exp_f32 per score, hardware bf16 packing
@@ -92,8 +92,9 @@ def test_attention_w64q_no_scratch_and_hardware_conversions(attn):
 
 def test_attention_bounded_loop_instruction_mix(attn):
     """The DiT's self-attention (FLAGS 6 = pre-scaled q, bounded softmax): per 64-kv tile of a wave exactly 64 MFMAs, 64
-    v_exp_f32, 32 packed conversions, 32 v_pk_add_f32 row-sum updates, 32 ds_read_b128, 8 LDS-DMA pieces, one barrier -- and
-    no row-max / compare / rescale instruction anywhere in the loop."""
+    v_exp_f32, 32 packed conversions, 64 plain v_add_f32 row-sum updates (NOT v_pk_add_f32: packed f32 VALU beside MFMAs is an
+    anti-lever), 32 ds_read_b128, 8 LDS-DMA pieces, one barrier and ONE vmcnt wait (the tile top: an LDS-DMA issued through the
+    builtin makes hipcc serialise the ring with vmcnt(0) in front of ds_reads) -- and no row-max / compare / rescale instruction."""
     ops, meta = attn[next(n for n in attn if "ILi6E" in n)]
     assert meta["NumVgprs"] <= 216, meta
     bars = [i for i, o in enumerate(ops) if o == "s_barrier"]
@@ -104,8 +105,8 @@ def test_attention_bounded_loop_instruction_mix(attn):
             tiles.append(c)
     assert len(tiles) >= 2, [sum(v for k, v in collections.Counter(ops[a:b]).items() if k.startswith("v_mfma")) for a, b in zip(bars, bars[1:])]
     for c in tiles:
-        assert c["v_exp_f32_e32"] == 64 and c["v_cvt_pk_bf16_f32"] == 32 and c["v_pk_add_f32"] == 32, c
+        assert c["v_exp_f32_e32"] == 64 and c["v_cvt_pk_bf16_f32"] == 32 and c["v_add_f32"] == 64 and c["v_pk_add_f32"] == 0, c
         assert c["ds_read_b128"] == 32 and c["buffer_load_dwordx4"] == 8, c
         assert not any(k.startswith(("v_max", "v_cmp", "v_permlane", "scratch_")) for k in c), c
         valu = sum(v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma"))
-        assert valu <= 136, valu                                     # 128 + a few address / mask ops: half the 4-per-gap issue budget
+        assert valu <= 168, valu                                     # 160 + a few address / mask ops

@@ -13,6 +13,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--stamps" in sys.argv:   # the stamp kernels live in the tuning build only (make -C wan2gp_amd/csrc timing)
+    from wan2gp_amd import lib as _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libwanhip_timing.so")
+    os.environ["WAN_ATTN_STAMPS"] = "1"
 from wan2gp_amd import ops  # noqa: E402
 
 
@@ -44,7 +48,9 @@ def main():
             o = run[m]()
             torch.cuda.synchronize()
             st = o.view(-1)[:80].view(torch.int64).cpu().tolist()
-            print("stamps", m, "top->barrier", st[1] - st[0], "per 4 gaps:", [st[i + 1] - st[i] for i in range(2, 18)], "tile:", st[18] - st[0])
+            last = 18 if m == "bounded" else 19                      # 64 gaps (bounded) / 68 gaps (tracking)
+            print("stamps", m, "top->barrier", st[1] - st[0], "barrier->tile", st[2] - st[1], "per 4 gaps:",
+                  [st[i + 1] - st[i] for i in range(2, last)], "tile:", st[last] - st[0])
         return
     flops = 4.0 * a.B * a.H * a.L * Lk * 128
     outs, times = {}, {m: [] for m in modes}

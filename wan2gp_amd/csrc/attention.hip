@@ -16,12 +16,10 @@
 //     the MFMA C layout (row = (reg&3) + 8*(reg>>2) + 4*half) into "regs 0..7 = 8 consecutive
 //     kv, regs 8..15 = the next-but-one 8", i.e. directly the B-operand k-order of the PV MFMA.
 //
-// The kernels:
-//   attention_w64q.hip  attn_w64q_kernel: 4 waves = one per SIMD, 64 q rows per wave, 3-deep LDS-DMA ring -- every
-//                       self-attention and long-KV call.  Two tile loops: the bounded softmax (no running max; taken
-//                       when a pre-pass over K proves |s| <= 96 in log2 units for the whole workgroup) and the lazy-max
-//                       tracking loop (any input).
-//   attention_pp.hip    attn_pp_kernel<0,0,4>: 4 waves x 32 q rows, 2-deep ring -- short KV (cross-attention, Lk = 512).
+// The kernel (attention_w64q.hip, attn_w64q_kernel): 4 waves = one per SIMD, 64 q rows per wave, 3-deep LDS-DMA ring, for
+// every call.  Two tile loops: the bounded softmax (no running max; long KV only, taken when a pre-pass over K proves
+// |s| <= 96 in log2 units for the whole workgroup) and the lazy-max tracking loop (any input; short KV -- cross-attention,
+// Lk = 512 -- always: measured equal to the former 4 x 32-row short-KV kernel there, 775 vs 772 TFLOP/s).
 // LDS images are XOR-swizzled on the DMA *source* address (K: 256-B rows, chunk ^= row&15; V^T: 128-B rows,
 // chunk ^= (row>>1)&7) so every ds_read_b128 lane group hits 16 distinct 16-B slots.  Workgroup ids are remapped so that
 // each XCD owns whole (batch, head) pairs: the blocks resident on an XCD stream the same K/V through its private L2.
@@ -30,9 +28,6 @@
 
 #include "common.h"
 
-int wan_attention_pp_launch(int flags, int mode, int nw, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
-                            int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
-                            int64_t vt_seg_stride, float scale_log2e, hipStream_t stream);
 int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
                              int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
                              int64_t vt_seg_stride, float scale_log2e, float* kmax_scratch, hipStream_t stream);
@@ -78,19 +73,16 @@ static int attention_dispatch(const wan_bf16* q, const wan_bf16* k, const wan_bf
   WAN_REQUIRE(Lk * (int64_t)H * 256 < ((int64_t)1 << 32) && ldv * 256 < ((int64_t)1 << 32),
               "wan_attention: a K / V^T segment of %lld rows x %d heads exceeds the 32-bit DMA offsets of the kernels",
               (long long)Lk, H);
-  // tuning switches (A/B runs only; tools/bench_attn.py): WAN_ATTN_TRACK=1 never takes the bounded loop,
-  // WAN_ATTN_SHORT=w64q sends short KV to the 4x64 kernel as well
-  static const bool env_track = [] { const char* e = getenv("WAN_ATTN_TRACK"); return e && e[0] == '1'; }();
-  static const bool env_short64 = [] { const char* e = getenv("WAN_ATTN_SHORT"); return e && !strcmp(e, "w64q"); }();
   const bool long_kv = Lk * (int64_t)nseg > 2048;
-  if (long_kv || q_prescaled || env_short64) {
+  {
+    // the bounded loop sums UNROUNDED P into l while P enters the PV product rounded to bf16: negligible over thousands of
+    // keys, a visible 2^-9 for a handful (Lk = 1: O = bf16(2^s) v / 2^s instead of v) -- short KV always takes the tracking
+    // loop, whose dominant term is exactly 1
     float* km = nullptr;
-    if (!env_track) km = scratch_kind == SCRATCH_CALLER ? scratch : (scratch_kind == SCRATCH_RING ? kmax_ring_slot(wan_attention_scratch_words(B, Bk, Lq, H)) : nullptr);
+    if (long_kv) km = scratch_kind == SCRATCH_CALLER ? scratch : (scratch_kind == SCRATCH_RING ? kmax_ring_slot(wan_attention_scratch_words(B, Bk, Lq, H)) : nullptr);
     return wan_attention_w64q_launch(q_prescaled ? 2 : 0, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride,
                                      vt_seg_stride, SCALE_LOG2E, km, as_stream(stream));
   }
-  return wan_attention_pp_launch(0, 0, 4, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, SCALE_LOG2E,
-                                 as_stream(stream));
 }
 
 extern "C" int wan_attention(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,

@@ -271,15 +271,16 @@ __device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8]
 //   q-block b: exp2 of score k at gap (51 + k) mod 64: 51..63 and 0..18 of the next tile, tail at 19  -> one v_exp_f32 in
 //   every gap; pair j is packed at the gap of score 2j + 2, >= 2 gaps before the PV MFMA that reads it
 //   (a: pair j at 21 + 2j, PV k-step c at 48 + 4c;  b: pair j at (53 + 2j) mod 64, PV k-step c at 16 + 4c of the next tile).
-//   LDS reads on the odd gaps (the lighter ones): V^T(t) fragment f at gap 17 + 2f (PV_b's MFMA f, its last reader, issued at
-//   16 + f); K(t+1) fragments in need order, 8 at the odd gaps 49..63 and 8 at gaps 0..7 of the next tile; DMA pieces of tile
-//   t+2 at the even gaps 8..22 (SCHED 0) or the odd gaps 9..23 (SCHED 1).
+//   Nothing but MFMAs, exps and the 8 DMA pieces of tile t+2 (odd gaps 1..15) behind the barrier; V^T(t) fragment f at gap
+//   17 + f (PV_b's MFMA f, its last reader, issued at 16 + f); K(t+1) fragment r (need order; its register was last read by
+//   S_b's MFMA at 32 + r) at gap 33 + 2r -- every K fragment of the next tile is read inside this one.
 constexpr float BOUND_LOG2 = 96.0f;
 // exp2 of score k (0..31) of q-block q, plus the bookkeeping of the PREVIOUS pair split over the two gaps of this pair:
 //   k even: pack pair k/2 - 1, l.x += its first element, then pe2.x := exp2(s_k)   (cvt + add + exp: 5 issue slots with exp = 3)
 //   k odd : l.y += the previous pair's second element, then pe2.y := exp2(s_k)      (add + exp: 4, room for one ds_read)
 // Plain v_add_f32: packed-f32 VALU (v_pk_add_f32) beside MFMAs is an anti-lever (+13 cycles each: measured 2x on this loop).
 __device__ __forceinline__ void vadd(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+template <bool DIAG>  // DIAG (timing build only): the row-sum adds left out -- what the loop would cost if l came for free
 __device__ __forceinline__ void expn(QB& q, int k, int kv_rem, int half) {
   if (k == 0) mask_tail(q, kv_rem, half);  // cold: only a segment's ragged last tile (zero-filled K rows -> s = 0 -> -inf)
   if ((k & 1) == 0) {
@@ -287,21 +288,25 @@ __device__ __forceinline__ void expn(QB& q, int k, int kv_rem, int half) {
       const int j = (k >> 1) - 1;
       q.pk[j >> 2][j & 3] = cvt_pk(q.p0, q.p1);
       asm volatile("" : "+v"(q.pk[j >> 2]));
-      vadd(q.l0, q.p0);
+      if (!DIAG) vadd(q.l0, q.p0);
     }
     q.p0 = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
     asm volatile("" : "+v"(q.p0));
   } else {
-    if (k >= 3) vadd(q.l1, q.p1);
+    if (k >= 3 && !DIAG) vadd(q.l1, q.p1);
     q.p1 = __builtin_amdgcn_exp2f(q.s[k >> 4][k & 15]);
     asm volatile("" : "+v"(q.p1));
   }
 }
-__device__ __forceinline__ void exptail(QB& q) {  // pair 15: pack, both sums
-  q.pk[3][3] = cvt_pk(q.p0, q.p1);
-  asm volatile("" : "+v"(q.pk[3]));
-  vadd(q.l0, q.p0);
-  vadd(q.l1, q.p1);
+template <bool DIAG>
+__device__ __forceinline__ void exptail(QB& q, int part) {  // pair 15: pack + first sum (part 0), second sum (part 1, one gap later)
+  if (part == 0) {
+    q.pk[3][3] = cvt_pk(q.p0, q.p1);
+    asm volatile("" : "+v"(q.pk[3]));
+    if (!DIAG) vadd(q.l0, q.p0);
+  } else if (!DIAG) {
+    vadd(q.l1, q.p1);
+  }
 }
 // S sub-tile i&1, k-step i>>1 (i = 0..15); k-step 0 starts from the inline constant 0
 __device__ __forceinline__ void qk_stepn(QB& x, const mfma_bf16x8 (&kf)[2][8], const mfma_bf16x8 (&qf)[8], int i) {
@@ -309,7 +314,7 @@ __device__ __forceinline__ void qk_stepn(QB& x, const mfma_bf16x8 (&kf)[2][8], c
   else mfma_qk(x.s[i & 1], kf[i & 1][i >> 1], qf[i >> 1]);
 }
 
-template <int ST, bool TIMING, int SCHED>
+template <int ST, bool TIMING, bool DIAG>
 __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
                                           const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
                                           mfma_bf16x8 (&vf)[4][4], QB& a, QB& b, int kv_rem, int half, char* smem_rw,
@@ -317,25 +322,23 @@ __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8]
   constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
 #define BND_GAP(G)                                                                                               \
   do {                                                                                                           \
-    if ((G) <= 18) expn(b, (G) + 13, kv_rem, half);                     /* q-block b, tile t-1: scores 13..31 */    \
-    if ((G) == 19) exptail(b);                                                                                    \
-    if ((G) >= 19 && (G) <= 50) expn(a, (G) - 19, kv_rem, half);        /* q-block a, tile t */                     \
-    if ((G) == 51) exptail(a);                                                                                    \
-    if ((G) >= 51) expn(b, (G) - 51, kv_rem, half);                     /* q-block b, tile t: scores 0..12 */       \
-    if ((G) >= 17 && (G) <= 47 && (((G) - 17) & 1) == 0) {              /* V^T(t) fragment f at gap 17 + 2f */      \
-      const int f = ((G) - 17) >> 1;                                                                              \
+    if ((G) <= 18) expn<DIAG>(b, (G) + 13, kv_rem, half);               /* q-block b, tile t-1: scores 13..31 */    \
+    if ((G) == 19) exptail<DIAG>(b, 0);                                 /* pair 15: pack + first sum ... */         \
+    if ((G) == 20) exptail<DIAG>(b, 1);                                 /* ... second sum (a's gap 20 has none) */  \
+    if ((G) >= 19 && (G) <= 50) expn<DIAG>(a, (G) - 19, kv_rem, half);  /* q-block a, tile t */                     \
+    if ((G) == 51) exptail<DIAG>(a, 0);                                                                           \
+    if ((G) == 52) exptail<DIAG>(a, 1);                                                                           \
+    if ((G) >= 51) expn<DIAG>(b, (G) - 51, kv_rem, half);               /* q-block b, tile t: scores 0..12 */       \
+    if ((G) >= 17 && (G) <= 32) {                                       /* V^T(t) fragment f at gap 17 + f */       \
+      const int f = (G) - 17;                                                                                     \
       vf[f >> 2][f & 3] = *(lds_frag*)(smem + (VB + (f & 3) * 4096) + vaddr[f >> 2]);                             \
     }                                                                                                            \
-    if ((G) >= 49 && (((G) - 49) & 1) == 0) {                           /* K(t+1), need order, first 8 */          \
-      const int r = ((G) - 49) >> 1, f = (r & 1) * 8 + (r >> 1);                                                  \
+    if ((G) >= 33 && (((G) - 33) & 1) == 0) {                           /* K(t+1) fragment r (need order) at 33 + 2r */ \
+      const int r = ((G) - 33) >> 1, f = (r & 1) * 8 + (r >> 1);                                                  \
       kf[f >> 3][f & 7] = *(lds_frag*)(smem + (KN + (f >> 3) * 8192) + kaddr[f & 7]);                             \
     }                                                                                                            \
-    if ((G) <= 7) {                                                     /* K(t) read 8..15: this tile's stage */   \
-      const int r = 8 + (G), f = (r & 1) * 8 + (r >> 1);                                                          \
-      kf[f >> 3][f & 7] = *(lds_frag*)(smem + (ST * IMG + (f >> 3) * 8192) + kaddr[f & 7]);                       \
-    }                                                                                                            \
-    if ((G) >= 8 + SCHED && (G) <= 22 + SCHED && (((G) - 8 - SCHED) & 1) == 0) {                                  \
-      const int pc = ((G) - 8 - SCHED) >> 1;                            /* DMA pieces K0 V0 K1 V1 ... */           \
+    if ((G) >= 1 && (G) <= 15 && (((G) - 1) & 1) == 0) {                                                          \
+      const int pc = ((G) - 1) >> 1;                                    /* DMA pieces K0 V0 K1 V1 ... */           \
       dma_piece_i<DST>(smem_rw, dma, (pc & 1) * 4 + (pc >> 1));                                                   \
     }                                                                                                            \
     if (TIMING && rec && ((G) & 3) == 3) stamp[3 + ((G) >> 2)] = __builtin_amdgcn_s_memtime();                    \
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   constexpr bool TIMING = (FLAGS & 1) != 0;
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
   constexpr bool BND = (FLAGS & 4) != 0;
-  constexpr int SCHED = (FLAGS >> 3) & 1;  // tuning: placement of the DMA pieces in the bounded loop
+  constexpr bool DIAG = (FLAGS & 8) != 0;  // timing build only: bounded loop without its row-sum adds (wrong results)
   uint64_t stamp[20] = {};
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stages][V^T stages] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
@@ -442,12 +445,16 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
     int64_t ra = q0 + l31, rb = q0 + 32 + l31;
     if (ra > Lq - 1) ra = Lq - 1;
     if (rb > Lq - 1) rb = Lq - 1;
+    uint4 wa[8], wb[8];  // all 16 loads in flight before the first use (pinning a fragment to the accumulator file waits for it)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const uint4 wa = *reinterpret_cast<const uint4*>(qbase + ra * rs + ks * 16 + half * 8);
-      const uint4 wb = *reinterpret_cast<const uint4*>(qbase + rb * rs + ks * 16 + half * 8);
-      qfa[ks] = PRESCALED ? __builtin_bit_cast(mfma_bf16x8, wa) : prescale8(wa, scale_log2e);
-      qfb[ks] = PRESCALED ? __builtin_bit_cast(mfma_bf16x8, wb) : prescale8(wb, scale_log2e);
+      wa[ks] = *reinterpret_cast<const uint4*>(qbase + ra * rs + ks * 16 + half * 8);
+      wb[ks] = *reinterpret_cast<const uint4*>(qbase + rb * rs + ks * 16 + half * 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      qfa[ks] = PRESCALED ? __builtin_bit_cast(mfma_bf16x8, wa[ks]) : prescale8(wa[ks], scale_log2e);
+      qfb[ks] = PRESCALED ? __builtin_bit_cast(mfma_bf16x8, wb[ks]) : prescale8(wb[ks], scale_log2e);
       ssa += sumsq8(qfa[ks]);
       ssb += sumsq8(qfb[ks]);
       // make each fragment ONE accumulator-file tuple from here on (otherwise the allocator keeps scattered master copies
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 #define W64N_STEP(J)                                                                                         \
   if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
     W64Q_TOP(J)                                                                                              \
-    tile_w64n<J, TIMING, SCHED>(lds, kaddr, vaddr, qfa, qfb, kf, vf, qa, qbk, kv_rem, half, smem, dma, stamp, rec); \
+    tile_w64n<J, TIMING, DIAG>(lds, kaddr, vaddr, qfa, qfb, kf, vf, qa, qbk, kv_rem, half, smem, dma, stamp, rec); \
     kv_rem_prev = kv_rem;                                                                                    \
   }
     for (int t = 0; t < ntile; t += NST) {
@@ -569,8 +576,9 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 #undef W64N_STEP
     // drain: q-block b's last tile
 #pragma unroll
-    for (int k = 13; k < 32; ++k) expn(qbk, k, kv_rem_prev, half);
-    exptail(qbk);
+    for (int k = 13; k < 32; ++k) expn<DIAG>(qbk, k, kv_rem_prev, half);
+    exptail<DIAG>(qbk, 0);
+    exptail<DIAG>(qbk, 1);
     qa.l_run = qa.l0 + qa.l1;
     qbk.l_run = qbk.l0 + qbk.l1;
   } else {
@@ -702,16 +710,16 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
 #ifdef W64Q_TIMING
   static const bool stamps = [] { const char* e = getenv("WAN_ATTN_STAMPS"); return e && e[0] == '1'; }();
   if (stamps) {  // stamps of the loop that runs: bounded if there is a pre-pass, else tracking
-    if (kmax_scratch != nullptr) { if (pre) W64Q_LAUNCH(7); else W64Q_LAUNCH(5); }
+    static const bool diag = [] { const char* e = getenv("WAN_ATTN_DIAG"); return e && e[0] == '1'; }();
+    if (kmax_scratch != nullptr && diag) { if (pre) W64Q_LAUNCH(15); else W64Q_LAUNCH(13); }
+    else if (kmax_scratch != nullptr) { if (pre) W64Q_LAUNCH(7); else W64Q_LAUNCH(5); }
     else { if (pre) W64Q_LAUNCH(3); else W64Q_LAUNCH(1); }
     WAN_LAUNCH_CHECK();
     return 0;
   }
 #endif
   if (kmax_scratch != nullptr) {
-    static const bool sched1 = [] { const char* e = getenv("WAN_ATTN_SCHED"); return e && e[0] == '1'; }();
-    if (sched1) { if (pre) W64Q_LAUNCH(14); else W64Q_LAUNCH(12); }
-    else { if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4); }
+    if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4);
     WAN_LAUNCH_CHECK();
   }
   if (pre) W64Q_LAUNCH(2); else W64Q_LAUNCH(0);

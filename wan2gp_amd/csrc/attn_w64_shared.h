@@ -90,18 +90,26 @@ __device__ __forceinline__ void dma_init(Dma& d, const void* kbase, const void* 
   }
   d.wave = wave;
 }
-// piece I = 0..3: K, 4..7: V^T, into ring stage ST (I is a template argument or an unrolled loop variable)
+// piece I = 0..3: K, 4..7: V^T, into ring stage ST (I is a template argument or an unrolled loop variable).
+// Issued as INLINE ASM: for the builtin form hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of every ds_read it
+// cannot prove disjoint from a pending LDS-DMA (it cannot tell the ring stages apart once a per-lane address is involved) --
+// measured: four such waits per tile in the bounded loop, ~2,500 cycles each, the whole DMA latency serialised.  The asm form
+// is invisible to that pass; completion is counted by hand (one vmcnt(0) + barrier at the top of each tile).
+typedef uint32_t dma_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_issue(uint32_t voff, const char* base, uint32_t num_records, uint32_t lds_addr) {
+  const uint64_t b = (uint64_t)base;
+  dma_u4 r;
+  r[0] = (uint32_t)b;
+  r[1] = (uint32_t)(b >> 32) & 0xffffu;  // stride 0
+  r[2] = num_records;                    // bytes from base that may be read; beyond: zeros (range check)
+  r[3] = 0x00020000u;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(r), "s"(lds_addr) : "memory");
+}
 template <int ST>
 __device__ __forceinline__ void dma_piece_i(char* smem, const Dma& d, int I) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  if (I < 4) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(d.k), 0, d.klen, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + ST * IMG + d.wave * 1024 + I * 4096), 16, d.kofs[I], 0, 0, 0);
-  } else {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(d.v), 0, 0xffffffffu, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(smem + NST * IMG + ST * IMG + d.wave * 1024 + (I - 4) * 4096), 16,
-                                             d.vofs[I - 4], 0, 0, 0);
-  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  if (I < 4) dma_issue(d.kofs[I], d.k, d.klen, lds0 + ST * IMG + d.wave * 1024 + I * 4096);
+  else dma_issue(d.vofs[I - 4], d.v, 0xffffffffu, lds0 + NST * IMG + ST * IMG + d.wave * 1024 + (I - 4) * 4096);
 }
 template <int I, int ST>
 __device__ __forceinline__ void dma_piece(char* smem, const Dma& d) {

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -93,15 +94,20 @@ struct ProfScope {
   }
 };
 
+constexpr int CLIP_TOK = 257, CLIP_DIM = 1280, CLIP_LDV = 320;
+
 struct Tensor {
   const void* ptr;
-  int dtype;  // 0 bf16, 1 fp32
+  int dtype;  // 0 bf16, 1 fp32, 2 fp8 e4m3fn (Linear weights of scaled-fp8 checkpoints)
   int64_t numel;
 };
 
 struct Lin {
-  const bf16_t* w = nullptr;
+  const bf16_t* w = nullptr;   // bf16 weight [N, K] ...
   const bf16_t* b = nullptr;
+  const uint8_t* w8 = nullptr; // ... or fp8 e4m3fn weight + `<name>.scale_weight` (QLinearScaledFP8, shared/qtypes/scaled_fp8.py:563-637)
+  const float* ws = nullptr;
+  int ns = 0;                  // 1 (per tensor) or N (per output row)
 };
 struct Attn {
   Lin q, k, v, o;
@@ -123,6 +129,7 @@ struct wan_ctx {
   wan_dit_config cfg;
   std::map<std::string, Tensor> weights;
   bool resolved = false;
+  bool any_fp8 = false;
   std::vector<Layer> layers;
   const float* pe_w = nullptr;
   const float* pe_b = nullptr;
@@ -145,8 +152,6 @@ struct wan_ctx {
   bf16_t* clip_tmp = nullptr;   // 2 x [257, 1280] scratch, owned
   bool clip_set = false;
 };
-constexpr int CLIP_TOK = 257, CLIP_DIM = 1280, CLIP_LDV = 320;
-
 extern "C" int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out) {
   WAN_REQUIRE(cfg && out, "wan_dit_create: null argument");
   WAN_REQUIRE(cfg->dim % cfg->num_heads == 0 && cfg->dim / cfg->num_heads == 128,
@@ -171,7 +176,7 @@ extern "C" void wan_dit_destroy(wan_ctx* ctx) {
 
 extern "C" int wan_dit_set_weight(wan_ctx* ctx, const char* name, const void* ptr, int dtype, int64_t numel) {
   WAN_REQUIRE(ctx && name && ptr, "wan_dit_set_weight: null argument");
-  WAN_REQUIRE(dtype == 0 || dtype == 1, "wan_dit_set_weight: dtype must be 0 (bf16) or 1 (fp32)");
+  WAN_REQUIRE(dtype == 0 || dtype == 1 || dtype == 2, "wan_dit_set_weight: dtype must be 0 (bf16), 1 (fp32) or 2 (fp8 e4m3fn)");
   WAN_REQUIRE((((uintptr_t)ptr) & 15) == 0, "wan_dit_set_weight: %s is not 16-byte aligned", name);
   ctx->weights[name] = Tensor{ptr, dtype, numel};
   ctx->resolved = false;
@@ -202,7 +207,24 @@ static int get_w(wan_ctx* c, const std::string& name, int dtype, int64_t numel, 
   } while (0)
 
 static int get_lin(wan_ctx* c, Lin& l, const std::string& prefix, int64_t out_f, int64_t in_f) {
-  GETB(l.w, prefix + ".weight", out_f * in_f);
+  l = Lin();
+  auto it = c->weights.find(prefix + ".weight");
+  if (it != c->weights.end() && it->second.dtype == 2) {
+    // scaled-fp8 Linear: fp8 weight + fp32 scale (scalar, [N] or [N, 1]) registered as `<prefix>.scale_weight`
+    WAN_REQUIRE(it->second.numel == out_f * in_f, "weight '%s.weight' has %lld elements, expected %lld", prefix.c_str(),
+                (long long)it->second.numel, (long long)(out_f * in_f));
+    WAN_REQUIRE(in_f % 128 == 0 && out_f % 16 == 0, "fp8 Linear '%s': in_features %lld must be a multiple of 128, out_features %lld of 16",
+                prefix.c_str(), (long long)in_f, (long long)out_f);
+    auto is = c->weights.find(prefix + ".scale_weight");
+    WAN_REQUIRE(is != c->weights.end() && is->second.dtype == 1 && (is->second.numel == 1 || is->second.numel == out_f),
+                "fp8 Linear '%s' needs '%s.scale_weight': fp32, 1 or %lld elements", prefix.c_str(), prefix.c_str(), (long long)out_f);
+    l.w8 = (const uint8_t*)it->second.ptr;
+    l.ws = (const float*)is->second.ptr;
+    l.ns = (int)is->second.numel;
+    c->any_fp8 = true;
+  } else {
+    GETB(l.w, prefix + ".weight", out_f * in_f);
+  }
   GETB(l.b, prefix + ".bias", out_f);
   return 0;
 }
@@ -229,6 +251,7 @@ static int load_layer(wan_ctx* c, Layer& L, const std::string& p) {
 
 static int resolve(wan_ctx* c) {
   if (c->resolved) return 0;
+  c->any_fp8 = false;
   const wan_dit_config& g = c->cfg;
   const int64_t d = g.dim;
   GETF(c->pe_w, "patch_embedding.weight", d * g.in_dim * 4);
@@ -299,11 +322,14 @@ struct Carve {
 
 struct Bufs {
   bf16_t *x, *xm, *q, *k, *vt, *h, *ctx_h, *ctx_e, *ck, *cvt, *sinus, *e_h, *e, *e_s, *e0, *kfull, *vtfull, *ckimg, *cvtimg, *vc, *vskip;
+  uint8_t* xq;  // fp8 checkpoints: quantised activations, one slot per stream (q8_slot bytes each), and their scale pairs
+  float* qws;
+  int64_t q8_slot;
   float* kmax;  // scratch of the self-attention K pre-pass (wan_attention_bounded): wan_attention_scratch_words(S, S, Ll, heads)
   int64_t Lp;
 };
 
-static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, bool vace = false) {
+static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, bool vace = false, bool fp8 = false) {
   Carve c(ws);
   const int64_t d = g.dim, rows = (int64_t)S * Ll;
   const int64_t Lp = ((Ll + 63) / 64) * 64;
@@ -325,6 +351,13 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.e_s = c.take<bf16_t>(d);
   t.e0 = c.take<bf16_t>(6 * d);
   t.kmax = c.take<float>(wan_attention_scratch_words(S, S, Ll, g.num_heads));
+  // scaled-fp8 Linears quantise their input per tensor = per stream (the reference runs the streams of a joint pass one
+  // after the other through each block, model.py:1993-2036): the widest Linear input of one stream, S slots
+  const int64_t tmax = std::max<int64_t>(std::max<int64_t>(Ll, g.text_len), CLIP_TOK);
+  const int64_t kmax_in = std::max(std::max(g.dim, g.ffn_dim), std::max(g.text_dim, CLIP_DIM));
+  t.q8_slot = fp8 ? ((tmax * kmax_in + 255) / 256) * 256 : 0;
+  t.xq = fp8 ? c.take<uint8_t>(t.q8_slot * S) : nullptr;
+  t.qws = fp8 ? c.take<float>(64 * S) : nullptr;
   t.ckimg = c.take<bf16_t>((int64_t)CLIP_TOK * d);      // i2v CLIP branch: K_img [257, d] and V_img^T [d, 320] (3.3 + 3.3 MB at 14B)
   t.cvtimg = c.take<bf16_t>((int64_t)d * CLIP_LDV);
   t.vc = vace ? c.take<bf16_t>(rows * d) : nullptr;      // VACE: the hint token streams and the projected hint of one block
@@ -340,11 +373,17 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   return c.off;
 }
 
+static bool ctx_has_fp8(const wan_ctx* c) {
+  for (const auto& kv : c->weights)
+    if (kv.second.dtype == 2) return true;
+  return false;
+}
+
 extern "C" int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int H, int W, int seq_shards) {
   if (!ctx || S < 1 || seq_shards < 1) return -1;
   const int64_t L = (int64_t)F * (H / 2) * (W / 2);
   if (L % seq_shards != 0) return -1;
-  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, !ctx->vace_layers.empty());
+  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, !ctx->vace_layers.empty(), ctx_has_fp8(ctx));
 }
 
 #define RC(expr)             \
@@ -352,10 +391,31 @@ extern "C" int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int
     if (int _rc = (expr)) return _rc; \
   } while (0)
 
+// One nn.Linear of the forward.  bf16 weights: one GEMM over all M rows.  Scaled-fp8 weights (Lin::w8): the M rows are `nt`
+// equal tensors (the streams of the joint pass), each quantised on its own (_quantize_activation is per tensor) into its
+// fp8 slot and multiplied by its own launch; `reuse` = the slots already hold this input (q / k / v share one quantisation).
+// ldc != 0 with WAN_EPI_TRANSPOSED: C is [N, ldc] (V^T); callers pass one stream at a time (nt = 1, slot = stream).
+struct Q8 {
+  uint8_t* xq = nullptr;
+  float* ws = nullptr;
+  int64_t slot_bytes = 0;
+};
 static int linear(const bf16_t* A, const Lin& l, bf16_t* C, int64_t M, int N, int K, int epi, void* st,
                   const bf16_t* R = nullptr, const bf16_t* mod = nullptr, const bf16_t* e = nullptr, int gate = -1,
-                  int64_t rpb = 1, int64_t ldc = 0) {
-  return wan_gemm_bf16(A, K, l.w, l.b, C, ldc ? ldc : N, M, N, K, epi, R, mod, e, 6, gate, rpb, st);
+                  int64_t rpb = 1, int64_t ldc = 0, const Q8* q8 = nullptr, int nt = 1, int slot0 = 0, bool reuse = false) {
+  if (l.w8 == nullptr) return wan_gemm_bf16(A, K, l.w, l.b, C, ldc ? ldc : N, M, N, K, epi, R, mod, e, 6, gate, rpb, st);
+  WAN_REQUIRE(q8 && q8->xq && M % nt == 0, "fp8 Linear without quantisation scratch (internal)");
+  const int64_t Mt = M / nt;
+  WAN_REQUIRE(Mt * K <= q8->slot_bytes, "fp8 Linear input %lld x %d exceeds the quantisation slot (internal)", (long long)Mt, K);
+  for (int t = 0; t < nt; ++t) {
+    uint8_t* xq = q8->xq + (int64_t)(slot0 + t) * q8->slot_bytes;
+    float* ws = q8->ws + (int64_t)(slot0 + t) * 64;
+    if (!reuse) RC(wan_fp8_quantize(A + (int64_t)t * Mt * K, xq, ws, Mt * K, st));
+    const int64_t co = (epi == WAN_EPI_TRANSPOSED) ? 0 : (int64_t)t * Mt * N;
+    RC(wan_gemm_fp8(xq, K, ws, l.w8, l.ws, l.ns, l.b, C + co, ldc ? ldc : N, Mt, N, K, epi, R ? R + co : nullptr, mod, e, 6, gate,
+                    rpb < Mt ? rpb : Mt, st));
+  }
+  return 0;
 }
 
 extern "C" int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void* stream);
@@ -375,6 +435,7 @@ extern "C" int wan_dit_set_clip(wan_ctx* c, const wan_bf16* clip_fea, void* stre
   bf16_t* t1 = c->clip_tmp;
   bf16_t* t2 = t1 + (int64_t)CLIP_TOK * CLIP_DIM;
   bf16_t* t3 = t2 + (int64_t)CLIP_TOK * CLIP_DIM;
+  WAN_REQUIRE(!c->ie1.w8 && !c->ie3.w8, "wan_dit_set_clip: img_emb Linears must be bf16 (dequantise them at load)");
   RC(wan_ln_affine(clip_fea, t1, c->ie_ln0w, c->ie_ln0b, CLIP_TOK, CLIP_DIM, 1e-5f, stream));
   RC(linear(t1, c->ie1, t2, CLIP_TOK, CLIP_DIM, CLIP_DIM, WAN_EPI_NONE, stream));
   RC(wan_act_bf16(t2, t2, (int64_t)CLIP_TOK * CLIP_DIM, 2, stream));
@@ -412,12 +473,15 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
   WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
   Bufs b;
-  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, !c->vace_layers.empty());
+  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, !c->vace_layers.empty(), c->any_fp8);
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
               (long long)workspace_bytes, (long long)need);
   WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
   hipStream_t st = as_stream(stream);
   const int64_t Lp = b.Lp;
+  Q8 q8v;
+  q8v.xq = b.xq; q8v.ws = b.qws; q8v.slot_bytes = b.q8_slot;
+  const Q8* q8 = c->any_fp8 ? &q8v : nullptr;
 
   // V^T padding columns must be finite for the PV MFMA (P = 0 there)
   WAN_CHECK_HIP(hipMemsetAsync(b.vt, 0, (size_t)S * d * Lp * 2, st));
@@ -428,15 +492,21 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, g.out_dim, g.in_dim - g.out_dim, F, H, W, d,
                              tok0, Ll, stream));
   RC(wan_sinusoid_val(t, b.sinus, g.freq_dim, stream));
-  RC(wan_gemv_bf16(b.sinus, c->tm0.w, c->tm0.b, b.e_h, 1, d, g.freq_dim, stream));
+  // M = 1 Linears of the time MLP: the GEMV kernel for bf16 weights, the tile GEMM (one ragged row) for fp8 ones
+  auto gemv = [&](const bf16_t* A, const Lin& l, bf16_t* C, int N, int K) -> int {
+    if (l.w8) return linear(A, l, C, 1, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8);
+    return wan_gemv_bf16(A, l.w, l.b, C, 1, N, K, stream);
+  };
+  RC(gemv(b.sinus, c->tm0, b.e_h, d, g.freq_dim));
   RC(wan_act_bf16(b.e_h, b.e_h, d, 1, stream));
-  RC(wan_gemv_bf16(b.e_h, c->tm2.w, c->tm2.b, b.e, 1, d, d, stream));
+  RC(gemv(b.e_h, c->tm2, b.e, d, d));
   RC(wan_act_bf16(b.e, b.e_s, d, 1, stream));
-  RC(wan_gemv_bf16(b.e_s, c->tp1.w, c->tp1.b, b.e0, 1, 6 * d, d, stream));
+  RC(gemv(b.e_s, c->tp1, b.e0, 6 * d, d));
   for (int s = 0; s < S; ++s) {
-    RC(linear(context[s], c->te0, b.ctx_h + (int64_t)s * TL * d, TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream));
+    RC(linear(context[s], c->te0, b.ctx_h + (int64_t)s * TL * d, TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream, nullptr, nullptr, nullptr,
+              -1, 1, 0, q8, 1, s));
   }
-  RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream));
+  RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
 
   // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups (rpb = rows in run_blocks)
 
@@ -482,15 +552,16 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     // -- self attention (model.py:632-660) --
     RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
     // V^T first: under sequence parallelism its all-gather then overlaps the Q/K projections + RMSNorm/RoPE
-    for (int s = 0; s < S; ++s)
-      RC(wan_gemm_bf16(b.xm + (int64_t)s * Ll * d, d, Lw.self.v.w, Lw.self.v.b, b.vt + (int64_t)s * d * Lp, Lp, Ll, d, d,
-                       WAN_EPI_TRANSPOSED, nullptr, nullptr, nullptr, 0, -1, 1, stream));
+    for (int s = 0; s < S; ++s)  // (fp8: this quantises stream s of xm into slot s; q and k below reuse the slots)
+      RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                nullptr, nullptr, -1, 1, Lp, q8, 1, s));
     if (world > 1 && sp->gather_begin(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
       wan_set_error("wan_dit_forward: V^T all-gather failed");
       return 3;
     }
-    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream));
-    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream));
+    const bool vq = Lw.self.v.w8 != nullptr;  // slots hold xm already
+    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq));
+    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq || Lw.self.q.w8));
     {
       ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
       RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(),
@@ -509,38 +580,39 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       ProfScope ps(PROF_SELF_ATTN, st);
       RC(wan_attention_bounded(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, 1, b.kmax, stream));
     }
-    RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb));
+    RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb, 0, q8, S));
     // -- cross attention (model.py:663-668, :245-265) --
     RC(wan_ln_affine(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, stream));
-    RC(linear(b.xm, Lw.cross.q, b.q, rows, d, d, WAN_EPI_NONE, stream));
-    RC(wan_rmsnorm_rope(b.q, nullptr, Lw.cross.nq, nullptr, nullptr, nullptr, rows, Ll, 0, d, g.eps, stream));
-    RC(linear(b.ctx_e, Lw.cross.k, b.ck, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream));
+    RC(linear(b.xm, Lw.cross.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+    // norm only; the softmax scale * log2(e) folded into q as for self-attention
+    RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.cross.nq, nullptr, nullptr, nullptr, rows, Ll, 0, d, g.eps, wan_attention_qscale(), stream));
+    RC(linear(b.ctx_e, Lw.cross.k, b.ck, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
     RC(wan_rmsnorm_rope(b.ck, nullptr, Lw.cross.nk, nullptr, nullptr, nullptr, (int64_t)S * TL, TL, 0, d, g.eps, stream));
     for (int s = 0; s < S; ++s)
-      RC(wan_gemm_bf16(b.ctx_e + (int64_t)s * TL * d, d, Lw.cross.v.w, Lw.cross.v.b, b.cvt + (int64_t)s * d * TL, TL, TL,
-                       d, d, WAN_EPI_TRANSPOSED, nullptr, nullptr, nullptr, 0, -1, 1, stream));
+      RC(linear(b.ctx_e + (int64_t)s * TL * d, Lw.cross.v, b.cvt + (int64_t)s * d * TL, TL, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                nullptr, nullptr, -1, 1, TL, q8, 1, s, Lw.cross.k.w8 != nullptr));
     if (!c->has_img) {
       ProfScope ps(PROF_CROSS_ATTN, st);
-      RC(wan_attention(b.q, b.ck, b.cvt, b.q, S, S, Ll, TL, TL, nh, stream));
+      RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.q, S, S, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
     } else {
       // WanI2VCrossAttention (model.py:466-499): the same q attends the text tokens and the 257 CLIP tokens (K_img / V_img
       // shared by every stream), the two bf16 results are added, then o.  xm is free here: it takes the text result.
-      RC(linear(c->clip_ctx, Lw.kimg, b.ckimg, CLIP_TOK, d, d, WAN_EPI_NONE, stream));
+      RC(linear(c->clip_ctx, Lw.kimg, b.ckimg, CLIP_TOK, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8));
       RC(wan_rmsnorm_rope(b.ckimg, nullptr, Lw.nkimg, nullptr, nullptr, nullptr, CLIP_TOK, CLIP_TOK, 0, d, g.eps, stream));
-      RC(wan_gemm_bf16(c->clip_ctx, d, Lw.vimg.w, Lw.vimg.b, b.cvtimg, CLIP_LDV, CLIP_TOK, d, d, WAN_EPI_TRANSPOSED, nullptr,
-                       nullptr, nullptr, 0, -1, 1, stream));
+      RC(linear(c->clip_ctx, Lw.vimg, b.cvtimg, CLIP_TOK, d, d, WAN_EPI_TRANSPOSED, stream, nullptr, nullptr, nullptr, -1, 1, CLIP_LDV,
+                q8, 1, 0, Lw.kimg.w8 != nullptr));
       ProfScope ps(PROF_CROSS_ATTN, st);
-      RC(wan_attention(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TL, TL, nh, stream));
-      RC(wan_attention(b.q, b.ckimg, b.cvtimg, b.q, S, 1, Ll, CLIP_TOK, CLIP_LDV, nh, stream));
+      RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+      RC(wan_attention_bounded(b.q, b.ckimg, b.cvtimg, b.q, S, 1, Ll, CLIP_TOK, CLIP_LDV, nh, 1, 0, 0, 1, nullptr, stream));
       RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }
-    RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb));
+    RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb, 0, q8, S));
     // -- FFN (model.py:686-711) --
     RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 3, 4, rows, rpb, d, g.eps, stream));
     {
       ProfScope ps(PROF_GEMM, st);  // the two FFN GEMMs: 4*rows*d*ffn FLOP
-      RC(linear(b.xm, Lw.f0, b.h, rows, ffn, d, WAN_EPI_GELU_TANH, stream));
-      RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb));
+      RC(linear(b.xm, Lw.f0, b.h, rows, ffn, d, WAN_EPI_GELU_TANH, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb, 0, q8, S));
     }
     return 0;
   };
@@ -552,13 +624,13 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       // runs the same layer code on the hint streams, with the main streams' e0 / text context / RoPE.
       const Layer& Vw = c->vlayers[n];
       if (n == 0) {  // c = before_proj(c) + x
-        RC(linear(vc, Vw.before, vskip, rows, d, d, WAN_EPI_GATE_RES, stream, x_main, nullptr, nullptr, -1, rpb));
+        RC(linear(vc, Vw.before, vskip, rows, d, d, WAN_EPI_GATE_RES, stream, x_main, nullptr, nullptr, -1, rpb, 0, q8, S));
         bf16_t* t2 = vc; vc = vskip; vskip = t2;
       }
       b.x = vc;
       RC(run_layer(Vw));
       b.x = x_main;
-      RC(linear(vc, Vw.after, vskip, rows, d, d, WAN_EPI_NONE, stream));  // c_skip = after_proj(c)
+      RC(linear(vc, Vw.after, vskip, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));  // c_skip = after_proj(c)
     }
     RC(run_layer(c->layers[i]));
     if (n >= 0) RC(wan_axpy_bf16(b.x, vskip, vace_scale, b.x, rows * (int64_t)d, stream));  // x.add_(hint[, alpha=scale]) (:713-719)

@@ -84,6 +84,23 @@ class WanModelHIP:
                 k = k[len("model.diffusion_model."):]
             if k.endswith("modulation.weight"):           # post-init form (model.py:1291-1303)
                 k = k[: -len(".weight")]
+            # scaled-fp8 checkpoints (QLinearScaledFP8._load_from_state_dict, shared/qtypes/scaled_fp8.py:563-637): fp8 weight +
+            # fp32 `<name>.scale_weight` (alias `.weight_scale`); input / output scales are not used at inference
+            if k.endswith((".input_scale", ".output_scale", ".comfy_quant")) or k == "scaled_fp8":
+                continue
+            if k.endswith((".scale_weight", ".weight_scale")):
+                k = k[: k.rindex(".")] + ".scale_weight"
+                t = v.detach().to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+                self._weights[k] = t
+                check(lib.wan_dit_set_weight(self._ctx, k.encode(), ptr(t), 1, t.numel()), f"wan_dit_set_weight({k})")
+                continue
+            if v.dtype == torch.float8_e4m3fn:
+                t = v.detach().to(device=self.device).contiguous()
+                self._weights[k] = t
+                check(lib.wan_dit_set_weight(self._ctx, k.encode(), ptr(t), 2, t.numel()), f"wan_dit_set_weight({k})")
+                continue
+            if v.dtype == torch.float8_e5m2:
+                raise NotImplementedError(f"{k}: float8_e5m2 weights (scaled_float8_e5m2) are not implemented; e4m3fn is")
             want = torch.float32 if k.startswith(FP32_PREFIXES) else torch.bfloat16
             if k.startswith("vace_patch_embedding."):
                 # a bf16 Conv3d in the reference (lock_layers_dtypes, model.py:1351-1355); the fp32 patch-embed kernel gets

@@ -1,0 +1,201 @@
+"""`family_handler` of the HIP backend -- the model-family plugin surface of the reference (seam B4).
+
+The reference discovers model families through modules that expose a `family_handler` object: built-in ones are listed in
+`family_handlers` (wgp.py:2469) and mapped by `map_family_handlers` (wgp.py:2717-2735); a *model plugin* adds more through
+`plugin_info.json: {"type": "model", "model_handlers": [...]}` (docs/PLUGINS.md:37-56).  This module is such a handler: the
+same static interface as `models/wan/wan_handler.py:72` for the model types the HIP path implements, whose `load_model`
+(:1116-1158) builds a resident-weights `WanAny2VHIP` pipeline instead of `WanAny2V` + mmgp offload.
+
+    plugin_info.json:  {"name": "Wan on MI355X (HIP)", "type": "model", "model_handlers": ["wan2gp_amd.wan_handler"]}
+
+The HIP handler claims DISTINCT type names (suffix `_hip`) so that it can be installed next to the built-in Wan handler:
+`map_family_handlers` raises when two handlers claim one model type (wgp.py:2727-2729).  A model definition JSON selects
+it with `"architecture": "t2v_2_2_hip"` etc.  `load_model` returns `(pipeline, {"pipe": {...}})`: the modules handed to
+`offload.profile` (wgp.py:4074-4090) are empty because nothing is offloaded -- all weights stay in the 288 GB of HBM.
+"""
+import os
+
+import torch
+
+# architecture of each supported base type (models/wan/configs/<type>.json of the reference)
+_ARCH = {
+    "t2v": dict(model_type="t2v", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=16, out_dim=16),
+    "t2v_1.3B": dict(model_type="t2v", dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, in_dim=16, out_dim=16),
+    "t2v_2_2": dict(model_type="t2v", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=16, out_dim=16),
+    "i2v": dict(model_type="i2v", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, out_dim=16),
+    "i2v_2_2": dict(model_type="i2v2_2", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, out_dim=16),
+    "ti2v_2_2": dict(model_type="ti2v2_2", dim=3072, ffn_dim=14336, num_heads=24, num_layers=30, in_dim=48, out_dim=48),
+    "vace_14B": dict(model_type="t2v", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=16, out_dim=16,
+                     vace_layers=list(range(0, 40, 5)), vace_in_dim=96),
+    "vace_1.3B": dict(model_type="t2v", dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, in_dim=16, out_dim=16,
+                      vace_layers=list(range(0, 30, 2)), vace_in_dim=96),
+}
+SUFFIX = "_hip"
+
+
+def base_of(model_type: str) -> str:
+    return model_type[: -len(SUFFIX)] if model_type.endswith(SUFFIX) else model_type
+
+
+def test_class_i2v(base_model_type):            # wan_handler.py:16-17 restricted to the supported types
+    return base_of(base_model_type) in ("i2v", "i2v_2_2")
+
+
+def test_class_t2v(base_model_type):
+    return base_of(base_model_type) in ("t2v", "t2v_1.3B", "t2v_2_2")
+
+
+def test_class_1_3B(base_model_type):
+    return base_of(base_model_type) in ("t2v_1.3B", "vace_1.3B")
+
+
+def test_vace(base_model_type):
+    return base_of(base_model_type) in ("vace_14B", "vace_1.3B")
+
+
+def test_wan_5B(base_model_type):
+    return base_of(base_model_type) in ("ti2v_2_2",)
+
+
+def test_i2v_2_2(base_model_type):
+    return base_of(base_model_type) in ("i2v_2_2",)
+
+
+class family_handler():
+    @staticmethod
+    def query_supported_types():
+        return [k + SUFFIX for k in _ARCH]
+
+    @staticmethod
+    def query_family_maps():
+        """(equivalence map, compatibility map) of wan_handler.py:81-107, restricted to the supported types."""
+        eqv = {"t2v_1.3B" + SUFFIX: "t2v" + SUFFIX, "t2v_2_2" + SUFFIX: "t2v" + SUFFIX}
+        comp = {"t2v" + SUFFIX: [t + SUFFIX for t in ("vace_14B", "vace_1.3B", "t2v_1.3B")]}
+        return eqv, comp
+
+    @staticmethod
+    def query_model_family():
+        return "wan"
+
+    @staticmethod
+    def query_family_infos():
+        return {"wan": (0, "Wan2.1"), "wan2_2": (1, "Wan2.2")}
+
+    @staticmethod
+    def query_model_def(base_model_type, model_def):
+        """The properties wgp.py reads from a Wan model definition (wan_handler.py:216-1007), for the supported types: class
+        flags, fps, frame grid, VAE block size, profile folders, the sampler / guidance / step-skipping capabilities."""
+        b = base_of(base_model_type)
+        i2v, t2v, vace, wan_5B = test_class_i2v(b), test_class_t2v(b), test_vace(b), test_wan_5B(b)
+        multiple_submodels = "URLs2" in model_def
+        group = "wan2_2" if (b in ("t2v_2_2", "ti2v_2_2") or test_i2v_2_2(b)) else "wan"
+        if b == "t2v_2_2" or test_i2v_2_2(b):
+            profiles_dir = "wan_2_2"
+        elif i2v:
+            profiles_dir = "wan_i2v"
+        elif wan_5B:
+            profiles_dir = "wan_2_2_5B"
+        elif test_class_1_3B(b):
+            profiles_dir = "wan_1.3B"
+        else:
+            profiles_dir = "wan"
+        extra = {
+            "riflex": True, "i2v_class": i2v, "t2v_class": t2v, "vace_class": vace, "wan_5B_class": wan_5B,
+            "multitalk_class": False, "standin_class": False, "lynx_class": False, "alpha_class": False,
+            "i2v_2_2": test_i2v_2_2(b), "color_correction": True,
+            "vae_block_size": 32 if wan_5B else 16, "profiles_dir": [profiles_dir], "group": group, "fps": 24 if wan_5B else 16,
+            "frames_minimum": 17 if vace else 5, "frames_steps": 4,
+            "sliding_window": b in ("t2v", "t2v_2_2") or i2v or wan_5B or vace,
+            "multiple_submodels": multiple_submodels, "guidance_max_phases": 3, "flow_shift": True, "cfg_zero": True, "cfg_star": True,
+            "adaptive_projected_guidance": True,
+            "tea_cache": not (b == "i2v_2_2" or wan_5B or multiple_submodels), "mag_cache": True,
+            "sample_solvers": [("unipc", "unipc"), ("euler", "euler"), ("dpm++", "dpm++"), ("flowmatch causvid", "causvid"), ("lcm + ltx", "lcm")],
+            "sub_parallel_windows": False,
+            # what the HIP path does not implement: offload, compile, in-app quantisation
+            "compile": False, "no_quantization": True, "backend": "hip-gfx950",
+        }
+        if multiple_submodels:
+            extra["no_steps_skipping"] = True
+        if i2v:
+            extra["motion_amplitude"] = True
+            extra["black_frame"] = True
+        return extra
+
+    @staticmethod
+    def query_model_files(computeList, base_model_type, model_def=None):
+        """Nothing to download beyond what the model definition's URLs name: VAE and text-encoder files are read from `ckpts/`
+        under the reference's own file names (wan_handler.py:1016-1070)."""
+        return []
+
+    @staticmethod
+    def get_rgb_factors(base_model_type):
+        return None, None
+
+    @staticmethod
+    def load_model(model_filename, model_type, base_model_type, model_def, quantizeTransformer=False, text_encoder_quantization=None,
+                   dtype=torch.bfloat16, VAE_dtype=torch.float32, mixed_precision_transformer=False, save_quantized=False,
+                   submodel_no_list=None, text_encoder_filename=None, VAE_upsampling=None, checkpoint_dir="ckpts", device="cuda",
+                   state_dicts=None, vae_state_dict=None, text_encoder=None, **kwargs):
+        """wan_handler.load_model (:1116-1158) for the HIP backend.  `model_filename`: the checkpoint path(s) wgp.py resolved
+        (one per expert for Wan2.2).  Returns (WanAny2VHIP, {"pipe": {...}}).
+        Test hooks: `state_dicts` / `vae_state_dict` / `text_encoder` bypass the file reads."""
+        if quantizeTransformer or save_quantized:
+            raise NotImplementedError("on-the-fly quantisation is part of the reference's low-VRAM machinery; the HIP backend loads "
+                                      "bf16 or scaled-fp8 checkpoints as they are")
+        if mixed_precision_transformer:
+            raise NotImplementedError("mixed-precision (fp32 residual stream) transformer: bf16 only")
+        from .checkpoint import normalize_wan_keys, read_safetensors
+        from .model import WanModelHIP
+        from .pipeline import WanAny2VHIP
+        b = base_of(base_model_type)
+        if b not in _ARCH:
+            raise ValueError(f"model type {base_model_type!r} is not supported by the HIP Wan handler ({sorted(_ARCH)})")
+        arch = _ARCH[b]
+        files = [model_filename] if isinstance(model_filename, str) else list(model_filename or [])
+        if submodel_no_list:
+            files = [f for f, no in zip(files, submodel_no_list) if no in (1, 2)] or files
+        sds = list(state_dicts) if state_dicts is not None else [normalize_wan_keys(read_safetensors(f)) for f in files]
+        if not sds:
+            raise ValueError("load_model: no checkpoint given")
+        models = [WanModelHIP(device=device, **arch).load_state_dict(sd) for sd in sds[:2]]
+        vae = None
+        if vae_state_dict is not None or os.path.isdir(checkpoint_dir):
+            if wan_5B := test_wan_5B(b):
+                from .vae22 import Wan22VAEHIP as VAE
+                name = "Wan2.2_VAE.safetensors"
+            else:
+                from .vae import WanVAEHIP as VAE
+                name = "Wan2.1_VAE.safetensors"
+            path = os.path.join(checkpoint_dir, name)
+            if vae_state_dict is not None:
+                vae = VAE(state_dict=vae_state_dict, device=device)
+            elif os.path.isfile(path):
+                vae = VAE(vae_pth=path, device=device)
+        if text_encoder is None and text_encoder_filename and os.path.isfile(str(text_encoder_filename)):
+            # any2video.py:128-134: T5EncoderModel(text_len, checkpoint, tokenizer_path = <checkpoint's folder>)
+            from .t5 import T5EncoderModelHIP
+            from .tokenizers import HuggingfaceTokenizer
+            tok = HuggingfaceTokenizer(name=os.path.dirname(str(text_encoder_filename)), seq_len=512, clean="whitespace")
+            text_encoder = T5EncoderModelHIP(512, tok, state_dict=read_safetensors(text_encoder_filename), device=device)
+        pipe = WanAny2VHIP(models[0], models[1] if len(models) > 1 else None, vae=vae, text_encoder=text_encoder, device=device,
+                           vae_stride=(4, 16, 16) if test_wan_5B(b) else (4, 8, 8))
+        pipe.model_def, pipe.base_model_type = model_def, base_model_type
+        # wgp.py:4074-4076: a handler may return {"pipe": modules_for_mmgp, **kwargs}; nothing here is offloaded
+        return pipe, {"pipe": {}}
+
+    @staticmethod
+    def fix_settings(base_model_type, settings_version, model_def, ui_defaults):
+        return None
+
+    @staticmethod
+    def update_default_settings(base_model_type, model_def, ui_defaults):
+        """Defaults of wan_handler.update_default_settings (:1252-1455) for the supported types."""
+        ui_defaults.update({"sample_solver": "unipc"})
+        if test_class_i2v(base_model_type) and "S" in model_def.get("image_prompt_types_allowed", ""):
+            ui_defaults["image_prompt_type"] = "S"
+
+    @staticmethod
+    def validate_generative_settings(base_model_type, model_def, inputs):
+        if inputs.get("sample_solver", "unipc") not in ("unipc", "", "euler", "dpm++", "causvid", "lcm"):
+            return f"Unsupported sample solver {inputs.get('sample_solver')!r}"
+        return None
