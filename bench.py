@@ -8,7 +8,7 @@ synthetic random latents / context / random-init weights of the named architectu
 region.  Default workload = BASELINE.json configs[2]: Wan2.2 t2v 14B (both experts resident),
 720p x 81 frames (latent 16x21x90x160, L = 75,600 tokens), bf16.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 14B-720p|1.3B-480p|i2v-14B-720p|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 14B-720p|1.3B-480p|i2v-14B-720p|tiny] [--fp8]
 
 N > 1: one rank per GPU over RCCL; the token axis is sharded across ranks (temporal sequence parallelism,
 SURVEY.md section 8e) -- total work fixed -> "strong".  Launched by `torch.distributed.run` (the driver's way) the ranks
@@ -57,8 +57,9 @@ def forward_flops(cfg, L, text_len=512):
     return per_block * n
 
 
-def random_weights(model, cfg, seed):
-    """Random-init weights of the named architecture, generated directly in HBM."""
+def random_weights(model, cfg, seed, fp8=False):
+    """Random-init weights of the named architecture, generated directly in HBM.  fp8: the ten Linears of every block become a
+    scaled-fp8 checkpoint (float8_e4m3fn weight + fp32 per-row `scale_weight`, shared/qtypes/scaled_fp8.py:563-637)."""
     import math
     import torch
     g = torch.Generator(device="cuda").manual_seed(seed)
@@ -85,6 +86,12 @@ def random_weights(model, cfg, seed):
         sd[b + "norm3.weight"] = rn(d, mean=1.0); sd[b + "norm3.bias"] = rn(d, std=0.01)
         sd[b + "ffn.0.weight"] = rn(f, d); sd[b + "ffn.0.bias"] = rn(f, std=0.01)
         sd[b + "ffn.2.weight"] = rn(d, f); sd[b + "ffn.2.bias"] = rn(d, std=0.01)
+        if fp8:
+            for name in [f"{a}.{l}" for a in ("self_attn", "cross_attn") for l in "qkvo"] + ["ffn.0", "ffn.2"]:
+                w = sd[b + name + ".weight"].float()
+                sc = (w.abs().amax(dim=1, keepdim=True) / 448.0).clamp_min(1e-12)
+                sd[b + name + ".weight"] = (w / sc).clamp(-448, 448).to(torch.float8_e4m3fn)
+                sd[b + name + ".scale_weight"] = sc.reshape(-1)
     model.load_state_dict(sd)
     return model
 
@@ -145,6 +152,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the VAE decode / end-to-end block")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
+    ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -183,8 +191,8 @@ def main():
     two_experts = args.workload in ("14B-720p", "i2v-14B-720p")
     i2v = cfg.get("in_dim", 16) == 36
     log(f"workload {args.workload}: building random-init weights")
-    model = random_weights(WanModelHIP(**mcfg), cfg, 1234)
-    model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321) if two_experts else None
+    model = random_weights(WanModelHIP(**mcfg), cfg, 1234, args.fp8)
+    model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321, args.fp8) if two_experts else None
     if world > 1:
         from wan2gp_amd.sp import SequenceParallel
         sp = SequenceParallel(rank, world)
@@ -311,7 +319,8 @@ def main():
         out = {
             "metric": "denoise-steps/s", "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "world": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
                        "solver": "unipc", "parallelism": "sp%d" % world if world > 1 else "single",
                        "forward_TFLOP": forward_flops(cfg, L) / 1e12},

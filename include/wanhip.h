@@ -330,6 +330,11 @@ typedef struct {
   wan_bf16* const* residual;
   const float* vace_context;
   float vace_scale;
+  /* per-frame timesteps (model.py:1812-1818: t is a vector with one entry per latent frame -- ti2v image conditioning,
+   * any2video.py:1496-1499, diffusion forcing): HOST array of F floats, n_t_frames = F; n_t_frames = 0: the scalar t.
+   * Tokens of frame f are modulated by e0[f] (model.py:631-638) and the head by e[f] (:856-862). */
+  const float* t_frames;
+  int n_t_frames;
 } wan_dit_args;
 int wan_dit_forward_ex(wan_ctx* ctx, const wan_dit_args* args, void* stream);
 /* VACE: main-block indices that carry a context block (WanModel(vace_layers=...), model.py:1178-1183; 0,5,...,35 for the

@@ -36,7 +36,7 @@ def test_ctypes_binding_covers_header(built):
     for s in header_symbols():
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
         assert hasattr(L, s)
-    assert L.wan_version() == 1
+    assert L.wan_version() == 2          # bumped with wan_dit_args.t_frames, wan_attention_bounded, wan_gemm_fp8
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

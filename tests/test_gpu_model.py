@@ -241,3 +241,32 @@ def test_vace_scale_and_plain_paths():
     m2, _ = build(O.make_config("tiny"))
     with pytest.raises(NotImplementedError):
         m2([lat.cuda()], t=t, context=[ctx.cuda()], vace_context=[vace.cuda()])
+
+
+def test_per_frame_timesteps_vs_reference_golden():
+    """ti2v image conditioning / diffusion forcing: t is a vector with one entry per latent frame (model.py:1812-1818; the
+    reference zeroes the timestep of the injected source frames, any2video.py:1496-1499); tokens of frame f are modulated with
+    e0[f].  Golden: the reference's own WanModel(model_type='ti2v2_2') forward with t = [0, 455] on a 2-frame latent."""
+    g = load("forward_tiny_ti2v.npz")
+    f, h, w = [int(v) for v in g["shape"]]
+    cfg = O.make_config("tiny_ti2v")
+    m, W = build(cfg)
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    tf = torch.full((f,), int(g["t"][0]), dtype=torch.int64)
+    tf[:1] = 0
+    outs = m([lat.cuda(), lat.cuda()], t=tf, context=[ctx.cuda(), ctx_null.cuda()])
+    plain = m([lat.cuda(), lat.cuda()], t=torch.tensor([int(g["t"][0])]), context=[ctx.cuda(), ctx_null.cuda()])
+    W32 = O.synth_weights(cfg, dtype=torch.float32)
+    anchor = O.dit_forward([lat, lat], tf, [ctx.float(), ctx_null.float()], W32, cfg, dtype=torch.float32, exact=True)
+    for o, p, key, a in zip(outs, plain, ("cond_tframe_bf16", "uncond_tframe_bf16"), anchor):
+        ref = torch.from_numpy(g[key])
+        err_ref, err_hip = rel(ref, a), rel(o.cpu(), a)
+        print(f"per-frame t / {key}: err_ref={err_ref:.4e} err_hip={err_hip:.4e} hip-vs-ref={rel(o.cpu(), ref):.4e}")
+        assert err_hip <= 1.5 * err_ref + 2e-3 and rel(o.cpu(), ref) <= 2.5e-2
+        assert rel(o.cpu(), p.cpu()) > 1e-2                                  # frame 0 really saw t = 0
+    # a [1, F] tensor (diffusion forcing) is the same call; a wrong length is an error
+    o2 = m([lat.cuda()], t=tf.view(1, -1), context=[ctx.cuda()])[0]
+    assert torch.equal(o2.cpu(), outs[0].cpu())
+    from wan2gp_amd.lib import WanHipError
+    with pytest.raises(WanHipError):
+        m([lat.cuda()], t=torch.tensor([1, 2, 3]), context=[ctx.cuda()])

@@ -22,9 +22,10 @@ class FakeDiT:
     def __call__(self, x, t, context, **kw):
         xs = list(x)
         x.clear()
-        self.calls.append(dict(tag=self.tag, t=float(t), n=len(xs), step=kw.get("current_step_no"), x_id=kw.get("x_id", 0),
+        tmax = float(t.flatten().max())                      # per-frame t (ti2v injection): the denoising frames' timestep
+        self.calls.append(dict(tag=self.tag, t=tmax, n=len(xs), step=kw.get("current_step_no"), x_id=kw.get("x_id", 0),
                                freqs=kw["freqs"], y=kw.get("y")))
-        g = torch.Generator().manual_seed(int(float(t)) + len(self.calls))
+        g = torch.Generator().manual_seed(int(tmax) + len(self.calls))
         return [0.1 * torch.randn(u.shape, generator=g) + 0.05 * i for i, u in enumerate(xs)]
 
     # step-skipping cache API used by generate()
@@ -275,3 +276,27 @@ def test_clip_fea_reaches_the_model_and_i2v21_requires_it():
     cf = torch.zeros(1, 257, 1280)
     run(pipe, y=torch.zeros(20, 3, 8, 8), clip_fea=cf, sampling_steps=2)
     assert got and all(g is cf for g in got)
+
+
+def test_ti2v_timestep_injection_passes_a_per_frame_t_and_pins_the_source_latents():
+    """any2video.py:1496-1499, :1753-1754: with an input video the ti2v model sees t = [0 (source frames), t, t, ...] and the
+    source latents are re-imposed before every step and after the last."""
+    seen = []
+
+    class Dit(FakeDiT):
+        model_type = "ti2v2_2"
+
+        def __call__(self, x, t, context, **kw):
+            seen.append((t.clone(), x[0][:, :, :1].clone()))
+            return super().__call__(x, t, context, **kw)
+
+    class Vae:
+        def encode(self, videos, tile_size=0):
+            return [torch.full((16, 1, 8, 8), 7.0)]
+    out = run(WanAny2VHIP(Dit("A"), vae=Vae(), device="cpu"), input_video=torch.zeros(3, 1, 64, 64), sampling_steps=3)
+    for t, first in seen:
+        assert t.shape == (3,) and t[0] == 0 and (t[1:] == t[1]).all() and t[1] > 0
+        assert (first == 7.0).all()
+    assert (out["latents"][:, :, :1] == 7.0).all()
+    with pytest.raises(ValueError, match="ti2v"):
+        run(WanAny2VHIP(FakeDiT("A"), vae=Vae(), device="cpu"), input_video=torch.zeros(3, 1, 64, 64))

@@ -22,7 +22,7 @@ void wan_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wan_last_error(void) { return g_err; }
-extern "C" int wan_version(void) { return 1; }
+extern "C" int wan_version(void) { return 2; }
 extern "C" int wan_device_cus(void) {
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -35,7 +35,7 @@ int wan_patch_embed_range(const float* x, const float* y, const float* w, const 
                           int Cy, int F, int H, int W, int d, int64_t tok0, int64_t ntok, void* stream);
 int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const float* w, const float* bias, bf16_t* tmp,
                    float* out, int B, int F, int Hg, int Wg, int d, float eps, int64_t tok0, int64_t ntok,
-                   int token_major_out, int e_shared, int nout, void* stream);
+                   int token_major_out, int64_t e_rows_per_batch, int nout, void* stream);
 int wan_sinusoid_val(float t, bf16_t* out, int dim, void* stream);
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ----
@@ -329,7 +329,7 @@ struct Bufs {
   int64_t Lp;
 };
 
-static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, bool vace = false, bool fp8 = false) {
+static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, bool vace, bool fp8, int F) {
   Carve c(ws);
   const int64_t d = g.dim, rows = (int64_t)S * Ll;
   const int64_t Lp = ((Ll + 63) / 64) * 64;
@@ -345,11 +345,14 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.ctx_e = c.take<bf16_t>((int64_t)S * g.text_len * d);
   t.ck = c.take<bf16_t>((int64_t)S * g.text_len * d);
   t.cvt = c.take<bf16_t>((int64_t)S * d * g.text_len);
-  t.sinus = c.take<bf16_t>(g.freq_dim);
-  t.e_h = c.take<bf16_t>(d);
-  t.e = c.take<bf16_t>(d);
-  t.e_s = c.take<bf16_t>(d);
-  t.e0 = c.take<bf16_t>(6 * d);
+  // time embedding / projection: one row per timestep -- 1 normally, up to F with per-frame timesteps (model.py:1812-1818;
+  // ti2v image conditioning any2video.py:1496-1499, diffusion forcing); e0 is replicated per stream so that a kernel's
+  // row / rows_per_batch lookup works on the stacked streams
+  t.sinus = c.take<bf16_t>((int64_t)F * g.freq_dim);
+  t.e_h = c.take<bf16_t>((int64_t)F * d);
+  t.e = c.take<bf16_t>((int64_t)F * d);
+  t.e_s = c.take<bf16_t>((int64_t)F * d);
+  t.e0 = c.take<bf16_t>((int64_t)S * F * 6 * d);
   t.kmax = c.take<float>(wan_attention_scratch_words(S, S, Ll, g.num_heads));
   // scaled-fp8 Linears quantise their input per tensor = per stream (the reference runs the streams of a joint pass one
   // after the other through each block, model.py:1993-2036): the widest Linear input of one stream, S slots
@@ -383,7 +386,7 @@ extern "C" int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int
   if (!ctx || S < 1 || seq_shards < 1) return -1;
   const int64_t L = (int64_t)F * (H / 2) * (W / 2);
   if (L % seq_shards != 0) return -1;
-  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, !ctx->vace_layers.empty(), ctx_has_fp8(ctx));
+  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, !ctx->vace_layers.empty(), ctx_has_fp8(ctx), F);
 }
 
 #define RC(expr)             \
@@ -449,7 +452,7 @@ extern "C" int wan_dit_set_clip(wan_ctx* c, const wan_bf16* clip_fea, void* stre
 // with residual[s] != NULL either runs the block chain and leaves residual[s] = x_after_blocks - x_after_patch_embed
 // (should_calc[s] != 0), or skips the chain and adds the stored residual to its freshly embedded tokens.  The decision is
 // host logic (wan2gp_amd/skipcache.py); both arrays NULL = the plain forward.
-static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
+static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, const float* t_frames, const wan_bf16* const* context,
                             const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
                             int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                             void* poll_user, const int* should_calc, wan_bf16* const* residual, const float* vace_context,
@@ -473,7 +476,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
   WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
   Bufs b;
-  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, !c->vace_layers.empty(), c->any_fp8);
+  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, !c->vace_layers.empty(), c->any_fp8, F);
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
               (long long)workspace_bytes, (long long)need);
   WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
@@ -491,17 +494,31 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   for (int s = 0; s < S; ++s)
     RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, g.out_dim, g.in_dim - g.out_dim, F, H, W, d,
                              tok0, Ll, stream));
-  RC(wan_sinusoid_val(t, b.sinus, g.freq_dim, stream));
-  // M = 1 Linears of the time MLP: the GEMV kernel for bf16 weights, the tile GEMM (one ragged row) for fp8 ones
-  auto gemv = [&](const bf16_t* A, const Lin& l, bf16_t* C, int N, int K) -> int {
-    if (l.w8) return linear(A, l, C, 1, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8);
+  // Timesteps: one scalar, or one per latent frame (t_frames[F], HOST pointer): tokens of frame f are modulated by
+  // e0[f] (model.py:631-638, :856-862).  Under sequence parallelism a rank needs the rows of its own frames only, which
+  // requires shards made of whole frames.
+  const int64_t tpf = (int64_t)Hg * Wg;  // tokens per frame
+  int nt = 1, frame0 = 0;
+  if (t_frames != nullptr) {
+    WAN_REQUIRE(Ll % tpf == 0 && tok0 % tpf == 0, "wan_dit_forward: per-frame timesteps need sequence shards made of whole frames "
+                "(%lld tokens per shard, %lld per frame)", (long long)Ll, (long long)tpf);
+    nt = (int)(Ll / tpf);
+    frame0 = (int)(tok0 / tpf);
+  }
+  for (int f = 0; f < nt; ++f)
+    RC(wan_sinusoid_val(t_frames ? t_frames[frame0 + f] : t, b.sinus + (int64_t)f * g.freq_dim, g.freq_dim, stream));
+  // the time MLP: GEMV for one row of bf16 weights, the tile GEMM otherwise (several rows, or fp8 weights: one tensor)
+  auto tlin = [&](const bf16_t* A, const Lin& l, bf16_t* C, int N, int K) -> int {
+    if (l.w8 || nt > 1) return linear(A, l, C, nt, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8);
     return wan_gemv_bf16(A, l.w, l.b, C, 1, N, K, stream);
   };
-  RC(gemv(b.sinus, c->tm0, b.e_h, d, g.freq_dim));
-  RC(wan_act_bf16(b.e_h, b.e_h, d, 1, stream));
-  RC(gemv(b.e_h, c->tm2, b.e, d, d));
-  RC(wan_act_bf16(b.e, b.e_s, d, 1, stream));
-  RC(gemv(b.e_s, c->tp1, b.e0, 6 * d, d));
+  RC(tlin(b.sinus, c->tm0, b.e_h, d, g.freq_dim));
+  RC(wan_act_bf16(b.e_h, b.e_h, (int64_t)nt * d, 1, stream));
+  RC(tlin(b.e_h, c->tm2, b.e, d, d));
+  RC(wan_act_bf16(b.e, b.e_s, (int64_t)nt * d, 1, stream));
+  RC(tlin(b.e_s, c->tp1, b.e0, 6 * d, d));
+  for (int s = 1; s < S && nt > 1; ++s)
+    WAN_CHECK_HIP(hipMemcpyAsync(b.e0 + (int64_t)s * nt * 6 * d, b.e0, (size_t)nt * 6 * d * 2, hipMemcpyDeviceToDevice, st));
   for (int s = 0; s < S; ++s) {
     RC(linear(context[s], c->te0, b.ctx_h + (int64_t)s * TL * d, TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream, nullptr, nullptr, nullptr,
               -1, 1, 0, q8, 1, s));
@@ -540,7 +557,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   // text context are offset (maximal runs of computing streams; all of them in the plain forward)
   auto run_blocks = [&](const int s0, const int Sn) -> int {
   const int S = Sn;
-  const int64_t rows = (int64_t)Sn * Ll, rpb = rows;
+  const int64_t rows = (int64_t)Sn * Ll, rpb = nt > 1 ? tpf : rows;
   struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; } b2 = {
       b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax};
   bf16_t* const x_main = b.x + s0 * sn;
@@ -651,7 +668,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   // ---- head + unpatchify (model.py:2068-2097) -------------------------------------------------------
   for (int s = 0; s < S; ++s)
     RC(wan_head_range(b.x + (int64_t)s * Ll * d, c->head_mod, b.e, c->head_w, c->head_b, b.xm, outs[s], 1, F, Hg, Wg, d,
-                      g.eps, tok0, Ll, world > 1 ? 1 : 0, 1, 4 * g.out_dim, stream));
+                      g.eps, tok0, Ll, world > 1 ? 1 : 0, nt > 1 ? tpf : 0, 4 * g.out_dim, stream));
   return 0;
 }
 
@@ -659,7 +676,7 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
                                const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
                                int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                void* poll_user, void* stream) {
-  return dit_forward_impl(c, S, x, t, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
+  return dit_forward_impl(c, S, x, t, nullptr, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
                           nullptr, nullptr, nullptr, 1.0f, stream);
 }
 
@@ -667,13 +684,15 @@ extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, fl
                                     const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
                                     int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                     void* poll_user, const int* should_calc, wan_bf16* const* residual, void* stream) {
-  return dit_forward_impl(c, S, x, t, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
+  return dit_forward_impl(c, S, x, t, nullptr, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
                           should_calc, residual, nullptr, 1.0f, stream);
 }
 
 extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* stream) {
   WAN_REQUIRE(c && a, "wan_dit_forward_ex: null argument");
-  return dit_forward_impl(c, a->S, a->x, a->t, a->context, a->y, a->cos, a->sin, a->outs, a->F, a->H, a->W, a->workspace,
+  WAN_REQUIRE(a->n_t_frames == 0 || (a->t_frames != nullptr && a->n_t_frames == a->F),
+              "wan_dit_forward_ex: t_frames must hold one timestep per latent frame (%d given, F = %d)", a->n_t_frames, a->F);
+  return dit_forward_impl(c, a->S, a->x, a->t, a->n_t_frames ? a->t_frames : nullptr, a->context, a->y, a->cos, a->sin, a->outs, a->F, a->H, a->W, a->workspace,
                           a->workspace_bytes, a->sp, a->poll, a->poll_user, a->should_calc, a->residual, a->vace_context,
                           a->vace_scale, stream);
 }

@@ -160,12 +160,13 @@ __global__ void unpatchify_kernel(const float* __restrict__ in, float* __restric
 
 int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const float* w, const float* bias, bf16_t* tmp,
                    float* out, int B, int F, int Hg, int Wg, int d, float eps, int64_t tok0, int64_t ntok,
-                   int token_major_out, int e_shared, int nout, void* stream) {
+                   int token_major_out, int64_t e_rows_per_batch, int nout, void* stream) {
   WAN_REQUIRE(x && hmod && e && w && bias && tmp && out, "wan_head: null pointer");
   WAN_REQUIRE(nout >= 4 && nout % 4 == 0 && nout <= 1024, "wan_head: nout=%d must be 4 * out_dim", nout);
   const int64_t rows = (int64_t)B * ntok;
-  // e_shared: one e [1,d] for every batch row (the streams of a joint CFG pass share t)
-  int rc = wan_ln_modulate_head(x, tmp, hmod, e, rows, e_shared ? (rows > 0 ? rows : 1) : ntok, d, eps, stream);
+  // e_rows_per_batch: 0 = one e [1,d] for every row (the streams of a joint CFG pass share t); else e [n,d] with row r using
+  // e[r / e_rows_per_batch] (per-frame timesteps: tokens per frame; or one e per batch element: ntok)
+  int rc = wan_ln_modulate_head(x, tmp, hmod, e, rows, e_rows_per_batch > 0 ? e_rows_per_batch : (rows > 0 ? rows : 1), d, eps, stream);
   if (rc) return rc;
   if (ntok == 0) return 0;
   dim3 grid((unsigned)((ntok + 63) / 64), (unsigned)B, (unsigned)((nout + 63) / 64));
@@ -177,12 +178,12 @@ int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const fl
 
 extern "C" int wan_head(const wan_bf16* x, const float* hmod, const wan_bf16* e, const float* w, const float* bias,
                         wan_bf16* tmp, float* out, int B, int F, int Hg, int Wg, int d, float eps, void* stream) {
-  return wan_head_range(x, hmod, e, w, bias, tmp, out, B, F, Hg, Wg, d, eps, 0, (int64_t)F * Hg * Wg, 0, 0, 64, stream);
+  return wan_head_range(x, hmod, e, w, bias, tmp, out, B, F, Hg, Wg, d, eps, 0, (int64_t)F * Hg * Wg, 0, (int64_t)F * Hg * Wg, 64, stream);
 }
 
 extern "C" int wan_head_n(const wan_bf16* x, const float* hmod, const wan_bf16* e, const float* w, const float* bias,
                           wan_bf16* tmp, float* out, int B, int F, int Hg, int Wg, int d, float eps, int nout, void* stream) {
-  return wan_head_range(x, hmod, e, w, bias, tmp, out, B, F, Hg, Wg, d, eps, 0, (int64_t)F * Hg * Wg, 0, 0, nout, stream);
+  return wan_head_range(x, hmod, e, w, bias, tmp, out, B, F, Hg, Wg, d, eps, 0, (int64_t)F * Hg * Wg, 0, (int64_t)F * Hg * Wg, nout, stream);
 }
 
 static int unpatchify_n(const float* in, float* out, int B, int F, int Hg, int Wg, int nout, void* stream) {

@@ -36,7 +36,7 @@ class DitArgs(ctypes.Structure):
                 ("cos", c_void_p), ("sin", c_void_p), ("outs", POINTER(c_void_p)), ("F", c_int), ("H", c_int), ("W", c_int),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64), ("sp", c_void_p), ("poll", c_void_p),
                 ("poll_user", c_void_p), ("should_calc", POINTER(c_int)), ("residual", POINTER(c_void_p)),
-                ("vace_context", c_void_p), ("vace_scale", c_float)]
+                ("vace_context", c_void_p), ("vace_scale", c_float), ("t_frames", POINTER(c_float)), ("n_t_frames", c_int)]
 GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p)
 GATHER_WAIT_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p)
 

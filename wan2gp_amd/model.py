@@ -203,9 +203,13 @@ class WanModelHIP:
         ctxs = [c.to(device=dev, dtype=torch.bfloat16).contiguous() for c in context]
         if any(c.shape[-2] != self.text_len or c.shape[0] != 1 for c in ctxs):
             raise _L.WanHipError(f"context must be [1,{self.text_len},{self.text_dim}] per stream")
-        if t.numel() != 1:
-            raise NotImplementedError("per-frame / diffusion-forcing timesteps (model.py:1812) are not implemented")
-        tval = float(t.flatten()[0].item())
+        # t: one timestep, or one per latent frame (model.py:1812-1818; ti2v image conditioning any2video.py:1496-1499,
+        # diffusion forcing with a [1, F] tensor)
+        tflat = t.detach().flatten().to(torch.float32).cpu()
+        if tflat.numel() not in (1, F):
+            raise _L.WanHipError(f"t must hold 1 or F={F} timesteps, got {tflat.numel()}")
+        tval = float(tflat[0].item())
+        t_frames = (ctypes.c_float * F)(*[float(v) for v in tflat]) if tflat.numel() == F and F > 1 else None
         yy = None if y is None else y.to(device=dev, dtype=torch.float32).contiguous()
         if freqs is None:
             freqs = get_rotary_pos_embed((F, H, W))
@@ -238,14 +242,14 @@ class WanModelHIP:
         CP = (c_void_p * S)(*[a.data_ptr() for a in ctxs])
         OP = (c_void_p * S)(*[a.data_ptr() for a in outs])
         cache = self.cache
-        if vace_t is not None:
-            if tuple(vace_t.shape) != (self.vace_in_dim, F, H, W):
+        if vace_t is not None or t_frames is not None:
+            if vace_t is not None and tuple(vace_t.shape) != (self.vace_in_dim, F, H, W):
                 raise _L.WanHipError(f"vace_context must be [{self.vace_in_dim},{F},{H},{W}], got {list(vace_t.shape)}")
             if cache is not None:
-                raise NotImplementedError("VACE together with a step-skipping cache")
+                raise NotImplementedError("VACE / per-frame timesteps together with a step-skipping cache")
             a = _L.DitArgs(S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws), ws.numel(),
                            None if sp_struct is None else ctypes.cast(sp_struct, c_void_p), ctypes.cast(poll, c_void_p), None, None, None,
-                           ptr(vace_t), vace_scale)
+                           ptr(vace_t), vace_scale, t_frames, F if t_frames is not None else 0)
             rc = _L.load().wan_dit_forward_ex(self._ctx, ctypes.byref(a), stream_ptr())
         elif cache is None:
             rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),

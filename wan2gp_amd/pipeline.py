@@ -130,7 +130,7 @@ class WanAny2VHIP:
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
-                 motion_amplitude=1.0, clip_fea=None, **bbargs):
+                 motion_amplitude=1.0, clip_fea=None, input_video=None, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -165,6 +165,14 @@ class WanAny2VHIP:
             if self.vae is None:
                 raise ValueError("image_start needs a VAE to encode the conditioning video")
             y, ext_latents = self.build_i2v_conditioning(image_start, frame_num, height, width, VAE_tile_size, motion_amplitude)
+        # ti2v (Wan2.2 5B) image / video conditioning by timestep injection (any2video.py:1060-1072, :1496-1499, :1753-1754):
+        # the VAE latents of the source frames replace the first latent frames before every step and after the last one, and
+        # those frames are given timestep 0 -- a per-frame t vector
+        source_latents = None
+        if input_video is not None:
+            if getattr(self.model, "model_type", None) != "ti2v2_2" or self.vae is None:
+                raise ValueError("input_video (timestep injection) is the ti2v_2_2 conditioning path and needs the Wan2.2 VAE")
+            source_latents = self.vae.encode([input_video.to(dev)], VAE_tile_size)[0].unsqueeze(0)
         vace_kwargs = {}
         if input_frames is not None:                         # VACE control video + mask (any2video.py:1128-1147), no reference images
             if self.vae is None or input_masks is None:
@@ -232,6 +240,11 @@ class WanAny2VHIP:
                         trans = self.model2
                     guide_scale, guidance_switch2_done = guide3_scale, True
                 timestep = torch.stack([t])
+                if source_latents is not None:                   # any2video.py:1496-1499
+                    n_src = source_latents.shape[2]
+                    latents[:, :, :n_src] = source_latents
+                    timestep = torch.full((target_shape[1],), int(t), dtype=torch.int64, device=latents.device)
+                    timestep[:n_src] = 0
                 kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": i})
                 if loras_slists is not None and getattr(trans, "loras", None) is not None:
                     trans.loras.set_step(loras_slists, len(timesteps), i, phase_switch_step, phase_switch_step2)
@@ -280,6 +293,8 @@ class WanAny2VHIP:
                     callback(i, latents[0], False)
         finally:
             restore_caches()                                 # also when a forward raises: parked caches must come back
+        if source_latents is not None:
+            latents[:, :, :source_latents.shape[2]] = source_latents                               # :1753-1754
         if ext_latents is not None:
             latents[:, :, :ext_latents.shape[2]] = ext_latents                                     # :1755-1756
         if return_latents or self.vae is None:
