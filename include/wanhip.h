@@ -155,6 +155,20 @@ int64_t wan_attention_scratch_words(int B, int Bk, int64_t Lq, int H);
 int wan_attention_bounded(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
                           int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
                           int64_t vt_seg_stride, int q_prescaled, float* kmax_scratch, void* stream);
+/* Sequence-parallel self-attention in two launches (q pre-scaled, Bk == B), so that compute starts before the K / V^T
+ * all-gathers of the other ranks' segments have finished:
+ *   wan_attention_sp_local : the rank's OWN segment k_local [B,Lk,H,128], vt_local [B,H*128,ldv] -> unnormalised partial sums
+ *                            in raw (wan_attention_raw_words(B, Lq, H) floats);
+ *   wan_attention_sp_remote: after the gathers -- every other segment of k_all / vt_all (layout of wan_attention_seg; own_seg is
+ *                            skipped) on top of raw, normalised into o.
+ * Partial sums add because the bounded softmax has no reference shift; workgroups whose rows exceed the bound are recomputed by
+ * the lazy-max loop over all segments.  scratch: wan_attention_scratch_words(B, B, Lq, H) words, shared by the two calls. */
+int64_t wan_attention_raw_words(int B, int64_t Lq, int H);
+int wan_attention_sp_local(const wan_bf16* q, const wan_bf16* k_local, const wan_bf16* vt_local, int B, int64_t Lq, int64_t Lk,
+                           int64_t ldv, int H, float* scratch, float* raw, void* stream);
+int wan_attention_sp_remote(const wan_bf16* q, const wan_bf16* k_all, const wan_bf16* vt_all, wan_bf16* o, int B, int64_t Lq,
+                            int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride, int64_t vt_seg_stride, int own_seg,
+                            float* scratch, float* raw, void* stream);
 /* (1/sqrt(128)) * log2(e): the factor wan_attention_prescaled expects folded into q */
 float wan_attention_qscale(void);
 

@@ -470,3 +470,38 @@ def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
     got2 = ops.attention(cu(qs), cu(k2), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
     assert (scratch[B * H:].view(torch.int32) == 1).all()
     assert attn_ok(got2, _prescaled_ref(qs, k2, v))
+
+
+@pytest.mark.parametrize("own", [0, 2, 3])
+def test_attention_sp_local_first_equals_contiguous(ops, own):
+    """wan_attention_sp_local (own segment, partial sums) + wan_attention_sp_remote (the other segments on top, own skipped) ==
+    attention over the concatenated segments, for the first / a middle / the last rank; ragged segment length (2,130 = 33 tiles +
+    18 rows) and ragged q (300 rows); the own segment inside k_all is poisoned to prove it is never read."""
+    g = torch.Generator().manual_seed(40 + own)
+    B, Lq, Lk, H, nseg = 2, 300, 2130, 2, 4
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF)
+    k = torch.randn(nseg, B, Lk, H, 128, generator=g).to(BF); v = torch.randn(nseg, B, Lk, H, 128, generator=g).to(BF)
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    ref = _prescaled_ref(qs, torch.cat(list(k), dim=1), torch.cat(list(v), dim=1))
+    vt = torch.stack([ops.transpose_v(cu(v[s])) for s in range(nseg)]).contiguous()
+    k_all = cu(k).clone(); vt_all = vt.clone()
+    k_all[own] = float("nan"); vt_all[own] = float("nan")                      # a rank's own slot of the gather buffer is not needed
+    got, scratch = ops.attention_sp(cu(qs), cu(k[own]), vt[own].contiguous(), k_all, vt_all, own)
+    assert attn_ok(got, ref), (got.float().cpu() - ref).abs().max().item()
+    assert (scratch[B * H:].view(torch.int32) == 0).all()                        # every workgroup stayed on the bounded path
+
+
+def test_attention_sp_bound_exceeded_is_recomputed_by_the_tracking_loop(ops):
+    """A q-block whose rows break the bound only against a REMOTE segment (a huge key there): phase 0 accepts it (local bound),
+    phase 1 flags it, and the tracking loop recomputes it over all four segments."""
+    g = torch.Generator().manual_seed(50)
+    B, Lq, Lk, H, nseg, own = 1, 600, 2112, 1, 4, 1
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF)
+    k = torch.randn(nseg, B, Lk, H, 128, generator=g).to(BF); v = torch.randn(nseg, B, Lk, H, 128, generator=g).to(BF)
+    k[3, 0, 77, 0] *= 90.0                                                       # |k| ~ 1000: bound ~ 1400 log2 units for every q row
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    ref = _prescaled_ref(qs, torch.cat(list(k), dim=1), torch.cat(list(v), dim=1))
+    vt = torch.stack([ops.transpose_v(cu(v[s])) for s in range(nseg)]).contiguous()
+    got, scratch = ops.attention_sp(cu(qs), cu(k[own]), vt[own].contiguous(), cu(k), vt, own)
+    assert (scratch[B * H:].view(torch.int32) == 1).all()
+    assert attn_ok(got, ref), (got.float().cpu() - ref).abs().max().item()

@@ -18,15 +18,20 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, q, backend="gloo"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if backend == "nccl" else 0               # RCCL: one GPU per rank; gloo: both ranks share cuda:0 (host-staged gathers)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import wan_oracle as O
         from wan2gp_amd.model import WanModelHIP
         from wan2gp_amd.sp import SequenceParallel
-        torch.cuda.set_device(0)
         cfg = O.make_config("small")
         W = O.synth_weights(cfg, seed=77)
         m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers)
@@ -61,3 +66,21 @@ def test_sp_forward_two_ranks_one_gpu():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_sp_forward_rccl_when_two_gpus_are_present():
+    """The same comparison over RCCL (backend "nccl"): exercises the asynchronous `all_gather_into_tensor(async_op=True)` branch of
+    wan2gp_amd/sp.py -- K and V^T gathers in flight while the rank attends its own segment.  Needs >= 2 GPUs: skipped on the
+    single-GPU test boxes (the multi-GPU driver run is where it executes)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -32,6 +32,10 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
                              int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
                              int64_t vt_seg_stride, float scale_log2e, float* kmax_scratch, hipStream_t stream);
 
+int wan_attention_w64q_sp(int phase, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int64_t Lq, int64_t Lk,
+                          int64_t ldv, int H, int nseg, int64_t k_seg_stride, int64_t vt_seg_stride, int own_seg,
+                          float scale_log2e, float* kmax_scratch, float* raw, hipStream_t stream);
+
 constexpr int KVBLK = 64;
 constexpr float SCALE_LOG2E = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
 
@@ -109,6 +113,26 @@ extern "C" int wan_attention_bounded(const wan_bf16* q, const wan_bf16* k, const
                                      int64_t vt_seg_stride, int q_prescaled, float* kmax_scratch, void* stream) {
   return attention_dispatch(q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, q_prescaled != 0,
                             kmax_scratch ? SCRATCH_CALLER : SCRATCH_NONE, kmax_scratch, stream);
+}
+
+extern "C" int64_t wan_attention_raw_words(int B, int64_t Lq, int H) {
+  return ((Lq + 255) / 256) * H * B * (int64_t)(4 * 2 * (64 * 64 + 64));  // per 256-row workgroup: 4 waves x 2 q-blocks x (accumulators + row sums)
+}
+
+// Sequence-parallel self-attention, local segment first (q pre-scaled): see wan_attention_w64q_sp.
+extern "C" int wan_attention_sp_local(const wan_bf16* q, const wan_bf16* k_local, const wan_bf16* vt_local, int B, int64_t Lq,
+                                      int64_t Lk, int64_t ldv, int H, float* scratch, float* raw, void* stream) {
+  WAN_REQUIRE(q && k_local && vt_local && scratch && raw, "wan_attention_sp_local: null pointer");
+  WAN_REQUIRE(ldv % KVBLK == 0 && ldv >= Lk && Lq >= 1 && Lk >= 1, "wan_attention_sp_local: bad shape");
+  return wan_attention_w64q_sp(0, q, k_local, vt_local, nullptr, B, Lq, Lk, ldv, H, 2, 0, 0, 0, SCALE_LOG2E, scratch, raw, as_stream(stream));
+}
+extern "C" int wan_attention_sp_remote(const wan_bf16* q, const wan_bf16* k_all, const wan_bf16* vt_all, wan_bf16* o, int B, int64_t Lq,
+                                       int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride, int64_t vt_seg_stride,
+                                       int own_seg, float* scratch, float* raw, void* stream) {
+  WAN_REQUIRE(q && k_all && vt_all && o && scratch && raw, "wan_attention_sp_remote: null pointer");
+  WAN_REQUIRE(ldv % KVBLK == 0 && ldv >= Lk && Lq >= 1 && Lk >= 1, "wan_attention_sp_remote: bad shape");
+  return wan_attention_w64q_sp(1, q, k_all, vt_all, o, B, Lq, Lk, ldv, H, nseg, k_seg_stride, vt_seg_stride, own_seg, SCALE_LOG2E,
+                               scratch, raw, as_stream(stream));
 }
 
 extern "C" float wan_attention_qscale(void) { return SCALE_LOG2E; }

@@ -405,16 +405,23 @@ __device__ __forceinline__ mfma_bf16x8 prescale8(const uint4 raw, float c) {
 //             allocator needs 256 VGPRs + scratch; apart 202 / 226, no scratch), launched back to back: the bounded one
 //             first -- a workgroup whose rows fail the bound sets wg_flags[id] and returns before touching LDS -- then
 //             the tracking one, whose workgroups return at once unless their flag is set (wg_flags == NULL: all run).
+//       bit4 / bit5 (bounded only): RAW_OUT -- leave the unnormalised fp32 accumulators and row-sum shares in `raw` instead of
+//             writing O; CARRY_IN -- start from them.  The bounded softmax has no reference shift, so partial results over
+//             disjoint kv ranges simply add: sequence parallelism attends the rank's own K / V^T segment (RAW_OUT) while the
+//             all-gather of the others is in flight, then the remote segments (CARRY_IN, skip_seg = own).
 template <int FLAGS>
 __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int B, int Bk,
                                                        int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e,
                                                        int nseg, int64_t k_seg_stride, int64_t vt_seg_stride,
-                                                       const float* __restrict__ kmax2, int* __restrict__ wg_flags) {
+                                                       const float* __restrict__ kmax2, int* __restrict__ wg_flags,
+                                                       float* __restrict__ raw, int skip_seg) {
   constexpr bool TIMING = (FLAGS & 1) != 0;
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
   constexpr bool BND = (FLAGS & 4) != 0;
   constexpr bool DIAG = (FLAGS & 8) != 0;  // timing build only: bounded loop without its row-sum adds (wrong results)
+  constexpr bool RAW_OUT = (FLAGS & 16) != 0, CARRY_IN = (FLAGS & 32) != 0;
+  constexpr int WAVE_RAW = 2 * (64 * 64 + 64), WG_RAW = 4 * WAVE_RAW;  // floats: per q-block 64 accumulators x 64 lanes + 64 row-sum shares
   uint64_t stamp[20] = {};
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stages][V^T stages] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
@@ -427,6 +434,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   const int total = nqb * H * B;
   const int v = xcd_remap(blockIdx.x, total);
   if (!BND && wg_flags != nullptr && wg_flags[v] == 0) return;  // the bounded launch did this workgroup
+  if (BND && CARRY_IN && wg_flags[v] != 0) return;              // an earlier partial launch already gave this workgroup up
   const int pair = v / nqb;
   const int qb = v - pair * nqb;
   const int b = pair / H, h = pair - b * H;
@@ -479,9 +487,9 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   // ---- DMA stream ---------------------------------------------------------------------------------------
   const int Lk32 = (int)Lk;
   const int tps = (Lk32 + KVBLK - 1) / KVBLK;
-  const int ntile = tps * nseg;
+  const int ntile = tps * (nseg - (skip_seg >= 0 ? 1 : 0));
   Dma dma;
-  dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave);
+  dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, skip_seg);
   int cur_tt = 0;
   auto next_kv_rem = [&]() {  // valid kv rows from the start of the tile being consumed to the end of its segment
     const int rem = Lk32 - cur_tt * KVBLK;
@@ -502,6 +510,21 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { qa.accO[dt][r] = 0.f; qbk.accO[dt][r] = 0.f; }
+  if (CARRY_IN) {  // partial sums of an earlier launch over other kv segments (same grid, same workgroup -> same slots)
+    const float4* src = reinterpret_cast<const float4*>(raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        f32x16& acc = blk ? qbk.accO[dt] : qa.accO[dt];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w = src[((blk * 4 + dt) * 4 + g) * 64 + lane];
+          acc[g * 4 + 0] = w.x; acc[g * 4 + 1] = w.y; acc[g * 4 + 2] = w.z; acc[g * 4 + 3] = w.w;
+        }
+        asm volatile("" : "+a"(acc));
+      }
+  }
   set_mref(qa, 0.f, half);
   set_mref(qbk, 0.f, half);
   mfma_bf16x8 kones;  // A fragment of the S-initialising MFMA: 1.0 in k slots 0..2 (lanes < 32), zeros elsewhere
@@ -515,6 +538,11 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   }
   qa.l_run = qbk.l_run = 0.f;
   qa.p0 = qa.p1 = qbk.p0 = qbk.p1 = qa.l0 = qa.l1 = qbk.l0 = qbk.l1 = 0.f;
+  if (CARRY_IN) {
+    const float* ls = raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
+    qa.l0 = ls[lane];
+    qbk.l0 = ls[64 + lane];
+  }
   qa.pe0 = qa.pe1 = qbk.pe0 = qbk.pe1 = 0.f;
   qa.cur0 = qa.ps = qbk.cur0 = qbk.ps = 0.f;
   qa.tmax = qbk.tmax = 0.f;
@@ -605,6 +633,21 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   for (int i = 0; i < 16; ++i) pv_mfma(qbk.accO[i & 3], vf[i >> 2][i & 3], __builtin_bit_cast(mfma_bf16x8, qbk.pk[i >> 2]));
 
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA lands before O staging reuses LDS; last PV MFMAs -> accumulator reads
+  if (RAW_OUT) {  // partial result: accumulators and row-sum shares as they are, lane-major (1-KB stores)
+    float4* dst = reinterpret_cast<float4*>(raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const f32x16 acc = blk ? qbk.accO[dt] : qa.accO[dt];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dst[((blk * 4 + dt) * 4 + g) * 64 + lane] = float4{acc[g * 4 + 0], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
+      }
+    float* ls = raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
+    ls[lane] = qa.l_run;
+    ls[64 + lane] = qbk.l_run;
+    return;
+  }
   // ---- epilogue: normalise, stage the wave's 64 x 128 O tile through LDS, store whole rows -------------------
   const float inva = 1.0f / (qa.l_run + __shfl_xor(qa.l_run, 32, 64));
   const float invb = 1.0f / (qbk.l_run + __shfl_xor(qbk.l_run, 32, 64));
@@ -692,6 +735,8 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   const int64_t nqb = (Lq + 255) / 256;
   const int64_t total = nqb * H * B;
   WAN_REQUIRE(total < ((int64_t)1 << 31), "wan_attention: grid too large");
+  float* raw = nullptr;
+  const int skip_seg = -1;
   int* wg_flags = nullptr;
   if (kmax_scratch != nullptr) {
     // pre-pass: max over the kv rows (all segments) of |k_h|^2 per (batch, head) -> the bounded-softmax test of the kernel;
@@ -705,7 +750,7 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   }
 #define W64Q_LAUNCH(FL)                                                                                              \
   hipLaunchKernelGGL((attn_w64q_kernel<FL>), dim3((unsigned)total), dim3(256), 0, stream, q, k, vt, o, B, Bk, Lq, Lk, \
-                     ldv, H, (int)nqb, scale_log2e, nseg, k_seg_stride, vt_seg_stride, (const float*)kmax_scratch, wg_flags)
+                     ldv, H, (int)nqb, scale_log2e, nseg, k_seg_stride, vt_seg_stride, (const float*)kmax_scratch, wg_flags, raw, skip_seg)
   const bool pre = (flags & 2) != 0;
 #ifdef W64Q_TIMING
   static const bool stamps = [] { const char* e = getenv("WAN_ATTN_STAMPS"); return e && e[0] == '1'; }();
@@ -725,5 +770,49 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   if (pre) W64Q_LAUNCH(2); else W64Q_LAUNCH(0);
 #undef W64Q_LAUNCH
   WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Sequence-parallel self-attention in two phases (q pre-scaled; Bk == B).  The bounded softmax has no reference shift, so the
+// contributions of disjoint kv ranges add:
+//   phase 0  the rank's OWN K / V^T segment (k, vt = the local buffers, available before any collective finishes): K pre-pass
+//            over it, bounded loop, unnormalised accumulators -> raw.  Workgroups whose rows fail the (local) bound are flagged.
+//   phase 1  after the all-gathers: K pre-pass over every segment, bounded loop over the OTHER segments starting from raw
+//            (skip = own_seg), normalise, write O; a workgroup that fails the global bound flags itself, and the tracking loop
+//            then recomputes every flagged workgroup over all segments (it ignores raw).
+// scratch: wan_attention_scratch_words(B, B, Lq, H) words; raw: wan_attention_raw_words(B, Lq, H) floats.
+int wan_attention_w64q_sp(int phase, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int64_t Lq, int64_t Lk,
+                          int64_t ldv, int H, int nseg, int64_t k_seg_stride, int64_t vt_seg_stride, int own_seg,
+                          float scale_log2e, float* kmax_scratch, float* raw, hipStream_t stream) {
+  WAN_REQUIRE(Lk * (int64_t)H * 256 < ((int64_t)1 << 32) && ldv * 256 < ((int64_t)1 << 32),
+              "wan_attention: K/V^T extent exceeds the 32-bit DMA offsets of this kernel");
+  WAN_REQUIRE(kmax_scratch && raw && nseg >= 2 && own_seg >= 0 && own_seg < nseg, "wan_attention_sp: bad arguments");
+  const int Bk = B;
+  const int64_t nqb = (Lq + 255) / 256;
+  const int64_t total = nqb * H * B;
+  WAN_REQUIRE(total < ((int64_t)1 << 31), "wan_attention: grid too large");
+  int* wg_flags = reinterpret_cast<int*>(kmax_scratch + (size_t)B * H);
+  const int rblocks = (int)((Lk + KMAX_ROWS - 1) / KMAX_ROWS);
+#define W64Q_LAUNCH_SP(FL, NSEG, KS, VS, SKIP)                                                                          \
+  hipLaunchKernelGGL((attn_w64q_kernel<FL>), dim3((unsigned)total), dim3(256), 0, stream, q, k, vt, o, B, Bk, Lq, Lk, \
+                     ldv, H, (int)nqb, scale_log2e, NSEG, KS, VS, (const float*)kmax_scratch, wg_flags, raw, SKIP)
+  if (phase == 0) {
+    WAN_CHECK_HIP(hipMemsetAsync(kmax_scratch, 0, ((size_t)B * H + (size_t)total) * 4, stream));   // maxima AND flags
+    hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(B * H), 1u), dim3(256), 0, stream, k, kmax_scratch, B, Lk,
+                       H, (int64_t)0);
+    WAN_LAUNCH_CHECK();
+    W64Q_LAUNCH_SP(2 | 4 | 16, 1, (int64_t)0, (int64_t)0, -1);
+    WAN_LAUNCH_CHECK();
+    return 0;
+  }
+  WAN_CHECK_HIP(hipMemsetAsync(kmax_scratch, 0, (size_t)B * H * 4, stream));                          // maxima only: flags of phase 0 stand
+  hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(B * H), (unsigned)nseg), dim3(256), 0, stream, k,
+                     kmax_scratch, B, Lk, H, k_seg_stride);
+  WAN_LAUNCH_CHECK();
+  W64Q_LAUNCH_SP(2 | 4 | 32, nseg, k_seg_stride, vt_seg_stride, own_seg);
+  WAN_LAUNCH_CHECK();
+  W64Q_LAUNCH_SP(2, nseg, k_seg_stride, vt_seg_stride, -1);
+  WAN_LAUNCH_CHECK();
+#undef W64Q_LAUNCH_SP
   return 0;
 }

@@ -63,19 +63,23 @@ struct Dma {
   const char* vseg0;
   int64_t kseg, vseg;
   int tt, tps, left;  // tile inside the segment, tiles per segment, tiles not yet fetched
+  int seg, skip;      // current segment; segment to leave out (-1: none) -- sequence parallelism attends the rank's own
+                      // segment in a first launch while the others are still arriving
   uint32_t klen, klen0;    // valid K bytes from d.k to the end of the segment ((rows-1)*pitch + 256); at a segment start
   uint32_t rs2, ldv2;      // K / V^T row pitch in bytes
   uint32_t kofs[4], vofs[4];
   int wave;
 };
 __device__ __forceinline__ void dma_init(Dma& d, const void* kbase, const void* vbase, int64_t kseg_bytes, int64_t vseg_bytes,
-                                         int Lk, int nseg, uint32_t rs2, uint32_t ldv2, int tid, int wave) {
-  d.k = d.kseg0 = reinterpret_cast<const char*>(kbase);
-  d.v = d.vseg0 = reinterpret_cast<const char*>(vbase);
+                                         int Lk, int nseg, uint32_t rs2, uint32_t ldv2, int tid, int wave, int skip = -1) {
+  d.seg = (skip == 0) ? 1 : 0;
+  d.skip = skip;
+  d.k = d.kseg0 = reinterpret_cast<const char*>(kbase) + (int64_t)d.seg * kseg_bytes;
+  d.v = d.vseg0 = reinterpret_cast<const char*>(vbase) + (int64_t)d.seg * vseg_bytes;
   d.kseg = kseg_bytes;
   d.vseg = vseg_bytes;
   d.tps = (Lk + KVBLK - 1) / KVBLK;
-  d.tt = 0; d.left = d.tps * nseg;
+  d.tt = 0; d.left = d.tps * (nseg - (skip >= 0 ? 1 : 0));
   d.klen = d.klen0 = (uint32_t)(Lk - 1) * rs2 + 256u;
   d.rs2 = rs2;
   d.ldv2 = ldv2;
@@ -123,8 +127,10 @@ __device__ __forceinline__ void dma_advance(Dma& d) {
   const bool stp = adv && !sw;                 // next tile of the same segment
   d.left -= adv ? 1 : 0;
   d.tt = sw ? 0 : d.tt + (stp ? 1 : 0);
-  d.kseg0 = sw ? d.kseg0 + d.kseg : d.kseg0;
-  d.vseg0 = sw ? d.vseg0 + d.vseg : d.vseg0;
+  const int hop = (sw && d.seg + 1 == d.skip) ? 2 : 1;  // jump over the left-out segment
+  d.seg += sw ? hop : 0;
+  d.kseg0 = sw ? d.kseg0 + hop * d.kseg : d.kseg0;
+  d.vseg0 = sw ? d.vseg0 + hop * d.vseg : d.vseg0;
   const char* kstep = d.k + (int64_t)KVBLK * d.rs2;
   const char* vstep = d.v + KVBLK * 2;
   d.k = sw ? d.kseg0 : (stp ? kstep : d.k);

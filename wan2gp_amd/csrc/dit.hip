@@ -325,6 +325,7 @@ struct Bufs {
   uint8_t* xq;  // fp8 checkpoints: quantised activations, one slot per stream (q8_slot bytes each), and their scale pairs
   float* qws;
   int64_t q8_slot;
+  float* raw;   // sequence parallelism: partial attention sums of the local segment (wan_attention_raw_words)
   float* kmax;  // scratch of the self-attention K pre-pass (wan_attention_bounded): wan_attention_scratch_words(S, S, Ll, heads)
   int64_t Lp;
 };
@@ -368,9 +369,11 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   if (world > 1) {
     t.kfull = c.take<bf16_t>((int64_t)world * rows * d);
     t.vtfull = c.take<bf16_t>((int64_t)world * S * d * Lp);
+    t.raw = c.take<float>(wan_attention_raw_words(S, Ll, g.num_heads));
   } else {
     t.kfull = nullptr;
     t.vtfull = nullptr;
+    t.raw = nullptr;
   }
   if (b) *b = t;
   return c.off;
@@ -558,8 +561,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   auto run_blocks = [&](const int s0, const int Sn) -> int {
   const int S = Sn;
   const int64_t rows = (int64_t)Sn * Ll, rpb = nt > 1 ? tpf : rows;
-  struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; } b2 = {
-      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax};
+  struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; float* raw; } b2 = {
+      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
   bf16_t* const x_main = b.x + s0 * sn;
   bf16_t* vc = vace ? b.vc + s0 * sn : nullptr;      // hint streams of this run; vskip doubles as the swap buffer of before_proj
   bf16_t* vskip = vace ? b.vskip : nullptr;
@@ -568,32 +571,46 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   auto run_layer = [&](const Layer& Lw) -> int {
     // -- self attention (model.py:632-660) --
     RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
-    // V^T first: under sequence parallelism its all-gather then overlaps the Q/K projections + RMSNorm/RoPE
-    for (int s = 0; s < S; ++s)  // (fp8: this quantises stream s of xm into slot s; q and k below reuse the slots)
-      RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                nullptr, nullptr, -1, 1, Lp, q8, 1, s));
-    if (world > 1 && sp->gather_begin(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
-      wan_set_error("wan_dit_forward: V^T all-gather failed");
-      return 3;
-    }
-    const bool vq = Lw.self.v.w8 != nullptr;  // slots hold xm already
-    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq));
-    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq || Lw.self.q.w8));
-    {
-      ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
-      RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(),
-                                 stream));
-    }
     if (world > 1) {
-      if (sp->gather_begin(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream) ||
-          sp->gather_wait(sp->user, 1, stream) || sp->gather_wait(sp->user, 0, stream)) {
+      // Sequence parallelism: K first (projection, RMSNorm + RoPE), its all-gather started at once; then V^T and its gather; the
+      // Q projection / norm and the attention over the rank's OWN K / V^T segment run while both collectives are in flight;
+      // only then the waits, and the other ranks' segments on top of the partial sums (wan_attention_sp_local / _remote).
+      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
+      if (sp->gather_begin(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream)) {
+        wan_set_error("wan_dit_forward: K all-gather failed");
+        return 3;
+      }
+      for (int s = 0; s < S; ++s)
+        RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr));
+      if (sp->gather_begin(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
+        wan_set_error("wan_dit_forward: V^T all-gather failed");
+        return 3;
+      }
+      RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
+                Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr));
+      RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
+      ProfScope ps(PROF_SELF_ATTN, st);
+      RC(wan_attention_sp_local(b.q, b.k, b.vt, S, Ll, Ll, Lp, nh, b.kmax, b.raw, stream));
+      if (sp->gather_wait(sp->user, 0, stream) || sp->gather_wait(sp->user, 1, stream)) {
         wan_set_error("wan_dit_forward: K / V^T all-gather failed");
         return 3;
       }
-      ProfScope ps(PROF_SELF_ATTN, st);
-      RC(wan_attention_bounded(b.q, b.kfull, b.vtfull, b.q, S, S, Ll, Ll, Lp, nh, world, rows * (int64_t)d, (int64_t)S * d * Lp, 1,
-                               b.kmax, stream));
+      RC(wan_attention_sp_remote(b.q, b.kfull, b.vtfull, b.q, S, Ll, Ll, Lp, nh, world, rows * (int64_t)d, (int64_t)S * d * Lp, sp->rank,
+                                 b.kmax, b.raw, stream));
     } else {
+      for (int s = 0; s < S; ++s)  // (fp8: this quantises stream s of xm into slot s; q and k below reuse the slots)
+        RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                  nullptr, nullptr, -1, 1, Lp, q8, 1, s));
+      const bool vq = Lw.self.v.w8 != nullptr;  // slots hold xm already
+      RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq));
+      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq || Lw.self.q.w8));
+      {
+        ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
+        RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(),
+                                   stream));
+      }
       ProfScope ps(PROF_SELF_ATTN, st);
       RC(wan_attention_bounded(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, 1, b.kmax, stream));
     }

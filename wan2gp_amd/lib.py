@@ -74,6 +74,10 @@ SIGNATURES = {
     "wan_attention_bounded": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,
                                       c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "wan_attention_scratch_words": (c_int64, [c_int, c_int, c_int64, c_int]),
+    "wan_attention_raw_words": (c_int64, [c_int, c_int64, c_int]),
+    "wan_attention_sp_local": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "wan_attention_sp_remote": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_int64,
+                                        c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "wan_attention_qscale": (c_float, []),
     "wan_transpose_v": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "wan_t5_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -197,6 +197,26 @@ def attention(q, k, vt, Lk=None, out=None, nseg=1, k_seg_stride=0, vt_seg_stride
     return out
 
 
+def attention_sp(q, k_local, vt_local, k_all, vt_all, own_seg, out=None):
+    """Sequence-parallel self-attention, local segment first (wan_attention_sp_local + wan_attention_sp_remote): q [B,Lq,H,128]
+    pre-scaled, k_local [B,Lk,H,128] / vt_local [B,H*128,ldv] = this rank's segment, k_all [nseg,B,Lk,H,128] / vt_all
+    [nseg,B,H*128,ldv] = the gathered segments (own_seg is not read from them).  Returns (out, between) where `between()` is
+    where a caller waits for its all-gathers; this helper runs both phases back to back."""
+    for t, n in ((q, "q"), (k_local, "k_local"), (vt_local, "vt_local"), (k_all, "k_all"), (vt_all, "vt_all")):
+        _req(t, BF16, n)
+    B, Lq, H, _ = q.shape
+    nseg, Lk, ldv = k_all.shape[0], k_all.shape[2], vt_all.shape[-1]
+    lib = _L.load()
+    scratch = torch.zeros(int(lib.wan_attention_scratch_words(B, B, Lq, H)), dtype=torch.float32, device=q.device)
+    raw = torch.empty(int(lib.wan_attention_raw_words(B, Lq, H)), dtype=torch.float32, device=q.device)
+    out = torch.empty_like(q) if out is None else out
+    check(lib.wan_attention_sp_local(ptr(q), ptr(k_local), ptr(vt_local), B, Lq, Lk, ldv, H, ptr(scratch), ptr(raw), stream_ptr()),
+          "wan_attention_sp_local")
+    check(lib.wan_attention_sp_remote(ptr(q), ptr(k_all), ptr(vt_all), ptr(out), B, Lq, Lk, ldv, H, nseg, B * Lk * H * 128,
+                                      B * H * 128 * ldv, own_seg, ptr(scratch), ptr(raw), stream_ptr()), "wan_attention_sp_remote")
+    return out, scratch
+
+
 def pay_attention(qkv_list, dropout_p=0., softmax_scale=None, causal=False, window_size=(-1, -1),
                   deterministic=False, version=None, force_attention=None, attention_mask=None, recycle_q=False,
                   q_lens=None, k_lens=None):
