@@ -244,15 +244,16 @@ def test_attention_index_algebra(Lq, Lk, nseg):
 
 
 # ----------------------------------------------------------------------------------------------
-# GEMM generations 2 / 3 (gemm32.hip, gemm256.hip): 32x32x16 MFMA, 64-byte LDS rows
+# gemm32.hip (64-row waves) and the 128-row wave layout gemm256k.hip inherited from the removed BK = 32 generation: 32x32x16
+# MFMA, 64-byte LDS rows
 # ----------------------------------------------------------------------------------------------
 def _pi(rho):
-    """LDS row rho of a 32-row x tile holds x row pi(rho) (gemm32.hip / gemm256.hip staging permutation)."""
+    """LDS row rho of a 32-row x tile holds x row pi(rho) (the x-row staging permutation of gemm32.hip / gemm256k.hip / gemm_fp8.hip)."""
     return 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3)
 
 
 def emulate_gemm256_wave(Y, X, wy, wx, wave_rows_x, k0):
-    """One k-step pair (BK = 32) of one wave of gemm256 (wave_rows_x = 128) or gemm32 (64): stages the two LDS images
+    """One k-step pair (BK = 32) of one wave with 128-row (wave_rows_x = 128) or gemm32's 64-row x slabs: stages the two LDS images
     exactly as the DMA plan does, reads the fragments with the kernel's addresses and returns
     (acc[yt][xt][lane][r], conflict_free).  Y/X are float arrays [rows, K]."""
     nxt = wave_rows_x // 32

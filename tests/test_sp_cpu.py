@@ -102,3 +102,52 @@ def test_shard_range_rejects_ragged():
     assert shard_range(147600, 7, 8) == (7 * 18450, 18450)
     with pytest.raises(ValueError):
         shard_range(75601, 0, 8)
+
+
+# ---- the gather callbacks the C++ forward calls back into (wan_sp_info.gather_begin / gather_wait) ------------------------------
+def _cb_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wan2gp_amd.sp import SequenceParallel
+        sp = SequenceParallel(rank, world)
+        # a stand-in for the forward workspace: [K send | V^T send | K recv (world slots) | V^T recv (world slots)]
+        nk, nv = 96, 160
+        ws = torch.zeros(nk + nv + world * (nk + nv), dtype=torch.uint8)
+        ws[:nk] = torch.arange(nk, dtype=torch.uint8) + rank * 3
+        ws[nk:nk + nv] = torch.arange(nv, dtype=torch.uint8) + 100 + rank * 5
+        sp.bind_workspace(ws)
+        info = sp.make_info(L=64 * world)
+        assert (info.rank, info.world, info.tok0, info.tok_local) == (rank, world, 64 * rank, 64)
+        base = ws.data_ptr()
+        # the order wan_dit_forward uses: K gather, V^T gather, (compute), wait K, wait V^T
+        assert sp._gather_begin_cb(None, 0, base, base + nk + nv, nk, None) == 0
+        assert sp._gather_begin_cb(None, 1, base + nk, base + nk + nv + world * nk, nv, None) == 0
+        assert sp._gather_wait_cb(None, 0, None) == 0 and sp._gather_wait_cb(None, 1, None) == 0
+        kr = ws[nk + nv: nk + nv + world * nk].view(world, nk)
+        vr = ws[nk + nv + world * nk:].view(world, nv)
+        for r in range(world):
+            assert torch.equal(kr[r], torch.arange(nk, dtype=torch.uint8) + r * 3)
+            assert torch.equal(vr[r], torch.arange(nv, dtype=torch.uint8) + 100 + r * 5)
+        assert sp._gather_wait_cb(None, 0, None) == 0                     # a second wait is a no-op
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_callbacks_fill_every_ranks_slot_in_rank_order(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cb_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

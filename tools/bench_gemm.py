@@ -8,12 +8,11 @@ from wan2gp_amd import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--M", type=int, default=151200)
 ap.add_argument("--rounds", type=int, default=5)
-ap.add_argument("--variants", default="")
 a = ap.parse_args()
 shapes = [("qkvo", a.M, 5120, 5120, 0), ("o+gate", a.M, 5120, 5120, 2), ("ffn1+gelu", a.M, 13824, 5120, 1), ("ffn2+gate", a.M, 5120, 13824, 2), ("vT", a.M // 2, 5120, 5120, 3)]
 g = torch.Generator(device="cuda").manual_seed(0)
 res = {}
-variants = a.variants.split(",") if a.variants else [""]
+variants = [""]
 for name, M, N, K, epi in shapes:
     x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
@@ -23,8 +22,6 @@ for name, M, N, K, epi in shapes:
     e = torch.randn(1, 6, N, device="cuda", generator=g).to(torch.bfloat16) if epi == 2 else None
     out = torch.empty(N, (M + 63) // 64 * 64, device="cuda", dtype=torch.bfloat16) if epi == 3 else torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     for vn in variants:
-        if vn:
-            os.environ["WAN_GEMM_VARIANT"] = vn
         ts = []
         for i in range(a.rounds + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

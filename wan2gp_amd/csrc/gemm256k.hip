@@ -1,9 +1,9 @@
-// bf16 / fp16 NT GEMM for gfx950, fourth generation: gemm256.hip's one-wave-per-SIMD 256x256 tile with FULL-LINE operand
-// fetches.  Out[y][x] = epilogue( sum_k Y[y][k] * X[x][k] + bias ), same contract / epilogues as the other generations.
+// bf16 / fp16 NT GEMM for gfx950, fourth generation: a one-wave-per-SIMD 256x256 tile (4 waves, each 128x128 = 4x4 MFMA 32x32x16
+// tiles, 256 accumulators in the accumulator file) with FULL-LINE operand fetches.  Out[y][x] = epilogue( sum_k Y[y][k] * X[x][k] + bias ), same contract / epilogues as the other generations.
 //
 // Why: tools/probes/line_probe.hip streams the operand panels of a 16x16 grid of 256x256 tiles through LDS-DMA with no
-// MFMA work at all and 64 KB in flight per CU.  With 64 B per row per piece (the k-tile of 32 that gemm32 / gemm256
-// fetch) a CU ingests 24.2 B/clk -- the L2 -> L1 path moves whole 128-B lines, half of each is thrown away and
+// MFMA work at all and 64 KB in flight per CU.  With 64 B per row per piece (the k-tile of 32 that gemm32 and the
+// removed third generation fetch) a CU ingests 24.2 B/clk -- the L2 -> L1 path moves whole 128-B lines, half of each is thrown away and
 // re-fetched one k-tile later -- with 128 B per row it ingests 38.0 B/clk (13.5 vs 20.8 TB/s chip-wide).  A 256x256 tile
 // needs 32 B/clk/CU at full MFMA rate: the BK=32 kernels are capped at 76 % before any other loss.
 //
@@ -14,10 +14,11 @@
 //     and nobody reads stage S any more (its last fragments are already in registers) -> its two units are free;
 //   * k-step 3 of S issues X_{S+2} (8 pieces per wave, every other MFMA gap) into Y_S's unit: 48 MFMAs = 1536 cycles
 //     before P_{S+1} needs it; k-steps 0 and 1 of S+1 issue Y_{S+3} (4 pieces each) into X_S's unit: > 3000 cycles ahead;
-//   * per MFMA: 0.5 ds_read_b128, 0.25 DMA pieces, no VALU -- as in gemm256.hip; loop unrolled by 5 (unit index = 2S % 5).
+//   * per MFMA: 0.5 ds_read_b128, 0.25 DMA pieces, no VALU; loop unrolled by 5 (unit index = 2S % 5).
 // LDS rows are 128 B; physical 16-B chunk p of row r holds logical chunk p ^ ((r >> 1) & 7): the 16 lanes a ds_read_b128
 // services together (rows {0-3,12-15,20-27} or {4-11,16-19,28-31} of a 32-row tile, same logical chunk) then cover all
-// 64 banks exactly once.  X-row permutation, accumulator layout and epilogue are gemm256.hip's.
+// 64 banks exactly once.  The X operand is the first MFMA operand and its rows are staged in a permuted order (see the DMA plan
+// below), so that a lane's 16 accumulators of one output row are 16 consecutive columns (gemm_bf16.hip's header).
 #include <stdlib.h>
 
 #include "common.h"
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void gemm256k_kernel(const bf16_t* __restrict_
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA; last asm MFMAs -> accumulator reads of the epilogue
 
   // ---- epilogue, through LDS --------------------------------------------------------------------------------------------
-  // Measured with the row-per-lane stores of gemm256.hip (each lane writing 32 B of its own row, a store instruction
+  // Measured with row-per-lane stores (each lane writing 32 B of its own row, a store instruction
   // touching 32 rows): 30.5k cycles per tile = 13.5 % of a K = 5120 tile, three times what 128 KB cost at the rate a CU
   // can store.  The ring is dead now, so each wave parks its 128 x 128 result in its own 34-KB LDS region (bias / GELU
   // applied in the accumulator layout, rows of 256 B + 16 B pad) and reads it back row-major: a store instruction then
@@ -374,8 +375,7 @@ int wan_gemm256k_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
   const int64_t ty = (YM + G_BM - 1) / G_BM, tx = (XN + G_BN - 1) / G_BN;
   if (ty * tx >= ((int64_t)1 << 31)) return -1;
   // y tiles per group of the tile order (measured: 4 beats 8 by 2-7 % on the y = tokens shapes; 16 / 32 lose 10-25 %)
-  static const int group_env = [] { const char* e = getenv("WAN_GEMM_GROUP"); return e ? atoi(e) : 0; }();
-  const int group = group_env > 0 ? group_env : (BIAS_ROWS ? 8 : 4);
+  const int group = BIAS_ROWS ? 8 : 4;
   hipLaunchKernelGGL((gemm256k_kernel<EPI, BIAS_ROWS, F16>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx,
                      XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, out_scale, group);
   WAN_LAUNCH_CHECK();

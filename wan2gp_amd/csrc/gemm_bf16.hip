@@ -4,11 +4,13 @@
 //   normal     : Y = activations A [M,K], X = weights W [N,K]      -> C[M,N]
 //   transposed : Y = weights W [N,K],     X = activations A [M,K]  -> Ct[N,M]  (emits V^T)
 //
-// Two tile shapes, each wave 64x64 = 4x4 MFMA 16x16x32 tiles:
-//   WY = 2: 128(y) x 128(x) x 64(k), 4 waves in 2x2, two workgroups per CU, 2-deep LDS ring (small problems)
-//   WY = 4: 256(y) x 128(x) x 64(k), 8 waves in 4x2, one workgroup per CU, 3-deep LDS ring with counted vmcnt (k-tiles
-//           t+1 and t+2 in flight).  Correct but 20 % slower than WY = 2 on the Wan shapes (see launch_gemm): kept
-//           behind WAN_GEMM_TILE=256.
+// This file: the small-problem kernel (WY = 2: 128(y) x 128(x) x 64(k) tiles, 4 waves in 2x2, each wave 64x64 = 4x4 MFMA
+// 16x16x32 tiles, two workgroups per CU, 2-deep LDS ring) and the launcher that picks a kernel by problem size:
+//   >= 256 tiles of 256x256  -> gemm256k.hip (every Wan projection at 480p and above)
+//   M >= 512 and N >= 128    -> gemm32.hip   (256x128x32 tiles)
+//   anything else            -> this kernel  (time / text MLPs, toy shapes)
+// (A 256-row, 8-wave variant of this kernel -- one workgroup per CU -- measured 20 % slower than two 4-wave workgroups, and the
+// BK = 32 256x256 kernel gemm256.hip 13 % slower than gemm256k; both were removed in round 2.)
 // Global->LDS staging uses the LDS-DMA path (global_load_lds_dwordx4, 16 B per lane, 1 KiB per wave-instruction).
 //
 // LDS image: rows of 64 bf16 (128 B = 8 chunks of 16 B).  LDS-DMA writes lane-linearly, so the
@@ -261,11 +263,7 @@ int wan_gemm32_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, in
                    int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                    int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
-// third-generation kernel (gemm256.hip): 256x256 tiles, one wave per SIMD, accumulators in the accumulator file
-template <int EPI, bool BIAS_ROWS, bool F16>
-int wan_gemm256_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
-                    int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
-                    int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
+// fourth-generation kernel (gemm256k.hip): 256x256x64 tiles, one wave per SIMD, accumulators in the accumulator file
 template <int EPI, bool BIAS_ROWS, bool F16>
 int wan_gemm256k_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                     int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
@@ -277,49 +275,21 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
                        const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st,
                        float out_scale = 1.0f) {
   const int64_t tx = (XN + BN - 1) / BN;
-  // large problems: 256x128x32 tiles on 32x32x16 MFMAs (gemm32.hip); WAN_GEMM_KERNEL=v1 keeps this file's kernel
-  // v4 (default): gemm256k.hip, full-line (BK = 64) fetches; v3: gemm256.hip (BK = 32); *f: whatever the problem size (tests)
-  static const int gen = [] {
-    const char* e = getenv("WAN_GEMM_KERNEL");
-    return !e ? 5 : !strcmp(e, "v1") ? 1 : !strcmp(e, "v2") ? 2 : !strcmp(e, "v3") ? 3 : !strcmp(e, "v3f") ? 4 : !strcmp(e, "v4f") ? 6 : 5;
-  }();
-  const bool use_v1 = gen == 1;
-  // Measured (M = 151200, TFLOP/s, gemm256 with its 4-deep ring vs gemm32): qkvo 1106 vs 946, o+gate 902 vs 869,
-  // ffn1+GELU 1040 vs 918, ffn2+gate 1060 vs 925, V^T 1089 vs 910.  v3f (tests): gemm256 whatever the problem size.
   const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= 256;
-  if (gen == 6 || (gen == 5 && many_tiles)) {
+  if (many_tiles) {
     const int rc = wan_gemm256k_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
                                                          rows_per_batch, st, out_scale);
     if (rc >= 0) return rc;
   }
-  if (gen == 4 || gen == 6 || (gen >= 3 && many_tiles)) {
-    const int rc = wan_gemm256_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
-                                                        rows_per_batch, st, out_scale);
-    if (rc >= 0) return rc;
-  }
-  if (!use_v1 && YM >= 512 && XN >= 128) {
+  if (YM >= 512 && XN >= 128) {
     const int rc = wan_gemm32_try<EPI, BIAS_ROWS, F16>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx,
                                                        rows_per_batch, st, out_scale);
     if (rc >= 0) return rc;
   }
-  // Measured on MI355X (M=151200, Wan 14B shapes): 128-row tiles 790-920 TF, 256-row tiles 620-690 TF -- two independent
-  // 4-wave workgroups per CU cover each other's barrier / DMA-issue bubbles, one 8-wave workgroup cannot.  The 256-row
-  // variant stays selectable (WAN_GEMM_TILE=256) for tuning.
-  static const int forced = [] { const char* e = getenv("WAN_GEMM_TILE"); return e ? atoi(e) : 0; }();
-  const bool big = forced == 256;
-  if (big) {
-    const int64_t ty = (YM + 255) / 256;
-    WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm: too many tiles");
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16, 4>), dim3((unsigned)(ty * tx)), dim3(512), 0, st, Y, ldy, YM,
-                       X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx,
-                       out_scale);
-  } else {
-    const int64_t ty = (YM + 127) / 128;
-    WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm: too many tiles");
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16, 2>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM,
-                       X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx,
-                       out_scale);
-  }
+  const int64_t ty = (YM + 127) / 128;
+  WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm: too many tiles");
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16, 2>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx,
+                     XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, out_scale);
   WAN_LAUNCH_CHECK();
   return 0;
 }
