@@ -20,10 +20,6 @@ __device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {
   hw_f32x2 v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hw_bf16x2));
 }
-__device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
-}
 __device__ __forceinline__ float xhalf_max(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));

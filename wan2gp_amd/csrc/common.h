@@ -115,4 +115,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
+// ---- LDS-DMA (global -> LDS without registers), 16 B per lane, 1 KiB per wave-instruction -----------------------------------
+// `ldst` is the wave-uniform LDS address the wave's 64 lanes fill contiguously (lane l lands at +16 l); `gsrc` is per lane.
+// INLINE ASM on purpose: for the builtin (__builtin_amdgcn_global_load_lds) hipcc's waitcnt pass inserts `s_waitcnt vmcnt(0)` in
+// front of every later ds_read it cannot prove disjoint from the pending DMA -- in a ring of LDS stages that serialises the
+// prefetch with the compute of the stage being read (measured in the attention kernel: 2,500 cycles per wait).  The asm form is
+// invisible to the pass: every kernel that uses it counts completion by hand (s_waitcnt vmcnt(N) + barrier before the reads).
+__device__ __forceinline__ void wan_lds_dma16(const void* gsrc, void* ldst) {
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ldst);  // wave-uniform by contract
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory");
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

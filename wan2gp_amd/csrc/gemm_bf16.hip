@@ -43,10 +43,7 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c)
 #define BK 64
 #define XSTAGE_BYTES (BN * BK * 2)  // 16 KiB: X operand per stage
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* ldst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
-}
+__device__ __forceinline__ void glds16(const void* gsrc, void* ldst) { wan_lds_dma16(gsrc, ldst); }
 
 // torch GELU(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3)  ==  x / (1 + exp(-2u))
 __device__ __forceinline__ float gelu_tanh_f(float x) {

@@ -46,9 +46,10 @@ __global__ __launch_bounds__(256) void t5_attention_kernel(const bf16_t* __restr
       for (int c = 0; c < T5_HD; ++c) s += qs[i][c] * kr[c];
       // einsum output is a bf16 tensor; + attn_bias (bf16) rounds again; masked_fill_ AFTER the position bias was added
       const int qi = q0 + i;
+      if (qi >= L) { ps[i][j] = 0.f; continue; }  // padding rows of the last q block: no bias entry exists for them (index < 0)
       float a = rbf(rbf(s) + (keep ? bf2f(bias[j - qi + L - 1]) : 0.f));
       if (!keep) a = rbf(rbf(s) + NEG);  // attn_bias = min, then scores + attn_bias in bf16 (saturates at min / -inf)
-      ps[i][j] = (qi < L) ? a : 0.f;
+      ps[i][j] = a;
     }
   }
   __syncthreads();

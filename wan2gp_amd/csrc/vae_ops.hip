@@ -22,10 +22,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 mfma_f16x8v;
 #define CBN 128
 #define CSTAGE (CBM * 64 * 2)
 
-__device__ __forceinline__ void glds16v(const void* gsrc, void* ldst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
-}
+__device__ __forceinline__ void glds16v(const void* gsrc, void* ldst) { wan_lds_dma16(gsrc, ldst); }
 
 struct ConvP {
   const uint16_t* x;
