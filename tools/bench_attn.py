@@ -13,7 +13,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-if "--stamps" in sys.argv:   # the stamp kernels live in the tuning build only (make -C wan2gp_amd/csrc timing)
+if "--lib" in sys.argv:      # A/B against another build of the library (file name under wan2gp_amd/)
+    from wan2gp_amd import lib as _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), sys.argv[sys.argv.index("--lib") + 1])
+elif "--stamps" in sys.argv:   # the stamp kernels live in the tuning build only (make -C wan2gp_amd/csrc timing)
     from wan2gp_amd import lib as _lib
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libwanhip_timing.so")
     os.environ["WAN_ATTN_STAMPS"] = "1"
@@ -28,6 +31,7 @@ def main():
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--modes", default="bounded,tracking")
+    ap.add_argument("--lib", default=None)
     ap.add_argument("--stamps", action="store_true", help="library built with -DW64Q_TIMING and WAN_ATTN_STAMPS=1: print stamp deltas")
     a = ap.parse_args()
     Lk = a.Lk or a.L
