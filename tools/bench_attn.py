@@ -19,6 +19,7 @@ if "--lib" in sys.argv:      # A/B against another build of the library (file na
 elif "--stamps" in sys.argv:   # the stamp kernels live in the tuning build only (make -C wan2gp_amd/csrc timing)
     from wan2gp_amd import lib as _lib
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libwanhip_timing.so")
+if "--stamps" in sys.argv:
     os.environ["WAN_ATTN_STAMPS"] = "1"
 from wan2gp_amd import ops  # noqa: E402
 
