@@ -268,10 +268,11 @@ __device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8]
 // (scores that could exceed +-96 in log2 units = +-66 nats) runs the tracking loop below, unchanged.
 //   64 gaps: A 0..15 (S_a), B 16..31 (PV_b of tile t-1), C 32..47 (S_b), D 48..63 (PV_a).
 //   q-block a: exp2 of score k at gap 19 + k (19..50), tail (sum / pack of pair 15) at 51;
-//   q-block b: exp2 of score k at gap (51 + k) mod 64: 51..63 and 0..18 of the next tile, tail at 19  -> one v_exp_f32 in
-//   every gap; pair j is packed at the gap of score 2j + 2, >= 2 gaps before the PV MFMA that reads it
-//   (a: pair j at 21 + 2j, PV k-step c at 48 + 4c;  b: pair j at (53 + 2j) mod 64, PV k-step c at 16 + 4c of the next tile).
-//   Nothing but MFMAs, exps and the 8 DMA pieces of tile t+2 (odd gaps 1..15) behind the barrier; V^T(t) fragment f at gap
+//   q-block b: scores 0..16 at gaps 51..63 (two in the even gaps 56..62), scores 17..31 at gaps 4..18 of the next tile, tail
+//   at 19 / 20 -> one v_exp_f32 in every gap but the four behind the barrier (MFMA + DMA issue only, see tile_w64n);
+//   pair j is packed at the gap of score 2j + 2, >= 2 gaps before the PV MFMA that reads it
+//   (a: pair j at 21 + 2j, PV k-step c at 48 + 4c;  b: pairs 8..15 at gaps 6..19, PV k-step c at 16 + 4c of the next tile).
+//   Nothing but MFMAs, exps and the 8 DMA pieces of tile t+2 (odd gaps 1..15) in gaps 0..15; V^T(t) fragment f at gap
 //   17 + f (PV_b's MFMA f, its last reader, issued at 16 + f); K(t+1) fragment r (need order; its register was last read by
 //   S_b's MFMA at 32 + r) at gap 33 + 2r -- every K fragment of the next tile is read inside this one.
 constexpr float BOUND_LOG2 = 96.0f;
@@ -314,6 +315,11 @@ __device__ __forceinline__ void qk_stepn(QB& x, const mfma_bf16x8 (&kf)[2][8], c
   else mfma_qk(x.s[i & 1], kf[i & 1][i >> 1], qf[i >> 1]);
 }
 
+// The four MFMA gaps behind the tile's barrier carry no VALU (VALU / transcendental work in the first ~250 cycles after a
+// barrier release does not overlap -- MI355X_MICROARCH.md "start-of-segment VALU penalty"; stamps: 332 cycles for those four
+// gaps against 165 elsewhere, 208 without the VALU); q-block b's four displaced exps ride in the even gaps 56..62 of the
+// previous tile (scores 0..16 there instead of 0..12), which carry nothing but one exp and its pair bookkeeping.  Worth +0.4 %
+// (1361 against 1356 TFLOP/s, alternating libraries on one box) and 27 VGPRs.
 template <int ST, bool TIMING, bool DIAG>
 __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
                                           const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
@@ -322,13 +328,17 @@ __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8]
   constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
 #define BND_GAP(G)                                                                                               \
   do {                                                                                                           \
-    if ((G) <= 18) expn<DIAG>(b, (G) + 13, kv_rem, half);               /* q-block b, tile t-1: scores 13..31 */    \
+    if ((G) >= 4 && (G) <= 18) expn<DIAG>(b, (G) + 13, kv_rem, half);   /* q-block b, tile t-1: scores 17..31 (gaps 0..3: MFMA only) */ \
     if ((G) == 19) exptail<DIAG>(b, 0);                                 /* pair 15: pack + first sum ... */         \
     if ((G) == 20) exptail<DIAG>(b, 1);                                 /* ... second sum (a's gap 20 has none) */  \
     if ((G) >= 19 && (G) <= 50) expn<DIAG>(a, (G) - 19, kv_rem, half);  /* q-block a, tile t */                     \
     if ((G) == 51) exptail<DIAG>(a, 0);                                                                           \
     if ((G) == 52) exptail<DIAG>(a, 1);                                                                           \
-    if ((G) >= 51) expn<DIAG>(b, (G) - 51, kv_rem, half);               /* q-block b, tile t: scores 0..12 */       \
+    if ((G) >= 51) {                                                    /* q-block b, tile t: scores 0..16, two in the even gaps 56..62 */ \
+      const int k0 = (G) - 51 + ((G) > 56 ? ((G) - 55) / 2 : 0);                                                  \
+      expn<DIAG>(b, k0, kv_rem, half);                                                                            \
+      if ((G) >= 56 && (((G) - 56) & 1) == 0) expn<DIAG>(b, k0 + 1, kv_rem, half);                                \
+    }                                                                                                            \
     if ((G) >= 17 && (G) <= 32) {                                       /* V^T(t) fragment f at gap 17 + f */       \
       const int f = (G) - 17;                                                                                     \
       vf[f >> 2][f & 3] = *(lds_frag*)(smem + (VB + (f & 3) * 4096) + vaddr[f >> 2]);                             \
@@ -604,7 +614,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 #undef W64N_STEP
     // drain: q-block b's last tile
 #pragma unroll
-    for (int k = 13; k < 32; ++k) expn<DIAG>(qbk, k, kv_rem_prev, half);
+    for (int k = 17; k < 32; ++k) expn<DIAG>(qbk, k, kv_rem_prev, half);
     exptail<DIAG>(qbk, 0);
     exptail<DIAG>(qbk, 1);
     qa.l_run = qa.l0 + qa.l1;

@@ -28,16 +28,23 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
   const bf16_t* w = (blockIdx.y == 0 ? wq : wk);
   const int nchunk = d >> 3;
 
-  float v[NCH][8];
+  // the row stays PACKED in registers (4 VGPRs per chunk, unpacked again in the output pass: 8 shifts / masks) -- as fp32 it
+  // cost 8 per chunk, 142 VGPRs at d = 5120 = 3 waves per SIMD, too few to cover one wave's load latency with another's VALU
+  uint4 raw[NCH];
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    if (c < nchunk) {
-      uint4 raw = *reinterpret_cast<const uint4*>(x + c * 8);
-      unpack8(raw, v[i]);
+    if (c < nchunk) raw[i] = *reinterpret_cast<const uint4*>(x + c * 8);
+  }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float v[8];
+      unpack8(raw[i], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
     }
   }
   ss = wave_sum(ss);
@@ -59,11 +66,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
     const int c = lane + 64 * i;
     if (c < nchunk) {
       uint4 wraw = *reinterpret_cast<const uint4*>(w + c * 8);
-      float wf[8];
+      float wf[8], v[8];
       unpack8(wraw, wf);
+      unpack8(raw[i], v);
       float y[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[i][j] * r) * wf[j]);  // x *= rsqrt ; x *= weight
+      for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[j] * r) * wf[j]);  // x *= rsqrt ; x *= weight
       if (cosT != nullptr) {
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
@@ -99,16 +107,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   bf16_t* o = out + row * (int64_t)d;
   const int nchunk = d >> 3;
 
-  float v[NCH][8];
+  uint4 raw[NCH];  // the row stays packed in registers (see rmsnorm_rope_kernel)
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    if (c < nchunk) {
-      uint4 raw = *reinterpret_cast<const uint4*>(x + c * 8);
-      unpack8(raw, v[i]);
+    if (c < nchunk) raw[i] = *reinterpret_cast<const uint4*>(x + c * 8);
+  }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[i][j];
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float v[8];
+      unpack8(raw[i], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
     }
   }
   const float mean = wave_sum(s) / (float)d;
@@ -117,9 +130,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
+      float v[8];
+      unpack8(raw[i], v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float t = v[i][j] - mean;
+        const float t = v[j] - mean;
         ss += t * t;
       }
     }
@@ -131,14 +146,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
-      float y[8];
+      float y[8], v[8];
+      unpack8(raw[i], v);
       if (MODE == 1) {
         const bf16_t* w = reinterpret_cast<const bf16_t*>(p0);
         float wf[8], bfv[8];
         unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wf);
         unpack8(*reinterpret_cast<const uint4*>(p1 + c * 8), bfv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = (v[i][j] - mean) * rstd * wf[j] + bfv[j];
+        for (int j = 0; j < 8; ++j) y[j] = (v[j] - mean) * rstd * wf[j] + bfv[j];
       } else if (MODE == 0) {
         const bf16_t* mod = reinterpret_cast<const bf16_t*>(p0);
         float msh[8], msc[8], esh[8], esc[8];
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
         unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)scale_idx * d + c * 8), esc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float ln = rbf((v[i][j] - mean) * rstd);        // F.layer_norm -> bf16
+          const float ln = rbf((v[j] - mean) * rstd);           // F.layer_norm -> bf16
           const float sc = rbf(1.0f + rbf(msc[j] + esc[j]));    // 1 + e[scale]    (bf16 ops)
           const float sh = rbf(msh[j] + esh[j]);                // e[shift]
           y[j] = rbf(ln * sc) + sh;                             // x *= 1+scale ; x += shift
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
         unpack8(*reinterpret_cast<const uint4*>(p1 + b * (int64_t)d + c * 8), ev);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float ln = rbf((v[i][j] - mean) * rstd);
+          const float ln = rbf((v[j] - mean) * rstd);
           const float sc = 1.0f + (hm[(int64_t)scale_idx * d + c * 8 + j] + ev[j]);
           const float sh = hm[(int64_t)shift_idx * d + c * 8 + j] + ev[j];
           y[j] = rbf(ln * sc) + sh;
