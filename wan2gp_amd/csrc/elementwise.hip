@@ -14,79 +14,100 @@
 // ------------------------------------------------------------------------------------------------
 // RMSNorm(q,k) + RoPE  -- model.py:160-175, posemb_layers.py:251-269
 // ------------------------------------------------------------------------------------------------
+// PERSIST = true (wide rows, d >= 4096): the grid is the resident set, a wave walks rows row0, row0 + stride, ... and issues the
+// 16-byte loads of its NEXT row before it touches the current one, so every resident wave keeps one row (d * 2 bytes) in flight
+// for the whole time it computes -- the bytes in flight no longer depend on how many waves the register budget admits (one row
+// per wave holds 3 waves per SIMD at d = 5120).  Measured, RMSNorm+RoPE at the 14B-720p shape: 4.30-4.33 TB/s against 3.56.
+// PERSIST = false (one row per wave, grid = rows / 4): narrow rows, where 7 waves per SIMD already cover the latency and the
+// persistent form loses a third (d = 1536: 3.5 against 5.2 TB/s), and the LayerNorm family, which is VALU-bound either way
+// (~30 VALU operations per element at the reference's rounding points; 3.3 TB/s both ways at d = 5120).
+// Rows stay PACKED in registers (4 VGPRs per chunk), unpacked again in each pass.
 template <int NCH>
+__device__ __forceinline__ void load_row(uint4 (&r)[NCH], const bf16_t* x, int lane, int nchunk) {
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) r[i] = *reinterpret_cast<const uint4*>(x + c * 8);
+  }
+}
+
+template <int NCH, bool PERSIST>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
     bf16_t* __restrict__ q, bf16_t* __restrict__ k, const bf16_t* __restrict__ wq,
     const bf16_t* __restrict__ wk, const float* __restrict__ cosT, const float* __restrict__ sinT,
     int64_t rows, int64_t L, int64_t pos0, int d, float eps, float q_scale) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+  int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
   if (row >= rows) return;
+  const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
   const float oscale = (blockIdx.y == 0) ? q_scale : 1.0f;  // q only: fp32 scale folded in front of the ONE bf16 rounding
-  bf16_t* x = (blockIdx.y == 0 ? q : k) + row * (int64_t)d;
+  bf16_t* base = (blockIdx.y == 0 ? q : k);
   const bf16_t* w = (blockIdx.y == 0 ? wq : wk);
   const int nchunk = d >> 3;
 
-  // the row stays PACKED in registers (4 VGPRs per chunk, unpacked again in the output pass: 8 shifts / masks) -- as fp32 it
-  // cost 8 per chunk, 142 VGPRs at d = 5120 = 3 waves per SIMD, too few to cover one wave's load latency with another's VALU
-  uint4 raw[NCH];
-  float ss = 0.f;
+  uint4 raw[NCH], nxt[NCH];
+  load_row<NCH>(raw, base + row * (int64_t)d, lane, nchunk);
+  for (;;) {
+    const int64_t nrow = row + stride;
+    const bool more = PERSIST && nrow < rows;  // wave-uniform
+    if (more) load_row<NCH>(nxt, base + nrow * (int64_t)d, lane, nchunk);
+    bf16_t* x = base + row * (int64_t)d;
+    float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) raw[i] = *reinterpret_cast<const uint4*>(x + c * 8);
-  }
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float v[8];
+        unpack8(raw[i], v);
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) {
-      float v[8];
-      unpack8(raw[i], v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+        for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+      }
     }
-  }
-  ss = wave_sum(ss);
-  const float r = rsqrtf(ss / (float)d + eps);
-  const int64_t pos = (int64_t)((uint32_t)row % (uint32_t)L) + pos0;  // rows < 2^31 (launcher): 32-bit modulo, a 64-bit one costs ~100 VALU per lane
-  // the lane's column inside the 128-wide head is the same for all of its chunks (c = lane + 64 i, 64*8 = 0 mod 128):
-  // ONE cos / sin fetch per row instead of one per chunk (the kernel was VMEM-issue bound: 6 loads per 16 B of data)
-  float cs[8], sn[8];
-  if (cosT != nullptr) {
-    const int hc = (lane * 8) & 127;
-    const float4* cp = reinterpret_cast<const float4*>(cosT + pos * 128 + hc);
-    const float4* sp = reinterpret_cast<const float4*>(sinT + pos * 128 + hc);
-    const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
-    cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
-    sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
-  }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)d + eps);
+    const int64_t pos = (int64_t)((uint32_t)row % (uint32_t)L) + pos0;  // rows < 2^31 (launcher): 32-bit modulo, a 64-bit one costs ~100 VALU per lane
+    // the lane's column inside the 128-wide head is the same for all of its chunks (c = lane + 64 i, 64*8 = 0 mod 128):
+    // ONE cos / sin fetch per row instead of one per chunk (the kernel was VMEM-issue bound: 6 loads per 16 B of data)
+    float cs[8], sn[8];
+    if (cosT != nullptr) {
+      const int hc = (lane * 8) & 127;
+      const float4* cp = reinterpret_cast<const float4*>(cosT + pos * 128 + hc);
+      const float4* sp = reinterpret_cast<const float4*>(sinT + pos * 128 + hc);
+      const float4 c0 = cp[0], c1 = cp[1], s0 = sp[0], s1 = sp[1];
+      cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+      sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+    }
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) {
-      uint4 wraw = *reinterpret_cast<const uint4*>(w + c * 8);
-      float wf[8], v[8];
-      unpack8(wraw, wf);
-      unpack8(raw[i], v);
-      float y[8];
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        uint4 wraw = *reinterpret_cast<const uint4*>(w + c * 8);
+        float wf[8], v[8];
+        unpack8(wraw, wf);
+        unpack8(raw[i], v);
+        float y[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[j] * r) * wf[j]);  // x *= rsqrt ; x *= weight
-      if (cosT != nullptr) {
+        for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[j] * r) * wf[j]);  // x *= rsqrt ; x *= weight
+        if (cosT != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-          // x0' = x0*cos0 - x1*sin0 ; x1' = x1*cos1 + x0*sin1   (fp32, one rounding to bf16)
-          const float a = y[j], b = y[j + 1];
-          y[j] = __fmul_rn(a, cs[j]) - __fmul_rn(b, sn[j]);
-          y[j + 1] = __fmul_rn(b, cs[j + 1]) + __fmul_rn(a, sn[j + 1]);
+          for (int j = 0; j < 8; j += 2) {
+            // x0' = x0*cos0 - x1*sin0 ; x1' = x1*cos1 + x0*sin1   (fp32, one rounding to bf16)
+            const float a = y[j], b = y[j + 1];
+            y[j] = __fmul_rn(a, cs[j]) - __fmul_rn(b, sn[j]);
+            y[j + 1] = __fmul_rn(b, cs[j + 1]) + __fmul_rn(a, sn[j + 1]);
+          }
         }
-      }
-      if (oscale != 1.0f) {
+        if (oscale != 1.0f) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] *= oscale;
+          for (int j = 0; j < 8; ++j) y[j] *= oscale;
+        }
+        *reinterpret_cast<uint4*>(x + c * 8) = pack8(y);
       }
-      *reinterpret_cast<uint4*>(x + c * 8) = pack8(y);
     }
+    if (!more) break;
+    for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
+    row = nrow;
   }
 }
 
@@ -94,97 +115,101 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
 // LayerNorm family.  MODE 0: LN + modulate (norm1/norm2), MODE 1: LN affine (norm3),
 // MODE 2: LN + modulate with fp32 modulation table (head, model.py:856-862)
 // ------------------------------------------------------------------------------------------------
-template <int NCH, int MODE>
+template <int NCH, int MODE, bool PERSIST = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const bf16_t* __restrict__ xin, bf16_t* __restrict__ out, const void* __restrict__ p0,
     const bf16_t* __restrict__ p1, int n_mod, int shift_idx, int scale_idx, int64_t rows,
     int64_t rows_per_batch, int d, float eps) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+  int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
   if (row >= rows) return;
-  const bf16_t* x = xin + row * (int64_t)d;
-  bf16_t* o = out + row * (int64_t)d;
+  const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
   const int nchunk = d >> 3;
 
-  uint4 raw[NCH];  // the row stays packed in registers (see rmsnorm_rope_kernel)
-  float s = 0.f;
+  uint4 raw[NCH], nxt[NCH];  // rows packed in registers; the PERSIST form exists but is not launched (see above)
+  load_row<NCH>(raw, xin + row * (int64_t)d, lane, nchunk);
+  for (;;) {
+    const int64_t nrow = row + stride;
+    const bool more = PERSIST && nrow < rows;  // wave-uniform
+    if (more) load_row<NCH>(nxt, xin + nrow * (int64_t)d, lane, nchunk);
+    bf16_t* o = out + row * (int64_t)d;
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) raw[i] = *reinterpret_cast<const uint4*>(x + c * 8);
-  }
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float v[8];
+        unpack8(raw[i], v);
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) {
-      float v[8];
-      unpack8(raw[i], v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[j];
-    }
-  }
-  const float mean = wave_sum(s) / (float)d;
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) {
-      float v[8];
-      unpack8(raw[i], v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float t = v[j] - mean;
-        ss += t * t;
+        for (int j = 0; j < 8; ++j) s += v[j];
       }
     }
-  }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
-  const int64_t b = (int64_t)((uint32_t)row / (uint32_t)rows_per_batch);  // 32-bit: a 64-bit division costs ~100 VALU per lane
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float v[8];
+        unpack8(raw[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = v[j] - mean;
+          ss += t * t;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    const int64_t b = (int64_t)((uint32_t)row / (uint32_t)rows_per_batch);  // 32-bit: a 64-bit division costs ~100 VALU per lane
 
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) {
-      float y[8], v[8];
-      unpack8(raw[i], v);
-      if (MODE == 1) {
-        const bf16_t* w = reinterpret_cast<const bf16_t*>(p0);
-        float wf[8], bfv[8];
-        unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wf);
-        unpack8(*reinterpret_cast<const uint4*>(p1 + c * 8), bfv);
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float y[8], v[8];
+        unpack8(raw[i], v);
+        if (MODE == 1) {
+          const bf16_t* w = reinterpret_cast<const bf16_t*>(p0);
+          float wf[8], bfv[8];
+          unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wf);
+          unpack8(*reinterpret_cast<const uint4*>(p1 + c * 8), bfv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = (v[j] - mean) * rstd * wf[j] + bfv[j];
-      } else if (MODE == 0) {
-        const bf16_t* mod = reinterpret_cast<const bf16_t*>(p0);
-        float msh[8], msc[8], esh[8], esc[8];
-        unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)shift_idx * d + c * 8), msh);
-        unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)scale_idx * d + c * 8), msc);
-        const bf16_t* eb = p1 + b * (int64_t)n_mod * d;
-        unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)shift_idx * d + c * 8), esh);
-        unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)scale_idx * d + c * 8), esc);
+          for (int j = 0; j < 8; ++j) y[j] = (v[j] - mean) * rstd * wf[j] + bfv[j];
+        } else if (MODE == 0) {
+          const bf16_t* mod = reinterpret_cast<const bf16_t*>(p0);
+          float msh[8], msc[8], esh[8], esc[8];
+          unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)shift_idx * d + c * 8), msh);
+          unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)scale_idx * d + c * 8), msc);
+          const bf16_t* eb = p1 + b * (int64_t)n_mod * d;
+          unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)shift_idx * d + c * 8), esh);
+          unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)scale_idx * d + c * 8), esc);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float ln = rbf((v[j] - mean) * rstd);           // F.layer_norm -> bf16
-          const float sc = rbf(1.0f + rbf(msc[j] + esc[j]));    // 1 + e[scale]    (bf16 ops)
-          const float sh = rbf(msh[j] + esh[j]);                // e[shift]
-          y[j] = rbf(ln * sc) + sh;                             // x *= 1+scale ; x += shift
+          for (int j = 0; j < 8; ++j) {
+            const float ln = rbf((v[j] - mean) * rstd);           // F.layer_norm -> bf16
+            const float sc = rbf(1.0f + rbf(msc[j] + esc[j]));    // 1 + e[scale]    (bf16 ops)
+            const float sh = rbf(msh[j] + esh[j]);                // e[shift]
+            y[j] = rbf(ln * sc) + sh;                             // x *= 1+scale ; x += shift
+          }
+        } else {
+          // head: modulation fp32 [2,d] + e bf16 [B,d] -> fp32; x bf16 updated in place twice
+          const float* hm = reinterpret_cast<const float*>(p0);
+          float ev[8];
+          unpack8(*reinterpret_cast<const uint4*>(p1 + b * (int64_t)d + c * 8), ev);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float ln = rbf((v[j] - mean) * rstd);
+            const float sc = 1.0f + (hm[(int64_t)scale_idx * d + c * 8 + j] + ev[j]);
+            const float sh = hm[(int64_t)shift_idx * d + c * 8 + j] + ev[j];
+            y[j] = rbf(ln * sc) + sh;
+          }
         }
-      } else {
-        // head: modulation fp32 [2,d] + e bf16 [B,d] -> fp32; x bf16 updated in place twice
-        const float* hm = reinterpret_cast<const float*>(p0);
-        float ev[8];
-        unpack8(*reinterpret_cast<const uint4*>(p1 + b * (int64_t)d + c * 8), ev);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float ln = rbf((v[j] - mean) * rstd);
-          const float sc = 1.0f + (hm[(int64_t)scale_idx * d + c * 8 + j] + ev[j]);
-          const float sh = hm[(int64_t)shift_idx * d + c * 8 + j] + ev[j];
-          y[j] = rbf(ln * sc) + sh;
-        }
+        *reinterpret_cast<uint4*>(o + c * 8) = pack8(y);
       }
-      *reinterpret_cast<uint4*>(o + c * 8) = pack8(y);
     }
+    if (!more) break;
+    for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
+    row = nrow;
   }
 }
 
@@ -356,6 +381,20 @@ static int pick_nch(int d) {
   return -1;
 }
 
+// grid of a persistent row kernel: every workgroup resident at once (occupancy x CUs, queried once per instantiation), never
+// more workgroups than there are 4-row groups
+template <typename K>
+static unsigned persistent_blocks(K kernel, int64_t rows) {
+  static const int resident = [&] {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    return per_cu * cus;
+  }();
+  const int64_t groups = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return (unsigned)(groups < resident ? groups : resident);
+}
+
 #define DISPATCH_NCH(nch, ...)                          \
   switch (nch) {                                        \
     case 1: { constexpr int NCH = 1; __VA_ARGS__; } break;   \
@@ -386,9 +425,16 @@ extern "C" int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16*
   WAN_REQUIRE(rows < ((int64_t)1 << 31) && L > 0 && L < ((int64_t)1 << 31), "wan_rmsnorm_rope: rows / L must fit 31 bits");
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
-  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), k ? 2 : 1);
-  DISPATCH_NCH(nch, hipLaunchKernelGGL(rmsnorm_rope_kernel<NCH>, grid, dim3(256), 0, as_stream(stream), q, k, wq,
-                                       wk, cos, sin, rows, L, pos0, d, eps, q_scale));
+  DISPATCH_NCH(nch, {
+    constexpr bool P = NCH >= 8;
+    unsigned gx = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    if (P) {  // q and k rows share the resident slots (grid.y = 2): half the persistent width each
+      gx = persistent_blocks(rmsnorm_rope_kernel<NCH, P>, rows);
+      if (k && gx > 1) gx = (gx + 1) / 2;
+    }
+    hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH, P>), dim3(gx, k ? 2 : 1), dim3(256), 0, as_stream(stream), q, k, wq, wk, cos,
+                       sin, rows, L, pos0, d, eps, q_scale);
+  });
   WAN_LAUNCH_CHECK();
   return 0;
 }
@@ -403,9 +449,8 @@ extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16*
               "wan_ln_modulate: rows / rows_per_batch must fit 31 bits");
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
-  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 0>), grid, dim3(256), 0, as_stream(stream), x, out,
-                                       (const void*)mod, e, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps));
+  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 0>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
+                                       dim3(256), 0, as_stream(stream), x, out, (const void*)mod, e, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps));
   WAN_LAUNCH_CHECK();
   return 0;
 }
@@ -416,9 +461,8 @@ extern "C" int wan_ln_affine(const wan_bf16* x, wan_bf16* out, const wan_bf16* w
   WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_ln_affine: d=%d must be a multiple of 8 and <= 8192", d);
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
-  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 1>), grid, dim3(256), 0, as_stream(stream), x, out,
-                                       (const void*)w, b, 0, 0, 0, rows, rows, d, eps));
+  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 1>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
+                                       dim3(256), 0, as_stream(stream), x, out, (const void*)w, b, 0, 0, 0, rows, rows, d, eps));
   WAN_LAUNCH_CHECK();
   return 0;
 }
@@ -428,9 +472,8 @@ int wan_ln_modulate_head(const bf16_t* x, bf16_t* out, const float* hmod, const 
                          int64_t rows_per_batch, int d, float eps, void* stream) {
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
-  dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 2>), grid, dim3(256), 0, as_stream(stream), x, out,
-                                       (const void*)hmod, e, 2, 0, 1, rows, rows_per_batch, d, eps));
+  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 2>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
+                                       dim3(256), 0, as_stream(stream), x, out, (const void*)hmod, e, 2, 0, 1, rows, rows_per_batch, d, eps));
   WAN_LAUNCH_CHECK();
   return 0;
 }

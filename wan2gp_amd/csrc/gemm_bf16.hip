@@ -4,7 +4,7 @@
 //   normal     : Y = activations A [M,K], X = weights W [N,K]      -> C[M,N]
 //   transposed : Y = weights W [N,K],     X = activations A [M,K]  -> Ct[N,M]  (emits V^T)
 //
-// This file: the small-problem kernel (WY = 2: 128(y) x 128(x) x 64(k) tiles, 4 waves in 2x2, each wave 64x64 = 4x4 MFMA
+// This file: the small-problem kernel (128(y) x 128(x) x 64(k) tiles, 4 waves in 2x2, each wave 64x64 = 4x4 MFMA
 // 16x16x32 tiles, two workgroups per CU, 2-deep LDS ring) and the launcher that picks a kernel by problem size:
 //   >= 256 tiles of 256x256  -> gemm256k.hip (every Wan projection at 480p and above)
 //   M >= 512 and N >= 128    -> gemm32.hip   (256x128x32 tiles)
@@ -55,15 +55,15 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 
 // F16 = false: bf16 storage (DiT);  F16 = true: fp16 storage (VAE) -- same tiles, MFMA f16 variant.
 // out_scale multiplies the fp32 accumulator before the bias (used for QK^T / sqrt(C) in the VAE).
-template <int EPI, bool BIAS_ROWS, bool F16, int WY>
-__global__ __launch_bounds__(WY * 128, WY == 2 ? 2 : 1) void gemm_bf16_kernel(
+template <int EPI, bool BIAS_ROWS, bool F16>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(
     const bf16_t* __restrict__ Y, int64_t ldy, int64_t YM, const bf16_t* __restrict__ X, int64_t ldx,
     int64_t XN, int K, bf16_t* __restrict__ Out, int64_t ldo, const bf16_t* __restrict__ bias,
     const bf16_t* __restrict__ R, const bf16_t* __restrict__ mod, const bf16_t* __restrict__ e, int n_mod,
     int gate_idx, int64_t rows_per_batch, int tiles_y, int tiles_x, float out_scale) {
-  constexpr int BM = WY * 64;                   // y rows per workgroup tile
-  constexpr int NTHR = WY * 128;
-  constexpr int NSTG = (WY == 4) ? 3 : 2;       // LDS ring depth
+  constexpr int BM = 128;                       // y rows per workgroup tile (4 waves in 2 x 2, 64 x 64 each)
+  constexpr int NTHR = 256;
+  constexpr int NSTG = 2;                       // LDS ring depth
   constexpr int YSTAGE_BYTES = BM * BK * 2;
   constexpr int STAGE_ALL = YSTAGE_BYTES + XSTAGE_BYTES;
   constexpr int XS = 1024 / NTHR;               // X staging slots per thread (Y: always 4)
@@ -155,30 +155,12 @@ __global__ __launch_bounds__(WY * 128, WY == 2 ? 2 : 1) void gemm_bf16_kernel(
     }
   };
   stage(0, 0);
-  if (NSTG == 3) {
-    if (nk > 1) stage(1, BK);
-    int st = 0;  // ring slot of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-      // tile kt has landed once at most the youngest tile's 4 + XS pieces per lane are still in flight
-      if (kt + 1 < nk) {
-        if (XS == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      if (kt + 2 < nk) stage(st == 0 ? 2 : st - 1, (kt + 2) * BK);  // slot of tile kt-1: every wave is past it
-      const char* ybase = smem + st * STAGE_ALL;
-      compute(ybase, ybase + YSTAGE_BYTES);
-      st = (st == 2) ? 0 : st + 1;
-    }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
-      const char* ybase = smem + (kt & 1) * STAGE_ALL;
-      compute(ybase, ybase + YSTAGE_BYTES);
-    }
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+    const char* ybase = smem + (kt & 1) * STAGE_ALL;
+    compute(ybase, ybase + YSTAGE_BYTES);
   }
 
   // ---- epilogue: lane holds, for y row (yt, lane&15), 16 consecutive x starting at xb ---------
@@ -285,7 +267,7 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
   }
   const int64_t ty = (YM + 127) / 128;
   WAN_REQUIRE(ty * tx < (int64_t)1 << 31, "wan_gemm: too many tiles");
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16, 2>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx,
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BIAS_ROWS, F16>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx,
                      XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, out_scale);
   WAN_LAUNCH_CHECK();
   return 0;
