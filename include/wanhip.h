@@ -274,6 +274,24 @@ int wan_lincomb(float* out, int n_in, const float* const* in, const float* coef,
 int wan_cfg_combine(float* out, const float* cond, const float* uncond, float guide_scale, int64_t n,
                     void* stream);
 
+/* ---- sampler step objects (SURVEY.md section 8b `wan_sched_*`) ------------------------------ */
+/* The scheduler object WanAny2V.generate() builds (any2video.py:505-543) and steps once per denoise step (:1463-1467):
+ *   kind 0  FlowUniPCMultistepScheduler(shift=1, use_dynamic_shifting=False)  -- shared/utils/fm_solvers_unipc.py:77-132,
+ *           set_timesteps :163-239, step :640-721 (convert_model_output :279-348, UniP :350-480, UniC :482-626)
+ *   kind 1  EulerScheduler(use_timestep_transform=True)                       -- shared/utils/euler_scheduler.py:26-87
+ * Host scalars (sigmas, bh2 coefficients) are computed in the library with the reference's precision and order of
+ * operations; each tensor update is one wan_lincomb launch on `stream`; the x0-prediction history and the corrected sample
+ * (UniPC) live in library-owned fp32 device buffers sized at the first step.  Not re-entrant per object. */
+typedef struct wan_sched wan_sched;
+int wan_sched_create(wan_sched** out, int kind, int num_train_timesteps);
+void wan_sched_destroy(wan_sched* s);
+/* set_timesteps(num_inference_steps, shift=...): resets the multistep state.  timesteps_out[steps] (UniPC: the int64 values,
+ * Euler: the fp32 values, both exact in a double) and sigmas_out[steps + 1] (UniPC only) may be NULL. */
+int wan_sched_set_timesteps(wan_sched* s, int steps, double shift, double* timesteps_out, float* sigmas_out);
+/* prev_sample = step(model_output, timestep, sample): fp32 device tensors of n elements; prev_out must not alias an input. */
+int wan_sched_step(wan_sched* s, const float* model_output, double timestep, const float* sample, float* prev_out,
+                   int64_t n, void* stream);
+
 /* ---- whole-DiT context (weights resident in HBM) ----------------------------------------- */
 typedef struct wan_ctx wan_ctx;
 

@@ -135,6 +135,65 @@ def test_euler_vs_reference_golden(steps, shift):
         x = torch.from_numpy(ref[i])
 
 
+@pytest.mark.parametrize("steps,shift", [(10, 5.0), (30, 12.0), (4, 3.0)])
+def test_native_unipc_vs_reference_golden(steps, shift):
+    """wan_sched_* (kind UniPC) through HipScheduler: timesteps / sigmas exactly the reference's, every step of the reference
+    trajectory within 2e-5 -- the bar of the Python mirror above."""
+    from wan2gp_amd.schedulers import HipScheduler
+    g = load("sched.npz")
+    s = HipScheduler("unipc", num_train_timesteps=1000)
+    s.set_timesteps(steps, device="cuda", shift=shift)
+    assert np.array_equal(s.timesteps.cpu().numpy(), g[f"unipc_ts_{steps}_{shift}"])
+    assert np.array_equal(s.sigmas.numpy(), g[f"unipc_sig_{steps}_{shift}"])
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 2, 4, 4, generator=gen)
+    xd = x.cuda()
+    ref = g[f"unipc_trace_{steps}_{shift}"]
+    for i, t in enumerate(s.timesteps):
+        v = torch.randn(x.shape, generator=gen) * 0.7 + 0.1 * x
+        xd = s.step(v.cuda(), t, xd, return_dict=False)[0]
+        x = torch.from_numpy(ref[i])
+        assert torch.allclose(xd.cpu(), x, atol=2e-5, rtol=2e-5), (i, (xd.cpu() - x).abs().max())
+        xd = x.cuda()
+    with pytest.raises(Exception, match="past the last"):
+        s.step(v.cuda(), t, xd)
+    s.set_timesteps(steps, device="cuda", shift=shift)                 # reset: the same object serves the next generate()
+    assert s.step(v.cuda(), s.timesteps[0], xd)[0].shape == xd.shape
+
+
+@pytest.mark.parametrize("steps,shift", [(10, 5.0), (4, 3.0)])
+def test_native_euler_vs_reference_golden(steps, shift):
+    from wan2gp_amd.schedulers import HipScheduler
+    g = load("sched.npz")
+    s = HipScheduler("euler", num_train_timesteps=1000)
+    ts = s.set_timesteps(steps, device="cuda", shift=shift)
+    assert np.array_equal(ts.numpy(), g[f"euler_ts_{steps}_{shift}"])
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 2, 4, 4, generator=gen)
+    ref = g[f"euler_trace_{steps}_{shift}"]
+    for i, t in enumerate(ts):
+        v = torch.randn(x.shape, generator=gen) * 0.7 + 0.1 * x
+        x = s.step(v.cuda(), t, x.cuda(), return_dict=False)[0].cpu()
+        assert torch.allclose(x, torch.from_numpy(ref[i]), atol=1e-6, rtol=1e-6), i
+        x = torch.from_numpy(ref[i])
+
+
+def test_native_scheduler_rejects_bad_arguments():
+    from wan2gp_amd.lib import WanHipError
+    from wan2gp_amd.schedulers import HipScheduler
+    s = HipScheduler("unipc")
+    x = torch.zeros(1, 16, 1, 4, 4, device="cuda")
+    with pytest.raises(ValueError):
+        s.step(x, 999, x)                                              # set_timesteps not called
+    s.set_timesteps(4, device="cuda", shift=3.0)
+    with pytest.raises(WanHipError, match="not one of"):
+        s.step(x, 123456, x)
+    with pytest.raises(WanHipError):
+        s.step(x.cpu(), int(s.timesteps[0]), x)                        # no CPU path
+    with pytest.raises(NotImplementedError):
+        HipScheduler("dpm++")
+
+
 def _follow(ref, stepfn, timesteps, atol):
     gen = torch.Generator().manual_seed(3)
     x = torch.randn(1, 16, 2, 4, 4, generator=gen)

@@ -6,7 +6,7 @@ library is missing or a call fails, a RuntimeError is raised.
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwanhip.so")
@@ -109,6 +109,10 @@ SIGNATURES = {
     "wan_gemv_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wan_lincomb": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_float), c_int64, c_void_p]),
     "wan_cfg_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "wan_sched_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
+    "wan_sched_destroy": (None, [c_void_p]),
+    "wan_sched_set_timesteps": (c_int, [c_void_p, c_int, c_double, POINTER(c_double), POINTER(c_float)]),
+    "wan_sched_step": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_vae_conv3d": (c_int, [c_void_p] * 7 + [c_int] * 17 + [c_void_p]),
     "wan_vae_rmsnorm_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "wan_gemm_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64,

@@ -16,7 +16,7 @@ import torch
 
 from .rope import get_rotary_pos_embed
 from .schedulers import (EulerScheduler, FlowDPMSolverMultistepScheduler, FlowMatchScheduler, FlowUniPCMultistepScheduler,
-                         LCMScheduler, cfg_combine, get_sampling_sigmas, retrieve_timesteps)
+                         HipScheduler, LCMScheduler, cfg_combine, get_sampling_sigmas, retrieve_timesteps)
 
 
 class WanAny2VHIP:
@@ -29,7 +29,10 @@ class WanAny2VHIP:
         self._interrupt = False
 
     def _scheduler(self, sample_solver, sampling_steps, shift):
-        if sample_solver == "euler":
+        if sample_solver in ("unipc", "", "euler") and torch.device(self.device).type == "cuda":
+            s = HipScheduler("euler" if sample_solver == "euler" else "unipc", num_train_timesteps=self.num_train_timesteps)
+            s.set_timesteps(sampling_steps, device=self.device, shift=shift)          # wan_sched_* of the C ABI
+        elif sample_solver == "euler":
             s = EulerScheduler(num_train_timesteps=self.num_train_timesteps, use_timestep_transform=True)
             s.set_timesteps(sampling_steps, device=self.device, shift=shift)
         elif sample_solver in ("unipc", ""):

@@ -204,6 +204,64 @@ class EulerScheduler:
         return sample
 
 
+class HipScheduler:
+    """The `wan_sched_*` object of the C ABI behind the reference's scheduler surface (`set_timesteps`, `.timesteps`,
+    `.sigmas`, `step(...)[0]`, `scale_model_input`): kind "unipc" = FlowUniPCMultistepScheduler(shift=1,
+    use_dynamic_shifting=False), kind "euler" = EulerScheduler(use_timestep_transform=True).  What `WanAny2VHIP.generate`
+    steps with on a GPU; the Python classes above carry the same algebra for hosts without one (control-flow tests)."""
+    order = 1
+    is_stateful = True
+
+    def __init__(self, kind="unipc", num_train_timesteps=1000):
+        from ctypes import byref, c_void_p
+        from . import lib as _L
+        if kind not in ("unipc", "euler"):
+            raise NotImplementedError(f"HipScheduler: kind {kind!r}")
+        self.kind, self.num_train_timesteps = kind, num_train_timesteps
+        self._L = _L
+        h = c_void_p()
+        _L.check(_L.load().wan_sched_create(byref(h), 0 if kind == "unipc" else 1, num_train_timesteps), "wan_sched_create")
+        self._h = h
+        self.timesteps = self.sigmas = self.num_inference_steps = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.load().wan_sched_destroy(h)
+
+    def set_timesteps(self, num_inference_steps, device=None, shift=5.0, **unused):
+        from ctypes import c_double, c_float
+        ts = (c_double * num_inference_steps)()
+        sg = (c_float * (num_inference_steps + 1))()
+        self._L.check(self._L.load().wan_sched_set_timesteps(self._h, num_inference_steps, float(shift), ts, sg), "wan_sched_set_timesteps")
+        self.num_inference_steps = num_inference_steps
+        if self.kind == "unipc":
+            self.timesteps = torch.tensor([int(v) for v in ts], dtype=torch.int64, device=device)
+            self.sigmas = torch.tensor(list(sg), dtype=torch.float32)
+        else:
+            self.timesteps = torch.tensor(list(ts), dtype=torch.float32)
+        return self.timesteps
+
+    def step(self, model_output, timestep, sample, return_dict=True, **kwargs):
+        if self.timesteps is None:
+            raise ValueError("Timesteps are not set. Call set_timesteps first.")
+        t = float(timestep.flatten()[0].item()) if torch.is_tensor(timestep) else float(timestep)
+        v = model_output.to(torch.float32).contiguous()
+        x = sample.contiguous()
+        ops._req(v, torch.float32, "model_output"); ops._req(x, torch.float32, "sample")
+        if v.shape != x.shape:
+            raise ValueError(f"model_output {tuple(v.shape)} and sample {tuple(x.shape)} differ")
+        prev = torch.empty_like(x)
+        self._L.check(self._L.load().wan_sched_step(self._h, self._L.ptr(v), t, self._L.ptr(x), self._L.ptr(prev), x.numel(),
+                                                    self._L.stream_ptr()), "wan_sched_step")
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev)
+
+    def scale_model_input(self, sample, *a, **k):
+        return sample
+
+
 def cfg_combine(cond, uncond, guide_scale):
     """noise_pred = uncond + g * (cond - uncond)   (any2video.py:1722)"""
     return ops.cfg_combine(cond, uncond, guide_scale)
