@@ -29,5 +29,26 @@ def main(ns, out_dir):
         enc = vae.encode(vid, scale)
     out = {"dec": dec.numpy(), "dec_u8": u8.numpy(), "enc": enc.numpy(), "seed": np.array([21])}
     np.savez_compressed(os.path.join(out_dir, "vae_small.npz"), **out)
+    # spatial tiling (vae.py:676-717, :769-839, :841-881): tile 64 px on a 128 x 128 clip -> 3 x 3 overlapping tiles (8, 8 and 4
+    # latents wide), seams blended over 16 px
+    g = torch.Generator().manual_seed(22)
+    zt = torch.randn(1, 16, 2, 16, 16, generator=g)
+    vt = (torch.rand(1, 3, 5, 128, 128, generator=g) * 2 - 1)
+    vt[:, :, 1:] *= 0.5
+    with torch.no_grad():
+        tdec = vae.spatial_tiled_decode(zt.clone(), scale, 64)
+        # The tiled branch of decode_to_cpu_uint8 slices `latent_source` and moves the slice `.to(device, dtype)` before scaling
+        # it IN PLACE (vae.py:799-804).  In the pipeline the source is on the CPU and the device is the GPU, so the slice is a
+        # copy; run on the CPU in one dtype, `.to()` returns a VIEW and the overlapping latent columns get scaled twice.  A
+        # float64 source (exact copy of the fp32 values) with the model dtype pinned to fp32 restores the copy.
+        vae._model_dtype = torch.float32
+        tu8 = vae.decode_to_cpu_uint8(zt.double(), scale, 64)
+        tu8_crop = vae.decode_to_cpu_uint8(zt.double(), scale, 64, target_frames=3, target_height=100, target_width=120, frame_start=1)
+        del vae._model_dtype
+        tenc = vae.spatial_tiled_encode(vt.clone(), scale, 64)
+    tiled = {"dec": tdec.numpy(), "dec_u8": tu8.numpy(), "dec_u8_crop": tu8_crop.numpy(), "enc": tenc.numpy(), "seed": np.array([22]),
+             "tile_size": np.array([64])}
+    np.savez_compressed(os.path.join(out_dir, "vae_tiled.npz"), **tiled)
+    print("vae_tiled.npz", {k: v.shape for k, v in tiled.items()})
     print("vae_small.npz", {k: v.shape for k, v in out.items()}, "dec range", float(dec.min()), float(dec.max()),
           "u8 mean", float(u8.float().mean()))

@@ -299,6 +299,108 @@ def vae_encode(x, W, scale=None, cfg=CFG):
     return mu
 
 
+# ---- spatial tiling (vae.py:664-717 decode, :769-839 decode_to_cpu_uint8, :841-881 encode) -------------------------------
+def _blend_v(a, b, be):
+    """blend_v (vae.py:664-668): rows 0..be-1 of b become a[-be + y] * (1 - y/be) + b[y] * (y/be), in place (Python-float weights)."""
+    be = min(a.shape[-2], b.shape[-2], be)
+    for y in range(be):
+        b[:, :, :, y, :] = a[:, :, :, -be + y, :] * (1 - y / be) + b[:, :, :, y, :] * (y / be)
+    return b
+
+
+def _blend_h(a, b, be):
+    be = min(a.shape[-1], b.shape[-1], be)
+    for x in range(be):
+        b[:, :, :, :, x] = a[:, :, :, :, -be + x] * (1 - x / be) + b[:, :, :, :, x] * (x / be)
+    return b
+
+
+def _blend_tiles(rows, be, row_limit):
+    out_rows = []
+    for i, row in enumerate(rows):
+        out = []
+        for j, tile in enumerate(row):
+            if i > 0:
+                tile = _blend_v(rows[i - 1][j], tile, be)
+            if j > 0:
+                tile = _blend_h(row[j - 1], tile, be)
+            out.append(tile[:, :, :, :row_limit, :row_limit])
+        out_rows.append(torch.cat(out, dim=-1))
+    return torch.cat(out_rows, dim=-2)
+
+
+def vae_tiled_decode(z, W, scale, tile_size, cfg=CFG):
+    """spatial_tiled_decode (vae.py:676-717): overlapping latent tiles decoded independently, seams blended over tile_size/4 px."""
+    tl = int(tile_size / 8)
+    z = z / scale[1].view(1, -1, 1, 1, 1) + scale[0].view(1, -1, 1, 1, 1)
+    ov = int(tl * 0.75)
+    be = int(tile_size * 0.25)
+    rows = [[vae_decode(z[:, :, :, i:i + tl, j:j + tl], W, None, cfg) for j in range(0, z.shape[-1], ov)]
+            for i in range(0, z.shape[-2], ov)]
+    return _blend_tiles(rows, be, tile_size - be)
+
+
+def _blend_edge(edge, tile, be, dim):
+    """_blend_v_edge_ / _blend_h_edge_ (vae.py:23-40): the streaming form of the blend (fp32 tensor weights)."""
+    be = min(int(edge.shape[dim]), int(tile.shape[dim]), int(be))
+    if be <= 0:
+        return
+    shape = [1] * 5
+    shape[dim] = be
+    w = torch.arange(be, dtype=tile.dtype).div_(be).view(shape)
+    e = edge.narrow(dim, edge.shape[dim] - be, be).clone()
+    e.mul_(1.0 - w)
+    tile.narrow(dim, 0, be).mul_(w).add_(e)
+
+
+def vae_tiled_decode_uint8(z, W, scale, tile_size, cfg=CFG):
+    """The tiled branch of decode_to_cpu_uint8 (vae.py:769-839) for the whole clip: tiles in row-major order, each blended with
+    the saved bottom edge of the tile above and the right edge of the tile to its left (edges taken AFTER blending), cropped
+    to row_limit and converted to uint8."""
+    tl = max(1, int(tile_size / 8))
+    ov = max(1, int(tl * 0.75))
+    be = int(tile_size * 0.25)
+    row_limit = max(1, tile_size - be)
+    T, H, Wd = (z.shape[2] - 1) * 4 + 1, z.shape[-2] * 8, z.shape[-1] * 8
+    out = torch.empty(z.shape[0], 3, T, H, Wd, dtype=torch.uint8)
+    prev_edges, r = [], 0
+    for ly in range(0, z.shape[-2], ov):
+        y0, y1 = r * row_limit, min(r * row_limit + row_limit, H)
+        if y1 <= y0:
+            break
+        cur_edges, left, c = [], None, 0
+        for lx in range(0, z.shape[-1], ov):
+            x0, x1 = c * row_limit, min(c * row_limit + row_limit, Wd)
+            if x1 <= x0:
+                break
+            tz = z[:, :, :, ly:ly + tl, lx:lx + tl].clone()
+            tz.div_(scale[1].view(1, -1, 1, 1, 1)).add_(scale[0].view(1, -1, 1, 1, 1))
+            tile = vae_decode(tz, W, None, cfg)
+            if r > 0 and c < len(prev_edges) and prev_edges[c] is not None:
+                _blend_edge(prev_edges[c], tile, be, 3)
+            if left is not None:
+                _blend_edge(left, tile, be, 4)
+            cur_edges.append(tile[:, :, :, -min(be, tile.shape[-2]):, :].clone() if y1 < H else None)
+            left = tile[:, :, :, :, -min(be, tile.shape[-1]):].clone() if x1 < Wd else None
+            tile = tile[:, :, :, :y1 - y0, :x1 - x0]
+            out[:, :, :, y0:y0 + tile.shape[-2], x0:x0 + tile.shape[-1]] = float_to_uint8(tile)
+            c += 1
+        prev_edges = cur_edges
+        r += 1
+    return out
+
+
+def vae_tiled_encode(x, W, scale, tile_size, cfg=CFG):
+    """spatial_tiled_encode (vae.py:841-881)."""
+    tl = int(tile_size / 8)
+    ov = int(tile_size * 0.75)
+    be = int(tl * 0.25)
+    rows = [[vae_encode(x[:, :, :, i:i + tile_size, j:j + tile_size], W, None, cfg) for j in range(0, x.shape[-1], ov)]
+            for i in range(0, x.shape[-2], ov)]
+    mu = _blend_tiles(rows, be, tl - be)
+    return (mu - scale[0].view(1, -1, 1, 1, 1)) * scale[1].view(1, -1, 1, 1, 1)
+
+
 def float_to_uint8(frames):
     """_vae_float_to_cpu_uint8 (vae.py:18-20): clamp -> +1 -> *127.5 -> round-half-even -> uint8."""
     return frames.clone().clamp_(-1.0, 1.0).add_(1.0).mul_(127.5).round_().clamp_(0.0, 255.0).to(torch.uint8)

@@ -84,3 +84,51 @@ def test_sp_forward_rccl_when_two_gpus_are_present():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _rccl_world1_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from wan2gp_amd.sp import SequenceParallel
+        sp = SequenceParallel(0, 1)
+        assert dist.get_backend() == "nccl"
+        n = 1 << 20
+        ws = torch.zeros(4 * n, dtype=torch.uint8, device="cuda")
+        sp.bind_workspace(ws)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for which, (s_off, r_off) in enumerate(((0, 2 * n), (n, 3 * n))):          # two gathers in flight (K, then V^T)
+            ws[s_off:s_off + n] = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda", generator=g)
+            assert sp._gather_begin_cb(None, which, ws.data_ptr() + s_off, ws.data_ptr() + r_off, n, None) == 0
+        assert set(sp._pending) == {0, 1} and all(w is not None for w in sp._pending.values())   # async handles (RCCL branch)
+        busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")  # compute stream keeps going
+        for which in (0, 1):
+            assert sp._gather_wait_cb(None, which, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(ws[2 * n:3 * n], ws[0:n]) and torch.equal(ws[3 * n:4 * n], ws[n:2 * n]) and torch.isfinite(busy).all()
+        x = torch.randn(1, 24, 64, device="cuda")
+        full = sp.all_gather(x[0])
+        assert torch.equal(full, x[0])
+        q.put("ok")
+    except Exception:
+        import traceback
+        q.put(traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_callbacks_over_rccl_world_1():
+    """The collective plumbing the C++ forward drives under sequence parallelism -- `gather_begin` (asynchronous
+    `all_gather_into_tensor` on views of the workspace, ordered behind the compute stream) and `gather_wait` -- over a real RCCL
+    communicator.  One rank is all a single-GPU box can host (RCCL refuses two ranks on one device), so the payload of the gather
+    is the rank's own segment; what is exercised is the backend branch, the async handles, and the stream ordering."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert res == "ok", res

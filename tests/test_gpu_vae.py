@@ -161,6 +161,34 @@ def test_encode_vs_reference_golden(vae):
     assert err <= 1e-2 * ref.abs().max().item() + 1e-3
 
 
+def test_spatial_tiling_vs_reference_golden(vae):
+    """tile_size > 0 (vae.py:676-717, :769-839, :841-881): 3 x 3 overlapping 64-px tiles of a 128 x 128 clip against the
+    reference's own tiled decode / uint8 decode / encode (tests/golden/vae_tiled.npz); same bars as the untiled paths."""
+    gold = dict(np.load(os.path.join(G, "vae_tiled.npz")))
+    gen = torch.Generator().manual_seed(22)
+    z = torch.randn(1, 16, 2, 16, 16, generator=gen)
+    vid = (torch.rand(1, 3, 5, 128, 128, generator=gen) * 2 - 1)
+    vid[:, :, 1:] *= 0.5
+    dec = vae.decode([z[0]], 64)[0].cpu()
+    refd = torch.from_numpy(gold["dec"])[0].clamp(-1, 1)
+    assert dec.shape == refd.shape and (dec - refd).abs().max().item() <= 1.5e-2
+    u8 = vae.decode_to_cpu_uint8([z[0]], 64)[0]
+    ref = torch.from_numpy(gold["dec_u8"])[0]
+    d = (u8.int() - ref.int()).abs()
+    frac_same = (d == 0).float().mean().item()
+    print(f"VAE tiled uint8: identical {frac_same * 100:.2f}%  max delta {int(d.max())}  mean delta {d.float().mean().item():.4f}")
+    assert u8.shape == ref.shape and int(d.max()) <= 2 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
+    crop = vae.decode_to_cpu_uint8([z[0]], 64, target_frames=3, target_height=100, target_width=120, frame_start=1)[0]
+    assert torch.equal(crop, u8[:, 1:4, :100, :120]) and crop.shape == torch.from_numpy(gold["dec_u8_crop"])[0].shape
+    untiled = vae.decode_to_cpu_uint8([z[0]], 0)[0]
+    assert (untiled.int() - u8.int()).abs().float().mean().item() > 0.5          # tiling really changes the picture (no cross-tile context)
+    mu = vae.encode([vid[0]], 64)[0].cpu()
+    refe = torch.from_numpy(gold["enc"])[0]
+    err = (mu - refe).abs().max().item()
+    print(f"VAE tiled encode: max abs err {err:.4e} (|ref| max {refe.abs().max().item():.3f})")
+    assert mu.shape == refe.shape and err <= 1e-2 * refe.abs().max().item() + 1e-3
+
+
 def test_encode_decode_roundtrip_shapes(vae):
     """size-independent property at a larger size: chunked causal encode (1+4+4 frames) and frame-by-frame
     decode agree on shapes ( (T-1)/4+1 latents, (t-1)*4+1 frames ) and stay finite."""

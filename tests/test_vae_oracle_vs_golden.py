@@ -28,3 +28,21 @@ def test_vae_decode_encode_match_reference():
         vid[:, :, 1:] *= 0.5
         enc = VO.vae_encode(vid, W, scale)
         assert torch.equal(enc, torch.from_numpy(g["enc"]))
+
+
+def test_vae_spatial_tiling_matches_reference():
+    """vae.py:676-717 (spatial_tiled_decode), :769-839 (tiled decode_to_cpu_uint8), :841-881 (spatial_tiled_encode): 3 x 3
+    overlapping tiles of a 128 x 128 clip, tile 64 px."""
+    g = dict(np.load(os.path.join(G, "vae_tiled.npz")))
+    W = VO.synth_vae_weights()
+    scale = VO.default_scale()
+    gen = torch.Generator().manual_seed(22)
+    z = torch.randn(1, 16, 2, 16, 16, generator=gen)
+    vid = (torch.rand(1, 3, 5, 128, 128, generator=gen) * 2 - 1)
+    vid[:, :, 1:] *= 0.5
+    with torch.no_grad():
+        assert torch.equal(VO.vae_tiled_decode(z, W, scale, 64), torch.from_numpy(g["dec"]))
+        u8 = VO.vae_tiled_decode_uint8(z, W, scale, 64)
+        assert torch.equal(u8, torch.from_numpy(g["dec_u8"]))
+        assert torch.equal(u8[:, :, 1:4, :100, :120], torch.from_numpy(g["dec_u8_crop"]))     # frame_start / target_* only crop
+        assert torch.equal(VO.vae_tiled_encode(vid, W, scale, 64), torch.from_numpy(g["enc"]))

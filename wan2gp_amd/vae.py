@@ -8,9 +8,10 @@ Decoder3d / WanVAE_.encode / .decode (vae.py:318-662) run here on the host; ever
 libwanhip kernel on fp16 channels-last activations [T,H,W,C] (vae_ops.hip): implicit-GEMM MFMA
 convolutions with the 2-frame cache, fused nearest-2x upsample, fused time interleave, fused
 residual add, RMS_norm+SiLU, the attention block as fp16 GEMMs + a row softmax, and the
-float->uint8 conversion.  Spatial tiling (tile_size > 0) exists in the reference only to fit
-small VRAM; with 288 GB of HBM the full frame is always decoded in one piece (the tile_size == 0
-path of vae.py:762-767), so tile_size is accepted and ignored.
+float->uint8 conversion.  Spatial tiling (tile_size > 0: vae.py:676-717, :769-839, :841-881) exists in the
+reference to fit small VRAM; `get_VAE_tile_size` here always answers 0 (288 GB of HBM: the full frame in one
+piece, the tile_size == 0 path of vae.py:762-767), but a caller that passes a tile size gets the reference's
+tiling: overlapping tiles decoded / encoded independently, seams blended over a quarter tile.
 """
 import math
 from typing import Dict, List, Optional
@@ -361,9 +362,95 @@ class WanVAEHIP:
         assert t0 == T_out, (t0, T_out)
         return u8, f32
 
+    # ---- spatial tiling (host logic of vae.py:664-717, :769-839, :841-881; latent-sized torch arithmetic on the seams) ------
+    @staticmethod
+    def _blend(a, b, be, dim):
+        """blend_v / blend_h (vae.py:664-674), vectorised: b[y] = a[-be + y] * (1 - y/be) + b[y] * (y/be), Python-float weights."""
+        be = min(a.shape[dim], b.shape[dim], be)
+        if be <= 0:
+            return b
+        shape = [1] * b.dim()
+        shape[dim] = be
+        w = torch.arange(be, dtype=torch.float64) / be
+        w0, w1 = (1 - w).to(torch.float32).view(shape).to(b.device), w.to(torch.float32).view(shape).to(b.device)
+        bb = b.narrow(dim, 0, be)
+        bb.copy_(a.narrow(dim, a.shape[dim] - be, be) * w0 + bb * w1)
+        return b
+
+    def _blend_tiles(self, rows, be, row_limit):
+        out_rows = []
+        for i, row in enumerate(rows):
+            out = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend(rows[i - 1][j], tile, be, -2)
+                if j > 0:
+                    tile = self._blend(row[j - 1], tile, be, -1)
+                out.append(tile[..., :row_limit, :row_limit])
+            out_rows.append(torch.cat(out, dim=-1))
+        return torch.cat(out_rows, dim=-2)
+
+    def _tiled_decode_f32(self, z, tile_size):
+        """spatial_tiled_decode (vae.py:676-717) on one latent [16,t,h,w] -> fp32 [3,T,H,W] (not clamped)."""
+        tl = int(tile_size / 8)
+        ov, be = int(tl * 0.75), int(tile_size * self.upsampler_factor * 0.25)
+        if tl < 1 or ov < 1:
+            raise ValueError(f"tile_size {tile_size} is too small to tile")
+        rows = [[self._decode_frames(z[:, :, i:i + tl, j:j + tl], False, True)[1] for j in range(0, z.shape[-1], ov)]
+                for i in range(0, z.shape[-2], ov)]
+        return self._blend_tiles(rows, be, tile_size * self.upsampler_factor - be)
+
+    @staticmethod
+    def _blend_edge(edge, tile, be, dim):
+        """_blend_v_edge_ / _blend_h_edge_ (vae.py:23-40): the streaming form used by the tiled uint8 decode (fp32 tensor weights)."""
+        be = min(int(edge.shape[dim]), int(tile.shape[dim]), int(be))
+        if be <= 0:
+            return
+        shape = [1] * tile.dim()
+        shape[dim] = be
+        w = torch.arange(be, device=tile.device, dtype=tile.dtype).div_(be).view(shape)
+        e = edge.narrow(dim, edge.shape[dim] - be, be).clone()
+        e.mul_(1.0 - w)
+        tile.narrow(dim, 0, be).mul_(w).add_(e)
+
+    def _tiled_decode_u8(self, z, tile_size):
+        """The tiled branch of decode_to_cpu_uint8 (vae.py:769-839) for the whole clip: uint8 [3,T,H,W] on the device."""
+        tl = max(1, int(tile_size / 8))
+        ov = max(1, int(tl * 0.75))
+        be = int(tile_size * self.upsampler_factor * 0.25)
+        row_limit = max(1, tile_size * self.upsampler_factor - be)
+        T, H, W = (z.shape[1] - 1) * 4 + 1, z.shape[-2] * 8, z.shape[-1] * 8
+        out = torch.empty(3, T, H, W, dtype=torch.uint8, device=self.device)
+        prev_edges, r = [], 0
+        for ly in range(0, z.shape[-2], ov):
+            y0, y1 = r * row_limit, min(r * row_limit + row_limit, H)
+            if y1 <= y0:
+                break
+            cur_edges, left, c = [], None, 0
+            for lx in range(0, z.shape[-1], ov):
+                x0, x1 = c * row_limit, min(c * row_limit + row_limit, W)
+                if x1 <= x0:
+                    break
+                tile = self._decode_frames(z[:, :, ly:ly + tl, lx:lx + tl], False, True)[1]
+                if r > 0 and c < len(prev_edges) and prev_edges[c] is not None:
+                    self._blend_edge(prev_edges[c], tile, be, -2)
+                if left is not None:
+                    self._blend_edge(left, tile, be, -1)
+                cur_edges.append(tile[..., -min(be, tile.shape[-2]):, :].clone() if y1 < H else None)
+                left = tile[..., -min(be, tile.shape[-1]):].clone() if x1 < W else None
+                tile = tile[..., :y1 - y0, :x1 - x0]
+                out[:, :, y0:y0 + tile.shape[-2], x0:x0 + tile.shape[-1]] = \
+                    tile.clamp(-1.0, 1.0).add_(1.0).mul_(127.5).round_().clamp_(0.0, 255.0).to(torch.uint8)    # vae.py:18-20
+                c += 1
+            prev_edges = cur_edges
+            r += 1
+        return out
+
     def decode(self, zs, tile_size=0, any_end_frame=False):
         if any_end_frame:
             raise NotImplementedError("any_end_frame decode is outside the hot path")
+        if int(tile_size or 0) > 0:
+            return [self._tiled_decode_f32(u.to(self.device), int(tile_size)).clamp_(-1, 1) for u in zs]
         return [self._decode_frames(u, False, True)[1].clamp_(-1, 1) for u in zs]
 
     def decode_to_cpu_uint8(self, zs, tile_size=0, target_frames=None, target_height=None, target_width=None,
@@ -372,7 +459,10 @@ class WanVAEHIP:
             raise NotImplementedError("any_end_frame decode is outside the hot path")
         outs = []
         for u in zs:
-            u8 = self._decode_frames(u, True, False)[0]
+            if int(tile_size or 0) > 0:
+                u8 = self._tiled_decode_u8(u.to(self.device), int(tile_size))
+            else:
+                u8 = self._decode_frames(u, True, False)[0]
             T = u8.shape[1]
             fs = min(max(0, int(frame_start or 0)), T)
             te = T if target_frames is None else min(T, fs + int(target_frames))
@@ -385,6 +475,17 @@ class WanVAEHIP:
     def encode(self, videos, tile_size=0, any_end_frame=False):
         if any_end_frame:
             raise NotImplementedError("any_end_frame encode is outside the hot path")
+        if int(tile_size or 0) > 0:                          # spatial_tiled_encode (vae.py:841-881)
+            ts = int(tile_size)
+            tl = int(ts / 8)
+            ov, be = int(ts * 0.75), int(tl * 0.25)
+            outs = []
+            for v in videos:
+                v = v.to(self.device)
+                rows = [[self.encode([v[:, :, i:i + ts, j:j + ts]])[0] for j in range(0, v.shape[-1], ov)]
+                        for i in range(0, v.shape[-2], ov)]
+                outs.append(self._blend_tiles(rows, be, tl - be))   # blending commutes with the (affine) latent normalisation
+            return outs
         lib = self.net.lib
         outs = []
         for v in videos:
