@@ -116,6 +116,25 @@ def test_rmsnorm_silu(net):
     close(uncl(n.norm(cl(x), "g.gamma", silu=False)), ref, "rmsnorm", tol=3e-3)
 
 
+@pytest.mark.parametrize("C,npix", [(32, 5), (96, 70), (192, 33), (384, 129), (512, 7), (640, 50), (1024, 3)])
+def test_rmsnorm_kernel_every_channel_width(C, npix):
+    """The lane-group layouts of wan_vae_rmsnorm_silu: 16 / 32 / 64 lanes per pixel, two chunks per lane above 512 channels (the
+    Wan2.2 VAE's 640), pixel counts that do not fill the last wave; against F.normalize * sqrt(C) * gamma (vae.py:94-107)."""
+    from wan2gp_amd import lib as L
+    g = torch.Generator().manual_seed(C + npix)
+    x = (torch.randn(npix, C, generator=g) * 2).to(F16)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(F16)
+    for silu in (0, 1):
+        xc, gc = x.cuda(), gamma.cuda()
+        out = torch.empty_like(xc)
+        L.check(L.load().wan_vae_rmsnorm_silu(L.ptr(xc), L.ptr(out), L.ptr(gc), npix, C, silu, L.stream_ptr()), "rmsnorm")
+        ref = F.normalize(x.float(), dim=1) * (C ** 0.5) * gamma.float()
+        if silu:
+            ref = F.silu(ref.half().float())
+        err = (out.float().cpu() - ref).abs().max().item()
+        assert err <= 3e-3 * max(1.0, ref.abs().max().item()), (C, npix, silu, err)
+
+
 @pytest.fixture(scope="module")
 def vae():
     from wan2gp_amd.vae import WanVAEHIP
