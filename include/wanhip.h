@@ -367,8 +367,17 @@ typedef struct {
    * Tokens of frame f are modulated by e0[f] (model.py:631-638) and the head by e[f] (:856-862). */
   const float* t_frames;
   int n_t_frames;
+  /* several VACE contexts in one call (model.py:1905-1912 one hint list per context, :617-629 each through the context block,
+   * :713-719 added to x in context order with its own scale; scale 0 = that context is off).  n_vace > 0: HOST arrays of
+   * n_vace device pointers / scales replace the vace_context / vace_scale pair above; n_vace <= wan_dit_set_vace_contexts. */
+  int n_vace;
+  const float* const* vace_contexts;
+  const float* vace_scales;
 } wan_dit_args;
 int wan_dit_forward_ex(wan_ctx* ctx, const wan_dit_args* args, void* stream);
+/* How many VACE contexts one forward may mix (default 1): sizes the hint-stream region of the workspace
+ * (wan_dit_workspace_bytes grows by 2 x S x L x dim x 2 bytes per extra context). */
+int wan_dit_set_vace_contexts(wan_ctx* ctx, int n);
 /* VACE: main-block indices that carry a context block (WanModel(vace_layers=...), model.py:1178-1183; 0,5,...,35 for the
  * 14B VACE model).  Weights: vace_blocks.N.* (a block's keys + before_proj for N = 0 + after_proj), and
  * vace_patch_embedding.weight / .bias registered as fp32 copies of the bf16 parameters.  Call before the first forward /

@@ -131,8 +131,10 @@ def decide(cache, n, x_id, step, e):
     return [calc] * n
 
 
-def dit_forward_cached(x_list, t, context_list, W, cfg, cache, x_id=0, real_step_no=0, dtype=torch.bfloat16):
-    """WanModel.forward with `self.cache` set (model.py:1914-2064), t2v path.  Returns (outputs, x_should_calc)."""
+def dit_forward_cached(x_list, t, context_list, W, cfg, cache, x_id=0, real_step_no=0, dtype=torch.bfloat16, vace_context=None,
+                       vace_scale=1.0):
+    """WanModel.forward with `self.cache` set (model.py:1914-2064), t2v path (+ VACE context blocks, which a skipped stream skips
+    together with its main blocks).  Returns (outputs, x_should_calc)."""
     hs = []
     grid = None
     for x in x_list:
@@ -149,10 +151,11 @@ def dit_forward_cached(x_list, t, context_list, W, cfg, cache, x_id=0, real_step
             hs[s] = hs[s] + cache.previous_residual[sl]                      # x += previous_residual (:1967-1971)
     ori = [h.clone() if c else None for h, c in zip(hs, flags)]
     ctxs = [O.text_embed(c.to(dtype), W) for c in context_list]
+    hints, scales = O.vace_hints(vace_context, vace_scale, W, cfg, len(hs))
     for i in range(cfg.num_layers):
         for s in range(len(hs)):
             if flags[s]:
-                hs[s] = O.block_forward(hs[s], e0, ctxs[s], cos, sin, W, i, cfg, False)
+                hs[s] = O.block_with_hints(hs[s], None if hints is None else hints[s], scales, e0, ctxs[s], cos, sin, W, i, cfg, False)
     for s, (sl, calc) in enumerate(zip(slots, flags)):
         if calc:
             cache.previous_residual[sl] = hs[s] - ori[s]                      # torch.sub(x, ori) (:2044-2062)

@@ -379,6 +379,39 @@ def vace_block_forward(c, x, e0, ctx, cos, sin, W, n: int, cfg: WanConfig, exact
     return c, _linear(c, W, p + "after_proj")
 
 
+def vace_hints(vace_context, vace_scale, W, cfg: WanConfig, n_streams: int):
+    """model.py:1905-1912: every VACE context (one tensor, or a list of them with one scale each) is embedded once; every x stream
+    gets its own copy of every context's hint tokens.  Returns (hints[stream][context], scales) or (None, None)."""
+    if vace_context is None:
+        return None, None
+    ctxs = list(vace_context) if isinstance(vace_context, (list, tuple)) else [vace_context]
+    scales = list(vace_scale) if isinstance(vace_scale, (list, tuple)) else [vace_scale] * len(ctxs)
+    w = W["vace_patch_embedding.weight"]
+    emb = [F.conv3d(u.to(w.dtype).unsqueeze(0), w, W["vace_patch_embedding.bias"], stride=cfg.patch_size).flatten(2).transpose(1, 2)
+           for u in ctxs]
+    return [[c.clone() for c in emb] for _ in range(n_streams)], scales
+
+
+def block_with_hints(x, hints, scales, e0, ctx, cos, sin, W, i: int, cfg: WanConfig, exact: bool = False):
+    """One main block with its VACE context block(s) (model.py:617-629 in front of the block, :713-719 behind it): every context
+    with a non-zero scale runs the context block on its own hint stream (in place in `hints`); the projected hints are added to
+    x in context order, each add rounding to the stream's dtype."""
+    skips = []
+    if hints is not None and cfg.vace_layers is not None and i in cfg.vace_layers:
+        n = cfg.vace_layers.index(i)
+        for k, sc in enumerate(scales):
+            if sc == 0:
+                skips.append(None)
+                continue
+            hints[k], sk = vace_block_forward(hints[k], x, e0, ctx, cos, sin, W, n, cfg, exact)
+            skips.append(sk)
+    x = block_forward(x, e0, ctx, cos, sin, W, i, cfg, exact)
+    for sk, sc in zip(skips, scales or []):
+        if sk is not None:
+            x = x + sk if sc == 1 else torch.add(x, sk, alpha=sc)
+    return x
+
+
 # --------------------------------------------------------------------------------------
 # head + unpatchify -- model.py:847-865, :2100-2126
 # --------------------------------------------------------------------------------------
@@ -416,7 +449,7 @@ def unpatchify(x, grid, cfg: WanConfig):
 def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[torch.Tensor],
                 W, cfg: WanConfig, y: Optional[torch.Tensor] = None, freqs=None,
                 dtype=torch.bfloat16, exact: bool = False, return_hidden: bool = False, clip_fea: Optional[torch.Tensor] = None,
-                vace_context: Optional[torch.Tensor] = None, vace_scale: float = 1.0, probe=None):
+                vace_context=None, vace_scale=1.0, probe=None):
     """x_list: S tensors [B,16,F,H,W] fp32; t [1]; context_list: S tensors [B,512,4096].
     Returns S fp32 tensors [B,16,F,H,W] (model.py:2093-2097).
     probe(i, s, hidden): called with stream s's token stream after block i (error-growth tables)."""
@@ -436,20 +469,10 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
     if clip_fea is not None:                                # model.py:1858-1869: [clip tokens ; text tokens]
         cc = img_emb(clip_fea.to(dtype), W)
         ctxs = [torch.cat([cc, c], dim=1) for c in ctxs]
-    hints = None
-    if vace_context is not None:                            # model.py:1908-1912: one hint stream per x, all from the same embedding
-        w = W["vace_patch_embedding.weight"]
-        c0 = F.conv3d(vace_context.to(w.dtype).unsqueeze(0), w, W["vace_patch_embedding.bias"], stride=cfg.patch_size)
-        c0 = c0.flatten(2).transpose(1, 2)
-        hints = [c0.clone() for _ in hs]
+    hints, scales = vace_hints(vace_context, vace_scale, W, cfg, len(hs))
     for i in range(cfg.num_layers):                         # model.py:1993-2036
         for s in range(len(hs)):
-            skip = None
-            if hints is not None and i in cfg.vace_layers and vace_scale != 0:
-                hints[s], skip = vace_block_forward(hints[s], hs[s], e0, ctxs[s], cos, sin, W, cfg.vace_layers.index(i), cfg, exact)
-            hs[s] = block_forward(hs[s], e0, ctxs[s], cos, sin, W, i, cfg, exact)
-            if skip is not None:                            # model.py:713-719: x.add_(hint[, alpha=scale])
-                hs[s] = hs[s] + skip if vace_scale == 1 else torch.add(hs[s], skip, alpha=vace_scale)
+            hs[s] = block_with_hints(hs[s], None if hints is None else hints[s], scales, e0, ctxs[s], cos, sin, W, i, cfg, exact)
             if probe is not None:
                 probe(i, s, hs[s])
     if return_hidden:

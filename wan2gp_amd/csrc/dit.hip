@@ -148,6 +148,7 @@ struct wan_ctx {
   const float* vpe_w = nullptr;   // vace_patch_embedding as fp32 copies of the bf16 parameters
   const float* vpe_b = nullptr;
   int vace_in_dim = 0;
+  int vace_max_ctx = 1;           // hint-stream sets the workspace holds (wan_dit_set_vace_contexts): contexts mixed in one call
   bf16_t* clip_ctx = nullptr;   // [257, dim], owned; filled by wan_dit_set_clip
   bf16_t* clip_tmp = nullptr;   // 2 x [257, 1280] scratch, owned
   bool clip_set = false;
@@ -330,7 +331,7 @@ struct Bufs {
   int64_t Lp;
 };
 
-static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, bool vace, bool fp8, int F) {
+static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, int nvace, bool fp8, int F) {
   Carve c(ws);
   const int64_t d = g.dim, rows = (int64_t)S * Ll;
   const int64_t Lp = ((Ll + 63) / 64) * 64;
@@ -364,8 +365,8 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.qws = fp8 ? c.take<float>(64 * S) : nullptr;
   t.ckimg = c.take<bf16_t>((int64_t)CLIP_TOK * d);      // i2v CLIP branch: K_img [257, d] and V_img^T [d, 320] (3.3 + 3.3 MB at 14B)
   t.cvtimg = c.take<bf16_t>((int64_t)d * CLIP_LDV);
-  t.vc = vace ? c.take<bf16_t>(rows * d) : nullptr;      // VACE: the hint token streams and the projected hint of one block
-  t.vskip = vace ? c.take<bf16_t>(rows * d) : nullptr;
+  t.vc = nvace ? c.take<bf16_t>((int64_t)nvace * rows * d) : nullptr;      // VACE: per context, the hint token streams and the projected hint of one block
+  t.vskip = nvace ? c.take<bf16_t>((int64_t)nvace * rows * d) : nullptr;
   if (world > 1) {
     t.kfull = c.take<bf16_t>((int64_t)world * rows * d);
     t.vtfull = c.take<bf16_t>((int64_t)world * S * d * Lp);
@@ -389,7 +390,7 @@ extern "C" int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int
   if (!ctx || S < 1 || seq_shards < 1) return -1;
   const int64_t L = (int64_t)F * (H / 2) * (W / 2);
   if (L % seq_shards != 0) return -1;
-  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, !ctx->vace_layers.empty(), ctx_has_fp8(ctx), F);
+  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, ctx->vace_layers.empty() ? 0 : ctx->vace_max_ctx, ctx_has_fp8(ctx), F);
 }
 
 #define RC(expr)             \
@@ -458,8 +459,8 @@ extern "C" int wan_dit_set_clip(wan_ctx* c, const wan_bf16* clip_fea, void* stre
 static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, const float* t_frames, const wan_bf16* const* context,
                             const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
                             int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
-                            void* poll_user, const int* should_calc, wan_bf16* const* residual, const float* vace_context,
-                            float vace_scale, void* stream) {
+                            void* poll_user, const int* should_calc, wan_bf16* const* residual, int n_vace,
+                            const float* const* vace_contexts, const float* vace_scales, void* stream) {
   WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
   WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
@@ -479,7 +480,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
   WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
   Bufs b;
-  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, !c->vace_layers.empty(), c->any_fp8, F);
+  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, c->vace_layers.empty() ? 0 : c->vace_max_ctx, c->any_fp8, F);
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
               (long long)workspace_bytes, (long long)need);
   WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
@@ -545,16 +546,26 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     else RC(wan_add_bf16(b.x + s * sn, residual[s], b.x + s * sn, sn, stream));
   }
 
-  // ---- VACE: c = vace_patch_embedding(vace_context) for every stream (model.py:1908-1912) ------------------------------------
-  const bool vace = vace_context != nullptr && vace_scale != 0.f;
-  if (vace_context != nullptr) {
+  // ---- VACE: c_k = vace_patch_embedding(vace_context[k]) for every context and stream (model.py:1905-1912) -------------------------
+  // Context k with scale 0 is switched off (model.py:622-626): no hint stream, no context block, no add.
+  const int S_all = S;
+  int n_on = 0;
+  int on_k[8];
+  if (n_vace > 0) {
     WAN_REQUIRE(!c->vace_layers.empty(), "wan_dit_forward: vace_context given but the model has no VACE blocks (wan_dit_set_vace_layers)");
-    if (vace) {
-      RC(wan_patch_embed_range(vace_context, nullptr, c->vpe_w, c->vpe_b, b.vc, 1, c->vace_in_dim, 0, F, H, W, d, tok0, Ll, stream));
+    WAN_REQUIRE(vace_contexts && vace_scales && n_vace <= c->vace_max_ctx && n_vace <= 8,
+                "wan_dit_forward: %d VACE contexts, the workspace holds %d (wan_dit_set_vace_contexts)", n_vace, c->vace_max_ctx);
+    for (int k = 0; k < n_vace; ++k) {
+      if (vace_scales[k] == 0.f) continue;
+      WAN_REQUIRE(vace_contexts[k] != nullptr, "wan_dit_forward: vace_contexts[%d] is null", k);
+      bf16_t* vck = b.vc + (int64_t)k * S * sn;
+      RC(wan_patch_embed_range(vace_contexts[k], nullptr, c->vpe_w, c->vpe_b, vck, 1, c->vace_in_dim, 0, F, H, W, d, tok0, Ll, stream));
       for (int s = 1; s < S; ++s)
-        WAN_CHECK_HIP(hipMemcpyAsync(b.vc + s * sn, b.vc, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
+        WAN_CHECK_HIP(hipMemcpyAsync(vck + s * sn, vck, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
+      on_k[n_on++] = k;
     }
   }
+  const bool vace = n_on > 0;
 
   // the block chain over streams [s0, s0 + Sn): every scratch buffer is used from its base, only the token stream and the
   // text context are offset (maximal runs of computing streams; all of them in the plain forward)
@@ -564,8 +575,12 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; float* raw; } b2 = {
       b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
   bf16_t* const x_main = b.x + s0 * sn;
-  bf16_t* vc = vace ? b.vc + s0 * sn : nullptr;      // hint streams of this run; vskip doubles as the swap buffer of before_proj
-  bf16_t* vskip = vace ? b.vskip : nullptr;
+  // hint streams of this run, per active context; vskip[k] doubles as the swap buffer of before_proj
+  bf16_t *vc[8], *vskip[8];
+  for (int j = 0; j < n_on; ++j) {
+    vc[j] = b.vc + ((int64_t)on_k[j] * S_all + s0) * sn;
+    vskip[j] = b.vskip + ((int64_t)on_k[j] * S_all + s0) * sn;
+  }
   auto& b = b2;
   // one WanAttentionBlock (model.py:575-724) on the token streams at b.x, with the weights Lw
   auto run_layer = [&](const Layer& Lw) -> int {
@@ -654,20 +669,23 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     if (poll && poll(poll_user, i)) return WAN_ABORTED;  // model.py:1995-1998
     const int n = vace ? c->vace_at[i] : -1;
     if (n >= 0) {
-      // VaceWanAttentionBlock.forward (model.py:816-828), called at the top of main block i (:617-629): the context block
-      // runs the same layer code on the hint streams, with the main streams' e0 / text context / RoPE.
+      // VaceWanAttentionBlock.forward (model.py:816-828), called at the top of main block i (:617-629) once per active context:
+      // the context block runs the same layer code on that context's hint streams, with the main streams' e0 / text context / RoPE.
       const Layer& Vw = c->vlayers[n];
-      if (n == 0) {  // c = before_proj(c) + x
-        RC(linear(vc, Vw.before, vskip, rows, d, d, WAN_EPI_GATE_RES, stream, x_main, nullptr, nullptr, -1, rpb, 0, q8, S));
-        bf16_t* t2 = vc; vc = vskip; vskip = t2;
+      for (int j = 0; j < n_on; ++j) {
+        if (n == 0) {  // c = before_proj(c) + x
+          RC(linear(vc[j], Vw.before, vskip[j], rows, d, d, WAN_EPI_GATE_RES, stream, x_main, nullptr, nullptr, -1, rpb, 0, q8, S));
+          bf16_t* t2 = vc[j]; vc[j] = vskip[j]; vskip[j] = t2;
+        }
+        b.x = vc[j];
+        RC(run_layer(Vw));
+        b.x = x_main;
+        RC(linear(vc[j], Vw.after, vskip[j], rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));  // c_skip = after_proj(c)
       }
-      b.x = vc;
-      RC(run_layer(Vw));
-      b.x = x_main;
-      RC(linear(vc, Vw.after, vskip, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));  // c_skip = after_proj(c)
     }
     RC(run_layer(c->layers[i]));
-    if (n >= 0) RC(wan_axpy_bf16(b.x, vskip, vace_scale, b.x, rows * (int64_t)d, stream));  // x.add_(hint[, alpha=scale]) (:713-719)
+    if (n >= 0)  // x.add_(hint[, alpha=scale]) per context, in context order (:713-719)
+      for (int j = 0; j < n_on; ++j) RC(wan_axpy_bf16(b.x, vskip[j], vace_scales[on_k[j]], b.x, rows * (int64_t)d, stream));
   }
   return 0;
   };
@@ -694,7 +712,7 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
                                int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                void* poll_user, void* stream) {
   return dit_forward_impl(c, S, x, t, nullptr, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
-                          nullptr, nullptr, nullptr, 1.0f, stream);
+                          nullptr, nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
@@ -702,16 +720,27 @@ extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, fl
                                     int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                     void* poll_user, const int* should_calc, wan_bf16* const* residual, void* stream) {
   return dit_forward_impl(c, S, x, t, nullptr, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
-                          should_calc, residual, nullptr, 1.0f, stream);
+                          should_calc, residual, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* stream) {
   WAN_REQUIRE(c && a, "wan_dit_forward_ex: null argument");
   WAN_REQUIRE(a->n_t_frames == 0 || (a->t_frames != nullptr && a->n_t_frames == a->F),
               "wan_dit_forward_ex: t_frames must hold one timestep per latent frame (%d given, F = %d)", a->n_t_frames, a->F);
+  // one context through the original pair of fields, or n_vace of them through the arrays
+  const float* one_ctx[1] = {a->vace_context};
+  const float one_scale[1] = {a->vace_scale};
+  const bool many = a->n_vace > 0;
+  WAN_REQUIRE(!many || (a->vace_contexts && a->vace_scales), "wan_dit_forward_ex: n_vace = %d but the arrays are null", a->n_vace);
   return dit_forward_impl(c, a->S, a->x, a->t, a->n_t_frames ? a->t_frames : nullptr, a->context, a->y, a->cos, a->sin, a->outs, a->F, a->H, a->W, a->workspace,
-                          a->workspace_bytes, a->sp, a->poll, a->poll_user, a->should_calc, a->residual, a->vace_context,
-                          a->vace_scale, stream);
+                          a->workspace_bytes, a->sp, a->poll, a->poll_user, a->should_calc, a->residual,
+                          many ? a->n_vace : (a->vace_context ? 1 : 0), many ? a->vace_contexts : one_ctx, many ? a->vace_scales : one_scale, stream);
+}
+
+extern "C" int wan_dit_set_vace_contexts(wan_ctx* c, int n) {
+  WAN_REQUIRE(c && n >= 1 && n <= 8, "wan_dit_set_vace_contexts: 1..8 contexts, got %d", n);
+  c->vace_max_ctx = n;
+  return 0;
 }
 
 extern "C" int wan_dit_set_vace_layers(wan_ctx* c, const int* layers, int n) {

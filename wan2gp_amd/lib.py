@@ -36,7 +36,8 @@ class DitArgs(ctypes.Structure):
                 ("cos", c_void_p), ("sin", c_void_p), ("outs", POINTER(c_void_p)), ("F", c_int), ("H", c_int), ("W", c_int),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64), ("sp", c_void_p), ("poll", c_void_p),
                 ("poll_user", c_void_p), ("should_calc", POINTER(c_int)), ("residual", POINTER(c_void_p)),
-                ("vace_context", c_void_p), ("vace_scale", c_float), ("t_frames", POINTER(c_float)), ("n_t_frames", c_int)]
+                ("vace_context", c_void_p), ("vace_scale", c_float), ("t_frames", POINTER(c_float)), ("n_t_frames", c_int),
+                ("n_vace", c_int), ("vace_contexts", POINTER(c_void_p)), ("vace_scales", POINTER(c_float))]
 GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p)
 GATHER_WAIT_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p)
 
@@ -89,6 +90,7 @@ SIGNATURES = {
     "wan_dit_set_clip": (c_int, [c_void_p, c_void_p, c_void_p]),
     "wan_dit_forward_ex": (c_int, [c_void_p, POINTER(DitArgs), c_void_p]),
     "wan_dit_set_vace_layers": (c_int, [c_void_p, POINTER(c_int), c_int]),
+    "wan_dit_set_vace_contexts": (c_int, [c_void_p, c_int]),
     "wan_axpy_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     "wan_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_sub_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

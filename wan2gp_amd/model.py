@@ -61,6 +61,7 @@ class WanModelHIP:
         # VACE (model.py:1178-1206): context blocks attached to the main blocks `vace_layers`
         self.vace_layers = None if vace_layers is None else [int(v) for v in vace_layers]
         self.vace_in_dim = (in_dim if vace_in_dim is None else vace_in_dim) if vace_layers is not None else None
+        self._vace_max_ctx = 1                # hint-stream sets the C workspace is sized for (wan_dit_set_vace_contexts)
         if self.vace_layers is not None:
             arr = (ctypes.c_int * len(self.vace_layers))(*self.vace_layers)
             check(_L.load().wan_dit_set_vace_layers(self._ctx, arr, len(self.vace_layers)), "wan_dit_set_vace_layers")
@@ -159,16 +160,18 @@ class WanModelHIP:
     def forward(self, x, t, context, y=None, freqs=None, pipeline=None, current_step_no=0, real_step_no=0, x_id=0,
                 max_steps=0, callback=None, clip_fea=None, vace_context=None, vace_context_scale=None, **variant_kwargs):
         active = {k: v for k, v in variant_kwargs.items() if not _is_default(k, v)}
-        vace_t, vace_scale = None, 1.0
+        vace_ts, vace_scales = None, None
         if vace_context is not None:
             if self.vace_layers is None:
                 active["vace_context"] = vace_context
-            else:
-                if len(vace_context) != 1:
-                    raise NotImplementedError("one VACE context per call (vace_context=[tensor]); multi-context mixing is not implemented")
-                scales = [1.0] if vace_context_scale is None else list(vace_context_scale)
-                vace_scale = float(scales[0])
-                vace_t = vace_context[0].to(device=self.device, dtype=torch.bfloat16).to(torch.float32).contiguous()   # u.to(weight.dtype)
+            else:                                           # one hint stream set per context, each with its own scale (model.py:1905-1912)
+                vace_scales = [float(v) for v in ([1.0] if vace_context_scale is None else vace_context_scale)]
+                if len(vace_scales) != len(vace_context) or not 1 <= len(vace_context) <= 8:
+                    raise _L.WanHipError(f"{len(vace_context)} VACE contexts with {len(vace_scales)} scales (1..8 contexts, one scale each)")
+                vace_ts = [u.to(device=self.device, dtype=torch.bfloat16).to(torch.float32).contiguous() for u in vace_context]   # u.to(weight.dtype)
+                if len(vace_ts) > self._vace_max_ctx:       # the workspace holds one hint-stream set per context
+                    check(_L.load().wan_dit_set_vace_contexts(self._ctx, len(vace_ts)), "wan_dit_set_vace_contexts")
+                    self._vace_max_ctx = len(vace_ts)
         if self.model_type == "i2v":
             if clip_fea is None or y is None:
                 raise _L.WanHipError("model_type 'i2v' needs clip_fea [1,257,1280] and y (model.py:1547)")
@@ -242,20 +245,11 @@ class WanModelHIP:
         CP = (c_void_p * S)(*[a.data_ptr() for a in ctxs])
         OP = (c_void_p * S)(*[a.data_ptr() for a in outs])
         cache = self.cache
-        if vace_t is not None or t_frames is not None:
-            if vace_t is not None and tuple(vace_t.shape) != (self.vace_in_dim, F, H, W):
-                raise _L.WanHipError(f"vace_context must be [{self.vace_in_dim},{F},{H},{W}], got {list(vace_t.shape)}")
-            if cache is not None:
-                raise NotImplementedError("VACE / per-frame timesteps together with a step-skipping cache")
-            a = _L.DitArgs(S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws), ws.numel(),
-                           None if sp_struct is None else ctypes.cast(sp_struct, c_void_p), ctypes.cast(poll, c_void_p), None, None, None,
-                           ptr(vace_t), vace_scale, t_frames, F if t_frames is not None else 0)
-            rc = _L.load().wan_dit_forward_ex(self._ctx, ctypes.byref(a), stream_ptr())
-        elif cache is None:
-            rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
-                                           ws.numel(), sp_struct, poll, None, stream_ptr())
-        else:
-            # TeaCache / MagCache (model.py:1914-2064): host decision, residual bookkeeping inside wan_dit_forward_skip
+        FL = RP = None
+        if cache is not None:
+            # TeaCache / MagCache (model.py:1914-2064): host decision, residual bookkeeping inside the forward
+            if t_frames is not None:
+                raise NotImplementedError("per-frame timesteps together with a step-skipping cache")
             from . import skipcache
             e = self.time_embedding(tval) if (cache.cache_type == "tea" and x_id == 0) else None
             flags = skipcache.decide(cache, S, x_id, real_step_no, e)
@@ -275,6 +269,21 @@ class WanModelHIP:
                 bufs.append(r)
             FL = (ctypes.c_int * S)(*[1 if f else 0 for f in flags])
             RP = (c_void_p * S)(*[r.data_ptr() for r in bufs])
+        if vace_ts is not None or t_frames is not None:
+            nv = 0 if vace_ts is None else len(vace_ts)
+            for u in vace_ts or ():
+                if tuple(u.shape) != (self.vace_in_dim, F, H, W):
+                    raise _L.WanHipError(f"vace_context must be [{self.vace_in_dim},{F},{H},{W}], got {list(u.shape)}")
+            VP = (c_void_p * nv)(*[u.data_ptr() for u in vace_ts]) if nv else None
+            VS = (ctypes.c_float * nv)(*vace_scales) if nv else None
+            a = _L.DitArgs(S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws), ws.numel(),
+                           None if sp_struct is None else ctypes.cast(sp_struct, c_void_p), ctypes.cast(poll, c_void_p), None, FL, RP,
+                           None, 1.0, t_frames, F if t_frames is not None else 0, nv, VP, VS)
+            rc = _L.load().wan_dit_forward_ex(self._ctx, ctypes.byref(a), stream_ptr())
+        elif cache is None:
+            rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
+                                           ws.numel(), sp_struct, poll, None, stream_ptr())
+        else:
             rc = _L.load().wan_dit_forward_skip(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
                                                 ws.numel(), sp_struct, poll, None, FL, RP, stream_ptr())
         if rc == _L.WAN_ABORTED:
