@@ -253,6 +253,33 @@ __global__ __launch_bounds__(256) void gemm256k_kernel(const bf16_t* __restrict_
   asm volatile("" ::: "memory");
   constexpr int EROW = 272;      // bytes per parked row: 256 + 16 (ds_write_b128 of 16 lanes on consecutive rows: 64 banks once)
   char* const park = smem + wave * (128 * EROW);
+  // read-back geometry: instruction i covers rows 4i .. 4i+3 of the wave's sub-tile, lane -> (row 4i + lane/16, 16-B chunk lane%16)
+  const int prow = lane >> 4, pchunk = lane & 15;
+  const int64_t xc = x0 + wx * 128 + pchunk * 8;          // first of the lane's 8 columns: the same for every row group
+  const bool col_full = xc + 8 <= XN;
+  const int64_t yrow0 = y0 + wy * 128 + prow;
+  // Gated epilogue: the residual (and the per-batch gate row) of a 4-row group is one 16-byte load per lane from HBM.  GDEPTH
+  // groups are kept in flight during the read-back (the accumulators' registers are free by then; issued before the parking
+  // phase they cost an accumulator spill).  With two groups in flight (the first version) this epilogue was latency-bound:
+  // 65 % matrix-pipe utilisation on the o-projection against 82 % for the plain epilogue (PMC).
+  constexpr int GDEPTH = 8;
+  uint4 rq[GDEPTH] = {}, eq[GDEPTH] = {};
+  // (values returned, not written through references: arrays handed to a lambda by reference were left in scratch memory)
+  auto fetch_r = [&](int i) -> uint4 {
+    uint4 z = {};
+    if (EPI != WAN_EPI_GATE_RES || !col_full) return z;
+    int64_t yr = yrow0 + i * 4;
+    if (yr > YM - 1) yr = YM - 1;
+    return *reinterpret_cast<const uint4*>(R + yr * ldo + xc);
+  };
+  auto fetch_e = [&](int i) -> uint4 {
+    uint4 z = {};
+    if (EPI != WAN_EPI_GATE_RES || !col_full || gate_idx < 0) return z;
+    int64_t yr = yrow0 + i * 4;
+    if (yr > YM - 1) yr = YM - 1;
+    const uint32_t bidx = (uint32_t)yr / (uint32_t)rows_per_batch;
+    return *reinterpret_cast<const uint4*>(e + ((int64_t)bidx * n_mod + gate_idx) * XN + xc);
+  };
 #pragma unroll
   for (int xt = 0; xt < 4; ++xt) {
     const int64_t xb = x0 + wx * 128 + xt * 32 + half * 16;
@@ -290,27 +317,11 @@ __global__ __launch_bounds__(256) void gemm256k_kernel(const bf16_t* __restrict_
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the region is private to the wave: its own writes are all it waits for
-  // read-back: instruction i covers rows 4i .. 4i+3 of the wave's sub-tile, lane -> (row 4i + lane/16, 16-B chunk lane%16)
-  const int prow = lane >> 4, pchunk = lane & 15;
-  const int64_t xc = x0 + wx * 128 + pchunk * 8;          // first of the lane's 8 columns: the same for every row group
-  const bool col_full = xc + 8 <= XN;
-  const int64_t yrow0 = y0 + wy * 128 + prow;
   uint4 mchunk = {};
   if (EPI == WAN_EPI_GATE_RES && gate_idx >= 0 && col_full) mchunk = *reinterpret_cast<const uint4*>(mod + (int64_t)gate_idx * XN + xc);
-  // two row groups in flight ahead of the one being stored: three named operand slots rotate (arrays indexed through a
-  // lambda were left in scratch memory by the compiler)
-  uint4 r0 = {}, r1 = {}, r2 = {}, e0 = {}, e1 = {}, e2 = {};
-  auto gate_fetch = [&](int i, uint4& rq, uint4& eq) {
-    if (EPI != WAN_EPI_GATE_RES || !col_full) return;
-    int64_t yr = yrow0 + i * 4;
-    if (yr > YM - 1) yr = YM - 1;
-    rq = *reinterpret_cast<const uint4*>(R + yr * ldo + xc);
-    if (gate_idx >= 0) {
-      const uint32_t bidx = (uint32_t)yr / (uint32_t)rows_per_batch;
-      eq = *reinterpret_cast<const uint4*>(e + ((int64_t)bidx * n_mod + gate_idx) * XN + xc);
-    }
-  };
-  auto emit = [&](int i, const uint4& rq, const uint4& eq) {
+#pragma unroll
+  for (int i = 0; i < GDEPTH; ++i) { rq[i] = fetch_r(i); eq[i] = fetch_e(i); }
+  auto emit = [&](int i, const uint4 rq_, const uint4 eq_) {
     const int64_t yr = yrow0 + i * 4;
     const uint4 raw = *reinterpret_cast<const uint4*>(park + (i * 4 + prow) * EROW + pchunk * 16);
     if (yr >= YM) return;
@@ -319,11 +330,11 @@ __global__ __launch_bounds__(256) void gemm256k_kernel(const bf16_t* __restrict_
       if (EPI == WAN_EPI_GATE_RES) {
         float v[8], rv[8];
         unpack8t<F16>(raw, v);
-        unpack8t<F16>(rq, rv);
+        unpack8t<F16>(rq_, rv);
         if (gate_idx >= 0) {
           float mv[8], ev[8];
           unpack8t<F16>(mchunk, mv);
-          unpack8t<F16>(eq, ev);
+          unpack8t<F16>(eq_, ev);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = rv[j] + v[j] * rnd16<F16>(mv[j] + ev[j]);
         } else {
@@ -343,15 +354,11 @@ __global__ __launch_bounds__(256) void gemm256k_kernel(const bf16_t* __restrict_
         if (xc + j < XN) optr[j] = (bf16_t)(w4[j >> 1] >> ((j & 1) * 16));
     }
   };
-  gate_fetch(0, r0, e0);
-  gate_fetch(1, r1, e1);
-  for (int i = 0; i < 30; i += 3) {
-    gate_fetch(i + 2, r2, e2); emit(i, r0, e0);
-    gate_fetch(i + 3, r0, e0); emit(i + 1, r1, e1);
-    gate_fetch(i + 4, r1, e1); emit(i + 2, r2, e2);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {  // fully unrolled: the slot index i % GDEPTH is a constant, the arrays stay in registers
+    emit(i, rq[i % GDEPTH], eq[i % GDEPTH]);
+    if (i + GDEPTH < 32) { rq[i % GDEPTH] = fetch_r(i + GDEPTH); eq[i % GDEPTH] = fetch_e(i + GDEPTH); }
   }
-  emit(30, r0, e0);
-  emit(31, r1, e1);
 #ifdef G256K_TIMING
   if (blockIdx.x == 40 && tid == 0) {  // whole-tile timeline of one ordinary workgroup -> row 1 of tile (0,0) (whose epilogue is skipped)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

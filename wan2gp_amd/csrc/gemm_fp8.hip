@@ -267,18 +267,26 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
   const int64_t yrow0 = y0 + wy * 128 + prow;
   uint4 mchunk = {};
   if (EPI == WAN_EPI_GATE_RES && gate_idx >= 0 && col_full) mchunk = *reinterpret_cast<const uint4*>(mod + (int64_t)gate_idx * XN + xc);
-  uint4 r0 = {}, r1 = {}, r2 = {}, e0 = {}, e1 = {}, e2 = {};
-  auto gate_fetch = [&](int i, uint4& rq, uint4& eq) {
-    if (EPI != WAN_EPI_GATE_RES || !col_full) return;
+  // residual / gate rows of GDEPTH 4-row groups in flight during the read-back (gemm256k.hip: with two the gated epilogue was
+  // latency-bound); values are returned from the lambdas, arrays passed by reference end up in scratch memory
+  constexpr int GDEPTH = 8;
+  uint4 rqa[GDEPTH] = {}, eqa[GDEPTH] = {};
+  auto fetch_r = [&](int i) -> uint4 {
+    uint4 z = {};
+    if (EPI != WAN_EPI_GATE_RES || !col_full) return z;
     int64_t yr = yrow0 + i * 4;
     if (yr > YM - 1) yr = YM - 1;
-    rq = *reinterpret_cast<const uint4*>(R + yr * ldo + xc);
-    if (gate_idx >= 0) {
-      const uint32_t bidx = (uint32_t)yr / (uint32_t)rows_per_batch;
-      eq = *reinterpret_cast<const uint4*>(e + ((int64_t)bidx * n_mod + gate_idx) * XN + xc);
-    }
+    return *reinterpret_cast<const uint4*>(R + yr * ldo + xc);
   };
-  auto emit = [&](int i, const uint4& rq, const uint4& eq) {
+  auto fetch_e = [&](int i) -> uint4 {
+    uint4 z = {};
+    if (EPI != WAN_EPI_GATE_RES || !col_full || gate_idx < 0) return z;
+    int64_t yr = yrow0 + i * 4;
+    if (yr > YM - 1) yr = YM - 1;
+    const uint32_t bidx = (uint32_t)yr / (uint32_t)rows_per_batch;
+    return *reinterpret_cast<const uint4*>(e + ((int64_t)bidx * n_mod + gate_idx) * XN + xc);
+  };
+  auto emit = [&](int i, const uint4 rq, const uint4 eq) {
     const int64_t yr = yrow0 + i * 4;
     const uint4 raw = *reinterpret_cast<const uint4*>(park + (i * 4 + prow) * EROW + pchunk * 16);
     if (yr >= YM) return;
@@ -309,15 +317,13 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
         if (xc + j < XN) optr[j] = (bf16_t)(w4[j >> 1] >> ((j & 1) * 16));
     }
   };
-  gate_fetch(0, r0, e0);
-  gate_fetch(1, r1, e1);
-  for (int i = 0; i < 30; i += 3) {
-    gate_fetch(i + 2, r2, e2); emit(i, r0, e0);
-    gate_fetch(i + 3, r0, e0); emit(i + 1, r1, e1);
-    gate_fetch(i + 4, r1, e1); emit(i + 2, r2, e2);
+#pragma unroll
+  for (int i = 0; i < GDEPTH; ++i) { rqa[i] = fetch_r(i); eqa[i] = fetch_e(i); }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {  // fully unrolled: the slot index is a constant, the arrays stay in registers
+    emit(i, rqa[i % GDEPTH], eqa[i % GDEPTH]);
+    if (i + GDEPTH < 32) { rqa[i % GDEPTH] = fetch_r(i + GDEPTH); eqa[i % GDEPTH] = fetch_e(i + GDEPTH); }
   }
-  emit(30, r0, e0);
-  emit(31, r1, e1);
 }
 
 // ---- activation quantisation (scaled_fp8.py:162-169) --------------------------------------------------------------------------
