@@ -183,7 +183,7 @@ def main():
     from wan2gp_amd import lib as L_
     from wan2gp_amd.model import WanModelHIP
     from wan2gp_amd.rope import get_rotary_pos_embed
-    from wan2gp_amd.schedulers import FlowUniPCMultistepScheduler, cfg_combine
+    from wan2gp_amd.schedulers import HipScheduler, cfg_combine
 
     cfg, (f, h, w), desc = WORKLOADS[args.workload]
     mcfg = {k: v for k, v in cfg.items()}
@@ -210,7 +210,7 @@ def main():
     ctx = (torch.randn(1, 512, 4096, device="cuda", generator=g) * 0.5).to(torch.bfloat16); ctx[:, 77:] = 0
     ctx_null = (torch.randn(1, 512, 4096, device="cuda", generator=g) * 0.5).to(torch.bfloat16); ctx_null[:, 8:] = 0
     freqs = get_rotary_pos_embed((f, h, w), device="cuda")
-    sched = FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    sched = HipScheduler("unipc", num_train_timesteps=1000)          # wan_sched_*: what generate() steps with on a GPU
     total_steps = args.steps + args.warmup
     sched.set_timesteps(max(VIDEO_STEPS, total_steps), device="cuda", shift=12.0)
     guide, switch_threshold = 4.0, 875

@@ -441,6 +441,32 @@ int wan_vae_unpack(const uint16_t* in, float* out, const float* sub, const float
 int wan_vae_to_video(const float* in, uint8_t* u8, float* f32, int T, int64_t hw, int Ttot, int t0,
                      void* stream);
 
+/* ---- the whole Wan2.1 VAE (SURVEY.md section 8b `wan_vae_encode`, `wan_vae_decode_u8`) ----------------------------------
+ * Encoder3d / Decoder3d / WanVAE_.encode / .decode (vae.py:318-662) as one call each: the layer graph and the causal
+ * feature-cache bookkeeping run inside the library (csrc/vae_graph.hip) on the op-level entry points above.
+ * Registration (host fp32 arrays, packed to fp16 on the way in; names are the checkpoint's, e.g. "decoder.conv1",
+ * "decoder.middle.0.residual.2", "decoder.upsamples.3.resample.1", "conv2"; gammas by their full key):
+ *   wan_vae_set_conv(v, name, weight[cout,cin,kt,kh,kw], cout, cin, kt, kh, kw, bias[cout] or NULL, cout_pad)
+ *       (Conv2d: kt = 1; cout_pad = 32 for "conv2", whose output feeds a 32-channel-padded tensor, else 0)
+ *   wan_vae_set_gamma(v, "decoder.head.0.gamma", g[C], C);   wan_vae_set_attention(v, "decoder.middle.1.", wqkv[3C,C], bqkv[3C], C)
+ * wan_vae_workspace_bytes(v, decode, t, h, w): decode = 1: latent [16,t,h,w]; decode = 0: video [3,t,h,w] (t = T frames,
+ * h, w = pixels).  Runs the graph in planning mode -- call it after the weights are registered.  -1 on error.
+ * wan_vae_decode: z [16,t,h,w] fp32 (normalised latents, WanVAE.decode's input) -> u8 [3,T,H,W] (decode_to_cpu_uint8's
+ * conversion, vae.py:18-20) and/or f32 [3,T,H,W] (unclamped), T = 4(t-1)+1, H = 8h, W = 8w; either may be NULL.
+ * wan_vae_encode: video [3,T,H,W] fp32 in [-1,1], T = 4k+1 -> mu [16,t,h,w] fp32, normalised (WanVAE.encode's output). */
+typedef struct wan_vae wan_vae;
+int wan_vae_create(wan_vae** out);
+void wan_vae_destroy(wan_vae* v);
+int wan_vae_set_conv(wan_vae* v, const char* name, const float* w, int cout, int cin, int kt, int kh, int kw, const float* bias,
+                     int cout_pad);
+int wan_vae_set_gamma(wan_vae* v, const char* name, const float* g, int C);
+int wan_vae_set_attention(wan_vae* v, const char* prefix, const float* wqkv, const float* bqkv, int C);
+int64_t wan_vae_workspace_bytes(wan_vae* v, int decode, int t, int h, int w);
+int wan_vae_decode(wan_vae* v, const float* z, int t, int h, int w, uint8_t* u8, float* f32, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+int wan_vae_encode(wan_vae* v, const float* video, int T, int H, int W, float* mu, void* workspace, int64_t workspace_bytes,
+                   void* stream);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------------------
  * wan_prof_enable(1): wan_dit_forward brackets each kernel class with HIP events recorded on the
  * launch stream; wan_prof_collect sums the elapsed ms per class (0 self-attention, 1 cross-

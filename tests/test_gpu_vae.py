@@ -208,6 +208,33 @@ def test_spatial_tiling_vs_reference_golden(vae):
     assert mu.shape == refe.shape and err <= 1e-2 * refe.abs().max().item() + 1e-3
 
 
+def test_native_graph_equals_the_host_graph_bit_for_bit(vae):
+    """wan_vae_decode / wan_vae_encode (csrc/vae_graph.hip) run the same kernels in the same order as the host graph of
+    wan2gp_amd/vae.py: every output byte must be equal; the planned workspace is what the run needs."""
+    assert vae.native is not None
+    gen = torch.Generator().manual_seed(33)
+    z = torch.randn(16, 4, 8, 12, generator=gen)
+    vid = torch.rand(3, 9, 64, 96, generator=gen) * 2 - 1
+    nat_u8, nat_f32 = vae._decode_frames(z, True, True)
+    nat_mu = vae.encode([vid])[0]
+    keep, vae.native = vae.native, None
+    try:
+        host_u8, host_f32 = vae._decode_frames(z, True, True)
+        host_mu = vae.encode([vid])[0]
+    finally:
+        vae.native = keep
+    assert torch.equal(nat_u8, host_u8) and torch.equal(nat_f32, host_f32) and torch.equal(nat_mu, host_mu)
+    need = vae.native.lib.wan_vae_workspace_bytes(vae.native._h, 1, 4, 8, 12)
+    assert 0 < need <= vae.native._ws.numel()
+    from wan2gp_amd.lib import WanHipError, check, ptr, stream_ptr
+    small = torch.empty(need // 2, dtype=torch.uint8, device="cuda")
+    out = torch.empty(3, 13, 64, 96, dtype=torch.uint8, device="cuda")
+    with pytest.raises(WanHipError, match="workspace too small"):
+        check(vae.native.lib.wan_vae_decode(vae.native._h, ptr(z.cuda()), 4, 8, 12, ptr(out), None, ptr(small), small.numel(), stream_ptr()), "decode")
+    with pytest.raises(WanHipError, match="4k \\+ 1"):
+        check(vae.native.lib.wan_vae_encode(vae.native._h, ptr(vid.cuda()), 8, 64, 96, ptr(out), ptr(small), small.numel(), stream_ptr()), "encode")
+
+
 def test_encode_decode_roundtrip_shapes(vae):
     """size-independent property at a larger size: chunked causal encode (1+4+4 frames) and frame-by-frame
     decode agree on shapes ( (T-1)/4+1 latents, (t-1)*4+1 frames ) and stay finite."""

@@ -222,6 +222,67 @@ def random_vae_state_dict(seed=0):
     return sd
 
 
+class _NativeGraph:
+    """`wan_vae_*` of the C ABI: the whole encode / decode as one library call each (csrc/vae_graph.hip runs the layer graph and the
+    cache bookkeeping on the op-level entry points `_VaeNet` uses).  Weights are handed over as host fp32 arrays and packed inside
+    the library; the workspace is a torch-owned byte tensor sized by `wan_vae_workspace_bytes`."""
+
+    def __init__(self, sd, dev):
+        from ctypes import byref, c_void_p
+        self.lib, self.dev, self._ws = _L.load(), dev, None
+        h = c_void_p()
+        check(self.lib.wan_vae_create(byref(h)), "wan_vae_create")
+        self._h = h
+        f32 = lambda t: t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        for k, v in sd.items():
+            if k.endswith(".weight") and v.dim() in (4, 5):
+                name = k[: -len(".weight")]
+                w = f32(v if v.dim() == 5 else v.unsqueeze(2))
+                b = sd.get(name + ".bias")
+                bb = None if b is None else f32(b)
+                cout, cin, kt, kh, kw = w.shape
+                check(self.lib.wan_vae_set_conv(h, name.encode(), ptr(w), cout, cin, kt, kh, kw, ptr(bb), _pad32(cout) if name == "conv2" else 0),
+                      f"wan_vae_set_conv({name})")
+            elif k.endswith("gamma"):
+                g = f32(v).reshape(-1)
+                check(self.lib.wan_vae_set_gamma(h, k.encode(), ptr(g), g.numel()), f"wan_vae_set_gamma({k})")
+        for side in ("encoder.middle.1.", "decoder.middle.1."):
+            if side + "to_qkv.weight" in sd:
+                C = sd[side + "proj.weight"].shape[0]
+                wq, bq = f32(sd[side + "to_qkv.weight"]).reshape(3 * C, C).contiguous(), f32(sd[side + "to_qkv.bias"])
+                check(self.lib.wan_vae_set_attention(h, side.encode(), ptr(wq), ptr(bq), C), "wan_vae_set_attention")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self.lib.wan_vae_destroy(h)
+
+    def _workspace(self, decode, t, h, w):
+        need = self.lib.wan_vae_workspace_bytes(self._h, 1 if decode else 0, t, h, w)
+        if need < 0:
+            raise _L.WanHipError("wan_vae_workspace_bytes: " + self.lib.wan_last_error().decode("utf-8", "replace"))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        return self._ws
+
+    def decode(self, z, want_u8, want_f32):
+        C, t, h, w = z.shape
+        ws = self._workspace(True, t, h, w)
+        T, H, W = (t - 1) * 4 + 1, h * 8, w * 8
+        u8 = torch.empty(3, T, H, W, dtype=torch.uint8, device=self.dev) if want_u8 else None
+        f32 = torch.empty(3, T, H, W, dtype=torch.float32, device=self.dev) if want_f32 else None
+        check(self.lib.wan_vae_decode(self._h, ptr(z), t, h, w, ptr(u8), ptr(f32), ptr(ws), ws.numel(), stream_ptr()), "wan_vae_decode")
+        return u8, f32
+
+    def encode(self, v):
+        C, T, H, W = v.shape
+        ws = self._workspace(False, T, H, W)
+        out = torch.empty(16, 1 + (T - 1) // 4, H // 8, W // 8, dtype=torch.float32, device=self.dev)
+        check(self.lib.wan_vae_encode(self._h, ptr(v), T, H, W, ptr(out), ptr(ws), ws.numel(), stream_ptr()), "wan_vae_encode")
+        return out
+
+
 def _cache_update(x, old):
     """cache_x bookkeeping (vae.py:256-263): last 2 frames of [old ; x]."""
     if x.shape[0] >= 2:
@@ -248,8 +309,11 @@ class WanVAEHIP:
             from safetensors.torch import load_file
             self.load_state_dict(load_file(vae_pth))
 
+    NATIVE_GRAPH = True                                    # run encode / decode through wan_vae_* (the Wan2.2 subclass keeps the host graph)
+
     def load_state_dict(self, sd):
         self.net = _VaeNet(sd, self.device)
+        self.native = _NativeGraph(sd, self.device) if self.NATIVE_GRAPH else None
         return self
 
     @staticmethod
@@ -343,6 +407,8 @@ class WanVAEHIP:
         lib = self.net.lib
         z = z.to(device=self.device, dtype=torch.float32).contiguous()          # [16, t, h, w]
         C, t, h, w = z.shape
+        if getattr(self, "native", None) is not None:
+            return self.native.decode(z, want_u8, want_f32)
         zp = torch.empty(t, h, w, 32, dtype=F16, device=self.device)
         inv_std = (1.0 / self.scale[1]).contiguous()                             # z / scale[1] + scale[0]
         check(lib.wan_vae_pack(ptr(z), ptr(zp), ptr(inv_std), ptr(self.scale[0].contiguous()), C, 32, t * h * w,
@@ -491,6 +557,9 @@ class WanVAEHIP:
         for v in videos:
             v = v.to(device=self.device, dtype=torch.float32).contiguous()       # [3, T, H, W]
             C, T, H, W = v.shape
+            if getattr(self, "native", None) is not None:
+                outs.append(self.native.encode(v))
+                continue
             vp = torch.empty(T, H, W, 32, dtype=F16, device=self.device)
             check(lib.wan_vae_pack(ptr(v), ptr(vp), None, None, C, 32, T * H * W, stream_ptr()), "wan_vae_pack")
             cache = [None] * self._n_cached("encoder.")

@@ -28,6 +28,7 @@ def _pad32(c):
 
 
 class Wan22VAEHIP(WanVAEHIP):
+    NATIVE_GRAPH = False          # this graph (patchify, AvgDown / DupUp shortcuts, 48 latent channels) stays on the host
     CFG = dict(dim=160, dec_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2, temperal_downsample=[False, True, True])
 
     def __init__(self, z_dim=48, c_dim=160, vae_pth=None, dim_mult=(1, 2, 4, 4), temperal_downsample=(False, True, True),
