@@ -70,3 +70,36 @@ def test_vace_with_magcache_vs_reference(model):
         assert c.skipped_steps == 4 and worst <= 2.5e-2
     finally:
         model.cache = None
+
+
+def test_per_frame_timesteps_with_magcache_vs_reference():
+    """ti2v timestep injection (t = [0, t]) with MagCache on the 48-channel model: decisions equal the reference's, outputs of
+    computed and skipped steps within the forward bar."""
+    from oracle.make_golden_vace_extra import inputs_ti2v
+    from wan2gp_amd.model import WanModelHIP
+    from wan2gp_amd.skipcache import SkipStepsCache, reset_for_generation
+    cfg = O.make_config("tiny_ti2v")
+    m = WanModelHIP(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers,
+                    in_dim=cfg.in_dim, out_dim=cfg.out_dim).load_state_dict(O.synth_weights(cfg, seed=SEED_W))
+    lats, ts, ctx, ctx_null = inputs_ti2v(cfg)
+    c = SkipStepsCache(cache_type="mag", multiplier=2.0, start_step=1, num_steps=STEPS, skipped_steps=0, previous_residual=None,
+                       previous_modulated_input=None)
+    c.update({"magcache_thresh": 0, "magcache_K": 2, "def_mag_ratios": list(MAG_RATIOS)})
+    reset_for_generation(c, 2)
+    m.cache = c
+    m.compute_magcache_threshold(c.start_step, ts, c.multiplier)
+    worst = 0.0
+    for i in range(STEPS):
+        tf = torch.stack([torch.zeros(()), ts[i]])
+        outs = m([lats[i].cuda(), lats[i].cuda()], t=tf, context=[ctx.cuda(), ctx_null.cuda()], real_step_no=i, current_step_no=i)
+        assert [int(s == 0) for s in c.accumulated_steps] == G["tfmag_flags"][i].tolist(), i
+        for k in range(2):
+            worst = max(worst, rel(outs[k], G[f"tfmag_{i}_{k}"]))
+    print(f"per-frame t + MagCache: skipped {c.skipped_steps}/{STEPS}, worst rel err {worst:.4f}")
+    assert c.skipped_steps == 4 and worst <= 2.5e-2
+    c2 = SkipStepsCache(cache_type="tea", multiplier=2.0, start_step=1, num_steps=STEPS, skipped_steps=0, previous_residual=None,
+                        previous_modulated_input=None)
+    c2.update({"coefficients": [0.04, 0.001], "rel_l1_thresh": 0.1, "accumulated_rel_l1_distance": 0})
+    m.cache = c2
+    with pytest.raises(NotImplementedError, match="TeaCache"):
+        m([lats[0].cuda()], t=torch.stack([torch.zeros(()), ts[0]]), context=[ctx.cuda()])

@@ -40,3 +40,21 @@ def test_vace_with_magcache_is_bit_exact():
                                             vace_context=[v0], vace_scale=[1.0])
         assert [int(f) for f in flags] == g["vmag_flags"][i].tolist(), i
         assert torch.equal(outs[0], torch.from_numpy(g[f"vmag_{i}_0"])) and torch.equal(outs[1], torch.from_numpy(g[f"vmag_{i}_1"])), i
+
+
+def test_per_frame_timesteps_with_magcache_is_bit_exact():
+    """ti2v timestep injection (t = [0, t]) together with MagCache on the 48-channel model."""
+    from oracle.make_golden_vace_extra import inputs_ti2v
+    g = dict(np.load(G))
+    cfg = O.make_config("tiny_ti2v")
+    W = O.synth_weights(cfg, seed=SEED_W)
+    lats, ts, ctx, ctx_null = inputs_ti2v(cfg)
+    c = SO.Cache(**new_cache("mag").__dict__)
+    c.previous_residual = [None] * 2
+    SO.magcache_threshold(c, c.start_step, ts, c.multiplier)
+    c.accumulated_err, c.accumulated_steps, c.accumulated_ratio, c.one_for_all = [0.0] * 2, [0] * 2, [1.0] * 2, False
+    for i in range(STEPS):
+        tf = torch.stack([torch.zeros(()), ts[i]])
+        outs, flags = SO.dit_forward_cached([lats[i], lats[i]], tf, [ctx, ctx_null], W, cfg, c, real_step_no=i)
+        assert [int(f) for f in flags] == g["tfmag_flags"][i].tolist(), i
+        assert torch.equal(outs[0], torch.from_numpy(g[f"tfmag_{i}_0"])) and torch.equal(outs[1], torch.from_numpy(g[f"tfmag_{i}_1"])), i

@@ -248,8 +248,10 @@ class WanModelHIP:
         FL = RP = None
         if cache is not None:
             # TeaCache / MagCache (model.py:1914-2064): host decision, residual bookkeeping inside the forward
-            if t_frames is not None:
-                raise NotImplementedError("per-frame timesteps together with a step-skipping cache")
+            if t_frames is not None and cache.cache_type == "tea":
+                # TeaCache decides on the time embedding of ONE timestep; the reference's handler switches it off for the model that
+                # uses per-frame timesteps (wan_handler.py: tea_cache is False for the 5B ti2v model, mag_cache stays on)
+                raise NotImplementedError("per-frame timesteps together with TeaCache (MagCache works)")
             from . import skipcache
             e = self.time_embedding(tval) if (cache.cache_type == "tea" and x_id == 0) else None
             flags = skipcache.decide(cache, S, x_id, real_step_no, e)
