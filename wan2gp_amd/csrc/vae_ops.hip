@@ -14,6 +14,8 @@
 // frame) fetch from a 16-byte zero page, frames t < 0 come from the layer's 2-frame cache.
 // Activations are [T, H, W, C] fp16 with C % 32 == 0 (3- and 16-channel tensors are zero padded
 // to 32 channels by the layout kernels / weight packer).
+#include <type_traits>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) _Float16 mfma_f16x8v;
@@ -42,6 +44,7 @@ struct ConvP {
   int tiles_y, tiles_x;
 };
 
+template <bool BIG, bool UPS>  // BIG: input chunks of 2^31 elements and more (64-bit gather offsets); UPS: 2x upsampled input
 __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * CSTAGE];
   const int tid = threadIdx.x;
@@ -58,10 +61,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
 
   const int HWo = p.Hout * p.Wout;
   const int64_t frame_in = (int64_t)p.Hin * p.Win * p.Cin;
-  const int Heff = p.ups ? p.Hin * 2 : p.Hin, Weff = p.ups ? p.Win * 2 : p.Win;
+  const int Heff = UPS ? p.Hin * 2 : p.Hin, Weff = UPS ? p.Win * 2 : p.Win;
   const int Kp = p.nk * 64;
 
-  // per-slot constants
+  // per-slot constants: the output pixel's position in INPUT coordinates before the tap offset is added (time / row / column),
+  // which of the K-step's two units the slot's chunk belongs to, and its channel offset inside the unit
   int s_to[4], s_ho[4], s_wo[4], s_usel[4], s_coff[4];
   const uint16_t* xsrc[4];
 #pragma unroll
@@ -73,9 +77,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
     if (pp > p.M - 1) pp = p.M - 1;
     const int to = (int)(pp / HWo);
     const int rem = (int)(pp - (int64_t)to * HWo);
-    s_to[i] = to;
     s_ho[i] = rem / p.Wout;
     s_wo[i] = rem - s_ho[i] * p.Wout;
+    s_to[i] = to * p.st_t - p.front;
+    s_ho[i] = s_ho[i] * p.st_s - p.pad_s;
+    s_wo[i] = s_wo[i] * p.st_s - p.pad_s;
     s_usel[i] = lch >> 2;
     s_coff[i] = (lch & 3) * 8;
     const int slab = row >> 6, jj = row & 63;
@@ -85,6 +91,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
     xsrc[i] = p.w + (int64_t)xr * Kp + lch * 8;
   }
 
+  using off_t = typename std::conditional<BIG, int64_t, int>::type;
+  const off_t fin = (off_t)frame_in;
+  off_t s_base[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s_base[i] = (off_t)s_to[i] * fin + ((off_t)s_ho[i] * p.Win + s_wo[i]) * p.Cin + s_coff[i];
+  const bool my_unit = s_usel[0] != 0;
   auto stage = [&](int s, int ks) {
     char* ybase = smem + s * 2 * CSTAGE;
     char* xbase = ybase + CSTAGE;
@@ -102,22 +114,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
       ukh[j] = t2 % p.KH;
       ukt[j] = t2 / p.KH;
     }
+    // frames t >= 0 live in x, frames -2 / -1 in the layer's cache: with the cache base shifted by two frames both are
+    // base + t * frame (32-bit element offsets unless the chunk has 2^31 elements or more)
+    const uint16_t* const cbase = p.cache + 2 * frame_in;
+    // the thread's unit of this K-step (one select per quantity, not one per piece: all four slots of a thread sit in the same
+    // unit -- chunk bit 2 after the swizzle is (tid >> 2 ^ tid >> 6) & 1 for every slot)
+    const bool j = my_unit;
+    const int kt = j ? ukt[1] : ukt[0], kh = j ? ukh[1] : ukh[0], kw = j ? ukw[1] : ukw[0];
+    const bool ok_u = j ? uok[1] : uok[0];
+    const off_t tapoff = (off_t)kt * fin + ((off_t)kh * p.Win + kw) * p.Cin + (j ? ucb[1] : ucb[0]) * 32;  // !ups: offset of the tap
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int woff = (i * 256 + wave * 64) * 16;
-      const int j = s_usel[i];
-      const int kt = j ? ukt[1] : ukt[0], kh = j ? ukh[1] : ukh[0], kw = j ? ukw[1] : ukw[0];
-      const int cb = j ? ucb[1] : ucb[0];
-      const bool ok_u = j ? uok[1] : uok[0];
-      const int ti = s_to[i] * p.st_t + kt - p.front;
-      int hi = s_ho[i] * p.st_s + kh - p.pad_s;
-      int wi = s_wo[i] * p.st_s + kw - p.pad_s;
-      const bool ok = ok_u && hi >= 0 && hi < Heff && wi >= 0 && wi < Weff && ti >= -p.ncache && ti < p.Tin;
-      if (p.ups) { hi >>= 1; wi >>= 1; }
-      const uint16_t* fb = (ti >= 0) ? p.x + (int64_t)ti * frame_in : p.cache + (int64_t)(2 + ti) * frame_in;
-      const uint16_t* src = ok ? fb + ((int64_t)hi * p.Win + wi) * p.Cin + cb * 32 + s_coff[i] : p.zero16;
-      glds16v(src, ybase + woff);
-      glds16v(xsrc[i] + ks * 64, xbase + woff);
+      const int ti = s_to[i] + kt;
+      int hi = s_ho[i] + kh;
+      int wi = s_wo[i] + kw;
+      // unsigned compares fold the two-sided range checks: 0 <= hi < Heff, 0 <= wi < Weff, -ncache <= ti < Tin
+      const bool ok = ok_u && (unsigned)hi < (unsigned)Heff && (unsigned)wi < (unsigned)Weff &&
+                      (unsigned)(ti + p.ncache) < (unsigned)(p.Tin + p.ncache);
+      off_t off;
+      if (UPS) {  // nearest-exact 2x upsample on the fly: source pixel (hi >> 1, wi >> 1)
+        hi >>= 1; wi >>= 1;
+        off = (off_t)ti * fin + ((off_t)hi * p.Win + wi) * p.Cin + (j ? ucb[1] : ucb[0]) * 32 + s_coff[i];
+      } else {      // linear in the tap: the slot's base (its output pixel at tap 0) + the tap's uniform offset
+        off = s_base[i] + tapoff;
+      }
+      const uint16_t* src = (ti >= 0 ? p.x : cbase) + off;
+      glds16v(ok ? src : p.zero16, ybase + woff);
+      glds16v(xsrc[i], xbase + woff);
+      xsrc[i] += 64;  // stages are issued for consecutive K-steps: the weight rows advance by one 64-wide k-tile
     }
   };
 
@@ -254,9 +279,14 @@ extern "C" int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const ui
   p.interleave = interleave;
   p.M = (int64_t)Tout * Hout * Wout;
   if (p.M == 0) return 0;
+  const bool big = (int64_t)(Tin + 2) * Hin * Win * Cin >= ((int64_t)1 << 31);
   p.tiles_y = (int)((p.M + CBM - 1) / CBM);
   p.tiles_x = (Cout + CBN - 1) / CBN;
-  hipLaunchKernelGGL(conv3d_f16_kernel, dim3((unsigned)(p.tiles_y * p.tiles_x)), dim3(256), 0, st, p);
+  const dim3 grid((unsigned)(p.tiles_y * p.tiles_x));
+  if (big && ups) hipLaunchKernelGGL((conv3d_f16_kernel<true, true>), grid, dim3(256), 0, st, p);
+  else if (big) hipLaunchKernelGGL((conv3d_f16_kernel<true, false>), grid, dim3(256), 0, st, p);
+  else if (ups) hipLaunchKernelGGL((conv3d_f16_kernel<false, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv3d_f16_kernel<false, false>), grid, dim3(256), 0, st, p);
   WAN_LAUNCH_CHECK();
   return 0;
 }
