@@ -1,0 +1,46 @@
+"""CPU: the host half of `wan_vae_*` (csrc/vae_graph.hip).  Registration packs weights in host memory and the workspace planner
+runs the layer graph without launching anything, so both work without a GPU: the planner must visit every registered layer
+(missing ones are named), respect the causal chunking (one latent frame / 1+4k video frames at a time: the peak does not grow
+with clip length beyond the chunk), and stay within what the host graph needed on the GPU (11.1 GB at 720p x 81f)."""
+import pytest
+import torch
+
+from oracle import vae_oracle as VO
+from wan2gp_amd import lib as L
+from wan2gp_amd.vae import _NativeGraph
+
+
+@pytest.fixture(scope="module")
+def graph():
+    return _NativeGraph(VO.synth_vae_weights(), "cpu")
+
+
+def plan(g, decode, t, h, w):
+    return g.lib.wan_vae_workspace_bytes(g._h, 1 if decode else 0, t, h, w)
+
+
+def test_decode_plan_is_bounded_by_the_chunk_not_the_clip(graph):
+    a, b, c = plan(graph, True, 2, 8, 8), plan(graph, True, 21, 8, 8), plan(graph, True, 41, 8, 8)
+    assert 0 < a <= b <= c
+    per_frame = (c - b) / 20                       # what an extra latent frame costs: its 32-channel latent rows (a few KB), not
+    assert per_frame <= 32 * 1024                  # a decoder chunk's activations (3 MB at this size)
+    big = plan(graph, True, 21, 90, 160)           # 720p x 81f
+    assert 6e9 < big < 13e9, big
+
+
+def test_encode_plan(graph):
+    a, b = plan(graph, False, 9, 64, 64), plan(graph, False, 17, 64, 64)
+    assert 0 < a <= b and (b - a) <= 3 * 8 * 64 * 64 * 32 * 2                          # grows with the packed input frames only (first-fit slack included)
+    assert 2e9 < plan(graph, False, 81, 720, 1280) < 13e9
+
+
+def test_missing_layers_are_named_and_duplicates_rejected():
+    sd = VO.synth_vae_weights()
+    sd.pop("decoder.upsamples.3.resample.1.weight")
+    g = _NativeGraph(sd, "cpu")
+    assert plan(g, True, 2, 8, 8) == -1
+    assert b"decoder.upsamples.3.resample.1" in g.lib.wan_last_error()
+    assert plan(g, False, 5, 64, 64) > 0           # the encoder is complete
+    w = torch.zeros(4, 4, 1, 1, 1)
+    assert g.lib.wan_vae_set_conv(g._h, b"conv1", L.ptr(w), 4, 4, 1, 1, 1, None, 0) != 0 and b"twice" in g.lib.wan_last_error()
+    assert plan(g, True, 0, 8, 8) == -1

@@ -36,15 +36,19 @@ const float VAE_STD[Z] = {2.8184f, 1.4541f, 2.3275f, 2.6558f, 1.2196f, 1.7708f, 
 
 inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
+// Packed parameters wait in host memory until the first encode / decode uploads them (ensure_uploaded): registration and the
+// workspace planner need no device.
 struct VConv {
   uint16_t* w = nullptr;
   uint16_t* b = nullptr;
+  std::vector<uint16_t> hw, hb;
   int cin = 0, cout = 0, kt = 1, kh = 1, kw = 1;
 };
 struct VAttn {
   int C = 0;
   uint16_t* wqkv = nullptr;
   uint16_t* bqkv = nullptr;
+  std::vector<uint16_t> hw, hb;
 };
 
 // first-fit region allocator over the caller's workspace (offsets, 256-byte granules); planning mode only tracks the peak
@@ -81,6 +85,8 @@ struct Ten {
 struct wan_vae {
   std::map<std::string, VConv> convs;
   std::map<std::string, uint16_t*> gamma;
+  std::map<std::string, std::vector<uint16_t>> gamma_h;
+  bool dirty = true;  // something registered since the last upload
   std::map<std::string, VAttn> attn;
   std::vector<void*> owned;
   float* mean_d = nullptr;  // scale[0]
@@ -186,13 +192,12 @@ struct Graph {
   }
   Ten norm(const Ten& x, const std::string& gname, bool silu = true) {
     Ten out = make(x.T, x.H, x.W, x.C);
-    auto it = v->gamma.find(gname);
-    if (it == v->gamma.end()) {
+    if (v->gamma_h.find(gname) == v->gamma_h.end()) {
       if (rc == 0) { wan_set_error("wan_vae: gamma '%s' was not registered (wan_vae_set_gamma)", gname.c_str()); rc = 1; }
       return out;
     }
     if (!plan && rc == 0) {
-      const int r = wan_vae_rmsnorm_silu(h(x), h(out), it->second, x.numel() / x.C, x.C, silu ? 1 : 0, stream);
+      const int r = wan_vae_rmsnorm_silu(h(x), h(out), v->gamma[gname], x.numel() / x.C, x.C, silu ? 1 : 0, stream);
       if (r) rc = r;
     }
     return out;
@@ -488,21 +493,49 @@ int upload(wan_vae* v, const std::vector<T>& host, T** dev) {
 }
 inline uint16_t to_half(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 
+int ensure_uploaded(wan_vae* v) {
+  if (!v->dirty) return 0;
+  if (!v->mean_d) {
+    std::vector<float> mean(VAE_MEAN, VAE_MEAN + Z), sd(Z), isd(Z);
+    for (int i = 0; i < Z; ++i) {
+      isd[i] = 1.0f / VAE_STD[i];  // scale[1] as the reference builds it (fp32 reciprocal, vae.py:956-958)
+      sd[i] = 1.0f / isd[i];       // decode multiplies by 1 / scale[1]: the reciprocal of the reciprocal, not std itself
+    }
+    if (int rc = upload(v, mean, &v->mean_d)) return rc;
+    if (int rc = upload(v, sd, &v->std_d)) return rc;
+    if (int rc = upload(v, isd, &v->istd_d)) return rc;
+  }
+  for (auto& kv : v->convs) {
+    VConv& c = kv.second;
+    if (c.w) continue;
+    if (int rc = upload(v, c.hw, &c.w)) return rc;
+    if (int rc = upload(v, c.hb, &c.b)) return rc;
+    std::vector<uint16_t>().swap(c.hw);
+    std::vector<uint16_t>().swap(c.hb);
+  }
+  for (auto& kv : v->gamma_h)
+    if (v->gamma.find(kv.first) == v->gamma.end()) {
+      uint16_t* d = nullptr;
+      if (int rc = upload(v, kv.second, &d)) return rc;
+      v->gamma[kv.first] = d;
+    }
+  for (auto& kv : v->attn) {
+    VAttn& a = kv.second;
+    if (a.wqkv) continue;
+    if (int rc = upload(v, a.hw, &a.wqkv)) return rc;
+    if (int rc = upload(v, a.hb, &a.bqkv)) return rc;
+    std::vector<uint16_t>().swap(a.hw);
+    std::vector<uint16_t>().swap(a.hb);
+  }
+  v->dirty = false;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" int wan_vae_create(wan_vae** out) {
   WAN_REQUIRE(out != nullptr, "wan_vae_create: null out");
-  wan_vae* v = new wan_vae();
-  std::vector<float> mean(VAE_MEAN, VAE_MEAN + Z), sd(VAE_STD, VAE_STD + Z), isd(Z);
-  for (int i = 0; i < Z; ++i) {
-    isd[i] = 1.0f / VAE_STD[i];  // scale[1] as the reference builds it (fp32 reciprocal, vae.py:956-958)
-    sd[i] = 1.0f / isd[i];       // decode multiplies by 1 / scale[1]: the reciprocal of the reciprocal, not std itself
-  }
-  int rc = upload(v, mean, &v->mean_d);
-  if (!rc) rc = upload(v, sd, &v->std_d);
-  if (!rc) rc = upload(v, isd, &v->istd_d);
-  if (rc) { delete v; return rc; }
-  *out = v;
+  *out = new wan_vae();
   return 0;
 }
 
@@ -530,12 +563,12 @@ extern "C" int wan_vae_set_conv(wan_vae* v, const char* name, const float* w, in
                 to_half(w[((((int64_t)o * cin + c) * kt + a) * kh + b) * kw + d]);
   if (bias)
     for (int o = 0; o < cout; ++o) bp[o] = to_half(bias[o]);
-  VConv c;
+  WAN_REQUIRE(v->convs.find(name) == v->convs.end(), "wan_vae_set_conv: '%s' registered twice", name);
+  VConv& c = v->convs[name];
   c.cin = cin_p; c.cout = cout_p; c.kt = kt; c.kh = kh; c.kw = kw;
-  int rc = upload(v, wp, &c.w);
-  if (!rc) rc = upload(v, bp, &c.b);
-  if (rc) return rc;
-  v->convs[name] = c;
+  c.hw.swap(wp);
+  c.hb.swap(bp);
+  v->dirty = true;
   return 0;
 }
 
@@ -543,9 +576,9 @@ extern "C" int wan_vae_set_gamma(wan_vae* v, const char* name, const float* g, i
   WAN_REQUIRE(v && name && g && C > 0, "wan_vae_set_gamma: bad arguments");
   std::vector<uint16_t> hp((size_t)C);
   for (int i = 0; i < C; ++i) hp[i] = to_half(g[i]);
-  uint16_t* d = nullptr;
-  if (int rc = upload(v, hp, &d)) return rc;
-  v->gamma[name] = d;
+  WAN_REQUIRE(v->gamma_h.find(name) == v->gamma_h.end(), "wan_vae_set_gamma: '%s' registered twice", name);
+  v->gamma_h[name].swap(hp);
+  v->dirty = true;
   return 0;
 }
 
@@ -555,12 +588,12 @@ extern "C" int wan_vae_set_attention(wan_vae* v, const char* prefix, const float
   std::vector<uint16_t> wp((size_t)3 * C * C), bp((size_t)3 * C);
   for (size_t i = 0; i < wp.size(); ++i) wp[i] = to_half(wqkv[i]);
   for (size_t i = 0; i < bp.size(); ++i) bp[i] = to_half(bqkv[i]);
-  VAttn a;
+  WAN_REQUIRE(v->attn.find(prefix) == v->attn.end(), "wan_vae_set_attention: '%s' registered twice", prefix);
+  VAttn& a = v->attn[prefix];
   a.C = C;
-  int rc = upload(v, wp, &a.wqkv);
-  if (!rc) rc = upload(v, bp, &a.bqkv);
-  if (rc) return rc;
-  v->attn[prefix] = a;
+  a.hw.swap(wp);
+  a.hb.swap(bp);
+  v->dirty = true;
   return 0;
 }
 
@@ -576,6 +609,7 @@ extern "C" int wan_vae_decode(wan_vae* v, const float* z, int t, int h, int w, u
                               int64_t workspace_bytes, void* stream) {
   WAN_REQUIRE(v && z && (u8 || f32) && workspace, "wan_vae_decode: null argument");
   WAN_REQUIRE(t >= 1 && h >= 1 && w >= 1, "wan_vae_decode: bad latent shape [16,%d,%d,%d]", t, h, w);
+  if (int rc = ensure_uploaded(v)) return rc;
   return run_decode(v, z, t, h, w, u8, f32, workspace, workspace_bytes, stream, false, nullptr);
 }
 
@@ -584,5 +618,6 @@ extern "C" int wan_vae_encode(wan_vae* v, const float* video, int T, int H, int 
   WAN_REQUIRE(v && video && mu && workspace, "wan_vae_encode: null argument");
   WAN_REQUIRE(T >= 1 && (T - 1) % 4 == 0 && H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8,
               "wan_vae_encode: video [3,%d,%d,%d] needs T = 4k + 1 and H, W multiples of 8", T, H, W);
+  if (int rc = ensure_uploaded(v)) return rc;
   return run_encode(v, video, T, H, W, mu, workspace, workspace_bytes, stream, false, nullptr);
 }
