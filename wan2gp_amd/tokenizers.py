@@ -37,57 +37,64 @@ def _fix_text_subset(text):
     return unicodedata.normalize("NFC", text)
 
 
-def basic_clean(text):
-    text = _ftfy.fix_text(text) if _ftfy is not None else _fix_text_subset(text)
-    text = html.unescape(html.unescape(text))
-    return text.strip()
+_WS = re.compile(r"\s+")
+_NO_PUNCT = str.maketrans("", "", string.punctuation)
 
 
-def whitespace_clean(text):
-    text = re.sub(r"\s+", " ", text)
-    return text.strip()
+def _unescape_and_fix(prompt):
+    """Mojibake / entity repair: ftfy when present, otherwise its prompt-relevant subset; HTML entities decoded twice."""
+    repaired = _ftfy.fix_text(prompt) if _ftfy is not None else _fix_text_subset(prompt)
+    for _ in range(2):
+        repaired = html.unescape(repaired)
+    return repaired.strip()
 
 
-def canonicalize(text, keep_punctuation_exact_string=None):
-    text = text.replace("_", " ")
-    if keep_punctuation_exact_string:
-        text = keep_punctuation_exact_string.join(part.translate(str.maketrans("", "", string.punctuation))
-                                                  for part in text.split(keep_punctuation_exact_string))
-    else:
-        text = text.translate(str.maketrans("", "", string.punctuation))
-    text = text.lower()
-    text = re.sub(r"\s+", " ", text)
-    return text.strip()
+def _squeeze(prompt):
+    return _WS.sub(" ", prompt).strip()
+
+
+def _canonical(prompt, keep=None):
+    """Underscores to spaces, punctuation dropped (except the exact string `keep`), lower case, single spaces."""
+    prompt = prompt.replace("_", " ")
+    pieces = prompt.split(keep) if keep else [prompt]
+    prompt = (keep or "").join(piece.translate(_NO_PUNCT) for piece in pieces)
+    return _squeeze(prompt.lower())
+
+
+# cleaning mode -> function of the raw prompt (the reference's three `clean` settings)
+_CLEANERS = {
+    None: lambda prompt: prompt,
+    "whitespace": lambda prompt: _squeeze(_unescape_and_fix(prompt)),
+    "lower": lambda prompt: _squeeze(_unescape_and_fix(prompt)).lower(),
+    "canonicalize": lambda prompt: _canonical(_unescape_and_fix(prompt)),
+}
+basic_clean, whitespace_clean, canonicalize = _unescape_and_fix, _squeeze, _canonical      # the reference module's function names
 
 
 class HuggingfaceTokenizer:
+    """Wraps `transformers.AutoTokenizer.from_pretrained(name)`: prompts are cleaned by mode, then padded / truncated to `seq_len`."""
+
     def __init__(self, name, seq_len=None, clean=None, **kwargs):
-        assert clean in (None, "whitespace", "lower", "canonicalize")
-        self.name, self.seq_len, self.clean = name, seq_len, clean
+        if clean not in _CLEANERS:
+            raise AssertionError(f"clean must be one of {sorted(k for k in _CLEANERS if k)} or None, got {clean!r}")
         from transformers import AutoTokenizer
+        self.name, self.seq_len, self.clean = name, seq_len, clean
         self.tokenizer = AutoTokenizer.from_pretrained(name, **kwargs)
         self.vocab_size = self.tokenizer.vocab_size
 
-    def __call__(self, sequence, **kwargs):
-        return_mask = kwargs.pop("return_mask", False)
-        _kwargs = {"return_tensors": "pt"}
+    def _encode_kwargs(self, overrides):
+        kw = {"return_tensors": "pt"}
         if self.seq_len is not None:
-            _kwargs.update({"padding": "max_length", "truncation": True, "max_length": self.seq_len})
-        _kwargs.update(**kwargs)
-        if isinstance(sequence, str):
-            sequence = [sequence]
-        if self.clean:
-            sequence = [self._clean(u) for u in sequence]
-        ids = self.tokenizer(sequence, **_kwargs)
-        if return_mask:
-            return ids.input_ids, ids.attention_mask
-        return ids.input_ids
+            kw.update(padding="max_length", truncation=True, max_length=self.seq_len)
+        kw.update(overrides)
+        return kw
+
+    def __call__(self, sequence, **kwargs):
+        want_mask = kwargs.pop("return_mask", False)
+        prompts = [sequence] if isinstance(sequence, str) else list(sequence)
+        cleaner = _CLEANERS[self.clean]
+        enc = self.tokenizer([cleaner(p) for p in prompts], **self._encode_kwargs(kwargs))
+        return (enc.input_ids, enc.attention_mask) if want_mask else enc.input_ids
 
     def _clean(self, text):
-        if self.clean == "whitespace":
-            text = whitespace_clean(basic_clean(text))
-        elif self.clean == "lower":
-            text = whitespace_clean(basic_clean(text)).lower()
-        elif self.clean == "canonicalize":
-            text = canonicalize(basic_clean(text))
-        return text
+        return _CLEANERS[self.clean](text)
