@@ -331,6 +331,21 @@ typedef struct {
   void* user;
 } wan_sp_info;
 
+/* A library-owned RCCL communicator for those hooks (SURVEY.md section 8b `wan_sp_init(rank, nranks, ncclUniqueId)`): one
+ * communicator per process / GPU, a side HIP stream and one completion event per gather slot.  Rank 0 makes the 128-byte id
+ * (wan_sp_unique_id), the host runtime hands it to every rank, every rank calls wan_sp_init (collective; binds to the current
+ * device).  wan_sp_gather_begin / wan_sp_gather_wait have the hook signatures: set wan_sp_info.gather_begin / gather_wait to
+ * them and `user` to the wan_sp* and wan_dit_forward drives its all-gathers without leaving the library.  RCCL is bound at run
+ * time (dlopen), sharing the instance the process already carries (PyTorch's).  wan_sp_all_gather: the same collective ordered
+ * on `stream` on both sides. */
+typedef struct wan_sp wan_sp;
+int wan_sp_unique_id(void* id128);
+int wan_sp_init(wan_sp** out, int rank, int nranks, const void* id128);
+void wan_sp_destroy(wan_sp* sp);
+int wan_sp_gather_begin(void* sp, int which, const void* send, void* recv, int64_t bytes, void* stream);
+int wan_sp_gather_wait(void* sp, int which, void* stream);
+int wan_sp_all_gather(wan_sp* sp, const void* send, void* recv, int64_t bytes, void* stream);
+
 /* WanModel.forward for the t2v / i2v2_2 path (model.py:1485-2098): S streams (the joint CFG
  * pass, any2video.py:1626-1634), each x_s [1, 16, F, H, W] fp32, t scalar, context_s
  * [1, 512, text_dim] bf16, y optional [in_dim-out_dim, F, H, W] fp32 (x streams are [1, out_dim, F, H, W]), cos/sin [L,128] fp32.

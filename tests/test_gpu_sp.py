@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", native=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     import torch.distributed as dist
@@ -40,7 +40,7 @@ def _worker(rank, world, port, q, backend="gloo"):
         lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w, seed=9)
         t = torch.tensor([412])
         ref = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])
-        m.sp = SequenceParallel(rank, world)
+        m.sp = SequenceParallel(rank, world, native=native)
         got = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])
         for g, r in zip(got, ref):
             assert g.shape == r.shape
@@ -132,3 +132,60 @@ def test_gather_callbacks_over_rccl_world_1():
     res = q.get(timeout=600)
     p.join(timeout=60)
     assert res == "ok", res
+
+
+def _native_world1_worker(q):
+    try:
+        torch.cuda.set_device(0)
+        from wan2gp_amd.lib import stream_ptr
+        from wan2gp_amd.sp import SequenceParallel
+        sp = SequenceParallel(0, 1, native=True)                       # wan_sp_unique_id + wan_sp_init: a real RCCL communicator
+        info = sp.make_info(192)
+        assert info.world == 1 and info.user
+        n = 1 << 20
+        g = torch.Generator(device="cuda").manual_seed(2)
+        send = [torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda", generator=g) for _ in range(2)]
+        recv = [torch.zeros(n, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        for which in (0, 1):                                           # the C hooks, exactly as wan_dit_forward calls them
+            assert info.gather_begin(info.user, which, send[which].data_ptr(), recv[which].data_ptr(), n, stream_ptr().value) == 0
+        assert info.gather_begin(info.user, 0, send[0].data_ptr(), recv[0].data_ptr(), n, stream_ptr().value) != 0   # slot busy
+        busy = torch.randn(2048, 2048, device="cuda") @ torch.randn(2048, 2048, device="cuda")
+        for which in (0, 1):
+            assert info.gather_wait(info.user, which, stream_ptr().value) == 0
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(send, recv)) and torch.isfinite(busy).all()
+        x = torch.randn(24, 64, device="cuda")
+        assert torch.equal(sp.all_gather(x), x)
+        del sp
+        q.put("ok")
+    except Exception:
+        import traceback
+        q.put(traceback.format_exc())
+
+
+def test_native_rccl_communicator_world_1():
+    """`wan_sp_init` / `wan_sp_gather_begin` / `_wait` / `wan_sp_all_gather` (csrc/sp_rccl.hip): the library's own RCCL
+    communicator, side stream and events, driven through the very function pointers `wan_dit_forward` receives in wan_sp_info.
+    One rank is what a single-GPU box can host; the 2-GPU form below runs the sequence-parallel forward on it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_native_world1_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=60)
+    assert res == "ok", res
+
+
+def test_sp_forward_native_rccl_when_two_gpus_are_present():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "nccl", True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -111,6 +111,12 @@ SIGNATURES = {
     "wan_gemv_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wan_lincomb": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_float), c_int64, c_void_p]),
     "wan_cfg_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    "wan_sp_unique_id": (c_int, [c_void_p]),
+    "wan_sp_init": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p]),
+    "wan_sp_destroy": (None, [c_void_p]),
+    "wan_sp_gather_begin": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_sp_gather_wait": (c_int, [c_void_p, c_int, c_void_p]),
+    "wan_sp_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_sched_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
     "wan_sched_destroy": (None, [c_void_p]),
     "wan_sched_set_timesteps": (c_int, [c_void_p, c_int, c_double, POINTER(c_double), POINTER(c_float)]),

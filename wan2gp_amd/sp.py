@@ -11,6 +11,11 @@ rank runs the identical scheduler arithmetic, so there is no broadcast either; t
 exchange is the all-gather of the head's token-major output once per forward.
 
 Host logic here is device-agnostic (`gloo` on CPU in tests, `nccl` == RCCL on GPUs).
+
+Two ways to run the collectives: through `torch.distributed` (default: host callbacks `gather_begin` / `gather_wait`, torch owns
+the communicator and its side stream), or `native=True`: the library's own RCCL communicator (`wan_sp_init`, csrc/sp_rccl.hip) --
+the gather hooks are then C functions and the forward never re-enters Python; torch.distributed is only used once, to hand
+rank 0's 128-byte communicator id to the other ranks.
 """
 import ctypes
 from ctypes import c_void_p
@@ -30,13 +35,36 @@ def shard_range(L: int, rank: int, world: int):
 
 
 class SequenceParallel:
-    def __init__(self, rank: int, world: int, group=None):
+    def __init__(self, rank: int, world: int, group=None, native: bool = False):
         self.rank, self.world, self.group = rank, world, group
         self._ws = None
         self._cb = None
         self._cbw = None
         self._info = None
         self._pending = {}          # which -> async Work handle of the in-flight all-gather
+        self._native = None         # wan_sp* (library-owned RCCL communicator)
+        if native:
+            self._init_native()
+
+    def _init_native(self):
+        from . import lib as _L
+        lib = _L.load()
+        dev = "cuda" if (not dist.is_initialized() or dist.get_backend(self.group) != "gloo") else "cpu"
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            _L.check(lib.wan_sp_unique_id(c_void_p(ident.data_ptr())), "wan_sp_unique_id")
+        if self.world > 1:
+            t = ident.to(dev)
+            dist.broadcast(t, src=0, group=self.group)
+            ident = t.cpu()
+        h = c_void_p()
+        _L.check(lib.wan_sp_init(ctypes.byref(h), self.rank, self.world, c_void_p(ident.data_ptr())), "wan_sp_init")
+        self._native, self._lib = h, lib
+
+    def __del__(self):
+        h, self._native = getattr(self, "_native", None), None
+        if h:
+            self._lib.wan_sp_destroy(h)
 
     # ---- collectives (torch.distributed; backend nccl == RCCL on ROCm) ---------------------------
     def _all_gather_into(self, out: torch.Tensor, send: torch.Tensor):
@@ -54,6 +82,12 @@ class SequenceParallel:
     def all_gather(self, send: torch.Tensor) -> torch.Tensor:
         """[n, ...] per rank -> [world*n, ...] in rank order."""
         out = torch.empty((self.world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        if self._native is not None:
+            from . import lib as _L
+            send = send.contiguous()
+            _L.check(self._lib.wan_sp_all_gather(self._native, c_void_p(send.data_ptr()), c_void_p(out.data_ptr()),
+                                                 send.numel() * send.element_size(), _L.stream_ptr()), "wan_sp_all_gather")
+            return out
         self._all_gather_into(out, send)
         return out
 
@@ -95,6 +129,12 @@ class SequenceParallel:
 
     def make_info(self, L: int) -> SpInfo:
         tok0, n = shard_range(L, self.rank, self.world)
+        if self._native is not None:                          # the library's own hooks: no Python in the block loop
+            if self._cb is None:
+                self._cb = ctypes.cast(self._lib.wan_sp_gather_begin, GATHER_FN)
+                self._cbw = ctypes.cast(self._lib.wan_sp_gather_wait, GATHER_WAIT_FN)
+            self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, self._native)
+            return self._info
         if self._cb is None:
             self._cb = GATHER_FN(self._gather_begin_cb)      # keep the ctypes thunks alive
             self._cbw = GATHER_WAIT_FN(self._gather_wait_cb)
