@@ -22,7 +22,7 @@ void wan_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wan_last_error(void) { return g_err; }
-extern "C" int wan_version(void) { return 2; }
+extern "C" int wan_version(void) { return 3; }
 extern "C" int wan_device_cus(void) {
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
