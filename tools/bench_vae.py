@@ -3,11 +3,14 @@
 import argparse, json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:      # A/B against another build of the library (file name under wan2gp_amd/)
+    from wan2gp_amd import lib as _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), sys.argv[sys.argv.index("--lib") + 1])
 from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=81); ap.add_argument("--h", type=int, default=720); ap.add_argument("--w", type=int, default=1280)
-ap.add_argument("--encode", action="store_true")
+ap.add_argument("--encode", action="store_true"); ap.add_argument("--lib", default=None)
 a = ap.parse_args()
 vae = WanVAEHIP(state_dict=random_vae_state_dict())
 t = (a.frames - 1) // 4 + 1
