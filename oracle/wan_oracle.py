@@ -318,15 +318,41 @@ def self_attention(x, W, p, cfg: WanConfig, cos, sin, exact):
     return _linear(o.flatten(2), W, p + "o")
 
 
-def cross_attention(x, ctx, W, p, cfg: WanConfig, exact):
+def nag_combine(x_pos, x_neg, nag_scale, nag_tau, nag_alpha):
+    """Normalized attention guidance on the two cross-attention results (text_cross_attention, model.py:276-293), one torch
+    statement per reference statement on the tensors' own dtype (bf16 in the real plan: every in-place op rounds):
+    guidance = x_neg (1 - s) + s x_pos; rows whose L1 norm exceeds tau times the positive row's are scaled back to tau;
+    result = alpha guidance + (1 - alpha) x_pos."""
+    x_pos, x_neg = x_pos.clone(), x_neg.clone()
+    x_neg.mul_(1 - nag_scale)                                                  # :278
+    x_neg.add_(x_pos, alpha=nag_scale)                                         # :279
+    x_guidance = x_neg
+    norm_positive = torch.norm(x_pos, p=1, dim=-1, keepdim=True)               # :282
+    norm_guidance = torch.norm(x_guidance, p=1, dim=-1, keepdim=True)          # :283
+    scale = torch.nan_to_num(norm_guidance / norm_positive, 10)                # :284-285
+    factor = 1 / (norm_guidance + 1e-7) * norm_positive * nag_tau              # :286
+    x_guidance = torch.where(scale > nag_tau, x_guidance * factor, x_guidance)  # :287
+    x_pos.mul_(1 - nag_alpha)                                                  # :289
+    x_guidance.mul_(nag_alpha)                                                 # :290
+    x_guidance.add_(x_pos)                                                     # :291
+    return x_guidance
+
+
+def cross_attention(x, ctx, W, p, cfg: WanConfig, exact, nag=None):
+    """nag = (nag_scale, nag_tau, nag_alpha) = offload.shared_state["_nag_*"] (any2video.py:607): with nag_scale > 1 a context
+    of batch 2 is (positive ; negative) prompt and the two attention results go through nag_combine (model.py:260-292)."""
     b, n, d = x.shape[0], cfg.num_heads, cfg.head_dim
     q = rms_norm(_linear(x, W, p + "q"), W[p + "norm_q.weight"], cfg.eps).view(b, -1, n, d)
     ctx_img = None
     if cfg.model_type == "i2v":                                # WanI2VCrossAttention.forward (model.py:466-499)
         ctx_img, ctx = ctx[:, :CLIP_TOKENS], ctx[:, CLIP_TOKENS:]
+        ctx_img = ctx_img[:b]                                  # :476-477
     k = rms_norm(_linear(ctx, W, p + "k"), W[p + "norm_k.weight"], cfg.eps).view(ctx.shape[0], -1, n, d)
     v = _linear(ctx, W, p + "v").view(ctx.shape[0], -1, n, d)
-    o = attention(q, k, v, exact).flatten(2, 3)
+    if nag is not None and nag[0] > 1 and k.shape[0] != 1:     # :260 `nag_scale <= 1 or len(k)==1` is the plain path
+        o = nag_combine(attention(q, k[:1], v[:1], exact).flatten(2, 3), attention(q, k[1:], v[1:], exact).flatten(2, 3), *nag)
+    else:
+        o = attention(q, k, v, exact).flatten(2, 3)
     if ctx_img is not None:
         k_img = rms_norm(_linear(ctx_img, W, p + "k_img"), W[p + "norm_k_img.weight"], cfg.eps).view(ctx_img.shape[0], -1, n, d)
         v_img = _linear(ctx_img, W, p + "v_img").view(ctx_img.shape[0], -1, n, d)
@@ -343,7 +369,7 @@ def img_emb(clip_fea, W):
     return F.layer_norm(x, (x.shape[-1],), W["img_emb.proj.4.weight"], W["img_emb.proj.4.bias"], 1e-5)
 
 
-def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = False):
+def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = False, nag=None):
     """WanAttentionBlock.forward, t2v path (model.py:631-711).  x [B,L,dim] in the
     residual dtype, e0 [1,6,dim] (latent_frames = e.shape[0] = 1, so the reshape at
     :635/:658/:688 is a no-op broadcast).  i: block index, or a key prefix (VACE context blocks)."""
@@ -357,7 +383,7 @@ def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = Fals
     y = self_attention(x_mod, W, p + "self_attn.", cfg, cos, sin, exact)   # :653
     x = un(torch.addcmul(rs(x), rs(y), e[2]))                  # :658-660
     y = layer_norm(x, cfg.eps, W[p + "norm3.weight"], W[p + "norm3.bias"])  # :664
-    x = x + cross_attention(y, ctx, W, p + "cross_attn.", cfg, exact)       # :668
+    x = x + cross_attention(y, ctx, W, p + "cross_attn.", cfg, exact, nag)  # :668
     y = rs(layer_norm(x, cfg.eps))                             # :686-688
     y = y * (1 + e[4]); y = un(y + e[3])                       # :689-691
     shp = y.shape                                              # :698-707 three row chunks
@@ -369,13 +395,13 @@ def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = Fals
     return x
 
 
-def vace_block_forward(c, x, e0, ctx, cos, sin, W, n: int, cfg: WanConfig, exact: bool = False):
+def vace_block_forward(c, x, e0, ctx, cos, sin, W, n: int, cfg: WanConfig, exact: bool = False, nag=None):
     """VaceWanAttentionBlock.forward (model.py:816-828) as called from the main block (:617-629): returns (c, c_skip)."""
     p = f"vace_blocks.{n}."
     if n == 0:
         c = _linear(c, W, p + "before_proj")
         c = c + x                                            # c += x
-    c = block_forward(c, e0, ctx, cos, sin, W, p, cfg, exact)
+    c = block_forward(c, e0, ctx, cos, sin, W, p, cfg, exact, nag)
     return c, _linear(c, W, p + "after_proj")
 
 
@@ -392,7 +418,7 @@ def vace_hints(vace_context, vace_scale, W, cfg: WanConfig, n_streams: int):
     return [[c.clone() for c in emb] for _ in range(n_streams)], scales
 
 
-def block_with_hints(x, hints, scales, e0, ctx, cos, sin, W, i: int, cfg: WanConfig, exact: bool = False):
+def block_with_hints(x, hints, scales, e0, ctx, cos, sin, W, i: int, cfg: WanConfig, exact: bool = False, nag=None):
     """One main block with its VACE context block(s) (model.py:617-629 in front of the block, :713-719 behind it): every context
     with a non-zero scale runs the context block on its own hint stream (in place in `hints`); the projected hints are added to
     x in context order, each add rounding to the stream's dtype."""
@@ -403,9 +429,9 @@ def block_with_hints(x, hints, scales, e0, ctx, cos, sin, W, i: int, cfg: WanCon
             if sc == 0:
                 skips.append(None)
                 continue
-            hints[k], sk = vace_block_forward(hints[k], x, e0, ctx, cos, sin, W, n, cfg, exact)
+            hints[k], sk = vace_block_forward(hints[k], x, e0, ctx, cos, sin, W, n, cfg, exact, nag)
             skips.append(sk)
-    x = block_forward(x, e0, ctx, cos, sin, W, i, cfg, exact)
+    x = block_forward(x, e0, ctx, cos, sin, W, i, cfg, exact, nag)
     for sk, sc in zip(skips, scales or []):
         if sk is not None:
             x = x + sk if sc == 1 else torch.add(x, sk, alpha=sc)
@@ -449,8 +475,9 @@ def unpatchify(x, grid, cfg: WanConfig):
 def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[torch.Tensor],
                 W, cfg: WanConfig, y: Optional[torch.Tensor] = None, freqs=None,
                 dtype=torch.bfloat16, exact: bool = False, return_hidden: bool = False, clip_fea: Optional[torch.Tensor] = None,
-                vace_context=None, vace_scale=1.0, probe=None):
-    """x_list: S tensors [B,16,F,H,W] fp32; t [1]; context_list: S tensors [B,512,4096].
+                vace_context=None, vace_scale=1.0, probe=None, nag=None):
+    """x_list: S tensors [B,16,F,H,W] fp32; t [1]; context_list: S tensors [B,512,4096] ([2,512,4096] = positive ; negative
+    prompt for a stream under normalized attention guidance, nag = (scale, tau, alpha), any2video.py:607-608).
     Returns S fp32 tensors [B,16,F,H,W] (model.py:2093-2097).
     probe(i, s, hidden): called with stream s's token stream after block i (error-growth tables)."""
     hs = []
@@ -468,11 +495,11 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
     ctxs = [text_embed(c.to(dtype), W) for c in context_list]
     if clip_fea is not None:                                # model.py:1858-1869: [clip tokens ; text tokens]
         cc = img_emb(clip_fea.to(dtype), W)
-        ctxs = [torch.cat([cc, c], dim=1) for c in ctxs]
+        ctxs = [torch.cat([cc.repeat(len(c), 1, 1) if len(c) != len(cc) else cc, c], dim=1) for c in ctxs]   # :1864-1868
     hints, scales = vace_hints(vace_context, vace_scale, W, cfg, len(hs))
     for i in range(cfg.num_layers):                         # model.py:1993-2036
         for s in range(len(hs)):
-            hs[s] = block_with_hints(hs[s], None if hints is None else hints[s], scales, e0, ctxs[s], cos, sin, W, i, cfg, exact)
+            hs[s] = block_with_hints(hs[s], None if hints is None else hints[s], scales, e0, ctxs[s], cos, sin, W, i, cfg, exact, nag)
             if probe is not None:
                 probe(i, s, hs[s])
     if return_hidden:
