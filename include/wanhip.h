@@ -81,6 +81,14 @@ int wan_gated_residual(wan_bf16* x, const wan_bf16* y, const wan_bf16* mod, cons
                        int n_mod, int gate_idx, int64_t rows, int64_t rows_per_batch, int d,
                        void* stream);
 
+/* Normalized attention guidance on the two results of the text cross-attention (text_cross_attention, model.py:276-293; switched
+ * on by WanAny2V.generate(NAG_scale > 1), any2video.py:607-608): x_pos = attention against the positive prompt, x_neg against
+ * the negative one, both [rows, d] bf16.  g = bf16(bf16(x_neg (1 - s)) + s x_pos); rows with |g|_1 / |x_pos|_1 > tau are
+ * scaled by bf16(tau |x_pos|_1 / |g|_1); out = bf16(bf16(alpha g) + bf16((1 - alpha) x_pos)) -- one bf16 rounding per
+ * reference statement.  out may alias x_pos or x_neg. */
+int wan_nag_combine(const wan_bf16* x_pos, const wan_bf16* x_neg, wan_bf16* out, int64_t rows, int d, float nag_scale,
+                    float nag_tau, float nag_alpha, void* stream);
+
 /* ---- GEMM ------------------------------------------------------------------------------ */
 enum {
   WAN_EPI_NONE = 0,       /* C = bf16(A W^T + bias)                                  nn.Linear     */
@@ -388,6 +396,12 @@ typedef struct {
   int n_vace;
   const float* const* vace_contexts;
   const float* vace_scales;
+  /* normalized attention guidance (any2video.py:607-608; text_cross_attention, model.py:245-293): nag_scale > 1 and
+   * context_batches[s] == 2 -> context[s] is [2, text_len, text_dim] = (positive ; negative) prompt, stream s's text
+   * cross-attention runs against both and combines them with wan_nag_combine (in every block, VACE context blocks included).
+   * context_batches: HOST array of S ints (1 or 2), NULL = every context has batch 1; a 2 needs nag_scale > 1. */
+  float nag_scale, nag_tau, nag_alpha;
+  const int* context_batches;
 } wan_dit_args;
 int wan_dit_forward_ex(wan_ctx* ctx, const wan_dit_args* args, void* stream);
 /* How many VACE contexts one forward may mix (default 1): sizes the hint-stream region of the workspace

@@ -300,3 +300,28 @@ def test_ti2v_timestep_injection_passes_a_per_frame_t_and_pins_the_source_latent
     assert (out["latents"][:, :, :1] == 7.0).all()
     with pytest.raises(ValueError, match="ti2v"):
         run(WanAny2VHIP(FakeDiT("A"), vae=Vae(), device="cpu"), input_video=torch.zeros(3, 1, 64, 64))
+
+
+def test_nag_stacks_the_negative_prompt_under_the_positive_one_and_arms_both_experts():
+    """any2video.py:607-608: NAG_scale > 1 -> context = cat([context, context_null]) and the three parameters reach the model
+    (offload.shared_state there, model.nag here); with CFG on top the uncond stream keeps its plain batch-1 context."""
+    class NagDiT(FakeDiT):
+        nag = None
+
+        def __call__(self, x, t, context, **kw):
+            self.ctx_shapes = [tuple(c.shape) for c in context]
+            self.ctx_rows = [c[:, 0, 0].float().tolist() for c in context]
+            return super().__call__(x, t, context, **kw)
+    a, b = NagDiT("A"), NagDiT("B")
+    pos = torch.full((1, 512, 4096), 1.0, dtype=torch.bfloat16)
+    neg = torch.full((1, 512, 4096), -1.0, dtype=torch.bfloat16)
+    run(WanAny2VHIP(a, b, device="cpu"), context=pos, context_null=neg, guide_scale=1.0, NAG_scale=11, NAG_tau=2.5, NAG_alpha=0.25,
+        guide_phases=2, guide2_scale=1.0, switch_threshold=800)
+    assert a.nag == b.nag == (11.0, 2.5, 0.25)
+    assert a.ctx_shapes == b.ctx_shapes == [(2, 512, 4096)] and a.ctx_rows == [[1.0, -1.0]]
+    m = NagDiT("A")
+    run(WanAny2VHIP(m, device="cpu"), context=pos, context_null=neg, NAG_scale=11)
+    assert m.ctx_shapes == [(2, 512, 4096), (1, 512, 4096)] and m.ctx_rows == [[1.0, -1.0], [-1.0]] and m.nag == (11.0, 3.5, 0.5)
+    m = NagDiT("A")
+    run(WanAny2VHIP(m, device="cpu"), context=pos, context_null=neg, NAG_scale=1)        # off (nag_scale <= 1, model.py:260)
+    assert m.ctx_shapes == [(1, 512, 4096), (1, 512, 4096)] and m.nag is None

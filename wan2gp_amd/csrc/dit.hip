@@ -22,7 +22,7 @@ void wan_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wan_last_error(void) { return g_err; }
-extern "C" int wan_version(void) { return 3; }
+extern "C" int wan_version(void) { return 4; }
 extern "C" int wan_device_cus(void) {
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -343,10 +343,11 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.k = c.take<bf16_t>(rows * d);
   t.vt = c.take<bf16_t>((int64_t)S * d * Lp);
   t.h = c.take<bf16_t>(rows * g.ffn_dim);
-  t.ctx_h = c.take<bf16_t>((int64_t)S * g.text_len * d);
-  t.ctx_e = c.take<bf16_t>((int64_t)S * g.text_len * d);
-  t.ck = c.take<bf16_t>((int64_t)S * g.text_len * d);
-  t.cvt = c.take<bf16_t>((int64_t)S * d * g.text_len);
+  // text context: up to two prompts per stream (normalized attention guidance: positive ; negative, any2video.py:608)
+  t.ctx_h = c.take<bf16_t>((int64_t)2 * S * g.text_len * d);
+  t.ctx_e = c.take<bf16_t>((int64_t)2 * S * g.text_len * d);
+  t.ck = c.take<bf16_t>((int64_t)2 * S * g.text_len * d);
+  t.cvt = c.take<bf16_t>((int64_t)2 * S * d * g.text_len);
   // time embedding / projection: one row per timestep -- 1 normally, up to F with per-frame timesteps (model.py:1812-1818;
   // ti2v image conditioning any2video.py:1496-1499, diffusion forcing); e0 is replicated per stream so that a kernel's
   // row / rows_per_batch lookup works on the stacked streams
@@ -358,7 +359,7 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.kmax = c.take<float>(wan_attention_scratch_words(S, S, Ll, g.num_heads));
   // scaled-fp8 Linears quantise their input per tensor = per stream (the reference runs the streams of a joint pass one
   // after the other through each block, model.py:1993-2036): the widest Linear input of one stream, S slots
-  const int64_t tmax = std::max<int64_t>(std::max<int64_t>(Ll, g.text_len), CLIP_TOK);
+  const int64_t tmax = std::max<int64_t>(std::max<int64_t>(Ll, 2 * (int64_t)g.text_len), CLIP_TOK);
   const int64_t kmax_in = std::max(std::max(g.dim, g.ffn_dim), std::max(g.text_dim, CLIP_DIM));
   t.q8_slot = fp8 ? ((tmax * kmax_in + 255) / 256) * 256 : 0;
   t.xq = fp8 ? c.take<uint8_t>(t.q8_slot * S) : nullptr;
@@ -460,7 +461,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
                             const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
                             int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                             void* poll_user, const int* should_calc, wan_bf16* const* residual, int n_vace,
-                            const float* const* vace_contexts, const float* vace_scales, void* stream) {
+                            const float* const* vace_contexts, const float* vace_scales, const float* nag, const int* context_batches,
+                            void* stream) {
   WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
   WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
@@ -479,6 +481,20 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
               "wan_dit_forward: inconsistent sequence-parallel info");
   WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
   WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
+  // Normalized attention guidance (any2video.py:607-608): a stream whose context holds two prompts (positive ; negative) runs its
+  // text cross-attention against both and combines the results (text_cross_attention, model.py:260-292).  crow[s] = first row of
+  // stream s's context in the stacked context buffers, cb[s] = its prompts.
+  int cb[8], crow[9];
+  bool any_nag = false;
+  crow[0] = 0;
+  for (int s = 0; s < S; ++s) {
+    cb[s] = context_batches ? context_batches[s] : 1;
+    WAN_REQUIRE(cb[s] == 1 || (cb[s] == 2 && nag && nag[0] > 1.f),
+                "wan_dit_forward: context_batches[%d] = %d (1, or 2 together with nag_scale > 1: model.py:260)", s, cb[s]);
+    any_nag = any_nag || cb[s] == 2;
+    crow[s + 1] = crow[s] + cb[s] * TL;
+  }
+  WAN_REQUIRE(!any_nag || ffn >= d, "wan_dit_forward: normalized attention guidance parks a result in the FFN buffer (ffn_dim >= dim)");
   Bufs b;
   const int64_t need = carve_all(g, S, Ll, world, workspace, &b, c->vace_layers.empty() ? 0 : c->vace_max_ctx, c->any_fp8, F);
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
@@ -523,11 +539,17 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   RC(tlin(b.e_s, c->tp1, b.e0, 6 * d, d));
   for (int s = 1; s < S && nt > 1; ++s)
     WAN_CHECK_HIP(hipMemcpyAsync(b.e0 + (int64_t)s * nt * 6 * d, b.e0, (size_t)nt * 6 * d * 2, hipMemcpyDeviceToDevice, st));
-  for (int s = 0; s < S; ++s) {
-    RC(linear(context[s], c->te0, b.ctx_h + (int64_t)s * TL * d, TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream, nullptr, nullptr, nullptr,
-              -1, 1, 0, q8, 1, s));
+  for (int s = 0; s < S; ++s) {  // one tensor per stream (fp8: one quantisation per tensor), [cb[s] * TL, text_dim]
+    RC(linear(context[s], c->te0, b.ctx_h + (int64_t)crow[s] * d, (int64_t)cb[s] * TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream, nullptr,
+              nullptr, nullptr, -1, 1, 0, q8, 1, s));
   }
-  RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+  if (!any_nag) {
+    RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+  } else {
+    for (int s = 0; s < S; ++s)
+      RC(linear(b.ctx_h + (int64_t)crow[s] * d, c->te2, b.ctx_e + (int64_t)crow[s] * d, (int64_t)cb[s] * TL, d, d, WAN_EPI_NONE, stream,
+                nullptr, nullptr, nullptr, -1, 1, 0, q8, 1, s));
+  }
 
   // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups (rpb = rows in run_blocks)
 
@@ -573,7 +595,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   const int S = Sn;
   const int64_t rows = (int64_t)Sn * Ll, rpb = nt > 1 ? tpf : rows;
   struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; float* raw; } b2 = {
-      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)s0 * TL * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
+      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)crow[s0] * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
   bf16_t* const x_main = b.x + s0 * sn;
   // hint streams of this run, per active context; vskip[k] doubles as the swap buffer of before_proj
   bf16_t *vc[8], *vskip[8];
@@ -635,14 +657,56 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     RC(linear(b.xm, Lw.cross.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
     // norm only; the softmax scale * log2(e) folded into q as for self-attention
     RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.cross.nq, nullptr, nullptr, nullptr, rows, Ll, 0, d, g.eps, wan_attention_qscale(), stream));
+    if (any_nag) {
+      // text_cross_attention with a (positive ; negative) context on some streams (model.py:260-292).  K / V per stream: its context
+      // is ONE tensor of cb * TL rows (fp8: one quantisation), V^T one [d, TL] image per prompt.  Per stream: attention against the
+      // positive prompt -> xm, against the negative one -> h (the FFN buffer is idle here), wan_nag_combine -> q (xm under the
+      // CLIP branch, which adds the image result to the text result below).
+      const int64_t crow0 = crow[s0];
+      for (int s = 0; s < S; ++s) {
+        const int64_t r0 = crow[s0 + s] - crow0, nr = (int64_t)cb[s0 + s] * TL;
+        bf16_t* cs = b.ctx_e + r0 * d;
+        bf16_t* ks = b.ck + r0 * d;
+        bf16_t* vs = b.cvt + r0 * d;
+        RC(linear(cs, Lw.cross.k, ks, nr, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, 1, s));
+        RC(wan_rmsnorm_rope(ks, nullptr, Lw.cross.nk, nullptr, nullptr, nullptr, nr, TL, 0, d, g.eps, stream));
+        if (Lw.cross.v.w8 == nullptr) {
+          for (int j = 0; j < cb[s0 + s]; ++j)
+            RC(wan_gemm_bf16(cs + (int64_t)j * TL * d, d, Lw.cross.v.w, Lw.cross.v.b, vs + (int64_t)j * TL * d, TL, TL, d, d, WAN_EPI_TRANSPOSED,
+                             nullptr, nullptr, nullptr, 6, -1, 1, stream));
+        } else {
+          uint8_t* xq = q8->xq + (int64_t)s * q8->slot_bytes;
+          float* ws = q8->ws + (int64_t)s * 64;
+          if (Lw.cross.k.w8 == nullptr) RC(wan_fp8_quantize(cs, xq, ws, nr * d, stream));  // else: slot s holds this tensor already
+          for (int j = 0; j < cb[s0 + s]; ++j)
+            RC(wan_gemm_fp8(xq + (int64_t)j * TL * d, d, ws, Lw.cross.v.w8, Lw.cross.v.ws, Lw.cross.v.ns, Lw.cross.v.b, vs + (int64_t)j * TL * d, TL,
+                            TL, d, d, WAN_EPI_TRANSPOSED, nullptr, nullptr, nullptr, 6, -1, 1, stream));
+        }
+        bf16_t* qs = b.q + (int64_t)s * Ll * d;
+        bf16_t* xs = b.xm + (int64_t)s * Ll * d;
+        bf16_t* dst = c->has_img ? xs : qs;
+        ProfScope ps(PROF_CROSS_ATTN, st);
+        if (cb[s0 + s] == 2) {
+          bf16_t* hs = b.h + (int64_t)s * Ll * d;
+          RC(wan_attention_bounded(qs, ks, vs, xs, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+          RC(wan_attention_bounded(qs, ks + (int64_t)TL * d, vs + (int64_t)TL * d, hs, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+          RC(wan_nag_combine(xs, hs, dst, Ll, d, nag[0], nag[1], nag[2], stream));
+        } else {
+          RC(wan_attention_bounded(qs, ks, vs, dst, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+        }
+      }
+    } else {
     RC(linear(b.ctx_e, Lw.cross.k, b.ck, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
     RC(wan_rmsnorm_rope(b.ck, nullptr, Lw.cross.nk, nullptr, nullptr, nullptr, (int64_t)S * TL, TL, 0, d, g.eps, stream));
     for (int s = 0; s < S; ++s)
       RC(linear(b.ctx_e + (int64_t)s * TL * d, Lw.cross.v, b.cvt + (int64_t)s * d * TL, TL, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
                 nullptr, nullptr, -1, 1, TL, q8, 1, s, Lw.cross.k.w8 != nullptr));
+    }
     if (!c->has_img) {
-      ProfScope ps(PROF_CROSS_ATTN, st);
-      RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.q, S, S, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+      if (!any_nag) {
+        ProfScope ps(PROF_CROSS_ATTN, st);
+        RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.q, S, S, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+      }
     } else {
       // WanI2VCrossAttention (model.py:466-499): the same q attends the text tokens and the 257 CLIP tokens (K_img / V_img
       // shared by every stream), the two bf16 results are added, then o.  xm is free here: it takes the text result.
@@ -651,7 +715,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(linear(c->clip_ctx, Lw.vimg, b.cvtimg, CLIP_TOK, d, d, WAN_EPI_TRANSPOSED, stream, nullptr, nullptr, nullptr, -1, 1, CLIP_LDV,
                 q8, 1, 0, Lw.kimg.w8 != nullptr));
       ProfScope ps(PROF_CROSS_ATTN, st);
-      RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+      if (!any_nag) RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
       RC(wan_attention_bounded(b.q, b.ckimg, b.cvtimg, b.q, S, 1, Ll, CLIP_TOK, CLIP_LDV, nh, 1, 0, 0, 1, nullptr, stream));
       RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }
@@ -712,7 +776,7 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
                                int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                void* poll_user, void* stream) {
   return dit_forward_impl(c, S, x, t, nullptr, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
-                          nullptr, nullptr, 0, nullptr, nullptr, stream);
+                          nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
@@ -720,7 +784,7 @@ extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, fl
                                     int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                     void* poll_user, const int* should_calc, wan_bf16* const* residual, void* stream) {
   return dit_forward_impl(c, S, x, t, nullptr, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
-                          should_calc, residual, 0, nullptr, nullptr, stream);
+                          should_calc, residual, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* stream) {
@@ -732,9 +796,11 @@ extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* strea
   const float one_scale[1] = {a->vace_scale};
   const bool many = a->n_vace > 0;
   WAN_REQUIRE(!many || (a->vace_contexts && a->vace_scales), "wan_dit_forward_ex: n_vace = %d but the arrays are null", a->n_vace);
+  const float nag[3] = {a->nag_scale, a->nag_tau, a->nag_alpha};
   return dit_forward_impl(c, a->S, a->x, a->t, a->n_t_frames ? a->t_frames : nullptr, a->context, a->y, a->cos, a->sin, a->outs, a->F, a->H, a->W, a->workspace,
                           a->workspace_bytes, a->sp, a->poll, a->poll_user, a->should_calc, a->residual,
-                          many ? a->n_vace : (a->vace_context ? 1 : 0), many ? a->vace_contexts : one_ctx, many ? a->vace_scales : one_scale, stream);
+                          many ? a->n_vace : (a->vace_context ? 1 : 0), many ? a->vace_contexts : one_ctx, many ? a->vace_scales : one_scale,
+                          nag, a->context_batches, stream);
 }
 
 extern "C" int wan_dit_set_vace_contexts(wan_ctx* c, int n) {

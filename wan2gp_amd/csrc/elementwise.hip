@@ -7,6 +7,8 @@
 // are L2-resident.
 //
 // Rounding points follow the reference's eager bf16 graph (see include/wanhip.h).
+#include <string.h>
+
 #include "common.h"
 
 #define ROWS_PER_BLOCK 4  // 4 waves of 64 lanes
@@ -243,6 +245,59 @@ __global__ __launch_bounds__(256) void gated_residual_kernel(
       for (int j = 0; j < 8; ++j) xv[j] = xv[j] + yv[j];
     }
     *reinterpret_cast<uint4*>(x + row * d + c * 8) = pack8(xv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalized attention guidance on the two cross-attention results -- text_cross_attention, model.py:276-293
+// ------------------------------------------------------------------------------------------------
+// One wave per token row, two passes over the row pair (the second read comes out of L2: 4 * d bytes per wave):
+//   pass 1  g = bf16(bf16(x_neg * (1 - s)) + s * x_pos)   (mul_ then add_(alpha): two roundings, :278-279), L1 norms of x_pos and g
+//   row     n+ , ng rounded to bf16 (torch.norm returns the input dtype), ratio = bf16(ng / n+) with nan -> 10 and inf -> the
+//           largest bf16 (nan_to_num, :285), factor = bf16(bf16(bf16(1 / bf16(ng + 1e-7)) * n+) * tau)   (:286, a rounding per op)
+//   pass 2  g' = ratio > tau ? bf16(g * factor) : g;  out = bf16(bf16(g' * alpha) + bf16(x_pos * (1 - alpha)))   (:287-291)
+// The scalars arrive the way torch's CPU kernels see them (probed on the torch of this image): mul_ by a Python number keeps it in
+// fp32, add_(alpha=) and the comparison round it to the tensor's dtype first -- hence s_add / tau_cmp beside tau_mul.
+// out may alias x_pos or x_neg (a lane reads its chunk of both rows before it writes it; pass 1 ends in a wave reduction).
+__global__ __launch_bounds__(256) void nag_combine_kernel(const bf16_t* x_pos, const bf16_t* x_neg, bf16_t* out, int64_t rows,
+                                                         int d, float one_minus_s, float s_add, float tau_cmp, float tau_mul,
+                                                         float one_minus_alpha, float alpha) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = d >> 3;
+  const bf16_t* xp = x_pos + row * d;
+  const bf16_t* xn = x_neg + row * d;
+  bf16_t* o = out + row * d;
+  float sp = 0.f, sg = 0.f;
+  for (int c = lane; c < nchunk; c += 64) {
+    float p[8], n[8];
+    unpack8(*reinterpret_cast<const uint4*>(xp + c * 8), p);
+    unpack8(*reinterpret_cast<const uint4*>(xn + c * 8), n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float g = rbf(__builtin_fmaf(s_add, p[j], rbf(n[j] * one_minus_s)));
+      sp += __builtin_fabsf(p[j]);
+      sg += __builtin_fabsf(g);
+    }
+  }
+  const float np = rbf(wave_sum(sp)), ng = rbf(wave_sum(sg));
+  float ratio = rbf(ng / np);
+  if (ratio != ratio) ratio = 10.f;
+  if (ratio > 3.3895313892515355e38f) ratio = 3.3895313892515355e38f;
+  const float factor = rbf(rbf(rbf(1.0f / rbf(ng + 1e-7f)) * np) * tau_mul);
+  const bool clip = ratio > tau_cmp;
+  for (int c = lane; c < nchunk; c += 64) {
+    float p[8], n[8];
+    unpack8(*reinterpret_cast<const uint4*>(xp + c * 8), p);
+    unpack8(*reinterpret_cast<const uint4*>(xn + c * 8), n);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float g = rbf(__builtin_fmaf(s_add, p[j], rbf(n[j] * one_minus_s)));
+      if (clip) g = rbf(g * factor);
+      n[j] = rbf(g * alpha) + rbf(p[j] * one_minus_alpha);
+    }
+    *reinterpret_cast<uint4*>(o + c * 8) = pack8(n);
   }
 }
 
@@ -489,6 +544,26 @@ extern "C" int wan_gated_residual(wan_bf16* x, const wan_bf16* y, const wan_bf16
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(gated_residual_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, mod, e, n_mod,
                      gate_idx, rows, rows_per_batch, d);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_nag_combine(const wan_bf16* x_pos, const wan_bf16* x_neg, wan_bf16* out, int64_t rows, int d, float nag_scale,
+                               float nag_tau, float nag_alpha, void* stream) {
+  WAN_REQUIRE(x_pos && x_neg && out, "wan_nag_combine: null pointer");
+  WAN_REQUIRE(d % 8 == 0 && d > 0, "wan_nag_combine: d %% 8 != 0");
+  if (rows == 0) return 0;
+  auto to_bf16 = [](float f) {  // round-to-nearest-even, as torch casts a Python scalar to a bf16 tensor's dtype
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    memcpy(&f, &u, 4);
+    return f;
+  };
+  const unsigned blocks = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(nag_combine_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x_pos, x_neg, out, rows, d,
+                     (float)(1.0 - (double)nag_scale), to_bf16(nag_scale), to_bf16(nag_tau), nag_tau,
+                     (float)(1.0 - (double)nag_alpha), nag_alpha);
   WAN_LAUNCH_CHECK();
   return 0;
 }

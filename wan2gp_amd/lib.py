@@ -37,7 +37,8 @@ class DitArgs(ctypes.Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_int64), ("sp", c_void_p), ("poll", c_void_p),
                 ("poll_user", c_void_p), ("should_calc", POINTER(c_int)), ("residual", POINTER(c_void_p)),
                 ("vace_context", c_void_p), ("vace_scale", c_float), ("t_frames", POINTER(c_float)), ("n_t_frames", c_int),
-                ("n_vace", c_int), ("vace_contexts", POINTER(c_void_p)), ("vace_scales", POINTER(c_float))]
+                ("n_vace", c_int), ("vace_contexts", POINTER(c_void_p)), ("vace_scales", POINTER(c_float)),
+                ("nag_scale", c_float), ("nag_tau", c_float), ("nag_alpha", c_float), ("context_batches", POINTER(c_int))]
 GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p)
 GATHER_WAIT_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p)
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     "wan_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                                 c_int, c_float, c_void_p]),
     "wan_ln_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "wan_nag_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_float, c_void_p]),
     "wan_gated_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int,
                                    c_void_p]),
     "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,

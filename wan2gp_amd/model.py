@@ -52,6 +52,9 @@ class WanModelHIP:
         self.cache = None
         self.reference_module = None      # optional: the reference nn.Module to delegate variant calls to
         self.sp = None                    # optional sequence-parallel group (wan2gp_amd.sp.SequenceParallel)
+        # normalized attention guidance (NAG_scale, NAG_tau, NAG_alpha), set by generate() (any2video.py:607); None: read
+        # mmgp.offload.shared_state["_nag_*"] when the reference's own generate() drives this model
+        self.nag = None
         self._weights: Dict[str, torch.Tensor] = {}
         self._ws = None
         cfg = DitConfig(dim, ffn_dim, num_heads, num_layers, in_dim, out_dim, text_dim, freq_dim, text_len, eps)
@@ -134,6 +137,17 @@ class WanModelHIP:
         from . import skipcache
         return skipcache.compute_magcache_threshold(self.cache, start_step, timesteps, speed_factor)
 
+    def _nag_params(self):
+        """(scale, tau, alpha) of text_cross_attention's NAG branch (model.py:249, :263-264) or None when it is off."""
+        nag = self.nag
+        if nag is None:
+            import sys
+            off = sys.modules.get("mmgp.offload") or getattr(sys.modules.get("mmgp"), "offload", None)
+            st = getattr(off, "shared_state", None)
+            if st and st.get("_nag_scale", 0) > 1:
+                nag = (st["_nag_scale"], st["_nag_tau"], st["_nag_alpha"])
+        return None if nag is None or nag[0] <= 1 else tuple(float(v) for v in nag)
+
     def apply_post_init_changes(self):  # reference API; nothing to adapt here
         return self
 
@@ -204,8 +218,15 @@ class WanModelHIP:
         dev = self.device
         xs = [xx.to(device=dev, dtype=torch.float32).contiguous() for xx in x_list]
         ctxs = [c.to(device=dev, dtype=torch.bfloat16).contiguous() for c in context]
-        if any(c.shape[-2] != self.text_len or c.shape[0] != 1 for c in ctxs):
-            raise _L.WanHipError(f"context must be [1,{self.text_len},{self.text_dim}] per stream")
+        if any(c.shape[-2] != self.text_len or c.shape[0] not in (1, 2) for c in ctxs):
+            raise _L.WanHipError(f"context must be [1,{self.text_len},{self.text_dim}] per stream ([2,...] = positive ; negative "
+                                 "prompt under normalized attention guidance)")
+        # NAG (any2video.py:607-608; text_cross_attention model.py:260): a batch-2 context is (positive ; negative) prompt
+        ctx_batches = [int(c.shape[0]) for c in ctxs]
+        nag = self._nag_params() if max(ctx_batches) == 2 else None
+        if max(ctx_batches) == 2 and nag is None:
+            raise _L.WanHipError("a context of batch 2 needs normalized attention guidance (NAG_scale > 1): set model.nag = "
+                                 "(scale, tau, alpha) as generate() does")
         # t: one timestep, or one per latent frame (model.py:1812-1818; ti2v image conditioning any2video.py:1496-1499,
         # diffusion forcing with a [1, F] tensor)
         tflat = t.detach().flatten().to(torch.float32).cpu()
@@ -271,7 +292,7 @@ class WanModelHIP:
                 bufs.append(r)
             FL = (ctypes.c_int * S)(*[1 if f else 0 for f in flags])
             RP = (c_void_p * S)(*[r.data_ptr() for r in bufs])
-        if vace_ts is not None or t_frames is not None:
+        if vace_ts is not None or t_frames is not None or nag is not None:
             nv = 0 if vace_ts is None else len(vace_ts)
             for u in vace_ts or ():
                 if tuple(u.shape) != (self.vace_in_dim, F, H, W):
@@ -280,7 +301,8 @@ class WanModelHIP:
             VS = (ctypes.c_float * nv)(*vace_scales) if nv else None
             a = _L.DitArgs(S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws), ws.numel(),
                            None if sp_struct is None else ctypes.cast(sp_struct, c_void_p), ctypes.cast(poll, c_void_p), None, FL, RP,
-                           None, 1.0, t_frames, F if t_frames is not None else 0, nv, VP, VS)
+                           None, 1.0, t_frames, F if t_frames is not None else 0, nv, VP, VS,
+                           *((0.0, 0.0, 0.0, None) if nag is None else (*nag, (ctypes.c_int * S)(*ctx_batches))))
             rc = _L.load().wan_dit_forward_ex(self._ctx, ctypes.byref(a), stream_ptr())
         elif cache is None:
             rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),

@@ -91,6 +91,17 @@ def gated_residual_(x, y, mod=None, e=None, gate_idx=-1):
     return x
 
 
+def nag_combine(x_pos, x_neg, nag_scale, nag_tau, nag_alpha, out=None):
+    """Normalized attention guidance on the two text cross-attention results (text_cross_attention, model.py:276-293):
+    x_pos / x_neg [..., d] bf16 -> bf16, one rounding per reference statement.  out may be x_pos or x_neg."""
+    _req(x_pos, BF16, "x_pos"); _req(x_neg, BF16, "x_neg")
+    d = x_pos.shape[-1]
+    out = torch.empty_like(x_pos) if out is None else out
+    check(_L.load().wan_nag_combine(ptr(x_pos), ptr(x_neg), ptr(out), x_pos.numel() // d, d, float(nag_scale), float(nag_tau),
+                                    float(nag_alpha), stream_ptr()), "wan_nag_combine")
+    return out
+
+
 def linear(x, weight, bias=None, epilogue=EPI_NONE, residual=None, mod=None, e=None, gate_idx=-1, out=None,
            ldc=None):
     """nn.Linear on MFMA: bf16(x @ weight.T + bias) with an optional fused epilogue.

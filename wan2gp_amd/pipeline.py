@@ -133,7 +133,7 @@ class WanAny2VHIP:
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
-                 motion_amplitude=1.0, clip_fea=None, input_video=None, **bbargs):
+                 motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -147,6 +147,16 @@ class WanAny2VHIP:
                 return torch.cat([c, c.new_zeros(text_len - c.size(0), c.size(1))]).unsqueeze(0)
             context = _encode(input_prompt)
             context_null = _encode(n_prompt)
+        # normalized attention guidance (any2video.py:607-608): the positive prompt's context carries the negative one as a second
+        # batch entry; the text cross-attention of every block combines the two results (model.py:260-292)
+        nag = (float(NAG_scale), float(NAG_tau), float(NAG_alpha)) if NAG_scale > 1 else None
+        for m in (self.model, self.model2):
+            if m is not None and hasattr(m, "nag"):
+                m.nag = nag
+        if nag is not None:
+            if context_null is None:
+                raise ValueError("NAG_scale > 1 needs the negative prompt's context (context_null)")
+            context = torch.cat([context, context_null.to(context)], dim=0)
         if getattr(self.model, "model_type", None) == "i2v" and clip_fea is None:
             raise ValueError("a Wan2.1 i2v model (model_type 'i2v') needs clip_fea [1,257,1280]: the CLIP vision features of the "
                              "start image (any2video.py:721-729)")
