@@ -104,9 +104,9 @@ def test_forward_with_nag_vs_reference_golden(name):
     assert rel(solo.cpu(), outs[0].cpu()) <= 1e-6
 
 
-def test_forward_with_nag_vace_and_skip_cache_paths():
+def test_forward_with_nag_inside_vace_context_blocks():
     """NAG inside the VACE context blocks (their cross-attention sees the same batch-2 context, model.py:816-828) against the
-    oracle, and NAG through the step-skipping entry (a MagCache-computed step + a skipped one)."""
+    oracle."""
     cfg = O.make_config("tiny_vace")
     W = O.synth_weights(cfg)
     f, h, w = 2, 8, 8
