@@ -5,7 +5,8 @@ tests/golden/nag.npz = the reference's own WanModel run with offload.shared_stat
 
 Tolerances.  wan_nag_combine follows the reference's bf16 rounding points; what can differ is the fp32 summation order of the
 two L1 norms (a last-bit difference moves the bf16 norm by one ulp in ~2^-16 of the rows, and with it every element of a
-clipped row by <= 1 bf16 ulp): >= 99 % of the elements must be bit-identical, every element within 2 bf16 ulp.  Forwards: the
+clipped row's guidance term by <= 1 bf16 ulp): >= 99 % of the elements must be bit-identical, every element within 2 bf16 ulp
+of the magnitude its last rounding step worked on.  Forwards: the
 criterion of tests/test_gpu_model.py (no further from the fp32 anchor than the reference's bf16 run is, x 1.5 + 2e-3).
 """
 import os
@@ -25,11 +26,13 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def check_rows(got, ref, what):
+def check_rows(got, ref, mag, what):
+    """mag: magnitude the last rounding step worked on, |ref| + (1 - alpha) |x_pos| >= |alpha g'| -- the result is a sum of two
+    rounded terms and may be far smaller than either, so a one-ulp difference of a term is many ulps of a small result."""
     got, ref = got.float().cpu(), ref.float()
     assert torch.isfinite(got).all(), what
     same = (got == ref).float().mean().item()
-    ulp = ref.abs().clamp_min(1e-30) * 2.0 ** -7                 # one (coarse) bf16 ulp of the reference value
+    ulp = mag.float().clamp_min(1e-30) * 2.0 ** -7               # one (coarse) bf16 ulp at that magnitude
     worst = ((got - ref).abs() / ulp).max().item()
     print(f"[nag_combine {what}] identical {same:.5f}, worst {worst:.2f} ulp")
     assert same >= 0.99 and worst <= 2.0, (what, same, worst)
@@ -52,7 +55,7 @@ def test_nag_combine_vs_oracle(d, rows, nag):
     if nag[0] > 3:
         assert 0 < clipped < rows                               # both arms of the norm clip are exercised
     got = ops.nag_combine(xp.cuda(), xn.cuda(), *nag)
-    check_rows(got, ref, f"d={d} nag={nag}")
+    check_rows(got, ref, ref.float().abs() + (1 - nag[2]) * xp.float().abs(), f"d={d} nag={nag}")
     a, b = xp.cuda(), xn.cuda()
     assert torch.equal(ops.nag_combine(a, b, *nag, out=a), got)          # in place over x_pos ...
     a = xp.cuda()
@@ -94,10 +97,11 @@ def test_forward_with_nag_vs_reference_golden(name):
         print(f"nag {name}/{key}: err_ref={err_ref:.4e} err_hip={err_hip:.4e} hip-vs-ref={rel(o.cpu(), ref):.4e}")
         assert err_hip <= 1.5 * err_ref + 2e-3, (err_hip, err_ref)
         assert rel(o.cpu(), ref) <= 2.5e-2
-    # the guidance is really in the result: the same stream without it differs far beyond the tolerance
+    # the guidance is really in the result: the same stream without it sits several times further from the golden
     m.nag = None
     plain = m([lat.cuda()], t=t, context=[c.cuda()], y=None if y is None else y.cuda(), **kw)[0].cpu()
-    assert rel(plain, torch.from_numpy(G[f"fwd_{name}_cond"])) > 5e-2
+    gold = torch.from_numpy(G[f"fwd_{name}_cond"])
+    assert rel(plain, gold) > 3 * rel(outs[0].cpu(), gold)
     # a single NAG stream (guidance scale 1, the distilled-LoRA use of NAG) equals the cond stream of the pair
     m.nag = nag
     solo = m([lat.cuda()], t=t, context=[c2.cuda()], y=None if y is None else y.cuda(), **kw)[0]
