@@ -189,3 +189,47 @@ def test_sp_forward_native_rccl_when_two_gpus_are_present():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _vae_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import types
+        from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
+        vae = WanVAEHIP(state_dict=random_vae_state_dict())
+        g = torch.Generator().manual_seed(5)
+        z = torch.randn(16, 2, 16, 16, generator=g).cuda()              # 3 x 3 tiles of 8, 8 and 4 latent rows / columns
+        vid = (torch.rand(3, 5, 128, 128, generator=g) * 2 - 1).cuda()
+        ref_u8 = vae.decode_to_cpu_uint8([z], 64)[0]
+        ref_f32 = vae.decode([z], 64)[0]
+        ref_enc = vae.encode([vid], 64)[0]
+        vae.sp = types.SimpleNamespace(rank=rank, world=world, group=None)
+        assert torch.equal(vae.decode_to_cpu_uint8([z], 64)[0], ref_u8)
+        assert torch.equal(vae.decode([z], 64)[0], ref_f32)
+        assert torch.equal(vae.encode([vid], 64)[0], ref_enc)
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tiled_vae_sharded_over_two_ranks_one_gpu():
+    """The multi-GPU split of the tiled VAE (wan2gp_amd/vae.py:_sharded_tiles): rank k % 2 decodes / encodes tile k with the HIP
+    kernels, tiles are exchanged (host-staged here, RCCL broadcast on a multi-GPU node) and blended by every rank -- bit-identical
+    to the single-process tiled result for decode_to_cpu_uint8, decode and encode."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vae_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

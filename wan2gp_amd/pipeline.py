@@ -312,6 +312,8 @@ class WanAny2VHIP:
             latents[:, :, :ext_latents.shape[2]] = ext_latents                                     # :1755-1756
         if return_latents or self.vae is None:
             return {"x": None, "latents": latents, "latent_slice": None}
+        if getattr(self.vae, "sp", None) is None and getattr(self.model, "sp", None) is not None:
+            self.vae.sp = self.model.sp                      # multi-GPU: a tiled decode spreads its tiles over the sequence-parallel ranks
         x0 = latents.unbind(0)                                                                     # :1763
         videos = self.vae.decode_to_cpu_uint8(x0, VAE_tile_size)                                   # :1784
         return {"x": videos[0], "latents": latents, "latent_slice": None}

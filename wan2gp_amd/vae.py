@@ -303,6 +303,9 @@ class WanVAEHIP:
         self.model = self                                  # reference code reads vae.model.z_dim
         self.upsampler_factor = 1
         self.net = None
+        # multi-GPU: a process group view (rank, world, group -- e.g. wan2gp_amd.sp.SequenceParallel) over which the spatial tiles
+        # of a tiled decode / encode are spread; None = every tile on this device
+        self.sp = None
         if state_dict is not None:
             self.load_state_dict(state_dict)
         elif vae_pth is not None:
@@ -456,15 +459,49 @@ class WanVAEHIP:
             out_rows.append(torch.cat(out, dim=-1))
         return torch.cat(out_rows, dim=-2)
 
+    def _sharded_tiles(self, boxes, work, shape_of):
+        """The tiles of a tiled decode / encode are independent until they are blended (vae.py:676-717, :769-839, :841-881) -- the
+        unit of the multi-GPU VAE split: with `self.sp` set, tile k is computed by rank k % world and broadcast from it, so every
+        rank holds every tile and blends them in the reference's order (replicated result, like the latents).  `boxes`: one
+        (y, x) origin per tile; work(y, x) -> tile; shape_of(y, x) -> its shape (what a non-owner allocates).  Returns a function
+        k -> tile; without `self.sp` it computes on demand (the streaming form keeps one tile alive at a time)."""
+        sp = getattr(self, "sp", None)
+        if sp is None or sp.world == 1:
+            return lambda k: work(*boxes[k])
+        import torch.distributed as dist
+        grp = getattr(sp, "group", None)
+        staged = dist.get_backend(grp) == "gloo" and self.device.type != "cpu"       # single-GPU functional tests: host staging
+        tiles = []
+        for k, (y, x) in enumerate(boxes):
+            own = k % sp.world == sp.rank
+            t = work(y, x).contiguous() if own else torch.empty(shape_of(y, x), dtype=torch.float32, device=self.device)
+            tiles.append(t)
+        for k, t in enumerate(tiles):                                                 # compute first, exchange after: the
+            src = dist.get_global_rank(grp, k % sp.world) if grp is not None else k % sp.world   # owners run concurrently
+            if staged:
+                h = t.cpu()
+                dist.broadcast(h, src=src, group=grp)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src, group=grp)
+        return lambda k: tiles[k]
+
     def _tiled_decode_f32(self, z, tile_size):
         """spatial_tiled_decode (vae.py:676-717) on one latent [16,t,h,w] -> fp32 [3,T,H,W] (not clamped)."""
         tl = int(tile_size / 8)
         ov, be = int(tl * 0.75), int(tile_size * self.upsampler_factor * 0.25)
         if tl < 1 or ov < 1:
             raise ValueError(f"tile_size {tile_size} is too small to tile")
-        rows = [[self._decode_frames(z[:, :, i:i + tl, j:j + tl], False, True)[1] for j in range(0, z.shape[-1], ov)]
-                for i in range(0, z.shape[-2], ov)]
+        ys, xs = list(range(0, z.shape[-2], ov)), list(range(0, z.shape[-1], ov))
+        get = self._sharded_tiles([(i, j) for i in ys for j in xs],
+                                  lambda i, j: self._decode_frames(z[:, :, i:i + tl, j:j + tl], False, True)[1],
+                                  lambda i, j: self._decoded_tile_shape(z, i, j, tl))
+        rows = [[get(a * len(xs) + b) for b in range(len(xs))] for a in range(len(ys))]
         return self._blend_tiles(rows, be, tile_size * self.upsampler_factor - be)
+
+    def _decoded_tile_shape(self, z, i, j, tl):
+        f = 8 * self.upsampler_factor
+        return (3, (z.shape[1] - 1) * 4 + 1, min(tl, z.shape[-2] - i) * f, min(tl, z.shape[-1] - j) * f)
 
     @staticmethod
     def _blend_edge(edge, tile, be, dim):
@@ -487,7 +524,17 @@ class WanVAEHIP:
         row_limit = max(1, tile_size * self.upsampler_factor - be)
         T, H, W = (z.shape[1] - 1) * 4 + 1, z.shape[-2] * 8, z.shape[-1] * 8
         out = torch.empty(3, T, H, W, dtype=torch.uint8, device=self.device)
-        prev_edges, r = [], 0
+        boxes = []                                          # the tiles the loop below visits, in its order
+        for r, ly in enumerate(range(0, z.shape[-2], ov)):
+            if min(r * row_limit + row_limit, H) <= r * row_limit:
+                break
+            for c, lx in enumerate(range(0, z.shape[-1], ov)):
+                if min(c * row_limit + row_limit, W) <= c * row_limit:
+                    break
+                boxes.append((ly, lx))
+        get = self._sharded_tiles(boxes, lambda i, j: self._decode_frames(z[:, :, i:i + tl, j:j + tl], False, True)[1],
+                                  lambda i, j: self._decoded_tile_shape(z, i, j, tl))
+        prev_edges, r, k = [], 0, 0
         for ly in range(0, z.shape[-2], ov):
             y0, y1 = r * row_limit, min(r * row_limit + row_limit, H)
             if y1 <= y0:
@@ -497,7 +544,8 @@ class WanVAEHIP:
                 x0, x1 = c * row_limit, min(c * row_limit + row_limit, W)
                 if x1 <= x0:
                     break
-                tile = self._decode_frames(z[:, :, ly:ly + tl, lx:lx + tl], False, True)[1]
+                tile = get(k)
+                k += 1
                 if r > 0 and c < len(prev_edges) and prev_edges[c] is not None:
                     self._blend_edge(prev_edges[c], tile, be, -2)
                 if left is not None:
@@ -548,8 +596,12 @@ class WanVAEHIP:
             outs = []
             for v in videos:
                 v = v.to(self.device)
-                rows = [[self.encode([v[:, :, i:i + ts, j:j + ts]])[0] for j in range(0, v.shape[-1], ov)]
-                        for i in range(0, v.shape[-2], ov)]
+                ys, xs = list(range(0, v.shape[-2], ov)), list(range(0, v.shape[-1], ov))
+                get = self._sharded_tiles([(i, j) for i in ys for j in xs],
+                                          lambda i, j: self.encode([v[:, :, i:i + ts, j:j + ts]])[0],
+                                          lambda i, j: (self.z_dim, (v.shape[1] - 1) // 4 + 1, min(ts, v.shape[-2] - i) // 8,
+                                                        min(ts, v.shape[-1] - j) // 8))
+                rows = [[get(a * len(xs) + b) for b in range(len(xs))] for a in range(len(ys))]
                 outs.append(self._blend_tiles(rows, be, tl - be))   # blending commutes with the (affine) latent normalisation
             return outs
         lib = self.net.lib
