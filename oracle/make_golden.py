@@ -244,6 +244,9 @@ def main():
         gen_sched2(ns)
     if "loop" in which:
         gen_loop(ns)
+    if "vae_endframe" in which:
+        from oracle import make_golden_vae
+        make_golden_vae.main_endframe(ns, OUT)
     if "vae" in which:
         try:
             from oracle import make_golden_vae

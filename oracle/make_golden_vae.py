@@ -52,3 +52,23 @@ def main(ns, out_dir):
     print("vae_tiled.npz", {k: v.shape for k, v in tiled.items()})
     print("vae_small.npz", {k: v.shape for k, v in out.items()}, "dec range", float(dec.min()), float(dec.max()),
           "u8 mean", float(u8.float().mean()))
+
+
+def main_endframe(ns, out_dir):
+    """any_end_frame (vae.py:590-606, :646-650): start + end image clips -- the last frame / latent frame bypasses the feature
+    cache.  Encode of a 10-frame clip (1 + 4 + 4 + the end frame -> 4 latent frames) and decode of 4 latent frames
+    (1 + 4 + 4 + 1 = 10 frames), float and uint8."""
+    W = VO.synth_vae_weights()
+    vae = build_ref_vae(ns, W)
+    scale = VO.default_scale()
+    g = torch.Generator().manual_seed(23)
+    z = torch.randn(1, 16, 4, 8, 8, generator=g)
+    vid = (torch.rand(1, 3, 10, 64, 64, generator=g) * 2 - 1)
+    vid[:, :, 1:-1] *= 0.5
+    with torch.no_grad():
+        dec = vae.decode(z, scale, any_end_frame=True)
+        u8 = vae.decode_to_cpu_uint8(z, scale, 0, any_end_frame=True)
+        enc = vae.encode(vid, scale, any_end_frame=True)
+    out = {"dec": dec.numpy(), "dec_u8": u8.numpy(), "enc": enc.numpy(), "seed": np.array([23])}
+    np.savez_compressed(os.path.join(out_dir, "vae_endframe.npz"), **out)
+    print("vae_endframe.npz", {k: v.shape for k, v in out.items()})

@@ -272,26 +272,40 @@ def _n_cached_convs(W, side):
     return sum(1 for k, v in W.items() if k.startswith(side) and k.endswith(".weight") and v.dim() == 5)
 
 
-def vae_decode(z, W, scale=None, cfg=CFG):
-    """WanVAE_.decode (vae.py:628-662): one latent frame at a time through the cached decoder."""
+def vae_decode(z, W, scale=None, cfg=CFG, any_end_frame=False):
+    """WanVAE_.decode (vae.py:628-662): one latent frame at a time through the cached decoder.  any_end_frame (:646-650): the
+    last latent frame -- the end image of a start + end conditioned clip -- goes through the decoder WITHOUT the feature cache
+    (feat_cache=None: causal zero padding, no temporal upsampling), i.e. it decodes to one frame like the first."""
     if scale is not None:
         z = z / scale[1].view(1, -1, 1, 1, 1) + scale[0].view(1, -1, 1, 1, 1)
     x = causal_conv3d(z, W["conv2.weight"], W["conv2.bias"])
-    cache = [None] * _n_cached_convs(W, "decoder.")
+    n = _n_cached_convs(W, "decoder.")
+    cache = [None] * n
     outs = []
-    for i in range(z.shape[2]):
-        outs.append(decoder_forward(x[:, :, i:i + 1], W, cache, [0], cfg))
+    it = z.shape[2]
+    for i in range(it):
+        if any_end_frame and i == it - 1 and i > 0:
+            outs.append(decoder_forward(x[:, :, -1:], W, [None] * n, [0], cfg))      # a cache of its own = no cache
+        else:
+            outs.append(decoder_forward(x[:, :, i:i + 1], W, cache, [0], cfg))
     return torch.cat(outs, 2)
 
 
-def vae_encode(x, W, scale=None, cfg=CFG):
-    """WanVAE_.encode (vae.py:586-625): chunks of 1,4,4,... frames; returns the normalised mu."""
+def vae_encode(x, W, scale=None, cfg=CFG, any_end_frame=False):
+    """WanVAE_.encode (vae.py:586-625): chunks of 1,4,4,... frames; returns the normalised mu.  any_end_frame (:590-606):
+    2 + (t - 2) // 4 chunks, the last one being the clip's last frame alone, encoded without the feature cache."""
     t = x.shape[2]
-    cache = [None] * _n_cached_convs(W, "encoder.")
+    n = _n_cached_convs(W, "encoder.")
+    cache = [None] * n
     outs = []
-    for i in range(1 + (t - 1) // 4):
-        chunk = x[:, :, :1] if i == 0 else x[:, :, 1 + 4 * (i - 1):1 + 4 * i]
-        outs.append(encoder_forward(chunk, W, cache, [0], cfg))
+    it = 2 + (t - 2) // 4 if any_end_frame else 1 + (t - 1) // 4
+    for i in range(it):
+        if i == 0:
+            outs.append(encoder_forward(x[:, :, :1], W, cache, [0], cfg))
+        elif any_end_frame and i == it - 1:
+            outs.append(encoder_forward(x[:, :, -1:], W, [None] * n, [0], cfg))
+        else:
+            outs.append(encoder_forward(x[:, :, 1 + 4 * (i - 1):1 + 4 * i], W, cache, [0], cfg))
     out = torch.cat(outs, 2)
     mu, _ = causal_conv3d(out, W["conv1.weight"], W["conv1.bias"]).chunk(2, dim=1)
     if scale is not None:

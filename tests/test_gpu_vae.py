@@ -244,3 +244,31 @@ def test_encode_decode_roundtrip_shapes(vae):
     assert tuple(mu.shape) == (16, 4, 12, 20) and torch.isfinite(mu).all()
     u8 = vae.decode_to_cpu_uint8([mu], 0)[0]
     assert tuple(u8.shape) == (3, 13, 96, 160)
+
+
+def test_any_end_frame_vs_reference_golden(vae):
+    """Start + end image clips (vae.py:590-606, :646-650; any2video.py:743 / :1784 for the Wan2.1 i2v model): the end frame bypasses
+    the causal feature cache.  tests/golden/vae_endframe.npz = the reference's own encode / decode / decode_to_cpu_uint8 with
+    any_end_frame=True; same bars as the plain paths; the tiled form takes the same route per tile."""
+    gold = dict(np.load(os.path.join(G, "vae_endframe.npz")))
+    gen = torch.Generator().manual_seed(23)
+    z = torch.randn(1, 16, 4, 8, 8, generator=gen)
+    vid = (torch.rand(1, 3, 10, 64, 64, generator=gen) * 2 - 1)
+    vid[:, :, 1:-1] *= 0.5
+    u8 = vae.decode_to_cpu_uint8([z[0]], 0, any_end_frame=True)[0]
+    ref = torch.from_numpy(gold["dec_u8"])[0]
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (3, 10, 64, 64) == tuple(ref.shape)
+    d = (u8.int() - ref.int()).abs()
+    frac_same = (d == 0).float().mean().item()
+    print(f"VAE end-frame uint8: identical {frac_same * 100:.2f}%  max delta {int(d.max())}  mean delta {d.float().mean().item():.4f}")
+    assert int(d.max()) <= 2 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
+    dec = vae.decode([z[0]], 0, any_end_frame=True)[0].cpu()
+    assert (dec - torch.from_numpy(gold["dec"])[0].clamp(-1, 1)).abs().max().item() <= 1.5e-2
+    mu = vae.encode([vid[0]], any_end_frame=True)[0].cpu()
+    refe = torch.from_numpy(gold["enc"])[0]
+    assert tuple(mu.shape) == (16, 4, 8, 8)
+    err = (mu - refe).abs().max().item()
+    print(f"VAE end-frame encode: max abs err {err:.4e} (|ref| max {refe.abs().max().item():.3f})")
+    assert err <= 1e-2 * refe.abs().max().item() + 1e-3
+    body = vae.encode([vid[0][:, :9]])[0].cpu()                        # the first nine frames are the ordinary causal chain
+    assert torch.equal(mu[:, :3], body)

@@ -325,3 +325,34 @@ def test_nag_stacks_the_negative_prompt_under_the_positive_one_and_arms_both_exp
     m = NagDiT("A")
     run(WanAny2VHIP(m, device="cpu"), context=pos, context_null=neg, NAG_scale=1)        # off (nag_scale <= 1, model.py:260)
     assert m.ctx_shapes == [(1, 512, 4096), (1, 512, 4096)] and m.nag is None
+
+
+def test_image_end_adds_a_latent_frame_only_for_the_wan21_i2v_model_and_trims_it():
+    """any2video.py:684-691, :1759: start + end image.  Wan2.2 i2v (i2v2_2): same latent frame count, the mask's last entry is 1;
+    Wan2.1 i2v: one extra latent frame through the whole loop, encoded with any_end_frame, cut off before decoding."""
+    from oracle.make_golden_i2v_cond import FakeVAE
+
+    class Vae(FakeVAE):
+        def __init__(self):
+            self.encodes = []
+
+        def encode(self, videos, tile_size=0, any_end_frame=False):
+            self.encodes.append((tuple(videos[0].shape), any_end_frame))
+            return super().encode(videos, tile_size, any_end_frame)
+
+    img, end = torch.rand(3, 64, 64) * 2 - 1, torch.rand(3, 64, 64) * 2 - 1
+    for mt, lat_f, flag in (("i2v2_2", 3, False), ("i2v", 4, True)):
+        m, vae = FakeDiT("A"), Vae()
+        m.model_type = mt
+        out = run(WanAny2VHIP(m, vae=vae, device="cpu"), image_start=img, image_end=end, clip_fea=torch.zeros(1, 257, 1280))
+        assert vae.encodes == [((3, 10 if flag else 9, 64, 64), flag)]
+        ys = [c["y"] for c in m.calls]
+        assert all(tuple(y.shape) == (20, lat_f, 8, 8) for y in ys)
+        # the mask folds 4 frames into 4 channels per latent frame: Wan2.2 marks the clip's last FRAME (channel 3 of the last latent
+        # frame), the Wan2.1 form repeats the end frame's entry over all four channels of its own latent frame (:749)
+        last = ys[0][:4, -1]
+        assert bool((last[3] == 1).all()) and bool((last[:3] == (1 if flag else 0)).all()) and bool((ys[0][:4, 1:-1] == 0).all())
+        assert bool((ys[0][:4, 0] == 1).all())
+        assert tuple(out["latents"].shape) == (1, 16, 3, 8, 8)                                 # the extra frame is trimmed (:1759)
+    with pytest.raises(ValueError):
+        run(WanAny2VHIP(FakeDiT("A"), device="cpu"), image_end=end)

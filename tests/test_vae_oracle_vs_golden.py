@@ -46,3 +46,29 @@ def test_vae_spatial_tiling_matches_reference():
         assert torch.equal(u8, torch.from_numpy(g["dec_u8"]))
         assert torch.equal(u8[:, :, 1:4, :100, :120], torch.from_numpy(g["dec_u8_crop"]))     # frame_start / target_* only crop
         assert torch.equal(VO.vae_tiled_encode(vid, W, scale, 64), torch.from_numpy(g["enc"]))
+
+
+def endframe_inputs():
+    gen = torch.Generator().manual_seed(23)
+    z = torch.randn(1, 16, 4, 8, 8, generator=gen)
+    vid = (torch.rand(1, 3, 10, 64, 64, generator=gen) * 2 - 1)
+    vid[:, :, 1:-1] *= 0.5
+    return z, vid
+
+
+def test_vae_any_end_frame_matches_reference():
+    """vae.py:590-606 / :646-650: the end image of a start + end conditioned clip bypasses the causal feature cache.  Also pins the
+    identity the product relies on: that chunk is an independent one-frame clip, so any_end_frame = (clip without its last
+    frame) followed by (the last frame on its own)."""
+    g = dict(np.load(os.path.join(G, "vae_endframe.npz")))
+    W = VO.synth_vae_weights()
+    scale = VO.default_scale()
+    z, vid = endframe_inputs()
+    with torch.no_grad():
+        dec = VO.vae_decode(z, W, scale, any_end_frame=True)
+        assert tuple(dec.shape) == (1, 3, 10, 64, 64) and torch.equal(dec, torch.from_numpy(g["dec"]))
+        assert torch.equal(VO.float_to_uint8(dec), torch.from_numpy(g["dec_u8"]))
+        enc = VO.vae_encode(vid, W, scale, any_end_frame=True)
+        assert tuple(enc.shape) == (1, 16, 4, 8, 8) and torch.equal(enc, torch.from_numpy(g["enc"]))
+        assert torch.equal(dec, torch.cat([VO.vae_decode(z[:, :, :-1], W, scale), VO.vae_decode(z[:, :, -1:], W, scale)], 2))
+        assert torch.equal(enc, torch.cat([VO.vae_encode(vid[:, :, :9], W, scale), VO.vae_encode(vid[:, :, -1:], W, scale)], 2))

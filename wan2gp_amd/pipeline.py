@@ -55,29 +55,48 @@ class WanAny2VHIP:
             raise NotImplementedError(f"Unsupported Scheduler {sample_solver}")
         return s, s.timesteps
 
-    def build_i2v_conditioning(self, image_start, frame_num, height, width, VAE_tile_size=0, motion_amplitude=1.0):
+    def build_i2v_conditioning(self, image_start, frame_num, height, width, VAE_tile_size=0, motion_amplitude=1.0, image_end=None,
+                               add_frames_for_end_image=False):
         """y = cat(mask[4,f,h,w], vae.encode(known frames + zero frames)[16,f,h,w]) (any2video.py:699-774) and the clean
         latents of the known frames that are re-injected every step (:775-782).  `image_start`: one image [3,H,W] or a
         prefix video [3,P,H,W] to continue (control_video, :671-680); `motion_amplitude` > 1 stretches the latent
-        differences to the first frame (:761-770)."""
+        differences to the first frame (:761-770).  `image_end` [3,H,W]: the clip's last frame is known as well (:684-704,
+        :747-751): it closes the encoded video and its mask entry is 1; for the Wan2.1 i2v model (`add_frames_for_end_image`,
+        :685-691) the clip grows by one frame -- one more latent frame, encoded without the causal cache (any_end_frame) and
+        trimmed from the latents before they are decoded (:1759)."""
         dev = self.device
         video = image_start.to(device=dev, dtype=torch.float32)
         if video.dim() == 3:
             video = video.unsqueeze(1)                                                 # [3,1,H,W]
         P = video.shape[1]
+        end = image_end is not None
+        add = bool(end and add_frames_for_end_image)
+        if add:
+            frame_num += 1                                                             # :689
         lat_h, lat_w = height // self.vae_stride[1], width // self.vae_stride[2]
-        enc = torch.cat([video, torch.zeros(3, frame_num - P, height, width, device=dev)], dim=1)  # :739
-        lat_y = self.vae.encode([enc], VAE_tile_size)[0]                                           # :743
+        if end:                                                                        # :700-705
+            enc = torch.cat([video, torch.zeros(3, frame_num - P - 1, height, width, device=dev),
+                             image_end.to(device=dev, dtype=torch.float32).unsqueeze(1)], dim=1)
+        else:
+            enc = torch.cat([video, torch.zeros(3, frame_num - P, height, width, device=dev)], dim=1)  # :739
+        lat_y = self.vae.encode([enc], VAE_tile_size, any_end_frame=True)[0] if add else self.vae.encode([enc], VAE_tile_size)[0]   # :743
         msk = torch.ones(1, frame_num, lat_h, lat_w, device=dev)                                   # :746-757
-        msk[:, P:] = 0
-        msk = torch.cat([torch.repeat_interleave(msk[:, 0:1], repeats=4, dim=1), msk[:, 1:]], dim=1)
+        if end:
+            msk[:, P:-1] = 0
+        else:
+            msk[:, P:] = 0
+        if add:
+            msk = torch.cat([torch.repeat_interleave(msk[:, 0:1], repeats=4, dim=1), msk[:, 1:-1],
+                             torch.repeat_interleave(msk[:, -1:], repeats=4, dim=1)], dim=1)
+        else:
+            msk = torch.cat([torch.repeat_interleave(msk[:, 0:1], repeats=4, dim=1), msk[:, 1:]], dim=1)
         msk = msk.view(1, msk.shape[1] // 4, 4, lat_h, lat_w).transpose(1, 2)[0]
         if motion_amplitude > 1:                                                                   # :761-770
             base = lat_y[:, :1]
             diff = lat_y[:, P:] - base
             mean = diff.mean(dim=(0, 2, 3), keepdim=True)
             scaled = torch.clamp(base + (diff - mean) * motion_amplitude + mean, -6, 6)
-            lat_y = torch.cat([lat_y[:, :P], scaled], dim=1)
+            lat_y = torch.cat([lat_y[:, :P], scaled[:, :-1], lat_y[:, -1:]] if end else [lat_y[:, :P], scaled], dim=1)
         y = torch.cat([msk, lat_y.to(msk.dtype)])                                                  # :774
         n_known = int(1 + (P - 1) // 4)                                                            # :775
         return y, lat_y[:, :n_known].clone().unsqueeze(0)
@@ -133,7 +152,8 @@ class WanAny2VHIP:
                  joint_pass=True, y=None, image_start=None, latents=None, VAE_tile_size=0, return_latents=False,
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
-                 motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, **bbargs):
+                 motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, image_end=None,
+                 **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -165,6 +185,15 @@ class WanAny2VHIP:
         seed_g = torch.Generator(device=dev)
         seed_g.manual_seed(seed if seed >= 0 else torch.seed() % (2 ** 31))
         lat_frames = (frame_num - 1) // self.vae_stride[0] + 1                       # any2video.py:647
+        # start + end image (any2video.py:684-691): the Wan2.1 i2v model gets one extra frame -- one more latent frame, encoded
+        # without the causal cache and trimmed from the latents before decoding; Wan2.2 i2v keeps the frame count
+        trim_frames = 0
+        add_end = image_end is not None and getattr(self.model, "model_type", None) == "i2v"
+        if image_end is not None and image_start is None:
+            raise ValueError("image_end needs image_start (any2video.py:667-704)")
+        if add_end:
+            lat_frames = int((frame_num + 1 - 2) // self.vae_stride[0] + 2)
+            trim_frames = 1
         target_shape = (getattr(self.model, "out_dim", 16), lat_frames, height // self.vae_stride[1],
                         width // self.vae_stride[2])                                   # :1166 (48 channels, stride 16 for ti2v 5B)
         freqs = get_rotary_pos_embed(target_shape[1:], enable_RIFLEx=bool(enable_RIFLEx), device=dev)   # :1192
@@ -177,7 +206,8 @@ class WanAny2VHIP:
         if image_start is not None:
             if self.vae is None:
                 raise ValueError("image_start needs a VAE to encode the conditioning video")
-            y, ext_latents = self.build_i2v_conditioning(image_start, frame_num, height, width, VAE_tile_size, motion_amplitude)
+            y, ext_latents = self.build_i2v_conditioning(image_start, frame_num, height, width, VAE_tile_size, motion_amplitude,
+                                                         image_end=image_end, add_frames_for_end_image=add_end)
         # ti2v (Wan2.2 5B) image / video conditioning by timestep injection (any2video.py:1060-1072, :1496-1499, :1753-1754):
         # the VAE latents of the source frames replace the first latent frames before every step and after the last one, and
         # those frames are given timestep 0 -- a per-frame t vector
@@ -310,6 +340,8 @@ class WanAny2VHIP:
             latents[:, :, :source_latents.shape[2]] = source_latents                               # :1753-1754
         if ext_latents is not None:
             latents[:, :, :ext_latents.shape[2]] = ext_latents                                     # :1755-1756
+        if trim_frames > 0:
+            latents = latents[:, :, :-trim_frames]                                                 # :1759
         if return_latents or self.vae is None:
             return {"x": None, "latents": latents, "latent_slice": None}
         if getattr(self.vae, "sp", None) is None and getattr(self.model, "sp", None) is not None:

@@ -486,7 +486,7 @@ class WanVAEHIP:
                 dist.broadcast(t, src=src, group=grp)
         return lambda k: tiles[k]
 
-    def _tiled_decode_f32(self, z, tile_size):
+    def _tiled_decode_f32(self, z, tile_size, end=False):
         """spatial_tiled_decode (vae.py:676-717) on one latent [16,t,h,w] -> fp32 [3,T,H,W] (not clamped)."""
         tl = int(tile_size / 8)
         ov, be = int(tl * 0.75), int(tile_size * self.upsampler_factor * 0.25)
@@ -494,14 +494,27 @@ class WanVAEHIP:
             raise ValueError(f"tile_size {tile_size} is too small to tile")
         ys, xs = list(range(0, z.shape[-2], ov)), list(range(0, z.shape[-1], ov))
         get = self._sharded_tiles([(i, j) for i in ys for j in xs],
-                                  lambda i, j: self._decode_frames(z[:, :, i:i + tl, j:j + tl], False, True)[1],
-                                  lambda i, j: self._decoded_tile_shape(z, i, j, tl))
+                                  lambda i, j: self._decode_clip(z[:, :, i:i + tl, j:j + tl], False, True, end)[1],
+                                  lambda i, j: self._decoded_tile_shape(z, i, j, tl, end))
         rows = [[get(a * len(xs) + b) for b in range(len(xs))] for a in range(len(ys))]
         return self._blend_tiles(rows, be, tile_size * self.upsampler_factor - be)
 
-    def _decoded_tile_shape(self, z, i, j, tl):
+    def _decoded_tile_shape(self, z, i, j, tl, end=False):
         f = 8 * self.upsampler_factor
-        return (3, (z.shape[1] - 1) * 4 + 1, min(tl, z.shape[-2] - i) * f, min(tl, z.shape[-1] - j) * f)
+        return (3, self._decoded_frames(z.shape[1], end), min(tl, z.shape[-2] - i) * f, min(tl, z.shape[-1] - j) * f)
+
+    @staticmethod
+    def _decoded_frames(t, end=False):
+        return (t - 2) * 4 + 2 if (end and t > 1) else (t - 1) * 4 + 1
+
+    def _decode_clip(self, z, want_u8, want_f32, any_end_frame=False):
+        """_decode_frames, or with any_end_frame (vae.py:646-650) the clip without its last latent frame followed by that frame on
+        its own: the reference runs it through the decoder with feat_cache=None -- no cache in, none out, no temporal upsampling
+        -- which is exactly a one-frame clip (pinned on the oracle: tests/test_vae_oracle_vs_golden.py)."""
+        if not any_end_frame or z.shape[1] < 2:
+            return self._decode_frames(z, want_u8, want_f32)
+        a, b = self._decode_frames(z[:, :-1], want_u8, want_f32), self._decode_frames(z[:, -1:], want_u8, want_f32)
+        return tuple(None if x is None else torch.cat([x, y], dim=1) for x, y in zip(a, b))
 
     @staticmethod
     def _blend_edge(edge, tile, be, dim):
@@ -516,13 +529,13 @@ class WanVAEHIP:
         e.mul_(1.0 - w)
         tile.narrow(dim, 0, be).mul_(w).add_(e)
 
-    def _tiled_decode_u8(self, z, tile_size):
+    def _tiled_decode_u8(self, z, tile_size, end=False):
         """The tiled branch of decode_to_cpu_uint8 (vae.py:769-839) for the whole clip: uint8 [3,T,H,W] on the device."""
         tl = max(1, int(tile_size / 8))
         ov = max(1, int(tl * 0.75))
         be = int(tile_size * self.upsampler_factor * 0.25)
         row_limit = max(1, tile_size * self.upsampler_factor - be)
-        T, H, W = (z.shape[1] - 1) * 4 + 1, z.shape[-2] * 8, z.shape[-1] * 8
+        T, H, W = self._decoded_frames(z.shape[1], end), z.shape[-2] * 8, z.shape[-1] * 8
         out = torch.empty(3, T, H, W, dtype=torch.uint8, device=self.device)
         boxes = []                                          # the tiles the loop below visits, in its order
         for r, ly in enumerate(range(0, z.shape[-2], ov)):
@@ -532,8 +545,8 @@ class WanVAEHIP:
                 if min(c * row_limit + row_limit, W) <= c * row_limit:
                     break
                 boxes.append((ly, lx))
-        get = self._sharded_tiles(boxes, lambda i, j: self._decode_frames(z[:, :, i:i + tl, j:j + tl], False, True)[1],
-                                  lambda i, j: self._decoded_tile_shape(z, i, j, tl))
+        get = self._sharded_tiles(boxes, lambda i, j: self._decode_clip(z[:, :, i:i + tl, j:j + tl], False, True, end)[1],
+                                  lambda i, j: self._decoded_tile_shape(z, i, j, tl, end))
         prev_edges, r, k = [], 0, 0
         for ly in range(0, z.shape[-2], ov):
             y0, y1 = r * row_limit, min(r * row_limit + row_limit, H)
@@ -561,22 +574,20 @@ class WanVAEHIP:
         return out
 
     def decode(self, zs, tile_size=0, any_end_frame=False):
-        if any_end_frame:
-            raise NotImplementedError("any_end_frame decode is outside the hot path")
+        end = bool(any_end_frame)
         if int(tile_size or 0) > 0:
-            return [self._tiled_decode_f32(u.to(self.device), int(tile_size)).clamp_(-1, 1) for u in zs]
-        return [self._decode_frames(u, False, True)[1].clamp_(-1, 1) for u in zs]
+            return [self._tiled_decode_f32(u.to(self.device), int(tile_size), end).clamp_(-1, 1) for u in zs]
+        return [self._decode_clip(u, False, True, end)[1].clamp_(-1, 1) for u in zs]
 
     def decode_to_cpu_uint8(self, zs, tile_size=0, target_frames=None, target_height=None, target_width=None,
                             any_end_frame=False, frame_start=0):
-        if any_end_frame:
-            raise NotImplementedError("any_end_frame decode is outside the hot path")
+        end = bool(any_end_frame)
         outs = []
         for u in zs:
             if int(tile_size or 0) > 0:
-                u8 = self._tiled_decode_u8(u.to(self.device), int(tile_size))
+                u8 = self._tiled_decode_u8(u.to(self.device), int(tile_size), end)
             else:
-                u8 = self._decode_frames(u, True, False)[0]
+                u8 = self._decode_clip(u, True, False, end)[0]
             T = u8.shape[1]
             fs = min(max(0, int(frame_start or 0)), T)
             te = T if target_frames is None else min(T, fs + int(target_frames))
@@ -588,7 +599,17 @@ class WanVAEHIP:
     # ---- WanVAE_.encode (vae.py:586-625) ------------------------------------------------------------------
     def encode(self, videos, tile_size=0, any_end_frame=False):
         if any_end_frame:
-            raise NotImplementedError("any_end_frame encode is outside the hot path")
+            # vae.py:590-606: 2 + (T - 2) // 4 chunks -- first frame, groups of four, and the clip's LAST frame through the encoder
+            # with feat_cache=None, i.e. as a one-frame clip of its own (pinned on the oracle); per tile when tiling (:857)
+            outs = []
+            for v in videos:
+                T = v.shape[1]
+                if T < 2:
+                    outs.append(self.encode([v], tile_size)[0])
+                    continue
+                body, last = self.encode([v[:, :1 + 4 * ((T - 2) // 4)], v[:, -1:]], tile_size)
+                outs.append(torch.cat([body, last], dim=1))
+            return outs
         if int(tile_size or 0) > 0:                          # spatial_tiled_encode (vae.py:841-881)
             ts = int(tile_size)
             tl = int(ts / 8)
