@@ -175,3 +175,22 @@ def test_generate_with_nag_runs_the_loop():
     r = rel(out["latents"].cpu(), x)
     print(f"[nag generate] 3-step latents vs oracle loop: {r:.3e}")
     assert r <= 4e-2
+
+
+def test_nag_combine_at_the_14b_720p_shape_scaling_and_row_properties():
+    """BASELINE configs[2] size (75,600 token rows x 5120 channels, beyond what the oracle checks in seconds): properties that do
+    not depend on the size.  (a) powers of two commute with every bf16 / fp32 rounding, and the guidance is homogeneous of degree
+    one in (x_pos, x_neg): scaling both by 4 scales the result by 4 BIT-EXACTLY; (b) rows are independent: reversing the row order
+    reverses the result; (c) a sample of rows equals the oracle."""
+    from wan2gp_amd import ops
+    rows, d, nag = 75600, 5120, (11.0, 2.5, 0.25)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    xp = torch.randn(rows, d, device="cuda", generator=g).to(BF)
+    xn = (0.6 * xp.float() + 0.8 * torch.randn(rows, d, device="cuda", generator=g)).to(BF)
+    out = ops.nag_combine(xp, xn, *nag)
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(ops.nag_combine(xp * 4, xn * 4, *nag), out * 4)
+    assert torch.equal(ops.nag_combine(xp.flip(0).contiguous(), xn.flip(0).contiguous(), *nag).flip(0), out)
+    idx = torch.arange(0, rows, 997, device="cuda")
+    ref = O.nag_combine(xp[idx].cpu().unsqueeze(0), xn[idx].cpu().unsqueeze(0), *nag)[0]
+    check_rows(out[idx], ref, ref.float().abs() + (1 - nag[2]) * xp[idx].float().cpu().abs(), "14B-720p rows, sampled")
