@@ -194,3 +194,35 @@ def test_nag_combine_at_the_14b_720p_shape_scaling_and_row_properties():
     idx = torch.arange(0, rows, 997, device="cuda")
     ref = O.nag_combine(xp[idx].cpu().unsqueeze(0), xn[idx].cpu().unsqueeze(0), *nag)[0]
     check_rows(out[idx], ref, ref.float().abs() + (1 - nag[2]) * xp[idx].float().cpu().abs(), "14B-720p rows, sampled")
+
+
+def test_nag_together_with_magcache():
+    """NAG through the step-skipping entry (wan_dit_forward_ex carries should_calc / residual beside nag_* / context_batches): on
+    the steps MagCache computes the result is the uncached NAG forward's, bit for bit; on the steps it skips the stored residual
+    is replayed (finite, near the computed result)."""
+    from oracle.make_golden_skipcache import MAG_RATIOS, STEPS, inputs
+    from wan2gp_amd.skipcache import SkipStepsCache, reset_for_generation
+    cfg = O.make_config("tiny")
+    m = build(cfg, O.synth_weights(cfg, seed=4321))
+    lats, ts, c, cn = inputs(cfg)
+    c2 = torch.cat([c, cn]).cuda()
+    m.nag = (11.0, 2.5, 0.25)
+    plain = [m([lats[i].cuda(), lats[i].cuda()], t=torch.stack([ts[i]]), context=[c2, cn.cuda()]) for i in range(STEPS)]
+    cache = m.cache = SkipStepsCache(cache_type="mag", multiplier=2.0, start_step=1, num_steps=STEPS, skipped_steps=0,
+                                     previous_residual=None, previous_modulated_input=None)
+    cache.update({"magcache_thresh": 0, "magcache_K": 2, "def_mag_ratios": list(MAG_RATIOS)})
+    reset_for_generation(cache, 2)
+    try:
+        m.compute_magcache_threshold(cache.start_step, ts, cache.multiplier)
+        n_skipped = 0
+        for i in range(STEPS):
+            outs = m([lats[i].cuda(), lats[i].cuda()], t=torch.stack([ts[i]]), context=[c2, cn.cuda()], real_step_no=i, current_step_no=i)
+            for k in range(2):
+                if cache.accumulated_steps[k] == 0:                      # computed this step
+                    assert torch.equal(outs[k], plain[i][k]), (i, k)
+                else:
+                    n_skipped += 1
+                    assert torch.isfinite(outs[k]).all() and rel(outs[k], plain[i][k]) < 0.5, (i, k)
+        assert n_skipped > 0 and cache.skipped_steps > 0
+    finally:
+        m.cache = None
