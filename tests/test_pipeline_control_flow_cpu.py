@@ -356,3 +356,11 @@ def test_image_end_adds_a_latent_frame_only_for_the_wan21_i2v_model_and_trims_it
         assert tuple(out["latents"].shape) == (1, 16, 3, 8, 8)                                 # the extra frame is trimmed (:1759)
     with pytest.raises(ValueError):
         run(WanAny2VHIP(FakeDiT("A"), device="cpu"), image_end=end)
+
+
+def test_return_latent_slice_hands_back_the_requested_latent_frames():
+    """any2video.py:1760-1761, :1810: `return_latent_slice` (a slice over the latent time axis, what a sliding-window caller
+    overlaps the next window with) is cut after the end-frame trim and returned beside the video."""
+    out = run(WanAny2VHIP(FakeDiT("A"), device="cpu"), return_latent_slice=slice(-2, None))
+    assert tuple(out["latent_slice"].shape) == (1, 16, 2, 8, 8) and torch.equal(out["latent_slice"], out["latents"][:, :, -2:])
+    assert run(WanAny2VHIP(FakeDiT("A"), device="cpu"))["latent_slice"] is None

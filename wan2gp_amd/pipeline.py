@@ -153,7 +153,7 @@ class WanAny2VHIP:
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
                  motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, image_end=None,
-                 **bbargs):
+                 return_latent_slice=None, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -342,10 +342,12 @@ class WanAny2VHIP:
             latents[:, :, :ext_latents.shape[2]] = ext_latents                                     # :1755-1756
         if trim_frames > 0:
             latents = latents[:, :, :-trim_frames]                                                 # :1759
+        # :1760-1761: the latent frames a sliding-window caller asks back (a slice object over the latent time axis)
+        latent_slice = latents[:, :, return_latent_slice].clone() if return_latent_slice is not None else None
         if return_latents or self.vae is None:
-            return {"x": None, "latents": latents, "latent_slice": None}
+            return {"x": None, "latents": latents, "latent_slice": latent_slice}
         if getattr(self.vae, "sp", None) is None and getattr(self.model, "sp", None) is not None:
             self.vae.sp = self.model.sp                      # multi-GPU: a tiled decode spreads its tiles over the sequence-parallel ranks
         x0 = latents.unbind(0)                                                                     # :1763
         videos = self.vae.decode_to_cpu_uint8(x0, VAE_tile_size)                                   # :1784
-        return {"x": videos[0], "latents": latents, "latent_slice": None}
+        return {"x": videos[0], "latents": latents, "latent_slice": latent_slice}
