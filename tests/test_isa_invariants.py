@@ -81,7 +81,9 @@ def test_gemm256k_main_loop_instruction_mix(gemm):
 
 
 def test_attention_w64q_no_scratch_and_hardware_conversions(attn):
-    assert len(attn) in (4, 6)                                       # {bounded, tracking} x {q pre-scaled, pre-scaling pass} (+ 2 while a DMA-placement variant is being A/B-ed)
+    # {bounded, tracking} x {q pre-scaled, pre-scaling pass} x {one kv segment, several (FLAGS bit 6: the long form of the DMA
+    # stream's step)} + the two partial-sum forms of sequence parallelism (RAW_OUT on one segment, CARRY_IN over the others)
+    assert len(attn) == 10, sorted(attn)
     for name, (ops, meta) in attn.items():
         assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256 and meta["LDSByteSize"] <= 96 * 1024 + 256, (name, meta)
     # tracking loop (FLAGS 2): 68 MFMAs per KV tile (4 carry -m_ref), one v_exp_f32 per score, hardware bf16 packing
@@ -110,3 +112,30 @@ def test_attention_bounded_loop_instruction_mix(attn):
         assert not any(k.startswith(("v_max", "v_cmp", "v_permlane", "scratch_")) for k in c), c
         valu = sum(v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma"))
         assert valu <= 168, valu                                     # 160 + a few address / mask ops
+
+
+def test_attention_bounded_tile_scalar_work_and_loop_header_wait(tmp_path_factory):
+    """Two properties of the single-segment bounded kernel (FLAGS 6) that cost matrix-pipe time when they are lost:
+    (a) the DMA stream's step is the short form: a tile issues < 70 scalar ALU instructions and no v_cndmask / v_readfirstlane
+        (the segment walk is ~60 scalar instructions + lane-mask round trips, sunk by LLVM into ONE MFMA gap);
+    (b) no `s_waitcnt lgkmcnt(0)` between a tile's barrier and its first MFMAs: the loop header must see the same pending K-fragment
+        read order from the preheader as from the back edge (the preheader issues them in the loop's order, pinned), otherwise
+        hipcc flushes the LDS queue in front of every third tile while the last fragment read is one gap old."""
+    asm = asm_of("attention_w64q", tmp_path_factory)
+    m = re.search(r"^(_Z\S*attn_w64q_kernelILi6E\S*):", asm, re.M)
+    body = [l.strip() for l in asm[m.end():asm.index(".Lfunc_end", m.end())].split("\n")]
+    body = [l.split(";")[0].strip() for l in body if l and not l.startswith((";", ".")) and not l.endswith(":")]
+    bars = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
+    tiles = [(a, b) for a, b in zip(bars, bars[1:]) if sum(1 for l in body[a:b] if l.startswith("v_mfma")) == 64]
+    assert len(tiles) >= 2
+    for a, b in tiles:
+        ops = [l.split()[0] for l in body[a:b]]
+        salu = [o for o in ops if o.startswith("s_") and not o.startswith(("s_waitcnt", "s_barrier", "s_cbranch", "s_nop"))]
+        assert len(salu) < 70, len(salu)
+        assert not any(o.startswith(("v_cndmask", "v_readfirstlane")) for o in ops)
+    for a in bars:                                                    # every tile top, the loop header included
+        head = body[a + 1:a + 40]
+        first_mfma = next((i for i, l in enumerate(head) if l.startswith("v_mfma")), None)
+        if first_mfma is None:
+            continue
+        assert not any(l.startswith("s_waitcnt") and "lgkmcnt(0)" in l for l in head[:first_mfma + 1]), head[:first_mfma + 1]

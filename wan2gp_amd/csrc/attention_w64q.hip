@@ -190,7 +190,7 @@ __device__ __forceinline__ void chunkf(QB& q, int c, int kv_rem, int half, bool 
   }
 }
 
-template <int ST, bool TIMING>
+template <int ST, bool TIMING, bool MULTI>
 __device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
                                           const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
                                           mfma_bf16x8 (&vf)[4][4], const mfma_bf16x8& kones, QB& a, QB& b, int kv_rem,
@@ -229,7 +229,7 @@ __device__ __forceinline__ void tile_w64f(lds_cchar* smem, const int (&kaddr)[8]
     FLAT_GAP(i);
     SB();
   }
-  dma_advance(dma);
+  dma_advance<MULTI>(dma);
   SB();
   // ---- B: O_b += V^T(t-1) P_b(t-1)^T
 #pragma unroll
@@ -320,7 +320,7 @@ __device__ __forceinline__ void qk_stepn(QB& x, const mfma_bf16x8 (&kf)[2][8], c
 // gaps against 165 elsewhere, 208 without the VALU); q-block b's four displaced exps ride in the even gaps 56..62 of the
 // previous tile (scores 0..16 there instead of 0..12), which carry nothing but one exp and its pair bookkeeping.  Worth +0.4 %
 // (1361 against 1356 TFLOP/s, alternating libraries on one box) and 27 VGPRs.
-template <int ST, bool TIMING, bool DIAG>
+template <int ST, bool TIMING, bool DIAG, bool MULTI>
 __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8], const int (&vaddr)[4],
                                           const mfma_bf16x8 (&qfa)[8], const mfma_bf16x8 (&qfb)[8], mfma_bf16x8 (&kf)[2][8],
                                           mfma_bf16x8 (&vf)[4][4], QB& a, QB& b, int kv_rem, int half, char* smem_rw,
@@ -366,7 +366,7 @@ __device__ __forceinline__ void tile_w64n(lds_cchar* smem, const int (&kaddr)[8]
     BND_GAP(16 + i);
     SB();
   }
-  dma_advance(dma);
+  dma_advance<MULTI>(dma);
   SB();
 #pragma unroll
   for (int i = 0; i < 16; ++i) {  // ---- C: S_b = K Q_b^T
@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   constexpr bool BND = (FLAGS & 4) != 0;
   constexpr bool DIAG = (FLAGS & 8) != 0;  // timing build only: bounded loop without its row-sum adds (wrong results)
   constexpr bool RAW_OUT = (FLAGS & 16) != 0, CARRY_IN = (FLAGS & 32) != 0;
+  constexpr bool MULTI = (FLAGS & 64) != 0;  // several kv segments and / or a left-out one (sequence parallelism): the long form of the DMA stream's step
   constexpr int WAVE_RAW = 2 * (64 * 64 + 64), WG_RAW = 4 * WAVE_RAW;  // floats: per q-block 64 accumulators x 64 lanes + 64 row-sum shares
   uint64_t stamp[20] = {};
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stages][V^T stages] = 96 KB
@@ -577,16 +578,20 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
       for (int dt = 0; dt < 4; ++dt) vf[c4][dt] = __builtin_bit_cast(mfma_bf16x8, z);
   }
 
-  dma_tile<0>(smem, dma);
-  dma_tile<1>(smem, dma);
+  dma_tile<0, MULTI>(smem, dma);
+  dma_tile<1, MULTI>(smem, dma);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   mfma_bf16x8 kf[2][8];
+  // in the order the tile loop re-reads them (r -> sub-tile r & 1, k-step r >> 1): the loop header then sees the same pending-read
+  // order from the preheader and from the back edge, and hipcc's waitcnt pass keeps its exact lgkmcnt there instead of a full
+  // `s_waitcnt lgkmcnt(0)` in front of every third tile's first MFMA (the last K fragment read is one gap old at that point)
 #pragma unroll
-  for (int T = 0; T < 2; ++T)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kf[T][ks] = *(lds_frag*)(lds + T * 8192 + kaddr[ks]);
+  for (int r = 0; r < 16; ++r) {
+    kf[r & 1][r >> 1] = *(lds_frag*)(lds + (r & 1) * 8192 + kaddr[r >> 1]);
+    SB();  // keep the issue order (left alone the scheduler emits them last-to-first)
+  }
 
   int kv_rem_prev = KVBLK;
 #define W64Q_TOP(J)                                                                                          \
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 #define W64N_STEP(J)                                                                                         \
   if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
     W64Q_TOP(J)                                                                                              \
-    tile_w64n<J, TIMING, DIAG>(lds, kaddr, vaddr, qfa, qfb, kf, vf, qa, qbk, kv_rem, half, smem, dma, stamp, rec); \
+    tile_w64n<J, TIMING, DIAG, MULTI>(lds, kaddr, vaddr, qfa, qfb, kf, vf, qa, qbk, kv_rem, half, smem, dma, stamp, rec); \
     kv_rem_prev = kv_rem;                                                                                    \
   }
     for (int t = 0; t < ntile; t += NST) {
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 #define W64Q_STEP(J)                                                                                         \
   if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
     W64Q_TOP(J)                                                                                              \
-    tile_w64f<J, TIMING>(lds, kaddr, vaddr, qfa, qfb, kf, vf, kones, qa, qbk, kv_rem, half, t + (J) == 0, smem, dma, stamp,  \
+    tile_w64f<J, TIMING, MULTI>(lds, kaddr, vaddr, qfa, qfb, kf, vf, kones, qa, qbk, kv_rem, half, t + (J) == 0, smem, dma, stamp,  \
                          rec);                                                                               \
     kv_rem_prev = kv_rem;                                                                                    \
   }
@@ -774,10 +779,12 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   }
 #endif
   if (kmax_scratch != nullptr) {
-    if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4);
+    if (nseg > 1) { if (pre) W64Q_LAUNCH(6 | 64); else W64Q_LAUNCH(4 | 64); }
+    else { if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4); }
     WAN_LAUNCH_CHECK();
   }
-  if (pre) W64Q_LAUNCH(2); else W64Q_LAUNCH(0);
+  if (nseg > 1) { if (pre) W64Q_LAUNCH(2 | 64); else W64Q_LAUNCH(0 | 64); }
+  else { if (pre) W64Q_LAUNCH(2); else W64Q_LAUNCH(0); }
 #undef W64Q_LAUNCH
   WAN_LAUNCH_CHECK();
   return 0;
@@ -819,9 +826,9 @@ int wan_attention_w64q_sp(int phase, const bf16_t* q, const bf16_t* k, const bf1
   hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(B * H), (unsigned)nseg), dim3(256), 0, stream, k,
                      kmax_scratch, B, Lk, H, k_seg_stride);
   WAN_LAUNCH_CHECK();
-  W64Q_LAUNCH_SP(2 | 4 | 32, nseg, k_seg_stride, vt_seg_stride, own_seg);
+  W64Q_LAUNCH_SP(2 | 4 | 32 | 64, nseg, k_seg_stride, vt_seg_stride, own_seg);
   WAN_LAUNCH_CHECK();
-  W64Q_LAUNCH_SP(2, nseg, k_seg_stride, vt_seg_stride, -1);
+  W64Q_LAUNCH_SP(2 | 64, nseg, k_seg_stride, vt_seg_stride, -1);
   WAN_LAUNCH_CHECK();
 #undef W64Q_LAUNCH_SP
   return 0;

@@ -66,19 +66,29 @@ struct Dma {
   uint32_t kofs[4], vofs[4];
   int wave;
 };
+// The stream's state is wave-uniform and must LIVE in scalar registers: the bases arrive through integer divisions of the
+// workgroup id (VALU sequences), and a loop-carried value that starts in a VGPR stays there -- every step then runs on the vector
+// ALU beside the MFMAs and every DMA descriptor is rebuilt with v_readfirstlane.  These put the initial values into SGPRs.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ int64_t uni(int64_t x) {
+  const uint64_t u = (uint64_t)x;
+  return (int64_t)(((uint64_t)uni((uint32_t)(u >> 32)) << 32) | uni((uint32_t)u));
+}
+__device__ __forceinline__ const char* uni(const char* p) { return (const char*)uni((int64_t)(uintptr_t)p); }
 __device__ __forceinline__ void dma_init(Dma& d, const void* kbase, const void* vbase, int64_t kseg_bytes, int64_t vseg_bytes,
                                          int Lk, int nseg, uint32_t rs2, uint32_t ldv2, int tid, int wave, int skip = -1) {
-  d.seg = (skip == 0) ? 1 : 0;
-  d.skip = skip;
-  d.k = d.kseg0 = reinterpret_cast<const char*>(kbase) + (int64_t)d.seg * kseg_bytes;
-  d.v = d.vseg0 = reinterpret_cast<const char*>(vbase) + (int64_t)d.seg * vseg_bytes;
-  d.kseg = kseg_bytes;
-  d.vseg = vseg_bytes;
-  d.tps = (Lk + KVBLK - 1) / KVBLK;
-  d.tt = 0; d.left = d.tps * (nseg - (skip >= 0 ? 1 : 0));
-  d.klen = d.klen0 = (uint32_t)(Lk - 1) * rs2 + 256u;
-  d.rs2 = rs2;
-  d.ldv2 = ldv2;
+  d.seg = uni((skip == 0) ? 1 : 0);
+  d.skip = uni(skip);
+  d.k = d.kseg0 = uni(reinterpret_cast<const char*>(kbase) + (int64_t)d.seg * kseg_bytes);
+  d.v = d.vseg0 = uni(reinterpret_cast<const char*>(vbase) + (int64_t)d.seg * vseg_bytes);
+  d.kseg = uni(kseg_bytes);
+  d.vseg = uni(vseg_bytes);
+  d.tps = uni((Lk + KVBLK - 1) / KVBLK);
+  d.tt = uni(0); d.left = uni(d.tps * (nseg - (skip >= 0 ? 1 : 0)));
+  d.klen = d.klen0 = uni((uint32_t)(Lk - 1) * rs2 + 256u);
+  d.rs2 = uni(rs2);
+  d.ldv2 = uni(ldv2);
   const uint32_t kr0 = (uint32_t)(tid >> 4);
   const uint32_t krow0 = (kr0 & 3u) | ((kr0 & 4u) << 1) | ((kr0 & 8u) >> 1);
   const uint32_t kcol = (uint32_t)(((tid & 15) ^ (int)kr0) << 4);
@@ -116,28 +126,41 @@ __device__ __forceinline__ void dma_piece(char* smem, const Dma& d) {
   dma_piece_i<ST>(smem, d, I);
 }
 // step to the next tile; after the last tile the stream stays put (later fetches re-read it into a dead stage).
-// Branch-free (scalar selects): a taken branch in the tile loop costs ~100 cycles of instruction fetch.
+// Branch-free (scalar selects): a taken branch in the tile loop costs ~100 cycles of instruction fetch.  MULTI = false is the
+// single-segment stream (every self- / cross-attention launch outside sequence parallelism): ~10 scalar instructions per tile
+// instead of the ~60 the segment walk needs -- the compiler sinks the whole step behind the tile's last branch, i.e. into ONE MFMA
+// gap, where the long form held the matrix pipe up for 60-90 cycles per tile (the "PV_a head" of the stamps).  Flags are 0 / 1
+// integers, not bools: hipcc carried bool selects through a lane mask and a v_cndmask + v_readfirstlane round trip.
+template <bool MULTI>
 __device__ __forceinline__ void dma_advance(Dma& d) {
-  const bool adv = d.left > 1;
-  const bool sw = adv && (d.tt + 1 == d.tps);  // move to the next kv segment
-  const bool stp = adv && !sw;                 // next tile of the same segment
-  d.left -= adv ? 1 : 0;
-  d.tt = sw ? 0 : d.tt + (stp ? 1 : 0);
-  const int hop = (sw && d.seg + 1 == d.skip) ? 2 : 1;  // jump over the left-out segment
-  d.seg += sw ? hop : 0;
-  d.kseg0 = sw ? d.kseg0 + hop * d.kseg : d.kseg0;
-  d.vseg0 = sw ? d.vseg0 + hop * d.vseg : d.vseg0;
-  const char* kstep = d.k + (int64_t)KVBLK * d.rs2;
-  const char* vstep = d.v + KVBLK * 2;
-  d.k = sw ? d.kseg0 : (stp ? kstep : d.k);
-  d.v = sw ? d.vseg0 : (stp ? vstep : d.v);
-  d.klen = sw ? d.klen0 : (stp ? d.klen - (uint32_t)KVBLK * d.rs2 : d.klen);
+  const int adv = d.left > 1 ? 1 : 0;
+  d.left -= adv;
+  if (!MULTI) {
+    const uint32_t kb = adv ? (uint32_t)KVBLK * d.rs2 : 0u;
+    d.k += kb;
+    d.v += adv ? KVBLK * 2 : 0;
+    d.klen -= kb;
+    return;
+  }
+  const int last = (d.tt + 1 == d.tps) ? 1 : 0;
+  const int sw = adv & last;                                     // move to the next kv segment
+  const int stp = adv & (last ^ 1);                              // next tile of the same segment
+  const int hop2 = sw & ((d.seg + 1 == d.skip) ? 1 : 0);         // jump over the left-out segment
+  d.tt = sw ? 0 : d.tt + stp;
+  d.seg += sw ? 1 + hop2 : 0;
+  d.kseg0 = sw ? d.kseg0 + (hop2 ? 2 * d.kseg : d.kseg) : d.kseg0;
+  d.vseg0 = sw ? d.vseg0 + (hop2 ? 2 * d.vseg : d.vseg) : d.vseg0;
+  const char* kstep = d.k + (stp ? (int64_t)KVBLK * d.rs2 : (int64_t)0);
+  const char* vstep = d.v + (stp ? KVBLK * 2 : 0);
+  d.k = sw ? d.kseg0 : kstep;
+  d.v = sw ? d.vseg0 : vstep;
+  d.klen = sw ? d.klen0 : d.klen - (stp ? (uint32_t)KVBLK * d.rs2 : 0u);
 }
-template <int ST>
+template <int ST, bool MULTI>
 __device__ __forceinline__ void dma_tile(char* smem, Dma& d) {
 #pragma unroll
   for (int I = 0; I < 8; ++I) dma_piece_i<ST>(smem, d, I);
-  dma_advance(d);
+  dma_advance<MULTI>(d);
 }
 
 }  // namespace
