@@ -3,11 +3,15 @@
 import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:      # A/B against another build of the library (file name under wan2gp_amd/)
+    from wan2gp_amd import lib as _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), sys.argv[sys.argv.index("--lib") + 1])
 from wan2gp_amd import ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--M", type=int, default=151200)
 ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--lib", default=None)
 a = ap.parse_args()
 shapes = [("qkvo", a.M, 5120, 5120, 0), ("o+gate", a.M, 5120, 5120, 2), ("ffn1+gelu", a.M, 13824, 5120, 1), ("ffn2+gate", a.M, 5120, 13824, 2), ("vT", a.M // 2, 5120, 5120, 3)]
 g = torch.Generator(device="cuda").manual_seed(0)
