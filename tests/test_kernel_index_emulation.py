@@ -527,3 +527,81 @@ def test_gemm256k_epilogue_park_and_readback():
             for dword in range(4):
                 banks.add(((l31 * EROW) // 4 + dword) % 64)
         assert len(banks) == 64
+
+
+# ----------------------------------------------------------------------------------------------
+# attention: the per-wave LDS-DMA stream's step (attn_w64_shared.h: dma_advance<MULTI>) and the bounded tile's read plan
+# ----------------------------------------------------------------------------------------------
+KVBLK = 64
+
+
+def dma_stream(Lk, nseg, skip, rs2, kseg, vseg, multi, n_fetch):
+    """Transliteration of dma_init + n_fetch x (fetch, dma_advance<multi>): the (k offset, v offset, klen) each fetch uses."""
+    seg = 1 if skip == 0 else 0
+    k = kseg0 = seg * kseg
+    v = vseg0 = seg * vseg
+    tps = (Lk + KVBLK - 1) // KVBLK
+    tt, left = 0, tps * (nseg - (1 if skip >= 0 else 0))
+    klen = klen0 = (Lk - 1) * rs2 + 256
+    out = []
+    for _ in range(n_fetch):
+        out.append((k, v, klen))
+        adv = 1 if left > 1 else 0
+        left -= adv
+        if not multi:
+            kb = KVBLK * rs2 if adv else 0
+            k += kb; v += KVBLK * 2 if adv else 0; klen -= kb
+            continue
+        last = 1 if tt + 1 == tps else 0
+        sw, stp = adv & last, adv & (last ^ 1)
+        hop2 = sw & (1 if seg + 1 == skip else 0)
+        tt = 0 if sw else tt + stp
+        seg += (1 + hop2) if sw else 0
+        kseg0 = kseg0 + (2 * kseg if hop2 else kseg) if sw else kseg0
+        vseg0 = vseg0 + (2 * vseg if hop2 else vseg) if sw else vseg0
+        kstep, vstep = k + (KVBLK * rs2 if stp else 0), v + (KVBLK * 2 if stp else 0)
+        k = kseg0 if sw else kstep
+        v = vseg0 if sw else vstep
+        klen = klen0 if sw else klen - (KVBLK * rs2 if stp else 0)
+    return out
+
+
+def dma_stream_reference(Lk, nseg, skip, rs2, kseg, vseg, n_fetch):
+    """What the stream must deliver: the tiles of every segment but `skip`, in order; then the last tile again and again."""
+    tps = (Lk + KVBLK - 1) // KVBLK
+    seq = [(s * kseg + t * KVBLK * rs2, s * vseg + t * KVBLK * 2, (Lk - 1) * rs2 + 256 - t * KVBLK * rs2)
+           for s in range(nseg) if s != skip for t in range(tps)]
+    return [seq[min(i, len(seq) - 1)] for i in range(n_fetch)]
+
+
+@pytest.mark.parametrize("Lk,nseg,skip", [(75600, 1, -1), (512, 1, -1), (257, 1, -1), (64, 1, -1), (9450, 8, 3), (9450, 8, 0),
+                                          (9450, 8, 7), (100, 2, 1), (100, 2, 0), (130, 3, -1), (37800, 2, -1)])
+def test_attention_dma_stream_step_both_forms(Lk, nseg, skip):
+    rs2, kseg, vseg = 40 * 256, 10 ** 9 + 64, 7 * 10 ** 8 + 128
+    tps = (Lk + KVBLK - 1) // KVBLK
+    n = tps * (nseg - (1 if skip >= 0 else 0)) + 5               # the kernel fetches two tiles ahead: past the end it must stay put
+    ref = dma_stream_reference(Lk, nseg, skip, rs2, kseg, vseg, n)
+    assert dma_stream(Lk, nseg, skip, rs2, kseg, vseg, True, n) == ref
+    if nseg == 1 and skip < 0:                                    # the short form is what single-segment launches instantiate
+        assert dma_stream(Lk, nseg, skip, rs2, kseg, vseg, False, n) == ref
+    # the K descriptor's num_records ends at the segment's last valid row: a ragged last tile reads zeros beyond it
+    last = ref[tps - 1]
+    assert last[2] == ((Lk - 1) % KVBLK) * rs2 + 256
+
+
+def test_bounded_tile_read_plan_register_lifetimes():
+    """tile_w64n's LDS read plan (attention_w64q.hip): K(t+1) fragment r (need order: S MFMA i consumes fragment i) is read at gap
+    33 + r -- after its register's last reader (S_b's MFMA at gap 32 + r) and >= 15 gaps before the tile ends, so the single
+    lgkmcnt(0) at the next tile's top finds every read retired; V^T(t) fragment f is read at gap 17 + f, after PV_b's MFMA f
+    (gap 16 + f) read the register's previous content and before PV_a (gaps 48..63) needs the new one."""
+    for r in range(16):
+        g = 33 + r
+        assert g > 32 + r and g <= 48 and (64 - g) >= 15
+        f = (r & 1) * 8 + (r >> 1)                                  # register index [sub-tile][k-step]
+        i_next = r                                                  # S_a MFMA i of the next tile uses kf[i & 1][i >> 1]
+        assert (f >> 3, f & 7) == (i_next & 1, i_next >> 1)
+        assert (64 - g) + i_next >= 15                              # gaps between the read and its first consumer
+    for f in range(16):
+        g = 17 + f
+        assert g > 16 + f and g <= 32 and 48 + (f >> 2) * 4 - g >= 16 - f + 4 * (f >> 2) - 1
+    assert sorted({(r & 1) * 8 + (r >> 1) for r in range(16)}) == list(range(16))

@@ -146,6 +146,11 @@ class WanAny2VHIP:
         m0 = self.vace_encode_masks(input_masks, input_ref_images)
         return [torch.cat([zz, mm.to(zz.dtype)], dim=0) for zz, mm in zip(z0, m0)]
 
+    def get_loras_transformer(self, get_model_recursive_prop, base_model_type, model_type, video_prompt_type, model_mode, **kwargs):
+        """wgp.py asks the pipeline for model-specific preloaded LoRAs (any2video.py:1828-1839): only the `animate` and
+        `vace_ditto_14B` model types have any, neither of which this backend serves -> none."""
+        return [], []
+
     def generate(self, input_prompt=None, n_prompt="", context=None, context_null=None, width=1280, height=720,
                  frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
                  guide2_scale=5.0, guide3_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
