@@ -329,6 +329,7 @@ def main():
                          "traffic": traffic, "launches": n, "avg_ms": ms / n if n else None,
                          "flop_per_launch": attn_flops, "other_kernels": kern},
             "step_TFLOPs": 2 * forward_flops(cfg, L) / (dt / args.steps) / 1e12,
+            "forwards_per_s": 2 * args.steps / dt,          # a CFG step is two forwards (SURVEY.md section 8d reports both)
         }
         if e2e is not None:
             out["e2e"] = e2e
