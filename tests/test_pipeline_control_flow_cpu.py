@@ -364,3 +364,54 @@ def test_return_latent_slice_hands_back_the_requested_latent_frames():
     out = run(WanAny2VHIP(FakeDiT("A"), device="cpu"), return_latent_slice=slice(-2, None))
     assert tuple(out["latent_slice"].shape) == (1, 16, 2, 8, 8) and torch.equal(out["latent_slice"], out["latents"][:, :, -2:])
     assert run(WanAny2VHIP(FakeDiT("A"), device="cpu"))["latent_slice"] is None
+
+
+def test_video_to_video_cuts_the_schedule_or_reinjects_and_pins_unmasked_regions():
+    """"G" in video_prompt_type (any2video.py:1004-1044, :1504-1515, :1737-1740; the arithmetic itself is pinned to the reference's
+    statements in tests/test_v2v_vs_golden.py): what generate() does around it -- the Python scheduler mirror with its tables cut
+    short, real_step_no offset, the first forward seeing the noised source, the re-injection path for a source shorter than the
+    clip, the masked merge behind the scheduler step."""
+    from oracle.make_golden_i2v_cond import FakeVAE
+
+    class Rec(FakeDiT):
+        def __call__(self, x, t, context, **kw):
+            self.seen = getattr(self, "seen", []) + [(x[0].clone(), kw.get("real_step_no"))]
+            return super().__call__(x, t, context, **kw)
+
+    g = torch.Generator().manual_seed(0)
+    vid = torch.rand(3, 9, 64, 64, generator=g) * 2 - 1
+    vae = FakeVAE()
+    src = vae.encode([vid])[0].unsqueeze(0)
+    # (a) the source covers the clip: 6 steps at strength 0.5 -> the last 3 steps only, starting from the noised source
+    m = Rec("A")
+    out = run(WanAny2VHIP(m, vae=vae, device="cpu"), input_frames=vid, video_prompt_type="G", denoising_strength=0.5, guide_scale=1.0)
+    assert len(m.calls) == 3 and [r for _, r in m.seen] == [3, 4, 5]
+    ts_all = schedulers.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, use_dynamic_shifting=False)
+    ts_all.set_timesteps(6, device="cpu", shift=5.0)
+    assert [c["t"] for c in m.calls] == [float(v) for v in ts_all.timesteps[3:]]
+    x0, sigma = m.seen[0][0], float(ts_all.timesteps[3]) / 1000
+    noise = (x0 - (1 - sigma) * src) / sigma                              # what must have been the initial noise
+    assert abs(float(noise.mean())) < 0.05 and abs(float(noise.std()) - 1.0) < 0.05
+    assert torch.isfinite(out["latents"]).all()
+    # (b) without "G" the same arguments are a plain generation (and input_frames without masks is refused as a VACE input)
+    with pytest.raises(ValueError):
+        run(WanAny2VHIP(FakeDiT("A"), vae=vae, device="cpu"), input_frames=vid, denoising_strength=0.5)
+    # (c) a source shorter than the clip: every step runs, the first injection steps see the noised source in front
+    m = Rec("A")
+    run(WanAny2VHIP(m, vae=vae, device="cpu"), input_frames=vid[:, :5], video_prompt_type="G", denoising_strength=0.5, guide_scale=1.0)
+    assert len(m.calls) == 6 and [r for _, r in m.seen] == list(range(6))
+    src5 = vae.encode([vid[:, :5]])[0].unsqueeze(0)
+    for k in range(4):                                                    # steps 0..3 (i <= injection step 3) are re-injected
+        sg = float(ts_all.timesteps[k]) / 1000
+        z = (m.seen[k][0][:, :, :2] - (1 - sg) * src5) / sg
+        assert torch.allclose(z, (m.seen[0][0][:, :, :2] - (1 - float(ts_all.timesteps[0]) / 1000) * src5) / (float(ts_all.timesteps[0]) / 1000),
+                              atol=1e-4)                                  # always the same initial noise
+    # (d) a mask: outside it the result of the masked steps is the source at the next step's noise level
+    mask = torch.zeros(1, 9, 64, 64)
+    mask[..., :32] = 1                                                    # regenerate the left half only
+    m = Rec("A")
+    out = run(WanAny2VHIP(m, vae=vae, device="cpu"), input_frames=vid, input_masks=mask, video_prompt_type="G", denoising_strength=0.5,
+              masking_strength=1.0, guide_scale=1.0)
+    right = out["latents"][..., 4:]
+    assert torch.allclose(right, src[..., 4:], atol=1e-5)                 # last step: sigma_next = 0 -> exactly the source
+    assert not torch.allclose(out["latents"][..., :4], src[..., :4], atol=1e-2)

@@ -28,8 +28,10 @@ class WanAny2VHIP:
         self.vae_stride, self.patch_size = vae_stride, patch_size
         self._interrupt = False
 
-    def _scheduler(self, sample_solver, sampling_steps, shift):
-        if sample_solver in ("unipc", "", "euler") and torch.device(self.device).type == "cuda":
+    def _scheduler(self, sample_solver, sampling_steps, shift, native=True):
+        """native=False: the Python mirrors even on a GPU -- their `timesteps` / `sigmas` tables can be cut short by the caller
+        (video-to-video, any2video.py:1029-1033); the library's scheduler object owns its tables."""
+        if native and sample_solver in ("unipc", "", "euler") and torch.device(self.device).type == "cuda":
             s = HipScheduler("euler" if sample_solver == "euler" else "unipc", num_train_timesteps=self.num_train_timesteps)
             s.set_timesteps(sampling_steps, device=self.device, shift=shift)          # wan_sched_* of the C ABI
         elif sample_solver == "euler":
@@ -158,7 +160,8 @@ class WanAny2VHIP:
                  loras_slists=None, switch2_threshold=0, enable_RIFLEx=False, cfg_star_switch=0, cfg_zero_step=5, apg_switch=0,
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
                  motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, image_end=None,
-                 return_latent_slice=None, **bbargs):
+                 return_latent_slice=None, video_prompt_type="", denoising_strength=1.0, masking_strength=1.0, keep_frames_parsed=None,
+                 prefix_frames_count=0, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -186,7 +189,11 @@ class WanAny2VHIP:
             raise ValueError("a Wan2.1 i2v model (model_type 'i2v') needs clip_fea [1,257,1280]: the CLIP vision features of the "
                              "start image (any2video.py:721-729)")
         dev = self.device
-        sample_scheduler, timesteps = self._scheduler(sample_solver, sampling_steps, shift)
+        # video-to-video ("G" in video_prompt_type, any2video.py:1004-1044): start from the VAE latents of `input_frames`
+        v2v_on = "G" in (video_prompt_type or "") and input_frames is not None
+        if not v2v_on:
+            denoising_strength = 1                                                      # :1044
+        sample_scheduler, timesteps = self._scheduler(sample_solver, sampling_steps, shift, native=not (v2v_on and denoising_strength < 1))
         seed_g = torch.Generator(device=dev)
         seed_g.manual_seed(seed if seed >= 0 else torch.seed() % (2 ** 31))
         lat_frames = (frame_num - 1) // self.vae_stride[0] + 1                       # any2video.py:647
@@ -221,8 +228,22 @@ class WanAny2VHIP:
             if getattr(self.model, "model_type", None) != "ti2v2_2" or self.vae is None:
                 raise ValueError("input_video (timestep injection) is the ti2v_2_2 conditioning path and needs the Wan2.2 VAE")
             source_latents = self.vae.encode([input_video.to(dev)], VAE_tile_size)[0].unsqueeze(0)
+        v2v, v2v_src, randn, start_step_no = None, None, None, 0
+        if v2v_on:
+            from . import video2video
+            if self.vae is None:
+                raise ValueError("video-to-video needs a VAE to encode input_frames")
+            if tuple(input_frames.shape[-2:]) != (height, width):
+                raise ValueError(f"input_frames are {tuple(input_frames.shape[-2:])}, height x width = {(height, width)} (any2video.py:1005)")
+            v2v_src = self.vae.encode([input_frames.to(dev)], VAE_tile_size)[0].unsqueeze(0)              # :1006
+            v2v = video2video.plan(input_frames, None if input_masks is None else input_masks.to(dev), v2v_src, lat_frames, sampling_steps,
+                                   denoising_strength, masking_strength, list(keep_frames_parsed or []), prefix_frames_count, timesteps,
+                                   sample_scheduler, device=dev, video_prompt_type=video_prompt_type)
+            timesteps, start_step_no = v2v.timesteps, v2v.start_step_no
+            randn = latents                                                                  # :1475 -- the SAME tensor, as there
         vace_kwargs = {}
-        if input_frames is not None:                         # VACE control video + mask (any2video.py:1128-1147), no reference images
+        if input_frames is not None and (not v2v_on or getattr(self.model, "vace_layers", None) is not None):
+            # VACE control video + mask (any2video.py:1128-1147), no reference images
             if self.vae is None or input_masks is None:
                 raise ValueError("VACE needs a VAE, input_frames [3,T,H,W] and input_masks [1,T,H,W]")
             z = self.vace_context([input_frames.to(dev)], [input_masks.to(dev)], None, VAE_tile_size)
@@ -293,7 +314,9 @@ class WanAny2VHIP:
                     latents[:, :, :n_src] = source_latents
                     timestep = torch.full((target_shape[1],), int(t), dtype=torch.int64, device=latents.device)
                     timestep[:n_src] = 0
-                kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": i})
+                kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": start_step_no + i})
+                if v2v is not None:                              # any2video.py:1504-1515: the noised source in front of the first steps
+                    latents = video2video.inject(latents, randn, v2v_src, t, i, denoising_strength, v2v)
                 if loras_slists is not None and getattr(trans, "loras", None) is not None:
                     trans.loras.set_step(loras_slists, len(timesteps), i, phase_switch_step, phase_switch_step2)
                 if ext_latents is not None:                      # any2video.py:1517-1523: re-noise the known first latent
@@ -337,6 +360,8 @@ class WanAny2VHIP:
                     latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents)[0]
                 else:
                     latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
+                if v2v is not None:                              # :1737-1740: outside the mask, the source at the next step's noise level
+                    latents = video2video.merge(latents, randn, v2v_src, timesteps, i, v2v)
                 if callback is not None:
                     callback(i, latents[0], False)
         finally:

@@ -105,7 +105,7 @@ class FlowUniPCMultistepScheduler:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         if self._step_index is None:                                      # index_for_timestep (:630-637)
             tv = int(timestep) if not torch.is_tensor(timestep) else int(timestep.item())
-            idx = (self._timesteps_host == tv).nonzero()
+            idx = (self.timesteps.detach().cpu() == tv).nonzero()      # the CURRENT table: video-to-video cuts it short (any2video.py:1029-1033)
             self._step_index = idx[1 if len(idx) > 1 else 0].item()
         i = self._step_index
         sig = self.sigmas
@@ -330,7 +330,7 @@ class FlowDPMSolverMultistepScheduler:
             raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
         if self._step_index is None:
             tv = int(timestep) if not torch.is_tensor(timestep) else int(timestep.item())
-            idx = (self._timesteps_host == tv).nonzero()
+            idx = (self.timesteps.detach().cpu() == tv).nonzero()      # the CURRENT table: video-to-video cuts it short (any2video.py:1029-1033)
             self._step_index = idx[1 if len(idx) > 1 else 0].item()
         i, sig, n = self._step_index, self.sigmas, len(self.timesteps)
         lower_order_final = i == n - 1                      # final_sigmas_type == "zero" (:745-748)
@@ -415,6 +415,7 @@ class LCMScheduler:
 
     def step(self, model_output, timestep, sample, **kwargs):
         if self._step_index is None:
+            self._sig_host, self._ts_host = self.sigmas.clone(), self.timesteps.clone()      # the current tables (a caller may have cut them short)
             tv = float(timestep.flatten()[0].item()) if torch.is_tensor(timestep) else float(timestep)
             idx = (self._ts_host == tv).nonzero()
             self._step_index = idx[0].item() if len(idx) > 0 else int(torch.argmin((self._ts_host - tv).abs()).item())
