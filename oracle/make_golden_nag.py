@@ -71,6 +71,18 @@ def main():
         r = ref_forward(ns, m, [lat, lat], t, [c2, cn], y=y, clip_fea=clip)
         out[f"fwd_{name}_cond"], out[f"fwd_{name}_uncond"] = f32(r[0]), f32(r[1])
         out[f"fwd_{name}_shape"], out[f"fwd_{name}_t"] = np.array([f, h, w]), np.array([tval])
+    # skip-layer guidance (any2video.py:1502, model.py:2025-2028): blocks listed in perturbation_layers run for the first stream only
+    ns.offload.shared_state.update({"_nag_scale": 0})
+    cfg = O.make_config("small")
+    W = O.synth_weights(cfg)
+    m = build_ref_model(ns, cfg, W, torch.bfloat16)
+    lat, c, cn, _ = O.synth_inputs(cfg, 3, 10, 14)
+    freqs = ns.P.get_rotary_pos_embed((3, 10, 14))
+    import types
+    with torch.no_grad():
+        r = m([lat.clone(), lat.clone()], t=torch.tensor([412]), context=[c.clone(), cn.clone()], freqs=freqs,
+              pipeline=types.SimpleNamespace(_interrupt=False), perturbation_layers=[1])
+    out["slg_small_cond"], out["slg_small_uncond"] = f32(r[0]), f32(r[1])
     out["fwd_nag"] = np.array(NAG)
     ns.offload.shared_state.update({"_nag_scale": 0})
     np.savez_compressed(OUT, **out)

@@ -475,9 +475,11 @@ def unpatchify(x, grid, cfg: WanConfig):
 def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[torch.Tensor],
                 W, cfg: WanConfig, y: Optional[torch.Tensor] = None, freqs=None,
                 dtype=torch.bfloat16, exact: bool = False, return_hidden: bool = False, clip_fea: Optional[torch.Tensor] = None,
-                vace_context=None, vace_scale=1.0, probe=None, nag=None):
+                vace_context=None, vace_scale=1.0, probe=None, nag=None, perturbation_layers=None):
     """x_list: S tensors [B,16,F,H,W] fp32; t [1]; context_list: S tensors [B,512,4096] ([2,512,4096] = positive ; negative
     prompt for a stream under normalized attention guidance, nag = (scale, tau, alpha), any2video.py:607-608).
+    perturbation_layers: block indices every stream but the first passes through unchanged (skip-layer guidance,
+    any2video.py:1502, model.py:2025-2028; joint pass, x_id 0).
     Returns S fp32 tensors [B,16,F,H,W] (model.py:2093-2097).
     probe(i, s, hidden): called with stream s's token stream after block i (error-growth tables)."""
     hs = []
@@ -499,6 +501,8 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
     hints, scales = vace_hints(vace_context, vace_scale, W, cfg, len(hs))
     for i in range(cfg.num_layers):                         # model.py:1993-2036
         for s in range(len(hs)):
+            if perturbation_layers is not None and i in perturbation_layers and s != 0:
+                continue                                    # skip-layer guidance (:2025-2028): only the first stream runs such a block
             hs[s] = block_with_hints(hs[s], None if hints is None else hints[s], scales, e0, ctxs[s], cos, sin, W, i, cfg, exact, nag)
             if probe is not None:
                 probe(i, s, hs[s])

@@ -59,3 +59,17 @@ def test_forward_with_nag_bit_exact(name):
     assert torch.equal(uncond, torch.from_numpy(G[f"fwd_{name}_uncond"]))
     plain = O.dit_forward([lat], t, [c], W, cfg, y=y, clip_fea=clip)[0]
     assert not torch.equal(plain, cond)
+
+
+def test_skip_layer_guidance_bit_exact():
+    """perturbation_layers (any2video.py:1502, model.py:2025-2028): the listed blocks run for the first stream of the joint pass
+    only -- the uncond stream passes through them unchanged.  Oracle only: the HIP forward does not take the argument yet
+    (WanModelHIP.forward raises / delegates), DESIGN.md section 8."""
+    cfg = O.make_config("small")
+    W = O.synth_weights(cfg)
+    lat, c, cn, _ = O.synth_inputs(cfg, 3, 10, 14)
+    t = torch.tensor([412], dtype=torch.int64)
+    cond, uncond = O.dit_forward([lat, lat], t, [c, cn], W, cfg, perturbation_layers=[1])
+    assert torch.equal(cond, torch.from_numpy(G["slg_small_cond"])) and torch.equal(uncond, torch.from_numpy(G["slg_small_uncond"]))
+    plain = O.dit_forward([lat, lat], t, [c, cn], W, cfg)
+    assert torch.equal(plain[0], cond) and not torch.equal(plain[1], uncond)
