@@ -47,9 +47,9 @@ def main():
     body = [l.split(";")[0].strip() for l in asm[m.end():end].split("\n")]
     body = [l for l in body if l and not l.startswith(".") and not l.endswith(":")]
     bars = [i for i, l in enumerate(body) if l.startswith("s_barrier")]
-    segs = list(zip(bars, bars[1:]))
+    segs = list(zip(bars, bars[1:] + [len(body)]))          # the last segment runs to the end of the kernel (single-barrier loops)
     if a.segment is None:
-        a.segment = next(i for i, (x, y) in enumerate(segs) if sum(1 for l in body[x:y] if l.startswith("v_mfma")) >= 64)
+        a.segment = next((i for i, (x, y) in enumerate(segs) if sum(1 for l in body[x:y] if l.startswith("v_mfma")) >= 64), 0)
     x, y = segs[a.segment]
     print(m.group(1)[:100], meta, f"segment {a.segment} of {len(segs)}: instructions {x}..{y}")
     gap, row = -1, []
