@@ -69,3 +69,14 @@ def test_model_def_properties_and_settings():
         H.load_model(["a.safetensors"], "t2v_hip", "t2v_hip", {}, quantizeTransformer=True)
     with pytest.raises(ValueError, match="not supported"):
         H.load_model(["a.safetensors"], "multitalk", "multitalk", {}, state_dicts=[{}])
+
+
+def test_model_definition_advertises_nag_and_image_prompt_types():
+    """wan_handler.py:956-978, :994: the UI reads `NAG` and `image_prompt_types_allowed` (Start / End image, Video to continue,
+    Last frames) from the model definition."""
+    from wan2gp_amd.wan_handler import family_handler as fh
+    i2v = fh.query_model_def("i2v_2_2_hip", {"URLs2": ["x"]})
+    assert i2v["NAG"] and i2v["image_prompt_types_allowed"] == "SEVL"
+    assert fh.query_model_def("t2v_2_2_hip", {})["image_prompt_types_allowed"] == "TVL"
+    assert fh.query_model_def("ti2v_2_2_hip", {})["image_prompt_types_allowed"] == "TSVL"
+    assert fh.query_model_def("vace_14B_hip", {})["NAG"]

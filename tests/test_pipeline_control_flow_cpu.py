@@ -415,3 +415,22 @@ def test_video_to_video_cuts_the_schedule_or_reinjects_and_pins_unmasked_regions
     right = out["latents"][..., 4:]
     assert torch.allclose(right, src[..., 4:], atol=1e-5)                 # last step: sigma_next = 0 -> exactly the source
     assert not torch.allclose(out["latents"][..., :4], src[..., :4], atol=1e-2)
+
+
+def test_nag_parameters_reach_a_model_driven_by_the_references_own_generate(monkeypatch):
+    """The reference publishes NAG through mmgp.offload.shared_state["_nag_*"] (any2video.py:607); a WanModelHIP used under the
+    reference's own generate() has no `.nag` set and reads them from there (WanModelHIP._nag_params)."""
+    import sys
+    import types as _t
+    from wan2gp_amd.model import WanModelHIP
+    m = object.__new__(WanModelHIP)                                     # no library: only the parameter lookup is exercised
+    m.nag = None
+    assert m._nag_params() is None
+    off = _t.ModuleType("mmgp.offload")
+    off.shared_state = {"_nag_scale": 11, "_nag_tau": 3.5, "_nag_alpha": 0.5}
+    monkeypatch.setitem(sys.modules, "mmgp.offload", off)
+    assert m._nag_params() == (11.0, 3.5, 0.5)
+    off.shared_state["_nag_scale"] = 1                                  # nag_scale <= 1: off (model.py:260)
+    assert m._nag_params() is None
+    m.nag = (2.0, 2.5, 0.25)                                            # an explicit setting wins
+    assert m._nag_params() == (2.0, 2.5, 0.25)
