@@ -61,7 +61,8 @@ def test_model_def_properties_and_settings():
     assert d["i2v_class"] and d["black_frame"] and d["motion_amplitude"] and d["profiles_dir"] == ["wan_i2v"] and d["tea_cache"]
     ui = {}
     H.update_default_settings("i2v_2_2_hip", {"image_prompt_types_allowed": "SEV"}, ui)
-    assert ui == {"sample_solver": "unipc", "image_prompt_type": "S"}
+    assert ui == {"sample_solver": "unipc", "image_prompt_type": "S", "masking_strength": 0.1, "denoising_strength": 0.9,
+                  "sliding_window_overlap": 1, "sliding_window_color_correction_strength": 0}          # wan_handler.py:1441-1449
     assert H.validate_generative_settings("t2v_hip", {}, {"sample_solver": "euler"}) is None
     assert "Unsupported" in H.validate_generative_settings("t2v_hip", {}, {"sample_solver": "ddim"})
     assert H.query_model_family() == "wan" and H.query_model_files(None, "t2v_hip") == []
@@ -80,3 +81,86 @@ def test_model_definition_advertises_nag_and_image_prompt_types():
     assert fh.query_model_def("t2v_2_2_hip", {})["image_prompt_types_allowed"] == "TVL"
     assert fh.query_model_def("ti2v_2_2_hip", {})["image_prompt_types_allowed"] == "TSVL"
     assert fh.query_model_def("vace_14B_hip", {})["NAG"]
+
+
+def _ref_update_default_settings():
+    """wan_handler.update_default_settings (:1252-1455) lifted from the reference with `ast`, together with the module-level
+    `test_*` predicates it calls (bodies untouched).  None when the reference tree is absent."""
+    src = os.path.join(REF, "models", "wan", "wan_handler.py")
+    if not os.path.isfile(src):
+        return None
+    tree = ast.parse(open(src).read())
+    preds = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name.startswith("test_")]
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "family_handler")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "update_default_settings")
+    fn.decorator_list = []
+    # `test_scail2` is imported from models/wan/scail2/__init__.py: lift it (and the constants it reads) from there
+    s2 = ast.parse(open(os.path.join(REF, "models", "wan", "scail2", "__init__.py")).read())
+    s2_fn = next(n for n in s2.body if isinstance(n, ast.FunctionDef) and n.name == "test_scail2")
+    used = {n.id for n in ast.walk(s2_fn) if isinstance(n, ast.Name)}
+    s2_consts = [n for n in s2.body if isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id in used for t in n.targets)]
+    ns = {}
+    exec(compile(ast.Module(body=s2_consts + [s2_fn] + preds + [fn], type_ignores=[]), src, "exec"), ns)
+    return ns["update_default_settings"]
+
+
+@pytest.mark.parametrize("b,model_def", [("t2v", {}), ("t2v_1.3B", {}), ("t2v_2_2", {"multiple_submodels": True}),
+                                         ("i2v", {}), ("i2v_2_2", {"multiple_submodels": True}), ("ti2v_2_2", {}),
+                                         ("vace_14B", {}), ("vace_1.3B", {})])
+def test_default_settings_equal_the_references(b, model_def):
+    """For every supported type the defaults the HIP handler writes are the ones the reference's own function writes for the
+    corresponding built-in type (run on the lifted function in the build container)."""
+    ref = _ref_update_default_settings()
+    if ref is None:
+        pytest.skip("reference tree not present")
+    from wan2gp_amd.wan_handler import family_handler as H
+    md = dict(H.query_model_def(b + "_hip", {"URLs2": ["x"]} if model_def.get("multiple_submodels") else {}), **model_def)
+    want, got = {}, {}
+    ref(b, dict(md), want)
+    H.update_default_settings(b + "_hip", dict(md), got)
+    assert got == want, (b, got, want)
+
+
+def _ref_query_model_def():
+    """wan_handler.query_model_def (:216-1007) lifted with `ast` together with every module-level function / constant it may read;
+    UI-only names (gradio, file locator, prompt-info tables of other variants) are inert stand-ins."""
+    src = os.path.join(REF, "models", "wan", "wan_handler.py")
+    if not os.path.isfile(src):
+        return None
+    tree = ast.parse(open(src).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "family_handler")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "query_model_def")
+    fn.decorator_list = []
+    s2 = ast.parse(open(os.path.join(REF, "models", "wan", "scail2", "__init__.py")).read())
+    body = ([n for n in s2.body if isinstance(n, ast.Assign)] + [n for n in s2.body if isinstance(n, ast.FunctionDef) and n.name.startswith("test_scail2")]
+            + [n for n in tree.body if isinstance(n, (ast.Assign, ast.FunctionDef))] + [fn])
+
+    class Inert:
+        def __getattr__(self, k): return Inert()
+        def __call__(self, *a, **k): return Inert()
+        def __getitem__(self, k): return Inert()
+        def __iter__(self): return iter([])
+    import re as _re
+    ns = {"os": os, "re": _re, "gr": Inert(), "fl": Inert(), "VACE_INFOS": "", "SHOTPLAN_PROMPT_ENHANCER": "", "SHOTPLAN_PROMPT_INFOS": "",
+          "get_bernini_infos": lambda *a, **k: "", "get_bernini_prompt_infos": lambda *a, **k: "",
+          "get_kiwi_variant_model_def": lambda *a, **k: {}, "build_hf_url": lambda *a, **k: "url"}
+    exec(compile(ast.Module(body=body, type_ignores=[]), src, "exec"), ns)
+    return ns["query_model_def"]
+
+
+@pytest.mark.parametrize("b,md", [("t2v", {}), ("t2v_1.3B", {}), ("t2v_2_2", {"URLs2": ["x"]}), ("i2v", {}), ("i2v_2_2", {"URLs2": ["x"]}),
+                                  ("ti2v_2_2", {}), ("vace_14B", {}), ("vace_1.3B", {})])
+def test_model_definition_agrees_with_the_references_on_every_shared_property(b, md):
+    """Every property both handlers write (class flags, fps, frame grid, VAE block size, profile folders, samplers, guidance /
+    step-skipping capabilities, NAG, image prompt types, ...) has the reference's value for the corresponding built-in type --
+    except `compile` (the reference names modules for torch.compile; nothing to compile here).  Properties only the reference
+    writes are UI features this backend does not claim (`perturbation`, `self_refiner`, upsamplers, ...)."""
+    ref = _ref_query_model_def()
+    if ref is None:
+        pytest.skip("reference tree not present")
+    from wan2gp_amd.wan_handler import family_handler as H
+    want, got = ref(b, dict(md)), H.query_model_def(b + "_hip", dict(md))
+    shared = (set(want) & set(got)) - {"compile"}
+    assert len(shared) >= 28
+    assert {k: got[k] for k in shared} == {k: want[k] for k in shared}
+    assert not got.get("perturbation") and not got.get("self_refiner")          # not claimed: skip-layer guidance, self-refiner

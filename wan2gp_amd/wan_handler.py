@@ -42,7 +42,7 @@ def test_class_i2v(base_model_type):            # wan_handler.py:16-17 restricte
 
 
 def test_class_t2v(base_model_type):
-    return base_of(base_model_type) in ("t2v", "t2v_1.3B", "t2v_2_2")
+    return base_of(base_model_type) in ("t2v", "t2v_2_2")       # wan_handler.py:35-36: the 1.3B model is not in the reference's list
 
 
 def test_class_1_3B(base_model_type):
@@ -194,9 +194,23 @@ class family_handler():
     @staticmethod
     def update_default_settings(base_model_type, model_def, ui_defaults):
         """Defaults of wan_handler.update_default_settings (:1252-1455) for the supported types."""
+        b = base_of(base_model_type)
         ui_defaults.update({"sample_solver": "unipc"})
         if test_class_i2v(base_model_type) and "S" in model_def.get("image_prompt_types_allowed", ""):
             ui_defaults["image_prompt_type"] = "S"
+        if b == "vace_14B":                                                             # :1317-1320
+            ui_defaults.update({"sliding_window_discard_last_frames": 0})
+        elif b == "ti2v_2_2":                                                           # :1322-1325
+            ui_defaults.update({"image_prompt_type": "T"})
+        if test_wan_5B(b):                                                              # :1436-1439
+            ui_defaults.update({"sliding_window_size": 121})
+        if b == "i2v_2_2":                                                              # :1441-1442
+            ui_defaults.update({"masking_strength": 0.1, "denoising_strength": 0.9})
+        if test_class_i2v(b) or test_wan_5B(b):                                         # test_oneframe_overlap (:41-42, :1447-1449)
+            ui_defaults["sliding_window_overlap"] = 1
+            ui_defaults["sliding_window_color_correction_strength"] = 0
+        if model_def.get("multiple_submodels", False):                                  # :1454-1455
+            ui_defaults["guidance_phases"] = 2
 
     @staticmethod
     def validate_generative_settings(base_model_type, model_def, inputs):
