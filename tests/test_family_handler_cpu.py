@@ -164,3 +164,39 @@ def test_model_definition_agrees_with_the_references_on_every_shared_property(b,
     assert len(shared) >= 28
     assert {k: got[k] for k in shared} == {k: want[k] for k in shared}
     assert not got.get("perturbation") and not got.get("self_refiner")          # not claimed: skip-layer guidance, self-refiner
+
+
+def _ref_static(name):
+    """A static method of the reference's family_handler lifted with the module-level predicates (see _ref_update_default_settings)."""
+    src = os.path.join(REF, "models", "wan", "wan_handler.py")
+    if not os.path.isfile(src):
+        return None
+    tree = ast.parse(open(src).read())
+    preds = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name.startswith("test_")]
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "family_handler")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    fn.decorator_list = []
+    s2 = ast.parse(open(os.path.join(REF, "models", "wan", "scail2", "__init__.py")).read())
+    s2_body = [n for n in s2.body if isinstance(n, ast.Assign)] + [n for n in s2.body if isinstance(n, ast.FunctionDef) and n.name.startswith("test_scail2")]
+    ns = {}
+    exec(compile(ast.Module(body=s2_body + preds + [fn], type_ignores=[]), src, "exec"), ns)
+    return ns[name]
+
+
+@pytest.mark.parametrize("b", ["t2v", "t2v_1.3B", "t2v_2_2", "i2v", "i2v_2_2", "ti2v_2_2", "vace_14B", "vace_1.3B"])
+def test_fix_settings_migrates_old_settings_like_the_reference(b):
+    ref = _ref_static("fix_settings")
+    if ref is None:
+        pytest.skip("reference tree not present")
+    from wan2gp_amd.wan_handler import family_handler as H
+    md0 = H.query_model_def(b + "_hip", {"URLs2": ["x"]} if b.endswith("2_2") and b != "ti2v_2_2" else {})
+    saved = [{}, {"sample_solver": ""}, {"sample_solver": "euler", "switch_threshold": 875}, {"guidance_phases": 2}, {"guidance_phases": 2, "image_prompt_type": "S"},
+             {"image_prompt_type": "", "sliding_window_overlap": 5}]
+    for version in (2.0, 2.23, 2.24, 2.3, 2.31, 2.32, 2.46, 2.47, 2.6):
+        for extra in ({}, {"loras_multipliers": ["1;0;0", "0;1;0"]}, {"self_refiner": True}):
+            for ui in saved:
+                md = dict(md0, **extra)
+                want, got = dict(ui), dict(ui)
+                ref(b, version, dict(md), want)
+                H.fix_settings(b + "_hip", version, dict(md), got)
+                assert got == want, (b, version, extra, ui, got, want)

@@ -189,7 +189,30 @@ class family_handler():
 
     @staticmethod
     def fix_settings(base_model_type, settings_version, model_def, ui_defaults):
-        return None
+        """Migration of saved settings of older versions (wan_handler.fix_settings, :1161-1250), the branches that apply to the
+        supported types: empty solver name, guidance phases of two-expert models, three-phase LoRA multipliers, the one-frame
+        sliding-window overlap of the i2v / 5B models, the start-image default, a self-refiner plan stored as a list."""
+        b = base_of(base_model_type)
+        if ui_defaults.get("sample_solver", "") == "":
+            ui_defaults["sample_solver"] = "unipc"
+        if settings_version < 2.24:
+            if (model_def.get("multiple_submodels", False) or ui_defaults.get("switch_threshold", 0) > 0) and ui_defaults.get("guidance_phases", 0) < 2:
+                ui_defaults["guidance_phases"] = 2
+        if settings_version == 2.24 and ui_defaults.get("guidance_phases", 0) == 2:
+            mult = model_def.get("loras_multipliers", "")
+            if len(mult) > 1 and len(mult[0].split(";")) == 3:
+                ui_defaults["guidance_phases"] = 3
+        if settings_version < 2.31 and (test_class_i2v(b) or test_wan_5B(b)):          # test_oneframe_overlap
+            ui_defaults["sliding_window_overlap"] = 1
+        if settings_version < 2.32:
+            if test_class_i2v(b) and len(ui_defaults.get("image_prompt_type", "")) == 0 and "S" in model_def.get("image_prompt_types_allowed", ""):
+                ui_defaults["image_prompt_type"] = "S"
+        if model_def.get("self_refiner", False) and settings_version < 2.47:
+            ui_defaults["self_refiner_setting"] = 0
+            ui_defaults["self_refiner_plan"] = ""
+        if model_def.get("self_refiner", False) and settings_version < 2.48:
+            ui_defaults["self_refiner_f_uncertainty"] = 0.1
+            ui_defaults["self_refiner_certain_percentage"] = 0.999
 
     @staticmethod
     def update_default_settings(base_model_type, model_def, ui_defaults):
