@@ -200,3 +200,24 @@ def test_fix_settings_migrates_old_settings_like_the_reference(b):
                 ref(b, version, dict(md), want)
                 H.fix_settings(b + "_hip", version, dict(md), got)
                 assert got == want, (b, version, extra, ui, got, want)
+
+
+@pytest.mark.parametrize("b,md", [("t2v", {}), ("t2v", {"URLs2": ["x"]}), ("t2v_1.3B", {}), ("t2v_2_2", {"URLs2": ["x"]}), ("i2v", {}),
+                                  ("i2v_2_2", {"URLs2": ["x"]}), ("ti2v_2_2", {}), ("vace_14B", {}), ("vace_1.3B", {})])
+def test_set_cache_parameters_hands_over_the_references_calibration_tables(b, md):
+    """wgp.py:7079 calls handler.set_cache_parameters when TeaCache / MagCache is switched on: same tables, chosen the same way
+    (model class; resolution for the Wan2.1 i2v model; start image + source video for the 5B model) as the lifted reference
+    function, into the same attribute bag."""
+    ref = _ref_static("set_cache_parameters")
+    if ref is None:
+        pytest.skip("reference tree not present")
+    from wan2gp_amd.skipcache import SkipStepsCache
+    from wan2gp_amd.wan_handler import family_handler as H
+    for cache_type in ("mag", "tea"):
+        for inputs in ({"resolution": "832x480"}, {"resolution": "1280x720"},
+                       {"resolution": "1280x704", "image_start": object(), "video_source": "v.mp4"}):
+            want, got = SkipStepsCache(), SkipStepsCache()
+            ref(cache_type, b, dict(md), dict(inputs), want)
+            H.set_cache_parameters(cache_type, b + "_hip", dict(md), dict(inputs), got)
+            assert got.__dict__ == want.__dict__, (b, cache_type, inputs)
+            assert len(getattr(got, "def_mag_ratios", getattr(got, "coefficients", []))) in (5, 78, 98)

@@ -188,6 +188,42 @@ class family_handler():
         return pipe, {"pipe": {}}
 
     @staticmethod
+    def set_cache_parameters(cache_type, base_model_type, model_def, inputs, skip_steps_cache):
+        """wan_handler.set_cache_parameters (:172-214; called from wgp.py:7079 when step skipping is switched on): hands the
+        per-model calibration data to the cache object -- MagCache magnitude ratios (+ threshold 0, K 2) or the TeaCache rescale
+        polynomial, picked by model class and, for the Wan2.1 i2v model, by resolution.  The tables are the reference's literals
+        (wan2gp_amd/data/skip_cache_tables.json, extracted by oracle/extract_cache_tables.py)."""
+        import json
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "skip_cache_tables.json")) as f:
+            tables = json.load(f)
+        b = base_of(base_model_type)
+        i2v = test_class_i2v(b)
+        width, height = inputs["resolution"].split("x")
+        pixels = int(width) * int(height)
+        if cache_type == "mag":
+            skip_steps_cache.update({"magcache_thresh": 0, "magcache_K": 2})
+            if b == "t2v" and "URLs2" in model_def:
+                key = "t2v_two_experts"
+            elif b == "i2v_2_2":
+                key = "i2v_2_2"
+            elif test_wan_5B(b):
+                both = inputs.get("image_start", None) is not None and inputs.get("video_source", None) is not None
+                key = "ti2v_5B_with_start_image_and_source_video" if both else "ti2v_5B"
+            elif test_class_1_3B(b):
+                key = "t2v_1.3B"
+            elif i2v:
+                key = "i2v_720p" if pixels >= 1280 * 720 else "i2v_480p"
+            else:
+                key = "t2v_14B"
+            skip_steps_cache.def_mag_ratios = list(tables["mag_ratios"][key])
+        else:
+            if i2v:
+                key = "i2v_720p" if pixels >= 1280 * 720 else "i2v_480p"
+            else:
+                key = "t2v_1.3B" if test_class_1_3B(b) else "t2v_14B"
+            skip_steps_cache.coefficients = list(tables["tea_coefficients"][key])
+
+    @staticmethod
     def fix_settings(base_model_type, settings_version, model_def, ui_defaults):
         """Migration of saved settings of older versions (wan_handler.fix_settings, :1161-1250), the branches that apply to the
         supported types: empty solver name, guidance phases of two-expert models, three-phase LoRA multipliers, the one-frame
