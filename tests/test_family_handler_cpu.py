@@ -178,7 +178,7 @@ def _ref_static(name):
     fn.decorator_list = []
     s2 = ast.parse(open(os.path.join(REF, "models", "wan", "scail2", "__init__.py")).read())
     s2_body = [n for n in s2.body if isinstance(n, ast.Assign)] + [n for n in s2.body if isinstance(n, ast.FunctionDef) and n.name.startswith("test_scail2")]
-    ns = {}
+    ns = {"os": os}
     exec(compile(ast.Module(body=s2_body + preds + [fn], type_ignores=[]), src, "exec"), ns)
     return ns[name]
 
@@ -221,3 +221,16 @@ def test_set_cache_parameters_hands_over_the_references_calibration_tables(b, md
             H.set_cache_parameters(cache_type, b + "_hip", dict(md), dict(inputs), got)
             assert got.__dict__ == want.__dict__, (b, cache_type, inputs)
             assert len(getattr(got, "def_mag_ratios", getattr(got, "coefficients", []))) in (5, 78, 98)
+
+
+@pytest.mark.parametrize("b", ["t2v", "t2v_1.3B", "t2v_2_2", "i2v", "i2v_2_2", "ti2v_2_2", "vace_14B", "vace_1.3B"])
+def test_lora_folders_are_the_builtin_types(b):
+    """wan_handler.get_lora_dir (:150-168): same folder, same command-line overrides as the built-in type."""
+    import types
+    ref = _ref_static("get_lora_dir")
+    if ref is None:
+        pytest.skip("reference tree not present")
+    from wan2gp_amd.wan_handler import family_handler as H
+    for args in (types.SimpleNamespace(), types.SimpleNamespace(lora_dir="/x/t2v", lora_dir_i2v="/x/i2v"),
+                 types.SimpleNamespace(lora_dir_wan="/y/wan", lora_dir_wan_i2v="/y/i2v", lora_dir_wan_1_3b="/y/1.3", lora_dir_wan_5b="/y/5")):
+        assert H.get_lora_dir(b + "_hip", args, "loras") == ref(b, args, "loras"), (b, vars(args))

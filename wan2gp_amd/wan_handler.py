@@ -188,6 +188,25 @@ class family_handler():
         return pipe, {"pipe": {}}
 
     @staticmethod
+    def get_lora_dir(base_model_type, args, lora_root):
+        """wan_handler.get_lora_dir (:150-168; wgp.py:2482-2490 asks the handler): the HIP types read LoRAs from the same folders
+        as the built-in Wan types they stand for -- `wan_i2v` for the Wan2.1 i2v model, `wan_1.3B`, `wan_5B`, else `wan` -- with
+        the same command-line overrides.  (`register_lora_cli_args` is left to the built-in handler: the flags exist once.)"""
+        b = base_of(base_model_type)
+        i2v = test_class_i2v(b) and not test_i2v_2_2(b)
+        wan_dir = getattr(args, "lora_dir_wan", None) or getattr(args, "lora_dir", None) or os.path.join(lora_root, "wan")
+        wan_i2v_dir = getattr(args, "lora_dir_wan_i2v", None) or getattr(args, "lora_dir_i2v", None) or os.path.join(lora_root, "wan_i2v")
+        wan_1_3b_dir = getattr(args, "lora_dir_wan_1_3b", None) or os.path.join(lora_root, "wan_1.3B")
+        wan_5b_dir = getattr(args, "lora_dir_wan_5b", None) or os.path.join(lora_root, "wan_5B")
+        if i2v:
+            return wan_i2v_dir
+        if "1.3B" in b:
+            return wan_1_3b_dir
+        if test_wan_5B(b):
+            return wan_5b_dir
+        return wan_dir
+
+    @staticmethod
     def set_cache_parameters(cache_type, base_model_type, model_def, inputs, skip_steps_cache):
         """wan_handler.set_cache_parameters (:172-214; called from wgp.py:7079 when step skipping is switched on): hands the
         per-model calibration data to the cache object -- MagCache magnitude ratios (+ threshold 0, K 2) or the TeaCache rescale
