@@ -154,7 +154,7 @@ def test_model_definition_agrees_with_the_references_on_every_shared_property(b,
     """Every property both handlers write (class flags, fps, frame grid, VAE block size, profile folders, samplers, guidance /
     step-skipping capabilities, NAG, image prompt types, ...) has the reference's value for the corresponding built-in type --
     except `compile` (the reference names modules for torch.compile; nothing to compile here).  Properties only the reference
-    writes are UI features this backend does not claim (`perturbation`, `self_refiner`, upsamplers, ...)."""
+    writes are UI features this backend does not claim (`perturbation`, upsamplers, ...)."""
     ref = _ref_query_model_def()
     if ref is None:
         pytest.skip("reference tree not present")
@@ -163,7 +163,7 @@ def test_model_definition_agrees_with_the_references_on_every_shared_property(b,
     shared = (set(want) & set(got)) - {"compile"}
     assert len(shared) >= 28
     assert {k: got[k] for k in shared} == {k: want[k] for k in shared}
-    assert not got.get("perturbation") and not got.get("self_refiner")          # not claimed: skip-layer guidance, self-refiner
+    assert not got.get("perturbation")                                         # not claimed: skip-layer guidance
 
 
 def _ref_static(name):

@@ -434,3 +434,17 @@ def test_nag_parameters_reach_a_model_driven_by_the_references_own_generate(monk
     assert m._nag_params() is None
     m.nag = (2.0, 2.5, 0.25)                                            # an explicit setting wins
     assert m._nag_params() == (2.0, 2.5, 0.25)
+
+
+def test_self_refiner_repeats_the_planned_steps_through_the_same_denoise_function():
+    """any2video.py:1485-1488, :1729-1731 (the handler itself is pinned to the reference's in tests/test_refiner_vs_reference.py):
+    generate() builds it from the four self_refiner_* keywords, switches to a copyable scheduler, and the planned steps call the
+    model again through the same CFG path (joint pass, both contexts)."""
+    m = FakeDiT("A")
+    out = run(WanAny2VHIP(m, device="cpu"), self_refiner_setting=1, self_refiner_plan="1-2:3", self_refiner_f_uncertainty=0.0)
+    assert torch.isfinite(out["latents"]).all()
+    assert len(m.calls) == 6 + 2 * 2 and all(c["n"] == 2 for c in m.calls)             # two extra repetitions on steps 1 and 2
+    assert [c["step"] for c in m.calls] == [0, 1, 1, 1, 2, 2, 2, 3, 4, 5]
+    m = FakeDiT("A")
+    run(WanAny2VHIP(m, device="cpu"), self_refiner_setting=0, self_refiner_plan="1-2:3")
+    assert len(m.calls) == 6

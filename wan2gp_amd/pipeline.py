@@ -161,7 +161,8 @@ class WanAny2VHIP:
                  input_frames=None, input_masks=None, context_scale=None, sub_parallel_window_size=0, sub_parallel_window_overlap=0,
                  motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, image_end=None,
                  return_latent_slice=None, video_prompt_type="", denoising_strength=1.0, masking_strength=1.0, keep_frames_parsed=None,
-                 prefix_frames_count=0, **bbargs):
+                 prefix_frames_count=0, self_refiner_setting=0, self_refiner_plan="", self_refiner_f_uncertainty=0.0,
+                 self_refiner_certain_percentage=0.999, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -193,7 +194,13 @@ class WanAny2VHIP:
         v2v_on = "G" in (video_prompt_type or "") and input_frames is not None
         if not v2v_on:
             denoising_strength = 1                                                      # :1044
-        sample_scheduler, timesteps = self._scheduler(sample_solver, sampling_steps, shift, native=not (v2v_on and denoising_strength < 1))
+        # self-refining steps (any2video.py:1485-1488): the handler copies and restores the scheduler -> a Python mirror
+        refiner_handler = None
+        if self_refiner_setting > 0:
+            from . import refiner
+            refiner_handler = refiner.create(self_refiner_plan, self_refiner_f_uncertainty, self_refiner_setting, self_refiner_certain_percentage)
+        sample_scheduler, timesteps = self._scheduler(sample_solver, sampling_steps, shift,
+                                                      native=not ((v2v_on and denoising_strength < 1) or refiner_handler is not None))
         seed_g = torch.Generator(device=dev)
         seed_g.manual_seed(seed if seed >= 0 else torch.seed() % (2 ** 31))
         lat_frames = (frame_num - 1) // self.vae_stride[0] + 1                       # any2video.py:647
@@ -350,13 +357,22 @@ class WanAny2VHIP:
 
                 if sub_windows is not None:                      # any2video.py:1724: one forward per temporal window, blended
                     from . import subparallel
-                    noise_pred = subparallel.denoise(latents, denoise_with_cfg, sub_windows, sub_overlap, kwargs,
-                                                     (target_shape[2] // self.patch_size[1]) * (target_shape[3] // self.patch_size[2]))
+
+                    def denoise_fn(lat):
+                        return subparallel.denoise(lat, denoise_with_cfg, sub_windows, sub_overlap, kwargs,
+                                                   (target_shape[2] // self.patch_size[1]) * (target_shape[3] // self.patch_size[2]))
                 else:
-                    noise_pred = denoise_with_cfg(latents)
+                    denoise_fn = denoise_with_cfg
+                noise_pred = denoise_fn(latents)
                 if noise_pred is None:
                     return None
-                if isinstance(sample_scheduler, FlowMatchScheduler):                                    # :1463-1467
+                if refiner_handler is not None:                  # :1729-1731: the scheduler step, repeated on the plan's steps
+                    sk = {} if isinstance(sample_scheduler, FlowMatchScheduler) else {"generator": seed_g}
+                    latents, sample_scheduler = refiner_handler.step(i, latents, noise_pred, t, timesteps, target_shape, seed_g,
+                                                                     sample_scheduler, sk, denoise_fn)
+                    if latents is None:
+                        return None
+                elif isinstance(sample_scheduler, FlowMatchScheduler):                                  # :1463-1467
                     latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents)[0]
                 else:
                     latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
