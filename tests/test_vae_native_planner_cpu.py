@@ -44,3 +44,26 @@ def test_missing_layers_are_named_and_duplicates_rejected():
     w = torch.zeros(4, 4, 1, 1, 1)
     assert g.lib.wan_vae_set_conv(g._h, b"conv1", L.ptr(w), 4, 4, 1, 1, 1, None, 0) != 0 and b"twice" in g.lib.wan_last_error()
     assert plan(g, True, 0, 8, 8) == -1
+
+
+def test_vae_tile_size_choice_equals_the_references():
+    """WanVAE.get_VAE_tile_size (vae.py:969-1001) lifted from the reference with `ast`: automatic choice by memory / resolution,
+    user presets kept."""
+    import ast
+    import os
+    import pytest
+    src = os.path.join(os.environ.get("WAN_REFERENCE_ROOT", "/root/reference"), "models", "wan", "modules", "vae.py")
+    if not os.path.isfile(src):
+        pytest.skip("reference tree not present")
+    tree = ast.parse(open(src).read())
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "WanVAE")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "get_VAE_tile_size")
+    fn.decorator_list = []
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), src, "exec"), ns)
+    from wan2gp_amd.vae import WanVAEHIP
+    for cfg in (0, 1, 2, 3):
+        for mem in (4000, 8000, 12000, 16000, 23999, 24000, 48000, 294000):
+            for mixed in (False, True):
+                for hw in ((None, None), (720, 1280), (1088, 1920), (1440, 2560)):
+                    assert WanVAEHIP.get_VAE_tile_size(cfg, mem, mixed, *hw) == ns["get_VAE_tile_size"](cfg, mem, mixed, *hw), (cfg, mem, mixed, hw)

@@ -321,7 +321,19 @@ class WanVAEHIP:
 
     @staticmethod
     def get_VAE_tile_size(vae_config, device_mem_capacity, mixed_precision, output_height=None, output_width=None):
-        return 0                                           # 288 GB: never tile (vae.py:970-1001 picks 0 for >= 24 GB)
+        """vae.py:969-1001.  Automatic (vae_config 0): no tiling from 24 GB up -- 1024-px tiles beyond 1920 x 1088 pixels -- and
+        512 / 256 / 128 below 24 / 16 / 8 GB; a preset the user forced (1, 2, 3) keeps its tile size (512 / 256 / 128) even on a
+        288-GB device: tiled and untiled decodes are different pictures, so the choice is the caller's, not the backend's."""
+        if vae_config == 0:
+            mem = device_mem_capacity / 2 if mixed_precision else device_mem_capacity
+            if mem >= 24000:
+                big = output_height is not None and output_width is not None and int(output_height) * int(output_width) > 1920 * 1088
+                tier = 2 if big else 1
+            else:
+                tier = 3 if mem >= 16000 else (4 if mem >= 8000 else 5)
+        else:
+            tier = vae_config + 2
+        return {1: 0, 2: 1024, 3: 512, 4: 256}.get(tier, 128)
 
     # ---- layer graph (vae.py:338-369, 449-484) -------------------------------------------------------
     def _res(self, x, p, cache, idx):

@@ -31,6 +31,12 @@ class Wan22VAEHIP(WanVAEHIP):
     NATIVE_GRAPH = False          # this graph (patchify, AvgDown / DupUp shortcuts, 48 latent channels) stays on the host
     CFG = dict(dim=160, dec_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2, temperal_downsample=[False, True, True])
 
+    @staticmethod
+    def get_VAE_tile_size(vae_config, device_mem_capacity, mixed_precision, output_height=None, output_width=None):
+        """vae2_2.py:1286-1307 picks 0 / 256 / 128; this class decodes and encodes untiled whatever it is given (see the module
+        docstring), so it reports the size it honours."""
+        return 0
+
     def __init__(self, z_dim=48, c_dim=160, vae_pth=None, dim_mult=(1, 2, 4, 4), temperal_downsample=(False, True, True),
                  dtype=torch.float16, upsampler_factor=1, device="cuda", state_dict=None, dec_dim=256, **unused):
         assert upsampler_factor == 1                                     # vae2_2.py:1160
