@@ -9,9 +9,10 @@ libwanhip kernel on fp16 channels-last activations [T,H,W,C] (vae_ops.hip): impl
 convolutions with the 2-frame cache, fused nearest-2x upsample, fused time interleave, fused
 residual add, RMS_norm+SiLU, the attention block as fp16 GEMMs + a row softmax, and the
 float->uint8 conversion.  Spatial tiling (tile_size > 0: vae.py:676-717, :769-839, :841-881) exists in the
-reference to fit small VRAM; `get_VAE_tile_size` here always answers 0 (288 GB of HBM: the full frame in one
-piece, the tile_size == 0 path of vae.py:762-767), but a caller that passes a tile size gets the reference's
-tiling: overlapping tiles decoded / encoded independently, seams blended over a quarter tile.
+reference to fit small VRAM; `get_VAE_tile_size` makes the reference's choice (0 on a 288-GB device unless the caller forces a
+preset or the picture exceeds 1920 x 1088), and a tile size gets the reference's tiling: overlapping tiles decoded / encoded
+independently -- on several GPUs spread over the ranks of `self.sp` -- seams blended over a quarter tile.  `any_end_frame`
+(start + end image clips) is the clip without its last frame followed by that frame alone.
 """
 import math
 from typing import Dict, List, Optional
