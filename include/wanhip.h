@@ -402,6 +402,12 @@ typedef struct {
    * context_batches: HOST array of S ints (1 or 2), NULL = every context has batch 1; a 2 needs nag_scale > 1. */
   float nag_scale, nag_tau, nag_alpha;
   const int* context_batches;
+  /* skip-layer guidance (any2video.py:1502; WanModel.forward perturbation_layers, model.py:2025-2028): HOST array of block
+   * indices that run for the FIRST stream of the call only, and only when x_id == 0 (the call that carries the conditional
+   * stream); every other stream passes through them unchanged.  n_perturbation_layers = 0: off.  Not together with VACE. */
+  const int* perturbation_layers;
+  int n_perturbation_layers;
+  int x_id;
 } wan_dit_args;
 int wan_dit_forward_ex(wan_ctx* ctx, const wan_dit_args* args, void* stream);
 /* How many VACE contexts one forward may mix (default 1): sizes the hint-stream region of the workspace

@@ -1,0 +1,344 @@
+"""CPU: the HOST LOGIC of the DiT forward driver (wan2gp_amd/csrc/dit.hip) on a recording stand-in for the kernels.
+
+The forward is a composition of op-level launches (GEMMs, norms, attention, ...), each checked on the GPU against the oracle.
+What composes them -- workspace carving, per-layer launch order, which weights go where, which streams a step-skipping call
+touches, the pointer arithmetic of the NAG branch, the call order under sequence parallelism -- is host C++ and needs no GPU:
+tests/mock/mock_ops.cpp defines every function dit.o calls (the library's op-level C entries with the prototypes of
+include/wanhip.h, and the HIP runtime calls) as recorders, the REAL dit.hip is compiled and linked against it, and
+`wan_dit_forward*` is driven through the same ctypes structures the product uses, with fake (never dereferenced) device
+addresses.  Needs hipcc (to compile dit.hip's host code) and g++."""
+import ctypes
+import os
+import shutil
+import subprocess
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_uint64, c_void_p
+
+import pytest
+
+from oracle import wan_oracle as O
+from wan2gp_amd.lib import DitArgs, DitConfig, GATHER_FN, GATHER_WAIT_FN, POLL_FN, SpInfo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) and shutil.which("g++")), reason="needs hipcc and g++")
+
+WS = 0x7000_0000_0000                                  # fake workspace base (256-aligned)
+TL, TD = 512, 4096
+
+
+class Call(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32), ("p", c_uint64 * 8), ("i", c_int64 * 12), ("f", c_double * 4)]
+
+
+@pytest.fixture(scope="module")
+def mock(tmp_path_factory):
+    d = tmp_path_factory.mktemp("mock")
+    inc = os.path.join(ROOT, "include")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-Wno-unused-function", "-I" + inc, "-c",
+                    os.path.join(ROOT, "wan2gp_amd", "csrc", "dit.hip"), "-o", str(d / "dit.o")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c",
+                    os.path.join(ROOT, "tests", "mock", "mock_ops.cpp"), "-o", str(d / "mock.o")], check=True)
+    subprocess.run(["g++", "-shared", "-fPIC", "-o", str(d / "libwanhip_mock.so"), str(d / "dit.o"), str(d / "mock.o")], check=True)
+    L = ctypes.CDLL(str(d / "libwanhip_mock.so"))
+    L.mock_get.restype = POINTER(Call)
+    L.wan_last_error.restype = c_char_p
+    L.wan_dit_workspace_bytes.restype = c_int64
+    L.wan_dit_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int]
+    L.wan_dit_set_weight.argtypes = [c_void_p, c_char_p, c_void_p, c_int, c_int64]
+    L.wan_dit_forward_ex.argtypes = [c_void_p, POINTER(DitArgs), c_void_p]
+    return L
+
+
+class Model:
+    """A context with every weight of the `tiny` config registered at a distinct fake address."""
+
+    def __init__(self, L, name="tiny", fp8=False):
+        self.L, self.cfg = L, O.make_config(name)
+        c = self.cfg
+        dc = DitConfig(c.dim, c.ffn_dim, c.num_heads, c.num_layers, c.in_dim, c.out_dim, c.text_dim, c.freq_dim, c.text_len, c.eps)
+        self.ctx = c_void_p()
+        assert L.wan_dit_create(ctypes.byref(dc), ctypes.byref(self.ctx)) == 0
+        self.addr = {}
+        for n, (k, shape) in enumerate(O.param_shapes(c).items()):
+            numel = 1
+            for s in shape:
+                numel *= s
+            a = 0x1000_0000_0000 + n * 0x10_0000_0000
+            self.addr[k] = a
+            dt = 1 if k.startswith(("patch_embedding.", "head.")) else 0
+            lin = k.endswith(".weight") and ".norm" not in k and "norm3" not in k and k.startswith("blocks.") and ("attn." in k or "ffn." in k)
+            if fp8 and lin:
+                dt = 2
+                s_addr = a + 0x8_0000_0000
+                assert L.wan_dit_set_weight(self.ctx, (k[:-len("weight")] + "scale_weight").encode(), c_void_p(s_addr), 1, shape[0]) == 0
+            assert L.wan_dit_set_weight(self.ctx, k.encode(), c_void_p(a), dt, numel) == 0, L.wan_last_error()
+
+    def forward(self, S=2, fhw=(2, 8, 8), should_calc=None, residual=None, nag=None, ctx_batches=None, sp=None, t_frames=None, poll=None,
+                perturb=None, x_id=0):
+        L, (F, H, W) = self.L, fhw
+        shards = 1 if sp is None else sp.world
+        nbytes = L.wan_dit_workspace_bytes(self.ctx, S, F, H, W, shards)
+        assert nbytes > 0
+        X = (c_void_p * S)(*[0x6000_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+        C = (c_void_p * S)(*[0x6100_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+        OUT = (c_void_p * S)(*[0x6200_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+        FL = None if should_calc is None else (c_int * S)(*should_calc)
+        RP = None if residual is None else (c_void_p * S)(*residual)
+        TF = None if t_frames is None else (ctypes.c_float * F)(*t_frames)
+        a = DitArgs(S, X, 637.0, C, None, 0x6300_0000_0000, 0x6310_0000_0000, OUT, F, H, W, WS, nbytes,
+                    None if sp is None else ctypes.cast(ctypes.byref(sp), c_void_p), None if poll is None else ctypes.cast(poll, c_void_p), None, FL, RP,
+                    None, 1.0, TF, F if t_frames is not None else 0, 0, None, None,
+                    *((0.0, 0.0, 0.0, None) if nag is None else (*nag, (c_int * S)(*ctx_batches))),
+                    None if not perturb else (c_int * len(perturb))(*perturb), len(perturb or ()), x_id)
+        L.mock_reset()
+        rc = L.wan_dit_forward_ex(self.ctx, ctypes.byref(a), None)
+        calls = [L.mock_get(i).contents for i in range(L.mock_count())]
+        return rc, [(c.name.decode(), list(c.p), list(c.i), list(c.f)) for c in calls], nbytes
+
+
+def extents(call):
+    """(pointer, bytes) pairs an op touches, from its recorded arguments."""
+    name, p, i, _ = call
+    if name in ("gemm", "gemm_fp8"):
+        M, N, K, lda, ldc, epi = i[:6]
+        a_el = 1 if name == "gemm_fp8" else 2
+        out = [(p[0], M * lda * a_el), (p[3], (N if epi == 3 else M) * ldc * 2)]
+        if p[4]:
+            out.append((p[4], M * ldc * 2))
+        return out
+    if name == "ln_modulate" or name == "ln_affine":
+        return [(p[0], i[0] * i[1] * 2), (p[1], i[0] * i[1] * 2)]
+    if name == "rmsnorm_rope":
+        return [(q, i[0] * i[3] * 2) for q in p[:2] if q]
+    if name == "attention":
+        B, Bk, Lq, Lk, ldv, H = i[:6]
+        return [(p[0], B * Lq * H * 256), (p[1], Bk * Lk * H * 256), (p[2], Bk * H * 128 * ldv * 2), (p[3], B * Lq * H * 256)]
+    if name == "nag_combine":
+        return [(q, i[0] * i[1] * 2) for q in p[:3]]
+    if name in ("add", "sub", "axpy"):
+        return [(q, i[0] * 2) for q in p[:3]]
+    if name == "act":
+        return [(p[0], i[0] * 2), (p[1], i[0] * 2)]
+    if name == "memset":
+        return [(p[0], i[0])]
+    if name == "memcpy":
+        return [(p[0], i[0]), (p[1], i[0])]
+    if name == "fp8_quantize":
+        return [(p[0], i[0] * 2), (p[1], i[0])]
+    return []
+
+
+def in_ws(ptr, nbytes):
+    return WS <= ptr < WS + nbytes
+
+
+def test_plain_forward_launch_order_weights_and_workspace_bounds(mock):
+    m = Model(mock)
+    c, (F, H, W) = m.cfg, (2, 8, 8)
+    Ll = F * (H // 2) * (W // 2)
+    rc, calls, nbytes = m.forward(S=2)
+    assert rc == 0, mock.wan_last_error()
+    # (a) nothing the forward reads or writes inside the workspace leaves it
+    touched = 0
+    for cl in calls:
+        for ptr, n in extents(cl):
+            if in_ws(ptr, nbytes):
+                assert ptr + n <= WS + nbytes, (cl[0], hex(ptr - WS), n, nbytes)
+                touched += 1
+    assert touched > 60
+    # (b) per layer: the launch order of WanAttentionBlock.forward (model.py:631-711)
+    names = [cl[0] for cl in calls]
+    first_block = names.index("ln_modulate")
+    per_layer = ["ln_modulate", "gemm", "gemm", "gemm", "gemm", "rmsnorm_rope", "attention", "gemm",            # v x2 (V^T per stream), q, k, norms+RoPE, o
+                 "ln_affine", "gemm", "rmsnorm_rope", "gemm", "rmsnorm_rope", "gemm", "gemm", "attention", "gemm",   # cross: q, ck, cv x2, o
+                 "ln_modulate", "gemm", "gemm"]                                                                # ffn
+    body = names[first_block:first_block + len(per_layer) * c.num_layers]
+    assert body == per_layer * c.num_layers
+    assert names[first_block + len(per_layer) * c.num_layers:] == ["head", "head"]
+    # (c) every Linear of block 1 multiplies by the weight registered under its name, with its bias
+    blk = calls[first_block + len(per_layer):first_block + 2 * len(per_layer)]
+    gemms = [cl for cl in blk if cl[0] == "gemm"]
+    want = ["self_attn.v", "self_attn.v", "self_attn.q", "self_attn.k", "self_attn.o", "cross_attn.q", "cross_attn.k", "cross_attn.v",
+            "cross_attn.v", "cross_attn.o", "ffn.0", "ffn.2"]
+    assert [g[1][1] for g in gemms] == [m.addr[f"blocks.1.{w}.weight"] for w in want]
+    assert [g[1][2] for g in gemms] == [m.addr[f"blocks.1.{w}.bias"] for w in want]
+    # shapes: token GEMMs run on both streams' rows at once, the V^T form per stream, text K on 2 x 512 rows
+    assert [(g[2][0], g[2][1], g[2][2], g[2][5]) for g in gemms] == [
+        (Ll, c.dim, c.dim, 3), (Ll, c.dim, c.dim, 3), (2 * Ll, c.dim, c.dim, 0), (2 * Ll, c.dim, c.dim, 0), (2 * Ll, c.dim, c.dim, 2),
+        (2 * Ll, c.dim, c.dim, 0), (2 * TL, c.dim, c.dim, 0), (TL, c.dim, c.dim, 3), (TL, c.dim, c.dim, 3), (2 * Ll, c.dim, c.dim, 2),
+        (2 * Ll, c.ffn_dim, c.dim, 1), (2 * Ll, c.dim, c.ffn_dim, 2)]
+    att = [cl for cl in blk if cl[0] == "attention"]
+    assert att[0][2][:6] == [2, 2, Ll, Ll, (Ll + 63) // 64 * 64, c.num_heads] and att[1][2][:6] == [2, 2, Ll, TL, TL, c.num_heads]
+    assert att[0][1][4] != 0 and att[1][1][4] == 0                      # the K pre-pass scratch: self-attention only
+
+
+def test_step_skipping_touches_only_the_computing_stream(mock):
+    m = Model(mock)
+    c, (F, H, W) = m.cfg, (2, 8, 8)
+    Ll = F * 16
+    res = [0x6400_0000_0000, 0x6400_1000_0000]
+    rc, calls, nbytes = m.forward(S=2, should_calc=[1, 0], residual=res)
+    assert rc == 0, mock.wan_last_error()
+    x1 = WS + Ll * c.dim * 2                                             # stream 1's token stream inside the workspace
+    adds = [cl for cl in calls if cl[0] == "add"]
+    assert len(adds) == 1 and adds[0][1][:3] == [x1, res[1], x1]         # skipped stream: x += stored residual (model.py:1977-1990)
+    cp = [cl for cl in calls if cl[0] == "memcpy" and cl[1][0] == res[0]]
+    assert len(cp) == 1 and cp[0][1][1] == WS                            # computing stream: x parked in its residual buffer ...
+    subs = [cl for cl in calls if cl[0] == "sub"]
+    assert len(subs) == 1 and subs[0][1][:3] == [WS, res[0], res[0]]     # ... and replaced by x_after - x_before at the end
+    for cl in calls:                                                     # no block op reads or writes stream 1's rows
+        if cl[0] in ("ln_modulate", "ln_affine"):
+            assert cl[2][0] == Ll and cl[1][0] == WS
+    assert sum(1 for cl in calls if cl[0] == "attention") == 2 * c.num_layers
+    assert [cl[2][0] for cl in calls if cl[0] == "attention"] == [1] * (2 * c.num_layers)
+    assert [cl[0] for cl in calls][-2:] == ["head", "head"]             # both streams still go through the head
+    # a skipped stream without a residual buffer is refused
+    rc, _, _ = m.forward(S=2, should_calc=[1, 0], residual=[res[0], None])
+    assert rc == 1 and b"residual" in mock.wan_last_error()
+
+
+def test_nag_branch_pointer_arithmetic(mock):
+    """Stream 0 carries (positive ; negative) prompts, stream 1 a plain context (any2video.py:608, :1551)."""
+    m = Model(mock)
+    c, (F, H, W) = m.cfg, (2, 8, 8)
+    Ll, d = F * 16, m.cfg.dim
+    rc, calls, nbytes = m.forward(S=2, nag=(11.0, 2.5, 0.25), ctx_batches=[2, 1])
+    assert rc == 0, mock.wan_last_error()
+    for cl in calls:
+        for ptr, n in extents(cl):
+            if in_ws(ptr, nbytes):
+                assert ptr + n <= WS + nbytes, (cl[0], hex(ptr - WS), n)
+    names = [cl[0] for cl in calls]
+    assert names.count("nag_combine") == c.num_layers
+    # text embedding: one tensor per stream, 1024 rows for the stacked context
+    te = [cl for cl in calls if cl[0] == "gemm" and cl[1][1] == m.addr["text_embedding.0.weight"]]
+    assert [t_[2][0] for t_ in te] == [2 * TL, TL]
+    i0 = names.index("nag_combine")
+    seg = calls[i0 - 8:i0 + 5]
+    seq = [s[0] for s in seg]
+    print(seq)
+    assert seq == ["gemm", "rmsnorm_rope",                                                                  # (cross q projection + norm, all streams)
+                   "gemm", "rmsnorm_rope", "gemm", "gemm", "attention", "attention", "nag_combine",          # stream 0: K on 1024 rows, 2 x V^T, 2 x attention
+                   "gemm", "rmsnorm_rope", "gemm", "attention"]                                              # stream 1: K on 512 rows, V^T, attention
+    k0 = next(s for s in seg if s[0] == "gemm" and s[2][0] == 2 * TL)
+    a_pos, a_neg = [s for s in seg if s[0] == "attention"][:2]
+    nc = calls[i0]
+    q0 = a_pos[1][0]
+    assert a_neg[1][0] == q0                                             # the same q rows against both prompts
+    assert a_pos[1][1] == k0[1][3] and a_neg[1][1] == k0[1][3] + TL * d * 2          # K of the negative prompt: 512 rows further
+    assert a_neg[1][2] == a_pos[1][2] + TL * d * 2                       # its V^T image: d x 512 elements further
+    assert a_pos[2][:4] == [1, 1, Ll, TL] and a_neg[2][:4] == [1, 1, Ll, TL]
+    assert nc[1][:3] == [a_pos[1][3], a_neg[1][3], q0] and nc[2][:2] == [Ll, d] and nc[3][:3] == [11.0, 2.5, 0.25]
+    assert len({a_pos[1][3], a_neg[1][3], q0}) == 3                      # three different buffers: xm, the idle FFN buffer, q
+    # stream 1 (plain context): one attention on its own q rows / its own K behind stream 0's 1024 context rows
+    a1 = [s for s in calls[i0:] if s[0] == "attention"][0]
+    assert a1[1][0] == q0 + Ll * d * 2 and a1[1][1] == k0[1][3] + 2 * TL * d * 2 and a1[1][3] == a1[1][0]
+    # a batch-2 context without NAG parameters is refused (model.py:260)
+    rc, _, _ = m.forward(S=2, nag=(1.0, 2.5, 0.25), ctx_batches=[2, 1])
+    assert rc == 1 and b"context_batches" in mock.wan_last_error()
+
+
+def test_sequence_parallel_call_order(mock):
+    """K projection -> K gather begins -> V^T -> its gather -> Q -> attention on the own segment -> both waits -> the other
+    segments, per layer; shards see their token range."""
+    m = Model(mock)
+    c, (F, H, W) = m.cfg, (2, 8, 8)
+    L_ = F * 16
+    events = []
+
+    def begin(user, which, send, recv, nbytes, stream):
+        events.append(("begin", which, send, recv, nbytes, mock.mock_count()))
+        return 0
+
+    def wait(user, which, stream):
+        events.append(("wait", which, mock.mock_count()))
+        return 0
+    cb, cw = GATHER_FN(begin), GATHER_WAIT_FN(wait)
+    sp = SpInfo(1, 2, L_ // 2, L_ // 2, cb, cw, None)
+    rc, calls, nbytes = m.forward(S=2, sp=sp)
+    assert rc == 0, mock.wan_last_error()
+    Ll, d = L_ // 2, c.dim
+    assert len(events) == 4 * c.num_layers
+    for layer in range(c.num_layers):
+        b0, b1, w0, w1 = events[4 * layer:4 * layer + 4]
+        assert (b0[0], b0[1], b1[0], b1[1], w0[:2], w1[:2]) == ("begin", 0, "begin", 1, ("wait", 0), ("wait", 1))
+        assert b0[4] == 2 * Ll * d * 2 and b1[4] == 2 * d * ((Ll + 63) // 64 * 64) * 2        # K rows / V^T images of both streams
+        between = [cl[0] for cl in calls[b0[5]:b1[5]]]
+        assert between == ["gemm", "gemm"]                                # the two V^T projections run under the K gather
+        local = [cl[0] for cl in calls[b1[5]:w0[2]]]
+        assert local == ["gemm", "rmsnorm_rope", "attention_sp_local"]   # Q projection, norm + RoPE, own segment -- gathers in flight
+        assert calls[w1[2]][0] == "attention_sp_remote" and calls[w1[2]][2][5:9] == [2, 2 * Ll * d, 2 * d * ((Ll + 63) // 64 * 64), 1]
+    pe = [cl for cl in calls if cl[0] == "patch_embed"]
+    assert all(cl[2][7:9] == [Ll, Ll] for cl in pe)                      # rank 1 of 2 embeds tokens [Ll, 2 Ll)
+    rr = [cl for cl in calls if cl[0] == "rmsnorm_rope" and cl[1][4] != 0]
+    assert all(cl[2][2] == Ll for cl in rr)                              # RoPE positions start at the shard's first token
+    hd = [cl for cl in calls if cl[0] == "head"]
+    assert all(cl[2][7] == 1 for cl in hd)                               # token-major output for the gather
+
+
+def test_fp8_checkpoint_quantises_once_per_shared_input(mock):
+    """q / k / v share one activation quantisation per stream (the reference quantises per tensor = per stream), the Linears go
+    through the fp8 GEMM with their scales."""
+    m = Model(mock, fp8=True)
+    rc, calls, nbytes = m.forward(S=2)
+    assert rc == 0, mock.wan_last_error()
+    names = [cl[0] for cl in calls]
+    i0 = names.index("ln_modulate")
+    i1 = names.index("rmsnorm_rope", i0)
+    head = names[i0:i1]
+    assert head.count("fp8_quantize") == 2 and head.count("gemm_fp8") == 2 + 2 + 2       # 2 streams: V^T, q, k
+    for cl in calls:
+        for ptr, n in extents(cl):
+            if in_ws(ptr, nbytes):
+                assert ptr + n <= WS + nbytes, (cl[0], hex(ptr - WS), n)
+    assert "gemm" in names                                               # time / text embeddings stay bf16
+
+
+def test_interrupt_poll_aborts_between_blocks(mock):
+    m = Model(mock)
+    seen = []
+
+    def poll(user, i):
+        seen.append(i)
+        return 1 if i == 1 else 0
+    rc, calls, _ = m.forward(S=1, poll=POLL_FN(poll))
+    assert rc == 100 and seen == [0, 1]                                  # WAN_ABORTED before block 1 (model.py:1995-1998)
+    assert "head" not in [cl[0] for cl in calls]
+
+
+def test_skip_layer_guidance_runs_listed_blocks_for_the_first_stream_only(mock):
+    """perturbation_layers (any2video.py:1502, model.py:2025-2028): a listed block runs on stream 0 of the call that carries the
+    conditional stream (x_id 0) and nowhere else; unlisted blocks are untouched.  The listed block on stream 0 is exactly the
+    single-stream run step skipping already uses (GPU-tested); the oracle's restatement is pinned to the reference's own forward
+    (tests/test_nag_oracle_vs_golden.py)."""
+    m = Model(mock)
+    c = m.cfg
+    Ll, d = 2 * 16, m.cfg.dim
+    rc, plain, _ = m.forward(S=2)
+    rc, calls, nbytes = m.forward(S=2, perturb=[1])
+    assert rc == 0, mock.wan_last_error()
+    names = [cl[0] for cl in calls]
+    b0, per = names.index("ln_modulate"), 20
+    assert [cl[0] for cl in plain][:b0 + per] == names[:b0 + per]                      # block 0 (unlisted): as in the plain forward
+    assert [(cl[1], cl[2]) for cl in plain[:b0 + per]] == [(cl[1], cl[2]) for cl in calls[:b0 + per]]
+    blk1 = calls[b0 + per:-2]
+    # block 1 on stream 0 alone: one V^T GEMM, every token op on Ll rows at stream 0's addresses, attention with batch 1
+    assert [cl[0] for cl in blk1] == ["ln_modulate", "gemm", "gemm", "gemm", "rmsnorm_rope", "attention", "gemm", "ln_affine", "gemm", "rmsnorm_rope",
+                                      "gemm", "rmsnorm_rope", "gemm", "attention", "gemm", "ln_modulate", "gemm", "gemm"]
+    assert all(cl[2][0] == Ll and cl[1][0] == WS for cl in blk1 if cl[0] in ("ln_modulate", "ln_affine"))
+    assert [cl[2][0] for cl in blk1 if cl[0] == "attention"] == [1, 1]
+    x1 = WS + Ll * d * 2
+    for cl in blk1:                                                                    # nothing of block 1 writes stream 1's token rows
+        if cl[0] == "gemm" and cl[2][5] == 2:
+            assert cl[1][3] == WS and cl[2][0] == Ll
+        assert x1 not in (cl[1][0], cl[1][3]) or cl[0] == "head"
+    assert names[-2:] == ["head", "head"]
+    # the unconditional call of a non-joint pass (x_id 1): the listed block is skipped altogether
+    rc, solo, _ = m.forward(S=1, perturb=[1], x_id=1)
+    assert rc == 0 and [cl[0] for cl in solo].count("ln_modulate") == 2 * (c.num_layers - 1)
+    # ... and so it is when stream 0 is skipped by the step-skipping cache while stream 1 computes
+    rc, part, _ = m.forward(S=2, perturb=[1], should_calc=[0, 1], residual=[0x6400_0000_0000, 0x6400_1000_0000])
+    assert rc == 0 and [cl[0] for cl in part].count("ln_modulate") == 2 * (c.num_layers - 1)
+    # every block listed: only stream 0 moves
+    rc, allp, _ = m.forward(S=2, perturb=[0, 1])
+    assert rc == 0 and all(cl[2][0] == 1 for cl in allp if cl[0] == "attention")

@@ -448,3 +448,17 @@ def test_self_refiner_repeats_the_planned_steps_through_the_same_denoise_functio
     m = FakeDiT("A")
     run(WanAny2VHIP(m, device="cpu"), self_refiner_setting=0, self_refiner_plan="1-2:3")
     assert len(m.calls) == 6
+
+
+def test_skip_layer_guidance_is_passed_inside_its_window_of_steps():
+    """any2video.py:1502: kwargs["perturbation_layers"] = perturbation_layers if int(start * steps) <= i < int(end * steps) else None."""
+    class Rec(FakeDiT):
+        def __call__(self, x, t, context, **kw):
+            self.slg = getattr(self, "slg", []) + [kw.get("perturbation_layers")]
+            return super().__call__(x, t, context, **kw)
+    m = Rec("A")
+    run(WanAny2VHIP(m, device="cpu"), perturbation_layers=[9, 10], perturbation_start=0.2, perturbation_end=0.7)
+    assert m.slg == [None, [9, 10], [9, 10], [9, 10], None, None]
+    m = Rec("A")
+    run(WanAny2VHIP(m, device="cpu"))
+    assert m.slg == [None] * 6

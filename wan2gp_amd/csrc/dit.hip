@@ -22,7 +22,7 @@ void wan_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wan_last_error(void) { return g_err; }
-extern "C" int wan_version(void) { return 4; }
+extern "C" int wan_version(void) { return 5; }
 extern "C" int wan_device_cus(void) {
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -462,7 +462,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
                             int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                             void* poll_user, const int* should_calc, wan_bf16* const* residual, int n_vace,
                             const float* const* vace_contexts, const float* vace_scales, const float* nag, const int* context_batches,
-                            void* stream) {
+                            const int* perturb_layers, int n_perturb, int x_id, void* stream) {
   WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
   WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
@@ -591,7 +591,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
 
   // the block chain over streams [s0, s0 + Sn): every scratch buffer is used from its base, only the token stream and the
   // text context are offset (maximal runs of computing streams; all of them in the plain forward)
-  auto run_blocks = [&](const int s0, const int Sn) -> int {
+  // layers [l0, l1) of the block chain over streams [s0, s0 + Sn)
+  auto run_blocks = [&](const int s0, const int Sn, const int l0, const int l1) -> int {
   const int S = Sn;
   const int64_t rows = (int64_t)Sn * Ll, rpb = nt > 1 ? tpf : rows;
   struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; float* raw; } b2 = {
@@ -729,7 +730,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     }
     return 0;
   };
-  for (int i = 0; i < g.num_layers; ++i) {
+  for (int i = l0; i < l1; ++i) {
     if (poll && poll(poll_user, i)) return WAN_ABORTED;  // model.py:1995-1998
     const int n = vace ? c->vace_at[i] : -1;
     if (n >= 0) {
@@ -753,12 +754,41 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   }
   return 0;
   };
-  for (int s0 = 0; s0 < S;) {
-    if (!calc(s0)) { ++s0; continue; }
-    int Sn = 1;
-    while (s0 + Sn < S && calc(s0 + Sn)) ++Sn;
-    if (int rc = run_blocks(s0, Sn)) return rc;
-    s0 += Sn;
+  // maximal runs of computing streams through layers [l0, l1)
+  auto run_streams = [&](const int l0, const int l1) -> int {
+    for (int s0 = 0; s0 < S;) {
+      if (!calc(s0)) { ++s0; continue; }
+      int Sn = 1;
+      while (s0 + Sn < S && calc(s0 + Sn)) ++Sn;
+      if (int rc = run_blocks(s0, Sn, l0, l1)) return rc;
+      s0 += Sn;
+    }
+    return 0;
+  };
+  if (n_perturb == 0) {
+    RC(run_streams(0, g.num_layers));
+  } else {
+    // Skip-layer guidance (any2video.py:1502; model.py:2025-2028): a block listed in perturbation_layers runs for the FIRST stream
+    // of the call only -- and only in the call that carries the conditional stream (x_id 0) -- every other stream passes through
+    // it unchanged.  The chain is cut at those blocks: [unlisted blocks: every computing stream] [listed block: stream 0] ...
+    WAN_REQUIRE(perturb_layers != nullptr && !vace, "wan_dit_forward: perturbation_layers %s",
+                vace ? "together with VACE context blocks is not implemented (the hint streams' state spans the chain)" : "is null");
+    auto listed = [&](int i) {
+      for (int k = 0; k < n_perturb; ++k)
+        if (perturb_layers[k] == i) return true;
+      return false;
+    };
+    for (int l = 0; l < g.num_layers;) {
+      if (listed(l)) {
+        if (x_id == 0 && calc(0)) RC(run_blocks(0, 1, l, l + 1));
+        ++l;
+        continue;
+      }
+      int e = l;
+      while (e < g.num_layers && !listed(e)) ++e;
+      RC(run_streams(l, e));
+      l = e;
+    }
   }
   for (int s = 0; s < S; ++s)
     if (residual != nullptr && residual[s] != nullptr && calc(s))
@@ -776,7 +806,7 @@ extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t
                                int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                void* poll_user, void* stream) {
   return dit_forward_impl(c, S, x, t, nullptr, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
-                          nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, stream);
+                          nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
@@ -784,7 +814,7 @@ extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, fl
                                     int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                                     void* poll_user, const int* should_calc, wan_bf16* const* residual, void* stream) {
   return dit_forward_impl(c, S, x, t, nullptr, context, y, cos, sin, outs, F, H, W, workspace, workspace_bytes, sp, poll, poll_user,
-                          should_calc, residual, 0, nullptr, nullptr, nullptr, nullptr, stream);
+                          should_calc, residual, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* stream) {
@@ -797,10 +827,13 @@ extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* strea
   const bool many = a->n_vace > 0;
   WAN_REQUIRE(!many || (a->vace_contexts && a->vace_scales), "wan_dit_forward_ex: n_vace = %d but the arrays are null", a->n_vace);
   const float nag[3] = {a->nag_scale, a->nag_tau, a->nag_alpha};
+  WAN_REQUIRE(a->n_perturbation_layers <= 0 || a->perturbation_layers, "wan_dit_forward_ex: n_perturbation_layers = %d but the array is null",
+              a->n_perturbation_layers);
   return dit_forward_impl(c, a->S, a->x, a->t, a->n_t_frames ? a->t_frames : nullptr, a->context, a->y, a->cos, a->sin, a->outs, a->F, a->H, a->W, a->workspace,
                           a->workspace_bytes, a->sp, a->poll, a->poll_user, a->should_calc, a->residual,
                           many ? a->n_vace : (a->vace_context ? 1 : 0), many ? a->vace_contexts : one_ctx, many ? a->vace_scales : one_scale,
-                          nag, a->context_batches, stream);
+                          nag, a->context_batches, a->n_perturbation_layers > 0 ? a->perturbation_layers : nullptr,
+                          a->n_perturbation_layers > 0 ? a->n_perturbation_layers : 0, a->x_id, stream);
 }
 
 extern "C" int wan_dit_set_vace_contexts(wan_ctx* c, int n) {

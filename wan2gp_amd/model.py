@@ -172,7 +172,8 @@ class WanModelHIP:
         return self._ws
 
     def forward(self, x, t, context, y=None, freqs=None, pipeline=None, current_step_no=0, real_step_no=0, x_id=0,
-                max_steps=0, callback=None, clip_fea=None, vace_context=None, vace_context_scale=None, **variant_kwargs):
+                max_steps=0, callback=None, clip_fea=None, vace_context=None, vace_context_scale=None, perturbation_layers=None,
+                **variant_kwargs):
         active = {k: v for k, v in variant_kwargs.items() if not _is_default(k, v)}
         vace_ts, vace_scales = None, None
         if vace_context is not None:
@@ -292,7 +293,11 @@ class WanModelHIP:
                 bufs.append(r)
             FL = (ctypes.c_int * S)(*[1 if f else 0 for f in flags])
             RP = (c_void_p * S)(*[r.data_ptr() for r in bufs])
-        if vace_ts is not None or t_frames is not None or nag is not None:
+        # skip-layer guidance (any2video.py:1502; model.py:2025-2028): blocks that run for the first stream of the x_id-0 call only
+        slg = [int(v) for v in perturbation_layers] if perturbation_layers is not None else []
+        if any(v < 0 or v >= self.num_layers for v in slg):
+            raise _L.WanHipError(f"perturbation_layers {slg} outside [0, {self.num_layers})")
+        if vace_ts is not None or t_frames is not None or nag is not None or slg:
             nv = 0 if vace_ts is None else len(vace_ts)
             for u in vace_ts or ():
                 if tuple(u.shape) != (self.vace_in_dim, F, H, W):
@@ -302,7 +307,8 @@ class WanModelHIP:
             a = _L.DitArgs(S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws), ws.numel(),
                            None if sp_struct is None else ctypes.cast(sp_struct, c_void_p), ctypes.cast(poll, c_void_p), None, FL, RP,
                            None, 1.0, t_frames, F if t_frames is not None else 0, nv, VP, VS,
-                           *((0.0, 0.0, 0.0, None) if nag is None else (*nag, (ctypes.c_int * S)(*ctx_batches))))
+                           *((0.0, 0.0, 0.0, None) if nag is None else (*nag, (ctypes.c_int * S)(*ctx_batches))),
+                           (ctypes.c_int * len(slg))(*slg) if slg else None, len(slg), int(x_id))
             rc = _L.load().wan_dit_forward_ex(self._ctx, ctypes.byref(a), stream_ptr())
         elif cache is None:
             rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),

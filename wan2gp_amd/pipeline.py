@@ -162,7 +162,7 @@ class WanAny2VHIP:
                  motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, image_end=None,
                  return_latent_slice=None, video_prompt_type="", denoising_strength=1.0, masking_strength=1.0, keep_frames_parsed=None,
                  prefix_frames_count=0, self_refiner_setting=0, self_refiner_plan="", self_refiner_f_uncertainty=0.0,
-                 self_refiner_certain_percentage=0.999, **bbargs):
+                 self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         if context is None:
@@ -322,6 +322,9 @@ class WanAny2VHIP:
                     timestep = torch.full((target_shape[1],), int(t), dtype=torch.int64, device=latents.device)
                     timestep[:n_src] = 0
                 kwargs.update({"t": timestep, "current_step_no": i, "real_step_no": start_step_no + i})
+                # skip-layer guidance inside its window of steps (any2video.py:1502)
+                kwargs["perturbation_layers"] = perturbation_layers if (perturbation_layers is not None and int(perturbation_start * sampling_steps)
+                                                                        <= i < int(perturbation_end * sampling_steps)) else None
                 if v2v is not None:                              # any2video.py:1504-1515: the noised source in front of the first steps
                     latents = video2video.inject(latents, randn, v2v_src, t, i, denoising_strength, v2v)
                 if loras_slists is not None and getattr(trans, "loras", None) is not None:

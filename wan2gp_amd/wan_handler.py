@@ -113,7 +113,7 @@ class family_handler():
             "sub_parallel_windows": False,
             # normalized attention guidance (wan_handler.py:994) and the image prompt types (:956-978): Start / End image, Video to
             # continue, Last-frame options for the i2v models -- generate(image_start=, image_end=) / the prefix-video path
-            "NAG": vace or t2v or i2v, "self_refiner": True,
+            "NAG": vace or t2v or i2v, "self_refiner": True, "perturbation": not vace,      # skip-layer guidance: not with VACE blocks
             "image_prompt_types_allowed": "TVL" if (vace or b in ("t2v", "t2v_2_2")) else ("TSVL" if b == "ti2v_2_2" else ("SEVL" if i2v else "")),
             # what the HIP path does not implement: offload, compile, in-app quantisation
             "compile": False, "no_quantization": True, "backend": "hip-gfx950",
