@@ -342,3 +342,81 @@ def test_skip_layer_guidance_runs_listed_blocks_for_the_first_stream_only(mock):
     # every block listed: only stream 0 moves
     rc, allp, _ = m.forward(S=2, perturb=[0, 1])
     assert rc == 0 and all(cl[2][0] == 1 for cl in allp if cl[0] == "attention")
+
+
+def _vace_model(L):
+    m = Model.__new__(Model)
+    m.L, m.cfg = L, O.make_config("tiny_vace")
+    c = m.cfg
+    dc = DitConfig(c.dim, c.ffn_dim, c.num_heads, c.num_layers, c.in_dim, c.out_dim, c.text_dim, c.freq_dim, c.text_len, c.eps)
+    m.ctx = c_void_p()
+    assert L.wan_dit_create(ctypes.byref(dc), ctypes.byref(m.ctx)) == 0
+    assert L.wan_dit_set_vace_layers(m.ctx, (c_int * len(c.vace_layers))(*c.vace_layers), len(c.vace_layers)) == 0
+    assert L.wan_dit_set_vace_contexts(m.ctx, 2) == 0
+    m.addr = {}
+    for n, (k, shape) in enumerate(O.param_shapes(c).items()):
+        numel = 1
+        for s in shape:
+            numel *= s
+        m.addr[k] = 0x1000_0000_0000 + n * 0x10_0000_0000
+        dt = 1 if k.startswith(("patch_embedding.", "head.", "vace_patch_embedding.")) else 0
+        assert L.wan_dit_set_weight(m.ctx, k.encode(), c_void_p(m.addr[k]), dt, numel) == 0, (k, L.wan_last_error())
+    return m
+
+
+def _forward_vace(L, m, contexts, scales, S=2, fhw=(2, 8, 8)):
+    F, H, W = fhw
+    nb = L.wan_dit_workspace_bytes(m.ctx, S, F, H, W, 1)
+    X = (c_void_p * S)(*[0x6000_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+    C = (c_void_p * S)(*[0x6100_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+    OUT = (c_void_p * S)(*[0x6200_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+    nv = len(contexts)
+    a = DitArgs(S, X, 588.0, C, None, 0x6300_0000_0000, 0x6310_0000_0000, OUT, F, H, W, WS, nb, None, None, None, None, None,
+                None, 1.0, None, 0, nv, (c_void_p * nv)(*contexts), (ctypes.c_float * nv)(*scales), 0.0, 0.0, 0.0, None, None, 0, 0)
+    L.mock_reset()
+    rc = L.wan_dit_forward_ex(m.ctx, ctypes.byref(a), None)
+    return rc, [(c.name.decode(), list(c.p), list(c.i), list(c.f)) for c in (L.mock_get(i).contents for i in range(L.mock_count()))], nb
+
+
+def test_vace_context_blocks_launch_order_and_scales(mock):
+    """VaceWanAttentionBlock around the main blocks it is attached to (model.py:617-629, :713-719, :816-828): per active context a
+    patch embedding of the context, before_proj (+ x) in front of context block 0, the same layer code on the hint stream,
+    after_proj, and behind the main block x += scale * hint in context order; a context with scale 0 is switched off."""
+    m = _vace_model(mock)
+    c = m.cfg
+    rc, calls, nbytes = _forward_vace(mock, m, [0x6500_0000_0000, 0x6510_0000_0000], [1.0, 0.5])
+    assert rc == 0, mock.wan_last_error()
+    for cl in calls:
+        for ptr, n in extents(cl):
+            if in_ws(ptr, nbytes):
+                assert ptr + n <= WS + nbytes, (cl[0], hex(ptr - WS), n)
+    pe = [cl for cl in calls if cl[0] == "patch_embed"]
+    assert [cl[1][0] for cl in pe[2:]] == [0x6500_0000_0000, 0x6510_0000_0000] and all(cl[1][2] == m.addr["vace_patch_embedding.weight"] for cl in pe[2:])
+    ax = [cl for cl in calls if cl[0] == "axpy"]
+    assert len(ax) == 2 * len(c.vace_layers) and [round(cl[3][0], 6) for cl in ax] == [1.0, 0.5] * len(c.vace_layers)
+    assert all(cl[1][0] == WS and cl[1][2] == WS for cl in ax)                                   # x += scale * hint, in place on the main streams
+    before = [cl for cl in calls if cl[0] == "gemm" and cl[1][1] == m.addr["vace_blocks.0.before_proj.weight"]]
+    assert len(before) == 2 and all(cl[2][5] == 2 and cl[1][4] == WS for cl in before)           # c = before_proj(c) + x: residual = the main streams
+    after = [cl for cl in calls if cl[0] == "gemm" and cl[1][1] in (m.addr["vace_blocks.0.after_proj.weight"], m.addr["vace_blocks.1.after_proj.weight"])]
+    assert len(after) == 4
+    n_ln = [cl[0] for cl in calls].count("ln_modulate")
+    assert n_ln == 2 * (c.num_layers + 2 * len(c.vace_layers))                                   # main blocks + a context block per context per attachment
+    rc, off, _ = _forward_vace(mock, m, [0x6500_0000_0000, 0x6510_0000_0000], [0.0, 0.5])
+    assert rc == 0 and [cl[0] for cl in off].count("axpy") == len(c.vace_layers) and [cl[0] for cl in off].count("patch_embed") == 3
+    rc, _, _ = _forward_vace(mock, m, [0x6500_0000_0000], [1.0], S=2)
+    assert rc == 0
+
+
+def test_per_frame_timesteps_need_whole_frame_shards(mock):
+    """t as a vector (model.py:1812-1818): the time MLP runs on F rows and every modulation lookup takes rows_per_batch = tokens per
+    frame; under sequence parallelism a rank owns whole frames or the call is refused."""
+    m = Model(mock)
+    rc, calls, _ = m.forward(S=2, t_frames=[0.0, 637.0])
+    assert rc == 0
+    assert [cl[0] for cl in calls].count("sinusoid") == 2
+    assert all(cl[2][5] == 16 for cl in calls if cl[0] == "ln_modulate")                        # rows_per_batch = 4 x 4 tokens per frame
+    cb, cw = GATHER_FN(lambda *a: 0), GATHER_WAIT_FN(lambda *a: 0)
+    rc, _, _ = m.forward(S=2, t_frames=[0.0, 637.0, 300.0], fhw=(3, 8, 8), sp=SpInfo(0, 2, 0, 24, cb, cw, None))
+    assert rc == 1 and b"whole frames" in mock.wan_last_error()
+    rc, calls, _ = m.forward(S=2, t_frames=[0.0, 637.0], sp=SpInfo(1, 2, 16, 16, cb, cw, None))
+    assert rc == 0 and [round(cl[3][0]) for cl in calls if cl[0] == "sinusoid"] == [637]        # rank 1 embeds its own frame's timestep only
