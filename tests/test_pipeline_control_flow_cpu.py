@@ -462,3 +462,16 @@ def test_skip_layer_guidance_is_passed_inside_its_window_of_steps():
     m = Rec("A")
     run(WanAny2VHIP(m, device="cpu"))
     assert m.slg == [None] * 6
+
+
+def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():
+    """wgp.py passes every generate() the union of all variants' keywords (wgp.py:7762-7885): defaults and UI plumbing are accepted
+    silently, a keyword that would change the video through a path this backend does not serve raises."""
+    pipe = WanAny2VHIP(FakeDiT("A"), device="cpu")
+    out = run(pipe, input_ref_images=None, audio_guide=None, overlap_noise=0, image_mode=0, alt_guide_scale=1.0, fit_into_canvas=True, window_no=1,
+              offloadobj=object(), set_header_text=lambda *a: None, model_filename="x.safetensors", fps=16, gen_state={}, custom_settings=None)
+    assert torch.isfinite(out["latents"]).all()
+    for kw in (dict(input_ref_images=[torch.zeros(3, 8, 8)]), dict(prefix_video=torch.zeros(3, 5, 8, 8)), dict(overlapped_latents=torch.zeros(1, 16, 2, 8, 8)),
+               dict(audio_proj=torch.zeros(1)), dict(image_mode=1), dict(overlap_noise=20), dict(alt_guide_scale=2.0), dict(vae_upsampler="x")):
+        with pytest.raises(NotImplementedError, match=list(kw)[0]):
+            run(pipe, **kw)

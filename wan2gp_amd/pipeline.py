@@ -19,6 +19,21 @@ from .schedulers import (EulerScheduler, FlowDPMSolverMultistepScheduler, FlowMa
                          HipScheduler, LCMScheduler, cfg_combine, get_sampling_sigmas, retrieve_timesteps)
 
 
+# keyword -> the reference's default (any2video.py:414-503): a non-default value asks for something generate() below does not do
+_UNSERVED_WHEN_SET = {"input_frames2": None, "input_masks2": None, "input_ref_images": None, "input_ref_masks": None, "input_faces": None,
+                      "input_custom": None, "audio_scale": None, "audio_proj": None, "audio_context_lens": None, "audio_guide": None,
+                      "audio_guide2": None, "input_waveform": None, "alt_guide_scale": 1.0, "overlapped_latents": None, "overlap_noise": 0,
+                      "conditioning_latents_size": 0, "speakers_bboxes": None, "image_mode": 0, "pre_video_frame": None, "prefix_video": None,
+                      "face_arc_embeds": None, "control_scale_alt": 1.0, "vae_upsampler": None, "causal_attention": False}
+
+
+def _same(v, default):
+    try:
+        return bool(v == default)
+    except Exception:                                         # tensors and the like: set
+        return False
+
+
 class WanAny2VHIP:
     def __init__(self, model, model2=None, vae=None, text_encoder: Optional[Callable] = None, device="cuda",
                  num_train_timesteps=1000, vae_stride=(4, 8, 8), patch_size=(1, 2, 2)):
@@ -165,6 +180,14 @@ class WanAny2VHIP:
                  self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
+        # wgp.py hands every generate() the union of all variants' keywords (wgp.py:7762-7885); the ones below change the result
+        # when they are set and belong to paths this backend does not serve: refuse instead of producing a different video
+        # (the other unknown keywords -- UI handles, file names, progress hooks -- are swallowed like the reference's **bbargs)
+        unserved = {k: bbargs[k] for k, default in _UNSERVED_WHEN_SET.items()
+                    if bbargs.get(k, None) is not None and not _same(bbargs[k], default)}
+        if unserved:
+            raise NotImplementedError(f"WanAny2VHIP.generate: {sorted(unserved)} select reference paths outside this backend "
+                                      "(reference images / second control video / audio / sliding-window overlap / image outputs / VAE upsampler)")
         if context is None:
             if self.text_encoder is None or input_prompt is None:
                 raise ValueError("pass `context`/`context_null` ([1,512,4096] bf16) or a text_encoder + input_prompt")
