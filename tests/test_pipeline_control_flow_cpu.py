@@ -475,3 +475,71 @@ def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():
                dict(audio_proj=torch.zeros(1)), dict(image_mode=1), dict(overlap_noise=20), dict(alt_guide_scale=2.0), dict(vae_upsampler="x")):
         with pytest.raises(NotImplementedError, match=list(kw)[0]):
             run(pipe, **kw)
+
+
+def test_progress_protocol_matches_the_references_callback_calls():
+    """any2video.py:1410-1411, :1434-1436, :1442, :1446, :1743-1750: what wgp.py's callback and set_header_text receive."""
+    calls, headers = [], []
+
+    def cb(step, latents=None, force=False, override_num_inference_steps=-1, denoising_extra="", **kw):
+        calls.append((step, None if latents is None else tuple(latents.shape), force, override_num_inference_steps, denoising_extra))
+    a, b = FakeDiT("A"), FakeDiT("B")
+    run(WanAny2VHIP(a, b, device="cpu"), guide_phases=2, switch_threshold=800, callback=cb, set_header_text=headers.append)
+    n_high = len(a.calls)
+    assert 0 < n_high < 6
+    assert headers == [f"Denoising Steps:  Phase 1 = 1:{n_high}, Phase 2 = {n_high + 1}:6"]
+    assert calls[0] == (-1, None, True, -1, "") and calls[1] == (-1, None, True, 6, "Phase 1/2 High Noise")
+    body = calls[2:]
+    switch = [c for c in body if c[1] is None]
+    assert switch == [(n_high - 1, None, False, -1, "Phase 2/2 Low Noise")]                    # callback(step_no - 1, denoising_extra=)
+    steps = [c for c in body if c[1] is not None]
+    assert [c[0] for c in steps] == list(range(6)) and all(c[1] == (16, 3, 8, 8) and c[2] is False for c in steps)
+    assert [c[4] for c in steps] == ["Phase 1/2 High Noise"] * n_high + ["Phase 2/2 Low Noise"] * (6 - n_high)
+    assert body.index(switch[0]) == n_high                                                     # in front of the first low-noise step
+    # one expert, several phases: no noise-level suffix; one phase: empty extra, no header
+    calls.clear(), headers.clear()
+    run(WanAny2VHIP(FakeDiT("A"), device="cpu"), guide_phases=2, switch_threshold=800, callback=cb, set_header_text=headers.append)
+    assert calls[1][4] == "Phase 1/2" and calls[-1][4] == "Phase 2/2" and len(headers) == 1
+    calls.clear(), headers.clear()
+    run(WanAny2VHIP(FakeDiT("A"), device="cpu"), callback=cb, set_header_text=headers.append)
+    assert headers == [] and all(c[4] == "" for c in calls) and calls[1][3] == 6
+
+
+def test_positional_callbacks_keep_working_and_previews_leave_out_the_padded_end_frame():
+    seen = []
+    run(WanAny2VHIP(FakeDiT("A"), device="cpu"), guide_phases=2, switch_threshold=800, callback=lambda i, lat, force: seen.append((i, force)))
+    assert seen == [(-1, True), (-1, True)] + [(i, False) for i in range(6)]
+    from oracle.make_golden_i2v_cond import FakeVAE
+    m = FakeDiT("A")
+    m.model_type = "i2v"
+    shapes = []
+    img = torch.rand(3, 64, 64) * 2 - 1
+    out = run(WanAny2VHIP(m, vae=FakeVAE(), device="cpu"), image_start=img, image_end=img, clip_fea=torch.zeros(1, 257, 1280),
+              callback=lambda i, lat, force: shapes.append(None if lat is None else lat.shape[1]))
+    assert out["latents"].shape[2] == 3 and shapes[2:] == [3] * 6          # 4 latent frames inside the loop, 3 shown
+
+
+def test_video_to_video_keeps_the_whole_schedule_for_cache_thresholds_and_lora_steps():
+    """any2video.py:546, :1404-1406, :1444, :1493: when the schedule is cut short, the step-skipping thresholds and the LoRA
+    multipliers still refer to the uncut schedule -- start step max(cache.start_step, start_step_no), step start_step_no + i."""
+    from oracle.make_golden_i2v_cond import FakeVAE
+    from wan2gp_amd.skipcache import SkipStepsCache
+    from wan2gp_amd.lora import parse_loras_multipliers
+
+    class Rec:
+        def __init__(self):
+            self.steps = []
+
+        def set_step(self, slists, n, step_no, s1, s2):
+            self.steps.append((n, step_no))
+    vid = torch.rand(3, 9, 64, 64, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    m = FakeDiT("A")
+    m.cache = SkipStepsCache(cache_type="mag", multiplier=2.0, start_step=1, magcache_K=2, magcache_thresh=0, def_mag_ratios=[0.99] * 10)
+    m.loras = Rec()
+    _, slists, err = parse_loras_multipliers("1", 1, 6)
+    assert err == ""
+    run(WanAny2VHIP(m, vae=FakeVAE(), device="cpu"), input_frames=vid, video_prompt_type="G", denoising_strength=0.5, guide_scale=1.0,
+        loras_slists=slists)
+    assert len(m.calls) == 3
+    assert m.thresholds == ("mag", 3, 6, 2.0) and m.cache.num_steps == 6
+    assert m.loras.steps == [(6, 3), (6, 4), (6, 5)]

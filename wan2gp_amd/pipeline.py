@@ -34,6 +34,54 @@ def _same(v, default):
         return False
 
 
+class _Progress:
+    """The progress protocol `WanAny2V.generate` speaks to wgp.py's callback (any2video.py:1410-1411, :1434, :1442, :1446,
+    :1743-1750): `(-1, None, True)` once the setup is done, `(-1, None, True, override_num_inference_steps=, denoising_extra=)`
+    in front of the loop, `(step - 1, denoising_extra=)` when a guidance phase begins, `(step, preview latents, False,
+    denoising_extra=)` behind every step.  The keyword half is passed only to callbacks whose signature takes it, so plain
+    `cb(step, latents, flag)` callables keep working."""
+
+    def __init__(self, callback, set_header_text=None):
+        self.callback, self.set_header_text, self.extra = callback, set_header_text, ""
+        self.keywords = False
+        if callback is not None:
+            import inspect
+            try:
+                params = inspect.signature(callback).parameters.values()
+                self.keywords = any(q.kind is q.VAR_KEYWORD for q in params) or \
+                    {"override_num_inference_steps", "denoising_extra"} <= {q.name for q in params}
+            except (TypeError, ValueError):
+                self.keywords = False
+
+    def ready(self):
+        if self.callback is not None:
+            self.callback(-1, None, True)
+
+    def begin(self, num_steps, guide_phases, two_experts, phases_description):
+        if phases_description and self.set_header_text is not None:
+            self.set_header_text(phases_description)
+        if guide_phases > 1:
+            self.extra = f"Phase 1/{guide_phases} High Noise" if two_experts else f"Phase 1/{guide_phases}"
+        if self.callback is not None:
+            if self.keywords:
+                self.callback(-1, None, True, override_num_inference_steps=num_steps, denoising_extra=self.extra)
+            else:
+                self.callback(-1, None, True)
+
+    def phase(self, step_no, phase_no, guide_phases, two_experts, low_noise):
+        self.extra = f"Phase {phase_no}/{guide_phases}" + ((" Low Noise" if low_noise else " High Noise") if two_experts else "")
+        if self.callback is not None and self.keywords:
+            self.callback(step_no - 1, denoising_extra=self.extra)
+
+    def step(self, i, preview):
+        if self.callback is not None:
+            if self.keywords:
+                self.callback(i, preview, False, denoising_extra=self.extra)
+            else:
+                self.callback(i, preview, False)
+
+
+
 class WanAny2VHIP:
     def __init__(self, model, model2=None, vae=None, text_encoder: Optional[Callable] = None, device="cuda",
                  num_train_timesteps=1000, vae_stride=(4, 8, 8), patch_size=(1, 2, 2)):
@@ -177,7 +225,7 @@ class WanAny2VHIP:
                  motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, image_end=None,
                  return_latent_slice=None, video_prompt_type="", denoising_strength=1.0, masking_strength=1.0, keep_frames_parsed=None,
                  prefix_frames_count=0, self_refiner_setting=0, self_refiner_plan="", self_refiner_f_uncertainty=0.0,
-                 self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, **bbargs):
+                 self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, set_header_text=None, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         # wgp.py hands every generate() the union of all variants' keywords (wgp.py:7762-7885); the ones below change the result
@@ -259,6 +307,7 @@ class WanAny2VHIP:
                 raise ValueError("input_video (timestep injection) is the ti2v_2_2 conditioning path and needs the Wan2.2 VAE")
             source_latents = self.vae.encode([input_video.to(dev)], VAE_tile_size)[0].unsqueeze(0)
         v2v, v2v_src, randn, start_step_no = None, None, None, 0
+        original_timesteps = timesteps            # any2video.py:546: the whole schedule, also when video-to-video cuts it short
         if v2v_on:
             from . import video2video
             if self.vae is None:
@@ -284,11 +333,11 @@ class WanAny2VHIP:
         text_momentum = None
         # LoRA multipliers per step (any2video.py:1431-1445, :1493): the reference re-selects the active multipliers on
         # every step (offload.set_step_no_for_lora); merged adapters are re-merged only when a step's multipliers change
-        if loras_slists is not None:
-            from .lora import get_model_switch_steps
-            phase_switch_step, phase_switch_step2, _ = get_model_switch_steps(
-                [float(t) for t in timesteps], guide_phases, 0 if self.model2 is None else model_switch_phase, switch_threshold,
-                switch2_threshold)
+        from .lora import get_model_switch_steps
+        phase_switch_step, phase_switch_step2, phases_description = get_model_switch_steps(
+            [float(t) for t in original_timesteps], guide_phases, 0 if self.model2 is None else model_switch_phase, switch_threshold,
+            switch2_threshold)
+        progress = _Progress(callback, set_header_text)
         # sub-parallel temporal windows (any2video.py:1199-1223, :1392-1397): per-step forwards on overlapping windows of latent
         # frames; step-skipping caches are parked while they are active (their residuals have the full clip's token count)
         from . import subparallel
@@ -318,12 +367,14 @@ class WanAny2VHIP:
                 seen.append(cache)
                 from . import skipcache
                 skipcache.reset_for_generation(cache, 2)
-                cache.num_steps = len(timesteps)
+                cache.num_steps = len(original_timesteps)
                 cache.previous_modulated_input = None
                 if cache.cache_type == "tea":
-                    m.compute_teacache_threshold(cache.start_step, timesteps, cache.multiplier)
+                    m.compute_teacache_threshold(max(cache.start_step, start_step_no), original_timesteps, cache.multiplier)
                 else:
-                    m.compute_magcache_threshold(cache.start_step, timesteps, cache.multiplier)
+                    m.compute_magcache_threshold(max(cache.start_step, start_step_no), original_timesteps, cache.multiplier)
+        progress.ready()                                                                           # :1410-1411
+        progress.begin(len(timesteps), guide_phases, self.model2 is not None, phases_description)  # :1434-1436, :1446
         kwargs = {"freqs": freqs, "pipeline": self, "callback": callback, "y": y, "max_steps": len(timesteps), **vace_kwargs}
         if clip_fea is not None:
             kwargs["clip_fea"] = clip_fea
@@ -334,10 +385,12 @@ class WanAny2VHIP:
                     if model_switch_phase == 1 and self.model2 is not None:
                         trans = self.model2
                     guide_scale, guidance_switch_done = guide2_scale, True
+                    progress.phase(i, 2, guide_phases, self.model2 is not None, trans is self.model2)
                 if guide_phases >= 3 and not guidance_switch2_done and t <= switch2_threshold:          # phase 3 (:1492)
                     if model_switch_phase == 2 and self.model2 is not None:
                         trans = self.model2
                     guide_scale, guidance_switch2_done = guide3_scale, True
+                    progress.phase(i, 3, guide_phases, self.model2 is not None, trans is self.model2)
                 timestep = torch.stack([t])
                 if source_latents is not None:                   # any2video.py:1496-1499
                     n_src = source_latents.shape[2]
@@ -351,7 +404,7 @@ class WanAny2VHIP:
                 if v2v is not None:                              # any2video.py:1504-1515: the noised source in front of the first steps
                     latents = video2video.inject(latents, randn, v2v_src, t, i, denoising_strength, v2v)
                 if loras_slists is not None and getattr(trans, "loras", None) is not None:
-                    trans.loras.set_step(loras_slists, len(timesteps), i, phase_switch_step, phase_switch_step2)
+                    trans.loras.set_step(loras_slists, len(original_timesteps), start_step_no + i, phase_switch_step, phase_switch_step2)   # :1444, :1493
                 if ext_latents is not None:                      # any2video.py:1517-1523: re-noise the known first latent
                     f = float(t) / 1000.0
                     n = ext_latents.shape[2]
@@ -404,8 +457,8 @@ class WanAny2VHIP:
                     latents = sample_scheduler.step(noise_pred[:, :, :target_shape[1]], t, latents, generator=seed_g)[0]
                 if v2v is not None:                              # :1737-1740: outside the mask, the source at the next step's noise level
                     latents = video2video.merge(latents, randn, v2v_src, timesteps, i, v2v)
-                if callback is not None:
-                    callback(i, latents[0], False)
+                if callback is not None:                         # :1743-1750: the preview leaves out the padded end-image frame
+                    progress.step(i, (latents[:, :, :-trim_frames] if trim_frames > 0 else latents)[0])
         finally:
             restore_caches()                                 # also when a forward raises: parked caches must come back
         if source_latents is not None:
