@@ -509,6 +509,11 @@ def test_positional_callbacks_keep_working_and_previews_leave_out_the_padded_end
     seen = []
     run(WanAny2VHIP(FakeDiT("A"), device="cpu"), guide_phases=2, switch_threshold=800, callback=lambda i, lat, force: seen.append((i, force)))
     assert seen == [(-1, True), (-1, True)] + [(i, False) for i in range(6)]
+    # a callable that takes keywords but needs the latents (the GPU loop tests' tracing lambdas): no latent-less phase notice
+    trace, kws = [], []
+    run(WanAny2VHIP(FakeDiT("A"), FakeDiT("B"), device="cpu"), guide_phases=2, switch_threshold=800,
+        callback=lambda i, l, *a, **k: (kws.append(k), trace.append(l.shape) if i >= 0 else None))
+    assert len(trace) == 6 and kws[1]["override_num_inference_steps"] == 6 and kws[-1]["denoising_extra"] == "Phase 2/2 Low Noise"
     from oracle.make_golden_i2v_cond import FakeVAE
     m = FakeDiT("A")
     m.model_type = "i2v"

@@ -38,20 +38,23 @@ class _Progress:
     """The progress protocol `WanAny2V.generate` speaks to wgp.py's callback (any2video.py:1410-1411, :1434, :1442, :1446,
     :1743-1750): `(-1, None, True)` once the setup is done, `(-1, None, True, override_num_inference_steps=, denoising_extra=)`
     in front of the loop, `(step - 1, denoising_extra=)` when a guidance phase begins, `(step, preview latents, False,
-    denoising_extra=)` behind every step.  The keyword half is passed only to callbacks whose signature takes it, so plain
-    `cb(step, latents, flag)` callables keep working."""
+    denoising_extra=)` behind every step.  The keyword half is passed only to callbacks whose signature takes it (and the phase
+    notice only to those callable with the step alone), so plain `cb(step, latents, flag)` callables keep working."""
 
     def __init__(self, callback, set_header_text=None):
         self.callback, self.set_header_text, self.extra = callback, set_header_text, ""
-        self.keywords = False
+        self.keywords = self.step_only = False
         if callback is not None:
             import inspect
             try:
-                params = inspect.signature(callback).parameters.values()
+                params = list(inspect.signature(callback).parameters.values())
                 self.keywords = any(q.kind is q.VAR_KEYWORD for q in params) or \
                     {"override_num_inference_steps", "denoising_extra"} <= {q.name for q in params}
+                # the phase notice is `callback(step - 1, denoising_extra=)`: only for callables whose other arguments are optional
+                self.step_only = self.keywords and all(q.default is not q.empty or q.kind in (q.VAR_POSITIONAL, q.VAR_KEYWORD)
+                                                       for q in params[1:])
             except (TypeError, ValueError):
-                self.keywords = False
+                self.keywords = self.step_only = False
 
     def ready(self):
         if self.callback is not None:
@@ -70,7 +73,7 @@ class _Progress:
 
     def phase(self, step_no, phase_no, guide_phases, two_experts, low_noise):
         self.extra = f"Phase {phase_no}/{guide_phases}" + ((" Low Noise" if low_noise else " High Noise") if two_experts else "")
-        if self.callback is not None and self.keywords:
+        if self.callback is not None and self.step_only:
             self.callback(step_no - 1, denoising_extra=self.extra)
 
     def step(self, i, preview):
