@@ -194,17 +194,16 @@ class family_handler():
         the same command-line overrides.  (`register_lora_cli_args` is left to the built-in handler: the flags exist once.)"""
         b = base_of(base_model_type)
         i2v = test_class_i2v(b) and not test_i2v_2_2(b)
-        wan_dir = getattr(args, "lora_dir_wan", None) or getattr(args, "lora_dir", None) or os.path.join(lora_root, "wan")
-        wan_i2v_dir = getattr(args, "lora_dir_wan_i2v", None) or getattr(args, "lora_dir_i2v", None) or os.path.join(lora_root, "wan_i2v")
-        wan_1_3b_dir = getattr(args, "lora_dir_wan_1_3b", None) or os.path.join(lora_root, "wan_1.3B")
-        wan_5b_dir = getattr(args, "lora_dir_wan_5b", None) or os.path.join(lora_root, "wan_5B")
+
+        def folder(default, *flags):                       # first command-line override that is set, else the folder under lora_root
+            return next((v for v in (getattr(args, f, None) for f in flags) if v), os.path.join(lora_root, default))
         if i2v:
-            return wan_i2v_dir
+            return folder("wan_i2v", "lora_dir_wan_i2v", "lora_dir_i2v")
         if "1.3B" in b:
-            return wan_1_3b_dir
+            return folder("wan_1.3B", "lora_dir_wan_1_3b")
         if test_wan_5B(b):
-            return wan_5b_dir
-        return wan_dir
+            return folder("wan_5B", "lora_dir_wan_5b")
+        return folder("wan", "lora_dir_wan", "lora_dir")
 
     @staticmethod
     def set_cache_parameters(cache_type, base_model_type, model_def, inputs, skip_steps_cache):
