@@ -463,6 +463,9 @@ int wan_vae_rmsnorm_silu(const uint16_t* x, uint16_t* out, const uint16_t* gamma
 int wan_gemm_f16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
                  uint16_t* C, int64_t ldc, int64_t M, int64_t N, int K, float scale, int transposed,
                  void* stream);
+/* Test hook (not a product entry): force wan_vae_conv3d onto its 64-bit-offset instantiations, which inputs below 2^31
+ * elements never reach; returns the previous setting.  Process-wide. */
+int wan_vae_debug_force_big(int on);
 /* P[r,:L] = softmax(S[r,:L]); P[r,L:ld] = 0 */
 int wan_vae_softmax(const uint16_t* S, uint16_t* P, int64_t rows, int L, int64_t ld, void* stream);
 /* fp32 [C,thw] -> fp16 [thw,Cp] (zero padded channels), optional v*mul[c]+add[c] */

@@ -8,7 +8,15 @@ Restates models/wan/modules/vae.py (file:line citations into /root/reference):
 Functional, NCTHW tensors, weights = the reference's state_dict keys.  Pinned bit-exactly (fp32)
 against the reference's own module on tests/golden/vae_small.npz (oracle/make_golden_vae.py).
 Only used by tests / bench cpu_baseline / smoke -- never by the product package.
+
+Second plan, `with fp16_plan():` -- the SAME graph with every tensor the HIP library stores in fp16 rounded to fp16 at the
+point where it is stored (wan2gp_amd/vae.py, csrc/vae_graph.hip: the packed input, every convolution output after bias /
+residual, RMS_norm(+SiLU), the attention block's q|k, V^T, scaled scores, probabilities and P.V), arithmetic in fp32 in
+between, the decoder head kept in fp32.  It is NOT pinned to the reference (the reference has no such mode on a CPU);
+it exists so that a test can attribute the bytes in which the HIP decode differs from the fp32 golden to the fp16
+storage plan rather than to a kernel (tests/test_gpu_vae_720p.py).  Outside the context manager nothing changes.
 """
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -21,6 +29,23 @@ STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
        3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
 
 CFG = dict(dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, temperal_downsample=[False, True, True])
+
+_PLAN16 = [False]
+
+
+@contextlib.contextmanager
+def fp16_plan():
+    """Round every tensor the HIP VAE stores in fp16 to fp16 where it is stored (see the module docstring)."""
+    old = _PLAN16[0]
+    _PLAN16[0] = True
+    try:
+        yield
+    finally:
+        _PLAN16[0] = old
+
+
+def _q(x):
+    return x.to(torch.float16).to(x.dtype) if _PLAN16[0] else x
 
 
 def vae_param_shapes(cfg=CFG) -> Dict[str, tuple]:
@@ -137,9 +162,9 @@ def _cache_update(x, old):
 
 def residual_block(x, W, p, cache, idx):
     """ResidualBlock.forward (vae.py:251-273)."""
-    h = causal_conv3d(x, W[p + "shortcut.weight"], W[p + "shortcut.bias"]) if (p + "shortcut.weight") in W else x
+    h = _q(causal_conv3d(x, W[p + "shortcut.weight"], W[p + "shortcut.bias"])) if (p + "shortcut.weight") in W else x
     for n, c in (("0", "2"), ("3", "6")):
-        x = F.silu(rms_norm(x, W[p + f"residual.{n}.gamma"]))
+        x = _q(F.silu(rms_norm(x, W[p + f"residual.{n}.gamma"])))
         if cache is not None:
             cx = _cache_update(x, cache[idx[0]])
             x = causal_conv3d(x, W[p + f"residual.{c}.weight"], W[p + f"residual.{c}.bias"], cache[idx[0]])
@@ -147,21 +172,27 @@ def residual_block(x, W, p, cache, idx):
             idx[0] += 1
         else:
             x = causal_conv3d(x, W[p + f"residual.{c}.weight"], W[p + f"residual.{c}.bias"])
-    return x + h
+        if c == "2":
+            x = _q(x)           # fp16 plan: the second convolution's rounding comes after the fused residual add
+    return _q(x + h)
 
 
 def attention_block(x, W, p):
     """AttentionBlock.forward (vae.py:294-315): per-frame single-head attention over h*w tokens."""
     b, c, t, h, w = x.shape
     y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
-    y = rms_norm(y, W[p + "norm.gamma"])
-    qkv = F.conv2d(y, W[p + "to_qkv.weight"], W[p + "to_qkv.bias"])
+    y = _q(rms_norm(y, W[p + "norm.gamma"]))
+    qkv = _q(F.conv2d(y, W[p + "to_qkv.weight"], W[p + "to_qkv.bias"]))
     q, k, v = qkv.reshape(b * t, 1, c * 3, -1).permute(0, 1, 3, 2).contiguous().chunk(3, dim=-1)
-    y = F.scaled_dot_product_attention(q, k, v)
+    if _PLAN16[0]:              # scores, probabilities and P.V are fp16 tensors in HBM (wan2gp_amd/vae.py attention_block)
+        sc = _q((q @ k.transpose(-1, -2)) * (1.0 / c ** 0.5))
+        y = _q(_q(torch.softmax(sc, dim=-1)) @ v)
+    else:
+        y = F.scaled_dot_product_attention(q, k, v)
     y = y.squeeze(1).permute(0, 2, 1).reshape(b * t, c, h, w)
     y = F.conv2d(y, W[p + "proj.weight"], W[p + "proj.bias"])
     y = y.reshape(b, t, c, h, w).permute(0, 2, 1, 3, 4)
-    return y + x
+    return _q(y + x)
 
 
 def resample(x, W, p, mode, cache, idx):
@@ -181,9 +212,9 @@ def resample(x, W, p, mode, cache, idx):
             else:
                 cache_x = cache_x.clone()
             if isinstance(cache[i], str):
-                x = causal_conv3d(x, W[p + "time_conv.weight"], W[p + "time_conv.bias"], pad=(1, 0, 0))
+                x = _q(causal_conv3d(x, W[p + "time_conv.weight"], W[p + "time_conv.bias"], pad=(1, 0, 0)))
             else:
-                x = causal_conv3d(x, W[p + "time_conv.weight"], W[p + "time_conv.bias"], cache[i], pad=(1, 0, 0))
+                x = _q(causal_conv3d(x, W[p + "time_conv.weight"], W[p + "time_conv.bias"], cache[i], pad=(1, 0, 0)))
             cache[i] = cache_x
             idx[0] += 1
             x = x.reshape(b, 2, c, t, h, w)
@@ -192,9 +223,9 @@ def resample(x, W, p, mode, cache, idx):
     y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
     if mode in ("upsample2d", "upsample3d"):
         y = F.interpolate(y.float(), scale_factor=(2., 2.), mode="nearest-exact").type_as(y)
-        y = F.conv2d(y, W[p + "resample.1.weight"], W[p + "resample.1.bias"], padding=1)
+        y = _q(F.conv2d(y, W[p + "resample.1.weight"], W[p + "resample.1.bias"], padding=1))
     else:
-        y = F.conv2d(F.pad(y, (0, 1, 0, 1)), W[p + "resample.1.weight"], W[p + "resample.1.bias"], stride=2)
+        y = _q(F.conv2d(F.pad(y, (0, 1, 0, 1)), W[p + "resample.1.weight"], W[p + "resample.1.bias"], stride=2))
     x = y.reshape(b, t, *y.shape[1:]).permute(0, 2, 1, 3, 4)
     if mode == "downsample3d" and cache is not None:
         i = idx[0]
@@ -203,18 +234,19 @@ def resample(x, W, p, mode, cache, idx):
             idx[0] += 1
         else:
             cache_x = x[:, :, -1:].clone()
-            x = causal_conv3d(torch.cat([cache[i][:, :, -1:], x], 2), W[p + "time_conv.weight"], W[p + "time_conv.bias"],
-                              stride=(2, 1, 1), pad=(0, 0, 0))
+            x = _q(causal_conv3d(torch.cat([cache[i][:, :, -1:], x], 2), W[p + "time_conv.weight"], W[p + "time_conv.bias"],
+                                 stride=(2, 1, 1), pad=(0, 0, 0)))
             cache[i] = cache_x
             idx[0] += 1
     return x
 
 
 def _cached_conv(x, W, name, cache, idx):
+    q = (lambda v: v) if name == "decoder.head.2" else _q        # the decoder head writes fp32 in the HIP library as well
     if cache is None:
-        return causal_conv3d(x, W[name + ".weight"], W[name + ".bias"])
+        return q(causal_conv3d(x, W[name + ".weight"], W[name + ".bias"]))
     cx = _cache_update(x, cache[idx[0]])
-    y = causal_conv3d(x, W[name + ".weight"], W[name + ".bias"], cache[idx[0]])
+    y = q(causal_conv3d(x, W[name + ".weight"], W[name + ".bias"], cache[idx[0]]))
     cache[idx[0]] = cx
     idx[0] += 1
     return y
@@ -252,7 +284,7 @@ def decoder_forward(x, W, cache, idx, cfg=CFG):
     x = residual_block(x, W, "decoder.middle.2.", cache, idx)
     for kind, p, mode in decoder_layers(cfg):
         x = residual_block(x, W, p, cache, idx) if kind == "res" else resample(x, W, p, mode, cache, idx)
-    x = F.silu(rms_norm(x, W["decoder.head.0.gamma"]))
+    x = _q(F.silu(rms_norm(x, W["decoder.head.0.gamma"])))
     return _cached_conv(x, W, "decoder.head.2", cache, idx)
 
 
@@ -264,7 +296,7 @@ def encoder_forward(x, W, cache, idx, cfg=CFG):
     x = residual_block(x, W, "encoder.middle.0.", cache, idx)
     x = attention_block(x, W, "encoder.middle.1.")
     x = residual_block(x, W, "encoder.middle.2.", cache, idx)
-    x = F.silu(rms_norm(x, W["encoder.head.0.gamma"]))
+    x = _q(F.silu(rms_norm(x, W["encoder.head.0.gamma"])))
     return _cached_conv(x, W, "encoder.head.2", cache, idx)
 
 
@@ -278,7 +310,7 @@ def vae_decode(z, W, scale=None, cfg=CFG, any_end_frame=False):
     (feat_cache=None: causal zero padding, no temporal upsampling), i.e. it decodes to one frame like the first."""
     if scale is not None:
         z = z / scale[1].view(1, -1, 1, 1, 1) + scale[0].view(1, -1, 1, 1, 1)
-    x = causal_conv3d(z, W["conv2.weight"], W["conv2.bias"])
+    x = _q(causal_conv3d(_q(z), W["conv2.weight"], W["conv2.bias"]))
     n = _n_cached_convs(W, "decoder.")
     cache = [None] * n
     outs = []
@@ -295,6 +327,7 @@ def vae_encode(x, W, scale=None, cfg=CFG, any_end_frame=False):
     """WanVAE_.encode (vae.py:586-625): chunks of 1,4,4,... frames; returns the normalised mu.  any_end_frame (:590-606):
     2 + (t - 2) // 4 chunks, the last one being the clip's last frame alone, encoded without the feature cache."""
     t = x.shape[2]
+    x = _q(x)
     n = _n_cached_convs(W, "encoder.")
     cache = [None] * n
     outs = []
@@ -307,7 +340,7 @@ def vae_encode(x, W, scale=None, cfg=CFG, any_end_frame=False):
         else:
             outs.append(encoder_forward(x[:, :, 1 + 4 * (i - 1):1 + 4 * i], W, cache, [0], cfg))
     out = torch.cat(outs, 2)
-    mu, _ = causal_conv3d(out, W["conv1.weight"], W["conv1.bias"]).chunk(2, dim=1)
+    mu, _ = _q(causal_conv3d(out, W["conv1.weight"], W["conv1.bias"])).chunk(2, dim=1)
     if scale is not None:
         mu = (mu - scale[0].view(1, -1, 1, 1, 1)) * scale[1].view(1, -1, 1, 1, 1)
     return mu

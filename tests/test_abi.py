@@ -63,3 +63,98 @@ def test_cpu_tensors_are_rejected(built):
     x = torch.zeros(4, 256, dtype=torch.bfloat16)
     with pytest.raises(lib.WanHipError):
         ops.ln_affine(x, x[0], x[0])
+
+
+# ---- the ctypes table against the header's declarations: arity, argument classes, struct layouts -------------------------------
+_FN_PTR_TYPES = {"wan_poll_fn", "wan_gather_begin_fn", "wan_gather_wait_fn"}
+
+
+def _c_class(decl):
+    """'const float* const* x' -> 'ptr'; 'int64_t n' -> 'i64'; works on a declaration with or without the name."""
+    d = decl.strip()
+    if "*" in d or any(re.search(r"\b%s\b" % t, d) for t in _FN_PTR_TYPES):
+        return "ptr"
+    for pat, cls in ((r"\bint64_t\b", "i64"), (r"\bdouble\b", "f64"), (r"\bfloat\b", "f32"), (r"\bint\b", "i32"), (r"\bvoid\b", "void")):
+        if re.search(pat, d):
+            return cls
+    raise AssertionError(f"unclassified C declaration: {decl!r}")
+
+
+def _ctypes_class(t):
+    import ctypes
+    if t is None:
+        return "void"
+    if t in (ctypes.c_int,):
+        return "i32"
+    if t is ctypes.c_int64:
+        return "i64"
+    if t is ctypes.c_float:
+        return "f32"
+    if t is ctypes.c_double:
+        return "f64"
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or isinstance(t, type(ctypes.CFUNCTYPE(None))):
+        return "ptr"
+    raise AssertionError(f"unclassified ctypes type: {t!r}")
+
+
+def _parse_header():
+    src = open(os.path.join(ROOT, "include", "wanhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for stmt in body.split(";"):
+            stmt = " ".join(stmt.split())
+            if not stmt:
+                continue
+            first, *rest = [s.strip() for s in stmt.split(",")]
+            m = re.match(r"(.*?)(\w+)$", first)
+            base, fname = m.group(1), m.group(2)
+            fields.append((fname, _c_class(base + " x")))
+            for r in rest:                                              # 'int F, H, W': the base type without its pointer stars
+                stars = r.count("*")
+                fields.append((r.replace("*", "").strip(), "ptr" if stars else _c_class(base.replace("*", "") + " x")))
+        structs[name] = fields
+    src_nostruct = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    src_nostruct = re.sub(r"typedef[^;]*;", "", src_nostruct)
+    funcs = {}
+    for ret, name, args in re.findall(r"([\w\s\*]+?)\b(wan_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", src_nostruct, flags=re.S):
+        args = " ".join(args.split())
+        arglist = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        funcs[name] = (_c_class(ret + " r") if ret.strip() != "void" else "void", [_c_class(a) for a in arglist])
+    return structs, funcs
+
+
+def test_ctypes_signatures_match_the_header_argument_by_argument():
+    """Names alone do not catch an argtype drift (wan_dit_args grew three times in one round): every prototype's return
+    class, arity and argument classes (pointer / int / int64_t / float / double) must equal lib.SIGNATURES'."""
+    from wan2gp_amd import lib
+    _, funcs = _parse_header()
+    assert set(funcs) == set(header_symbols()) and len(funcs) > 80
+    for name, (ret, args) in sorted(funcs.items()):
+        res, argtypes = lib.SIGNATURES[name]
+        got = [_ctypes_class(a) for a in argtypes]
+        assert len(got) == len(args), f"{name}: header has {len(args)} arguments, ctypes table {len(got)}"
+        assert got == args, f"{name}: header {args} vs ctypes {got}"
+        want_ret = "ptr" if name == "wan_last_error" else ret
+        assert _ctypes_class(res) == want_ret, f"{name}: return {ret} vs ctypes {_ctypes_class(res)}"
+
+
+def test_ctypes_structs_match_the_header_field_by_field():
+    """wan_dit_args / wan_dit_config / wan_sp_info: field names, order, classes and the resulting size (natural alignment)."""
+    import ctypes
+    from wan2gp_amd import lib
+    structs, _ = _parse_header()
+    size_of = {"i32": 4, "f32": 4, "i64": 8, "f64": 8, "ptr": 8}
+    for cname, cls in (("wan_dit_args", lib.DitArgs), ("wan_dit_config", lib.DitConfig), ("wan_sp_info", lib.SpInfo)):
+        want = structs[cname]
+        got = [(n, _ctypes_class(t)) for n, t in cls._fields_]
+        assert got == want, f"{cname}: header {want} vs ctypes {got}"
+        off = 0
+        for _, c in want:
+            a = size_of[c]
+            off = (off + a - 1) // a * a + a
+        size = (off + 7) // 8 * 8 if any(size_of[c] == 8 for _, c in want) else off
+        assert ctypes.sizeof(cls) == size, (cname, ctypes.sizeof(cls), size)

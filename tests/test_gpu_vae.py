@@ -4,7 +4,7 @@ reference) and the reference-generated fixture tests/golden/vae_small.npz.
 Tolerances: the HIP VAE stores activations in fp16 (the reference's default VAE dtype, wgp.py:4038) and
 accumulates in fp32; the oracle runs the same graph in fp32.  Per-op: |err| <= 2e-3 * max|ref| (fp16
 rounding of inputs/outputs).  End to end the check is on the INTEGER pixel output (BASELINE north star):
-max |delta| <= 2 LSB, >= 90% of the bytes identical, mean |delta| <= 0.1 LSB.
+max |delta| <= 1 LSB, >= 90% of the bytes identical, mean |delta| <= 0.1 LSB.
 """
 import os
 
@@ -160,7 +160,7 @@ def test_decode_to_uint8_vs_reference_golden(vae):
     d = (u8.int() - ref.int()).abs()
     frac_same = (d == 0).float().mean().item()
     print(f"VAE uint8: identical {frac_same * 100:.2f}%  max delta {int(d.max())}  mean delta {d.float().mean().item():.4f}")
-    assert int(d.max()) <= 2 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
+    assert int(d.max()) <= 1 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
     dec = vae.decode([z[0]], 0)[0].cpu()
     refd = torch.from_numpy(gold["dec"])[0].clamp(-1, 1)
     assert (dec - refd).abs().max().item() <= 1.5e-2
@@ -196,7 +196,7 @@ def test_spatial_tiling_vs_reference_golden(vae):
     d = (u8.int() - ref.int()).abs()
     frac_same = (d == 0).float().mean().item()
     print(f"VAE tiled uint8: identical {frac_same * 100:.2f}%  max delta {int(d.max())}  mean delta {d.float().mean().item():.4f}")
-    assert u8.shape == ref.shape and int(d.max()) <= 2 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
+    assert u8.shape == ref.shape and int(d.max()) <= 1 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
     crop = vae.decode_to_cpu_uint8([z[0]], 64, target_frames=3, target_height=100, target_width=120, frame_start=1)[0]
     assert torch.equal(crop, u8[:, 1:4, :100, :120]) and crop.shape == torch.from_numpy(gold["dec_u8_crop"])[0].shape
     untiled = vae.decode_to_cpu_uint8([z[0]], 0)[0]
@@ -261,7 +261,7 @@ def test_any_end_frame_vs_reference_golden(vae):
     d = (u8.int() - ref.int()).abs()
     frac_same = (d == 0).float().mean().item()
     print(f"VAE end-frame uint8: identical {frac_same * 100:.2f}%  max delta {int(d.max())}  mean delta {d.float().mean().item():.4f}")
-    assert int(d.max()) <= 2 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
+    assert int(d.max()) <= 1 and frac_same >= 0.90 and d.float().mean().item() <= 0.1
     dec = vae.decode([z[0]], 0, any_end_frame=True)[0].cpu()
     assert (dec - torch.from_numpy(gold["dec"])[0].clamp(-1, 1)).abs().max().item() <= 1.5e-2
     mu = vae.encode([vid[0]], any_end_frame=True)[0].cpu()

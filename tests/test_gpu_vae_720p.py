@@ -1,0 +1,260 @@
+"""-m gpu: the causal 3D VAE at the BASELINE size (720 x 1280) and the integer output conversion, through the C ABI.
+
+  * wan_vae_to_video against _vae_float_to_cpu_uint8 (vae.py:18-20) -- integer work, bar = BIT-EXACT (torch.equal) on a
+    crafted fp32 tensor: every tie (x + 1) * 127.5 = k + 0.5 with its fp32 neighbours, every exact level k / 127.5 - 1,
+    the +-1 clamp edges, values beyond them, +-inf, zeros / denormals, uniform and normal randoms.
+  * decode and encode at 720 x 1280 for 1 + 4 + 4 frames (latent t = 3) against oracle/vae_oracle.py run on the box's
+    cores: (a) the fp32 plan = the reference-pinned restatement, bar on the uint8 frames: max |delta| <= 1 LSB,
+    >= 90 % of the bytes identical (the HIP library stores activations in fp16, the reference's default VAE dtype on a
+    GPU, wgp.py:4038; the golden is the reference's fp32 CPU run); (b) the fp16 storage plan of the same restatement
+    (`with VO.fp16_plan()`): rounding to fp16 at the points where the library stores fp16 -- what is left between the
+    two is accumulation order, bar >= 99 % of the bytes identical, max 1 LSB.  (b) is what attributes the bytes of (a)
+    to the storage plan and not to a kernel.
+  * conv3d_f16_kernel<BIG> (64-bit gather offsets): forced onto an ordinary input and held bit-for-bit against the 32-bit
+    instantiation (plain, cached, up-sampled, stride-2), and reached for real by a chunk of more than 2^31 elements,
+    checked on sampled output pixels against an fp64 dot product of the same taps.
+
+The tables go to gpurun_out/parity/ (committed under profiles/).
+"""
+import json
+import os
+import time
+
+import pytest
+import torch
+
+from oracle import vae_oracle as VO
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F16 = torch.float16
+
+
+def _report(name, obj):
+    d = os.path.join(ROOT, "gpurun_out", "parity")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name + ".json"), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+
+
+# ---- a21: float -> uint8 --------------------------------------------------------------------------------------------------------
+def _crafted_floats():
+    k = torch.arange(0, 256, dtype=torch.float64)
+    ties = ((k + 0.5) / 127.5 - 1.0).float()                  # (x + 1) * 127.5 lands on or next to k + 0.5
+    levels = (k / 127.5 - 1.0).float()
+    base = torch.cat([ties, levels, torch.tensor([-1.0, 1.0, 0.0, -0.0, 1e-40, -1e-40, 1e-30, -1e-30])])
+    near = [base]
+    for step in range(1, 4):                                   # the three fp32 neighbours on each side
+        up, dn = base.clone(), base.clone()
+        for _ in range(step):
+            up = torch.nextafter(up, torch.full_like(up, 10.0))
+            dn = torch.nextafter(dn, torch.full_like(dn, -10.0))
+        near += [up, dn]
+    g = torch.Generator().manual_seed(5)
+    rnd = [torch.rand(200000, generator=g) * 2.4 - 1.2, torch.randn(200000, generator=g),
+           torch.randn(1000, generator=g) * 1e3, torch.tensor([float("inf"), float("-inf"), 3.0e38, -3.0e38, 2.0, -2.0])]
+    # ties reached in fp32 arithmetic itself: x such that fl(fl(x + 1) * 127.5) is exactly k + 0.5
+    exact = []
+    for kk in range(0, 255):
+        x = torch.tensor([(kk + 0.5) / 127.5 - 1.0], dtype=torch.float32)
+        for _ in range(8):
+            x = torch.cat([x, torch.nextafter(x[-1:], torch.tensor([10.0])), torch.nextafter(x[:1], torch.tensor([-10.0]))])
+        exact.append(x[((x + 1.0) * 127.5) == kk + 0.5])
+    return torch.cat(near + rnd + exact)
+
+
+def test_float_to_uint8_is_bit_exact():
+    from wan2gp_amd import lib as L
+    vals = _crafted_floats()
+    n_ties = int((((vals.clamp(-1, 1) + 1.0) * 127.5) % 1.0 == 0.5).sum())
+    assert n_ties >= 200, n_ties                                # the crafted set really contains round-half-even cases
+    T, HW = 3, (vals.numel() + 8) // 9 + 1
+    x = torch.zeros(T * HW * 3)
+    x[: vals.numel()] = vals
+    x = x[torch.randperm(x.numel(), generator=torch.Generator().manual_seed(1))].reshape(T, HW, 3)   # channels-last [T, HW, 3]
+    ref = VO.float_to_uint8(x.permute(2, 0, 1).contiguous())    # [3, T, HW] -- the reference's own statement sequence
+    lib = L.load()
+    xc = x.cuda()
+    Ttot, t0 = T + 3, 2
+    u8 = torch.full((3, Ttot, HW), 77, dtype=torch.uint8, device="cuda")
+    f32 = torch.full((3, Ttot, HW), -5.0, dtype=torch.float32, device="cuda")
+    L.check(lib.wan_vae_to_video(L.ptr(xc), L.ptr(u8), L.ptr(f32), T, HW, Ttot, t0, L.stream_ptr()), "wan_vae_to_video")
+    torch.cuda.synchronize()
+    got = u8.cpu()
+    assert torch.equal(got[:, t0:t0 + T], ref), "float -> uint8 differs from _vae_float_to_cpu_uint8"
+    assert (got[:, :t0] == 77).all() and (got[:, t0 + T:] == 77).all()          # frames outside [t0, t0 + T) untouched
+    assert torch.equal(f32.cpu()[:, t0:t0 + T], x.permute(2, 0, 1))             # the fp32 output is the unclamped copy (decode())
+    # the Wan2.1 decode path uses the same conversion at frame granularity: u8-only and f32-only calls
+    u8b = torch.empty(3, T, HW, dtype=torch.uint8, device="cuda")
+    L.check(lib.wan_vae_to_video(L.ptr(xc), L.ptr(u8b), None, T, HW, T, 0, L.stream_ptr()), "wan_vae_to_video")
+    assert torch.equal(u8b.cpu(), ref)
+    print(f"\n[a21] {vals.numel()} crafted values ({n_ties} exact ties): bit-exact")
+
+
+# ---- a18 / a20 at 720 x 1280 ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def vae():
+    from wan2gp_amd.vae import WanVAEHIP
+    return WanVAEHIP(state_dict=VO.synth_vae_weights(), device="cuda")
+
+
+def _u8_stats(a, b):
+    d = (a.int() - b.int()).abs()
+    return {"identical": (d == 0).float().mean().item(), "max_lsb": int(d.max()), "mean_lsb": d.float().mean().item()}
+
+
+def test_decode_720p_vs_oracle_fp32_and_fp16_plan(vae):
+    W = VO.synth_vae_weights()
+    scale = VO.default_scale()
+    g = torch.Generator().manual_seed(720)
+    z = torch.randn(16, 3, 90, 160, generator=g)
+    t0 = time.time()
+    u8 = vae.decode_to_cpu_uint8([z], 0)[0]
+    dec = vae.decode([z], 0)[0].cpu()
+    t_hip = time.time() - t0
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == (3, 9, 720, 1280)
+    with torch.no_grad():
+        t0 = time.time()
+        ref32 = VO.vae_decode(z[None], W, scale)[0]
+        t32 = time.time() - t0
+        with VO.fp16_plan():
+            ref16 = VO.vae_decode(z[None], W, scale)[0]
+        t16 = time.time() - t0 - t32
+    s32 = _u8_stats(u8, VO.float_to_uint8(ref32))
+    s16 = _u8_stats(u8, VO.float_to_uint8(ref16))
+    plan = _u8_stats(VO.float_to_uint8(ref16), VO.float_to_uint8(ref32))
+    f32_err = (dec - ref32.clamp(-1, 1)).abs().max().item()
+    f16_err = (dec - ref16.clamp(-1, 1)).abs().max().item()
+    sat = ((ref32 <= -1) | (ref32 >= 1)).float().mean().item()
+    res = {"shape": list(u8.shape), "hip_vs_oracle_fp32": s32, "hip_vs_oracle_fp16_plan": s16, "fp16_plan_vs_fp32_oracle": plan,
+           "max_abs_err_float_frames": {"vs_fp32": f32_err, "vs_fp16_plan": f16_err}, "saturated_fraction": sat,
+           "seconds": {"hip_two_decodes": t_hip, "oracle_fp32": t32, "oracle_fp16_plan": t16, "threads": torch.get_num_threads()}}
+    print("\n[VAE decode 720x1280x9f] " + json.dumps(res))
+    _report("vae_decode_720p_t3", res)
+    assert sat < 0.5, "the synthetic decode saturates: the byte comparison would be vacuous"
+    assert s32["max_lsb"] <= 1 and s32["identical"] >= 0.90 and s32["mean_lsb"] <= 0.1, s32
+    assert s16["max_lsb"] <= 1 and s16["identical"] >= 0.99, s16
+    assert s16["identical"] > s32["identical"] and f16_err < f32_err        # the residue is the storage plan
+    assert f32_err <= 1.5e-2
+
+
+def test_encode_720p_vs_oracle_fp32_and_fp16_plan(vae):
+    W = VO.synth_vae_weights()
+    scale = VO.default_scale()
+    g = torch.Generator().manual_seed(721)
+    vid = torch.rand(3, 9, 720, 1280, generator=g) * 2 - 1
+    vid[:, 1:] *= 0.5
+    t0 = time.time()
+    mu = vae.encode([vid])[0].cpu()
+    t_hip = time.time() - t0
+    assert tuple(mu.shape) == (16, 3, 90, 160) and mu.dtype == torch.float32
+    with torch.no_grad():
+        t0 = time.time()
+        ref32 = VO.vae_encode(vid[None], W, scale)[0]
+        t32 = time.time() - t0
+        with VO.fp16_plan():
+            ref16 = VO.vae_encode(vid[None], W, scale)[0]
+        t16 = time.time() - t0 - t32
+    sc = ref32.abs().max().item()
+    e32, e16 = (mu - ref32).abs().max().item(), (mu - ref16).abs().max().item()
+    r32 = ((mu - ref32).norm() / ref32.norm()).item()
+    r16 = ((mu - ref16).norm() / ref16.norm()).item()
+    res = {"shape": list(mu.shape), "max_abs_ref": sc, "max_abs_err": {"vs_fp32": e32, "vs_fp16_plan": e16},
+           "rel_l2_err": {"vs_fp32": r32, "vs_fp16_plan": r16},
+           "seconds": {"hip": t_hip, "oracle_fp32": t32, "oracle_fp16_plan": t16, "threads": torch.get_num_threads()}}
+    print("\n[VAE encode 9f 720x1280] " + json.dumps(res))
+    _report("vae_encode_720p_9f", res)
+    assert e32 <= 1e-2 * sc + 1e-3, res                                     # the bar of the small-size golden test
+    assert r16 < r32 and e16 <= 0.5 * (1e-2 * sc + 1e-3), res               # closer to the plan it implements
+
+
+# ---- conv3d_f16_kernel<BIG> -------------------------------------------------------------------------------------------------
+def _cl(x):
+    return x[0].permute(1, 2, 3, 0).contiguous().to(F16).cuda()
+
+
+def test_conv_big_offsets_forced_equal_the_32bit_kernel_bit_for_bit():
+    from wan2gp_amd import lib as L
+    from wan2gp_amd.vae import _VaeNet
+    g = torch.Generator().manual_seed(14)
+    sd = {}
+
+    def mk(name, cout, cin, k):
+        fan = cin * k[0] * k[1] * k[2]
+        sd[name + ".weight"] = (torch.randn(cout, cin, *k, generator=g) / fan ** 0.5).half().float()
+        sd[name + ".bias"] = (0.1 * torch.randn(cout, generator=g)).half().float()
+    mk("c333", 96, 64, (3, 3, 3)); mk("tconv", 128, 64, (3, 1, 1)); mk("dtconv", 64, 64, (3, 1, 1))
+    sd["c2d.weight"] = (torch.randn(32, 64, 3, 3, generator=g) / 24).half().float()
+    sd["c2d.bias"] = (0.1 * torch.randn(32, generator=g)).half().float()
+    n = _VaeNet(sd, torch.device("cuda"))
+    x = _cl(torch.randn(1, 64, 3, 22, 30, generator=g)); cache = _cl(torch.randn(1, 64, 2, 22, 30, generator=g))
+    res = _cl(torch.randn(1, 96, 3, 22, 30, generator=g))
+    last = _cl(torch.randn(1, 64, 1, 22, 30, generator=g))
+    prev2 = torch.cat([torch.zeros_like(last), last], 0)
+    x4 = _cl(torch.randn(1, 64, 4, 22, 30, generator=g))
+    cases = {
+        "3x3x3 no cache": lambda: n.conv(x, "c333"),
+        "3x3x3 cache + residual": lambda: n.conv(x, "c333", cache=cache, res=res),
+        "upsampled conv2d": lambda: n.conv(x, "c2d", ups=True),
+        "stride-2 conv2d": lambda: n.conv(x, "c2d", st_s=2, pad_s=0),
+        "time interleave": lambda: n.conv(x, "tconv", cache=cache, interleave=True, pad_s=0),
+        "stride-2 time conv": lambda: n.conv(x4, "dtconv", cache=prev2, st_t=2, front=1, pad_s=0),
+    }
+    lib = L.load()
+    small = {k: f().clone() for k, f in cases.items()}
+    old = lib.wan_vae_debug_force_big(1)
+    try:
+        assert old == 0
+        big = {k: f().clone() for k, f in cases.items()}
+    finally:
+        lib.wan_vae_debug_force_big(0)
+    torch.cuda.synchronize()
+    for k in cases:
+        assert torch.isfinite(small[k].float()).all() and small[k].float().abs().max() > 0.1, k
+        assert torch.equal(small[k], big[k]), f"BIG instantiation differs from the 32-bit one: {k}"
+
+
+def test_conv_on_a_chunk_beyond_2_31_elements():
+    """(Tin + 2) * H * W * C >= 2^31: the launcher takes the 64-bit instantiation by itself.  384 channels at 720 x 1280,
+    4 frames + the 2-frame cache; 32 output channels keep it cheap.  Sampled output pixels (the far end of the tensor
+    included, where a 32-bit offset would have wrapped) against an fp64 dot product of the same 27 x 384 taps."""
+    from wan2gp_amd.vae import _VaeNet
+    T, H, Wd, C, Co = 4, 720, 1280, 384, 32
+    assert (T + 2) * H * Wd * C >= 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(3)
+    gc = torch.Generator().manual_seed(3)
+    w = (torch.randn(Co, C, 3, 3, 3, generator=gc) / (27 * C) ** 0.5).half().float()
+    b = (0.1 * torch.randn(Co, generator=gc)).half().float()
+    n = _VaeNet({"big.weight": w, "big.bias": b}, torch.device("cuda"))
+    x = torch.randn(T, H, Wd, C, device="cuda", generator=g, dtype=torch.float32).to(F16)
+    cache = torch.randn(2, H, Wd, C, device="cuda", generator=g, dtype=torch.float32).to(F16)
+    out = n.conv(x, "big", cache=cache)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (T, H, Wd, Co)
+    full = torch.cat([cache, x], 0)                              # frame t of x = frame t + 2 here; causal taps reach back 2 frames
+    wd = w.double().cuda()                                       # [Co, C, 3, 3, 3]
+    pts = [(0, 0, 0), (T - 1, H - 1, Wd - 1), (T - 1, H - 1, 0), (T - 1, 0, Wd - 1), (2, 359, 640), (3, 719, 1279 - 1)]
+    gp = torch.Generator().manual_seed(8)
+    pts += [(int(torch.randint(0, T, (1,), generator=gp)), int(torch.randint(0, H, (1,), generator=gp)),
+             int(torch.randint(0, Wd, (1,), generator=gp))) for _ in range(250)]
+    worst = 0.0
+    for (t, y, xx) in pts:
+        acc = b.double().cuda().clone()
+        for kt in range(3):
+            for kh in range(3):
+                yy = y + kh - 1
+                if yy < 0 or yy >= H:
+                    continue
+                for kw in range(3):
+                    xw = xx + kw - 1
+                    if xw < 0 or xw >= Wd:
+                        continue
+                    acc += wd[:, :, kt, kh, kw] @ full[t + kt, yy, xw].double()
+        err = (out[t, y, xx].double() - acc).abs().max().item()
+        worst = max(worst, err / max(1.0, acc.abs().max().item()))
+    print(f"\n[conv BIG] {(T + 2) * H * Wd * C / 2 ** 31:.2f} x 2^31 input elements, {len(pts)} sampled pixels: worst rel err {worst:.3e}")
+    _report("vae_conv_big_chunk", {"elements_over_2_31": (T + 2) * H * Wd * C / 2 ** 31, "sampled_pixels": len(pts), "worst_rel_err": worst})
+    assert worst <= 2e-3

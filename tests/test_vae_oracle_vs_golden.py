@@ -72,3 +72,20 @@ def test_vae_any_end_frame_matches_reference():
         assert tuple(enc.shape) == (1, 16, 4, 8, 8) and torch.equal(enc, torch.from_numpy(g["enc"]))
         assert torch.equal(dec, torch.cat([VO.vae_decode(z[:, :, :-1], W, scale), VO.vae_decode(z[:, :, -1:], W, scale)], 2))
         assert torch.equal(enc, torch.cat([VO.vae_encode(vid[:, :, :9], W, scale), VO.vae_encode(vid[:, :, -1:], W, scale)], 2))
+
+
+def test_fp16_storage_plan_is_off_by_default_and_stays_next_to_the_pinned_plan():
+    """`with VO.fp16_plan()` (rounding where the HIP library stores fp16) is a second, UNPINNED plan used only to attribute
+    differing bytes (tests/test_gpu_vae_720p.py): outside the context the pinned fp32 restatement is untouched; inside, the
+    uint8 frames move by at most 1 LSB in a few percent of the bytes -- the same size as the HIP library's distance to the golden."""
+    W, sc = VO.synth_vae_weights(), VO.default_scale()
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(1, 16, 3, 8, 8, generator=g)
+    with torch.no_grad():
+        a = VO.vae_decode(z, W, sc)
+        with VO.fp16_plan():
+            b = VO.vae_decode(z, W, sc)
+        c = VO.vae_decode(z, W, sc)
+    assert torch.equal(a, c) and not torch.equal(a, b)
+    d = (VO.float_to_uint8(a).int() - VO.float_to_uint8(b).int()).abs()
+    assert int(d.max()) == 1 and 0.85 <= (d == 0).float().mean().item() <= 0.99
