@@ -511,6 +511,13 @@ int wan_vae_encode(wan_vae* v, const float* video, int T, int H, int W, float* m
  * attention, 2 FFN GEMM pair, 3 fused RMSNorm+RoPE) and returns the bracket count. */
 int wan_prof_enable(int on);
 int wan_prof_collect(int cls, double* total_ms, int* count);
+/* The bounded softmax of the self-attention kernel is taken per 256-row workgroup when |q~_row| max|k_h| <= 96 holds for all
+ * of its rows; the others are flagged and run the tracking loop.  While profiling is enabled every self-attention launch of
+ * wan_dit_forward adds its flagged / launched workgroup counts; this returns the sums since wan_prof_enable(1) (synchronises).
+ * wan_attention_count_declined: the same count for one wan_attention_bounded launch given its scratch (acc: device uint64[2],
+ * added to on `stream`). */
+int wan_prof_attention_declined(int64_t* declined, int64_t* total);
+int wan_attention_count_declined(const float* scratch, int B, int Bk, int64_t Lq, int H, uint64_t* acc, void* stream);
 
 #ifdef __cplusplus
 }

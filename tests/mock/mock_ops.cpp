@@ -44,6 +44,8 @@ hipError_t hipMemsetAsync(void* dst, int value, size_t n, hipStream_t) { rec("me
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) { rec("memcpy", {dst, src}, {(int64_t)n}); return hipSuccess; }
 hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return hipSuccess; }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemset(void* dst, int value, size_t n) { memset(dst, value, n); return hipSuccess; }
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) { memcpy(dst, src, n); return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
@@ -90,6 +92,9 @@ float wan_attention_qscale(void) { return 0.12752041f; }
 int wan_attention_bounded(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk, int64_t Lq, int64_t Lk,
                           int64_t ldv, int H, int nseg, int64_t ks, int64_t vs, int pre, float* scratch, void*) {
   return rec("attention", {q, k, vt, o, scratch}, {B, Bk, Lq, Lk, ldv, H, nseg, ks, vs, pre});
+}
+int wan_attention_count_declined(const float* scratch, int B, int Bk, int64_t Lq, int H, uint64_t* acc, void*) {
+  return rec("attn_count_declined", {scratch, acc}, {B, Bk, Lq, H});
 }
 int wan_attention_sp_local(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, int B, int64_t Lq, int64_t Lk, int64_t ldv, int H,
                            float* scratch, float* raw, void*) {

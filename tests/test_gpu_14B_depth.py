@@ -1,0 +1,129 @@
+"""-m gpu: the COMPOSITION at the 14B dimensions -- all 40 blocks of d = 5120 / 40 heads / ffn 13,824 (BASELINE configs[2],
+Wan2.2 t2v 14B; model.py:1485-2098) in one forward at L = 2,048 tokens, against the CPU oracle in the reference's bf16 plan
+and against its fp32 anchor, with the per-layer error-growth table SURVEY.md section 7 asks for.
+
+What the other suites hold: 30 layers at d = 1536 against the reference's own run (test_gpu_baseline_configs.py), ONE block
+at d = 5120 against the oracle, every GEMM / the attention kernel at the bench shapes against fp64.  This file is the missing
+product of the two: depth 40 at width 5120.
+
+The checkpoint (14.3 G parameters) is drawn on the GPU (a CPU generator needs minutes for it), rounded to bf16-representable
+values there, loaded into the HIP model, and copied to the host once for the oracle; the fp32 anchor converts each tensor
+when it is touched.  One stream (the CFG pair of the bench is two independent rows ranges of the same kernels).
+
+Bars (the ones of test_gpu_baseline_configs.py): per layer and at the output err_hip <= 1.5 * err_ref + 2e-3 where
+err_x = |x - fp32 anchor| / |fp32 anchor|; |hip - ref| / |ref| <= 2.5e-2 at the output.
+"""
+import json
+import os
+import time
+from collections.abc import Mapping
+
+import pytest
+import torch
+
+from oracle import wan_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+class _AsFloat32(Mapping):
+    """The bf16-representable checkpoint seen as fp32 tensors, converted when touched (the anchor reads each weight once)."""
+
+    def __init__(self, base):
+        self.base = base
+
+    def __getitem__(self, k):
+        return self.base[k].float()
+
+    def __iter__(self):
+        return iter(self.base)
+
+    def __len__(self):
+        return len(self.base)
+
+
+def _checkpoint_on_gpu(cfg, seed):
+    """The distribution of O.synth_weights (modulation ~ N(0,1)/sqrt(d), norm weights 1 + 0.02 N, biases 0.01 N, the rest
+    0.02 N; fp32-locked tensors stay fp32), drawn with the device generator."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    W = {}
+    for k, shp in O.param_shapes(cfg).items():
+        r = torch.randn(shp, generator=g, device="cuda", dtype=torch.float32)
+        if k.endswith("modulation"):
+            w = r / cfg.dim ** 0.5
+        elif "norm" in k and k.endswith("weight"):
+            w = 1.0 + 0.02 * r
+        elif k.endswith("bias"):
+            w = 0.01 * r
+        else:
+            w = 0.02 * r
+        W[k] = w if k.startswith(O.FP32_LOCKED) else w.to(BF)
+    return W
+
+
+def test_14B_forty_layers_vs_oracle():
+    from wan2gp_amd.model import WanModelHIP
+    cfg = O.WanConfig(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40)
+    f, h, w = 4, 32, 64
+    L = f * (h // 2) * (w // 2)
+    assert L == 2048
+    t0 = time.time()
+    Wg = _checkpoint_on_gpu(cfg, 77)
+    m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers)
+    m.load_state_dict(Wg)
+    t_w = time.time() - t0
+    lat, ctx, _, _ = O.synth_inputs(cfg, f, h, w, seed=12)
+    t = torch.tensor([611], dtype=torch.int64)
+    rows = torch.arange(0, L, 8)                                  # 256 probed token rows
+    hip_layers = []
+
+    def cb(*a):
+        torch.cuda.synchronize()
+        hip_layers.append(m.debug_token_stream(1, L)[0, rows.cuda()].float().cpu())
+    out = m([lat.cuda()], t=t, context=[ctx.cuda()], callback=cb)[0].cpu()
+    torch.cuda.synchronize()
+    hip_layers = hip_layers[1:]                                   # entry 0 = the embedded tokens, entry i = after block i - 1
+    assert len(hip_layers) == cfg.num_layers - 1
+    t0 = time.time()
+    Wc = {k: v.cpu() for k, v in Wg.items()}
+    del Wg, m
+    torch.cuda.empty_cache()
+    t_copy = time.time() - t0
+
+    ref_layers, anc_layers = {}, {}
+    with torch.no_grad():
+        t0 = time.time()
+        ref = O.dit_forward([lat], t, [ctx], Wc, cfg, dtype=BF, probe=lambda i, s, hid: ref_layers.__setitem__(i, hid[0, rows].float()))[0]
+        t_bf = time.time() - t0
+        anchor = O.dit_forward([lat], t, [ctx.float()], _AsFloat32(Wc), cfg, dtype=torch.float32, exact=True,
+                               probe=lambda i, s, hid: anc_layers.__setitem__(i, hid[0, rows].float()))[0]
+        t_32 = time.time() - t0 - t_bf
+    table = []
+    for i in range(cfg.num_layers - 1):
+        a = anc_layers[i]
+        table.append({"layer": i, "err_ref": rel(ref_layers[i], a), "err_hip": rel(hip_layers[i], a),
+                      "hip_vs_ref": rel(hip_layers[i], ref_layers[i])})
+    fin = {"err_ref": rel(ref, anchor), "err_hip": rel(out, anchor), "hip_vs_ref": rel(out, ref)}
+    print(f"\n[14B x 40 layers, L={L}] checkpoint on the GPU {t_w:.0f}s, to the host {t_copy:.0f}s, oracle bf16 {t_bf:.0f}s, "
+          f"fp32 anchor {t_32:.0f}s on {torch.get_num_threads()} threads")
+    for r in table:
+        print("  layer %2d  err_ref %.3e  err_hip %.3e  hip-vs-ref %.3e" % (r["layer"], r["err_ref"], r["err_hip"], r["hip_vs_ref"]))
+    print(f"[14B x 40 layers] output: err_ref={fin['err_ref']:.4e} err_hip={fin['err_hip']:.4e} hip-vs-ref={fin['hip_vs_ref']:.4e}")
+    d = os.path.join(ROOT, "gpurun_out", "parity")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "forward14B_40layers_L2048.json"), "w") as fo:
+            json.dump({"layers": table, "output": fin, "probed_rows": len(rows),
+                       "seconds": {"oracle_bf16": t_bf, "fp32_anchor": t_32, "threads": torch.get_num_threads()}}, fo, indent=1)
+    except OSError:
+        pass
+    for r in table:
+        assert r["err_hip"] <= 1.5 * r["err_ref"] + 2e-3, r
+    assert fin["err_hip"] <= 1.5 * fin["err_ref"] + 2e-3, fin
+    assert fin["hip_vs_ref"] <= 2.5e-2, fin

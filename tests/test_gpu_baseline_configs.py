@@ -226,6 +226,64 @@ def test_attention_prescaled_at_bench_shape(B, L):
     _report(f"attn_w64q_B{B}_L{L}", r)
 
 
+def test_attention_bounded_and_tracking_loops_mixed_inside_one_launch():
+    """The hot loop is data dependent: a 256-row workgroup takes the bounded softmax only if |q~_row| * max|k_h| <= 96 for all of
+    its rows (attention_w64q.hip); real checkpoints' norm_q / norm_k weights are not ~1 in every head.  Bench shape (B = 2, H = 40,
+    L = 75,600) with per-head K gains 0.5 ... 12 so that both loops run inside ONE launch: sampled rows of low-, threshold- and
+    high-gain heads against the fp64 softmax, the flag count against the heads that must decline, and the launch rate with
+    nothing / about half / everything declined (profiles/: what a checkpoint with hot heads costs)."""
+    from wan2gp_amd import lib as L_, ops
+    B, H, L = 2, 40, 75600
+    lib = L_.load()
+    gains = [0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 8.0, 10.0, 12.0]
+    q, k, vt, ldv = _rand_qkv(B, L, L, H, 1, seed=77)
+    k0 = k[0].clone()
+    scratch = torch.zeros(ops.attention_scratch_words(B, B, L, H), dtype=torch.float32, device="cuda")
+    acc = torch.zeros(2, dtype=torch.int64, device="cuda")
+    nqb = (L + 255) // 256
+    flops = 4.0 * B * L * L * H * 128
+
+    def run(gain_per_head, check_pairs=None, what=""):
+        g = torch.tensor(gain_per_head, device="cuda", dtype=torch.float32).view(1, 1, H, 1)
+        kk = (k0.float() * g).to(BF)
+        ks = kk.unsqueeze(0)
+        acc.zero_()
+        out = ops.attention(q, kk, vt[0], q_prescaled=True, kmax_scratch=scratch)           # warm-up + the result that is checked
+        L_.check(lib.wan_attention_count_declined(L_.ptr(scratch), B, B, L, H, L_.ptr(acc), L_.stream_ptr()), "count")
+        torch.cuda.synchronize()
+        flags = scratch[B * H:B * H + nqb * H * B].view(torch.int32).clone().view(B * H, nqb)   # [pair = b*H + h][q-block]
+        declined, total = int(acc[0]), int(acc[1])
+        assert total == nqb * H * B and declined == int((flags != 0).sum())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            ops.attention(q, kk, vt[0], q_prescaled=True, kmax_scratch=scratch, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 2
+        r = None
+        if check_pairs:
+            r = _attn_sampled_check(q, ks, vt, out, check_pairs, 256, what=what)
+        return flags, declined / total, flops / (ms * 1e-3) / 1e12, r
+
+    mixed = [gains[h % len(gains)] for h in range(H)]
+    # heads 1 (gain 1: bounded), 4 (gain 4: near the threshold), 5 / 9 (gains 5, 12: tracking), both streams
+    flags, frac_mixed, tf_mixed, r = run(mixed, [(0, 1), (1, 4), (0, 5), (1, 9), (0, 37)], what="per-head K gains 0.5..12")
+    per_head = flags.view(B, H, nqb).float().mean(dim=(0, 2)).cpu()
+    for h in range(H):
+        if mixed[h] <= 2.0:
+            assert per_head[h] == 0.0, (h, mixed[h], per_head[h].item())        # bound ~ 22 * gain: far below 96
+        if mixed[h] >= 8.0:
+            assert per_head[h] == 1.0, (h, mixed[h], per_head[h].item())        # far above: every workgroup declines
+    _, frac0, tf0, _ = run([1.0] * H)
+    _, frac1, tf1, _ = run([12.0] * H)
+    assert frac0 == 0.0 and frac1 == 1.0 and 0.3 < frac_mixed < 0.7
+    res = {"shape": {"B": B, "H": H, "L": L}, "gains": gains, "declined_frac_by_gain": {str(gg): float(per_head[[h for h in range(H) if mixed[h] == gg]].mean()) for gg in gains},
+           "TFLOPs": {"declined_0": tf0, f"declined_{frac_mixed:.2f}": tf_mixed, "declined_1": tf1}, "parity_mixed": r}
+    print("\n[attention, mixed loops] " + json.dumps(res))
+    _report("attn_w64q_mixed_loops_B2_L75600", res)
+
+
 def test_cfg4_world8_rank_dryrun():
     """BASELINE configs[3] (720p x 161f, L = 147,600) as ONE rank of a world of 8 sees it: shard arithmetic, workspace size
     and 32-bit offset limits of wan_dit_forward, and the self-attention launch of that rank -- its 18,450 q rows against 8

@@ -471,10 +471,90 @@ def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():
     out = run(pipe, input_ref_images=None, audio_guide=None, overlap_noise=0, image_mode=0, alt_guide_scale=1.0, fit_into_canvas=True, window_no=1,
               offloadobj=object(), set_header_text=lambda *a: None, model_filename="x.safetensors", fps=16, gen_state={}, custom_settings=None)
     assert torch.isfinite(out["latents"]).all()
-    for kw in (dict(input_ref_images=[torch.zeros(3, 8, 8)]), dict(prefix_video=torch.zeros(3, 5, 8, 8)), dict(overlapped_latents=torch.zeros(1, 16, 2, 8, 8)),
-               dict(audio_proj=torch.zeros(1)), dict(image_mode=1), dict(overlap_noise=20), dict(alt_guide_scale=2.0), dict(vae_upsampler="x")):
+    for kw in (dict(input_ref_images=[torch.zeros(3, 8, 8)]), dict(overlapped_latents=torch.zeros(1, 16, 2, 8, 8)),
+               dict(audio_proj=torch.zeros(1)), dict(image_mode=1), dict(alt_guide_scale=2.0), dict(vae_upsampler="x")):
         with pytest.raises(NotImplementedError, match=list(kw)[0]):
             run(pipe, **kw)
+
+
+def _wgp_keywords(**over):
+    """The keyword set of wgp.py:7762-7885 for a first-window Wan generation, with the values wgp.py gives them when the feature
+    behind them is off: the hard-coded ones (`causal_block_size=5`, `causal_attention=True`), the UI defaults
+    (`overlap_noise` = sliding_window_overlap_noise 20, `overlap_size` = reuse_frames), empty containers and None otherwise."""
+    kw = dict(alt_prompt=None, image_start=None, image_end=None, input_frames=None, input_frames2=None, input_ref_images=None,
+              input_ref_masks=None, input_masks=None, input_masks2=None, input_video=None, input_faces=None, input_custom=None,
+              video_guide=None, video_guide2=None, denoising_strength=1.0, masking_strength=1.0, prefix_frames_count=0,
+              batch_size=1, fit_into_canvas=1, shift=5.0, sample_solver="unipc", guide2_scale=3.0, guide3_scale=3.0,
+              switch_threshold=0, switch2_threshold=0, guide_phases=1, model_switch_phase=1, embedded_guidance_scale=6.0,
+              n_prompt="", callback=None, enable_RIFLEx=False, VAE_tile_size=0, joint_pass=True, perturbation_switch=0,
+              perturbation_layers=[9], perturbation_start=0.1, perturbation_end=0.9, apg_switch=0, cfg_star_switch=0,
+              cfg_zero_step=-1, alt_guide_scale=1.0, audio_cfg_scale=4.0, input_waveform=None, input_waveform_sample_rate=None,
+              audio_guide=None, audio_guide2=None, audio_prompt_type="", audio_proj=None, audio_scale=None, audio_context_lens=None,
+              context_scale=None, control_scale_alt=1.0, alt_scale=0.0, motion_amplitude=1.0, model_mode=None, causal_block_size=5,
+              causal_attention=True, fps=16, overlapped_latents=None, return_latent_slice=None, overlap_noise=20, overlap_size=0,
+              sub_parallel_window_size=0, sub_parallel_window_overlap=0, color_correction_strength=1.0, conditioning_latents_size=0,
+              input_video_is_hdr=False, lora_dir="loras/wan", keep_frames_parsed=[], model_filename=["a.safetensors"],
+              model_type="t2v", loras_slists=None, NAG_scale=1, NAG_tau=3.5, NAG_alpha=0.5, attention_sparsity=0,
+              speakers_bboxes=None, image_mode=0, video_prompt_type="", window_no=1, offloadobj=object(),
+              set_header_text=lambda *a: None, pre_video_frame=None, prefix_video=None, original_input_ref_images=[],
+              image_refs_relative_size=50, outpainting_dims=None, face_arc_embeds=None, custom_settings=None,
+              frame_window_options=None, gen_state={}, temperature=1.0, window_start_frame_no=0, input_video_strength=1.0,
+              self_refiner_setting=0, self_refiner_plan="", self_refiner_f_uncertainty=0.0, self_refiner_certain_percentage=0.999,
+              duration_seconds=5, pause_seconds=0, top_p=0.9, top_k=50, set_progress_status=lambda *a: None, loras_selected=[],
+              frames_relative_positions_list=[], frames_to_inject=[], verbose_level=0, gen_cache=None, vae_upsampler=None,
+              save_masks=False)
+    kw.update(over)
+    return kw
+
+
+def test_generate_accepts_the_exact_keyword_set_wgp_passes_for_t2v():
+    """Every wgp.py-driven call carries `causal_attention=True`, `overlap_noise=20`, ... (wgp.py:7826, :7830): a plain t2v run with
+    that exact keyword set must run, and give the video the same call without the plumbing gives."""
+    a, b = FakeDiT("A"), FakeDiT("A")
+    got = run(WanAny2VHIP(a, device="cpu"), **_wgp_keywords(perturbation_layers=None))
+    want = run(WanAny2VHIP(b, device="cpu"), shift=5.0)
+    assert torch.equal(got["latents"], want["latents"]) and len(a.calls) == len(b.calls) == 6
+
+
+class _StubVAE:
+    """encode(): 16 latent channels, time (T - 1) // 4 + 1, space / 8, values a deterministic function of the frames."""
+
+    def __init__(self):
+        self.seen = []
+
+    def encode(self, videos, tile_size=0, any_end_frame=False):
+        self.seen.append(tuple(videos[0].shape))
+        out = []
+        for v in videos:
+            T, H, W = v.shape[1:]
+            t = (T - 1) // 4 + 1
+            base = torch.nn.functional.adaptive_avg_pool3d(v[None].float(), (t, H // 8, W // 8))[0].mean(0, keepdim=True)
+            out.append(base.repeat(16, 1, 1, 1) + torch.arange(16).view(16, 1, 1, 1) * 0.01)
+        return out
+
+
+def test_generate_takes_the_i2v_conditioning_from_input_video_like_the_reference():
+    """any2video.py:671-680: the i2v path conditions on `input_video` (wgp.py passes input_video = pre_video_guide: the start image
+    as [3, 1, H, W] or the video to continue, together with prefix_video / pre_video_frame / conditioning_latents_size > 0,
+    wgp.py:7378-7394, :7714).  Same y and same result as image_start= (the direct-call spelling); a t2v model ignores none of it
+    silently: input_video on a non-i2v, non-5B model still raises."""
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(3, 1, 64, 64, generator=g) * 2 - 1
+    prefix = torch.rand(3, 5, 64, 64, generator=g) * 2 - 1
+    for src in (img, prefix):
+        a, b = FakeDiT("A"), FakeDiT("A")
+        a.model_type = b.model_type = "i2v2_2"
+        va, vb = _StubVAE(), _StubVAE()
+        got = run(WanAny2VHIP(a, vae=va, device="cpu"),
+                  **_wgp_keywords(input_video=src, prefix_video=src, pre_video_frame=src[:, -1], conditioning_latents_size=1,
+                                  perturbation_layers=None, model_type="i2v_2_2"))
+        want = run(WanAny2VHIP(b, vae=vb, device="cpu"), image_start=src, shift=5.0)
+        assert va.seen == vb.seen == [(3, 9, 64, 64)]
+        ya, yb = a.calls[0]["y"], b.calls[0]["y"]
+        assert ya is not None and tuple(ya.shape) == (20, 3, 8, 8) and torch.equal(ya, yb)
+        assert torch.equal(got["latents"], want["latents"])
+    with pytest.raises(ValueError, match="input_video"):
+        run(WanAny2VHIP(FakeDiT("A"), device="cpu"), input_video=img)
 
 
 def test_progress_protocol_matches_the_references_callback_calls():

@@ -136,3 +136,28 @@ extern "C" int wan_attention_sp_remote(const wan_bf16* q, const wan_bf16* k_all,
 }
 
 extern "C" float wan_attention_qscale(void) { return SCALE_LOG2E; }
+
+// Measurement hook (bench.py `roofline.declined_workgroups`): after a wan_attention_bounded launch with a caller scratch, the
+// scratch holds one flag per 256-row workgroup (1 = the workgroup's rows failed |q~| max|k| <= 96 and the tracking loop ran it).
+// Adds (flagged, total) to acc[0..1] (device, 64-bit) on `stream`.
+__global__ void attn_count_flags_kernel(const int* __restrict__ flags, int n, unsigned long long* __restrict__ acc) {
+  unsigned long long c = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) c += flags[i] != 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+    atomicAdd(acc + 1, (unsigned long long)n);
+  }
+}
+extern "C" int wan_attention_count_declined(const float* scratch, int B, int Bk, int64_t Lq, int H, uint64_t* acc, void* stream) {
+  WAN_REQUIRE(scratch && acc && B >= 1 && Bk >= 1 && H >= 1 && Lq >= 1, "wan_attention_count_declined: bad args");
+  const int64_t n = ((Lq + 255) / 256) * H * B;
+  WAN_REQUIRE(n < ((int64_t)1 << 31), "wan_attention_count_declined: grid too large");
+  hipLaunchKernelGGL(attn_count_flags_kernel, dim3(1), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const int*>(scratch + (size_t)Bk * H), (int)n, reinterpret_cast<unsigned long long*>(acc));
+  WAN_LAUNCH_CHECK();
+  return 0;
+}

@@ -48,8 +48,13 @@ struct ProfPair {
 };
 static bool g_prof_on = false;
 static std::vector<ProfPair> g_prof;
+static uint64_t* g_prof_declined = nullptr;  // device [2]: self-attention workgroups the bounded loop declined / launched, while profiling
 extern "C" int wan_prof_enable(int on) {
   g_prof_on = on != 0;
+  if (g_prof_on) {
+    if (g_prof_declined == nullptr) WAN_CHECK_HIP(hipMalloc((void**)&g_prof_declined, 16));
+    WAN_CHECK_HIP(hipMemset(g_prof_declined, 0, 16));
+  }
   for (auto& p : g_prof) {
     (void)hipEventDestroy(p.a);
     (void)hipEventDestroy(p.b);
@@ -71,6 +76,14 @@ extern "C" int wan_prof_collect(int cls, double* total_ms, int* count) {
   }
   *total_ms = t;
   *count = n;
+  return 0;
+}
+extern "C" int wan_prof_attention_declined(int64_t* declined, int64_t* total) {
+  WAN_REQUIRE(declined && total, "wan_prof_attention_declined: bad args");
+  uint64_t h[2] = {0, 0};
+  if (g_prof_declined != nullptr) WAN_CHECK_HIP(hipMemcpy(h, g_prof_declined, 16, hipMemcpyDeviceToHost));  // synchronises with the device
+  *declined = (int64_t)h[0];
+  *total = (int64_t)h[1];
   return 0;
 }
 struct ProfScope {
@@ -652,6 +665,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       ProfScope ps(PROF_SELF_ATTN, st);
       RC(wan_attention_bounded(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, 1, b.kmax, stream));
     }
+    // outside the timed bracket: which share of the launch's workgroups failed the score bound and ran the tracking loop
+    if (g_prof_on && g_prof_declined != nullptr && b.kmax != nullptr) RC(wan_attention_count_declined(b.kmax, S, S, Ll, nh, g_prof_declined, stream));
     RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb, 0, q8, S));
     // -- cross attention (model.py:663-668, :245-265) --
     RC(wan_ln_affine(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, stream));

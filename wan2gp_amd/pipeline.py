@@ -19,12 +19,16 @@ from .schedulers import (EulerScheduler, FlowDPMSolverMultistepScheduler, FlowMa
                          HipScheduler, LCMScheduler, cfg_combine, get_sampling_sigmas, retrieve_timesteps)
 
 
-# keyword -> the reference's default (any2video.py:414-503): a non-default value asks for something generate() below does not do
+# keyword -> the reference's default (any2video.py:414-503): a non-default value asks for something generate() below does not do.
+# NOT in this table although wgp.py sets them on EVERY call (wgp.py:7762-7885): `causal_attention=True` (hard-coded at :7826; the
+# reference's generate() does not even declare it -- it falls into **bbargs), `overlap_noise` (the UI's sliding-window default 20;
+# read only for VACE with overlapped latents, which IS refused below), `prefix_video` / `pre_video_frame` /
+# `conditioning_latents_size` (non-empty whenever a start image or a source video is used, wgp.py:7378-7394, :7714; read only on
+# the svi_pro / infinitetalk / scail2 / reference-image paths, any2video.py:659-728, :861-897, none of which reaches this backend).
 _UNSERVED_WHEN_SET = {"input_frames2": None, "input_masks2": None, "input_ref_images": None, "input_ref_masks": None, "input_faces": None,
                       "input_custom": None, "audio_scale": None, "audio_proj": None, "audio_context_lens": None, "audio_guide": None,
-                      "audio_guide2": None, "input_waveform": None, "alt_guide_scale": 1.0, "overlapped_latents": None, "overlap_noise": 0,
-                      "conditioning_latents_size": 0, "speakers_bboxes": None, "image_mode": 0, "pre_video_frame": None, "prefix_video": None,
-                      "face_arc_embeds": None, "control_scale_alt": 1.0, "vae_upsampler": None, "causal_attention": False}
+                      "audio_guide2": None, "input_waveform": None, "alt_guide_scale": 1.0, "overlapped_latents": None,
+                      "speakers_bboxes": None, "image_mode": 0, "face_arc_embeds": None, "control_scale_alt": 1.0, "vae_upsampler": None}
 
 
 def _same(v, default):
@@ -295,7 +299,12 @@ class WanAny2VHIP:
         else:
             latents = latents.to(device=dev, dtype=torch.float32).clone()
         # ---- image2video conditioning (any2video.py:651-785, plain i2v2_2: one start image) -----------
+        # The reference's i2v path takes its conditioning from `input_video` (any2video.py:671-680: control_video = input_video,
+        # image_start = input_video[:, -1]); wgp.py always passes input_video = the start image as [3,1,H,W] or the video to
+        # continue.  `image_start` (what direct callers of this class pass) is the same thing under the other name.
         ext_latents = None
+        if getattr(self.model, "model_type", None) in ("i2v", "i2v2_2") and input_video is not None:
+            image_start, input_video = input_video, None
         if image_start is not None:
             if self.vae is None:
                 raise ValueError("image_start needs a VAE to encode the conditioning video")
@@ -317,7 +326,9 @@ class WanAny2VHIP:
                 raise ValueError("video-to-video needs a VAE to encode input_frames")
             if tuple(input_frames.shape[-2:]) != (height, width):
                 raise ValueError(f"input_frames are {tuple(input_frames.shape[-2:])}, height x width = {(height, width)} (any2video.py:1005)")
-            v2v_src = self.vae.encode([input_frames.to(dev)], VAE_tile_size)[0].unsqueeze(0)              # :1006
+            # :1006 `self.vae.encode([input_frames])`: no tile size given -> WanVAE.encode's default of 256 (vae.py:1003), i.e. the
+            # reference ALWAYS encodes the source in 256-pixel tiles, whatever VAE_tile_size says
+            v2v_src = self.vae.encode([input_frames.to(dev)], 256)[0].unsqueeze(0)
             v2v = video2video.plan(input_frames, None if input_masks is None else input_masks.to(dev), v2v_src, lat_frames, sampling_steps,
                                    denoising_strength, masking_strength, list(keep_frames_parsed or []), prefix_frames_count, timesteps,
                                    sample_scheduler, device=dev, video_prompt_type=video_prompt_type)

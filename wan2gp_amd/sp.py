@@ -55,7 +55,8 @@ class SequenceParallel:
             _L.check(lib.wan_sp_unique_id(c_void_p(ident.data_ptr())), "wan_sp_unique_id")
         if self.world > 1:
             t = ident.to(dev)
-            dist.broadcast(t, src=0, group=self.group)
+            # `src` is a GLOBAL rank: the group's first member, which need not be global rank 0 (CFG-parallel x SP layouts)
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
             ident = t.cpu()
         h = c_void_p()
         _L.check(lib.wan_sp_init(ctypes.byref(h), self.rank, self.world, c_void_p(ident.data_ptr())), "wan_sp_init")

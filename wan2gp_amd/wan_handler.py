@@ -105,7 +105,9 @@ class family_handler():
             "i2v_2_2": test_i2v_2_2(b), "color_correction": True,
             "vae_block_size": 32 if wan_5B else 16, "profiles_dir": [profiles_dir], "group": group, "fps": 24 if wan_5B else 16,
             "frames_minimum": 17 if vace else 5, "frames_steps": 4,
-            "sliding_window": b in ("t2v", "t2v_2_2") or i2v or wan_5B or vace,
+            # sliding windows hand `overlapped_latents` / a prefix of the previous window to generate(), which refuses them: not
+            # claimed until they are served (the reference claims them for t2v / i2v / 5B / VACE, wan_handler.py:266)
+            "sliding_window": False,
             "multiple_submodels": multiple_submodels, "guidance_max_phases": 3, "flow_shift": True, "cfg_zero": True, "cfg_star": True,
             "adaptive_projected_guidance": True,
             "tea_cache": not (b == "i2v_2_2" or wan_5B or multiple_submodels), "mag_cache": True,
@@ -114,7 +116,9 @@ class family_handler():
             # normalized attention guidance (wan_handler.py:994) and the image prompt types (:956-978): Start / End image, Video to
             # continue, Last-frame options for the i2v models -- generate(image_start=, image_end=) / the prefix-video path
             "NAG": vace or t2v or i2v, "self_refiner": True, "perturbation": not vace,      # skip-layer guidance: not with VACE blocks
-            "image_prompt_types_allowed": "TVL" if (vace or b in ("t2v", "t2v_2_2")) else ("TSVL" if b == "ti2v_2_2" else ("SEVL" if i2v else "")),
+            # of the reference's "TVL" / "TSVL" / "SEVL": 'L' (continue the last video) is a sliding-window feature; 'V' (video to
+            # continue) is served where generate() has the path -- the i2v prefix video and the 5B model's timestep injection
+            "image_prompt_types_allowed": "T" if (vace or b in ("t2v", "t2v_2_2")) else ("TSV" if b == "ti2v_2_2" else ("SEV" if i2v else "")),
             # what the HIP path does not implement: offload, compile, in-app quantisation
             "compile": False, "no_quantization": True, "backend": "hip-gfx950",
         }
@@ -156,9 +160,22 @@ class family_handler():
             raise ValueError(f"model type {base_model_type!r} is not supported by the HIP Wan handler ({sorted(_ARCH)})")
         arch = _ARCH[b]
         files = [model_filename] if isinstance(model_filename, str) else list(model_filename or [])
-        if submodel_no_list:
-            files = [f for f, no in zip(files, submodel_no_list) if no in (1, 2)] or files
-        sds = list(state_dicts) if state_dicts is not None else [normalize_wan_keys(read_safetensors(f)) for f in files]
+        # wgp.py:4003-4027: [expert 1, (expert 2,) module files ...] with submodel numbers [1, (2,) ...]; a module file (e.g. the
+        # VACE blocks kept apart from the t2v base) carries 0 = shared by both experts, 1 / 2 = that expert's
+        # (any2video.py:208-222: fast_load_transformers_model(main file, modules=[...]) reads them into the same module)
+        nos = list(submodel_no_list) if submodel_no_list else [1, 2][:len(files)]
+        if len(nos) != len(files) and state_dicts is None:
+            raise ValueError(f"load_model: {len(files)} files but submodel_no_list has {len(nos)} entries")
+        n_main = 2 if (len(nos) >= 2 and nos[1] == 2) else 1
+        if state_dicts is not None:
+            sds = list(state_dicts)
+        else:
+            sds = [normalize_wan_keys(read_safetensors(f)) for f in files[:n_main]]
+            for f, no in zip(files[n_main:], nos[n_main:]):
+                extra = normalize_wan_keys(read_safetensors(f))
+                for k, sd in enumerate(sds):
+                    if no in (0, k + 1):
+                        sd.update(extra)
         if not sds:
             raise ValueError("load_model: no checkpoint given")
         models = [WanModelHIP(device=device, **arch).load_state_dict(sd) for sd in sds[:2]]
@@ -175,6 +192,13 @@ class family_handler():
                 vae = VAE(state_dict=vae_state_dict, device=device)
             elif os.path.isfile(path):
                 vae = VAE(vae_pth=path, device=device)
+        # under wgp.py (real checkpoint files, no test hooks) a missing VAE / text-encoder file must fail HERE, not as an opaque
+        # error after a full denoise: generate() would return latents with x = None, or fail on `context`
+        from_files = state_dicts is None
+        if vae is None and from_files:
+            raise FileNotFoundError(f"load_model: VAE checkpoint not found ({os.path.join(checkpoint_dir, 'Wan2.2_VAE.safetensors' if test_wan_5B(b) else 'Wan2.1_VAE.safetensors')})")
+        if text_encoder is None and from_files and not (text_encoder_filename and os.path.isfile(str(text_encoder_filename))):
+            raise FileNotFoundError(f"load_model: text-encoder checkpoint not found ({text_encoder_filename!r})")
         if text_encoder is None and text_encoder_filename and os.path.isfile(str(text_encoder_filename)):
             # any2video.py:128-134: T5EncoderModel(text_len, checkpoint, tokenizer_path = <checkpoint's folder>)
             from .t5 import T5EncoderModelHIP
