@@ -48,6 +48,36 @@ def _q(x):
     return x.to(torch.float16).to(x.dtype) if _PLAN16[0] else x
 
 
+def _conv_taps(x, w, b, stride):
+    """conv3d of an already padded x [B,C,T,H,W] with w [Co,Ci,kt,kh,kw] as the sum over the taps of one fp32 matmul each.
+    Used when the tensors live on a GPU (tests/test_gpu_vae_720p.py runs this restatement at 720 x 1280 there: the box's CPU
+    needs minutes per pass at that size): same products, fp32 accumulation, only the summation order differs from
+    F.conv3d -- no vendor convolution library involved.  Pinned to the CPU execution at the golden size by that test."""
+    kt, kh, kw = w.shape[2:]
+    st, sh, sw = stride
+    To, Ho, Wo = (x.shape[2] - kt) // st + 1, (x.shape[3] - kh) // sh + 1, (x.shape[4] - kw) // sw + 1
+    out = None
+    for a in range(kt):
+        for i in range(kh):
+            for j in range(kw):
+                xs = x[:, :, a:a + (To - 1) * st + 1:st, i:i + (Ho - 1) * sh + 1:sh, j:j + (Wo - 1) * sw + 1:sw]
+                y = torch.einsum("oc,bcthw->bothw", w[:, :, a, i, j], xs)
+                out = y if out is None else out + y
+    return out if b is None else out + b.view(1, -1, 1, 1, 1)
+
+
+def _conv3d(x, w, b, stride=(1, 1, 1)):
+    return _conv_taps(x, w, b, stride) if x.is_cuda else F.conv3d(x, w, b, stride=stride)
+
+
+def _conv2d(x, w, b, stride=1, padding=0):
+    if not x.is_cuda:
+        return F.conv2d(x, w, b, stride=stride, padding=padding)
+    if padding:
+        x = F.pad(x, (padding,) * 4)
+    return _conv_taps(x.unsqueeze(2), w.unsqueeze(2), b, (1, stride, stride)).squeeze(2)
+
+
 def vae_param_shapes(cfg=CFG) -> Dict[str, tuple]:
     """state_dict key -> shape for WanVAE_(dim=96, z=16, mult [1,2,4,4], attn_scales=[]) (vae.py:906-918)."""
     dim, z = cfg["dim"], cfg["z_dim"]
@@ -144,7 +174,7 @@ def causal_conv3d(x, w, b, cache_x=None, stride=(1, 1, 1), pad=None):
         x = torch.cat([cache_x, x], dim=2)
         padding[4] -= cache_x.shape[2]
     x = F.pad(x, padding)
-    return F.conv3d(x, w, b, stride=stride)
+    return _conv3d(x, w, b, stride)
 
 
 def rms_norm(x, gamma, channel_dim=1):
@@ -182,15 +212,15 @@ def attention_block(x, W, p):
     b, c, t, h, w = x.shape
     y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
     y = _q(rms_norm(y, W[p + "norm.gamma"]))
-    qkv = _q(F.conv2d(y, W[p + "to_qkv.weight"], W[p + "to_qkv.bias"]))
+    qkv = _q(_conv2d(y, W[p + "to_qkv.weight"], W[p + "to_qkv.bias"]))
     q, k, v = qkv.reshape(b * t, 1, c * 3, -1).permute(0, 1, 3, 2).contiguous().chunk(3, dim=-1)
-    if _PLAN16[0]:              # scores, probabilities and P.V are fp16 tensors in HBM (wan2gp_amd/vae.py attention_block)
-        sc = _q((q @ k.transpose(-1, -2)) * (1.0 / c ** 0.5))
+    if _PLAN16[0] or x.is_cuda:  # fp16 plan: scores, probabilities and P.V are fp16 tensors in HBM (wan2gp_amd/vae.py attention_block);
+        sc = _q((q @ k.transpose(-1, -2)) * (1.0 / c ** 0.5))   # on a GPU (either plan): plain matmuls instead of a vendor attention kernel
         y = _q(_q(torch.softmax(sc, dim=-1)) @ v)
     else:
         y = F.scaled_dot_product_attention(q, k, v)
     y = y.squeeze(1).permute(0, 2, 1).reshape(b * t, c, h, w)
-    y = F.conv2d(y, W[p + "proj.weight"], W[p + "proj.bias"])
+    y = _conv2d(y, W[p + "proj.weight"], W[p + "proj.bias"])
     y = y.reshape(b, t, c, h, w).permute(0, 2, 1, 3, 4)
     return _q(y + x)
 
@@ -223,9 +253,9 @@ def resample(x, W, p, mode, cache, idx):
     y = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
     if mode in ("upsample2d", "upsample3d"):
         y = F.interpolate(y.float(), scale_factor=(2., 2.), mode="nearest-exact").type_as(y)
-        y = _q(F.conv2d(y, W[p + "resample.1.weight"], W[p + "resample.1.bias"], padding=1))
+        y = _q(_conv2d(y, W[p + "resample.1.weight"], W[p + "resample.1.bias"], padding=1))
     else:
-        y = _q(F.conv2d(F.pad(y, (0, 1, 0, 1)), W[p + "resample.1.weight"], W[p + "resample.1.bias"], stride=2))
+        y = _q(_conv2d(F.pad(y, (0, 1, 0, 1)), W[p + "resample.1.weight"], W[p + "resample.1.bias"], stride=2))
     x = y.reshape(b, t, *y.shape[1:]).permute(0, 2, 1, 3, 4)
     if mode == "downsample3d" and cache is not None:
         i = idx[0]

@@ -298,8 +298,17 @@ def text_embed(ctx: torch.Tensor, W) -> torch.Tensor:
 
 def patch_embed(x: torch.Tensor, W, cfg: WanConfig, dtype) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
     """model.py:1631,1731: fp32 Conv3d k=s=(1,2,2) -> .to(modulation dtype) -> [B,L,dim]."""
-    y = F.conv3d(x.to(W["patch_embedding.weight"].dtype), W["patch_embedding.weight"],
-                 W["patch_embedding.bias"], stride=cfg.patch_size).to(dtype)
+    w = W["patch_embedding.weight"]
+    if x.is_cuda:
+        # the oracle executed on a GPU (tests/test_gpu_14B_depth.py): kernel == stride, so the convolution is one matmul over
+        # the gathered patches -- no vendor convolution library; the CPU path below is the one pinned to the reference
+        pt, ph, pw = cfg.patch_size
+        B, C, Fr, H, Wd = x.shape
+        g = (Fr // pt, H // ph, Wd // pw)
+        xp = x.to(w.dtype).reshape(B, C, g[0], pt, g[1], ph, g[2], pw).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, g[0] * g[1] * g[2], -1)
+        y = (xp @ w.reshape(w.shape[0], -1).t() + W["patch_embedding.bias"]).to(dtype)
+        return y, g
+    y = F.conv3d(x.to(w.dtype), w, W["patch_embedding.bias"], stride=cfg.patch_size).to(dtype)
     grid = tuple(y.shape[2:])
     return y.flatten(2).transpose(1, 2), grid
 

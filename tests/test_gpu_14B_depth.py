@@ -7,8 +7,12 @@ at d = 5120 against the oracle, every GEMM / the attention kernel at the bench s
 product of the two: depth 40 at width 5120.
 
 The checkpoint (14.3 G parameters) is drawn on the GPU (a CPU generator needs minutes for it), rounded to bf16-representable
-values there, loaded into the HIP model, and copied to the host once for the oracle; the fp32 anchor converts each tensor
-when it is touched.  One stream (the CFG pair of the bench is two independent rows ranges of the same kernels).
+values there and loaded into the HIP model.  The oracle is plain torch code: at this size its CPU execution does not fit the
+GPU budget of a round (40 layers x two plans did not finish in 15 minutes on the box's 128 cores), so its arithmetic is executed
+by PyTorch on the GPU -- the fp32 anchor exactly (fp32 matmuls, exact attention path), the bf16 plan with torch's own bf16
+kernels, i.e. the way the reference itself runs in production -- and block 0 of that execution is pinned to the CPU execution
+(the one the goldens pin bit-exactly to the reference) in this test.  The fp32 anchor converts each tensor when it is touched.
+One stream (the CFG pair of the bench is two independent row ranges of the same kernels).
 
 Bars (the ones of test_gpu_baseline_configs.py): per layer and at the output err_hip <= 1.5 * err_ref + 2e-3 where
 err_x = |x - fp32 anchor| / |fp32 anchor|; |hip - ref| / |ref| <= 2.5e-2 at the output.
@@ -90,28 +94,44 @@ def test_14B_forty_layers_vs_oracle():
     torch.cuda.synchronize()
     hip_layers = hip_layers[1:]                                   # entry 0 = the embedded tokens, entry i = after block i - 1
     assert len(hip_layers) == cfg.num_layers - 1
-    t0 = time.time()
-    Wc = {k: v.cpu() for k, v in Wg.items()}
-    del Wg, m
+    del m
     torch.cuda.empty_cache()
-    t_copy = time.time() - t0
-
+    cos, sin = O.rope_tables((f, h // 2, w // 2))
+    freqs = (cos.cuda(), sin.cuda())
     ref_layers, anc_layers = {}, {}
     with torch.no_grad():
         t0 = time.time()
-        ref = O.dit_forward([lat], t, [ctx], Wc, cfg, dtype=BF, probe=lambda i, s, hid: ref_layers.__setitem__(i, hid[0, rows].float()))[0]
+        ref = O.dit_forward([lat.cuda()], t.cuda(), [ctx.cuda()], Wg, cfg, dtype=BF, freqs=freqs,
+                            probe=lambda i, s, hid: ref_layers.__setitem__(i, hid[0, rows.cuda()].float().cpu()))[0].cpu()
+        torch.cuda.synchronize()
         t_bf = time.time() - t0
-        anchor = O.dit_forward([lat], t, [ctx.float()], _AsFloat32(Wc), cfg, dtype=torch.float32, exact=True,
-                               probe=lambda i, s, hid: anc_layers.__setitem__(i, hid[0, rows].float()))[0]
+        anchor = O.dit_forward([lat.cuda()], t.cuda(), [ctx.float().cuda()], _AsFloat32(Wg), cfg, dtype=torch.float32, exact=True, freqs=freqs,
+                               probe=lambda i, s, hid: anc_layers.__setitem__(i, hid[0, rows.cuda()].float().cpu()))[0].cpu()
+        torch.cuda.synchronize()
         t_32 = time.time() - t0 - t_bf
+        # block 0 on the CPU (embeddings + the first block: the weights of one layer travel to the host)
+        t0 = time.time()
+        W0 = {k: v.cpu() for k, v in Wg.items() if not k.startswith("blocks.") or k.startswith("blocks.0.")}
+        cfg1 = O.WanConfig(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=1)
+        cpu0 = {}
+        O.dit_forward([lat], t, [ctx], W0, cfg1, dtype=BF, return_hidden=True, probe=lambda i, s, hid: cpu0.__setitem__(i, hid[0, rows].float()))
+        cpu0a = {}
+        O.dit_forward([lat], t, [ctx.float()], _AsFloat32(W0), cfg1, dtype=torch.float32, exact=True, return_hidden=True,
+                      probe=lambda i, s, hid: cpu0a.__setitem__(i, hid[0, rows].float()))
+        t_cpu0 = time.time() - t0
+    pin = {"bf16_gpu_vs_cpu": rel(ref_layers[0], cpu0[0]), "fp32_gpu_vs_cpu": rel(anc_layers[0], cpu0a[0]),
+           "cpu_bf16_vs_cpu_fp32": rel(cpu0[0], cpu0a[0])}
+    print(f"\n[14B x 40 layers] block 0, oracle executed on the GPU vs on the CPU: {pin} ({t_cpu0:.0f}s)")
+    # two bf16 executions with different summation orders sit about sqrt(2) x one execution's own rounding noise apart
+    assert pin["fp32_gpu_vs_cpu"] <= 1e-5 and pin["bf16_gpu_vs_cpu"] <= 1.5 * pin["cpu_bf16_vs_cpu_fp32"] + 1e-3, pin
+    t_copy = 0.0
     table = []
     for i in range(cfg.num_layers - 1):
         a = anc_layers[i]
         table.append({"layer": i, "err_ref": rel(ref_layers[i], a), "err_hip": rel(hip_layers[i], a),
                       "hip_vs_ref": rel(hip_layers[i], ref_layers[i])})
     fin = {"err_ref": rel(ref, anchor), "err_hip": rel(out, anchor), "hip_vs_ref": rel(out, ref)}
-    print(f"\n[14B x 40 layers, L={L}] checkpoint on the GPU {t_w:.0f}s, to the host {t_copy:.0f}s, oracle bf16 {t_bf:.0f}s, "
-          f"fp32 anchor {t_32:.0f}s on {torch.get_num_threads()} threads")
+    print(f"\n[14B x 40 layers, L={L}] checkpoint on the GPU {t_w:.0f}s, oracle (executed on the GPU) bf16 {t_bf:.0f}s, fp32 anchor {t_32:.0f}s")
     for r in table:
         print("  layer %2d  err_ref %.3e  err_hip %.3e  hip-vs-ref %.3e" % (r["layer"], r["err_ref"], r["err_hip"], r["hip_vs_ref"]))
     print(f"[14B x 40 layers] output: err_ref={fin['err_ref']:.4e} err_hip={fin['err_hip']:.4e} hip-vs-ref={fin['hip_vs_ref']:.4e}")
@@ -119,8 +139,8 @@ def test_14B_forty_layers_vs_oracle():
     try:
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, "forward14B_40layers_L2048.json"), "w") as fo:
-            json.dump({"layers": table, "output": fin, "probed_rows": len(rows),
-                       "seconds": {"oracle_bf16": t_bf, "fp32_anchor": t_32, "threads": torch.get_num_threads()}}, fo, indent=1)
+            json.dump({"layers": table, "output": fin, "probed_rows": len(rows), "block0_gpu_vs_cpu_execution_of_the_oracle": pin,
+                       "seconds": {"oracle_bf16_on_gpu": t_bf, "fp32_anchor_on_gpu": t_32, "block0_on_cpu": t_cpu0}}, fo, indent=1)
     except OSError:
         pass
     for r in table:

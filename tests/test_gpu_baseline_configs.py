@@ -182,8 +182,10 @@ def test_14B_block_cfg_pair_vs_oracle(grid):
 
 
 # ---- the shipped self-attention kernel at the bench / config-4 shapes ---------------------------------------------------
-def _attn_sampled_check(q, k, vt, got, pairs, n_rows, nseg=1, what=""):
-    """q [B,Lq,H,128] pre-scaled bf16, k [nseg,B,Lk,H,128], vt [nseg,B,H*128,ldv]; fp64 softmax on sampled rows."""
+def _attn_sampled_check(q, k, vt, got, pairs, n_rows, nseg=1, what="", coarse_ulp=False):
+    """q [B,Lq,H,128] pre-scaled bf16, k [nseg,B,Lk,H,128], vt [nseg,B,H*128,ldv]; fp64 softmax on sampled rows.
+    coarse_ulp: the bar of tests/test_gpu_ops.py `attn_ok` -- 1.5e-2 absolute, or one coarse bf16 ulp (2^-7 |ref|) where the
+    exact value is large (a peaked softmax returns single V entries of magnitude 2..4, whose bf16 ulp alone is 1.6e-2)."""
     B, Lq, H, _ = q.shape
     Lk = k.shape[2]
     gen = torch.Generator().manual_seed(1)
@@ -196,6 +198,8 @@ def _attn_sampled_check(q, k, vt, got, pairs, n_rows, nseg=1, what=""):
         p = torch.exp2(s_ - s_.amax(dim=-1, keepdim=True))
         o = (p / p.sum(dim=-1, keepdim=True)) @ vv.t()
         err = (got[b, rows, hd, :].double() - o).abs()
+        if coarse_ulp:
+            err = err * (1.5e-2 / torch.clamp(o.abs() * 2.0 ** -7, min=1.5e-2))      # in units where the bar is 1.5e-2 everywhere
         worst = max(worst, err.max().item()); mean_acc += err.mean().item(); n += 1
     print(f"[attention {what}] {n} (stream, head) pairs x {n_rows} rows: max abs err {worst:.3e}, mean {mean_acc / n:.3e}")
     assert worst <= 1.5e-2 and mean_acc / n <= 2e-3, (what, worst, mean_acc / n)
@@ -263,7 +267,7 @@ def test_attention_bounded_and_tracking_loops_mixed_inside_one_launch():
         ms = e0.elapsed_time(e1) / 2
         r = None
         if check_pairs:
-            r = _attn_sampled_check(q, ks, vt, out, check_pairs, 256, what=what)
+            r = _attn_sampled_check(q, ks, vt, out, check_pairs, 256, what=what, coarse_ulp=True)
         return flags, declined / total, flops / (ms * 1e-3) / 1e12, r
 
     mixed = [gains[h % len(gains)] for h in range(H)]

@@ -321,6 +321,11 @@ __global__ __launch_bounds__(256) void gemm256k_kernel(const bf16_t* __restrict_
   if (EPI == WAN_EPI_GATE_RES && gate_idx >= 0 && col_full) mchunk = *reinterpret_cast<const uint4*>(mod + (int64_t)gate_idx * XN + xc);
 #pragma unroll
   for (int i = 0; i < GDEPTH; ++i) { rq[i] = fetch_r(i); eq[i] = fetch_e(i); }
+#ifdef G256K_NT_STORE  // experiment (round 3, run 62): non-temporal stores for the 128 KB a tile writes once
+#define G256K_ST(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define G256K_ST(PTR, VAL) (*(PTR) = (VAL))
+#endif
   auto emit = [&](int i, const uint4 rq_, const uint4 eq_) {
     const int64_t yr = yrow0 + i * 4;
     const uint4 raw = *reinterpret_cast<const uint4*>(park + (i * 4 + prow) * EROW + pchunk * 16);
@@ -341,9 +346,9 @@ __global__ __launch_bounds__(256) void gemm256k_kernel(const bf16_t* __restrict_
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = rv[j] + v[j];
         }
-        *reinterpret_cast<uint4*>(optr) = pack8t<F16>(v);
+        G256K_ST(reinterpret_cast<g256k_u4*>(optr), __builtin_bit_cast(g256k_u4, pack8t<F16>(v)));
       } else {
-        *reinterpret_cast<uint4*>(optr) = raw;
+        G256K_ST(reinterpret_cast<g256k_u4*>(optr), __builtin_bit_cast(g256k_u4, raw));
       }
     } else if (EPI == WAN_EPI_NONE) {
       // ragged x edge: only the transposed / V^T form (x = tokens, EPI NONE) can hit it -- the launcher requires
