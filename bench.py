@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the VAE decode / end-to-end block")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
+    ap.add_argument("--simulate-world", default="", help="comma-separated world sizes (e.g. 2,4,8): after the timed region, run ONE "
+                    "rank's shard of a sequence-parallel world of that size on this GPU, the K / V^T all-gathers replaced by "
+                    "device-to-device copies of the bytes that rank would receive -> compute-side upper bound of the scaling curve")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -374,6 +377,10 @@ def main():
         lib.wan_prof_enable(0)
         if e2e is not None:
             out["e2e"] = e2e
+        if world == 1 and args.simulate_world:
+            log("simulated sequence-parallel ranks: " + args.simulate_world)
+            out["simulated_scaling"] = simulate_world([int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
+                                                      latents, args.warmup, dt / args.steps, cfg, L)
         if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
             log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
             out["secondary"] = secondary_1p3b(vae)
@@ -385,6 +392,81 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def simulate_world(worlds, model, model2, one_step, latents, first_step, step_s_1gpu, cfg, L):
+    """ONE rank (rank 0) of a sequence-parallel world of N on this GPU: its token shard (L / N query rows against N gathered K / V^T
+    segments, every token-local kernel at M = S L / N rows), the all-gathers replaced by device-to-device copies of what the rank
+    would receive, on a side stream like the RCCL path.  What it measures is the COMPUTE side of the scaling curve (tile
+    quantisation at L / N rows, GEMM and attention efficiency at the shard's shapes, the local / remote attention split); the
+    xGMI time of the real gathers is not in it (bytes per block and rank are reported beside it).  efficiency = t(1) / (N t(N))."""
+    import torch
+    from wan2gp_amd.sp import SequenceParallel
+
+    class SimulatedRank(SequenceParallel):
+        def __init__(self, world):
+            super().__init__(0, world)
+            self.side = torch.cuda.Stream()
+            self.bytes = 0
+
+        def _gather_begin_cb(self, user, which, send, recv, nbytes, stream):
+            try:
+                base = self._ws.data_ptr()
+                sv = self._ws[send - base:send - base + nbytes]
+                rv = self._ws[recv - base:recv - base + nbytes * self.world].view(self.world, nbytes)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev)
+                    rv.copy_(sv.unsqueeze(0).expand(self.world, nbytes))     # world x nbytes written: what the gather leaves in recv
+                    done = torch.cuda.Event()
+                    done.record(self.side)
+                self._pending[which] = done
+                self.bytes += nbytes * (self.world - 1)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _gather_wait_cb(self, user, which, stream):
+            ev = self._pending.pop(which, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            return 0
+
+        def all_gather(self, send):
+            return send.repeat(self.world, *([1] * (send.dim() - 1)))
+
+    rows = []
+    for n in worlds:
+        if L % n:
+            rows.append({"world": n, "skipped": f"{L} tokens do not divide by {n}"})
+            continue
+        sp = SimulatedRank(n)
+        model.sp = sp
+        if model2 is not None:
+            model2.sp = sp
+        lat = latents
+        lat = one_step(first_step, lat)                                   # warm-up: workspace of this sharding
+        torch.cuda.synchronize()
+        sp.bytes = 0
+        t0 = time.perf_counter()
+        k = 2
+        for i in range(k):
+            lat = one_step(first_step + 1 + i, lat)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        assert torch.isfinite(lat).all()
+        layers = cfg["num_layers"]
+        rows.append({"world": n, "rank_step_ms": dt * 1e3, "compute_side_efficiency": step_s_1gpu / (n * dt),
+                     "gathered_bytes_per_block_and_rank": sp.bytes / (k * layers),       # K + V^T of the other ranks, both CFG streams
+                     "tokens_per_rank": L // n})
+        model.sp = None
+        if model2 is not None:
+            model2.sp = None
+    return {"note": "one rank's shard on one GPU, all-gathers = device-to-device copies (compute-side upper bound; no xGMI time)",
+            "one_gpu_step_ms": step_s_1gpu * 1e3, "ranks": rows}
 
 
 def secondary_1p3b(vae):

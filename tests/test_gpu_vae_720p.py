@@ -11,9 +11,14 @@
     uint8 frames, float frames to 1e-4).  (a) the fp32 plan = the reference-pinned restatement, bar on the uint8 frames: max |delta| <= 1 LSB,
     >= 90 % of the bytes identical (the HIP library stores activations in fp16, the reference's default VAE dtype on a
     GPU, wgp.py:4038; the golden is the reference's fp32 CPU run); (b) the fp16 storage plan of the same restatement
-    (`with VO.fp16_plan()`): rounding to fp16 at the points where the library stores fp16 -- what is left between the
-    two is accumulation order, bar >= 99 % of the bytes identical, max 1 LSB.  (b) is what attributes the bytes of (a)
-    to the storage plan and not to a kernel.
+    (`with VO.fp16_plan()`): rounding to fp16 at the points where the library stores fp16.  Measured (run 63): an fp16
+    plan is NOT reproducible across summation orders -- the restatement's own two executions (CPU / GPU) of it agree on
+    92.3 % of the bytes only (its fp32 plan: 99.995 %), because a flipped fp16 rounding propagates through 60 layers.
+    So (b) cannot be "the library equals the fp16-plan oracle"; what it pins is the SIZE of the effect: the library's
+    distance to the fp32 frames (mean |delta| in LSB) must not exceed 1.25 x the distance of the restatement's own fp16
+    plan to them, and its distance to that fp16-plan run must stay within 1.5 x of it -- an independent implementation
+    of the storage plan lands as far from the fp32 golden as the library does, max 1 LSB everywhere.  That attributes
+    the differing bytes of (a) to the storage plan and not to a kernel.
   * conv3d_f16_kernel<BIG> (64-bit gather offsets): forced onto an ordinary input and held bit-for-bit against the 32-bit
     instantiation (plain, cached, up-sampled, stride-2), and reached for real by a chunk of more than 2^31 elements,
     checked on sampled output pixels against an fp64 dot product of the same taps.
@@ -131,9 +136,14 @@ def test_oracle_executed_on_the_gpu_equals_its_cpu_execution():
                 ec, eg = VO.vae_encode(vid, W, scale), VO.vae_encode(vid.cuda(), Wg, sg).cpu()
             st = _u8_stats(VO.float_to_uint8(dg), VO.float_to_uint8(dc))
             print(f"\n[oracle gpu vs cpu, fp16 plan={plan}] decode {st}, float {float((dg - dc).abs().max()):.2e}, encode {float((eg - ec).abs().max()):.2e}")
-            tol = 2e-3 if plan else 1e-4          # fp16 plan: a different summation order can flip an fp16 rounding (one fp16 ulp of O(1) values)
-            assert st["identical"] >= (0.995 if plan else 0.9999) and st["max_lsb"] <= 1
-            assert (dg - dc).abs().max() <= tol * max(1.0, float(dc.abs().max())) and (eg - ec).abs().max() <= tol * max(1.0, float(ec.abs().max()))
+            if plan:
+                # the fp16 plan amplifies summation order: a flipped fp16 rounding propagates (measured 92.3 % identical bytes
+                # between the two executions) -- this is the noise floor the 720p test measures the library against
+                assert st["max_lsb"] <= 1 and st["identical"] >= 0.85
+                assert (dg - dc).abs().max() <= 2e-2 and (eg - ec).abs().max() <= 2e-2 * max(1.0, float(ec.abs().max()))
+            else:
+                assert st["identical"] >= 0.9999 and st["max_lsb"] <= 1
+                assert (dg - dc).abs().max() <= 1e-4 * max(1.0, float(dc.abs().max())) and (eg - ec).abs().max() <= 1e-4 * max(1.0, float(ec.abs().max()))
 
 
 def test_decode_720p_vs_oracle_fp32_and_fp16_plan(vae):
@@ -167,8 +177,10 @@ def test_decode_720p_vs_oracle_fp32_and_fp16_plan(vae):
     _report("vae_decode_720p_t3", res)
     assert sat < 0.5, "the synthetic decode saturates: the byte comparison would be vacuous"
     assert s32["max_lsb"] <= 1 and s32["identical"] >= 0.90 and s32["mean_lsb"] <= 0.1, s32
-    assert s16["max_lsb"] <= 1 and s16["identical"] >= 0.99, s16
-    assert s16["identical"] > s32["identical"] and f16_err < f32_err        # the residue is the storage plan
+    assert plan["max_lsb"] <= 1 and s16["max_lsb"] <= 1
+    # the size of the effect is the storage plan's: an independent fp16-plan execution is as far from fp32 as the library
+    assert s32["mean_lsb"] <= 1.25 * plan["mean_lsb"] + 5e-3, (s32, plan)
+    assert s16["mean_lsb"] <= 1.5 * plan["mean_lsb"] + 5e-3, (s16, plan)
     assert f32_err <= 1.5e-2
 
 
@@ -199,8 +211,10 @@ def test_encode_720p_vs_oracle_fp32_and_fp16_plan(vae):
            "seconds": {"hip": t_hip, "oracle_fp32_on_gpu": t32, "oracle_fp16_plan_on_gpu": t16}}
     print("\n[VAE encode 9f 720x1280] " + json.dumps(res))
     _report("vae_encode_720p_9f", res)
+    rplan = ((ref16 - ref32).norm() / ref32.norm()).item()
+    print(f"[VAE encode 9f 720x1280] fp16-plan oracle vs fp32 oracle: rel l2 {rplan:.3e}")
     assert e32 <= 1e-2 * sc + 1e-3, res                                     # the bar of the small-size golden test
-    assert r16 < r32 and e16 <= 0.5 * (1e-2 * sc + 1e-3), res               # closer to the plan it implements
+    assert r32 <= 1.5 * rplan + 1e-4 and r16 <= 2.0 * rplan + 1e-4, (res, rplan)   # no further from fp32 than the storage plan itself puts an independent run
 
 
 # ---- conv3d_f16_kernel<BIG> -------------------------------------------------------------------------------------------------
@@ -251,10 +265,10 @@ def test_conv_big_offsets_forced_equal_the_32bit_kernel_bit_for_bit():
 
 def test_conv_on_a_chunk_beyond_2_31_elements():
     """(Tin + 2) * H * W * C >= 2^31: the launcher takes the 64-bit instantiation by itself.  384 channels at 720 x 1280,
-    4 frames + the 2-frame cache; 32 output channels keep it cheap.  Sampled output pixels (the far end of the tensor
+    5 frames + the 2-frame cache; 32 output channels keep it cheap.  Sampled output pixels (the far end of the tensor
     included, where a 32-bit offset would have wrapped) against an fp64 dot product of the same 27 x 384 taps."""
     from wan2gp_amd.vae import _VaeNet
-    T, H, Wd, C, Co = 4, 720, 1280, 384, 32
+    T, H, Wd, C, Co = 5, 720, 1280, 384, 32
     assert (T + 2) * H * Wd * C >= 2 ** 31
     g = torch.Generator(device="cuda").manual_seed(3)
     gc = torch.Generator().manual_seed(3)
@@ -268,7 +282,7 @@ def test_conv_on_a_chunk_beyond_2_31_elements():
     assert tuple(out.shape) == (T, H, Wd, Co)
     full = torch.cat([cache, x], 0)                              # frame t of x = frame t + 2 here; causal taps reach back 2 frames
     wd = w.double().cuda()                                       # [Co, C, 3, 3, 3]
-    pts = [(0, 0, 0), (T - 1, H - 1, Wd - 1), (T - 1, H - 1, 0), (T - 1, 0, Wd - 1), (2, 359, 640), (3, 719, 1279 - 1)]
+    pts = [(0, 0, 0), (T - 1, H - 1, Wd - 1), (T - 1, H - 1, 0), (T - 1, 0, Wd - 1), (2, 359, 640), (T - 2, 719, 1279 - 1)]
     gp = torch.Generator().manual_seed(8)
     pts += [(int(torch.randint(0, T, (1,), generator=gp)), int(torch.randint(0, H, (1,), generator=gp)),
              int(torch.randint(0, Wd, (1,), generator=gp))) for _ in range(250)]

@@ -605,3 +605,109 @@ def test_bounded_tile_read_plan_register_lifetimes():
         g = 17 + f
         assert g > 16 + f and g <= 32 and 48 + (f >> 2) * 4 - g >= 16 - f + 4 * (f >> 2) - 1
     assert sorted({(r & 1) * 8 + (r >> 1) for r in range(16)}) == list(range(16))
+
+
+# ----------------------------------------------------------------------------------------------
+# gemm256p.hip (persistent 256x256x64): X rows staged 4-way interleaved, operands swapped, register-direct epilogue,
+# continuous LDS-DMA stream across tiles
+# ----------------------------------------------------------------------------------------------
+def _mfma_c_row(r, half):
+    """v_mfma_f32_32x32x16: register r of lane (j, half) holds D[i][j] with i = 8 (r >> 2) + (r & 3) + 4 half
+    (cdna_hip_programming.md section 3; the layout attention_w64q.hip / gemm256k.hip are built on)."""
+    return 8 * (r >> 2) + (r & 3) + 4 * half
+
+
+def test_gemm256p_operand_interleave_and_register_direct_stores():
+    """End to end on one 256 x 256 tile with K = 64: DMA plan (which global row lands in which LDS row), fragment
+    addresses, MFMA semantics with Y as the A operand and X as the B operand, and the epilogue's (lane, yt, r) -> (row,
+    4 columns) map.  Every output element must be produced exactly once, with the right operands, and a store
+    instruction must write 2 rows x 256 contiguous bytes."""
+    rng = np.random.default_rng(5)
+    Yt = rng.integers(-3, 4, size=(256, 64)).astype(np.float64)      # tile-local operand panels (one stage)
+    Xt = rng.integers(-3, 4, size=(256, 64)).astype(np.float64)
+    # ---- DMA plan: LDS unit images (row, physical chunk) <- (global row, logical chunk)
+    ylds = np.zeros((256, 8, 8)); xlds = np.zeros((256, 8, 8))
+    for i in range(8):
+        for tid in range(256):
+            q = i * 256 + tid
+            row, pch = q >> 3, q & 7
+            lch = pch ^ ((row >> 1) & 7)
+            ylds[row, pch] = Yt[row, lch * 8:lch * 8 + 8]
+            slab, xt, rho = row >> 7, (row >> 5) & 3, row & 31
+            xlds[row, pch] = Xt[slab * 128 + 4 * rho + xt, lch * 8:lch * 8 + 8]
+    out = np.full((256, 256), np.nan)
+    writes = 0
+    for wave in range(4):
+        wy, wx = wave >> 1, wave & 1
+        acc = np.zeros((4, 4, 64, 16))                                # [yt][xt][lane][reg]
+        for ks in range(4):
+            yf = np.zeros((4, 64, 8)); xf = np.zeros((4, 64, 8))
+            for lane in range(64):
+                l31, half = lane & 31, lane >> 5
+                sw = (l31 >> 1) & 7
+                for r in range(4):
+                    ya = (wy * 128 + l31) * 128 + ((half ^ sw) << 4)
+                    addr = r * 4096 + (ya ^ (ks << 5))
+                    yf[r, lane] = ylds[addr // 128, (addr % 128) // 16]
+                    xa = (wx * 128 + l31) * 128 + ((half ^ sw) << 4)
+                    addr = r * 4096 + (xa ^ (ks << 5))
+                    xf[r, lane] = xlds[addr // 128, (addr % 128) // 16]
+            # MFMA: A[i][k] from lane (i, kh) of the Y fragment, B[j][k] from lane (j, kh) of the X fragment, k = 8 kh + e
+            for a in range(4):
+                for b in range(4):
+                    A = np.zeros((32, 16)); B = np.zeros((32, 16))
+                    for lane in range(64):
+                        A[lane & 31, (lane >> 5) * 8:(lane >> 5) * 8 + 8] = yf[a, lane]
+                        B[lane & 31, (lane >> 5) * 8:(lane >> 5) * 8 + 8] = xf[b, lane]
+                    D = A @ B.T
+                    for lane in range(64):
+                        for r in range(16):
+                            acc[a, b, lane, r] += D[_mfma_c_row(r, lane >> 5), lane & 31]
+        # ---- epilogue: lane (l31, half), chunk (yt, r): row wy*128 + yt*32 + 8 (r>>2) + (r&3) + 4 half, columns wx*128 + 4 l31 + (0..3)
+        for yt in range(4):
+            for r in range(16):
+                rows_of_instr = {}
+                for lane in range(64):
+                    l31, half = lane & 31, lane >> 5
+                    row = wy * 128 + yt * 32 + 8 * (r >> 2) + (r & 3) + 4 * half
+                    col = wx * 128 + 4 * l31
+                    byte = row * 512 + col * 2                      # ldo = 256 elements here
+                    rows_of_instr.setdefault(row, []).append(byte)
+                    for xt in range(4):
+                        assert np.isnan(out[row, col + xt])
+                        out[row, col + xt] = acc[yt, xt, lane, r]
+                        writes += 1
+                assert len(rows_of_instr) == 2                       # one store instruction = 2 rows ...
+                for row, bs in rows_of_instr.items():                # ... of 256 contiguous bytes each (32 lanes x 8 B)
+                    assert sorted(bs) == list(range(min(bs), min(bs) + 256, 8))
+    assert writes == 256 * 256
+    np.testing.assert_array_equal(out, Yt @ Xt.T)
+
+
+def test_gemm256p_continuous_stream_over_tiles():
+    """Event simulation of the two LDS-DMA streams and the MFMA stage counter across tile boundaries (nk not a multiple of
+    5, so a tile starts at any ring position): every stage the MFMAs consume was fetched from the right (tile, k-stage) into
+    the slot it is read from, two stages ahead, and after the last tile the streams stay on valid memory."""
+    for nk, ntiles in ((7, 3), (11, 2), (5, 4), (3, 5), (80, 2)):
+        slots = {}                                           # slot -> (kind, tile, stage) currently landing / resident
+        stream = {"Y": [0, 0], "X": [0, 0]}                  # [tile, stage] the stream points at
+
+        def issue(kind, slot):
+            t, s = stream[kind]
+            slots[slot] = (kind, min(t, ntiles - 1) if t < ntiles else ntiles - 1, s)
+            # advance: wrap to the next tile (or stay on the last tile's stage 0.. again: dead units)
+            if s + 1 == nk:
+                stream[kind] = [t + 1 if t + 1 < ntiles else t, 0]
+            else:
+                stream[kind] = [t, s + 1]
+        issue("Y", 0); issue("X", 1); issue("Y", 2); issue("X", 3)          # prologue: stages 0, 1
+        g = 0
+        for tile in range(ntiles):
+            for s in range(nk):
+                J = g % 5
+                SY, SX, DY, DX = (2 * J) % 5, (2 * J + 1) % 5, (2 * J + 4) % 5, (2 * J) % 5
+                assert slots[SY] == ("Y", tile, s) and slots[SX] == ("X", tile, s), (nk, tile, s, slots)
+                issue("Y", DY)                               # k-steps 0, 1: Y of global stage g + 2
+                # P_S ... k-step 3: X of global stage g + 2 goes into Y_S's slot (dead by now)
+                issue("X", DX)
+                g += 1

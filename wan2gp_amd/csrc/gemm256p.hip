@@ -51,7 +51,12 @@ __device__ __forceinline__ void mfma256p(f32x16& acc, const g256p_u4& ya, const 
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(ya), "v"(xb));
 }
 // LDS-DMA piece as inline asm (invisible to hipcc's waitcnt pass, see gemm256k.hip); completion is counted by hand
-__device__ __forceinline__ void g256p_dma16(uint32_t voff, const g256p_u4& rsrc, uint32_t lds_addr) {
+// The LDS address of a piece = the wave's base + a compile-time offset.  The base is laundered through an empty asm at every
+// use: left visible, hipcc hoists all 16 pieces x 5 slots of addresses into SGPRs for the whole kernel and the scalar file
+// (102) overflows into VGPR lanes and scratch; this way each address is one s_add right in front of its piece.
+__device__ __forceinline__ void g256p_dma16(uint32_t voff, const g256p_u4& rsrc, uint32_t lds_wave_base, uint32_t off) {
+  asm volatile("" : "+s"(lds_wave_base));
+  const uint32_t lds_addr = lds_wave_base + off;
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ g256p_u4 g256p_rsrc(const char* base, uint32_t num_records) {
@@ -105,14 +110,19 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
   // i*32 + w*8 .. +8, eight lanes per row = the row's whole 128-B line in one instruction; physical chunk p of row r holds
   // logical chunk p ^ ((r >> 1) & 7).  Y rows in place; X row (slab, xt, rho) = column slab*128 + 4 rho + xt of the tile.
   uint32_t yofs[8], xofs[8];
-#pragma unroll
+  const uint32_t ldy2 = (uint32_t)(ldy * 2), ldx2 = (uint32_t)(ldx * 2);   // 32-bit on purpose (the launcher checks 256 rows fit): 64-bit
+#pragma unroll                                                              // products were kept as register PAIRS for the whole kernel
   for (int i = 0; i < 8; ++i) {
     const int q = i * 256 + tid;
     const int row = q >> 3, pch = q & 7;
     const int lch = pch ^ ((row >> 1) & 7);
-    yofs[i] = (uint32_t)((int64_t)row * ldy * 2 + lch * 16);
+    uint32_t ty_ = (uint32_t)row * ldy2;
+    asm volatile("" : "+v"(ty_));  // product and sum apart: fused, hipcc emits v_mad_u64_u32 and keeps the 64-bit PAIR allocated
+    yofs[i] = ty_ + (uint32_t)(lch * 16);
     const int slab = row >> 7, xt = (row >> 5) & 3, rho = row & 31;
-    xofs[i] = (uint32_t)((int64_t)(slab * 128 + 4 * rho + xt) * ldx * 2 + lch * 16);
+    uint32_t tx_ = (uint32_t)(slab * 128 + 4 * rho + xt) * ldx2;
+    asm volatile("" : "+v"(tx_));
+    xofs[i] = tx_ + (uint32_t)(lch * 16);
   }
   const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -152,8 +162,9 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
     }
   };
   plan_next();
-  auto y_piece = [&](int slot, int p) { g256p_dma16(yofs[p], g256p_rsrc(ybase, ynum), smem_lds + slot * P_UNIT + (p * 256 + wave * 64) * 16); };
-  auto x_piece = [&](int slot, int p) { g256p_dma16(xofs[p], g256p_rsrc(xbase, xnum), smem_lds + slot * P_UNIT + (p * 256 + wave * 64) * 16); };
+  const uint32_t lds_wave = smem_lds + (uint32_t)wave * 1024u;   // + slot * P_UNIT + piece * 4096 per DMA piece
+#define y_piece(SLOT, P) g256p_dma16(yofs[P], g256p_rsrc(ybase, ynum), lds_wave, (uint32_t)((SLOT) * P_UNIT + (P) * 4096))
+#define x_piece(SLOT, P) g256p_dma16(xofs[P], g256p_rsrc(xbase, xnum), lds_wave, (uint32_t)((SLOT) * P_UNIT + (P) * 4096))
   auto y_advance = [&]() {
     const bool wrap = ky + 1 == nk;
     ybase = wrap ? ynext : ybase + P_BK * 2;
@@ -168,15 +179,20 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
   };
 
   f32x16 acc[4][4];  // [y tile][x tile], accumulator file
+  // Zeroed on the matrix pipe: D = 0 * 0 + 0 writes the 16 accumulator registers of a tile without staging 16 zeros in arch
+  // VGPRs first (the allocator materialised all 256 at once and spilled long-lived values around it); 16 MFMAs per tile.
   auto zero_acc = [&]() {
+    // the zero fragment is PRODUCED by a volatile asm, per tile: a loop-invariant value would be kept across the MFMA loop, i.e. in
+    // scratch, and its reload at the top of every tile drains the DMA stream (s_waitcnt vmcnt(0) in front of the first use)
+    g256p_u4 zfrag;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zfrag[0]));
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zfrag[1]));
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zfrag[2]));
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zfrag[3]));
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        asm volatile("" : "+a"(acc[a][b]));
-      }
+      for (int b = 0; b < 4; ++b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(acc[a][b]) : "v"(zfrag));
   };
 
   // ---- fragment addresses (as gemm256k.hip): k-step ks reads logical chunk 2ks + half ------------------------------------------
@@ -255,13 +271,13 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
   for (;;) {
     zero_acc();
     int left = nk;
-    while (left > 0) {
+    do {
       P_STEP(0)
       P_STEP(1)
       P_STEP(2)
       P_STEP(3)
       P_STEP(4)
-    }
+    } while (left > 0);
     // ---- epilogue of tile `cur`: straight from the registers ---------------------------------------------------------------
     // Stores (and the residual loads of the gated form) go through a buffer descriptor over the tile's rows of Out: rows past
     // the matrix fall outside num_records and are dropped / read as zero by the hardware -- no per-row predicate, and every wave
@@ -312,17 +328,29 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
         }
       }
       const uint32_t row_lane = (uint32_t)(wy * 128) + 4u * halfe;
+      // 16 chunks of 4 row pairs (one accumulator quarter of each of the block's four x tiles): the residual rows of chunk c + 1
+      // are requested before chunk c is converted (latency under 16 accumulator reads + the pack), and no more than two chunks'
+      // worth of registers is ever live beside the next tile's first fragments
+      auto rload = [&](int c, int k) -> g256p_u2 {
+        const int yt = c >> 2, r = (c & 3) * 4 + k;
+        return __builtin_bit_cast(g256p_u2, __builtin_amdgcn_raw_buffer_load_b64(
+                   rdesc, (int)(lane_off + (uint32_t)(yt * 32 + 8 * (r >> 2) + (r & 3)) * ldo2), 0, 0));
+      };
+      g256p_u2 rq[4] = {}, rn[4] = {};
+      if (EPI == WAN_EPI_GATE_RES) {
 #pragma unroll
-      for (int yt = 0; yt < 4; ++yt) {
-        g256p_u2 rq[16];
-        if (EPI == WAN_EPI_GATE_RES) {  // the block's residual rows: 16 loads of 2 rows x 256 B in flight before the first use
+        for (int k = 0; k < 4; ++k) rq[k] = rload(0, k);
+      }
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            rq[r] = __builtin_bit_cast(g256p_u2, __builtin_amdgcn_raw_buffer_load_b64(
-                        rdesc, (int)(lane_off + (uint32_t)(yt * 32 + 8 * (r >> 2) + (r & 3)) * ldo2), 0, 0));
+      for (int c = 0; c < 16; ++c) {
+        const int yt = c >> 2;
+        if (EPI == WAN_EPI_GATE_RES && c + 1 < 16) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rn[k] = rload(c + 1, k);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int k = 0; k < 4; ++k) {
+          const int r = (c & 3) * 4 + k;
           const uint32_t rit = (uint32_t)(yt * 32 + 8 * (r >> 2) + (r & 3));              // row in the wave's 128, before the half term
           float v[4] = {acc[yt][0][r] * out_scale + bcol[0], acc[yt][1][r] * out_scale + bcol[1], acc[yt][2][r] * out_scale + bcol[2],
                         acc[yt][3][r] * out_scale + bcol[3]};
@@ -332,8 +360,8 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
             for (int j = 0; j < 4; ++j) v[j] = g256p_gelu_tanh(rbf(v[j]));
           }
           if (EPI == WAN_EPI_GATE_RES) {
-            const float rv[4] = {__uint_as_float(rq[r][0] << 16), __uint_as_float(rq[r][0] & 0xffff0000u),
-                                 __uint_as_float(rq[r][1] << 16), __uint_as_float(rq[r][1] & 0xffff0000u)};
+            const float rv[4] = {__uint_as_float(rq[k][0] << 16), __uint_as_float(rq[k][0] & 0xffff0000u),
+                                 __uint_as_float(rq[k][1] << 16), __uint_as_float(rq[k][1] & 0xffff0000u)};
             if (gated) {
               const bool second = row_lane + rit >= rb;
 #pragma unroll
@@ -348,8 +376,13 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
           w[1] = pack2bf(v[2], v[3]);
           typedef unsigned int g256p_st2 __attribute__((__vector_size__(8)));
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(g256p_st2, w), odesc, (int)(lane_off + rit * ldo2), 0, 0);
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // 16 accumulators out of the file at a time, not 256
+          if (EPI == WAN_EPI_GELU_TANH) __builtin_amdgcn_sched_barrier(0);  // 4 GELUs' temporaries at a time
         }
+        if (EPI == WAN_EPI_GATE_RES) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rq[k] = rn[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (!has_next) break;
@@ -361,6 +394,8 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
 #undef P_STEP
 #undef P_KSTEP_A
 #undef P_SB
+#undef y_piece
+#undef x_piece
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing DMA of the dead stages must land before the LDS is released
 }
 
