@@ -1,9 +1,9 @@
-"""TEST / BUILD INFRASTRUCTURE -- writes wan2gp_amd/data/skip_cache_tables.json: the per-model calibration tables of the
+"""BUILD TOOL -- writes wan2gp_amd/data/skip_cache_tables.json: the per-model calibration tables of the
 reference's step-skipping caches (TeaCache rescale polynomials, MagCache magnitude ratios), i.e. the literals assigned inside
 `family_handler.set_cache_parameters` (models/wan/wan_handler.py:172-214).  They are model calibration DATA the plugin has to
 hand to `skip_steps_cache` exactly as the built-in handler does (wgp.py:7202); they are read out of the reference's source with
 `ast` -- by the order of the assignments in each branch -- instead of being retyped.
-Run in the build container:   python oracle/extract_cache_tables.py"""
+Run in the build container:   python tools/extract_cache_tables.py"""
 import ast
 import json
 import os

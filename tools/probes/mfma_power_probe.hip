@@ -1,0 +1,137 @@
+// Probe: sustained bf16 MFMA throughput of the whole chip on RANDOM data, 32x32x16 against 16x16x32, with and without the GEMM's
+// LDS fragment traffic.  Question (round 3, run 64): gemm256p saves 8 % of gemm256k's cycles per tile and gains nothing in wall
+// time -- the chip runs these kernels at its power limit (effective clock 1.42 vs 1.56 GHz), so what matters is energy per FLOP.
+// The vendor's hand-tuned 256x256x64 kernel uses 16x16x32 (half the accumulator read/write traffic per MAC: K = 32 per
+// instruction instead of 16).  One workgroup of 4 waves per CU, 256 accumulator registers per lane, ~100 ms per kernel.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_power_probe mfma_power_probe.hip && ./mfma_power_probe
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(16))) float f16v;
+typedef __attribute__((ext_vector_type(4))) float f4v;
+typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void k32(const u4* __restrict__ src, float* __restrict__ out, int iters) {
+  __shared__ __attribute__((aligned(16))) u4 lds[4096];  // 64 KB
+  for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = src[i];
+  __syncthreads();
+  const int lane = threadIdx.x;
+  bf8 a[4], b[4];
+  for (int i = 0; i < 4; ++i) {
+    a[i] = __builtin_bit_cast(bf8, src[lane + 256 * i]);
+    b[i] = __builtin_bit_cast(bf8, src[lane + 256 * (4 + i)]);
+  }
+  f16v acc[4][4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int off = lane;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (LDS) {  // the GEMM's rate: 8 fragment reads per 16 MFMAs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = __builtin_bit_cast(bf8, lds[(off + 256 * i) & 4095]);
+          b[i] = __builtin_bit_cast(bf8, lds[(off + 256 * (4 + i) + 64) & 4095]);
+        }
+        off += 1024;
+      }
+#pragma unroll
+      for (int m = 0; m < 16; ++m) acc[m >> 2][m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m >> 2], b[m & 3], acc[m >> 2][m & 3], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void k16(const u4* __restrict__ src, float* __restrict__ out, int iters) {
+  __shared__ __attribute__((aligned(16))) u4 lds[4096];
+  for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = src[i];
+  __syncthreads();
+  const int lane = threadIdx.x;
+  bf8 a[8], b[8];
+  for (int i = 0; i < 8; ++i) {
+    a[i] = __builtin_bit_cast(bf8, src[lane + 256 * (i & 3)]);
+    b[i] = __builtin_bit_cast(bf8, src[lane + 256 * (4 + (i & 3)) + 64 * (i >> 2)]);
+  }
+  f4v acc[8][8];
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j)
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  int off = lane;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // k = 32 per step: the same 64 k per iteration as k32
+      if (LDS) {                      // 16 fragment reads per 64 MFMAs: the same bytes per FLOP
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          a[i] = __builtin_bit_cast(bf8, lds[(off + 256 * i) & 4095]);
+          b[i] = __builtin_bit_cast(bf8, lds[(off + 256 * i + 2048 + 64) & 4095]);
+        }
+        off += 1024;
+      }
+#pragma unroll
+      for (int m = 0; m < 64; ++m) acc[m >> 3][m & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m >> 3], b[m & 7], acc[m >> 3][m & 7], 0, 0, 0);
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j)
+      for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+static uint16_t bf16_of(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16);
+}
+
+int main() {
+  int cus = 0;
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+  std::vector<uint16_t> h(4096 * 8);
+  srand(7);
+  for (auto& v : h) {  // ~N(0,1) by summing uniforms: full-mantissa random bf16 like activations / weights
+    float s = 0;
+    for (int k = 0; k < 12; ++k) s += rand() / (float)RAND_MAX;
+    v = bf16_of(s - 6.0f);
+  }
+  u4* src;
+  float* out;
+  hipMalloc(&src, 4096 * 16);
+  hipMalloc(&out, cus * 256 * 4);
+  hipMemcpy(src, h.data(), 4096 * 16, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int iters = 60000;  // x 64 MFMA-equivalents of 32 cycles = 123 M cycles ~ 60-80 ms
+  const double flop = (double)cus * 4 * iters * 4.0 * 16 * 32768.0;
+  for (int rep = 0; rep < 2; ++rep) {
+    for (int v = 0; v < 4; ++v) {
+      hipEventRecord(e0);
+      if (v == 0) hipLaunchKernelGGL(k32<false>, dim3(cus), dim3(256), 0, 0, src, out, iters);
+      if (v == 1) hipLaunchKernelGGL(k16<false>, dim3(cus), dim3(256), 0, 0, src, out, iters);
+      if (v == 2) hipLaunchKernelGGL(k32<true>, dim3(cus), dim3(256), 0, 0, src, out, iters);
+      if (v == 3) hipLaunchKernelGGL(k16<true>, dim3(cus), dim3(256), 0, 0, src, out, iters);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      const char* names[4] = {"32x32x16 registers only", "16x16x32 registers only", "32x32x16 + LDS fragment reads", "16x16x32 + LDS fragment reads"};
+      printf("%-32s %8.2f ms  %7.1f TFLOP/s  (implied clock %.3f GHz at one MFMA pipe pass per cycle)\n", names[v], ms, flop / ms / 1e9,
+             (double)iters * 64 * 32 / (ms * 1e-3) / 1e9);
+    }
+  }
+  return 0;
+}

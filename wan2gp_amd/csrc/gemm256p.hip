@@ -70,6 +70,15 @@ __device__ __forceinline__ g256p_u4 g256p_rsrc(const char* base, uint32_t num_re
 }
 __device__ __forceinline__ int p_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+#ifdef G256P_TIMING
+__device__ uint64_t g256p_stamps[16];  // tuning aid: s_memtime stamps of workgroup 40's third tile (tools/gemm_stamp.py --persistent)
+#define P_STAMP(I) do { if (blockIdx.x == 40 && it == 2 && threadIdx.x == 0) g256p_stamps[I] = __builtin_amdgcn_s_memtime(); } while (0)
+#define P_STAMP_NEXT(I) do { if (blockIdx.x == 40 && it == 3 && threadIdx.x == 0) g256p_stamps[I] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define P_STAMP(I)
+#define P_STAMP_NEXT(I)
+#endif
+
 struct TileXY {
   int ty, tx;
 };
@@ -260,6 +269,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
       P_SB();                                                                                                   \
     }                                                                                                           \
     x_advance();                                                                                                \
+    if (!first_done) { P_STAMP_NEXT(5); P_STAMP(1); first_done = true; }                                       \
     --left;                                                                                                     \
     gm = (J) == 4 ? 0 : (J) + 1;                                                                                \
   }
@@ -269,8 +279,10 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
   // epilogue geometry: lane (l31, half) owns columns 4 l31 .. 4 l31 + 3 of the wave's 128, and of the 32-row block yt the rows
   // 8 (r >> 2) + (r & 3) + 4 half
   for (;;) {
+    P_STAMP(0);
     zero_acc();
     int left = nk;
+    bool first_done = false;
     do {
       P_STEP(0)
       P_STEP(1)
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
     // issues exactly 64 stores per tile (what the vmcnt(63) of the next stage counts on).  Everything lane-dependent is derived
     // from an opaque lane id INSIDE this block: derived from threadIdx it is loop-invariant, hoisted in front of the tile loop
     // and kept in VGPRs across the MFMA loop (measured on the ISA: reloads from scratch in every stage).
+    P_STAMP(2);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMAs -> accumulator reads
     {
       uint32_t lane_e;
@@ -336,6 +349,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
         return __builtin_bit_cast(g256p_u2, __builtin_amdgcn_raw_buffer_load_b64(
                    rdesc, (int)(lane_off + (uint32_t)(yt * 32 + 8 * (r >> 2) + (r & 3)) * ldo2), 0, 0));
       };
+      P_STAMP(3);
       g256p_u2 rq[4] = {}, rn[4] = {};
       if (EPI == WAN_EPI_GATE_RES) {
 #pragma unroll
@@ -385,6 +399,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const bf16_t* __restrict_
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    P_STAMP(4);
     if (!has_next) break;
     after_epi = true;  // every wave issued exactly 64 stores (range-checked, never skipped)
     cur = nxt;
@@ -434,6 +449,13 @@ int wan_gemm256p_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
   WAN_LAUNCH_CHECK();
   return 0;
 }
+
+#ifdef G256P_TIMING
+extern "C" int wan_gemm256p_stamps(uint64_t* out16) {
+  WAN_CHECK_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g256p_stamps), sizeof(uint64_t) * 16));
+  return 0;
+}
+#endif
 
 #define G256P_INST(EPI)                                                                                                    \
   template int wan_gemm256p_try<EPI>(const bf16_t*, int64_t, int64_t, const bf16_t*, int64_t, int64_t, int, bf16_t*, int64_t, \

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
       float v[16];
       const float brow = (BIAS_ROWS && bias != nullptr) ? bf2f(bias[yr]) : 0.f;
       const float srow = (BIAS_ROWS && SCALE_VEC) ? rbf(scale_w[yr]) : 1.f;
+      asm volatile("" : "+a"(acc[yt][xt]));  // the tile stays in the accumulator file up to HERE (its copy-out cannot be hoisted above)
       const f32x16 av = acc[yt][xt];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -258,6 +259,9 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
       uint4* dst = reinterpret_cast<uint4*>(park + (yt * 32 + l31) * EROW + (xt * 32 + half * 16) * 2);
       dst[0] = pack8(v);
       dst[1] = pack8(v + 8);
+      // one accumulator tile at a time: left free, the scheduler hoists the next tiles' accumulator reads over this tile's GELU and,
+      // in the GELU + per-row-scale instantiation (32 live scale / bias values), ran out of registers (68 B of scratch per lane)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -234,7 +234,7 @@ class family_handler():
         """wan_handler.set_cache_parameters (:172-214; called from wgp.py:7079 when step skipping is switched on): hands the
         per-model calibration data to the cache object -- MagCache magnitude ratios (+ threshold 0, K 2) or the TeaCache rescale
         polynomial, picked by model class and, for the Wan2.1 i2v model, by resolution.  The tables are the reference's literals
-        (wan2gp_amd/data/skip_cache_tables.json, extracted by oracle/extract_cache_tables.py)."""
+        (wan2gp_amd/data/skip_cache_tables.json, extracted by tools/extract_cache_tables.py)."""
         import json
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "skip_cache_tables.json")) as f:
             tables = json.load(f)
