@@ -184,9 +184,10 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the VAE decode / end-to-end block")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
-    ap.add_argument("--simulate-world", default="", help="comma-separated world sizes (e.g. 2,4,8): after the timed region, run ONE "
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (i2v 14B, scaled-fp8 weights, VAE encode + decode)")
+    ap.add_argument("--simulate-world", default="2,4,8", help="comma-separated world sizes (e.g. 2,4,8): after the timed region, run ONE "
                     "rank's shard of a sequence-parallel world of that size on this GPU, the K / V^T all-gathers replaced by "
-                    "device-to-device copies of the bytes that rank would receive -> compute-side upper bound of the scaling curve")
+                    "device-to-device copies of the bytes that rank would receive -> compute-side upper bound of the scaling curve; '' = skip")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -204,6 +205,11 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if torch.cuda.device_count() < world and world > 1:
         sys.exit(f"bench.py: {world} ranks need {world} GPUs on this node, found {torch.cuda.device_count()}")
+    _cfg, (_f, _h, _w), _ = WORKLOADS[args.workload]
+    _L = _f * (_h // 2) * (_w // 2)
+    if _L % world:
+        sys.exit(f"bench.py: the {_L} tokens of workload {args.workload} do not shard over {world} sequence-parallel ranks "
+                 f"(divisors: 2, 4, 8 ...)")
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
@@ -352,6 +358,24 @@ def main():
                 traffic_source = ent.get("source", "profiles/attn_pmc_traffic.json") + " -- separate rocprofv3 --pmc pass, not measured in this run"
             except Exception:
                 traffic = None
+        # the ceiling THIS box reaches in THIS state: a bare MFMA loop on random bf16, no memory traffic (csrc/probe.hip) -- the
+        # data sheet's 2.5 PFLOP/s assumes 2.4 GHz; under random data the chip settles at its power limit well below it
+        sustained = None
+        try:
+            fl = ctypes.c_double()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            L_.check(lib.wan_mfma_sustained_probe(20000, ctypes.byref(fl), L_.stream_ptr()), "probe")      # warm-up / clock settles
+            for a, b in ((0, 1), (2, 3)):
+                evs[a].record()
+                L_.check(lib.wan_mfma_sustained_probe(40000, ctypes.byref(fl), L_.stream_ptr()), "probe")
+                evs[b].record()
+            torch.cuda.synchronize()
+            ms = min(evs[0].elapsed_time(evs[1]), evs[2].elapsed_time(evs[3]))
+            sustained = {"TFLOPs": fl.value / (ms * 1e-3) / 1e12, "ms": ms,
+                         "what": "v_mfma_f32_32x32x16_bf16 back to back, one wave per SIMD on every CU, random bf16 operands in registers, no "
+                                 "memory traffic: the power-limited rate of this box (wan_mfma_sustained_probe)"}
+        except Exception as ex:            # never lose the bench line to the probe
+            sustained = {"error": str(ex)}
         declined, launched = ctypes.c_int64(), ctypes.c_int64()
         L_.check(lib.wan_prof_attention_declined(ctypes.byref(declined), ctypes.byref(launched)), "wan_prof_attention_declined")
         out = {
@@ -370,6 +394,8 @@ def main():
                          # |q~_row| max|k_h| <= 96 and ran the tracking loop instead of the bounded one (read after the timed region)
                          "declined_workgroups": declined.value, "total_workgroups": launched.value,
                          "declined_frac": declined.value / launched.value if launched.value else None,
+                         "sustained_mfma": sustained,
+                         "frac_of_sustained_mfma": (achieved / sustained["TFLOPs"]) if sustained and sustained.get("TFLOPs") else None,
                          "other_kernels": kern},
             "step_TFLOPs": 2 * forward_flops(cfg, L) / (dt / args.steps) / 1e12,
             "forwards_per_s": 2 * args.steps / dt,          # a CFG step is two forwards (SURVEY.md section 8d reports both)
@@ -377,21 +403,100 @@ def main():
         lib.wan_prof_enable(0)
         if e2e is not None:
             out["e2e"] = e2e
-        if world == 1 and args.simulate_world:
+        cpu_thread, cpu_box = None, {}
+        if not args.no_cpu_baseline and world == 1:
+            # on the host cores WHILE the GPU runs the remaining blocks (they need one launching thread): the CPU leg costs ~2 minutes
+            import threading
+            log("cpu_baseline: config-1 oracle step + VAE decode on the host cores (in the background)")
+            fl_main = 2 * forward_flops(cfg, L)
+
+            def _cpu():
+                try:
+                    cpu_box["r"] = cpu_baseline(fl_main)
+                except Exception as ex:
+                    cpu_box["r"] = {"error": repr(ex)}
+            cpu_thread = threading.Thread(target=_cpu, daemon=True)
+            cpu_thread.start()
+        if world == 1 and args.simulate_world and args.workload in ("14B-720p", "i2v-14B-720p"):
             log("simulated sequence-parallel ranks: " + args.simulate_world)
             out["simulated_scaling"] = simulate_world([int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
                                                       latents, args.warmup, dt / args.steps, cfg, L)
         if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
             log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
             out["secondary"] = secondary_1p3b(vae)
-        if not args.no_cpu_baseline and world == 1:
-            log("cpu_baseline: config-1 oracle step on the host cores")
-            out["cpu_baseline"] = cpu_baseline(2 * forward_flops(cfg, L))
+        if world == 1 and not args.no_config5 and args.workload == "14B-720p" and not args.fp8:
+            log("config5: i2v 14B, scaled-fp8 weights, VAE encode + 3 steps + decode")
+            model = model2 = None                       # the bf16 experts of the main workload are done
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["config5"] = config5_block(vae)
+        if cpu_thread is not None:
+            cpu_thread.join()
+            out["cpu_baseline"] = cpu_box.get("r")
         log("done")
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def config5_block(vae):
+    """BASELINE configs[4] on one GPU: Wan2.2 i2v 14B 720x1280x81f with a scaled-fp8 checkpoint (block Linears on the fp8 MFMA,
+    shared/qtypes/scaled_fp8.py), both experts resident; the conditioning clip goes through the VAE encoder, the result through
+    the decoder.  1 warm-up + 2 timed CFG steps; the 30-step video is composed from them like the main block's."""
+    import torch
+    from wan2gp_amd.model import WanModelHIP
+    from wan2gp_amd.rope import get_rotary_pos_embed
+    from wan2gp_amd.schedulers import HipScheduler, cfg_combine
+    cfg, (f, h, w), desc = WORKLOADS["i2v-14B-720p"]
+    m1 = random_weights(WanModelHIP(**cfg), cfg, 1234, True)
+    m2 = random_weights(WanModelHIP(**cfg), cfg, 4321, True)
+    if vae is None:
+        from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
+        vae = WanVAEHIP(state_dict=random_vae_state_dict())
+    g = torch.Generator(device="cuda").manual_seed(43)
+    ctx = (torch.randn(1, 512, 4096, device="cuda", generator=g) * 0.5).to(torch.bfloat16); ctx[:, 77:] = 0
+    ctx_null = (torch.randn(1, 512, 4096, device="cuda", generator=g) * 0.5).to(torch.bfloat16); ctx_null[:, 8:] = 0
+    freqs = get_rotary_pos_embed((f, h, w), device="cuda")
+    sched = HipScheduler("unipc", num_train_timesteps=1000)
+    sched.set_timesteps(VIDEO_STEPS, device="cuda", shift=12.0)
+    torch.cuda.synchronize()
+    te = time.perf_counter()
+    img = torch.rand(3, 1, h * 8, w * 8, device="cuda", generator=g) * 2 - 1
+    clip = torch.cat([img, torch.zeros(3, (f - 1) * 4, h * 8, w * 8, device="cuda")], dim=1)
+    lat_y = vae.encode([clip])[0]
+    msk = torch.zeros(4, f, h, w, device="cuda"); msk[:, 0] = 1
+    y = torch.cat([msk, lat_y])
+    del clip
+    torch.cuda.synchronize()
+    enc_s = time.perf_counter() - te
+    lat = torch.randn(1, 16, f, h, w, device="cuda", generator=g)
+
+    def step(i, lat):
+        t = sched.timesteps[i]
+        trans = m2 if int(t) <= 875 else m1
+        cond, uncond = trans([lat, lat], t=torch.stack([t]), context=[ctx, ctx_null], freqs=freqs, y=y)
+        return sched.step(cfg_combine(cond, uncond, 4.0 if trans is m1 else 3.0), t, lat)[0]
+    lat = step(0, lat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = 2
+    for i in range(1, 1 + k):
+        lat = step(i, lat)
+    torch.cuda.synchronize()
+    step_s = (time.perf_counter() - t0) / k
+    assert torch.isfinite(lat).all()
+    td = time.perf_counter()
+    video = vae.decode_to_cpu_uint8([lat[0]], 0)[0]
+    torch.cuda.synchronize()
+    dec_s = time.perf_counter() - td
+    assert video.dtype == torch.uint8 and tuple(video.shape) == (3, (f - 1) * 4 + 1, h * 8, w * 8)
+    L = f * (h // 2) * (w // 2)
+    return {"workload": desc, "dtype": "fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere",
+            "metric": "denoise-steps/s", "value": 1.0 / step_s, "ms_per_step": step_s * 1e3, "steps": k, "warmup": 1,
+            "step_TFLOPs": 2 * forward_flops(cfg, L) / step_s / 1e12, "vae_encode_s": enc_s, "vae_decode_to_host_s": dec_s,
+            "composed_s_at_%d_steps" % VIDEO_STEPS: VIDEO_STEPS * step_s + enc_s + dec_s}
 
 
 def simulate_world(worlds, model, model2, one_step, latents, first_step, step_s_1gpu, cfg, L):

@@ -517,6 +517,11 @@ int wan_prof_collect(int cls, double* total_ms, int* count);
  * wan_attention_count_declined: the same count for one wan_attention_bounded launch given its scratch (acc: device uint64[2],
  * added to on `stream`). */
 int wan_prof_attention_declined(int64_t* declined, int64_t* total);
+/* What the matrix pipe sustains on this device right now: enqueues iters x 64 back-to-back v_mfma_f32_32x32x16_bf16 per wave, one
+ * wave per SIMD on every CU, random bf16 operands in registers, no memory traffic (iters = 40,000 is ~50 ms).  *flop_out = the FLOP
+ * of the launch; the caller times it (events on `stream`).  On MI355X the answer is the power limit, not the 2.5 PFLOP/s of the
+ * data sheet: 1.7-1.8 PFLOP/s on random data (csrc/probe.hip). */
+int wan_mfma_sustained_probe(int iters, double* flop_out, void* stream);
 int wan_attention_count_declined(const float* scratch, int B, int Bk, int64_t Lq, int H, uint64_t* acc, void* stream);
 
 #ifdef __cplusplus

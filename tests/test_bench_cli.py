@@ -51,3 +51,31 @@ def test_workload_flops_match_the_survey_table():
     assert L == 75600 and abs(bench.forward_flops(cfg, L) / 6.52e15 - 1) < 5e-3          # SURVEY.md section 8 shape table
     cfg, (f, h, w), _ = bench.WORKLOADS["1.3B-480p"]
     assert abs(bench.forward_flops(cfg, f * (h // 2) * (w // 2)) / 2.83e14 - 1) < 5e-3
+
+
+def test_more_ranks_than_gpus_is_an_error_before_any_collective(monkeypatch):
+    """torch.distributed.run started N ranks on a node with fewer GPUs: every rank exits with a message instead of hanging in
+    init_process_group / sharing a device."""
+    bench = _bench()
+    import torch
+    monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("RANK", "1"); monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: pytest.fail("must stop before touching a device"))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "4 ranks need 4 GPUs" in str(e.value.code)
+
+
+def test_token_count_that_does_not_shard_is_an_error_before_the_weights_are_built(monkeypatch):
+    """L = 75,600 tokens shard over 2 / 4 / 8 ranks; a world size that does not divide them (16: 4,725 -- fine; 32: not) stops with
+    a message that names the numbers, not with a ValueError inside the first forward of one rank while the others wait."""
+    bench = _bench()
+    import torch
+    monkeypatch.setenv("WORLD_SIZE", "32"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "32"])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 32)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: pytest.fail("must stop before touching a device"))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "75600" in str(e.value.code) and "32" in str(e.value.code)

@@ -276,6 +276,33 @@ def test_sequence_parallel_call_order(mock):
     assert all(cl[2][7] == 1 for cl in hd)                               # token-major output for the gather
 
 
+def test_sequence_parallel_failing_gather_hook_stops_the_forward_with_an_error(mock):
+    """Failure modes of the collective hooks (RCCL error, a Python exception inside the torch.distributed callback -> non-zero
+    return): the forward stops at that block with rc 3 and a message that names the gather; nothing after it is enqueued, and a
+    later forward on the same context works again (no state is left behind)."""
+    m = Model(mock)
+    c, (F, H, W) = m.cfg, (2, 8, 8)
+    L_ = F * 16
+    for fail_at, what in ((("begin", 0, 1), b"K all-gather"), (("begin", 1, 0), b"V^T all-gather"), (("wait", 0, 0), b"all-gather")):
+        seen = {"begin": [0, 0], "wait": [0, 0]}
+
+        def begin(user, which, send, recv, nbytes, stream):
+            seen["begin"][which] += 1
+            return 1 if fail_at[0] == "begin" and fail_at[1] == which and seen["begin"][which] - 1 == fail_at[2] else 0
+
+        def wait(user, which, stream):
+            seen["wait"][which] += 1
+            return 1 if fail_at[0] == "wait" and fail_at[1] == which and seen["wait"][which] - 1 == fail_at[2] else 0
+        cb, cw = GATHER_FN(begin), GATHER_WAIT_FN(wait)
+        rc, calls, _ = m.forward(S=2, sp=SpInfo(0, 2, 0, L_ // 2, cb, cw, None))
+        assert rc == 3 and what in mock.wan_last_error(), (rc, mock.wan_last_error())
+        names = [cl[0] for cl in calls]
+        assert "head" not in names and names.count("attention_sp_remote") == (1 if fail_at == ("begin", 0, 1) else 0)
+    cb, cw = GATHER_FN(lambda *a: 0), GATHER_WAIT_FN(lambda *a: 0)
+    rc, calls, _ = m.forward(S=2, sp=SpInfo(0, 2, 0, L_ // 2, cb, cw, None))
+    assert rc == 0 and [cl[0] for cl in calls].count("attention_sp_remote") == c.num_layers
+
+
 def test_fp8_checkpoint_quantises_once_per_shared_input(mock):
     """q / k / v share one activation quantisation per stream (the reference quantises per tensor = per stream), the Linears go
     through the fp8 GEMM with their scales."""

@@ -127,6 +127,29 @@ def test_layernorm_family(ops, d):
     assert_bf16_close(xx, x + y, what="plain residual")
 
 
+@pytest.mark.parametrize("d", [1536, 5120])
+def test_ln_modulate_table_form_is_bit_identical_to_the_per_row_form(ops, d):
+    """wan_ln_modulate derives the two modulation vectors once per batch (mod_table_kernel + layernorm_kernel<3>) when a batch has
+    >= 64 rows, and per row (layernorm_kernel<0>) below that: the same bf16 operations, so the same bits.  37 rows per batch take
+    the per-row form, the same rows followed by 91 more take the table form; also against the oracle, with per-frame batches."""
+    g = torch.Generator().manual_seed(d + 9)
+    B, Ls, Lb = 3, 37, 128
+    xb = (torch.randn(B, Lb, d, generator=g) * 2 + 0.3).to(BF)
+    mod = (torch.randn(1, 6, d, generator=g) / d ** 0.5).to(BF)
+    e0 = (0.5 * torch.randn(B, 6, d, generator=g)).to(BF)
+    for sh, sc in ((0, 1), (3, 4)):
+        small = ops.ln_modulate(cu(xb[:, :Ls].contiguous()), cu(mod), cu(e0), sh, sc)
+        big = ops.ln_modulate(cu(xb), cu(mod), cu(e0), sh, sc)
+        assert torch.equal(small.cpu(), big.cpu()[:, :Ls]), f"table form differs from the per-row form ({sh},{sc})"
+        ref, mag = [], []
+        for bi in range(B):
+            e = (mod + e0[bi:bi + 1]).chunk(6, dim=1)
+            y = O.layer_norm(xb[bi:bi + 1], 1e-6)
+            ref.append(y * (1 + e[sc]) + e[sh])
+            mag.append((y * (1 + e[sc])).float().abs() + e[sh].float().abs())       # the two terms cancel in places: ulps of the terms
+        assert_bf16_close(big, torch.cat(ref), what=f"ln_modulate table form {sh},{sc}", floor=torch.cat(mag))
+
+
 def test_layernorm_golden(ops):
     gold = dict(np.load(os.path.join(G, "ops.npz")))
     x, w, b3, v = _ops_inputs()

@@ -193,6 +193,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
             const float sh = rbf(msh[j] + esh[j]);                // e[shift]
             y[j] = rbf(ln * sc) + sh;                             // x *= 1+scale ; x += shift
           }
+        } else if (MODE == 3) {
+          // LN + modulate against a PRECOMPUTED table [batch][2][d] (mod_table_kernel below): row 0 = rbf(1 + rbf(mod + e)[scale]),
+          // row 1 = rbf((mod + e)[shift]) -- the two vectors MODE 0 re-derives for every token row (13 of its 30 VALU operations per
+          // element); the same bf16 values, so the output is bit-identical
+          const bf16_t* tb = p1 + b * (int64_t)2 * d;
+          float sc[8], sh[8];
+          unpack8(*reinterpret_cast<const uint4*>(tb + c * 8), sc);
+          unpack8(*reinterpret_cast<const uint4*>(tb + d + c * 8), sh);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float ln = rbf((v[j] - mean) * rstd);           // F.layer_norm -> bf16
+            y[j] = rbf(ln * sc[j]) + sh[j];                       // x *= 1+scale ; x += shift
+          }
         } else {
           // head: modulation fp32 [2,d] + e bf16 [B,d] -> fp32; x bf16 updated in place twice
           const float* hm = reinterpret_cast<const float*>(p0);
@@ -494,6 +507,44 @@ extern "C" int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16*
   return 0;
 }
 
+// table[b][0][c] = rbf(1 + rbf(mod[scale][c] + e[b][scale][c])), table[b][1][c] = rbf(mod[shift][c] + e[b][shift][c]): the bf16
+// operations of model.py:632-638 on the [6, d] modulation vectors, once per (layer, batch) instead of once per token row
+__global__ __launch_bounds__(256) void mod_table_kernel(const bf16_t* __restrict__ mod, const bf16_t* __restrict__ e, bf16_t* __restrict__ tab,
+                                                        int n_mod, int shift_idx, int scale_idx, int d, int nb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // 8-element chunk
+  const int nchunk = d >> 3;
+  if (i >= nb * nchunk) return;
+  const int b = i / nchunk, c = i - b * nchunk;
+  float msh[8], msc[8], esh[8], esc[8], sc[8], sh[8];
+  unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)shift_idx * d + c * 8), msh);
+  unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)scale_idx * d + c * 8), msc);
+  const bf16_t* eb = e + (int64_t)b * n_mod * d;
+  unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)shift_idx * d + c * 8), esh);
+  unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)scale_idx * d + c * 8), esc);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = rbf(1.0f + rbf(msc[j] + esc[j]));
+    sh[j] = rbf(msh[j] + esh[j]);
+  }
+  *reinterpret_cast<uint4*>(tab + (int64_t)b * 2 * d + c * 8) = pack8(sc);
+  *reinterpret_cast<uint4*>(tab + (int64_t)b * 2 * d + d + c * 8) = pack8(sh);
+}
+// Library-owned scratch for those tables: a ring of 16 slots x 1 MiB (21 frames x 2 streams x 2 x 5120 x 2 B = 860 KB is the largest
+// Wan case: per-frame timesteps at 14B); a call whose table does not fit keeps the per-row form.  Calls of one forward are serialised
+// on one stream and each table is dead when its LN kernel has run, 16 calls earlier at the latest.
+constexpr size_t MODTAB_SLOT = (size_t)1 << 20, MODTAB_NSLOT = 16;
+static bf16_t* modtab_slot(size_t need_bytes) {
+  static char* ring = nullptr;
+  static unsigned next = 0;
+  if (need_bytes > MODTAB_SLOT) return nullptr;
+  if (ring == nullptr && hipMalloc((void**)&ring, MODTAB_SLOT * MODTAB_NSLOT) != hipSuccess) {
+    ring = nullptr;
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return reinterpret_cast<bf16_t*>(ring + (size_t)(next++ % MODTAB_NSLOT) * MODTAB_SLOT);
+}
+
 extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod,
                                int shift_idx, int scale_idx, int64_t rows, int64_t rows_per_batch, int d, float eps,
                                void* stream) {
@@ -504,6 +555,19 @@ extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16*
               "wan_ln_modulate: rows / rows_per_batch must fit 31 bits");
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
+  const int64_t nb = (rows + rows_per_batch - 1) / rows_per_batch;
+  // many rows per batch: derive the two modulation vectors once per batch (a ~2 us kernel) and let the row kernel read them
+  bf16_t* tab = (rows >= 64 * nb) ? modtab_slot((size_t)nb * 2 * d * 2) : nullptr;
+  if (tab != nullptr) {
+    const int chunks = (int)nb * (d >> 3);
+    hipLaunchKernelGGL(mod_table_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, as_stream(stream), mod, e, tab, n_mod, shift_idx,
+                       scale_idx, d, (int)nb);
+    WAN_LAUNCH_CHECK();
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 3>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
+                                         dim3(256), 0, as_stream(stream), x, out, (const void*)nullptr, (const bf16_t*)tab, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps));
+    WAN_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 0>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
                                        dim3(256), 0, as_stream(stream), x, out, (const void*)mod, e, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps));
   WAN_LAUNCH_CHECK();

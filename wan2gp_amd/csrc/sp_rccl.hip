@@ -75,6 +75,8 @@ struct wan_sp {
   bool pending[kSlots] = {};
 };
 
+extern "C" void wan_sp_destroy(wan_sp* s);
+
 // 128 bytes identifying a new communicator: rank 0 creates it, the host runtime hands it to every rank (any broadcast will do)
 extern "C" int wan_sp_unique_id(void* id128) {
   WAN_REQUIRE(id128 != nullptr, "wan_sp_unique_id: null pointer");
@@ -105,6 +107,7 @@ extern "C" int wan_sp_init(wan_sp** out, int rank, int nranks, const void* id128
   for (int i = 0; i < kSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming);
   if (e != hipSuccess) {
     wan_set_error("wan_sp_init: stream / event creation failed: %s", hipGetErrorString(e));
+    wan_sp_destroy(s);  // the communicator and whatever was created: a failed init leaves nothing behind
     return 2;
   }
   *out = s;

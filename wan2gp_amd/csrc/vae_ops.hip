@@ -44,9 +44,29 @@ struct ConvP {
   int tiles_y, tiles_x;
 };
 
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: the weight rows of a tile sit at fixed
+// offsets from a base that advances by one k-tile per stage -- no per-lane pointer arithmetic in the K loop
+// (LDS destinations as 32-bit LDS addresses: a generic pointer costs a null-check select per cast, four scalar instructions per piece)
+__device__ __forceinline__ void glds16s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void glds16a(const void* gsrc, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory");
+}
+
+constexpr int CONV_UMAX = 27 * 32;  // K units of the largest layer served: 3x3x3 taps x 1024 input channels (Wan2.2 VAE)
+
 template <bool BIG, bool UPS>  // BIG: input chunks of 2^31 elements and more (64-bit gather offsets); UPS: 2x upsampled input
 __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * CSTAGE];
+  // Gather plan of the K loop, built once per workgroup (round 3; the K-step used to decode its two units with ~140 scalar
+  // instructions -- divisions by the channel-block / tap counts -- and re-derive every slot's three range checks: 146 VALU +
+  // 139 SALU beside 32 MFMAs, i.e. issue-bound at a quarter of the matrix rate):
+  //   utab[u]   unit u = tap * CB + channel block: {element offset of the tap + block (lo, hi), tap | kt << 8 | valid << 16 |
+  //             kh << 20 | kw << 24, 32 * block}; a thread reads ITS unit of a K-step with one ds_read_b128, a step ahead;
+  //   vmask[i]  per gather slot: bit tap = "the tap's input pixel exists" (spatial zero padding, causal front), bit 27 + kt =
+  //             "frame t + kt lies in the 2-frame cache" -- the K loop tests bits instead of comparing coordinates.
+  __shared__ __attribute__((aligned(16))) uint4 utab[CONV_UMAX + 2];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,11 +83,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
   const int64_t frame_in = (int64_t)p.Hin * p.Win * p.Cin;
   const int Heff = UPS ? p.Hin * 2 : p.Hin, Weff = UPS ? p.Win * 2 : p.Win;
   const int Kp = p.nk * 64;
+  using off_t = typename std::conditional<BIG, int64_t, int>::type;
+  const off_t fin = (off_t)frame_in;
+
+  for (int u = tid; u < 2 * p.nk; u += 256) {  // (the last K-step of an odd unit count has one invalid unit)
+    const bool uok = u < p.U;
+    const int uu = uok ? u : 0;
+    const int tap = uu / p.CB, cb = uu - tap * p.CB;
+    const int kw = tap % p.KW, t2 = tap / p.KW;
+    const int kh = t2 % p.KH, kt = t2 / p.KH;
+    const int64_t toff = (int64_t)kt * frame_in + ((int64_t)kh * p.Win + kw) * p.Cin + cb * 32;
+    uint4 e;
+    e.x = (uint32_t)toff;
+    e.y = (uint32_t)((uint64_t)toff >> 32);
+    e.z = (uint32_t)tap | ((uint32_t)kt << 8) | ((uok ? 1u : 0u) << 16) | ((uint32_t)kh << 20) | ((uint32_t)kw << 24);
+    e.w = (uint32_t)(cb * 32);
+    utab[u] = e;
+  }
 
   // per-slot constants: the output pixel's position in INPUT coordinates before the tap offset is added (time / row / column),
   // which of the K-step's two units the slot's chunk belongs to, and its channel offset inside the unit
   int s_to[4], s_ho[4], s_wo[4], s_usel[4], s_coff[4];
-  const uint16_t* xsrc[4];
+  uint32_t vmask[4], xoff32[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = i * 256 + tid;
@@ -88,62 +125,57 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
     const int nt = jj >> 4, ii = jj & 15;
     int xr = x0 + slab * 64 + (ii >> 2) * 16 + nt * 4 + (ii & 3);
     if (xr > p.Cout - 1) xr = p.Cout - 1;
-    xsrc[i] = p.w + (int64_t)xr * Kp + lch * 8;
+    xoff32[i] = (uint32_t)(((int64_t)xr * Kp + lch * 8) * 2);  // bytes from the k-tile's first weight (Cout x Kp x 2 B < 2^32)
+    // unsigned compares fold the two-sided range checks: 0 <= hi < Heff, 0 <= wi < Weff, -ncache <= ti < Tin
+    uint32_t m = 0;
+    for (int kt = 0; kt < p.KT; ++kt) {
+      const int ti = s_to[i] + kt;
+      const bool okt = (unsigned)(ti + p.ncache) < (unsigned)(p.Tin + p.ncache);
+      if (ti < 0) m |= 1u << (27 + kt);
+      for (int kh = 0; kh < p.KH; ++kh)
+        for (int kw = 0; kw < p.KW; ++kw)
+          if (okt && (unsigned)(s_ho[i] + kh) < (unsigned)Heff && (unsigned)(s_wo[i] + kw) < (unsigned)Weff)
+            m |= 1u << ((kt * p.KH + kh) * p.KW + kw);
+    }
+    vmask[i] = m;
   }
 
-  using off_t = typename std::conditional<BIG, int64_t, int>::type;
-  const off_t fin = (off_t)frame_in;
   off_t s_base[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) s_base[i] = (off_t)s_to[i] * fin + ((off_t)s_ho[i] * p.Win + s_wo[i]) * p.Cin + s_coff[i];
-  const bool my_unit = s_usel[0] != 0;
+  // all four slots of a thread sit in the same unit of a K-step: chunk bit 2 after the swizzle is (tid >> 2 ^ tid >> 6) & 1
+  const int my_unit = s_usel[0] != 0 ? 1 : 0;
+  // frames t >= 0 live in x, frames -2 / -1 in the layer's cache: with the cache base shifted by two frames both are
+  // base + t * frame (32-bit element offsets unless the chunk has 2^31 elements or more)
+  const uint16_t* const cbase = p.cache + 2 * frame_in;
+  const uint16_t* wbase = p.w;  // first weight of the next k-tile to fetch (wave-uniform)
+  __syncthreads();              // utab complete
+  uint4 ent = utab[my_unit];    // this thread's unit of K-step 0; the next one is read a step ahead
+  const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)wave * 1024u;
   auto stage = [&](int s, int ks) {
-    char* ybase = smem + s * 2 * CSTAGE;
-    char* xbase = ybase + CSTAGE;
-    // decode the two units of this K-step (wave-uniform scalars)
-    int ukt[2], ukh[2], ukw[2], ucb[2], uok[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int u = 2 * ks + j;
-      uok[j] = u < p.U;
-      const int uu = uok[j] ? u : 0;
-      const int tap = uu / p.CB;
-      ucb[j] = uu - tap * p.CB;
-      ukw[j] = tap % p.KW;
-      const int t2 = tap / p.KW;
-      ukh[j] = t2 % p.KH;
-      ukt[j] = t2 / p.KH;
-    }
-    // frames t >= 0 live in x, frames -2 / -1 in the layer's cache: with the cache base shifted by two frames both are
-    // base + t * frame (32-bit element offsets unless the chunk has 2^31 elements or more)
-    const uint16_t* const cbase = p.cache + 2 * frame_in;
-    // the thread's unit of this K-step (one select per quantity, not one per piece: all four slots of a thread sit in the same
-    // unit -- chunk bit 2 after the swizzle is (tid >> 2 ^ tid >> 6) & 1 for every slot)
-    const bool j = my_unit;
-    const int kt = j ? ukt[1] : ukt[0], kh = j ? ukh[1] : ukh[0], kw = j ? ukw[1] : ukw[0];
-    const bool ok_u = j ? uok[1] : uok[0];
-    const off_t tapoff = (off_t)kt * fin + ((off_t)kh * p.Win + kw) * p.Cin + (j ? ucb[1] : ucb[0]) * 32;  // !ups: offset of the tap
+    const uint32_t ybase = smem_lds + (uint32_t)(s * 2 * CSTAGE);
+    const uint32_t xbase = ybase + CSTAGE;
+    const uint4 E = ent;
+    ent = utab[2 * (ks + 1) + my_unit];  // (one entry past the last K-step is inside the array, never used)
+    const uint32_t tap = E.z & 0xffu, kt = (E.z >> 8) & 0xffu, uok = (E.z >> 16) & 1u;
+    const off_t tapoff = BIG ? (off_t)(((uint64_t)E.y << 32) | E.x) : (off_t)E.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int woff = (i * 256 + wave * 64) * 16;
-      const int ti = s_to[i] + kt;
-      int hi = s_ho[i] + kh;
-      int wi = s_wo[i] + kw;
-      // unsigned compares fold the two-sided range checks: 0 <= hi < Heff, 0 <= wi < Weff, -ncache <= ti < Tin
-      const bool ok = ok_u && (unsigned)hi < (unsigned)Heff && (unsigned)wi < (unsigned)Weff &&
-                      (unsigned)(ti + p.ncache) < (unsigned)(p.Tin + p.ncache);
+      const uint32_t woff = (uint32_t)(i * 256 * 16);
+      const bool ok = (uok & (vmask[i] >> tap) & 1u) != 0;
+      const bool in_cache = ((vmask[i] >> (27 + kt)) & 1u) != 0;
       off_t off;
       if (UPS) {  // nearest-exact 2x upsample on the fly: source pixel (hi >> 1, wi >> 1)
-        hi >>= 1; wi >>= 1;
-        off = (off_t)ti * fin + ((off_t)hi * p.Win + wi) * p.Cin + (j ? ucb[1] : ucb[0]) * 32 + s_coff[i];
-      } else {      // linear in the tap: the slot's base (its output pixel at tap 0) + the tap's uniform offset
+        const int hi = (s_ho[i] + (int)((E.z >> 20) & 0xfu)) >> 1, wi = (s_wo[i] + (int)((E.z >> 24) & 0xfu)) >> 1;
+        off = (off_t)(s_to[i] + (int)kt) * fin + ((off_t)hi * p.Win + wi) * p.Cin + (int)E.w + s_coff[i];
+      } else {      // linear in the tap: the slot's base (its output pixel at tap 0) + the unit's offset
         off = s_base[i] + tapoff;
       }
-      const uint16_t* src = (ti >= 0 ? p.x : cbase) + off;
-      glds16v(ok ? src : p.zero16, ybase + woff);
-      glds16v(xsrc[i], xbase + woff);
-      xsrc[i] += 64;  // stages are issued for consecutive K-steps: the weight rows advance by one 64-wide k-tile
+      const uint16_t* src = (in_cache ? cbase : p.x) + off;
+      glds16a(ok ? src : p.zero16, ybase + woff);
+      glds16s(xoff32[i], wbase, xbase + woff);
     }
+    wbase += 64;  // stages are issued for consecutive K-steps: the weight rows advance by one 64-wide k-tile
   };
 
   f32x4 acc[4][4];

@@ -144,6 +144,7 @@ SIGNATURES = {
     "wan_prof_enable": (c_int, [c_int]),
     "wan_prof_collect": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "wan_prof_attention_declined": (c_int, [POINTER(c_int64), POINTER(c_int64)]),
+    "wan_mfma_sustained_probe": (c_int, [c_int, POINTER(c_double), c_void_p]),
     "wan_attention_count_declined": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "wan_dit_create": (c_int, [POINTER(DitConfig), POINTER(c_void_p)]),
     "wan_dit_destroy": (None, [c_void_p]),
