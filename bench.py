@@ -370,8 +370,8 @@ def main():
                 L_.check(lib.wan_mfma_sustained_probe(40000, ctypes.byref(fl), L_.stream_ptr()), "probe")
                 evs[b].record()
             torch.cuda.synchronize()
-            ms = min(evs[0].elapsed_time(evs[1]), evs[2].elapsed_time(evs[3]))
-            sustained = {"TFLOPs": fl.value / (ms * 1e-3) / 1e12, "ms": ms,
+            probe_ms = min(evs[0].elapsed_time(evs[1]), evs[2].elapsed_time(evs[3]))
+            sustained = {"TFLOPs": fl.value / (probe_ms * 1e-3) / 1e12, "ms": probe_ms,
                          "what": "v_mfma_f32_32x32x16_bf16 back to back, one wave per SIMD on every CU, random bf16 operands in registers, no "
                                  "memory traffic: the power-limited rate of this box (wan_mfma_sustained_probe)"}
         except Exception as ex:            # never lose the bench line to the probe
@@ -403,9 +403,13 @@ def main():
         lib.wan_prof_enable(0)
         if e2e is not None:
             out["e2e"] = e2e
+        if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
+            log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
+            out["secondary"] = secondary_1p3b(vae)
         cpu_thread, cpu_box = None, {}
         if not args.no_cpu_baseline and world == 1:
-            # on the host cores WHILE the GPU runs the remaining blocks (they need one launching thread): the CPU leg costs ~2 minutes
+            # on the host cores WHILE the GPU runs the remaining blocks -- long kernels, one launching thread; the launch-dense
+            # 1.3B secondary run above is done by now (busy cores cost it 5-8 %): the CPU leg costs ~2 minutes
             import threading
             log("cpu_baseline: config-1 oracle step + VAE decode on the host cores (in the background)")
             fl_main = 2 * forward_flops(cfg, L)
@@ -421,9 +425,6 @@ def main():
             log("simulated sequence-parallel ranks: " + args.simulate_world)
             out["simulated_scaling"] = simulate_world([int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
                                                       latents, args.warmup, dt / args.steps, cfg, L)
-        if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
-            log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
-            out["secondary"] = secondary_1p3b(vae)
         if world == 1 and not args.no_config5 and args.workload == "14B-720p" and not args.fp8:
             log("config5: i2v 14B, scaled-fp8 weights, VAE encode + 3 steps + decode")
             model = model2 = None                       # the bf16 experts of the main workload are done
