@@ -140,6 +140,25 @@ def test_attention_bounded_tile_scalar_and_wait_instructions(tmp_path_factory):
         assert "ds_read_b128" not in ops[mf[49]:], "an LDS read in the last 15 MFMA gaps of the tile"
 
 
+def test_gemm256m_registers_and_stage_instruction_mix(tmp_path_factory):
+    """gemm256m.hip (the product GEMM since round 3, 16x16x32 MFMA): no scratch, 256 accumulators in the accumulator file, the
+    whole LDS, and between two barriers of the main loop exactly one stage: 128 MFMAs, 32 ds_read_b128, 16 LDS-DMA pieces and
+    NO vector-ALU instruction (a 16-cycle MFMA gap hides two issue slots; an address computation there is a stall)."""
+    ks = kernels(asm_of("gemm256m", tmp_path_factory), "gemm256m_kernel")
+    assert len(ks) == 3                                              # NONE / GELU / GATE_RES
+    for name, (ops, meta) in ks.items():
+        assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256 and meta["LDSByteSize"] == 160 * 1024, (name, meta)
+        bars = [i for i, o in enumerate(ops) if o == "s_barrier"]
+        stages = [collections.Counter(ops[a:b]) for a, b in zip(bars, bars[1:])]
+        stages = [c for c in stages if c["v_mfma_f32_16x16x32_bf16"] == 128]
+        assert len(stages) >= 4, name                                # the loop is unrolled by 5: four barrier-to-barrier spans inside it
+        for c in stages:
+            assert c["ds_read_b128"] == 32 and c["buffer_load_dwordx4"] == 16, c
+            valu = sum(v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma"))
+            assert valu == 0, c
+            assert c["s_waitcnt"] <= 20, c
+
+
 def test_no_kernel_of_the_library_spills_to_scratch(tmp_path_factory):
     """Every kernel of every translation unit: ScratchSize 0 (a spill inside a tile loop is a performance cliff, and the hot kernels
     run at the edge of the 512-register file).  No exceptions: round 2's one (the scaled-fp8 GEMM with GELU and a per-row weight
@@ -164,3 +183,4 @@ def test_no_kernel_of_the_library_spills_to_scratch(tmp_path_factory):
                 offenders.append((unit, m.group(1), int(meta.group(1))))
     assert seen >= 100 and not offenders, offenders
     assert "gemm256p" in asms and asms["gemm256p"].count("gemm256p_kernel") >= 3      # the persistent GEMM's three epilogues are in the sweep
+    assert "gemm256m" in asms and asms["gemm256m"].count("gemm256m_kernel") >= 3

@@ -711,3 +711,109 @@ def test_gemm256p_continuous_stream_over_tiles():
                 # P_S ... k-step 3: X of global stage g + 2 goes into Y_S's slot (dead by now)
                 issue("X", DX)
                 g += 1
+
+
+# ----------------------------------------------------------------------------------------------
+# gemm256m.hip (256x256x64 on the 16x16x32 MFMA): gemm256k's unit images, X rows staged 8-way interleaved, Y = A operand,
+# X = B operand, register-direct 16-byte stores
+# ----------------------------------------------------------------------------------------------
+def test_gemm256m_ds_read_b128_is_conflict_free():
+    """Fragment read of tile r by lane (n = lane & 15, g = lane >> 4): row 16 r + n, logical chunk 4 ks + g, physical chunk
+    ^ ((row >> 1) & 7).  The 16 lanes a ds_read_b128 services in one LDS cycle must cover 64 distinct banks."""
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for ks in range(2):
+        for r in range(8):
+            for grp in groups:
+                banks = set()
+                for lane in grp:
+                    n, g = lane & 15, lane >> 4
+                    addr = r * 2048 + ((n * 128 + ((g ^ ((n >> 1) & 7)) << 4)) ^ (ks << 6))
+                    for d in range(4):
+                        banks.add((addr // 4 + d) % 64)
+                assert len(banks) == 64
+
+
+def test_gemm256m_operand_interleave_and_register_direct_stores():
+    """End to end on one 256 x 256 tile with K = 64: DMA plan, fragment addresses, v_mfma_f32_16x16x32 semantics (A: lane (n, g)
+    holds row n, k = 8 g ..; B: column n, k = 8 g ..; D: register i of lane (n, g) = D[4 g + i][n]) and the epilogue's
+    (lane, a, i) -> (row, 8 columns) map.  Every output element exactly once, with the right operands; a store instruction
+    writes 4 rows x 256 contiguous bytes."""
+    rng = np.random.default_rng(6)
+    Yt = rng.integers(-3, 4, size=(256, 64)).astype(np.float64)
+    Xt = rng.integers(-3, 4, size=(256, 64)).astype(np.float64)
+    ylds = np.zeros((256, 8, 8)); xlds = np.zeros((256, 8, 8))
+    seen_x = set()
+    for i in range(8):
+        for tid in range(256):
+            q = i * 256 + tid
+            row, pch = q >> 3, q & 7
+            lch = pch ^ ((row >> 1) & 7)
+            ylds[row, pch] = Yt[row, lch * 8:lch * 8 + 8]
+            slab, t, n = row >> 7, (row >> 4) & 7, row & 15
+            xr = slab * 128 + 8 * n + t
+            seen_x.add(xr)
+            xlds[row, pch] = Xt[xr, lch * 8:lch * 8 + 8]
+    assert seen_x == set(range(256))
+    out = np.full((256, 256), np.nan)
+    writes = 0
+    order = list(range(1, 8)) + list(range(9, 16)) + [8, 0]        # M_ORD: read order of a k-step's 16 fragments (first-needed last)
+    assert sorted(order) == list(range(16))
+    for wave in range(4):
+        wy, wx = wave >> 1, wave & 1
+        acc = np.zeros((8, 8, 64, 4))                              # [a][t][lane][reg]
+        for ks in range(2):
+            yf = np.zeros((8, 64, 8)); xf = np.zeros((8, 64, 8))
+            for lane in range(64):
+                n, g = lane & 15, lane >> 4
+                sw = (n >> 1) & 7
+                ya = (wy * 128 + n) * 128 + ((g ^ sw) << 4)
+                xa = (wx * 128 + n) * 128 + ((g ^ sw) << 4)
+                for r in range(8):
+                    addr = r * 2048 + (ya ^ (ks << 6))
+                    yf[r, lane] = ylds[addr // 128, (addr % 128) // 16]
+                    addr = r * 2048 + (xa ^ (ks << 6))
+                    xf[r, lane] = xlds[addr // 128, (addr % 128) // 16]
+            for a in range(8):
+                for t in range(8):
+                    A = np.zeros((16, 32)); B = np.zeros((16, 32))
+                    for lane in range(64):
+                        A[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = yf[a, lane]
+                        B[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = xf[t, lane]
+                    D = A @ B.T                                    # D[i][j] = sum_k A[i][k] B[j][k]
+                    for lane in range(64):
+                        for i in range(4):
+                            acc[a, t, lane, i] += D[4 * (lane >> 4) + i, lane & 15]
+        for a in range(8):
+            for i in range(4):
+                rows_of_instr = {}
+                for lane in range(64):
+                    n, g = lane & 15, lane >> 4
+                    row = wy * 128 + 16 * a + 4 * g + i
+                    col = wx * 128 + 8 * n
+                    rows_of_instr.setdefault(row, []).append(row * 512 + col * 2)
+                    for t in range(8):
+                        assert np.isnan(out[row, col + t])
+                        out[row, col + t] = acc[a, t, lane, i]
+                        writes += 1
+                assert len(rows_of_instr) == 4                     # one store instruction = 4 rows ...
+                for row, bs in rows_of_instr.items():              # ... of 256 contiguous bytes each (16 lanes x 16 B)
+                    assert sorted(bs) == list(range(min(bs), min(bs) + 256, 16))
+    assert writes == 256 * 256
+    np.testing.assert_array_equal(out, Yt @ Xt.T)
+
+
+def test_gemm256m_stage_schedule():
+    """Issue slots of a stage: 8 Y pieces + 16 fragment reads in k-step 0, 8 X pieces + 16 reads behind the sync point of k-step 1,
+    never two in one MFMA gap, every fragment index exactly once per k-step, every read >= 16 MFMAs ahead of the k-step using it."""
+    k0_dma = [m for m in range(64) if (m & 7) == 0]
+    k0_rd = [m for m in range(64) if (m & 7) != 0 and (m & 1) == 1 and m < 32]
+    assert len(k0_dma) == 8 and len(k0_rd) == 16 and not set(k0_dma) & set(k0_rd)
+    assert [m >> 3 for m in k0_dma] == list(range(8)) and [m >> 1 for m in k0_rd] == list(range(16))
+    k1_dma = [m for m in range(16, 64) if (m - 16) % 6 == 0]
+    k1_rd = [m for m in range(16, 64) if (m - 16) % 6 != 0 and (m & 1) == 1 and m < 48]
+    assert len(k1_dma) == 8 and len(k1_rd) == 16 and not set(k1_dma) & set(k1_rd)
+    assert [(m - 16) // 6 for m in k1_dma] == list(range(8)) and [(m - 17) >> 1 for m in k1_rd] == list(range(16))
+    assert 64 - max(k0_rd) >= 16 and 64 - max(k1_rd) >= 16
+    order = [1 + i if i < 7 else 2 + i if i < 14 else 8 if i == 14 else 0 for i in range(16)]
+    assert sorted(order) == list(range(16)) and order[-2:] == [8, 0]      # x tile 0 and y tile 0 -- the first MFMA's operands -- last

@@ -121,6 +121,95 @@ __global__ __launch_bounds__(256) void k32_fp8(const u4* __restrict__ src, float
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+
+// The GEMM's operand stream under the MFMA loop: per k-tile of 64 (64 MFMAs 32x32x16, or 128 MFMAs 16x16x32, of each wave) the
+// workgroup brings 64 KB into LDS with 64 LDS-DMA pieces (buffer_load_dwordx4 ... lds, 16 per wave), 128 B per row per fetch, in
+// gemm256k's pattern: CU b works on "tile" (b / 16, b % 16) of a [8192 x KW] bf16 matrix -- Y rows (b/16)*256.., X rows 4096 + (b%16)*256..
+// SRC 0: no stream; 1: every CU streams the same 2 MB (L2-resident); 2: the GEMM pattern over the 128-MB matrix (L2 + MALL/HBM mix).
+// MODE bit 0: 16x16x32 instead of 32x32x16; bit 1: a workgroup barrier per k-tile (the GEMM's sync point); bit 2: odd waves (SIMDs 1, 3)
+// issue their fragment reads and DMA pieces half a k-step later than even waves (the vendor kernel's SIMD-parity pair of loop bodies);
+// bit 3: no MFMAs (the stream alone).  Fragments are double-buffered (read for k-step q + 1 while k-step q multiplies), as in the kernels.
+// Run under rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES: clock = GRBM_GUI_ACTIVE / 8 / time, utilisation = busy / (1024 x cycles).
+__device__ __forceinline__ void dma16(uint32_t voff, const u4& rsrc, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+template <int SRC, int MODE>
+__global__ __launch_bounds__(256) void ks(const u4* __restrict__ src, const char* __restrict__ big, float* __restrict__ out, int iters, int KW) {
+  constexpr bool MI16 = MODE & 1, BAR = MODE & 2, STAG = MODE & 4, MFMA = !(MODE & 8);
+  constexpr int NF = MI16 ? 8 : 4;                          // fragments per operand per k-step
+  constexpr int NQ = MI16 ? 2 : 4;                          // k-steps per k-tile of 64
+  constexpr int NM = NF * NF;                               // MFMAs per k-step
+  extern __shared__ __attribute__((aligned(16))) u4 lds[];  // 2 x 64 KB
+  for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = src[i & 4095];
+  __syncthreads();
+  const int lane = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool late = STAG && (wave & 1);
+  bf8 a[2][NF], b[2][NF];
+  for (int i = 0; i < NF; ++i)
+    for (int h = 0; h < 2; ++h) {
+      a[h][i] = __builtin_bit_cast(bf8, src[(lane + 256 * i + 64 * h) & 4095]);
+      b[h][i] = __builtin_bit_cast(bf8, src[(lane + 256 * (NF + i) + 64 * h) & 4095]);
+    }
+  f16v acc32[MI16 ? 1 : 4][MI16 ? 1 : 4];
+  f4v acc16[MI16 ? 8 : 1][MI16 ? 8 : 1];
+  for (auto& r : acc32) for (auto& c : r) for (int k = 0; k < 16; ++k) c[k] = 0.f;
+  for (auto& r : acc16) for (auto& c : r) for (int k = 0; k < 4; ++k) c[k] = 0.f;
+  const uint64_t bb = (uint64_t)big;
+  u4 rsrc;
+  rsrc[0] = __builtin_amdgcn_readfirstlane((uint32_t)bb);
+  rsrc[1] = __builtin_amdgcn_readfirstlane((uint32_t)(bb >> 32) & 0xffffu);
+  rsrc[2] = __builtin_amdgcn_readfirstlane(0xffffffffu);
+  rsrc[3] = __builtin_amdgcn_readfirstlane(0x00020000u);
+  const uint32_t ldsb = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds);
+  // piece p (0..15) of this wave: operand p >> 3, rows ((p & 7) * 4 + wave) * 8 + lane / 8 of its 256, 16 B at (lane & 7) * 16
+  uint32_t rowofs[16];
+  const uint32_t rowbytes = (uint32_t)KW * 2u;
+  for (int p = 0; p < 16; ++p) {
+    const uint32_t r = (((p & 7) * 4 + wave) * 8 + ((lane & 63) >> 3));
+    const uint32_t panel = (SRC == 2) ? ((p >> 3) ? 4096u + (blockIdx.x & 15) * 256u : (blockIdx.x >> 4) * 256u) : ((p >> 3) * 256u);
+    rowofs[p] = (panel + r) * ((SRC == 2) ? rowbytes : 4096u) + (lane & 7) * 16u;   // SRC 1: a 4096-B pitch: 512 rows x 4 KB = 2 MB
+  }
+  const int nk = (SRC == 2) ? KW / 64 : 32;
+  int off = lane, ks_ = 0, slot = 0;
+  auto reads = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+      a[h][i] = __builtin_bit_cast(bf8, lds[(off + 256 * i) & 4095]);
+      b[h][i] = __builtin_bit_cast(bf8, lds[(off + 256 * (NF + i) + 64) & 4095]);
+    }
+    off += 256 * 2 * NF;
+  };
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t kofs = (uint32_t)ks_ * 128u;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (MFMA && !late) reads((q + 1) & 1);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        if (MFMA && late && m == NM / 2) reads((q + 1) & 1);
+        if (MFMA) {
+          if (MI16) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc16[MI16 ? m / NF : 0][MI16 ? m % NF : 0]) : "v"(a[q & 1][m / NF]), "v"(b[q & 1][m % NF]));
+          else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc32[MI16 ? 0 : m / NF][MI16 ? 0 : m % NF]) : "v"(a[q & 1][m / NF]), "v"(b[q & 1][m % NF]));
+        }
+        constexpr int every = NM * NQ / 16;                 // MFMAs per DMA piece
+        if (SRC && (m % every) == (late ? every / 2 : 0)) {
+          const int p = (q * NM + m) / every;
+          dma16(rowofs[p] + kofs, rsrc, __builtin_amdgcn_readfirstlane(ldsb + slot * 65536 + (p * 256 + wave * 64) * 16));
+        }
+      }
+    }
+    if (SRC) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // one k-tile in flight behind the one being issued
+    if (BAR) __builtin_amdgcn_s_barrier();
+    ks_ = ks_ + 1 == nk ? 0 : ks_ + 1;
+    slot ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float sum = 0.f;
+  for (auto& r : acc32) for (auto& c : r) for (int k = 0; k < 16; ++k) sum += c[k];
+  for (auto& r : acc16) for (auto& c : r) for (int k = 0; k < 4; ++k) sum += c[k];
+  out[blockIdx.x * 256 + threadIdx.x] = sum;
+}
+
 static uint16_t bf16_of(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -175,6 +264,44 @@ int main() {
       hipEventElapsedTime(&ms, e0, e1);
       printf("%-32s %8.2f ms  %7.1f TFLOP/s  (of the 5 PFLOP/s fp8 peak: %.3f)\n", "32x32x64 fp8 registers only", ms, flop8 / ms / 1e9, flop8 / ms / 1e9 / 5000.0);
     }
+  }
+  {  // the operand stream: what it costs, and what it is alone
+    const int KW = 8192;
+    const size_t big_bytes = (size_t)8192 * KW * 2;   // 128 MB
+    char* big;
+    hipMalloc(&big, big_bytes);
+    for (size_t o = 0; o < big_bytes; o += 4096 * 16) hipMemcpy(big + o, src, 4096 * 16, hipMemcpyDeviceToDevice);
+    typedef void (*kfn)(const u4*, const char*, float*, int, int);
+    struct V { kfn f; const char* name; bool mfma; bool stream; };
+    const V vs[] = {
+        {ks<0, 0>, "A  32x32x16 + LDS reads", true, false},
+        {ks<1, 0>, "B  A + stream, 2 MB window (L2 hits)", true, true},
+        {ks<2, 0>, "C  A + stream, GEMM pattern over 128 MB", true, true},
+        {ks<2, 2>, "D  C + barrier per k-tile", true, true},
+        {ks<2, 6>, "E  D + SIMD-parity stagger", true, true},
+        {ks<2, 4>, "F  C + SIMD-parity stagger, no barrier", true, true},
+        {ks<0, 1>, "G  16x16x32 + LDS reads", true, false},
+        {ks<2, 1>, "H  G + stream, GEMM pattern", true, true},
+        {ks<2, 3>, "I  H + barrier per k-tile", true, true},
+        {ks<2, 7>, "J  I + SIMD-parity stagger", true, true},
+        {ks<1, 8>, "K  stream alone, 2 MB window", false, true},
+        {ks<2, 8>, "L  stream alone, GEMM pattern", false, true},
+    };
+    const int its = 50000;
+    const double fl = (double)cus * 4 * its * 4.0 * 16 * 32768.0, bytes = (double)cus * its * 65536.0;
+    for (const V& v : vs) hipFuncSetAttribute((const void*)v.f, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    for (int rep = 0; rep < 2; ++rep)
+      for (const V& v : vs) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(v.f, dim3(cus), dim3(256), 131072, 0, src, big, out, its, KW);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (hipGetLastError() != hipSuccess) printf("launch error\n");
+        if (v.mfma) printf("%-44s %8.2f ms  %7.1f TFLOP/s  stream %5.2f TB/s into the CUs\n", v.name, ms, fl / ms / 1e9, v.stream ? bytes / ms / 1e9 : 0.0);
+        else printf("%-44s %8.2f ms  stream %5.2f TB/s into the CUs\n", v.name, ms, bytes / ms / 1e9);
+      }
   }
   return 0;
 }
