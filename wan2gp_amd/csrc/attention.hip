@@ -116,7 +116,7 @@ extern "C" int wan_attention_bounded(const wan_bf16* q, const wan_bf16* k, const
 }
 
 extern "C" int64_t wan_attention_raw_words(int B, int64_t Lq, int H) {
-  return ((Lq + 255) / 256) * H * B * (int64_t)(4 * 2 * (64 * 64 + 64));  // per 256-row workgroup: 4 waves x 2 q-blocks x (accumulators + row sums)
+  return ((Lq + 255) / 256) * H * B * (int64_t)(4 * 2 * (64 * 64 + 128));  // per 256-row workgroup: 4 waves x 2 q halves x (accumulators + row-sum shares of two q tiles)
 }
 
 // Sequence-parallel self-attention, local segment first (q pre-scaled): see wan_attention_w64q_sp.

@@ -1,0 +1,482 @@
+// Flash attention forward for gfx950, the BOUNDED tile loop of attention_w64q.hip on the 16x16x32 MFMA ("w16n").
+// Same contract, same launch protocol (flags, workgroup flags, raw partial sums), same 4 waves x 64 q rows, same 3-deep LDS-DMA
+// ring and V^T / K images in LDS -- the matrix instruction is v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.
+//
+// Why (round 3): self-attention runs at the chip's power limit.  Counters on tools/probes/mfma_power_probe.hip:
+// the K = 32 form keeps the matrix pipe as busy at a 15 % higher clock (it reads and writes each accumulator half as often per
+// MAC); gemm256m.hip gained 9-17 % from nothing but this change of instruction.
+//
+// Layout (lane: n = lane & 15, g = lane >> 4).  A wave's 64 q rows are four 16-row q tiles; halves a = q tiles 0, 1 and b = 2, 3
+// play the roles of attention_w64q.hip's q-blocks (b runs half a tile behind a).
+//   S^T = K Q^T    A = K fragment (kv tile kt, k-step ks): lane (n, g) holds LDS row 16 kt + n, d = 32 ks + 8 g .. + 7;
+//                  B = Q fragment (q tile qt, ks): q row 16 qt + n, the same d; lane (n, g) then holds in register i of tile
+//                  (kt, qt) the score of q = 16 qt + n against LDS row 16 kt + 4 g + i.
+//   O^T = V^T P^T  A = V^T fragment (d tile dt, kv step c): d = 16 dt + n, k slots 8 g .. + 7 of the 32 kv of step c;
+//                  B = P^T fragment (qt, c): k slots 8 g + j, j = 0..3 from S tile (2c, qt) registers 0..3, j = 4..7 from tile
+//                  (2c + 1, qt).  P never moves between lanes.
+//   For the P^T slots to be the 8 CONSECUTIVE kv 32 c + 8 g + j (so that a V^T fragment is one ds_read_b128 of the untouched V^T
+//   image), LDS row 16 kt + m of the K image holds kv row 32 (kt >> 1) + 8 (m >> 2) + 4 (kt & 1) + (m & 3) of the tile -- a
+//   permutation of the DMA source rows (attn_w64_shared.h, dma_init).  Both images keep their XOR swizzles (K: chunk ^ (row & 15),
+//   V^T: chunk ^ ((row >> 1) & 7)): a ds_read_b128's four 16-lane service groups still cover the 64 banks once.
+//   O tile (dt, qt) register i = O[q = 16 qt + n][d = 16 dt + 4 g + i].
+// Registers: O 128 + V^T 64 + Q 64 in the accumulator file, K 64 + S 64 + P 32 in arch VGPRs -- as attention_w64q.hip.
+//
+// Schedule: attention_w64q.hip's bounded schedule with every 32-cycle MFMA gap split into two 16-cycle gaps (128 per tile:
+// A 0..31 S_a, B 32..63 PV_b of tile t-1, C 64..95 S_b, D 96..127 PV_a).  Old gap g -> new gaps 2g (the v_exp_f32 of g) and 2g + 1
+// (the previous pair's pack / row-sum adds, LDS fragment reads, DMA pieces).
+#include <stdlib.h>
+#include <string.h>
+
+#include "attn_w64_shared.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr float BOUND16_LOG2 = 96.0f;
+
+struct QH {           // one half of the wave's q rows: two 16-row q tiles
+  f32x4 accO[8][2];   // O^T tiles [d tile][q tile] ("a")
+  f32x4 s[4][2];      // S^T of the current tile [kv tile][q tile]
+  u32x4 pk[4];        // P^T fragments, f = 2 c + q tile
+  float p0, p1;       // the exp2 pair whose pack / sums are pending
+  float l[2][2];      // this lane's share of the row sums [q tile][even / odd score] (scalars + asm v_add_f32, see attention_w64q.hip)
+};
+
+__device__ __forceinline__ void qk16_0(f32x4& d, const mfma_bf16x8& k, const mfma_bf16x8& q) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void qk16(f32x4& d, const mfma_bf16x8& k, const mfma_bf16x8& q) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void pv16(f32x4& acc, const mfma_bf16x8& v, const mfma_bf16x8& p) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(v), "v"(p));
+}
+__device__ __forceinline__ void vadd16(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+
+// score k = 0..31 of a half, in the order its P^T fragments are needed: f = k >> 3 (= 2 c + q tile), then kv tile parity, then register
+__device__ __forceinline__ float score(const QH& q, int k) {
+  const int f = k >> 3;
+  return q.s[2 * (f >> 1) + ((k >> 2) & 1)][f & 1][k & 3];
+}
+// register (kt, i) of lane group g <-> kv row 32 (kt >> 1) + 8 g + 4 (kt & 1) + i of the tile; kv_rem = valid kv rows from the tile's first
+__device__ __forceinline__ void mask_tail16(QH& q, int kv_rem, int g) {
+  if (__builtin_expect(kv_rem < KVBLK, 0)) {
+    asm volatile("" ::: "memory");  // keep this rare path a real (wave-uniform) branch, out of line
+    int lim = kv_rem - 8 * g;
+    asm volatile("" : "+v"(lim));
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          q.s[kt][qt][i] = (32 * (kt >> 1) + 4 * (kt & 1) + i >= lim) ? -INFINITY : q.s[kt][qt][i];
+          asm volatile("" : "+v"(q.s[kt][qt][i]));
+        }
+  }
+}
+// bookkeeping in front of exp2 of score k: k even: pack the previous pair, first row-sum add; k odd: the second add
+__device__ __forceinline__ void book16(QH& q, int k) {
+  if ((k & 1) == 0) {
+    if (k >= 2) {
+      const int j = (k >> 1) - 1;
+      q.pk[j >> 2][j & 3] = cvt_pk(q.p0, q.p1);
+      asm volatile("" : "+v"(q.pk[j >> 2]));
+      vadd16(q.l[((k - 2) >> 3) & 1][0], q.p0);
+    }
+  } else if (k >= 3) {
+    vadd16(q.l[((k - 2) >> 3) & 1][1], q.p1);
+  }
+}
+__device__ __forceinline__ void exp16(QH& q, int k, int kv_rem, int g) {
+  if (k == 0) mask_tail16(q, kv_rem, g);  // cold: only a segment's ragged last tile (zero-filled K rows -> s = 0 -> -inf)
+  if ((k & 1) == 0) {
+    q.p0 = __builtin_amdgcn_exp2f(score(q, k));
+    asm volatile("" : "+v"(q.p0));
+  } else {
+    q.p1 = __builtin_amdgcn_exp2f(score(q, k));
+    asm volatile("" : "+v"(q.p1));
+  }
+}
+__device__ __forceinline__ void tail16(QH& q, int part) {  // pair 15 (q tile 1): pack + first sum (part 0), second sum (part 1)
+  if (part == 0) {
+    q.pk[3][3] = cvt_pk(q.p0, q.p1);
+    asm volatile("" : "+v"(q.pk[3]));
+    vadd16(q.l[1][0], q.p0);
+  } else {
+    vadd16(q.l[1][1], q.p1);
+  }
+}
+// MFMA i = 0..31 of an S phase: k-step i >> 3, kv tile (i >> 1) & 3, q tile i & 1 -- an accumulator is revisited every 8 MFMAs
+__device__ __forceinline__ void qk_step16(QH& x, const mfma_bf16x8 (&kf)[4][4], const mfma_bf16x8 (&qf)[4][4], int qt0, int i) {
+  const int ks = i >> 3, kt = (i >> 1) & 3, qt = i & 1;
+  if (ks == 0) qk16_0(x.s[kt][qt], kf[kt][0], qf[qt0 + qt][0]);
+  else qk16(x.s[kt][qt], kf[kt][ks], qf[qt0 + qt][ks]);
+}
+// MFMA i = 0..31 of a PV phase: P^T fragment f = i >> 3 (c = f >> 1, q tile f & 1), d tile i & 7
+__device__ __forceinline__ void pv_step16(QH& x, const mfma_bf16x8 (&vf)[8][2], int i) {
+  const int f = i >> 3, dt = i & 7;
+  pv16(x.accO[dt][f & 1], vf[dt][f >> 1], __builtin_bit_cast(mfma_bf16x8, x.pk[f]));
+}
+
+// old-gap position of q-half b's exp2 of score k0 in the part of its stream that sits in ITS OWN tile (old gaps 51..63: scores 0..16,
+// two in the even gaps 56..62) -- see attention_w64q.hip
+__device__ __forceinline__ constexpr int bk0(int g) { return g - 51 + (g > 56 ? (g - 55) / 2 : 0); }
+
+template <int ST, bool MULTI>
+__device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4], const int (&vaddr)[2], const mfma_bf16x8 (&qf)[4][4],
+                                          mfma_bf16x8 (&kf)[4][4], mfma_bf16x8 (&vf)[8][2], QH& a, QH& b, int kv_rem, int lg,
+                                          char* smem_rw, Dma& dma) {
+  constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
+  // the non-MFMA work of new gap G: g = G >> 1 is attention_w64q.hip's gap, sub-gap 0 carries its exp2, sub-gap 1 the bookkeeping of
+  // the NEXT exp2 (pack / sums of the pair before it), the fragment reads and the DMA pieces
+#define N16_GAP(G)                                                                                                  \
+  do {                                                                                                              \
+    const int g_ = (G) >> 1, g1_ = g_ + 1;                                                                          \
+    if (((G) & 1) == 0) {                                                                                           \
+      if (g_ >= 4 && g_ <= 18) exp16(b, g_ + 13, kv_rem, lg);            /* q-half b, tile t-1: scores 17..31 */       \
+      if (g_ >= 19 && g_ <= 50) exp16(a, g_ - 19, kv_rem, lg);           /* q-half a, tile t */                        \
+      if (g_ >= 51) exp16(b, bk0(g_), kv_rem, lg);                       /* q-half b, tile t: scores 0..16 */          \
+    } else {                                                                                                        \
+      if (g_ >= 56 && ((g_ - 56) & 1) == 0) { book16(b, bk0(g_) + 1); exp16(b, bk0(g_) + 1, kv_rem, lg); }           \
+      if (g_ == 19) tail16(b, 0);                                                                                   \
+      if (g_ == 20) tail16(b, 1);                                                                                   \
+      if (g_ == 51) tail16(a, 0);                                                                                   \
+      if (g_ == 52) tail16(a, 1);                                                                                   \
+      if (g1_ >= 4 && g1_ <= 18) book16(b, g1_ + 13);                                                               \
+      if (g1_ >= 19 && g1_ <= 50) book16(a, g1_ - 19);                                                              \
+      if (g1_ >= 51 && g1_ <= 63) book16(b, bk0(g1_));                                                              \
+    }                                                                                                               \
+    if ((G) >= 41 && (G) <= 55 && (((G) - 41) & 1) == 0) {               /* V^T(t) fragment (dt, 0): last read by PV_b's MFMA 8 + dt */ \
+      const int dt = ((G) - 41) >> 1;                                                                                \
+      vf[dt][0] = *(lds_frag*)(smem + (VB + dt * 2048) + vaddr[0]);                                                  \
+    }                                                                                                               \
+    if ((G) >= 57 && (G) <= 64) {                                        /* V^T(t) fragment (dt, 1): last read by MFMA 24 + dt */ \
+      const int dt = (G) - 57;                                                                                       \
+      vf[dt][1] = *(lds_frag*)(smem + (VB + dt * 2048) + vaddr[1]);                                                  \
+    }                                                                                                               \
+    if ((G) >= 67 && (G) <= 97 && (((G) - 67) & 1) == 0) {               /* K(t+1) fragment (kt, ks): last read by S_b's MFMA 8 ks + 2 kt + 1 */ \
+      const int r = ((G) - 67) >> 1, ks = r >> 2, kt = r & 3;                                                        \
+      kf[kt][ks] = *(lds_frag*)(smem + (KN + kt * 4096) + kaddr[ks]);                                                \
+    }                                                                                                               \
+    if ((G) >= 3 && (G) <= 31 && (((G) - 3) & 3) == 0) {                                                            \
+      const int pc = ((G) - 3) >> 2;                                     /* DMA pieces K0 V0 K1 V1 ... of tile t+2 */  \
+      dma_piece_i<DST>(smem_rw, dma, (pc & 1) * 4 + (pc >> 1));                                                      \
+    }                                                                                                               \
+  } while (0)
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {  // ---- A: S_a = K Q_a^T
+    qk_step16(a, kf, qf, 0, i); SB();
+    N16_GAP(i);
+    SB();
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {  // ---- B: O_b += V^T(t-1) P_b(t-1)^T
+    pv_step16(b, vf, i); SB();
+    N16_GAP(32 + i);
+    SB();
+  }
+  dma_advance<MULTI>(dma);
+  SB();
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {  // ---- C: S_b = K Q_b^T
+    qk_step16(b, kf, qf, 2, i); SB();
+    N16_GAP(64 + i);
+    SB();
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {  // ---- D: O_a += V^T(t) P_a(t)^T
+    pv_step16(a, vf, i); SB();
+    N16_GAP(96 + i);
+    SB();
+  }
+#undef N16_GAP
+}
+
+__device__ __forceinline__ float sumsq8_16(const mfma_bf16x8& f) {
+  const uint4 w = __builtin_bit_cast(uint4, f);
+  const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+    s = __builtin_fmaf(lo, lo, s);
+    s = __builtin_fmaf(hi, hi, s);
+  }
+  return s;
+}
+__device__ __forceinline__ mfma_bf16x8 prescale8_16(const uint4 raw, float c) {
+  uint4 o;
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  uint32_t r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = cvt_pk(__uint_as_float(w[i] << 16) * c, __uint_as_float(w[i] & 0xffff0000u) * c);
+  o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+  return __builtin_bit_cast(mfma_bf16x8, o);
+}
+
+// FLAGS: attention_w64q.hip's bits -- bit1 q pre-scaled, bit2 (always set here: the bounded loop), bit4 RAW_OUT, bit5 CARRY_IN,
+// bit6 MULTI (several kv segments / a left-out one).  A workgroup whose rows fail the bound sets wg_flags[id] and returns before
+// touching LDS; attention_w64q.hip's tracking instantiation, launched behind this kernel, then does it.
+template <int FLAGS>
+__global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
+                                                       const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int B, int Bk,
+                                                       int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e,
+                                                       int nseg, int64_t k_seg_stride, int64_t vt_seg_stride,
+                                                       const float* __restrict__ kmax2, int* __restrict__ wg_flags,
+                                                       float* __restrict__ raw, int skip_seg) {
+  constexpr bool PRESCALED = (FLAGS & 2) != 0;
+  constexpr bool RAW_OUT = (FLAGS & 16) != 0, CARRY_IN = (FLAGS & 32) != 0;
+  constexpr bool MULTI = (FLAGS & 64) != 0;
+  constexpr int WAVE_RAW = 2 * (64 * 64 + 128), WG_RAW = 4 * WAVE_RAW;  // floats: per half 64 accumulators x 64 lanes + 2 x 64 row-sum shares
+  __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];    // [K stages][V^T stages] = 96 KB
+  lds_cchar* lds = (lds_cchar*)smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  const int total = nqb * H * B;
+  const int v = xcd_remap(blockIdx.x, total);
+  if (CARRY_IN && wg_flags[v] != 0) return;  // an earlier partial launch already gave this workgroup up
+  const int pair = v / nqb;
+  const int qb = v - pair * nqb;
+  const int b = pair / H, h = pair - b * H;
+  const int bk = (Bk == 1) ? 0 : b;
+  const int64_t rs = (int64_t)H * 128;
+
+  const bf16_t* qbase = Q + ((int64_t)b * Lq) * rs + (int64_t)h * 128;
+  const bf16_t* kbase = Kg + ((int64_t)bk * Lk) * rs + (int64_t)h * 128;
+  const bf16_t* vbase = Vt + ((int64_t)bk * H * 128 + (int64_t)h * 128) * ldv;
+  bf16_t* obase = O + ((int64_t)b * Lq) * rs + (int64_t)h * 128;
+
+  const int64_t q0 = (int64_t)qb * 256 + wave * 64;
+  mfma_bf16x8 qf[4][4];  // Q~ = bf16(q * scale * log2 e), [q tile][k-step]
+  float ss[4] = {0.f, 0.f, 0.f, 0.f};  // |Q~_row|^2, this lane's 32 of the row's 128 channels
+  {
+    uint4 w[4][4];  // all 16 loads in flight before the first use
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      int64_t r = q0 + 16 * qt + l15;
+      if (r > Lq - 1) r = Lq - 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) w[qt][ks] = *reinterpret_cast<const uint4*>(qbase + r * rs + ks * 32 + lg * 8);
+    }
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qf[qt][ks] = PRESCALED ? __builtin_bit_cast(mfma_bf16x8, w[qt][ks]) : prescale8_16(w[qt][ks], scale_log2e);
+        ss[qt] += sumsq8_16(qf[qt][ks]);
+        asm volatile("" : "+a"(qf[qt][ks]));  // one accumulator-file tuple from here on
+      }
+  }
+  // ---- the bound: every row of the workgroup must satisfy |Q~_row| * max|k_h| <= 96 (workgroup-uniform) ------------------------
+  {
+    const float km = kmax2[bk * H + h];
+    bool ok = true;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      float s = ss[qt];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      ok = ok && (s * km <= BOUND16_LOG2 * BOUND16_LOG2);  // false for NaN
+    }
+    if (__syncthreads_and(ok ? 1 : 0) == 0) {
+      if (tid == 0) wg_flags[v] = 1;
+      return;
+    }
+  }
+
+  // ---- DMA stream ---------------------------------------------------------------------------------------------------------------
+  const int Lk32 = (int)Lk;
+  const int tps = (Lk32 + KVBLK - 1) / KVBLK;
+  const int ntile = tps * (nseg - (skip_seg >= 0 ? 1 : 0));
+  Dma dma;
+  dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, skip_seg, /*k_rows_16x16=*/true);
+  int cur_tt = 0;
+  auto next_kv_rem = [&]() {
+    const int rem = Lk32 - cur_tt * KVBLK;
+    if (++cur_tt == tps) cur_tt = 0;
+    return rem;
+  };
+
+  // ---- LDS fragment addresses: per-lane VGPR + compile-time immediates ------------------------------------------------------------
+  int kaddr[4], vaddr[2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kaddr[ks] = l15 * 256 + (((ks * 4 + lg) ^ l15) << 4);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)  // + V^T region base: keeps every ds_read offset inside the 16-bit immediate
+    vaddr[c] = NST * IMG + l15 * 128 + (((c * 4 + lg) ^ ((l15 >> 1) & 7)) << 4);
+
+  QH qa, qb2;
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { qa.accO[dt][qt][r] = 0.f; qb2.accO[dt][qt][r] = 0.f; }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) { qa.l[qt][0] = qa.l[qt][1] = 0.f; qb2.l[qt][0] = qb2.l[qt][1] = 0.f; }
+  if (CARRY_IN) {  // partial sums of an earlier launch over other kv segments (same grid, same workgroup -> same slots)
+    const float4* src = reinterpret_cast<const float4*>(raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          f32x4& acc = hf ? qb2.accO[dt][qt] : qa.accO[dt][qt];
+          const float4 w4 = src[((hf * 8 + dt) * 2 + qt) * 64 + lane];
+          acc[0] = w4.x; acc[1] = w4.y; acc[2] = w4.z; acc[3] = w4.w;
+          asm volatile("" : "+a"(acc));
+        }
+    const float* ls = raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
+    qa.l[0][0] = ls[lane]; qa.l[1][0] = ls[64 + lane];
+    qb2.l[0][0] = ls[128 + lane]; qb2.l[1][0] = ls[192 + lane];
+  }
+  qa.p0 = qa.p1 = qb2.p0 = qb2.p1 = 0.f;
+  // q-half b starts half a tile behind: its first PV_b runs on an all-masked dummy tile (P = 0)
+  {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { qa.pk[f] = z; qb2.pk[f] = z; }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { qb2.s[kt][qt][r] = -INFINITY; qa.s[kt][qt][r] = -INFINITY; }
+  }
+  mfma_bf16x8 vf[8][2];  // V^T fragments, carried from tile t (PV_a) to B of tile t+1 (PV_b)
+  {
+    uint4 z; z.x = z.y = z.z = z.w = 0u;
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) vf[dt][c] = __builtin_bit_cast(mfma_bf16x8, z);
+  }
+
+  dma_tile<0, MULTI>(smem, dma);
+  dma_tile<1, MULTI>(smem, dma);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  mfma_bf16x8 kf[4][4];
+  // in the order the tile loop re-reads them (k-step major, then kv tile)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    kf[r & 3][r >> 2] = *(lds_frag*)(lds + (r & 3) * 4096 + kaddr[r >> 2]);
+    SB();
+  }
+
+  int kv_rem_prev = KVBLK;
+#define W16N_STEP(J)                                                                                         \
+  if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
+    if (t + (J) > 0) {                                                                                       \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile t+J+1 landed */                               \
+      __builtin_amdgcn_s_barrier();                                                                          \
+      asm volatile("" ::: "memory");                                                                         \
+    }                                                                                                        \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): every K fragment of this tile was read >= 30 gaps ago */ \
+    const int kv_rem = next_kv_rem();                                                                        \
+    tile_w16n<J, MULTI>(lds, kaddr, vaddr, qf, kf, vf, qa, qb2, kv_rem, lg, smem, dma);                      \
+    kv_rem_prev = kv_rem;                                                                                    \
+  }
+  for (int t = 0; t < ntile; t += NST) {
+    W16N_STEP(0)
+    W16N_STEP(1)
+    W16N_STEP(2)
+  }
+#undef W16N_STEP
+  // drain: q-half b's last tile
+#pragma unroll
+  for (int k = 17; k < 32; ++k) { book16(qb2, k); exp16(qb2, k, kv_rem_prev, lg); }
+  tail16(qb2, 0);
+  tail16(qb2, 1);
+  asm volatile("s_nop 1" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 32; ++i) pv_step16(qb2, vf, i);
+
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA lands before O staging reuses LDS; last PV MFMAs -> accumulator reads
+  float lsum[4] = {qa.l[0][0] + qa.l[0][1], qa.l[1][0] + qa.l[1][1], qb2.l[0][0] + qb2.l[0][1], qb2.l[1][0] + qb2.l[1][1]};
+  if (RAW_OUT) {  // partial result: accumulators and row-sum shares as they are, lane-major (1-KB stores)
+    float4* dst = reinterpret_cast<float4*>(raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const f32x4 acc = hf ? qb2.accO[dt][qt] : qa.accO[dt][qt];
+          dst[((hf * 8 + dt) * 2 + qt) * 64 + lane] = float4{acc[0], acc[1], acc[2], acc[3]};
+        }
+    float* ls = raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ls[c * 64 + lane] = lsum[c];
+    return;
+  }
+  // ---- epilogue: normalise, stage the wave's 64 x 128 O tile through LDS, store whole rows ------------------------------------------
+  float inv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float s = lsum[c];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    inv[c] = 1.0f / s;
+  }
+  __syncthreads();
+  char* ob = smem + wave * (64 * 256);
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const float iv = inv[hf * 2 + qt];
+      const int row = (hf * 2 + qt) * 16 + l15;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const f32x4 acc = hf ? qb2.accO[dt][qt] : qa.accO[dt][qt];
+        uint2 w;
+        w.x = cvt_pk(acc[0] * iv, acc[1] * iv);
+        w.y = cvt_pk(acc[2] * iv, acc[3] * iv);
+        const int ch = (dt * 2 + (lg >> 1)) ^ (l15 & 15);  // d = 16 dt + 4 g .. + 3: 16-B chunk 2 dt + (g >> 1), its half g & 1
+        *reinterpret_cast<uint2*>(ob + row * 256 + ch * 16 + (lg & 1) * 8) = w;
+      }
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = i * 4 + (lane >> 4), c = lane & 15;
+    const int64_t qr = q0 + r;
+    if (qr < Lq) {
+      const uint4 val = *reinterpret_cast<const uint4*>(ob + r * 256 + ((c ^ (r & 15)) << 4));
+      *reinterpret_cast<uint4*>(obase + qr * rs + c * 8) = val;
+    }
+  }
+}
+
+}  // namespace
+
+// The bounded launch of attention_w64q.hip's protocol on this kernel.  fl = that file's FLAGS value (bit 2 set); every other argument as
+// attn_w64q_kernel's.  Returns -1 for a combination this file does not instantiate.
+int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B,
+                              int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e, int nseg, int64_t k_seg_stride,
+                              int64_t vt_seg_stride, const float* kmax2, int* wg_flags, float* raw, int skip_seg) {
+#define W16N_CASE(FL)                                                                                                              \
+  case FL:                                                                                                                         \
+    hipLaunchKernelGGL((attn_w16n_kernel<FL>), dim3(total), dim3(256), 0, stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nqb, scale_log2e, \
+                       nseg, k_seg_stride, vt_seg_stride, kmax2, wg_flags, raw, skip_seg);                                         \
+    break;
+  switch (fl) {
+    W16N_CASE(4)
+    W16N_CASE(6)
+    W16N_CASE(4 | 64)
+    W16N_CASE(6 | 64)
+    W16N_CASE(2 | 4 | 16)
+    W16N_CASE(2 | 4 | 32 | 64)
+    default: return -1;
+  }
+#undef W16N_CASE
+  WAN_LAUNCH_CHECK();
+  return 0;
+}

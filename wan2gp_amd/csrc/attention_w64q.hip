@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   constexpr bool DIAG = (FLAGS & 8) != 0;  // timing build only: bounded loop without its row-sum adds (wrong results)
   constexpr bool RAW_OUT = (FLAGS & 16) != 0, CARRY_IN = (FLAGS & 32) != 0;
   constexpr bool MULTI = (FLAGS & 64) != 0;  // several kv segments and / or a left-out one (sequence parallelism): the long form of the DMA stream's step
-  constexpr int WAVE_RAW = 2 * (64 * 64 + 64), WG_RAW = 4 * WAVE_RAW;  // floats: per q-block 64 accumulators x 64 lanes + 64 row-sum shares
+  constexpr int WAVE_RAW = 2 * (64 * 64 + 128), WG_RAW = 4 * WAVE_RAW;  // floats: per q-block 64 accumulators x 64 lanes + 64 row-sum shares (+ 64 unused: the slot size of attention_w16n.hip)
   uint64_t stamp[20] = {};
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];  // [K stages][V^T stages] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
@@ -747,6 +747,19 @@ __global__ __launch_bounds__(256) void attn_kmax_kernel(const bf16_t* __restrict
 
 }  // namespace
 
+// the bounded loop on the 16x16x32 MFMA (attention_w16n.hip): takes the bounded launches below unless the library is built
+// -DWAN_ATTN_NO_MI16 (the A/B library libwanhip_a32.so)
+int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B,
+                              int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e, int nseg, int64_t k_seg_stride,
+                              int64_t vt_seg_stride, const float* kmax2, int* wg_flags, float* raw, int skip_seg);
+#ifndef WAN_ATTN_NO_MI16
+#define W16N_TRY(FL, NSEG, KS, VS, SKIP)                                                                                         \
+  (wan_attention_w16n_launch(FL, (unsigned)total, stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, (int)nqb, scale_log2e, NSEG, KS, VS, \
+                             (const float*)kmax_scratch, wg_flags, raw, SKIP) == 0)
+#else
+#define W16N_TRY(FL, NSEG, KS, VS, SKIP) false
+#endif
+
 // called from attention.hip's dispatcher.  flags bit1: q is pre-scaled.  kmax_scratch: wan_attention_scratch_words() 4-byte
 // words (the K pre-pass maxima + one flag per workgroup), or NULL (tracking loop only)
 int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk,
@@ -786,8 +799,11 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   }
 #endif
   if (kmax_scratch != nullptr) {
-    if (nseg > 1) { if (pre) W64Q_LAUNCH(6 | 64); else W64Q_LAUNCH(4 | 64); }
-    else { if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4); }
+    const int fl = (pre ? 6 : 4) | (nseg > 1 ? 64 : 0);
+    if (!W16N_TRY(fl, nseg, k_seg_stride, vt_seg_stride, skip_seg)) {
+      if (nseg > 1) { if (pre) W64Q_LAUNCH(6 | 64); else W64Q_LAUNCH(4 | 64); }
+      else { if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4); }
+    }
     WAN_LAUNCH_CHECK();
   }
   if (nseg > 1) { if (pre) W64Q_LAUNCH(2 | 64); else W64Q_LAUNCH(0 | 64); }
@@ -825,7 +841,7 @@ int wan_attention_w64q_sp(int phase, const bf16_t* q, const bf16_t* k, const bf1
     hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(B * H), 1u), dim3(256), 0, stream, k, kmax_scratch, B, Lk,
                        H, (int64_t)0);
     WAN_LAUNCH_CHECK();
-    W64Q_LAUNCH_SP(2 | 4 | 16, 1, (int64_t)0, (int64_t)0, -1);
+    if (!W16N_TRY(2 | 4 | 16, 1, (int64_t)0, (int64_t)0, -1)) W64Q_LAUNCH_SP(2 | 4 | 16, 1, (int64_t)0, (int64_t)0, -1);
     WAN_LAUNCH_CHECK();
     return 0;
   }
@@ -833,7 +849,7 @@ int wan_attention_w64q_sp(int phase, const bf16_t* q, const bf16_t* k, const bf1
   hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(B * H), (unsigned)nseg), dim3(256), 0, stream, k,
                      kmax_scratch, B, Lk, H, k_seg_stride);
   WAN_LAUNCH_CHECK();
-  W64Q_LAUNCH_SP(2 | 4 | 32 | 64, nseg, k_seg_stride, vt_seg_stride, own_seg);
+  if (!W16N_TRY(2 | 4 | 32 | 64, nseg, k_seg_stride, vt_seg_stride, own_seg)) W64Q_LAUNCH_SP(2 | 4 | 32 | 64, nseg, k_seg_stride, vt_seg_stride, own_seg);
   WAN_LAUNCH_CHECK();
   W64Q_LAUNCH_SP(2 | 64, nseg, k_seg_stride, vt_seg_stride, -1);
   WAN_LAUNCH_CHECK();

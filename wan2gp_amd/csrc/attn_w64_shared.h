@@ -77,7 +77,7 @@ __device__ __forceinline__ int64_t uni(int64_t x) {
 }
 __device__ __forceinline__ const char* uni(const char* p) { return (const char*)uni((int64_t)(uintptr_t)p); }
 __device__ __forceinline__ void dma_init(Dma& d, const void* kbase, const void* vbase, int64_t kseg_bytes, int64_t vseg_bytes,
-                                         int Lk, int nseg, uint32_t rs2, uint32_t ldv2, int tid, int wave, int skip = -1) {
+                                         int Lk, int nseg, uint32_t rs2, uint32_t ldv2, int tid, int wave, int skip = -1, bool k_rows_16x16 = false) {
   d.seg = uni((skip == 0) ? 1 : 0);
   d.skip = uni(skip);
   d.k = d.kseg0 = uni(reinterpret_cast<const char*>(kbase) + (int64_t)d.seg * kseg_bytes);
@@ -95,7 +95,10 @@ __device__ __forceinline__ void dma_init(Dma& d, const void* kbase, const void* 
   const uint32_t vofs0 = (uint32_t)(tid >> 3) * ldv2 + (uint32_t)(((tid & 7) ^ ((tid >> 4) & 7)) << 4);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    d.kofs[i] = (krow0 + 16u * i) * rs2 + kcol;
+    // LDS row 16 i + m (m = tid >> 4) of the K image <- kv row of the tile: the 32x32x16 kernel swaps bits 2 <-> 3 of m; the
+    // 16x16x32 kernel (attention_w16n.hip) wants 32 (i >> 1) + 8 (m >> 2) + 4 (i & 1) + (m & 3)
+    const uint32_t src = k_rows_16x16 ? 32u * (i >> 1) + 8u * (kr0 >> 2) + 4u * (i & 1) + (kr0 & 3u) : krow0 + 16u * i;
+    d.kofs[i] = src * rs2 + kcol;
     d.vofs[i] = vofs0 + 32u * i * ldv2;
   }
   d.wave = wave;
