@@ -386,7 +386,7 @@ def main():
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
                        "solver": "unipc", "parallelism": "sp%d" % world if world > 1 else "single",
                        "forward_TFLOP": forward_flops(cfg, L) / 1e12},
-            "roofline": {"kernel": "attn_w64q_kernel (self-attention)", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "attn_w16n_kernel (self-attention: the bounded loop on the 16x16x32 MFMA)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source, "launches": n, "avg_ms": ms / n if n else None,
                          "flop_per_launch": attn_flops,

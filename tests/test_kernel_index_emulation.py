@@ -941,65 +941,56 @@ def test_attention_w16n_ds_read_b128_is_conflict_free():
 
 def test_attention_w16n_gap_schedule():
     """The split-gap schedule of tile_w16n as a state machine over three tiles: every score of both q halves is exponentiated exactly
-    once per tile and in order, a pair is packed after both its exps and >= 2 gaps before the PV MFMA that reads its fragment, the
-    row-sum adds see every score once, V^T / K fragment reads come after the last MFMA reading the register they overwrite."""
+    once per tile and in order; the row-sum add of score k sits in the gap of exp2(k + 1) (or the tail, k = 31); a pair is packed
+    after the exp2 of its odd score and >= 2 gaps before the PV MFMA that reads its fragment; V^T / K fragment reads come after the
+    last MFMA reading the register they overwrite."""
     def bk0(g):
         return g - 51 + ((g - 55) // 2 if g > 56 else 0)
-    events = []                                                                   # (tile, G, order, kind, half, k)
+    events = []                                                                   # (tile, G, kind, half, k)
     for t in range(3):
         for G in range(128):
-            g_, g1_ = G >> 1, (G >> 1) + 1
-            o = 0
-            def ev(kind, half, k):
-                nonlocal o
-                events.append((t, G, o, kind, half, k)); o += 1
+            g_ = G >> 1
             if G & 1 == 0:
-                if 4 <= g_ <= 18: ev("exp", "b", g_ + 13)
-                if 19 <= g_ <= 50: ev("exp", "a", g_ - 19)
-                if g_ >= 51: ev("exp", "b", bk0(g_))
+                if 4 <= g_ <= 18: events.append((t, G, "exp", "b", g_ + 13))
+                if 19 <= g_ <= 50: events.append((t, G, "exp", "a", g_ - 19))
+                if g_ >= 51: events.append((t, G, "exp", "b", bk0(g_)))
             else:
+                if 4 <= g_ <= 18 and (g_ + 13) & 1: events.append((t, G, "pack", "b", g_ + 13))
+                if g_ == 18: events.append((t, G, "tail", "b", 31))
+                if 19 <= g_ <= 50 and (g_ - 19) & 1: events.append((t, G, "pack", "a", g_ - 19))
+                if g_ == 50: events.append((t, G, "tail", "a", 31))
+                if g_ >= 51 and bk0(g_) & 1: events.append((t, G, "pack", "b", bk0(g_)))
                 if g_ >= 56 and (g_ - 56) % 2 == 0:
-                    ev("book", "b", bk0(g_) + 1); ev("exp", "b", bk0(g_) + 1)
-                if g_ == 19: ev("tail0", "b", 31)
-                if g_ == 20: ev("tail1", "b", 31)
-                if g_ == 51: ev("tail0", "a", 31)
-                if g_ == 52: ev("tail1", "a", 31)
-                if 4 <= g1_ <= 18: ev("book", "b", g1_ + 13)
-                if 19 <= g1_ <= 50: ev("book", "a", g1_ - 19)
-                if 51 <= g1_ <= 63: ev("book", "b", bk0(g1_))
+                    events.append((t, G, "exp", "b", bk0(g_) + 1))
+                    if (bk0(g_) + 1) & 1: events.append((t, G, "pack", "b", bk0(g_) + 1))
     for half in "ab":
-        seq = [(t, G, o, kind, k) for (t, G, o, kind, h, k) in events if h == half]
-        exps = [(t, G, k) for (t, G, o, kind, k) in seq if kind == "exp"]
-        # a: scores 0..31 inside its tile; b: 0..16 in its tile, 17..31 in the next one
-        ks = [k for (_, _, k) in exps]
+        seq = [(t, G, kind, k) for (t, G, kind, h, k) in events if h == half]
+        ks = [k for (_, _, kind, k) in seq if kind == "exp"]
         if half == "a":
             assert ks == list(range(32)) * 3
         else:
             assert ks == list(range(17, 32)) + (list(range(17)) + list(range(17, 32))) * 2 + list(range(17))
-        # book(k) directly precedes exp(k) in program order
-        kinds = [(kind, k) for (_, _, _, kind, k) in seq]
-        for i, (kind, k) in enumerate(kinds):
+        # state machine: p0 / p1 registers, what is packed and what is summed
+        p = {0: None, 1: None}
+        summed, packed = [], []
+        for (t, G, kind, k) in seq:
             if kind == "exp":
-                assert kinds[i - 1] == ("book", k) or (i == 0), (half, i, kinds[i - 1], k)
-        # pack times: pair j packed at book(2j + 2) (j < 15) or tail0 (j = 15); its fragment f = j >> 2 is read by the PV phase
-        # (a: D of the same tile, gaps 96 + 8 f ..; b: B of the NEXT tile for every pair, gaps 32 + 8 f ..)
-        for (t, G, o, kind, k) in seq:
-            if kind == "book" and k % 2 == 0 and k >= 2:
-                j = k // 2 - 1
-            elif kind == "tail0":
-                j = 15
+                p[k & 1] = (t if (half == "a" or k <= 16) else t - 1, k)      # (tile the score belongs to, k)
+                if k >= 1 and p[(k - 1) & 1] is not None: summed.append(p[(k - 1) & 1])
+            elif kind == "pack":
+                assert p[1] is not None and p[1][1] == k and (p[0] is None or p[0] == (p[1][0], k - 1))
+                packed.append((p[1][0], k >> 1, t, G))
             else:
-                continue
-            f = j >> 2
-            if half == "a":
-                assert G + 2 <= 96 + 8 * f
-            else:
-                tile_of_scores = t if k <= 17 and kind == "book" and k >= 2 and j <= 7 else t - 1   # pairs 0..7 packed in their own tile
-                use_tile = tile_of_scores + 1
-                assert (t, G + 2) <= (use_tile, 32 + 8 * f) or t < use_tile
-    # fragment reads behind the last reader of the register
+                summed.append(p[1])
+        full = [(tt, k) for (tt, k) in summed if tt in (0, 1)]
+        for tt in ((0, 1) if half == "a" else (0,)):                            # complete tiles inside the simulated window
+            assert sorted(k for (t2, k) in full if t2 == tt) == list(range(32)), (half, tt)
+        for (tt, j, t, G) in packed:                                             # fragment f = j >> 2: a -> PV_a of tile tt (gaps 96 + 8 f ..),
+            f = j >> 2                                                           # b -> PV_b in tile tt + 1 (gaps 32 + 8 f ..)
+            use = (tt, 96 + 8 * f) if half == "a" else (tt + 1, 32 + 8 * f)
+            assert (t, G + 2) <= use, (half, j, t, G, use)
     for dt in range(8):
-        assert 41 + 2 * dt > 32 + 8 * 1 + dt and 57 + dt > 32 + 8 * 3 + dt        # V^T (dt, 0) / (dt, 1): last PV_b readers f = 1 / f = 3
-    for ks in range(4):
+        assert 41 + 2 * dt > 32 + 8 * 1 + dt and 57 + 2 * dt > 32 + 8 * 3 + dt    # V^T (dt, 0) / (dt, 1): last PV_b readers f = 1 / f = 3
+    for ks_ in range(4):
         for kt in range(4):
-            assert 67 + 2 * (4 * ks + kt) > 64 + 8 * ks + 2 * kt + 1               # K (kt, ks): last S_b reader q tile 1
+            assert 67 + 2 * (4 * ks_ + kt) > 64 + 8 * ks_ + 2 * kt + 1             # K (kt, ks): last S_b reader q tile 1

@@ -20,11 +20,13 @@ def main():
     M = S * L
     k = json.load(open(src))["kernels"]
 
-    def tot(prefix):
+    def tot(prefix):                                            # a prefix or a tuple of prefixes
         rows = [(n, v) for n, v in k.items() if n.startswith(prefix)]
         return sum(v["calls"] for _, v in rows), sum(v["total_ms"] for _, v in rows)
 
-    n_self, _ = tot("attn_w64q_kernel<bounded")
+    SELF = ("attn_w16n_kernel", "attn_w64q_kernel<bounded")      # the bounded loop: attention_w16n.hip since round 3 (16x16x32 MFMA)
+    GEMM = ("gemm256m_kernel", "gemm256k_kernel")               # gemm256m.hip since round 3; gemm256k.hip keeps the row-bias (V^T) form
+    n_self, _ = tot(SELF)
     forwards = n_self / w["layers"] if n_self else 0            # forward passes in the trace (one joint CFG pass each)
     lines = {}
 
@@ -33,11 +35,11 @@ def main():
         if not calls or not forwards:
             return
         ach = work_per_forward * forwards / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
-        lines[name] = {"kernel": prefix, "launches": calls, "total_ms": round(ms, 2), "achieved": round(ach, 1), "unit": unit,
+        lines[name] = {"kernel": prefix if isinstance(prefix, str) else " + ".join(p for p in prefix if tot(p)[0]), "launches": calls, "total_ms": round(ms, 2), "achieved": round(ach, 1), "unit": unit,
                        "peak": peak, "frac": round(ach / peak, 3), "work_per_forward": work_per_forward, "note": note}
 
     # the bounded launch also serves cross-attention (short KV goes to the tracking instantiation): split by name
-    line("self-attention", "attn_w64q_kernel<bounded", w["layers"] * 4.0 * S * L * L * d, "TFLOP/s", 2500.0, "4 S L^2 d per block")
+    line("self-attention", SELF, w["layers"] * 4.0 * S * L * L * d, "TFLOP/s", 2500.0, "4 S L^2 d per block")
     line("cross-attention (Lk=512)", "attn_w64q_kernel<tracking", w["layers"] * 4.0 * S * L * text * d, "TFLOP/s", 2500.0,
          "4 S L 512 d per block; includes the bounded launch's declined-workgroup pass (zero work)")
     big = w["layers"] * 2.0 * M * (6.0 * d * d + 2.0 * d * ffn)          # q,k,v,o, cross q,o, ffn1, ffn2 per block
@@ -46,7 +48,7 @@ def main():
         line("fp8 activation quantisation", "fp8_", w["layers"] * 5.0 * M * (5.0 * d + 1.0 * ffn) , "GB/s", 8000.0,
              "absmax read 2 B + quantise read 2 B / write 1 B per element, 5 activations of width d and 1 of width ffn per block")
     else:
-        line("GEMM (bf16)", "gemm256k_kernel", big, "TFLOP/s", 2500.0, "2 M (6 d^2 + 2 d ffn) per block")
+        line("GEMM (bf16)", GEMM, big, "TFLOP/s", 2500.0, "2 M (6 d^2 + 2 d ffn) per block")
     line("RMSNorm+RoPE", "rmsnorm_rope_kernel", w["layers"] * 6.0 * M * d * 2, "GB/s", 8000.0,
          "q,k (r+w) of self-attention + q (r+w) of cross-attention per block")
     line("LayerNorm family", "layernorm_kernel", (w["layers"] * 3 + 1) * 2.0 * M * d * 2, "GB/s", 8000.0, "norm1, norm2, norm3 per block + head")

@@ -75,38 +75,27 @@ __device__ __forceinline__ void mask_tail16(QH& q, int kv_rem, int g) {
         }
   }
 }
-// bookkeeping in front of exp2 of score k: k even: pack the previous pair, first row-sum add; k odd: the second add
-__device__ __forceinline__ void book16(QH& q, int k) {
-  if ((k & 1) == 0) {
-    if (k >= 2) {
-      const int j = (k >> 1) - 1;
-      q.pk[j >> 2][j & 3] = cvt_pk(q.p0, q.p1);
-      asm volatile("" : "+v"(q.pk[j >> 2]));
-      vadd16(q.l[((k - 2) >> 3) & 1][0], q.p0);
-    }
-  } else if (k >= 3) {
-    vadd16(q.l[((k - 2) >> 3) & 1][1], q.p1);
-  }
-}
+// exp2 of score k, then the row-sum add of score k - 1 (one gap old: no transcendental -> VALU wait state; its register is the
+// other one of the pair).  Score 31's add is tail16, behind its exp2.
 __device__ __forceinline__ void exp16(QH& q, int k, int kv_rem, int g) {
   if (k == 0) mask_tail16(q, kv_rem, g);  // cold: only a segment's ragged last tile (zero-filled K rows -> s = 0 -> -inf)
   if ((k & 1) == 0) {
     q.p0 = __builtin_amdgcn_exp2f(score(q, k));
     asm volatile("" : "+v"(q.p0));
+    if (k >= 1) vadd16(q.l[((k - 1) >> 3) & 1][1], q.p1);
   } else {
     q.p1 = __builtin_amdgcn_exp2f(score(q, k));
     asm volatile("" : "+v"(q.p1));
+    vadd16(q.l[((k - 1) >> 3) & 1][0], q.p0);
   }
 }
-__device__ __forceinline__ void tail16(QH& q, int part) {  // pair 15 (q tile 1): pack + first sum (part 0), second sum (part 1)
-  if (part == 0) {
-    q.pk[3][3] = cvt_pk(q.p0, q.p1);
-    asm volatile("" : "+v"(q.pk[3]));
-    vadd16(q.l[1][0], q.p0);
-  } else {
-    vadd16(q.l[1][1], q.p1);
-  }
+// behind exp2 of the ODD score k (at least one VALU later): pair k >> 1 -> its P^T register
+__device__ __forceinline__ void pack16(QH& q, int k) {
+  const int j = k >> 1;
+  q.pk[j >> 2][j & 3] = cvt_pk(q.p0, q.p1);
+  asm volatile("" : "+v"(q.pk[j >> 2]));
 }
+__device__ __forceinline__ void tail16(QH& q) { vadd16(q.l[1][1], q.p1); }  // score 31's share of its row sum (q tile 1)
 // MFMA i = 0..31 of an S phase: k-step i >> 3, kv tile (i >> 1) & 3, q tile i & 1 -- an accumulator is revisited every 8 MFMAs
 __device__ __forceinline__ void qk_step16(QH& x, const mfma_bf16x8 (&kf)[4][4], const mfma_bf16x8 (&qf)[4][4], int qt0, int i) {
   const int ks = i >> 3, kt = (i >> 1) & 3, qt = i & 1;
@@ -123,36 +112,58 @@ __device__ __forceinline__ void pv_step16(QH& x, const mfma_bf16x8 (&vf)[8][2], 
 // two in the even gaps 56..62) -- see attention_w64q.hip
 __device__ __forceinline__ constexpr int bk0(int g) { return g - 51 + (g > 56 ? (g - 55) / 2 : 0); }
 
-template <int ST, bool MULTI>
+// dma_advance<true> (attn_w64_shared.h: the step of the segment-walking stream) cut into five parts spread over the three empty gaps behind the
+// barrier (all of it in front of the tile's first DMA piece at gap 3): in one piece its ~50 scalar instructions land in a single MFMA gap (200 cycles in front of one MFMA, every tile)
+struct MultiStep { int adv, sw, stp, hop2; };
+__device__ __forceinline__ void multi_step16(Dma& d, MultiStep& m, int part) {
+  if (part == 0) {
+    m.adv = d.left > 1 ? 1 : 0;
+    d.left -= m.adv;
+    const int last = (d.tt + 1 == d.tps) ? 1 : 0;
+    m.sw = m.adv & last;                                       // move to the next kv segment
+    m.stp = m.adv & (last ^ 1);                                // next tile of the same segment
+    m.hop2 = m.sw & ((d.seg + 1 == d.skip) ? 1 : 0);           // jump over the left-out segment
+  } else if (part == 1) {
+    d.tt = m.sw ? 0 : d.tt + m.stp;
+    d.seg += m.sw ? 1 + m.hop2 : 0;
+    d.klen = m.sw ? d.klen0 : d.klen - (m.stp ? (uint32_t)KVBLK * d.rs2 : 0u);
+  } else if (part == 2) {
+    d.kseg0 = m.sw ? d.kseg0 + (m.hop2 ? 2 * d.kseg : d.kseg) : d.kseg0;
+  } else if (part == 3) {
+    d.vseg0 = m.sw ? d.vseg0 + (m.hop2 ? 2 * d.vseg : d.vseg) : d.vseg0;
+  } else {
+    const char* kstep = d.k + (m.stp ? (int64_t)KVBLK * d.rs2 : (int64_t)0);
+    const char* vstep = d.v + (m.stp ? KVBLK * 2 : 0);
+    d.k = m.sw ? d.kseg0 : kstep;
+    d.v = m.sw ? d.vseg0 : vstep;
+  }
+}
+
+template <int ST, bool MULTI, bool TIMING>
 __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4], const int (&vaddr)[2], const mfma_bf16x8 (&qf)[4][4],
                                           mfma_bf16x8 (&kf)[4][4], mfma_bf16x8 (&vf)[8][2], QH& a, QH& b, int kv_rem, int lg,
-                                          char* smem_rw, Dma& dma) {
+                                          char* smem_rw, Dma& dma, int& cur_tt, int tps, uint64_t* stamp, bool rec) {
   constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
-  // the non-MFMA work of new gap G: g = G >> 1 is attention_w64q.hip's gap, sub-gap 0 carries its exp2, sub-gap 1 the bookkeeping of
-  // the NEXT exp2 (pack / sums of the pair before it), the fragment reads and the DMA pieces
+  int adv_ = 0;
+  uint32_t kb_ = 0;
+  MultiStep ms_ = {};
+  // the non-MFMA work of new gap G: g = G >> 1 is attention_w64q.hip's gap; the even sub-gap carries its exp2 and one row-sum add
+  // (MFMA + transcendental + add = the gap's four issue slots), the odd one the pack of a finished pair, the fragment reads and the
+  // DMA pieces
 #define N16_GAP(G)                                                                                                  \
   do {                                                                                                              \
-    const int g_ = (G) >> 1, g1_ = g_ + 1;                                                                          \
-    if (((G) & 1) == 0) {                                                                                           \
+    const int g_ = (G) >> 1;                                                                                        \
+    if (((G) & 1) == 0) {                                                /* exp2 + the previous score's row-sum add */  \
       if (g_ >= 4 && g_ <= 18) exp16(b, g_ + 13, kv_rem, lg);            /* q-half b, tile t-1: scores 17..31 */       \
       if (g_ >= 19 && g_ <= 50) exp16(a, g_ - 19, kv_rem, lg);           /* q-half a, tile t */                        \
       if (g_ >= 51) exp16(b, bk0(g_), kv_rem, lg);                       /* q-half b, tile t: scores 0..16 */          \
-    } else {                                                                                                        \
-      if (g_ >= 56 && ((g_ - 56) & 1) == 0) { book16(b, bk0(g_) + 1); exp16(b, bk0(g_) + 1, kv_rem, lg); }           \
-      if (g_ == 19) tail16(b, 0);                                                                                   \
-      if (g_ == 20) tail16(b, 1);                                                                                   \
-      if (g_ == 51) tail16(a, 0);                                                                                   \
-      if (g_ == 52) tail16(a, 1);                                                                                   \
-      if (g1_ >= 4 && g1_ <= 18) book16(b, g1_ + 13);                                                               \
-      if (g1_ >= 19 && g1_ <= 50) book16(a, g1_ - 19);                                                              \
-      if (g1_ >= 51 && g1_ <= 63) book16(b, bk0(g1_));                                                              \
     }                                                                                                               \
     if ((G) >= 41 && (G) <= 55 && (((G) - 41) & 1) == 0) {               /* V^T(t) fragment (dt, 0): last read by PV_b's MFMA 8 + dt */ \
       const int dt = ((G) - 41) >> 1;                                                                                \
       vf[dt][0] = *(lds_frag*)(smem + (VB + dt * 2048) + vaddr[0]);                                                  \
     }                                                                                                               \
-    if ((G) >= 57 && (G) <= 64) {                                        /* V^T(t) fragment (dt, 1): last read by MFMA 24 + dt */ \
-      const int dt = (G) - 57;                                                                                       \
+    if ((G) >= 57 && (G) <= 71 && (((G) - 57) & 1) == 0) {               /* V^T(t) fragment (dt, 1): last read by MFMA 24 + dt */ \
+      const int dt = ((G) - 57) >> 1;                                                                                \
       vf[dt][1] = *(lds_frag*)(smem + (VB + dt * 2048) + vaddr[1]);                                                  \
     }                                                                                                               \
     if ((G) >= 67 && (G) <= 97 && (((G) - 67) & 1) == 0) {               /* K(t+1) fragment (kt, ks): last read by S_b's MFMA 8 ks + 2 kt + 1 */ \
@@ -163,7 +174,35 @@ __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4]
       const int pc = ((G) - 3) >> 2;                                     /* DMA pieces K0 V0 K1 V1 ... of tile t+2 */  \
       dma_piece_i<DST>(smem_rw, dma, (pc & 1) * 4 + (pc >> 1));                                                      \
     }                                                                                                               \
+    if (((G) & 1) == 1) {                                                /* the pack of a finished pair (behind the gap's reads: no wait-state nop) */ \
+      if (g_ >= 4 && g_ <= 18 && ((g_ + 13) & 1)) pack16(b, g_ + 13);                                               \
+      if (g_ == 18) tail16(b);                                                                                      \
+      if (g_ >= 19 && g_ <= 50 && ((g_ - 19) & 1)) pack16(a, g_ - 19);                                              \
+      if (g_ == 50) tail16(a);                                                                                      \
+      if (g_ >= 51 && (bk0(g_) & 1)) pack16(b, bk0(g_));                                                            \
+      if (g_ >= 56 && ((g_ - 56) & 1) == 0) {                            /* the second exp2 of an old even gap 56..62 */ \
+        exp16(b, bk0(g_) + 1, kv_rem, lg);                                                                          \
+        if ((bk0(g_) + 1) & 1) pack16(b, bk0(g_) + 1);                                                              \
+      }                                                                                                             \
+    }                                                                                                               \
+    /* the DMA stream's step to tile t+2, in the three empty gaps behind the barrier (in one piece hipcc sinks it into a single gap: */ \
+    /* ~12 scalar instructions = 50 cycles in front of one MFMA); the pieces below (gaps 3..31) fetch from the stepped stream */       \
+    if (!MULTI && (G) == 0) {                                            /* plain integer arithmetic: a bool select travels through a lane mask */ \
+      const int lo_ = dma.left;                                                                                                    \
+      dma.left = lo_ > 2 ? lo_ - 1 : 1;                                  /* = lo - (lo > 1) for lo >= 1 */                           \
+      adv_ = lo_ - dma.left;                                                                                                       \
+      kb_ = (uint32_t)adv_ * ((uint32_t)KVBLK * dma.rs2);                                                                          \
+    }                                                                                                                              \
+    if (!MULTI && (G) == 1) { dma.k += kb_; dma.klen -= kb_; }                                                                     \
+    if (!MULTI && (G) == 2) { dma.v += adv_ * (KVBLK * 2); }                                                                        \
+    if ((G) == 4) { const int n_ = cur_tt + 1; cur_tt = n_ == tps ? 0 : n_; }  /* the tile counter of the ragged-tail test */       \
+    /* the segment walk (sequence parallelism), five parts over the three gaps in front of the first piece */                         \
+    if (MULTI && (G) == 0) { multi_step16(dma, ms_, 0); multi_step16(dma, ms_, 1); }                                                 \
+    if (MULTI && (G) == 1) { multi_step16(dma, ms_, 2); multi_step16(dma, ms_, 3); }                                                 \
+    if (MULTI && (G) == 2) multi_step16(dma, ms_, 4);                                                                               \
+    if (TIMING && rec && ((G) & 7) == 7) stamp[3 + ((G) >> 3)] = __builtin_amdgcn_s_memtime();  /* tuning build: one stamp per 8 gaps */ \
   } while (0)
+  if (TIMING && rec) stamp[2] = __builtin_amdgcn_s_memtime();
 #pragma unroll
   for (int i = 0; i < 32; ++i) {  // ---- A: S_a = K Q_a^T
     qk_step16(a, kf, qf, 0, i); SB();
@@ -176,8 +215,6 @@ __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4]
     N16_GAP(32 + i);
     SB();
   }
-  dma_advance<MULTI>(dma);
-  SB();
 #pragma unroll
   for (int i = 0; i < 32; ++i) {  // ---- C: S_b = K Q_b^T
     qk_step16(b, kf, qf, 2, i); SB();
@@ -225,12 +262,14 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
                                                        int nseg, int64_t k_seg_stride, int64_t vt_seg_stride,
                                                        const float* __restrict__ kmax2, int* __restrict__ wg_flags,
                                                        float* __restrict__ raw, int skip_seg) {
+  constexpr bool TIMING = (FLAGS & 1) != 0;  // s_memtime stamps of tile 300 of workgroup 0 -> first 160 B of O (tuning build only, -DW64Q_TIMING)
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
   constexpr bool RAW_OUT = (FLAGS & 16) != 0, CARRY_IN = (FLAGS & 32) != 0;
   constexpr bool MULTI = (FLAGS & 64) != 0;
   constexpr int WAVE_RAW = 2 * (64 * 64 + 128), WG_RAW = 4 * WAVE_RAW;  // floats: per half 64 accumulators x 64 lanes + 2 x 64 row-sum shares
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];    // [K stages][V^T stages] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
+  uint64_t stamp[20] = {};
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -295,11 +334,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   Dma dma;
   dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, skip_seg, /*k_rows_16x16=*/true);
   int cur_tt = 0;
-  auto next_kv_rem = [&]() {
-    const int rem = Lk32 - cur_tt * KVBLK;
-    if (++cur_tt == tps) cur_tt = 0;
-    return rem;
-  };
+  // valid kv rows from the start of the tile being consumed to the end of its segment: Lk - cur_tt * 64 (cur_tt steps inside the tile)
 
   // ---- LDS fragment addresses: per-lane VGPR + compile-time immediates ------------------------------------------------------------
   int kaddr[4], vaddr[2];
@@ -358,7 +393,8 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   }
 
   dma_tile<0, MULTI>(smem, dma);
-  dma_tile<1, MULTI>(smem, dma);
+#pragma unroll
+  for (int I = 0; I < 8; ++I) dma_piece_i<1>(smem, dma, I);  // tile 1; the stream steps at the top of every tile of the loop, in front of its pieces
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -373,14 +409,17 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   int kv_rem_prev = KVBLK;
 #define W16N_STEP(J)                                                                                         \
   if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
+    const bool rec = TIMING && (t + (J) == 300);                                                             \
+    if (TIMING && rec) stamp[0] = __builtin_amdgcn_s_memtime();                                              \
     if (t + (J) > 0) {                                                                                       \
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile t+J+1 landed */                               \
       __builtin_amdgcn_s_barrier();                                                                          \
       asm volatile("" ::: "memory");                                                                         \
     }                                                                                                        \
     __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): every K fragment of this tile was read >= 30 gaps ago */ \
-    const int kv_rem = next_kv_rem();                                                                        \
-    tile_w16n<J, MULTI>(lds, kaddr, vaddr, qf, kf, vf, qa, qb2, kv_rem, lg, smem, dma);                      \
+    if (TIMING && rec) stamp[1] = __builtin_amdgcn_s_memtime();                                              \
+    const int kv_rem = Lk32 - cur_tt * KVBLK;                                                                \
+    tile_w16n<J, MULTI, TIMING>(lds, kaddr, vaddr, qf, kf, vf, qa, qb2, kv_rem, lg, smem, dma, cur_tt, tps, stamp, rec); \
     kv_rem_prev = kv_rem;                                                                                    \
   }
   for (int t = 0; t < ntile; t += NST) {
@@ -391,9 +430,11 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
 #undef W16N_STEP
   // drain: q-half b's last tile
 #pragma unroll
-  for (int k = 17; k < 32; ++k) { book16(qb2, k); exp16(qb2, k, kv_rem_prev, lg); }
-  tail16(qb2, 0);
-  tail16(qb2, 1);
+  for (int k = 17; k < 32; ++k) {
+    exp16(qb2, k, kv_rem_prev, lg);
+    if (k & 1) pack16(qb2, k);
+  }
+  tail16(qb2);
   asm volatile("s_nop 1" ::: "memory");
 #pragma unroll
   for (int i = 0; i < 32; ++i) pv_step16(qb2, vf, i);
@@ -453,6 +494,11 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
       *reinterpret_cast<uint4*>(obase + qr * rs + c * 8) = val;
     }
   }
+  if (TIMING && blockIdx.x == 0 && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+#pragma unroll
+    for (int k6 = 0; k6 < 20; ++k6) reinterpret_cast<uint64_t*>(O)[k6] = stamp[k6];
+  }
 }
 
 }  // namespace
@@ -474,6 +520,9 @@ int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const 
     W16N_CASE(6 | 64)
     W16N_CASE(2 | 4 | 16)
     W16N_CASE(2 | 4 | 32 | 64)
+#ifdef W64Q_TIMING
+    W16N_CASE(7)
+#endif
     default: return -1;
   }
 #undef W16N_CASE

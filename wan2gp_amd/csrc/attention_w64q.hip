@@ -792,7 +792,7 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   if (stamps) {  // stamps of the loop that runs: bounded if there is a pre-pass, else tracking
     static const bool diag = [] { const char* e = getenv("WAN_ATTN_DIAG"); return e && e[0] == '1'; }();
     if (kmax_scratch != nullptr && diag) { if (pre) W64Q_LAUNCH(15); else W64Q_LAUNCH(13); }
-    else if (kmax_scratch != nullptr) { if (pre) W64Q_LAUNCH(7); else W64Q_LAUNCH(5); }
+    else if (kmax_scratch != nullptr) { if (!(pre && W16N_TRY(7, nseg, k_seg_stride, vt_seg_stride, skip_seg))) { if (pre) W64Q_LAUNCH(7); else W64Q_LAUNCH(5); } }
     else { if (pre) W64Q_LAUNCH(3); else W64Q_LAUNCH(1); }
     WAN_LAUNCH_CHECK();
     return 0;
