@@ -140,6 +140,35 @@ def test_attention_bounded_tile_scalar_and_wait_instructions(tmp_path_factory):
         assert "ds_read_b128" not in ops[mf[49]:], "an LDS read in the last 15 MFMA gaps of the tile"
 
 
+def test_attention_w16n_tile_instruction_mix(tmp_path_factory):
+    """attention_w16n.hip (the shipped bounded self-attention loop since round 3, 16x16x32 MFMA): every instantiation without scratch
+    and with the whole accumulator file; between two barriers of the single-segment pre-scaled kernel (FLAGS 6) exactly one tile: 128
+    MFMAs, 64 v_exp_f32, 64 plain v_add_f32 (never packed), 32 v_cvt_pk_bf16_f32, 32 ds_read_b128, 8 LDS-DMA pieces, no max / compare /
+    permute, <= 6 s_waitcnt, <= 12 s_nop beside the DMA pieces' own, and no MFMA gap with more than 6 instructions (the scalar step of
+    the DMA stream is spread over the gaps behind the barrier)."""
+    asm = asm_of("attention_w16n", tmp_path_factory)
+    ks = kernels(asm, "attn_w16n_kernel")
+    assert len(ks) == 6
+    for name, (ops, meta) in ks.items():
+        assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256 and 96 * 1024 <= meta["LDSByteSize"] <= 97 * 1024, (name, meta)  # the ring + the workgroup vote
+    name = [n for n in ks if "ILi6E" in n][0]
+    ops = ks[name][0]
+    bars = [i for i, o in enumerate(ops) if o == "s_barrier"]
+    tiles = [ops[a:b] for a, b in zip(bars, bars[1:]) if sum(1 for o in ops[a:b] if o.startswith("v_mfma")) == 128]
+    assert len(tiles) >= 2                                           # the ring of three: two barrier-to-barrier spans inside the loop
+    for t in tiles:
+        c = collections.Counter(t)
+        assert c["v_mfma_f32_16x16x32_bf16"] == 128 and c["v_exp_f32_e32"] == 64 and c["v_cvt_pk_bf16_f32"] == 32, c
+        assert c["v_add_f32_e32"] + c["v_add_f32"] == 64 and c["v_pk_add_f32"] == 0, c
+        assert c["ds_read_b128"] == 32 and c["buffer_load_dwordx4"] == 8, c
+        assert not any(k.startswith(("v_max", "v_cmp", "v_permlane", "scratch_", "v_readfirstlane", "v_cndmask")) for k in c), c
+        assert c["s_waitcnt"] <= 6 and c["s_nop"] <= 8 + 12, c
+        mf = [i for i, o in enumerate(t) if o.startswith("v_mfma")]
+        gaps = [b - a - 1 for a, b in zip(mf, mf[1:])]
+        assert max(gaps) <= 6, gaps
+        assert len(t) <= 400, len(t)
+
+
 def test_gemm256m_registers_and_stage_instruction_mix(tmp_path_factory):
     """gemm256m.hip (the product GEMM since round 3, 16x16x32 MFMA): no scratch, 256 accumulators in the accumulator file, the
     whole LDS, and between two barriers of the main loop exactly one stage: 128 MFMAs, 32 ds_read_b128, 16 LDS-DMA pieces and

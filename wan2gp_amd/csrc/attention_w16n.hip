@@ -51,7 +51,13 @@ __device__ __forceinline__ void qk16(f32x4& d, const mfma_bf16x8& k, const mfma_
 __device__ __forceinline__ void pv16(f32x4& acc, const mfma_bf16x8& v, const mfma_bf16x8& p) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(v), "v"(p));
 }
-__device__ __forceinline__ void vadd16(float& acc, float x) { asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x)); }
+// A row-sum add: a plain add fenced by an empty asm on its result (two of them can then not be SLP-packed into a v_pk_add_f32, an
+// anti-lever beside MFMAs).  NOT an asm instruction: hipcc's hazard recognizer does not count inline asm as wait states, and the pack
+// that follows the add in its gap reads a transcendental's result -- behind an asm add it gets an s_nop (15 per tile), behind this none.
+__device__ __forceinline__ void vadd16(float& acc, float x) {
+  acc = acc + x;
+  asm volatile("" : "+v"(acc));
+}
 
 // score k = 0..31 of a half, in the order its P^T fragments are needed: f = k >> 3 (= 2 c + q tile), then kv tile parity, then register
 __device__ __forceinline__ float score(const QH& q, int k) {
@@ -75,20 +81,32 @@ __device__ __forceinline__ void mask_tail16(QH& q, int kv_rem, int g) {
         }
   }
 }
-// exp2 of score k, then the row-sum add of score k - 1 (one gap old: no transcendental -> VALU wait state; its register is the
-// other one of the pair).  Score 31's add is tail16, behind its exp2.
+// exp2 of score k.  The row-sum add of score k - 1 (sum16; its register is the other one of the pair) sits in the NEXT (odd) gap, in
+// front of the pack: MFMA + transcendental fill an even gap's 16 cycles by themselves (measured both ways: -DW16N_ADD_EVEN puts the
+// add behind the exp2).  Score 31's add is tail16.
+__device__ __forceinline__ void sum16(QH& q, int k) {
+  if (k < 1) return;
+  if ((k & 1) == 0) vadd16(q.l[((k - 1) >> 3) & 1][1], q.p1);
+  else vadd16(q.l[((k - 1) >> 3) & 1][0], q.p0);
+}
 __device__ __forceinline__ void exp16(QH& q, int k, int kv_rem, int g) {
   if (k == 0) mask_tail16(q, kv_rem, g);  // cold: only a segment's ragged last tile (zero-filled K rows -> s = 0 -> -inf)
   if ((k & 1) == 0) {
     q.p0 = __builtin_amdgcn_exp2f(score(q, k));
     asm volatile("" : "+v"(q.p0));
-    if (k >= 1) vadd16(q.l[((k - 1) >> 3) & 1][1], q.p1);
   } else {
     q.p1 = __builtin_amdgcn_exp2f(score(q, k));
     asm volatile("" : "+v"(q.p1));
-    vadd16(q.l[((k - 1) >> 3) & 1][0], q.p0);
   }
+#ifdef W16N_ADD_EVEN
+  sum16(q, k);
+#endif
 }
+#ifdef W16N_ADD_EVEN
+#define SUM16_ODD(Q, K)
+#else
+#define SUM16_ODD(Q, K) sum16(Q, K)
+#endif
 // behind exp2 of the ODD score k (at least one VALU later): pair k >> 1 -> its P^T register
 __device__ __forceinline__ void pack16(QH& q, int k) {
   const int j = k >> 1;
@@ -170,18 +188,19 @@ __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4]
       const int r = ((G) - 67) >> 1, ks = r >> 2, kt = r & 3;                                                        \
       kf[kt][ks] = *(lds_frag*)(smem + (KN + kt * 4096) + kaddr[ks]);                                                \
     }                                                                                                               \
-    if ((G) >= 3 && (G) <= 31 && (((G) - 3) & 3) == 0) {                                                            \
-      const int pc = ((G) - 3) >> 2;                                     /* DMA pieces K0 V0 K1 V1 ... of tile t+2 */  \
+    if (((G) >= 3 && (G) <= 7) || (G) == 11 || (G) == 19 || (G) == 27) {  /* DMA pieces K0 V0 K1 V1 ... of tile t+2: five in the gaps behind */ \
+      const int pc = (G) <= 7 ? (G) - 3 : 5 + (((G) - 11) >> 3);         /* the barrier that carry nothing else, three beside row-sum adds */ \
       dma_piece_i<DST>(smem_rw, dma, (pc & 1) * 4 + (pc >> 1));                                                      \
     }                                                                                                               \
     if (((G) & 1) == 1) {                                                /* the pack of a finished pair (behind the gap's reads: no wait-state nop) */ \
-      if (g_ >= 4 && g_ <= 18 && ((g_ + 13) & 1)) pack16(b, g_ + 13);                                               \
+      if (g_ >= 4 && g_ <= 18) { SUM16_ODD(b, g_ + 13); if ((g_ + 13) & 1) pack16(b, g_ + 13); }                    \
       if (g_ == 18) tail16(b);                                                                                      \
-      if (g_ >= 19 && g_ <= 50 && ((g_ - 19) & 1)) pack16(a, g_ - 19);                                              \
+      if (g_ >= 19 && g_ <= 50) { SUM16_ODD(a, g_ - 19); if ((g_ - 19) & 1) pack16(a, g_ - 19); }                   \
       if (g_ == 50) tail16(a);                                                                                      \
-      if (g_ >= 51 && (bk0(g_) & 1)) pack16(b, bk0(g_));                                                            \
+      if (g_ >= 51) { SUM16_ODD(b, bk0(g_)); if (bk0(g_) & 1) pack16(b, bk0(g_)); }                                 \
       if (g_ >= 56 && ((g_ - 56) & 1) == 0) {                            /* the second exp2 of an old even gap 56..62 */ \
         exp16(b, bk0(g_) + 1, kv_rem, lg);                                                                          \
+        SUM16_ODD(b, bk0(g_) + 1);                                                                                  \
         if ((bk0(g_) + 1) & 1) pack16(b, bk0(g_) + 1);                                                              \
       }                                                                                                             \
     }                                                                                                               \
@@ -195,7 +214,7 @@ __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4]
     }                                                                                                                              \
     if (!MULTI && (G) == 1) { dma.k += kb_; dma.klen -= kb_; }                                                                     \
     if (!MULTI && (G) == 2) { dma.v += adv_ * (KVBLK * 2); }                                                                        \
-    if ((G) == 4) { const int n_ = cur_tt + 1; cur_tt = n_ == tps ? 0 : n_; }  /* the tile counter of the ragged-tail test */       \
+    if (MULTI && (G) == 4) { const int n_ = cur_tt + 1; cur_tt = n_ == tps ? 0 : n_; }  /* the segment's tile counter (ragged-tail test) */ \
     /* the segment walk (sequence parallelism), five parts over the three gaps in front of the first piece */                         \
     if (MULTI && (G) == 0) { multi_step16(dma, ms_, 0); multi_step16(dma, ms_, 1); }                                                 \
     if (MULTI && (G) == 1) { multi_step16(dma, ms_, 2); multi_step16(dma, ms_, 3); }                                                 \
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     }                                                                                                        \
     __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): every K fragment of this tile was read >= 30 gaps ago */ \
     if (TIMING && rec) stamp[1] = __builtin_amdgcn_s_memtime();                                              \
-    const int kv_rem = Lk32 - cur_tt * KVBLK;                                                                \
+    const int kv_rem = Lk32 - (MULTI ? cur_tt : t + (J)) * KVBLK;                                            \
     tile_w16n<J, MULTI, TIMING>(lds, kaddr, vaddr, qf, kf, vf, qa, qb2, kv_rem, lg, smem, dma, cur_tt, tps, stamp, rec); \
     kv_rem_prev = kv_rem;                                                                                    \
   }
@@ -432,6 +451,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int k = 17; k < 32; ++k) {
     exp16(qb2, k, kv_rem_prev, lg);
+    SUM16_ODD(qb2, k);
     if (k & 1) pack16(qb2, k);
   }
   tail16(qb2);
