@@ -1,6 +1,6 @@
 // bf16 NT GEMM for gfx950, fifth generation: gemm256k.hip's 256x256x64 tile, ring and sync structure on the 16x16x32 MFMA.
 // Out[y][x] = epilogue( sum_k Y[y][k] * X[x][k] + bias[x] ), same contract / epilogues as the other generations (bf16, bias per
-// column; the row-bias / fp16 forms stay with gemm256k.hip).
+// column, or per row with EPI NONE = the transposed V^T form; the fp16 forms stay with gemm256k.hip).
 //
 // Why (round 3, runs 68-71): these GEMMs run at the chip's power limit, where what a kernel is paid in is
 // energy per FLOP, not cycles.  rocprofv3 counters on tools/probes/mfma_power_probe.hip: a loop of v_mfma_f32_32x32x16_bf16 fed by
@@ -76,7 +76,7 @@ __device__ uint64_t g256m_stamps[16];  // tuning aid: s_memtime stamps of workgr
 #define M_STAMP(I)
 #endif
 
-template <int EPI>
+template <int EPI, bool BIAS_ROWS>
 __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict__ Y, int64_t ldy, int64_t YM,
                                                        const bf16_t* __restrict__ X, int64_t ldx, int64_t XN, int K,
                                                        bf16_t* __restrict__ Out, int64_t ldo, const bf16_t* __restrict__ bias,
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
     if (yr > YM - 1) yr = YM - 1;  // ragged tile: re-read the last row (its results are never stored)
     yofs[i] = (uint32_t)((yr - y0) * ldy * 2 + lch * 16);
     const int slab = row >> 7, t = (row >> 4) & 7, n = row & 15;
-    const int64_t xr = x0 + slab * 128 + 8 * n + t;  // the launcher requires XN % 256 == 0
+    int64_t xr = x0 + slab * 128 + 8 * n + t;
+    if (xr > XN - 1) xr = XN - 1;  // ragged x edge (the row-bias / V^T form: x = tokens): re-read the last row, its columns are never stored
     xofs[i] = (uint32_t)((xr - x0) * ldx * 2 + lch * 16);
   }
   const char* ybase = reinterpret_cast<const char*>(Y + y0 * ldy);  // next Y unit to fetch
@@ -253,9 +254,12 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
     const __amdgpu_buffer_rsrc_t rdesc =
         __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == WAN_EPI_GATE_RES ? R : Out) + y0 * ldo + x0), 0, (int)onum, 0x00020000);
     const uint32_t row_lane = (uint32_t)(wy * 128) + 4u * ge;
-    const uint32_t lane_off = row_lane * ldo2 + colb;
+    // a lane's 8 columns are inside the matrix or outside as a whole (the launcher requires XN % 8 == 0); outside: an offset past
+    // num_records, the stores are dropped like the rows past the matrix
+    const bool col_in = x0 + wx * 128 + 8 * (int64_t)ne + 8 <= XN;
+    const uint32_t lane_off = col_in ? row_lane * ldo2 + colb : 0x80000000u;
     float bcol[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (bias != nullptr) unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(bias + x0) + colb), bcol);
+    if (!BIAS_ROWS && bias != nullptr) unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(bias + x0) + colb), bcol);
     // gated residual: gate row = rnd16(mod[gate] + e[batch(row)][gate]) (model.py:658-660).  A 256-row tile touches at most two
     // batches (the launcher requires rows_per_batch >= 256: tokens per stream / per frame): both gate rows are fetched once.
     float gA[8], gB[8];
@@ -280,34 +284,42 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
       }
     }
     typedef unsigned int g256m_st4 __attribute__((__vector_size__(16)));
-    // 8 chunks (y tiles) of 4 rows: the residual rows of chunk a + 1 are requested before chunk a is converted
+    // 8 chunks (y tiles) of 4 rows
     auto rload = [&](int a, int i) -> uint4 {
       return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rdesc, (int)(lane_off + (uint32_t)(a * 16 + i) * ldo2), 0, 0));
     };
-    uint4 rq[4] = {}, rn[4] = {};
+    // residual rows of chunks a + 1 and a + 2 are in flight while chunk a is converted (the fragment registers are dead by now:
+    // three chunks = 48 VGPRs); with one chunk ahead the gated epilogue was latency-bound (15-17k cycles against 5k plain)
+    uint4 rq[3][4] = {};
     if (EPI == WAN_EPI_GATE_RES) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rq[i] = rload(0, i);
+      for (int i = 0; i < 4; ++i) { rq[0][i] = rload(0, i); rq[1][i] = rload(1, i); }
     }
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
-      if (EPI == WAN_EPI_GATE_RES && a + 1 < 8) {
+      if (EPI == WAN_EPI_GATE_RES && a + 2 < 8) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rn[i] = rload(a + 1, i);
+        for (int i = 0; i < 4; ++i) rq[(a + 2) % 3][i] = rload(a + 2, i);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const uint32_t rit = (uint32_t)(a * 16 + i);  // row in the wave's 128, before the lane-group term
         float v[8];
+        float brow = 0.f;
+        if (BIAS_ROWS && bias != nullptr) {
+          int64_t yr = y0 + row_lane + rit;
+          if (yr > YM - 1) yr = YM - 1;
+          brow = bf2f(bias[yr]);
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-          v[t] = acc[a][t][i] * out_scale + bcol[t];
+          v[t] = acc[a][t][i] * out_scale + (BIAS_ROWS ? brow : bcol[t]);
           // nn.Linear output is a 16-bit tensor: GELU sees the rounded value; otherwise the pack below is that rounding
           if (EPI == WAN_EPI_GELU_TANH) v[t] = g256m_gelu_tanh(rbf(v[t]));
         }
         if (EPI == WAN_EPI_GATE_RES) {
           float rv[8];
-          unpack8(rq[i], rv);
+          unpack8(rq[a % 3][i], rv);
           if (gated) {
             const bool second = row_lane + rit >= rb;
 #pragma unroll
@@ -321,10 +333,6 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g256m_st4, w), odesc, (int)(lane_off + rit * ldo2), 0, 0);
         if (EPI == WAN_EPI_GELU_TANH) __builtin_amdgcn_sched_barrier(0);  // 8 GELUs' temporaries at a time
       }
-      if (EPI == WAN_EPI_GATE_RES) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rq[i] = rn[i];
-      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -335,12 +343,13 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
 
 // Returns -1 when the problem does not fit this kernel (the caller falls back to gemm256k.hip and the generations before it),
 // else the launch status.
-template <int EPI>
+template <int EPI, bool BIAS_ROWS>
 int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                     int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                     int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale) {
-  if (K % M_BK != 0 || XN % M_BN != 0) return -1;
-  if (ldo % 8 != 0 || ((uintptr_t)Out & 15) != 0 || (bias != nullptr && ((uintptr_t)bias & 15) != 0)) return -1;  // 16-byte stores / bias loads
+  if (K % M_BK != 0 || XN % 8 != 0) return -1;             // a lane stores 8 columns or none
+  if (!BIAS_ROWS && XN % M_BN != 0) return -1;             // column bias / gate rows are fetched 16 bytes per lane without an edge form
+  if (ldo % 8 != 0 || ((uintptr_t)Out & 15) != 0 || (!BIAS_ROWS && bias != nullptr && ((uintptr_t)bias & 15) != 0)) return -1;  // 16-byte stores / bias loads
   // 32-bit DMA offsets: a tile's 256 rows times the row pitch in bytes, plus the row itself; 31-bit store offsets
   if (256 * ldy * 2 + (int64_t)K * 2 >= ((int64_t)1 << 32) || 256 * ldx * 2 + (int64_t)K * 2 >= ((int64_t)1 << 32)) return -1;
   if (256 * ldo * 2 + 512 >= ((int64_t)1 << 31)) return -1;
@@ -348,21 +357,22 @@ int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
     if (((uintptr_t)R & 15) != 0) return -1;
     if (gate_idx >= 0 && (rows_per_batch < M_BM || ((uintptr_t)mod & 15) != 0 || ((uintptr_t)e & 15) != 0)) return -1;
   }
-  const int64_t ty = (YM + M_BM - 1) / M_BM, tx = XN / M_BN;
+  const int64_t ty = (YM + M_BM - 1) / M_BM, tx = (XN + M_BN - 1) / M_BN;
   if (ty * tx >= ((int64_t)1 << 31)) return -1;
-  const int group = 4;  // y tiles per group of the tile order (gemm256k.hip)
-  hipLaunchKernelGGL((gemm256m_kernel<EPI>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R,
+  const int group = BIAS_ROWS ? 8 : 4;  // y tiles per group of the tile order (gemm256k.hip)
+  hipLaunchKernelGGL((gemm256m_kernel<EPI, BIAS_ROWS>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R,
                      mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, out_scale, group);
   WAN_LAUNCH_CHECK();
   return 0;
 }
 
-#define G256M_INST(EPI)                                                                                                            \
-  template int wan_gemm256m_try<EPI>(const bf16_t*, int64_t, int64_t, const bf16_t*, int64_t, int64_t, int, bf16_t*, int64_t,      \
-                                     const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int64_t, hipStream_t, float);
-G256M_INST(WAN_EPI_NONE)
-G256M_INST(WAN_EPI_GELU_TANH)
-G256M_INST(WAN_EPI_GATE_RES)
+#define G256M_INST(EPI, BR)                                                                                                        \
+  template int wan_gemm256m_try<EPI, BR>(const bf16_t*, int64_t, int64_t, const bf16_t*, int64_t, int64_t, int, bf16_t*, int64_t,  \
+                                         const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int64_t, hipStream_t, float);
+G256M_INST(WAN_EPI_NONE, false)
+G256M_INST(WAN_EPI_GELU_TANH, false)
+G256M_INST(WAN_EPI_GATE_RES, false)
+G256M_INST(WAN_EPI_NONE, true)   // the transposed / V^T form: bias per output row, x = tokens (ragged)
 #undef G256M_INST
 
 #ifdef G256M_TIMING

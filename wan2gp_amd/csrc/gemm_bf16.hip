@@ -256,7 +256,7 @@ int wan_gemm256p_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
                      int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
 // sixth-generation kernel (gemm256m.hip): gemm256k's tile on the 16x16x32 MFMA, register-direct epilogue; bf16, bias per column
-template <int EPI>
+template <int EPI, bool BIAS_ROWS>
 int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                      int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                      int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
@@ -269,9 +269,9 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
   const int64_t tx = (XN + BN - 1) / BN;
   const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= 256;
 #ifndef WAN_GEMM_NO_MI16  // (defined only for the A/B library libwanhip_k.so: gemm256k on every shape)
-  if constexpr (!BIAS_ROWS && !F16) {
+  if constexpr (!F16 && (!BIAS_ROWS || EPI == WAN_EPI_NONE)) {
     if (many_tiles) {
-      const int rc = wan_gemm256m_try<EPI>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale);
+      const int rc = wan_gemm256m_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale);
       if (rc >= 0) return rc;
     }
   }
