@@ -406,10 +406,14 @@ def main():
         if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
             log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
             out["secondary"] = secondary_1p3b(vae)
+        if world == 1 and args.simulate_world and args.workload in ("14B-720p", "i2v-14B-720p"):
+            log("simulated sequence-parallel ranks: " + args.simulate_world)
+            out["simulated_scaling"] = simulate_world([int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
+                                                      latents, args.warmup, dt / args.steps, cfg, L)
         cpu_thread, cpu_box = None, {}
         if not args.no_cpu_baseline and world == 1:
-            # on the host cores WHILE the GPU runs the remaining blocks -- long kernels, one launching thread; the launch-dense
-            # 1.3B secondary run above is done by now (busy cores cost it 5-8 %): the CPU leg costs ~2 minutes
+            # on the host cores WHILE the GPU runs the config-5 block -- long kernels, one launching thread; the launch-dense blocks
+            # above (the 1.3B secondary run, the simulated ranks) are done by now (128 busy host threads cost them 5-8 %): the CPU leg costs ~2 minutes
             import threading
             log("cpu_baseline: config-1 oracle step + VAE decode on the host cores (in the background)")
             fl_main = 2 * forward_flops(cfg, L)
@@ -421,10 +425,6 @@ def main():
                     cpu_box["r"] = {"error": repr(ex)}
             cpu_thread = threading.Thread(target=_cpu, daemon=True)
             cpu_thread.start()
-        if world == 1 and args.simulate_world and args.workload in ("14B-720p", "i2v-14B-720p"):
-            log("simulated sequence-parallel ranks: " + args.simulate_world)
-            out["simulated_scaling"] = simulate_world([int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
-                                                      latents, args.warmup, dt / args.steps, cfg, L)
         if world == 1 and not args.no_config5 and args.workload == "14B-720p" and not args.fp8:
             log("config5: i2v 14B, scaled-fp8 weights, VAE encode + 3 steps + decode")
             model = model2 = None                       # the bf16 experts of the main workload are done

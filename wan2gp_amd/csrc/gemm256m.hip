@@ -133,16 +133,6 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
   auto y_advance = [&]() { const bool ok = ky + 1 < nk; ybase += ok ? M_BK * 2 : 0; ky += ok ? 1 : 0; };
   auto x_advance = [&]() { const bool ok = kx + 1 < nk; xbase += ok ? M_BK * 2 : 0; kx += ok ? 1 : 0; };
 
-  f32x4 acc[8][8];  // [y tile][x tile], accumulator file
-#pragma unroll
-  for (int a = 0; a < 8; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
-      asm volatile("" : "+a"(acc[a][b]));
-    }
-
   // ---- fragment addresses: k-step ks (0, 1) reads logical chunk 4 ks + g; (row >> 1) & 7 == (n >> 1) & 7 for every tile ------
   // A ds_read carries a 16-bit immediate; the ring is 160 KB.  One base register per (operand, k-step, 64-KB window), opaque to
   // the compiler, and every fragment read is base + immediate: no address arithmetic inside the stages.
@@ -180,6 +170,16 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
 #pragma unroll
   for (int p = 0; p < 8; ++p) x_piece(3, p);
   x_advance();
+  f32x4 acc[8][8];  // [y tile][x tile], accumulator file; zeroed while the first stages are in flight (256 writes: ~1k cycles)
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+      asm volatile("" : "+a"(acc[a][b]));
+    }
+
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage 0 landed, stage 1 may be in flight
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
