@@ -33,7 +33,19 @@ __device__ __forceinline__ void load_row(uint4 (&r)[NCH], const bf16_t* x, int l
   }
 }
 
-template <int NCH, bool PERSIST>
+// x0' = x0*cos0 - x1*sin0 ; x1' = x1*cos1 + x0*sin1 -- fp32, the four products rounded SEPARATELY (posemb_layers.py:251-267: no fused
+// multiply-add), one bf16 rounding by the caller.  Written on pairs so that hipcc emits two v_pk_mul_f32 and one v_pk_add_f32.
+__device__ __forceinline__ wan_f32x2 rope_pair(wan_f32x2 y, float c0, float c1, float s0, float s1) {
+#pragma clang fp contract(off)
+  const wan_f32x2 cc = {c0, c1};
+  const wan_f32x2 ss = {-s0, s1};
+  const wan_f32x2 ys = {y.y, y.x};
+  const wan_f32x2 p = y * cc;
+  const wan_f32x2 q = ys * ss;      // (-x1*sin0, x0*sin1): the sign flip of a product is exact
+  return p + q;
+}
+
+template <int NCH, bool PERSIST, bool ROPE>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
     bf16_t* __restrict__ q, bf16_t* __restrict__ k, const bf16_t* __restrict__ wq,
     const bf16_t* __restrict__ wk, const float* __restrict__ cosT, const float* __restrict__ sinT,
@@ -72,7 +84,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
     // the lane's column inside the 128-wide head is the same for all of its chunks (c = lane + 64 i, 64*8 = 0 mod 128):
     // ONE cos / sin fetch per row instead of one per chunk (the kernel was VMEM-issue bound: 6 loads per 16 B of data)
     float cs[8], sn[8];
-    if (cosT != nullptr) {
+    if (ROPE) {
       const int hc = (lane * 8) & 127;
       const float4* cp = reinterpret_cast<const float4*>(cosT + pos * 128 + hc);
       const float4* sp = reinterpret_cast<const float4*>(sinT + pos * 128 + hc);
@@ -84,27 +96,30 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
       if (c < nchunk) {
-        uint4 wraw = *reinterpret_cast<const uint4*>(w + c * 8);
-        float wf[8], v[8];
-        unpack8(wraw, wf);
-        unpack8(raw[i], v);
-        float y[8];
+        // Pairs of elements all the way (round 3): the two bf16 of a 32-bit word stay together through both roundings, the rotation and
+        // the pack, so that every multiply / add is ONE packed-f32 instruction per pair and every rounding one v_cvt_pk_bf16_f32 per
+        // pair (the scalar form rounded with cvt_pk(f, 0): 144 VALU instructions per 16-byte chunk, this form ~90).  Same operations
+        // per element in the same order: bit-identical results (tests/test_gpu_ops.py).
+        const uint4 wraw = *reinterpret_cast<const uint4*>(w + c * 8);
+        const uint32_t ww[4] = {wraw.x, wraw.y, wraw.z, wraw.w};
+        const uint32_t vw[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+        uint32_t ow[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = rbf(rbf(v[j] * r) * wf[j]);  // x *= rsqrt ; x *= weight
-        if (cosT != nullptr) {
-#pragma unroll
-          for (int j = 0; j < 8; j += 2) {
-            // x0' = x0*cos0 - x1*sin0 ; x1' = x1*cos1 + x0*sin1   (fp32, one rounding to bf16)
-            const float a = y[j], b = y[j + 1];
-            y[j] = __fmul_rn(a, cs[j]) - __fmul_rn(b, sn[j]);
-            y[j + 1] = __fmul_rn(b, cs[j + 1]) + __fmul_rn(a, sn[j + 1]);
-          }
+        for (int pq = 0; pq < 4; ++pq) {
+          wan_f32x2 v2 = {__uint_as_float(vw[pq] << 16), __uint_as_float(vw[pq] & 0xffff0000u)};
+          const wan_f32x2 w2 = {__uint_as_float(ww[pq] << 16), __uint_as_float(ww[pq] & 0xffff0000u)};
+          v2 = v2 * r;                                                 // x *= rsqrt
+          uint32_t u = pack2bf(v2.x, v2.y);                            // bf16 rounding
+          v2 = wan_f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)} * w2;  // x *= weight
+          u = pack2bf(v2.x, v2.y);
+          wan_f32x2 y2 = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+          if (ROPE) y2 = rope_pair(y2, cs[2 * pq], cs[2 * pq + 1], sn[2 * pq], sn[2 * pq + 1]);
+          y2 = y2 * oscale;                                            // (x * 1.0f is x: no select on a launch constant inside the row)
+          ow[pq] = pack2bf(y2.x, y2.y);
         }
-        if (oscale != 1.0f) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) y[j] *= oscale;
-        }
-        *reinterpret_cast<uint4*>(x + c * 8) = pack8(y);
+        uint4 o;
+        o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
+        *reinterpret_cast<uint4*>(x + c * 8) = o;
       }
     }
     if (!more) break;
@@ -497,11 +512,13 @@ extern "C" int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16*
     constexpr bool P = NCH >= 8;
     unsigned gx = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     if (P) {  // q and k rows share the resident slots (grid.y = 2): half the persistent width each
-      gx = persistent_blocks(rmsnorm_rope_kernel<NCH, P>, rows);
+      gx = cos ? persistent_blocks(rmsnorm_rope_kernel<NCH, P, true>, rows) : persistent_blocks(rmsnorm_rope_kernel<NCH, P, false>, rows);
       if (k && gx > 1) gx = (gx + 1) / 2;
     }
-    hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH, P>), dim3(gx, k ? 2 : 1), dim3(256), 0, as_stream(stream), q, k, wq, wk, cos,
-                       sin, rows, L, pos0, d, eps, q_scale);
+    if (cos) hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH, P, true>), dim3(gx, k ? 2 : 1), dim3(256), 0, as_stream(stream), q, k, wq, wk, cos,
+                                sin, rows, L, pos0, d, eps, q_scale);
+    else hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH, P, false>), dim3(gx, k ? 2 : 1), dim3(256), 0, as_stream(stream), q, k, wq, wk, cos,
+                            sin, rows, L, pos0, d, eps, q_scale);
   });
   WAN_LAUNCH_CHECK();
   return 0;
