@@ -210,6 +210,67 @@ __global__ __launch_bounds__(256) void ks(const u4* __restrict__ src, const char
   out[blockIdx.x * 256 + threadIdx.x] = sum;
 }
 
+// The attention tile's energy budget (round 3, run 89): 16x16x32 MFMAs with the kernel's LDS fragment traffic (32 ds_read_b128 per 128
+// MFMAs = twice the GEMM's bytes per FLOP) and, per MFMA pair, the softmax's vector work (one v_exp_f32, one v_add_f32, half a
+// v_cvt_pk_bf16_f32).  MODE bit 0: the fragment reads; bit 1: the vector work.
+template <int MODE>
+__global__ __launch_bounds__(256) void ka(const u4* __restrict__ src, float* __restrict__ out, int iters) {
+  __shared__ __attribute__((aligned(16))) u4 lds[4096 + 512];  // 72 KB
+  for (int i = threadIdx.x; i < 4096 + 512; i += 256) lds[i] = src[i & 4095];
+  __syncthreads();
+  const int lane = threadIdx.x;
+  bf8 a[2][8], b[8];
+  for (int i = 0; i < 8; ++i) {
+    a[0][i] = __builtin_bit_cast(bf8, src[(lane + 256 * i) & 4095]);
+    a[1][i] = __builtin_bit_cast(bf8, src[(lane + 256 * i + 64) & 4095]);
+    b[i] = __builtin_bit_cast(bf8, src[(lane + 256 * (8 + i)) & 4095]);
+  }
+  f4v acc[8][8];
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j)
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  float e[4] = {0.3f + lane * 1e-3f, -0.7f, 1.1f, -0.2f}, l = 0.f;
+  uint32_t pk = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // 64 MFMAs per q: 16 fragment reads (immediate offsets from one base register), 32 exps
+      uint32_t boff = lane + 64 * ((it + q) & 3);
+      asm volatile("" : "+v"(boff));
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[m >> 3][m & 7]) : "v"(a[q][m >> 3]), "v"(b[m & 7]));
+        __builtin_amdgcn_sched_barrier(0);
+        if ((MODE & 1) && (m & 3) == 1) {   // 16 reads per 64 MFMAs: 8 into the other A buffer, 8 into B
+          if (((m >> 2) & 1) == 0) a[q ^ 1][(m >> 3) & 7] = __builtin_bit_cast(bf8, lds[boff + 256 * (m >> 3)]);
+          else b[(m >> 3) & 7] = __builtin_bit_cast(bf8, lds[boff + 256 * (8 + (m >> 3)) + 32]);
+        }
+        if (MODE & 2) {
+          if ((m & 1) == 0) {
+            e[(m >> 1) & 3] = __builtin_amdgcn_exp2f(-e[((m >> 1) + 1) & 3]);   // stays in (0.5, 1): 2^-x of x in (0, 1)
+            asm volatile("" : "+v"(e[(m >> 1) & 3]));
+          } else {
+            l += e[((m >> 1) + 2) & 3];
+            asm volatile("" : "+v"(l));
+            if ((m & 3) == 3) {
+              typedef float f2v __attribute__((ext_vector_type(2)));
+              typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+              f2v t = {e[0], e[1]};
+              pk ^= __builtin_bit_cast(uint32_t, __builtin_convertvector(t, b2v));
+              asm volatile("" : "+v"(pk));
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float s = l + (float)pk;
+  for (int i = 0; i < 8; ++i)
+    for (int j = 0; j < 8; ++j)
+      for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static uint16_t bf16_of(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -301,6 +362,23 @@ int main() {
         if (hipGetLastError() != hipSuccess) printf("launch error\n");
         if (v.mfma) printf("%-44s %8.2f ms  %7.1f TFLOP/s  stream %5.2f TB/s into the CUs\n", v.name, ms, fl / ms / 1e9, v.stream ? bytes / ms / 1e9 : 0.0);
         else printf("%-44s %8.2f ms  stream %5.2f TB/s into the CUs\n", v.name, ms, bytes / ms / 1e9);
+      }
+  }
+  {  // the attention tile's energy budget
+    typedef void (*kfn)(const u4*, float*, int);
+    const kfn fs[4] = {ka<0>, ka<1>, ka<2>, ka<3>};
+    const char* nm[4] = {"AT0 16x16x32, registers only (asm, AGPR acc)", "AT1 + the attention tile's fragment reads", "AT2 + its softmax vector work (exp, add, cvt/2 per MFMA pair)", "AT3 + both"};
+    const int its = 120000;  // ~130 ms per kernel: the power-limited state (a 27-ms kernel still runs at 2.04 GHz)
+    const double fl = (double)cus * 4 * its * 128.0 * 16384.0;
+    for (int rep = 0; rep < 2; ++rep)
+      for (int v = 0; v < 4; ++v) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(fs[v], dim3(cus), dim3(256), 0, 0, src, out, its);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("%-66s %8.2f ms  %7.1f TFLOP/s\n", nm[v], ms, fl / ms / 1e9);
       }
   }
   return 0;
