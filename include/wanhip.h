@@ -423,7 +423,12 @@ int wan_dit_set_vace_layers(wan_ctx* ctx, const int* layers, int n);
  * vision features clip_fea [257, 1280] bf16 through img_emb (MLPProj, model.py:868-889, :1858-1859) and keeps the 257 image
  * tokens for the k_img / v_img branch of every block's cross-attention (WanI2VCrossAttention, model.py:448-499).  Must be
  * called before wan_dit_forward for such a model (the reference asserts clip_fea is not None, model.py:1547); the result
- * is kept in the context until the next call (the features do not depend on the step). */
+ * is kept in the context until the next call (the features do not depend on the step).
+ * flf2v_720p (a checkpoint that also registers img_emb.emb_pos [514, 1280], MLPProj(flf_pos_emb=True), model.py:878-887): clip_fea
+ * is [2 x 257, 1280] -- the start and the end image (any2video.py:949-950) --, the position embedding is added before the MLP,
+ * and the blocks see what the reference's split at 257 gives them (model.py:472-473): the first image's 257 tokens in the
+ * k_img / v_img branch, the second image's 257 tokens in front of the text tokens of the text branch.  Not together with
+ * normalized attention guidance. */
 int wan_dit_set_clip(wan_ctx* ctx, const wan_bf16* clip_fea, void* stream);
 
 /* wan_dit_forward with the reference's step-skipping caches (TeaCache / MagCache, model.py:1373-1482 thresholds,

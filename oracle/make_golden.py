@@ -32,7 +32,7 @@ def build_ref_model(ns, cfg: O.WanConfig, W, dtype):
     reference's dtype locks (model.py:1330-1371): patch_embedding + head fp32."""
     m = ns.M.WanModel(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads,
                       num_layers=cfg.num_layers, in_dim=cfg.in_dim, out_dim=cfg.out_dim, text_dim=cfg.text_dim,
-                      freq_dim=cfg.freq_dim, eps=cfg.eps,
+                      freq_dim=cfg.freq_dim, eps=cfg.eps, **({"flf": True} if cfg.flf else {}),
                       **({} if cfg.vace_layers is None else {"vace_layers": list(cfg.vace_layers), "vace_in_dim": cfg.vace_in_dim}))
     sd = {k: v.clone() for k, v in W.items()}
     missing, unexpected = m.load_state_dict(sd, strict=False)
@@ -94,7 +94,7 @@ def gen_forward(ns, name, f, h, w, tval):
     cfg = O.make_config(name)
     out = {"shape": np.array([f, h, w]), "t": np.array([tval])}
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
-    clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None
+    clip = O.synth_clip_fea(images=2 if cfg.flf else 1) if cfg.model_type == "i2v" else None
     vace = O.synth_vace_context(cfg, f, h, w) if cfg.vace_layers is not None else None
     t = torch.tensor([tval], dtype=torch.int64)
     # NOTE: only the reference's real bf16 plan is a valid golden.  Run "fp32 everywhere" the
@@ -120,7 +120,7 @@ def gen_forward(ns, name, f, h, w, tval):
         L = f * (h // 2) * (w // 2)
         hid = torch.randn(1, L, cfg.dim, generator=g).to(dtype)
         e0 = (0.5 * torch.randn(1, 6, cfg.dim, generator=g)).to(dtype)
-        cemb = (0.5 * torch.randn(1, 512 + (O.CLIP_TOKENS if cfg.model_type == "i2v" else 0), cfg.dim, generator=g)).to(dtype)
+        cemb = (0.5 * torch.randn(1, 512 + (O.CLIP_TOKENS * (2 if cfg.flf else 1) if cfg.model_type == "i2v" else 0), cfg.dim, generator=g)).to(dtype)
         freqs = ns.P.get_rotary_pos_embed((f, h, w))
         with torch.no_grad():
             bo = m.blocks[0](hid.clone(), e=e0, grid_sizes=(f, h // 2, w // 2), freqs=freqs, context=cemb)
@@ -238,6 +238,8 @@ def main():
         gen_forward(ns, "tiny_i2v21", 2, 8, 8, 731)
         gen_forward(ns, "tiny_vace", 2, 8, 8, 588)
         gen_forward(ns, "small", 3, 10, 14, 412)            # 4 heads, 3 layers, ragged token count L = 105
+    if "forward" in which or "flf2v" in which:
+        gen_forward(ns, "tiny_flf2v", 2, 8, 8, 644)          # Wan2.1 flf2v: two images' CLIP tokens + position embedding
     if "sched" in which:
         gen_sched(ns)
     if "sched2" in which:

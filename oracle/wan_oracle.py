@@ -50,6 +50,7 @@ class WanConfig:
     model_type: str = "t2v"
     vace_layers: Optional[Tuple[int, ...]] = None   # VACE: main-block indices that carry a context block (model.py:1178-1206)
     vace_in_dim: int = 96
+    flf: bool = False         # flf2v_720p: MLPProj(flf_pos_emb=True), clip_fea of TWO images (model.py:878-887, :1162)
 
     @property
     def head_dim(self):
@@ -70,6 +71,10 @@ CONFIGS = {
     # Wan2.1 i2v: CLIP image tokens through img_emb + the k_img / v_img cross-attention branch (model.py:448-499, :868-889)
     "i2v_14B": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, model_type="i2v"),
     "tiny_i2v21": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, in_dim=36, model_type="i2v"),
+    # Wan2.1 flf2v 720p (first + last frame): the i2v model with a position embedding on the CLIP tokens of two images; the second
+    # image's 257 tokens land in front of the TEXT tokens of the cross-attention (WanI2VCrossAttention splits at 257, model.py:472-473)
+    "flf2v_14B": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, model_type="i2v", flf=True),
+    "tiny_flf2v": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, in_dim=36, model_type="i2v", flf=True),
     # VACE (Wan2.1 VACE 14B: vace_layers 0,5,...,35; 1.3B: every second block): context blocks feeding hints into the main blocks
     "vace_14B": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, vace_layers=tuple(range(0, 40, 5))),
     "tiny_vace": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=3, vace_layers=(0, 2)),
@@ -131,6 +136,8 @@ def param_shapes(cfg: WanConfig) -> Dict[str, Tuple[int, ...]]:
         p["img_emb.proj.1.weight"] = (CLIP_DIM, CLIP_DIM); p["img_emb.proj.1.bias"] = (CLIP_DIM,)
         p["img_emb.proj.3.weight"] = (d, CLIP_DIM); p["img_emb.proj.3.bias"] = (d,)
         p["img_emb.proj.4.weight"] = (d,); p["img_emb.proj.4.bias"] = (d,)
+        if cfg.flf:
+            p["img_emb.emb_pos"] = (1, 2 * CLIP_TOKENS, CLIP_DIM)   # MLPProj(flf_pos_emb=True) (:878-881)
     p["head.modulation"] = (1, 2, d)
     p["head.head.weight"] = (cfg.out_dim * math.prod(cfg.patch_size), d)
     p["head.head.bias"] = (cfg.out_dim * math.prod(cfg.patch_size),)
@@ -370,8 +377,11 @@ def cross_attention(x, ctx, W, p, cfg: WanConfig, exact, nag=None):
 
 
 def img_emb(clip_fea, W):
-    """MLPProj.forward (model.py:868-889, no flf position embedding): LayerNorm(1280) -> Linear -> GELU(erf) -> Linear ->
-    LayerNorm(dim); torch.nn.LayerNorm's default eps 1e-5."""
+    """MLPProj.forward (model.py:868-889): [flf2v: the two images' tokens as one sequence + the position embedding (:884-887)] ->
+    LayerNorm(1280) -> Linear -> GELU(erf) -> Linear -> LayerNorm(dim); torch.nn.LayerNorm's default eps 1e-5."""
+    if "img_emb.emb_pos" in W:
+        bs, n, d = clip_fea.shape
+        clip_fea = clip_fea.reshape(-1, 2 * n, d).to(W["img_emb.emb_pos"].dtype) + W["img_emb.emb_pos"]
     x = F.layer_norm(clip_fea, (clip_fea.shape[-1],), W["img_emb.proj.0.weight"], W["img_emb.proj.0.bias"], 1e-5)
     x = F.gelu(_linear(x, W, "img_emb.proj.1"))
     x = _linear(x, W, "img_emb.proj.3")
@@ -787,10 +797,11 @@ def synth_inputs(cfg: WanConfig, f: int, h: int, w: int, seed: int = 42, text_to
     return lat, ctx.to(torch.bfloat16), ctx_null.to(torch.bfloat16), y
 
 
-def synth_clip_fea(seed: int = 9):
-    """CLIP ViT-H penultimate features as `clip_fea` [1, 257, 1280] bf16 (any2video.py feeds clip.visual output)."""
+def synth_clip_fea(seed: int = 9, images: int = 1):
+    """CLIP ViT-H penultimate features as `clip_fea` [images, 257, 1280] bf16 (any2video.py feeds clip.visual output; flf2v: the
+    start and the end image, :949-950)."""
     g = torch.Generator().manual_seed(seed)
-    return torch.randn(1, CLIP_TOKENS, CLIP_DIM, generator=g).to(torch.bfloat16)
+    return torch.randn(images, CLIP_TOKENS, CLIP_DIM, generator=g).to(torch.bfloat16)
 
 
 def synth_vace_context(cfg: WanConfig, f: int, h: int, w: int, seed: int = 13):

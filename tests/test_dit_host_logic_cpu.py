@@ -447,3 +447,72 @@ def test_per_frame_timesteps_need_whole_frame_shards(mock):
     assert rc == 1 and b"whole frames" in mock.wan_last_error()
     rc, calls, _ = m.forward(S=2, t_frames=[0.0, 637.0], sp=SpInfo(1, 2, 16, 16, cb, cw, None))
     assert rc == 0 and [round(cl[3][0]) for cl in calls if cl[0] == "sinusoid"] == [637]        # rank 1 embeds its own frame's timestep only
+
+
+def _clip_forward(L, m, S, nag=None, ctx_batches=None):
+    """forward of a Wan2.1 i2v / flf2v model (y given) on the recording mock; wan_dit_set_clip first."""
+    F, H, W = 2, 8, 8
+    nbytes = L.wan_dit_workspace_bytes(m.ctx, S, F, H, W, 1)
+    X = (c_void_p * S)(*[0x6000_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+    C = (c_void_p * S)(*[0x6100_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+    OUT = (c_void_p * S)(*[0x6200_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+    a = DitArgs(S, X, 637.0, C, 0x6600_0000_0000, 0x6300_0000_0000, 0x6310_0000_0000, OUT, F, H, W, WS, nbytes, None, None, None, None, None,
+                None, 1.0, None, 0, 0, None, None, *((0.0, 0.0, 0.0, None) if nag is None else (*nag, (c_int * S)(*ctx_batches))), None, 0, 0)
+    L.mock_reset()
+    rc = L.wan_dit_forward_ex(m.ctx, ctypes.byref(a), None)
+    return rc, [(c.name.decode(), list(c.p), list(c.i), list(c.f)) for c in (L.mock_get(i).contents for i in range(L.mock_count()))]
+
+
+def test_flf2v_clip_context_of_two_images(mock):
+    """flf2v_720p (model.py:878-887, :472-473): img_emb adds its position embedding to the 2 x 257 CLIP tokens and projects 514; the
+    blocks' image branch takes the first 257 of them, the text branch [the other 257 ; the 512 text tokens] -- assembled once per
+    forward, K / V^T projected from 769 rows, V^T row pitch 832 with zeroed pad columns.  The plain i2v model keeps 257 / 512."""
+    L = mock
+    L.wan_dit_set_clip.argtypes = [c_void_p, c_void_p, c_void_p]
+    m = Model(L, "tiny_flf2v")
+    d, S = m.cfg.dim, 2
+    L.mock_reset()
+    assert L.wan_dit_set_clip(m.ctx, c_void_p(0x6700_0000_0000), None) == 0, L.wan_last_error()
+    calls = [(c.name.decode(), list(c.p), list(c.i)) for c in (L.mock_get(i).contents for i in range(L.mock_count()))]
+    assert [c[0] for c in calls] == ["add", "ln_affine", "gemm", "act", "gemm", "ln_affine"]
+    assert calls[0][1][0] == 0x6700_0000_0000 and calls[0][1][1] == m.addr["img_emb.emb_pos"] and calls[0][2][0] == 514 * 1280
+    assert calls[1][1][0] == calls[0][1][2] and calls[1][2][:2] == [514, 1280]            # LayerNorm of the sum, 514 rows
+    assert calls[2][2][:3] == [514, 1280, 1280] and calls[4][2][:3] == [514, d, 1280] and calls[5][2][:2] == [514, d]
+    clip_ctx = calls[5][1][1]
+    rc, fw = _clip_forward(L, m, S)
+    assert rc == 0, L.wan_last_error()
+    cp = [c for c in fw if c[0] == "memcpy" and c[2][0] in (257 * d * 2, 512 * d * 2)]
+    assert len(cp) == 2 * S
+    for s in range(S):                                                                     # [second image's tokens ; text tokens] per stream
+        a, b = cp[2 * s], cp[2 * s + 1]
+        assert a[1][1] == clip_ctx + 257 * d * 2 and a[2][0] == 257 * d * 2
+        assert b[1][0] == a[1][0] + 257 * d * 2 and b[2][0] == 512 * d * 2
+        if s:
+            assert a[1][0] == cp[0][1][0] + s * 769 * d * 2
+    ctx_x = cp[0][1][0]
+    ms = [c for c in fw if c[0] == "memset" and c[2][0] == S * d * 832 * 2]
+    assert len(ms) == 1
+    att = [c for c in fw if c[0] == "attention"]
+    text = [c for c in att if c[2][3] == 769]
+    img = [c for c in att if c[2][3] == 257]
+    assert len(text) == m.cfg.num_layers and len(img) == m.cfg.num_layers and all(c[2][4] == 832 for c in text) and all(c[2][4] == 320 for c in img)
+    assert all(c[1][2] == ms[0][1][0] for c in text)                                       # V^T images = the zero-padded buffer
+    kg = [c for c in fw if c[0] == "gemm" and c[1][0] == ctx_x and c[2][0] == S * 769]     # K projection of both streams' 769 rows
+    vg = [c for c in fw if c[0] == "gemm" and c[2][0] == 769 and c[2][5] == 3]             # V^T projections, one per stream
+    assert len(kg) == m.cfg.num_layers and len(vg) == S * m.cfg.num_layers and all(c[2][4] == 832 for c in vg)
+    assert {c[1][0] for c in vg} == {ctx_x, ctx_x + 769 * d * 2}
+    ki = [c for c in fw if c[0] == "gemm" and c[1][0] == clip_ctx]                         # k_img / v_img: the FIRST 257 tokens
+    assert len(ki) == 2 * m.cfg.num_layers and all(c[2][0] == 257 for c in ki)
+    # together with normalized attention guidance: refused, with a message
+    rc, _ = _clip_forward(L, m, 1, nag=(3.0, 2.5, 0.25), ctx_batches=[2])
+    assert rc != 0 and b"flf2v" in L.wan_last_error()
+    # the plain Wan2.1 i2v model: 257 tokens, text branch of 512, no assembly
+    m1 = Model(L, "tiny_i2v21")
+    L.mock_reset()
+    assert L.wan_dit_set_clip(m1.ctx, c_void_p(0x6700_0000_0000), None) == 0
+    c1 = [(c.name.decode(), list(c.i)) for c in (L.mock_get(i).contents for i in range(L.mock_count()))]
+    assert [c[0] for c in c1] == ["ln_affine", "gemm", "act", "gemm", "ln_affine"] and c1[0][1][:2] == [257, 1280]
+    rc, fw1 = _clip_forward(L, m1, S)
+    assert rc == 0
+    assert not [c for c in fw1 if c[0] == "memcpy" and c[2][0] == 257 * d * 2]
+    assert {c[2][3] for c in fw1 if c[0] == "attention"} == {16 * 2, 512, 257} or {c[2][3] for c in fw1 if c[0] == "attention"} >= {512, 257}

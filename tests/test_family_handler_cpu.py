@@ -59,6 +59,12 @@ def test_model_def_properties_and_settings():
     assert d["wan_5B_class"] and d["fps"] == 24 and d["vae_block_size"] == 32 and d["profiles_dir"] == ["wan_2_2_5B"]
     d = H.query_model_def("i2v_hip", {})
     assert d["i2v_class"] and d["black_frame"] and d["motion_amplitude"] and d["profiles_dir"] == ["wan_i2v"] and d["tea_cache"]
+    # flf2v_720p (first + last frame): an i2v-class model (wan_handler.py:33, :85, :103, :424) -- start AND end image, no NAG here
+    d = H.query_model_def("flf2v_720p_hip", {})
+    assert d["i2v_class"] and d["black_frame"] and d["image_prompt_types_allowed"] == "SEV" and d["NAG"] is False and d["group"] == "wan"
+    assert "flf2v_720p_hip" in H.query_supported_types()
+    eqv, comp = H.query_family_maps()
+    assert eqv["flf2v_720p_hip"] == "i2v_hip" and comp["i2v_hip"] == ["flf2v_720p_hip"]
     ui = {}
     H.update_default_settings("i2v_2_2_hip", {"image_prompt_types_allowed": "SEV"}, ui)
     assert ui == {"sample_solver": "unipc", "image_prompt_type": "S", "masking_strength": 0.1, "denoising_strength": 0.9,

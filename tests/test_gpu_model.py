@@ -39,7 +39,7 @@ def rel(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21", "tiny_vace"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21", "tiny_flf2v", "tiny_vace"])
 def test_forward_vs_reference_golden(name):
     g = load(f"forward_{name}.npz")
     f, h, w = [int(v) for v in g["shape"]]
@@ -48,7 +48,8 @@ def test_forward_vs_reference_golden(name):
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
     t = torch.tensor([int(g["t"][0])], dtype=torch.int64)
     xs = [lat.cuda(), lat.cuda()]
-    clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None     # Wan2.1 i2v: CLIP tokens + k_img / v_img branch
+    # Wan2.1 i2v: CLIP tokens + k_img / v_img branch; flf2v: two images, position embedding, the second image in the text branch
+    clip = O.synth_clip_fea(images=2 if cfg.flf else 1) if cfg.model_type == "i2v" else None
     kw = {} if clip is None else {"clip_fea": clip.cuda()}
     vace = O.synth_vace_context(cfg, f, h, w) if cfg.vace_layers is not None else None     # VACE context blocks
     if vace is not None:

@@ -70,7 +70,7 @@ def test_rmsnorm_rope_ln_sdpa_bit_exact():
     assert (ex - t(g["sdpa_bf16"])).abs().max() < 2e-2
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21", "tiny_vace", "small"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "tiny_i2v21", "tiny_flf2v", "tiny_vace", "small"])
 @pytest.mark.parametrize("tag,dtype", [("bf16", torch.bfloat16), ("fp32", torch.float32)])
 def test_forward_matches_reference(name, tag, dtype):
     g = load(f"forward_{name}.npz")
@@ -79,7 +79,7 @@ def test_forward_matches_reference(name, tag, dtype):
     W = O.synth_weights(cfg, dtype=dtype)
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
     tt = torch.tensor([int(g["t"][0])], dtype=torch.int64)
-    clip = O.synth_clip_fea() if cfg.model_type == "i2v" else None          # Wan2.1 i2v: CLIP tokens (model.py:1858-1869)
+    clip = O.synth_clip_fea(images=2 if cfg.flf else 1) if cfg.model_type == "i2v" else None   # Wan2.1 i2v / flf2v: CLIP tokens (model.py:1858-1869)
     vace = O.synth_vace_context(cfg, f, h, w) if cfg.vace_layers is not None else None     # VACE context blocks (model.py:790-828)
     cond, uncond = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, y=y, dtype=dtype, clip_fea=clip,
                                  vace_context=vace)
@@ -106,7 +106,7 @@ def test_forward_matches_reference(name, tag, dtype):
     L = f * (h // 2) * (w // 2)
     hid = torch.randn(1, L, cfg.dim, generator=gen).to(dtype)
     e0 = (0.5 * torch.randn(1, 6, cfg.dim, generator=gen)).to(dtype)
-    cemb = (0.5 * torch.randn(1, 512 + (O.CLIP_TOKENS if cfg.model_type == "i2v" else 0), cfg.dim, generator=gen)).to(dtype)
+    cemb = (0.5 * torch.randn(1, 512 + (O.CLIP_TOKENS * (2 if cfg.flf else 1) if cfg.model_type == "i2v" else 0), cfg.dim, generator=gen)).to(dtype)
     cos, sin = O.rope_tables((f, h // 2, w // 2))
     bo = O.block_forward(hid, e0, cemb, cos, sin, W, 0, cfg)
     if dtype == torch.bfloat16:

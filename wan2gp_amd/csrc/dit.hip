@@ -152,6 +152,8 @@ struct wan_ctx {
   const float* head_b = nullptr;
   // Wan2.1 i2v (model_type 'i2v'): img_emb = MLPProj(1280, dim) (model.py:868-889) and the projected CLIP tokens
   bool has_img = false;
+  bool has_flf = false;          // flf2v: img_emb carries emb_pos, clip_fea holds TWO images (model.py:878-887)
+  const bf16_t* ie_pos = nullptr;  // img_emb.emb_pos [514, 1280]
   const bf16_t *ie_ln0w = nullptr, *ie_ln0b = nullptr, *ie_ln4w = nullptr, *ie_ln4b = nullptr;
   Lin ie1, ie3;
   // VACE (model.py:790-828, :1178-1206): context blocks attached to the main blocks listed in vace_layers
@@ -309,6 +311,8 @@ static int resolve(wan_ctx* c) {
     if (int rc = get_lin(c, c->ie3, "img_emb.proj.3", d, CLIP_DIM)) return rc;
     GETB(c->ie_ln4w, "img_emb.proj.4.weight", d);
     GETB(c->ie_ln4b, "img_emb.proj.4.bias", d);
+    c->has_flf = c->weights.count("img_emb.emb_pos") != 0;   // MLPProj(flf_pos_emb=True): the flf2v_720p checkpoint
+    if (c->has_flf) GETB(c->ie_pos, "img_emb.emb_pos", 2 * CLIP_TOK * CLIP_DIM);
     for (int i = 0; i < g.num_layers; ++i) {
       Layer& L = c->layers[i];
       const std::string ap = "blocks." + std::to_string(i) + ".cross_attn.";
@@ -451,17 +455,26 @@ extern "C" int wan_dit_set_clip(wan_ctx* c, const wan_bf16* clip_fea, void* stre
   RC(resolve(c));
   WAN_REQUIRE(c->has_img, "wan_dit_set_clip: the loaded checkpoint has no img_emb / k_img / v_img weights (not a Wan2.1 i2v model)");
   const int d = c->cfg.dim;
-  if (!c->clip_ctx) WAN_CHECK_HIP(hipMalloc((void**)&c->clip_ctx, (size_t)CLIP_TOK * d * 2));
-  if (!c->clip_tmp) WAN_CHECK_HIP(hipMalloc((void**)&c->clip_tmp, (size_t)2 * CLIP_TOK * CLIP_DIM * 2 + (size_t)CLIP_TOK * d * 2));
+  // flf2v (model.py:884-887): clip_fea holds the start AND the end image, [2, 257, 1280]; MLPProj views them as one sequence of
+  // 514 tokens and adds its position embedding (one bf16 rounding) before the MLP.  The block's cross-attention then takes the
+  // FIRST 257 projected tokens as its image context and the other 257 in front of the text tokens (it splits at 257, :472-473).
+  const int64_t CT = (int64_t)CLIP_TOK * (c->has_flf ? 2 : 1);
+  if (!c->clip_ctx) WAN_CHECK_HIP(hipMalloc((void**)&c->clip_ctx, (size_t)CT * d * 2));
+  if (!c->clip_tmp) WAN_CHECK_HIP(hipMalloc((void**)&c->clip_tmp, (size_t)2 * CT * CLIP_DIM * 2 + (size_t)CT * d * 2));
   bf16_t* t1 = c->clip_tmp;
-  bf16_t* t2 = t1 + (int64_t)CLIP_TOK * CLIP_DIM;
-  bf16_t* t3 = t2 + (int64_t)CLIP_TOK * CLIP_DIM;
+  bf16_t* t2 = t1 + CT * CLIP_DIM;
+  bf16_t* t3 = t2 + CT * CLIP_DIM;
   WAN_REQUIRE(!c->ie1.w8 && !c->ie3.w8, "wan_dit_set_clip: img_emb Linears must be bf16 (dequantise them at load)");
-  RC(wan_ln_affine(clip_fea, t1, c->ie_ln0w, c->ie_ln0b, CLIP_TOK, CLIP_DIM, 1e-5f, stream));
-  RC(linear(t1, c->ie1, t2, CLIP_TOK, CLIP_DIM, CLIP_DIM, WAN_EPI_NONE, stream));
-  RC(wan_act_bf16(t2, t2, (int64_t)CLIP_TOK * CLIP_DIM, 2, stream));
-  RC(linear(t2, c->ie3, t3, CLIP_TOK, d, CLIP_DIM, WAN_EPI_NONE, stream));
-  RC(wan_ln_affine(t3, c->clip_ctx, c->ie_ln4w, c->ie_ln4b, CLIP_TOK, d, 1e-5f, stream));
+  const bf16_t* src = clip_fea;
+  if (c->has_flf) {
+    RC(wan_add_bf16(clip_fea, c->ie_pos, t2, CT * CLIP_DIM, stream));
+    src = t2;
+  }
+  RC(wan_ln_affine(src, t1, c->ie_ln0w, c->ie_ln0b, CT, CLIP_DIM, 1e-5f, stream));
+  RC(linear(t1, c->ie1, t2, CT, CLIP_DIM, CLIP_DIM, WAN_EPI_NONE, stream));
+  RC(wan_act_bf16(t2, t2, CT * CLIP_DIM, 2, stream));
+  RC(linear(t2, c->ie3, t3, CT, d, CLIP_DIM, WAN_EPI_NONE, stream));
+  RC(wan_ln_affine(t3, c->clip_ctx, c->ie_ln4w, c->ie_ln4b, CT, d, 1e-5f, stream));
   c->clip_set = true;
   return 0;
 }
@@ -564,6 +577,22 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
                 nullptr, nullptr, nullptr, -1, 1, 0, q8, 1, s));
   }
 
+  // flf2v: the text branch of the cross-attention sees [the second image's 257 CLIP tokens ; the text tokens] (model.py:472-473 splits
+  // the context at 257, img_emb produced 514).  Assembled once per forward in ctx_h (dead after the text embedding above): per
+  // stream TLx = 257 + text_len rows; the V^T images get a row pitch of TLx rounded up to 64, their pad columns zeroed here (the
+  // projection GEMMs of the blocks never write them).
+  const int XT = c->has_flf ? CLIP_TOK : 0;
+  const int TLx = TL + XT, LDVx = XT ? ((TLx + 63) / 64) * 64 : TL;
+  if (XT) {
+    WAN_REQUIRE(!any_nag, "wan_dit_forward: normalized attention guidance is not served together with the flf2v CLIP context");
+    for (int s = 0; s < S; ++s) {
+      bf16_t* dst = b.ctx_h + (int64_t)s * TLx * d;
+      WAN_CHECK_HIP(hipMemcpyAsync(dst, c->clip_ctx + (int64_t)CLIP_TOK * d, (size_t)CLIP_TOK * d * 2, hipMemcpyDeviceToDevice, st));
+      WAN_CHECK_HIP(hipMemcpyAsync(dst + (int64_t)XT * d, b.ctx_e + (int64_t)s * TL * d, (size_t)TL * d * 2, hipMemcpyDeviceToDevice, st));
+    }
+    WAN_CHECK_HIP(hipMemsetAsync(b.cvt, 0, (size_t)S * d * LDVx * 2, st));
+  }
+
   // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups (rpb = rows in run_blocks)
 
   // Self-attention: softmax scale * log2(e) is folded into q inside the fused RMSNorm+RoPE kernel (in front of q's single
@@ -609,7 +638,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   const int S = Sn;
   const int64_t rows = (int64_t)Sn * Ll, rpb = nt > 1 ? tpf : rows;
   struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; float* raw; } b2 = {
-      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, b.ctx_e + (int64_t)crow[s0] * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
+      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, XT ? b.ctx_h + (int64_t)s0 * TLx * d : b.ctx_e + (int64_t)crow[s0] * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
   bf16_t* const x_main = b.x + s0 * sn;
   // hint streams of this run, per active context; vskip[k] doubles as the swap buffer of before_proj
   bf16_t *vc[8], *vskip[8];
@@ -712,16 +741,17 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
         }
       }
     } else {
-    RC(linear(b.ctx_e, Lw.cross.k, b.ck, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
-    RC(wan_rmsnorm_rope(b.ck, nullptr, Lw.cross.nk, nullptr, nullptr, nullptr, (int64_t)S * TL, TL, 0, d, g.eps, stream));
+    // (TLx = text_len, or 257 + text_len under flf2v: b.ctx_e is then the assembled [CLIP tail ; text] context)
+    RC(linear(b.ctx_e, Lw.cross.k, b.ck, (int64_t)S * TLx, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+    RC(wan_rmsnorm_rope(b.ck, nullptr, Lw.cross.nk, nullptr, nullptr, nullptr, (int64_t)S * TLx, TLx, 0, d, g.eps, stream));
     for (int s = 0; s < S; ++s)
-      RC(linear(b.ctx_e + (int64_t)s * TL * d, Lw.cross.v, b.cvt + (int64_t)s * d * TL, TL, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                nullptr, nullptr, -1, 1, TL, q8, 1, s, Lw.cross.k.w8 != nullptr));
+      RC(linear(b.ctx_e + (int64_t)s * TLx * d, Lw.cross.v, b.cvt + (int64_t)s * d * LDVx, TLx, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                nullptr, nullptr, -1, 1, LDVx, q8, 1, s, Lw.cross.k.w8 != nullptr));
     }
     if (!c->has_img) {
       if (!any_nag) {
         ProfScope ps(PROF_CROSS_ATTN, st);
-        RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.q, S, S, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+        RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.q, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, nullptr, stream));
       }
     } else {
       // WanI2VCrossAttention (model.py:466-499): the same q attends the text tokens and the 257 CLIP tokens (K_img / V_img
@@ -731,7 +761,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(linear(c->clip_ctx, Lw.vimg, b.cvtimg, CLIP_TOK, d, d, WAN_EPI_TRANSPOSED, stream, nullptr, nullptr, nullptr, -1, 1, CLIP_LDV,
                 q8, 1, 0, Lw.kimg.w8 != nullptr));
       ProfScope ps(PROF_CROSS_ATTN, st);
-      if (!any_nag) RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+      if (!any_nag) RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, nullptr, stream));
       RC(wan_attention_bounded(b.q, b.ckimg, b.cvtimg, b.q, S, 1, Ll, CLIP_TOK, CLIP_LDV, nh, 1, 0, 0, 1, nullptr, stream));
       RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }

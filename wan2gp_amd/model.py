@@ -191,8 +191,11 @@ class WanModelHIP:
             if clip_fea is None or y is None:
                 raise _L.WanHipError("model_type 'i2v' needs clip_fea [1,257,1280] and y (model.py:1547)")
             cf = clip_fea.to(device=self.device, dtype=torch.bfloat16).contiguous()
-            if cf.numel() != 257 * 1280:
-                raise _L.WanHipError(f"clip_fea must be [1,257,1280], got {list(clip_fea.shape)}")
+            # flf2v_720p (a checkpoint whose img_emb carries emb_pos, model.py:878-887): the CLIP features of the start AND the end
+            # image, [2,257,1280] (any2video.py:949-950)
+            n_img = 2 if "img_emb.emb_pos" in self._weights else 1
+            if cf.numel() != n_img * 257 * 1280:
+                raise _L.WanHipError(f"clip_fea must be [{n_img},257,1280] for this checkpoint, got {list(clip_fea.shape)}")
             # img_emb(clip_fea): three small GEMMs + two LayerNorms on 257 tokens -- redone per call like the reference does
             # (a pointer-keyed cache would be fooled by the allocator handing the same address to a different tensor)
             check(_L.load().wan_dit_set_clip(self._ctx, ptr(cf), stream_ptr()), "wan_dit_set_clip")

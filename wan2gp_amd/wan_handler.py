@@ -23,6 +23,9 @@ _ARCH = {
     "t2v_1.3B": dict(model_type="t2v", dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, in_dim=16, out_dim=16),
     "t2v_2_2": dict(model_type="t2v", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=16, out_dim=16),
     "i2v": dict(model_type="i2v", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, out_dim=16),
+    # flf2v_720p (first + last frame, models/wan/configs/flf2v_720p.json): the i2v architecture; its checkpoint carries img_emb.emb_pos
+    # and the model takes the CLIP features of BOTH images (model.py:878-887, any2video.py:949-950)
+    "flf2v_720p": dict(model_type="i2v", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, out_dim=16),
     "i2v_2_2": dict(model_type="i2v2_2", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, out_dim=16),
     "ti2v_2_2": dict(model_type="ti2v2_2", dim=3072, ffn_dim=14336, num_heads=24, num_layers=30, in_dim=48, out_dim=48),
     "vace_14B": dict(model_type="t2v", dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=16, out_dim=16,
@@ -38,7 +41,7 @@ def base_of(model_type: str) -> str:
 
 
 def test_class_i2v(base_model_type):            # wan_handler.py:16-17 restricted to the supported types
-    return base_of(base_model_type) in ("i2v", "i2v_2_2")
+    return base_of(base_model_type) in ("i2v", "i2v_2_2", "flf2v_720p")
 
 
 def test_class_t2v(base_model_type):
@@ -69,8 +72,8 @@ class family_handler():
     @staticmethod
     def query_family_maps():
         """(equivalence map, compatibility map) of wan_handler.py:81-107, restricted to the supported types."""
-        eqv = {"t2v_1.3B" + SUFFIX: "t2v" + SUFFIX, "t2v_2_2" + SUFFIX: "t2v" + SUFFIX}
-        comp = {"t2v" + SUFFIX: [t + SUFFIX for t in ("vace_14B", "vace_1.3B", "t2v_1.3B")]}
+        eqv = {"t2v_1.3B" + SUFFIX: "t2v" + SUFFIX, "t2v_2_2" + SUFFIX: "t2v" + SUFFIX, "flf2v_720p" + SUFFIX: "i2v" + SUFFIX}
+        comp = {"t2v" + SUFFIX: [t + SUFFIX for t in ("vace_14B", "vace_1.3B", "t2v_1.3B")], "i2v" + SUFFIX: ["flf2v_720p" + SUFFIX]}
         return eqv, comp
 
     @staticmethod
@@ -115,7 +118,8 @@ class family_handler():
             "sub_parallel_windows": False,
             # normalized attention guidance (wan_handler.py:994) and the image prompt types (:956-978): Start / End image, Video to
             # continue, Last-frame options for the i2v models -- generate(image_start=, image_end=) / the prefix-video path
-            "NAG": vace or t2v or i2v, "self_refiner": True, "perturbation": not vace,      # skip-layer guidance: not with VACE blocks
+            # (not flf2v: its text branch carries the second image's CLIP tokens, which the NAG path of the forward driver does not serve)
+            "NAG": (vace or t2v or i2v) and b != "flf2v_720p", "self_refiner": True, "perturbation": not vace,      # skip-layer guidance: not with VACE blocks
             # of the reference's "TVL" / "TSVL" / "SEVL": 'L' (continue the last video) is a sliding-window feature; 'V' (video to
             # continue) is served where generate() has the path -- the i2v prefix video and the 5B model's timestep injection
             "image_prompt_types_allowed": "T" if (vace or b in ("t2v", "t2v_2_2")) else ("TSV" if b == "ti2v_2_2" else ("SEV" if i2v else "")),
