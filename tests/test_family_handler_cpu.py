@@ -81,15 +81,18 @@ def test_model_def_properties_and_settings():
 def test_model_definition_advertises_nag_and_image_prompt_types():
     """wan_handler.py:956-978, :994: the UI reads `NAG` and `image_prompt_types_allowed` (Start / End image, Video to continue,
     Last frames) from the model definition.  Only what generate() serves is claimed: no 'L' (continue the last video: a
-    sliding-window feature) and no sliding windows at all; 'V' where the prefix-video / timestep-injection path exists."""
+    sliding-window feature); 'V' where the prefix-video / timestep-injection path exists."""
     from wan2gp_amd.wan_handler import family_handler as fh
     i2v = fh.query_model_def("i2v_2_2_hip", {"URLs2": ["x"]})
     assert i2v["NAG"] and i2v["image_prompt_types_allowed"] == "SEV"
     assert fh.query_model_def("t2v_2_2_hip", {})["image_prompt_types_allowed"] == "T"
     assert fh.query_model_def("ti2v_2_2_hip", {})["image_prompt_types_allowed"] == "TSV"
     assert fh.query_model_def("vace_14B_hip", {})["NAG"]
-    for b in ("t2v", "t2v_2_2", "i2v", "i2v_2_2", "ti2v_2_2", "vace_14B"):
-        assert fh.query_model_def(b + "_hip", {})["sliding_window"] is False
+    # sliding windows: claimed where generate() carries the reference's window mechanics (i2v prefix video, 5B timestep injection,
+    # VACE's pinned context overlap), not for plain t2v
+    for b, want in (("t2v", False), ("t2v_2_2", False), ("t2v_1.3B", False), ("i2v", True), ("i2v_2_2", True), ("flf2v_720p", True),
+                    ("ti2v_2_2", True), ("vace_14B", True), ("vace_1.3B", True)):
+        assert fh.query_model_def(b + "_hip", {})["sliding_window"] is want, b
 
 
 def _ref_update_default_settings():
@@ -170,9 +173,9 @@ def test_model_definition_agrees_with_the_references_on_every_shared_property(b,
     from wan2gp_amd.wan_handler import family_handler as H
     want, got = ref(b, dict(md)), H.query_model_def(b + "_hip", dict(md))
     shared = (set(want) & set(got)) - {"compile"} - ({"perturbation"} if b.startswith("vace") else set())   # (no skip-layer guidance beside VACE blocks)
-    # deliberate: sliding windows (overlapped latents between windows) are not served, so neither they nor the image prompt
-    # types that depend on them are claimed; what IS claimed is a subset of the reference's letters
-    assert got["sliding_window"] is False and set(got["image_prompt_types_allowed"]) <= set(want["image_prompt_types_allowed"])
+    # deliberate: sliding windows are claimed only where generate() carries the window mechanics (never where the reference does not
+    # claim them), and the image prompt types claimed are a subset of the reference's letters
+    assert (not got["sliding_window"] or want["sliding_window"]) and set(got["image_prompt_types_allowed"]) <= set(want["image_prompt_types_allowed"])
     shared -= {"sliding_window", "image_prompt_types_allowed"}
     assert len(shared) >= 26
     assert {k: got[k] for k in shared} == {k: want[k] for k in shared}

@@ -464,6 +464,51 @@ def test_skip_layer_guidance_is_passed_inside_its_window_of_steps():
     assert m.slg == [None] * 6
 
 
+def test_vace_sliding_window_pins_the_overlap_of_the_control_video():
+    """Sliding windows on the VACE path (any2video.py:1150-1152, :1517-1526, :1755-1756): with the previous window's
+    `overlapped_latents` [1,16,n,h,w] the INACTIVE half of the context's first n latent frames is the pinned prefix -- in front of every
+    step latents[:, :, :n] = prefix (1 - t/1000) + noise t/1000 and context[0:16, :n] = prefix (1 - overlap_noise/1000) + noise
+    overlap_noise/1000 (two draws from the global generator, in this order), behind the last step the clean prefix; the requested
+    latent slice goes back to the caller for the next window.  Without overlapped latents nothing is pinned; on a model without
+    VACE blocks (the i2v path of the reference has the use switched off, :779) the keyword changes nothing."""
+    from oracle.make_golden_vace_context import FakeVAE, inputs
+
+    class VaceDiT(FakeDiT):
+        def __call__(self, x, t, context, vace_context=None, **kw):
+            self.seen = getattr(self, "seen", [])
+            self.seen.append((float(t[0] if torch.is_tensor(t) and t.dim() else t), x[0][:, :, :2].clone(), vace_context[0][:16, :2].clone()))
+            return super().__call__(x, t, context, **kw)
+    frames, mask, _ = inputs()
+    m = VaceDiT("A")
+    pipe = WanAny2VHIP(m, vae=FakeVAE(), device="cpu")
+    prefix = pipe.vace_context([frames], [mask], None, 0)[0][:16, :2].clone()
+    torch.manual_seed(77)
+    out = run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, overlapped_latents=torch.zeros(1, 16, 2, 4, 6), overlap_noise=20,
+              return_latent_slice=slice(-2, None), joint_pass=True)
+    assert torch.equal(out["latents"][:, :, :2], prefix.unsqueeze(0))                     # clean behind the last step
+    assert torch.equal(out["latent_slice"], out["latents"][:, :, -2:])
+    torch.manual_seed(77)
+    steps = []
+    for t, xs, zz in m.seen:                                                              # joint pass: one call per step
+        if not steps or steps[-1][0] != t:
+            steps.append((t, xs, zz))
+    assert len(steps) == 6
+    ext = prefix.unsqueeze(0)
+    for t, xs, zz in steps:
+        f = t / 1000.0
+        want_x = ext * (1.0 - f) + torch.randn_like(ext) * f
+        want_z = ext[0] * (1.0 - 0.02) + torch.randn_like(ext[0]) * 0.02
+        assert torch.equal(xs, want_x) and torch.equal(zz, want_z), t
+    # no overlapped latents: the context's first frames are left alone and nothing is pinned
+    m2 = VaceDiT("A")
+    out2 = run(WanAny2VHIP(m2, vae=FakeVAE(), device="cpu"), width=48, height=32, input_frames=frames, input_masks=mask)
+    assert all(torch.equal(zz, prefix) for _, _, zz in m2.seen) and not torch.equal(out2["latents"][:, :, :2], ext)
+    # a model without VACE blocks: accepted and without effect (wgp.py passes it for every window after the first)
+    a = run(WanAny2VHIP(FakeDiT("A"), device="cpu"), overlapped_latents=torch.zeros(1, 16, 2, 8, 8), overlap_noise=20)
+    b = run(WanAny2VHIP(FakeDiT("A"), device="cpu"))
+    assert torch.equal(a["latents"], b["latents"])
+
+
 def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():
     """wgp.py passes every generate() the union of all variants' keywords (wgp.py:7762-7885): defaults and UI plumbing are accepted
     silently, a keyword that would change the video through a path this backend does not serve raises."""
@@ -471,7 +516,7 @@ def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():
     out = run(pipe, input_ref_images=None, audio_guide=None, overlap_noise=0, image_mode=0, alt_guide_scale=1.0, fit_into_canvas=True, window_no=1,
               offloadobj=object(), set_header_text=lambda *a: None, model_filename="x.safetensors", fps=16, gen_state={}, custom_settings=None)
     assert torch.isfinite(out["latents"]).all()
-    for kw in (dict(input_ref_images=[torch.zeros(3, 8, 8)]), dict(overlapped_latents=torch.zeros(1, 16, 2, 8, 8)),
+    for kw in (dict(input_ref_images=[torch.zeros(3, 8, 8)]),
                dict(audio_proj=torch.zeros(1)), dict(image_mode=1), dict(alt_guide_scale=2.0), dict(vae_upsampler="x")):
         with pytest.raises(NotImplementedError, match=list(kw)[0]):
             run(pipe, **kw)

@@ -22,12 +22,14 @@ from .schedulers import (EulerScheduler, FlowDPMSolverMultistepScheduler, FlowMa
 # keyword -> the reference's default (any2video.py:414-503): a non-default value asks for something generate() below does not do.
 # NOT in this table although wgp.py sets them on EVERY call (wgp.py:7762-7885): `causal_attention=True` (hard-coded at :7826; the
 # reference's generate() does not even declare it -- it falls into **bbargs), `overlap_noise` (the UI's sliding-window default 20;
-# read only for VACE with overlapped latents, which IS refused below), `prefix_video` / `pre_video_frame` /
+# read only for VACE with overlapped latents, served below), `overlapped_latents` (the latent slice of the previous sliding
+# window, wgp.py's window loop: read by the reference on the VACE path -- any2video.py:1150-1152, :1524-1526, served below -- and on the
+# svi_pro path, which does not reach this backend; the i2v path's use of it is switched off there, :779), `prefix_video` / `pre_video_frame` /
 # `conditioning_latents_size` (non-empty whenever a start image or a source video is used, wgp.py:7378-7394, :7714; read only on
 # the svi_pro / infinitetalk / scail2 / reference-image paths, any2video.py:659-728, :861-897, none of which reaches this backend).
 _UNSERVED_WHEN_SET = {"input_frames2": None, "input_masks2": None, "input_ref_images": None, "input_ref_masks": None, "input_faces": None,
                       "input_custom": None, "audio_scale": None, "audio_proj": None, "audio_context_lens": None, "audio_guide": None,
-                      "audio_guide2": None, "input_waveform": None, "alt_guide_scale": 1.0, "overlapped_latents": None,
+                      "audio_guide2": None, "input_waveform": None, "alt_guide_scale": 1.0,
                       "speakers_bboxes": None, "image_mode": 0, "face_arc_embeds": None, "control_scale_alt": 1.0, "vae_upsampler": None}
 
 
@@ -232,7 +234,8 @@ class WanAny2VHIP:
                  motion_amplitude=1.0, clip_fea=None, input_video=None, NAG_scale=0, NAG_tau=3.5, NAG_alpha=0.5, image_end=None,
                  return_latent_slice=None, video_prompt_type="", denoising_strength=1.0, masking_strength=1.0, keep_frames_parsed=None,
                  prefix_frames_count=0, self_refiner_setting=0, self_refiner_plan="", self_refiner_f_uncertainty=0.0,
-                 self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, set_header_text=None, **bbargs):
+                 self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, set_header_text=None,
+                 overlapped_latents=None, overlap_noise=0, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         # wgp.py hands every generate() the union of all variants' keywords (wgp.py:7762-7885); the ones below change the result
@@ -242,7 +245,7 @@ class WanAny2VHIP:
                     if bbargs.get(k, None) is not None and not _same(bbargs[k], default)}
         if unserved:
             raise NotImplementedError(f"WanAny2VHIP.generate: {sorted(unserved)} select reference paths outside this backend "
-                                      "(reference images / second control video / audio / sliding-window overlap / image outputs / VAE upsampler)")
+                                      "(reference images / second control video / audio / image outputs / VAE upsampler)")
         if context is None:
             if self.text_encoder is None or input_prompt is None:
                 raise ValueError("pass `context`/`context_null` ([1,512,4096] bf16) or a text_encoder + input_prompt")
@@ -334,13 +337,19 @@ class WanAny2VHIP:
                                    sample_scheduler, device=dev, video_prompt_type=video_prompt_type)
             timesteps, start_step_no = v2v.timesteps, v2v.start_step_no
             randn = latents                                                                  # :1475 -- the SAME tensor, as there
-        vace_kwargs = {}
+        vace_kwargs, vace_overlap = {}, False
         if input_frames is not None and (not v2v_on or getattr(self.model, "vace_layers", None) is not None):
             # VACE control video + mask (any2video.py:1128-1147), no reference images
             if self.vae is None or input_masks is None:
                 raise ValueError("VACE needs a VAE, input_frames [3,T,H,W] and input_masks [1,T,H,W]")
             z = self.vace_context([input_frames.to(dev)], [input_masks.to(dev)], None, VAE_tile_size)
             vace_kwargs = {"vace_context": z, "vace_context_scale": context_scale if context_scale is not None else [1.0] * len(z)}
+            # sliding windows (any2video.py:1150-1152): wgp.py hands the previous window's last latent frames; the INACTIVE half of
+            # the control video's first latent frames (the overlap, which the control video repeats) is what gets pinned: injected
+            # re-noised in front of every step and clean behind the last one, like the i2v prefix
+            vace_overlap = overlapped_latents is not None
+            if vace_overlap:
+                ext_latents = z[0][:16, :overlapped_latents.shape[2]].clone().unsqueeze(0)
         any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
         trans = self.model
         guidance_switch_done = guidance_switch2_done = False
@@ -423,6 +432,10 @@ class WanAny2VHIP:
                     f = float(t) / 1000.0
                     n = ext_latents.shape[2]
                     latents[:, :, :n] = ext_latents * (1.0 - f) + torch.randn_like(ext_latents) * f
+                    if vace_overlap:                             # :1523-1526: the context's overlap frames get `overlap_noise` / 1000 of noise
+                        of = overlap_noise / 1000
+                        for zz in vace_kwargs["vace_context"]:
+                            zz[0:16, :n] = ext_latents[0] * (1.0 - of) + torch.randn_like(ext_latents[0]) * of
                 def denoise_with_cfg(lat):                       # denoise_with_cfg_fn, plain two-stream branch (any2video.py:1610-1722)
                     nonlocal text_momentum
                     if guide_scale == 1 or not any_guidance:

@@ -108,9 +108,12 @@ class family_handler():
             "i2v_2_2": test_i2v_2_2(b), "color_correction": True,
             "vae_block_size": 32 if wan_5B else 16, "profiles_dir": [profiles_dir], "group": group, "fps": 24 if wan_5B else 16,
             "frames_minimum": 17 if vace else 5, "frames_steps": 4,
-            # sliding windows hand `overlapped_latents` / a prefix of the previous window to generate(), which refuses them: not
-            # claimed until they are served (the reference claims them for t2v / i2v / 5B / VACE, wan_handler.py:266)
-            "sliding_window": False,
+            # sliding windows (the reference claims them for t2v / i2v / 5B / VACE, wan_handler.py:369): wgp.py's window loop hands
+            # generate() the previous window's last frames (`input_video` / the control video's prefix) and its last latent frames
+            # (`overlapped_latents`), and takes `latent_slice` back.  Served where generate() has the reference's mechanics: the i2v
+            # prefix video (re-noised injection + clean restore), the 5B model's timestep injection, VACE's pinned context overlap
+            # with `overlap_noise` (any2video.py:775-782, :1060-1072, :1150-1152, :1517-1526, :1755-1761).  Plain t2v: not claimed.
+            "sliding_window": bool(i2v or wan_5B or vace),
             "multiple_submodels": multiple_submodels, "guidance_max_phases": 3, "flow_shift": True, "cfg_zero": True, "cfg_star": True,
             "adaptive_projected_guidance": True,
             "tea_cache": not (b == "i2v_2_2" or wan_5B or multiple_submodels), "mag_cache": True,
