@@ -79,3 +79,29 @@ def test_token_count_that_does_not_shard_is_an_error_before_the_weights_are_buil
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "75600" in str(e.value.code) and "32" in str(e.value.code)
+
+
+def test_committed_bench_line_carries_the_contract():
+    """The bench line measured on the committed code (profiles/r03_bench_14B-720p_run87.json, written by `python bench.py` on an MI355X):
+    every field of the driver's contract, the roofline and cpu_baseline objects of the tier framing, self-consistent numbers."""
+    import json
+    p = os.path.join(ROOT, "profiles", "r03_bench_14B-720p_run87.json")
+    j = json.load(open(p))
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                   ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(j[k], typ), k
+    assert "vs_baseline" in j and j["vs_baseline"] is None           # BASELINE.md holds no published number for this metric
+    assert j["metric"] == "denoise-steps/s" and j["higher_is_better"] is True and j["n_gpus"] == 1 and "workload" in j["config"]
+    assert abs(j["value"] * j["ms_per_step"] / 1000.0 - 1.0) < 1e-6  # steps/s x s/step
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["traffic"] > 6.19e9 and "pmc" in r["traffic_source"].lower()      # PMC bytes per launch >= the algorithmic bytes
+    assert r["declined_workgroups"] == 0 and r["total_workgroups"] == 80 * 23680
+    assert 0.5 < r["frac_of_sustained_mfma"] < 1.0 and r["sustained_mfma"]["TFLOPs"] > 1500
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "denoise-steps/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu_model"]
+    assert [x["world"] for x in j["simulated_scaling"]["ranks"]] == [2, 4, 8]
+    assert all(0.5 < x["compute_side_efficiency"] <= 1.0 for x in j["simulated_scaling"]["ranks"])
+    assert j["config5"]["dtype"].startswith("fp8") and j["secondary"]["ms_per_step"] > 0 and j["e2e"]["composed_s_at_30_steps"] > 0
