@@ -188,6 +188,24 @@ def test_gemm256m_registers_and_stage_instruction_mix(tmp_path_factory):
             assert c["s_waitcnt"] <= 20, c
 
 
+def test_gemm256mp_experiment_fits_the_register_file(tmp_path_factory):
+    """gemm256mp.hip (NOT validated on hardware, not in the dispatch: gemm256m's stage inside gemm256p's persistent tile walk, written
+    after the round's GPU budget was spent).  What can be settled without a GPU: all three instantiations fit -- 256 accumulators,
+    no scratch -- and a steady-state stage keeps gemm256m's mix: 128 MFMAs, 32 ds_read_b128, 16 LDS-DMA pieces, no vector-ALU
+    instruction, <= 5 s_waitcnt."""
+    ks = kernels(asm_of("gemm256mp", tmp_path_factory), "gemm256mp_kernel")
+    assert len(ks) == 3
+    for name, (ops, meta) in ks.items():
+        assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256 and meta["LDSByteSize"] == 160 * 1024, (name, meta)
+        bars = [i for i, o in enumerate(ops) if o == "s_barrier"]
+        stages = [collections.Counter(ops[a:b]) for a, b in zip(bars, bars[1:])]
+        stages = [c for c in stages if c["v_mfma_f32_16x16x32_bf16"] == 128]
+        assert len(stages) >= 4, name
+        for c in stages:
+            assert c["ds_read_b128"] == 32 and c["buffer_load_dwordx4"] == 16 and c["s_waitcnt"] <= 5, c
+            assert sum(v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma")) == 0, c
+
+
 def test_no_kernel_of_the_library_spills_to_scratch(tmp_path_factory):
     """Every kernel of every translation unit: ScratchSize 0 (a spill inside a tile loop is a performance cliff, and the hot kernels
     run at the edge of the 512-register file).  No exceptions: round 2's one (the scaled-fp8 GEMM with GELU and a per-row weight
