@@ -509,6 +509,51 @@ def test_vace_sliding_window_pins_the_overlap_of_the_control_video():
     assert torch.equal(a["latents"], b["latents"])
 
 
+def test_vace_reference_images_are_extra_latent_frames_in_front_and_are_cut_off_at_the_end():
+    """VACE reference images (any2video.py:1128-1166, :1745, :1758, ref_images_before): n images = n extra latent frames in front of the
+    control context (their latents beside zero masks, vace_encode_frames / _masks -- pinned to the reference by
+    tests/golden/vace_context.npz) AND of the latents the model sees; the previews and the result leave them out.  Together with
+    sliding-window overlap the pinned prefix spans reference frames + overlap, the context noise only the overlap (:1151-1152, :1526).
+    Outside the VACE path, with a background reference mask, or with sub-parallel windows: refused."""
+    from oracle.make_golden_vace_context import FakeVAE, inputs
+
+    class VaceDiT(FakeDiT):
+        vace_layers = (0,)
+
+        def __call__(self, x, t, context, vace_context=None, **kw):
+            self.seen = getattr(self, "seen", [])
+            self.seen.append((tuple(x[0].shape), tuple(vace_context[0].shape), vace_context[0][:16, :4].clone()))
+            return super().__call__(x, t, context, **kw)
+    frames, mask, refs = inputs()
+    m = VaceDiT("A")
+    pipe = WanAny2VHIP(m, vae=FakeVAE(), device="cpu")
+    previews = []
+    out = run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs, input_ref_masks=[None, None],
+              callback=lambda i, lat=None, *a, **k: previews.append(None if lat is None else tuple(lat.shape)))
+    assert all(xs == (1, 16, 3 + 2, 4, 6) and zs == (96, 3 + 2, 4, 6) for xs, zs, _ in m.seen)       # 3 latent frames + 2 reference frames
+    assert tuple(out["latents"].shape) == (1, 16, 3, 4, 6)
+    assert [p for p in previews if p is not None and len(p) == 4][-1] == (16, 3, 4, 6)
+    zref = pipe.vace_context([frames], [mask], refs, 0)[0]
+    assert torch.equal(m.seen[0][2][:, :2], zref[:16, :2]) and torch.equal(zref[16:32, :2], torch.zeros_like(zref[16:32, :2]))   # ref latents | zeros
+    assert torch.equal(zref[32:, :2], torch.zeros_like(zref[32:, :2]))                               # zero mask frames in front
+    # + sliding-window overlap of 1 latent frame: prefix = 2 reference frames + 1 overlap frame, context noise on the overlap frame only
+    m2 = VaceDiT("A")
+    torch.manual_seed(5)
+    out2 = run(WanAny2VHIP(m2, vae=FakeVAE(), device="cpu"), width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs,
+               overlapped_latents=torch.zeros(1, 16, 1, 4, 6), overlap_noise=20, return_latent_slice=slice(-1, None))
+    assert tuple(out2["latents"].shape) == (1, 16, 3, 4, 6) and tuple(out2["latent_slice"].shape) == (1, 16, 1, 4, 6)
+    assert torch.equal(out2["latents"][:, :, :1], zref[:16, 2:3].unsqueeze(0))                       # the clean overlap frame leads the result
+    assert all(torch.equal(z4[:, :2], zref[:16, :2]) for _, _, z4 in m2.seen)                       # reference frames of the context untouched
+    assert not any(torch.equal(z4[:, 2:3], zref[:16, 2:3]) for _, _, z4 in m2.seen)                  # its overlap frame re-noised every step
+    # refusals
+    with pytest.raises(NotImplementedError, match="VACE path"):
+        run(WanAny2VHIP(FakeDiT("A"), device="cpu"), input_ref_images=refs)
+    with pytest.raises(NotImplementedError, match="input_ref_masks"):
+        run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs, input_ref_masks=[torch.zeros(1, 1, 32, 48), None])
+    with pytest.raises(NotImplementedError, match="sub-parallel"):
+        run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs, sub_parallel_window_size=9)
+
+
 def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():
     """wgp.py passes every generate() the union of all variants' keywords (wgp.py:7762-7885): defaults and UI plumbing are accepted
     silently, a keyword that would change the video through a path this backend does not serve raises."""
@@ -516,7 +561,7 @@ def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():
     out = run(pipe, input_ref_images=None, audio_guide=None, overlap_noise=0, image_mode=0, alt_guide_scale=1.0, fit_into_canvas=True, window_no=1,
               offloadobj=object(), set_header_text=lambda *a: None, model_filename="x.safetensors", fps=16, gen_state={}, custom_settings=None)
     assert torch.isfinite(out["latents"]).all()
-    for kw in (dict(input_ref_images=[torch.zeros(3, 8, 8)]),
+    for kw in (dict(input_frames2=torch.zeros(3, 5, 8, 8)),
                dict(audio_proj=torch.zeros(1)), dict(image_mode=1), dict(alt_guide_scale=2.0), dict(vae_upsampler="x")):
         with pytest.raises(NotImplementedError, match=list(kw)[0]):
             run(pipe, **kw)

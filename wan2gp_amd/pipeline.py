@@ -27,7 +27,7 @@ from .schedulers import (EulerScheduler, FlowDPMSolverMultistepScheduler, FlowMa
 # svi_pro path, which does not reach this backend; the i2v path's use of it is switched off there, :779), `prefix_video` / `pre_video_frame` /
 # `conditioning_latents_size` (non-empty whenever a start image or a source video is used, wgp.py:7378-7394, :7714; read only on
 # the svi_pro / infinitetalk / scail2 / reference-image paths, any2video.py:659-728, :861-897, none of which reaches this backend).
-_UNSERVED_WHEN_SET = {"input_frames2": None, "input_masks2": None, "input_ref_images": None, "input_ref_masks": None, "input_faces": None,
+_UNSERVED_WHEN_SET = {"input_frames2": None, "input_masks2": None, "input_faces": None,
                       "input_custom": None, "audio_scale": None, "audio_proj": None, "audio_context_lens": None, "audio_guide": None,
                       "audio_guide2": None, "input_waveform": None, "alt_guide_scale": 1.0,
                       "speakers_bboxes": None, "image_mode": 0, "face_arc_embeds": None, "control_scale_alt": 1.0, "vae_upsampler": None}
@@ -235,7 +235,7 @@ class WanAny2VHIP:
                  return_latent_slice=None, video_prompt_type="", denoising_strength=1.0, masking_strength=1.0, keep_frames_parsed=None,
                  prefix_frames_count=0, self_refiner_setting=0, self_refiner_plan="", self_refiner_f_uncertainty=0.0,
                  self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, set_header_text=None,
-                 overlapped_latents=None, overlap_noise=0, **bbargs):
+                 overlapped_latents=None, overlap_noise=0, input_ref_images=None, input_ref_masks=None, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         # wgp.py hands every generate() the union of all variants' keywords (wgp.py:7762-7885); the ones below change the result
@@ -245,7 +245,7 @@ class WanAny2VHIP:
                     if bbargs.get(k, None) is not None and not _same(bbargs[k], default)}
         if unserved:
             raise NotImplementedError(f"WanAny2VHIP.generate: {sorted(unserved)} select reference paths outside this backend "
-                                      "(reference images / second control video / audio / image outputs / VAE upsampler)")
+                                      "(second control video / faces / audio / image outputs / VAE upsampler)")
         if context is None:
             if self.text_encoder is None or input_prompt is None:
                 raise ValueError("pass `context`/`context_null` ([1,512,4096] bf16) or a text_encoder + input_prompt")
@@ -294,7 +294,21 @@ class WanAny2VHIP:
         if add_end:
             lat_frames = int((frame_num + 1 - 2) // self.vae_stride[0] + 2)
             trim_frames = 1
-        target_shape = (getattr(self.model, "out_dim", 16), lat_frames, height // self.vae_stride[1],
+        # VACE reference images (any2video.py:1128-1149, ref_images_before): each image becomes one extra latent frame IN FRONT of
+        # the control context and of the latents (target_shape :1166); those frames are cut off before decoding (:1758) and from the
+        # previews (:1745).  Reference images of other model families (phantom, lynx, ...) and the background-mask variant
+        # (input_ref_masks, :1138-1145) are not served.
+        ref_count = 0
+        if input_ref_images is not None and len(input_ref_images) > 0:
+            if getattr(self.model, "vace_layers", None) is None or input_frames is None:
+                raise NotImplementedError("WanAny2VHIP.generate: input_ref_images are served on the VACE path only (a model with VACE "
+                                          "blocks and a control video)")
+            if input_ref_masks is not None and any(m is not None for m in input_ref_masks):
+                raise NotImplementedError("WanAny2VHIP.generate: input_ref_masks (background reference mask, any2video.py:1138-1145) is not served")
+            if sub_parallel_window_size:
+                raise NotImplementedError("WanAny2VHIP.generate: reference images together with sub-parallel windows are not served")
+            ref_count = len(input_ref_images)
+        target_shape = (getattr(self.model, "out_dim", 16), lat_frames + ref_count, height // self.vae_stride[1],
                         width // self.vae_stride[2])                                   # :1166 (48 channels, stride 16 for ti2v 5B)
         freqs = get_rotary_pos_embed(target_shape[1:], enable_RIFLEx=bool(enable_RIFLEx), device=dev)   # :1192
         if latents is None:
@@ -339,17 +353,18 @@ class WanAny2VHIP:
             randn = latents                                                                  # :1475 -- the SAME tensor, as there
         vace_kwargs, vace_overlap = {}, False
         if input_frames is not None and (not v2v_on or getattr(self.model, "vace_layers", None) is not None):
-            # VACE control video + mask (any2video.py:1128-1147), no reference images
+            # VACE control video + mask (any2video.py:1128-1147), reference images in front if given
             if self.vae is None or input_masks is None:
                 raise ValueError("VACE needs a VAE, input_frames [3,T,H,W] and input_masks [1,T,H,W]")
-            z = self.vace_context([input_frames.to(dev)], [input_masks.to(dev)], None, VAE_tile_size)
+            z = self.vace_context([input_frames.to(dev)], [input_masks.to(dev)],
+                                  [u.to(dev) for u in input_ref_images] if ref_count else None, VAE_tile_size)
             vace_kwargs = {"vace_context": z, "vace_context_scale": context_scale if context_scale is not None else [1.0] * len(z)}
             # sliding windows (any2video.py:1150-1152): wgp.py hands the previous window's last latent frames; the INACTIVE half of
             # the control video's first latent frames (the overlap, which the control video repeats) is what gets pinned: injected
             # re-noised in front of every step and clean behind the last one, like the i2v prefix
             vace_overlap = overlapped_latents is not None
             if vace_overlap:
-                ext_latents = z[0][:16, :overlapped_latents.shape[2]].clone().unsqueeze(0)
+                ext_latents = z[0][:16, :overlapped_latents.shape[2] + ref_count].clone().unsqueeze(0)      # :1151-1152
         any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
         trans = self.model
         guidance_switch_done = guidance_switch2_done = False
@@ -435,7 +450,7 @@ class WanAny2VHIP:
                     if vace_overlap:                             # :1523-1526: the context's overlap frames get `overlap_noise` / 1000 of noise
                         of = overlap_noise / 1000
                         for zz in vace_kwargs["vace_context"]:
-                            zz[0:16, :n] = ext_latents[0] * (1.0 - of) + torch.randn_like(ext_latents[0]) * of
+                            zz[0:16, ref_count:n] = ext_latents[0, :, ref_count:] * (1.0 - of) + torch.randn_like(ext_latents[0, :, ref_count:]) * of
                 def denoise_with_cfg(lat):                       # denoise_with_cfg_fn, plain two-stream branch (any2video.py:1610-1722)
                     nonlocal text_momentum
                     if guide_scale == 1 or not any_guidance:
@@ -485,13 +500,16 @@ class WanAny2VHIP:
                 if v2v is not None:                              # :1737-1740: outside the mask, the source at the next step's noise level
                     latents = video2video.merge(latents, randn, v2v_src, timesteps, i, v2v)
                 if callback is not None:                         # :1743-1750: the preview leaves out the padded end-image frame
-                    progress.step(i, (latents[:, :, :-trim_frames] if trim_frames > 0 else latents)[0])
+                    pv = latents[:, :, ref_count:] if ref_count else latents                      # :1745: not the reference-image frames
+                    progress.step(i, (pv[:, :, :-trim_frames] if trim_frames > 0 else pv)[0])
         finally:
             restore_caches()                                 # also when a forward raises: parked caches must come back
         if source_latents is not None:
             latents[:, :, :source_latents.shape[2]] = source_latents                               # :1753-1754
         if ext_latents is not None:
             latents[:, :, :ext_latents.shape[2]] = ext_latents                                     # :1755-1756
+        if ref_count:
+            latents = latents[:, :, ref_count:]                                                    # :1758 (ref_images_before)
         if trim_frames > 0:
             latents = latents[:, :, :-trim_frames]                                                 # :1759
         # :1760-1761: the latent frames a sliding-window caller asks back (a slice object over the latent time axis)
