@@ -509,6 +509,34 @@ def test_vace_sliding_window_pins_the_overlap_of_the_control_video():
     assert torch.equal(a["latents"], b["latents"])
 
 
+def test_vace_second_control_video_is_a_second_context_with_its_own_scale():
+    """any2video.py:1129-1130, :1148: input_frames2 / input_masks2 = one more VACE context through the same context blocks;
+    context_scale carries one weight per context (wgp.py:7525).  Outside the VACE path the keyword is refused."""
+    from oracle.make_golden_vace_context import FakeVAE, inputs
+
+    class VaceDiT(FakeDiT):
+        vace_layers = (0,)
+
+        def __call__(self, x, t, context, vace_context=None, vace_context_scale=None, **kw):
+            self.vace = ([tuple(z.shape) for z in vace_context], list(vace_context_scale), [z.clone() for z in vace_context])
+            return super().__call__(x, t, context, **kw)
+    frames, mask, _ = inputs()
+    frames2, mask2 = frames.flip(1), 1 - mask
+    m = VaceDiT("A")
+    pipe = WanAny2VHIP(m, vae=FakeVAE(), device="cpu")
+    run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_frames2=frames2, input_masks2=mask2, context_scale=[0.5, 0.25],
+        control_scale_alt=0.3)
+    assert m.vace[0] == [(96, 3, 4, 6), (96, 3, 4, 6)] and m.vace[1] == [0.5, 0.25]
+    want = pipe.vace_context([frames, frames2], [mask, mask2], None, 0)
+    assert torch.equal(m.vace[2][0], want[0]) and torch.equal(m.vace[2][1], want[1]) and not torch.equal(want[0], want[1])
+    run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_frames2=frames2, input_masks2=mask2)
+    assert m.vace[1] == [1.0, 1.0]                                                                  # :1148
+    with pytest.raises(NotImplementedError, match="input_frames2"):
+        run(WanAny2VHIP(FakeDiT("A"), device="cpu"), input_frames2=frames2, input_masks2=mask2)
+    with pytest.raises(ValueError, match="come together"):
+        run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_frames2=frames2)
+
+
 def test_vace_reference_images_are_extra_latent_frames_in_front_and_are_cut_off_at_the_end():
     """VACE reference images (any2video.py:1128-1166, :1745, :1758, ref_images_before): n images = n extra latent frames in front of the
     control context (their latents beside zero masks, vace_encode_frames / _masks -- pinned to the reference by
@@ -561,8 +589,8 @@ def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():
     out = run(pipe, input_ref_images=None, audio_guide=None, overlap_noise=0, image_mode=0, alt_guide_scale=1.0, fit_into_canvas=True, window_no=1,
               offloadobj=object(), set_header_text=lambda *a: None, model_filename="x.safetensors", fps=16, gen_state={}, custom_settings=None)
     assert torch.isfinite(out["latents"]).all()
-    for kw in (dict(input_frames2=torch.zeros(3, 5, 8, 8)),
-               dict(audio_proj=torch.zeros(1)), dict(image_mode=1), dict(alt_guide_scale=2.0), dict(vae_upsampler="x")):
+    for kw in (dict(input_faces=torch.zeros(3, 5, 8, 8)),
+               dict(audio_proj=torch.zeros(1)), dict(image_mode=1), dict(alt_guide_scale=2.0), dict(vae_upsampler="x")):  # noqa: E501
         with pytest.raises(NotImplementedError, match=list(kw)[0]):
             run(pipe, **kw)
 

@@ -27,10 +27,11 @@ from .schedulers import (EulerScheduler, FlowDPMSolverMultistepScheduler, FlowMa
 # svi_pro path, which does not reach this backend; the i2v path's use of it is switched off there, :779), `prefix_video` / `pre_video_frame` /
 # `conditioning_latents_size` (non-empty whenever a start image or a source video is used, wgp.py:7378-7394, :7714; read only on
 # the svi_pro / infinitetalk / scail2 / reference-image paths, any2video.py:659-728, :861-897, none of which reaches this backend).
-_UNSERVED_WHEN_SET = {"input_frames2": None, "input_masks2": None, "input_faces": None,
+_UNSERVED_WHEN_SET = {"input_faces": None,
                       "input_custom": None, "audio_scale": None, "audio_proj": None, "audio_context_lens": None, "audio_guide": None,
                       "audio_guide2": None, "input_waveform": None, "alt_guide_scale": 1.0,
-                      "speakers_bboxes": None, "image_mode": 0, "face_arc_embeds": None, "control_scale_alt": 1.0, "vae_upsampler": None}
+                      "speakers_bboxes": None, "image_mode": 0, "face_arc_embeds": None, "vae_upsampler": None}
+# (`control_scale_alt` is read for the lynx models only, any2video.py:1103-1104: accepted without effect like there)
 
 
 def _same(v, default):
@@ -235,7 +236,8 @@ class WanAny2VHIP:
                  return_latent_slice=None, video_prompt_type="", denoising_strength=1.0, masking_strength=1.0, keep_frames_parsed=None,
                  prefix_frames_count=0, self_refiner_setting=0, self_refiner_plan="", self_refiner_f_uncertainty=0.0,
                  self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, set_header_text=None,
-                 overlapped_latents=None, overlap_noise=0, input_ref_images=None, input_ref_masks=None, **bbargs):
+                 overlapped_latents=None, overlap_noise=0, input_ref_images=None, input_ref_masks=None, input_frames2=None, input_masks2=None,
+                 **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         # wgp.py hands every generate() the union of all variants' keywords (wgp.py:7762-7885); the ones below change the result
@@ -245,7 +247,7 @@ class WanAny2VHIP:
                     if bbargs.get(k, None) is not None and not _same(bbargs[k], default)}
         if unserved:
             raise NotImplementedError(f"WanAny2VHIP.generate: {sorted(unserved)} select reference paths outside this backend "
-                                      "(second control video / faces / audio / image outputs / VAE upsampler)")
+                                      "(faces / audio / image outputs / VAE upsampler)")
         if context is None:
             if self.text_encoder is None or input_prompt is None:
                 raise ValueError("pass `context`/`context_null` ([1,512,4096] bf16) or a text_encoder + input_prompt")
@@ -352,11 +354,17 @@ class WanAny2VHIP:
             timesteps, start_step_no = v2v.timesteps, v2v.start_step_no
             randn = latents                                                                  # :1475 -- the SAME tensor, as there
         vace_kwargs, vace_overlap = {}, False
+        if input_frames2 is not None and (input_frames is None or getattr(self.model, "vace_layers", None) is None):
+            raise NotImplementedError("WanAny2VHIP.generate: input_frames2 is served as VACE's second control video only")
         if input_frames is not None and (not v2v_on or getattr(self.model, "vace_layers", None) is not None):
             # VACE control video + mask (any2video.py:1128-1147), reference images in front if given
             if self.vae is None or input_masks is None:
                 raise ValueError("VACE needs a VAE, input_frames [3,T,H,W] and input_masks [1,T,H,W]")
-            z = self.vace_context([input_frames.to(dev)], [input_masks.to(dev)],
+            # a second control video (any2video.py:1129-1130): one more context, run through the same context blocks with its own scale
+            if (input_frames2 is None) != (input_masks2 is None):
+                raise ValueError("input_frames2 and input_masks2 come together (any2video.py:1129-1130)")
+            z = self.vace_context([input_frames.to(dev)] + ([] if input_frames2 is None else [input_frames2.to(dev)]),
+                                  [input_masks.to(dev)] + ([] if input_masks2 is None else [input_masks2.to(dev)]),
                                   [u.to(dev) for u in input_ref_images] if ref_count else None, VAE_tile_size)
             vace_kwargs = {"vace_context": z, "vace_context_scale": context_scale if context_scale is not None else [1.0] * len(z)}
             # sliding windows (any2video.py:1150-1152): wgp.py hands the previous window's last latent frames; the INACTIVE half of
