@@ -746,3 +746,52 @@ def test_video_to_video_keeps_the_whole_schedule_for_cache_thresholds_and_lora_s
     assert len(m.calls) == 3
     assert m.thresholds == ("mag", 3, 6, 2.0) and m.cache.num_steps == 6
     assert m.loras.steps == [(6, 3), (6, 4), (6, 5)]
+
+
+def test_later_sliding_windows_are_colour_matched_to_their_reference_frame_after_decoding():
+    """any2video.py:552, :667-687, :1008-1009, :1153-1154, :1783-1808: with color_correction_strength > 0 (its default is 1) and
+    window_start_frame_no + prefix_frames_count > 1 the decoded window is Lab-matched to a reference frame -- the last prefix frame
+    of the control video (VACE), the last frame of the video being continued (i2v); never with an end image, never for the first
+    window, never for strength 0."""
+    from oracle.make_golden_vace_context import FakeVAE, inputs
+    from wan2gp_amd.color import correct_window
+
+    class DecVAE(FakeVAE):
+        def decode_to_cpu_uint8(self, zs, tile_size=0):
+            out = []
+            for z in zs:
+                v = torch.nn.functional.interpolate(z[None, :3].float(), scale_factor=(1, 8, 8), mode="nearest")[0]
+                out.append(((v * 0.6).tanh() * 0.8 + 1.0).mul(127.5).round().clamp(0, 255).to(torch.uint8))
+            return out
+
+    class VaceDiT(FakeDiT):
+        vace_layers = (0,)
+
+        def __call__(self, x, t, context, vace_context=None, vace_context_scale=None, **kw):
+            return super().__call__(x, t, context, **kw)
+    frames, mask, _ = inputs()
+    kw = dict(width=48, height=32, input_frames=frames, input_masks=mask, return_latents=False)
+    plain = run(WanAny2VHIP(VaceDiT("A"), vae=DecVAE(), device="cpu"), color_correction_strength=0, prefix_frames_count=3, window_start_frame_no=5, **kw)["x"]
+    first = run(WanAny2VHIP(VaceDiT("A"), vae=DecVAE(), device="cpu"), prefix_frames_count=1, window_start_frame_no=0, **kw)["x"]
+    noprefix = run(WanAny2VHIP(VaceDiT("A"), vae=DecVAE(), device="cpu"), prefix_frames_count=0, window_start_frame_no=5, **kw)["x"]
+    assert plain.dtype == torch.uint8 and torch.equal(first, plain) and torch.equal(noprefix, plain)      # no reference frame without a prefix
+    for strength in (1, 0.4):
+        got = run(WanAny2VHIP(VaceDiT("A"), vae=DecVAE(), device="cpu"), color_correction_strength=strength, prefix_frames_count=3,
+                  window_start_frame_no=5, **kw)["x"]
+        assert torch.equal(got, correct_window(plain, frames[:, 2:3], strength)) and not torch.equal(got, plain)
+    # i2v: the reference frame is the last frame of the continued video; an end image switches the correction off
+    g = torch.Generator().manual_seed(3)
+    prefix = torch.rand(3, 5, 64, 64, generator=g) * 2 - 1
+
+    class I2VVAE(_StubVAE, DecVAE):
+        pass
+
+    def i2v(**over):
+        m = FakeDiT("A")
+        m.model_type = "i2v2_2"
+        return run(WanAny2VHIP(m, vae=I2VVAE(), device="cpu"), input_video=prefix, return_latents=False, **over)["x"]
+    base = i2v(color_correction_strength=0, prefix_frames_count=5, window_start_frame_no=12)
+    assert torch.equal(i2v(prefix_frames_count=5, window_start_frame_no=12), correct_window(base, prefix[:, -1:], 1))
+    assert torch.equal(i2v(prefix_frames_count=1, window_start_frame_no=0), base)
+    with_end = dict(image_end=prefix[:, 0], prefix_frames_count=5, window_start_frame_no=12)
+    assert torch.equal(i2v(**with_end), i2v(color_correction_strength=0, **with_end))

@@ -237,7 +237,7 @@ class WanAny2VHIP:
                  prefix_frames_count=0, self_refiner_setting=0, self_refiner_plan="", self_refiner_f_uncertainty=0.0,
                  self_refiner_certain_percentage=0.999, perturbation_layers=None, perturbation_start=0.0, perturbation_end=1.0, set_header_text=None,
                  overlapped_latents=None, overlap_noise=0, input_ref_images=None, input_ref_masks=None, input_frames2=None, input_masks2=None,
-                 **bbargs):
+                 color_correction_strength=1, window_start_frame_no=0, **bbargs):
         if batch_size != 1:
             raise NotImplementedError("batch_size 1 per generate() call (as wgp.py drives it)")
         # wgp.py hands every generate() the union of all variants' keywords (wgp.py:7762-7885); the ones below change the result
@@ -291,7 +291,7 @@ class WanAny2VHIP:
         # without the causal cache and trimmed from the latents before decoding; Wan2.2 i2v keeps the frame count
         trim_frames = 0
         add_end = image_end is not None and getattr(self.model, "model_type", None) == "i2v"
-        if image_end is not None and image_start is None:
+        if image_end is not None and image_start is None and input_video is None:    # wgp.py's spelling of the start is input_video
             raise ValueError("image_end needs image_start (any2video.py:667-704)")
         if add_end:
             lat_frames = int((frame_num + 1 - 2) // self.vae_stride[0] + 2)
@@ -322,8 +322,14 @@ class WanAny2VHIP:
         # image_start = input_video[:, -1]); wgp.py always passes input_video = the start image as [3,1,H,W] or the video to
         # continue.  `image_start` (what direct callers of this class pass) is the same thing under the other name.
         ext_latents = None
-        if getattr(self.model, "model_type", None) in ("i2v", "i2v2_2") and input_video is not None:
-            image_start, input_video = input_video, None
+        # the frame a later sliding window's colours are matched to after decoding (any2video.py:552, :1783-1808; color.py)
+        color_reference_frame = None
+        if getattr(self.model, "model_type", None) in ("i2v", "i2v2_2"):
+            if input_video is None or image_end is not None:
+                color_correction_strength = 0                                        # :667-669, :686-687
+            if input_video is not None:
+                image_start, input_video = input_video, None
+                color_reference_frame = (image_start[:, -1] if image_start.dim() == 4 else image_start).unsqueeze(1).clone()   # :682
         if image_start is not None:
             if self.vae is None:
                 raise ValueError("image_start needs a VAE to encode the conditioning video")
@@ -352,6 +358,8 @@ class WanAny2VHIP:
                                    denoising_strength, masking_strength, list(keep_frames_parsed or []), prefix_frames_count, timesteps,
                                    sample_scheduler, device=dev, video_prompt_type=video_prompt_type)
             timesteps, start_step_no = v2v.timesteps, v2v.start_step_no
+            if denoising_strength < 1:
+                color_reference_frame = input_frames[:, -1:].clone()                              # :1008-1009
             randn = latents                                                                  # :1475 -- the SAME tensor, as there
         vace_kwargs, vace_overlap = {}, False
         if input_frames2 is not None and (input_frames is None or getattr(self.model, "vace_layers", None) is None):
@@ -373,6 +381,8 @@ class WanAny2VHIP:
             vace_overlap = overlapped_latents is not None
             if vace_overlap:
                 ext_latents = z[0][:16, :overlapped_latents.shape[2] + ref_count].clone().unsqueeze(0)      # :1151-1152
+            if prefix_frames_count > 0:
+                color_reference_frame = input_frames[:, prefix_frames_count - 1:prefix_frames_count].clone()   # :1153-1154
         any_guidance = guide_scale != 1 or (guide_phases > 1 and guide2_scale != 1)
         trans = self.model
         guidance_switch_done = guidance_switch2_done = False
@@ -527,5 +537,9 @@ class WanAny2VHIP:
         if getattr(self.vae, "sp", None) is None and getattr(self.model, "sp", None) is not None:
             self.vae.sp = self.model.sp                      # multi-GPU: a tiled decode spreads its tiles over the sequence-parallel ranks
         x0 = latents.unbind(0)                                                                     # :1763
-        videos = self.vae.decode_to_cpu_uint8(x0, VAE_tile_size)                                   # :1784
-        return {"x": videos[0], "latents": latents, "latent_slice": latent_slice}
+        videos = self.vae.decode_to_cpu_uint8(x0, VAE_tile_size)[0]                                # :1784, :1798
+        # :1783, :1799-1808: every window after the first is colour-matched (Lab mean / std per frame) to its reference frame
+        if color_correction_strength > 0 and (window_start_frame_no + prefix_frames_count) > 1 and color_reference_frame is not None:
+            from .color import correct_window
+            videos = correct_window(videos, color_reference_frame, color_correction_strength)
+        return {"x": videos, "latents": latents, "latent_slice": latent_slice}
