@@ -59,6 +59,17 @@ def main():
     z = ns["vace_encode_frames"](me, [frames], refs, masks=[mask])
     m = ns["vace_encode_masks"](me, [mask], refs)
     out["z_ref"], out["m_ref"] = z[0].numpy(), m[0].numpy()
+    # the background-mask variant of the first reference image: the composition of any2video.py:1138-1145 around the same two functions
+    bgm = (torch.rand(1, 1, 32, 48, generator=torch.Generator().manual_seed(78)) > 0.5).float()
+    ref_masks = [bgm, None]
+    z0 = ns["vace_encode_frames"](me, [frames], refs, masks=[mask])
+    m0 = ns["vace_encode_masks"](me, [mask], refs)
+    zbg = ns["vace_encode_frames"](me, refs[:1] * 1, None, masks=ref_masks[0])
+    mbg = ns["vace_encode_masks"](me, ref_masks[:1] * 1, None)
+    for zz0, mm0, zzbg, mmbg in zip(z0, m0, zbg, mbg):
+        zz0[:, 0:1] = zzbg
+        mm0[:, 0:1] = mmbg
+    out["bg_mask"], out["z_bg"], out["m_bg"] = bgm.numpy(), z0[0].numpy(), m0[0].numpy()
     out["z_nomask"] = ns["vace_encode_frames"](me, [frames], None, masks=None)[0].numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: v.shape for k, v in out.items()})

@@ -542,7 +542,7 @@ def test_vace_reference_images_are_extra_latent_frames_in_front_and_are_cut_off_
     control context (their latents beside zero masks, vace_encode_frames / _masks -- pinned to the reference by
     tests/golden/vace_context.npz) AND of the latents the model sees; the previews and the result leave them out.  Together with
     sliding-window overlap the pinned prefix spans reference frames + overlap, the context noise only the overlap (:1151-1152, :1526).
-    Outside the VACE path, with a background reference mask, or with sub-parallel windows: refused."""
+    Outside the VACE path or with sub-parallel windows: refused."""
     from oracle.make_golden_vace_context import FakeVAE, inputs
 
     class VaceDiT(FakeDiT):
@@ -576,8 +576,15 @@ def test_vace_reference_images_are_extra_latent_frames_in_front_and_are_cut_off_
     # refusals
     with pytest.raises(NotImplementedError, match="VACE path"):
         run(WanAny2VHIP(FakeDiT("A"), device="cpu"), input_ref_images=refs)
-    with pytest.raises(NotImplementedError, match="input_ref_masks"):
-        run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs, input_ref_masks=[torch.zeros(1, 1, 32, 48), None])
+    # a background mask for the first reference image (:1138-1145): its context frame becomes the masked encoding (pinned to the
+    # reference's functions by tests/test_vace_context_vs_golden.py), nothing else changes
+    bgm = (torch.rand(1, 1, 32, 48, generator=torch.Generator().manual_seed(78)) > 0.5).float()
+    m3 = VaceDiT("A")
+    run(WanAny2VHIP(m3, vae=FakeVAE(), device="cpu"), width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs,
+        input_ref_masks=[bgm, None])
+    zbg = pipe.vace_context([frames], [mask], refs, 0, [bgm, None])[0]
+    assert all(xs == (1, 16, 5, 4, 6) and zs == (96, 5, 4, 6) and torch.equal(z4, zbg[:16, :4]) for xs, zs, z4 in m3.seen)
+    assert not torch.equal(zbg[:16, :1], zref[:16, :1]) and torch.equal(zbg[:, 1:], zref[:, 1:])
     with pytest.raises(NotImplementedError, match="sub-parallel"):
         run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs, sub_parallel_window_size=9)
 
@@ -779,6 +786,12 @@ def test_later_sliding_windows_are_colour_matched_to_their_reference_frame_after
         got = run(WanAny2VHIP(VaceDiT("A"), vae=DecVAE(), device="cpu"), color_correction_strength=strength, prefix_frames_count=3,
                   window_start_frame_no=5, **kw)["x"]
         assert torch.equal(got, correct_window(plain, frames[:, 2:3], strength)) and not torch.equal(got, plain)
+    # VACE with a background mask on the first reference image and no prefix: that image is the colour reference (:1139)
+    _, _, refs = inputs()
+    bgm = (torch.rand(1, 1, 32, 48, generator=torch.Generator().manual_seed(78)) > 0.5).float()
+    kb = dict(kw, input_ref_images=refs, input_ref_masks=[bgm, None], prefix_frames_count=0, window_start_frame_no=5)
+    base_bg = run(WanAny2VHIP(VaceDiT("A"), vae=DecVAE(), device="cpu"), color_correction_strength=0, **kb)["x"]
+    assert torch.equal(run(WanAny2VHIP(VaceDiT("A"), vae=DecVAE(), device="cpu"), **kb)["x"], correct_window(base_bg, refs[0], 1))
     # i2v: the reference frame is the last frame of the continued video; an end image switches the correction off
     g = torch.Generator().manual_seed(3)
     prefix = torch.rand(3, 5, 64, 64, generator=g) * 2 - 1

@@ -25,3 +25,15 @@ def test_vace_context_reproduces_reference():
     z = pipe.vace_context([frames], [mask])[0]
     assert tuple(z.shape) == (96, 3, 4, 6) and torch.equal(z, torch.cat([t("z_noref"), t("m_noref")], dim=0))
     assert tuple(t("z_ref").shape) == (32, 5, 4, 6) and tuple(t("m_ref").shape) == (64, 5, 4, 6)      # two reference frames in front
+
+
+def test_background_mask_of_the_first_reference_image_replaces_its_latent_and_mask_frame():
+    """any2video.py:1138-1145 (recorded from the reference's two methods composed as generate() composes them): with
+    input_ref_masks[0] the first reference frame of the context is the masked (inactive | reactive) encoding and its folded mask."""
+    pipe = WanAny2VHIP(model=None, vae=FakeVAE(), device="cpu")
+    frames, mask, refs = inputs()
+    z = pipe.vace_context([frames], [mask], refs, 0, [t("bg_mask"), None])[0]
+    assert torch.equal(z, torch.cat([t("z_bg"), t("m_bg")], dim=0))
+    plain = pipe.vace_context([frames], [mask], refs)[0]
+    assert torch.equal(z[:, 1:], plain[:, 1:]) and not torch.equal(z[:, :1], plain[:, :1])
+    assert torch.equal(pipe.vace_context([frames], [mask], refs, 0, [None, None])[0], plain)

@@ -215,10 +215,18 @@ class WanAny2VHIP:
             out.append(m)
         return out
 
-    def vace_context(self, input_frames, input_masks, input_ref_images=None, tile_size=0):
-        """z = [cat(z0, m0)] as built at any2video.py:1136-1146 (no background reference mask): [96, F, H, W] per control video."""
+    def vace_context(self, input_frames, input_masks, input_ref_images=None, tile_size=0, input_ref_masks=None):
+        """z = [cat(z0, m0)] as built at any2video.py:1136-1146: [96, F, H, W] per control video.  With a background mask for the first
+        reference image (`input_ref_masks[0]`, [1,1,H,W]: an outpainted background, :1138-1145) that image's latent frame and mask frame
+        are replaced by the masked encodings (inactive / reactive halves, folded mask) in every context."""
         z0 = self.vace_encode_frames(input_frames, input_ref_images, masks=input_masks, tile_size=tile_size)
         m0 = self.vace_encode_masks(input_masks, input_ref_images)
+        if input_ref_masks is not None and len(input_ref_masks) > 0 and input_ref_masks[0] is not None:
+            zbg = self.vace_encode_frames(input_ref_images[:1] * len(input_frames), None, masks=input_ref_masks[0], tile_size=tile_size)
+            mbg = self.vace_encode_masks(input_ref_masks[:1] * len(input_frames), None)
+            for zz0, mm0, zzbg, mmbg in zip(z0, m0, zbg, mbg):
+                zz0[:, 0:1] = zzbg
+                mm0[:, 0:1] = mmbg
         return [torch.cat([zz, mm.to(zz.dtype)], dim=0) for zz, mm in zip(z0, m0)]
 
     def get_loras_transformer(self, get_model_recursive_prop, base_model_type, model_type, video_prompt_type, model_mode, **kwargs):
@@ -298,15 +306,12 @@ class WanAny2VHIP:
             trim_frames = 1
         # VACE reference images (any2video.py:1128-1149, ref_images_before): each image becomes one extra latent frame IN FRONT of
         # the control context and of the latents (target_shape :1166); those frames are cut off before decoding (:1758) and from the
-        # previews (:1745).  Reference images of other model families (phantom, lynx, ...) and the background-mask variant
-        # (input_ref_masks, :1138-1145) are not served.
+        # previews (:1745).  Reference images of other model families (phantom, lynx, ...) are not served.
         ref_count = 0
         if input_ref_images is not None and len(input_ref_images) > 0:
             if getattr(self.model, "vace_layers", None) is None or input_frames is None:
                 raise NotImplementedError("WanAny2VHIP.generate: input_ref_images are served on the VACE path only (a model with VACE "
                                           "blocks and a control video)")
-            if input_ref_masks is not None and any(m is not None for m in input_ref_masks):
-                raise NotImplementedError("WanAny2VHIP.generate: input_ref_masks (background reference mask, any2video.py:1138-1145) is not served")
             if sub_parallel_window_size:
                 raise NotImplementedError("WanAny2VHIP.generate: reference images together with sub-parallel windows are not served")
             ref_count = len(input_ref_images)
@@ -373,7 +378,10 @@ class WanAny2VHIP:
                 raise ValueError("input_frames2 and input_masks2 come together (any2video.py:1129-1130)")
             z = self.vace_context([input_frames.to(dev)] + ([] if input_frames2 is None else [input_frames2.to(dev)]),
                                   [input_masks.to(dev)] + ([] if input_masks2 is None else [input_masks2.to(dev)]),
-                                  [u.to(dev) for u in input_ref_images] if ref_count else None, VAE_tile_size)
+                                  [u.to(dev) for u in input_ref_images] if ref_count else None, VAE_tile_size,
+                                  None if not ref_count or input_ref_masks is None else [None if u is None else u.to(dev) for u in input_ref_masks])
+            if ref_count and input_ref_masks is not None and len(input_ref_masks) > 0 and input_ref_masks[0] is not None:
+                color_reference_frame = input_ref_images[0].clone()                                  # :1139
             vace_kwargs = {"vace_context": z, "vace_context_scale": context_scale if context_scale is not None else [1.0] * len(z)}
             # sliding windows (any2video.py:1150-1152): wgp.py hands the previous window's last latent frames; the INACTIVE half of
             # the control video's first latent frames (the overlap, which the control video repeats) is what gets pinned: injected
