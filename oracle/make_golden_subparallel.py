@@ -56,6 +56,9 @@ def fake_denoise_factory(kwargs):
             out = out + 0.1 * kwargs["y"].mean(dim=0).view(1, 1, f, *lat.shape[3:])
         if kwargs.get("vace_context") is not None:
             out = out + 0.05 * kwargs["vace_context"][0][:16].unsqueeze(0)
+        if torch.is_tensor(kwargs.get("t")) and kwargs["t"].numel() > 1:       # per-frame timesteps (ti2v): must arrive sliced to the window
+            assert kwargs["t"].numel() == f, (kwargs["t"].numel(), f)
+            out = out + 0.001 * kwargs["t"].to(out.dtype).view(1, 1, f, 1, 1)
         return out
     return fn
 
@@ -63,17 +66,25 @@ def fake_denoise_factory(kwargs):
 def cases():
     return [dict(name="w17o5_f21", size=17, overlap=5, lat=21), dict(name="w33o9_f21", size=33, overlap=9, lat=21),
             dict(name="w9o0_f11", size=9, overlap=0, lat=11), dict(name="w81o16_f21", size=81, overlap=16, lat=21),
-            dict(name="w13o20_f9", size=13, overlap=20, lat=9)]
+            dict(name="w13o20_f9", size=13, overlap=20, lat=9),
+            # reference-image prefix (VACE, ref_images_before): `prefix` extra latent frames in front of every window; per-frame t (ti2v)
+            dict(name="w17o5_f21_p2", size=17, overlap=5, lat=21, prefix=2), dict(name="w9o3_f11_p1_t", size=9, overlap=3, lat=11, prefix=1, t=True),
+            dict(name="w17o5_f21_t", size=17, overlap=5, lat=21, t=True)]
 
 
-def make_inputs(lat):
-    g = torch.Generator().manual_seed(100 + lat)
+def make_inputs(lat, prefix=0, per_frame_t=False):
+    g = torch.Generator().manual_seed(100 + lat + 1000 * prefix)
     h, w = 4, 6
+    lat = lat + prefix                      # the prefix frames lead every time axis (target_shape[1] = lat_frames + prefix)
     latents = torch.randn(1, 16, lat, h, w, generator=g)
     tok = (h // 2) * (w // 2)
     cos = torch.randn(lat * tok, 128, generator=g); sin = torch.randn(lat * tok, 128, generator=g)
     y = torch.randn(20, lat, h, w, generator=g)
     vace = [torch.randn(96, lat, h, w, generator=g)]
+    if per_frame_t:
+        t = torch.full((lat,), 700, dtype=torch.int64)
+        t[:prefix + 2] = 0
+        return latents, (cos, sin), y, vace, t
     return latents, (cos, sin), y, vace
 
 
@@ -83,9 +94,12 @@ def main():
     me = types.SimpleNamespace(vae_stride=(4, 8, 8))
     out = {}
     for c in cases():
-        latents, freqs, y, vace = make_inputs(c["lat"])
+        P = c.get("prefix", 0)
+        latents, freqs, y, vace, *tt = make_inputs(c["lat"], P, c.get("t", False))
         kwargs = {"freqs": freqs, "y": y, "vace_context": vace, "other": 3}
-        r = outer(me, c["size"], c["overlap"], c["lat"], (16, c["lat"], 4, 6), kwargs, False, 0, False, None)
+        if tt:
+            kwargs["t"] = tt[0]
+        r = outer(me, c["size"], c["overlap"], c["lat"], (16, c["lat"] + P, 4, 6), kwargs, P > 0, P, False, None)
         out[c["name"] + "_windows"] = np.array(r["windows"] if r["windows"] is not None else [], dtype=np.int64).reshape(-1, 2)
         out[c["name"] + "_counts"] = np.array([r["window"], r["overlap"]])
         if r["windows"] is not None:

@@ -298,6 +298,11 @@ def test_ti2v_timestep_injection_passes_a_per_frame_t_and_pins_the_source_latent
         assert t.shape == (3,) and t[0] == 0 and (t[1:] == t[1]).all() and t[1] > 0
         assert (first == 7.0).all()
     assert (out["latents"][:, :, :1] == 7.0).all()
+    # with sub-parallel windows the per-frame t follows each window (any2video.py:1303-1304): windows (0,2) and anchor + (1,3)
+    seen.clear()
+    run(WanAny2VHIP(Dit("A"), vae=Vae(), device="cpu"), input_video=torch.zeros(3, 1, 64, 64), sampling_steps=1, sub_parallel_window_size=5,
+        sub_parallel_window_overlap=1)
+    assert [tuple(t.shape) for t, _ in seen] == [(2,), (3,)] and all(t[0] == 0 and t[1] > 0 for t, _ in seen)
     with pytest.raises(ValueError, match="ti2v"):
         run(WanAny2VHIP(FakeDiT("A"), vae=Vae(), device="cpu"), input_video=torch.zeros(3, 1, 64, 64))
 
@@ -542,7 +547,7 @@ def test_vace_reference_images_are_extra_latent_frames_in_front_and_are_cut_off_
     control context (their latents beside zero masks, vace_encode_frames / _masks -- pinned to the reference by
     tests/golden/vace_context.npz) AND of the latents the model sees; the previews and the result leave them out.  Together with
     sliding-window overlap the pinned prefix spans reference frames + overlap, the context noise only the overlap (:1151-1152, :1526).
-    Outside the VACE path or with sub-parallel windows: refused."""
+    Outside the VACE path: refused."""
     from oracle.make_golden_vace_context import FakeVAE, inputs
 
     class VaceDiT(FakeDiT):
@@ -585,8 +590,15 @@ def test_vace_reference_images_are_extra_latent_frames_in_front_and_are_cut_off_
     zbg = pipe.vace_context([frames], [mask], refs, 0, [bgm, None])[0]
     assert all(xs == (1, 16, 5, 4, 6) and zs == (96, 5, 4, 6) and torch.equal(z4, zbg[:16, :4]) for xs, zs, z4 in m3.seen)
     assert not torch.equal(zbg[:16, :1], zref[:16, :1]) and torch.equal(zbg[:, 1:], zref[:, 1:])
-    with pytest.raises(NotImplementedError, match="sub-parallel"):
-        run(pipe, width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs, sub_parallel_window_size=9)
+    # together with sub-parallel windows (any2video.py:1222, :1234-1249, :1341-1343): the reference frames lead EVERY window
+    # (latents, RoPE rows, context), arithmetic pinned to the reference's closures by tests/test_subparallel_vs_golden.py
+    m4 = VaceDiT("A")
+    out4 = run(WanAny2VHIP(m4, vae=FakeVAE(), device="cpu"), width=48, height=32, input_frames=frames, input_masks=mask, input_ref_images=refs,
+               sub_parallel_window_size=5, sub_parallel_window_overlap=1, sampling_steps=2)
+    assert tuple(out4["latents"].shape) == (1, 16, 3, 4, 6)
+    shapes = [(xs[2], zs[1]) for xs, zs, _ in m4.seen[:2]]        # windows (0,2) and (1,3) of 3 latent frames: 2 + 2 frames, 2 + (anchor + 2)
+    assert shapes == [(4, 4), (5, 5)], shapes
+    assert all(torch.equal(z4[:, :2], zref[:16, :2]) for _, _, z4 in m4.seen)                        # the prefix of every window
 
 
 def test_keywords_of_unserved_reference_paths_are_refused_not_ignored():

@@ -1,7 +1,7 @@
 """Sub-parallel temporal windows (wan2gp_amd/subparallel.py) against tests/golden/subparallel.npz: the reference's own nested
 closures of `WanAny2V.generate` (any2video.py:1199-1387), lifted verbatim and executed by oracle/make_golden_subparallel.py
 for the plain case, with a deterministic stand-in for the CFG denoise function that depends on the window's latents AND on
-the sliced keywords (RoPE rows, y, vace_context).  Exact equality on CPU: windows, latent counts, blended predictions."""
+the sliced keywords (RoPE rows, t, y, vace_context), incl. a reference-image prefix in front of every window and per-frame t.  Exact equality on CPU: windows, latent counts, blended predictions."""
 import os
 
 import numpy as np
@@ -26,9 +26,12 @@ def test_windows_counts_and_blended_prediction(c):
     assert windows == as_list(G[c["name"] + "_windows"])
     if windows is None:
         return
-    latents, freqs, y, vace = make_inputs(c["lat"])
+    P = c.get("prefix", 0)
+    latents, freqs, y, vace, *tt = make_inputs(c["lat"], P, c.get("t", False))
     kwargs = {"freqs": freqs, "y": y, "vace_context": vace, "other": 3}
-    pred = SP.denoise(latents.clone(), fake_denoise_factory(kwargs), windows, ov, kwargs, tokens_per_frame=2 * 3)
+    if tt:
+        kwargs["t"] = tt[0]                                     # per-frame timesteps: the stand-in asserts they arrive sliced
+    pred = SP.denoise(latents.clone(), fake_denoise_factory(kwargs), windows, ov, kwargs, tokens_per_frame=2 * 3, prefix=P)
     assert kwargs["freqs"] is freqs and kwargs["y"] is y and kwargs["other"] == 3                 # restored after every window
     assert torch.equal(pred, torch.from_numpy(G[c["name"] + "_pred"]))
 

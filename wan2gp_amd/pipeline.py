@@ -312,8 +312,6 @@ class WanAny2VHIP:
             if getattr(self.model, "vace_layers", None) is None or input_frames is None:
                 raise NotImplementedError("WanAny2VHIP.generate: input_ref_images are served on the VACE path only (a model with VACE "
                                           "blocks and a control video)")
-            if sub_parallel_window_size:
-                raise NotImplementedError("WanAny2VHIP.generate: reference images together with sub-parallel windows are not served")
             ref_count = len(input_ref_images)
         target_shape = (getattr(self.model, "out_dim", 16), lat_frames + ref_count, height // self.vae_stride[1],
                         width // self.vae_stride[2])                                   # :1166 (48 channels, stride 16 for ti2v 5B)
@@ -507,7 +505,8 @@ class WanAny2VHIP:
 
                     def denoise_fn(lat):
                         return subparallel.denoise(lat, denoise_with_cfg, sub_windows, sub_overlap, kwargs,
-                                                   (target_shape[2] // self.patch_size[1]) * (target_shape[3] // self.patch_size[2]))
+                                                   (target_shape[2] // self.patch_size[1]) * (target_shape[3] // self.patch_size[2]),
+                                                   prefix=ref_count)          # :1222: reference-image frames lead every window
                 else:
                     denoise_fn = denoise_with_cfg
                 noise_pred = denoise_fn(latents)
