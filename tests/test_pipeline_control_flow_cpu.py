@@ -820,3 +820,21 @@ def test_later_sliding_windows_are_colour_matched_to_their_reference_frame_after
     assert torch.equal(i2v(prefix_frames_count=1, window_start_frame_no=0), base)
     with_end = dict(image_end=prefix[:, 0], prefix_frames_count=5, window_start_frame_no=12)
     assert torch.equal(i2v(**with_end), i2v(color_correction_strength=0, **with_end))
+
+
+def test_input_video_sets_height_and_width():
+    """any2video.py:571: `if input_video is not None: height, width = input_video.shape[-2:]` -- the keywords' size is overridden."""
+    m = FakeDiT("A")
+    m.model_type = "i2v2_2"
+    out = run(WanAny2VHIP(m, vae=_StubVAE(), device="cpu"), input_video=torch.zeros(3, 1, 32, 48), width=64, height=64)
+    assert tuple(out["latents"].shape) == (1, 16, 3, 4, 6)
+
+
+def test_ti2v_without_a_source_video_rounds_the_size_down_to_multiples_of_32():
+    """any2video.py:1063-1065."""
+    m = FakeDiT("A", out_dim=48)
+    m.model_type = "ti2v2_2"
+    pipe = WanAny2VHIP(m, device="cpu")
+    pipe.vae_stride = (4, 16, 16)
+    out = run(pipe, width=80, height=120)
+    assert tuple(out["latents"].shape) == (1, 48, 3, 96 // 16, 64 // 16)

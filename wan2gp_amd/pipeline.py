@@ -281,6 +281,10 @@ class WanAny2VHIP:
             raise ValueError("a Wan2.1 i2v model (model_type 'i2v') needs clip_fea [1,257,1280]: the CLIP vision features of the "
                              "start image (any2video.py:721-729)")
         dev = self.device
+        if input_video is not None:
+            height, width = input_video.shape[-2:]                                    # any2video.py:571: the video to continue sets the size
+        elif getattr(self.model, "model_type", None) == "ti2v2_2":
+            height, width = (height // 32) * 32, (width // 32) * 32                   # :1063-1065: the 5B model's VAE stride 16 x patch 2
         # video-to-video ("G" in video_prompt_type, any2video.py:1004-1044): start from the VAE latents of `input_frames`
         v2v_on = "G" in (video_prompt_type or "") and input_frames is not None
         if not v2v_on:
