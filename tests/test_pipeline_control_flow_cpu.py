@@ -838,3 +838,95 @@ def test_ti2v_without_a_source_video_rounds_the_size_down_to_multiples_of_32():
     pipe.vae_stride = (4, 16, 16)
     out = run(pipe, width=80, height=120)
     assert tuple(out["latents"].shape) == (1, 48, 3, 96 // 16, 64 // 16)
+
+
+def _ref_resize_lanczos():
+    """`resize_lanczos` lifted from the reference (shared/utils/utils.py:341-347) when the tree is present."""
+    import ast, os
+    src = os.path.join(os.environ.get("WAN_REFERENCE_ROOT", "/root/reference"), "shared", "utils", "utils.py")
+    if not os.path.isfile(src):
+        return None
+    fn = next(n for n in ast.parse(open(src).read()).body if isinstance(n, ast.FunctionDef) and n.name == "resize_lanczos")
+    import numpy as np
+    from PIL import Image
+    ns = {"torch": torch, "np": np, "Image": Image}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "utils.py", "exec"), ns)
+    return ns["resize_lanczos"]
+
+
+def test_wan21_i2v_takes_its_clip_features_from_the_host_applications_tower():
+    """any2video.py:945-954: without clip_fea the pipeline asks `self.clip` (the host application's CLIPModel, handed over by the plugin's
+    load_model): start image = last frame of input_video, Lanczos-resized through an 8-bit image to the tower's input size, as [3,1,S,S];
+    flf2v_720p sends start AND end image (the start twice without an end image).  The resize equals the reference's own function."""
+    pytest.importorskip("PIL")
+    seen, got = [], []
+
+    class Clip:
+        model = types.SimpleNamespace(image_size=16)
+
+        def visual(self, videos):
+            seen.append([v.clone() for v in videos])
+            return torch.full((len(videos), 257, 1280), 0.5)
+
+    class Dit(FakeDiT):
+        model_type = "i2v"
+
+        def __call__(self, x, t, context, **kw):
+            got.append(kw.get("clip_fea"))
+            return super().__call__(x, t, context, **kw)
+    g = torch.Generator().manual_seed(9)
+    video = torch.rand(3, 5, 64, 64, generator=g) * 2 - 1
+    end = torch.rand(3, 64, 64, generator=g) * 2 - 1
+    from oracle.make_golden_i2v_cond import FakeVAE
+    pipe = WanAny2VHIP(Dit("A"), vae=FakeVAE(), device="cpu")
+    pipe.clip = Clip()
+    run(pipe, input_video=video, sampling_steps=1)
+    assert len(seen) == 1 and [tuple(v.shape) for v in seen[0]] == [(3, 1, 16, 16)] and tuple(got[0].shape) == (1, 257, 1280)
+    ref = _ref_resize_lanczos()
+    if ref is not None:
+        assert torch.equal(seen[0][0][:, 0], ref(video[:, -1].clone(), 16, 16))
+    assert torch.equal(seen[0][0][:, 0], pipeline._resize_lanczos(video[:, -1].clone(), 16, 16))
+    # an explicit clip_fea wins; flf2v: two images
+    seen.clear(), got.clear()
+    cf = torch.zeros(1, 257, 1280)
+    run(pipe, input_video=video, clip_fea=cf, sampling_steps=1)
+    assert not seen and got[0] is cf
+    pipe.flf = True
+    run(pipe, input_video=video, image_end=end, sampling_steps=1)
+    assert [tuple(v.shape) for v in seen[0]] == [(3, 1, 16, 16)] * 2 and tuple(got[-1].shape) == (2, 257, 1280)
+    assert torch.equal(seen[0][1][:, 0], pipeline._resize_lanczos(end.clone(), 16, 16)) and not torch.equal(seen[0][0], seen[0][1])
+    seen.clear()
+    run(pipe, input_video=video, sampling_steps=1)
+    assert len(seen[0]) == 2 and torch.equal(seen[0][0], seen[0][1])                    # no end image: the start image twice (:948)
+
+
+def test_host_clip_is_built_like_the_reference_builds_it_and_absent_outside_the_host_application(monkeypatch):
+    """wan_handler._host_clip: any2video.py:127-132 with configs/wan_i2v_14B.py:17-19's names; None when `models` / `shared` are not importable."""
+    import sys
+    from wan2gp_amd import wan_handler as H
+    for name in ("models", "models.wan", "models.wan.modules", "models.wan.modules.clip", "shared", "shared.utils", "shared.utils.files_locator"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    monkeypatch.setattr(sys, "path", [p for p in sys.path if "reference" not in p])
+    assert H._host_clip("cpu") is None
+    made = {}
+
+    class CLIPModel:
+        def __init__(self, **kw):
+            made.update(kw)
+    fl = types.ModuleType("shared.utils.files_locator")
+    fl.locate_file = lambda rel: "/ckpts/" + rel
+    fl.locate_folder = lambda rel: "/ckpts/" + rel
+    mods = {"models": types.ModuleType("models"), "models.wan": types.ModuleType("models.wan"),
+            "models.wan.modules": types.ModuleType("models.wan.modules"), "models.wan.modules.clip": types.ModuleType("models.wan.modules.clip"),
+            "shared": types.ModuleType("shared"), "shared.utils": types.ModuleType("shared.utils"), "shared.utils.files_locator": fl}
+    mods["models.wan.modules.clip"].CLIPModel = CLIPModel
+    mods["shared.utils"].files_locator = fl
+    for pkg in ("models", "models.wan", "models.wan.modules", "shared", "shared.utils"):
+        mods[pkg].__path__ = []
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    clip = H._host_clip("cuda")
+    assert isinstance(clip, CLIPModel) and made == {
+        "dtype": torch.float16, "device": "cuda",
+        "checkpoint_path": "/ckpts/xlm-roberta-large/models_clip_open-clip-xlm-roberta-large-vit-huge-14-bf16.safetensors",
+        "tokenizer_path": "/ckpts/xlm-roberta-large"}

@@ -41,6 +41,16 @@ def _same(v, default):
         return False
 
 
+def _resize_lanczos(img, h, w):
+    """`resize_lanczos` (shared/utils/utils.py:341-347): [-1,1] float [3,H,W] -> 8-bit image (truncating cast) -> PIL Lanczos -> [-1,1]."""
+    import numpy as np
+    from PIL import Image
+    a = (img + 1).float().mul_(127.5)
+    pil = Image.fromarray(np.clip(a.movedim(0, -1).cpu().numpy(), 0, 255).astype(np.uint8))
+    pil = pil.resize((w, h), resample=Image.Resampling.LANCZOS)
+    return torch.from_numpy(np.array(pil).astype(np.float32)).movedim(-1, 0).div(127.5).sub_(1)
+
+
 class _Progress:
     """The progress protocol `WanAny2V.generate` speaks to wgp.py's callback (any2video.py:1410-1411, :1434, :1442, :1446,
     :1743-1750): `(-1, None, True)` once the setup is done, `(-1, None, True, override_num_inference_steps=, denoising_extra=)`
@@ -100,6 +110,10 @@ class WanAny2VHIP:
         self.num_train_timesteps = num_train_timesteps
         self.vae_stride, self.patch_size = vae_stride, patch_size
         self._interrupt = False
+        # Wan2.1 i2v: the CLIP visual tower whose [n,257,1280] features the model's image branch takes.  It is the host application's own
+        # `CLIPModel` (models/wan/modules/clip.py, any2video.py:127-132), handed over by the plugin's load_model: one 257-token ViT-H
+        # forward per video, outside the denoise path.  None: generate() must be given clip_fea.
+        self.clip, self.flf = None, False
 
     def _scheduler(self, sample_solver, sampling_steps, shift, native=True):
         """native=False: the Python mirrors even on a GPU -- their `timesteps` / `sigmas` tables can be cut short by the caller
@@ -229,6 +243,16 @@ class WanAny2VHIP:
                 mm0[:, 0:1] = mmbg
         return [torch.cat([zz, mm.to(zz.dtype)], dim=0) for zz, mm in zip(z0, m0)]
 
+    def clip_features(self, image_start, image_end=None):
+        """any2video.py:945-954: start (and, for flf2v_720p, end) image [3,H,W] in [-1,1] -> Lanczos resize to the tower's input size
+        (through 8-bit PIL images, `resize_lanczos`, shared/utils/utils.py:341-347) -> `clip.visual([[3,1,S,S], ...])` = [n,257,1280]."""
+        size = self.clip.model.image_size
+        start = _resize_lanczos(image_start, size, size)
+        if self.flf or "img_emb.emb_pos" in getattr(self.model, "_weights", ()):
+            end = _resize_lanczos(image_end, size, size) if image_end is not None else start
+            return self.clip.visual([start[:, None, :, :], end[:, None, :, :]])
+        return self.clip.visual([start[:, None, :, :]])
+
     def get_loras_transformer(self, get_model_recursive_prop, base_model_type, model_type, video_prompt_type, model_mode, **kwargs):
         """wgp.py asks the pipeline for model-specific preloaded LoRAs (any2video.py:1828-1839): only the `animate` and
         `vace_ditto_14B` model types have any, neither of which this backend serves -> none."""
@@ -278,8 +302,11 @@ class WanAny2VHIP:
                 raise ValueError("NAG_scale > 1 needs the negative prompt's context (context_null)")
             context = torch.cat([context, context_null.to(context)], dim=0)
         if getattr(self.model, "model_type", None) == "i2v" and clip_fea is None:
-            raise ValueError("a Wan2.1 i2v model (model_type 'i2v') needs clip_fea [1,257,1280]: the CLIP vision features of the "
-                             "start image (any2video.py:721-729)")
+            src = input_video if input_video is not None else image_start
+            if self.clip is None or src is None:
+                raise ValueError("a Wan2.1 i2v model (model_type 'i2v') needs clip_fea [1,257,1280] -- the CLIP vision features of the start "
+                                 "image (any2video.py:945-954) -- or a pipeline with the host application's CLIP tower (self.clip) and a start image")
+            clip_fea = self.clip_features(src[:, -1] if src.dim() == 4 else src, image_end)
         dev = self.device
         if input_video is not None:
             height, width = input_video.shape[-2:]                                    # any2video.py:571: the video to continue sets the size

@@ -36,6 +36,19 @@ _ARCH = {
 SUFFIX = "_hip"
 
 
+def _host_clip(device):
+    """The host application's CLIP model, constructed like any2video.py:127-132 (configs/wan_i2v_14B.py:17-19).  None when this package
+    is used outside Wan2GP (its `models` / `shared` packages are not importable)."""
+    try:
+        from models.wan.modules.clip import CLIPModel
+        from shared.utils import files_locator as fl
+    except ImportError:
+        return None
+    return CLIPModel(dtype=torch.float16, device=device,
+                     checkpoint_path=fl.locate_file("xlm-roberta-large/models_clip_open-clip-xlm-roberta-large-vit-huge-14-bf16.safetensors"),
+                     tokenizer_path=fl.locate_folder("xlm-roberta-large"))
+
+
 def base_of(model_type: str) -> str:
     return model_type[: -len(SUFFIX)] if model_type.endswith(SUFFIX) else model_type
 
@@ -150,7 +163,7 @@ class family_handler():
     def load_model(model_filename, model_type, base_model_type, model_def, quantizeTransformer=False, text_encoder_quantization=None,
                    dtype=torch.bfloat16, VAE_dtype=torch.float32, mixed_precision_transformer=False, save_quantized=False,
                    submodel_no_list=None, text_encoder_filename=None, VAE_upsampling=None, checkpoint_dir="ckpts", device="cuda",
-                   state_dicts=None, vae_state_dict=None, text_encoder=None, **kwargs):
+                   state_dicts=None, vae_state_dict=None, text_encoder=None, clip=None, **kwargs):
         """wan_handler.load_model (:1116-1158) for the HIP backend.  `model_filename`: the checkpoint path(s) wgp.py resolved
         (one per expert for Wan2.2).  Returns (WanAny2VHIP, {"pipe": {...}}).
         Test hooks: `state_dicts` / `vae_state_dict` / `text_encoder` bypass the file reads."""
@@ -215,8 +228,17 @@ class family_handler():
         pipe = WanAny2VHIP(models[0], models[1] if len(models) > 1 else None, vae=vae, text_encoder=text_encoder, device=device,
                            vae_stride=(4, 16, 16) if test_wan_5B(b) else (4, 8, 8))
         pipe.model_def, pipe.base_model_type = model_def, base_model_type
-        # wgp.py:4074-4076: a handler may return {"pipe": modules_for_mmgp, **kwargs}; nothing here is offloaded
-        return pipe, {"pipe": {}}
+        # Wan2.1 i2v class (any2video.py:127-132, :945-954): the CLIP visual tower is the host application's own module -- this plugin runs
+        # inside it -- built as the reference builds it and handed to its offload profile under the reference's name (wan_handler.py:1156-1157);
+        # one ViT-H forward on 257 tokens per video, outside the denoise path.  Standalone (no host application): generate(clip_fea=...)
+        modules = {}
+        if arch["model_type"] == "i2v":
+            pipe.flf = b == "flf2v_720p"
+            pipe.clip = clip if clip is not None else (_host_clip(device) if from_files else None)
+            if getattr(pipe.clip, "model", None) is not None and isinstance(pipe.clip.model, torch.nn.Module):
+                modules["text_encoder_2"] = pipe.clip.model
+        # wgp.py:4074-4076: a handler may return {"pipe": modules_for_mmgp, **kwargs}; the HIP models themselves are not offloaded
+        return pipe, {"pipe": modules}
 
     @staticmethod
     def get_lora_dir(base_model_type, args, lora_root):
