@@ -930,3 +930,27 @@ def test_host_clip_is_built_like_the_reference_builds_it_and_absent_outside_the_
         "dtype": torch.float16, "device": "cuda",
         "checkpoint_path": "/ckpts/xlm-roberta-large/models_clip_open-clip-xlm-roberta-large-vit-huge-14-bf16.safetensors",
         "tokenizer_path": "/ckpts/xlm-roberta-large"}
+
+
+def test_image_start_and_image_end_are_read_on_the_i2v_path_only():
+    """wgp.py:7765-7766 passes image_start / image_end to every model; the reference reads them inside `if i2v:` only
+    (any2video.py:651-785).  A 5B generation from a start image is conditioned through input_video (timestep injection), never through
+    an i2v `y`; a t2v / VACE model ignores both; an i2v model without any start image conditions on a black frame (:667-669)."""
+    g = torch.Generator().manual_seed(4)
+    img = torch.rand(3, 64, 64, generator=g) * 2 - 1
+    for mt, out_dim in (("ti2v2_2", 16), ("t2v", 16)):
+        a, b = FakeDiT("A", out_dim), FakeDiT("A", out_dim)
+        a.model_type = b.model_type = mt
+        kw = dict(input_video=img.unsqueeze(1)) if mt == "ti2v2_2" else {}
+        got = run(WanAny2VHIP(a, vae=_StubVAE(), device="cpu"), image_start=img, image_end=img, **kw)
+        want = run(WanAny2VHIP(b, vae=_StubVAE(), device="cpu"), **kw)
+        assert all(c["y"] is None for c in a.calls) and torch.equal(got["latents"], want["latents"])
+    m = FakeDiT("A")
+    m.model_type = "i2v2_2"
+    vae = _StubVAE()
+    run(WanAny2VHIP(m, vae=vae, device="cpu"), sampling_steps=1)
+    assert vae.seen == [(3, 9, 64, 64)] and m.calls[0]["y"] is not None
+    m2, vae2 = FakeDiT("A"), _StubVAE()
+    m2.model_type = "i2v2_2"
+    run(WanAny2VHIP(m2, vae=vae2, device="cpu"), image_start=torch.full((3, 64, 64), -1.0), sampling_steps=1)
+    assert torch.equal(m.calls[0]["y"], m2.calls[0]["y"])                               # = a start image that is -1 everywhere

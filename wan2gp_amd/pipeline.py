@@ -301,7 +301,14 @@ class WanAny2VHIP:
             if context_null is None:
                 raise ValueError("NAG_scale > 1 needs the negative prompt's context (context_null)")
             context = torch.cat([context, context_null.to(context)], dim=0)
-        if getattr(self.model, "model_type", None) == "i2v" and clip_fea is None:
+        # wgp.py hands `image_start` / `image_end` to EVERY model (wgp.py:7765-7766); the reference reads them on its i2v path only
+        # (any2video.py:651-785) -- a 5B or VACE generation with a start image is conditioned through input_video / input_frames
+        mt = getattr(self.model, "model_type", None)
+        if mt is not None and mt not in ("i2v", "i2v2_2"):
+            image_start = image_end = None
+        elif mt is not None and input_video is None and image_start is None and y is None:
+            input_video = torch.full((3, 1, height, width), -1.0)                     # :667-669: no start image -> a black frame
+        if mt == "i2v" and clip_fea is None:
             src = input_video if input_video is not None else image_start
             if self.clip is None or src is None:
                 raise ValueError("a Wan2.1 i2v model (model_type 'i2v') needs clip_fea [1,257,1280] -- the CLIP vision features of the start "
