@@ -954,3 +954,38 @@ def test_image_start_and_image_end_are_read_on_the_i2v_path_only():
     m2.model_type = "i2v2_2"
     run(WanAny2VHIP(m2, vae=vae2, device="cpu"), image_start=torch.full((3, 64, 64), -1.0), sampling_steps=1)
     assert torch.equal(m.calls[0]["y"], m2.calls[0]["y"])                               # = a start image that is -1 everywhere
+
+
+def test_wgp_keyword_set_for_the_5B_model_with_a_start_image_and_for_vace_with_a_control_video():
+    """The exact keyword set of wgp.py:7762-7885 for (a) ti2v_2_2 from a start image -- wgp.py passes the image BOTH as `image_start`
+    [3,H,W] and as `input_video` [3,1,H,W] (wgp.py:7375-7378, :7765, :7773) -- and (b) VACE with a control video + mask and a start image
+    in `image_start` (which the reference's VACE path never reads): same result as the direct call without the plumbing."""
+    from oracle.make_golden_vace_context import FakeVAE, inputs
+    g = torch.Generator().manual_seed(6)
+    img = torch.rand(3, 64, 64, generator=g) * 2 - 1
+
+    class Vae:
+        def encode(self, videos, tile_size=0):
+            return [torch.full((16, 1, 8, 8), 7.0)]
+    a, b = FakeDiT("A"), FakeDiT("A")
+    a.model_type = b.model_type = "ti2v2_2"
+    got = run(WanAny2VHIP(a, vae=Vae(), device="cpu"),
+              **_wgp_keywords(image_start=img, input_video=img.unsqueeze(1), prefix_video=img.unsqueeze(1), pre_video_frame=img,
+                              conditioning_latents_size=1, perturbation_layers=None, model_type="ti2v_2_2"))
+    want = run(WanAny2VHIP(b, vae=Vae(), device="cpu"), input_video=img.unsqueeze(1), shift=5.0)
+    assert torch.equal(got["latents"], want["latents"]) and all(c["y"] is None for c in a.calls)
+
+    class VaceDiT(FakeDiT):
+        vace_layers = (0,)
+        model_type = "t2v"
+
+        def __call__(self, x, t, context, vace_context=None, vace_context_scale=None, **kw):
+            self.scales = list(vace_context_scale)
+            return super().__call__(x, t, context, **kw)
+    frames, mask, _ = inputs()
+    a, b = VaceDiT("A"), VaceDiT("A")
+    got = run(WanAny2VHIP(a, vae=FakeVAE(), device="cpu"), width=48, height=32,
+              **_wgp_keywords(image_start=torch.rand(3, 32, 48, generator=g), input_frames=frames, input_masks=mask, context_scale=[0.8],
+                              video_prompt_type="PV", perturbation_layers=None, model_type="vace_14B", input_ref_images=None))
+    want = run(WanAny2VHIP(b, vae=FakeVAE(), device="cpu"), width=48, height=32, input_frames=frames, input_masks=mask, context_scale=[0.8], shift=5.0)
+    assert torch.equal(got["latents"], want["latents"]) and a.scales == [0.8] and all(c["y"] is None for c in a.calls)
