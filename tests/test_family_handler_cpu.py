@@ -250,3 +250,22 @@ def test_lora_folders_are_the_builtin_types(b):
     for args in (types.SimpleNamespace(), types.SimpleNamespace(lora_dir="/x/t2v", lora_dir_i2v="/x/i2v"),
                  types.SimpleNamespace(lora_dir_wan="/y/wan", lora_dir_wan_i2v="/y/i2v", lora_dir_wan_1_3b="/y/1.3", lora_dir_wan_5b="/y/5")):
         assert H.get_lora_dir(b + "_hip", args, "loras") == ref(b, args, "loras"), (b, vars(args))
+
+
+def test_preview_factors_come_from_the_host_applications_table(monkeypatch):
+    """wan_handler.get_rgb_factors (:1009-1014): `shared.RGB_factors.get_rgb_factors("wan", type)` with the 5B types mapped to
+    ti2v_2_2; (None, None) = "no preview" (wgp.py:8349-8352) outside the host application."""
+    import sys, types
+    from wan2gp_amd import wan_handler as W
+    monkeypatch.delitem(sys.modules, "shared", raising=False)
+    monkeypatch.delitem(sys.modules, "shared.RGB_factors", raising=False)
+    monkeypatch.setattr(sys, "path", [p for p in sys.path if "reference" not in p])
+    assert W.family_handler.get_rgb_factors("t2v_hip") == (None, None)
+    asked = []
+    mod, pkg = types.ModuleType("shared.RGB_factors"), types.ModuleType("shared")
+    mod.get_rgb_factors = lambda family, model_type=None, sub_family=None: (asked.append((family, model_type)), ("f", "b"))[1]
+    pkg.__path__ = []
+    monkeypatch.setitem(sys.modules, "shared", pkg)
+    monkeypatch.setitem(sys.modules, "shared.RGB_factors", mod)
+    assert W.family_handler.get_rgb_factors("ti2v_2_2_hip") == ("f", "b") and W.family_handler.get_rgb_factors("i2v_hip") == ("f", "b")
+    assert asked == [("wan", "ti2v_2_2"), ("wan", "i2v")]

@@ -157,7 +157,14 @@ class family_handler():
 
     @staticmethod
     def get_rgb_factors(base_model_type):
-        return None, None
+        """wan_handler.get_rgb_factors (:1009-1014): the latent -> RGB preview factors are a table of the host application
+        (`shared/RGB_factors.py`); outside it there is no preview (wgp.py:8349-8352 takes None for "no preview")."""
+        try:
+            from shared.RGB_factors import get_rgb_factors
+        except ImportError:
+            return None, None
+        b = base_of(base_model_type)
+        return get_rgb_factors("wan", "ti2v_2_2" if test_wan_5B(b) else b)
 
     @staticmethod
     def load_model(model_filename, model_type, base_model_type, model_def, quantizeTransformer=False, text_encoder_quantization=None,
