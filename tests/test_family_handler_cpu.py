@@ -269,3 +269,71 @@ def test_preview_factors_come_from_the_host_applications_table(monkeypatch):
     monkeypatch.setitem(sys.modules, "shared.RGB_factors", mod)
     assert W.family_handler.get_rgb_factors("ti2v_2_2_hip") == ("f", "b") and W.family_handler.get_rgb_factors("i2v_hip") == ("f", "b")
     assert asked == [("wan", "ti2v_2_2"), ("wan", "i2v")]
+
+
+def test_checkpoint_files_are_resolved_by_the_host_applications_locator_when_there_is_one(monkeypatch):
+    """any2video.py:143, :163: `fl.locate_file(name)` (the host's configurable checkpoint folders); outside the host, or when it does not
+    find the file, `checkpoint_dir/name` -- whose absence load_model reports."""
+    import sys, types
+    from wan2gp_amd import wan_handler as W
+    for name in ("shared", "shared.utils", "shared.utils.files_locator"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    monkeypatch.setattr(sys, "path", [p for p in sys.path if "reference" not in p])
+    assert W._locate("Wan2.1_VAE.safetensors", "ckpts") == os.path.join("ckpts", "Wan2.1_VAE.safetensors")
+    fl = types.ModuleType("shared.utils.files_locator")
+    fl.locate_file = lambda rel: {"Wan2.1_VAE.safetensors": "/models/wan/Wan2.1_VAE.safetensors"}.get(rel)
+    pkg, sub = types.ModuleType("shared"), types.ModuleType("shared.utils")
+    pkg.__path__, sub.__path__, sub.files_locator = [], [], fl
+    for k, v in (("shared", pkg), ("shared.utils", sub), ("shared.utils.files_locator", fl)):
+        monkeypatch.setitem(sys.modules, k, v)
+    assert W._locate("Wan2.1_VAE.safetensors", "ckpts") == "/models/wan/Wan2.1_VAE.safetensors"
+    assert W._locate("Wan2.2_VAE.safetensors", "ckpts") == os.path.join("ckpts", "Wan2.2_VAE.safetensors")       # not found there
+    assert W._locate("https://host/repo/custom_vae.safetensors", "ckpts") == os.path.join("ckpts", "custom_vae.safetensors")
+    assert W._locate("/abs/v.safetensors", "ckpts") == "/abs/v.safetensors"
+
+
+def test_load_model_wires_experts_vae_text_encoder_and_the_clip_tower(monkeypatch):
+    """`family_handler.load_model` end to end on stand-ins for the three device classes (the real ones need the GPU; tests/test_gpu_e2e.py
+    runs it there): experts per submodel number, the VAE class per family, and for the Wan2.1 i2v class the CLIP tower handed to the host's
+    offload profile under the reference's name (wan_handler.py:1156-1157) -- nothing of that for the other types."""
+    import torch
+    from wan2gp_amd import model as M, vae as V, vae22 as V22, wan_handler as W
+
+    class Dit:
+        def __init__(self, device=None, **arch):
+            self.arch, self.model_type = arch, arch["model_type"]
+
+        def load_state_dict(self, sd):
+            self.sd = sd
+            return self
+
+    class Vae:
+        def __init__(self, state_dict=None, vae_pth=None, device=None):
+            self.src = ("sd", state_dict) if state_dict is not None else ("file", vae_pth)
+
+    class Vae22(Vae):
+        pass
+    monkeypatch.setattr(M, "WanModelHIP", Dit)
+    monkeypatch.setattr(V, "WanVAEHIP", Vae)
+    monkeypatch.setattr(V22, "Wan22VAEHIP", Vae22)
+    H = W.family_handler
+    tower = torch.nn.Linear(2, 2)
+    clip = type("Clip", (), {"model": tower})()
+    te = object()
+    pipe, extra = H.load_model(["hi.safetensors", "lo.safetensors"], "t2v_2_2_hip", "t2v_2_2_hip", {}, state_dicts=[{"a": 1}, {"b": 2}],
+                               vae_state_dict={"v": 0}, text_encoder=te, clip=clip, profile=3, lm_decoder_engine="legacy")
+    assert extra == {"pipe": {}} and pipe.clip is None and pipe.model.sd == {"a": 1} and pipe.model2.sd == {"b": 2}
+    assert type(pipe.vae) is Vae and pipe.vae.src == ("sd", {"v": 0}) and pipe.text_encoder is te and pipe.vae_stride == (4, 8, 8)
+    pipe, extra = H.load_model(["m.safetensors"], "ti2v_2_2_hip", "ti2v_2_2_hip", None, state_dicts=[{}], vae_state_dict={}, text_encoder=te)
+    assert type(pipe.vae) is Vae22 and pipe.vae_stride == (4, 16, 16) and pipe.model2 is None and extra == {"pipe": {}}
+    for t, flf in (("i2v_hip", False), ("flf2v_720p_hip", True)):
+        pipe, extra = H.load_model(["m.safetensors"], t, t, {}, state_dicts=[{}], vae_state_dict={}, text_encoder=te, clip=clip)
+        assert pipe.clip is clip and pipe.flf is flf and extra == {"pipe": {"text_encoder_2": tower}}
+    pipe, extra = H.load_model(["m.safetensors"], "i2v_hip", "i2v_hip", {}, state_dicts=[{}], vae_state_dict={}, text_encoder=te)
+    assert pipe.clip is None and extra == {"pipe": {}}                   # test hooks + no tower given: generate() asks for clip_fea
+    # a VAE named by the model definition (any2video.py:137-143)
+    pipe, _ = H.load_model(["m.safetensors"], "t2v_hip", "t2v_hip", {"VAE_URLs": __file__}, state_dicts=[{}], text_encoder=te)
+    assert pipe.vae.src == ("file", __file__)
+    pipe, _ = H.load_model(["m.safetensors"], "t2v_hip", "t2v_hip", {"VAE_URLs": ["https://x/y/custom_vae.safetensors"]}, state_dicts=[{}],
+                           text_encoder=te, checkpoint_dir="/nowhere")
+    assert pipe.vae is None

@@ -36,6 +36,21 @@ _ARCH = {
 SUFFIX = "_hip"
 
 
+def _locate(name, checkpoint_dir):
+    """`fl.locate_file(name)` of the host application (shared/utils/files_locator.py: searches its configured checkpoint folders) when this
+    package runs inside it, else `checkpoint_dir/name`."""
+    try:
+        from shared.utils import files_locator as fl
+        found = fl.locate_file(name)
+        if found:
+            return found
+    except Exception:      # noqa: BLE001 -- not inside the host application, or the file is not there: the caller checks the path it gets
+        pass
+    if name.startswith("http"):                          # files_locator.py:211-212: a URL stands for its file name
+        name = os.path.basename(name)
+    return name if os.path.isabs(name) else os.path.join(checkpoint_dir, name)
+
+
 def _host_clip(device):
     """The host application's CLIP model, constructed like any2video.py:127-132 (configs/wan_i2v_14B.py:17-19).  None when this package
     is used outside Wan2GP (its `models` / `shared` packages are not importable)."""
@@ -206,24 +221,31 @@ class family_handler():
         if not sds:
             raise ValueError("load_model: no checkpoint given")
         models = [WanModelHIP(device=device, **arch).load_state_dict(sd) for sd in sds[:2]]
+        # any2video.py:137-163: VAE_URLs of the model definition (a path, or a list whose first entry the host's file locator resolves),
+        # else the family's default file, resolved by the host application's locator (its checkpoint folders are configurable) or, outside
+        # it, under `checkpoint_dir`
+        wan_5B = test_wan_5B(b)
+        if wan_5B:
+            from .vae22 import Wan22VAEHIP as VAE
+        else:
+            from .vae import WanVAEHIP as VAE
+        vae_url = (model_def or {}).get("VAE_URLs", None)
+        if isinstance(vae_url, str):
+            vae_path = vae_url
+        elif isinstance(vae_url, list) and len(vae_url):
+            vae_path = _locate(vae_url[0], checkpoint_dir)
+        else:
+            vae_path = _locate("Wan2.2_VAE.safetensors" if wan_5B else "Wan2.1_VAE.safetensors", checkpoint_dir)
         vae = None
-        if vae_state_dict is not None or os.path.isdir(checkpoint_dir):
-            if wan_5B := test_wan_5B(b):
-                from .vae22 import Wan22VAEHIP as VAE
-                name = "Wan2.2_VAE.safetensors"
-            else:
-                from .vae import WanVAEHIP as VAE
-                name = "Wan2.1_VAE.safetensors"
-            path = os.path.join(checkpoint_dir, name)
-            if vae_state_dict is not None:
-                vae = VAE(state_dict=vae_state_dict, device=device)
-            elif os.path.isfile(path):
-                vae = VAE(vae_pth=path, device=device)
+        if vae_state_dict is not None:
+            vae = VAE(state_dict=vae_state_dict, device=device)
+        elif os.path.isfile(vae_path):
+            vae = VAE(vae_pth=vae_path, device=device)
         # under wgp.py (real checkpoint files, no test hooks) a missing VAE / text-encoder file must fail HERE, not as an opaque
         # error after a full denoise: generate() would return latents with x = None, or fail on `context`
         from_files = state_dicts is None
         if vae is None and from_files:
-            raise FileNotFoundError(f"load_model: VAE checkpoint not found ({os.path.join(checkpoint_dir, 'Wan2.2_VAE.safetensors' if test_wan_5B(b) else 'Wan2.1_VAE.safetensors')})")
+            raise FileNotFoundError(f"load_model: VAE checkpoint not found ({vae_path})")
         if text_encoder is None and from_files and not (text_encoder_filename and os.path.isfile(str(text_encoder_filename))):
             raise FileNotFoundError(f"load_model: text-encoder checkpoint not found ({text_encoder_filename!r})")
         if text_encoder is None and text_encoder_filename and os.path.isfile(str(text_encoder_filename)):
