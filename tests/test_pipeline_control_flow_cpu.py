@@ -238,6 +238,12 @@ def test_text_encoder_output_is_padded_like_the_reference():
                         seed=1, return_latents=True)
     assert out is not None and enc_calls == [["a cat"], [""]]
     assert seen[0] == [(1, 512, 4096), (1, 512, 4096), torch.bfloat16, torch.bfloat16, 0.0, 0.0]
+    # the next window of the same video: both prompts come from the cache (TextEncoderCache, any2video.py:589-592); a new prompt is encoded
+    first = seen[0]
+    pipe.generate(input_prompt="a cat", n_prompt="", width=64, height=64, frame_num=9, sampling_steps=1, guide_scale=4.0, seed=1, return_latents=True)
+    assert enc_calls == [["a cat"], [""]] and seen[-1] == first
+    pipe.generate(input_prompt="a dog", n_prompt="", width=64, height=64, frame_num=9, sampling_steps=1, guide_scale=4.0, seed=1, return_latents=True)
+    assert enc_calls == [["a cat"], [""], ["a dog"]]
 
 
 def test_shared_cache_object_is_configured_once_from_model():

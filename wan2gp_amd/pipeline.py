@@ -114,6 +114,8 @@ class WanAny2VHIP:
         # `CLIPModel` (models/wan/modules/clip.py, any2video.py:127-132), handed over by the plugin's load_model: one 257-token ViT-H
         # forward per video, outside the denoise path.  None: generate() must be given clip_fea.
         self.clip, self.flf = None, False
+        import collections
+        self._text_cache, self._text_cache_bytes = collections.OrderedDict(), 0
 
     def _scheduler(self, sample_solver, sampling_steps, shift, native=True):
         """native=False: the Python mirrors even on a GPU -- their `timesteps` / `sigmas` tables can be cut short by the caller
@@ -287,7 +289,19 @@ class WanAny2VHIP:
             text_len = getattr(self.model, "text_len", 512)
 
             def _encode(prompt):
-                c = self.text_encoder([prompt], self.device)[0].to(torch.bfloat16)
+                # `TextEncoderCache.encode` (shared/utils/text_encoder_cache.py:16-61; any2video.py:589, :592): the encoder's output per
+                # prompt string, least recently used first out beyond 100 MB -- every sliding window repeats the video's prompts
+                c = self._text_cache.get(prompt)
+                if c is None:
+                    c = self.text_encoder([prompt], self.device)[0]
+                    self._text_cache[prompt] = c
+                    self._text_cache_bytes += c.numel() * c.element_size()
+                    while self._text_cache_bytes > 100 * 1024 * 1024 and len(self._text_cache) > 1:
+                        _, old = self._text_cache.popitem(last=False)
+                        self._text_cache_bytes -= old.numel() * old.element_size()
+                else:
+                    self._text_cache.move_to_end(prompt)
+                c = c.to(device=self.device, dtype=torch.bfloat16)
                 return torch.cat([c, c.new_zeros(text_len - c.size(0), c.size(1))]).unsqueeze(0)
             context = _encode(input_prompt)
             context_null = _encode(n_prompt)
