@@ -71,7 +71,7 @@ def test_model_def_properties_and_settings():
                   "sliding_window_overlap": 1, "sliding_window_color_correction_strength": 0}          # wan_handler.py:1441-1449
     assert H.validate_generative_settings("t2v_hip", {}, {"sample_solver": "euler"}) is None
     assert "Unsupported" in H.validate_generative_settings("t2v_hip", {}, {"sample_solver": "ddim"})
-    assert H.query_model_family() == "wan" and H.query_model_files(None, "t2v_hip") == []
+    assert H.query_model_family() == "wan"
     with pytest.raises(NotImplementedError):
         H.load_model(["a.safetensors"], "t2v_hip", "t2v_hip", {}, quantizeTransformer=True)
     with pytest.raises(ValueError, match="not supported"):
@@ -337,3 +337,22 @@ def test_load_model_wires_experts_vae_text_encoder_and_the_clip_tower(monkeypatc
     pipe, _ = H.load_model(["m.safetensors"], "t2v_hip", "t2v_hip", {"VAE_URLs": ["https://x/y/custom_vae.safetensors"]}, state_dicts=[{}],
                            text_encoder=te, checkpoint_dir="/nowhere")
     assert pipe.vae is None
+
+
+@pytest.mark.parametrize("b", ["t2v", "t2v_1.3B", "t2v_2_2", "i2v", "flf2v_720p", "i2v_2_2", "ti2v_2_2", "vace_14B", "vace_1.3B"])
+def test_files_to_fetch_are_a_subset_of_the_references_list(b):
+    """wan_handler.query_model_files (:1016-1070; wgp.py:3659 downloads what it names): every (repository, folder, file) this handler asks
+    for is one the reference's function asks for on the corresponding built-in type; the VAE, the tokenizer folder and -- Wan2.1 i2v class --
+    the CLIP checkpoint are among them."""
+    from wan2gp_amd.wan_handler import family_handler as H
+
+    def triples(defs):
+        return {(d["repoId"], folder, f) for d in defs for folder, fl in zip(d["sourceFolderList"], d["fileList"]) for f in fl}
+    got = triples(H.query_model_files([], b + "_hip", {}))
+    names = {f for _, _, f in got}
+    assert ("Wan2.2_VAE.safetensors" if b == "ti2v_2_2" else "Wan2.1_VAE.safetensors") in names and "spiece.model" in names
+    assert ("models_clip_open-clip-xlm-roberta-large-vit-huge-14-bf16.safetensors" in names) == (b in ("i2v", "flf2v_720p"))
+    ref = _ref_static("query_model_files")
+    if ref is None:
+        pytest.skip("reference tree not present")
+    assert got <= triples(ref([], b, {})), got - triples(ref([], b, {}))

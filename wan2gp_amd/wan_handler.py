@@ -166,9 +166,21 @@ class family_handler():
 
     @staticmethod
     def query_model_files(computeList, base_model_type, model_def=None):
-        """Nothing to download beyond what the model definition's URLs name: VAE and text-encoder files are read from `ckpts/`
-        under the reference's own file names (wan_handler.py:1016-1070)."""
-        return []
+        """wan_handler.query_model_files (:1016-1070) for the supported types: the files wgp.py fetches beside the model definition's
+        own URLs -- the UMT5 tokenizer folder, the family's VAE, and for the Wan2.1 i2v class the CLIP tower's folder (same repositories,
+        folders and names; a subset of the reference's list: the 2x-upscaling VAE is not served)."""
+        b = base_of(base_model_type)
+        files = [{"repoId": "DeepBeepMeep/Wan2.1", "sourceFolderList": ["umt5-xxl"],
+                  "fileList": [["special_tokens_map.json", "spiece.model", "tokenizer.json", "tokenizer_config.json"]]}]
+        if test_wan_5B(b):
+            files.append({"repoId": "DeepBeepMeep/Wan2.2", "sourceFolderList": [""], "fileList": [["Wan2.2_VAE.safetensors"]]})
+        elif _ARCH.get(b, {}).get("model_type") == "i2v":
+            files.append({"repoId": "DeepBeepMeep/Wan2.1", "sourceFolderList": ["xlm-roberta-large", ""],
+                          "fileList": [["models_clip_open-clip-xlm-roberta-large-vit-huge-14-bf16.safetensors", "sentencepiece.bpe.model",
+                                        "special_tokens_map.json", "tokenizer.json", "tokenizer_config.json"], ["Wan2.1_VAE.safetensors"]]})
+        else:
+            files.append({"repoId": "DeepBeepMeep/Wan2.1", "sourceFolderList": [""], "fileList": [["Wan2.1_VAE.safetensors"]]})
+        return files
 
     @staticmethod
     def get_rgb_factors(base_model_type):
