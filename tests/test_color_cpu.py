@@ -20,6 +20,10 @@ def test_round_trip_and_gamut_clip():
     rng = np.random.default_rng(3)
     x = rng.random((17, 19, 3))
     assert np.abs(C.lab2rgb(C.rgb2lab(x)) - x).max() < 1e-6
+    x32 = x.astype(np.float32)                                     # float32 frames stay float32 (scikit-image's rule; the reference's case)
+    lab32 = C.rgb2lab(x32)
+    assert lab32.dtype == np.float32 and C.lab2rgb(lab32).dtype == np.float32
+    assert np.abs(C.lab2rgb(lab32) - x32).max() < 2e-4 and np.abs(lab32 - C.rgb2lab(x)).max() < 2e-3
     out = C.lab2rgb(np.array([[60.0, 120.0, -120.0], [100.0, 0.0, 300.0], [-5.0, 0.0, 0.0]]))
     assert out.min() >= 0.0 and out.max() <= 1.0
 

@@ -18,27 +18,34 @@ _RGB_FROM_XYZ = np.linalg.inv(_XYZ_FROM_RGB)
 _WHITE = np.array([0.95047, 1.0, 1.08883], dtype=np.float64)          # D65, 2 degree observer
 
 
+def _float(a):
+    """scikit-image keeps a float32 image in float32 (`_supported_float_type`) and casts its constants to it; anything else -> float64.
+    The reference hands it float32 frames (numpy views of float32 tensors), so that is the arithmetic type of the whole transfer."""
+    a = np.asarray(a)
+    return a if a.dtype == np.float32 else a.astype(np.float64)
+
+
 def rgb2lab(rgb):
     """[..., 3] sRGB in [0, 1] -> CIE-Lab (L in [0, 100])."""
-    a = np.asarray(rgb, dtype=np.float64)
-    lin = np.where(a > 0.04045, np.power((a + 0.055) / 1.055, 2.4), a / 12.92)
-    xyz = lin @ _XYZ_FROM_RGB.T / _WHITE
-    f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0)
+    a = _float(rgb)
+    lin = np.where(a > 0.04045, np.power((a + 0.055) / 1.055, 2.4), a / 12.92).astype(a.dtype)
+    xyz = lin @ _XYZ_FROM_RGB.T.astype(a.dtype) / _WHITE.astype(a.dtype)
+    f = np.where(xyz > 0.008856, np.cbrt(xyz), 7.787 * xyz + 16.0 / 116.0).astype(a.dtype)
     fx, fy, fz = f[..., 0], f[..., 1], f[..., 2]
-    return np.stack([116.0 * fy - 16.0, 500.0 * (fx - fy), 200.0 * (fy - fz)], axis=-1)
+    return np.stack([116.0 * fy - 16.0, 500.0 * (fx - fy), 200.0 * (fy - fz)], axis=-1).astype(a.dtype)
 
 
 def lab2rgb(lab):
     """CIE-Lab -> [..., 3] sRGB, clipped to [0, 1] (a negative z is clamped to 0 first, as scikit-image does)."""
-    a = np.asarray(lab, dtype=np.float64)
+    a = _float(lab)
     fy = (a[..., 0] + 16.0) / 116.0
     fx = a[..., 1] / 500.0 + fy
     fz = np.maximum(fy - a[..., 2] / 200.0, 0.0)
-    f = np.stack([fx, fy, fz], axis=-1)
-    xyz = np.where(f > 0.2068966, np.power(f, 3.0), (f - 16.0 / 116.0) / 7.787) * _WHITE
-    lin = xyz @ _RGB_FROM_XYZ.T
+    f = np.stack([fx, fy, fz], axis=-1).astype(a.dtype)
+    xyz = (np.where(f > 0.2068966, np.power(f, 3.0), (f - 16.0 / 116.0) / 7.787) * _WHITE).astype(a.dtype)
+    lin = xyz @ _RGB_FROM_XYZ.T.astype(a.dtype)
     rgb = np.where(lin > 0.0031308, 1.055 * np.power(np.maximum(lin, 0.0), 1.0 / 2.4) - 0.055, 12.92 * lin)
-    return np.clip(rgb, 0.0, 1.0)
+    return np.clip(rgb, 0.0, 1.0).astype(a.dtype)
 
 
 def match_and_blend_colors(source_chunk: torch.Tensor, reference_image: torch.Tensor, strength: float) -> torch.Tensor:
