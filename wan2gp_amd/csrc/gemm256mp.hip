@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm256mp_kernel(const bf16_t* __restrict
   for (int r = 0; r < 16; ++r) load_frag(f0, 0, 1, 0, M_ORD(r));
 
   // Stage with global index g (counted over all tiles of this workgroup), J = g % 5: Y in slot 2J % 5, X in (2J+1) % 5;
-  // the schedule of a stage is gemm256k.hip's.  `after_epi`: the first stage behind an epilogue -- 64 stores are younger than
+  // the schedule of a stage is gemm256k.hip's.  `after_epi`: the first stage behind an epilogue -- 32 stores are younger than
   // the X pieces its sync point waits for.
 #define P_SB() __builtin_amdgcn_sched_barrier(0)
 #define P_STEP(J)                                                                                               \
@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256) void gemm256mp_kernel(const bf16_t* __restrict
     // ---- epilogue of tile `cur`: straight from the registers ---------------------------------------------------------------
     // Stores (and the residual loads of the gated form) go through a buffer descriptor over the tile's rows of Out: rows past
     // the matrix fall outside num_records and are dropped / read as zero by the hardware -- no per-row predicate, and every wave
-    // issues exactly 64 stores per tile (what the vmcnt(63) of the next stage counts on).  Everything lane-dependent is derived
+    // issues exactly 32 16-byte stores per tile (what the vmcnt(40) of the next stage counts on: 32 stores + its own 8 Y pieces; the
+    // counter retires loads and stores in issue order on gfx9-class parts, as gemm256p.hip's validated runs rely on).  Everything lane-dependent is derived
     // from an opaque lane id INSIDE this block: derived from threadIdx it is loop-invariant, hoisted in front of the tile loop
     // and kept in VGPRs across the MFMA loop (measured on the ISA: reloads from scratch in every stage).
     P_STAMP(2);
