@@ -994,3 +994,58 @@ def test_attention_w16n_gap_schedule():
     for ks_ in range(4):
         for kt in range(4):
             assert 67 + 2 * (4 * ks_ + kt) > 64 + 8 * ks_ + 2 * kt + 1             # K (kt, ks): last S_b reader q tile 1
+
+
+def test_gemm256mp_ring_hazards_across_tiles():
+    """gemm256mp.hip (experiment, not yet run on hardware): gemm256m's stage inside gemm256p's persistent walk.  Event simulation of
+    one workgroup with the stage's three phases -- A: k-step 0 (Y pieces of stage g+2 into slot (2J+4)%5, the f1 reads of this stage),
+    SYNC: s_waitcnt vmcnt(8 | 40 behind an epilogue) + barrier, C: rest of k-step 1 (X pieces of stage g+2 into slot 2J%5, the f0 reads
+    of stage g+1) -- and an epilogue of 32 stores between tiles.  Checked: (1) a DMA piece never lands in a slot whose last reads are
+    not separated from it by a barrier; (2) every fragment read sees the (operand, tile, k-stage) it multiplies, fetched by pieces the
+    counted wait in front of that barrier has retired (the memory counter retires in issue order); (3) the wait behind an epilogue is
+    exactly what keeps the X pieces of the next stage ahead of the 32 stores + 8 Y pieces."""
+    for nk, ntiles in ((7, 3), (5, 4), (3, 5), (24, 2), (2, 6)):
+        vm = []                                   # in-order queue of outstanding vector-memory ops: ("dma", slot) | ("store",)
+        content = {}                              # slot -> (kind, tile, stage) whose DMA was ISSUED last
+        landed = {}                               # slot -> content known complete AND published by a barrier
+        last_read_epoch = {s: -1 for s in range(5)}
+        epoch = 0                                 # number of barriers passed
+        stream = {"Y": [0, 0], "X": [0, 0]}
+
+        def issue(kind, slot):
+            assert last_read_epoch[slot] < epoch, (nk, kind, slot, "DMA into a slot still being read")
+            t, s = stream[kind]
+            content[slot] = (kind, t, s)
+            landed.pop(slot, None)
+            vm.append(("dma", slot))
+            stream[kind] = [t + 1 if t + 1 < ntiles else t, 0] if s + 1 == nk else [t, s + 1]
+
+        def wait_and_barrier(n):
+            nonlocal epoch
+            while len(vm) > n:                    # s_waitcnt vmcnt(n): the oldest retire first
+                op = vm.pop(0)
+                if op[0] == "dma":
+                    landed[op[1]] = content[op[1]] if not any(o == op for o in vm) else landed.get(op[1])
+            epoch += 1
+
+        def read(slot, kind, tile, stage):
+            assert landed.get(slot) == (kind, tile, stage), (nk, slot, landed.get(slot), (kind, tile, stage))
+            last_read_epoch[slot] = epoch
+        issue("Y", 0); issue("X", 1); issue("Y", 2); issue("X", 3)
+        wait_and_barrier(2)                       # vmcnt(16) in units of 8 pieces: stage 0 landed
+        read(0, "Y", 0, 0); read(1, "X", 0, 0)    # f0 of stage 0
+        g, after_epi = 0, False
+        for tile in range(ntiles):
+            for s in range(nk):
+                J = g % 5
+                SY, SX, NY, NX, DY, DX = (2 * J) % 5, (2 * J + 1) % 5, (2 * J + 2) % 5, (2 * J + 3) % 5, (2 * J + 4) % 5, (2 * J) % 5
+                issue("Y", DY)                                            # phase A
+                read(SY, "Y", tile, s); read(SX, "X", tile, s)            # f1 (k half 1) of this stage
+                wait_and_barrier(1 + (32 if after_epi else 0))            # vmcnt(8) = one Y piece group; vmcnt(40) = + 32 stores
+                after_epi = False
+                issue("X", DX)                                            # phase C
+                nt, ns = (tile, s + 1) if s + 1 < nk else (min(tile + 1, ntiles - 1), 0)
+                read(NY, "Y", nt, ns); read(NX, "X", nt, ns)              # f0 of the next stage (the next tile's first, at a boundary)
+                g += 1
+            vm.extend([("store",)] * 32)                                  # register-direct epilogue
+            after_epi = True
