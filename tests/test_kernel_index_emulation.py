@@ -1049,3 +1049,81 @@ def test_gemm256mp_ring_hazards_across_tiles():
                 g += 1
             vm.extend([("store",)] * 32)                                  # register-direct epilogue
             after_epi = True
+
+
+def test_conv_wide_tile_data_flow():
+    """vae_conv256.inc (experiment, not yet run on hardware): the 256-pixel x 128-channel convolution tile.  Labels instead of values:
+    every 16-byte chunk the LDS-DMA plan writes is tagged (operand, row, logical k-chunk); the fragment reads of wave (wy, wx), lane (n, g),
+    k half ks must then see pixel row wy*128 + 16 a + n / weight row wx*64 + 16 b + n at k-chunk 4 ks + g -- the 16x16x32 MFMA's operand
+    layout -- the per-thread unit / channel offset must not depend on the slot, and the epilogue's (pixel, channel) of every accumulator
+    register must be the product's."""
+    WYST = 256 * 128
+    lds = {}
+    for tid in range(256):
+        wave, lane = tid >> 6, tid & 63
+        pch0 = tid & 7
+        lch0 = pch0 ^ ((tid >> 4) & 7)
+        for i in range(8):                                   # gathered pixels: slot q = i * 256 + tid
+            q = i * 256 + tid
+            row, pch = q >> 3, q & 7
+            assert pch ^ ((row >> 1) & 7) == lch0            # unit (lch >> 2) and channel offset ((lch & 3) * 8) are per-thread constants
+            addr = wave * 1024 + i * 4096 + lane * 16        # smem_lds + i * 256 * 16, 16 bytes per lane behind M0
+            assert addr == q * 16 and addr not in lds
+            lds[addr] = ("Y", row, lch0)
+        for i in range(4):                                   # weights
+            q = i * 256 + tid
+            row, pch = q >> 3, q & 7
+            assert pch ^ ((row >> 1) & 7) == lch0
+            slab, jj = row >> 6, row & 63
+            nt, ii = jj >> 4, jj & 15
+            cout = slab * 64 + (ii >> 2) * 16 + nt * 4 + (ii & 3)      # which output channel the LDS row holds
+            lds[WYST + q * 16] = ("X", row, lch0, cout)
+    assert len(lds) == 2048 + 1024
+    seen = set()
+    for wave in range(4):
+        wy, wx = wave >> 1, wave & 1
+        for lane in range(64):
+            frow, fch = lane & 15, lane >> 4
+            for ks in range(2):
+                for t in range(8):
+                    ry = wy * 128 + t * 16 + frow
+                    off = (ry * 128 + ((fch ^ ((ry >> 1) & 7)) << 4)) ^ (ks << 6)
+                    assert lds[off] == ("Y", ry, 4 * ks + fch)
+                for t in range(4):
+                    rx = wx * 64 + t * 16 + frow
+                    off = (rx * 128 + ((fch ^ ((rx >> 1) & 7)) << 4)) ^ (ks << 6)
+                    kind, row, lch, cout = lds[WYST + off]
+                    assert (kind, row, lch) == ("X", rx, 4 * ks + fch)
+            # D = A (weights: rows) x B (pixels: columns): register r of acc[a][b] in lane (n, g) = weight row 4 g + r of tile b, pixel n
+            # of tile a; the epilogue writes v[b * 4 + r] to channel x0 + wx * 64 + g * 16 + b * 4 + r of pixel wy * 128 + a * 16 + n
+            n, g = lane & 15, lane >> 4
+            for a in range(8):
+                for b in range(4):
+                    for r in range(4):
+                        lrow = wx * 64 + b * 16 + 4 * g + r
+                        cout = lds[WYST + lrow * 128][3]                       # any chunk of that LDS row
+                        assert cout == wx * 64 + g * 16 + b * 4 + r
+                        seen.add((wy * 128 + a * 16 + n, cout))
+    assert len(seen) == 256 * 128
+    # the ring: buffer of stage kt + 2 = the one stage kt - 1 was multiplied from; 12 pieces per thread and stage
+    for nk in (1, 2, 3, 7):
+        vm, buf = [], 0
+        where = {}
+
+        def stage(s, ks):
+            where[ks] = s
+            vm.extend([ks] * 12)
+        stage(0, 0)
+        if nk > 1:
+            stage(1, 1)
+        for kt in range(nk):
+            allow = 12 if kt + 1 < nk else 0
+            while len(vm) > allow:
+                vm.pop(0)
+            assert kt not in vm                                               # stage kt has landed
+            if kt + 2 < nk:
+                s = 2 if buf == 0 else buf - 1
+                assert s == (kt + 2) % 3 and s not in (where[kt], where[kt + 1])   # not the buffer being read, nor the one in flight
+                stage(s, kt + 2)
+            assert where[kt] == buf
+            buf = 0 if buf == 2 else buf + 1
