@@ -153,15 +153,18 @@ def _ref_query_model_def():
         def __getitem__(self, k): return Inert()
         def __iter__(self): return iter([])
     import re as _re
+    hf = {"posixpath": __import__("posixpath")}                      # shared/utils/hf.py: build_hf_url is a pure function -- the real one
+    exec(compile(open(os.path.join(REF, "shared", "utils", "hf.py")).read(), "hf.py", "exec"), hf)
     ns = {"os": os, "re": _re, "gr": Inert(), "fl": Inert(), "VACE_INFOS": "", "SHOTPLAN_PROMPT_ENHANCER": "", "SHOTPLAN_PROMPT_INFOS": "",
           "get_bernini_infos": lambda *a, **k: "", "get_bernini_prompt_infos": lambda *a, **k: "",
-          "get_kiwi_variant_model_def": lambda *a, **k: {}, "build_hf_url": lambda *a, **k: "url"}
+          "get_kiwi_variant_model_def": lambda *a, **k: {}, "build_hf_url": hf["build_hf_url"]}
     exec(compile(ast.Module(body=body, type_ignores=[]), src, "exec"), ns)
     return ns["query_model_def"]
 
 
 @pytest.mark.parametrize("b,md", [("t2v", {}), ("t2v_1.3B", {}), ("t2v_2_2", {"URLs2": ["x"]}), ("i2v", {}), ("i2v_2_2", {"URLs2": ["x"]}),
-                                  ("ti2v_2_2", {}), ("vace_14B", {}), ("vace_1.3B", {})])
+                                  ("ti2v_2_2", {}), ("vace_14B", {}), ("vace_1.3B", {}), ("flf2v_720p", {}),
+                                  ("t2v", {"text_encoder_folder": "my-t5"}), ("i2v", {"text_encoder_URLs": ["https://h/x.safetensors"]})])
 def test_model_definition_agrees_with_the_references_on_every_shared_property(b, md):
     """Every property both handlers write (class flags, fps, frame grid, VAE block size, profile folders, samplers, guidance /
     step-skipping capabilities, NAG, image prompt types, ...) has the reference's value for the corresponding built-in type --
@@ -177,6 +180,9 @@ def test_model_definition_agrees_with_the_references_on_every_shared_property(b,
     # claim them), and the image prompt types claimed are a subset of the reference's letters
     assert (not got["sliding_window"] or want["sliding_window"]) and set(got["image_prompt_types_allowed"]) <= set(want["image_prompt_types_allowed"])
     shared -= {"sliding_window", "image_prompt_types_allowed"}
+    if b == "flf2v_720p":                                     # deliberate: NAG is not claimed beside the two-image CLIP context (refused by the driver)
+        assert got["NAG"] is False and want["NAG"] is True
+        shared -= {"NAG"}
     assert len(shared) >= 26
     assert {k: got[k] for k in shared} == {k: want[k] for k in shared}
     assert got.get("perturbation") == (not b.startswith("vace"))               # skip-layer guidance: claimed except beside VACE blocks
@@ -356,3 +362,41 @@ def test_files_to_fetch_are_a_subset_of_the_references_list(b):
     if ref is None:
         pytest.skip("reference tree not present")
     assert got <= triples(ref([], b, {})), got - triples(ref([], b, {}))
+
+
+def test_load_model_reads_quanto_int8_and_diffusers_files_the_way_wgp_picks_them(monkeypatch, tmp_path):
+    """wgp.py picks the checkpoint file by the user's quantisation setting (`get_model_filename`, wgp.py:2927; int8 is the default), for
+    the experts AND the text encoder (wgp.py:4051-4058): load_model runs every DiT file through the full reader (Diffusers names,
+    key normalisation, quanto pairs -> bf16) and dequantises a quanto text-encoder file before the encoder sees it."""
+    import torch
+    from wan2gp_amd import checkpoint as C, model as M, t5 as T5, tokenizers as TK, vae as V, wan_handler as W
+    files = {
+        "hi_quanto_mbf16_int8.safetensors": {"model.diffusion_model.blocks.0.self_attn.q.weight._data": torch.ones(2, 2, dtype=torch.int8),
+                                               "model.diffusion_model.blocks.0.self_attn.q.weight._scale": torch.ones(2, 1),
+                                               "blocks.0.self_attn.q.input_scale": torch.ones(1), "head.head.bias": torch.zeros(2)},
+        "t5_int8.safetensors": {"blocks.0.attn.q.weight._data": torch.ones(2, 2, dtype=torch.int8), "blocks.0.attn.q.weight._scale": torch.ones(2, 1),
+                                "token_embedding.weight": torch.zeros(2, 2)},
+    }
+    for name in files:
+        (tmp_path / name).write_bytes(b"")
+    monkeypatch.setattr(C, "read_safetensors", lambda p: dict(files[os.path.basename(str(p))]))
+    from wan2gp_amd import ops
+    monkeypatch.setattr(ops, "dequant_i8", lambda data, scale: (data.float() * scale.view(-1, 1)).to(torch.bfloat16))
+    seen = {}
+
+    class Dit:
+        def __init__(self, device=None, **arch):
+            self.model_type = arch["model_type"]
+
+        def load_state_dict(self, sd):
+            seen["dit"] = sd
+            return self
+    monkeypatch.setattr(M, "WanModelHIP", Dit)
+    monkeypatch.setattr(V, "WanVAEHIP", lambda state_dict=None, vae_pth=None, device=None: "vae")
+    monkeypatch.setattr(T5, "T5EncoderModelHIP", lambda n, tok, state_dict=None, device=None: seen.setdefault("t5", state_dict))
+    monkeypatch.setattr(TK, "HuggingfaceTokenizer", lambda **kw: seen.setdefault("tok", kw))
+    W.family_handler.load_model([str(tmp_path / "hi_quanto_mbf16_int8.safetensors")], "t2v_hip", "t2v_hip", {}, vae_state_dict={},
+                                text_encoder_filename=str(tmp_path / "t5_int8.safetensors"), device="cpu")
+    assert set(seen["dit"]) == {"blocks.0.self_attn.q.weight", "head.head.bias"} and seen["dit"]["blocks.0.self_attn.q.weight"].dtype == torch.bfloat16
+    assert set(seen["t5"]) == {"blocks.0.attn.q.weight", "token_embedding.weight"} and seen["t5"]["blocks.0.attn.q.weight"].dtype == torch.bfloat16
+    assert seen["tok"]["name"] == str(tmp_path)                           # the tokenizer folder = the checkpoint's (any2video.py:124)

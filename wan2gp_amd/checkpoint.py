@@ -168,6 +168,18 @@ def dequantize_quanto_(sd: Dict[str, torch.Tensor], device="cuda") -> Dict[str, 
     return sd
 
 
+def read_wan_file(path, device="cuda", dtype=torch.bfloat16, diffusers_names: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+    """One checkpoint file -> a state dict `WanModelHIP.load_state_dict` takes: Diffusers names converted (detected from
+    `condition_embedder.` / `attn1.` keys unless told), the reference's key normalisation, quanto int8 pairs dequantised to bf16."""
+    sd = read_safetensors(path)
+    if diffusers_names or (diffusers_names is None and any(".attn1." in k or k.startswith("condition_embedder.") for k in sd)):
+        sd = convert_diffusers_state_dict(sd)
+    sd = normalize_wan_keys(sd, dtype)
+    if any(k.endswith("._data") for k in sd):
+        dequantize_quanto_(sd, device=device)
+    return sd
+
+
 def load_wan_checkpoint(model, paths: Iterable[str], dtype=torch.bfloat16, diffusers_names: Optional[bool] = None):
     """Files -> `model.load_state_dict` (a `WanModelHIP`): what `offload.fast_load_transformers_model(files,
     preprocess_sd=...)` amounts to for a resident model (any2video.py:187-224).  `diffusers_names=None` detects the
@@ -175,11 +187,5 @@ def load_wan_checkpoint(model, paths: Iterable[str], dtype=torch.bfloat16, diffu
     if isinstance(paths, (str, bytes)):
         paths = [paths]
     for p in paths:
-        sd = read_safetensors(p)
-        if diffusers_names or (diffusers_names is None and any(".attn1." in k or k.startswith("condition_embedder.") for k in sd)):
-            sd = convert_diffusers_state_dict(sd)
-        sd = normalize_wan_keys(sd, dtype)
-        if any(k.endswith("._data") for k in sd):
-            dequantize_quanto_(sd, device=model.device)
-        model.load_state_dict(sd)
+        model.load_state_dict(read_wan_file(p, model.device, dtype, diffusers_names))
     return model

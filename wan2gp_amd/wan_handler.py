@@ -157,11 +157,37 @@ class family_handler():
             # what the HIP path does not implement: offload, compile, in-app quantisation
             "compile": False, "no_quantization": True, "backend": "hip-gfx950",
         }
+        # the text encoder's files (wan_handler.py:221-229, :295-299): wgp.py resolves `text_encoder_filename` -- what load_model is handed --
+        # from these URLs by the user's quantisation setting and downloads into this folder (wgp.py:4051-4058); a model definition may
+        # override either
+        folder = "umt5-xxl"
+        urls = ["https://huggingface.co/DeepBeepMeep/Wan2.1/resolve/main/umt5-xxl/" + f
+                for f in ("models_t5_umt5-xxl-enc-bf16.safetensors", "models_t5_umt5-xxl-enc-quanto_int8.safetensors")]
+        if model_def.get("text_encoder_URLs") is not None or model_def.get("text_encoder_folder") is not None:
+            folder = model_def.get("text_encoder_folder") or folder
+            urls = model_def.get("text_encoder_URLs") or urls
+        extra["text_encoder_URLs"], extra["text_encoder_folder"] = urls, folder
         if multiple_submodels:
             extra["no_steps_skipping"] = True
         if i2v:
             extra["motion_amplitude"] = True
             extra["black_frame"] = True
+        if vace:
+            # the control-video inputs of the VACE types (wan_handler.py:814-839): without them wgp.py offers no control video, mask or
+            # reference images for the type.  What they switch on is prepared by wgp.py (preprocessors, outpainting, padding, positioned
+            # frames) and reaches generate() as input_frames(2) / input_masks(2) / input_ref_images / input_ref_masks, all served.
+            # Not claimed: `v2i_switch_supported` (image outputs, image_mode = 1: refused by generate()).
+            extra.update({
+                "control_net_weight_name": "Vace", "control_net_weight_size": 2,
+                "guide_preprocessing": {"selection": ["", "UV", "PV", "OV", "DV", "SV", "LV", "CV", "MV", "V", "PDV", "PSV", "PLV", "DSV", "DLV", "SLV"],
+                                        "labels": {"V": "Use Vace raw format"}},
+                "mask_preprocessing": {"selection": ["", "A", "NA", "XA", "XNA", "YA", "YNA", "WA", "WNA", "ZA", "ZNA"]},
+                "image_ref_choices": {"choices": [("None", ""), ("People / Objects", "I"), ("Landscape followed by People / Objects (if any)", "KI"),
+                                                  ("Positioned Frames followed by People / Objects (if any)", "FI")], "letters_filter": "KFI"},
+                "background_removal_label": "Remove Backgrounds behind People / Objects, keep it for Landscape or Positioned Frames",
+                "video_guide_outpainting": [0, 1], "pad_guide_video": True, "guide_inpaint_color": 127.5, "forced_guide_mask_inputs": True,
+                "return_image_refs_tensor": True,
+            })
         return extra
 
     @staticmethod
@@ -206,7 +232,7 @@ class family_handler():
                                       "bf16 or scaled-fp8 checkpoints as they are")
         if mixed_precision_transformer:
             raise NotImplementedError("mixed-precision (fp32 residual stream) transformer: bf16 only")
-        from .checkpoint import normalize_wan_keys, read_safetensors
+        from .checkpoint import read_safetensors, read_wan_file
         from .model import WanModelHIP
         from .pipeline import WanAny2VHIP
         b = base_of(base_model_type)
@@ -224,9 +250,10 @@ class family_handler():
         if state_dicts is not None:
             sds = list(state_dicts)
         else:
-            sds = [normalize_wan_keys(read_safetensors(f)) for f in files[:n_main]]
+            # (wgp.py picks the file by the user's quantisation setting, get_model_filename wgp.py:2927: the quanto int8 form is the default)
+            sds = [read_wan_file(f, device) for f in files[:n_main]]
             for f, no in zip(files[n_main:], nos[n_main:]):
-                extra = normalize_wan_keys(read_safetensors(f))
+                extra = read_wan_file(f, device)
                 for k, sd in enumerate(sds):
                     if no in (0, k + 1):
                         sd.update(extra)
@@ -265,7 +292,11 @@ class family_handler():
             from .t5 import T5EncoderModelHIP
             from .tokenizers import HuggingfaceTokenizer
             tok = HuggingfaceTokenizer(name=os.path.dirname(str(text_encoder_filename)), seq_len=512, clean="whitespace")
-            text_encoder = T5EncoderModelHIP(512, tok, state_dict=read_safetensors(text_encoder_filename), device=device)
+            te_sd = read_safetensors(text_encoder_filename)
+            if any(k.endswith("._data") for k in te_sd):            # models_t5_umt5-xxl-enc-quanto_int8.safetensors
+                from .checkpoint import dequantize_quanto_
+                dequantize_quanto_(te_sd, device=device)
+            text_encoder = T5EncoderModelHIP(512, tok, state_dict=te_sd, device=device)
         pipe = WanAny2VHIP(models[0], models[1] if len(models) > 1 else None, vae=vae, text_encoder=text_encoder, device=device,
                            vae_stride=(4, 16, 16) if test_wan_5B(b) else (4, 8, 8))
         pipe.model_def, pipe.base_model_type = model_def, base_model_type
