@@ -172,6 +172,22 @@ class family_handler():
         if i2v:
             extra["motion_amplitude"] = True
             extra["black_frame"] = True
+        if i2v or wan_5B:       # test_oneframe_overlap (wan_handler.py:41-42, :996-997): windows of these types overlap by exactly one frame
+            extra["sliding_window_defaults"] = {"overlap_min": 1, "overlap_max": 1, "overlap_step": 0, "overlap_default": 1}
+        # video-to-video (the "G" letter generate() serves for every model, any2video.py:1004-1044): the UI's choice list exists for the
+        # reference's t2v class (wan_handler.py:428-443) and, with the start image, for i2v_2_2 (:394-410)
+        if t2v or b == "i2v_2_2":
+            with_image = b == "i2v_2_2"
+            extra["guide_custom_choices"] = {
+                "choices": [("Use Text & Image Prompt Only" if with_image else "Use Text Prompt Only", ""),
+                            ("Video to Video guided by Text Prompt & Image" if with_image else "Video to Video guided by Text Prompt", "GUV"),
+                            ("Video to Video guided by Text/Image Prompt and Restricted to the Area of the Video Mask" if with_image else
+                             "Video to Video guided by Text Prompt and Restricted to the Area of the Video Mask", "GVA")],
+                "default": "", "show_label": False, "letters_filter": "GUVA", "label": "Video to Video"}
+            extra["mask_preprocessing"] = {"selection": ["", "A"], "visible": False}
+            if with_image:
+                extra["i2v_v2v"] = True
+                extra["extract_guide_from_window_start"] = True
         if vace:
             # the control-video inputs of the VACE types (wan_handler.py:814-839): without them wgp.py offers no control video, mask or
             # reference images for the type.  What they switch on is prepared by wgp.py (preprocessors, outpainting, padding, positioned
