@@ -71,6 +71,8 @@ def test_model_def_properties_and_settings():
                   "sliding_window_overlap": 1, "sliding_window_color_correction_strength": 0}          # wan_handler.py:1441-1449
     assert H.validate_generative_settings("t2v_hip", {}, {"sample_solver": "euler"}) is None
     assert "Unsupported" in H.validate_generative_settings("t2v_hip", {}, {"sample_solver": "ddim"})
+    assert "image" in H.validate_generative_settings("t2v_hip", {}, {"sample_solver": "unipc", "image_mode": 1})
+    assert H.validate_generative_settings("t2v_hip", {}, {"sample_solver": "unipc", "image_mode": 0}) is None
     assert H.query_model_family() == "wan"
     with pytest.raises(NotImplementedError):
         H.load_model(["a.safetensors"], "t2v_hip", "t2v_hip", {}, quantizeTransformer=True)

@@ -434,4 +434,7 @@ class family_handler():
     def validate_generative_settings(base_model_type, model_def, inputs):
         if inputs.get("sample_solver", "unipc") not in ("unipc", "", "euler", "dpm++", "causvid", "lcm"):
             return f"Unsupported sample solver {inputs.get('sample_solver')!r}"
+        # what generate() would refuse in the middle of a run is refused here, where wgp.py shows the message (wgp.py:1056-1070)
+        if (inputs.get("image_mode", 0) or 0) == 1:
+            return "The HIP backend generates videos only (image outputs, image_mode 1, are not served)."
         return None
