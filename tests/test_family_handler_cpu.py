@@ -119,7 +119,7 @@ def _ref_update_default_settings():
 
 
 @pytest.mark.parametrize("b,model_def", [("t2v", {}), ("t2v_1.3B", {}), ("t2v_2_2", {"multiple_submodels": True}),
-                                         ("i2v", {}), ("i2v_2_2", {"multiple_submodels": True}), ("ti2v_2_2", {}),
+                                         ("i2v", {}), ("flf2v_720p", {}), ("i2v_2_2", {"multiple_submodels": True}), ("ti2v_2_2", {}),
                                          ("vace_14B", {}), ("vace_1.3B", {})])
 def test_default_settings_equal_the_references(b, model_def):
     """For every supported type the defaults the HIP handler writes are the ones the reference's own function writes for the
@@ -207,7 +207,7 @@ def _ref_static(name):
     return ns[name]
 
 
-@pytest.mark.parametrize("b", ["t2v", "t2v_1.3B", "t2v_2_2", "i2v", "i2v_2_2", "ti2v_2_2", "vace_14B", "vace_1.3B"])
+@pytest.mark.parametrize("b", ["t2v", "t2v_1.3B", "t2v_2_2", "i2v", "flf2v_720p", "i2v_2_2", "ti2v_2_2", "vace_14B", "vace_1.3B"])
 def test_fix_settings_migrates_old_settings_like_the_reference(b):
     ref = _ref_static("fix_settings")
     if ref is None:
@@ -227,7 +227,7 @@ def test_fix_settings_migrates_old_settings_like_the_reference(b):
 
 
 @pytest.mark.parametrize("b,md", [("t2v", {}), ("t2v", {"URLs2": ["x"]}), ("t2v_1.3B", {}), ("t2v_2_2", {"URLs2": ["x"]}), ("i2v", {}),
-                                  ("i2v_2_2", {"URLs2": ["x"]}), ("ti2v_2_2", {}), ("vace_14B", {}), ("vace_1.3B", {})])
+                                  ("flf2v_720p", {}), ("i2v_2_2", {"URLs2": ["x"]}), ("ti2v_2_2", {}), ("vace_14B", {}), ("vace_1.3B", {})])
 def test_set_cache_parameters_hands_over_the_references_calibration_tables(b, md):
     """wgp.py:7079 calls handler.set_cache_parameters when TeaCache / MagCache is switched on: same tables, chosen the same way
     (model class; resolution for the Wan2.1 i2v model; start image + source video for the 5B model) as the lifted reference
@@ -247,7 +247,7 @@ def test_set_cache_parameters_hands_over_the_references_calibration_tables(b, md
             assert len(getattr(got, "def_mag_ratios", getattr(got, "coefficients", []))) in (5, 78, 98)
 
 
-@pytest.mark.parametrize("b", ["t2v", "t2v_1.3B", "t2v_2_2", "i2v", "i2v_2_2", "ti2v_2_2", "vace_14B", "vace_1.3B"])
+@pytest.mark.parametrize("b", ["t2v", "t2v_1.3B", "t2v_2_2", "i2v", "flf2v_720p", "i2v_2_2", "ti2v_2_2", "vace_14B", "vace_1.3B"])
 def test_lora_folders_are_the_builtin_types(b):
     """wan_handler.get_lora_dir (:150-168): same folder, same command-line overrides as the built-in type."""
     import types
