@@ -49,6 +49,7 @@ WORKLOADS = {
 }
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 VIDEO_STEPS = 30            # UI default sampling steps (defaults/t2v_2_2.json)
+T_PROCESS0 = time.perf_counter()
 
 
 def forward_flops(cfg, L, text_len=512):
@@ -185,6 +186,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (i2v 14B, scaled-fp8 weights, VAE encode + decode)")
+    ap.add_argument("--extras-budget-s", type=float, default=float(os.environ.get("WAN_BENCH_EXTRAS_BUDGET_S", 900)),
+                    help="an OPTIONAL block behind the timed region (secondary workload, simulated ranks, config 5) is skipped -- and says so "
+                         "in its place -- when the process is already older than this; the headline measurement, roofline and cpu_baseline never are")
     ap.add_argument("--simulate-world", default="2,4,8", help="comma-separated world sizes (e.g. 2,4,8): after the timed region, run ONE "
                     "rank's shard of a sequence-parallel world of that size on this GPU, the K / V^T all-gathers replaced by "
                     "device-to-device copies of the bytes that rank would receive -> compute-side upper bound of the scaling curve; '' = skip")
@@ -405,11 +409,11 @@ def main():
             out["e2e"] = e2e
         if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
             log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
-            out["secondary"] = _extra_block(secondary_1p3b, vae)
+            out["secondary"] = _extra_block(secondary_1p3b, vae, budget_s=args.extras_budget_s)
         if world == 1 and args.simulate_world and args.workload in ("14B-720p", "i2v-14B-720p"):
             log("simulated sequence-parallel ranks: " + args.simulate_world)
             out["simulated_scaling"] = _extra_block(simulate_world, [int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
-                                                    latents, args.warmup, dt / args.steps, cfg, L)
+                                                    latents, args.warmup, dt / args.steps, cfg, L, budget_s=args.extras_budget_s)
         cpu_thread, cpu_box = None, {}
         if not args.no_cpu_baseline and world == 1:
             # on the host cores WHILE the GPU runs the config-5 block -- long kernels, one launching thread; the launch-dense blocks
@@ -431,7 +435,7 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            out["config5"] = _extra_block(config5_block, vae)
+            out["config5"] = _extra_block(config5_block, vae, budget_s=args.extras_budget_s)
         if cpu_thread is not None:
             cpu_thread.join()
             out["cpu_baseline"] = cpu_box.get("r")
@@ -442,9 +446,14 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def _extra_block(fn, *a):
+def _extra_block(fn, *a, budget_s=None):
     """The blocks behind the headline measurement (secondary workload, simulated ranks, config 5) must never cost the bench its JSON
-    line: a failure is recorded in the block's place."""
+    line: a failure is recorded in the block's place, and a block that would START after `budget_s` seconds of process time (a slow
+    box, a long --steps) is skipped with a note instead of pushing the run past whatever limit its caller has."""
+    age = time.perf_counter() - T_PROCESS0
+    if budget_s is not None and age > budget_s:
+        log("block %s skipped: process is %.0f s old (--extras-budget-s %.0f)" % (getattr(fn, "__name__", "?"), age, budget_s))
+        return {"skipped": "process was %.0f s old when this optional block would have started (--extras-budget-s %.0f)" % (age, budget_s)}
     try:
         return fn(*a)
     except Exception as ex:  # noqa: BLE001 -- reported, not swallowed

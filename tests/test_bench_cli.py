@@ -105,3 +105,20 @@ def test_committed_bench_line_carries_the_contract():
     assert [x["world"] for x in j["simulated_scaling"]["ranks"]] == [2, 4, 8]
     assert all(0.5 < x["compute_side_efficiency"] <= 1.0 for x in j["simulated_scaling"]["ranks"])
     assert j["config5"]["dtype"].startswith("fp8") and j["secondary"]["ms_per_step"] > 0 and j["e2e"]["composed_s_at_30_steps"] > 0
+
+
+def test_optional_blocks_are_skipped_past_the_extras_budget_and_failures_are_recorded(monkeypatch):
+    """_extra_block: an optional block never costs the JSON line -- it is skipped (with a note) once the process is older than the
+    budget, a failing one leaves its error in its place, one inside the budget runs."""
+    import bench
+    calls = []
+    monkeypatch.setattr(bench, "T_PROCESS0", bench.time.perf_counter() - 1000.0)
+    r = bench._extra_block(lambda: calls.append(1) or {"ok": 1}, budget_s=900.0)
+    assert "skipped" in r and not calls
+    assert bench._extra_block(lambda: {"ok": 1}, budget_s=1100.0) == {"ok": 1}
+    assert bench._extra_block(lambda: {"ok": 1}) == {"ok": 1}                      # no budget: always runs
+
+    def boom():
+        raise RuntimeError("no")
+    r = bench._extra_block(boom, budget_s=1100.0)
+    assert "RuntimeError" in r["error"] and "traceback" in r
