@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void gemm256mp_kernel(const bf16_t* __restrict
     }
     P_STAMP(4);
     if (!has_next) break;
-    after_epi = true;  // every wave issued exactly 64 stores (range-checked, never skipped)
+    after_epi = true;  // every wave issued exactly 32 stores (range-checked, never skipped)
     cur = nxt;
     ++it;
     plan_next();
