@@ -186,9 +186,16 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (i2v 14B, scaled-fp8 weights, VAE encode + decode)")
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "sp", "cfg-sp"],
+                    help="N > 1: 'sp' = the token axis over all N ranks, both CFG streams on every rank; 'cfg-sp' = the conditional stream on "
+                         "ranks [0, N/2), the unconditional one on [N/2, N), the token axis over the N/2 ranks of a half, one 2-rank swap of "
+                         "the predictions per step (wan2gp_amd/sp.py CfgParallel); 'auto' = cfg-sp for an even N, sp otherwise")
     ap.add_argument("--extras-budget-s", type=float, default=float(os.environ.get("WAN_BENCH_EXTRAS_BUDGET_S", 900)),
                     help="an OPTIONAL block behind the timed region (secondary workload, simulated ranks, config 5) is skipped -- and says so "
                          "in its place -- when the process is already older than this; the headline measurement, roofline and cpu_baseline never are")
+    ap.add_argument("--simulate-layout", default="sp", choices=["sp", "cfg-sp", "both"],
+                    help="which rank the simulated-ranks block runs: 'sp' = both streams at L / N rows (--parallelism sp), 'cfg-sp' = one stream "
+                         "at L / (N/2) rows + the per-step swap as a device-to-device copy (--parallelism cfg-sp; first GPU run pending: opt-in)")
     ap.add_argument("--simulate-world", default="2,4,8", help="comma-separated world sizes (e.g. 2,4,8): after the timed region, run ONE "
                     "rank's shard of a sequence-parallel world of that size on this GPU, the K / V^T all-gathers replaced by "
                     "device-to-device copies of the bytes that rank would receive -> compute-side upper bound of the scaling curve; '' = skip")
@@ -211,8 +218,12 @@ def main():
         sys.exit(f"bench.py: {world} ranks need {world} GPUs on this node, found {torch.cuda.device_count()}")
     _cfg, (_f, _h, _w), _ = WORKLOADS[args.workload]
     _L = _f * (_h // 2) * (_w // 2)
-    if _L % world:
-        sys.exit(f"bench.py: the {_L} tokens of workload {args.workload} do not shard over {world} sequence-parallel ranks "
+    if args.parallelism == "cfg-sp" and world > 1 and world % 2:
+        sys.exit(f"bench.py: --parallelism cfg-sp splits the ranks in two halves: {world} is odd")
+    cfg_sp = world > 1 and world % 2 == 0 and args.parallelism in ("auto", "cfg-sp")
+    sp_degree = world // 2 if cfg_sp else world            # ranks that share one stream's token axis
+    if _L % sp_degree:
+        sys.exit(f"bench.py: the {_L} tokens of workload {args.workload} do not shard over {sp_degree} sequence-parallel ranks "
                  f"(divisors: 2, 4, 8 ...)")
     torch.cuda.set_device(local)
     if world > 1:
@@ -237,7 +248,11 @@ def main():
     log(f"workload {args.workload}: building random-init weights")
     model = random_weights(WanModelHIP(**mcfg), cfg, 1234, args.fp8)
     model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321, args.fp8) if two_experts else None
-    if world > 1:
+    cfgp = None
+    if cfg_sp:
+        from wan2gp_amd.sp import CfgParallel
+        cfgp = CfgParallel(rank, world).attach(model, model2)          # this rank's stream; the half's sequence-parallel group on the experts
+    elif world > 1:
         from wan2gp_amd.sp import SequenceParallel
         sp = SequenceParallel(rank, world)
         model.sp = sp
@@ -283,10 +298,15 @@ def main():
         enc_s = time.perf_counter() - te
     latents = torch.randn(1, 16, f, h, w, device="cuda", generator=g)
 
+    par = {"cfgp": cfgp}           # (the simulated-ranks block swaps a stand-in in)
+
     def one_step(i, lat):
         t = sched.timesteps[i]
         trans = model2 if (model2 is not None and int(t) <= switch_threshold) else model
-        cond, uncond = trans([lat, lat], t=torch.stack([t]), context=[ctx, ctx_null], freqs=freqs, y=y)
+        if par["cfgp"] is not None:       # this rank's stream, then the 2-rank swap: every rank holds (cond, uncond) bit-identically
+            cond, uncond = par["cfgp"].guided_pair(trans, lat, ctx, ctx_null, t=torch.stack([t]), freqs=freqs, y=y)
+        else:
+            cond, uncond = trans([lat, lat], t=torch.stack([t]), context=[ctx, ctx_null], freqs=freqs, y=y)
         noise = cfg_combine(cond, uncond, guide if trans is model else 3.0)
         return sched.step(noise, t, lat)[0]
 
@@ -335,9 +355,9 @@ def main():
         L_.check(lib.wan_prof_collect(cls, ctypes.byref(ms), ctypes.byref(n)), "wan_prof_collect")
         prof[name] = (ms.value, n.value)
     if rank == 0:
-        S = 2
+        S = 1 if cfg_sp else 2                                  # streams one launch of this rank carries
         d, ffn = cfg["dim"], cfg["ffn_dim"]
-        Ll = L // world
+        Ll = L // sp_degree
         ms, n = prof["self_attn"]
         attn_flops = 4.0 * Ll * L * d * S                      # algorithmic FLOP of one launch (S streams)
         achieved = attn_flops / (ms / n * 1e-3) / 1e12 if n else 0.0
@@ -388,7 +408,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
-                       "solver": "unipc", "parallelism": "sp%d" % world if world > 1 else "single",
+                       "solver": "unipc", "parallelism": ("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) if world > 1 else "single",
                        "forward_TFLOP": forward_flops(cfg, L) / 1e12},
             "roofline": {"kernel": "attn_w16n_kernel (self-attention: the bounded loop on the 16x16x32 MFMA)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
@@ -413,7 +433,7 @@ def main():
         if world == 1 and args.simulate_world and args.workload in ("14B-720p", "i2v-14B-720p"):
             log("simulated sequence-parallel ranks: " + args.simulate_world)
             out["simulated_scaling"] = _extra_block(simulate_world, [int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
-                                                    latents, args.warmup, dt / args.steps, cfg, L, budget_s=args.extras_budget_s)
+                                                    latents, args.warmup, dt / args.steps, cfg, L, par, args.simulate_layout, budget_s=args.extras_budget_s)
         cpu_thread, cpu_box = None, {}
         if not args.no_cpu_baseline and world == 1:
             # on the host cores WHILE the GPU runs the config-5 block -- long kernels, one launching thread; the launch-dense blocks
@@ -520,7 +540,7 @@ def config5_block(vae):
             "composed_s_at_%d_steps" % VIDEO_STEPS: VIDEO_STEPS * step_s + enc_s + dec_s}
 
 
-def simulate_world(worlds, model, model2, one_step, latents, first_step, step_s_1gpu, cfg, L):
+def simulate_world(worlds, model, model2, one_step, latents, first_step, step_s_1gpu, cfg, L, par=None, layout="sp"):
     """ONE rank (rank 0) of a sequence-parallel world of N on this GPU: its token shard (L / N query rows against N gathered K / V^T
     segments, every token-local kernel at M = S L / N rows), the all-gathers replaced by device-to-device copies of what the rank
     would receive, on a side stream like the RCCL path.  What it measures is the COMPUTE side of the scaling curve (tile
@@ -564,33 +584,58 @@ def simulate_world(worlds, model, model2, one_step, latents, first_step, step_s_
         def all_gather(self, send):
             return send.repeat(self.world, *([1] * (send.dim() - 1)))
 
+    class SimulatedCfgRank:
+        """Rank 0 of a cfg2 x sp(N/2) world: the conditional stream alone through the model (S = 1, the half's simulated sequence-parallel
+        group on it), the partner's prediction = a device-to-device copy of this rank's (the bytes the 2-rank swap delivers)."""
+
+        def __init__(self, sp):
+            self.sp, self.stream = sp, 0
+
+        def guided_pair(self, model_, lat, context, context_null, **kw):
+            r = model_(x=[lat], context=[context], x_id=0, **kw)[0]
+            return r, r.clone()
+
     rows = []
-    for n in worlds:
-        if L % n:
-            rows.append({"world": n, "skipped": f"{L} tokens do not divide by {n}"})
+    plans = [(n, lay) for n in worlds for lay in (("sp", "cfg-sp") if layout == "both" else (layout,))]
+    for n, lay in plans:
+        deg = n // 2 if lay == "cfg-sp" else n                 # ranks sharing one stream's token axis
+        if lay == "cfg-sp" and n % 2:
+            rows.append({"world": n, "layout": lay, "skipped": f"world {n} is odd"})
             continue
-        sp = SimulatedRank(n)
-        model.sp = sp
-        if model2 is not None:
-            model2.sp = sp
-        lat = latents
-        lat = one_step(first_step, lat)                                   # warm-up: workspace of this sharding
-        torch.cuda.synchronize()
-        sp.bytes = 0
-        t0 = time.perf_counter()
-        k = 2
-        for i in range(k):
-            lat = one_step(first_step + 1 + i, lat)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / k
-        assert torch.isfinite(lat).all()
-        layers = cfg["num_layers"]
-        rows.append({"world": n, "rank_step_ms": dt * 1e3, "compute_side_efficiency": step_s_1gpu / (n * dt),
-                     "gathered_bytes_per_block_and_rank": sp.bytes / (k * layers),       # K + V^T of the other ranks, both CFG streams
-                     "tokens_per_rank": L // n})
-        model.sp = None
-        if model2 is not None:
-            model2.sp = None
+        if L % deg:
+            rows.append({"world": n, "layout": lay, "skipped": f"{L} tokens do not divide by {deg}"})
+            continue
+        sp = SimulatedRank(deg) if deg > 1 else None
+        try:
+            if lay == "cfg-sp" and par is not None:
+                par["cfgp"] = SimulatedCfgRank(sp)
+            model.sp = sp
+            if model2 is not None:
+                model2.sp = sp
+            lat = latents
+            lat = one_step(first_step, lat)                                   # warm-up: workspace of this sharding
+            torch.cuda.synchronize()
+            if sp is not None:
+                sp.bytes = 0
+            t0 = time.perf_counter()
+            k = 2
+            for i in range(k):
+                lat = one_step(first_step + 1 + i, lat)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / k
+            assert torch.isfinite(lat).all()
+            layers = cfg["num_layers"]
+            rows.append({"world": n, "layout": "cfg2 x sp%d" % deg if lay == "cfg-sp" else "sp%d" % n,
+                         "rank_step_ms": dt * 1e3, "compute_side_efficiency": step_s_1gpu / (n * dt),
+                         # K + V^T of the other ranks of the group, for the streams this rank runs
+                         "gathered_bytes_per_block_and_rank": (sp.bytes / (k * layers)) if sp is not None else 0.0,
+                         "tokens_per_rank": L // deg, "streams_per_rank": 1 if lay == "cfg-sp" else 2})
+        finally:                                                              # whatever happened: the models leave as they came
+            model.sp = None
+            if model2 is not None:
+                model2.sp = None
+            if par is not None:
+                par["cfgp"] = None
     return {"note": "one rank's shard on one GPU, all-gathers = device-to-device copies (compute-side upper bound; no xGMI time)",
             "one_gpu_step_ms": step_s_1gpu * 1e3, "ranks": rows}
 

@@ -67,18 +67,32 @@ def test_more_ranks_than_gpus_is_an_error_before_any_collective(monkeypatch):
     assert "4 ranks need 4 GPUs" in str(e.value.code)
 
 
-def test_token_count_that_does_not_shard_is_an_error_before_the_weights_are_built(monkeypatch):
-    """L = 75,600 tokens shard over 2 / 4 / 8 ranks; a world size that does not divide them (16: 4,725 -- fine; 32: not) stops with
-    a message that names the numbers, not with a ValueError inside the first forward of one rank while the others wait."""
+@pytest.mark.parametrize("world,parallelism,degree", [(32, "sp", 32), (64, "auto", 32), (64, "cfg-sp", 32)])
+def test_token_count_that_does_not_shard_is_an_error_before_the_weights_are_built(monkeypatch, world, parallelism, degree):
+    """L = 75,600 tokens shard over 2 / 4 / 8 / 16 sequence-parallel ranks; a degree that does not divide them (32) stops with a
+    message that names the numbers, not with a ValueError inside the first forward of one rank while the others wait.  Under
+    cfg-sp (the default for an even world) the degree is HALF the world: the two halves run the two CFG streams."""
     bench = _bench()
     import torch
-    monkeypatch.setenv("WORLD_SIZE", "32"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "32"])
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 32)
+    monkeypatch.setenv("WORLD_SIZE", str(world)); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", str(world), "--parallelism", parallelism])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: world)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: pytest.fail("must stop before touching a device"))
     with pytest.raises(SystemExit) as e:
         bench.main()
-    assert "75600" in str(e.value.code) and "32" in str(e.value.code)
+    assert "75600" in str(e.value.code) and f"over {degree} sequence-parallel" in str(e.value.code)
+
+
+def test_cfg_sp_needs_an_even_world(monkeypatch):
+    bench = _bench()
+    import torch
+    monkeypatch.setenv("WORLD_SIZE", "3"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--parallelism", "cfg-sp"])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 3)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: pytest.fail("must stop before touching a device"))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "odd" in str(e.value.code)
 
 
 def test_committed_bench_line_carries_the_contract():
@@ -122,3 +136,32 @@ def test_optional_blocks_are_skipped_past_the_extras_budget_and_failures_are_rec
         raise RuntimeError("no")
     r = bench._extra_block(boom, budget_s=1100.0)
     assert "RuntimeError" in r["error"] and "traceback" in r
+
+
+def test_simulated_cfg_sp_rank_runs_one_stream_and_leaves_the_models_as_they_came(monkeypatch):
+    """simulate_world(layout='cfg-sp'), world 2 (no sequence parallelism inside a half, so no device stream is needed): the simulated
+    rank sends ONE stream through the model, the swap is a copy, the row says so; an odd world is skipped; the stand-in and the
+    models' `sp` are gone afterwards."""
+    bench = _bench()
+    import torch
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    calls = []
+
+    class M:
+        sp = None
+
+        def __call__(self, x, context, **kw):
+            calls.append((len(x), kw.get("x_id")))
+            return [torch.zeros(2) for _ in x]
+    m = M()
+    par = {"cfgp": None}
+
+    def one_step(i, lat):
+        c, u = par["cfgp"].guided_pair(m, lat, "ctx", "null")
+        assert c is not u and torch.equal(c, u)
+        return lat
+    r = bench.simulate_world([2, 3], m, None, one_step, torch.zeros(2), 0, 8.0, {"num_layers": 40}, 75600, par, "cfg-sp")
+    rows = r["ranks"]
+    assert rows[0]["layout"] == "cfg2 x sp1" and rows[0]["streams_per_rank"] == 1 and rows[0]["tokens_per_rank"] == 75600
+    assert rows[0]["gathered_bytes_per_block_and_rank"] == 0.0 and "skipped" in rows[1]
+    assert calls == [(1, 0)] * 3 and par["cfgp"] is None and m.sp is None

@@ -114,6 +114,9 @@ class WanAny2VHIP:
         # `CLIPModel` (models/wan/modules/clip.py, any2video.py:127-132), handed over by the plugin's load_model: one 257-token ViT-H
         # forward per video, outside the denoise path.  None: generate() must be given clip_fea.
         self.clip, self.flf = None, False
+        # multi-GPU: None, or an sp.CfgParallel -- the two CFG streams on the two halves of the world (its `attach()` has put the
+        # half's sequence-parallel group on the experts); `model.sp` alone = sequence parallelism over the whole world
+        self.cfg_parallel = None
         import collections
         self._text_cache, self._text_cache_bytes = collections.OrderedDict(), 0
 
@@ -471,6 +474,13 @@ class WanAny2VHIP:
                 c.previous_modulated_input = None
                 m.cache = c
             return None
+        # multi-GPU: `self.cfg_parallel` (sp.CfgParallel) puts the conditional and the unconditional stream of every guided step on the
+        # two halves of the world.  A step-skipping cache decides for the unconditional stream from what it saw of the conditional
+        # one in the same process (skipcache.decide, x_id 0 then 1): with the streams in different processes that state is missing.
+        cfg_parallel = getattr(self, "cfg_parallel", None)
+        if cfg_parallel is not None and any(getattr(m, "cache", None) is not None for m in (self.model, self.model2) if m is not None):
+            raise NotImplementedError("WanAny2VHIP.generate: a step-skipping cache (TeaCache / MagCache) together with CFG parallelism -- "
+                                      "use sequence parallelism over the whole world (model.sp) with a cache")
         # step-skipping caches (any2video.py:1398-1408): reset, then pick the threshold that meets cache.multiplier
         # The reference configures only self.model.cache (any2video.py:1396-1406; wgp.py hands the SAME object to both
         # experts): one reset, threshold from model's time embedding.  A distinct cache object on model2 gets its own setup.
@@ -532,7 +542,13 @@ class WanAny2VHIP:
                     if guide_scale == 1 or not any_guidance:
                         ret = trans(x=[lat], context=[context], **kwargs)
                         return None if (self._interrupt or ret[0] is None) else ret[0]
-                    if joint_pass:
+                    if cfg_parallel is not None:
+                        # the two streams on the two halves of the world, swapped once per step (sp.CfgParallel): every rank ends up
+                        # with the (cond, uncond) pair the joint pass returns
+                        ret = cfg_parallel.guided_pair(trans, lat, context, context_null, **kwargs)
+                        if self._interrupt or ret is None:
+                            return None
+                    elif joint_pass:
                         ret = trans(x=[lat, lat], context=[context, context_null], **kwargs)              # :1626-1634
                         if self._interrupt or ret[0] is None:
                             return None
