@@ -11,7 +11,9 @@ region.  Default workload = BASELINE.json configs[2]: Wan2.2 t2v 14B (both exper
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 14B-720p|1.3B-480p|i2v-14B-720p|tiny] [--fp8]
 
 N > 1: one rank per GPU over RCCL; the token axis is sharded across ranks (temporal sequence parallelism,
-SURVEY.md section 8e) -- total work fixed -> "strong".  Launched by `torch.distributed.run` (the driver's way) the ranks
+SURVEY.md section 8e) -- total work fixed -> "strong".  An even N first splits the two CFG streams over the two halves of the
+world (no per-block exchange between the halves, one swap of the predictions per step) and shards tokens inside a half
+(--parallelism cfg-sp, the default there; --parallelism sp = tokens over all N ranks, both streams on every rank).  Launched by `torch.distributed.run` (the driver's way) the ranks
 are already there; launched as plain `python bench.py --gpus N` this process re-executes itself under
 torch.distributed.run with N ranks on 127.0.0.1.  Prints ONE JSON line on rank 0.
 
