@@ -3,6 +3,7 @@ group staging the exchanges through the host (the test boxes have one GPU; on a 
 world 2 = the conditional and the unconditional stream in two processes, no sequence parallelism; world 4 = two halves of two
 sequence-parallel ranks each -- the single-stream forward with the half's K / V^T gathers.  Every rank must end up with the
 (cond, uncond) pair of the single-rank joint pass.  (Named to run after the other -m gpu files.)"""
+import datetime
 import os
 import socket
 
@@ -24,7 +25,9 @@ def _worker(rank, world, port, q):
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # a bounded collective timeout: a rank that fails before a swap must not leave its partner (and the test run) waiting for the
+    # backend's 30-minute default
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     try:
         from oracle import wan_oracle as O
         from wan2gp_amd.model import WanModelHIP
@@ -62,11 +65,16 @@ def test_cfg_parallel_pair_matches_the_joint_pass(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=900) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    try:
+        res = [q.get(timeout=900) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:                        # a worker stuck in a collective must not outlive the test (nor block interpreter exit)
+            if p.is_alive():
+                p.kill()
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
