@@ -1,5 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- CPU statement of the adapter algebra of the checkpoint / LoRA row (SURVEY.md section 8(f)
-rank 2).  PARITY UNPINNED for this file: the arithmetic lives in mmgp 3.7.12 (`requirements.txt:2`,
+rank 2).  PARITY UNPINNED for the `alpha / rank` factor and the multiplier m_i (the alpha-less core -- W + B A, + diff, + diff_b at
+m = 1 -- IS pinned: tests/test_lora_extract_vs_golden.py merges the file the reference's own shared/extract_lora.py wrote for an
+(original, finetuned) pair and must get the finetuned checkpoint back): the arithmetic lives in mmgp 3.7.12 (`requirements.txt:2`,
 `offload.load_loras_into_model` / `activate_loras` and its patched `Linear.forward`), a third-party dependency that is not
 part of /root/reference, so there is no reference code to execute.  Restated from its published behaviour and from the
 reference's call sites (wgp.py:6893-6935; shared/utils/loras_mutipliers.py:143-148; key layout produced by

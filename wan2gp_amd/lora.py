@@ -14,7 +14,9 @@ kept to re-merge from scratch, so no rounding drift accumulates).  The two Wan 2
 covers the Lightning "1;0 0;1" profiles (`profiles/wan_2_2/*.json`) without any re-merge.
 
 mmgp 3.7.12 (requirements.txt:2) is not part of /root/reference: the adapter algebra above is its published behaviour
-restated; parity for the merge arithmetic is therefore against the oracle only ("parity unpinned"),
+restated; parity for the `alpha / rank` factor and the multiplier is therefore against the oracle only ("parity unpinned", DESIGN.md
+section 4) -- the alpha-less core (W + B A, + diff, + diff_b) is pinned to the reference's own adapter-file producer, shared/extract_lora.py:13-30,
+by an extract -> merge round trip (tests/golden/lora_extract.npz) --
 while every key / multiplier function below is pinned to the reference's own code through tests/golden/loader_golden.json.
 """
 from typing import Dict, List, Optional
