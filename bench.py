@@ -250,16 +250,9 @@ def main():
     log(f"workload {args.workload}: building random-init weights")
     model = random_weights(WanModelHIP(**mcfg), cfg, 1234, args.fp8)
     model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321, args.fp8) if two_experts else None
-    cfgp = None
-    if cfg_sp:
-        from wan2gp_amd.sp import CfgParallel
-        cfgp = CfgParallel(rank, world).attach(model, model2)          # this rank's stream; the half's sequence-parallel group on the experts
-    elif world > 1:
-        from wan2gp_amd.sp import SequenceParallel
-        sp = SequenceParallel(rank, world)
-        model.sp = sp
-        if model2 is not None:
-            model2.sp = sp
+    cfgp, layout_note = None, None
+    if world > 1:
+        cfgp, cfg_sp, sp_degree, layout_note = setup_parallel(rank, world, cfg_sp, L, (model, model2), args.parallelism == "cfg-sp")
 
     vae = None
     want_e2e = not args.no_e2e and rank == 0 and args.workload != "tiny"
@@ -411,6 +404,7 @@ def main():
             "dtype": "fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
                        "solver": "unipc", "parallelism": ("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) if world > 1 else "single",
+                       **({"parallelism_note": layout_note} if layout_note else {}),
                        "forward_TFLOP": forward_flops(cfg, L) / 1e12},
             "roofline": {"kernel": "attn_w16n_kernel (self-attention: the bounded loop on the 16x16x32 MFMA)", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
@@ -466,6 +460,46 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device="cuda"):
+    """The multi-GPU layout of this run on the resident experts -> (CfgParallel | None, cfg_sp, sp_degree, note).
+
+    cfg-sp (the default for an even world) is tried first: groups, then a self-test of the 2-rank swap on a tiny tensor.  A rank
+    whose setup or self-test raises says so in an all-reduce; if ANY rank failed, EVERY rank takes plain sequence parallelism over the
+    whole world instead (when the token count shards that way) and the JSON line carries the reason -- a scaling run is worth more
+    than the preferred layout.  With `--parallelism cfg-sp` given explicitly the failure is fatal instead.  (What this cannot help: ONE
+    rank failing inside a collective while its partner waits in it -- that ends at the backend's collective timeout.)"""
+    import torch
+    import torch.distributed as dist
+    from wan2gp_amd.sp import CfgParallel, SequenceParallel
+    note = None
+    if cfg_sp:
+        cfgp, err = None, ""
+        try:
+            cfgp = CfgParallel(rank, world)
+            mine = torch.full((8,), float(cfgp.stream), device=device)
+            a, b = cfgp.exchange(mine)
+            if not (bool((a == 0).all()) and bool((b == 1).all())):
+                raise RuntimeError("the 2-rank swap returned (%r, %r), not (conditional, unconditional)" % (a.tolist(), b.tolist()))
+        except Exception as ex:                                 # noqa: BLE001 -- any failure means: not this layout
+            err = repr(ex)
+        bad = torch.tensor([1.0 if err else 0.0], device=device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad.item()) == 0.0:
+            cfgp.attach(*models)                                # this rank's stream; the half's sequence-parallel group on the experts
+            return cfgp, True, world // 2, None
+        note = "cfg-sp setup failed on %s: %s -- fell back to sequence parallelism over all %d ranks" % (
+            "this rank" if err else "another rank", err or "(see that rank's log)", world)
+        log(note)
+        if cfg_sp_demanded or L % world:
+            sys.exit("bench.py: " + note + (" refused: --parallelism cfg-sp was asked for" if cfg_sp_demanded else
+                                            " impossible: %d tokens do not shard over %d ranks" % (L, world)))
+    sp = SequenceParallel(rank, world)
+    for m in models:
+        if m is not None:
+            m.sp = sp
+    return None, False, world, note
 
 
 def _extra_block(fn, *a, budget_s=None):

@@ -133,3 +133,86 @@ def test_cfg_parallel_needs_an_even_world():
         CfgParallel(0, 3)
     with pytest.raises(ValueError):
         CfgParallel(0, 1)
+
+
+def _layout_worker(rank, world, port, q):
+    """bench.setup_parallel on a gloo world: the healthy cfg-sp layout, then the agreed fall-back when ONE rank's setup fails."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib.util
+        import types
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        from wan2gp_amd import sp as SP
+        half = world // 2
+        m, m2 = types.SimpleNamespace(sp="unset"), types.SimpleNamespace(sp="unset")
+        cfgp, cfg_sp, degree, note = bench.setup_parallel(rank, world, True, 75600, (m, m2, None), device="cpu")
+        assert cfg_sp and degree == half and note is None and cfgp.stream == rank // half
+        assert m.sp is cfgp.sp and m2.sp is cfgp.sp and (cfgp.sp is None) == (half == 1)
+        # the swap raises (the same code on every rank, so on every rank -- a failure of ONE rank inside a collective leaves its
+        # partner waiting for the backend's timeout, which no in-process fall-back can help): every rank leaves the cfg-sp layout, and
+        # a rank that did NOT fail itself follows the others (the self-test of ranks below the last one succeeds in the second pass)
+        real = SP.CfgParallel.exchange
+
+        def broken(self, mine):
+            raise RuntimeError("injected failure of the swap")
+        SP.CfgParallel.exchange = broken
+        m, m2 = types.SimpleNamespace(sp="unset"), types.SimpleNamespace(sp="unset")
+        cfgp, cfg_sp, degree, note = bench.setup_parallel(rank, world, True, 75600, (m, m2, None), device="cpu")
+        assert cfgp is None and not cfg_sp and degree == world
+        assert isinstance(m.sp, SP.SequenceParallel) and m.sp is m2.sp and (m.sp.rank, m.sp.world, m.sp.group) == (rank, world, None)
+        assert "fell back" in note and "injected failure" in note
+        got = m.sp.all_gather(torch.tensor([[float(rank)]]))           # the fall-back layout's group works: the whole world
+        assert got.flatten().tolist() == [float(r) for r in range(world)]
+        # a rank whose own self-test passed still follows a rank that reports a failure (here: a wrong result seen by the last rank only,
+        # after the swap completed everywhere)
+        def wrong_on_last(self, mine):
+            a, b = real(self, mine)
+            return (a + 1, b) if self.rank == world - 1 else (a, b)
+        SP.CfgParallel.exchange = wrong_on_last
+        m = types.SimpleNamespace(sp="unset")
+        cfgp, cfg_sp, degree, note = bench.setup_parallel(rank, world, True, 75600, (m,), device="cpu")
+        assert cfgp is None and not cfg_sp and degree == world and m.sp.world == world
+        assert ("another rank" in note) == (rank != world - 1)
+        SP.CfgParallel.exchange = broken
+        # asked for explicitly, or a token count the whole world does not shard: fatal on every rank, not a silent change of layout
+        for demanded, L in ((True, 75600), (False, 75600 + half)):
+            try:
+                bench.setup_parallel(rank, world, True, L, (m,), demanded, device="cpu")
+                raise AssertionError("must exit")
+            except SystemExit as ex:
+                assert "cfg-sp" in str(ex.code)
+        # plain sequence parallelism when cfg-sp was not selected (odd worlds, --parallelism sp)
+        SP.CfgParallel.exchange = real
+        m = types.SimpleNamespace(sp=None)
+        assert bench.setup_parallel(rank, world, False, 75600, (m,), device="cpu")[:3] == (None, False, world) and m.sp.world == world
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_layout_falls_back_to_sequence_parallelism_on_every_rank_together(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_layout_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=240) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
