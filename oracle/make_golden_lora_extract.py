@@ -14,7 +14,7 @@ under the key names `diffusion_model.<module>.lora_down.weight` / `.lora_up.weig
 that class, unmodified, on a synthetic (original, finetuned) pair over Wan module names whose weight differences have exact rank 8,
 and records the pair and the extractor's file.  The tests then require that merging the file at multiplier 1 gives the finetuned
 checkpoint back (tests/test_lora_extract_vs_golden.py on the CPU for oracle/loader_oracle.py and the host-side key handling,
-tests/test_gpu_loader.py for the HIP merge): the round trip extract -> merge = identity pins the alpha-less case of the algebra to
+tests/test_gpu_zzz_lora_extract.py for the HIP merge): the round trip extract -> merge = identity pins the alpha-less case of the algebra to
 reference-held code.  Not pinned by it: the `alpha / rank` factor of files that carry `.alpha` and the multiplier (mmgp only).
 """
 import importlib.util

@@ -4,7 +4,8 @@
     float64 value W + sum m_i (alpha_i/r_i) B_i A_i (+ diffs) -- half a bf16 ulp plus 2^-20 of the summed terms' magnitude for the fp32 accumulation
     (oracle/loader_oracle.py; "parity unpinned" for alpha / rank and the multiplier: mmgp is not in the reference tree).
   * the alpha-less core pinned to reference-held code: the file the reference's shared/extract_lora.py wrote for an (original,
-    finetuned) pair (tests/golden/lora_extract.npz), merged at multiplier 1, gives the finetuned checkpoint back.
+    finetuned) pair (tests/golden/lora_extract.npz), merged at multiplier 1, gives the finetuned checkpoint back
+    (tests/test_gpu_zzz_lora_extract.py: written after round 3's GPU budget was spent, it runs behind the suites that have).
   * merged model == run-time adapter form y = xW^T + m s (xA^T)B^T within bf16 GEMM tolerance.
   * wan_dequant_i8 bit-exact; safetensors file -> WanModelHIP bit-identical forward to a direct load_state_dict.
 """
@@ -105,50 +106,6 @@ def test_merged_loras_roundings_remerge_unload():
     ml.set_multipliers([0.0, 0.0])
     assert all(torch.equal(model._weights[k].cpu(), W[k]) for k in W)
     ml.set_multipliers([1.0]); check([1.0, 0.0])                        # short list: missing multipliers are 0
-    ml.unload()
-    assert all(torch.equal(model._weights[k].cpu(), W[k]) for k in W)
-
-
-def test_merge_of_the_references_extracted_file_gives_the_finetuned_checkpoint_back():
-    """The adapter algebra pinned to reference-held code: tests/golden/lora_extract.npz is an (original, finetuned) pair and the
-    file the reference's own `shared/extract_lora.py` wrote for it (oracle/make_golden_lora_extract.py; its meaning --
-    finetuned = original + lora_up @ lora_down, + diff_b, no alpha -- is stated there, :13-30, :254-256).  Merged at multiplier 1
-    into the bf16 original, every Linear weight / bias must be a correct bf16 rounding of bf16(original) + (finetuned - original);
-    unloading gives the original back.  (The CPU half -- oracle and key handling on the same file -- is
-    tests/test_lora_extract_vs_golden.py.)"""
-    import os
-    from wan2gp_amd.lora import MergedLoras
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "lora_extract.npz"))
-    orig = {k[5:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("orig/")}
-    fine = {k[5:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("fine/")}
-    file = {str(k): torch.from_numpy(gold["file/" + str(k)]) for k in gold["file_keys"]}
-    # the Linear layers (the 1-D RMSNorm gain's `.diff` stays with the CPU test: the resident model keeps those gains in fp32)
-    lin = sorted(k[:-7] for k, v in orig.items() if k.endswith(".weight") and v.dim() == 2)
-    W = {}
-    for m in lin:
-        W[m + ".weight"] = orig[m + ".weight"].to(BF)
-        if m + ".bias" in orig:
-            W[m + ".bias"] = orig[m + ".bias"].to(BF)
-    model = _fake_model(W)
-    ml = MergedLoras(model)
-    ml.add({k: v for k, v in file.items() if not k.endswith("norm_q.diff")})          # through normalize_lora_keys, as wgp.py's loader does
-    assert ml.errors == []
-    ml.set_multipliers([1.0])
-    moved = 0
-    for m in lin:
-        w0 = W[m + ".weight"]
-        dw = fine[m + ".weight"].double() - orig[m + ".weight"].double()
-        exact = w0.double() + dw
-        mag = float(w0.abs().max()) + float(dw.abs().max())
-        # 2e-6 of the terms: the reference extractor's fp32 SVD does not reproduce the difference better than that
-        assert LO.bf16_round_ok(model._weights[m + ".weight"].cpu(), exact, mag, slack=4e-6).all(), m
-        moved += int(not torch.equal(model._weights[m + ".weight"].cpu(), w0))
-        if m + ".bias" in W:
-            b0 = W[m + ".bias"]
-            exb = b0.double() + (fine[m + ".bias"].double() - orig[m + ".bias"].double())
-            assert LO.bf16_round_ok(model._weights[m + ".bias"].cpu(), exb, float(b0.abs().max()) + 0.1).all(), m
-    assert moved == 5                                                   # every fine-tuned Linear moved, the untouched one did not
-    assert torch.equal(model._weights["blocks.1.self_attn.v.weight"].cpu(), W["blocks.1.self_attn.v.weight"])
     ml.unload()
     assert all(torch.equal(model._weights[k].cpu(), W[k]) for k in W)
 

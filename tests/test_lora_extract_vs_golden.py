@@ -8,7 +8,7 @@ biases, + diff on weights that are not 2-D -- so merging its file at multiplier 
   * oracle/loader_oracle.py (the float64 restatement every GPU merge test is checked against) does,
   * the product's host-side handling of the file (key normalisation, grouping, scale) reads it without loss,
   * with the reference tree present, re-running the extractor reproduces the fixture.
-The HIP merge itself is held to the same round trip in tests/test_gpu_loader.py.  NOT covered by this pin: `alpha / rank` for
+The HIP merge itself is held to the same round trip in tests/test_gpu_zzz_lora_extract.py.  NOT covered by this pin: `alpha / rank` for
 files that carry `.alpha`, and per-step multipliers other than 1 (applied by mmgp, which the reference tree does not hold)."""
 import os
 
