@@ -238,9 +238,11 @@ def test_nag_branch_pointer_arithmetic(mock):
     assert rc == 1 and b"context_batches" in mock.wan_last_error()
 
 
-def test_sequence_parallel_call_order(mock):
+@pytest.mark.parametrize("S", [2, 1])
+def test_sequence_parallel_call_order(mock, S):
     """K projection -> K gather begins -> V^T -> its gather -> Q -> attention on the own segment -> both waits -> the other
-    segments, per layer; shards see their token range."""
+    segments, per layer; shards see their token range.  S = 2: both CFG streams on every rank (pure sequence
+    parallelism); S = 1: the single-stream forward of a CFG-parallel half (sp.CfgParallel) -- the gathers carry ONE stream."""
     m = Model(mock)
     c, (F, H, W) = m.cfg, (2, 8, 8)
     L_ = F * 16
@@ -255,19 +257,19 @@ def test_sequence_parallel_call_order(mock):
         return 0
     cb, cw = GATHER_FN(begin), GATHER_WAIT_FN(wait)
     sp = SpInfo(1, 2, L_ // 2, L_ // 2, cb, cw, None)
-    rc, calls, nbytes = m.forward(S=2, sp=sp)
+    rc, calls, nbytes = m.forward(S=S, sp=sp)
     assert rc == 0, mock.wan_last_error()
     Ll, d = L_ // 2, c.dim
     assert len(events) == 4 * c.num_layers
     for layer in range(c.num_layers):
         b0, b1, w0, w1 = events[4 * layer:4 * layer + 4]
         assert (b0[0], b0[1], b1[0], b1[1], w0[:2], w1[:2]) == ("begin", 0, "begin", 1, ("wait", 0), ("wait", 1))
-        assert b0[4] == 2 * Ll * d * 2 and b1[4] == 2 * d * ((Ll + 63) // 64 * 64) * 2        # K rows / V^T images of both streams
+        assert b0[4] == S * Ll * d * 2 and b1[4] == S * d * ((Ll + 63) // 64 * 64) * 2        # K rows / V^T images of the rank's S streams
         between = [cl[0] for cl in calls[b0[5]:b1[5]]]
-        assert between == ["gemm", "gemm"]                                # the two V^T projections run under the K gather
+        assert between == ["gemm"] * S                                    # the V^T projections (one per stream) run under the K gather
         local = [cl[0] for cl in calls[b1[5]:w0[2]]]
         assert local == ["gemm", "rmsnorm_rope", "attention_sp_local"]   # Q projection, norm + RoPE, own segment -- gathers in flight
-        assert calls[w1[2]][0] == "attention_sp_remote" and calls[w1[2]][2][5:9] == [2, 2 * Ll * d, 2 * d * ((Ll + 63) // 64 * 64), 1]
+        assert calls[w1[2]][0] == "attention_sp_remote" and calls[w1[2]][2][5:9] == [2, S * Ll * d, S * d * ((Ll + 63) // 64 * 64), 1]
     pe = [cl for cl in calls if cl[0] == "patch_embed"]
     assert all(cl[2][7:9] == [Ll, Ll] for cl in pe)                      # rank 1 of 2 embeds tokens [Ll, 2 Ll)
     rr = [cl for cl in calls if cl[0] == "rmsnorm_rope" and cl[1][4] != 0]
