@@ -151,7 +151,10 @@ def cpu_baseline(flops_step_main):
             "os_cpu_count": os.cpu_count(), "torch": torch.__version__,
             "kind": "port",
             "kind_note": "CPU restatement of the reference (oracle/), bit-exact to the reference's own modules on tests/golden/cfg1_*.npz "
-                         "and vae_small.npz; the reference tree does not exist on the GPU box",
+                         "and vae_small.npz; the reference tree does not exist on the GPU box.  Calibration on a machine that has both (8-core build "
+                         "container, profiles/r03_cpu_reference_e2e_configs0.json vs r03_cpu_port_same_machine_configs0.json; NOT measured in this "
+                         "run): the reference's own WanModel / UniPC / WanVAE_ take 8.90 s per CFG step (median of steps 2..10), 51.3 s for the "
+                         "decode and 140.3 s for the 10-step video end to end; this port 9.15 s, 53.7 s and 145.1 s composed -- within 3-5 %",
             "sample": f"BASELINE configs[0]: Wan2.1 t2v 1.3B 320x512x17f (L={L}): one full CFG step (2 forwards x 30 layers + "
                       f"combine + UniPC) in the reference's bf16 plan: {dt:.2f} s measured ({fl / dt / 1e12:.3f} TFLOP/s); one VAE "
                       f"decode (fp32) to uint8 [3,17,320,512]: {dt_vae:.2f} s measured; synthetic checkpoint built in {t_w:.0f} s (untimed)",
