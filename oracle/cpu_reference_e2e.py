@@ -1,10 +1,11 @@
 #!/usr/bin/env python
-"""BASELINE.md section 3 as written: BASELINE configs[0] (Wan2.1 t2v 1.3B, 320x512x17f, 10 steps, unipc, shift 5, guidance 5)
+"""TEST / BASELINE INFRASTRUCTURE ONLY (lives under oracle/ like the golden generators: nothing in the product imports it).
+BASELINE.md section 3 as written: BASELINE configs[0] (Wan2.1 t2v 1.3B, 320x512x17f, 10 steps, unipc, shift 5, guidance 5)
 END TO END on host cores through the REFERENCE'S OWN modules -- `WanModel`, `FlowUniPCMultistepScheduler`, `WanVAE_` executed from
 /root/reference through oracle/ref_shim.py -- noise -> 10 CFG steps (20 forwards) -> VAE decode -> uint8 [3,17,320,512], every
 step timed, nothing composed or extrapolated.
 
-    python tools/cpu_reference_e2e.py [out.json]        (build container only: needs /root/reference; ~10 minutes on 8 cores)
+    python oracle/cpu_reference_e2e.py [out.json]        (build container only: needs /root/reference; ~10 minutes on 8 cores)
 
 `bench.py`'s `cpu_baseline` leg cannot do this -- the reference tree does not travel to the GPU box and the leg is bounded to one step
 + one decode of the bit-exact port -- so this measurement lives under profiles/ as its own file, from the machine it ran on (named in
