@@ -8,7 +8,7 @@ synthetic random latents / context / random-init weights of the named architectu
 region.  Default workload = BASELINE.json configs[2]: Wan2.2 t2v 14B (both experts resident),
 720p x 81 frames (latent 16x21x90x160, L = 75,600 tokens), bf16.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 14B-720p|1.3B-480p|i2v-14B-720p|tiny] [--fp8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 14B-720p|14B-720p-161f|1.3B-480p|i2v-14B-720p|tiny] [--fp8]
 
 N > 1: one rank per GPU over RCCL; the token axis is sharded across ranks (temporal sequence parallelism,
 SURVEY.md section 8e) -- total work fixed -> "strong".  An even N first splits the two CFG streams over the two halves of the
@@ -42,6 +42,9 @@ WORKLOADS = {
     # name: (config, latent f,h,w, description)
     "14B-720p": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), (21, 90, 160),
                  "Wan2.2 t2v 14B 720x1280x81f (L=75600), CFG joint pass, UniPC, both experts resident"),
+    # BASELINE configs[3]: 161 frames -> (161 - 1) // 4 + 1 = 41 latent frames (any2video.py:647,1166), L = 41 x 45 x 80 = 147,600
+    "14B-720p-161f": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40), (41, 90, 160),
+                      "Wan2.2 t2v 14B 720x1280x161f (L=147600), CFG joint pass, UniPC, both experts resident"),
     "i2v-14B-720p": (dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, in_dim=36, model_type="i2v2_2"), (21, 90, 160),
                      "Wan2.2 i2v 14B 720x1280x81f (L=75600, in_dim 36), CFG joint pass, UniPC, both experts resident, "
                      "VAE encode of the conditioning video + decode in the e2e figure"),
@@ -49,6 +52,7 @@ WORKLOADS = {
                   "Wan2.1 t2v 1.3B 480x832x81f (L=32760), CFG joint pass, UniPC"),
     "tiny": (dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2), (3, 16, 16), "plumbing check"),
 }
+TWO_EXPERT_WORKLOADS = ("14B-720p", "14B-720p-161f", "i2v-14B-720p")
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 VIDEO_STEPS = 30            # UI default sampling steps (defaults/t2v_2_2.json)
 T_PROCESS0 = time.perf_counter()
@@ -109,7 +113,7 @@ def _cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(flops_step_main):
+def cpu_baseline(flops_step_main, sweep=(8, 16, 32, 64, 128)):
     """BASELINE.md section 3 on the host cores of this box, through the oracle: kind "port" = the CPU restatement of the
     reference (oracle/wan_oracle.py, oracle/vae_oracle.py), bit-exact to the reference's own modules on tests/golden/cfg1_*.npz
     and vae_small.npz.  The reference tree itself does not travel to the GPU box (/root/reference exists only in the build
@@ -118,11 +122,15 @@ def cpu_baseline(flops_step_main):
     guidance 5 -> 20 forwards + 10 scheduler steps + 1 VAE decode to uint8 [3,17,320,512].  BOUNDED sample of it (the bench must
     finish in minutes): ONE real CFG step (joint cond + uncond forward of all 30 layers, CFG combine, UniPC step) and the ONE
     VAE decode are timed; the 10-step end-to-end figure is composed as 10 x step + decode and labelled as composed.  The
-    14B-720p figure next to it is a FLOP-ratio extrapolation and labelled as such.  Baseline only."""
+    14B-720p figure next to it is a FLOP-ratio extrapolation and labelled as such.  Baseline only.
+    Thread count: L = 3,200 problems do not feed 128 cores (round 3's line ran 3.9x slower on 128 threads of the GPU box than on 8
+    cores of the build container), so both legs are first timed on a short sample -- the first 3 layers of the joint forward at the
+    full L; the first latent frame of the decode -- at every count of `sweep` the machine has, and the full sample runs at the best
+    one; the sweep is reported.  Runs alone: nothing is on the GPU while it runs."""
+    import dataclasses
     import torch
     from oracle import vae_oracle as VO
     from oracle import wan_oracle as O
-    # torch's default intra-op pool = the physical cores (os.cpu_count() would add the SMT siblings: slower, not faster)
     cfg = O.make_config("t2v_1.3B")
     f, h, w = 5, 40, 64
     t0 = time.perf_counter()
@@ -132,23 +140,46 @@ def cpu_baseline(flops_step_main):
     sch = O.UniPCOracle()
     ts = sch.set_timesteps(10, 5.0)
     freqs = O.rope_tables((f, h // 2, w // 2))
+    default_threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or default_threads
+    counts = sorted({n for n in sweep if n <= ncpu} | {default_threads})
+    cfg3 = dataclasses.replace(cfg, num_layers=min(3, cfg.num_layers))
+    WV = VO.synth_vae_weights()
+    z1 = torch.randn(1, 16, 1, h // 2, w, generator=torch.Generator().manual_seed(3))       # half the rows: the sweep stays a few seconds per count
+    sweep_dit, sweep_vae = {}, {}
     with torch.no_grad():
-        O.dit_forward([lat[:, :, :1, :8, :8]], torch.stack([ts[0]]), [ctx], W, cfg)                 # warm-up: thread pool, kernels
+        for n in counts:
+            torch.set_num_threads(n)
+            O.dit_forward([lat[:, :, :1, :8, :8]], torch.stack([ts[0]]), [ctx], W, cfg3)             # warm-up: thread pool, kernels
+            t0 = time.perf_counter()
+            O.dit_forward([lat, lat], torch.stack([ts[0]]), [ctx, ctx_null], W, cfg3, freqs=freqs)
+            sweep_dit[n] = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            VO.vae_decode(z1, WV, VO.default_scale())
+            sweep_vae[n] = time.perf_counter() - t0
+        n_dit = min(sweep_dit, key=sweep_dit.get)
+        n_vae = min(sweep_vae, key=sweep_vae.get)
+        torch.set_num_threads(n_dit)
         t0 = time.perf_counter()
         cond, uncond = O.dit_forward([lat, lat], torch.stack([ts[0]]), [ctx, ctx_null], W, cfg, freqs=freqs)
         nxt = sch.step(O.cfg_combine(cond, uncond, 5.0), lat)
         dt = time.perf_counter() - t0
         del W
-        WV = VO.synth_vae_weights()
         z = (nxt[0] if isinstance(nxt, (tuple, list)) else nxt).float()
+        torch.set_num_threads(n_vae)
         t0 = time.perf_counter()
         frames = VO.float_to_uint8(VO.vae_decode(z.reshape(1, 16, f, h, w), WV, VO.default_scale())[0])
         dt_vae = time.perf_counter() - t0
+        torch.set_num_threads(default_threads)
     assert tuple(frames.shape) == (3, (f - 1) * 4 + 1, h * 8, w * 8)
     L = f * (h // 2) * (w // 2)
     fl = 2 * forward_flops(dict(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_layers=cfg.num_layers), L)
-    return {"value": 1.0 / dt, "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "cpu_model": _cpu_model_name(),
-            "os_cpu_count": os.cpu_count(), "torch": torch.__version__,
+    return {"value": 1.0 / dt, "unit": "denoise-steps/s", "cores": n_dit, "cores_vae_decode": n_vae, "cpu_model": _cpu_model_name(),
+            "os_cpu_count": os.cpu_count(), "torch_default_threads": default_threads, "torch": torch.__version__,
+            "thread_sweep": {"sample": "joint CFG forward, first 3 of 30 layers, L = %d; VAE decode of the first latent frame, upper half of the picture" % L,
+                             "dit_3_layers_s": {str(k): round(v, 3) for k, v in sweep_dit.items()},
+                             "vae_first_frame_s": {str(k): round(v, 3) for k, v in sweep_vae.items()},
+                             "note": "the full sample below ran at the best count of each leg ('cores', 'cores_vae_decode'), alone on the box"},
             "kind": "port",
             "kind_note": "CPU restatement of the reference (oracle/), bit-exact to the reference's own modules on tests/golden/cfg1_*.npz "
                          "and vae_small.npz; the reference tree does not exist on the GPU box.  Calibration on a machine that has both (8-core build "
@@ -156,8 +187,8 @@ def cpu_baseline(flops_step_main):
                          "run): the reference's own WanModel / UniPC / WanVAE_ take 8.90 s per CFG step (median of steps 2..10), 51.3 s for the "
                          "decode and 140.3 s for the 10-step video end to end; this port 9.15 s, 53.7 s and 145.1 s composed -- within 3-5 %",
             "sample": f"BASELINE configs[0]: Wan2.1 t2v 1.3B 320x512x17f (L={L}): one full CFG step (2 forwards x 30 layers + "
-                      f"combine + UniPC) in the reference's bf16 plan: {dt:.2f} s measured ({fl / dt / 1e12:.3f} TFLOP/s); one VAE "
-                      f"decode (fp32) to uint8 [3,17,320,512]: {dt_vae:.2f} s measured; synthetic checkpoint built in {t_w:.0f} s (untimed)",
+                      f"combine + UniPC) in the reference's bf16 plan on {n_dit} threads: {dt:.2f} s measured ({fl / dt / 1e12:.3f} TFLOP/s); one VAE "
+                      f"decode (fp32) to uint8 [3,17,320,512] on {n_vae} threads: {dt_vae:.2f} s measured; synthetic checkpoint built in {t_w:.0f} s (untimed)",
             "step_s": dt, "vae_decode_s": dt_vae,
             "e2e_s_per_video_composed": 10 * dt + dt_vae,
             "e2e_note": "configs[0] end to end = 10 steps + VAE decode, COMPOSED from the one timed step and the one timed decode "
@@ -190,6 +221,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the VAE decode / end-to-end block")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the BASELINE configs[3] block (14B 720p x 161 frames, L = 147,600: 3 steps + a simulated rank of 8)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (i2v 14B, scaled-fp8 weights, VAE encode + decode)")
     ap.add_argument("--parallelism", default="auto", choices=["auto", "sp", "cfg-sp"],
                     help="N > 1: 'sp' = the token axis over all N ranks, both CFG streams on every rank; 'cfg-sp' = the conditional stream on "
@@ -198,9 +230,9 @@ def main():
     ap.add_argument("--extras-budget-s", type=float, default=float(os.environ.get("WAN_BENCH_EXTRAS_BUDGET_S", 900)),
                     help="an OPTIONAL block behind the timed region (secondary workload, simulated ranks, config 5) is skipped -- and says so "
                          "in its place -- when the process is already older than this; the headline measurement, roofline and cpu_baseline never are")
-    ap.add_argument("--simulate-layout", default="sp", choices=["sp", "cfg-sp", "both"],
+    ap.add_argument("--simulate-layout", default="both", choices=["sp", "cfg-sp", "both"],
                     help="which rank the simulated-ranks block runs: 'sp' = both streams at L / N rows (--parallelism sp), 'cfg-sp' = one stream "
-                         "at L / (N/2) rows + the per-step swap as a device-to-device copy (--parallelism cfg-sp; first GPU run pending: opt-in)")
+                         "at L / (N/2) rows + the per-step swap as a device-to-device copy (--parallelism cfg-sp); 'both' = a row for each")
     ap.add_argument("--simulate-world", default="2,4,8", help="comma-separated world sizes (e.g. 2,4,8): after the timed region, run ONE "
                     "rank's shard of a sequence-parallel world of that size on this GPU, the K / V^T all-gathers replaced by "
                     "device-to-device copies of the bytes that rank would receive -> compute-side upper bound of the scaling curve; '' = skip")
@@ -248,7 +280,7 @@ def main():
     cfg, (f, h, w), desc = WORKLOADS[args.workload]
     mcfg = {k: v for k, v in cfg.items()}
     L = f * (h // 2) * (w // 2)
-    two_experts = args.workload in ("14B-720p", "i2v-14B-720p")
+    two_experts = args.workload in TWO_EXPERT_WORKLOADS
     i2v = cfg.get("in_dim", 16) == 36
     log(f"workload {args.workload}: building random-init weights")
     model = random_weights(WanModelHIP(**mcfg), cfg, 1234, args.fp8)
@@ -298,15 +330,24 @@ def main():
 
     par = {"cfgp": cfgp}           # (the simulated-ranks block swaps a stand-in in)
 
-    def one_step(i, lat):
-        t = sched.timesteps[i]
+    def new_sched(n_steps=VIDEO_STEPS):
+        """A scheduler of its own for every block behind the timed region: a block never depends on how many timesteps the
+        timed region (or the block before it) consumed -- the native scheduler refuses to step past its last timestep."""
+        sc = HipScheduler("unipc", num_train_timesteps=1000)
+        sc.set_timesteps(n_steps, device="cuda", shift=12.0)
+        return sc
+
+    def one_step(i, lat, sc=None, fr=None):
+        sc = sched if sc is None else sc
+        t = sc.timesteps[i]
         trans = model2 if (model2 is not None and int(t) <= switch_threshold) else model
+        fr = freqs if fr is None else fr
         if par["cfgp"] is not None:       # this rank's stream, then the 2-rank swap: every rank holds (cond, uncond) bit-identically
-            cond, uncond = par["cfgp"].guided_pair(trans, lat, ctx, ctx_null, t=torch.stack([t]), freqs=freqs, y=y)
+            cond, uncond = par["cfgp"].guided_pair(trans, lat, ctx, ctx_null, t=torch.stack([t]), freqs=fr, y=y)
         else:
-            cond, uncond = trans([lat, lat], t=torch.stack([t]), context=[ctx, ctx_null], freqs=freqs, y=y)
+            cond, uncond = trans([lat, lat], t=torch.stack([t]), context=[ctx, ctx_null], freqs=fr, y=y)
         noise = cfg_combine(cond, uncond, guide if trans is model else 3.0)
-        return sched.step(noise, t, lat)[0]
+        return sc.step(noise, t, lat)[0]
 
     lat = latents
     log(f"{args.warmup} warm-up + {args.steps} timed steps")
@@ -347,11 +388,7 @@ def main():
         torch.distributed.barrier()
 
     import ctypes
-    prof = {}
-    for cls, name in ((0, "self_attn"), (1, "cross_attn"), (2, "ffn_gemm_pair"), (3, "rmsnorm_rope")):
-        ms, n = ctypes.c_double(), ctypes.c_int()
-        L_.check(lib.wan_prof_collect(cls, ctypes.byref(ms), ctypes.byref(n)), "wan_prof_collect")
-        prof[name] = (ms.value, n.value)
+    prof = collect_prof(lib)
     if rank == 0:
         S = 1 if cfg_sp else 2                                  # streams one launch of this rank carries
         d, ffn = cfg["dim"], cfg["ffn_dim"]
@@ -426,28 +463,16 @@ def main():
         lib.wan_prof_enable(0)
         if e2e is not None:
             out["e2e"] = e2e
-        if world == 1 and not args.no_secondary and args.workload in ("14B-720p", "i2v-14B-720p"):
+        if world == 1 and not args.no_secondary and args.workload in TWO_EXPERT_WORKLOADS:
             log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
             out["secondary"] = _extra_block(secondary_1p3b, vae, budget_s=args.extras_budget_s)
-        if world == 1 and args.simulate_world and args.workload in ("14B-720p", "i2v-14B-720p"):
+        if world == 1 and args.simulate_world and args.workload in TWO_EXPERT_WORKLOADS:
             log("simulated sequence-parallel ranks: " + args.simulate_world)
             out["simulated_scaling"] = _extra_block(simulate_world, [int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
-                                                    latents, args.warmup, dt / args.steps, cfg, L, par, args.simulate_layout, budget_s=args.extras_budget_s)
-        cpu_thread, cpu_box = None, {}
-        if not args.no_cpu_baseline and world == 1:
-            # on the host cores WHILE the GPU runs the config-5 block -- long kernels, one launching thread; the launch-dense blocks
-            # above (the 1.3B secondary run, the simulated ranks) are done by now (128 busy host threads cost them 5-8 %): the CPU leg costs ~2 minutes
-            import threading
-            log("cpu_baseline: config-1 oracle step + VAE decode on the host cores (in the background)")
-            fl_main = 2 * forward_flops(cfg, L)
-
-            def _cpu():
-                try:
-                    cpu_box["r"] = cpu_baseline(fl_main)
-                except Exception as ex:
-                    cpu_box["r"] = {"error": repr(ex)}
-            cpu_thread = threading.Thread(target=_cpu, daemon=True)
-            cpu_thread.start()
+                                                    latents, new_sched, dt / args.steps, cfg, L, par, args.simulate_layout, budget_s=args.extras_budget_s)
+        if world == 1 and not args.no_configs3 and args.workload == "14B-720p":
+            log("configs3: 14B 720p x 161 frames (L = 147,600), 1 warm-up + 2 timed steps, simulated rank of a world of 8")
+            out["configs3"] = _extra_block(configs3_block, model, model2, one_step, new_sched, par, lib, budget_s=args.extras_budget_s)
         if world == 1 and not args.no_config5 and args.workload == "14B-720p" and not args.fp8:
             log("config5: i2v 14B, scaled-fp8 weights, VAE encode + 3 steps + decode")
             model = model2 = None                       # the bf16 experts of the main workload are done
@@ -455,14 +480,68 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["config5"] = _extra_block(config5_block, vae, budget_s=args.extras_budget_s)
-        if cpu_thread is not None:
-            cpu_thread.join()
-            out["cpu_baseline"] = cpu_box.get("r")
+        if not args.no_cpu_baseline and world == 1:
+            # LAST and alone: nothing runs on the GPU beside it (round 3 ran it next to the config-5 block: its 128 host threads cost
+            # launch-dense GPU blocks 5-8 %, and the GPU's launching thread cost the CPU leg cores)
+            log("cpu_baseline: thread sweep, then the config-1 oracle step + VAE decode on the host cores")
+            try:
+                out["cpu_baseline"] = cpu_baseline(2 * forward_flops(cfg, L))
+            except Exception as ex:                      # noqa: BLE001 -- reported in place, never costs the line
+                out["cpu_baseline"] = {"error": repr(ex)}
         log("done")
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def collect_prof(lib):
+    """{class: (total ms, launches)} of the launches bracketed with HIP events on the launch stream since wan_prof_enable(1)."""
+    import ctypes
+    from wan2gp_amd import lib as L_
+    prof = {}
+    for cls, name in ((0, "self_attn"), (1, "cross_attn"), (2, "ffn_gemm_pair"), (3, "rmsnorm_rope")):
+        ms, n = ctypes.c_double(), ctypes.c_int()
+        L_.check(lib.wan_prof_collect(cls, ctypes.byref(ms), ctypes.byref(n)), "wan_prof_collect")
+        prof[name] = (ms.value, n.value)
+    return prof
+
+
+def configs3_block(model, model2, one_step, new_sched, par, lib):
+    """BASELINE configs[3] on one GPU: Wan2.2 t2v 14B, 720 x 1280 x 161 frames -> 41 latent frames (any2video.py:647,1166),
+    L = 147,600 tokens, on the resident experts of the main workload.  1 warm-up + 2 timed CFG steps with a scheduler of their own;
+    self-attention's roofline at this L from HIP events like the headline's; then rank 0 of a world of 8 (both layouts) on this GPU
+    -- the compute side of the configuration BASELINE quotes at 8 GPUs."""
+    import torch
+    from wan2gp_amd.rope import get_rotary_pos_embed
+    cfg, (f, h, w), desc = WORKLOADS["14B-720p-161f"]
+    L = f * (h // 2) * (w // 2)
+    freqs = get_rotary_pos_embed((f, h, w), device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(44)
+    latents = torch.randn(1, 16, f, h, w, device="cuda", generator=g)
+    sc = new_sched()
+    lat = one_step(0, latents, sc, freqs)                                    # warm-up: the workspace grows to this L
+    torch.cuda.synchronize()
+    lib.wan_prof_enable(1)
+    t0 = time.perf_counter()
+    k = 2
+    for i in range(k):
+        lat = one_step(1 + i, lat, sc, freqs)
+    torch.cuda.synchronize()
+    step_s = (time.perf_counter() - t0) / k
+    assert torch.isfinite(lat).all()
+    ms, n = collect_prof(lib)["self_attn"]
+    lib.wan_prof_enable(0)
+    attn_flops = 4.0 * L * L * cfg["dim"] * 2
+    achieved = attn_flops / (ms / n * 1e-3) / 1e12 if n else 0.0
+    out = {"workload": desc, "latent": [16, f, h, w], "tokens": L, "metric": "denoise-steps/s", "value": 1.0 / step_s,
+           "ms_per_step": step_s * 1e3, "steps": k, "warmup": 1, "step_TFLOPs": 2 * forward_flops(cfg, L) / step_s / 1e12,
+           "composed_s_at_%d_steps_without_vae" % VIDEO_STEPS: VIDEO_STEPS * step_s,
+           "roofline": {"kernel": "self-attention", "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_BF16_TFLOPS, "launches": n, "avg_ms": ms / n if n else None, "flop_per_launch": attn_flops}}
+    del lat
+    out["simulated_scaling"] = simulate_world([8], model, model2, one_step, latents, new_sched, step_s, cfg, L, par, "both", fr=freqs)
+    return out
 
 
 def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device="cuda"):
@@ -579,7 +658,7 @@ def config5_block(vae):
             "composed_s_at_%d_steps" % VIDEO_STEPS: VIDEO_STEPS * step_s + enc_s + dec_s}
 
 
-def simulate_world(worlds, model, model2, one_step, latents, first_step, step_s_1gpu, cfg, L, par=None, layout="sp"):
+def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1gpu, cfg, L, par=None, layout="sp", fr=None, k=2):
     """ONE rank (rank 0) of a sequence-parallel world of N on this GPU: its token shard (L / N query rows against N gathered K / V^T
     segments, every token-local kernel at M = S L / N rows), the all-gathers replaced by device-to-device copies of what the rank
     would receive, on a side stream like the RCCL path.  What it measures is the COMPUTE side of the scaling curve (tile
@@ -651,15 +730,15 @@ def simulate_world(worlds, model, model2, one_step, latents, first_step, step_s_
             model.sp = sp
             if model2 is not None:
                 model2.sp = sp
+            sc = new_sched()                                                  # its own: never the timed region's (steps past its end)
             lat = latents
-            lat = one_step(first_step, lat)                                   # warm-up: workspace of this sharding
+            lat = one_step(0, lat, sc, fr)                                    # warm-up: workspace of this sharding
             torch.cuda.synchronize()
             if sp is not None:
                 sp.bytes = 0
             t0 = time.perf_counter()
-            k = 2
             for i in range(k):
-                lat = one_step(first_step + 1 + i, lat)
+                lat = one_step(1 + i, lat, sc, fr)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / k
             assert torch.isfinite(lat).all()

@@ -156,12 +156,101 @@ def test_simulated_cfg_sp_rank_runs_one_stream_and_leaves_the_models_as_they_cam
     m = M()
     par = {"cfgp": None}
 
-    def one_step(i, lat):
+    def one_step(i, lat, sc=None, fr=None):
         c, u = par["cfgp"].guided_pair(m, lat, "ctx", "null")
         assert c is not u and torch.equal(c, u)
         return lat
-    r = bench.simulate_world([2, 3], m, None, one_step, torch.zeros(2), 0, 8.0, {"num_layers": 40}, 75600, par, "cfg-sp")
+    r = bench.simulate_world([2, 3], m, None, one_step, torch.zeros(2), lambda: None, 8.0, {"num_layers": 40}, 75600, par, "cfg-sp")
     rows = r["ranks"]
     assert rows[0]["layout"] == "cfg2 x sp1" and rows[0]["streams_per_rank"] == 1 and rows[0]["tokens_per_rank"] == 75600
     assert rows[0]["gathered_bytes_per_block_and_rank"] == 0.0 and "skipped" in rows[1]
     assert calls == [(1, 0)] * 3 and par["cfgp"] is None and m.sp is None
+
+
+class _StrictScheduler:
+    """The native scheduler's contract that cost round 3's driver run its scaling table: `n` timesteps, and stepping past the last
+    one raises ("wan_sched_step: stepped past the last timestep")."""
+    made = 0
+
+    def __init__(self, n=30):
+        import torch
+        type(self).made += 1
+        self.timesteps = torch.arange(999, 999 - n, -1)
+        self.n, self.used = n, 0
+
+    def step(self, noise, t, lat):
+        if self.used >= self.n:
+            raise RuntimeError("wan_sched_step: stepped past the last timestep")
+        self.used += 1
+        return (lat,)
+
+
+def test_blocks_behind_the_timed_region_do_not_depend_on_the_timesteps_it_consumed(monkeypatch):
+    """The driver's own command line, `--gpus 1 --steps 20 --warmup 5`, leaves 5 of the main scheduler's 30 timesteps; round 3's
+    simulated-ranks block kept stepping THAT scheduler (6 plans x 3 steps) and died.  Every block now takes a scheduler of its own
+    from `new_sched`: the same sequence on a scheduler with the native one's refusal -- 25 steps of the timed region, then worlds
+    2 / 4 / 8 in both layouts, then the 161-frame configuration's world of 8 -- returns data in every row."""
+    bench = _bench()
+    import torch
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: object())
+    _StrictScheduler.made = 0
+    main_sched = _StrictScheduler(30)
+    par = {"cfgp": None}
+
+    class M:
+        sp = None
+    m, m2 = M(), M()
+    seen = []
+
+    def one_step(i, lat, sc=None, fr=None):
+        sc = main_sched if sc is None else sc
+        t = sc.timesteps[i]
+        seen.append((sc is main_sched, m.sp.world if m.sp is not None else 1, par["cfgp"] is not None, fr))
+        return sc.step(None, t, lat)[0]
+    lat = torch.zeros(2)
+    for i in range(25):                                   # --warmup 5 --steps 20
+        lat = one_step(i, lat)
+    r = bench.simulate_world([2, 4, 8], m, m2, one_step, lat, _StrictScheduler, 8.5, {"num_layers": 40}, 75600, par, "both")
+    rows = r["ranks"]
+    assert [(x["world"], x["layout"]) for x in rows] == [(2, "sp2"), (2, "cfg2 x sp1"), (4, "sp4"), (4, "cfg2 x sp2"), (8, "sp8"), (8, "cfg2 x sp4")]
+    assert all("rank_step_ms" in x and "error" not in x and "skipped" not in x for x in rows)
+    assert [x["tokens_per_rank"] for x in rows] == [37800, 75600, 18900, 37800, 9450, 18900]
+    assert _StrictScheduler.made == 1 + 6 and main_sched.used == 25
+    assert m.sp is None and m2.sp is None and par["cfgp"] is None
+    # the simulated steps saw their own scheduler, the shard's world and (cfg-sp) the stand-in for the 2-rank swap
+    sim = seen[25:]
+    assert len(sim) == 18 and not any(s[0] for s in sim)
+    assert [s[1] for s in sim[::3]] == [2, 1, 4, 2, 8, 4] and [s[2] for s in sim[::3]] == [False, True] * 3
+    # BASELINE configs[3] (161 frames, L = 147,600): the same block at that L with its own rope tables handed through
+    r3 = bench.simulate_world([8], m, m2, one_step, lat, _StrictScheduler, 28.0, {"num_layers": 40}, 147600, par, "both", fr="freqs161")
+    assert [x["tokens_per_rank"] for x in r3["ranks"]] == [18450, 36900] and all(s[3] == "freqs161" for s in seen[43:])
+
+
+def test_the_161_frame_workload_is_baseline_configs_3():
+    """BASELINE.json configs[3]: 720p x 161 frames -> (161 - 1) // 4 + 1 = 41 latent frames (any2video.py:647), 41 x 45 x 80 = 147,600
+    tokens, which shard over 2 / 4 / 8 sequence-parallel ranks and over the 4-rank halves of cfg2 x sp4."""
+    bench = _bench()
+    cfg, (f, h, w), desc = bench.WORKLOADS["14B-720p-161f"]
+    assert f == (161 - 1) // 4 + 1 and (h * 8, w * 8) == (720, 1280)
+    L = f * (h // 2) * (w // 2)
+    assert L == 147600 and all(L % n == 0 for n in (2, 4, 8)) and "161f" in desc
+    assert cfg == bench.WORKLOADS["14B-720p"][0] and "14B-720p-161f" in bench.TWO_EXPERT_WORKLOADS
+
+
+def test_cpu_baseline_reports_its_thread_sweep(monkeypatch):
+    """cpu_baseline(): the thread sweep is in the record, the full sample ran at the best count of each leg (tiny stand-ins for the
+    oracle's model so that the test takes seconds)."""
+    bench = _bench()
+    import torch
+    from oracle import vae_oracle as VO
+    from oracle import wan_oracle as O
+    tiny = O.make_config("tiny")
+    monkeypatch.setattr(O, "make_config", lambda name: tiny)
+    monkeypatch.setattr(VO, "vae_decode", lambda z, W, scale=None, **k: [torch.zeros(3, (z.shape[2] - 1) * 4 + 1, z.shape[3] * 8, z.shape[4] * 8)])
+    monkeypatch.setattr(VO, "synth_vae_weights", lambda: {})
+    r = bench.cpu_baseline(1.0e16, sweep=(1, 2))
+    assert r["kind"] == "port" and r["cores"] in (1, 2, r["torch_default_threads"]) and r["value"] > 0
+    assert set(r["thread_sweep"]["dit_3_layers_s"]) >= {"1", "2"} and set(r["thread_sweep"]["vae_first_frame_s"]) >= {"1", "2"}
+    assert str(r["cores"]) in r["thread_sweep"]["dit_3_layers_s"] and "threads" in r["sample"]
+    assert torch.get_num_threads() == r["torch_default_threads"]                  # restored

@@ -608,112 +608,6 @@ def test_bounded_tile_read_plan_register_lifetimes():
 
 
 # ----------------------------------------------------------------------------------------------
-# gemm256p.hip (persistent 256x256x64): X rows staged 4-way interleaved, operands swapped, register-direct epilogue,
-# continuous LDS-DMA stream across tiles
-# ----------------------------------------------------------------------------------------------
-def _mfma_c_row(r, half):
-    """v_mfma_f32_32x32x16: register r of lane (j, half) holds D[i][j] with i = 8 (r >> 2) + (r & 3) + 4 half
-    (cdna_hip_programming.md section 3; the layout attention_w64q.hip / gemm256k.hip are built on)."""
-    return 8 * (r >> 2) + (r & 3) + 4 * half
-
-
-def test_gemm256p_operand_interleave_and_register_direct_stores():
-    """End to end on one 256 x 256 tile with K = 64: DMA plan (which global row lands in which LDS row), fragment
-    addresses, MFMA semantics with Y as the A operand and X as the B operand, and the epilogue's (lane, yt, r) -> (row,
-    4 columns) map.  Every output element must be produced exactly once, with the right operands, and a store
-    instruction must write 2 rows x 256 contiguous bytes."""
-    rng = np.random.default_rng(5)
-    Yt = rng.integers(-3, 4, size=(256, 64)).astype(np.float64)      # tile-local operand panels (one stage)
-    Xt = rng.integers(-3, 4, size=(256, 64)).astype(np.float64)
-    # ---- DMA plan: LDS unit images (row, physical chunk) <- (global row, logical chunk)
-    ylds = np.zeros((256, 8, 8)); xlds = np.zeros((256, 8, 8))
-    for i in range(8):
-        for tid in range(256):
-            q = i * 256 + tid
-            row, pch = q >> 3, q & 7
-            lch = pch ^ ((row >> 1) & 7)
-            ylds[row, pch] = Yt[row, lch * 8:lch * 8 + 8]
-            slab, xt, rho = row >> 7, (row >> 5) & 3, row & 31
-            xlds[row, pch] = Xt[slab * 128 + 4 * rho + xt, lch * 8:lch * 8 + 8]
-    out = np.full((256, 256), np.nan)
-    writes = 0
-    for wave in range(4):
-        wy, wx = wave >> 1, wave & 1
-        acc = np.zeros((4, 4, 64, 16))                                # [yt][xt][lane][reg]
-        for ks in range(4):
-            yf = np.zeros((4, 64, 8)); xf = np.zeros((4, 64, 8))
-            for lane in range(64):
-                l31, half = lane & 31, lane >> 5
-                sw = (l31 >> 1) & 7
-                for r in range(4):
-                    ya = (wy * 128 + l31) * 128 + ((half ^ sw) << 4)
-                    addr = r * 4096 + (ya ^ (ks << 5))
-                    yf[r, lane] = ylds[addr // 128, (addr % 128) // 16]
-                    xa = (wx * 128 + l31) * 128 + ((half ^ sw) << 4)
-                    addr = r * 4096 + (xa ^ (ks << 5))
-                    xf[r, lane] = xlds[addr // 128, (addr % 128) // 16]
-            # MFMA: A[i][k] from lane (i, kh) of the Y fragment, B[j][k] from lane (j, kh) of the X fragment, k = 8 kh + e
-            for a in range(4):
-                for b in range(4):
-                    A = np.zeros((32, 16)); B = np.zeros((32, 16))
-                    for lane in range(64):
-                        A[lane & 31, (lane >> 5) * 8:(lane >> 5) * 8 + 8] = yf[a, lane]
-                        B[lane & 31, (lane >> 5) * 8:(lane >> 5) * 8 + 8] = xf[b, lane]
-                    D = A @ B.T
-                    for lane in range(64):
-                        for r in range(16):
-                            acc[a, b, lane, r] += D[_mfma_c_row(r, lane >> 5), lane & 31]
-        # ---- epilogue: lane (l31, half), chunk (yt, r): row wy*128 + yt*32 + 8 (r>>2) + (r&3) + 4 half, columns wx*128 + 4 l31 + (0..3)
-        for yt in range(4):
-            for r in range(16):
-                rows_of_instr = {}
-                for lane in range(64):
-                    l31, half = lane & 31, lane >> 5
-                    row = wy * 128 + yt * 32 + 8 * (r >> 2) + (r & 3) + 4 * half
-                    col = wx * 128 + 4 * l31
-                    byte = row * 512 + col * 2                      # ldo = 256 elements here
-                    rows_of_instr.setdefault(row, []).append(byte)
-                    for xt in range(4):
-                        assert np.isnan(out[row, col + xt])
-                        out[row, col + xt] = acc[yt, xt, lane, r]
-                        writes += 1
-                assert len(rows_of_instr) == 2                       # one store instruction = 2 rows ...
-                for row, bs in rows_of_instr.items():                # ... of 256 contiguous bytes each (32 lanes x 8 B)
-                    assert sorted(bs) == list(range(min(bs), min(bs) + 256, 8))
-    assert writes == 256 * 256
-    np.testing.assert_array_equal(out, Yt @ Xt.T)
-
-
-def test_gemm256p_continuous_stream_over_tiles():
-    """Event simulation of the two LDS-DMA streams and the MFMA stage counter across tile boundaries (nk not a multiple of
-    5, so a tile starts at any ring position): every stage the MFMAs consume was fetched from the right (tile, k-stage) into
-    the slot it is read from, two stages ahead, and after the last tile the streams stay on valid memory."""
-    for nk, ntiles in ((7, 3), (11, 2), (5, 4), (3, 5), (80, 2)):
-        slots = {}                                           # slot -> (kind, tile, stage) currently landing / resident
-        stream = {"Y": [0, 0], "X": [0, 0]}                  # [tile, stage] the stream points at
-
-        def issue(kind, slot):
-            t, s = stream[kind]
-            slots[slot] = (kind, min(t, ntiles - 1) if t < ntiles else ntiles - 1, s)
-            # advance: wrap to the next tile (or stay on the last tile's stage 0.. again: dead units)
-            if s + 1 == nk:
-                stream[kind] = [t + 1 if t + 1 < ntiles else t, 0]
-            else:
-                stream[kind] = [t, s + 1]
-        issue("Y", 0); issue("X", 1); issue("Y", 2); issue("X", 3)          # prologue: stages 0, 1
-        g = 0
-        for tile in range(ntiles):
-            for s in range(nk):
-                J = g % 5
-                SY, SX, DY, DX = (2 * J) % 5, (2 * J + 1) % 5, (2 * J + 4) % 5, (2 * J) % 5
-                assert slots[SY] == ("Y", tile, s) and slots[SX] == ("X", tile, s), (nk, tile, s, slots)
-                issue("Y", DY)                               # k-steps 0, 1: Y of global stage g + 2
-                # P_S ... k-step 3: X of global stage g + 2 goes into Y_S's slot (dead by now)
-                issue("X", DX)
-                g += 1
-
-
-# ----------------------------------------------------------------------------------------------
 # gemm256m.hip (256x256x64 on the 16x16x32 MFMA): gemm256k's unit images, X rows staged 8-way interleaved, Y = A operand,
 # X = B operand, register-direct 16-byte stores
 # ----------------------------------------------------------------------------------------------
@@ -996,134 +890,5 @@ def test_attention_w16n_gap_schedule():
             assert 67 + 2 * (4 * ks_ + kt) > 64 + 8 * ks_ + 2 * kt + 1             # K (kt, ks): last S_b reader q tile 1
 
 
-def test_gemm256mp_ring_hazards_across_tiles():
-    """gemm256mp.hip (experiment, not yet run on hardware): gemm256m's stage inside gemm256p's persistent walk.  Event simulation of
-    one workgroup with the stage's three phases -- A: k-step 0 (Y pieces of stage g+2 into slot (2J+4)%5, the f1 reads of this stage),
-    SYNC: s_waitcnt vmcnt(8 | 40 behind an epilogue) + barrier, C: rest of k-step 1 (X pieces of stage g+2 into slot 2J%5, the f0 reads
-    of stage g+1) -- and an epilogue of 32 stores between tiles.  Checked: (1) a DMA piece never lands in a slot whose last reads are
-    not separated from it by a barrier; (2) every fragment read sees the (operand, tile, k-stage) it multiplies, fetched by pieces the
-    counted wait in front of that barrier has retired (the memory counter retires in issue order); (3) the wait behind an epilogue is
-    exactly what keeps the X pieces of the next stage ahead of the 32 stores + 8 Y pieces."""
-    for nk, ntiles in ((7, 3), (5, 4), (3, 5), (24, 2), (2, 6)):
-        vm = []                                   # in-order queue of outstanding vector-memory ops: ("dma", slot) | ("store",)
-        content = {}                              # slot -> (kind, tile, stage) whose DMA was ISSUED last
-        landed = {}                               # slot -> content known complete AND published by a barrier
-        last_read_epoch = {s: -1 for s in range(5)}
-        epoch = 0                                 # number of barriers passed
-        stream = {"Y": [0, 0], "X": [0, 0]}
-
-        def issue(kind, slot):
-            assert last_read_epoch[slot] < epoch, (nk, kind, slot, "DMA into a slot still being read")
-            t, s = stream[kind]
-            content[slot] = (kind, t, s)
-            landed.pop(slot, None)
-            vm.append(("dma", slot))
-            stream[kind] = [t + 1 if t + 1 < ntiles else t, 0] if s + 1 == nk else [t, s + 1]
-
-        def wait_and_barrier(n):
-            nonlocal epoch
-            while len(vm) > n:                    # s_waitcnt vmcnt(n): the oldest retire first
-                op = vm.pop(0)
-                if op[0] == "dma":
-                    landed[op[1]] = content[op[1]] if not any(o == op for o in vm) else landed.get(op[1])
-            epoch += 1
-
-        def read(slot, kind, tile, stage):
-            assert landed.get(slot) == (kind, tile, stage), (nk, slot, landed.get(slot), (kind, tile, stage))
-            last_read_epoch[slot] = epoch
-        issue("Y", 0); issue("X", 1); issue("Y", 2); issue("X", 3)
-        wait_and_barrier(2)                       # vmcnt(16) in units of 8 pieces: stage 0 landed
-        read(0, "Y", 0, 0); read(1, "X", 0, 0)    # f0 of stage 0
-        g, after_epi = 0, False
-        for tile in range(ntiles):
-            for s in range(nk):
-                J = g % 5
-                SY, SX, NY, NX, DY, DX = (2 * J) % 5, (2 * J + 1) % 5, (2 * J + 2) % 5, (2 * J + 3) % 5, (2 * J + 4) % 5, (2 * J) % 5
-                issue("Y", DY)                                            # phase A
-                read(SY, "Y", tile, s); read(SX, "X", tile, s)            # f1 (k half 1) of this stage
-                wait_and_barrier(1 + (32 if after_epi else 0))            # vmcnt(8) = one Y piece group; vmcnt(40) = + 32 stores
-                after_epi = False
-                issue("X", DX)                                            # phase C
-                nt, ns = (tile, s + 1) if s + 1 < nk else (min(tile + 1, ntiles - 1), 0)
-                read(NY, "Y", nt, ns); read(NX, "X", nt, ns)              # f0 of the next stage (the next tile's first, at a boundary)
-                g += 1
-            vm.extend([("store",)] * 32)                                  # register-direct epilogue
-            after_epi = True
 
 
-def test_conv_wide_tile_data_flow():
-    """vae_conv256.inc (experiment, not yet run on hardware): the 256-pixel x 128-channel convolution tile.  Labels instead of values:
-    every 16-byte chunk the LDS-DMA plan writes is tagged (operand, row, logical k-chunk); the fragment reads of wave (wy, wx), lane (n, g),
-    k half ks must then see pixel row wy*128 + 16 a + n / weight row wx*64 + 16 b + n at k-chunk 4 ks + g -- the 16x16x32 MFMA's operand
-    layout -- the per-thread unit / channel offset must not depend on the slot, and the epilogue's (pixel, channel) of every accumulator
-    register must be the product's."""
-    WYST = 256 * 128
-    lds = {}
-    for tid in range(256):
-        wave, lane = tid >> 6, tid & 63
-        pch0 = tid & 7
-        lch0 = pch0 ^ ((tid >> 4) & 7)
-        for i in range(8):                                   # gathered pixels: slot q = i * 256 + tid
-            q = i * 256 + tid
-            row, pch = q >> 3, q & 7
-            assert pch ^ ((row >> 1) & 7) == lch0            # unit (lch >> 2) and channel offset ((lch & 3) * 8) are per-thread constants
-            addr = wave * 1024 + i * 4096 + lane * 16        # smem_lds + i * 256 * 16, 16 bytes per lane behind M0
-            assert addr == q * 16 and addr not in lds
-            lds[addr] = ("Y", row, lch0)
-        for i in range(4):                                   # weights
-            q = i * 256 + tid
-            row, pch = q >> 3, q & 7
-            assert pch ^ ((row >> 1) & 7) == lch0
-            slab, jj = row >> 6, row & 63
-            nt, ii = jj >> 4, jj & 15
-            cout = slab * 64 + (ii >> 2) * 16 + nt * 4 + (ii & 3)      # which output channel the LDS row holds
-            lds[WYST + q * 16] = ("X", row, lch0, cout)
-    assert len(lds) == 2048 + 1024
-    seen = set()
-    for wave in range(4):
-        wy, wx = wave >> 1, wave & 1
-        for lane in range(64):
-            frow, fch = lane & 15, lane >> 4
-            for ks in range(2):
-                for t in range(8):
-                    ry = wy * 128 + t * 16 + frow
-                    off = (ry * 128 + ((fch ^ ((ry >> 1) & 7)) << 4)) ^ (ks << 6)
-                    assert lds[off] == ("Y", ry, 4 * ks + fch)
-                for t in range(4):
-                    rx = wx * 64 + t * 16 + frow
-                    off = (rx * 128 + ((fch ^ ((rx >> 1) & 7)) << 4)) ^ (ks << 6)
-                    kind, row, lch, cout = lds[WYST + off]
-                    assert (kind, row, lch) == ("X", rx, 4 * ks + fch)
-            # D = A (weights: rows) x B (pixels: columns): register r of acc[a][b] in lane (n, g) = weight row 4 g + r of tile b, pixel n
-            # of tile a; the epilogue writes v[b * 4 + r] to channel x0 + wx * 64 + g * 16 + b * 4 + r of pixel wy * 128 + a * 16 + n
-            n, g = lane & 15, lane >> 4
-            for a in range(8):
-                for b in range(4):
-                    for r in range(4):
-                        lrow = wx * 64 + b * 16 + 4 * g + r
-                        cout = lds[WYST + lrow * 128][3]                       # any chunk of that LDS row
-                        assert cout == wx * 64 + g * 16 + b * 4 + r
-                        seen.add((wy * 128 + a * 16 + n, cout))
-    assert len(seen) == 256 * 128
-    # the ring: buffer of stage kt + 2 = the one stage kt - 1 was multiplied from; 12 pieces per thread and stage
-    for nk in (1, 2, 3, 7):
-        vm, buf = [], 0
-        where = {}
-
-        def stage(s, ks):
-            where[ks] = s
-            vm.extend([ks] * 12)
-        stage(0, 0)
-        if nk > 1:
-            stage(1, 1)
-        for kt in range(nk):
-            allow = 12 if kt + 1 < nk else 0
-            while len(vm) > allow:
-                vm.pop(0)
-            assert kt not in vm                                               # stage kt has landed
-            if kt + 2 < nk:
-                s = 2 if buf == 0 else buf - 1
-                assert s == (kt + 2) % 3 and s not in (where[kt], where[kt + 1])   # not the buffer being read, nor the one in flight
-                stage(s, kt + 2)
-            assert where[kt] == buf
-            buf = 0 if buf == 2 else buf + 1

@@ -248,24 +248,11 @@ int wan_gemm256k_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
                     int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                     int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
-// fifth-generation kernel (gemm256p.hip): the same tile loop, persistent (continuous LDS-DMA stream across tiles, register-direct
-// epilogue); bf16, bias per column
-template <int EPI>
-int wan_gemm256p_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
-                     int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
-                     int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
-
-// sixth-generation kernel (gemm256m.hip): gemm256k's tile on the 16x16x32 MFMA, register-direct epilogue; bf16, bias per column
+// fifth-generation kernel (gemm256m.hip): gemm256k's tile on the 16x16x32 MFMA, register-direct epilogue; bf16, bias per column
 template <int EPI, bool BIAS_ROWS>
 int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                      int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                      int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
-
-// experiment, not validated on hardware (gemm256mp.hip): gemm256m's stage in a persistent tile walk; only in libwanhip_mp.so
-template <int EPI>
-int wan_gemm256mp_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
-                      int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
-                      int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
 template <int EPI, bool BIAS_ROWS, bool F16 = false>
 static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K,
@@ -274,26 +261,10 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
                        float out_scale = 1.0f) {
   const int64_t tx = (XN + BN - 1) / BN;
   const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= 256;
-#ifdef WAN_GEMM_PERSISTENT16  // (defined only for the experiment library libwanhip_mp.so)
-  if constexpr (!BIAS_ROWS && !F16) {
-    if (many_tiles) {
-      const int rc = wan_gemm256mp_try<EPI>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale);
-      if (rc >= 0) return rc;
-    }
-  }
-#endif
 #ifndef WAN_GEMM_NO_MI16  // (defined only for the A/B library libwanhip_k.so: gemm256k on every shape)
   if constexpr (!F16 && (!BIAS_ROWS || EPI == WAN_EPI_NONE)) {
     if (many_tiles) {
       const int rc = wan_gemm256m_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale);
-      if (rc >= 0) return rc;
-    }
-  }
-#endif
-#ifdef WAN_GEMM_PERSISTENT
-  if constexpr (!BIAS_ROWS && !F16) {
-    if (many_tiles) {
-      const int rc = wan_gemm256p_try<EPI>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale);
       if (rc >= 0) return rc;
     }
   }

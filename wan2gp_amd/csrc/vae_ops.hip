@@ -281,10 +281,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
   }
 }
 
-#ifdef WAN_CONV_WIDE  // (defined only for the experiment library libwanhip_conv.so: `make convwide`)
-#include "vae_conv256.inc"
-#endif
-
 static uint16_t* g_zero_page = nullptr;
 static int ensure_zero_page(hipStream_t st) {
   if (g_zero_page) return 0;
@@ -327,12 +323,6 @@ extern "C" int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const ui
   const bool big = g_force_big || (int64_t)(Tin + 2) * Hin * Win * Cin >= ((int64_t)1 << 31);
   p.tiles_y = (int)((p.M + CBM - 1) / CBM);
   p.tiles_x = (Cout + CBN - 1) / CBN;
-#ifdef WAN_CONV_WIDE
-  if (conv_wide_launch(p, big, ups != 0, st)) {
-    WAN_LAUNCH_CHECK();
-    return 0;
-  }
-#endif
   const dim3 grid((unsigned)(p.tiles_y * p.tiles_x));
   if (big && ups) hipLaunchKernelGGL((conv3d_f16_kernel<true, true>), grid, dim3(256), 0, st, p);
   else if (big) hipLaunchKernelGGL((conv3d_f16_kernel<true, false>), grid, dim3(256), 0, st, p);
