@@ -86,7 +86,7 @@ int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* sa, const uint8_t* 
                  int64_t rpb, void*) {
   return rec("gemm_fp8", {A, W, bias, C, R, mod, e, sa}, {M, N, K, lda, ldc, epi, gate_idx, rpb, wn});
 }
-int64_t wan_attention_scratch_words(int B, int Bk, int64_t Lq, int H) { return (int64_t)Bk * H + (Lq + 255) / 256 * H * B; }
+int64_t wan_attention_scratch_words(int B, int Bk, int64_t Lq, int H) { return (int64_t)Bk * H + (Lq + 255) / 256 * H * B + (int64_t)Bk * H; }
 int64_t wan_attention_raw_words(int B, int64_t Lq, int H) { return (Lq + 255) / 256 * H * B * 4 * 2 * (64 * 64 + 64); }
 float wan_attention_qscale(void) { return 0.12752041f; }
 int wan_attention_bounded(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk, int64_t Lq, int64_t Lk,

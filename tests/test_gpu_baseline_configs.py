@@ -231,31 +231,47 @@ def test_attention_prescaled_at_bench_shape(B, L):
 
 
 def test_attention_bounded_and_tracking_loops_mixed_inside_one_launch():
-    """The hot loop is data dependent: a 256-row workgroup takes the bounded softmax only if |q~_row| * max|k_h| <= 96 for all of
-    its rows (attention_w64q.hip); real checkpoints' norm_q / norm_k weights are not ~1 in every head.  Bench shape (B = 2, H = 40,
-    L = 75,600) with per-head K gains 0.5 ... 12 so that both loops run inside ONE launch: sampled rows of low-, threshold- and
-    high-gain heads against the fp64 softmax, the flag count against the heads that must decline, and the launch rate with
-    nothing / about half / everything declined (profiles/: what a checkpoint with hot heads costs)."""
+    """The hot loop used to be data dependent: a 256-row workgroup took the bounded softmax only if U = |q~_row| * max|k_h| <= 96 for all
+    of its rows, i.e. only while a head's RMSNorm gains stay below gamma_q gamma_k ~ 6 (round 3: gain 4 declined 71 % of its workgroups,
+    >= 5 all of them, -12 % on the tracking loop).  Since round 4 a workgroup beyond the bound runs the SAME loop with a per-row
+    reference shift m = U - 96 (attention_w16n.hip, SHIFT) and only rows that underflow against it go to the tracking loop.
+    Bench shape (B = 2, H = 40, L = 75,600):
+      * per-head K gains 0.5 ... 12 inside ONE launch (plain and shifted workgroups side by side): nothing reaches the tracking loop,
+        sampled rows of low-, threshold- and high-gain heads against the fp64 softmax;
+      * launch rate with every head at gain 1 (all plain) and at gain 12 (all shifted): the same loop, the same rate;
+      * an adversarial key in a quarter of the heads (400 e_0, every query of those heads with a component along e_0: a score ~ 300
+        where the first tile's scores suggest a reference ~ 85): P overflows, the row sums say so, those workgroups flag themselves
+        AFTER the loop and the tracking launch redoes them -- correctness never depends on the data, the fast loop on nothing a
+        normalised head produces."""
     from wan2gp_amd import lib as L_, ops
     B, H, L = 2, 40, 75600
     lib = L_.load()
     gains = [0.5, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 8.0, 10.0, 12.0]
-    q, k, vt, ldv = _rand_qkv(B, L, L, H, 1, seed=77)
+    q0, k, vt, ldv = _rand_qkv(B, L, L, H, 1, seed=77)
     k0 = k[0].clone()
     scratch = torch.zeros(ops.attention_scratch_words(B, B, L, H), dtype=torch.float32, device="cuda")
     acc = torch.zeros(2, dtype=torch.int64, device="cuda")
     nqb = (L + 255) // 256
     flops = 4.0 * B * L * L * H * 128
 
-    def run(gain_per_head, check_pairs=None, what=""):
+    def run(gain_per_head, check_pairs=None, what="", outlier_heads=()):
         g = torch.tensor(gain_per_head, device="cuda", dtype=torch.float32).view(1, 1, H, 1)
-        kk = (k0.float() * g).to(BF)
+        kk = (k0.float() * g)
+        q = q0
+        if outlier_heads:
+            q = q0.clone()
+            for h in outlier_heads:
+                kk[:, 12345, h] = 0.0
+                kk[:, 12345, h, 0] = 400.0
+                q[:, :, h, 0] += 6.0 * ops.attention_qscale()
+        kk = kk.to(BF)
         ks = kk.unsqueeze(0)
         acc.zero_()
         out = ops.attention(q, kk, vt[0], q_prescaled=True, kmax_scratch=scratch)           # warm-up + the result that is checked
         L_.check(lib.wan_attention_count_declined(L_.ptr(scratch), B, B, L, H, L_.ptr(acc), L_.stream_ptr()), "count")
         torch.cuda.synchronize()
         flags = scratch[B * H:B * H + nqb * H * B].view(torch.int32).clone().view(B * H, nqb)   # [pair = b*H + h][q-block]
+        assert bool(((flags == 0) | (flags == 1)).all())                                     # 2 (wants the shifted loop) never survives a call
         declined, total = int(acc[0]), int(acc[1])
         assert total == nqb * H * B and declined == int((flags != 0).sum())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -271,21 +287,28 @@ def test_attention_bounded_and_tracking_loops_mixed_inside_one_launch():
         return flags, declined / total, flops / (ms * 1e-3) / 1e12, r
 
     mixed = [gains[h % len(gains)] for h in range(H)]
-    # heads 1 (gain 1: bounded), 4 (gain 4: near the threshold), 5 / 9 (gains 5, 12: tracking), both streams
+    # heads 1 (gain 1: plain), 4 (gain 4: round 3's threshold), 5 / 9 (gains 5, 12: shifted), both streams
     flags, frac_mixed, tf_mixed, r = run(mixed, [(0, 1), (1, 4), (0, 5), (1, 9), (0, 37)], what="per-head K gains 0.5..12")
-    per_head = flags.view(B, H, nqb).float().mean(dim=(0, 2)).cpu()
-    for h in range(H):
-        if mixed[h] <= 2.0:
-            assert per_head[h] == 0.0, (h, mixed[h], per_head[h].item())        # bound ~ 22 * gain: far below 96
-        if mixed[h] >= 8.0:
-            assert per_head[h] == 1.0, (h, mixed[h], per_head[h].item())        # far above: every workgroup declines
+    assert frac_mixed == 0.0, frac_mixed                                                     # no gain of the sweep reaches the tracking loop
     _, frac0, tf0, _ = run([1.0] * H)
-    _, frac1, tf1, _ = run([12.0] * H)
-    assert frac0 == 0.0 and frac1 == 1.0 and 0.3 < frac_mixed < 0.7
-    res = {"shape": {"B": B, "H": H, "L": L}, "gains": gains, "declined_frac_by_gain": {str(gg): float(per_head[[h for h in range(H) if mixed[h] == gg]].mean()) for gg in gains},
-           "TFLOPs": {"declined_0": tf0, f"declined_{frac_mixed:.2f}": tf_mixed, "declined_1": tf1}, "parity_mixed": r}
+    _, frac12, tf12, r12 = run([12.0] * H, [(0, 0), (1, 39)], what="every head at K gain 12 (all workgroups shifted)")
+    assert frac0 == 0.0 and frac12 == 0.0
+    assert tf12 >= 0.95 * tf0, (tf12, tf0)                                                   # the shifted loop IS the plain loop
+    out_heads = list(range(0, H, 4))
+    flags_o, frac_o, tf_o, r_o = run([1.0] * H, [(0, 0), (1, 4), (0, 1), (1, 39)], what="adversarial key in every fourth head", outlier_heads=out_heads)
+    per_head = flags_o.view(B, H, nqb).float().mean(dim=(0, 2)).cpu()
+    for h in range(H):
+        assert per_head[h] == (1.0 if h in out_heads else 0.0), (h, per_head[h].item())      # underflow against the shift -> tracking loop, per head
+    assert abs(frac_o - len(out_heads) / H) < 1e-9
+    _, frac_all, tf_all, _ = run([1.0] * H, outlier_heads=list(range(H)))                    # every workgroup redone by the tracking loop (after a wasted shifted pass)
+    assert frac_all == 1.0
+    res = {"shape": {"B": B, "H": H, "L": L}, "gains": gains,
+           "TFLOPs": {"gain_1_all_plain": tf0, "gains_0.5_to_12_mixed": tf_mixed, "gain_12_all_shifted": tf12,
+                      "adversarial_key_in_a_quarter_of_the_heads": tf_o, "adversarial_key_in_every_head_all_redone_by_tracking": tf_all},
+           "reached_tracking_loop_frac": {"gain_1": frac0, "mixed": frac_mixed, "gain_12": frac12, "outlier_quarter": frac_o, "outlier_all": frac_all},
+           "parity_mixed": r, "parity_gain_12": r12, "parity_outlier": r_o}
     print("\n[attention, mixed loops] " + json.dumps(res))
-    _report("attn_w64q_mixed_loops_B2_L75600", res)
+    _report("attn_mixed_loops_B2_L75600", res)
 
 
 def test_cfg4_world8_rank_dryrun():

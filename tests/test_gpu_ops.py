@@ -456,13 +456,13 @@ def test_attention_bounded_and_tracking_loops_agree_with_fp64(ops, B, Lq, Lk, H,
     ref = _prescaled_ref(qs, k, v)
     vt = ops.transpose_v(cu(v))
     scratch = torch.full((ops.attention_scratch_words(B, Bk, Lq, H),), -1.0, device="cuda")
-    assert scratch.numel() == Bk * H + (Lq + 255) // 256 * H * B
+    assert scratch.numel() == 2 * Bk * H + (Lq + 255) // 256 * H * B          # maxima, flags, (sequence parallelism) the previous maxima
     outs = {"bounded": ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch),
             "library scratch": ops.attention(cu(qs), cu(k), vt, q_prescaled=True),
             "tracking": ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=False)}
     kn = (k.float() ** 2).sum(-1).amax(dim=1).reshape(-1)                       # [Bk*H]
     assert torch.allclose(scratch[:Bk * H].cpu(), kn, rtol=1e-5), (scratch.cpu(), kn)
-    assert (scratch[Bk * H:].view(torch.int32) == 0).all()                     # no workgroup had to fall back to the tracking loop
+    assert (scratch[Bk * H:-Bk * H].view(torch.int32) == 0).all()              # no workgroup had to fall back to the tracking loop
     for name, o in outs.items():
         err = (o.float().cpu() - ref).abs()
         assert attn_ok(o, ref) and err.mean().item() <= 2e-3, (name, err.max().item())
@@ -472,9 +472,11 @@ def test_attention_bounded_and_tracking_loops_agree_with_fp64(ops, B, Lq, Lk, H,
 
 
 def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
-    """Rows whose Cauchy-Schwarz bound |q~| * max|k| exceeds 96 log2 units must take the tracking loop -- per 256-row
-    workgroup: here q rows 256..511 are scaled 80x (scores up to +-1800 log2 units, far beyond fp32's exponent range if
-    exponentiated unshifted), the other workgroups stay bounded.  Both must match the fp64 softmax."""
+    """Rows whose Cauchy-Schwarz bound U = |q~| * max|k| exceeds 96 log2 units cannot be exponentiated unshifted.  q rows 256..511
+    scaled 80x (scores up to +-1800 log2 units, far beyond fp32's exponent range): since round 4 that workgroup runs the bounded loop
+    with a per-row reference shift (attention_w16n.hip) and stays off the tracking loop; with K scaled 70x on top its U passes
+    SHIFT_LIMIT = 2048 (the reference would cost the fp32 scores visible bits) and it falls back to the tracking loop -- per 256-row
+    workgroup, the others (U ~ 1400, shifted) do not.  All of it must match the fp64 softmax."""
     g = torch.Generator().manual_seed(77)
     B, Lq, Lk, H = 1, 700, 2300, 2
     q = torch.randn(B, Lq, H, 128, generator=g); k = torch.randn(B, Lk, H, 128, generator=g).to(BF)
@@ -483,16 +485,90 @@ def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
     qs = (q * ops.attention_qscale()).to(BF)
     scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
     got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
-    assert scratch[B * H:].view(torch.int32).view(B * H, -1).cpu().tolist() == [[0, 1, 0]] * (B * H)   # q-block 1 of every head fell back
+    assert scratch[B * H:-B * H].view(torch.int32).view(B * H, -1).cpu().tolist() == [[0, 0, 0]] * (B * H)   # q-block 1 took the shifted loop
     ref = _prescaled_ref(qs, k, v)
     assert torch.isfinite(got).all()
     err = (got - ref).abs()
     assert attn_ok(got, ref), err.max().item()
-    # and a K so large that every workgroup is out of bounds
+    # and a K so large that q-block 1 is beyond any usable reference
     k2 = (k.float() * 70).to(BF)
     got2 = ops.attention(cu(qs), cu(k2), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
-    assert (scratch[B * H:].view(torch.int32) == 1).all()
+    assert scratch[B * H:-B * H].view(torch.int32).view(B * H, -1).cpu().tolist() == [[0, 1, 0]] * (B * H)
     assert attn_ok(got2, _prescaled_ref(qs, k2, v))
+
+
+@pytest.mark.parametrize("gain", [6.0, 8.0, 12.0, 30.0])
+def test_attention_shifted_bounded_loop_agrees_with_fp64(ops, gain):
+    """Round 4: rows beyond the bound U = |q~| max|k| <= 96 run the bounded loop with a per-row reference shift m = U - 96
+    (attention_w16n.hip, SHIFT) instead of the tracking loop -- m = U - 96 while the row's maximum over the first 64 keys lies within
+    176 of U (gains 6, 8), that sample maximum + 80 beyond (gains 12, 30).  K scaled by `gain` puts every row at U ~ 120 .. 600
+    (round 3: all declined): the result must be the fp64 softmax's, no workgroup may reach the tracking loop, and the workgroup flags
+    end at 0 (2 = "wants the shifted loop" never survives a call).  One head stays at gain 1: plain and shifted workgroups in one launch."""
+    g = torch.Generator().manual_seed(int(gain) * 7)
+    B, Lq, Lk, H = 2, 520, 4200, 3
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF); k = torch.randn(B, Lk, H, 128, generator=g)
+    v = torch.randn(B, Lk, H, 128, generator=g).to(BF)
+    k[:, :, :2] *= gain
+    k = k.to(BF)
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    u = (qs.float().norm(dim=-1).amax(dim=1) * k.float().norm(dim=-1).amax(dim=1))           # [B, H]: the largest bound of a head
+    assert (u[:, :2] > 100).all() and (u[:, 2] < 96).all()
+    ref = _prescaled_ref(qs, k, v)
+    scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
+    got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch)
+    assert (scratch[B * H:-B * H].view(torch.int32) == 0).all()
+    err = (got.float().cpu() - ref).abs()
+    assert attn_ok(got, ref) and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+    # shift invariance: the tracking loop on the same tensors (two roundings to bf16 apart: twice the tolerance)
+    trk = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=False).float().cpu()
+    assert ((got.float().cpu() - trk).abs() <= torch.clamp(trk.abs() * 2.0 ** -6, min=3e-2)).all()
+
+
+def test_attention_shifted_rows_that_leave_the_exponent_range_are_redone_by_the_tracking_loop(ops):
+    """The shifted loop does not watch the exponent range inside the loop; the row sum does.  Head 0: every query carries a component
+    along e_0 and ONE key (not among the first 64) is 400 e_0 -- its score ~ 300 sits far above the reference the sample of the first
+    tile suggests (m ~ 85), P overflows to inf, the row sums say so, the workgroups flag themselves AFTER the loop and the tracking
+    launch redoes them.  Head 1: one key scaled x40 in a random direction (U ~ 650, but its scores ~ N(0, 58) stay inside the window
+    of nearly every row): handled by the shifted loop.  Both match the fp64 softmax."""
+    g = torch.Generator().manual_seed(123)
+    B, Lq, Lk, H = 1, 700, 4100, 2
+    q = torch.randn(B, Lq, H, 128, generator=g); k = torch.randn(B, Lk, H, 128, generator=g)
+    v = torch.randn(B, Lk, H, 128, generator=g).to(BF)
+    q[:, :, 0, 0] += 6.0
+    k[0, 1234, 0] = 0.0
+    k[0, 1234, 0, 0] = 400.0
+    k[0, 2345, 1] *= 40.0
+    k = k.to(BF)
+    qs = (q * ops.attention_qscale()).to(BF)
+    scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
+    got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
+    flags = scratch[B * H:-B * H].view(torch.int32).view(B * H, -1).cpu()
+    assert flags[0].tolist() == [1, 1, 1] and int(flags[1].sum()) <= 1, flags.tolist()
+    assert attn_ok(got, _prescaled_ref(qs, k, v))
+
+
+@pytest.mark.parametrize("gains", [(1.0, 8.0), (8.0, 10.0), (9.0, 2.0)], ids=["plain_then_shifted", "shifted_then_larger_shift", "shifted_then_same"])
+def test_attention_sp_partial_sums_carry_their_shift(ops, gains):
+    """Sequence parallelism: phase 0 leaves partial sums shifted by m(local max|k|), phase 1 knows the maxima of ALL segments and
+    rescales what it carries by 2^(m_local - m_global) (the local maxima travel behind the flags in the scratch).  Local / remote K
+    gains such that the carried sums are unshifted -> shifted, shifted -> shifted further, and shifted -> unchanged."""
+    g_local, g_remote = gains
+    g = torch.Generator().manual_seed(61)
+    B, Lq, Lk, H, nseg, own = 2, 300, 2130, 2, 3, 1
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF)
+    k = torch.randn(nseg, B, Lk, H, 128, generator=g); v = torch.randn(nseg, B, Lk, H, 128, generator=g).to(BF)
+    k *= g_remote
+    k[own] *= g_local / g_remote
+    k = k.to(BF)
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    ref = _prescaled_ref(qs, torch.cat(list(k), dim=1), torch.cat(list(v), dim=1))
+    vt = torch.stack([ops.transpose_v(cu(v[s])) for s in range(nseg)]).contiguous()
+    got, scratch = ops.attention_sp(cu(qs), cu(k[own]), vt[own].contiguous(), cu(k), vt, own)
+    assert (scratch[B * H:-B * H].view(torch.int32) == 0).all()                  # nothing needed the tracking loop
+    kn_all = (k.float() ** 2).sum(-1).amax(dim=(0, 2)).reshape(-1)
+    kn_own = (k[own].float() ** 2).sum(-1).amax(dim=1).reshape(-1)
+    assert torch.allclose(scratch[:B * H].cpu(), kn_all, rtol=1e-5) and torch.allclose(scratch[-B * H:].cpu(), kn_own, rtol=1e-5)
+    assert attn_ok(got, ref), (got.float().cpu() - ref).abs().max().item()
 
 
 @pytest.mark.parametrize("own", [0, 2, 3])
@@ -511,7 +587,7 @@ def test_attention_sp_local_first_equals_contiguous(ops, own):
     k_all[own] = float("nan"); vt_all[own] = float("nan")                      # a rank's own slot of the gather buffer is not needed
     got, scratch = ops.attention_sp(cu(qs), cu(k[own]), vt[own].contiguous(), k_all, vt_all, own)
     assert attn_ok(got, ref), (got.float().cpu() - ref).abs().max().item()
-    assert (scratch[B * H:].view(torch.int32) == 0).all()                        # every workgroup stayed on the bounded path
+    assert (scratch[B * H:-B * H].view(torch.int32) == 0).all()                        # every workgroup stayed on the bounded path
 
 
 def test_attention_sp_bound_exceeded_is_recomputed_by_the_tracking_loop(ops):
@@ -526,5 +602,5 @@ def test_attention_sp_bound_exceeded_is_recomputed_by_the_tracking_loop(ops):
     ref = _prescaled_ref(qs, torch.cat(list(k), dim=1), torch.cat(list(v), dim=1))
     vt = torch.stack([ops.transpose_v(cu(v[s])) for s in range(nseg)]).contiguous()
     got, scratch = ops.attention_sp(cu(qs), cu(k[own]), vt[own].contiguous(), cu(k), vt, own)
-    assert (scratch[B * H:].view(torch.int32) == 1).all()
+    assert (scratch[B * H:-B * H].view(torch.int32) == 1).all()
     assert attn_ok(got, ref), (got.float().cpu() - ref).abs().max().item()

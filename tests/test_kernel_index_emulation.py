@@ -892,3 +892,69 @@ def test_attention_w16n_gap_schedule():
 
 
 
+
+
+# ----------------------------------------------------------------------------------------------
+# attention_w16n.hip, SHIFT (round 4): the bounded loop with a per-row reference that never changes inside the loop
+# ----------------------------------------------------------------------------------------------
+def _shifted_softmax_rows(qt, k, v, L_tile0=64):
+    """The arithmetic of attn_w16n_kernel<SHIFT> for a block of rows, in fp32 like the kernel: U from Cauchy-Schwarz, m_s from the
+    first 64 keys, the reference m, P = 2^(s - m) exponentiated ONCE with no maximum tracked, row sums, the post-loop verdict.
+    -> (o [rows, d] fp32, flagged [rows] bool, m [rows])."""
+    f = np.float32
+    s = (qt.astype(np.float64) @ k.astype(np.float64).T).astype(f)            # bf16 products are exact in fp32; the order of the sum is not pinned
+    u2 = (qt.astype(f) ** 2).sum(1) * f((k.astype(f) ** 2).sum(1).max())
+    u = np.sqrt(u2) * f(1.0001) + f(0.01)
+    m_cs = np.where(u2 <= f(96.0 * 96.0), f(0), u - f(96.0)).astype(f)
+    ms = s[:, :L_tile0].max(1)
+    m = np.where(m_cs == 0, f(0), np.where(u - ms <= f(176.0), m_cs, ms + f(80.0))).astype(f)
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        p = np.exp2((s - m[:, None]).astype(f)).astype(f)                     # inf above 2^128, 0 below 2^-149 (the hardware flushes earlier: 2^-126)
+        p = np.where(p < f(2.0 ** -126), f(0), p)
+        l = p.sum(1, dtype=f)
+        o = (p @ v.astype(f)) / l[:, None]
+    ok = ((l >= f(2.0 ** -80)) & (l <= f(2.0 ** 100))) | (m == 0)
+    too_far = u2 > f(2048.0 * 2048.0)
+    return o, ~ok | too_far, m
+
+
+def test_shifted_bounded_softmax_covers_what_the_plain_bound_declined_and_flags_the_rest():
+    """The algebra the SHIFT instantiation rests on, on the CPU in fp32: (1) wherever a row is not flagged its result is the fp64
+    softmax's (shift invariance; what underflows is < 2^-46 of the row sum per term); (2) diffuse random rows are never flagged up to
+    gains far beyond round 3's limit (gamma ~ 6 declined everything); (3) a row whose maximum sits more than 176 above what its first
+    64 keys suggest overflows, is FLAGGED, and is never returned as a number; (4) rows inside the plain bound keep m = 0 (the plain
+    kernel's arithmetic, bit for bit)."""
+    rng = np.random.default_rng(5)
+    L, d, rows = 6000, 128, 96
+    c = np.float32(0.08838834764831845 * 1.4426950408889634)
+
+    bf = _bf16_rne
+    v = bf(rng.standard_normal((L, d)).astype(np.float32))
+    q = bf(rng.standard_normal((rows, d)).astype(np.float32) * c)
+    seen_shifted = False
+    for gain in (1.0, 4.0, 6.0, 12.0, 30.0):
+        k = bf(rng.standard_normal((L, d)).astype(np.float32) * gain)
+        o, flagged, m = _shifted_softmax_rows(q, k, v)
+        assert not flagged.any(), (gain, int(flagged.sum()))
+        assert (m == 0).all() if gain <= 4.0 else (m > 0).all(), gain
+        seen_shifted |= bool((m > 0).any())
+        s64 = q.astype(np.float64) @ k.astype(np.float64).T
+        p64 = np.exp2(s64 - s64.max(1, keepdims=True))
+        ref = (p64 / p64.sum(1, keepdims=True)) @ v.astype(np.float64)
+        assert np.abs(o - ref).max() < 2e-4, (gain, np.abs(o - ref).max())
+    assert seen_shifted
+    # adversarial: every query has a component along e_0, one key far from the first tile is 400 e_0
+    q2 = q.copy(); q2[:, 0] += bf(np.float32(6.0) * c)
+    k = bf(rng.standard_normal((L, d)).astype(np.float32)); k[1234] = 0; k[1234, 0] = 400.0
+    o, flagged, m = _shifted_softmax_rows(q2, k, v)
+    s64 = q2.astype(np.float64) @ k.astype(np.float64).T
+    out_of_window = s64.max(1) - m > 127.0
+    assert out_of_window.sum() > rows // 2 and flagged[out_of_window].all()
+    fine = ~flagged
+    if fine.any():
+        p64 = np.exp2(s64 - s64.max(1, keepdims=True))
+        ref = (p64 / p64.sum(1, keepdims=True)) @ v.astype(np.float64)
+        assert np.abs(o[fine] - ref[fine]).max() < 2e-4
+    # a reference beyond SHIFT_LIMIT is not attempted
+    _, flagged, _ = _shifted_softmax_rows(q * np.float32(80.0), bf(rng.standard_normal((L, d)).astype(np.float32) * 70.0), v)
+    assert flagged.all()

@@ -309,8 +309,10 @@ def test_ti2v_timestep_injection_passes_a_per_frame_t_and_pins_the_source_latent
     run(WanAny2VHIP(Dit("A"), vae=Vae(), device="cpu"), input_video=torch.zeros(3, 1, 64, 64), sampling_steps=1, sub_parallel_window_size=5,
         sub_parallel_window_overlap=1)
     assert [tuple(t.shape) for t, _ in seen] == [(2,), (3,)] and all(t[0] == 0 and t[1] > 0 for t, _ in seen)
-    with pytest.raises(ValueError, match="ti2v"):
-        run(WanAny2VHIP(FakeDiT("A"), vae=Vae(), device="cpu"), input_video=torch.zeros(3, 1, 64, 64))
+    # a model that is neither the 5B nor i2v: the reference reads the size of input_video and nothing else (any2video.py:571)
+    seen.clear()
+    run(WanAny2VHIP(FakeDiT("A"), vae=Vae(), device="cpu"), input_video=torch.zeros(3, 1, 64, 64))
+    assert not seen
 
 
 def test_nag_stacks_the_negative_prompt_under_the_positive_one_and_arms_both_experts():
@@ -679,8 +681,8 @@ class _StubVAE:
 def test_generate_takes_the_i2v_conditioning_from_input_video_like_the_reference():
     """any2video.py:671-680: the i2v path conditions on `input_video` (wgp.py passes input_video = pre_video_guide: the start image
     as [3, 1, H, W] or the video to continue, together with prefix_video / pre_video_frame / conditioning_latents_size > 0,
-    wgp.py:7378-7394, :7714).  Same y and same result as image_start= (the direct-call spelling); a t2v model ignores none of it
-    silently: input_video on a non-i2v, non-5B model still raises."""
+    wgp.py:7378-7394, :7714).  Same y and same result as image_start= (the direct-call spelling).  On a t2v-class
+    model the reference reads nothing of input_video but its height and width (any2video.py:571): same here."""
     g = torch.Generator().manual_seed(3)
     img = torch.rand(3, 1, 64, 64, generator=g) * 2 - 1
     prefix = torch.rand(3, 5, 64, 64, generator=g) * 2 - 1
@@ -696,8 +698,35 @@ def test_generate_takes_the_i2v_conditioning_from_input_video_like_the_reference
         ya, yb = a.calls[0]["y"], b.calls[0]["y"]
         assert ya is not None and tuple(ya.shape) == (20, 3, 8, 8) and torch.equal(ya, yb)
         assert torch.equal(got["latents"], want["latents"])
-    with pytest.raises(ValueError, match="input_video"):
-        run(WanAny2VHIP(FakeDiT("A"), device="cpu"), input_video=img)
+    a = run(WanAny2VHIP(FakeDiT("A"), device="cpu"), input_video=img)                      # 64 x 64 like the default keywords: size unchanged
+    b = run(WanAny2VHIP(FakeDiT("A"), device="cpu"))
+    assert torch.equal(a["latents"], b["latents"])
+
+
+def test_vace_second_sliding_window_gets_input_video_from_wgp_and_only_its_size_is_read():
+    """Window 2 and later of a long VACE video as wgp.py drives them: input_video = pre_video_guide (the overlap frames of the previous
+    window, wgp.py:7740, :7995) goes to EVERY model type together with overlapped_latents and prefix_frames_count.  The reference reads
+    height / width from it (any2video.py:571) and nothing else on the VACE path -- the overlap itself arrives through input_frames and
+    overlapped_latents (:837, :1150-1163).  Round 3 raised here ("input_video ... is the ti2v_2_2 conditioning path"), i.e. every long
+    VACE video died after its first window.  Same result with and without the keyword."""
+    from oracle.make_golden_vace_context import FakeVAE, inputs
+
+    class VaceDiT(FakeDiT):
+        vace_layers = (0,)
+
+        def __call__(self, x, t, context, vace_context=None, **kw):
+            assert vace_context is not None
+            return super().__call__(x, t, context, **kw)
+    frames, mask, _ = inputs()
+    prefix_px = frames[:, :5].clone()                                                       # the previous window's last frames, as wgp.py passes them
+    kw = dict(width=48, height=32, input_frames=frames, input_masks=mask, overlapped_latents=torch.zeros(1, 16, 2, 4, 6), overlap_noise=20,
+              prefix_frames_count=5, return_latent_slice=slice(-2, None), window_no=2, video_prompt_type="V", model_type="vace_14B")
+    outs = []
+    for extra in (dict(input_video=prefix_px, prefix_video=prefix_px, pre_video_frame=prefix_px[:, -1]), dict()):
+        torch.manual_seed(5)
+        outs.append(run(WanAny2VHIP(VaceDiT("A"), vae=FakeVAE(), device="cpu"), **_wgp_keywords(**kw, **extra)))
+    assert torch.equal(outs[0]["latents"], outs[1]["latents"]) and torch.equal(outs[0]["latent_slice"], outs[1]["latent_slice"])
+    assert tuple(outs[0]["latents"].shape[-2:]) == (4, 6)
 
 
 def test_progress_protocol_matches_the_references_callback_calls():

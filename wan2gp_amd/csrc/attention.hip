@@ -40,7 +40,8 @@ constexpr int KVBLK = 64;
 constexpr float SCALE_LOG2E = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
 
 extern "C" int64_t wan_attention_scratch_words(int B, int Bk, int64_t Lq, int H) {
-  return (int64_t)Bk * H + ((Lq + 255) / 256) * H * B;  // max |k_h|^2 per (batch, head) + one flag per 256-row workgroup
+  // max |k_h|^2 per (batch, head) + one flag per 256-row workgroup + (sequence parallelism) the maxima of the previous partial launch
+  return (int64_t)Bk * H + ((Lq + 255) / 256) * H * B + (int64_t)Bk * H;
 }
 
 // Library-owned scratch for the K pre-pass of callers that bring none (wan_attention / _seg / _prescaled): a ring of

@@ -47,6 +47,11 @@ struct QH {           // one half of the wave's q rows: two 16-row q tiles
 __device__ __forceinline__ void qk16_0(f32x4& d, const mfma_bf16x8& k, const mfma_bf16x8& q) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
 }
+// the first k-step of an S tile when the q tile carries a reference shift: C = {-m, -m, -m, -m} of the lane's q column (a lane's four
+// registers of a tile belong to ONE q row), so the tile comes out as s - m at no instruction's cost
+__device__ __forceinline__ void qk16_c(f32x4& d, const mfma_bf16x8& k, const mfma_bf16x8& q, const f32x4& c) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(k), "a"(q), "v"(c));
+}
 __device__ __forceinline__ void qk16(f32x4& d, const mfma_bf16x8& k, const mfma_bf16x8& q) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "a"(q));
 }
@@ -117,10 +122,15 @@ __device__ __forceinline__ void pack16(QH& q, int k) {
 }
 __device__ __forceinline__ void tail16(QH& q) { vadd16(q.l[1][1], q.p1); }  // score 31's share of its row sum (q tile 1)
 // MFMA i = 0..31 of an S phase: k-step i >> 3, kv tile (i >> 1) & 3, q tile i & 1 -- an accumulator is revisited every 8 MFMAs
-__device__ __forceinline__ void qk_step16(QH& x, const mfma_bf16x8 (&kf)[4][4], const mfma_bf16x8 (&qf)[4][4], int qt0, int i) {
+template <bool SHIFT>
+__device__ __forceinline__ void qk_step16(QH& x, const mfma_bf16x8 (&kf)[4][4], const mfma_bf16x8 (&qf)[4][4], const f32x4 (&negm)[4], int qt0, int i) {
   const int ks = i >> 3, kt = (i >> 1) & 3, qt = i & 1;
-  if (ks == 0) qk16_0(x.s[kt][qt], kf[kt][0], qf[qt0 + qt][0]);
-  else qk16(x.s[kt][qt], kf[kt][ks], qf[qt0 + qt][ks]);
+  if (ks == 0) {
+    if (SHIFT) qk16_c(x.s[kt][qt], kf[kt][0], qf[qt0 + qt][0], negm[qt0 + qt]);
+    else qk16_0(x.s[kt][qt], kf[kt][0], qf[qt0 + qt][0]);
+  } else {
+    qk16(x.s[kt][qt], kf[kt][ks], qf[qt0 + qt][ks]);
+  }
 }
 // MFMA i = 0..31 of a PV phase: P^T fragment f = i >> 3 (c = f >> 1, q tile f & 1), d tile i & 7
 __device__ __forceinline__ void pv_step16(QH& x, const mfma_bf16x8 (&vf)[8][2], int i) {
@@ -159,9 +169,9 @@ __device__ __forceinline__ void multi_step16(Dma& d, MultiStep& m, int part) {
   }
 }
 
-template <int ST, bool MULTI, bool TIMING>
+template <int ST, bool MULTI, bool TIMING, bool SHIFT>
 __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4], const int (&vaddr)[2], const mfma_bf16x8 (&qf)[4][4],
-                                          mfma_bf16x8 (&kf)[4][4], mfma_bf16x8 (&vf)[8][2], QH& a, QH& b, int kv_rem, int lg,
+                                          const f32x4 (&negm)[4], mfma_bf16x8 (&kf)[4][4], mfma_bf16x8 (&vf)[8][2], QH& a, QH& b, int kv_rem, int lg,
                                           char* smem_rw, Dma& dma, int& cur_tt, int tps, uint64_t* stamp, bool rec) {
   constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
   int adv_ = 0;
@@ -226,7 +236,7 @@ __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4]
   if (TIMING && rec) stamp[2] = __builtin_amdgcn_s_memtime();
 #pragma unroll
   for (int i = 0; i < 32; ++i) {  // ---- A: S_a = K Q_a^T
-    qk_step16(a, kf, qf, 0, i); SB();
+    qk_step16<SHIFT>(a, kf, qf, negm, 0, i); SB();
     N16_GAP(i);
     SB();
   }
@@ -238,7 +248,7 @@ __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4]
   }
 #pragma unroll
   for (int i = 0; i < 32; ++i) {  // ---- C: S_b = K Q_b^T
-    qk_step16(b, kf, qf, 2, i); SB();
+    qk_step16<SHIFT>(b, kf, qf, negm, 2, i); SB();
     N16_GAP(64 + i);
     SB();
   }
@@ -274,8 +284,34 @@ __device__ __forceinline__ mfma_bf16x8 prescale8_16(const uint4 raw, float c) {
 }
 
 // FLAGS: attention_w64q.hip's bits -- bit1 q pre-scaled, bit2 (always set here: the bounded loop), bit4 RAW_OUT, bit5 CARRY_IN,
-// bit6 MULTI (several kv segments / a left-out one).  A workgroup whose rows fail the bound sets wg_flags[id] and returns before
-// touching LDS; attention_w64q.hip's tracking instantiation, launched behind this kernel, then does it.
+// bit6 MULTI (several kv segments / a left-out one), bit7 SHIFT.
+//
+// Three launches back to back share one flag word per workgroup (wg_flags: 0 = done, 2 = wants the shifted loop, 1 = wants the
+// tracking loop):
+//   plain (SHIFT = 0)  every row of the workgroup obeys U = |Q~_row| max|k_h| <= 96: P = 2^s unshifted, as since round 2.  Else the
+//                      workgroup sets its flag -- 2 if every U is finite and <= SHIFT_LIMIT, 1 otherwise -- and returns before touching LDS.
+//   shifted (SHIFT = 1, round 4)  runs the workgroups flagged 2: the SAME loop, instruction for instruction, with P = 2^(s - m) for a
+//                      per-row constant m that enters through the C operand of every S tile's first MFMA.  The row's true maximum
+//                      lies in [m_s, U]: U by Cauchy-Schwarz, m_s = its maximum over the 64 keys of tile 0 (one S phase in the
+//                      prologue).  U - m_s <= 176: m = U - 96, nothing can overflow or lose its maximum -- guaranteed.  Wider: m =
+//                      m_s + 80 and the interval [m_s, m_s + 176] for the true maximum.  Nothing in the loop watches the exponent range
+//                      -- the row sum does: a row that left it ends with l outside [2^-80, 2^100] (or NaN), the workgroup then flags
+//                      itself 1 AFTER the loop and the tracking launch redoes it.  (Partial launches -- RAW_OUT / CARRY_IN -- must agree
+//                      on m without seeing each other's tiles: m = U - 96 only.)  Softmax is shift invariant, so wherever l >= 2^-80 the result is
+//                      the max-subtracting kernel's: the terms that underflowed are < 2^-46 of the row sum each.  What this buys: the
+//                      fast loop no longer depends on RMSNorm gains staying near 1 -- diffuse random heads pass while the maximum of L
+//                      scores stays within 176 of the maximum of 64 (gamma_q gamma_k ~ 40; plain: ~ 6), peaky rows (true maximum near
+//                      U) at any gain up to SHIFT_LIMIT.
+//   tracking           attention_w64q.hip's instantiation: the workgroups flagged 1.
+// Partial sums (sequence parallelism): RAW_OUT leaves them shifted by m(local max|k|); the CARRY_IN launch recomputes that m from the
+// previous maxima (kept behind the flags in the scratch) and rescales by 2^(m_old - m_new) before it continues.
+constexpr float SHIFT_LIMIT = 2048.0f;      // |m| beyond this costs the fp32 scores visible bits: tracking loop
+constexpr float SHIFT_MIN_ROWSUM = 8.271806125530277e-25f;  // 2^-80
+constexpr float SHIFT_MAX_ROWSUM = 1.2676506002282294e30f;  // 2^100: |sum P V| <= l max|v| stays finite for |v| < 2^27
+constexpr float SHIFT_UNDER = 80.0f, SHIFT_WINDOW = 176.0f;  // a row maximum may lie 80 below its reference m and 96 above it
+__device__ __forceinline__ float ref_shift16(float u2) {     // u2 = U^2 of a row; the reference m its scores are shifted by
+  return u2 <= BOUND16_LOG2 * BOUND16_LOG2 ? 0.f : __builtin_amdgcn_sqrtf(u2) * 1.0001f + 0.01f - BOUND16_LOG2;  // 1-ulp sqrt + margin
+}
 template <int FLAGS>
 __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kg,
                                                        const bf16_t* __restrict__ Vt, bf16_t* __restrict__ O, int B, int Bk,
@@ -287,6 +323,8 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
   constexpr bool RAW_OUT = (FLAGS & 16) != 0, CARRY_IN = (FLAGS & 32) != 0;
   constexpr bool MULTI = (FLAGS & 64) != 0;
+  constexpr bool SHIFT = (FLAGS & 128) != 0;
+  constexpr bool SAMPLE = SHIFT && !RAW_OUT && !CARRY_IN;  // the reference also uses a lower bound of the row maximum (partial launches must agree on m: Cauchy-Schwarz only)
   constexpr int WAVE_RAW = 2 * (64 * 64 + 128), WG_RAW = 4 * WAVE_RAW;  // floats: per half 64 accumulators x 64 lanes + 2 x 64 row-sum shares
   __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];    // [K stages][V^T stages] = 96 KB
   lds_cchar* lds = (lds_cchar*)smem;
@@ -298,7 +336,8 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
 
   const int total = nqb * H * B;
   const int v = xcd_remap(blockIdx.x, total);
-  if (CARRY_IN && wg_flags[v] != 0) return;  // an earlier partial launch already gave this workgroup up
+  if (SHIFT) { if (wg_flags[v] != 2) return; }  // only what the plain launch handed over
+  else if (CARRY_IN && wg_flags[v] != 0) return;  // an earlier partial launch already gave this workgroup up
   const int pair = v / nqb;
   const int qb = v - pair * nqb;
   const int b = pair / H, h = pair - b * H;
@@ -331,20 +370,33 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
         asm volatile("" : "+a"(qf[qt][ks]));  // one accumulator-file tuple from here on
       }
   }
-  // ---- the bound: every row of the workgroup must satisfy |Q~_row| * max|k_h| <= 96 (workgroup-uniform) ------------------------
+  // ---- the bound: every row of the workgroup must satisfy |Q~_row| * max|k_h| <= 96 (workgroup-uniform) -- or carry a reference shift
+  f32x4 negm[4];      // SHIFT: {-m} x 4 per q tile, the C operand of the tile's first MFMA
+  float mref[4] = {0.f, 0.f, 0.f, 0.f};
   {
     const float km = kmax2[bk * H + h];
-    bool ok = true;
+    bool ok = true, shiftable = true;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       float s = ss[qt];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);
-      ok = ok && (s * km <= BOUND16_LOG2 * BOUND16_LOG2);  // false for NaN
+      ss[qt] = s;
+      const float u2 = s * km;
+      ok = ok && (u2 <= BOUND16_LOG2 * BOUND16_LOG2);          // false for NaN
+      shiftable = shiftable && (u2 <= SHIFT_LIMIT * SHIFT_LIMIT);
+      if (SHIFT) {
+        mref[qt] = ref_shift16(u2);
+        const float n = -mref[qt];
+        negm[qt] = f32x4{n, n, n, n};
+      }
     }
-    if (__syncthreads_and(ok ? 1 : 0) == 0) {
-      if (tid == 0) wg_flags[v] = 1;
-      return;
+    if (!SHIFT) {
+      if (__syncthreads_and(ok ? 1 : 0) == 0) {
+        const int can = __syncthreads_and(shiftable ? 1 : 0);
+        if (tid == 0) wg_flags[v] = can ? 2 : 1;
+        return;
+      }
     }
   }
 
@@ -390,6 +442,24 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     const float* ls = raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
     qa.l[0][0] = ls[lane]; qa.l[1][0] = ls[64 + lane];
     qb2.l[0][0] = ls[128 + lane]; qb2.l[1][0] = ls[192 + lane];
+    if (SHIFT) {  // the carried sums were shifted by m(previous maxima) <= m: bring them to this launch's reference
+      const float kmp = kmax2[(size_t)Bk * H + (size_t)total + bk * H + h];
+      float f[4];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) f[qt] = __builtin_amdgcn_exp2f(ref_shift16(ss[qt] * kmp) - mref[qt]);
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            f32x4& acc = hf ? qb2.accO[dt][qt] : qa.accO[dt][qt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] *= f[hf * 2 + qt];
+            asm volatile("" : "+a"(acc));
+          }
+      qa.l[0][0] *= f[0]; qa.l[1][0] *= f[1]; qb2.l[0][0] *= f[2]; qb2.l[1][0] *= f[3];
+    }
   }
   qa.p0 = qa.p1 = qb2.p0 = qb2.p1 = 0.f;
   // q-half b starts half a tile behind: its first PV_b runs on an all-masked dummy tile (P = 0)
@@ -427,6 +497,45 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     SB();
   }
 
+  if (SAMPLE && Lk32 >= KVBLK) {
+    // ---- a LOWER bound of every row's maximum: its scores against the 64 keys of tile 0 (the MFMAs of one S phase, once per workgroup).
+    // The row's true maximum lies in [m_s, U].  Where that interval is at most 176 wide, m = U - 96 covers it (nothing can overflow, the
+    // maximum cannot underflow below 2^-80): guaranteed.  Where it is wider -- large gains on diffuse rows: U grows like 16 gamma, the
+    // maximum of L random scores like 6 gamma -- m = m_s + 80 keeps the guarantee on the low side and leaves [m_s, m_s + 176] for the true
+    // maximum; beyond that P overflows to inf, the row sum says so, and the workgroup goes to the tracking loop like an underflowed one.
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          f32x4& d = (qt < 2) ? qa.s[kt][qt] : qb2.s[kt][qt - 2];
+          if (ks == 0) qk16_0(d, kf[kt][0], qf[qt][0]);
+          else qk16(d, kf[kt][ks], qf[qt][ks]);
+        }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // inline-asm MFMAs: the hazard recognizer does not see their latency
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4& d = (qt < 2) ? qa.s[kt][qt] : qb2.s[kt][qt - 2];
+        asm volatile("" : "+v"(d));
+        mx = fmaxf(fmaxf(mx, fmaxf(d[0], d[1])), fmaxf(d[2], d[3]));
+        d = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // back to the dummy tile the first PV_b expects
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (mref[qt] != 0.f) {
+        const float u = mref[qt] + BOUND16_LOG2;                // the row's U (with its margin)
+        const float m = (u - mx <= SHIFT_WINDOW) ? mref[qt] : mx + SHIFT_UNDER;   // NaN scores: the comparison fails, m = NaN, the row sum flags it
+        mref[qt] = m;
+        const float n = -m;
+        negm[qt] = f32x4{n, n, n, n};
+      }
+    }
+  }
+
   int kv_rem_prev = KVBLK;
 #define W16N_STEP(J)                                                                                         \
   if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
@@ -440,7 +549,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): every K fragment of this tile was read >= 30 gaps ago */ \
     if (TIMING && rec) stamp[1] = __builtin_amdgcn_s_memtime();                                              \
     const int kv_rem = Lk32 - (MULTI ? cur_tt : t + (J)) * KVBLK;                                            \
-    tile_w16n<J, MULTI, TIMING>(lds, kaddr, vaddr, qf, kf, vf, qa, qb2, kv_rem, lg, smem, dma, cur_tt, tps, stamp, rec); \
+    tile_w16n<J, MULTI, TIMING, SHIFT>(lds, kaddr, vaddr, qf, negm, kf, vf, qa, qb2, kv_rem, lg, smem, dma, cur_tt, tps, stamp, rec); \
     kv_rem_prev = kv_rem;                                                                                    \
   }
   for (int t = 0; t < ntile; t += NST) {
@@ -477,18 +586,26 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     float* ls = raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
 #pragma unroll
     for (int c = 0; c < 4; ++c) ls[c * 64 + lane] = lsum[c];
+    if (SHIFT && tid == 0) wg_flags[v] = 0;  // partial sums left; underflow is judged on the final row sums (CARRY_IN launch)
     return;
   }
   // ---- epilogue: normalise, stage the wave's 64 x 128 O tile through LDS, store whole rows ------------------------------------------
   float inv[4];
+  bool bad = false;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     float s = lsum[c];
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     inv[c] = 1.0f / s;
+    if (SHIFT) bad = bad || !((s >= SHIFT_MIN_ROWSUM && s <= SHIFT_MAX_ROWSUM) || mref[c] == 0.f);  // under- / overflowed against its shift (or NaN): the tracking loop redoes the workgroup
   }
-  __syncthreads();
+  if (SHIFT) {
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (tid == 0) wg_flags[v] = any_bad ? 1 : 0;
+  } else {
+    __syncthreads();
+  }
   char* ob = smem + wave * (64 * 256);
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf)
@@ -542,6 +659,12 @@ int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const 
     W16N_CASE(6 | 64)
     W16N_CASE(2 | 4 | 16)
     W16N_CASE(2 | 4 | 32 | 64)
+    W16N_CASE(4 | 128)
+    W16N_CASE(6 | 128)
+    W16N_CASE(4 | 64 | 128)
+    W16N_CASE(6 | 64 | 128)
+    W16N_CASE(2 | 4 | 16 | 128)
+    W16N_CASE(2 | 4 | 32 | 64 | 128)
 #ifdef W64Q_TIMING
     W16N_CASE(7)
 #endif

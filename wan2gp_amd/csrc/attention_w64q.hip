@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
 
   const int total = nqb * H * B;
   const int v = xcd_remap(blockIdx.x, total);
-  if (!BND && wg_flags != nullptr && wg_flags[v] == 0) return;  // the bounded launch did this workgroup
+  if (!BND && wg_flags != nullptr && wg_flags[v] != 1) return;  // a bounded launch (plain, or attention_w16n.hip's shifted one) did this workgroup
   if (BND && CARRY_IN && wg_flags[v] != 0) return;              // an earlier partial launch already gave this workgroup up
   const int pair = v / nqb;
   const int qb = v - pair * nqb;
@@ -803,6 +803,9 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
     if (!W16N_TRY(fl, nseg, k_seg_stride, vt_seg_stride, skip_seg)) {
       if (nseg > 1) { if (pre) W64Q_LAUNCH(6 | 64); else W64Q_LAUNCH(4 | 64); }
       else { if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4); }
+    } else {
+      WAN_LAUNCH_CHECK();
+      (void)W16N_TRY(fl | 128, nseg, k_seg_stride, vt_seg_stride, skip_seg);  // the workgroups the plain launch flagged 2: the same loop with a per-row reference shift
     }
     WAN_LAUNCH_CHECK();
   }
@@ -842,14 +845,18 @@ int wan_attention_w64q_sp(int phase, const bf16_t* q, const bf16_t* k, const bf1
                        H, (int64_t)0);
     WAN_LAUNCH_CHECK();
     if (!W16N_TRY(2 | 4 | 16, 1, (int64_t)0, (int64_t)0, -1)) W64Q_LAUNCH_SP(2 | 4 | 16, 1, (int64_t)0, (int64_t)0, -1);
+    else { WAN_LAUNCH_CHECK(); (void)W16N_TRY(2 | 4 | 16 | 128, 1, (int64_t)0, (int64_t)0, -1); }
     WAN_LAUNCH_CHECK();
     return 0;
   }
+  // the local maxima of phase 0 move behind the flags: the shifted CARRY_IN launch derives the shift its carried sums were left in from them
+  WAN_CHECK_HIP(hipMemcpyAsync(kmax_scratch + (size_t)B * H + (size_t)total, kmax_scratch, (size_t)B * H * 4, hipMemcpyDeviceToDevice, stream));
   WAN_CHECK_HIP(hipMemsetAsync(kmax_scratch, 0, (size_t)B * H * 4, stream));                          // maxima only: flags of phase 0 stand
   hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(B * H), (unsigned)nseg), dim3(256), 0, stream, k,
                      kmax_scratch, B, Lk, H, k_seg_stride);
   WAN_LAUNCH_CHECK();
   if (!W16N_TRY(2 | 4 | 32 | 64, nseg, k_seg_stride, vt_seg_stride, own_seg)) W64Q_LAUNCH_SP(2 | 4 | 32 | 64, nseg, k_seg_stride, vt_seg_stride, own_seg);
+  else { WAN_LAUNCH_CHECK(); (void)W16N_TRY(2 | 4 | 32 | 64 | 128, nseg, k_seg_stride, vt_seg_stride, own_seg); }
   WAN_LAUNCH_CHECK();
   W64Q_LAUNCH_SP(2 | 64, nseg, k_seg_stride, vt_seg_stride, -1);
   WAN_LAUNCH_CHECK();

@@ -263,6 +263,44 @@ class WanAny2VHIP:
         `vace_ditto_14B` model types have any, neither of which this backend serves -> none."""
         return [], []
 
+    # ---- multi-GPU: what must be bit-identical on every rank -------------------------------------------------------------------
+    def _ranks_share_latents(self):
+        """True when this process is one rank of a CFG-parallel / sequence-parallel world: latents are replicated and nothing is
+        broadcast per step (sp.py), so every random draw of generate() has to come out the same on every rank."""
+        if getattr(self, "cfg_parallel", None) is not None:
+            return True
+        sp = getattr(self.model, "sp", None)
+        return sp is not None and getattr(sp, "world", 1) > 1
+
+    def _replicated_seed(self, seed):
+        """seed >= 0 as given; a negative seed means "draw one" (torch.seed()) -- in a multi-rank world rank 0's draw, for all."""
+        if seed >= 0:
+            return seed
+        drawn = torch.seed() % (2 ** 31)
+        if self._ranks_share_latents():
+            import torch.distributed as dist
+            t = torch.tensor([drawn], dtype=torch.int64, device=self.device if dist.get_backend() != "gloo" else "cpu")
+            dist.broadcast(t, src=0)
+            drawn = int(t.item())
+        return drawn
+
+    def _replicated_randn_like(self, ref):
+        """torch.randn_like(ref) from the process-global generator, as the reference draws the per-step noise of a pinned prefix
+        (any2video.py:1517-1526).  That generator is neither seeded from `seed` nor the same on two ranks: in a multi-rank world rank
+        0 draws and every rank takes its tensor (one broadcast of the prefix's size per step) -- otherwise the conditional and the
+        unconditional half of a CFG-parallel world, or the shards of a sequence-parallel one, would denoise different latents."""
+        noise = torch.randn_like(ref)
+        if self._ranks_share_latents():
+            import torch.distributed as dist
+            if dist.get_backend() == "gloo" and noise.is_cuda:
+                host = noise.cpu()
+                dist.broadcast(host, src=0)
+                noise = host.to(ref.device)
+            else:
+                noise = noise.contiguous()
+                dist.broadcast(noise, src=0)
+        return noise
+
     def generate(self, input_prompt=None, n_prompt="", context=None, context_null=None, width=1280, height=720,
                  frame_num=81, batch_size=1, shift=5.0, sample_solver="unipc", sampling_steps=30, guide_scale=5.0,
                  guide2_scale=5.0, guide3_scale=5.0, switch_threshold=0, guide_phases=1, model_switch_phase=1, seed=-1, callback=None,
@@ -348,7 +386,7 @@ class WanAny2VHIP:
         sample_scheduler, timesteps = self._scheduler(sample_solver, sampling_steps, shift,
                                                       native=not ((v2v_on and denoising_strength < 1) or refiner_handler is not None))
         seed_g = torch.Generator(device=dev)
-        seed_g.manual_seed(seed if seed >= 0 else torch.seed() % (2 ** 31))
+        seed_g.manual_seed(self._replicated_seed(seed))
         lat_frames = (frame_num - 1) // self.vae_stride[0] + 1                       # any2video.py:647
         # start + end image (any2video.py:684-691): the Wan2.1 i2v model gets one extra frame -- one more latent frame, encoded
         # without the causal cache and trimmed from the latents before decoding; Wan2.2 i2v keeps the frame count
@@ -397,9 +435,15 @@ class WanAny2VHIP:
         # the VAE latents of the source frames replace the first latent frames before every step and after the last one, and
         # those frames are given timestep 0 -- a per-frame t vector
         source_latents = None
+        if input_video is not None and getattr(self.model, "model_type", None) != "ti2v2_2":
+            # any2video.py:571 is the ONLY line that reads input_video for a t2v-class / VACE model -- height and width, taken above.
+            # wgp.py passes it to every model type for every sliding window after the first (wgp.py:7740, :7995: input_video =
+            # pre_video_guide, the overlap frames of the previous window); the VACE path takes those frames from input_frames /
+            # overlapped_latents instead (any2video.py:837, :1150-1163)
+            input_video = None
         if input_video is not None:
-            if getattr(self.model, "model_type", None) != "ti2v2_2" or self.vae is None:
-                raise ValueError("input_video (timestep injection) is the ti2v_2_2 conditioning path and needs the Wan2.2 VAE")
+            if self.vae is None:
+                raise ValueError("input_video (timestep injection, the ti2v_2_2 conditioning path) needs the Wan2.2 VAE")
             source_latents = self.vae.encode([input_video.to(dev)], VAE_tile_size)[0].unsqueeze(0)
         v2v, v2v_src, randn, start_step_no = None, None, None, 0
         original_timesteps = timesteps            # any2video.py:546: the whole schedule, also when video-to-video cuts it short
@@ -532,11 +576,11 @@ class WanAny2VHIP:
                 if ext_latents is not None:                      # any2video.py:1517-1523: re-noise the known first latent
                     f = float(t) / 1000.0
                     n = ext_latents.shape[2]
-                    latents[:, :, :n] = ext_latents * (1.0 - f) + torch.randn_like(ext_latents) * f
+                    latents[:, :, :n] = ext_latents * (1.0 - f) + self._replicated_randn_like(ext_latents) * f
                     if vace_overlap:                             # :1523-1526: the context's overlap frames get `overlap_noise` / 1000 of noise
                         of = overlap_noise / 1000
                         for zz in vace_kwargs["vace_context"]:
-                            zz[0:16, ref_count:n] = ext_latents[0, :, ref_count:] * (1.0 - of) + torch.randn_like(ext_latents[0, :, ref_count:]) * of
+                            zz[0:16, ref_count:n] = ext_latents[0, :, ref_count:] * (1.0 - of) + self._replicated_randn_like(ext_latents[0, :, ref_count:]) * of
                 def denoise_with_cfg(lat):                       # denoise_with_cfg_fn, plain two-stream branch (any2video.py:1610-1722)
                     nonlocal text_momentum
                     if guide_scale == 1 or not any_guidance:
