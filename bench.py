@@ -113,7 +113,7 @@ def _cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(flops_step_main, sweep=(8, 16, 32, 64, 128)):
+def cpu_baseline(flops_step_main, sweep=(8, 16, 32, 64, 128), _cfg_name="t2v_1.3B", _fhw=(5, 40, 64)):
     """BASELINE.md section 3 on the host cores of this box, through the oracle: kind "port" = the CPU restatement of the
     reference (oracle/wan_oracle.py, oracle/vae_oracle.py), bit-exact to the reference's own modules on tests/golden/cfg1_*.npz
     and vae_small.npz.  The reference tree itself does not travel to the GPU box (/root/reference exists only in the build
@@ -131,8 +131,8 @@ def cpu_baseline(flops_step_main, sweep=(8, 16, 32, 64, 128)):
     import torch
     from oracle import vae_oracle as VO
     from oracle import wan_oracle as O
-    cfg = O.make_config("t2v_1.3B")
-    f, h, w = 5, 40, 64
+    cfg = O.make_config(_cfg_name)                   # (the underscore arguments exist for the CPU test: a tiny stand-in, seconds)
+    f, h, w = _fhw
     t0 = time.perf_counter()
     W = O.synth_weights(cfg)
     t_w = time.perf_counter() - t0

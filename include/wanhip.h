@@ -132,7 +132,8 @@ int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* scale_a, const uint
  * head_dim 128, scale 1/sqrt(128).  Replaces pay_attention(qkv_list) -> sdpa_wrapper
  * (shared/attention.py:360-373, :208-225) as called from model.py:264,385.
  *   q  : [B, Lq, H, 128]   (row stride H*128)
- *   k  : [Bk, Lk, H, 128]  Bk == B or 1 (broadcast, attention.py:415)
+ *   k  : [Bk, Lk, H, 128]  Bk divides B: q batch b attends K / V^T batch b mod Bk (Bk == B: its own; Bk == 1: the
+ *                          broadcast of attention.py:415; in between: the Ulysses layout, q batches = (source rank, stream))
  *   vt : [Bk, H*128, ldv]  V transposed (kv contiguous), columns [Lk, ldv) must be finite;
  *        ldv % 64 == 0.  Produced directly by wan_gemm_bf16(WAN_EPI_TRANSPOSED) or by
  *        wan_transpose_v for callers that hold V as [B, Lk, H, 128].
@@ -274,6 +275,9 @@ int wan_dequant_i8(const int8_t* data, const float* scale, wan_bf16* out, int64_
  * (fm_solvers_unipc.py:313-315 x0 = x - sigma*v, :350-480 UniP, :482-626 UniC;
  * euler_scheduler.py:79) and CFG (any2video.py:1722) are all such combinations with host
  * scalars; coefficients are computed on the host exactly as the reference does. */
+/* Block transpose (the Ulysses re-packs, wan_dit_forward with WAN_SP_ULYSSES): src [A][B][bytes] -> dst [B][A][bytes], bytes a
+ * multiple of 16, src != dst.  One pass at the copy rate. */
+int wan_permute16(const void* src, void* dst, int64_t A, int64_t B, int64_t bytes, void* stream);
 int wan_lincomb(float* out, int n_in, const float* const* in, const float* coef, int64_t n,
                 void* stream);
 
@@ -331,12 +335,24 @@ typedef int (*wan_poll_fn)(void* user, int block_idx);
 typedef int (*wan_gather_begin_fn)(void* user, int which, const void* send, void* recv, int64_t bytes,
                                    void* stream);
 typedef int (*wan_gather_wait_fn)(void* user, int which, void* stream);
+/* mode WAN_SP_ULYSSES (round 4): the other way to shard self-attention -- instead of gathering every rank's K / V^T, an
+ * ALL-TO-ALL re-shards q, k, v from "my tokens, all heads" to "all tokens, my heads" (H % world == 0), the rank attends the whole
+ * sequence for H / world heads in ONE launch, and a fourth all-to-all brings the output back to token shards.  Per block and rank
+ * 4 x (world - 1) / world x S L/world d 2 bytes move (0.68 GB at 8 ranks, 14B, 720p x 81 f) instead of 2 (world - 1) of them
+ * (2.71 GB); the k and v exchanges hide under the V and Q projections, the q and o exchanges do not.
+ *   a2a_begin(user, which, send, recv, bytes_per_peer, stream): send = world chunks of bytes_per_peer, chunk j for rank j; recv
+ *       = world chunks, chunk i from rank i; which 0 = k, 1 = v^T, 2 = q, 3 = o.  Same ordering contract as gather_begin.
+ *   a2a_wait(user, which, stream). */
+enum { WAN_SP_ALLGATHER = 0, WAN_SP_ULYSSES = 1 };
 typedef struct {
   int rank, world;          /* this rank, number of sequence shards */
   int64_t tok0, tok_local;  /* first global token and number of local tokens */
   wan_gather_begin_fn gather_begin;
   wan_gather_wait_fn gather_wait;
   void* user;
+  int mode;                 /* WAN_SP_ALLGATHER (gather_* are used) or WAN_SP_ULYSSES (a2a_* are used) */
+  wan_gather_begin_fn a2a_begin;
+  wan_gather_wait_fn a2a_wait;
 } wan_sp_info;
 
 /* A library-owned RCCL communicator for those hooks (SURVEY.md section 8b `wan_sp_init(rank, nranks, ncclUniqueId)`): one
@@ -352,6 +368,9 @@ int wan_sp_init(wan_sp** out, int rank, int nranks, const void* id128);
 void wan_sp_destroy(wan_sp* sp);
 int wan_sp_gather_begin(void* sp, int which, const void* send, void* recv, int64_t bytes, void* stream);
 int wan_sp_gather_wait(void* sp, int which, void* stream);
+/* the all-to-all pair of WAN_SP_ULYSSES on the same communicator and side stream (grouped ncclSend / ncclRecv: `bytes` to and from
+ * every peer; the rank's own chunk is a device-to-device copy); which = 0..3; wait with wan_sp_gather_wait */
+int wan_sp_a2a_begin(void* sp, int which, const void* send, void* recv, int64_t bytes, void* stream);
 int wan_sp_all_gather(wan_sp* sp, const void* send, void* recv, int64_t bytes, void* stream);
 
 /* WanModel.forward for the t2v / i2v2_2 path (model.py:1485-2098): S streams (the joint CFG

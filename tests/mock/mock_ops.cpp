@@ -104,6 +104,7 @@ int wan_attention_sp_remote(const wan_bf16* q, const wan_bf16* k, const wan_bf16
                             int H, int nseg, int64_t ks, int64_t vs, int own, float* scratch, float* raw, void*) {
   return rec("attention_sp_remote", {q, k, vt, o, scratch, raw}, {B, Lq, Lk, ldv, H, nseg, ks, vs, own});
 }
+int wan_permute16(const void* src, void* dst, int64_t A, int64_t B, int64_t bytes, void*) { return rec("permute16", {src, dst}, {A, B, bytes}); }
 int wan_act_bf16(const wan_bf16* x, wan_bf16* y, int64_t n, int act, void*) { return rec("act", {x, y}, {n, act}); }
 int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C, int M, int N, int K, void*) {
   return rec("gemv", {A, W, bias, C}, {M, N, K});

@@ -85,6 +85,33 @@ def _worker(rank, world, port, q):
         assert len(m.calls) == 5 and all(n == 1 and x_id == cfgp.stream for n, x_id, _ in m.calls)
         assert all(abs(cm - (0.5 if cfgp.stream == 0 else 0.0)) < 1e-6 for _, _, cm in m.calls)   # its own stream's prompt
         assert torch.equal(out, ref), f"max diff {(out - ref).abs().max().item()}"
+        # i2v: the pinned start frame is re-noised before every step from the PROCESS-GLOBAL generator (any2video.py:1517-1523), which
+        # `seed` does not seed and which differs between ranks (here: seeded with the rank).  Rank 0's draw must reach every rank --
+        # otherwise the two halves denoise different latents and the combine mixes predictions of two inputs (round-3 advisor finding)
+        class StubVAE:
+            def encode(self, videos, tile_size=0, any_end_frame=False):
+                out = []
+                for v in videos:
+                    T, H, W = v.shape[1:]
+                    base = torch.nn.functional.adaptive_avg_pool3d(v[None].float(), ((T - 1) // 4 + 1, H // 8, W // 8))[0].mean(0, keepdim=True)
+                    out.append(base.repeat(16, 1, 1, 1) + torch.arange(16).view(16, 1, 1, 1) * 0.01)
+                return out
+        img = torch.rand(3, 64, 64, generator=torch.Generator().manual_seed(9)) * 2 - 1
+        mi_ref = StreamDiT(); mi_ref.model_type = "i2v2_2"
+        torch.manual_seed(1000)                                  # the state rank 0 starts the parallel run from
+        ref_i = _generate(WanAny2VHIP(mi_ref, vae=StubVAE(), device="cpu"), image_start=img)
+        mi = StreamDiT(); mi.model_type = "i2v2_2"
+        pi = WanAny2VHIP(mi, vae=StubVAE(), device="cpu")
+        pi.cfg_parallel = cfgp.attach(mi)
+        torch.manual_seed(1000 + rank)
+        out_i = _generate(pi, image_start=img)
+        assert torch.equal(out_i, ref_i), f"i2v under CFG parallelism: max diff {(out_i - ref_i).abs().max().item()}"
+        assert not torch.equal(ref_i, ref)
+        # a negative seed means "draw one": rank 0's draw, on every rank
+        drawn = [pi._replicated_seed(-1)]
+        allr = [None] * world
+        dist.all_gather_object(allr, drawn[0])
+        assert len(set(allr)) == 1
         # without guidance every rank runs the one forward there is (no swap)
         m1 = StreamDiT()
         p1 = WanAny2VHIP(m1, device="cpu")

@@ -278,6 +278,85 @@ def test_sequence_parallel_call_order(mock, S):
     assert all(cl[2][7] == 1 for cl in hd)                               # token-major output for the gather
 
 
+@pytest.mark.parametrize("S", [2, 1])
+def test_ulysses_call_order_layouts_and_buffer_lifetimes(mock, S):
+    """WAN_SP_ULYSSES (round 4): per layer K projection -> norm + RoPE -> head-group-major re-pack -> k all-to-all begins; V^T
+    projections (+ the [S][world] -> [world][S] block swap when S = 2) -> v^T all-to-all; Q projection -> norm -> re-pack -> q
+    all-to-all; the three waits; ONE attention launch over world x S query batches of L / world rows against S K / V^T batches in
+    `world` segments, H / world heads; o all-to-all, its wait, the re-pack back to token-major, the output projection.  Chunk sizes
+    are what one peer receives; every buffer lies inside the workspace; a buffer is never rewritten while its exchange is in flight."""
+    from wan2gp_amd.lib import SP_ULYSSES
+    m = Model(mock)
+    c, (F, H, W) = m.cfg, (2, 8, 8)
+    L_, world = F * 16, 2
+    Ll, d, nh = L_ // world, c.dim, c.num_heads
+    Hn, Wd, Lp, rows = nh // world, nh // world * 128, (Ll + 63) // 64 * 64, S * Ll
+    events = []
+
+    def begin(user, which, send, recv, nbytes, stream):
+        events.append(("begin", which, send, recv, nbytes, mock.mock_count()))
+        return 0
+
+    def wait(user, which, stream):
+        events.append(("wait", which, mock.mock_count()))
+        return 0
+    cb, cw = GATHER_FN(begin), GATHER_WAIT_FN(wait)
+    never = GATHER_FN(lambda *a: pytest.fail("the all-gather hooks must not be used in Ulysses mode"))
+    sp = SpInfo(1, world, Ll, Ll, never, GATHER_WAIT_FN(lambda *a: 1), None, SP_ULYSSES, cb, cw)
+    rc, calls, nbytes = m.forward(S=S, sp=sp)
+    assert rc == 0, mock.wan_last_error()
+    assert len(events) == 8 * c.num_layers
+    names = [cl[0] for cl in calls]
+    assert "attention_sp_local" not in names and "attention_sp_remote" not in names
+    for layer in range(c.num_layers):
+        ev = events[8 * layer:8 * layer + 8]
+        assert [(e[0], e[1]) for e in ev] == [("begin", 0), ("begin", 1), ("begin", 2), ("wait", 0), ("wait", 1), ("wait", 2), ("begin", 3), ("wait", 3)]
+        bk, bv, bq, w0, w1, w2, bo, wo = ev
+        assert bk[4] == bq[4] == bo[4] == rows * Wd * 2 and bv[4] == S * Wd * Lp * 2              # bytes per PEER
+        # in front of the k exchange: K projection, norm + RoPE at the shard's positions, the re-pack into the send buffer
+        pre = calls[bk[5] - 3:bk[5]]
+        assert [cl[0] for cl in pre] == ["gemm", "rmsnorm_rope", "permute16"] and pre[1][2][2] == Ll
+        assert pre[2][2][:3] == [rows, world, Wd * 2] and pre[2][1][1] == bk[2]                    # [rows][world][W] -> [world][rows][W] = what is sent
+        # under the k exchange: the V^T projections (+ the block swap for S = 2); the v^T exchange sends what they left
+        under_k = [cl[0] for cl in calls[bk[5]:bv[5]]]
+        assert under_k == ["gemm"] * S + (["permute16"] if S > 1 else [])
+        if S > 1:
+            sw = calls[bv[5] - 1]
+            assert sw[2][:3] == [S, world, Wd * Lp * 2] and sw[1][1] == bv[2]
+        else:
+            assert calls[bv[5] - 1][1][3] == bv[2]                                                    # S = 1: sent straight from the epilogue's image
+        under_v = [cl[0] for cl in calls[bv[5]:bq[5]]]
+        assert under_v == ["gemm", "rmsnorm_rope", "permute16"]                                       # Q projection + norm + re-pack under the v^T exchange
+        assert calls[bq[5] - 1][1][1] == bq[2]
+        assert w0[2] == w1[2] == w2[2] == bq[5]                                                       # nothing between the q exchange and the waits
+        att = calls[w2[2]]
+        assert att[0] == "attention" and att[2][:10] == [world * S, S, Ll, Ll, Lp, Hn, world, rows * Wd, S * Wd * Lp, 1]
+        assert (att[1][0], att[1][1], att[1][2]) == (bq[3], bk[3], bv[3])                            # q / k / v^T as RECEIVED
+        assert att[1][3] == bo[2] == bk[2]                                                           # o written over the dead k send buffer = the o exchange's send
+        assert bo[3] == bq[2]                                                                        # ... and received over the dead q send buffer
+        back = calls[wo[2]]
+        assert back[0] == "permute16" and back[2][:3] == [world, rows, Wd * 2] and back[1][0] == bo[3]
+        proj = calls[wo[2] + 1]
+        assert proj[0] == "gemm" and proj[1][0] == back[1][1] and proj[2][5] == 2                     # the output projection (gated residual) reads the re-packed rows
+        # the six exchange buffers are distinct and inside the workspace
+        bufs = [(bk[2], rows * d * 2), (bk[3], rows * d * 2), (bq[2], rows * d * 2), (bq[3], rows * d * 2), (bv[3], S * d * Lp * 2)]
+        if S > 1:
+            bufs.append((bv[2], S * d * Lp * 2))
+        for a, na in bufs:
+            assert in_ws(a, nbytes) and in_ws(a + na - 1, nbytes)
+        for i, (a, na) in enumerate(bufs):
+            for b, nb in bufs[i + 1:]:
+                assert a + na <= b or b + nb <= a, (hex(a), na, hex(b), nb)
+    # heads the world does not divide: refused before anything is enqueued
+    sp3 = SpInfo(0, 4, 0, L_ // 4, never, GATHER_WAIT_FN(lambda *a: 1), None, SP_ULYSSES, cb, cw)
+    rc, calls, _ = m.forward(S=S, sp=sp3)
+    assert rc == 1 and b"head count" in mock.wan_last_error() and not calls
+    # a failing exchange stops the forward at that block
+    fail = GATHER_FN(lambda user, which, *a: 1 if which == 2 else 0)
+    rc, calls, _ = m.forward(S=S, sp=SpInfo(1, world, Ll, Ll, never, GATHER_WAIT_FN(lambda *a: 1), None, SP_ULYSSES, fail, cw))
+    assert rc == 3 and b"all-to-all 2" in mock.wan_last_error() and "attention" not in [cl[0] for cl in calls if cl[0] == "attention" and cl[2][6] == world]
+
+
 def test_sequence_parallel_failing_gather_hook_stops_the_forward_with_an_error(mock):
     """Failure modes of the collective hooks (RCCL error, a Python exception inside the torch.distributed callback -> non-zero
     return): the forward stops at that block with rc 3 and a message that names the gather; nothing after it is enqueued, and a

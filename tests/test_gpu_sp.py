@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, backend="gloo", native=False):
+def _worker(rank, world, port, q, backend="gloo", native=False, mode="allgather", fhw=(4, 12, 16)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     import torch.distributed as dist
@@ -36,11 +36,11 @@ def _worker(rank, world, port, q, backend="gloo", native=False):
         W = O.synth_weights(cfg, seed=77)
         m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers)
         m.load_state_dict(W)
-        f, h, w = 4, 12, 16                    # L = 4*6*8 = 192 tokens -> 96 per rank (not a multiple of 64)
+        f, h, w = fhw                          # default: L = 4*6*8 = 192 tokens -> 96 per rank (not a multiple of 64)
         lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w, seed=9)
         t = torch.tensor([412])
         ref = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])
-        m.sp = SequenceParallel(rank, world, native=native)
+        m.sp = SequenceParallel(rank, world, native=native, mode=mode)
         got = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])
         for g, r in zip(got, ref):
             assert g.shape == r.shape
@@ -66,6 +66,44 @@ def test_sp_forward_two_ranks_one_gpu():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+@pytest.mark.parametrize("world,fhw", [(2, (4, 12, 16)), (4, (4, 12, 16)), (2, (9, 32, 32))], ids=["world2_L192", "world4_L192", "world2_L2304_long_kv"])
+def test_ulysses_forward_ranks_on_one_gpu(world, fhw):
+    """WAN_SP_ULYSSES end to end on the HIP path (all ranks on cuda:0, the four all-to-alls per block staged through the host by gloo):
+    re-packs, v^T block swap, ONE attention launch over world x S query batches against S K / V^T batches in `world` segments with
+    H / world heads, the way back -- every rank must reproduce the single-rank forward of both CFG streams.  4 heads: world 2 (2 heads
+    per rank) and 4 (1 head, 48 tokens per rank: one padded V^T tile); L = 2,304 takes the long-KV kernels (plain / shifted bounded
+    loop with the segment walk) instead of the tracking loop."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "gloo", False, "ulysses", fhw)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+@pytest.mark.parametrize("native", [False, True], ids=["torch_distributed", "library_communicator"])
+def test_ulysses_forward_rccl_when_two_gpus_are_present(native):
+    """The same over RCCL: `all_to_all_single(async_op=True)` (torch.distributed owns the communicator) and the library's own grouped
+    ncclSend / ncclRecv (wan_sp_a2a_begin).  Needs >= 2 GPUs: skipped on the single-GPU boxes."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "nccl", native, "ulysses")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
 def test_sp_forward_rccl_when_two_gpus_are_present():

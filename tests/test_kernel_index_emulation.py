@@ -907,7 +907,7 @@ def _shifted_softmax_rows(qt, k, v, L_tile0=64):
     u = np.sqrt(u2) * f(1.0001) + f(0.01)
     m_cs = np.where(u2 <= f(96.0 * 96.0), f(0), u - f(96.0)).astype(f)
     ms = s[:, :L_tile0].max(1)
-    m = np.where(m_cs == 0, f(0), np.where(u - ms <= f(176.0), m_cs, ms + f(80.0))).astype(f)
+    m = np.where(m_cs == 0, f(0), np.where(u - ms <= f(168.0), m_cs, ms + f(72.0))).astype(f)
     with np.errstate(over="ignore", under="ignore", invalid="ignore"):
         p = np.exp2((s - m[:, None]).astype(f)).astype(f)                     # inf above 2^128, 0 below 2^-149 (the hardware flushes earlier: 2^-126)
         p = np.where(p < f(2.0 ** -126), f(0), p)
@@ -921,7 +921,7 @@ def _shifted_softmax_rows(qt, k, v, L_tile0=64):
 def test_shifted_bounded_softmax_covers_what_the_plain_bound_declined_and_flags_the_rest():
     """The algebra the SHIFT instantiation rests on, on the CPU in fp32: (1) wherever a row is not flagged its result is the fp64
     softmax's (shift invariance; what underflows is < 2^-46 of the row sum per term); (2) diffuse random rows are never flagged up to
-    gains far beyond round 3's limit (gamma ~ 6 declined everything); (3) a row whose maximum sits more than 176 above what its first
+    gains far beyond round 3's limit (gamma ~ 6 declined everything); (3) a row whose maximum sits more than 168 above what its first
     64 keys suggest overflows, is FLAGGED, and is never returned as a number; (4) rows inside the plain bound keep m = 0 (the plain
     kernel's arithmetic, bit for bit)."""
     rng = np.random.default_rng(5)

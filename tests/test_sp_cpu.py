@@ -151,3 +151,125 @@ def test_gather_callbacks_fill_every_ranks_slot_in_rank_order(world):
         p.join(timeout=30)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+# ---- Ulysses (WAN_SP_ULYSSES): the four all-to-alls of a block with the layouts of csrc/dit.hip, on oracle arithmetic ---------------
+def _ulysses_worker(rank, world, port, q, cfg_name):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wan2gp_amd.lib import SP_ULYSSES
+        from wan2gp_amd.sp import SequenceParallel, shard_range
+        torch.set_num_threads(2)
+        sp = SequenceParallel(rank, world, mode="ulysses")
+        cfg = O.make_config(cfg_name)
+        W = O.synth_weights(cfg, dtype=torch.float32)
+        f, h, w = 2, 8, 8
+        S = 2
+        lats = [O.synth_inputs(cfg, f, h, w, seed=42 + s)[0] for s in range(S)]
+        ctx = O.synth_inputs(cfg, f, h, w)[1]
+        grid = (f, h // 2, w // 2)
+        L = f * (h // 2) * (w // 2)
+        tok0, Ll = shard_range(L, rank, world)
+        H, d = cfg.num_heads, cfg.dim
+        assert H % world == 0
+        Hn, Wd, Lp, rows = H // world, H // world * 128, (Ll + 63) // 64 * 64, S * Ll
+        cos, sin = O.rope_tables(grid)
+        t = torch.tensor([500])
+        dt = torch.float32
+        e, e0 = O.time_embed(t, W, cfg, dt)
+        cemb = O.text_embed(ctx.float(), W)
+        info = sp.make_info(L)
+        assert (info.mode, info.rank, info.world, info.tok0, info.tok_local) == (SP_ULYSSES, rank, world, tok0, Ll)
+        # the forward's exchange buffers as ONE flat fp32 "workspace" (the callbacks address it by byte offsets)
+        blkq, blkv = rows * d, S * d * Lp
+        ws = torch.zeros(4 * blkq + 2 * blkv, dtype=torch.float32)
+        sp.bind_workspace(ws.view(torch.uint8))
+        base, el = ws.data_ptr(), 4
+        ks, kr, qs, qr = (ws[i * blkq:(i + 1) * blkq] for i in range(4))
+        vs, vr = ws[4 * blkq:4 * blkq + blkv], ws[4 * blkq + blkv:]
+
+        def permute16(src, A, B, n):                              # wan_permute16: [A][B][n] -> [B][A][n]
+            return src.reshape(A, B, n).transpose(0, 1).contiguous().reshape(-1)
+
+        def a2a(which, send, recv, n_per_peer):
+            assert sp._a2a_begin_cb(None, which, send.data_ptr(), recv.data_ptr(), n_per_peer * el, None) == 0
+
+        refs, xs = [], []
+        for s in range(S):
+            full_h, _ = O.patch_embed(lats[s], W, cfg, dt)
+            refs.append(O.block_forward(full_h, e0, cemb, cos, sin, W, 0, cfg, exact=True))
+            xs.append(full_h[:, tok0:tok0 + Ll])
+        p = "blocks.0."
+        sa = p + "self_attn."
+        ee = (W[p + "modulation"] + e0).chunk(6, dim=1)
+        xm = torch.cat([O.layer_norm(x, cfg.eps) * (1 + ee[1]) + ee[0] for x in xs], dim=1)[0]          # [S Ll, d]: the streams stacked as rows
+        pos = slice(tok0, tok0 + Ll)
+
+        def normed(name, nw):
+            y = O.rms_norm(O._linear(xm, W, sa + name), W[sa + nw], cfg.eps).view(S, Ll, H, 128)
+            return O.rope_apply(y, cos[pos], sin[pos]).reshape(rows, d)
+        # k: projection, norm + RoPE, re-pack head-group-major, exchange
+        ks.copy_(permute16(normed("k", "norm_k.weight"), rows, world, Wd)); a2a(0, ks, kr, rows * Wd)
+        # v^T: the transposed epilogue's [S][d][Lp] image (zero padded), blocks swapped [S][world] -> [world][S], exchange
+        vt = torch.zeros(S, d, Lp)
+        vt[:, :, :Ll] = O._linear(xm, W, sa + "v").view(S, Ll, d).transpose(1, 2)
+        vs.copy_(permute16(vt.reshape(-1), S, world, Wd * Lp)); a2a(1, vs, vr, S * Wd * Lp)
+        qs.copy_(permute16(normed("q", "norm_q.weight"), rows, world, Wd)); a2a(2, qs, qr, rows * Wd)
+        for wch in range(3):
+            assert sp._a2a_wait_cb(None, wch, None) == 0
+        # ONE attention over world x S query batches of Ll rows, S K / V^T batches in `world` segments, Hn heads (q batch b -> b mod S)
+        Q = qr.view(world, S, Ll, Hn, 128)
+        K = kr.view(world, S, Ll, Hn, 128)
+        V = vr.view(world, S, Hn, 128, Lp)
+        out = torch.empty(world, S, Ll, Hn, 128)
+        for s in range(S):
+            kf = K[:, s].reshape(1, world * Ll, Hn, 128)                                               # the segments in rank order = token order
+            vf = V[:, s, :, :, :Ll].permute(0, 3, 1, 2).reshape(1, world * Ll, Hn, 128)
+            for i in range(world):
+                out[i, s] = O.attention(Q[i, s].unsqueeze(0), kf, vf, exact=True)[0]
+        # o: written in the send layout of the way back (over the dead k send buffer), received over the dead q send buffer
+        ks.copy_(out.reshape(-1)); a2a(3, ks, qs, rows * Wd)
+        assert sp._a2a_wait_cb(None, 3, None) == 0
+        o_rows = permute16(qs, world, rows, Wd).view(S, Ll, d)
+        assert sp.a2a_bytes == (3 * rows * Wd + S * Wd * Lp) * el * (world - 1)
+        for s in range(S):
+            x = torch.addcmul(xs[s], O._linear(o_rows[s:s + 1], W, sa + "o"), ee[2])
+            y = O.layer_norm(x, cfg.eps, W[p + "norm3.weight"], W[p + "norm3.bias"])
+            x = x + O.cross_attention(y, cemb, W, p + "cross_attn.", cfg, True)
+            y = O.layer_norm(x, cfg.eps) * (1 + ee[4]) + ee[3]
+            y = O._linear(torch.nn.functional.gelu(O._linear(y, W, p + "ffn.0"), approximate="tanh"), W, p + "ffn.2")
+            x = torch.addcmul(x, y, ee[5])
+            assert torch.allclose(x, refs[s][:, tok0:tok0 + Ll], atol=1e-4, rtol=1e-4), (s, (x - refs[s][:, tok0:tok0 + Ll]).abs().max().item())
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,cfg_name", [(2, "tiny"), (4, "small")])
+def test_ulysses_exchanges_with_the_forwards_layouts(world, cfg_name):
+    """The four all-to-alls of a WAN_SP_ULYSSES block through sp.py's callbacks, with the buffer layouts csrc/dit.hip uses (re-pack
+    [rows][world][W] -> [world][rows][W]; v^T blocks [S][world] -> [world][S]; received = world x S query batches and `world` K / V^T
+    segments; o back over the dead send buffers): every rank's block output equals the single-process oracle block on its token
+    shard, for both CFG streams.  world 2: 2 heads -> 1 per rank; world 4: 4 heads, 8 tokens per rank (one padded V^T tile)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ulysses_worker, args=(r, world, port, q, cfg_name)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_sequence_parallel_mode_is_validated():
+    from wan2gp_amd.sp import SequenceParallel
+    with pytest.raises(ValueError):
+        SequenceParallel(0, 2, mode="ring")
+    assert SequenceParallel(0, 2, mode="ulysses").mode == "ulysses" and SequenceParallel(0, 2).mode == "allgather"

@@ -44,20 +44,13 @@ extern "C" int64_t wan_attention_scratch_words(int B, int Bk, int64_t Lq, int H)
   return (int64_t)Bk * H + ((Lq + 255) / 256) * H * B + (int64_t)Bk * H;
 }
 
-// Library-owned scratch for the K pre-pass of callers that bring none (wan_attention / _seg / _prescaled): a ring of
-// 16 slots x 64 Ki words, so that calls enqueued on different streams do not share a slot unless > 16 are in flight.
-// wan_dit_forward passes a slice of its own workspace instead (wan_attention_bounded).
-constexpr int64_t KMAX_SLOT = 65536, KMAX_NSLOT = 16;
-static float* kmax_ring_slot(int64_t need) {
-  static float* ring = nullptr;
-  static unsigned next = 0;
-  if (need > KMAX_SLOT) return nullptr;
-  if (ring == nullptr && hipMalloc((void**)&ring, (size_t)KMAX_SLOT * KMAX_NSLOT * sizeof(float)) != hipSuccess) {
-    ring = nullptr;
-    (void)hipGetLastError();
-    return nullptr;  // no scratch: the kernel runs its tracking loop
-  }
-  return ring + (size_t)(next++ % KMAX_NSLOT) * KMAX_SLOT;
+// Library-owned scratch for the K pre-pass of callers that bring none (wan_attention / _seg / _prescaled): rings of 16 slots x
+// 64 Ki words per (device, stream) (common.h wan_scratch_ring_slot).  wan_dit_forward passes a slice of its own workspace instead
+// (wan_attention_bounded).
+constexpr int64_t KMAX_SLOT = 65536;
+constexpr int KMAX_NSLOT = 16;
+static float* kmax_ring_slot(int64_t need, hipStream_t stream) {
+  return reinterpret_cast<float*>(wan_scratch_ring_slot(/*tag=*/2, (size_t)KMAX_SLOT * sizeof(float), KMAX_NSLOT, (size_t)need * sizeof(float), stream));
 }
 
 enum { SCRATCH_NONE = 0, SCRATCH_RING = 1, SCRATCH_CALLER = 2 };
@@ -66,7 +59,7 @@ static int attention_dispatch(const wan_bf16* q, const wan_bf16* k, const wan_bf
                               int64_t vt_seg_stride, bool q_prescaled, int scratch_kind, float* scratch, void* stream) {
   WAN_REQUIRE(q && k && vt && o, "wan_attention: null pointer");
   WAN_REQUIRE(nseg >= 1, "wan_attention: nseg must be >= 1");
-  WAN_REQUIRE(B >= 1 && (Bk == B || Bk == 1), "wan_attention: Bk must be B or 1 (B=%d Bk=%d)", B, Bk);
+  WAN_REQUIRE(B >= 1 && Bk >= 1 && B % Bk == 0, "wan_attention: Bk must divide B (q batch b attends K / V^T batch b mod Bk; B=%d Bk=%d)", B, Bk);
   WAN_REQUIRE(Lq >= 1 && Lk >= 1 && H >= 1, "wan_attention: empty problem (Lq=%lld Lk=%lld H=%d)", (long long)Lq,
               (long long)Lk, H);
   WAN_REQUIRE(ldv % KVBLK == 0 && ldv >= Lk, "wan_attention: ldv=%lld must be a multiple of 64 and >= Lk",
@@ -84,7 +77,7 @@ static int attention_dispatch(const wan_bf16* q, const wan_bf16* k, const wan_bf
     // keys, a visible 2^-9 for a handful (Lk = 1: O = bf16(2^s) v / 2^s instead of v) -- short KV always takes the tracking
     // loop, whose dominant term is exactly 1
     float* km = nullptr;
-    if (long_kv) km = scratch_kind == SCRATCH_CALLER ? scratch : (scratch_kind == SCRATCH_RING ? kmax_ring_slot(wan_attention_scratch_words(B, Bk, Lq, H)) : nullptr);
+    if (long_kv) km = scratch_kind == SCRATCH_CALLER ? scratch : (scratch_kind == SCRATCH_RING ? kmax_ring_slot(wan_attention_scratch_words(B, Bk, Lq, H), as_stream(stream)) : nullptr);
     return wan_attention_w64q_launch(q_prescaled ? 2 : 0, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nseg, k_seg_stride,
                                      vt_seg_stride, SCALE_LOG2E, km, as_stream(stream));
   }

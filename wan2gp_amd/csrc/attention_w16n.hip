@@ -293,14 +293,14 @@ __device__ __forceinline__ mfma_bf16x8 prescale8_16(const uint4 raw, float c) {
 //   shifted (SHIFT = 1, round 4)  runs the workgroups flagged 2: the SAME loop, instruction for instruction, with P = 2^(s - m) for a
 //                      per-row constant m that enters through the C operand of every S tile's first MFMA.  The row's true maximum
 //                      lies in [m_s, U]: U by Cauchy-Schwarz, m_s = its maximum over the 64 keys of tile 0 (one S phase in the
-//                      prologue).  U - m_s <= 176: m = U - 96, nothing can overflow or lose its maximum -- guaranteed.  Wider: m =
-//                      m_s + 80 and the interval [m_s, m_s + 176] for the true maximum.  Nothing in the loop watches the exponent range
+//                      prologue).  U - m_s <= 168: m = U - 96, nothing can overflow or lose its maximum -- guaranteed.  Wider: m =
+//                      m_s + 72 and the interval [m_s, m_s + 168] for the true maximum.  Nothing in the loop watches the exponent range
 //                      -- the row sum does: a row that left it ends with l outside [2^-80, 2^100] (or NaN), the workgroup then flags
 //                      itself 1 AFTER the loop and the tracking launch redoes it.  (Partial launches -- RAW_OUT / CARRY_IN -- must agree
 //                      on m without seeing each other's tiles: m = U - 96 only.)  Softmax is shift invariant, so wherever l >= 2^-80 the result is
 //                      the max-subtracting kernel's: the terms that underflowed are < 2^-46 of the row sum each.  What this buys: the
 //                      fast loop no longer depends on RMSNorm gains staying near 1 -- diffuse random heads pass while the maximum of L
-//                      scores stays within 176 of the maximum of 64 (gamma_q gamma_k ~ 40; plain: ~ 6), peaky rows (true maximum near
+//                      scores stays within 168 of the maximum of 64 (gamma_q gamma_k ~ 40; plain: ~ 6), peaky rows (true maximum near
 //                      U) at any gain up to SHIFT_LIMIT.
 //   tracking           attention_w64q.hip's instantiation: the workgroups flagged 1.
 // Partial sums (sequence parallelism): RAW_OUT leaves them shifted by m(local max|k|); the CARRY_IN launch recomputes that m from the
@@ -308,7 +308,9 @@ __device__ __forceinline__ mfma_bf16x8 prescale8_16(const uint4 raw, float c) {
 constexpr float SHIFT_LIMIT = 2048.0f;      // |m| beyond this costs the fp32 scores visible bits: tracking loop
 constexpr float SHIFT_MIN_ROWSUM = 8.271806125530277e-25f;  // 2^-80
 constexpr float SHIFT_MAX_ROWSUM = 1.2676506002282294e30f;  // 2^100: |sum P V| <= l max|v| stays finite for |v| < 2^27
-constexpr float SHIFT_UNDER = 80.0f, SHIFT_WINDOW = 176.0f;  // a row maximum may lie 80 below its reference m and 96 above it
+// a row maximum may lie 72 below its reference m (its term is then 2^-72: the row sum clears 2^-80 by itself -- with 80 the first
+// hardware run flagged the rows whose largest key sits in tile 0, l = 2^-80 (1 + tiny) rounding below the bar) and 96 above it
+constexpr float SHIFT_UNDER = 72.0f, SHIFT_WINDOW = 168.0f;
 __device__ __forceinline__ float ref_shift16(float u2) {     // u2 = U^2 of a row; the reference m its scores are shifted by
   return u2 <= BOUND16_LOG2 * BOUND16_LOG2 ? 0.f : __builtin_amdgcn_sqrtf(u2) * 1.0001f + 0.01f - BOUND16_LOG2;  // 1-ulp sqrt + margin
 }
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   const int pair = v / nqb;
   const int qb = v - pair * nqb;
   const int b = pair / H, h = pair - b * H;
-  const int bk = (Bk == 1) ? 0 : b;
+  const int bk = b % Bk;  // Bk == B: its own K / V^T; Bk == 1: shared; Bk | B (Ulysses: q batches = (source rank, stream), K / V^T batches = stream): b mod Bk
   const int64_t rs = (int64_t)H * 128;
 
   const bf16_t* qbase = Q + ((int64_t)b * Lq) * rs + (int64_t)h * 128;

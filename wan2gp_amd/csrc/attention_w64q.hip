@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void attn_w64q_kernel(const bf16_t* __restrict
   const int pair = v / nqb;
   const int qb = v - pair * nqb;
   const int b = pair / H, h = pair - b * H;
-  const int bk = (Bk == 1) ? 0 : b;
+  const int bk = b % Bk;  // Bk == B: its own K / V^T; Bk == 1: shared; Bk | B (Ulysses: q batches = (source rank, stream), K / V^T batches = stream): b mod Bk
   const int64_t rs = (int64_t)H * 128;
 
   const bf16_t* qbase = Q + ((int64_t)b * Lq) * rs + (int64_t)h * 128;

@@ -127,3 +127,10 @@ __device__ __forceinline__ void wan_lds_dma16(const void* gsrc, void* ldst) {
 }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// ---- library-owned scratch rings for ops called without a caller workspace (elementwise.hip) --------------------------------------
+// One ring of `nslot` slots x `slot_bytes` per (purpose tag, device, stream): calls on one stream are serialised, so a slot is dead
+// `nslot` calls later; another stream or another device gets a ring of its own (round-3 advisor finding: one process-global ring was
+// allocated on whichever device was current first and handed the same slots to every stream).  Thread-safe.  NULL when the request
+// does not fit a slot, the table of rings is full (64) or the allocation fails -- callers then take their scratch-free path.
+void* wan_scratch_ring_slot(int tag, size_t slot_bytes, int nslot, size_t need_bytes, hipStream_t stream);

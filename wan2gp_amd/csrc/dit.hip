@@ -22,7 +22,7 @@ void wan_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wan_last_error(void) { return g_err; }
-extern "C" int wan_version(void) { return 5; }
+extern "C" int wan_version(void) { return 6; }
 extern "C" int wan_device_cus(void) {
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -386,7 +386,9 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
   t.vc = nvace ? c.take<bf16_t>((int64_t)nvace * rows * d) : nullptr;      // VACE: per context, the hint token streams and the projected hint of one block
   t.vskip = nvace ? c.take<bf16_t>((int64_t)nvace * rows * d) : nullptr;
   if (world > 1) {
-    t.kfull = c.take<bf16_t>((int64_t)world * rows * d);
+    // all-gather form: the gathered K / V^T of every rank.  Ulysses form (wan_sp_info.mode): the same two regions hold its six
+    // exchange buffers -- k / q send and receive (4 x rows x d) in kfull, v^T send and receive (2 x S d Lp) in vtfull
+    t.kfull = c.take<bf16_t>((int64_t)std::max(world, 4) * rows * d);
     t.vtfull = c.take<bf16_t>((int64_t)world * S * d * Lp);
     t.raw = c.take<float>(wan_attention_raw_words(S, Ll, g.num_heads));
   } else {
@@ -498,12 +500,16 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   const int Hg = H / 2, Wg = W / 2;
   const int64_t L = (int64_t)F * Hg * Wg;
   const int world = sp ? sp->world : 1;
+  const bool ulysses = sp && world > 1 && sp->mode == WAN_SP_ULYSSES;
   WAN_REQUIRE(world >= 1 && L % world == 0, "wan_dit_forward: L=%lld not divisible by %d sequence shards",
               (long long)L, world);
   const int64_t Ll = L / world;
   const int64_t tok0 = sp ? sp->tok0 : 0;
+  WAN_REQUIRE(!ulysses || (sp->a2a_begin && sp->a2a_wait && g.num_heads % world == 0),
+              "wan_dit_forward: the Ulysses exchange needs its all-to-all hooks and a head count the world divides (%d heads, world %d)",
+              g.num_heads, world);
   WAN_REQUIRE(!sp || (sp->tok_local == Ll && sp->tok0 == (int64_t)sp->rank * Ll &&
-                      (world == 1 || (sp->gather_begin && sp->gather_wait))),
+                      (world == 1 || ulysses || (sp->gather_begin && sp->gather_wait))),
               "wan_dit_forward: inconsistent sequence-parallel info");
   WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
   WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
@@ -651,7 +657,63 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   auto run_layer = [&](const Layer& Lw) -> int {
     // -- self attention (model.py:632-660) --
     RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
-    if (world > 1) {
+    if (ulysses) {
+      // Ulysses (round 4): re-shard q, k, v from "my tokens, all heads" to "all tokens, my heads" by all-to-all, attend the whole
+      // sequence for nh / world heads in ONE launch, bring o back the same way.  Order K, V, Q as below: the k exchange runs under
+      // the V projection, the v exchange under the Q projection + norm; q and o are exposed.  Layouts (W = 128 nh / world):
+      //   send  [world][S][Ll][W]      the projection's [S Ll][d] rows re-packed head-group-major (wan_permute16: one pass)
+      //   recv  [world][S][Ll][W]      = world x S query "batches" of Ll rows for the attention kernel (q batch b attends K / V^T
+      //                                batch b mod S) and world K segments (seg stride S Ll W) -- the all-gather form's layout
+      //   v^T   [world][S][W][Lp]      the transposed epilogue's [S][d][Lp] rows ARE head-group-major per stream: blocks swapped
+      //                                [S][world] -> [world][S] (nothing to do for S = 1); received = world V^T segments
+      //   o     the attention writes [world][S][Ll][W] = the send layout of the way back; received and un-permuted to [S Ll][d]
+      const int Hn = nh / world;
+      const int64_t Wd = (int64_t)Hn * 128, blkq = rows * d, blkv = (int64_t)S * d * Lp;
+      bf16_t *ks = b.kfull, *kr = b.kfull + blkq, *qs = b.kfull + 2 * blkq, *qr = b.kfull + 3 * blkq;
+      bf16_t *vs = b.vtfull, *vr = b.vtfull + blkv;
+      auto a2a = [&](int which, const bf16_t* send, bf16_t* recv, int64_t bytes) -> int {
+        if (sp->a2a_begin(sp->user, which, send, recv, bytes, stream)) {
+          wan_set_error("wan_dit_forward: all-to-all %d (0 k, 1 v^T, 2 q, 3 o) failed", which);
+          return 3;
+        }
+        return 0;
+      };
+      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
+      RC(wan_permute16(b.k, ks, rows, world, Wd * 2, stream));
+      RC(a2a(0, ks, kr, rows * Wd * 2));
+      for (int s = 0; s < S; ++s)
+        RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr));
+      const bf16_t* vsend = b.vt;
+      if (S > 1) {
+        RC(wan_permute16(b.vt, vs, S, world, Wd * Lp * 2, stream));
+        vsend = vs;
+      }
+      RC(a2a(1, vsend, vr, (int64_t)S * Wd * Lp * 2));
+      RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
+                Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr));
+      RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
+      RC(wan_permute16(b.q, qs, rows, world, Wd * 2, stream));
+      RC(a2a(2, qs, qr, rows * Wd * 2));
+      for (int w3 = 0; w3 < 3; ++w3)
+        if (sp->a2a_wait(sp->user, w3, stream)) {
+          wan_set_error("wan_dit_forward: all-to-all %d failed", w3);
+          return 3;
+        }
+      {
+        ProfScope ps(PROF_SELF_ATTN, st);
+        RC(wan_attention_bounded(qr, kr, vr, ks, world * S, S, Ll, Ll, Lp, Hn, world, rows * Wd, (int64_t)S * Wd * Lp, 1, b.kmax, stream));
+      }
+      if (g_prof_on && g_prof_declined != nullptr && Ll * (int64_t)world > 2048)
+        RC(wan_attention_count_declined(b.kmax, world * S, S, Ll, Hn, g_prof_declined, stream));
+      RC(a2a(3, ks, qs, rows * Wd * 2));
+      if (sp->a2a_wait(sp->user, 3, stream)) {
+        wan_set_error("wan_dit_forward: all-to-all 3 (o) failed");
+        return 3;
+      }
+      RC(wan_permute16(qs, b.q, world, rows, Wd * 2, stream));
+    } else if (world > 1) {
       // Sequence parallelism: K first (projection, RMSNorm + RoPE), its all-gather started at once; then V^T and its gather; the
       // Q projection / norm and the attention over the rank's OWN K / V^T segment run while both collectives are in flight;
       // only then the waits, and the other ranks' segments on top of the partial sums (wan_attention_sp_local / _remote).
@@ -695,7 +757,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(wan_attention_bounded(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, 1, b.kmax, stream));
     }
     // outside the timed bracket: which share of the launch's workgroups failed the score bound and ran the tracking loop
-    if (g_prof_on && g_prof_declined != nullptr && b.kmax != nullptr) RC(wan_attention_count_declined(b.kmax, S, S, Ll, nh, g_prof_declined, stream));
+    // (attention.hip hands the scratch to the kernels only for long KV -- Lk > 2048: for shorter sequences the flags are never written)
+    if (!ulysses && g_prof_on && g_prof_declined != nullptr && b.kmax != nullptr && Ll > 2048) RC(wan_attention_count_declined(b.kmax, S, S, Ll, nh, g_prof_declined, stream));
     RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb, 0, q8, S));
     // -- cross attention (model.py:663-668, :245-265) --
     RC(wan_ln_affine(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, stream));

@@ -9,6 +9,9 @@
 // Rounding points follow the reference's eager bf16 graph (see include/wanhip.h).
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
+
 #include "common.h"
 
 #define ROWS_PER_BLOCK 4  // 4 waves of 64 lanes
@@ -24,12 +27,12 @@
 // persistent form loses a third (d = 1536: 3.5 against 5.2 TB/s), and the LayerNorm family, which is VALU-bound either way
 // (~30 VALU operations per element at the reference's rounding points; 3.3 TB/s both ways at d = 5120).
 // Rows stay PACKED in registers (4 VGPRs per chunk), unpacked again in each pass.
-template <int NCH>
+template <int NCH, bool FULL = false>
 __device__ __forceinline__ void load_row(uint4 (&r)[NCH], const bf16_t* x, int lane, int nchunk) {
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = lane + 64 * i;
-    if (c < nchunk) r[i] = *reinterpret_cast<const uint4*>(x + c * 8);
+    if (FULL || c < nchunk) r[i] = *reinterpret_cast<const uint4*>(x + c * 8);
   }
 }
 
@@ -45,13 +48,16 @@ __device__ __forceinline__ wan_f32x2 rope_pair(wan_f32x2 y, float c0, float c1, 
   return p + q;
 }
 
-template <int NCH, bool PERSIST, bool ROPE>
-__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
+template <int NCH, bool PERSIST, bool ROPE, bool FULL>
+__global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? 3 : 1)) void rmsnorm_rope_kernel(
     bf16_t* __restrict__ q, bf16_t* __restrict__ k, const bf16_t* __restrict__ wq,
     const bf16_t* __restrict__ wk, const float* __restrict__ cosT, const float* __restrict__ sinT,
     int64_t rows, int64_t L, int64_t pos0, int d, float eps, float q_scale) {
+  // FULL: d == NCH * 512 exactly (every Wan width): no per-chunk bounds test -- each test is an exec-masked branch that also keeps
+  // the chunk's 64-bit address in a VGPR pair.  The wave index is made scalar so that the row pointers live in SGPRs and every
+  // access is `base(SGPR) + lane * 16 (one VGPR) + immediate`: round 3's kernel spent ~40 VGPRs on addresses at d = 5120.
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
   if (row >= rows) return;
   const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
@@ -60,23 +66,32 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
   const bf16_t* w = (blockIdx.y == 0 ? wq : wk);
   const int nchunk = d >> 3;
 
+  // PERSIST: the norm weights (one 16-byte chunk per lane and chunk index, the same for every row) live in LDS instead of 4 NCH
+  // registers the compiler would otherwise keep across the row loop: 194 -> <= 168 VGPRs at d = 5120 = a third wave per SIMD for a
+  // kernel that is bound by the bytes it keeps in flight (round 4; the outputs do not change: same operations on the same values)
+  __shared__ uint4 wlds[PERSIST ? NCH * 64 : 1];
+  if (PERSIST) {
+    for (int c = threadIdx.x; c < nchunk; c += 256) wlds[c] = *reinterpret_cast<const uint4*>(w + c * 8);
+  }
   uint4 raw[NCH], nxt[NCH];
-  load_row<NCH>(raw, base + row * (int64_t)d, lane, nchunk);
+  load_row<NCH, FULL>(raw, base + row * (int64_t)d, lane, nchunk);
+  if (PERSIST) __syncthreads();   // (every wave of the block reaches this: a block whose first row is past the end does not exist in the persistent grid)
   for (;;) {
     const int64_t nrow = row + stride;
     const bool more = PERSIST && nrow < rows;  // wave-uniform
-    if (more) load_row<NCH>(nxt, base + nrow * (int64_t)d, lane, nchunk);
+    if (more) load_row<NCH, FULL>(nxt, base + nrow * (int64_t)d, lane, nchunk);
     bf16_t* x = base + row * (int64_t)d;
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
-      if (c < nchunk) {
+      if (FULL || c < nchunk) {
         float v[8];
         unpack8(raw[i], v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
       }
+      if (PERSIST) __builtin_amdgcn_sched_barrier(0);   // one chunk unpacked at a time (the scheduler otherwise unpacks the whole row: 8 NCH registers)
     }
     ss = wave_sum(ss);
     const float r = rsqrtf(ss / (float)d + eps);
@@ -92,15 +107,22 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
       cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
       sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
     }
+    uint4 wnext;
+    if (PERSIST) wnext = wlds[lane];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
-      if (c < nchunk) {
+      uint4 wcur;
+      if (PERSIST) {  // the chunk's weights one chunk ahead, and a scheduling fence per chunk: nothing of chunk i + 2 is live while chunk i computes
+        wcur = wnext;
+        if (i + 1 < NCH && (FULL || c + 64 < nchunk)) wnext = wlds[c + 64];
+      }
+      if (FULL || c < nchunk) {
         // Pairs of elements all the way (round 3): the two bf16 of a 32-bit word stay together through both roundings, the rotation and
         // the pack, so that every multiply / add is ONE packed-f32 instruction per pair and every rounding one v_cvt_pk_bf16_f32 per
         // pair (the scalar form rounded with cvt_pk(f, 0): 144 VALU instructions per 16-byte chunk, this form ~90).  Same operations
         // per element in the same order: bit-identical results (tests/test_gpu_ops.py).
-        const uint4 wraw = *reinterpret_cast<const uint4*>(w + c * 8);
+        const uint4 wraw = PERSIST ? wcur : *reinterpret_cast<const uint4*>(w + c * 8);
         const uint32_t ww[4] = {wraw.x, wraw.y, wraw.z, wraw.w};
         const uint32_t vw[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
         uint32_t ow[4];
@@ -121,6 +143,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(
         o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
         *reinterpret_cast<uint4*>(x + c * 8) = o;
       }
+      if (PERSIST) __builtin_amdgcn_sched_barrier(0);
     }
     if (!more) break;
     for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
@@ -508,18 +531,23 @@ extern "C" int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16*
   WAN_REQUIRE(rows < ((int64_t)1 << 31) && L > 0 && L < ((int64_t)1 << 31), "wan_rmsnorm_rope: rows / L must fit 31 bits");
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
+#define RMSROPE_LAUNCH(ROPE_, FULL_)                                                                                                       \
+  do {                                                                                                                                    \
+    unsigned gx = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);                                                               \
+    if (P) { /* q and k rows share the resident slots (grid.y = 2): half the persistent width each */                                     \
+      gx = persistent_blocks(rmsnorm_rope_kernel<NCH, P, ROPE_, FULL_>, rows);                                                            \
+      if (k && gx > 1) gx = (gx + 1) / 2;                                                                                                 \
+    }                                                                                                                                     \
+    hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH, P, ROPE_, FULL_>), dim3(gx, k ? 2 : 1), dim3(256), 0, as_stream(stream), q, k, wq, wk, cos, \
+                       sin, rows, L, pos0, d, eps, q_scale);                                                                              \
+  } while (0)
   DISPATCH_NCH(nch, {
     constexpr bool P = NCH >= 8;
-    unsigned gx = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-    if (P) {  // q and k rows share the resident slots (grid.y = 2): half the persistent width each
-      gx = cos ? persistent_blocks(rmsnorm_rope_kernel<NCH, P, true>, rows) : persistent_blocks(rmsnorm_rope_kernel<NCH, P, false>, rows);
-      if (k && gx > 1) gx = (gx + 1) / 2;
-    }
-    if (cos) hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH, P, true>), dim3(gx, k ? 2 : 1), dim3(256), 0, as_stream(stream), q, k, wq, wk, cos,
-                                sin, rows, L, pos0, d, eps, q_scale);
-    else hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH, P, false>), dim3(gx, k ? 2 : 1), dim3(256), 0, as_stream(stream), q, k, wq, wk, cos,
-                            sin, rows, L, pos0, d, eps, q_scale);
+    const bool full = d == NCH * 512;
+    if (cos) { if (full) RMSROPE_LAUNCH(true, true); else RMSROPE_LAUNCH(true, false); }
+    else { if (full) RMSROPE_LAUNCH(false, true); else RMSROPE_LAUNCH(false, false); }
   });
+#undef RMSROPE_LAUNCH
   WAN_LAUNCH_CHECK();
   return 0;
 }
@@ -546,20 +574,50 @@ __global__ __launch_bounds__(256) void mod_table_kernel(const bf16_t* __restrict
   *reinterpret_cast<uint4*>(tab + (int64_t)b * 2 * d + c * 8) = pack8(sc);
   *reinterpret_cast<uint4*>(tab + (int64_t)b * 2 * d + d + c * 8) = pack8(sh);
 }
-// Library-owned scratch for those tables: a ring of 16 slots x 1 MiB (21 frames x 2 streams x 2 x 5120 x 2 B = 860 KB is the largest
-// Wan case: per-frame timesteps at 14B); a call whose table does not fit keeps the per-row form.  Calls of one forward are serialised
-// on one stream and each table is dead when its LN kernel has run, 16 calls earlier at the latest.
-constexpr size_t MODTAB_SLOT = (size_t)1 << 20, MODTAB_NSLOT = 16;
-static bf16_t* modtab_slot(size_t need_bytes) {
-  static char* ring = nullptr;
-  static unsigned next = 0;
-  if (need_bytes > MODTAB_SLOT) return nullptr;
-  if (ring == nullptr && hipMalloc((void**)&ring, MODTAB_SLOT * MODTAB_NSLOT) != hipSuccess) {
-    ring = nullptr;
+// Library-owned scratch for those tables: rings of 16 slots x 1 MiB per (device, stream) (21 frames x 2 streams x 2 x 5120 x 2 B =
+// 860 KB is the largest Wan case: per-frame timesteps at 14B); a call whose table does not fit keeps the per-row form.  Calls on one
+// stream are serialised and each table is dead when its LN kernel has run, 16 calls earlier at the latest.
+constexpr size_t MODTAB_SLOT = (size_t)1 << 20;
+constexpr int MODTAB_NSLOT = 16;
+static bf16_t* modtab_slot(size_t need_bytes, hipStream_t stream) {
+  return reinterpret_cast<bf16_t*>(wan_scratch_ring_slot(/*tag=*/1, MODTAB_SLOT, MODTAB_NSLOT, need_bytes, stream));
+}
+
+namespace {
+struct ScratchRing {
+  int tag, device;
+  hipStream_t stream;
+  char* base;
+  size_t slot_bytes;
+  int nslot;
+  unsigned next;
+};
+std::mutex g_ring_mutex;
+ScratchRing g_rings[64];
+int g_nrings = 0;
+}  // namespace
+void* wan_scratch_ring_slot(int tag, size_t slot_bytes, int nslot, size_t need_bytes, hipStream_t stream) {
+  if (need_bytes > slot_bytes) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
-  return reinterpret_cast<bf16_t*>(ring + (size_t)(next++ % MODTAB_NSLOT) * MODTAB_SLOT);
+  std::lock_guard<std::mutex> lock(g_ring_mutex);
+  ScratchRing* r = nullptr;
+  for (int i = 0; i < g_nrings; ++i)
+    if (g_rings[i].tag == tag && g_rings[i].device == dev && g_rings[i].stream == stream) r = &g_rings[i];
+  if (r == nullptr) {
+    if (g_nrings == 64) return nullptr;
+    char* base = nullptr;
+    if (hipMalloc((void**)&base, slot_bytes * (size_t)nslot) != hipSuccess) {  // on the CURRENT device: the one the caller launches on
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    r = &g_rings[g_nrings++];
+    *r = ScratchRing{tag, dev, stream, base, slot_bytes, nslot, 0u};
+  }
+  return r->base + (size_t)(r->next++ % (unsigned)r->nslot) * r->slot_bytes;
 }
 
 extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod,
@@ -574,7 +632,7 @@ extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16*
   const int nch = pick_nch(d);
   const int64_t nb = (rows + rows_per_batch - 1) / rows_per_batch;
   // many rows per batch: derive the two modulation vectors once per batch (a ~2 us kernel) and let the row kernel read them
-  bf16_t* tab = (rows >= 64 * nb) ? modtab_slot((size_t)nb * 2 * d * 2) : nullptr;
+  bf16_t* tab = (rows >= 64 * nb) ? modtab_slot((size_t)nb * 2 * d * 2, as_stream(stream)) : nullptr;
   if (tab != nullptr) {
     const int chunks = (int)nb * (d >> 3);
     hipLaunchKernelGGL(mod_table_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, as_stream(stream), mod, e, tab, n_mod, shift_idx,
@@ -716,6 +774,30 @@ extern "C" int wan_transpose_v(const wan_bf16* v, wan_bf16* vt, int B, int64_t L
   WAN_REQUIRE(v && vt && ldv >= L, "wan_transpose_v: bad args");
   dim3 grid((unsigned)((ldv + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
   hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, as_stream(stream), v, vt, L, ldv, C);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// src [A][B][n16 x 16 B] -> dst [B][A][n16 x 16 B]: the head-group-major re-packs around the Ulysses all-to-alls (dit.hip)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void permute16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t A, int64_t B,
+                                                        int64_t n16) {
+  const int64_t total = A * B * n16, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {  // i walks dst: coalesced stores, piece-wise coalesced loads
+    const int64_t c = i % n16, ba = i / n16;
+    const int64_t a = ba % A, b = ba / A;
+    dst[i] = src[(a * B + b) * n16 + c];
+  }
+}
+extern "C" int wan_permute16(const void* src, void* dst, int64_t A, int64_t B, int64_t bytes, void* stream) {
+  WAN_REQUIRE(src && dst && src != dst, "wan_permute16: null or aliased pointers");
+  WAN_REQUIRE(A >= 0 && B >= 0 && bytes >= 0 && bytes % 16 == 0, "wan_permute16: bytes=%lld must be a multiple of 16", (long long)bytes);
+  WAN_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "wan_permute16: pointers must be 16-byte aligned");
+  const int64_t total = A * B * (bytes / 16);
+  if (total == 0) return 0;
+  const int64_t blocks = std::min<int64_t>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(permute16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const uint4*)src, (uint4*)dst, A, B, bytes / 16);
   WAN_LAUNCH_CHECK();
   return 0;
 }

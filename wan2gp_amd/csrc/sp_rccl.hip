@@ -31,7 +31,12 @@ struct Api {
   Result (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
   Result (*CommDestroy)(Comm) = nullptr;
   const char* (*GetErrorString)(Result) = nullptr;
-  bool ok = false;
+  // the all-to-all of WAN_SP_ULYSSES: grouped point-to-point (ncclAllToAll is an RCCL extension this file does not rely on)
+  Result (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  Result (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  Result (*GroupStart)() = nullptr;
+  Result (*GroupEnd)() = nullptr;
+  bool ok = false, p2p = false;
 };
 
 const Api& api() {
@@ -47,7 +52,12 @@ const Api& api() {
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(h, "ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(h, "ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     r.ok = r.GetUniqueId && r.CommInitRank && r.AllGather && r.CommDestroy && r.GetErrorString;
+    r.p2p = r.ok && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
     return r;
   }();
   return a;
@@ -62,7 +72,7 @@ const Api& api() {
     }                                                                                               \
   } while (0)
 
-constexpr int kSlots = 4;
+constexpr int kSlots = 5;   // 0..3: the per-block exchanges (k, v^T, q, o); 4: wan_sp_all_gather
 
 }  // namespace
 
@@ -133,6 +143,36 @@ extern "C" int wan_sp_gather_begin(void* user, int which, const void* send, void
   WAN_CHECK_HIP(hipEventRecord(s->ready, as_stream(stream)));
   WAN_CHECK_HIP(hipStreamWaitEvent(s->side, s->ready, 0));
   WAN_CHECK_NCCL(api().AllGather(send, recv, (size_t)bytes, kNcclInt8, s->comm, s->side));
+  WAN_CHECK_HIP(hipEventRecord(s->done[which], s->side));
+  s->pending[which] = true;
+  return 0;
+}
+
+// wan_gather_begin_fn signature, all-to-all semantics (WAN_SP_ULYSSES): chunk j of send[world][bytes] goes to rank j, chunk i of
+// recv[world][bytes] comes from rank i.  One group of ncclSend / ncclRecv pairs on the side stream (every pair uses its own xGMI
+// link: point-to-point is what the fabric is); the rank's own chunk is a device-to-device copy.
+extern "C" int wan_sp_a2a_begin(void* user, int which, const void* send, void* recv, int64_t bytes, void* stream) {
+  wan_sp* s = static_cast<wan_sp*>(user);
+  WAN_REQUIRE(s && send && recv && bytes > 0 && which >= 0 && which < kSlots, "wan_sp_a2a_begin: bad arguments (slot %d)", which);
+  WAN_REQUIRE(api().p2p, "wan_sp_a2a_begin: the loaded RCCL has no ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+  WAN_REQUIRE(!s->pending[which], "wan_sp_a2a_begin: slot %d still has an exchange in flight (missing wan_sp_gather_wait)", which);
+  WAN_CHECK_HIP(hipEventRecord(s->ready, as_stream(stream)));
+  WAN_CHECK_HIP(hipStreamWaitEvent(s->side, s->ready, 0));
+  const char* sb = static_cast<const char*>(send);
+  char* rb = static_cast<char*>(recv);
+  WAN_CHECK_HIP(hipMemcpyAsync(rb + (size_t)s->rank * bytes, sb + (size_t)s->rank * bytes, (size_t)bytes, hipMemcpyDeviceToDevice, s->side));
+  WAN_CHECK_NCCL(api().GroupStart());
+  for (int p = 0; p < s->world; ++p) {
+    if (p == s->rank) continue;
+    const Result a = api().Send(sb + (size_t)p * bytes, (size_t)bytes, kNcclInt8, p, s->comm, s->side);
+    const Result b = a == 0 ? api().Recv(rb + (size_t)p * bytes, (size_t)bytes, kNcclInt8, p, s->comm, s->side) : a;
+    if (b != 0) {
+      (void)api().GroupEnd();
+      wan_set_error("wan_sp_a2a_begin: ncclSend / ncclRecv with rank %d failed: %s", p, api().GetErrorString(b));
+      return 2;
+    }
+  }
+  WAN_CHECK_NCCL(api().GroupEnd());
   WAN_CHECK_HIP(hipEventRecord(s->done[which], s->side));
   s->pending[which] = true;
   return 0;

@@ -44,9 +44,13 @@ GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64
 GATHER_WAIT_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p)
 
 
+SP_ALLGATHER, SP_ULYSSES = 0, 1
+
+
 class SpInfo(ctypes.Structure):
     _fields_ = [("rank", c_int), ("world", c_int), ("tok0", c_int64), ("tok_local", c_int64),
-                ("gather_begin", GATHER_FN), ("gather_wait", GATHER_WAIT_FN), ("user", c_void_p)]
+                ("gather_begin", GATHER_FN), ("gather_wait", GATHER_WAIT_FN), ("user", c_void_p),
+                ("mode", c_int), ("a2a_begin", GATHER_FN), ("a2a_wait", GATHER_WAIT_FN)]
 
 
 # name -> (restype, argtypes); the single source of truth mirrored by tests/test_abi.py
@@ -119,6 +123,8 @@ SIGNATURES = {
     "wan_sp_destroy": (None, [c_void_p]),
     "wan_sp_gather_begin": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_sp_gather_wait": (c_int, [c_void_p, c_int, c_void_p]),
+    "wan_sp_a2a_begin": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_permute16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "wan_sp_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_sched_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
     "wan_sched_destroy": (None, [c_void_p]),

@@ -163,6 +163,19 @@ def linear_fp8(x, weight_fp8, weight_scale, bias=None, epilogue=EPI_NONE, residu
     return out
 
 
+def permute16(src, A, B):
+    """Block transpose src [A][B][blk] -> [B][A][blk] (wan_permute16: the head-group-major re-packs around the Ulysses all-to-alls);
+    blk = the rest of the tensor, a multiple of 16 bytes.  Returns a new contiguous tensor of src's dtype."""
+    if not src.is_cuda or not src.is_contiguous():
+        raise _L.WanHipError("permute16: a contiguous CUDA tensor is required")
+    nbytes = src.numel() * src.element_size()
+    if A * B == 0 or nbytes % (A * B):
+        raise _L.WanHipError(f"permute16: {nbytes} bytes do not split into {A} x {B} blocks")
+    out = torch.empty_like(src)
+    check(_L.load().wan_permute16(ptr(src), ptr(out), A, B, nbytes // (A * B), stream_ptr()), "wan_permute16")
+    return out
+
+
 def transpose_v(v, ldv=None):
     """[B,L,H,128] (or [B,L,C]) -> V^T [B, C, ldv] with zero padding."""
     _req(v, BF16, "v")

@@ -361,8 +361,10 @@ class WanAny2VHIP:
         mt = getattr(self.model, "model_type", None)
         if mt is not None and mt not in ("i2v", "i2v2_2"):
             image_start = image_end = None
-        elif mt is not None and input_video is None and image_start is None and y is None:
-            input_video = torch.full((3, 1, height, width), -1.0)                     # :667-669: no start image -> a black frame
+        black_start = False
+        if mt is not None and mt in ("i2v", "i2v2_2") and input_video is None and image_start is None and y is None:
+            input_video = torch.full((3, 1, height, width), -1.0)                     # :667-669: no start image -> a black frame ...
+            black_start = True                                                        # ... and no colour matching against it (:669)
         if mt == "i2v" and clip_fea is None:
             src = input_video if input_video is not None else image_start
             if self.clip is None or src is None:
@@ -421,7 +423,7 @@ class WanAny2VHIP:
         # the frame a later sliding window's colours are matched to after decoding (any2video.py:552, :1783-1808; color.py)
         color_reference_frame = None
         if getattr(self.model, "model_type", None) in ("i2v", "i2v2_2"):
-            if input_video is None or image_end is not None:
+            if input_video is None or image_end is not None or black_start:
                 color_correction_strength = 0                                        # :667-669, :686-687
             if input_video is not None:
                 image_start, input_video = input_video, None

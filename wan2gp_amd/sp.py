@@ -23,7 +23,7 @@ from ctypes import c_void_p
 import torch
 import torch.distributed as dist
 
-from .lib import GATHER_FN, GATHER_WAIT_FN, SpInfo
+from .lib import GATHER_FN, GATHER_WAIT_FN, SP_ALLGATHER, SP_ULYSSES, SpInfo
 
 
 def shard_range(L: int, rank: int, world: int):
@@ -35,8 +35,17 @@ def shard_range(L: int, rank: int, world: int):
 
 
 class SequenceParallel:
-    def __init__(self, rank: int, world: int, group=None, native: bool = False):
-        self.rank, self.world, self.group = rank, world, group
+    """mode "allgather" (default): every rank gathers the other shards' K / V^T per block and attends its own query rows.
+    mode "ulysses": per block four all-to-alls re-shard q, k, v^T from "my tokens, all heads" to "all tokens, my heads" and o back
+    (wan_dit_forward with WAN_SP_ULYSSES, csrc/dit.hip): one attention launch at full L for H / world heads; 4 (world - 1) / world
+    shard-sized transfers per block and rank instead of 2 (world - 1); needs H % world == 0 (14B: 40 heads -> 2, 4, 8; 1.3B: 12
+    heads -> 2, 4).  Everything outside self-attention is identical in both modes."""
+
+    def __init__(self, rank: int, world: int, group=None, native: bool = False, mode: str = "allgather"):
+        if mode not in ("allgather", "ulysses"):
+            raise ValueError(f"SequenceParallel: mode {mode!r} is not 'allgather' or 'ulysses'")
+        self.rank, self.world, self.group, self.mode = rank, world, group, mode
+        self.a2a_bytes = 0          # bytes this rank SENT to other ranks through the Ulysses exchanges (bench: per block and rank)
         self._ws = None
         self._cb = None
         self._cbw = None
@@ -128,18 +137,56 @@ class SequenceParallel:
             traceback.print_exc()
             return 1
 
+    def _a2a_begin_cb(self, user, which, send, recv, nbytes, stream):
+        """Start an all-to-all of workspace regions: chunk j of send[world][nbytes] -> rank j, chunk i of recv <- rank i.  RCCL: async
+        on the communicator's stream behind the work already enqueued on the compute stream."""
+        try:
+            base = self._ws.data_ptr()
+            s_off, r_off = send - base, recv - base
+            sv = self._ws[s_off:s_off + nbytes * self.world]
+            rv = self._ws[r_off:r_off + nbytes * self.world]
+            if dist.get_backend(self.group) == "gloo":       # host-staged, synchronous (CPU tests; all ranks of a test on one GPU)
+                src = sv.detach().cpu().contiguous()
+                dst = torch.empty_like(src)
+                dist.all_to_all_single(dst, src, group=self.group)
+                rv.copy_(dst)
+                self._pending[("a2a", which)] = None
+            else:
+                self._pending[("a2a", which)] = dist.all_to_all_single(rv, sv, group=self.group, async_op=True)
+            self.a2a_bytes += nbytes * (self.world - 1)
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def _a2a_wait_cb(self, user, which, stream):
+        try:
+            w = self._pending.pop(("a2a", which), None)
+            if w is not None:
+                w.wait()
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
     def make_info(self, L: int) -> SpInfo:
         tok0, n = shard_range(L, self.rank, self.world)
+        mode = SP_ULYSSES if self.mode == "ulysses" else SP_ALLGATHER
         if self._native is not None:                          # the library's own hooks: no Python in the block loop
             if self._cb is None:
                 self._cb = ctypes.cast(self._lib.wan_sp_gather_begin, GATHER_FN)
                 self._cbw = ctypes.cast(self._lib.wan_sp_gather_wait, GATHER_WAIT_FN)
-            self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, self._native)
+                self._cba = ctypes.cast(self._lib.wan_sp_a2a_begin, GATHER_FN)
+            self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, self._native, mode, self._cba, self._cbw)
             return self._info
         if self._cb is None:
             self._cb = GATHER_FN(self._gather_begin_cb)      # keep the ctypes thunks alive
             self._cbw = GATHER_WAIT_FN(self._gather_wait_cb)
-        self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, None)
+            self._cba = GATHER_FN(self._a2a_begin_cb)
+            self._cbaw = GATHER_WAIT_FN(self._a2a_wait_cb)
+        self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, None, mode, self._cba, self._cbaw)
         return self._info
 
     def gather_output(self, tok_major: torch.Tensor, grid):
