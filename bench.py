@@ -223,16 +223,20 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
     ap.add_argument("--no-configs3", action="store_true", help="skip the BASELINE configs[3] block (14B 720p x 161 frames, L = 147,600: 3 steps + a simulated rank of 8)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (i2v 14B, scaled-fp8 weights, VAE encode + decode)")
-    ap.add_argument("--parallelism", default="auto", choices=["auto", "sp", "cfg-sp"],
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "sp", "cfg-sp", "ulysses", "cfg-ulysses"],
                     help="N > 1: 'sp' = the token axis over all N ranks, both CFG streams on every rank; 'cfg-sp' = the conditional stream on "
                          "ranks [0, N/2), the unconditional one on [N/2, N), the token axis over the N/2 ranks of a half, one 2-rank swap of "
-                         "the predictions per step (wan2gp_amd/sp.py CfgParallel); 'auto' = cfg-sp for an even N, sp otherwise")
+                         "the predictions per step (wan2gp_amd/sp.py CfgParallel); 'ulysses' / 'cfg-ulysses' = the same two layouts with the "
+                         "per-block exchange as four all-to-alls of q, k, v^T, o (heads sharded inside the attention, WAN_SP_ULYSSES; the head "
+                         "count must divide by the sequence-parallel degree) instead of the K / V^T all-gathers; 'auto' = cfg-sp for an even N, "
+                         "sp otherwise (DESIGN.md section 6: the choice and the one-GPU tables behind it)")
     ap.add_argument("--extras-budget-s", type=float, default=float(os.environ.get("WAN_BENCH_EXTRAS_BUDGET_S", 900)),
                     help="an OPTIONAL block behind the timed region (secondary workload, simulated ranks, config 5) is skipped -- and says so "
                          "in its place -- when the process is already older than this; the headline measurement, roofline and cpu_baseline never are")
-    ap.add_argument("--simulate-layout", default="both", choices=["sp", "cfg-sp", "both"],
+    ap.add_argument("--simulate-layout", default="all", choices=["sp", "cfg-sp", "both", "ulysses", "cfg-ulysses", "all"],
                     help="which rank the simulated-ranks block runs: 'sp' = both streams at L / N rows (--parallelism sp), 'cfg-sp' = one stream "
-                         "at L / (N/2) rows + the per-step swap as a device-to-device copy (--parallelism cfg-sp); 'both' = a row for each")
+                         "at L / (N/2) rows + the per-step swap as a device-to-device copy (--parallelism cfg-sp); 'both' = a row for each; 'ulysses' / "
+                         "'cfg-ulysses' = the same shards with the all-to-all exchange; 'all' = the four of them")
     ap.add_argument("--simulate-world", default="2,4,8", help="comma-separated world sizes (e.g. 2,4,8): after the timed region, run ONE "
                     "rank's shard of a sequence-parallel world of that size on this GPU, the K / V^T all-gathers replaced by "
                     "device-to-device copies of the bytes that rank would receive -> compute-side upper bound of the scaling curve; '' = skip")
@@ -255,13 +259,21 @@ def main():
         sys.exit(f"bench.py: {world} ranks need {world} GPUs on this node, found {torch.cuda.device_count()}")
     _cfg, (_f, _h, _w), _ = WORKLOADS[args.workload]
     _L = _f * (_h // 2) * (_w // 2)
-    if args.parallelism == "cfg-sp" and world > 1 and world % 2:
-        sys.exit(f"bench.py: --parallelism cfg-sp splits the ranks in two halves: {world} is odd")
-    cfg_sp = world > 1 and world % 2 == 0 and args.parallelism in ("auto", "cfg-sp")
+    if args.parallelism in ("cfg-sp", "cfg-ulysses") and world > 1 and world % 2:
+        sys.exit(f"bench.py: --parallelism {args.parallelism} splits the ranks in two halves: {world} is odd")
+    cfg_sp = world > 1 and world % 2 == 0 and args.parallelism in ("auto", "cfg-sp", "cfg-ulysses")
     sp_degree = world // 2 if cfg_sp else world            # ranks that share one stream's token axis
+    # the per-block exchange: 'auto' takes the Ulysses all-to-alls where the heads divide by the degree (at a
+    # world of 8 the compute side of a rank is 0.93 against 0.87 and the exchanged bytes 0.58 GB against 1.16 GB per block), else the
+    # K / V^T all-gathers
+    sp_mode = "ulysses" if (args.parallelism in ("ulysses", "cfg-ulysses") or
+                            (args.parallelism == "auto" and sp_degree > 1 and _cfg["num_heads"] % sp_degree == 0)) else "allgather"
     if _L % sp_degree:
         sys.exit(f"bench.py: the {_L} tokens of workload {args.workload} do not shard over {sp_degree} sequence-parallel ranks "
                  f"(divisors: 2, 4, 8 ...)")
+    if sp_mode == "ulysses" and _cfg["num_heads"] % sp_degree:
+        sys.exit(f"bench.py: --parallelism {args.parallelism} shards the {_cfg['num_heads']} heads of workload {args.workload} over "
+                 f"{sp_degree} sequence-parallel ranks: not divisible")
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
@@ -287,7 +299,10 @@ def main():
     model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321, args.fp8) if two_experts else None
     cfgp, layout_note = None, None
     if world > 1:
-        cfgp, cfg_sp, sp_degree, layout_note = setup_parallel(rank, world, cfg_sp, L, (model, model2), args.parallelism == "cfg-sp")
+        cfgp, cfg_sp, sp_degree, layout_note = setup_parallel(rank, world, cfg_sp, L, (model, model2), args.parallelism in ("cfg-sp", "cfg-ulysses"),
+                                                              sp_mode=sp_mode, sp_mode_demanded=args.parallelism in ("ulysses", "cfg-ulysses"))
+        eff = cfgp.sp if cfgp is not None else model.sp        # the exchange the run ended up with (the self-test may have fallen back)
+        sp_mode = eff.mode if eff is not None else "allgather"
 
     vae = None
     want_e2e = not args.no_e2e and rank == 0 and args.workload != "tiny"
@@ -443,7 +458,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
-                       "solver": "unipc", "parallelism": ("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) if world > 1 else "single",
+                       "solver": "unipc", "parallelism": (("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) + (" (ulysses)" if sp_mode == "ulysses" else "")) if world > 1 else "single",
                        **({"parallelism_note": layout_note} if layout_note else {}),
                        "forward_TFLOP": forward_flops(cfg, L) / 1e12},
             "roofline": {"kernel": "attn_w16n_kernel (self-attention: the bounded loop on the 16x16x32 MFMA)", "bound": "mfma", "achieved": achieved,
@@ -469,7 +484,8 @@ def main():
         if world == 1 and args.simulate_world and args.workload in TWO_EXPERT_WORKLOADS:
             log("simulated sequence-parallel ranks: " + args.simulate_world)
             out["simulated_scaling"] = _extra_block(simulate_world, [int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
-                                                    latents, new_sched, dt / args.steps, cfg, L, par, args.simulate_layout, budget_s=args.extras_budget_s)
+                                                    latents, new_sched, dt / args.steps, cfg, L, par, args.simulate_layout, None,
+                                                    1 if args.simulate_layout == "all" else 2, budget_s=args.extras_budget_s)
         if world == 1 and not args.no_configs3 and args.workload == "14B-720p":
             log("configs3: 14B 720p x 161 frames (L = 147,600), 1 warm-up + 2 timed steps, simulated rank of a world of 8")
             out["configs3"] = _extra_block(configs3_block, model, model2, one_step, new_sched, par, lib, budget_s=args.extras_budget_s)
@@ -540,18 +556,19 @@ def configs3_block(model, model2, one_step, new_sched, par, lib):
            "roofline": {"kernel": "self-attention", "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_BF16_TFLOPS, "launches": n, "avg_ms": ms / n if n else None, "flop_per_launch": attn_flops}}
     del lat
-    out["simulated_scaling"] = simulate_world([8], model, model2, one_step, latents, new_sched, step_s, cfg, L, par, "both", fr=freqs)
+    out["simulated_scaling"] = simulate_world([8], model, model2, one_step, latents, new_sched, step_s, cfg, L, par, "all", fr=freqs, k=1)
     return out
 
 
-def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device="cuda"):
+def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device="cuda", sp_mode="allgather", sp_mode_demanded=False):
     """The multi-GPU layout of this run on the resident experts -> (CfgParallel | None, cfg_sp, sp_degree, note).
 
     cfg-sp (the default for an even world) is tried first: groups, then a self-test of the 2-rank swap on a tiny tensor.  A rank
     whose setup or self-test raises says so in an all-reduce; if ANY rank failed, EVERY rank takes plain sequence parallelism over the
     whole world instead (when the token count shards that way) and the JSON line carries the reason -- a scaling run is worth more
     than the preferred layout.  With `--parallelism cfg-sp` given explicitly the failure is fatal instead.  (What this cannot help: ONE
-    rank failing inside a collective while its partner waits in it -- that ends at the backend's collective timeout.)"""
+    rank failing inside a collective while its partner waits in it -- that ends at the backend's collective timeout.)  The same
+    agreement in front of the Ulysses exchange (sp_mode "ulysses": _ulysses_self_test), whose fall-back is the all-gather exchange."""
     import torch
     import torch.distributed as dist
     from wan2gp_amd.sp import CfgParallel, SequenceParallel
@@ -559,7 +576,7 @@ def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device
     if cfg_sp:
         cfgp, err = None, ""
         try:
-            cfgp = CfgParallel(rank, world)
+            cfgp = CfgParallel(rank, world, mode=sp_mode)
             mine = torch.full((8,), float(cfgp.stream), device=device)
             a, b = cfgp.exchange(mine)
             if not (bool((a == 0).all()) and bool((b == 1).all())):
@@ -569,19 +586,57 @@ def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device
         bad = torch.tensor([1.0 if err else 0.0], device=device)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if float(bad.item()) == 0.0:
+            note = _ulysses_self_test(cfgp.sp, device, sp_mode_demanded, None)
             cfgp.attach(*models)                                # this rank's stream; the half's sequence-parallel group on the experts
-            return cfgp, True, world // 2, None
+            return cfgp, True, world // 2, note
         note = "cfg-sp setup failed on %s: %s -- fell back to sequence parallelism over all %d ranks" % (
             "this rank" if err else "another rank", err or "(see that rank's log)", world)
         log(note)
         if cfg_sp_demanded or L % world:
             sys.exit("bench.py: " + note + (" refused: --parallelism cfg-sp was asked for" if cfg_sp_demanded else
                                             " impossible: %d tokens do not shard over %d ranks" % (L, world)))
-    sp = SequenceParallel(rank, world)
+    sp = SequenceParallel(rank, world, mode=sp_mode)
+    note = _ulysses_self_test(sp, device, sp_mode_demanded, note)
     for m in models:
         if m is not None:
             m.sp = sp
     return None, False, world, note
+
+
+def _ulysses_self_test(sp, device, demanded, note):
+    """The Ulysses exchange before its first use on this node: one tiny all-to-all on the sequence-parallel group (chunk j must arrive
+    from rank j), every rank reports in one all-reduce; if ANY rank failed EVERY rank keeps the all-gather exchange (sp.mode) and the
+    line says so -- unless the mode was asked for explicitly, then the failure is fatal."""
+    import torch
+    import torch.distributed as dist
+    if sp is None or sp.mode != "ulysses" or sp.world < 2:
+        return note
+    err = ""
+    try:
+        send = (torch.arange(sp.world * 4, device=device, dtype=torch.float32) // 4) * 0 + float(sp.rank)
+        recv = torch.full_like(send, -1.0)
+        if dist.get_backend(sp.group) == "gloo":
+            hs, hr = send.cpu(), recv.cpu()
+            dist.all_to_all_single(hr, hs, group=sp.group)
+            recv = hr.to(device)
+        else:
+            dist.all_to_all_single(recv, send, group=sp.group)
+        want = torch.arange(sp.world, device=device, dtype=torch.float32).repeat_interleave(4)
+        if not torch.equal(recv, want):
+            raise RuntimeError("all-to-all returned %r" % recv.tolist())
+    except Exception as ex:                                     # noqa: BLE001
+        err = repr(ex)
+    bad = torch.tensor([1.0 if err else 0.0], device=device)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX)                  # over the WORLD: both halves of a cfg layout decide together
+    if float(bad.item()) != 0.0:
+        msg = "the Ulysses all-to-all self-test failed on %s: %s -- the per-block exchange stays the K / V^T all-gather" % (
+            "this rank" if err else "another rank", err or "(see that rank's log)")
+        if demanded:
+            sys.exit("bench.py: " + msg + " refused: the mode was asked for")
+        log(msg)
+        sp.mode = "allgather"
+        note = (note + "; " if note else "") + msg
+    return note
 
 
 def _extra_block(fn, *a, budget_s=None):
@@ -668,10 +723,37 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
     from wan2gp_amd.sp import SequenceParallel
 
     class SimulatedRank(SequenceParallel):
-        def __init__(self, world):
-            super().__init__(0, world)
+        def __init__(self, world, mode="allgather"):
+            super().__init__(0, world, mode=mode)
             self.side = torch.cuda.Stream()
             self.bytes = 0
+
+        def _a2a_begin_cb(self, user, which, send, recv, nbytes, stream):
+            """Ulysses: what the all-to-all leaves in recv = `world` chunks of nbytes (here: this rank's own chunks, copied)."""
+            try:
+                base = self._ws.data_ptr()
+                sv = self._ws[send - base:send - base + nbytes * self.world]
+                rv = self._ws[recv - base:recv - base + nbytes * self.world]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev)
+                    rv.copy_(sv)
+                    done = torch.cuda.Event()
+                    done.record(self.side)
+                self._pending[("a2a", which)] = done
+                self.bytes += nbytes * (self.world - 1)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _a2a_wait_cb(self, user, which, stream):
+            ev = self._pending.pop(("a2a", which), None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+            return 0
 
         def _gather_begin_cb(self, user, which, send, recv, nbytes, stream):
             try:
@@ -714,18 +796,27 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
             return r, r.clone()
 
     rows = []
-    plans = [(n, lay) for n in worlds for lay in (("sp", "cfg-sp") if layout == "both" else (layout,))]
+    lays = {"both": ("sp", "cfg-sp"), "all": ("sp", "cfg-sp", "ulysses", "cfg-ulysses")}.get(layout, (layout,))
+    plans = [(n, lay) for n in worlds for lay in lays]
     for n, lay in plans:
-        deg = n // 2 if lay == "cfg-sp" else n                 # ranks sharing one stream's token axis
-        if lay == "cfg-sp" and n % 2:
+        cfg_half = lay.startswith("cfg-")                      # the two CFG streams on the two halves of the world
+        uly = lay.endswith("ulysses")                          # the per-block exchange: four all-to-alls instead of two all-gathers
+        deg = n // 2 if cfg_half else n                        # ranks sharing one stream's token axis
+        name = ("cfg2 x sp%d" % deg if cfg_half else "sp%d" % n) + (" (ulysses)" if uly else "")
+        if cfg_half and n % 2:
             rows.append({"world": n, "layout": lay, "skipped": f"world {n} is odd"})
             continue
         if L % deg:
             rows.append({"world": n, "layout": lay, "skipped": f"{L} tokens do not divide by {deg}"})
             continue
-        sp = SimulatedRank(deg) if deg > 1 else None
+        if uly and cfg["num_heads"] % deg:
+            rows.append({"world": n, "layout": lay, "skipped": f"{cfg['num_heads']} heads do not divide by {deg}"})
+            continue
+        if uly and deg == 1:
+            continue                                           # cfg2 x sp1: no exchange inside a half -- the cfg-sp row already is this layout
+        sp = SimulatedRank(deg, "ulysses" if uly else "allgather") if deg > 1 else None
         try:
-            if lay == "cfg-sp" and par is not None:
+            if cfg_half and par is not None:
                 par["cfgp"] = SimulatedCfgRank(sp)
             model.sp = sp
             if model2 is not None:
@@ -743,18 +834,21 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
             dt = (time.perf_counter() - t0) / k
             assert torch.isfinite(lat).all()
             layers = cfg["num_layers"]
-            rows.append({"world": n, "layout": "cfg2 x sp%d" % deg if lay == "cfg-sp" else "sp%d" % n,
+            rows.append({"world": n, "layout": name,
                          "rank_step_ms": dt * 1e3, "compute_side_efficiency": step_s_1gpu / (n * dt),
-                         # K + V^T of the other ranks of the group, for the streams this rank runs
+                         # all-gather form: K + V^T of the other ranks of the group; Ulysses: the (deg - 1) / deg of q, k, v^T, o this rank
+                         # sends away (= receives) -- per block, for the streams this rank runs
                          "gathered_bytes_per_block_and_rank": (sp.bytes / (k * layers)) if sp is not None else 0.0,
-                         "tokens_per_rank": L // deg, "streams_per_rank": 1 if lay == "cfg-sp" else 2})
+                         "exchange": "all-to-all x 4 (q, k, v^T, o)" if uly else ("all-gather x 2 (K, V^T)" if sp is not None else "none"),
+                         "tokens_per_rank": L // deg, "streams_per_rank": 1 if cfg_half else 2})
         finally:                                                              # whatever happened: the models leave as they came
             model.sp = None
             if model2 is not None:
                 model2.sp = None
             if par is not None:
                 par["cfgp"] = None
-    return {"note": "one rank's shard on one GPU, all-gathers = device-to-device copies (compute-side upper bound; no xGMI time)",
+    return {"note": "one rank's shard on one GPU, all-gathers / all-to-alls = device-to-device copies (compute-side upper bound; no xGMI time); "
+                    "timed steps per row: %d" % k,
             "one_gpu_step_ms": step_s_1gpu * 1e3, "ranks": rows}
 
 

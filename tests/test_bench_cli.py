@@ -225,6 +225,19 @@ def test_blocks_behind_the_timed_region_do_not_depend_on_the_timesteps_it_consum
     # BASELINE configs[3] (161 frames, L = 147,600): the same block at that L with its own rope tables handed through
     r3 = bench.simulate_world([8], m, m2, one_step, lat, _StrictScheduler, 28.0, {"num_layers": 40}, 147600, par, "both", fr="freqs161")
     assert [x["tokens_per_rank"] for x in r3["ranks"]] == [18450, 36900] and all(s[3] == "freqs161" for s in seen[43:])
+    # all four layouts (the default of the bench line): the Ulysses rows carry the all-to-all exchange, heads must divide by the degree,
+    # cfg2 x sp1 has no exchange and therefore no Ulysses twin
+    modes = []
+
+    def one_step2(i, lat, sc=None, fr=None):
+        modes.append((m.sp.mode, m.sp.world) if m.sp is not None else None)
+        return sc.step(None, sc.timesteps[i], lat)[0]
+    r4 = bench.simulate_world([2, 8], m, m2, one_step2, lat, _StrictScheduler, 8.5, {"num_layers": 40, "num_heads": 40}, 75600, par, "all", None, 1)
+    assert [x["layout"] for x in r4["ranks"]] == ["sp2", "cfg2 x sp1", "sp2 (ulysses)", "sp8", "cfg2 x sp4", "sp8 (ulysses)", "cfg2 x sp4 (ulysses)"]
+    assert [x["exchange"].split(" ")[0] for x in r4["ranks"]] == ["all-gather", "none", "all-to-all", "all-gather", "all-gather", "all-to-all", "all-to-all"]
+    assert modes[::2] == [("allgather", 2), None, ("ulysses", 2), ("allgather", 8), ("allgather", 4), ("ulysses", 8), ("ulysses", 4)]
+    r5 = bench.simulate_world([8], m, m2, one_step2, lat, _StrictScheduler, 0.4, {"num_layers": 30, "num_heads": 12}, 32760, par, "ulysses")
+    assert "12 heads do not divide by 8" in r5["ranks"][0]["skipped"]
 
 
 def test_the_161_frame_workload_is_baseline_configs_3():

@@ -112,6 +112,9 @@ def _worker(rank, world, port, q):
         allr = [None] * world
         dist.all_gather_object(allr, drawn[0])
         assert len(set(allr)) == 1
+        # the per-block exchange inside a half can be the Ulysses all-to-alls instead of the all-gathers (bench --parallelism cfg-ulysses)
+        cfgu = CfgParallel(rank, world, mode="ulysses")
+        assert (cfgu.sp is None) if half == 1 else (cfgu.sp.mode == "ulysses" and cfgu.sp.world == half and cfgu.sp.make_info(64 * half).mode == 1)
         # without guidance every rank runs the one forward there is (no swap)
         m1 = StreamDiT()
         p1 = WanAny2VHIP(m1, device="cpu")
@@ -212,6 +215,27 @@ def _layout_worker(rank, world, port, q):
                 raise AssertionError("must exit")
             except SystemExit as ex:
                 assert "cfg-sp" in str(ex.code)
+        # the Ulysses exchange (the bench's default where the heads divide by the degree) is self-tested the same way: healthy -> kept;
+        # a failing all-to-all -> EVERY rank keeps the K / V^T all-gathers and says so; asked for explicitly -> fatal
+        SP.CfgParallel.exchange = real
+        m = types.SimpleNamespace(sp="unset")
+        cfgp, cfg_sp, degree, note = bench.setup_parallel(rank, world, True, 75600, (m,), device="cpu", sp_mode="ulysses")
+        assert cfg_sp and note is None and ((cfgp.sp is None) if half == 1 else cfgp.sp.mode == "ulysses")
+        cfgp, cfg_sp, degree, note = bench.setup_parallel(rank, world, False, 75600, (m,), device="cpu", sp_mode="ulysses")
+        assert cfgp is None and note is None and m.sp.mode == "ulysses" and m.sp.world == world
+        real_a2a = dist.all_to_all_single
+
+        def broken_a2a(*a, **k):
+            raise RuntimeError("injected failure of the all-to-all")
+        dist.all_to_all_single = broken_a2a
+        cfgp, cfg_sp, degree, note = bench.setup_parallel(rank, world, False, 75600, (m,), device="cpu", sp_mode="ulysses")
+        assert m.sp.mode == "allgather" and "self-test failed" in note and "injected failure" in note
+        try:
+            bench.setup_parallel(rank, world, False, 75600, (m,), device="cpu", sp_mode="ulysses", sp_mode_demanded=True)
+            raise AssertionError("must exit")
+        except SystemExit as ex:
+            assert "asked for" in str(ex.code)
+        dist.all_to_all_single = real_a2a
         # plain sequence parallelism when cfg-sp was not selected (odd worlds, --parallelism sp)
         SP.CfgParallel.exchange = real
         m = types.SimpleNamespace(sp=None)

@@ -374,10 +374,26 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const bf16_t* __restrict
   }
 }
 
+}  // namespace
+// second-generation kernel (gemm_fp8m.hip): gemm256m's stage discipline on the K = 128 fp8 MFMA; tried first on the shapes it accepts
+// (-DWAN_FP8_NO_M: the A/B library libwanhip_f8k.so keeps this file's kernel on every shape)
+template <int EPI, bool BIAS_ROWS>
+int wan_gemm_fp8m_try(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                      int64_t ldo, const bf16_t* bias, const float* scale_a, const float* scale_w, bool scale_vec, const bf16_t* R,
+                      const bf16_t* mod, const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st);
+namespace {
+
 template <int EPI, bool BIAS_ROWS>
 int launch_fp8(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                int64_t ldo, const bf16_t* bias, const float* scale_a, const float* scale_w, bool scale_vec, const bf16_t* R,
                const bf16_t* mod, const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st) {
+#ifndef WAN_FP8_NO_M
+  {
+    const int rc = wan_gemm_fp8m_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, scale_a, scale_w, scale_vec, R, mod, e, n_mod,
+                                                     gate_idx, rows_per_batch, st);
+    if (rc >= 0) return rc;
+  }
+#endif
   WAN_REQUIRE(256 * ldy + (int64_t)K < ((int64_t)1 << 32) && 256 * ldx + (int64_t)K < ((int64_t)1 << 32),
               "wan_gemm_fp8: row pitch exceeds the 32-bit DMA offsets of a tile");
   const int64_t ty = (YM + F_BM - 1) / F_BM, tx = (XN + F_BN - 1) / F_BN;

@@ -214,7 +214,7 @@ class CfgParallel:
 
     `new_group` is collective over ALL ranks and must run in the same order everywhere: every rank creates every group here."""
 
-    def __init__(self, rank: int, world: int, native: bool = False):
+    def __init__(self, rank: int, world: int, native: bool = False, mode: str = "allgather"):
         if world < 2 or world % 2:
             raise ValueError(f"CFG parallelism splits the world in two halves: world size {world} is not a positive even number")
         self.rank, self.world, self.half = rank, world, world // 2
@@ -223,7 +223,7 @@ class CfgParallel:
         halves = [dist.new_group(list(range(s * self.half, (s + 1) * self.half))) if self.half > 1 else None for s in (0, 1)]
         pairs = [dist.new_group([i, i + self.half]) for i in range(self.half)]
         self.pair = pairs[self.sp_rank]                      # {i, i + k}: group rank 0 = conditional, 1 = unconditional
-        self.sp = SequenceParallel(self.sp_rank, self.half, group=halves[self.stream], native=native) if self.half > 1 else None
+        self.sp = SequenceParallel(self.sp_rank, self.half, group=halves[self.stream], native=native, mode=mode) if self.half > 1 else None
 
     def attach(self, *models):
         """The half's sequence-parallel group on every resident expert (None for a world of 2)."""
