@@ -221,6 +221,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the VAE decode / end-to-end block")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
+    ap.add_argument("--no-robustness", action="store_true", help="skip the self-attention launches on gain-12 and adversarial inputs (roofline.robustness)")
     ap.add_argument("--no-configs3", action="store_true", help="skip the BASELINE configs[3] block (14B 720p x 161 frames, L = 147,600: 3 steps + a simulated rank of 8)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (i2v 14B, scaled-fp8 weights, VAE encode + decode)")
     ap.add_argument("--parallelism", default="auto", choices=["auto", "sp", "cfg-sp", "ulysses", "cfg-ulysses"],
@@ -478,6 +479,15 @@ def main():
         lib.wan_prof_enable(0)
         if e2e is not None:
             out["e2e"] = e2e
+        if world == 1 and not args.no_robustness and args.workload in TWO_EXPERT_WORKLOADS:
+            # what the headline's roofline.frac depends on: nothing a normalised head produces (the shifted loop), and the price of the
+            # worst case (every workgroup redone by the tracking loop)
+            log("attention on gain-1 / gain-12 / adversarial inputs")
+            rb = _extra_block(attention_robustness, cfg, L, budget_s=args.extras_budget_s)
+            out["roofline"]["robustness"] = rb
+            if isinstance(rb, dict) and "adversarial_key_all_redone_by_tracking_loop" in rb:
+                out["roofline"]["frac_gain_12"] = rb["gain_12_shifted_loop"]["frac"]
+                out["roofline"]["frac_all_declined"] = rb["adversarial_key_all_redone_by_tracking_loop"]["frac"]
         if world == 1 and not args.no_secondary and args.workload in TWO_EXPERT_WORKLOADS:
             log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
             out["secondary"] = _extra_block(secondary_1p3b, vae, budget_s=args.extras_budget_s)
@@ -509,6 +519,54 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def attention_robustness(cfg, L, S=2):
+    """The self-attention launch of the headline shape on three kinds of input, standalone (HIP events, 1 warm-up + 2 timed launches
+    each): RMS-normalised-like rows at gain 1 (every workgroup takes the plain bounded loop -- the state the timed region's synthetic
+    weights produce), the same at K gain 12 (round 3: every workgroup declined to the tracking loop; round 4: the SAME loop with a
+    per-row reference shift, attention_w16n.hip SHIFT), and an adversarial key in every head (a score ~ 300 log2 units where the
+    first tile suggests ~ 85: P overflows, the row sums say so, every workgroup is redone by the tracking loop after a wasted pass)
+    -- the worst case of the protocol.  -> TFLOP/s, fraction of 2.5 PFLOP/s and the share of workgroups that reached the tracking loop."""
+    import ctypes
+    import torch
+    from wan2gp_amd import lib as L_, ops
+    lib = L_.load()
+    H = cfg["num_heads"]
+    g = torch.Generator(device="cuda").manual_seed(7)
+    q = (torch.randn(S, L, H, 128, device="cuda", generator=g) * ops.attention_qscale()).to(torch.bfloat16)
+    k = torch.randn(S, L, H, 128, device="cuda", generator=g).to(torch.bfloat16)
+    ldv = (L + 63) // 64 * 64
+    vt = torch.zeros(S, H * 128, ldv, device="cuda", dtype=torch.bfloat16)
+    vt[..., :L] = torch.randn(S, H * 128, L, device="cuda", generator=g).to(torch.bfloat16)
+    scratch = torch.zeros(ops.attention_scratch_words(S, S, L, H), dtype=torch.float32, device="cuda")
+    acc = torch.zeros(2, dtype=torch.int64, device="cuda")
+    out = torch.empty_like(q)
+    flops = 4.0 * S * L * L * H * 128
+    res = {}
+
+    def run(name, qq, kk):
+        ops.attention(qq, kk, vt, q_prescaled=True, kmax_scratch=scratch, out=out)
+        acc.zero_()
+        L_.check(lib.wan_attention_count_declined(L_.ptr(scratch), S, S, L, H, L_.ptr(acc), L_.stream_ptr()), "count")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            ops.attention(qq, kk, vt, q_prescaled=True, kmax_scratch=scratch, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 2
+        tf = flops / (ms * 1e-3) / 1e12
+        res[name] = {"ms": ms, "TFLOPs": tf, "frac": tf / PEAK_BF16_TFLOPS, "reached_tracking_loop_frac": int(acc[0]) / max(int(acc[1]), 1),
+                     "finite": bool(torch.isfinite(out.float()).all())}
+    run("gain_1_plain_loop", q, k)
+    k12 = (k.float() * 12.0).to(torch.bfloat16)
+    run("gain_12_shifted_loop", q, k12)
+    del k12
+    qa = q.clone(); qa[..., 0] += 6.0 * ops.attention_qscale()
+    ka = k.clone(); ka[:, 12345] = 0; ka[:, 12345, :, 0] = 400.0
+    run("adversarial_key_all_redone_by_tracking_loop", qa, ka)
+    return res
 
 
 def collect_prof(lib):

@@ -503,6 +503,21 @@ int wan_vae_unpack(const uint16_t* in, float* out, const float* sub, const float
 int wan_vae_to_video(const float* in, uint8_t* u8, float* f32, int T, int64_t hw, int Ttot, int t0,
                      void* stream);
 
+/* ---- the fp32 plan of the Wan2.1 VAE (round 4; `vae_precision` "32", wgp.py:4038 -> WanVAE(dtype = torch.float32)): the same ops
+ * on fp32 channels-last activations [T,H,W,C] and fp32 weights, fp32 throughout -- plain FMA kernels, an option beside the fp16
+ * default (csrc/vae_f32.hip).  wan_vae_conv3d_f32: the arguments of wan_vae_conv3d, weights [Cout][ldw] with K = ((kt*KH+kh)*KW+kw)
+ * * Cin + c, Cin % 16 == 0.  wan_gemm_f32: C[M][N] = scale * A[M][K] . (b_transposed ? B[N][K]^T : B[K][N]) (+ bias[N]) -- the
+ * to_qkv / q k^T / p v products of AttentionBlock (vae.py:294-315).  wan_vae_softmax_f32: rows in place. */
+int wan_vae_conv3d_f32(const float* x, const float* cache, const float* w, int64_t ldw, const float* bias, const float* res, float* out,
+                       int Tin, int Hin, int Win, int Cin, int Tout, int Hout, int Wout, int Cout, int KT, int KH, int KW, int st_t,
+                       int st_s, int front, int pad_s, int ups, int interleave, void* stream);
+int wan_vae_rmsnorm_silu_f32(const float* x, float* out, const float* gamma, int64_t npix, int C, int silu, void* stream);
+int wan_gemm_f32(const float* A, int64_t lda, const float* B, int64_t ldb, int b_transposed, const float* bias, float* C, int64_t ldc,
+                 int M, int N, int K, float scale, void* stream);
+int wan_vae_softmax_f32(float* S, int64_t rows, int L, int64_t ld, void* stream);
+int wan_vae_pack_f32(const float* in, float* out, const float* mul, const float* add, int C, int Cp, int64_t thw, void* stream);
+int wan_vae_unpack_f32(const float* in, float* out, const float* sub, const float* mul, int C, int Cs, int64_t thw, void* stream);
+
 /* ---- the whole Wan2.1 VAE (SURVEY.md section 8b `wan_vae_encode`, `wan_vae_decode_u8`) ----------------------------------
  * Encoder3d / Decoder3d / WanVAE_.encode / .decode (vae.py:318-662) as one call each: the layer graph and the causal
  * feature-cache bookkeeping run inside the library (csrc/vae_graph.hip) on the op-level entry points above.

@@ -24,7 +24,8 @@ def main():
         rows = [(n, v) for n, v in k.items() if n.startswith(prefix)]
         return sum(v["calls"] for _, v in rows), sum(v["total_ms"] for _, v in rows)
 
-    SELF = ("attn_w16n_kernel", "attn_w64q_kernel<bounded")      # the bounded loop: attention_w16n.hip since round 3 (16x16x32 MFMA)
+    SELF = ("attn_w16n_kernel<bounded", "attn_w64q_kernel<bounded")      # the bounded loop: attention_w16n.hip since round 3 (16x16x32 MFMA)
+    SELF_ALL = SELF + ("attn_w16n_kernel<shifted",)              # + its shifted twin (round 4): the time of both launches against one launch's work
     GEMM = ("gemm256m_kernel", "gemm256k_kernel")               # gemm256m.hip since round 3; gemm256k.hip keeps the row-bias (V^T) form
     n_self, _ = tot(SELF)
     forwards = n_self / w["layers"] if n_self else 0            # forward passes in the trace (one joint CFG pass each)
@@ -39,12 +40,14 @@ def main():
                        "peak": peak, "frac": round(ach / peak, 3), "work_per_forward": work_per_forward, "note": note}
 
     # the bounded launch also serves cross-attention (short KV goes to the tracking instantiation): split by name
-    line("self-attention", SELF, w["layers"] * 4.0 * S * L * L * d, "TFLOP/s", 2500.0, "4 S L^2 d per block")
+    line("self-attention", SELF_ALL, w["layers"] * 4.0 * S * L * L * d, "TFLOP/s", 2500.0, "4 S L^2 d per block; plain + shifted launch of every call")
+    if "self-attention" in lines:
+        lines["self-attention"]["launches"] = n_self
     line("cross-attention (Lk=512)", "attn_w64q_kernel<tracking", w["layers"] * 4.0 * S * L * text * d, "TFLOP/s", 2500.0,
          "4 S L 512 d per block; includes the bounded launch's declined-workgroup pass (zero work)")
     big = w["layers"] * 2.0 * M * (6.0 * d * d + 2.0 * d * ffn)          # q,k,v,o, cross q,o, ffn1, ffn2 per block
     if fp8:
-        line("GEMM (scaled fp8)", "gemm_fp8_kernel", big, "TFLOP/s", 5000.0, "2 M (6 d^2 + 2 d ffn) per block")
+        line("GEMM (scaled fp8)", ("gemm_fp8m_kernel", "gemm_fp8_kernel"), big, "TFLOP/s", 5000.0, "2 M (6 d^2 + 2 d ffn) per block")
         line("fp8 activation quantisation", "fp8_", w["layers"] * 5.0 * M * (5.0 * d + 1.0 * ffn) , "GB/s", 8000.0,
              "absmax read 2 B + quantise read 2 B / write 1 B per element, 5 activations of width d and 1 of width ffn per block")
     else:

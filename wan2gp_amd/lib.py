@@ -125,6 +125,12 @@ SIGNATURES = {
     "wan_sp_gather_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "wan_sp_a2a_begin": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_permute16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "wan_vae_conv3d_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p] + [c_int] * 17 + [c_void_p]),
+    "wan_vae_rmsnorm_silu_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "wan_gemm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "wan_vae_softmax_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "wan_vae_pack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
+    "wan_vae_unpack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "wan_sp_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_sched_create": (c_int, [POINTER(c_void_p), c_int, c_int]),
     "wan_sched_destroy": (None, [c_void_p]),

@@ -36,7 +36,7 @@ def _pad32(c):
 class _Conv:
     """A packed convolution: weights [Cout_p][Kp] fp16 with K = ((kt*KH+kh)*KW+kw)*Cin_p + c."""
 
-    def __init__(self, w, b, dev, cout_pad=None):
+    def __init__(self, w, b, dev, cout_pad=None, dtype=None):
         if w.dim() == 4:                       # Conv2d -> KT = 1
             w = w.unsqueeze(2)
         cout, cin, kt, kh, kw = w.shape
@@ -51,8 +51,8 @@ class _Conv:
         bb = torch.zeros(cout_p, dtype=torch.float32)
         if b is not None:
             bb[:cout] = b.detach().float()
-        self.w = flat.to(device=dev, dtype=F16).contiguous()
-        self.b = bb.to(device=dev, dtype=F16).contiguous()
+        self.w = flat.to(device=dev, dtype=dtype or F16).contiguous()
+        self.b = bb.to(device=dev, dtype=dtype or F16).contiguous()
         self.cin, self.cout, self.k = cin_p, cout_p, (kt, kh, kw)
 
 
@@ -145,6 +145,78 @@ class _VaeNet:
             check(lib.wan_vae_softmax(ptr(S), ptr(S), L, L, Lp, stream_ptr()), "vae softmax")
             o = torch.empty(L, C, dtype=F16, device=self.dev)
             check(lib.wan_gemm_f16(ptr(S), Lp, ptr(vt), Lp, None, ptr(o), C, L, C, Lp, 1.0, 0, stream_ptr()), "vae pv")
+            out[t] = self.conv(o.view(1, H, W, C), p + "proj", res=x[t:t + 1].contiguous())[0]
+        return out
+
+
+class _VaeNetF32(_VaeNet):
+    """The fp32 plan (`vae_precision` "32", wgp.py:4038 -> WanVAE(dtype=torch.float32), models/wan/modules/vae.py): the same layer
+    graph on fp32 channels-last activations and fp32 weights through the fp32 ops of csrc/vae_f32.hip -- no 16-bit rounding point
+    anywhere.  Plain FMA kernels (a 720p x 81-frame decode is a minute-class job): an option, not the default."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], dev):
+        self.dev = dev
+        self.lib = _L.load()
+        self.convs: Dict[str, _Conv] = {}
+        self.gamma: Dict[str, torch.Tensor] = {}
+        f32 = torch.float32
+        for k, v in sd.items():
+            if k.endswith(".weight") and v.dim() in (4, 5):
+                name = k[: -len(".weight")]
+                pad = _pad32(v.shape[0]) if name == "conv2" else None
+                c = _Conv(v, sd.get(name + ".bias"), "cpu", cout_pad=pad, dtype=f32)
+                c.w, c.b = c.w.to(dev), c.b.to(dev)
+                self.convs[name] = c
+            elif k.endswith("gamma"):
+                self.gamma[k] = v.detach().reshape(-1).to(device=dev, dtype=f32).contiguous()
+        self.attn = {}
+        for side in ("encoder.middle.1.", "decoder.middle.1."):
+            if side + "to_qkv.weight" in sd:
+                C = sd[side + "proj.weight"].shape[0]
+                self.attn[side] = dict(C=C, wqkv=sd[side + "to_qkv.weight"].detach().reshape(3 * C, C).to(device=dev, dtype=f32).contiguous(),
+                                       bqkv=sd[side + "to_qkv.bias"].detach().to(device=dev, dtype=f32).contiguous())
+
+    def conv(self, x, name, cache=None, res=None, out_f32=False, ups=False, interleave=False, st_t=1, st_s=1, front=None, pad_s=None):
+        c = self.convs[name]
+        T, H, W, C = x.shape
+        assert C == c.cin and x.dtype == torch.float32, (name, C, c.cin, x.dtype)
+        kt, kh, kw = c.k
+        front = kt - 1 if front is None else front
+        pad_s = kh // 2 if pad_s is None else pad_s
+        He, We = (2 * H, 2 * W) if ups else (H, W)
+        Ho, Wo = ((He + 1 - kh) // 2 + 1, (We + 1 - kw) // 2 + 1) if st_s == 2 else (He, We)
+        To = (T + front - kt) // st_t + 1
+        out = torch.empty((2 * To, Ho, Wo, c.cout // 2) if interleave else (To, Ho, Wo, c.cout), dtype=torch.float32, device=self.dev)
+        check(self.lib.wan_vae_conv3d_f32(ptr(x), ptr(cache), ptr(c.w), c.w.shape[1], ptr(c.b), ptr(res), ptr(out), T, H, W, C, To, Ho, Wo, c.cout,
+                                          kt, kh, kw, st_t, st_s, front, pad_s, 1 if ups else 0, 1 if interleave else 0, stream_ptr()),
+              f"wan_vae_conv3d_f32({name})")
+        return out
+
+    def norm(self, x, gname, silu=True):
+        out = torch.empty_like(x)
+        C = x.shape[-1]
+        check(self.lib.wan_vae_rmsnorm_silu_f32(ptr(x), ptr(out), ptr(self.gamma[gname]), x.numel() // C, C, 1 if silu else 0, stream_ptr()),
+              "wan_vae_rmsnorm_silu_f32")
+        return out
+
+    def attention_block(self, x, p):
+        """AttentionBlock.forward (vae.py:294-315) per frame in fp32: [q | k | v] = x W^T + b, softmax(q k^T / sqrt(C)) v, proj + x."""
+        a = self.attn[p]
+        C = a["C"]
+        T, H, W, _ = x.shape
+        L = H * W
+        xn = self.norm(x, p + "norm.gamma", silu=False)
+        out = torch.empty_like(x)
+        lib, f32 = self.lib, torch.float32
+        for t in range(T):
+            xt = xn[t].reshape(L, C)
+            qkv = torch.empty(L, 3 * C, dtype=f32, device=self.dev)
+            check(lib.wan_gemm_f32(ptr(xt), C, ptr(a["wqkv"]), C, 1, ptr(a["bqkv"]), ptr(qkv), 3 * C, L, 3 * C, C, 1.0, stream_ptr()), "vae qkv (fp32)")
+            S = torch.empty(L, L, dtype=f32, device=self.dev)
+            check(lib.wan_gemm_f32(ptr(qkv), 3 * C, ptr(qkv[:, C:]), 3 * C, 1, None, ptr(S), L, L, L, C, 1.0 / math.sqrt(C), stream_ptr()), "vae q k^T (fp32)")
+            check(lib.wan_vae_softmax_f32(ptr(S), L, L, L, stream_ptr()), "vae softmax (fp32)")
+            o = torch.empty(L, C, dtype=f32, device=self.dev)
+            check(lib.wan_gemm_f32(ptr(S), L, ptr(qkv[:, 2 * C:]), 3 * C, 0, None, ptr(o), C, L, C, L, 1.0, stream_ptr()), "vae p v (fp32)")
             out[t] = self.conv(o.view(1, H, W, C), p + "proj", res=x[t:t + 1].contiguous())[0]
         return out
 
@@ -316,9 +388,26 @@ class WanVAEHIP:
     NATIVE_GRAPH = True                                    # run encode / decode through wan_vae_* (the Wan2.2 subclass keeps the host graph)
 
     def load_state_dict(self, sd):
+        if self.dtype == torch.float32:                    # `vae_precision` "32" (wgp.py:4038): the fp32 plan, on the host graph below
+            self.net = _VaeNetF32(sd, self.device)
+            self.native = None
+            return self
         self.net = _VaeNet(sd, self.device)
         self.native = _NativeGraph(sd, self.device) if self.NATIVE_GRAPH else None
         return self
+
+    @property
+    def _adt(self):
+        """The activation dtype of the plan in use."""
+        return torch.float32 if self.dtype == torch.float32 else F16
+
+    def _pack(self, src, out, mul, add, C, Cp, n):
+        fn = self.net.lib.wan_vae_pack_f32 if self.dtype == torch.float32 else self.net.lib.wan_vae_pack
+        check(fn(ptr(src), ptr(out), ptr(mul), ptr(add), C, Cp, n, stream_ptr()), "wan_vae_pack")
+
+    def _unpack(self, src, out, sub, mul, C, Cs, n):
+        fn = self.net.lib.wan_vae_unpack_f32 if self.dtype == torch.float32 else self.net.lib.wan_vae_unpack
+        check(fn(ptr(src), ptr(out), ptr(sub), ptr(mul), C, Cs, n, stream_ptr()), "wan_vae_unpack")
 
     @staticmethod
     def get_VAE_tile_size(vae_config, device_mem_capacity, mixed_precision, output_height=None, output_width=None):
@@ -425,10 +514,9 @@ class WanVAEHIP:
         C, t, h, w = z.shape
         if getattr(self, "native", None) is not None:
             return self.native.decode(z, want_u8, want_f32)
-        zp = torch.empty(t, h, w, 32, dtype=F16, device=self.device)
+        zp = torch.empty(t, h, w, 32, dtype=self._adt, device=self.device)
         inv_std = (1.0 / self.scale[1]).contiguous()                             # z / scale[1] + scale[0]
-        check(lib.wan_vae_pack(ptr(z), ptr(zp), ptr(inv_std), ptr(self.scale[0].contiguous()), C, 32, t * h * w,
-                               stream_ptr()), "wan_vae_pack")
+        self._pack(z, zp, inv_std, self.scale[0].contiguous(), C, 32, t * h * w)
         x = self.net.conv(zp, "conv2")                                           # 1x1x1, 16 -> 16 (padded to 32)
         T_out = (t - 1) * 4 + 1
         H, W = h * 8, w * 8
@@ -646,8 +734,8 @@ class WanVAEHIP:
             if getattr(self, "native", None) is not None:
                 outs.append(self.native.encode(v))
                 continue
-            vp = torch.empty(T, H, W, 32, dtype=F16, device=self.device)
-            check(lib.wan_vae_pack(ptr(v), ptr(vp), None, None, C, 32, T * H * W, stream_ptr()), "wan_vae_pack")
+            vp = torch.empty(T, H, W, 32, dtype=self._adt, device=self.device)
+            self._pack(v, vp, None, None, C, 32, T * H * W)
             cache = [None] * self._n_cached("encoder.")
             chunks = []
             for i in range(1 + (T - 1) // 4):
@@ -657,7 +745,6 @@ class WanVAEHIP:
             mu = self.net.conv(enc, "conv1")                                     # 1x1x1 32 -> 32; mu = first 16
             t, h, w, _ = mu.shape
             out = torch.empty(16, t, h, w, dtype=torch.float32, device=self.device)
-            check(lib.wan_vae_unpack(ptr(mu), ptr(out), ptr(self.scale[0].contiguous()), ptr(self.scale[1].contiguous()),
-                                     16, 32, t * h * w, stream_ptr()), "wan_vae_unpack")
+            self._unpack(mu, out, self.scale[0].contiguous(), self.scale[1].contiguous(), 16, 32, t * h * w)
             outs.append(out)
         return outs

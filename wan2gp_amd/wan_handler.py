@@ -237,11 +237,13 @@ class family_handler():
 
     @staticmethod
     def load_model(model_filename, model_type, base_model_type, model_def, quantizeTransformer=False, text_encoder_quantization=None,
-                   dtype=torch.bfloat16, VAE_dtype=torch.float32, mixed_precision_transformer=False, save_quantized=False,
+                   dtype=torch.bfloat16, VAE_dtype=torch.float16, mixed_precision_transformer=False, save_quantized=False,
                    submodel_no_list=None, text_encoder_filename=None, VAE_upsampling=None, checkpoint_dir="ckpts", device="cuda",
                    state_dicts=None, vae_state_dict=None, text_encoder=None, clip=None, **kwargs):
         """wan_handler.load_model (:1116-1158) for the HIP backend.  `model_filename`: the checkpoint path(s) wgp.py resolved
-        (one per expert for Wan2.2).  Returns (WanAny2VHIP, {"pipe": {...}}).
+        (one per expert for Wan2.2).  Returns (WanAny2VHIP, {"pipe": {...}}).  VAE_dtype: what wgp.py:4038 passes -- torch.float16
+        unless the user set `vae_precision` "32" (the default HERE is wgp.py's, not the reference signature's torch.float32: the
+        fp32 plan is an exact but minute-class option).
         Test hooks: `state_dicts` / `vae_state_dict` / `text_encoder` bypass the file reads."""
         if quantizeTransformer or save_quantized:
             raise NotImplementedError("on-the-fly quantisation is part of the reference's low-VRAM machinery; the HIP backend loads "
@@ -292,10 +294,13 @@ class family_handler():
         else:
             vae_path = _locate("Wan2.2_VAE.safetensors" if wan_5B else "Wan2.1_VAE.safetensors", checkpoint_dir)
         vae = None
+        # VAE_dtype: wgp.py:4038 passes torch.float16 for `vae_precision` "16" (its default) and torch.float for "32".  The Wan2.1 VAE
+        # serves both plans (fp32: csrc/vae_f32.hip, a slow exact option); any other dtype, and the Wan2.2 VAE, run the fp16 plan
+        vae_kw = {"dtype": torch.float32} if (VAE_dtype == torch.float32 and not wan_5B) else {}
         if vae_state_dict is not None:
-            vae = VAE(state_dict=vae_state_dict, device=device)
+            vae = VAE(state_dict=vae_state_dict, device=device, **vae_kw)
         elif os.path.isfile(vae_path):
-            vae = VAE(vae_pth=vae_path, device=device)
+            vae = VAE(vae_pth=vae_path, device=device, **vae_kw)
         # under wgp.py (real checkpoint files, no test hooks) a missing VAE / text-encoder file must fail HERE, not as an opaque
         # error after a full denoise: generate() would return latents with x = None, or fail on `context`
         from_files = state_dicts is None
