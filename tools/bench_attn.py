@@ -33,13 +33,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--modes", default="bounded,tracking")
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--gain", type=float, default=1.0, help="K scaled by this: beyond ~6 every workgroup of `bounded` takes the shifted loop (attention_w16n.hip SHIFT)")
     ap.add_argument("--stamps", action="store_true", help="library built with -DW64Q_TIMING and WAN_ATTN_STAMPS=1: print stamp deltas")
     a = ap.parse_args()
     Lk = a.Lk or a.L
     g = torch.Generator(device="cuda").manual_seed(0)
     q = torch.randn(a.B, a.L, a.H, 128, device="cuda", generator=g).to(torch.bfloat16)
     qs = (q.float() * ops.attention_qscale()).to(torch.bfloat16)
-    k = torch.randn(a.B, Lk, a.H, 128, device="cuda", generator=g).to(torch.bfloat16)
+    k = (torch.randn(a.B, Lk, a.H, 128, device="cuda", generator=g) * a.gain).to(torch.bfloat16)
     v = torch.randn(a.B, Lk, a.H, 128, device="cuda", generator=g).to(torch.bfloat16)
     vt = ops.transpose_v(v)
     del v
