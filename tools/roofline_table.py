@@ -28,6 +28,8 @@ def main():
     SELF_ALL = SELF + ("attn_w16n_kernel<shifted",)              # + its shifted twin (round 4): the time of both launches against one launch's work
     GEMM = ("gemm256m_kernel", "gemm256k_kernel")               # gemm256m.hip since round 3; gemm256k.hip keeps the row-bias (V^T) form
     n_self, _ = tot(SELF)
+    if not n_self:                                              # one bounded launch per call since the second half of round 4: the shifted twin alone
+        n_self, _ = tot("attn_w16n_kernel<shifted")
     forwards = n_self / w["layers"] if n_self else 0            # forward passes in the trace (one joint CFG pass each)
     lines = {}
 

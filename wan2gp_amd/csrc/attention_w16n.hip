@@ -286,7 +286,11 @@ __device__ __forceinline__ mfma_bf16x8 prescale8_16(const uint4 raw, float c) {
 // FLAGS: attention_w64q.hip's bits -- bit1 q pre-scaled, bit2 (always set here: the bounded loop), bit4 RAW_OUT, bit5 CARRY_IN,
 // bit6 MULTI (several kv segments / a left-out one), bit7 SHIFT.
 //
-// Three launches back to back share one flag word per workgroup (wg_flags: 0 = done, 2 = wants the shifted loop, 1 = wants the
+// Since the second half of round 4 a call launches ONLY the shifted instantiation for its bounded pass: a row inside the plain bound
+// carries m = 0, i.e. C = +0 -- the plain kernel's arithmetic bit for bit -- and one launch has no second tail and no hand-over (the
+// two-launch protocol below cost 4 % when a model's heads were split between the two loops; it remains as the A/B build
+// libwanhip_a2l.so, -DWAN_ATTN_TWO_LAUNCH, and the plain instantiations remain for it).  The protocol as first built:
+// three launches back to back share one flag word per workgroup (wg_flags: 0 = done, 2 = wants the shifted loop, 1 = wants the
 // tracking loop):
 //   plain (SHIFT = 0)  every row of the workgroup obeys U = |Q~_row| max|k_h| <= 96: P = 2^s unshifted, as since round 2.  Else the
 //                      workgroup sets its flag -- 2 if every U is finite and <= SHIFT_LIMIT, 1 otherwise -- and returns before touching LDS.
@@ -338,8 +342,12 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
 
   const int total = nqb * H * B;
   const int v = xcd_remap(blockIdx.x, total);
+#ifdef WAN_ATTN_TWO_LAUNCH   // (the A/B library libwanhip_a2l.so: plain launch first, the shifted twin for what it hands over)
   if (SHIFT) { if (wg_flags[v] != 2) return; }  // only what the plain launch handed over
   else if (CARRY_IN && wg_flags[v] != 0) return;  // an earlier partial launch already gave this workgroup up
+#else
+  if (CARRY_IN && wg_flags[v] != 0) return;       // an earlier partial launch already gave this workgroup up
+#endif
   const int pair = v / nqb;
   const int qb = v - pair * nqb;
   const int b = pair / H, h = pair - b * H;
@@ -375,6 +383,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   // ---- the bound: every row of the workgroup must satisfy |Q~_row| * max|k_h| <= 96 (workgroup-uniform) -- or carry a reference shift
   f32x4 negm[4];      // SHIFT: {-m} x 4 per q tile, the C operand of the tile's first MFMA
   float mref[4] = {0.f, 0.f, 0.f, 0.f};
+  bool wg_any_shift = true;  // does any row of the workgroup carry a shift (else the sample of tile 0 is skipped)
   {
     const float km = kmax2[bk * H + h];
     bool ok = true, shiftable = true;
@@ -400,6 +409,15 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
         return;
       }
     }
+#ifndef WAN_ATTN_TWO_LAUNCH
+    else {  // the ONE bounded launch of a call: a row inside the plain bound has m = 0 (C = +0: the plain kernel's arithmetic, bit for bit)
+      if (__syncthreads_and(shiftable ? 1 : 0) == 0) {  // a reference beyond SHIFT_LIMIT (or NaN): tracking loop, before LDS is touched
+        if (tid == 0) wg_flags[v] = 1;
+        return;
+      }
+      wg_any_shift = __syncthreads_or(ok ? 0 : 1) != 0;
+    }
+#endif
   }
 
   // ---- DMA stream ---------------------------------------------------------------------------------------------------------------
@@ -499,7 +517,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     SB();
   }
 
-  if (SAMPLE && Lk32 >= KVBLK) {
+  if (SAMPLE && Lk32 >= KVBLK && wg_any_shift) {
     // ---- a LOWER bound of every row's maximum: its scores against the 64 keys of tile 0 (the MFMAs of one S phase, once per workgroup).
     // The row's true maximum lies in [m_s, U].  Where that interval is at most 176 wide, m = U - 96 covers it (nothing can overflow, the
     // maximum cannot underflow below 2^-80): guaranteed.  Where it is wider -- large gains on diffuse rows: U grows like 16 gamma, the

@@ -800,6 +800,11 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
 #endif
   if (kmax_scratch != nullptr) {
     const int fl = (pre ? 6 : 4) | (nseg > 1 ? 64 : 0);
+#ifndef WAN_ATTN_TWO_LAUNCH
+    if (W16N_TRY(fl | 128, nseg, k_seg_stride, vt_seg_stride, skip_seg)) {
+      // ONE bounded launch: the shifted instantiation takes every workgroup (m = 0 inside the plain bound)
+    } else
+#endif
     if (!W16N_TRY(fl, nseg, k_seg_stride, vt_seg_stride, skip_seg)) {
       if (nseg > 1) { if (pre) W64Q_LAUNCH(6 | 64); else W64Q_LAUNCH(4 | 64); }
       else { if (pre) W64Q_LAUNCH(6); else W64Q_LAUNCH(4); }
@@ -844,6 +849,10 @@ int wan_attention_w64q_sp(int phase, const bf16_t* q, const bf16_t* k, const bf1
     hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(B * H), 1u), dim3(256), 0, stream, k, kmax_scratch, B, Lk,
                        H, (int64_t)0);
     WAN_LAUNCH_CHECK();
+#ifndef WAN_ATTN_TWO_LAUNCH
+    if (W16N_TRY(2 | 4 | 16 | 128, 1, (int64_t)0, (int64_t)0, -1)) {
+    } else
+#endif
     if (!W16N_TRY(2 | 4 | 16, 1, (int64_t)0, (int64_t)0, -1)) W64Q_LAUNCH_SP(2 | 4 | 16, 1, (int64_t)0, (int64_t)0, -1);
     else { WAN_LAUNCH_CHECK(); (void)W16N_TRY(2 | 4 | 16 | 128, 1, (int64_t)0, (int64_t)0, -1); }
     WAN_LAUNCH_CHECK();
@@ -855,6 +864,10 @@ int wan_attention_w64q_sp(int phase, const bf16_t* q, const bf16_t* k, const bf1
   hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(B * H), (unsigned)nseg), dim3(256), 0, stream, k,
                      kmax_scratch, B, Lk, H, k_seg_stride);
   WAN_LAUNCH_CHECK();
+#ifndef WAN_ATTN_TWO_LAUNCH
+  if (W16N_TRY(2 | 4 | 32 | 64 | 128, nseg, k_seg_stride, vt_seg_stride, own_seg)) {
+  } else
+#endif
   if (!W16N_TRY(2 | 4 | 32 | 64, nseg, k_seg_stride, vt_seg_stride, own_seg)) W64Q_LAUNCH_SP(2 | 4 | 32 | 64, nseg, k_seg_stride, vt_seg_stride, own_seg);
   else { WAN_LAUNCH_CHECK(); (void)W16N_TRY(2 | 4 | 32 | 64 | 128, nseg, k_seg_stride, vt_seg_stride, own_seg); }
   WAN_LAUNCH_CHECK();
