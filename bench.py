@@ -264,11 +264,12 @@ def main():
         sys.exit(f"bench.py: --parallelism {args.parallelism} splits the ranks in two halves: {world} is odd")
     cfg_sp = world > 1 and world % 2 == 0 and args.parallelism in ("auto", "cfg-sp", "cfg-ulysses")
     sp_degree = world // 2 if cfg_sp else world            # ranks that share one stream's token axis
-    # the per-block exchange: 'auto' takes the Ulysses all-to-alls where the heads divide by the degree (at a
-    # world of 8 the compute side of a rank is 0.93 against 0.87 and the exchanged bytes 0.58 GB against 1.16 GB per block), else the
-    # K / V^T all-gathers
+    # the per-block exchange: 'auto' takes the Ulysses all-to-alls from a sequence-parallel degree of 4 up, where the heads divide by
+    # it (at a world of 8 a rank computes at 0.93 of linear against 0.92 and exchanges 0.58 GB per block against
+    # 1.16 GB, of which only q and o -- 2 x 48 MB per link -- are exposed), else the K / V^T all-gathers (degree 2: one peer, the same
+    # bytes either way, and the gathers hide under a local attention segment half a block long where q / o exchanges would not)
     sp_mode = "ulysses" if (args.parallelism in ("ulysses", "cfg-ulysses") or
-                            (args.parallelism == "auto" and sp_degree > 1 and _cfg["num_heads"] % sp_degree == 0)) else "allgather"
+                            (args.parallelism == "auto" and sp_degree >= 4 and _cfg["num_heads"] % sp_degree == 0)) else "allgather"
     if _L % sp_degree:
         sys.exit(f"bench.py: the {_L} tokens of workload {args.workload} do not shard over {sp_degree} sequence-parallel ranks "
                  f"(divisors: 2, 4, 8 ...)")

@@ -267,3 +267,34 @@ def test_cpu_baseline_reports_its_thread_sweep():
     assert set(r["thread_sweep"]["dit_3_layers_s"]) >= {"1", "2"} and set(r["thread_sweep"]["vae_first_frame_s"]) >= {"1", "2"}
     assert str(r["cores"]) in r["thread_sweep"]["dit_3_layers_s"] and "threads" in r["sample"]
     assert r["threads_after"] == r["torch_default_threads"]                       # restored
+
+
+def test_the_drivers_own_command_line_produced_the_whole_record():
+    """profiles/r04_bench_14B-720p_run11.json = `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command, which cost round 3
+    its scaling table) on an MI355X: every block behind the timed region returned data -- the simulated layouts in all four forms at
+    worlds 2 / 4 / 8, BASELINE configs[3] with its own world of 8, the attention robustness probe, config 5, the CPU baseline with its
+    thread sweep -- and the numbers are self-consistent."""
+    import json
+    j = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_14B-720p_run11.json")))
+    assert (j["steps"], j["warmup"], j["n_gpus"]) == (20, 5, 1) and abs(j["value"] * j["ms_per_step"] / 1000.0 - 1.0) < 1e-6
+    assert "error" not in json.dumps({k: j[k] for k in ("secondary", "simulated_scaling", "configs3", "config5", "cpu_baseline")}).lower().replace("max_abs_err", "")
+    rows = j["simulated_scaling"]["ranks"]
+    assert [(r["world"], r["layout"]) for r in rows] == [(2, "sp2"), (2, "cfg2 x sp1"), (2, "sp2 (ulysses)"), (4, "sp4"), (4, "cfg2 x sp2"), (4, "sp4 (ulysses)"),
+                                                         (4, "cfg2 x sp2 (ulysses)"), (8, "sp8"), (8, "cfg2 x sp4"), (8, "sp8 (ulysses)"), (8, "cfg2 x sp4 (ulysses)")]
+    assert all(0.8 < r["compute_side_efficiency"] < 1.05 for r in rows)
+    by = {r["layout"]: r for r in rows}
+    assert by["cfg2 x sp4 (ulysses)"]["gathered_bytes_per_block_and_rank"] < 0.55 * by["cfg2 x sp4"]["gathered_bytes_per_block_and_rank"]
+    assert by["cfg2 x sp4 (ulysses)"]["compute_side_efficiency"] > by["cfg2 x sp4"]["compute_side_efficiency"] > by["sp8"]["compute_side_efficiency"]
+    c3 = j["configs3"]
+    assert c3["tokens"] == 147600 and c3["steps"] == 2 and 0.5 < c3["roofline"]["frac"] < 0.7 and len(c3["simulated_scaling"]["ranks"]) == 4
+    assert abs(c3["roofline"]["achieved"] - c3["roofline"]["flop_per_launch"] / (c3["roofline"]["avg_ms"] * 1e-3) / 1e12) < 1e-6 * c3["roofline"]["achieved"]
+    r = j["roofline"]
+    rb = r["robustness"]
+    assert rb["gain_12_shifted_loop"]["reached_tracking_loop_frac"] == 0.0 and rb["gain_12_shifted_loop"]["TFLOPs"] >= 0.95 * rb["gain_1_plain_loop"]["TFLOPs"]
+    assert rb["adversarial_key_all_redone_by_tracking_loop"]["reached_tracking_loop_frac"] == 1.0 and all(v["finite"] for v in rb.values())
+    assert r["frac_gain_12"] == rb["gain_12_shifted_loop"]["frac"] and r["frac_all_declined"] == rb["adversarial_key_all_redone_by_tracking_loop"]["frac"]
+    assert r["declined_workgroups"] == 0 and abs(r["frac"] - r["achieved"] / 2500.0) < 1e-9
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and str(c["cores"]) in c["thread_sweep"]["dit_3_layers_s"] and len(c["thread_sweep"]["dit_3_layers_s"]) >= 4
+    assert min(c["thread_sweep"]["dit_3_layers_s"].values()) == c["thread_sweep"]["dit_3_layers_s"][str(c["cores"])]
+    assert j["config5"]["dtype"].startswith("fp8") and j["config5"]["ms_per_step"] < j["ms_per_step"]
