@@ -150,6 +150,31 @@ def _rccl_world1_worker(port, q):
         x = torch.randn(1, 24, 64, device="cuda")
         full = sp.all_gather(x[0])
         assert torch.equal(full, x[0])
+        # round 4: the Ulysses all-to-all callbacks on real RCCL (`all_to_all_single(async_op=True)`): four exchanges in flight, as a block
+        # issues them (k, v^T, q, then o behind the waits), async handles pending until waited
+        spu = SequenceParallel(0, 1, mode="ulysses")
+        spu.bind_workspace(ws)
+        ws[2 * n:] = 0
+        for which, (s_off, r_off) in enumerate(((0, 2 * n), (n, 3 * n))):
+            assert spu._a2a_begin_cb(None, which, ws.data_ptr() + s_off, ws.data_ptr() + r_off, n, None) == 0
+        assert set(spu._pending) == {("a2a", 0), ("a2a", 1)} and all(w is not None for w in spu._pending.values())
+        for which in (0, 1):
+            assert spu._a2a_wait_cb(None, which, None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(ws[2 * n:3 * n], ws[0:n]) and torch.equal(ws[3 * n:4 * n], ws[n:2 * n]) and spu.a2a_bytes == 0
+        # ... and a forward with a one-rank Ulysses group attached: a world of one shards nothing (wan_dit_forward takes the plain path),
+        # the mode must not disturb it
+        from oracle import wan_oracle as O
+        from wan2gp_amd.model import WanModelHIP
+        cfg = O.make_config("tiny")
+        m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers).load_state_dict(O.synth_weights(cfg))
+        lat, ctx, ctx_null, _ = O.synth_inputs(cfg, 2, 8, 8, seed=3)
+        t = torch.tensor([500])
+        ref = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])
+        m.sp = SequenceParallel(0, 1, mode="ulysses")
+        got = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])
+        for a, b in zip(got, ref):
+            assert ((a - b).norm() / b.norm()).item() < 1e-2
         q.put("ok")
     except Exception:
         import traceback
@@ -194,7 +219,21 @@ def _native_world1_worker(q):
         assert all(torch.equal(a, b) for a, b in zip(send, recv)) and torch.isfinite(busy).all()
         x = torch.randn(24, 64, device="cuda")
         assert torch.equal(sp.all_gather(x), x)
-        del sp
+        # round 4: wan_sp_a2a_begin (grouped ncclSend / ncclRecv; at one rank the own chunk's device copy inside an empty group) through
+        # the function pointer a WAN_SP_ULYSSES forward receives; four slots in flight
+        spu = SequenceParallel(0, 1, native=True, mode="ulysses")
+        iu = spu.make_info(192)
+        assert iu.mode == 1 and iu.user
+        recv4 = [torch.zeros(n, dtype=torch.uint8, device="cuda") for _ in range(4)]
+        send4 = [torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda", generator=g) for _ in range(4)]
+        for which in range(4):
+            assert iu.a2a_begin(iu.user, which, send4[which].data_ptr(), recv4[which].data_ptr(), n, stream_ptr().value) == 0
+        assert iu.a2a_begin(iu.user, 2, send4[2].data_ptr(), recv4[2].data_ptr(), n, stream_ptr().value) != 0                # slot busy
+        for which in range(4):
+            assert iu.a2a_wait(iu.user, which, stream_ptr().value) == 0
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(send4, recv4))
+        del sp, spu
         q.put("ok")
     except Exception:
         import traceback

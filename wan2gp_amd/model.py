@@ -243,7 +243,7 @@ class WanModelHIP:
             freqs = get_rotary_pos_embed((F, H, W))
         cos, sin = (f.to(device=dev, dtype=torch.float32).contiguous() for f in freqs)
 
-        sp = self.sp
+        sp = self.sp if (self.sp is not None and self.sp.world > 1) else None   # a group of one shards nothing: the plain forward
         shards = 1 if sp is None else sp.world
         ws = self._workspace(S, F, H, W, shards)
         L = F * (H // 2) * (W // 2)
