@@ -10,7 +10,7 @@ if "--lib" in sys.argv:
 from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
 vae = WanVAEHIP(state_dict=random_vae_state_dict())
 res = {}
-for name, (t, h, w) in (("96x160x13f", (4, 12, 20)), ("360x640x9f", (3, 45, 80)), ("720x1280x5f", (2, 90, 160))):
+for name, (t, h, w) in (("128x160x13f", (4, 16, 20)), ("360x640x9f", (3, 45, 80)), ("720x1280x5f", (2, 90, 160))):
     g = torch.Generator().manual_seed(t * 1000 + h)
     z = torch.randn(16, t, h, w, generator=g)
     u8 = vae.decode_to_cpu_uint8([z], 0)[0]

@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
     const int tap = uu / p.CB, cb = uu - tap * p.CB;
     const int kw = tap % p.KW, t2 = tap / p.KW;
     const int kh = t2 % p.KH, kt = t2 / p.KH;
-    const int64_t toff = (int64_t)kt * frame_in + ((int64_t)kh * p.Win + kw) * p.Cin + cb * 32;
+    // UPS: the unit's whole element offset (the up-sampled gather recomputes its address per slot anyway); else the SPATIAL part only
+    // -- (kh Win + kw) Cin + 32 cb, 32 bits -- the frame part kt * frame sits in the slot's per-kt base pointer (round 4)
+    const int64_t toff = (UPS ? (int64_t)kt * frame_in : (int64_t)0) + ((int64_t)kh * p.Win + kw) * p.Cin + cb * 32;
     uint4 e;
     e.x = (uint32_t)toff;
     e.y = (uint32_t)((uint64_t)toff >> 32);
@@ -151,6 +153,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
   const uint16_t* wbase = p.w;  // first weight of the next k-tile to fetch (wave-uniform)
   __syncthreads();              // utab complete
   uint4 ent = utab[my_unit];    // this thread's unit of K-step 0; the next one is read a step ahead
+  // Round 4 (counters, profiles/r04_vae_conv_pmc_sq_run15.json: 3.9 vector instructions per MFMA, the matrix pipe 44 % busy -- the K
+  // loop was bound by the gather's address arithmetic: per slot a 64-bit tap offset, the cache / input pointer select, the zero-page
+  // select).  The frame index kt of a unit changes every KH KW CB units only: each slot keeps the POINTER of its output pixel at the
+  // current kt -- cache or input, frame offset folded in -- and a K-step adds the unit's 32-bit spatial offset to it.
+  const uint16_t* cur[4];
+  int cur_kt = -1;
   const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)wave * 1024u;
   auto stage = [&](int s, int ks) {
     const uint32_t ybase = smem_lds + (uint32_t)(s * 2 * CSTAGE);
@@ -158,20 +166,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
     const uint4 E = ent;
     ent = utab[2 * (ks + 1) + my_unit];  // (one entry past the last K-step is inside the array, never used)
     const uint32_t tap = E.z & 0xffu, kt = (E.z >> 8) & 0xffu, uok = (E.z >> 16) & 1u;
-    const off_t tapoff = BIG ? (off_t)(((uint64_t)E.y << 32) | E.x) : (off_t)E.x;
+    if (!UPS && (int)kt != cur_kt) {  // (lanes of a wave may sit in two consecutive units: a lane-masked update at a kt boundary)
+      cur_kt = (int)kt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        cur[i] = ((((vmask[i] >> (27 + kt)) & 1u) != 0) ? cbase : p.x) + (s_base[i] + (off_t)kt * fin);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t woff = (uint32_t)(i * 256 * 16);
       const bool ok = (uok & (vmask[i] >> tap) & 1u) != 0;
-      const bool in_cache = ((vmask[i] >> (27 + kt)) & 1u) != 0;
-      off_t off;
+      const uint16_t* src;
       if (UPS) {  // nearest-exact 2x upsample on the fly: source pixel (hi >> 1, wi >> 1)
+        const bool in_cache = ((vmask[i] >> (27 + kt)) & 1u) != 0;
         const int hi = (s_ho[i] + (int)((E.z >> 20) & 0xfu)) >> 1, wi = (s_wo[i] + (int)((E.z >> 24) & 0xfu)) >> 1;
-        off = (off_t)(s_to[i] + (int)kt) * fin + ((off_t)hi * p.Win + wi) * p.Cin + (int)E.w + s_coff[i];
-      } else {      // linear in the tap: the slot's base (its output pixel at tap 0) + the unit's offset
-        off = s_base[i] + tapoff;
+        const off_t off = (off_t)(s_to[i] + (int)kt) * fin + ((off_t)hi * p.Win + wi) * p.Cin + (int)E.w + s_coff[i];
+        src = (in_cache ? cbase : p.x) + off;
+      } else {      // the slot's pointer at this kt + the unit's spatial offset
+        src = cur[i] + E.x;
       }
-      const uint16_t* src = (in_cache ? cbase : p.x) + off;
       glds16a(ok ? src : p.zero16, ybase + woff);
       glds16s(xoff32[i], wbase, xbase + woff);
     }
