@@ -207,20 +207,39 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
     xoff[t] = rx * 128 + ((fch ^ ((rx >> 1) & 7)) << 4);
   }
 
+  // WAN_CONV_ABL (make cabl; diagnostics builds only, outputs are garbage): 1 = no gather in the K loop, 2 = no LDS reads / MFMAs,
+  // 3 = MFMAs on fragments read once -- what each of the loop's three streams costs alone (profiles/r04_vae_conv_ablation_*.log)
+#ifndef WAN_CONV_ABL
+#define WAN_CONV_ABL 0
+#endif
   stage(0, 0);
+#if WAN_CONV_ABL == 3
+  mfma_f16x8v yf0[4], xf0[4];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < 4; ++t) {
+    yf0[t] = *reinterpret_cast<const mfma_f16x8v*>(smem + yoff[t]);
+    xf0[t] = *reinterpret_cast<const mfma_f16x8v*>(smem + CSTAGE + xoff[t]);
+  }
+#endif
   for (int kt = 0; kt < p.nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < p.nk) stage((kt + 1) & 1, kt + 1);
+    if (kt + 1 < p.nk && WAN_CONV_ABL != 1) stage((kt + 1) & 1, kt + 1);
     const char* ybase = smem + (kt & 1) * 2 * CSTAGE;
     const char* xbase = ybase + CSTAGE;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < (WAN_CONV_ABL == 2 ? 0 : 2); ++ks) {
       mfma_f16x8v yf[4], xf[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+#if WAN_CONV_ABL == 3
+        yf[t] = yf0[t]; xf[t] = xf0[t];
+        asm volatile("" : "+v"(yf[t]), "+v"(xf[t]));
+#else
         yf[t] = *reinterpret_cast<const mfma_f16x8v*>(ybase + (yoff[t] ^ (ks << 6)));
         xf[t] = *reinterpret_cast<const mfma_f16x8v*>(xbase + (xoff[t] ^ (ks << 6)));
+#endif
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a)
