@@ -159,7 +159,12 @@ int wan_attention_prescaled(const wan_bf16* q, const wan_bf16* k, const wan_bf16
  * whole 256-row workgroup, that workgroup skips the running-max bookkeeping altogether (softmax is shift-invariant; bf16 /
  * fp32 carry P with relative precision); the others are flagged in the rest of the scratch and run the lazy-max loop in a
  * second launch.  wan_attention / _seg / _prescaled do the same with a library-owned scratch ring.  q_prescaled != 0:
- * q already holds q * wan_attention_qscale(). */
+ * q already holds q * wan_attention_qscale().
+ * Short KV (one segment, 449 <= Lk <= 2048: text cross-attention, model.py:410-445) with a scratch takes the same bounded loop as ONE
+ * persistent workgroup per CU that walks a run of q blocks and fetches the next block's Q rows while it works (round 4); without a
+ * scratch, and below 449 keys, the lazy-max loop as before.  o may alias q (wan_dit_forward attends in place): a workgroup that
+ * hands itself over to the lazy-max launch stores nothing.
+ * wan_attention_debug_no_persist(1): test / A-B hook, short KV with a scratch runs as ordinary one-block workgroups; returns the old value. */
 int64_t wan_attention_scratch_words(int B, int Bk, int64_t Lq, int H);
 int wan_attention_bounded(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
                           int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,
@@ -490,6 +495,7 @@ int wan_gemm_f16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
 /* Test hook (not a product entry): force wan_vae_conv3d onto its 64-bit-offset instantiations, which inputs below 2^31
  * elements never reach; returns the previous setting.  Process-wide. */
 int wan_vae_debug_force_big(int on);
+int wan_attention_debug_no_persist(int on);
 /* P[r,:L] = softmax(S[r,:L]); P[r,L:ld] = 0 */
 int wan_vae_softmax(const uint16_t* S, uint16_t* P, int64_t rows, int L, int64_t ld, void* stream);
 /* fp32 [C,thw] -> fp16 [thw,Cp] (zero padded channels), optional v*mul[c]+add[c] */

@@ -169,7 +169,7 @@ def test_plain_forward_launch_order_weights_and_workspace_bounds(mock):
         (2 * Ll, c.ffn_dim, c.dim, 1), (2 * Ll, c.dim, c.ffn_dim, 2)]
     att = [cl for cl in blk if cl[0] == "attention"]
     assert att[0][2][:6] == [2, 2, Ll, Ll, (Ll + 63) // 64 * 64, c.num_heads] and att[1][2][:6] == [2, 2, Ll, TL, TL, c.num_heads]
-    assert att[0][1][4] != 0 and att[1][1][4] == 0                      # the K pre-pass scratch: self-attention only
+    assert att[0][1][4] != 0 and att[1][1][4] == att[0][1][4]           # the K pre-pass scratch: self-attention, and since round 4 cross-attention too (the persistent bounded walk over 512 keys)
 
 
 def test_step_skipping_touches_only_the_computing_stream(mock):

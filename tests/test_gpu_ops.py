@@ -549,6 +549,76 @@ def test_attention_shifted_rows_that_leave_the_exponent_range_are_redone_by_the_
     assert attn_ok(got, _prescaled_ref(qs, k, v))
 
 
+def _no_persist(on):
+    from wan2gp_amd import lib as L
+    return L.load().wan_attention_debug_no_persist(1 if on else 0)
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,Bk,gain", [(2, 3405, 512, 12, 2, 1.0), (2, 3405, 512, 12, 2, 8.0), (1, 700, 512, 3, 1, 1.0), (3, 1100, 500, 5, 1, 6.0),
+                                                (1, 2100, 449, 7, 1, 1.0), (2, 900, 2048, 9, 2, 12.0), (2, 1300, 1100, 8, 2, 1.0)],
+                         ids=["text512_two_blocks_per_cu", "text512_gain8", "fewer_blocks_than_cus", "ragged_500_shared_kv", "449_keys", "2048_keys_gain12", "1100_keys"])
+def test_cross_attention_persistent_workgroups_agree_with_fp64_and_with_one_block_launches(ops, B, Lq, Lk, H, Bk, gain):
+    """Round 4: short KV with a scratch (text cross-attention: 512 keys) runs the bounded loop as ONE persistent workgroup per CU that walks a
+    run of q blocks and pulls the next block's Q rows into LDS while it works (attention_w16n.hip PERSIST).  Against the fp64 softmax, and
+    BIT FOR BIT against the same loop launched one block per workgroup (wan_attention_debug_no_persist): a block's arithmetic does not
+    know which workgroup ran it.  Shapes: more blocks than CUs (a workgroup walks several, across (batch, head) pairs), fewer, a ragged
+    last q block, a ragged last KV tile, shared K / V^T, 8 and 32 tiles, rows that carry a reference shift (gain)."""
+    g = torch.Generator().manual_seed(Lq + Lk)
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF); k = torch.randn(Bk, Lk, H, 128, generator=g)
+    v = torch.randn(Bk, Lk, H, 128, generator=g).to(BF)
+    k[:, :, : max(1, H - 1)] *= gain      # (the last head stays at gain 1: plain and shifted blocks in one walk)
+    k = k.to(BF)
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    ref = _prescaled_ref(qs, k.expand(B, -1, -1, -1) if Bk == 1 else k, v.expand(B, -1, -1, -1) if Bk == 1 else v)
+    scratch = torch.zeros(ops.attention_scratch_words(B, Bk, Lq, H), device="cuda")
+    vt = ops.transpose_v(cu(v))
+    got = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch, Bk=Bk)
+    nflag = ((Lq + 255) // 256) * H * B
+    flags = scratch[Bk * H:Bk * H + nflag].view(torch.int32)
+    assert int((flags != 0).sum()) == 0, flags.cpu().tolist()
+    err = (got.float().cpu() - ref).abs()
+    assert attn_ok(got, ref) and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+    old = _no_persist(True)
+    try:
+        one = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch, Bk=Bk)
+    finally:
+        _no_persist(old)
+    assert torch.equal(got, one)
+    # not pre-scaled (the other instantiation): the same rows up to the rounding of q * scale
+    got2 = ops.attention(cu(q), cu(k), vt, q_prescaled=False, kmax_scratch=scratch, Bk=Bk)
+    assert attn_ok(got2, ref)
+
+
+def test_cross_attention_persistent_handover_keeps_q_intact_in_place(ops):
+    """wan_dit_forward attends in place (o = q).  A block whose rows leave the exponent range hands itself over to the tracking launch AFTER
+    its loop -- it must not have stored anything, or that launch would read O where it expects Q.  Head 0 carries a key far above what the
+    first tile suggests (row sums overflow: every block of the head is redone), head 1 is ordinary, q blocks 2.. of head 2 are beyond
+    SHIFT_LIMIT (declined before the loop: the walk must still fetch the next block's rows).  In place == out of place == fp64."""
+    g = torch.Generator().manual_seed(5)
+    B, Lq, Lk, H = 2, 1500, 512, 3
+    q = torch.randn(B, Lq, H, 128, generator=g); k = torch.randn(B, Lk, H, 128, generator=g)
+    v = torch.randn(B, Lk, H, 128, generator=g).to(BF)
+    q[:, :, 0, 0] += 6.0
+    k[:, 300, 0] = 0.0
+    k[:, 300, 0, 0] = 400.0
+    q[:, 512:, 2] *= 400.0
+    k = k.to(BF)
+    qs = (q * ops.attention_qscale()).to(BF)
+    ref = _prescaled_ref(qs, k, v)
+    scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
+    vt = ops.transpose_v(cu(v))
+    out = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch)
+    nqb = (Lq + 255) // 256
+    flags = scratch[B * H:B * H + nqb * H * B].view(torch.int32).view(B * H, nqb).cpu()
+    assert flags[0].tolist() == [1] * nqb and flags[3].tolist() == [1] * nqb          # head 0: handed over after the loop
+    assert flags[1].tolist() == [0] * nqb
+    assert flags[2].tolist() == [0, 0] + [1] * (nqb - 2)                                # head 2: declined before the loop from block 2 on
+    assert attn_ok(out, ref)
+    qio = cu(qs).clone()
+    same = ops.attention(qio, cu(k), vt, q_prescaled=True, kmax_scratch=scratch, out=qio)
+    assert same.data_ptr() == qio.data_ptr() and torch.equal(same, out)
+
+
 @pytest.mark.parametrize("gains", [(1.0, 8.0), (6.0, 8.0), (8.0, 2.0)], ids=["plain_then_shifted", "shifted_then_larger_shift", "shifted_then_same"])
 def test_attention_sp_partial_sums_carry_their_shift(ops, gains):
     """Sequence parallelism: phase 0 leaves partial sums shifted by m(local max|k|), phase 1 knows the maxima of ALL segments and

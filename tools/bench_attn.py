@@ -4,6 +4,7 @@ Interleaved rounds of the kernel's entry points in one process (cdna guide secti
   bounded    wan_attention_bounded with caller scratch: K pre-pass + bounded-softmax loop (the DiT's self-attention)
   tracking   the same kernel without a pre-pass: lazy-max loop
   generic    wan_attention on unscaled q (long KV: the 4x64 kernel with its pre-scaling pass; short KV: attn_pp<0,0,4>)
+  oneblock   (short KV, --Lk 449..2048) `bounded` is then the persistent walk of round 4; this is the same loop, one q block per workgroup
 """
 import argparse
 import json
@@ -22,6 +23,16 @@ elif "--stamps" in sys.argv:   # the stamp kernels live in the tuning build only
 if "--stamps" in sys.argv:
     os.environ["WAN_ATTN_STAMPS"] = "1"
 from wan2gp_amd import ops  # noqa: E402
+
+
+def _one_block(fn):
+    """short KV (--Lk 449..2048): `bounded` is the persistent walk; this is the same loop launched one q block per workgroup"""
+    from wan2gp_amd import lib as L
+    old = L.load().wan_attention_debug_no_persist(1)
+    try:
+        return fn()
+    finally:
+        L.load().wan_attention_debug_no_persist(old)
 
 
 def main():
@@ -47,6 +58,7 @@ def main():
     scratch = torch.zeros(ops.attention_scratch_words(a.B, a.B, a.L, a.H), device="cuda")
     run = {"bounded": lambda: ops.attention(qs, k, vt, q_prescaled=True, kmax_scratch=scratch),
            "tracking": lambda: ops.attention(qs, k, vt, q_prescaled=True, kmax_scratch=False),
+           "oneblock": lambda: _one_block(lambda: ops.attention(qs, k, vt, q_prescaled=True, kmax_scratch=scratch)),
            "generic": lambda: ops.attention(q, k, vt)}
     modes = a.modes.split(",")
     if a.stamps:

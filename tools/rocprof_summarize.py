@@ -22,7 +22,8 @@ def short(name):
         fl = int(m.group(1) or m.group(2))
         # round 4: the shifted twin (FLAGS | 128) is launched behind every plain launch and runs only the workgroups the plain one
         # handed over -- its own row, so that launches of the plain kernel still count forwards
-        return "attn_w16n_kernel<%s%s>" % ("shifted" if fl & 128 else "bounded", ",prescaled" if fl & 2 else "")
+        # (second half of round 4: FLAGS | 256 = the persistent short-KV form, text cross-attention)
+        return "attn_w16n_kernel<%s%s>" % ("persistent" if fl & 256 else "shifted" if fl & 128 else "bounded", ",prescaled" if fl & 2 else "")
     for k in ("gemm_fp8m_kernel", "gemm_fp8_kernel", "permute16_kernel", "fp8_quant_kernel", "fp8_absmax_kernel", "attn_kmax_kernel", "gemm256m_kernel", "gemm256k_kernel", "gemm256_kernel", "gemm32_kernel", "attn_w64q_kernel", "attn_w64_kernel", "attn_pp_kernel", "attn_fwd_kernel", "gemm_bf16_kernel", "rmsnorm_rope_kernel", "layernorm_kernel", "gated_residual",
               "patch_embed_kernel", "head_gemm_kernel", "gemv_kernel", "lincomb_kernel", "cfg_combine", "transpose_v"):
         if k in name:

@@ -45,8 +45,8 @@ def main():
     line("self-attention", SELF_ALL, w["layers"] * 4.0 * S * L * L * d, "TFLOP/s", 2500.0, "4 S L^2 d per block; plain + shifted launch of every call")
     if "self-attention" in lines:
         lines["self-attention"]["launches"] = n_self
-    line("cross-attention (Lk=512)", "attn_w64q_kernel<tracking", w["layers"] * 4.0 * S * L * text * d, "TFLOP/s", 2500.0,
-         "4 S L 512 d per block; includes the bounded launch's declined-workgroup pass (zero work)")
+    line("cross-attention (Lk=512)", ("attn_w16n_kernel<persistent", "attn_w64q_kernel<tracking"), w["layers"] * 4.0 * S * L * text * d, "TFLOP/s", 2500.0,
+         "4 S L 512 d per block; the persistent bounded walk (round 4) + every tracking launch of the trace (the hand-over passes behind self- and cross-attention: zero work)")
     big = w["layers"] * 2.0 * M * (6.0 * d * d + 2.0 * d * ffn)          # q,k,v,o, cross q,o, ffn1, ffn2 per block
     if fp8:
         line("GEMM (scaled fp8)", ("gemm_fp8m_kernel", "gemm_fp8_kernel"), big, "TFLOP/s", 5000.0, "2 M (6 d^2 + 2 d ffn) per block")

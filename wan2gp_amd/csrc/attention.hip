@@ -71,7 +71,9 @@ static int attention_dispatch(const wan_bf16* q, const wan_bf16* k, const wan_bf
   WAN_REQUIRE(Lk * (int64_t)H * 256 < ((int64_t)1 << 32) && ldv * 256 < ((int64_t)1 << 32),
               "wan_attention: a K / V^T segment of %lld rows x %d heads exceeds the 32-bit DMA offsets of the kernels",
               (long long)Lk, H);
-  const bool long_kv = Lk * (int64_t)nseg > 2048;
+  // long KV: the bounded loop.  Short KV of at least 8 tiles in one segment (cross-attention: 512 text tokens) takes it too when the caller
+  // brings a scratch -- as ONE persistent workgroup per CU (attention_w16n.hip PERSIST).  Below that (CLIP's 257 tokens, toy shapes): tracking loop.
+  const bool long_kv = Lk * (int64_t)nseg > 2048 || (nseg == 1 && Lk > 448 && scratch_kind == SCRATCH_CALLER);
   {
     // the bounded loop sums UNROUNDED P into l while P enters the PV product rounded to bf16: negligible over thousands of
     // keys, a visible 2^-9 for a handful (Lk = 1: O = bf16(2^s) v / 2^s instead of v) -- short KV always takes the tracking

@@ -331,8 +331,16 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   constexpr bool MULTI = (FLAGS & 64) != 0;
   constexpr bool SHIFT = (FLAGS & 128) != 0;
   constexpr bool SAMPLE = SHIFT && !RAW_OUT && !CARRY_IN;  // the reference also uses a lower bound of the row maximum (partial launches must agree on m: Cauchy-Schwarz only)
+  // PERSIST (bit 8; short KV -- cross-attention, 8 to 32 tiles): one workgroup per CU walks a contiguous run of q blocks.  With a handful
+  // of tiles per block everything around the tile loop used to be exposed -- the workgroup's launch, the Q rows' trip from HBM, the first
+  // two tiles' DMA, the O rows' way out, one workgroup per CU and nobody to run meanwhile (cross-attention at 0.30 of peak for four
+  // rounds).  Here the NEXT block's 64 KB of Q rows arrive by LDS-DMA into the 64 KB of LDS the ring leaves free, two pieces per wave at
+  // the top of each of the block's first eight tiles, and a block switch costs the O staging, 16 DMA pieces and 16 ds_reads.
+  constexpr bool PERSIST = (FLAGS & 256) != 0;
+  static_assert(!PERSIST || (SHIFT && !RAW_OUT && !CARRY_IN && !MULTI && !TIMING), "PERSIST: the one-launch bounded pass of a single-segment call");
+  constexpr int QAREA = 2 * NST * IMG;  // PERSIST: the next block's Q rows, 16 KB per wave (row r of the wave at r * 256, 16-B chunk c at slot c ^ (r & 15))
   constexpr int WAVE_RAW = 2 * (64 * 64 + 128), WG_RAW = 4 * WAVE_RAW;  // floats: per half 64 accumulators x 64 lanes + 2 x 64 row-sum shares
-  __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG];    // [K stages][V^T stages] = 96 KB
+  __shared__ __attribute__((aligned(16))) char smem[2 * NST * IMG + (PERSIST ? 4 * 16384 : 0)];    // [K stages][V^T stages] = 96 KB (+ 64 KB)
   lds_cchar* lds = (lds_cchar*)smem;
   uint64_t stamp[20] = {};
   const int tid = threadIdx.x;
@@ -341,18 +349,73 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   const int l15 = lane & 15, lg = lane >> 4;
 
   const int total = nqb * H * B;
-  const int v = xcd_remap(blockIdx.x, total);
+  const int64_t rs = (int64_t)H * 128;
+  // PERSIST: the wave's 64 Q rows of block vn -> its 16 KB of the Q area, piece p = rows 4 p .. 4 p + 3 (a lane: row 4 p + lg, slot l15).  Rows
+  // past Lq read as zeros (the descriptor ends at the last valid row); a wave wholly past Lq re-reads row Lq - 1 (never stored).
+  const char* qpf_base = nullptr;
+  uint32_t qpf_len = 0;
+  // PERSIST: the block's coordinates are carried along (an integer division is a ~40-instruction VALU sequence: three per block cost 2,000 cycles)
+  int p_pair = 0, p_qb = 0, p_b = 0, p_h = 0;
+  auto p_adv = [&]() {
+    if (!PERSIST) return;
+    if (++p_qb == nqb) { p_qb = 0; ++p_pair; p_b = p_pair / H; p_h = p_pair - p_b * H; }
+  };
+  auto qpf_set = [&](int pr, int qbn, int bn, int hn) {
+    int64_t r0 = (int64_t)qbn * 256 + wave * 64;
+    if (r0 > Lq - 1) r0 = Lq - 1;
+    int64_t nv = Lq - r0;
+    if (nv > 64) nv = 64;
+    qpf_base = uni(reinterpret_cast<const char*>(Q + ((int64_t)bn * Lq + r0) * rs + (int64_t)hn * 128));
+    qpf_len = uni((uint32_t)(nv - 1) * (uint32_t)(rs * 2) + 256u);
+  };
+  auto qpf_piece = [&](int pc) {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t voff = (uint32_t)(4 * pc + lg) * (uint32_t)(rs * 2) + (uint32_t)((l15 ^ ((4 * pc + lg) & 15)) << 4);
+    dma_issue(voff, qpf_base, qpf_len, lds0 + QAREA + wave * 16384 + pc * 1024);
+  };
+  // -DW16N_PSTAMPS (make pstamp; diagnostics): s_memtime at the stations of workgroup 0's fourth block -> raw (the launcher prints them)
+#ifdef W16N_PSTAMPS
+#define PST(I) do { if (PERSIST && pst_on && tid == 0) reinterpret_cast<uint64_t*>(raw)[I] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PST(I) do { } while (0)
+#endif
+  int v_first, v_end;
+  if (PERSIST) {
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    v_first = (int)blockIdx.x * per;
+    v_end = v_first + per < total ? v_first + per : total;
+    if (v_first >= v_end) return;
+    p_pair = v_first / nqb; p_qb = v_first - p_pair * nqb; p_b = p_pair / H; p_h = p_pair - p_b * H;
+    qpf_set(p_pair, p_qb, p_b, p_h);
+    for (int pc = 0; pc < 16; ++pc) qpf_piece(pc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
+    v_first = xcd_remap(blockIdx.x, total);
+    v_end = v_first + 1;
+  }
+  auto qpf_set_next = [&]() {   // the block after the current one
+    if (p_qb + 1 < nqb) { qpf_set(p_pair, p_qb + 1, p_b, p_h); return; }
+    const int pr = p_pair + 1, bn = pr / H;
+    qpf_set(pr, 0, bn, pr - bn * H);
+  };
+  for (int v = v_first; v < v_end; ++v, p_adv()) {
+#ifdef W16N_PSTAMPS
+  const bool pst_on = PERSIST && raw != nullptr && blockIdx.x == 0 && v == v_first + 3;
+#endif
+  PST(0);
+  if (PERSIST && v != v_first) __syncthreads();   // every wave is done with the O staging area: the ring may be written again
+  PST(1);
 #ifdef WAN_ATTN_TWO_LAUNCH   // (the A/B library libwanhip_a2l.so: plain launch first, the shifted twin for what it hands over)
   if (SHIFT) { if (wg_flags[v] != 2) return; }  // only what the plain launch handed over
   else if (CARRY_IN && wg_flags[v] != 0) return;  // an earlier partial launch already gave this workgroup up
 #else
   if (CARRY_IN && wg_flags[v] != 0) return;       // an earlier partial launch already gave this workgroup up
 #endif
-  const int pair = v / nqb;
-  const int qb = v - pair * nqb;
-  const int b = pair / H, h = pair - b * H;
+  const int pair = PERSIST ? p_pair : v / nqb;
+  const int qb = PERSIST ? p_qb : v - pair * nqb;
+  const int b = PERSIST ? p_b : pair / H, h = PERSIST ? p_h : pair - b * H;
   const int bk = b % Bk;  // Bk == B: its own K / V^T; Bk == 1: shared; Bk | B (Ulysses: q batches = (source rank, stream), K / V^T batches = stream): b mod Bk
-  const int64_t rs = (int64_t)H * 128;
 
   const bf16_t* qbase = Q + ((int64_t)b * Lq) * rs + (int64_t)h * 128;
   const bf16_t* kbase = Kg + ((int64_t)bk * Lk) * rs + (int64_t)h * 128;
@@ -360,6 +423,14 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   bf16_t* obase = O + ((int64_t)b * Lq) * rs + (int64_t)h * 128;
 
   const int64_t q0 = (int64_t)qb * 256 + wave * 64;
+  const int Lk32 = (int)Lk;
+  Dma dma;
+  if (PERSIST) {  // tiles 0 and 1 first: they travel while the Q fragments are read and the rows are judged
+    dma_init(dma, kbase, vbase, 0, 0, Lk32, 1, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, -1, /*k_rows_16x16=*/true);
+    dma_tile<0, false>(smem, dma);
+#pragma unroll
+    for (int I = 0; I < 8; ++I) dma_piece_i<1>(smem, dma, I);
+  }
   mfma_bf16x8 qf[4][4];  // Q~ = bf16(q * scale * log2 e), [q tile][k-step]
   float ss[4] = {0.f, 0.f, 0.f, 0.f};  // |Q~_row|^2, this lane's 32 of the row's 128 channels
   {
@@ -369,7 +440,10 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
       int64_t r = q0 + 16 * qt + l15;
       if (r > Lq - 1) r = Lq - 1;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) w[qt][ks] = *reinterpret_cast<const uint4*>(qbase + r * rs + ks * 32 + lg * 8);
+      for (int ks = 0; ks < 4; ++ks) {
+        if (PERSIST) w[qt][ks] = *reinterpret_cast<const uint4*>(smem + QAREA + wave * 16384 + (16 * qt + l15) * 256 + (((ks * 4 + lg) ^ l15) << 4));
+        else w[qt][ks] = *reinterpret_cast<const uint4*>(qbase + r * rs + ks * 32 + lg * 8);
+      }
     }
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt)
@@ -380,6 +454,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
         asm volatile("" : "+a"(qf[qt][ks]));  // one accumulator-file tuple from here on
       }
   }
+  PST(2);   // Q fragments in registers
   // ---- the bound: every row of the workgroup must satisfy |Q~_row| * max|k_h| <= 96 (workgroup-uniform) -- or carry a reference shift
   f32x4 negm[4];      // SHIFT: {-m} x 4 per q tile, the C operand of the tile's first MFMA
   float mref[4] = {0.f, 0.f, 0.f, 0.f};
@@ -410,6 +485,28 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
       }
     }
 #ifndef WAN_ATTN_TWO_LAUNCH
+    else if (PERSIST) {
+      // (all 160 KB of LDS are taken: the workgroup-wide votes go through one word per wave instead of __syncthreads_and / _or's own
+      // 256 bytes.  Here the word is the first of the wave's Q row 63 -- its Q fragments are in registers, and the piece of the next block's
+      // rows that lands there is issued at the top of tile 7, seven barriers from here.)
+      const int mine = (__builtin_amdgcn_ballot_w64(!shiftable) != 0 ? 1 : 0) | (__builtin_amdgcn_ballot_w64(!ok) != 0 ? 2 : 0);
+      if (lane == 0) *reinterpret_cast<int*>(smem + QAREA + wave * 16384 + 63 * 256) = mine;
+      __syncthreads();
+      int any = 0;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) any |= *reinterpret_cast<const int*>(smem + QAREA + w4 * 16384 + 63 * 256);
+      if (any & 1) {  // a reference beyond SHIFT_LIMIT (or NaN): tracking loop
+        if (tid == 0) wg_flags[v] = 1;
+        if (v + 1 < v_end) {  // the next block's Q rows, all at once (this block has no tile loop to spread them over)
+          __syncthreads();    // (every wave has read the votes)
+          qpf_set_next();
+          for (int pc = 0; pc < 16; ++pc) qpf_piece(pc);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (tiles 0 and 1 of this block were on their way)
+        continue;
+      }
+      wg_any_shift = (any & 2) != 0;
+    }
     else {  // the ONE bounded launch of a call: a row inside the plain bound has m = 0 (C = +0: the plain kernel's arithmetic, bit for bit)
       if (__syncthreads_and(shiftable ? 1 : 0) == 0) {  // a reference beyond SHIFT_LIMIT (or NaN): tracking loop, before LDS is touched
         if (tid == 0) wg_flags[v] = 1;
@@ -419,13 +516,14 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     }
 #endif
   }
+  const bool qpf_on = PERSIST && v + 1 < v_end;
+  if (qpf_on) qpf_set_next();
+  PST(3);   // votes done
 
   // ---- DMA stream ---------------------------------------------------------------------------------------------------------------
-  const int Lk32 = (int)Lk;
   const int tps = (Lk32 + KVBLK - 1) / KVBLK;
   const int ntile = tps * (nseg - (skip_seg >= 0 ? 1 : 0));
-  Dma dma;
-  dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, skip_seg, /*k_rows_16x16=*/true);
+  if (!PERSIST) dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, skip_seg, /*k_rows_16x16=*/true);
   int cur_tt = 0;
   // valid kv rows from the start of the tile being consumed to the end of its segment: Lk - cur_tt * 64 (cur_tt steps inside the tile)
 
@@ -503,12 +601,17 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
       for (int c = 0; c < 2; ++c) vf[dt][c] = __builtin_bit_cast(mfma_bf16x8, z);
   }
 
-  dma_tile<0, MULTI>(smem, dma);
+  PST(4);   // accumulators cleared, stream set up
+  if (!PERSIST) {
+    dma_tile<0, MULTI>(smem, dma);
 #pragma unroll
-  for (int I = 0; I < 8; ++I) dma_piece_i<1>(smem, dma, I);  // tile 1; the stream steps at the top of every tile of the loop, in front of its pieces
+    for (int I = 0; I < 8; ++I) dma_piece_i<1>(smem, dma, I);  // tile 1; the stream steps at the top of every tile of the loop, in front of its pieces
+  }
+  PST(5);   // 16 pieces issued
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  PST(6);   // tiles 0, 1 landed
   mfma_bf16x8 kf[4][4];
   // in the order the tile loop re-reads them (k-step major, then kv tile)
 #pragma unroll
@@ -556,6 +659,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     }
   }
 
+  PST(7);   // K fragments read, sample done
   int kv_rem_prev = KVBLK;
 #define W16N_STEP(J)                                                                                         \
   if (__builtin_expect(t + (J) < ntile, 1)) {                                                                \
@@ -567,6 +671,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
       asm volatile("" ::: "memory");                                                                         \
     }                                                                                                        \
     __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): every K fragment of this tile was read >= 30 gaps ago */ \
+    if (PERSIST && __builtin_expect(qpf_on && t + (J) < 8, 1)) { qpf_piece(2 * (t + (J))); qpf_piece(2 * (t + (J)) + 1); } /* the next block's Q rows */ \
     if (TIMING && rec) stamp[1] = __builtin_amdgcn_s_memtime();                                              \
     const int kv_rem = Lk32 - (MULTI ? cur_tt : t + (J)) * KVBLK;                                            \
     tile_w16n<J, MULTI, TIMING, SHIFT>(lds, kaddr, vaddr, qf, negm, kf, vf, qa, qb2, kv_rem, lg, smem, dma, cur_tt, tps, stamp, rec); \
@@ -578,6 +683,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     W16N_STEP(2)
   }
 #undef W16N_STEP
+  PST(8);   // tile loop done
   // drain: q-half b's last tile
 #pragma unroll
   for (int k = 17; k < 32; ++k) {
@@ -591,6 +697,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   for (int i = 0; i < 32; ++i) pv_step16(qb2, vf, i);
 
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA lands before O staging reuses LDS; last PV MFMAs -> accumulator reads
+  PST(9);   // drained
   float lsum[4] = {qa.l[0][0] + qa.l[0][1], qa.l[1][0] + qa.l[1][1], qb2.l[0][0] + qb2.l[0][1], qb2.l[1][0] + qb2.l[1][1]};
   if (RAW_OUT) {  // partial result: accumulators and row-sum shares as they are, lane-major (1-KB stores)
     float4* dst = reinterpret_cast<float4*>(raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW);
@@ -610,6 +717,10 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     return;
   }
   // ---- epilogue: normalise, stage the wave's 64 x 128 O tile through LDS, store whole rows ------------------------------------------
+  // (PERSIST: lane-derived addresses of the epilogue are recomputed per block from opaque copies -- hoisted out of the block loop they
+  // would sit in vector registers through the tile loop, which has none to spare)
+  int l15e = l15, lge = lg, lanee = lane;
+  if (PERSIST) asm volatile("" : "+v"(l15e), "+v"(lge), "+v"(lanee));
   float inv[4];
   bool bad = false;
 #pragma unroll
@@ -621,43 +732,73 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     if (SHIFT) bad = bad || !((s >= SHIFT_MIN_ROWSUM && s <= SHIFT_MAX_ROWSUM) || mref[c] == 0.f);  // under- / overflowed against its shift (or NaN): the tracking loop redoes the workgroup
   }
   if (SHIFT) {
-    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    int any_bad;
+    if (PERSIST) {  // the vote through V^T stage 2 (the O staging below covers the K stages and V^T stage 0; the ring is idle behind the first barrier)
+      __syncthreads();
+      if (lanee == 0) *reinterpret_cast<int*>(smem + (NST + 2) * IMG + wave * 4) = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
+      __syncthreads();
+      const int4 vt4 = *reinterpret_cast<const int4*>(smem + (NST + 2) * IMG);
+      any_bad = vt4.x | vt4.y | vt4.z | vt4.w;
+    } else {
+      any_bad = __syncthreads_or(bad ? 1 : 0);
+    }
     if (tid == 0) wg_flags[v] = any_bad ? 1 : 0;
+    // a handed-over workgroup stores nothing: wan_dit_forward attends IN PLACE (o = q), and the tracking launch that redoes the workgroup
+    // reads its Q rows again
+    if (any_bad) { if (PERSIST) continue; return; }
   } else {
     __syncthreads();
   }
+  PST(10);  // verdict
   char* ob = smem + wave * (64 * 256);
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const float iv = inv[hf * 2 + qt];
-      const int row = (hf * 2 + qt) * 16 + l15;
+      const int row = (hf * 2 + qt) * 16 + l15e;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         const f32x4 acc = hf ? qb2.accO[dt][qt] : qa.accO[dt][qt];
         uint2 w;
         w.x = cvt_pk(acc[0] * iv, acc[1] * iv);
         w.y = cvt_pk(acc[2] * iv, acc[3] * iv);
-        const int ch = (dt * 2 + (lg >> 1)) ^ (l15 & 15);  // d = 16 dt + 4 g .. + 3: 16-B chunk 2 dt + (g >> 1), its half g & 1
-        *reinterpret_cast<uint2*>(ob + row * 256 + ch * 16 + (lg & 1) * 8) = w;
+        const int ch = (dt * 2 + (lge >> 1)) ^ (l15e & 15);  // d = 16 dt + 4 g .. + 3: 16-B chunk 2 dt + (g >> 1), its half g & 1
+        *reinterpret_cast<uint2*>(ob + row * 256 + ch * 16 + (lge & 1) * 8) = w;
       }
     }
   __syncthreads();
+  if (PERSIST) {  // all sixteen staged rows first: one read per conditional store serialises sixteen LDS round trips (2,400 cycles of a 4,500-cycle epilogue)
+    uint4 vals[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = i * 4 + (lanee >> 4), c = lanee & 15;
+      vals[i] = *reinterpret_cast<const uint4*>(ob + r * 256 + ((c ^ (r & 15)) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = i * 4 + (lanee >> 4), c = lanee & 15;
+      const int64_t qr = q0 + r;
+      if (qr < Lq) *reinterpret_cast<uint4*>(obase + qr * rs + c * 8) = vals[i];
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int r = i * 4 + (lane >> 4), c = lane & 15;
+    const int r = i * 4 + (lanee >> 4), c = lanee & 15;
     const int64_t qr = q0 + r;
     if (qr < Lq) {
       const uint4 val = *reinterpret_cast<const uint4*>(ob + r * 256 + ((c ^ (r & 15)) << 4));
       *reinterpret_cast<uint4*>(obase + qr * rs + c * 8) = val;
     }
   }
+  }
+  PST(11);  // O rows on their way
   if (TIMING && blockIdx.x == 0 && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
 #pragma unroll
     for (int k6 = 0; k6 < 20; ++k6) reinterpret_cast<uint64_t*>(O)[k6] = stamp[k6];
   }
+  }  // q blocks of the workgroup (one unless PERSIST)
 }
 
 }  // namespace
@@ -685,6 +826,8 @@ int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const 
     W16N_CASE(6 | 64 | 128)
     W16N_CASE(2 | 4 | 16 | 128)
     W16N_CASE(2 | 4 | 32 | 64 | 128)
+    W16N_CASE(4 | 128 | 256)
+    W16N_CASE(6 | 128 | 256)
 #ifdef W64Q_TIMING
     W16N_CASE(7)
 #endif

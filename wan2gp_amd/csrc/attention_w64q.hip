@@ -747,6 +747,14 @@ __global__ __launch_bounds__(256) void attn_kmax_kernel(const bf16_t* __restrict
 
 }  // namespace
 
+// Test / A-B hook: short KV with a scratch takes the bounded loop as ordinary (one q block per workgroup) launches instead of the persistent form
+static int g_no_persist = 0;
+extern "C" int wan_attention_debug_no_persist(int on) {
+  const int old = g_no_persist;
+  g_no_persist = on ? 1 : 0;
+  return old;
+}
+
 // the bounded loop on the 16x16x32 MFMA (attention_w16n.hip): takes the bounded launches below unless the library is built
 // -DWAN_ATTN_NO_MI16 (the A/B library libwanhip_a32.so)
 int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B,
@@ -801,6 +809,29 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   if (kmax_scratch != nullptr) {
     const int fl = (pre ? 6 : 4) | (nseg > 1 ? 64 : 0);
 #ifndef WAN_ATTN_TWO_LAUNCH
+    // short KV (cross-attention; attention.hip hands a scratch over from 8 tiles on): one persistent workgroup per CU walks a run of q blocks
+    if (nseg == 1 && Lk <= 2048 && Lk > 448 && !g_no_persist) {
+      static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+      const unsigned grid = (unsigned)(total < cus ? total : cus);
+#ifdef W16N_PSTAMPS
+      static uint64_t* pst = nullptr;
+      if (!pst) WAN_CHECK_HIP(hipMalloc((void**)&pst, 32 * 8));
+      raw = reinterpret_cast<float*>(pst);
+#endif
+      if (wan_attention_w16n_launch(fl | 128 | 256, grid, stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, (int)nqb, scale_log2e, 1, 0, 0,
+                                    (const float*)kmax_scratch, wg_flags, raw, skip_seg) != 0) return -1;
+#ifdef W16N_PSTAMPS
+      {
+        uint64_t h[12];
+        WAN_CHECK_HIP(hipStreamSynchronize(stream));
+        WAN_CHECK_HIP(hipMemcpy(h, pst, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "pstamps:");
+        for (int i = 1; i < 12; ++i) fprintf(stderr, " %lld", (long long)(h[i] - h[i - 1]));
+        fprintf(stderr, "  block %lld\n", (long long)(h[11] - h[0]));
+        raw = nullptr;
+      }
+#endif
+    } else
     if (W16N_TRY(fl | 128, nseg, k_seg_stride, vt_seg_stride, skip_seg)) {
       // ONE bounded launch: the shifted instantiation takes every workgroup (m = 0 inside the plain bound)
     } else

@@ -796,11 +796,11 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
         ProfScope ps(PROF_CROSS_ATTN, st);
         if (cb[s0 + s] == 2) {
           bf16_t* hs = b.h + (int64_t)s * Ll * d;
-          RC(wan_attention_bounded(qs, ks, vs, xs, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
-          RC(wan_attention_bounded(qs, ks + (int64_t)TL * d, vs + (int64_t)TL * d, hs, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+          RC(wan_attention_bounded(qs, ks, vs, xs, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, b.kmax, stream));
+          RC(wan_attention_bounded(qs, ks + (int64_t)TL * d, vs + (int64_t)TL * d, hs, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, b.kmax, stream));
           RC(wan_nag_combine(xs, hs, dst, Ll, d, nag[0], nag[1], nag[2], stream));
         } else {
-          RC(wan_attention_bounded(qs, ks, vs, dst, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, nullptr, stream));
+          RC(wan_attention_bounded(qs, ks, vs, dst, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, b.kmax, stream));
         }
       }
     } else {
@@ -814,7 +814,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     if (!c->has_img) {
       if (!any_nag) {
         ProfScope ps(PROF_CROSS_ATTN, st);
-        RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.q, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, nullptr, stream));
+        RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.q, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, b.kmax, stream));
       }
     } else {
       // WanI2VCrossAttention (model.py:466-499): the same q attends the text tokens and the 257 CLIP tokens (K_img / V_img
@@ -824,7 +824,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(linear(c->clip_ctx, Lw.vimg, b.cvtimg, CLIP_TOK, d, d, WAN_EPI_TRANSPOSED, stream, nullptr, nullptr, nullptr, -1, 1, CLIP_LDV,
                 q8, 1, 0, Lw.kimg.w8 != nullptr));
       ProfScope ps(PROF_CROSS_ATTN, st);
-      if (!any_nag) RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, nullptr, stream));
+      if (!any_nag) RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, b.kmax, stream));
       RC(wan_attention_bounded(b.q, b.ckimg, b.cvtimg, b.q, S, 1, Ll, CLIP_TOK, CLIP_LDV, nh, 1, 0, 0, 1, nullptr, stream));
       RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }
