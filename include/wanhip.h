@@ -495,6 +495,9 @@ int wan_gemm_f16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw,
 /* Test hook (not a product entry): force wan_vae_conv3d onto its 64-bit-offset instantiations, which inputs below 2^31
  * elements never reach; returns the previous setting.  Process-wide. */
 int wan_vae_debug_force_big(int on);
+/* Test / A-B hook: 1 = the 3 x 3 x 3 stride-1 layers stay on the gather kernel instead of the halo-patch kernel (csrc/vae_conv_halo.hip; the two
+ * sum in different orders and agree to fp32 rounding, not bit for bit); returns the old value. */
+int wan_vae_debug_no_halo(int on);
 int wan_attention_debug_no_persist(int on);
 /* P[r,:L] = softmax(S[r,:L]); P[r,L:ld] = 0 */
 int wan_vae_softmax(const uint16_t* S, uint16_t* P, int64_t rows, int L, int64_t ld, void* stream);

@@ -250,17 +250,70 @@ def test_conv_big_offsets_forced_equal_the_32bit_kernel_bit_for_bit():
         "stride-2 time conv": lambda: n.conv(x4, "dtconv", cache=prev2, st_t=2, front=1, pad_s=0),
     }
     lib = L.load()
-    small = {k: f().clone() for k, f in cases.items()}
-    old = lib.wan_vae_debug_force_big(1)
+    no_halo = lib.wan_vae_debug_no_halo(1)     # the 3 x 3 x 3 cases on the gather kernel both times (the halo-patch kernel sums in another order)
     try:
-        assert old == 0
-        big = {k: f().clone() for k, f in cases.items()}
+        small = {k: f().clone() for k, f in cases.items()}
+        old = lib.wan_vae_debug_force_big(1)
+        try:
+            assert old == 0
+            big = {k: f().clone() for k, f in cases.items()}
+        finally:
+            lib.wan_vae_debug_force_big(0)
     finally:
-        lib.wan_vae_debug_force_big(0)
+        lib.wan_vae_debug_no_halo(no_halo)
     torch.cuda.synchronize()
     for k in cases:
         assert torch.isfinite(small[k].float()).all() and small[k].float().abs().max() > 0.1, k
         assert torch.equal(small[k], big[k]), f"BIG instantiation differs from the 32-bit one: {k}"
+
+
+@pytest.mark.parametrize("cin,cout,T,H,W,cached,resid,f32out", [
+    (96, 96, 3, 48, 80, True, True, False),      # a residual block conv of the 96-channel level: whole tiles, cache, residual
+    (192, 192, 2, 37, 53, True, False, False),   # ragged tiles on both edges, two cout tiles (the second half empty above 192)
+    (32, 96, 1, 16, 16, False, False, False),    # one tile, one channel block, no cache (causal front = zeros)
+    (384, 160, 2, 9, 23, True, True, False),     # image smaller than a tile in height, 12 channel blocks, ragged cout tile
+    (96, 32, 4, 30, 40, False, False, True),     # the decoder's head: fp32 output, a quarter cout tile
+    (64, 64, 5, 33, 17, True, False, False),
+], ids=["96_level", "192_ragged", "one_tile", "384_short", "head_f32", "64ch"])
+def test_conv_halo_patch_kernel_against_fp64_and_the_gather_kernel(cin, cout, T, H, W, cached, resid, f32out):
+    """Round 4: the 3 x 3 x 3 stride-1 convolutions run on the halo-patch kernel (csrc/vae_conv_halo.hip: the 18 x 18 input patch of a 16 x 16
+    tile staged once per frame tap and channel block, nine taps read shifted windows).  Against an fp64 convolution of the same fp16
+    operands on every output element (the error of an fp32-accumulating kernel: rounding of the fp16 store), and against the gather
+    kernel (wan_vae_debug_no_halo) -- the two sum in different orders and may differ by an fp16 ulp here and there, never more."""
+    from wan2gp_amd import lib as L
+    from wan2gp_amd.vae import _VaeNet
+    g = torch.Generator().manual_seed(cin + cout + H)
+    wt = (torch.randn(cout, cin, 3, 3, 3, generator=g) / (27 * cin) ** 0.5).half().float()
+    bs = (0.1 * torch.randn(cout, generator=g)).half().float()
+    n = _VaeNet({"c.weight": wt, "c.bias": bs}, torch.device("cuda"))
+    x5 = torch.randn(1, cin, T, H, W, generator=g).half().float()
+    c5 = torch.randn(1, cin, 2, H, W, generator=g).half().float() if cached else None
+    r5 = torch.randn(1, cout, T, H, W, generator=g).half().float() if resid else None
+    x, cache, res = _cl(x5), (_cl(c5) if cached else None), (_cl(r5) if resid else None)
+    lib = L.load()
+    got = n.conv(x, "c", cache=cache, res=res, out_f32=f32out).float().cpu()
+    old = lib.wan_vae_debug_no_halo(1)
+    try:
+        gat = n.conv(x, "c", cache=cache, res=res, out_f32=f32out).float().cpu()
+    finally:
+        lib.wan_vae_debug_no_halo(old)
+    # fp64 reference: causal front = the cache's two frames or zeros, "same" zero padding in space
+    front = c5 if cached else torch.zeros(1, cin, 2, H, W)
+    xin = torch.cat([front, x5], 2).double().cuda()
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(xin, (1, 1, 1, 1, 0, 0)), wt.double().cuda(), bs.double().cuda())
+    if not f32out:
+        ref = ref.half().double() if resid else ref
+    if resid:
+        ref = ref + r5.double().cuda()
+    ref = ref[0].permute(1, 2, 3, 0).float().cpu()
+    assert got.shape == ref.shape == gat.shape
+    tol = 2e-5 if f32out else 2.0 ** -10                       # fp32 accumulation order / one fp16 rounding of O(1) values (+ the residual's)
+    for name, o in (("halo", got), ("gather", gat)):
+        err = (o - ref).abs()
+        assert torch.isfinite(o).all() and (err <= tol * (1.0 + ref.abs()) * (3 if resid and not f32out else 1.5)).all(), (name, err.max().item())
+    assert ((got - gat).abs() <= 2 * tol * (1.0 + ref.abs())).all()
+    if not f32out:
+        assert (got != gat).float().mean().item() < 0.2              # (mostly the same fp16 value)
 
 
 def test_conv_on_a_chunk_beyond_2_31_elements():

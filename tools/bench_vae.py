@@ -11,7 +11,11 @@ from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=81); ap.add_argument("--h", type=int, default=720); ap.add_argument("--w", type=int, default=1280)
 ap.add_argument("--encode", action="store_true"); ap.add_argument("--lib", default=None)
+ap.add_argument("--no-halo", action="store_true", help="3x3x3 stride-1 convolutions on the gather kernel (wan_vae_debug_no_halo)")
 a = ap.parse_args()
+if a.no_halo:
+    from wan2gp_amd import lib as _l2
+    _l2.load().wan_vae_debug_no_halo(1)
 vae = WanVAEHIP(state_dict=random_vae_state_dict())
 t = (a.frames - 1) // 4 + 1
 z = torch.randn(16, t, a.h // 8, a.w // 8, device="cuda")

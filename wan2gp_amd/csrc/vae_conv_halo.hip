@@ -1,0 +1,244 @@
+// The 3 x 3 x 3 stride-1 causal convolutions of the Wan VAE (vae.py:43-82: every ResidualBlock conv, conv1 / conv_in / head of the
+// decoder and encoder -- most of a decode's FLOPs) as an implicit GEMM whose activation operand is a HALO PATCH in LDS.
+//
+// Why (round 4): the gather kernel of vae_ops.hip fetches every K-step's 128 x 64 im2col slab from L2 -- each input
+// pixel once per tap, 27 times -- and the ablation (make cabl, profiles/r04_vae_conv_ablation_run18.log) showed that stream alone costs 80 %
+// of the loop's time: 64 B per matrix-peak clock and CU are needed, ~23 are delivered.  Here a workgroup owns a 16 x 16 pixel tile of one
+// output frame and 128 output channels; for each (frame tap kt, 32-channel block cb) it stages the 18 x 18 x 32-channel input patch ONCE
+// (25.9 KB) and the nine spatial taps read shifted windows of it: the activation half of the stream drops ninefold, the weight half is
+// shared by 256 pixels instead of 128.  Per (kt, cb): 26 KB of patch + 9 x 8 KB of weights for 9 x 16 MFMAs per wave.
+//
+// K order: (kt, cb, kh, kw) -- not vae_ops.hip's (kt, kh, kw, cb): the fp32 sums are taken in another order, so the two kernels agree to
+// rounding, not bit for bit (tests compare both with the oracle; the bit-for-bit BIG / non-BIG comparison runs with this kernel switched off).
+//
+// Workgroup: 512 threads = 8 waves, wave (wr = wave >> 1, wc = wave & 1) owns pixel rows 4 wr .. + 3 of the tile (four 16-pixel MFMA tiles,
+// one per row) x output channels 64 wc .. + 63 (four 16-channel tiles); two workgroups per CU (76 KB of LDS each, <= 128 registers).
+// LDS: patch stage s (2): pixel pp = pr * 18 + pc of the patch at s * 26,624 + pp * 80 (64 B of channels + 16 B of padding: 16
+//      consecutive pixels x 4 chunks land on distinct banks up to 2-way); weights ring (3): row R (= permuted output channel, as
+//      vae_ops.hip: MFMA tile xt row 4 g + r <-> channel 16 g + 4 xt + r, so a lane ends with 16 consecutive channels) at R * 64, 16-B chunk c
+//      at slot c ^ ((R >> 2) & 3).
+// MFMA: acc[a][b] += W frag(b) x P frag(a), v_mfma_f32_16x16x32_f16, one k-step per (tap, cb).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 halo_f16x8;
+
+namespace {
+
+constexpr int HT = 16;                       // tile edge (pixels)
+constexpr int HP = HT + 2;                   // patch edge
+constexpr int HPITCH = 80;                   // bytes per patch pixel
+constexpr int HPATCH = 26 * 1024;            // bytes per patch stage (324 x 80 = 25,920, rounded up to DMA pieces)
+constexpr int HWST = 128 * 64;               // bytes per weight stage
+constexpr int HW0 = 2 * HPATCH;              // weights ring offset
+
+struct HaloP {
+  const uint16_t* x;
+  const uint16_t* cache;     // two frames in front of x (or null)
+  const uint16_t* zero16;
+  const uint16_t* w;         // [Cout][Kp], K in units of 32 channels, unit = tap * CB + cb (vae_ops.hip's packing)
+  const uint16_t* bias;
+  const uint16_t* res;
+  uint16_t* out;
+  float* out_f32;
+  int Tin, H, W, Cin, Tout, Cout, CB, Kp, front, ncache;
+  int tiles_h, tiles_w, tiles_x;
+};
+
+__device__ __forceinline__ void hglds_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void hglds_a(const void* gsrc, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ const char* huni(const char* p) {
+  const uint64_t u = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+  return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * HPATCH + 3 * HWST];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int n = lane & 15, lg = lane >> 4;
+
+  const int nwg = p.Tout * p.tiles_h * p.tiles_w * p.tiles_x;
+  int wg = xcd_remap(blockIdx.x, nwg);
+  const int tx = wg % p.tiles_x; wg /= p.tiles_x;       // cout tiles fastest: they share the patch in L2
+  const int tw = wg % p.tiles_w; wg /= p.tiles_w;
+  const int th = wg % p.tiles_h;
+  const int to = wg / p.tiles_h;
+  const int h0 = th * HT, w0 = tw * HT, x0 = tx * 128;
+  const int64_t frame = (int64_t)p.H * p.W * p.Cin;
+
+  // ---- patch pieces: this wave's four 1-KB pieces of a stage (32 issued for 26: the last six repeat pieces 0..5 -- same bytes to the
+  // same place -- so that every wave has the same number of loads in flight and one s_waitcnt serves all)
+  int so[4];          // element offset of the lane's 16 bytes inside a frame (channel block 0), -1: zeros
+  uint32_t pdst[4];   // LDS offset of the piece inside a stage
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pi = (wave * 4 + i) % 26;
+    const int o = pi * 1024 + lane * 16;
+    const int pp = o / HPITCH, slot = (o - pp * HPITCH) >> 4;
+    const int pr = pp / HP, pc = pp - pr * HP;
+    const int hi = h0 - 1 + pr, wi = w0 - 1 + pc;
+    const bool ok = pp < HP * HP && slot < 4 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+    so[i] = ok ? (hi * p.W + wi) * p.Cin + slot * 8 : -1;
+    pdst[i] = (uint32_t)(pi * 1024);
+  }
+  // ---- weight piece: the wave's 16 rows x 64 B of a stage
+  uint32_t wvoff;
+  {
+    const int R = wave * 16 + (lane >> 2), slot = lane & 3;
+    const int c = slot ^ ((R >> 2) & 3);
+    const int slab = R >> 6, jj = R & 63, xt = jj >> 4, ii = jj & 15;
+    int co = x0 + slab * 64 + (ii >> 2) * 16 + xt * 4 + (ii & 3);
+    if (co > p.Cout - 1) co = p.Cout - 1;
+    wvoff = (uint32_t)(((int64_t)co * p.Kp + c * 8) * 2);
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // frame tap kt of this output frame: input frame ti = to - front + kt; < 0: the cache (two frames in front of x), beyond: zeros
+  auto frame_ptr = [&](int kt) -> const uint16_t* {
+    const int ti = to - p.front + kt;
+    if (ti >= 0) return ti < p.Tin ? p.x + (int64_t)ti * frame : nullptr;
+    return (p.ncache > 0 && ti >= -p.ncache) ? p.cache + (int64_t)(ti + 2) * frame : nullptr;
+  };
+  const int G = 3 * p.CB;  // groups (kt, cb), walked with carried coordinates (a scalar division by CB per tap is a VALU sequence)
+  auto issue_patch = [&](int stage, int kt, int cb) {
+    const uint16_t* fp = frame_ptr(kt);
+    const uint32_t st = lds0 + (uint32_t)(stage * HPATCH);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint16_t* src = (fp != nullptr && so[i] >= 0) ? fp + so[i] + cb * 32 : p.zero16;
+      hglds_a(src, st + pdst[i]);
+    }
+  };
+  auto issue_w = [&](int u, int stage) {   // K unit u = (kt * 9 + tap) * CB + cb: 64 bytes of every weight row
+    hglds_s(wvoff, huni(reinterpret_cast<const char*>(p.w) + (int64_t)u * 64), lds0 + HW0 + stage * HWST + wave * 1024);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int ybase[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) ybase[a] = ((4 * wr + a) * HP + n) * HPITCH + lg * 16;
+  const int xbase = HW0 + (wc * 64 + n) * 64 + ((lg ^ ((n >> 2) & 3)) << 4);
+
+  int kt = 0, cb = 0;                                   // group g
+  int kt1 = p.CB > 1 ? 0 : 1, cb1 = p.CB > 1 ? 1 : 0;   // group g + 1 (the last group repeats itself: its re-loads land in idle stages)
+  issue_patch(0, 0, 0);
+  issue_w(0, 0);
+  issue_w(p.CB, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int g = 0; g < G; ++g) {
+    const int poff = (g & 1) * HPATCH;
+    const int ub = kt * 9 * p.CB + cb, ub1 = kt1 * 9 * p.CB + cb1;
+#define HALO_TAP(TAP)                                                                                                              \
+  {                                                                                                                                \
+    if ((TAP) > 0 || g > 0) {                                                                                                      \
+      if ((TAP) == 1 || (TAP) == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); /* W(q) landed; W(q+1) and the next patch's four pieces may be out */ \
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                                                        \
+      __builtin_amdgcn_s_barrier();                                                                                                \
+      asm volatile("" ::: "memory");                                                                                               \
+    }                                                                                                                              \
+    issue_w((TAP) + 2 < 9 ? ub + ((TAP) + 2) * p.CB : ub1 + ((TAP) + 2 - 9) * p.CB, ((TAP) + 2) % 3);                               \
+    if ((TAP) == 0) issue_patch((g + 1) & 1, kt1, cb1);                                                                            \
+    constexpr int dy = (TAP) / 3, dx = (TAP) % 3;                                                                                  \
+    halo_f16x8 yf[4], xf[4];                                                                                                       \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                                \
+      yf[t] = *reinterpret_cast<const halo_f16x8*>(smem + poff + ybase[t] + (dy * HP + dx) * HPITCH);                              \
+      xf[t] = *reinterpret_cast<const halo_f16x8*>(smem + xbase + ((TAP) % 3) * HWST + t * 1024);                                  \
+    }                                                                                                                              \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                                  \
+      _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                                                \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[b], yf[a], acc[a][b], 0, 0, 0);                                      \
+  }
+    HALO_TAP(0) HALO_TAP(1) HALO_TAP(2) HALO_TAP(3) HALO_TAP(4) HALO_TAP(5) HALO_TAP(6) HALO_TAP(7) HALO_TAP(8)
+#undef HALO_TAP
+    kt = kt1; cb = cb1;
+    if (g + 2 < G) { if (++cb1 == p.CB) { cb1 = 0; ++kt1; } }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (clamped) loads
+
+  // ---- epilogue (vae_ops.hip's: bias, fp16 rounding then + residual, fp16 or fp32 store; a lane owns 16 consecutive channels of a pixel)
+  const int xb = x0 + wc * 64 + lg * 16;
+  float bcol[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bcol[j] = 0.f;
+  const bool full = xb + 16 <= p.Cout;
+  if (p.bias != nullptr) {
+    if (full) {
+      unpack8t<true>(*reinterpret_cast<const uint4*>(p.bias + xb), bcol);
+      unpack8t<true>(*reinterpret_cast<const uint4*>(p.bias + xb + 8), bcol + 8);
+    } else {
+      for (int j = 0; j < 16; ++j)
+        if (xb + j < p.Cout) bcol[j] = h2f(p.bias[xb + j]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int h = h0 + 4 * wr + a, w = w0 + n;
+    if (h >= p.H || w >= p.W) continue;
+    const int64_t pp = ((int64_t)to * p.H + h) * p.W + w;
+    float v[16];
+#pragma unroll
+    for (int xt = 0; xt < 4; ++xt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[xt * 4 + r] = acc[a][xt][r] + bcol[xt * 4 + r];
+    if (full) {
+      const int64_t oidx = pp * p.Cout + xb;
+      if (p.res != nullptr) {
+        float rv[16];
+        unpack8t<true>(*reinterpret_cast<const uint4*>(p.res + oidx), rv);
+        unpack8t<true>(*reinterpret_cast<const uint4*>(p.res + oidx + 8), rv + 8);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = rnd16<true>(v[j]) + rv[j];  // conv output is fp16, then x + h
+      }
+      if (p.out_f32 != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) p.out_f32[oidx + j] = v[j];
+      } else {
+        *reinterpret_cast<uint4*>(p.out + oidx) = pack8t<true>(v);
+        *reinterpret_cast<uint4*>(p.out + oidx + 8) = pack8t<true>(v + 8);
+      }
+    } else {
+      for (int j = 0; j < 16; ++j) {
+        if (xb + j < p.Cout) {
+          const int64_t oidx = pp * p.Cout + xb + j;
+          float o = v[j];
+          if (p.res != nullptr) o = rnd16<true>(o) + h2f(p.res[oidx]);
+          if (p.out_f32 != nullptr) p.out_f32[oidx] = o;
+          else p.out[oidx] = f2h(o);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Launch for wan_vae_conv3d (vae_ops.hip): the caller has checked 3 x 3 x 3, stride 1, pad 1, no up-sampling / interleave, 32-bit offsets.
+int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const uint16_t* zero16, const uint16_t* w, const uint16_t* bias,
+                               const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int H, int W, int Cin, int Tout, int Cout,
+                               int front, int Kp, hipStream_t stream) {
+  HaloP p;
+  p.x = x; p.cache = cache; p.zero16 = zero16; p.w = w; p.bias = bias; p.res = res; p.out = out; p.out_f32 = out_f32;
+  p.Tin = Tin; p.H = H; p.W = W; p.Cin = Cin; p.Tout = Tout; p.Cout = Cout; p.CB = Cin / 32; p.Kp = Kp; p.front = front;
+  p.ncache = cache ? 2 : 0;
+  p.tiles_h = (H + HT - 1) / HT; p.tiles_w = (W + HT - 1) / HT; p.tiles_x = (Cout + 127) / 128;
+  const int64_t nwg = (int64_t)Tout * p.tiles_h * p.tiles_w * p.tiles_x;
+  if (nwg == 0) return 0;
+  WAN_REQUIRE(nwg < ((int64_t)1 << 31), "wan_vae_conv3d: grid too large");
+  hipLaunchKernelGGL(conv3d_halo_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}

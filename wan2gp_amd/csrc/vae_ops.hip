@@ -323,6 +323,17 @@ static int ensure_zero_page(hipStream_t st) {
 
 // Test hook: take the 64-bit-offset instantiations (BIG) regardless of the input size, so that a parity test can hold them
 // bit-for-bit against the 32-bit ones on the same input (they are otherwise reached only by chunks of 2^31 elements and more).
+// Test / A-B hook: keep the 3 x 3 x 3 stride-1 layers on the gather kernel above instead of the halo-patch kernel (vae_conv_halo.hip)
+static int g_no_halo = 0;
+extern "C" int wan_vae_debug_no_halo(int on) {
+  const int old = g_no_halo;
+  g_no_halo = on ? 1 : 0;
+  return old;
+}
+int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const uint16_t* zero16, const uint16_t* w, const uint16_t* bias,
+                               const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int H, int W, int Cin, int Tout, int Cout,
+                               int front, int Kp, hipStream_t stream);
+
 static int g_force_big = 0;
 extern "C" int wan_vae_debug_force_big(int on) {
   const int old = g_force_big;
@@ -353,6 +364,11 @@ extern "C" int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const ui
   p.M = (int64_t)Tout * Hout * Wout;
   if (p.M == 0) return 0;
   const bool big = g_force_big || (int64_t)(Tin + 2) * Hin * Win * Cin >= ((int64_t)1 << 31);
+  // the residual blocks' convolutions (3 x 3 x 3, stride 1, "same" in space): the halo-patch kernel -- each input pixel staged once per
+  // frame tap and channel block instead of gathered once per tap (round 4)
+  if (!big && !g_no_halo && KT == 3 && KH == 3 && KW == 3 && st_t == 1 && st_s == 1 && pad_s == 1 && !ups && !interleave && Hout == Hin &&
+      Wout == Win && (int64_t)Tout * Hout * Wout * Cout < ((int64_t)1 << 31))
+    return wan_vae_conv3d_halo_launch(x, cache, g_zero_page, w, bias, res, out, out_f32, Tin, Hin, Win, Cin, Tout, Cout, front, p.nk * 64, st);
   p.tiles_y = (int)((p.M + CBM - 1) / CBM);
   p.tiles_x = (Cout + CBN - 1) / CBN;
   const dim3 grid((unsigned)(p.tiles_y * p.tiles_x));

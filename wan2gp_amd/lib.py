@@ -138,6 +138,7 @@ SIGNATURES = {
     "wan_sched_step": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_vae_conv3d": (c_int, [c_void_p] * 7 + [c_int] * 17 + [c_void_p]),
     "wan_vae_debug_force_big": (c_int, [c_int]),
+    "wan_vae_debug_no_halo": (c_int, [c_int]),
     "wan_attention_debug_no_persist": (c_int, [c_int]),
     "wan_vae_create": (c_int, [POINTER(c_void_p)]),
     "wan_vae_destroy": (None, [c_void_p]),
