@@ -316,6 +316,39 @@ def test_conv_halo_patch_kernel_against_fp64_and_the_gather_kernel(cin, cout, T,
         assert (got != gat).float().mean().item() < 0.2              # (mostly the same fp16 value)
 
 
+@pytest.mark.parametrize("cin,cout,T,H,W,ups", [(192, 96, 3, 24, 40, True), (384, 192, 2, 11, 13, True), (96, 96, 2, 19, 33, False), (32, 32, 1, 8, 8, True)],
+                         ids=["resample_192_96", "resample_384_ragged", "conv2d_plain", "one_tile_ups"])
+def test_conv2d_3x3_on_the_halo_patch_kernel(cin, cout, T, H, W, ups):
+    """Resample's Conv2d 3 x 3 behind the nearest-exact 2x up-sampling (vae.py:105-111, :124-141) on the halo-patch kernel (KT = 1; patch
+    pixel (hi, wi) of the up-sampled frame = input pixel (hi >> 1, wi >> 1)): every output element against an fp64 convolution of the
+    up-sampled input, and against the gather kernel."""
+    from wan2gp_amd import lib as L
+    from wan2gp_amd.vae import _VaeNet
+    g = torch.Generator().manual_seed(cin + cout + W)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).half().float()
+    bs = (0.1 * torch.randn(cout, generator=g)).half().float()
+    n = _VaeNet({"c.weight": wt, "c.bias": bs}, torch.device("cuda"))
+    x5 = torch.randn(1, cin, T, H, W, generator=g).half().float()
+    x = _cl(x5)
+    lib = L.load()
+    got = n.conv(x, "c", ups=ups).float().cpu()
+    old = lib.wan_vae_debug_no_halo(1)
+    try:
+        gat = n.conv(x, "c", ups=ups).float().cpu()
+    finally:
+        lib.wan_vae_debug_no_halo(old)
+    xin = x5[0].permute(1, 0, 2, 3).double().cuda()                      # [T, C, H, W]
+    if ups:
+        xin = torch.nn.functional.interpolate(xin, scale_factor=2.0, mode="nearest-exact")
+    ref = torch.nn.functional.conv2d(xin, wt.double().cuda(), bs.double().cuda(), padding=1).permute(0, 2, 3, 1).float().cpu()
+    assert got.shape == ref.shape == gat.shape
+    tol = 2.0 ** -10
+    for name, o in (("halo", got), ("gather", gat)):
+        err = (o - ref).abs()
+        assert torch.isfinite(o).all() and (err <= 1.5 * tol * (1.0 + ref.abs())).all(), (name, err.max().item())
+    assert ((got - gat).abs() <= 2 * tol * (1.0 + ref.abs())).all() and (got != gat).float().mean().item() < 0.2
+
+
 def test_conv_on_a_chunk_beyond_2_31_elements():
     """(Tin + 2) * H * W * C >= 2^31: the launcher takes the 64-bit instantiation by itself.  384 channels at 720 x 1280,
     5 frames + the 2-frame cache; 32 output channels keep it cheap.  Sampled output pixels (the far end of the tensor

@@ -24,6 +24,11 @@ def short(name):
         # handed over -- its own row, so that launches of the plain kernel still count forwards
         # (second half of round 4: FLAGS | 256 = the persistent short-KV form, text cross-attention)
         return "attn_w16n_kernel<%s%s>" % ("persistent" if fl & 256 else "shifted" if fl & 128 else "bounded", ",prescaled" if fl & 2 else "")
+    m = re.search(r"conv3d_halo_kernelILi(\d)ELb(\d)", name)
+    if m:
+        return "conv3d_halo_kernel<kt=%s%s>" % (m.group(1), ",ups" if m.group(2) == "1" else "")
+    if "conv3d_halo_kernel" in name:
+        return "conv3d_halo_kernel"
     for k in ("gemm_fp8m_kernel", "gemm_fp8_kernel", "permute16_kernel", "fp8_quant_kernel", "fp8_absmax_kernel", "attn_kmax_kernel", "gemm256m_kernel", "gemm256k_kernel", "gemm256_kernel", "gemm32_kernel", "attn_w64q_kernel", "attn_w64_kernel", "attn_pp_kernel", "attn_fwd_kernel", "gemm_bf16_kernel", "rmsnorm_rope_kernel", "layernorm_kernel", "gated_residual",
               "patch_embed_kernel", "head_gemm_kernel", "gemv_kernel", "lincomb_kernel", "cfg_combine", "transpose_v"):
         if k in name:

@@ -5,18 +5,20 @@
 // pixel once per tap, 27 times -- and the ablation (make cabl, profiles/r04_vae_conv_ablation_run18.log) showed that stream alone costs 80 %
 // of the loop's time: 64 B per matrix-peak clock and CU are needed, ~23 are delivered.  Here a workgroup owns a 16 x 16 pixel tile of one
 // output frame and 128 output channels; for each (frame tap kt, 32-channel block cb) it stages the 18 x 18 x 32-channel input patch ONCE
-// (25.9 KB) and the nine spatial taps read shifted windows of it: the activation half of the stream drops ninefold, the weight half is
-// shared by 256 pixels instead of 128.  Per (kt, cb): 26 KB of patch + 9 x 8 KB of weights for 9 x 16 MFMAs per wave.
+// (20.7 KB) and the nine spatial taps read shifted windows of it: the activation half of the stream drops ninefold, the weight half is
+// shared by 256 pixels instead of 128.  Per (kt, cb): 21 KB of patch + 9 x 8 KB of weights for 9 x 16 MFMAs per wave.
 //
 // K order: (kt, cb, kh, kw) -- not vae_ops.hip's (kt, kh, kw, cb): the fp32 sums are taken in another order, so the two kernels agree to
 // rounding, not bit for bit (tests compare both with the oracle; the bit-for-bit BIG / non-BIG comparison runs with this kernel switched off).
 //
 // Workgroup: 512 threads = 8 waves, wave (wr = wave >> 1, wc = wave & 1) owns pixel rows 4 wr .. + 3 of the tile (four 16-pixel MFMA tiles,
-// one per row) x output channels 64 wc .. + 63 (four 16-channel tiles); two workgroups per CU (76 KB of LDS each, <= 128 registers).
-// LDS: patch stage s (2): pixel pp = pr * 18 + pc of the patch at s * 26,624 + pp * 80 (64 B of channels + 16 B of padding: 16
-//      consecutive pixels x 4 chunks land on distinct banks up to 2-way); weights ring (3): row R (= permuted output channel, as
-//      vae_ops.hip: MFMA tile xt row 4 g + r <-> channel 16 g + 4 xt + r, so a lane ends with 16 consecutive channels) at R * 64, 16-B chunk c
-//      at slot c ^ ((R >> 2) & 3).
+// one per row) x output channels 64 wc .. + 63 (four 16-channel tiles); two workgroups per CU (66 KB of LDS each, <= 128 registers).
+// LDS: patch stage s (2): pixel pp = pr * 18 + pc of the patch at s * 21,504 + pp * 64, its 8-channel chunk c in 16-byte slot
+//      c ^ ((pp >> 1) & 2); weights ring (3): row R (= permuted output channel, as vae_ops.hip: MFMA tile xt row 4 g + r <-> channel
+//      16 g + 4 xt + r, so a lane ends with 16 consecutive channels) at R * 64, chunk c in slot c ^ ((R >> 1) & 2).  That swizzle is the one
+//      (found by enumeration over ds_read_b128's four lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) that keeps 16 consecutive rows x
+//      4 chunks conflict-free from ANY starting row -- the patch windows start anywhere.  The first version (80-byte pixels, no swizzle)
+//      spent half of its LDS cycles in bank conflicts (profiles/r04_vae_conv_pmc_lds_run24.json).
 // MFMA: acc[a][b] += W frag(b) x P frag(a), v_mfma_f32_16x16x32_f16, one k-step per (tap, cb).
 #include "common.h"
 
@@ -26,8 +28,9 @@ namespace {
 
 constexpr int HT = 16;                       // tile edge (pixels)
 constexpr int HP = HT + 2;                   // patch edge
-constexpr int HPITCH = 80;                   // bytes per patch pixel
-constexpr int HPATCH = 26 * 1024;            // bytes per patch stage (324 x 80 = 25,920, rounded up to DMA pieces)
+constexpr int HPITCH = 64;                   // bytes per patch pixel: 32 channels, no padding
+constexpr int HPIECES = 21;                  // 1-KB DMA pieces per patch stage (324 x 64 = 20,736 B)
+constexpr int HPATCH = HPIECES * 1024;       // bytes per patch stage
 constexpr int HWST = 128 * 64;               // bytes per weight stage
 constexpr int HW0 = 2 * HPATCH;              // weights ring offset
 
@@ -56,6 +59,8 @@ __device__ __forceinline__ const char* huni(const char* p) {
   return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
+template <int KT, bool UPS>  // KT = 3: the causal 3 x 3 x 3 convolution; KT = 1: Resample's Conv2d 3 x 3 -- UPS: on the nearest-exact 2x up-sampled input (vae.py:105-111,
+                             // :124-141), i.e. patch pixel (hi, wi) of the up-sampled frame is input pixel (hi >> 1, wi >> 1); p.H / p.W are the OUTPUT sizes
 __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * HPATCH + 3 * HWST];
   const int tid = threadIdx.x;
@@ -71,28 +76,31 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   const int th = wg % p.tiles_h;
   const int to = wg / p.tiles_h;
   const int h0 = th * HT, w0 = tw * HT, x0 = tx * 128;
-  const int64_t frame = (int64_t)p.H * p.W * p.Cin;
+  const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;   // the stored input frame
+  const int64_t frame = (int64_t)Hs * Ws * p.Cin;
 
-  // ---- patch pieces: this wave's four 1-KB pieces of a stage (32 issued for 26: the last six repeat pieces 0..5 -- same bytes to the
+  // ---- patch pieces: this wave's three 1-KB pieces of a stage (24 issued for 21: the last three repeat pieces 0..2 -- same bytes to the
   // same place -- so that every wave has the same number of loads in flight and one s_waitcnt serves all)
-  int so[4];          // element offset of the lane's 16 bytes inside a frame (channel block 0), -1: zeros
-  uint32_t pdst[4];   // LDS offset of the piece inside a stage
+  constexpr int NPP = 3;
+  int so[NPP];          // element offset of the lane's 16 bytes inside a frame (channel block 0), -1: zeros
+  uint32_t pdst[NPP];   // LDS offset of the piece inside a stage
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pi = (wave * 4 + i) % 26;
+  for (int i = 0; i < NPP; ++i) {
+    const int pi = (wave * NPP + i) % HPIECES;
     const int o = pi * 1024 + lane * 16;
-    const int pp = o / HPITCH, slot = (o - pp * HPITCH) >> 4;
+    const int pp = o >> 6, slot = (o >> 4) & 3;
+    const int ch = slot ^ ((pp >> 1) & 2);               // the 8-channel chunk that lives in this slot (see the LDS note above)
     const int pr = pp / HP, pc = pp - pr * HP;
     const int hi = h0 - 1 + pr, wi = w0 - 1 + pc;
-    const bool ok = pp < HP * HP && slot < 4 && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-    so[i] = ok ? (hi * p.W + wi) * p.Cin + slot * 8 : -1;
-    pdst[i] = (uint32_t)(pi * 1024);
+    const bool ok = pp < HP * HP && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+    so[i] = ok ? ((UPS ? hi >> 1 : hi) * Ws + (UPS ? wi >> 1 : wi)) * p.Cin + ch * 8 : -1;
+    pdst[i] = (uint32_t)__builtin_amdgcn_readfirstlane(pi * 1024);   // (wave-uniform: a scalar register)
   }
   // ---- weight piece: the wave's 16 rows x 64 B of a stage
   uint32_t wvoff;
   {
     const int R = wave * 16 + (lane >> 2), slot = lane & 3;
-    const int c = slot ^ ((R >> 2) & 3);
+    const int c = slot ^ ((R >> 1) & 2);
     const int slab = R >> 6, jj = R & 63, xt = jj >> 4, ii = jj & 15;
     int co = x0 + slab * 64 + (ii >> 2) * 16 + xt * 4 + (ii & 3);
     if (co > p.Cout - 1) co = p.Cout - 1;
@@ -106,12 +114,12 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
     if (ti >= 0) return ti < p.Tin ? p.x + (int64_t)ti * frame : nullptr;
     return (p.ncache > 0 && ti >= -p.ncache) ? p.cache + (int64_t)(ti + 2) * frame : nullptr;
   };
-  const int G = 3 * p.CB;  // groups (kt, cb), walked with carried coordinates (a scalar division by CB per tap is a VALU sequence)
+  const int G = KT * p.CB;  // groups (kt, cb), walked with carried coordinates (a scalar division by CB per tap is a VALU sequence)
   auto issue_patch = [&](int stage, int kt, int cb) {
     const uint16_t* fp = frame_ptr(kt);
     const uint32_t st = lds0 + (uint32_t)(stage * HPATCH);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPP; ++i) {
       const uint16_t* src = (fp != nullptr && so[i] >= 0) ? fp + so[i] + cb * 32 : p.zero16;
       hglds_a(src, st + pdst[i]);
     }
@@ -128,11 +136,11 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
 
   int ybase[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) ybase[a] = ((4 * wr + a) * HP + n) * HPITCH + lg * 16;
-  const int xbase = HW0 + (wc * 64 + n) * 64 + ((lg ^ ((n >> 2) & 3)) << 4);
+  for (int a = 0; a < 4; ++a) ybase[a] = ((4 * wr + a) * HP + n) * HPITCH + lg * 16;   // before the swizzle (it depends on the tap: bit 2 of the patch pixel)
+  const int xbase = HW0 + (wc * 64 + n) * 64 + ((lg ^ ((n >> 1) & 2)) << 4);
 
   int kt = 0, cb = 0;                                   // group g
-  int kt1 = p.CB > 1 ? 0 : 1, cb1 = p.CB > 1 ? 1 : 0;   // group g + 1 (the last group repeats itself: its re-loads land in idle stages)
+  int kt1 = (G > 1 && p.CB == 1) ? 1 : 0, cb1 = (G > 1 && p.CB > 1) ? 1 : 0;   // group g + 1 (the last group repeats itself: its re-loads land in idle stages)
   issue_patch(0, 0, 0);
   issue_w(0, 0);
   issue_w(p.CB, 1);
@@ -140,12 +148,13 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   __syncthreads();
 
   for (int g = 0; g < G; ++g) {
-    const int poff = (g & 1) * HPATCH;
-    const int ub = kt * 9 * p.CB + cb, ub1 = kt1 * 9 * p.CB + cb1;
+    int poff = (g & 1) * HPATCH;
+    asm volatile("" : "+s"(poff));   // (opaque: the swizzled window addresses are computed per tap, not kept for all nine across the loop)
+    const int ub = kt * 9 * p.CB + cb, ub1 = kt1 * 9 * p.CB + cb1;   // K unit of tap 0 of the group: ((kt * 3 + kh) * 3 + kw) * CB + cb
 #define HALO_TAP(TAP)                                                                                                              \
   {                                                                                                                                \
     if ((TAP) > 0 || g > 0) {                                                                                                      \
-      if ((TAP) == 1 || (TAP) == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); /* W(q) landed; W(q+1) and the next patch's four pieces may be out */ \
+      if ((TAP) == 1 || (TAP) == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); /* W(q) landed; W(q+1) and the next patch's three pieces may be out */ \
       else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                                                        \
       __builtin_amdgcn_s_barrier();                                                                                                \
       asm volatile("" ::: "memory");                                                                                               \
@@ -155,7 +164,8 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
     constexpr int dy = (TAP) / 3, dx = (TAP) % 3;                                                                                  \
     halo_f16x8 yf[4], xf[4];                                                                                                       \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                                \
-      yf[t] = *reinterpret_cast<const halo_f16x8*>(smem + poff + ybase[t] + (dy * HP + dx) * HPITCH);                              \
+      const int ya = ybase[t] + (poff + (dy * HP + dx) * HPITCH);                                                                  \
+      yf[t] = *reinterpret_cast<const halo_f16x8*>(smem + (ya ^ ((ya >> 3) & 32)));   /* chunk slot ^= 2 where bit 2 of the pixel is set (poff is a multiple of 512) */ \
       xf[t] = *reinterpret_cast<const halo_f16x8*>(smem + xbase + ((TAP) % 3) * HWST + t * 1024);                                  \
     }                                                                                                                              \
     _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                                  \
@@ -170,7 +180,11 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (clamped) loads
 
   // ---- epilogue (vae_ops.hip's: bias, fp16 rounding then + residual, fp16 or fp32 store; a lane owns 16 consecutive channels of a pixel)
-  const int xb = x0 + wc * 64 + lg * 16;
+  // (lane-derived addresses of the epilogue come from an opaque copy: hoisted above the K loop they cost it registers it does not have)
+  int lane2 = lane;
+  asm volatile("" : "+v"(lane2));
+  const int n2 = lane2 & 15, lg2 = lane2 >> 4;
+  const int xb = x0 + wc * 64 + lg2 * 16;
   float bcol[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) bcol[j] = 0.f;
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    const int h = h0 + 4 * wr + a, w = w0 + n;
+    const int h = h0 + 4 * wr + a, w = w0 + n2;
     if (h >= p.H || w >= p.W) continue;
     const int64_t pp = ((int64_t)to * p.H + h) * p.W + w;
     float v[16];
@@ -226,10 +240,11 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
 
 }  // namespace
 
-// Launch for wan_vae_conv3d (vae_ops.hip): the caller has checked 3 x 3 x 3, stride 1, pad 1, no up-sampling / interleave, 32-bit offsets.
+// Launch for wan_vae_conv3d (vae_ops.hip): the caller has checked KT x 3 x 3 (KT = 3 or 1), stride 1, pad 1, no interleave, 32-bit offsets.
+// H, W: the OUTPUT frame (= the input's, or twice it with ups).
 int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const uint16_t* zero16, const uint16_t* w, const uint16_t* bias,
                                const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int H, int W, int Cin, int Tout, int Cout,
-                               int front, int Kp, hipStream_t stream) {
+                               int front, int Kp, int KT, int ups, hipStream_t stream) {
   HaloP p;
   p.x = x; p.cache = cache; p.zero16 = zero16; p.w = w; p.bias = bias; p.res = res; p.out = out; p.out_f32 = out_f32;
   p.Tin = Tin; p.H = H; p.W = W; p.Cin = Cin; p.Tout = Tout; p.Cout = Cout; p.CB = Cin / 32; p.Kp = Kp; p.front = front;
@@ -238,7 +253,9 @@ int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const u
   const int64_t nwg = (int64_t)Tout * p.tiles_h * p.tiles_w * p.tiles_x;
   if (nwg == 0) return 0;
   WAN_REQUIRE(nwg < ((int64_t)1 << 31), "wan_vae_conv3d: grid too large");
-  hipLaunchKernelGGL(conv3d_halo_kernel, dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  if (KT == 3) hipLaunchKernelGGL((conv3d_halo_kernel<3, false>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else if (ups) hipLaunchKernelGGL((conv3d_halo_kernel<1, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((conv3d_halo_kernel<1, false>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
   WAN_LAUNCH_CHECK();
   return 0;
 }

@@ -332,7 +332,7 @@ extern "C" int wan_vae_debug_no_halo(int on) {
 }
 int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const uint16_t* zero16, const uint16_t* w, const uint16_t* bias,
                                const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int H, int W, int Cin, int Tout, int Cout,
-                               int front, int Kp, hipStream_t stream);
+                               int front, int Kp, int KT, int ups, hipStream_t stream);
 
 static int g_force_big = 0;
 extern "C" int wan_vae_debug_force_big(int on) {
@@ -366,9 +366,12 @@ extern "C" int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const ui
   const bool big = g_force_big || (int64_t)(Tin + 2) * Hin * Win * Cin >= ((int64_t)1 << 31);
   // the residual blocks' convolutions (3 x 3 x 3, stride 1, "same" in space): the halo-patch kernel -- each input pixel staged once per
   // frame tap and channel block instead of gathered once per tap (round 4)
-  if (!big && !g_no_halo && KT == 3 && KH == 3 && KW == 3 && st_t == 1 && st_s == 1 && pad_s == 1 && !ups && !interleave && Hout == Hin &&
-      Wout == Win && (int64_t)Tout * Hout * Wout * Cout < ((int64_t)1 << 31))
-    return wan_vae_conv3d_halo_launch(x, cache, g_zero_page, w, bias, res, out, out_f32, Tin, Hin, Win, Cin, Tout, Cout, front, p.nk * 64, st);
+  // ... and Resample's Conv2d 3 x 3 behind the nearest-exact 2x up-sampling (KT = 1: the patch pixel (hi, wi) is input pixel (hi >> 1, wi >> 1))
+  if (!big && !g_no_halo && (KT == 3 || KT == 1) && KH == 3 && KW == 3 && st_t == 1 && st_s == 1 && pad_s == 1 && !interleave &&
+      Hout == (ups ? 2 * Hin : Hin) && Wout == (ups ? 2 * Win : Win) && (KT == 3 ? !ups : (front == 0 && cache == nullptr)) &&
+      (int64_t)Tout * Hout * Wout * Cout < ((int64_t)1 << 31))
+    return wan_vae_conv3d_halo_launch(x, cache, g_zero_page, w, bias, res, out, out_f32, Tin, Hout, Wout, Cin, Tout, Cout, front, p.nk * 64, KT,
+                                      ups, st);
   p.tiles_y = (int)((p.M + CBM - 1) / CBM);
   p.tiles_x = (Cout + CBN - 1) / CBN;
   const dim3 grid((unsigned)(p.tiles_y * p.tiles_x));
