@@ -274,7 +274,9 @@ def test_conv_big_offsets_forced_equal_the_32bit_kernel_bit_for_bit():
     (384, 160, 2, 9, 23, True, True, False),     # image smaller than a tile in height, 12 channel blocks, ragged cout tile
     (96, 32, 4, 30, 40, False, False, True),     # the decoder's head: fp32 output, a quarter cout tile
     (64, 64, 5, 33, 17, True, False, False),
-], ids=["96_level", "192_ragged", "one_tile", "384_short", "head_f32", "64ch"])
+    (192, 384, 1, 20, 21, True, True, False),    # four 96-wide cout tiles
+    (96, 96, 2, 18, 35, False, False, True),     # the 96-wide tile with fp32 output
+], ids=["96_level", "192_ragged", "one_tile", "384_short", "head_f32", "64ch", "cout_384", "96_f32"])
 def test_conv_halo_patch_kernel_against_fp64_and_the_gather_kernel(cin, cout, T, H, W, cached, resid, f32out):
     """Round 4: the 3 x 3 x 3 stride-1 convolutions run on the halo-patch kernel (csrc/vae_conv_halo.hip: the 18 x 18 input patch of a 16 x 16
     tile staged once per frame tap and channel block, nine taps read shifted windows).  Against an fp64 convolution of the same fp16

@@ -958,3 +958,130 @@ def test_shifted_bounded_softmax_covers_what_the_plain_bound_declined_and_flags_
     # a reference beyond SHIFT_LIMIT is not attempted
     _, flagged, _ = _shifted_softmax_rows(q * np.float32(80.0), bf(rng.standard_normal((L, d)).astype(np.float32) * 70.0), v)
     assert flagged.all()
+
+
+# ---- vae_conv_halo.hip: the halo-patch convolution (round 4) ----------------------------------------------------------------------
+def _halo_patch_dma(wave, i, lane):
+    """piece i of wave `wave` -> (LDS byte offset inside a patch stage, patch pixel, 8-channel chunk) of lane `lane`"""
+    pi = (wave * 3 + i) % 21
+    o = pi * 1024 + lane * 16
+    pp, slot = o >> 6, (o >> 4) & 3
+    return o, pp, slot ^ ((pp >> 1) & 2)
+
+
+@pytest.mark.parametrize("NB", [4, 3])
+def test_conv_halo_layout_end_to_end(NB):
+    """csrc/vae_conv_halo.hip transliterated lane by lane on one 16 x 16 tile, one (kt, channel block) group, all nine taps: the 24 patch
+    pieces (21 distinct) fill every (pixel, chunk) of the 18 x 18 x 32 patch exactly where the window reads look for it; the weight pieces
+    (8, or 6 + 2 repeats for the 96-wide tile) do the same for the permuted channel rows; the MFMA fragments built from those LDS images
+    (16x16x32 lane layouts) reproduce a plain 3 x 3 convolution; a lane ends with NB * 4 consecutive output channels of one pixel.  Every
+    ds_read_b128 of the loop is bank-conflict free -- for every tap's window start."""
+    rng = np.random.default_rng(NB)
+    NW = NB * 16
+    patch = rng.standard_normal((18, 18, 32))                 # [pr, pc, channel]
+    wts = rng.standard_normal((9, 2 * NW, 32))                # [tap, cout, channel]
+    # --- LDS images written by the DMA pieces
+    P = np.full(21 * 1024 // 2, np.nan)                       # halfs
+    seen = set()
+    for wave in range(8):
+        for i in range(3):
+            for lane in range(64):
+                o, pp, ch = _halo_patch_dma(wave, i, lane)
+                if pp < 324:
+                    P[o // 2:o // 2 + 8] = patch[pp // 18, pp % 18, ch * 8:ch * 8 + 8]
+                    seen.add((pp, ch))
+    assert seen == {(pp, c) for pp in range(324) for c in range(4)}
+    W = np.full((9, 2 * NW * 32), np.nan)
+    rows_seen = set()
+    for wave in range(8):
+        wpiece = wave % (2 * NB)
+        for lane in range(64):
+            R, slot = wpiece * 16 + (lane >> 2), lane & 3
+            c = slot ^ ((R >> 1) & 2)
+            slab, jj = divmod(R, NW)
+            xt, ii = jj >> 4, jj & 15
+            co = slab * NW + (ii >> 2) * (NB * 4) + xt * 4 + (ii & 3)
+            rows_seen.add(co)
+            for tap in range(9):
+                W[tap, (wpiece * 1024 + lane * 16) // 2:(wpiece * 1024 + lane * 16) // 2 + 8] = wts[tap, co, c * 8:c * 8 + 8]
+    assert rows_seen == set(range(2 * NW))
+    # --- the K loop of every wave
+    out = np.zeros((16, 16, 2 * NW))
+    owner = {}
+    for wave in range(8):
+        wr, wc = wave >> 1, wave & 1
+        acc = np.zeros((4, NB, 64, 4))
+        for tap in range(9):
+            dy, dx = divmod(tap, 3)
+            yaddr = np.zeros((4, 64), dtype=np.int64)
+            xaddr = np.zeros((NB, 64), dtype=np.int64)
+            for lane in range(64):
+                n, lg = lane & 15, lane >> 4
+                for a in range(4):
+                    ya = ((4 * wr + a) * 18 + n) * 64 + lg * 16 + (dy * 18 + dx) * 64
+                    yaddr[a, lane] = ya ^ ((ya >> 3) & 32)
+                for b in range(NB):
+                    xaddr[b, lane] = (wc * NW + n) * 64 + ((lg ^ ((n >> 1) & 2)) << 4) + b * 1024
+            for a in range(4):
+                assert b128_conflict_free(list(yaddr[a])), (tap, a)
+            for b in range(NB):
+                assert b128_conflict_free(list(xaddr[b]))
+            for a in range(4):
+                for b in range(NB):
+                    # D[i][j] += sum_k A[i][k] B[j][k]: A = weights (lane l: row l & 15, k 8 (l >> 4) ..), B = pixels (lane l: col l & 15, same k)
+                    A = np.zeros((16, 32)); Bm = np.zeros((16, 32))
+                    for lane in range(64):
+                        n, lg = lane & 15, lane >> 4
+                        A[n, lg * 8:lg * 8 + 8] = W[tap, xaddr[b, lane] // 2:xaddr[b, lane] // 2 + 8]
+                        Bm[n, lg * 8:lg * 8 + 8] = P[yaddr[a, lane] // 2:yaddr[a, lane] // 2 + 8]
+                    D = A @ Bm.T
+                    for lane in range(64):
+                        for r in range(4):
+                            acc[a, b, lane, r] += D[(lane >> 4) * 4 + r, lane & 15]
+        for a in range(4):
+            for lane in range(64):
+                n2, lg2 = lane & 15, lane >> 4
+                xb = wc * NW + lg2 * NB * 4
+                for xt in range(NB):
+                    for r in range(4):
+                        key = (4 * wr + a, n2, xb + xt * 4 + r)
+                        assert key not in owner
+                        owner[key] = (wave, lane)
+                        out[key] = acc[a, xt, lane, r]
+    ref = np.zeros((16, 16, 2 * NW))
+    for tap in range(9):
+        dy, dx = divmod(tap, 3)
+        ref += np.einsum("hwc,oc->hwo", patch[dy:dy + 16, dx:dx + 16], wts[tap])
+    assert len(owner) == 16 * 16 * 2 * NW
+    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_conv_halo_ring_schedule():
+    """The in-order load counter of vae_conv_halo.hip's K loop: per wave P(0) x 3, W(0), W(1), drain; then at the top of tap q (= 9 g + tap)
+    wait until at most N loads are out, barrier, issue W(q + 2) and -- at tap 0 -- the next group's three patch pieces.  With N = 4 at taps
+    1 and 2 and 1 elsewhere: W(q) has landed at its tap's top, the patch of group g at the top of its tap 0, no stage is overwritten while a
+    tap may still read it."""
+    for groups in (3, 9, 36):
+        issued, landed_upto = [], 0          # issue log: (kind, index); completion is in order
+        def wait(n):
+            nonlocal landed_upto
+            landed_upto = max(landed_upto, len(issued) - n)
+        def landed(kind, idx):
+            return (kind, idx) in issued[:landed_upto]
+        issued += [("P", 0)] * 3 + [("W", 0), ("W", 1)]
+        wait(0)
+        wstage_owner = {0: 0, 1: 1}
+        for g in range(groups):
+            for tap in range(9):
+                q = 9 * g + tap
+                if q > 0:
+                    wait(4 if tap in (1, 2) else 1)
+                assert landed("W", q)
+                if tap == 0:
+                    assert landed("P", g)
+                # after the barrier: W(q + 2) into the stage tap q - 1 read
+                assert wstage_owner.get((q + 2) % 3, q - 1) <= q - 1
+                issued.append(("W", q + 2)); wstage_owner[(q + 2) % 3] = q + 2
+                if tap == 0:
+                    issued += [("P", g + 1)] * 3      # into patch stage (g + 1) & 1: last read in group g - 1
+                assert wstage_owner[q % 3] == q       # the stage this tap reads still holds W(q)

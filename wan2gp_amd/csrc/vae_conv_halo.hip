@@ -31,7 +31,7 @@ constexpr int HP = HT + 2;                   // patch edge
 constexpr int HPITCH = 64;                   // bytes per patch pixel: 32 channels, no padding
 constexpr int HPIECES = 21;                  // 1-KB DMA pieces per patch stage (324 x 64 = 20,736 B)
 constexpr int HPATCH = HPIECES * 1024;       // bytes per patch stage
-constexpr int HWST = 128 * 64;               // bytes per weight stage
+constexpr int HWST = 128 * 64;               // bytes per weight stage (96 x 64 used by the 96-channel tile)
 constexpr int HW0 = 2 * HPATCH;              // weights ring offset
 
 struct HaloP {
@@ -59,7 +59,8 @@ __device__ __forceinline__ const char* huni(const char* p) {
   return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
-template <int KT, bool UPS>  // KT = 3: the causal 3 x 3 x 3 convolution; KT = 1: Resample's Conv2d 3 x 3 -- UPS: on the nearest-exact 2x up-sampled input (vae.py:105-111,
+template <int KT, bool UPS, int NB>  // NB: 16-channel tiles per wave -- 4: 128 output channels per workgroup; 3: 96 (Cout a multiple of 96: the 96- / 192- /
+                                     // 384-channel levels -- a 128-wide tile would spend a quarter of its MFMAs on channels that do not exist).  KT = 3: the causal 3 x 3 x 3 convolution; KT = 1: Resample's Conv2d 3 x 3 -- UPS: on the nearest-exact 2x up-sampled input (vae.py:105-111,
                              // :124-141), i.e. patch pixel (hi, wi) of the up-sampled frame is input pixel (hi >> 1, wi >> 1); p.H / p.W are the OUTPUT sizes
 __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * HPATCH + 3 * HWST];
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   const int tw = wg % p.tiles_w; wg /= p.tiles_w;
   const int th = wg % p.tiles_h;
   const int to = wg / p.tiles_h;
-  const int h0 = th * HT, w0 = tw * HT, x0 = tx * 128;
+  constexpr int NW = NB * 16;            // output channels per wave
+  const int h0 = th * HT, w0 = tw * HT, x0 = tx * (2 * NW);
   const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;   // the stored input frame
   const int64_t frame = (int64_t)Hs * Ws * p.Cin;
 
@@ -96,13 +98,14 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
     so[i] = ok ? ((UPS ? hi >> 1 : hi) * Ws + (UPS ? wi >> 1 : wi)) * p.Cin + ch * 8 : -1;
     pdst[i] = (uint32_t)__builtin_amdgcn_readfirstlane(pi * 1024);   // (wave-uniform: a scalar register)
   }
-  // ---- weight piece: the wave's 16 rows x 64 B of a stage
+  // ---- weight piece: 16 rows x 64 B of a stage per wave (NB = 3: six pieces, waves 6 and 7 repeat pieces 0 and 1)
   uint32_t wvoff;
+  const int wpiece = __builtin_amdgcn_readfirstlane(wave % (2 * NB));
   {
-    const int R = wave * 16 + (lane >> 2), slot = lane & 3;
+    const int R = wpiece * 16 + (lane >> 2), slot = lane & 3;
     const int c = slot ^ ((R >> 1) & 2);
-    const int slab = R >> 6, jj = R & 63, xt = jj >> 4, ii = jj & 15;
-    int co = x0 + slab * 64 + (ii >> 2) * 16 + xt * 4 + (ii & 3);
+    const int slab = R / NW, jj = R - slab * NW, xt = jj >> 4, ii = jj & 15;
+    int co = x0 + slab * NW + (ii >> 2) * (NB * 4) + xt * 4 + (ii & 3);   // MFMA tile xt row 4 g + r <-> channel (NB * 4) g + 4 xt + r of the wave's NW
     if (co > p.Cout - 1) co = p.Cout - 1;
     wvoff = (uint32_t)(((int64_t)co * p.Kp + c * 8) * 2);
   }
@@ -125,19 +128,19 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
     }
   };
   auto issue_w = [&](int u, int stage) {   // K unit u = (kt * 9 + tap) * CB + cb: 64 bytes of every weight row
-    hglds_s(wvoff, huni(reinterpret_cast<const char*>(p.w) + (int64_t)u * 64), lds0 + HW0 + stage * HWST + wave * 1024);
+    hglds_s(wvoff, huni(reinterpret_cast<const char*>(p.w) + (int64_t)u * 64), lds0 + HW0 + stage * HWST + wpiece * 1024);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   int ybase[4];
 #pragma unroll
   for (int a = 0; a < 4; ++a) ybase[a] = ((4 * wr + a) * HP + n) * HPITCH + lg * 16;   // before the swizzle (it depends on the tap: bit 2 of the patch pixel)
-  const int xbase = HW0 + (wc * 64 + n) * 64 + ((lg ^ ((n >> 1) & 2)) << 4);
+  const int xbase = HW0 + (wc * NW + n) * 64 + ((lg ^ ((n >> 1) & 2)) << 4);   // (NW is a multiple of 16: bit 2 of the row is bit 2 of n)
 
   int kt = 0, cb = 0;                                   // group g
   int kt1 = (G > 1 && p.CB == 1) ? 1 : 0, cb1 = (G > 1 && p.CB > 1) ? 1 : 0;   // group g + 1 (the last group repeats itself: its re-loads land in idle stages)
@@ -162,14 +165,14 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
     issue_w((TAP) + 2 < 9 ? ub + ((TAP) + 2) * p.CB : ub1 + ((TAP) + 2 - 9) * p.CB, ((TAP) + 2) % 3);                               \
     if ((TAP) == 0) issue_patch((g + 1) & 1, kt1, cb1);                                                                            \
     constexpr int dy = (TAP) / 3, dx = (TAP) % 3;                                                                                  \
-    halo_f16x8 yf[4], xf[4];                                                                                                       \
+    halo_f16x8 yf[4], xf[NB];                                                                                                      \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                                \
       const int ya = ybase[t] + (poff + (dy * HP + dx) * HPITCH);                                                                  \
       yf[t] = *reinterpret_cast<const halo_f16x8*>(smem + (ya ^ ((ya >> 3) & 32)));   /* chunk slot ^= 2 where bit 2 of the pixel is set (poff is a multiple of 512) */ \
-      xf[t] = *reinterpret_cast<const halo_f16x8*>(smem + xbase + ((TAP) % 3) * HWST + t * 1024);                                  \
+      if (t < NB) xf[t] = *reinterpret_cast<const halo_f16x8*>(smem + xbase + ((TAP) % 3) * HWST + t * 1024);                      \
     }                                                                                                                              \
     _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                                  \
-      _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                                                \
+      _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                               \
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[b], yf[a], acc[a][b], 0, 0, 0);                                      \
   }
     HALO_TAP(0) HALO_TAP(1) HALO_TAP(2) HALO_TAP(3) HALO_TAP(4) HALO_TAP(5) HALO_TAP(6) HALO_TAP(7) HALO_TAP(8)
@@ -181,51 +184,54 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
 
   // ---- epilogue (vae_ops.hip's: bias, fp16 rounding then + residual, fp16 or fp32 store; a lane owns 16 consecutive channels of a pixel)
   // (lane-derived addresses of the epilogue come from an opaque copy: hoisted above the K loop they cost it registers it does not have)
-  int lane2 = lane;
+  int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // the lane id again, from the exec mask (nothing kept across the loop)
   asm volatile("" : "+v"(lane2));
   const int n2 = lane2 & 15, lg2 = lane2 >> 4;
-  const int xb = x0 + wc * 64 + lg2 * 16;
-  float bcol[16];
+  constexpr int NV = NB * 4;             // consecutive output channels a lane owns
+  const int xb = x0 + wc * NW + lg2 * NV;
+  float bcol[NV];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) bcol[j] = 0.f;
-  const bool full = xb + 16 <= p.Cout;
+  for (int j = 0; j < NV; ++j) bcol[j] = 0.f;
+  const bool full = xb + NV <= p.Cout;
   if (p.bias != nullptr) {
-    if (full) {
-      unpack8t<true>(*reinterpret_cast<const uint4*>(p.bias + xb), bcol);
-      unpack8t<true>(*reinterpret_cast<const uint4*>(p.bias + xb + 8), bcol + 8);
-    } else {
-      for (int j = 0; j < 16; ++j)
-        if (xb + j < p.Cout) bcol[j] = h2f(p.bias[xb + j]);
-    }
+    for (int j = 0; j < NV; ++j)
+      if (xb + j < p.Cout) bcol[j] = h2f(p.bias[xb + j]);
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int h = h0 + 4 * wr + a, w = w0 + n2;
     if (h >= p.H || w >= p.W) continue;
     const int64_t pp = ((int64_t)to * p.H + h) * p.W + w;
-    float v[16];
+    float v[NV];
 #pragma unroll
-    for (int xt = 0; xt < 4; ++xt)
+    for (int xt = 0; xt < NB; ++xt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[xt * 4 + r] = acc[a][xt][r] + bcol[xt * 4 + r];
-    if (full) {
+    if (full) {   // 8-byte pieces (4 channels): a 96-channel row is 8- but not 16-byte aligned at every lane
       const int64_t oidx = pp * p.Cout + xb;
       if (p.res != nullptr) {
-        float rv[16];
-        unpack8t<true>(*reinterpret_cast<const uint4*>(p.res + oidx), rv);
-        unpack8t<true>(*reinterpret_cast<const uint4*>(p.res + oidx + 8), rv + 8);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = rnd16<true>(v[j]) + rv[j];  // conv output is fp16, then x + h
+        for (int q = 0; q < NB; ++q) {
+          const uint2 rw = *reinterpret_cast<const uint2*>(p.res + oidx + 4 * q);
+          const float rv[4] = {h2f((uint16_t)(rw.x & 0xffffu)), h2f((uint16_t)(rw.x >> 16)), h2f((uint16_t)(rw.y & 0xffffu)), h2f((uint16_t)(rw.y >> 16))};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[4 * q + j] = rnd16<true>(v[4 * q + j]) + rv[j];  // conv output is fp16, then x + h
+        }
       }
       if (p.out_f32 != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) p.out_f32[oidx + j] = v[j];
+        for (int j = 0; j < NV; ++j) p.out_f32[oidx + j] = v[j];
       } else {
-        *reinterpret_cast<uint4*>(p.out + oidx) = pack8t<true>(v);
-        *reinterpret_cast<uint4*>(p.out + oidx + 8) = pack8t<true>(v + 8);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          uint2 ow;
+          ow.x = (uint32_t)f2h(v[4 * q]) | ((uint32_t)f2h(v[4 * q + 1]) << 16);
+          ow.y = (uint32_t)f2h(v[4 * q + 2]) | ((uint32_t)f2h(v[4 * q + 3]) << 16);
+          *reinterpret_cast<uint2*>(p.out + oidx + 4 * q) = ow;
+        }
       }
     } else {
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < NV; ++j) {
         if (xb + j < p.Cout) {
           const int64_t oidx = pp * p.Cout + xb + j;
           float o = v[j];
@@ -249,13 +255,16 @@ int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const u
   p.x = x; p.cache = cache; p.zero16 = zero16; p.w = w; p.bias = bias; p.res = res; p.out = out; p.out_f32 = out_f32;
   p.Tin = Tin; p.H = H; p.W = W; p.Cin = Cin; p.Tout = Tout; p.Cout = Cout; p.CB = Cin / 32; p.Kp = Kp; p.front = front;
   p.ncache = cache ? 2 : 0;
-  p.tiles_h = (H + HT - 1) / HT; p.tiles_w = (W + HT - 1) / HT; p.tiles_x = (Cout + 127) / 128;
+  const bool n96 = Cout % 96 == 0;   // 96 / 192 / 384 output channels: 96-wide tiles, no MFMA on channels that do not exist
+  p.tiles_h = (H + HT - 1) / HT; p.tiles_w = (W + HT - 1) / HT; p.tiles_x = n96 ? Cout / 96 : (Cout + 127) / 128;
   const int64_t nwg = (int64_t)Tout * p.tiles_h * p.tiles_w * p.tiles_x;
   if (nwg == 0) return 0;
   WAN_REQUIRE(nwg < ((int64_t)1 << 31), "wan_vae_conv3d: grid too large");
-  if (KT == 3) hipLaunchKernelGGL((conv3d_halo_kernel<3, false>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else if (ups) hipLaunchKernelGGL((conv3d_halo_kernel<1, true>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((conv3d_halo_kernel<1, false>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+#define HALO_GO(K, U, N) hipLaunchKernelGGL((conv3d_halo_kernel<K, U, N>), dim3((unsigned)nwg), dim3(512), 0, stream, p)
+  if (KT == 3) { if (n96) HALO_GO(3, false, 3); else HALO_GO(3, false, 4); }
+  else if (ups) { if (n96) HALO_GO(1, true, 3); else HALO_GO(1, true, 4); }
+  else { if (n96) HALO_GO(1, false, 3); else HALO_GO(1, false, 4); }
+#undef HALO_GO
   WAN_LAUNCH_CHECK();
   return 0;
 }
