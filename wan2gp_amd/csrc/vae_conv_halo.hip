@@ -255,8 +255,10 @@ int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const u
   p.x = x; p.cache = cache; p.zero16 = zero16; p.w = w; p.bias = bias; p.res = res; p.out = out; p.out_f32 = out_f32;
   p.Tin = Tin; p.H = H; p.W = W; p.Cin = Cin; p.Tout = Tout; p.Cout = Cout; p.CB = Cin / 32; p.Kp = Kp; p.front = front;
   p.ncache = cache ? 2 : 0;
-  const bool n96 = Cout % 96 == 0;   // 96 / 192 / 384 output channels: 96-wide tiles, no MFMA on channels that do not exist
-  p.tiles_h = (H + HT - 1) / HT; p.tiles_w = (W + HT - 1) / HT; p.tiles_x = n96 ? Cout / 96 : (Cout + 127) / 128;
+  // the tile width that pads Cout least: 96 for the 96 / 192 / 384-channel levels (exact), for 160 (192 against 256), for the 32-channel
+  // heads and latents; 128 for 128, 256, 640, 1024 ...
+  const bool n96 = (Cout + 95) / 96 * 96 < (Cout + 127) / 128 * 128;
+  p.tiles_h = (H + HT - 1) / HT; p.tiles_w = (W + HT - 1) / HT; p.tiles_x = n96 ? (Cout + 95) / 96 : (Cout + 127) / 128;
   const int64_t nwg = (int64_t)Tout * p.tiles_h * p.tiles_w * p.tiles_x;
   if (nwg == 0) return 0;
   WAN_REQUIRE(nwg < ((int64_t)1 << 31), "wan_vae_conv3d: grid too large");
