@@ -399,6 +399,9 @@ def main():
                "measured_note": "noise -> W+K sampler steps (the first includes one-time workspace allocation) -> VAE decode -> uint8 "
                                 "on the host, wall clock of this run; text encoding excluded (synthetic context)",
                "vae_decode_to_host_s": dec_s, "vae_encode_s": enc_s,
+               # ~6.4e14 FLOP per 720 x 1280 x 81-frame decode (convolutions), scaled by the pixel count; the time includes
+               # RMS_norm / SiLU passes, float -> uint8 and the device -> host copy (round 4: the 3x3x3 convolutions on a halo patch)
+               "vae_decode_TFLOPs": 6.4e14 * ((f - 1) * 4 + 1) * h * 8 * w * 8 / (81.0 * 720 * 1280) / dec_s / 1e12,
                "composed_s_at_%d_steps" % VIDEO_STEPS: VIDEO_STEPS * step_s + dec_s + (enc_s or 0.0),
                "composed_note": "%d x the step time of the timed region + the VAE times measured in this run" % VIDEO_STEPS}
     if world > 1:
