@@ -275,7 +275,12 @@ def test_the_drivers_own_command_line_produced_the_whole_record():
     worlds 2 / 4 / 8, BASELINE configs[3] with its own world of 8, the attention robustness probe, config 5, the CPU baseline with its
     thread sweep -- and the numbers are self-consistent."""
     import json
-    j = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_14B-720p_run11.json")))
+    for name in ("r04_bench_14B-720p_run11.json", "r04_bench_14B-720p_run30.json"):     # mid-round (slowest box met) and the round's last tree (a fast one)
+        _check_driver_line(json.load(open(os.path.join(ROOT, "profiles", name))))
+
+
+def _check_driver_line(j):
+    import json
     assert (j["steps"], j["warmup"], j["n_gpus"]) == (20, 5, 1) and abs(j["value"] * j["ms_per_step"] / 1000.0 - 1.0) < 1e-6
     assert "error" not in json.dumps({k: j[k] for k in ("secondary", "simulated_scaling", "configs3", "config5", "cpu_baseline")}).lower().replace("max_abs_err", "")
     rows = j["simulated_scaling"]["ranks"]
