@@ -142,7 +142,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_cfg_parallel_groups_swap_and_generate(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -249,7 +249,7 @@ def _layout_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_layout_falls_back_to_sequence_parallelism_on_every_rank_together(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
