@@ -1,8 +1,10 @@
 """-m gpu: CFG parallelism (wan2gp_amd/sp.py `CfgParallel`) end to end on the HIP path, all ranks on cuda:0 with a `gloo` process
 group staging the exchanges through the host (the test boxes have one GPU; on a multi-GPU node the same code runs over RCCL):
 world 2 = the conditional and the unconditional stream in two processes, no sequence parallelism; world 4 = two halves of two
-sequence-parallel ranks each -- the single-stream forward with the half's K / V^T gathers.  Every rank must end up with the
-(cond, uncond) pair of the single-rank joint pass.  (Named to run after the other -m gpu files.)"""
+sequence-parallel ranks each -- the single-stream forward with the half's K / V^T gathers; the same world with the Ulysses exchange,
+and world 8 = two halves of four ranks with the Ulysses exchange (`cfg2 x sp4 (ulysses)`: what `bench.py --gpus 8` runs by default) --
+the ONE-stream form of the all-to-all path (no V^T block swap, world x 1 query batches), one head per rank.  Every rank must end up
+with the (cond, uncond) pair of the single-rank joint pass.  (Named to run after the other -m gpu files.)"""
 import datetime
 import os
 import socket
@@ -20,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="allgather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     import torch.distributed as dist
@@ -40,8 +42,8 @@ def _worker(rank, world, port, q):
         lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w, seed=9)
         t = torch.tensor([412])
         ref = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])        # the joint pass on one rank
-        cfgp = CfgParallel(rank, world).attach(m)
-        assert (m.sp is None) == (world == 2)
+        cfgp = CfgParallel(rank, world, mode=mode).attach(m)
+        assert (m.sp is None) == (world == 2) and (m.sp is None or (m.sp.mode == mode and m.sp.world == world // 2))
         got = cfgp.guided_pair(m, lat.cuda(), ctx.cuda(), ctx_null.cuda(), t=t)
         for name, g, r in zip(("cond", "uncond"), got, ref):
             assert g.shape == r.shape and g.is_cuda
@@ -60,12 +62,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_cfg_parallel_pair_matches_the_joint_pass(world):
+@pytest.mark.parametrize("world,mode", [(2, "allgather"), (4, "allgather"), (4, "ulysses"), (8, "ulysses")])
+def test_cfg_parallel_pair_matches_the_joint_pass(world, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     try:
