@@ -27,7 +27,7 @@ def f32(t):
     return t.detach().to(torch.float32).cpu().numpy()
 
 
-def build_ref_model(ns, cfg: O.WanConfig, W, dtype):
+def build_ref_model(ns, cfg: O.WanConfig, W, dtype, mixed=False):
     """Construct the reference WanModel and load the synthetic checkpoint with the
     reference's dtype locks (model.py:1330-1371): patch_embedding + head fp32."""
     m = ns.M.WanModel(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads,
@@ -42,8 +42,8 @@ def build_ref_model(ns, cfg: O.WanConfig, W, dtype):
     m.eval()
     if dtype != torch.float32:
         for name, p in m.named_parameters():
-            if name.startswith(O.FP32_LOCKED):
-                continue
+            if O.is_fp32_locked(name, mixed):      # mixed: + layer_list2 of lock_layers_dtypes (model.py:1338-1345), what mmgp keeps in fp32
+                continue                            # for `mixed_precision_transformer` (any2video.py:190)
             p.data = p.data.to(dtype)
     return m
 
@@ -127,6 +127,40 @@ def gen_forward(ns, name, f, h, w, tval):
         out[f"block0_{tag}"] = f32(bo)
     np.savez_compressed(os.path.join(OUT, f"forward_{name}.npz"), **out)
     print(f"forward_{name}.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_forward_mixed(ns, name, f, h, w, tval):
+    """The reference's forward under `mixed_precision_transformer` (wgp.py:4039 -> any2video.py:190 -> model.py:1330-1371): the time MLP,
+    the time projection and every block's norm3 hold their (bf16-valued) weights in fp32; by type promotion the residual stream, e / e0
+    and every modulate / gated residual then run in fp32 between bf16 Linears.  Same seeds and weights as forward_<name>.npz."""
+    cfg = O.make_config(name)
+    out = {"shape": np.array([f, h, w]), "t": np.array([tval])}
+    lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
+    t = torch.tensor([tval], dtype=torch.int64)
+    dtype = torch.bfloat16
+    W = O.synth_weights(cfg, dtype=dtype, mixed=True)
+    m = build_ref_model(ns, cfg, W, dtype, mixed=True)
+    assert m.time_projection[1].weight.dtype == torch.float32 and m.blocks[0].norm3.weight.dtype == torch.float32
+    assert m.blocks[0].self_attn.q.weight.dtype == dtype and m.text_embedding[0].weight.dtype == dtype
+    r = ref_forward(ns, m, [lat, lat], t, [ctx.to(dtype), ctx_null.to(dtype)], y=y)
+    out["cond_mixed"], out["uncond_mixed"] = f32(r[0]), f32(r[1])
+    if name == "tiny_ti2v":                                     # per-frame timesteps
+        tf = torch.full((f,), tval, dtype=torch.int64)
+        tf[:1] = 0
+        r = ref_forward(ns, m, [lat, lat], tf, [ctx.to(dtype), ctx_null.to(dtype)])
+        out["cond_tframe_mixed"], out["uncond_tframe_mixed"] = f32(r[0]), f32(r[1])
+    g = torch.Generator().manual_seed(11)
+    L = f * (h // 2) * (w // 2)
+    hid = torch.randn(1, L, cfg.dim, generator=g)                # the residual stream is fp32 in this plan
+    e0 = 0.5 * torch.randn(1, 6, cfg.dim, generator=g)
+    cemb = (0.5 * torch.randn(1, 512, cfg.dim, generator=g)).to(dtype)
+    freqs = ns.P.get_rotary_pos_embed((f, h, w))
+    with torch.no_grad():
+        bo = m.blocks[0](hid.clone(), e=e0, grid_sizes=(f, h // 2, w // 2), freqs=freqs, context=cemb)
+    assert bo.dtype == torch.float32
+    out["block0_mixed"] = f32(bo)
+    np.savez_compressed(os.path.join(OUT, f"forward_{name}_mixed.npz"), **out)
+    print(f"forward_{name}_mixed.npz", {k: v.shape for k, v in out.items()})
 
 
 def gen_sched(ns):
@@ -240,6 +274,11 @@ def main():
         gen_forward(ns, "small", 3, 10, 14, 412)            # 4 heads, 3 layers, ragged token count L = 105
     if "forward" in which or "flf2v" in which:
         gen_forward(ns, "tiny_flf2v", 2, 8, 8, 644)          # Wan2.1 flf2v: two images' CLIP tokens + position embedding
+    if "mixed" in which:                                     # (its own keyword: the files above are not regenerated by it)
+        gen_forward_mixed(ns, "tiny", 3, 8, 12, 637)
+        gen_forward_mixed(ns, "tiny_i2v", 2, 8, 8, 912)      # i2v2_2: y (mask + latents) concatenated in front of the patch embedding
+        gen_forward_mixed(ns, "tiny_ti2v", 2, 6, 10, 455)    # + per-frame timesteps: e0 [frames, 6, dim] in fp32
+        gen_forward_mixed(ns, "small", 3, 10, 14, 412)
     if "sched" in which:
         gen_sched(ns)
     if "sched2" in which:

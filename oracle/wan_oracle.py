@@ -145,9 +145,20 @@ def param_shapes(cfg: WanConfig) -> Dict[str, Tuple[int, ...]]:
 
 
 FP32_LOCKED = ("patch_embedding.", "head.")  # model.py:1331 (lock_layers_dtypes layer_list)
+# `mixed_precision_transformer` (wgp.py:4039 server setting "mixed_precision" -> any2video.py:190 lock_layers_dtypes(torch.float32)):
+# layer_list2 of model.py:1338-1345 is kept in fp32 as well -- the time MLP, the time projection and every block's norm3.  The weights are
+# the checkpoint's bf16 values (upcast, exact); what changes is the arithmetic that follows from them by type promotion: the modulation
+# dtype (= time_projection[1].weight.dtype, model.py:1545) becomes fp32, so the residual stream x, e / e0 and every AdaLN modulate /
+# gated residual run in fp32, with ONE rounding to bf16 in front of each Linear / attention (`.to(attention_dtype)`, model.py:650,665,692)
+MIXED_LOCKED = ("time_embedding.", "time_projection.")
 
 
-def synth_weights(cfg: WanConfig, seed: int = 1234, dtype=torch.bfloat16, max_layers: Optional[int] = None) -> Dict[str, torch.Tensor]:
+def is_fp32_locked(key: str, mixed: bool = False) -> bool:
+    """Does this parameter stay fp32 under the reference's dtype locks (model.py:1330-1371)?"""
+    return key.startswith(FP32_LOCKED) or (mixed and (key.startswith(MIXED_LOCKED) or ".norm3." in key))
+
+
+def synth_weights(cfg: WanConfig, seed: int = 1234, dtype=torch.bfloat16, max_layers: Optional[int] = None, mixed: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded synthetic checkpoint. fp32 master values are drawn first, then cast per the
     reference's dtype lock (patch_embedding/head fp32, rest `dtype`), so the bf16 and fp32
     plans share the *same* (bf16-representable) weights: the master is rounded through
@@ -167,7 +178,8 @@ def synth_weights(cfg: WanConfig, seed: int = 1234, dtype=torch.bfloat16, max_la
             w = 0.02 * torch.randn(shp, generator=g)
         if not k.startswith(FP32_LOCKED):
             w = w.to(torch.bfloat16).to(torch.float32)  # bf16-representable master
-            w = w.to(dtype)
+            if not is_fp32_locked(k, mixed):            # mixed: the same bf16 values, held in fp32 (the loader's upcast is exact)
+                w = w.to(dtype)
         out[k] = w
     return out
 
@@ -388,7 +400,7 @@ def img_emb(clip_fea, W):
     return F.layer_norm(x, (x.shape[-1],), W["img_emb.proj.4.weight"], W["img_emb.proj.4.bias"], 1e-5)
 
 
-def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = False, nag=None):
+def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = False, nag=None, adt=None):
     """WanAttentionBlock.forward, t2v path (model.py:631-711).  x [B,L,dim] in the
     residual dtype, e0 [1,6,dim] (latent_frames = e.shape[0] = 1, so the reshape at
     :635/:658/:688 is a no-op broadcast).  i: block index, or a key prefix (VACE context blocks)."""
@@ -396,20 +408,25 @@ def block_forward(x, e0, ctx, cos, sin, W, i, cfg: WanConfig, exact: bool = Fals
     nf = e0.shape[0]                                           # latent_frames (:631): > 1 with per-frame timesteps (ti2v injection,
     rs = (lambda v: v.reshape(v.shape[0], nf, -1, v.shape[-1])) if nf > 1 else (lambda v: v)      # diffusion forcing): reshape_latent
     un = (lambda v: v.reshape(v.shape[0], -1, v.shape[-1])) if nf > 1 else (lambda v: v)          # / restore_latent_shape (:45-49)
+    # adt: the attention dtype (model.py:614) where it differs from the residual stream's -- the mixed-precision plan (x, e0 fp32; the
+    # Linears bf16): one rounding in front of every Linear / attention (:650, :665, :692), results widened back (:654, :668, :708).
+    # None: the two are the same dtype and every cast below is the identity (the bf16 plan, the fp32 anchor).
+    dt = x.dtype
+    to_a = (lambda v: v.to(adt)) if adt is not None else (lambda v: v)
     e = (W[p + "modulation"] + e0).chunk(6, dim=1)            # :632   6 x [nf,1,dim]
     x_mod = rs(layer_norm(x, cfg.eps))                         # :634-635
     x_mod = x_mod * (1 + e[1]); x_mod = un(x_mod + e[0])       # :636-638 (two roundings)
-    y = self_attention(x_mod, W, p + "self_attn.", cfg, cos, sin, exact)   # :653
+    y = self_attention(to_a(x_mod), W, p + "self_attn.", cfg, cos, sin, exact).to(dt)   # :650-654
     x = un(torch.addcmul(rs(x), rs(y), e[2]))                  # :658-660
     y = layer_norm(x, cfg.eps, W[p + "norm3.weight"], W[p + "norm3.bias"])  # :664
-    x = x + cross_attention(y, ctx, W, p + "cross_attn.", cfg, exact, nag)  # :668
+    x = x + cross_attention(to_a(y), ctx, W, p + "cross_attn.", cfg, exact, nag).to(dt)  # :665-668
     y = rs(layer_norm(x, cfg.eps))                             # :686-688
-    y = y * (1 + e[4]); y = un(y + e[3])                       # :689-691
+    y = y * (1 + e[4]); y = to_a(un(y + e[3]))                 # :689-692
     shp = y.shape                                              # :698-707 three row chunks
     y2 = y.reshape(-1, shp[-1])
     outs = [_linear(F.gelu(_linear(c, W, p + "ffn.0"), approximate="tanh"), W, p + "ffn.2")
             for c in torch.split(y2, int(y2.shape[0] / 2.7))]
-    y = torch.cat(outs, 0).view(shp)
+    y = torch.cat(outs, 0).view(shp).to(dt)                    # :708
     x = un(torch.addcmul(rs(x), rs(y), e[5]))                  # :708-711
     return x
 
@@ -437,7 +454,7 @@ def vace_hints(vace_context, vace_scale, W, cfg: WanConfig, n_streams: int):
     return [[c.clone() for c in emb] for _ in range(n_streams)], scales
 
 
-def block_with_hints(x, hints, scales, e0, ctx, cos, sin, W, i: int, cfg: WanConfig, exact: bool = False, nag=None):
+def block_with_hints(x, hints, scales, e0, ctx, cos, sin, W, i: int, cfg: WanConfig, exact: bool = False, nag=None, adt=None):
     """One main block with its VACE context block(s) (model.py:617-629 in front of the block, :713-719 behind it): every context
     with a non-zero scale runs the context block on its own hint stream (in place in `hints`); the projected hints are added to
     x in context order, each add rounding to the stream's dtype."""
@@ -450,7 +467,7 @@ def block_with_hints(x, hints, scales, e0, ctx, cos, sin, W, i: int, cfg: WanCon
                 continue
             hints[k], sk = vace_block_forward(hints[k], x, e0, ctx, cos, sin, W, n, cfg, exact, nag)
             skips.append(sk)
-    x = block_forward(x, e0, ctx, cos, sin, W, i, cfg, exact, nag)
+    x = block_forward(x, e0, ctx, cos, sin, W, i, cfg, exact, nag, adt)
     for sk, sc in zip(skips, scales or []):
         if sk is not None:
             x = x + sk if sc == 1 else torch.add(x, sk, alpha=sc)
@@ -503,16 +520,22 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
     probe(i, s, hidden): called with stream s's token stream after block i (error-growth tables)."""
     hs = []
     grid = None
+    # modulation dtype = time_projection[1].weight.dtype (model.py:1545): `dtype` in the bf16 plan and in the fp32 anchor, fp32 under the
+    # mixed-precision locks (synth_weights(mixed=True)) -- then the residual stream runs in fp32 between bf16 Linears (block_forward `adt`)
+    mdt = W["time_projection.1.weight"].dtype
+    adt = dtype if mdt != dtype else None
+    if adt is not None and (vace_context is not None or clip_fea is not None):
+        raise NotImplementedError("wan_oracle: the mixed-precision plan is restated for the t2v / i2v2_2 / ti2v block chain only")
     for x in x_list:
         if y is not None:                                   # model.py:1597-1600
             yy = y.unsqueeze(0)
             if x.shape[0] > 1:
                 yy = yy.expand(x.shape[0], -1, -1, -1, -1)
             x = torch.cat([x, yy.to(x.dtype)], dim=1)
-        h, grid = patch_embed(x, W, cfg, dtype)
+        h, grid = patch_embed(x, W, cfg, mdt)
         hs.append(h)
     cos, sin = freqs if freqs is not None else rope_tables(grid)
-    e, e0 = time_embed(t, W, cfg, dtype)
+    e, e0 = time_embed(t, W, cfg, mdt)
     ctxs = [text_embed(c.to(dtype), W) for c in context_list]
     if clip_fea is not None:                                # model.py:1858-1869: [clip tokens ; text tokens]
         cc = img_emb(clip_fea.to(dtype), W)
@@ -522,7 +545,7 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
         for s in range(len(hs)):
             if perturbation_layers is not None and i in perturbation_layers and s != 0:
                 continue                                    # skip-layer guidance (:2025-2028): only the first stream runs such a block
-            hs[s] = block_with_hints(hs[s], None if hints is None else hints[s], scales, e0, ctxs[s], cos, sin, W, i, cfg, exact, nag)
+            hs[s] = block_with_hints(hs[s], None if hints is None else hints[s], scales, e0, ctxs[s], cos, sin, W, i, cfg, exact, nag, adt)
             if probe is not None:
                 probe(i, s, hs[s])
     if return_hidden:

@@ -116,6 +116,44 @@ def test_forward_matches_reference(name, tag, dtype):
         assert rel < 1e-2, rel
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "small"])
+def test_forward_mixed_precision_plan_matches_reference(name):
+    """`mixed_precision_transformer` (wgp.py:4039 -> any2video.py:190 -> lock_layers_dtypes(torch.float32), model.py:1330-1371): the time
+    MLP, the time projection and every norm3 hold their bf16-valued weights in fp32, and by type promotion the residual stream, e / e0 and
+    every modulate / gated residual run in fp32 between bf16 Linears.  The goldens are the reference's own forward with those locks
+    (oracle/make_golden.py mixed); the restatement (block_forward's `adt` casts, the modulation dtype read off the weights) must equal
+    them bit for bit, and the plan must differ from the bf16 plan's result by what a precision plan is worth (1e-4 .. 3e-2)."""
+    g = load(f"forward_{name}_mixed.npz")
+    f, h, w = [int(v) for v in g["shape"]]
+    cfg = O.make_config(name)
+    dtype = torch.bfloat16
+    W = O.synth_weights(cfg, dtype=dtype, mixed=True)
+    Wb = O.synth_weights(cfg, dtype=dtype)
+    assert W["time_projection.1.weight"].dtype == torch.float32 and W["blocks.0.norm3.weight"].dtype == torch.float32
+    assert W["blocks.0.self_attn.q.weight"].dtype == dtype and W["blocks.0.modulation"].dtype == dtype
+    assert all(torch.equal(W[k].float(), Wb[k].float()) for k in W)          # the same values: the upcast of a bf16 checkpoint is exact
+    lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
+    tt = torch.tensor([int(g["t"][0])], dtype=torch.int64)
+    cond, uncond = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, y=y, dtype=dtype)
+    assert torch.equal(cond, t(g["cond_mixed"])) and torch.equal(uncond, t(g["uncond_mixed"]))
+    gb = load(f"forward_{name}.npz")
+    rel = ((cond - t(gb["cond_bf16"])).norm() / t(gb["cond_bf16"]).norm()).item()
+    assert 1e-4 < rel < 3e-2, rel
+    if name == "tiny_ti2v":
+        tf = torch.full((f,), int(g["t"][0]), dtype=torch.int64)
+        tf[:1] = 0
+        c2, u2 = O.dit_forward([lat, lat], tf, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, dtype=dtype)
+        assert torch.equal(c2, t(g["cond_tframe_mixed"])) and torch.equal(u2, t(g["uncond_tframe_mixed"]))
+    gen = torch.Generator().manual_seed(11)
+    L = f * (h // 2) * (w // 2)
+    hid = torch.randn(1, L, cfg.dim, generator=gen)
+    e0 = 0.5 * torch.randn(1, 6, cfg.dim, generator=gen)
+    cemb = (0.5 * torch.randn(1, 512, cfg.dim, generator=gen)).to(dtype)
+    cos, sin = O.rope_tables((f, h // 2, w // 2))
+    bo = O.block_forward(hid, e0, cemb, cos, sin, W, 0, cfg, adt=dtype)
+    assert bo.dtype == torch.float32 and torch.equal(bo, t(g["block0_mixed"]))
+
+
 def test_unipc_known_answer_timesteps():
     # BASELINE.md §2 known-answer from the reference run during the survey
     s = O.UniPCOracle()
