@@ -499,6 +499,39 @@ int wan_vae_debug_force_big(int on);
  * sum in different orders and agree to fp32 rounding, not bit for bit); returns the old value. */
 int wan_vae_debug_no_halo(int on);
 int wan_attention_debug_no_persist(int on);
+
+/* ---- the mixed-precision transformer plan (`mixed_precision_transformer`: wgp.py:4039 "mixed_precision" -> any2video.py:190 ->
+ * WanModel.lock_layers_dtypes(torch.float32), models/wan/modules/model.py:1330-1371).  The time MLP, the time projection and every
+ * block's norm3 hold their (bf16-valued) weights in fp32; the modulation dtype (model.py:1545) is then fp32 and by type promotion the
+ * residual stream x, e / e0, every AdaLN modulate and every gated residual run in fp32 between bf16 Linears (one rounding in front of
+ * each: `.to(attention_dtype)`, model.py:650,665,692).  Row / edge kernels of that plan (csrc/mixed_ops.hip).  A wan_dit context runs the
+ * plan when 'time_projection.1.weight' was registered as fp32 (wan_dit_set_weight dtype 1) -- the reference's own rule; 'time_embedding.*',
+ * 'time_projection.*' and every 'blocks.N.norm3.*' must then be fp32, wan_dit_workspace_bytes grows by the fp32 stream, and the forward
+ * refuses what keeps bf16 state of its own (step-skipping residuals, VACE context blocks, the Wan2.1 i2v CLIP branch). ---- */
+/* norm1 / norm2 + modulate (model.py:634-638, :686-692): out = bf16( LN(x) * (1 + scale) + shift ) with LN, scale, shift in fp32;
+ * scale = float(mod[scale_idx]) + e0[b][scale_idx].  x [rows, d] fp32; mod [n_mod, d] bf16; e0 [batches, n_mod, d] fp32. */
+int wan_mx_ln_modulate(const float* x, wan_bf16* out, const wan_bf16* mod, const float* e0, int n_mod, int shift_idx, int scale_idx,
+                       int64_t rows, int64_t rows_per_batch, int d, float eps, void* stream);
+/* norm3 with its fp32 weight and bias (model.py:664-665; WanLayerNorm.forward :199-212): out = bf16( LN(x) * w + b ). */
+int wan_mx_ln_affine(const float* x, wan_bf16* out, const float* w, const float* b, int64_t rows, int d, float eps, void* stream);
+/* x.addcmul_(y, e[gate_idx]) (model.py:658, :708) on the fp32 stream, y the bf16 result of a Linear: x += y * (float(mod[gate_idx]) +
+ * e0[b][gate_idx]) with the product rounded first; gate_idx < 0: x += y (the cross-attention residual, :668; mod, e0 unused). */
+int wan_mx_gated_residual(float* x, const wan_bf16* y, const wan_bf16* mod, const float* e0, int n_mod, int gate_idx, int64_t rows,
+                          int64_t rows_per_batch, int d, void* stream);
+/* patch_embedding(x).to(fp32) (model.py:1620-1631; i2v: y concatenated behind x's channels, :1597-1600): the fp32 Conv3d with
+ * kernel = stride = (1, 2, 2), result left in fp32.  x [Cin, F, H, W], y [Cy, F, H, W] or NULL, w [d, Cin + Cy, 1, 2, 2], out
+ * [ntok, d] = tokens tok0 .. tok0 + ntok of the f-major grid. */
+int wan_mx_patch_embed(const float* x, const float* y, const float* w, const float* bias, float* out, int Cin, int Cy, int F, int H,
+                       int W, int d, int64_t tok0, int64_t ntok, void* stream);
+/* sinusoidal_embedding_1d(dim, t) in fp32 (model.py:32-42), and an fp32 Linear on few rows with an optional SiLU on its INPUT:
+ * C[m][n] = bias[n] + sum_k act(A[m][k]) W[n][k] -- time_embedding and time_projection under the fp32 lock (model.py:1815-1818). */
+int wan_mx_sinusoid(float t, float* out, int dim, void* stream);
+int wan_mx_linear_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, void* stream);
+/* Head.forward (model.py:847-865) on the fp32 stream: LayerNorm, modulate with head.modulation + e in fp32 (tmp: fp32 [ntok, d]),
+ * the fp32 head Linear; out [ntok, nout] token-major (wan_unpatchify_n lays it out as [out_dim, F, H, W]).  e [batches, d] fp32,
+ * one row per e_rows_per_batch tokens. */
+int wan_mx_head(const float* x, const float* hmod, const float* e, const float* w, const float* bias, float* tmp, float* out,
+                int64_t ntok, int d, float eps, int64_t e_rows_per_batch, int nout, void* stream);
 /* P[r,:L] = softmax(S[r,:L]); P[r,L:ld] = 0 */
 int wan_vae_softmax(const uint16_t* S, uint16_t* P, int64_t rows, int L, int64_t ld, void* stream);
 /* fp32 [C,thw] -> fp16 [thw,Cp] (zero padded channels), optional v*mul[c]+add[c] */

@@ -112,6 +112,31 @@ int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wa
 int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void*) { return rec("add", {a, b, out}, {n}); }
 int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void*) { return rec("sub", {a, b, out}, {n}); }
 int wan_axpy_bf16(const wan_bf16* x, const wan_bf16* y, float alpha, wan_bf16* out, int64_t n, void*) { return rec("axpy", {x, y, out}, {n}, {alpha}); }
+// the mixed-precision plan's kernels (csrc/mixed_ops.hip)
+int wan_mx_ln_modulate(const float* x, wan_bf16* out, const wan_bf16* mod, const float* e0, int n_mod, int shift_idx, int scale_idx, int64_t rows,
+                       int64_t rows_per_batch, int d, float, void*) {
+  return rec("mx_ln_modulate", {x, out, mod, e0}, {rows, d, n_mod, shift_idx, scale_idx, rows_per_batch});
+}
+int wan_mx_ln_affine(const float* x, wan_bf16* out, const float* w, const float* b, int64_t rows, int d, float, void*) {
+  return rec("mx_ln_affine", {x, out, w, b}, {rows, d});
+}
+int wan_mx_gated_residual(float* x, const wan_bf16* y, const wan_bf16* mod, const float* e0, int n_mod, int gate_idx, int64_t rows, int64_t rpb, int d,
+                          void*) {
+  return rec("mx_gated_residual", {x, y, mod, e0}, {rows, d, n_mod, gate_idx, rpb});
+}
+int wan_mx_patch_embed(const float* x, const float* y, const float* w, const float* bias, float* out, int Cin, int Cy, int F, int H, int W, int d,
+                       int64_t tok0, int64_t ntok, void*) {
+  return rec("mx_patch_embed", {x, y, w, bias, out}, {Cin, Cy, F, H, W, d, tok0, ntok});
+}
+int wan_mx_sinusoid(float t, float* out, int dim, void*) { return rec("mx_sinusoid", {out}, {dim}, {t}); }
+int wan_mx_linear_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, void*) {
+  return rec("mx_linear_f32", {A, W, bias, C}, {M, N, K, act});
+}
+int wan_mx_head(const float* x, const float* hmod, const float* e, const float* w, const float* bias, float* tmp, float* out, int64_t ntok, int d, float,
+                int64_t e_rpb, int nout, void*) {
+  return rec("mx_head", {x, hmod, e, w, bias, tmp, out}, {ntok, d, e_rpb, nout});
+}
+int wan_unpatchify_n(const float* in, float* out, int B, int F, int Hg, int Wg, int nout, void*) { return rec("unpatchify", {in, out}, {B, F, Hg, Wg, nout}); }
 }
 // internal (non-ABI) entry points of the other translation units, as dit.hip declares them
 int wan_patch_embed_range(const float* x, const float* y, const float* w, const float* bias, bf16_t* out, int B, int Cin, int Cy, int F, int H,

@@ -52,7 +52,7 @@ def mock(tmp_path_factory):
 class Model:
     """A context with every weight of the `tiny` config registered at a distinct fake address."""
 
-    def __init__(self, L, name="tiny", fp8=False):
+    def __init__(self, L, name="tiny", fp8=False, mixed=False):
         self.L, self.cfg = L, O.make_config(name)
         c = self.cfg
         dc = DitConfig(c.dim, c.ffn_dim, c.num_heads, c.num_layers, c.in_dim, c.out_dim, c.text_dim, c.freq_dim, c.text_len, c.eps)
@@ -65,7 +65,7 @@ class Model:
                 numel *= s
             a = 0x1000_0000_0000 + n * 0x10_0000_0000
             self.addr[k] = a
-            dt = 1 if k.startswith(("patch_embedding.", "head.")) else 0
+            dt = 1 if (k.startswith(("patch_embedding.", "head.")) or (mixed and O.is_fp32_locked(k, True))) else 0
             lin = k.endswith(".weight") and ".norm" not in k and "norm3" not in k and k.startswith("blocks.") and ("attn." in k or "ffn." in k)
             if fp8 and lin:
                 dt = 2
@@ -125,6 +125,18 @@ def extents(call):
         return [(p[0], i[0]), (p[1], i[0])]
     if name == "fp8_quantize":
         return [(p[0], i[0] * 2), (p[1], i[0])]
+    if name in ("mx_ln_modulate", "mx_ln_affine"):                       # fp32 rows in, bf16 rows out
+        return [(p[0], i[0] * i[1] * 4), (p[1], i[0] * i[1] * 2)]
+    if name == "mx_gated_residual":
+        return [(p[0], i[0] * i[1] * 4), (p[1], i[0] * i[1] * 2)]
+    if name == "mx_patch_embed":
+        return [(p[4], i[7] * i[5] * 4)]
+    if name == "mx_linear_f32":
+        return [(p[0], i[0] * i[2] * 4), (p[3], i[0] * i[1] * 4)]
+    if name == "mx_sinusoid":
+        return [(p[0], i[0] * 4)]
+    if name == "mx_head":
+        return [(p[0], i[0] * i[1] * 4), (p[5], i[0] * i[1] * 4), (p[6], i[0] * i[3] * 4)]
     return []
 
 
@@ -170,6 +182,85 @@ def test_plain_forward_launch_order_weights_and_workspace_bounds(mock):
     att = [cl for cl in blk if cl[0] == "attention"]
     assert att[0][2][:6] == [2, 2, Ll, Ll, (Ll + 63) // 64 * 64, c.num_heads] and att[1][2][:6] == [2, 2, Ll, TL, TL, c.num_heads]
     assert att[0][1][4] != 0 and att[1][1][4] == att[0][1][4]           # the K pre-pass scratch: self-attention, and since round 4 cross-attention too (the persistent bounded walk over 512 keys)
+
+
+def test_mixed_precision_plan_launch_order_pointers_and_refusals(mock):
+    """A context whose time_projection.1.weight is registered as fp32 runs the reference's mixed-precision plan (model.py:1330-1371, :1545):
+    the fp32 kernels of csrc/mixed_ops.hip in WanAttentionBlock.forward's order, every Linear that ended in a fused residual epilogue writing
+    bf16 to xm with a separate fp32 pass behind it, the residual stream as fp32 rows (stream s at x + s * L * d * 4 bytes), e0 per frame and
+    stream under per-frame timesteps, a token-major head + unpatchify; nothing of the bf16 plan's row kernels; step skipping refused."""
+    m = Model(mock, mixed=True)
+    c, (F, H, W) = m.cfg, (2, 8, 8)
+    Ll = F * (H // 2) * (W // 2)
+    plain_bytes = mock.wan_dit_workspace_bytes(Model(mock).ctx, 2, F, H, W, 1)
+    rc, calls, nbytes = m.forward(S=2)
+    assert rc == 0, mock.wan_last_error()
+    assert nbytes > plain_bytes + 2 * Ll * c.dim * 2                        # the fp32 stream and the plan's fp32 scratch
+    touched = 0
+    for cl in calls:
+        for ptr, n in extents(cl):
+            if in_ws(ptr, nbytes):
+                assert ptr + n <= WS + nbytes, (cl[0], hex(ptr - WS), n, nbytes)
+                touched += 1
+    assert touched > 80
+    names = [cl[0] for cl in calls]
+    assert not {"ln_modulate", "ln_affine", "head", "patch_embed", "gemv", "sinusoid", "act"} & set(names)
+    assert names[:names.index("mx_ln_modulate")].count("mx_patch_embed") == 2
+    i0 = names.index("mx_sinusoid")
+    assert names[i0:i0 + 4] == ["mx_sinusoid", "mx_linear_f32", "mx_linear_f32", "mx_linear_f32"]
+    lins = calls[i0 + 1:i0 + 4]
+    assert [(l[2][0], l[2][1], l[2][2], l[2][3]) for l in lins] == [(1, c.dim, c.freq_dim, 0), (1, c.dim, c.dim, 1), (1, 6 * c.dim, c.dim, 1)]
+    assert [l[1][1] for l in lins] == [m.addr["time_embedding.0.weight"], m.addr["time_embedding.2.weight"], m.addr["time_projection.1.weight"]]
+    assert lins[0][1][3] == lins[1][1][0] and lins[1][1][3] == lins[2][1][0]          # sinusoid -> hidden -> e -> e0, chained
+    first_block = names.index("mx_ln_modulate")
+    per_layer = ["mx_ln_modulate", "gemm", "gemm", "gemm", "gemm", "rmsnorm_rope", "attention", "gemm", "mx_gated_residual",
+                 "mx_ln_affine", "gemm", "rmsnorm_rope", "gemm", "rmsnorm_rope", "gemm", "gemm", "attention", "gemm", "mx_gated_residual",
+                 "mx_ln_modulate", "gemm", "gemm", "mx_gated_residual"]
+    body = names[first_block:first_block + len(per_layer) * c.num_layers]
+    assert body == per_layer * c.num_layers
+    assert names[first_block + len(per_layer) * c.num_layers:] == ["mx_head", "unpatchify", "mx_head", "unpatchify"]
+    blk = calls[first_block + len(per_layer):first_block + 2 * len(per_layer)]
+    x32 = blk[0][1][0]
+    xm = blk[0][1][1]
+    e0 = blk[0][1][3]
+    assert x32 == WS                                                        # the residual stream is the first region of the workspace
+    gemms = [cl for cl in blk if cl[0] == "gemm"]
+    assert all(g[2][5] in (0, 1, 3) for g in gemms)                         # no fused residual epilogue (2) in this plan
+    res = [cl for cl in blk if cl[0] == "mx_gated_residual"]
+    assert [r[2][3] for r in res] == [2, -1, 5] and all(r[1][0] == x32 and r[1][1] == xm for r in res)
+    assert [g[1][3] for g in (gemms[4], gemms[9], gemms[11])] == [xm, xm, xm]          # self o, cross o, ffn.2 -> xm
+    assert res[0][1][2] == m.addr["blocks.1.modulation"] and res[0][1][3] == e0 and res[1][1][2] == 0
+    aff = [cl for cl in blk if cl[0] == "mx_ln_affine"][0]
+    assert aff[1][0] == x32 and aff[1][2] == m.addr["blocks.1.norm3.weight"] and aff[1][3] == m.addr["blocks.1.norm3.bias"]
+    mods = [cl for cl in blk if cl[0] == "mx_ln_modulate"]
+    assert [(q[2][3], q[2][4]) for q in mods] == [(0, 1), (3, 4)] and all(q[2][0] == 2 * Ll and q[2][5] == 2 * Ll for q in mods)
+    heads = [cl for cl in calls if cl[0] == "mx_head"]
+    assert [h[1][0] for h in heads] == [x32, x32 + Ll * c.dim * 4] and all(h[2][0] == Ll and h[2][2] == Ll and h[2][3] == 4 * c.out_dim for h in heads)
+    unp = [cl for cl in calls if cl[0] == "unpatchify"]
+    assert [u[1][1] for u in unp] == [0x6200_0000_0000, 0x6200_0000_0000 + 0x1_0000_0000] and all(u[1][0] == heads[0][1][6] for u in unp)
+    # per-frame timesteps: one e0 row set per frame, replicated per stream; rows_per_batch = tokens per frame
+    rc, calls, _ = m.forward(S=2, t_frames=[0.0, 637.0])
+    assert rc == 0, mock.wan_last_error()
+    names = [cl[0] for cl in calls]
+    assert names.count("mx_sinusoid") == 2 and [cl for cl in calls if cl[0] == "mx_linear_f32"][0][2][0] == 2
+    assert any(cl[0] == "memcpy" and cl[2][0] == 2 * 6 * c.dim * 4 for cl in calls)
+    assert all(cl[2][5] == Ll // F for cl in calls if cl[0] == "mx_ln_modulate") and all(cl[2][2] == Ll // F for cl in calls if cl[0] == "mx_head")
+    # one stream (a CFG-parallel half), sequence parallelism: the head hands over token-major rows, nothing unpatchifies
+    sp = SpInfo(1, 2, Ll // 2, Ll // 2, GATHER_FN(lambda *a: 0), GATHER_WAIT_FN(lambda *a: 0), None, 0, GATHER_FN(lambda *a: 0), GATHER_WAIT_FN(lambda *a: 0))
+    rc, calls, _ = m.forward(S=1, sp=sp)
+    assert rc == 0, mock.wan_last_error()
+    names = [cl[0] for cl in calls]
+    assert "unpatchify" not in names and names[-1] == "mx_head" and calls[-1][1][6] == 0x6200_0000_0000
+    pe = [cl for cl in calls if cl[0] == "mx_patch_embed"][0]
+    assert pe[2][6:8] == [Ll // 2, Ll // 2]                                  # this rank's token range
+    # a step-skipping residual buffer: refused (the caches keep bf16 state), with a message that says so
+    rc, _, _ = m.forward(S=2, should_calc=[1, 1], residual=[0x6400_0000_0000, 0x6410_0000_0000])
+    assert rc != 0 and b"mixed-precision" in mock.wan_last_error()
+    # an inconsistent registration (fp32 projection, bf16 norm3) is an error, not a silent mix of plans
+    bad = Model(mock, mixed=True)
+    assert mock.wan_dit_set_weight(bad.ctx, b"blocks.0.norm3.weight", c_void_p(bad.addr["blocks.0.norm3.weight"]), 0, c.dim) == 0
+    rc, _, _ = bad.forward(S=1)
+    assert rc != 0 and b"norm3.weight" in mock.wan_last_error()
 
 
 def test_step_skipping_touches_only_the_computing_stream(mock):

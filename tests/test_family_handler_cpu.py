@@ -331,6 +331,11 @@ def test_load_model_wires_experts_vae_text_encoder_and_the_clip_tower(monkeypatc
     pipe, extra = H.load_model(["hi.safetensors", "lo.safetensors"], "t2v_2_2_hip", "t2v_2_2_hip", {}, state_dicts=[{"a": 1}, {"b": 2}],
                                vae_state_dict={"v": 0}, text_encoder=te, clip=clip, profile=3, lm_decoder_engine="legacy")
     assert extra == {"pipe": {}} and pipe.clip is None and pipe.model.sd == {"a": 1} and pipe.model2.sd == {"b": 2}
+    assert pipe.model.arch["mixed_precision"] is False and pipe.model2.arch["mixed_precision"] is False
+    # wgp.py:4039 / :4071: the server setting "mixed_precision" arrives as mixed_precision_transformer -- both experts take the fp32-stream plan
+    pmx, _ = H.load_model(["hi.safetensors", "lo.safetensors"], "t2v_2_2_hip", "t2v_2_2_hip", {}, state_dicts=[{"a": 1}, {"b": 2}],
+                          vae_state_dict={"v": 0}, text_encoder=te, mixed_precision_transformer=True)
+    assert pmx.model.arch["mixed_precision"] is True and pmx.model2.arch["mixed_precision"] is True
     assert type(pipe.vae) is Vae and pipe.vae.src == ("sd", {"v": 0}) and pipe.text_encoder is te and pipe.vae_stride == (4, 8, 8)
     pipe, extra = H.load_model(["m.safetensors"], "ti2v_2_2_hip", "ti2v_2_2_hip", None, state_dicts=[{}], vae_state_dict={}, text_encoder=te)
     assert type(pipe.vae) is Vae22 and pipe.vae_stride == (4, 16, 16) and pipe.model2 is None and extra == {"pipe": {}}

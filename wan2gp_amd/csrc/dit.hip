@@ -135,6 +135,8 @@ struct Layer {
   Lin before, after;              // VACE context block: before_proj (block 0 only) / after_proj (model.py:805-812)
   const bf16_t* n3w = nullptr;
   const bf16_t* n3b = nullptr;
+  const float* n3w32 = nullptr;   // mixed-precision plan: norm3 under the fp32 lock (model.py:1342-1346)
+  const float* n3b32 = nullptr;
   Lin f0, f2;
 };
 
@@ -147,6 +149,12 @@ struct wan_ctx {
   const float* pe_w = nullptr;
   const float* pe_b = nullptr;
   Lin te0, te2, tm0, tm2, tp1;
+  // `mixed_precision_transformer` (any2video.py:190 -> lock_layers_dtypes(torch.float32), model.py:1330-1371): the context runs that plan
+  // when 'time_projection.1.weight' was registered as fp32 -- the reference's own rule (modulation_dtype = time_projection[1].weight.dtype,
+  // model.py:1545).  Then the time MLP, the projection and every norm3 are fp32 tensors, the residual stream / e / e0 live in fp32 and the
+  // row kernels of csrc/mixed_ops.hip replace the bf16 plan's (fused GEMM epilogues become separate passes).
+  bool mixed = false;
+  const float *mx_tm0w = nullptr, *mx_tm0b = nullptr, *mx_tm2w = nullptr, *mx_tm2b = nullptr, *mx_tp1w = nullptr, *mx_tp1b = nullptr;
   const float* head_mod = nullptr;
   const float* head_w = nullptr;
   const float* head_b = nullptr;
@@ -245,6 +253,12 @@ static int get_lin(wan_ctx* c, Lin& l, const std::string& prefix, int64_t out_f,
   return 0;
 }
 
+// the mixed-precision plan is chosen by the registered weights, like the reference chooses its modulation dtype (model.py:1545)
+static bool ctx_is_mixed(const wan_ctx* c) {
+  auto it = c->weights.find("time_projection.1.weight");
+  return it != c->weights.end() && it->second.dtype == 1;
+}
+
 static int load_layer(wan_ctx* c, Layer& L, const std::string& p) {
   const int64_t d = c->cfg.dim, f = c->cfg.ffn_dim;
   GETB(L.mod, p + "modulation", 6 * d);
@@ -258,8 +272,13 @@ static int load_layer(wan_ctx* c, Layer& L, const std::string& p) {
     GETB(A.nq, ap + "norm_q.weight", d);
     GETB(A.nk, ap + "norm_k.weight", d);
   }
-  GETB(L.n3w, p + "norm3.weight", d);
-  GETB(L.n3b, p + "norm3.bias", d);
+  if (c->mixed) {
+    GETF(L.n3w32, p + "norm3.weight", d);
+    GETF(L.n3b32, p + "norm3.bias", d);
+  } else {
+    GETB(L.n3w, p + "norm3.weight", d);
+    GETB(L.n3b, p + "norm3.bias", d);
+  }
   if (int rc = get_lin(c, L.f0, p + "ffn.0", f, d)) return rc;
   if (int rc = get_lin(c, L.f2, p + "ffn.2", d, f)) return rc;
   return 0;
@@ -274,9 +293,19 @@ static int resolve(wan_ctx* c) {
   GETF(c->pe_b, "patch_embedding.bias", d);
   if (int rc = get_lin(c, c->te0, "text_embedding.0", d, g.text_dim)) return rc;
   if (int rc = get_lin(c, c->te2, "text_embedding.2", d, d)) return rc;
-  if (int rc = get_lin(c, c->tm0, "time_embedding.0", d, g.freq_dim)) return rc;
-  if (int rc = get_lin(c, c->tm2, "time_embedding.2", d, d)) return rc;
-  if (int rc = get_lin(c, c->tp1, "time_projection.1", 6 * d, d)) return rc;
+  c->mixed = ctx_is_mixed(c);
+  if (c->mixed) {
+    GETF(c->mx_tm0w, "time_embedding.0.weight", d * g.freq_dim);
+    GETF(c->mx_tm0b, "time_embedding.0.bias", d);
+    GETF(c->mx_tm2w, "time_embedding.2.weight", d * d);
+    GETF(c->mx_tm2b, "time_embedding.2.bias", d);
+    GETF(c->mx_tp1w, "time_projection.1.weight", 6 * d * d);
+    GETF(c->mx_tp1b, "time_projection.1.bias", 6 * d);
+  } else {
+    if (int rc = get_lin(c, c->tm0, "time_embedding.0", d, g.freq_dim)) return rc;
+    if (int rc = get_lin(c, c->tm2, "time_embedding.2", d, d)) return rc;
+    if (int rc = get_lin(c, c->tp1, "time_projection.1", 6 * d, d)) return rc;
+  }
   GETF(c->head_mod, "head.modulation", 2 * d);
   GETF(c->head_w, "head.head.weight", (int64_t)4 * g.out_dim * d);
   GETF(c->head_b, "head.head.bias", 4 * g.out_dim);
@@ -346,15 +375,17 @@ struct Bufs {
   float* raw;   // sequence parallelism: partial attention sums of the local segment (wan_attention_raw_words)
   float* kmax;  // scratch of the self-attention K pre-pass (wan_attention_bounded): wan_attention_scratch_words(S, S, Ll, heads)
   int64_t Lp;
+  // mixed-precision plan only (x then holds fp32 rows): sinusoid / time MLP / e / e0 in fp32, the head's modulated rows, its token-major result
+  float *mx_sin = nullptr, *mx_eh = nullptr, *mx_e = nullptr, *mx_e0 = nullptr, *mx_tmp = nullptr, *mx_tok = nullptr;
 };
 
-static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, int nvace, bool fp8, int F) {
+static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, void* ws, Bufs* b, int nvace, bool fp8, int F, bool mixed = false) {
   Carve c(ws);
   const int64_t d = g.dim, rows = (int64_t)S * Ll;
   const int64_t Lp = ((Ll + 63) / 64) * 64;
   Bufs t;
   t.Lp = Lp;
-  t.x = c.take<bf16_t>(rows * d);
+  t.x = c.take<bf16_t>(rows * d * (mixed ? 2 : 1));   // mixed-precision plan: the residual stream in fp32
   t.xm = c.take<bf16_t>(rows * d);
   t.q = c.take<bf16_t>(rows * d);
   t.k = c.take<bf16_t>(rows * d);
@@ -396,6 +427,14 @@ static int64_t carve_all(const wan_dit_config& g, int S, int64_t Ll, int world, 
     t.vtfull = nullptr;
     t.raw = nullptr;
   }
+  if (mixed) {  // (behind everything else: the bf16 plan's layout does not move)
+    t.mx_sin = c.take<float>((int64_t)F * g.freq_dim);
+    t.mx_eh = c.take<float>((int64_t)F * d);
+    t.mx_e = c.take<float>((int64_t)F * d);
+    t.mx_e0 = c.take<float>((int64_t)S * F * 6 * d);
+    t.mx_tmp = c.take<float>(Ll * d);
+    t.mx_tok = c.take<float>(Ll * 4 * (int64_t)g.out_dim);
+  }
   if (b) *b = t;
   return c.off;
 }
@@ -410,7 +449,8 @@ extern "C" int64_t wan_dit_workspace_bytes(const wan_ctx* ctx, int S, int F, int
   if (!ctx || S < 1 || seq_shards < 1) return -1;
   const int64_t L = (int64_t)F * (H / 2) * (W / 2);
   if (L % seq_shards != 0) return -1;
-  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, ctx->vace_layers.empty() ? 0 : ctx->vace_max_ctx, ctx_has_fp8(ctx), F);
+  return carve_all(ctx->cfg, S, L / seq_shards, seq_shards, nullptr, nullptr, ctx->vace_layers.empty() ? 0 : ctx->vace_max_ctx, ctx_has_fp8(ctx), F,
+                   ctx_is_mixed(ctx));
 }
 
 #define RC(expr)             \
@@ -528,7 +568,16 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   }
   WAN_REQUIRE(!any_nag || ffn >= d, "wan_dit_forward: normalized attention guidance parks a result in the FFN buffer (ffn_dim >= dim)");
   Bufs b;
-  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, c->vace_layers.empty() ? 0 : c->vace_max_ctx, c->any_fp8, F);
+  const bool mx = c->mixed;
+  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, c->vace_layers.empty() ? 0 : c->vace_max_ctx, c->any_fp8, F, mx);
+  // the mixed-precision plan serves the block chain of the t2v / i2v2_2 / ti2v models (also under sequence parallelism, NAG, skip-layer
+  // guidance, fp8 Linears); what keeps bf16 state of its own is refused rather than silently run in the other plan
+  bool any_residual = false;
+  for (int s = 0; residual != nullptr && s < S; ++s) any_residual = any_residual || residual[s] != nullptr;
+  WAN_REQUIRE(!mx || (!any_residual && n_vace == 0 && c->vace_layers.empty() && !c->has_img),
+              "wan_dit_forward: the mixed-precision plan (fp32 time_projection / norm3 weights) does not serve step-skipping caches, VACE "
+              "context blocks or the Wan2.1 i2v CLIP branch");
+  float* const x32 = reinterpret_cast<float*>(b.x);
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
               (long long)workspace_bytes, (long long)need);
   WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
@@ -543,9 +592,11 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   if (c->has_img) WAN_CHECK_HIP(hipMemsetAsync(b.cvtimg, 0, (size_t)d * CLIP_LDV * 2, st));
 
   // ---- embeddings (model.py:1631,1731 ; :1815-1818 ; :1856) -----------------------------------------
-  for (int s = 0; s < S; ++s)
-    RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, g.out_dim, g.in_dim - g.out_dim, F, H, W, d,
-                             tok0, Ll, stream));
+  for (int s = 0; s < S; ++s) {
+    if (mx) RC(wan_mx_patch_embed(x[s], y, c->pe_w, c->pe_b, x32 + (int64_t)s * Ll * d, g.out_dim, g.in_dim - g.out_dim, F, H, W, d, tok0, Ll, stream));
+    else RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, g.out_dim, g.in_dim - g.out_dim, F, H, W, d,
+                                  tok0, Ll, stream));
+  }
   // Timesteps: one scalar, or one per latent frame (t_frames[F], HOST pointer): tokens of frame f are modulated by
   // e0[f] (model.py:631-638, :856-862).  Under sequence parallelism a rank needs the rows of its own frames only, which
   // requires shards made of whole frames.
@@ -557,20 +608,32 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     nt = (int)(Ll / tpf);
     frame0 = (int)(tok0 / tpf);
   }
-  for (int f = 0; f < nt; ++f)
+  if (mx) {
+    // the time MLP and the projection under the fp32 lock (model.py:1815-1818 with an fp32 modulation dtype): e, e0 stay fp32
+    for (int f = 0; f < nt; ++f)
+      RC(wan_mx_sinusoid(t_frames ? t_frames[frame0 + f] : t, b.mx_sin + (int64_t)f * g.freq_dim, g.freq_dim, stream));
+    RC(wan_mx_linear_f32(b.mx_sin, c->mx_tm0w, c->mx_tm0b, b.mx_eh, nt, d, g.freq_dim, 0, stream));
+    RC(wan_mx_linear_f32(b.mx_eh, c->mx_tm2w, c->mx_tm2b, b.mx_e, nt, d, d, 1, stream));          // Linear(SiLU(.))
+    RC(wan_mx_linear_f32(b.mx_e, c->mx_tp1w, c->mx_tp1b, b.mx_e0, nt, 6 * d, d, 1, stream));       // time_projection = SiLU -> Linear
+    for (int s = 1; s < S && nt > 1; ++s)
+      WAN_CHECK_HIP(hipMemcpyAsync(b.mx_e0 + (int64_t)s * nt * 6 * d, b.mx_e0, (size_t)nt * 6 * d * 4, hipMemcpyDeviceToDevice, st));
+  }
+  for (int f = 0; f < nt && !mx; ++f)
     RC(wan_sinusoid_val(t_frames ? t_frames[frame0 + f] : t, b.sinus + (int64_t)f * g.freq_dim, g.freq_dim, stream));
   // the time MLP: GEMV for one row of bf16 weights, the tile GEMM otherwise (several rows, or fp8 weights: one tensor)
   auto tlin = [&](const bf16_t* A, const Lin& l, bf16_t* C, int N, int K) -> int {
     if (l.w8 || nt > 1) return linear(A, l, C, nt, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8);
     return wan_gemv_bf16(A, l.w, l.b, C, 1, N, K, stream);
   };
-  RC(tlin(b.sinus, c->tm0, b.e_h, d, g.freq_dim));
-  RC(wan_act_bf16(b.e_h, b.e_h, (int64_t)nt * d, 1, stream));
-  RC(tlin(b.e_h, c->tm2, b.e, d, d));
-  RC(wan_act_bf16(b.e, b.e_s, (int64_t)nt * d, 1, stream));
-  RC(tlin(b.e_s, c->tp1, b.e0, 6 * d, d));
-  for (int s = 1; s < S && nt > 1; ++s)
-    WAN_CHECK_HIP(hipMemcpyAsync(b.e0 + (int64_t)s * nt * 6 * d, b.e0, (size_t)nt * 6 * d * 2, hipMemcpyDeviceToDevice, st));
+  if (!mx) {
+    RC(tlin(b.sinus, c->tm0, b.e_h, d, g.freq_dim));
+    RC(wan_act_bf16(b.e_h, b.e_h, (int64_t)nt * d, 1, stream));
+    RC(tlin(b.e_h, c->tm2, b.e, d, d));
+    RC(wan_act_bf16(b.e, b.e_s, (int64_t)nt * d, 1, stream));
+    RC(tlin(b.e_s, c->tp1, b.e0, 6 * d, d));
+    for (int s = 1; s < S && nt > 1; ++s)
+      WAN_CHECK_HIP(hipMemcpyAsync(b.e0 + (int64_t)s * nt * 6 * d, b.e0, (size_t)nt * 6 * d * 2, hipMemcpyDeviceToDevice, st));
+  }
   for (int s = 0; s < S; ++s) {  // one tensor per stream (fp8: one quantisation per tensor), [cb[s] * TL, text_dim]
     RC(linear(context[s], c->te0, b.ctx_h + (int64_t)crow[s] * d, (int64_t)cb[s] * TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream, nullptr,
               nullptr, nullptr, -1, 1, 0, q8, 1, s));
@@ -644,8 +707,9 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   const int S = Sn;
   const int64_t rows = (int64_t)Sn * Ll, rpb = nt > 1 ? tpf : rows;
   struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; float* raw; } b2 = {
-      b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, XT ? b.ctx_h + (int64_t)s0 * TLx * d : b.ctx_e + (int64_t)crow[s0] * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
-  bf16_t* const x_main = b.x + s0 * sn;
+      mx ? reinterpret_cast<bf16_t*>(x32 + s0 * sn) : b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, XT ? b.ctx_h + (int64_t)s0 * TLx * d : b.ctx_e + (int64_t)crow[s0] * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
+  bf16_t* const x_main = mx ? reinterpret_cast<bf16_t*>(x32 + s0 * sn) : b.x + s0 * sn;
+  const float* const e0f = b.mx_e0;   // (the outer Bufs: captured before `b` is shadowed below)
   // hint streams of this run, per active context; vskip[k] doubles as the swap buffer of before_proj
   bf16_t *vc[8], *vskip[8];
   for (int j = 0; j < n_on; ++j) {
@@ -656,7 +720,11 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   // one WanAttentionBlock (model.py:575-724) on the token streams at b.x, with the weights Lw
   auto run_layer = [&](const Layer& Lw) -> int {
     // -- self attention (model.py:632-660) --
-    RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
+    // mixed-precision plan (mx): b.x holds fp32 rows; modulate / norm3 / the gated residuals are the fp32 kernels of mixed_ops.hip, each
+    // Linear that ended in a fused residual epilogue writes its bf16 result to xm (dead at those three points) and a separate pass adds it
+    float* const xf = reinterpret_cast<float*>(b.x);
+    if (mx) RC(wan_mx_ln_modulate(xf, b.xm, Lw.mod, e0f, 6, 0, 1, rows, rpb, d, g.eps, stream));
+    else RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
     if (ulysses) {
       // Ulysses (round 4): re-shard q, k, v from "my tokens, all heads" to "all tokens, my heads" by all-to-all, attend the whole
       // sequence for nh / world heads in ONE launch, bring o back the same way.  Order K, V, Q as below: the k exchange runs under
@@ -759,9 +827,15 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     // outside the timed bracket: which share of the launch's workgroups failed the score bound and ran the tracking loop
     // (attention.hip hands the scratch to the kernels only for long KV -- Lk > 2048: for shorter sequences the flags are never written)
     if (!ulysses && g_prof_on && g_prof_declined != nullptr && b.kmax != nullptr && Ll > 2048) RC(wan_attention_count_declined(b.kmax, S, S, Ll, nh, g_prof_declined, stream));
-    RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb, 0, q8, S));
+    if (mx) {
+      RC(linear(b.q, Lw.self.o, b.xm, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      RC(wan_mx_gated_residual(xf, b.xm, Lw.mod, e0f, 6, 2, rows, rpb, d, stream));
+    } else {
+      RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb, 0, q8, S));
+    }
     // -- cross attention (model.py:663-668, :245-265) --
-    RC(wan_ln_affine(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, stream));
+    if (mx) RC(wan_mx_ln_affine(xf, b.xm, Lw.n3w32, Lw.n3b32, rows, d, g.eps, stream));
+    else RC(wan_ln_affine(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, stream));
     RC(linear(b.xm, Lw.cross.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
     // norm only; the softmax scale * log2(e) folded into q as for self-attention
     RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.cross.nq, nullptr, nullptr, nullptr, rows, Ll, 0, d, g.eps, wan_attention_qscale(), stream));
@@ -828,14 +902,22 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(wan_attention_bounded(b.q, b.ckimg, b.cvtimg, b.q, S, 1, Ll, CLIP_TOK, CLIP_LDV, nh, 1, 0, 0, 1, nullptr, stream));
       RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }
-    RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb, 0, q8, S));
+    if (mx) {
+      RC(linear(b.q, Lw.cross.o, b.xm, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      RC(wan_mx_gated_residual(xf, b.xm, nullptr, nullptr, 6, -1, rows, rpb, d, stream));
+    } else {
+      RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb, 0, q8, S));
+    }
     // -- FFN (model.py:686-711) --
-    RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 3, 4, rows, rpb, d, g.eps, stream));
+    if (mx) RC(wan_mx_ln_modulate(xf, b.xm, Lw.mod, e0f, 6, 3, 4, rows, rpb, d, g.eps, stream));
+    else RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 3, 4, rows, rpb, d, g.eps, stream));
     {
       ProfScope ps(PROF_GEMM, st);  // the two FFN GEMMs: 4*rows*d*ffn FLOP
       RC(linear(b.xm, Lw.f0, b.h, rows, ffn, d, WAN_EPI_GELU_TANH, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
-      RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb, 0, q8, S));
+      if (mx) RC(linear(b.h, Lw.f2, b.xm, rows, d, ffn, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      else RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb, 0, q8, S));
     }
+    if (mx) RC(wan_mx_gated_residual(xf, b.xm, Lw.mod, e0f, 6, 5, rows, rpb, d, stream));
     return 0;
   };
   for (int i = l0; i < l1; ++i) {
@@ -903,9 +985,18 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(wan_sub_bf16(b.x + s * sn, residual[s], residual[s], sn, stream));  // previous_residual = x - ori (model.py:2044-2062)
 
   // ---- head + unpatchify (model.py:2068-2097) -------------------------------------------------------
-  for (int s = 0; s < S; ++s)
-    RC(wan_head_range(b.x + (int64_t)s * Ll * d, c->head_mod, b.e, c->head_w, c->head_b, b.xm, outs[s], 1, F, Hg, Wg, d,
-                      g.eps, tok0, Ll, world > 1 ? 1 : 0, nt > 1 ? tpf : 0, 4 * g.out_dim, stream));
+  for (int s = 0; s < S; ++s) {
+    if (mx) {
+      // Head.forward on the fp32 stream (model.py:847-865): token-major result; one rank unpatchifies here, a sequence-parallel rank
+      // hands its shard's rows to the host's gather like the bf16 plan does
+      RC(wan_mx_head(x32 + (int64_t)s * Ll * d, c->head_mod, b.mx_e, c->head_w, c->head_b, b.mx_tmp, world > 1 ? outs[s] : b.mx_tok, Ll, d, g.eps,
+                     nt > 1 ? tpf : Ll, 4 * g.out_dim, stream));
+      if (world == 1) RC(wan_unpatchify_n(b.mx_tok, outs[s], 1, F, Hg, Wg, 4 * g.out_dim, stream));
+    } else {
+      RC(wan_head_range(b.x + (int64_t)s * Ll * d, c->head_mod, b.e, c->head_w, c->head_b, b.xm, outs[s], 1, F, Hg, Wg, d,
+                        g.eps, tok0, Ll, world > 1 ? 1 : 0, nt > 1 ? tpf : 0, 4 * g.out_dim, stream));
+    }
+  }
   return 0;
 }
 

@@ -1,0 +1,268 @@
+// The row / edge kernels of the reference's MIXED-PRECISION transformer plan (`mixed_precision_transformer`: wgp.py:4039 server
+// setting "mixed_precision" -> any2video.py:190 -> lock_layers_dtypes(torch.float32), models/wan/modules/model.py:1330-1371).
+// With the time MLP, the time projection and every block's norm3 held in fp32, the modulation dtype (model.py:1545) is fp32 and, by type
+// promotion, the residual stream x, e / e0, every AdaLN modulate and every gated residual run in fp32; each Linear / attention still sees
+// bf16 (ONE rounding, `.to(attention_dtype)`, model.py:650,665,692) and returns bf16 that is widened back (:654,668,708).
+// An option, not the default plan: these kernels are plain (one wave per token row, rows re-read from L2 for the second and third pass;
+// GEMM epilogues are separate passes) -- the bf16 plan's fused kernels (elementwise.hip, gemm256m.hip) are untouched.
+//   wan_mx_ln_modulate    norm1 / norm2 + modulate   model.py:634-638, :686-692   x fp32 -> bf16
+//   wan_mx_ln_affine      norm3 (fp32 weight, bias)  model.py:664-665             x fp32 -> bf16
+//   wan_mx_gated_residual x.addcmul_(y, e[k]) / x += y   model.py:658, :668, :708   x fp32 in place, y bf16
+//   wan_mx_patch_embed    patch_embedding(x).to(fp32)    model.py:1620-1631      fp32 Conv3d k = s = (1, 2, 2), no rounding
+//   wan_mx_sinusoid, wan_mx_linear_f32                   model.py:1815-1818      the time MLP and projection in fp32
+//   wan_mx_head           Head.forward on fp32 x         model.py:847-865        token-major fp32 [ntok, nout]
+#include "common.h"
+
+namespace {
+
+// 0: modulate -> bf16 (p0 = modulation bf16 [n_mod, d], p1 = e0 fp32 [batches, n_mod, d]);  1: affine -> bf16 (p0 = weight fp32, p1 = bias fp32)
+// 2: modulate -> fp32 (p0 = head.modulation fp32 [2, d], p1 = e fp32 [batches, d]; shift row 0, scale row 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void mx_ln_kernel(const float* __restrict__ x, void* __restrict__ out, const void* __restrict__ p0,
+                                                    const float* __restrict__ p1, int n_mod, int shift_idx, int scale_idx, int64_t rows,
+                                                    int64_t rpb, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * d;
+  float s = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, dd = v.w - mean;
+    q += (a * a + b * b) + (cc * cc + dd * dd);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  const int64_t batch = row / rpb;
+  for (int c = lane * 4; c < d; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    float y[4] = {(v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd};
+    float r[4];
+    if (MODE == 0) {
+      const bf16_t* mod = reinterpret_cast<const bf16_t*>(p0);
+      const float* e0 = p1 + batch * (int64_t)n_mod * d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sc = bf2f(mod[(int64_t)scale_idx * d + c + j]) + e0[(int64_t)scale_idx * d + c + j];   // bf16 parameter + fp32 e0 -> fp32 (:632)
+        const float sh = bf2f(mod[(int64_t)shift_idx * d + c + j]) + e0[(int64_t)shift_idx * d + c + j];
+        r[j] = __fadd_rn(__fmul_rn(y[j], 1.0f + sc), sh);                                                 // `x_mod *= 1 + e[1]; x_mod += e[0]`: two fp32 roundings
+      }
+    } else if (MODE == 1) {
+      const float* w = reinterpret_cast<const float*>(p0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = y[j] * w[c + j] + p1[c + j];
+    } else {
+      const float* hm = reinterpret_cast<const float*>(p0);
+      const float* e = p1 + batch * (int64_t)d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sh = hm[c + j] + e[c + j], sc = hm[d + c + j] + e[c + j];                             // (head.modulation + e.unsqueeze(1)).chunk(2): shift, scale (:857)
+        r[j] = __fadd_rn(__fmul_rn(y[j], 1.0f + sc), sh);
+      }
+    }
+    if (MODE == 2) {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row * d + c) = float4{r[0], r[1], r[2], r[3]};
+    } else {
+      uint2 w2;
+      w2.x = pack2bf(r[0], r[1]);
+      w2.y = pack2bf(r[2], r[3]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + row * d + c) = w2;
+    }
+  }
+}
+
+// x[row][c] += y[row][c] * gate[batch][c]   (gate = modulation[gate_idx] + e0[batch][gate_idx], fp32)   or   x += y  (mod == nullptr)
+__global__ __launch_bounds__(256) void mx_gated_residual_kernel(float* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ mod,
+                                                                const float* __restrict__ e0, int n_mod, int gate_idx, int64_t rows,
+                                                                int64_t rpb, int d) {
+  const int64_t n4 = rows * (int64_t)d / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t el = i * 4;
+    const int64_t row = el / d;
+    const int c = (int)(el - row * d);
+    float4 xv = *reinterpret_cast<const float4*>(x + el);
+    const uint2 yv = *reinterpret_cast<const uint2*>(y + el);
+    const float yy[4] = {__uint_as_float(yv.x << 16), __uint_as_float(yv.x & 0xffff0000u), __uint_as_float(yv.y << 16), __uint_as_float(yv.y & 0xffff0000u)};
+    float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (mod != nullptr) {
+      const float* e = e0 + ((row / rpb) * n_mod + gate_idx) * (int64_t)d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = bf2f(mod[(int64_t)gate_idx * d + c + j]) + e[c + j];
+        xx[j] = __fadd_rn(xx[j], __fmul_rn(yy[j], g));      // addcmul_: self + (t1 * t2), the product rounded first
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xx[j] = xx[j] + yy[j];
+    }
+    *reinterpret_cast<float4*>(x + el) = float4{xx[0], xx[1], xx[2], xx[3]};
+  }
+}
+
+// out[tok][c] = bias[c] + sum_{ci, ph, pw} in(ci, f, 2 h + ph, 2 w + pw) * w[c][ci][0][ph][pw];  channels >= Cin come from y (i2v: mask + latents)
+__global__ __launch_bounds__(256) void mx_patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int Cin, int Cy, int F,
+                                                             int H, int W, int d, int64_t tok0, int64_t ntok) {
+  const int Hg = H / 2, Wg = W / 2, Ct = Cin + Cy;
+  const int64_t total = ntok * (int64_t)d;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t tl = i / d;
+    const int c = (int)(i - tl * d);
+    const int64_t tok = tok0 + tl;
+    const int f = (int)(tok / ((int64_t)Hg * Wg));
+    const int rem = (int)(tok - (int64_t)f * Hg * Wg);
+    const int hg = rem / Wg, wg = rem - hg * Wg;
+    float acc = 0.f;
+    for (int ci = 0; ci < Ct; ++ci) {
+      const float* src = ci < Cin ? x + (((int64_t)ci * F + f) * H + 2 * hg) * W + 2 * wg : y + (((int64_t)(ci - Cin) * F + f) * H + 2 * hg) * W + 2 * wg;
+      const float* wk = w + ((int64_t)c * Ct + ci) * 4;
+      acc += src[0] * wk[0];
+      acc += src[1] * wk[1];
+      acc += src[W] * wk[2];
+      acc += src[W + 1] * wk[3];
+    }
+    out[i] = acc + bias[c];
+  }
+}
+
+__global__ void mx_sinusoid_kernel(float tval, float* __restrict__ out, int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half) return;
+  const float freq = powf(10000.0f, -((float)i / (float)half));
+  const float a = tval * freq;
+  out[i] = cosf(a);
+  out[half + i] = sinf(a);
+}
+
+// C[m][n] = bias[n] + sum_k act(A[m][k]) * W[n][k]   (act 0 none, 1 SiLU on the INPUT);  one wave per (m, n)
+__global__ __launch_bounds__(256) void mx_linear_f32_kernel(const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                            float* __restrict__ C, int M, int N, int K, int act) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int m = blockIdx.y;
+  if (n >= N) return;
+  const float* a = A + (int64_t)m * K;
+  const float* w = Wt + (int64_t)n * K;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float v = a[k];
+    if (act == 1) v = v / (1.0f + expf(-v));
+    s += v * w[k];
+  }
+  s = wave_sum(s);
+  if (lane == 0) C[(int64_t)m * N + n] = s + (bias ? bias[n] : 0.f);
+}
+
+// out[tok][j] = bias[j] + sum_c xm[tok][c] * w[j][c]    (xm fp32: the modulated, unrounded head input);  one wave per (tok, 4 outputs)
+__global__ __launch_bounds__(256) void mx_head_gemm_kernel(const float* __restrict__ xm, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int64_t ntok, int d, int nout) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= ntok) return;
+  const float* xr = xm + tok * d;
+  for (int j0 = 0; j0 < nout; j0 += 4) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < d; c += 64) {
+      const float v = xr[c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j0 + j < nout) s[j] += v * w[(int64_t)(j0 + j) * d + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float r = wave_sum(s[j]);
+      if (lane == 0 && j0 + j < nout) out[tok * nout + j0 + j] = r + bias[j0 + j];
+    }
+  }
+}
+
+inline hipStream_t mx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int mx_blocks(int64_t work, int per_block) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b > 65536) b = 65536;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int wan_mx_ln_modulate(const float* x, wan_bf16* out, const wan_bf16* mod, const float* e0, int n_mod, int shift_idx, int scale_idx,
+                                  int64_t rows, int64_t rows_per_batch, int d, float eps, void* stream) {
+  WAN_REQUIRE(x && out && mod && e0, "wan_mx_ln_modulate: null pointer");
+  WAN_REQUIRE(d % 4 == 0 && rows >= 0 && rows_per_batch >= 1 && n_mod >= 1 && shift_idx >= 0 && shift_idx < n_mod && scale_idx >= 0 && scale_idx < n_mod,
+              "wan_mx_ln_modulate: bad arguments (d=%d n_mod=%d shift=%d scale=%d)", d, n_mod, shift_idx, scale_idx);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(mx_ln_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, mx_stream(stream), x, (void*)out, (const void*)mod, e0, n_mod,
+                     shift_idx, scale_idx, rows, rows_per_batch, d, eps);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_mx_ln_affine(const float* x, wan_bf16* out, const float* w, const float* b, int64_t rows, int d, float eps, void* stream) {
+  WAN_REQUIRE(x && out && w && b, "wan_mx_ln_affine: null pointer");
+  WAN_REQUIRE(d % 4 == 0 && rows >= 0, "wan_mx_ln_affine: bad arguments (d=%d)", d);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(mx_ln_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, mx_stream(stream), x, (void*)out, (const void*)w, b, 1, 0, 0, rows,
+                     rows, d, eps);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_mx_gated_residual(float* x, const wan_bf16* y, const wan_bf16* mod, const float* e0, int n_mod, int gate_idx, int64_t rows,
+                                     int64_t rows_per_batch, int d, void* stream) {
+  WAN_REQUIRE(x && y, "wan_mx_gated_residual: null pointer");
+  const bool gated = gate_idx >= 0;
+  WAN_REQUIRE(d % 4 == 0 && rows >= 0 && (!gated || (mod && e0 && gate_idx < n_mod && rows_per_batch >= 1)),
+              "wan_mx_gated_residual: bad arguments (d=%d gate=%d n_mod=%d)", d, gate_idx, n_mod);
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(mx_gated_residual_kernel, dim3(mx_blocks(rows * (int64_t)d / 4, 256)), dim3(256), 0, mx_stream(stream), x, y,
+                     gated ? mod : (const wan_bf16*)nullptr, e0, n_mod, gated ? gate_idx : 0, rows, gated ? rows_per_batch : rows, d);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_mx_patch_embed(const float* x, const float* y, const float* w, const float* bias, float* out, int Cin, int Cy, int F, int H, int W,
+                                  int d, int64_t tok0, int64_t ntok, void* stream) {
+  WAN_REQUIRE(x && w && bias && out && (Cy == 0 || y), "wan_mx_patch_embed: null pointer");
+  WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && tok0 >= 0 && ntok >= 0 && tok0 + ntok <= (int64_t)F * (H / 2) * (W / 2),
+              "wan_mx_patch_embed: H, W must be even and the token range inside the grid");
+  if (ntok == 0) return 0;
+  hipLaunchKernelGGL(mx_patch_embed_kernel, dim3(mx_blocks(ntok * (int64_t)d, 256)), dim3(256), 0, mx_stream(stream), x, y, w, bias, out, Cin, Cy, F, H,
+                     W, d, tok0, ntok);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_mx_sinusoid(float t, float* out, int dim, void* stream) {
+  WAN_REQUIRE(out && dim >= 2 && dim % 2 == 0, "wan_mx_sinusoid: bad arguments");
+  hipLaunchKernelGGL(mx_sinusoid_kernel, dim3((dim / 2 + 255) / 256), dim3(256), 0, mx_stream(stream), t, out, dim);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_mx_linear_f32(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act, void* stream) {
+  WAN_REQUIRE(A && W && C && M >= 1 && M <= 65535 && N >= 1 && K >= 1 && (act == 0 || act == 1), "wan_mx_linear_f32: bad arguments");
+  hipLaunchKernelGGL(mx_linear_f32_kernel, dim3((unsigned)((N + 3) / 4), (unsigned)M), dim3(256), 0, mx_stream(stream), A, W, bias, C, M, N, K, act);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// Head.forward on the fp32 token stream: LayerNorm, modulate with (head.modulation + e) in fp32 (into `tmp`, fp32 [ntok, d]), the fp32 head
+// Linear -> out [ntok, nout] token-major (the caller unpatchifies, or gathers the shards first under sequence parallelism).
+// e: [batches, d] fp32, one row per `e_rows_per_batch` tokens (per-frame timesteps: tokens of a frame).
+extern "C" int wan_mx_head(const float* x, const float* hmod, const float* e, const float* w, const float* bias, float* tmp, float* out, int64_t ntok,
+                           int d, float eps, int64_t e_rows_per_batch, int nout, void* stream) {
+  WAN_REQUIRE(x && hmod && e && w && bias && tmp && out, "wan_mx_head: null pointer");
+  WAN_REQUIRE(d % 4 == 0 && ntok >= 0 && e_rows_per_batch >= 1 && nout >= 1, "wan_mx_head: bad arguments");
+  if (ntok == 0) return 0;
+  hipLaunchKernelGGL(mx_ln_kernel<2>, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, mx_stream(stream), x, (void*)tmp, (const void*)hmod, e, 2, 0, 1,
+                     ntok, e_rows_per_batch, d, eps);
+  hipLaunchKernelGGL(mx_head_gemm_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, mx_stream(stream), (const float*)tmp, w, bias, out, ntok, d, nout);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}

@@ -140,6 +140,13 @@ SIGNATURES = {
     "wan_vae_debug_force_big": (c_int, [c_int]),
     "wan_vae_debug_no_halo": (c_int, [c_int]),
     "wan_attention_debug_no_persist": (c_int, [c_int]),
+    "wan_mx_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int, c_float, c_void_p]),
+    "wan_mx_ln_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "wan_mx_gated_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "wan_mx_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "wan_mx_sinusoid": (c_int, [c_float, c_void_p, c_int, c_void_p]),
+    "wan_mx_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_mx_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int64, c_int, c_void_p]),
     "wan_vae_create": (c_int, [POINTER(c_void_p)]),
     "wan_vae_destroy": (None, [c_void_p]),
     "wan_vae_set_conv": (c_int, [c_void_p, c_char_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int]),

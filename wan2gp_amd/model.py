@@ -20,6 +20,14 @@ from .rope import get_rotary_pos_embed
 
 # checkpoint tensors the reference locks to fp32 (lock_layers_dtypes, model.py:1330-1371)
 FP32_PREFIXES = ("patch_embedding.", "head.")
+# `mixed_precision_transformer` (wgp.py:4039 -> any2video.py:190 -> lock_layers_dtypes(torch.float32), model.py:1338-1346): the time MLP, the
+# time projection and every block's norm3 are kept in fp32 as well; the library then runs its mixed-precision plan (the residual stream, e / e0,
+# every modulate and gated residual in fp32 between bf16 Linears) -- chosen, like in the reference, by the dtype of time_projection.1.weight
+MIXED_FP32_PREFIXES = ("time_embedding.", "time_projection.")
+
+
+def _wants_fp32(key: str, mixed: bool) -> bool:
+    return key.startswith(FP32_PREFIXES) or (mixed and (key.startswith(MIXED_FP32_PREFIXES) or (key.startswith("blocks.") and ".norm3." in key)))
 
 # non-None defaults of the variant keywords of WanModel.forward (model.py:1485-1543); a call that
 # leaves them at these values is the plain t2v / i2v2_2 path
@@ -39,7 +47,7 @@ def _is_default(k, v):
 class WanModelHIP:
     def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
                  freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, eps=1e-6, device="cuda",
-                 vace_layers=None, vace_in_dim=None, **unused):
+                 vace_layers=None, vace_in_dim=None, mixed_precision=False, **unused):
         if tuple(patch_size) != (1, 2, 2):
             raise NotImplementedError("only patch_size (1,2,2) (all Wan 2.1/2.2 14B/1.3B models)")
         if model_type not in ("t2v", "i2v2_2", "ti2v2_2", "i2v"):
@@ -49,6 +57,10 @@ class WanModelHIP:
         self.in_dim, self.out_dim, self.text_dim, self.freq_dim, self.text_len, self.eps = in_dim, out_dim, text_dim, freq_dim, text_len, eps
         self.patch_size = tuple(patch_size)
         self.device = torch.device(device)
+        self.mixed_precision = bool(mixed_precision)
+        if self.mixed_precision and (vace_layers is not None or model_type == "i2v"):
+            raise NotImplementedError("mixed_precision: the fp32-stream plan serves the t2v / i2v2_2 / ti2v2_2 block chain; VACE context blocks "
+                                      "and the Wan2.1 i2v CLIP branch run in the bf16 plan only")
         self.cache = None
         self.reference_module = None      # optional: the reference nn.Module to delegate variant calls to
         self.sp = None                    # optional sequence-parallel group (wan2gp_amd.sp.SequenceParallel)
@@ -105,7 +117,7 @@ class WanModelHIP:
                 continue
             if v.dtype == torch.float8_e5m2:
                 raise NotImplementedError(f"{k}: float8_e5m2 weights (scaled_float8_e5m2) are not implemented; e4m3fn is")
-            want = torch.float32 if k.startswith(FP32_PREFIXES) else torch.bfloat16
+            want = torch.float32 if _wants_fp32(k, self.mixed_precision) else torch.bfloat16
             if k.startswith("vace_patch_embedding."):
                 # a bf16 Conv3d in the reference (lock_layers_dtypes, model.py:1351-1355); the fp32 patch-embed kernel gets
                 # fp32 copies of the bf16 values: identical products, fp32 accumulation, one bf16 rounding of the result
@@ -159,6 +171,8 @@ class WanModelHIP:
         wan_dit_workspace_bytes).  Valid between blocks (inside `callback`) after a torch.cuda.synchronize(): the
         per-layer error-growth tables of tests/test_gpu_baseline_configs.py read it."""
         n = S * L * self.dim
+        if self.mixed_precision:                       # the fp32 residual stream of the mixed-precision plan
+            return self._ws[: n * 4].view(torch.float32).view(S, L, self.dim)
         return self._ws[: n * 2].view(torch.bfloat16).view(S, L, self.dim)
 
     # ---- forward ---------------------------------------------------------------------------------

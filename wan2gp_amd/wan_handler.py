@@ -248,8 +248,6 @@ class family_handler():
         if quantizeTransformer or save_quantized:
             raise NotImplementedError("on-the-fly quantisation is part of the reference's low-VRAM machinery; the HIP backend loads "
                                       "bf16 or scaled-fp8 checkpoints as they are")
-        if mixed_precision_transformer:
-            raise NotImplementedError("mixed-precision (fp32 residual stream) transformer: bf16 only")
         from .checkpoint import read_safetensors, read_wan_file
         from .model import WanModelHIP
         from .pipeline import WanAny2VHIP
@@ -277,7 +275,11 @@ class family_handler():
                         sd.update(extra)
         if not sds:
             raise ValueError("load_model: no checkpoint given")
-        models = [WanModelHIP(device=device, **arch).load_state_dict(sd) for sd in sds[:2]]
+        # mixed_precision_transformer (wgp.py:4039 server setting "mixed_precision" -> any2video.py:190 lock_layers_dtypes(torch.float32)):
+        # the time MLP, the time projection and every norm3 are registered in fp32 and the library runs its fp32-stream plan (csrc/mixed_ops.hip;
+        # tests/test_gpu_mixed.py against the reference's own forward under those locks).  Served for the t2v / i2v2_2 / ti2v2_2 block chain;
+        # WanModelHIP refuses the combination with VACE blocks or the Wan2.1 CLIP branch, the forward refuses step-skipping caches.
+        models = [WanModelHIP(device=device, mixed_precision=bool(mixed_precision_transformer), **arch).load_state_dict(sd) for sd in sds[:2]]
         # any2video.py:137-163: VAE_URLs of the model definition (a path, or a list whose first entry the host's file locator resolves),
         # else the family's default file, resolved by the host application's locator (its checkpoint folders are configurable) or, outside
         # it, under `checkpoint_dir`
