@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the VAE decode / end-to-end block")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
+    ap.add_argument("--mixed-precision", action="store_true", help="the reference's mixed_precision_transformer plan (wgp.py:4039): time MLP, time projection "
+                    "and norm3 in fp32 -> fp32 residual stream and modulation between bf16 Linears (csrc/mixed_ops.hip, DESIGN.md section 3.12); an option of "
+                    "the reference, not the headline configuration")
     ap.add_argument("--no-robustness", action="store_true", help="skip the self-attention launches on gain-12 and adversarial inputs (roofline.robustness)")
     ap.add_argument("--no-configs3", action="store_true", help="skip the BASELINE configs[3] block (14B 720p x 161 frames, L = 147,600: 3 steps + a simulated rank of 8)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (i2v 14B, scaled-fp8 weights, VAE encode + decode)")
@@ -297,6 +300,8 @@ def main():
     two_experts = args.workload in TWO_EXPERT_WORKLOADS
     i2v = cfg.get("in_dim", 16) == 36
     log(f"workload {args.workload}: building random-init weights")
+    if args.mixed_precision:
+        mcfg["mixed_precision"] = True            # load_state_dict registers the locked tensors in fp32: the library picks the plan from them
     model = random_weights(WanModelHIP(**mcfg), cfg, 1234, args.fp8)
     model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321, args.fp8) if two_experts else None
     cfgp, layout_note = None, None
@@ -461,7 +466,8 @@ def main():
             "metric": "denoise-steps/s", "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "world": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere" if args.fp8 else "bf16", "data": "synthetic",
+            "dtype": ("fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere" if args.fp8 else "bf16") +
+                     (" -- mixed_precision_transformer: fp32 residual stream / modulation between the Linears" if args.mixed_precision else ""), "data": "synthetic",
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
                        "solver": "unipc", "parallelism": (("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) + (" (ulysses)" if sp_mode == "ulysses" else "")) if world > 1 else "single",
                        **({"parallelism_note": layout_note} if layout_note else {}),
