@@ -459,7 +459,8 @@ int wan_dit_set_clip(wan_ctx* ctx, const wan_bf16* clip_fea, void* stream);
  * :1914-2064 skip logic; the decisions are host code): should_calc [S] (NULL = all), residual [S] bf16 buffers of
  * tokens_local * dim elements (NULL entries = stream not cached).  A computing stream with a buffer leaves
  * residual = x_after_blocks - x_after_patch_embed there; a skipped stream gets x = patch_embed(x) + residual and goes
- * straight to the head. */
+ * straight to the head.  A context on the mixed-precision plan (fp32 time_projection / norm3 weights registered) keeps its
+ * residual stream in fp32, and so its residual buffers: tokens_local * dim FLOATS behind the same pointers. */
 int wan_dit_forward_skip(wan_ctx* ctx, int S, const float* const* x, float t, const wan_bf16* const* context,
                     const float* y, const float* cos, const float* sin, float* const* outs, int F,
                     int H, int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp,

@@ -3,7 +3,10 @@
 Run in the build container:   python oracle/make_golden_skipcache.py
 Tiny t2v config, bf16 plan, 8 sampler-like steps with drifting latents; three scenarios: MagCache joint pass, MagCache
 two single passes (x_id 0 / 1), TeaCache joint pass.  Recorded per step: should-calc decisions (from the accumulator
-state), outputs, and the chosen thresholds."""
+state), outputs, and the chosen thresholds.
+`python oracle/make_golden_skipcache.py mixed` writes skipcache_tiny_mixed.npz: the same three scenarios with the reference's
+`mixed_precision_transformer` locks (model.py:1330-1371: fp32 time MLP / projection / norm3 -> fp32 residual stream, fp32 `e` for
+TeaCache's distance and fp32 previous_residual)."""
 import os
 import sys
 import types
@@ -50,11 +53,11 @@ def new_cache(kind):
     return c
 
 
-def main():
+def main(mixed=False):
     ns = ref_shim.load()
     cfg = O.make_config("tiny")
-    W = O.synth_weights(cfg, seed=4321)
-    m = build_ref_model(ns, cfg, W, torch.bfloat16)
+    W = O.synth_weights(cfg, seed=4321, dtype=torch.bfloat16, mixed=True) if mixed else O.synth_weights(cfg, seed=4321)
+    m = build_ref_model(ns, cfg, W, torch.bfloat16, mixed=mixed)
     lats, ts, ctx, ctx_null = inputs(cfg)
     freqs = ns.P.get_rotary_pos_embed(lats[0].shape[2:])
     pipe = types.SimpleNamespace(_interrupt=False)
@@ -102,10 +105,11 @@ def main():
         out[f"teaj_{i}_0"], out[f"teaj_{i}_1"] = r[0].float().numpy(), r[1].float().numpy()
     out["teaj_flags"] = np.array(flags); out["teaj_skipped"] = np.array([c.skipped_steps])
     m.cache = None
-    np.savez_compressed(OUT, **out)
-    print("wrote", OUT, "mag thresh", out["mag_thresh"], "joint flags", out["magj_flags"].tolist(), "single", out["mags_flags"].tolist(),
+    dst = OUT.replace(".npz", "_mixed.npz") if mixed else OUT
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, "mag thresh", out["mag_thresh"], "joint flags", out["magj_flags"].tolist(), "single", out["mags_flags"].tolist(),
           "tea thresh", out["tea_thresh"], "tea flags", out["teaj_flags"].tolist())
 
 
 if __name__ == "__main__":
-    main()
+    main(mixed="mixed" in sys.argv[1:])

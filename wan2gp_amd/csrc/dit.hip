@@ -574,9 +574,10 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   // guidance, fp8 Linears); what keeps bf16 state of its own is refused rather than silently run in the other plan
   bool any_residual = false;
   for (int s = 0; residual != nullptr && s < S; ++s) any_residual = any_residual || residual[s] != nullptr;
-  WAN_REQUIRE(!mx || (!any_residual && n_vace == 0 && c->vace_layers.empty() && !c->has_img),
-              "wan_dit_forward: the mixed-precision plan (fp32 time_projection / norm3 weights) does not serve step-skipping caches, VACE "
-              "context blocks or the Wan2.1 i2v CLIP branch");
+  (void)any_residual;   // (round 5: the step-skipping caches run in the mixed plan too -- their residual buffers then hold fp32 rows)
+  WAN_REQUIRE(!mx || (n_vace == 0 && c->vace_layers.empty() && !c->has_img),
+              "wan_dit_forward: the mixed-precision plan (fp32 time_projection / norm3 weights) does not serve VACE context blocks or the "
+              "Wan2.1 i2v CLIP branch");
   float* const x32 = reinterpret_cast<float*>(b.x);
   WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
               (long long)workspace_bytes, (long long)need);
@@ -673,6 +674,19 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   for (int s = 0; s < S; ++s) {
     if (residual == nullptr || residual[s] == nullptr) {
       WAN_REQUIRE(calc(s), "wan_dit_forward: stream %d is skipped but has no residual buffer", s);
+      continue;
+    }
+    if (mx) {
+      // the mixed-precision plan: x is the fp32 stream, so is the reference's previous_residual (torch.sub of two fp32 tensors,
+      // model.py:2044-2062); the caller's buffer holds sn floats.  1 * x + 1 * r is one fma: the fp32 sum, rounded once.
+      float* xs = x32 + s * sn;
+      float* rs = reinterpret_cast<float*>(residual[s]);
+      if (calc(s)) WAN_CHECK_HIP(hipMemcpyAsync(rs, xs, (size_t)sn * 4, hipMemcpyDeviceToDevice, st));
+      else {
+        const float* in2[2] = {xs, rs};
+        const float one2[2] = {1.f, 1.f};
+        RC(wan_lincomb(xs, 2, in2, one2, sn, stream));
+      }
       continue;
     }
     if (calc(s)) WAN_CHECK_HIP(hipMemcpyAsync(residual[s], b.x + s * sn, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
@@ -981,8 +995,16 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     }
   }
   for (int s = 0; s < S; ++s)
-    if (residual != nullptr && residual[s] != nullptr && calc(s))
-      RC(wan_sub_bf16(b.x + s * sn, residual[s], residual[s], sn, stream));  // previous_residual = x - ori (model.py:2044-2062)
+    if (residual != nullptr && residual[s] != nullptr && calc(s)) {
+      if (mx) {
+        float* rs = reinterpret_cast<float*>(residual[s]);
+        const float* in2[2] = {x32 + s * sn, rs};
+        const float pm[2] = {1.f, -1.f};
+        RC(wan_lincomb(rs, 2, in2, pm, sn, stream));                          // fp32 x - ori, one rounding
+      } else {
+        RC(wan_sub_bf16(b.x + s * sn, residual[s], residual[s], sn, stream));  // previous_residual = x - ori (model.py:2044-2062)
+      }
+    }
 
   // ---- head + unpatchify (model.py:2068-2097) -------------------------------------------------------
   for (int s = 0; s < S; ++s) {

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? 3 : 1)) void r
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
-  if (row >= rows) return;
+  if (!PERSIST && row >= rows) return;
   const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
   const float oscale = (blockIdx.y == 0) ? q_scale : 1.0f;  // q only: fp32 scale folded in front of the ONE bf16 rounding
   bf16_t* base = (blockIdx.y == 0 ? q : k);
@@ -68,14 +68,22 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? 3 : 1)) void r
 
   // PERSIST: the norm weights (one 16-byte chunk per lane and chunk index, the same for every row) live in LDS instead of 4 NCH
   // registers the compiler would otherwise keep across the row loop: 194 -> <= 168 VGPRs at d = 5120 = a third wave per SIMD for a
-  // kernel that is bound by the bytes it keeps in flight (round 4; the outputs do not change: same operations on the same values)
+  // kernel that is bound by the bytes it keeps in flight (round 4; the outputs do not change: same operations on the same values).
+  // ALL 256 threads stage the weights and reach the barrier, then a wave without a row leaves: the last block of a grid with
+  // rows % 4 != 0 (k == nullptr and rows below the resident set, e.g. a 2,025-token single-frame run) has waves past the end whose
+  // share of wlds the live waves read (round 4 returned before the staging: the advisor's finding; tests/test_gpu_ops.py
+  // test_rmsnorm_rope_persist_ragged_rows)
   __shared__ uint4 wlds[PERSIST ? NCH * 64 : 1];
   if (PERSIST) {
     for (int c = threadIdx.x; c < nchunk; c += 256) wlds[c] = *reinterpret_cast<const uint4*>(w + c * 8);
   }
   uint4 raw[NCH], nxt[NCH];
-  load_row<NCH, FULL>(raw, base + row * (int64_t)d, lane, nchunk);
-  if (PERSIST) __syncthreads();   // (every wave of the block reaches this: a block whose first row is past the end does not exist in the persistent grid)
+  const bool alive = !PERSIST || row < rows;   // wave-uniform
+  if (alive) load_row<NCH, FULL>(raw, base + row * (int64_t)d, lane, nchunk);
+  if (PERSIST) {
+    __syncthreads();
+    if (!alive) return;
+  }
   for (;;) {
     const int64_t nrow = row + stride;
     const bool more = PERSIST && nrow < rows;  // wave-uniform

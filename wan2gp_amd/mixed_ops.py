@@ -1,7 +1,8 @@
 """Op-level wrappers of the mixed-precision transformer plan's kernels (csrc/mixed_ops.hip, include/wanhip.h `wan_mx_*`):
 `mixed_precision_transformer` of the reference (wgp.py:4039 -> any2video.py:190 -> model.py:1330-1371) keeps the residual stream, e / e0
-and every modulate / gated residual in fp32 between bf16 Linears.  Used by the -m gpu parity tests; the forward driver
-(wan_dit_forward with wan_dit_set_mixed) calls the same C entries."""
+and every modulate / gated residual in fp32 between bf16 Linears.  Used by the -m gpu parity tests and by WanModelHIP.time_embedding (TeaCache's fp32 `e`); the forward
+driver (wan_dit_forward, which switches to this plan when the registered time_projection / norm3 weights are fp32: csrc/dit.hip
+`ctx_is_mixed`) calls the same C entries."""
 import torch
 
 from . import lib as _L

@@ -137,6 +137,10 @@ class WanModelHIP:
         kernels wan_dit_forward runs."""
         from . import ops
         w = self._weights
+        if self.mixed_precision:      # the fp32 lock covers the time MLP (model.py:1338-1346): fp32 e, as the reference's TeaCache sees it
+            from . import mixed_ops as mx
+            h = mx.linear_f32(mx.sinusoid(float(tval), self.freq_dim, device=self.device), w["time_embedding.0.weight"], w["time_embedding.0.bias"])
+            return mx.linear_f32(h, w["time_embedding.2.weight"], w["time_embedding.2.bias"], silu_input=True)
         s = ops.sinusoid(torch.tensor([float(tval)], dtype=torch.float32, device=self.device), self.freq_dim)
         h = ops.silu(ops.gemv(s, w["time_embedding.0.weight"], w["time_embedding.0.bias"]))
         return ops.gemv(h, w["time_embedding.2.weight"], w["time_embedding.2.bias"])
@@ -298,15 +302,16 @@ class WanModelHIP:
                 cache.previous_residual = [None] * S
             slots = list(range(S)) if S > 1 else [x_id]
             n_res = (L // shards) * self.dim
+            rdt = torch.float32 if self.mixed_precision else torch.bfloat16     # the residual has the stream's dtype (model.py:2044-2062)
             bufs = []
             for sl, calc in zip(slots, flags):
                 while len(cache.previous_residual) <= sl:
                     cache.previous_residual.append(None)
                 r = cache.previous_residual[sl]
-                if r is None or r.numel() != n_res or not r.is_cuda:
+                if r is None or r.numel() != n_res or not r.is_cuda or r.dtype != rdt:
                     if not calc:
                         raise _L.WanHipError(f"step-skipping cache: stream {sl} is skipped at step {real_step_no} without a stored residual")
-                    r = cache.previous_residual[sl] = torch.empty(n_res, dtype=torch.bfloat16, device=dev)
+                    r = cache.previous_residual[sl] = torch.empty(n_res, dtype=rdt, device=dev)
                 bufs.append(r)
             FL = (ctypes.c_int * S)(*[1 if f else 0 for f in flags])
             RP = (c_void_p * S)(*[r.data_ptr() for r in bufs])
