@@ -50,6 +50,9 @@ WORKLOADS = {
                      "VAE encode of the conditioning video + decode in the e2e figure"),
     "1.3B-480p": (dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30), (21, 60, 104),
                   "Wan2.1 t2v 1.3B 480x832x81f (L=32760), CFG joint pass, UniPC"),
+    # BASELINE configs[0] (defaults/t2v_1.3B.json at 320 x 512 x 17 frames: the CPU-runnable case the cpu_baseline leg is quoted on)
+    "1.3B-320x512x17f": (dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30), (5, 40, 64),
+                         "Wan2.1 t2v 1.3B 320x512x17f (L=3200), CFG joint pass, UniPC"),
     "tiny": (dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2), (3, 16, 16), "plumbing check"),
 }
 TWO_EXPERT_WORKLOADS = ("14B-720p", "14B-720p-161f", "i2v-14B-720p")
@@ -244,6 +247,13 @@ def main():
     ap.add_argument("--simulate-world", default="2,4,8", help="comma-separated world sizes (e.g. 2,4,8): after the timed region, run ONE "
                     "rank's shard of a sequence-parallel world of that size on this GPU, the K / V^T all-gathers replaced by "
                     "device-to-device copies of the bytes that rank would receive -> compute-side upper bound of the scaling curve; '' = skip")
+    ap.add_argument("--simulate-link-GBs", type=float, default=50.0,
+                    help="the link model of the simulated-ranks block: every exchange a simulated rank issues is followed, on its side stream, by "
+                         "a delay of (bytes from ONE peer) / this rate -- xGMI is a full mesh of point-to-point links, every peer's share moves over "
+                         "a link of its own (MI355X: 7 x ~77 GB/s per direction; 50 = a conservative achieved RCCL rate).  Every row then also "
+                         "carries the link-modelled step time / efficiency and the exposed exchange time per block; 0 = compute side only")
+    ap.add_argument("--sp-chunks", type=int, default=0, help="N > 1, Ulysses exchange: head chunks of the q / o all-to-alls (wan_sp_info.a2a_chunks); "
+                    "0 = the library default (2 when a rank holds >= 4 heads)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -307,7 +317,8 @@ def main():
     cfgp, layout_note = None, None
     if world > 1:
         cfgp, cfg_sp, sp_degree, layout_note = setup_parallel(rank, world, cfg_sp, L, (model, model2), args.parallelism in ("cfg-sp", "cfg-ulysses"),
-                                                              sp_mode=sp_mode, sp_mode_demanded=args.parallelism in ("ulysses", "cfg-ulysses"))
+                                                              sp_mode=sp_mode, sp_mode_demanded=args.parallelism in ("ulysses", "cfg-ulysses"),
+                                                              chunks=args.sp_chunks or None)
         eff = cfgp.sp if cfgp is not None else model.sp        # the exchange the run ended up with (the self-test may have fallen back)
         sp_mode = eff.mode if eff is not None else "allgather"
 
@@ -339,15 +350,17 @@ def main():
     y, enc_s = None, None
     if i2v:
         # any2video.py:739-774: start image + zero frames -> VAE encode -> y = cat(mask[4], latents[16]); every rank encodes
-        te = time.perf_counter()
         img = torch.rand(3, 1, h * 8, w * 8, device="cuda", generator=g) * 2 - 1
         clip = torch.cat([img, torch.zeros(3, (f - 1) * 4, h * 8, w * 8, device="cuda")], dim=1)
+        vae.encode([clip])                                   # (first call: allocator warm-up, not the encode -- see config5_block)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
         lat_y = vae.encode([clip])[0]
+        torch.cuda.synchronize()
+        enc_s = time.perf_counter() - te
         msk = torch.zeros(4, f, h, w, device="cuda"); msk[:, 0] = 1
         y = torch.cat([msk, lat_y])
         del clip
-        torch.cuda.synchronize()
-        enc_s = time.perf_counter() - te
     latents = torch.randn(1, 16, f, h, w, device="cuda", generator=g)
 
     par = {"cfgp": cfgp}           # (the simulated-ranks block swaps a stand-in in)
@@ -376,7 +389,9 @@ def main():
     for i in range(args.warmup):
         lat = one_step(i, lat)
     sync()
-    lib.wan_prof_enable(1)
+    replayed = world == 1 and 2 * L <= model.graph_max_tokens and model.graph != "off"
+    if not replayed:                  # (the event brackets around single launches keep a forward on the eager path: launch-bound shapes go without)
+        lib.wan_prof_enable(1)
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         lat = one_step(i, lat)
@@ -419,7 +434,9 @@ def main():
         d, ffn = cfg["dim"], cfg["ffn_dim"]
         Ll = L // sp_degree
         ms, n = prof["self_attn"]
-        attn_flops = 4.0 * Ll * L * d * S                      # algorithmic FLOP of one launch (S streams)
+        eff_sp = (cfgp.sp if cfgp is not None else model.sp) if world > 1 else None
+        attn_chunks = eff_sp.resolved_chunks(cfg["num_heads"]) if eff_sp is not None else 1     # Ulysses: C launches per block, each 1 / C of the heads
+        attn_flops = 4.0 * Ll * L * d * S / attn_chunks        # algorithmic FLOP of one launch (S streams; a head chunk's share)
         achieved = attn_flops / (ms / n * 1e-3) / 1e12 if n else 0.0
         kern = {}
         if prof["ffn_gemm_pair"][1]:
@@ -469,7 +486,7 @@ def main():
             "dtype": ("fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere" if args.fp8 else "bf16") +
                      (" -- mixed_precision_transformer: fp32 residual stream / modulation between the Linears" if args.mixed_precision else ""), "data": "synthetic",
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
-                       "solver": "unipc", "parallelism": (("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) + (" (ulysses)" if sp_mode == "ulysses" else "")) if world > 1 else "single",
+                       "solver": "unipc", "parallelism": (("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) + ((" (ulysses, q / o in %d head chunks)" % attn_chunks if attn_chunks > 1 else " (ulysses)") if sp_mode == "ulysses" else "")) if world > 1 else "single",
                        **({"parallelism_note": layout_note} if layout_note else {}),
                        "forward_TFLOP": forward_flops(cfg, L) / 1e12},
             "roofline": {"kernel": "attn_w16n_kernel (self-attention: the bounded loop on the 16x16x32 MFMA)", "bound": "mfma", "achieved": achieved,
@@ -486,6 +503,10 @@ def main():
             "step_TFLOPs": 2 * forward_flops(cfg, L) / (dt / args.steps) / 1e12,
             "forwards_per_s": 2 * args.steps / dt,          # a CFG step is two forwards (SURVEY.md section 8d reports both)
         }
+        if replayed:
+            out["forwards"] = {"mode": "replayed launch lists (wan_dit_forward_graph)" if model.last_graph_how == 3 else "eager",
+                               "last_forward_how": int(model.last_graph_how),
+                               "note": "launch-bound shape: no per-launch event brackets (they would keep the forward eager), roofline.achieved is not measured here"}
         lib.wan_prof_enable(0)
         if e2e is not None:
             out["e2e"] = e2e
@@ -505,10 +526,10 @@ def main():
             log("simulated sequence-parallel ranks: " + args.simulate_world)
             out["simulated_scaling"] = _extra_block(simulate_world, [int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
                                                     latents, new_sched, dt / args.steps, cfg, L, par, args.simulate_layout, None,
-                                                    1 if args.simulate_layout == "all" else 2, budget_s=args.extras_budget_s)
+                                                    1 if args.simulate_layout == "all" else 2, args.simulate_link_GBs, budget_s=args.extras_budget_s)
         if world == 1 and not args.no_configs3 and args.workload == "14B-720p":
             log("configs3: 14B 720p x 161 frames (L = 147,600), 1 warm-up + 2 timed steps, simulated rank of a world of 8")
-            out["configs3"] = _extra_block(configs3_block, model, model2, one_step, new_sched, par, lib, budget_s=args.extras_budget_s)
+            out["configs3"] = _extra_block(configs3_block, model, model2, one_step, new_sched, par, lib, args.simulate_link_GBs, budget_s=args.extras_budget_s)
         if world == 1 and not args.no_config5 and args.workload == "14B-720p" and not args.fp8:
             log("config5: i2v 14B, scaled-fp8 weights, VAE encode + 3 steps + decode")
             model = model2 = None                       # the bf16 experts of the main workload are done
@@ -520,10 +541,25 @@ def main():
             # LAST and alone: nothing runs on the GPU beside it (round 3 ran it next to the config-5 block: its 128 host threads cost
             # launch-dense GPU blocks 5-8 %, and the GPU's launching thread cost the CPU leg cores)
             log("cpu_baseline: thread sweep, then the config-1 oracle step + VAE decode on the host cores")
+            same = None
+            if args.workload in TWO_EXPERT_WORKLOADS:
+                log("configs[0] on the GPU (the configuration the CPU leg is quoted on): generate() 10 steps + decode, replayed and eager forwards")
+                model = model2 = None
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                same = _extra_block(configs0_gpu, vae, budget_s=args.extras_budget_s + 120)
             try:
                 out["cpu_baseline"] = cpu_baseline(2 * forward_flops(cfg, L))
             except Exception as ex:                      # noqa: BLE001 -- reported in place, never costs the line
                 out["cpu_baseline"] = {"error": repr(ex)}
+            if same is not None:
+                out["cpu_baseline"]["gpu_same_config"] = same
+                if isinstance(same, dict) and "step_s" in same and "step_s" in out["cpu_baseline"]:
+                    out["cpu_baseline"]["gpu_same_config_step_s"] = same["step_s"]
+                    out["cpu_baseline"]["gpu_same_config_e2e_s"] = same["e2e_s"]
+                    out["cpu_baseline"]["gpu_over_cpu_same_config"] = {"step": out["cpu_baseline"]["step_s"] / same["step_s"],
+                                                                       "e2e_composed_cpu_over_measured_gpu": out["cpu_baseline"]["e2e_s_per_video_composed"] / same["e2e_s"]}
         log("done")
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -591,7 +627,7 @@ def collect_prof(lib):
     return prof
 
 
-def configs3_block(model, model2, one_step, new_sched, par, lib):
+def configs3_block(model, model2, one_step, new_sched, par, lib, link_GBs=50.0):
     """BASELINE configs[3] on one GPU: Wan2.2 t2v 14B, 720 x 1280 x 161 frames -> 41 latent frames (any2video.py:647,1166),
     L = 147,600 tokens, on the resident experts of the main workload.  1 warm-up + 2 timed CFG steps with a scheduler of their own;
     self-attention's roofline at this L from HIP events like the headline's; then rank 0 of a world of 8 (both layouts) on this GPU
@@ -624,11 +660,12 @@ def configs3_block(model, model2, one_step, new_sched, par, lib):
            "roofline": {"kernel": "self-attention", "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_BF16_TFLOPS, "launches": n, "avg_ms": ms / n if n else None, "flop_per_launch": attn_flops}}
     del lat
-    out["simulated_scaling"] = simulate_world([8], model, model2, one_step, latents, new_sched, step_s, cfg, L, par, "all", fr=freqs, k=1)
+    # (the two layouts a world of 8 would choose between: the halves' exchange as all-gathers or as chunked all-to-alls)
+    out["simulated_scaling"] = simulate_world([8], model, model2, one_step, latents, new_sched, step_s, cfg, L, par, "cfg-both", fr=freqs, k=1, link_GBs=link_GBs)
     return out
 
 
-def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device="cuda", sp_mode="allgather", sp_mode_demanded=False):
+def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device="cuda", sp_mode="allgather", sp_mode_demanded=False, chunks=None):
     """The multi-GPU layout of this run on the resident experts -> (CfgParallel | None, cfg_sp, sp_degree, note).
 
     cfg-sp (the default for an even world) is tried first: groups, then a self-test of the 2-rank swap on a tiny tensor.  A rank
@@ -644,7 +681,7 @@ def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device
     if cfg_sp:
         cfgp, err = None, ""
         try:
-            cfgp = CfgParallel(rank, world, mode=sp_mode)
+            cfgp = CfgParallel(rank, world, mode=sp_mode, chunks=chunks)
             mine = torch.full((8,), float(cfgp.stream), device=device)
             a, b = cfgp.exchange(mine)
             if not (bool((a == 0).all()) and bool((b == 1).all())):
@@ -663,7 +700,7 @@ def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device
         if cfg_sp_demanded or L % world:
             sys.exit("bench.py: " + note + (" refused: --parallelism cfg-sp was asked for" if cfg_sp_demanded else
                                             " impossible: %d tokens do not shard over %d ranks" % (L, world)))
-    sp = SequenceParallel(rank, world, mode=sp_mode)
+    sp = SequenceParallel(rank, world, mode=sp_mode, chunks=chunks)
     note = _ulysses_self_test(sp, device, sp_mode_demanded, note)
     for m in models:
         if m is not None:
@@ -743,16 +780,23 @@ def config5_block(vae):
     freqs = get_rotary_pos_embed((f, h, w), device="cuda")
     sched = HipScheduler("unipc", num_train_timesteps=1000)
     sched.set_timesteps(VIDEO_STEPS, device="cuda", shift=12.0)
-    torch.cuda.synchronize()
-    te = time.perf_counter()
+    # the conditioning clip is BUILT first, then the encode is timed alone -- twice: the first call after the empty_cache() in front of this
+    # block pays the first-touch allocation of its ~10 GB of activations (round 4's driver line: 4.01 s against 0.45 s in every builder
+    # run, where something had warmed the allocator), the second is the encode (what a server pays per video)
     img = torch.rand(3, 1, h * 8, w * 8, device="cuda", generator=g) * 2 - 1
     clip = torch.cat([img, torch.zeros(3, (f - 1) * 4, h * 8, w * 8, device="cuda")], dim=1)
+    torch.cuda.synchronize()
+    te = time.perf_counter()
     lat_y = vae.encode([clip])[0]
+    torch.cuda.synchronize()
+    enc_first_s = time.perf_counter() - te
+    te = time.perf_counter()
+    lat_y = vae.encode([clip])[0]
+    torch.cuda.synchronize()
+    enc_s = time.perf_counter() - te
     msk = torch.zeros(4, f, h, w, device="cuda"); msk[:, 0] = 1
     y = torch.cat([msk, lat_y])
     del clip
-    torch.cuda.synchronize()
-    enc_s = time.perf_counter() - te
     lat = torch.randn(1, 16, f, h, w, device="cuda", generator=g)
 
     def step(i, lat):
@@ -777,16 +821,33 @@ def config5_block(vae):
     L = f * (h // 2) * (w // 2)
     return {"workload": desc, "dtype": "fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere",
             "metric": "denoise-steps/s", "value": 1.0 / step_s, "ms_per_step": step_s * 1e3, "steps": k, "warmup": 1,
-            "step_TFLOPs": 2 * forward_flops(cfg, L) / step_s / 1e12, "vae_encode_s": enc_s, "vae_decode_to_host_s": dec_s,
+            "step_TFLOPs": 2 * forward_flops(cfg, L) / step_s / 1e12, "vae_encode_s": enc_s, "vae_encode_first_call_s": enc_first_s,
+            "vae_encode_note": "the encode of the 81-frame conditioning clip alone (inputs built before the clock starts), second call; "
+                               "first_call includes the allocator's first touch of the encoder's activations after empty_cache()",
+            "vae_decode_to_host_s": dec_s,
             "composed_s_at_%d_steps" % VIDEO_STEPS: VIDEO_STEPS * step_s + enc_s + dec_s}
 
 
-def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1gpu, cfg, L, par=None, layout="sp", fr=None, k=2):
+def _link_delay(nbytes, link_GBs):
+    """The link model's transfer time on the CURRENT stream: nbytes / (link_GBs GB/s), spent by one spinning lane (wan_debug_delay)."""
+    from wan2gp_amd import lib as L_
+    L_.check(L_.load().wan_debug_delay(nbytes / (link_GBs * 1e3), L_.stream_ptr()), "wan_debug_delay")     # bytes / (GB/s) -> microseconds
+
+
+def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1gpu, cfg, L, par=None, layout="sp", fr=None, k=2, link_GBs=50.0):
     """ONE rank (rank 0) of a sequence-parallel world of N on this GPU: its token shard (L / N query rows against N gathered K / V^T
-    segments, every token-local kernel at M = S L / N rows), the all-gathers replaced by device-to-device copies of what the rank
-    would receive, on a side stream like the RCCL path.  What it measures is the COMPUTE side of the scaling curve (tile
-    quantisation at L / N rows, GEMM and attention efficiency at the shard's shapes, the local / remote attention split); the
-    xGMI time of the real gathers is not in it (bytes per block and rank are reported beside it).  efficiency = t(1) / (N t(N))."""
+    segments, every token-local kernel at M = S L / N rows), the exchanges replaced by device-to-device copies of what the rank
+    would receive, on a side stream like the RCCL path.  `rank_step_ms` / `compute_side_efficiency` are the COMPUTE side of the
+    scaling curve (tile quantisation at L / N rows, GEMM and attention efficiency at the shard's shapes, the local / remote attention
+    split).  The LINK MODEL (round 5, --simulate-link-GBs R > 0) puts the transfer time behind every copy: on the side stream, a delay
+    of (bytes one peer sends this rank) / R -- xGMI is a full mesh of point-to-point links, every peer's share moves over its own link
+    concurrently -- so an exchange that the schedule does not hide stalls the compute stream exactly as it would on the node;
+    `rank_step_ms_link`, `link_modelled_efficiency`, `exposed_ms_per_block` = (t_link - t_compute) / layers.  Ulysses rows run the
+    exchange in head chunks (the library default) AND as one exchange per tensor (`one_exchange`), both with the model on: what the
+    chunking buys.  Efficiency = t(1) / (N t(N)).  The outputs of a simulated rank are not a forward's (the copies deliver the rank's
+    own data); what IS checked: finite, and the chunked and one-exchange runs of a row are bit-identical (same inputs, same fake
+    exchange -- the property tests/test_gpu_sp.py holds on real exchanges).  Parity of these layouts at this size:
+    tests/test_gpu_baseline_configs.py::test_ulysses_world_rank_dryruns_at_baseline_size, tests/test_gpu_sp.py::test_ulysses_ranks_at_baseline_size_*."""
     import torch
     from wan2gp_amd.sp import SequenceParallel
 
@@ -795,6 +856,21 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
             super().__init__(0, world, mode=mode)
             self.side = torch.cuda.Stream()
             self.bytes = 0
+            self.link_GBs = 0.0          # 0: copies only
+
+        def _transfer(self, copy, per_peer_bytes, key):
+            """The stand-in of one exchange on the side stream, ordered behind the compute stream: the copy, then the link time."""
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                copy()
+                if self.link_GBs > 0:
+                    _link_delay(per_peer_bytes, self.link_GBs)
+                done = torch.cuda.Event()
+                done.record(self.side)
+            self._pending[key] = done
+            self.bytes += per_peer_bytes * (self.world - 1)
 
         def _a2a_begin_cb(self, user, which, send, recv, nbytes, stream):
             """Ulysses: what the all-to-all leaves in recv = `world` chunks of nbytes (here: this rank's own chunks, copied)."""
@@ -802,15 +878,7 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
                 base = self._ws.data_ptr()
                 sv = self._ws[send - base:send - base + nbytes * self.world]
                 rv = self._ws[recv - base:recv - base + nbytes * self.world]
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                with torch.cuda.stream(self.side):
-                    self.side.wait_event(ev)
-                    rv.copy_(sv)
-                    done = torch.cuda.Event()
-                    done.record(self.side)
-                self._pending[("a2a", which)] = done
-                self.bytes += nbytes * (self.world - 1)
+                self._transfer(lambda: rv.copy_(sv), nbytes, ("a2a", which))
                 return 0
             except Exception:
                 import traceback
@@ -828,15 +896,7 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
                 base = self._ws.data_ptr()
                 sv = self._ws[send - base:send - base + nbytes]
                 rv = self._ws[recv - base:recv - base + nbytes * self.world].view(self.world, nbytes)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                with torch.cuda.stream(self.side):
-                    self.side.wait_event(ev)
-                    rv.copy_(sv.unsqueeze(0).expand(self.world, nbytes))     # world x nbytes written: what the gather leaves in recv
-                    done = torch.cuda.Event()
-                    done.record(self.side)
-                self._pending[which] = done
-                self.bytes += nbytes * (self.world - 1)
+                self._transfer(lambda: rv.copy_(sv.unsqueeze(0).expand(self.world, nbytes)), nbytes, which)   # world x nbytes written: what the gather leaves in recv
                 return 0
             except Exception:
                 import traceback
@@ -854,18 +914,23 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
 
     class SimulatedCfgRank:
         """Rank 0 of a cfg2 x sp(N/2) world: the conditional stream alone through the model (S = 1, the half's simulated sequence-parallel
-        group on it), the partner's prediction = a device-to-device copy of this rank's (the bytes the 2-rank swap delivers)."""
+        group on it), the partner's prediction = a device-to-device copy of this rank's (the bytes the 2-rank swap delivers; with the
+        link model on, the swap's transfer time on the compute stream -- nothing runs beside it)."""
 
         def __init__(self, sp):
-            self.sp, self.stream = sp, 0
+            self.sp, self.stream, self.link_GBs = sp, 0, 0.0
 
         def guided_pair(self, model_, lat, context, context_null, **kw):
             r = model_(x=[lat], context=[context], x_id=0, **kw)[0]
-            return r, r.clone()
+            other = r.clone()
+            if self.link_GBs > 0:
+                _link_delay(r.numel() * r.element_size(), self.link_GBs)
+            return r, other
 
     rows = []
-    lays = {"both": ("sp", "cfg-sp"), "all": ("sp", "cfg-sp", "ulysses", "cfg-ulysses")}.get(layout, (layout,))
+    lays = {"both": ("sp", "cfg-sp"), "all": ("sp", "cfg-sp", "ulysses", "cfg-ulysses"), "cfg-both": ("cfg-sp", "cfg-ulysses")}.get(layout, (layout,))
     plans = [(n, lay) for n in worlds for lay in lays]
+    layers = cfg["num_layers"]
     for n, lay in plans:
         cfg_half = lay.startswith("cfg-")                      # the two CFG streams on the two halves of the world
         uly = lay.endswith("ulysses")                          # the per-block exchange: four all-to-alls instead of two all-gathers
@@ -883,41 +948,121 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
         if uly and deg == 1:
             continue                                           # cfg2 x sp1: no exchange inside a half -- the cfg-sp row already is this layout
         sp = SimulatedRank(deg, "ulysses" if uly else "allgather") if deg > 1 else None
+        cfgr = SimulatedCfgRank(sp) if cfg_half else None
         try:
             if cfg_half and par is not None:
-                par["cfgp"] = SimulatedCfgRank(sp)
+                par["cfgp"] = cfgr
             model.sp = sp
             if model2 is not None:
                 model2.sp = sp
-            sc = new_sched()                                                  # its own: never the timed region's (steps past its end)
-            lat = latents
-            lat = one_step(0, lat, sc, fr)                                    # warm-up: workspace of this sharding
-            torch.cuda.synchronize()
-            if sp is not None:
-                sp.bytes = 0
-            t0 = time.perf_counter()
-            for i in range(k):
-                lat = one_step(1 + i, lat, sc, fr)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / k
-            assert torch.isfinite(lat).all()
-            layers = cfg["num_layers"]
-            rows.append({"world": n, "layout": name,
-                         "rank_step_ms": dt * 1e3, "compute_side_efficiency": step_s_1gpu / (n * dt),
-                         # all-gather form: K + V^T of the other ranks of the group; Ulysses: the (deg - 1) / deg of q, k, v^T, o this rank
-                         # sends away (= receives) -- per block, for the streams this rank runs
-                         "gathered_bytes_per_block_and_rank": (sp.bytes / (k * layers)) if sp is not None else 0.0,
-                         "exchange": "all-to-all x 4 (q, k, v^T, o)" if uly else ("all-gather x 2 (K, V^T)" if sp is not None else "none"),
-                         "tokens_per_rank": L // deg, "streams_per_rank": 1 if cfg_half else 2})
+            one_step(0, latents, new_sched(), fr)                             # warm-up: workspace of this sharding (a scheduler of its own:
+            torch.cuda.synchronize()                                          # never the timed region's, which may be at its last timestep)
+
+            def timed(link, chunks):
+                """k steps on a fresh scheduler from the SAME latents (a run's result can be compared with another's) -> (s / step, latents)"""
+                if sp is not None:
+                    sp.link_GBs, sp.chunks, sp.bytes = link, chunks, 0
+                if cfgr is not None:
+                    cfgr.link_GBs = link
+                sck = new_sched()
+                lat = latents
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(k):
+                    lat = one_step(i, lat, sck, fr)
+                torch.cuda.synchronize()
+                dt_ = (time.perf_counter() - t0) / k
+                assert torch.isfinite(lat).all()
+                return dt_, lat
+
+            C = sp.resolved_chunks(cfg.get("num_heads")) if sp is not None else 1
+            dt, lat_c = timed(0.0, None)
+            row = {"world": n, "layout": name,
+                   "rank_step_ms": dt * 1e3, "compute_side_efficiency": step_s_1gpu / (n * dt),
+                   # all-gather form: K + V^T of the other ranks of the group; Ulysses: the (deg - 1) / deg of q, k, v^T, o this rank
+                   # sends away (= receives) -- per block, for the streams this rank runs
+                   "gathered_bytes_per_block_and_rank": (sp.bytes / (k * layers)) if sp is not None else 0.0,
+                   "exchange": ("all-to-all: k, v^T whole, q / o in %d head chunks" % C if C > 1 else "all-to-all x 4 (q, k, v^T, o)") if uly
+                               else ("all-gather x 2 (K, V^T)" if sp is not None else "none"),
+                   "tokens_per_rank": L // deg, "streams_per_rank": 1 if cfg_half else 2}
+            if link_GBs > 0:
+                dl, _ = timed(link_GBs, None)
+                row.update({"rank_step_ms_link": dl * 1e3, "link_modelled_efficiency": step_s_1gpu / (n * dl),
+                            "exposed_ms_per_block": (dl - dt) * 1e3 / layers})
+                if uly and C > 1:
+                    d1, lat_1 = timed(0.0, 1)
+                    d1l, _ = timed(link_GBs, 1)
+                    same = bool(torch.equal(lat_1, lat_c))
+                    row["one_exchange"] = {"rank_step_ms": d1 * 1e3, "compute_side_efficiency": step_s_1gpu / (n * d1), "rank_step_ms_link": d1l * 1e3,
+                                           "link_modelled_efficiency": step_s_1gpu / (n * d1l), "exposed_ms_per_block": (d1l - d1) * 1e3 / layers,
+                                           "latents_bit_identical_to_chunked": same}
+                    row["chunking_gain_points"] = 100.0 * (row["link_modelled_efficiency"] - row["one_exchange"]["link_modelled_efficiency"])
+                    assert same, "the chunked and the one-exchange Ulysses runs of the simulated rank differ"
+            rows.append(row)
         finally:                                                              # whatever happened: the models leave as they came
             model.sp = None
             if model2 is not None:
                 model2.sp = None
             if par is not None:
                 par["cfgp"] = None
-    return {"note": "one rank's shard on one GPU, all-gathers / all-to-alls = device-to-device copies (compute-side upper bound; no xGMI time); "
-                    "timed steps per row: %d" % k,
+    return {"note": "one rank's shard on one GPU, all-gathers / all-to-alls = device-to-device copies on a side stream; rank_step_ms / "
+                    "compute_side_efficiency: copies only (compute-side upper bound); *_link: every copy followed by (bytes from one peer) / "
+                    "link rate on the side stream (the link model); timed steps per figure: %d" % k,
+            "link_model_GBs_per_peer": link_GBs,
             "one_gpu_step_ms": step_s_1gpu * 1e3, "ranks": rows}
+
+
+def configs0_gpu(vae):
+    """BASELINE configs[0] on the GPU -- Wan2.1 t2v 1.3B, 320 x 512 x 17 frames (L = 3,200), 10 UniPC steps, shift 5, guidance 5
+    (defaults/t2v_1.3B.json): the SAME configuration the cpu_baseline leg times on the host cores, through WanAny2VHIP.generate():
+    noise -> 10 CFG steps -> VAE decode -> uint8 frames on the host.  At this size a step is ~900 launches of microseconds each; the
+    forwards are replayed launch lists (wan_dit_forward_graph, WanModelHIP.graph = "auto" engages below 16,384 tokens per joint pass)
+    and the same video is timed once more with the eager forwards beside it; both produce the same frames (asserted)."""
+    import torch
+    from wan2gp_amd.model import WanModelHIP
+    from wan2gp_amd.pipeline import WanAny2VHIP
+    cfg, (f, h, w), desc = WORKLOADS["1.3B-320x512x17f"]
+    m = random_weights(WanModelHIP(**cfg), cfg, 99)
+    if vae is None:
+        from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
+        vae = WanVAEHIP(state_dict=random_vae_state_dict())
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ctx = (torch.randn(1, 512, 4096, device="cuda", generator=g) * 0.5).to(torch.bfloat16); ctx[:, 77:] = 0
+    ctx_null = torch.zeros_like(ctx)
+    pipe = WanAny2VHIP(m, vae=vae, device="cuda")
+    kw = dict(context=ctx, context_null=ctx_null, width=w * 8, height=h * 8, frame_num=(f - 1) * 4 + 1, shift=5.0,
+              sample_solver="unipc", guide_scale=5.0, seed=3, sampling_steps=10)
+    res = {}
+    frames = {}
+    for mode in ("auto", "off"):
+        m.graph = mode
+        pipe.generate(**kw)                                                    # warm-up: workspace, VAE buffers, (auto) the captures
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = pipe.generate(**kw)
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0
+            best = dt_ if best is None else min(best, dt_)
+        assert out["x"].dtype == torch.uint8 and tuple(out["x"].shape) == (3, (f - 1) * 4 + 1, h * 8, w * 8)
+        lat = pipe.generate(return_latents=True, **kw)["latents"]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vae.decode_to_cpu_uint8([lat[0] if lat.dim() == 5 else lat], 0)
+        torch.cuda.synchronize()
+        dec = time.perf_counter() - t0
+        frames[mode] = out["x"]
+        res[mode] = {"e2e_s": best, "vae_decode_to_host_s": dec, "step_s": (best - dec) / 10.0, "last_forward": int(m.last_graph_how)}
+    L = f * (h // 2) * (w // 2)
+    a, e = res["auto"], res["off"]
+    return {"workload": desc + " -- BASELINE configs[0], 10 steps, shift 5, guidance 5", "e2e_s": a["e2e_s"], "step_s": a["step_s"],
+            "vae_decode_to_host_s": a["vae_decode_to_host_s"], "forwards": "replayed launch lists (hipGraph)" if a["last_forward"] == 3 else
+            "eager (capture refused: last_forward = %d)" % a["last_forward"],
+            "eager_forwards": {"e2e_s": e["e2e_s"], "step_s": e["step_s"]}, "replay_over_eager_step": e["step_s"] / a["step_s"],
+            "frames_identical_to_eager": bool(torch.equal(frames["auto"], frames["off"])),
+            "step_TFLOPs": 2 * forward_flops(cfg, L) / a["step_s"] / 1e12,
+            "note": "best of 3 full generate() calls (noise -> 10 CFG steps -> VAE decode -> uint8 on the host); step_s = (e2e - decode) / 10"}
 
 
 def secondary_1p3b(vae):

@@ -283,6 +283,11 @@ int wan_dequant_i8(const int8_t* data, const float* scale, wan_bf16* out, int64_
 /* Block transpose (the Ulysses re-packs, wan_dit_forward with WAN_SP_ULYSSES): src [A][B][bytes] -> dst [B][A][bytes], bytes a
  * multiple of 16, src != dst.  One pass at the copy rate. */
 int wan_permute16(const void* src, void* dst, int64_t A, int64_t B, int64_t bytes, void* stream);
+/* The same with explicit pitches (bytes, multiples of 16): dst[b * dst_b_pitch + a * dst_a_pitch + i] = src[a * src_a_pitch +
+ * b * src_b_pitch + i] for a < A, b < B, i < bytes -- the per-head-chunk re-packs of the chunked Ulysses exchange (a column range
+ * of [rows][d] rows into a [world][rows][Wc] block of its own, and back). */
+int wan_permute16_ex(const void* src, void* dst, int64_t A, int64_t B, int64_t bytes, int64_t src_a_pitch, int64_t src_b_pitch,
+                     int64_t dst_a_pitch, int64_t dst_b_pitch, void* stream);
 int wan_lincomb(float* out, int n_in, const float* const* in, const float* coef, int64_t n,
                 void* stream);
 
@@ -347,8 +352,13 @@ typedef int (*wan_gather_wait_fn)(void* user, int which, void* stream);
  * (2.71 GB); the k and v exchanges hide under the V and Q projections, the q and o exchanges do not.
  *   a2a_begin(user, which, send, recv, bytes_per_peer, stream): send = world chunks of bytes_per_peer, chunk j for rank j; recv
  *       = world chunks, chunk i from rank i; which 0 = k, 1 = v^T, 2 = q, 3 = o.  Same ordering contract as gather_begin.
- *   a2a_wait(user, which, stream). */
+ *   a2a_wait(user, which, stream).
+ * Round 5: a2a_chunks = C > 1 splits the rank's H / world heads into C chunks (heads [c Hn / C, (c + 1) Hn / C)): k and v^T still
+ * travel whole (laid out per chunk), q and o travel PER CHUNK -- which 2 + c = q chunk c, 2 + C + c = o chunk c -- and chunk c's
+ * attention launch runs while q chunk c + 1 arrives and o chunk c - 1 returns: only the first q chunk and the last o chunk are
+ * exposed.  Results are bit-identical to C = 1.  C is clamped to [1, min(H / world, WAN_SP_MAX_CHUNKS)]. */
 enum { WAN_SP_ALLGATHER = 0, WAN_SP_ULYSSES = 1 };
+enum { WAN_SP_MAX_CHUNKS = 8 };
 typedef struct {
   int rank, world;          /* this rank, number of sequence shards */
   int64_t tok0, tok_local;  /* first global token and number of local tokens */
@@ -358,6 +368,7 @@ typedef struct {
   int mode;                 /* WAN_SP_ALLGATHER (gather_* are used) or WAN_SP_ULYSSES (a2a_* are used) */
   wan_gather_begin_fn a2a_begin;
   wan_gather_wait_fn a2a_wait;
+  int a2a_chunks;           /* WAN_SP_ULYSSES: head chunks of the q / o exchanges (0 or 1: one exchange each, the round-4 form) */
 } wan_sp_info;
 
 /* A library-owned RCCL communicator for those hooks (SURVEY.md section 8b `wan_sp_init(rank, nranks, ncclUniqueId)`): one
@@ -374,7 +385,7 @@ void wan_sp_destroy(wan_sp* sp);
 int wan_sp_gather_begin(void* sp, int which, const void* send, void* recv, int64_t bytes, void* stream);
 int wan_sp_gather_wait(void* sp, int which, void* stream);
 /* the all-to-all pair of WAN_SP_ULYSSES on the same communicator and side stream (grouped ncclSend / ncclRecv: `bytes` to and from
- * every peer; the rank's own chunk is a device-to-device copy); which = 0..3; wait with wan_sp_gather_wait */
+ * every peer; the rank's own chunk is a device-to-device copy); which = 0 .. 1 + 2 WAN_SP_MAX_CHUNKS; wait with wan_sp_gather_wait */
 int wan_sp_a2a_begin(void* sp, int which, const void* send, void* recv, int64_t bytes, void* stream);
 int wan_sp_all_gather(wan_sp* sp, const void* send, void* recv, int64_t bytes, void* stream);
 
@@ -434,6 +445,15 @@ typedef struct {
   int x_id;
 } wan_dit_args;
 int wan_dit_forward_ex(wan_ctx* ctx, const wan_dit_args* args, void* stream);
+/* The same forward as a REPLAYED launch list: a call is keyed by everything its launches depend on except
+ * the timestep (shapes, every pointer of args, guidance parameters); a key's first call runs eagerly, its second is captured into a
+ * hipGraph, every later one is ONE hipGraphLaunch -- for small token counts, where enqueueing ~900 launches from the host takes longer
+ * than running them (BASELINE configs[0]).  The caller keeps the pointers stable (staging buffers for the latents and outputs); the
+ * timestep is read from device memory.  Same kernels, arguments and order as wan_dit_forward_ex: bit-identical outputs.  Calls that
+ * cannot be replayed (sequence parallelism, per-frame timesteps, step-skipping caches, the mixed-precision plan, profiling on) fall
+ * through to the eager forward.  poll is called once, in front of the launch.  *how (optional): 0 eager (not eligible), 1 eager
+ * (first sight of the key), 2 captured + launched, 3 replayed.  Registering a weight drops the context's captured lists. */
+int wan_dit_forward_graph(wan_ctx* ctx, const wan_dit_args* args, void* stream, int* how);
 /* How many VACE contexts one forward may mix (default 1): sizes the hint-stream region of the workspace
  * (wan_dit_workspace_bytes grows by 2 x S x L x dim x 2 bytes per extra context). */
 int wan_dit_set_vace_contexts(wan_ctx* ctx, int n);
@@ -604,6 +624,9 @@ int wan_prof_attention_declined(int64_t* declined, int64_t* total);
  * of the launch; the caller times it (events on `stream`).  On MI355X the answer is the power limit, not the 2.5 PFLOP/s of the
  * data sheet: 1.7-1.8 PFLOP/s on random data (csrc/probe.hip). */
 int wan_mfma_sustained_probe(int iters, double* flop_out, void* stream);
+/* Measurement aid: occupies `stream` for `microseconds` (one lane spinning on the constant 100 MHz clock) and nothing else of the
+ * chip -- bench.py's link model puts an exchange's xGMI transfer time behind the device-to-device copy that stands in for it. */
+int wan_debug_delay(double microseconds, void* stream);
 int wan_attention_count_declined(const float* scratch, int B, int Bk, int64_t Lq, int H, uint64_t* acc, void* stream);
 
 #ifdef __cplusplus

@@ -54,6 +54,24 @@ hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "mock"; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+// stream capture / graphs (wan_dit_forward_graph): the "graph" is the span of recorded calls between begin and end; launching it
+// records one call that names the span
+static int g_capture_from = -1;
+struct MockGraph { int from, to; };
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)(uintptr_t)0xCA97; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) { rec("begin_capture", {(void*)s}, {}); g_capture_from = (int)g_calls.size(); return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
+  MockGraph* m = new MockGraph{g_capture_from, (int)g_calls.size()};
+  *g = (hipGraph_t)m;
+  rec("end_capture", {(void*)s}, {m->from, m->to});
+  return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) { *e = (hipGraphExec_t)g; return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t s) { MockGraph* m = (MockGraph*)e; rec("graph_launch", {(void*)s}, {m->from, m->to}); return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { delete (MockGraph*)g; return hipSuccess; }
 }
 
 // ---- the library's op-level entries (prototypes from wanhip.h) -------------------------------------------------------------
@@ -105,12 +123,18 @@ int wan_attention_sp_remote(const wan_bf16* q, const wan_bf16* k, const wan_bf16
   return rec("attention_sp_remote", {q, k, vt, o, scratch, raw}, {B, Lq, Lk, ldv, H, nseg, ks, vs, own});
 }
 int wan_permute16(const void* src, void* dst, int64_t A, int64_t B, int64_t bytes, void*) { return rec("permute16", {src, dst}, {A, B, bytes}); }
+int wan_permute16_ex(const void* src, void* dst, int64_t A, int64_t B, int64_t bytes, int64_t sa, int64_t sb, int64_t da, int64_t db, void*) {
+  return rec("permute16_ex", {src, dst}, {A, B, bytes, sa, sb, da, db});
+}
 int wan_act_bf16(const wan_bf16* x, wan_bf16* y, int64_t n, int act, void*) { return rec("act", {x, y}, {n, act}); }
 int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wan_bf16* C, int M, int N, int K, void*) {
   return rec("gemv", {A, W, bias, C}, {M, N, K});
 }
 int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void*) { return rec("add", {a, b, out}, {n}); }
 int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void*) { return rec("sub", {a, b, out}, {n}); }
+int wan_lincomb(float* out, int n_in, const float* const* in, const float* coef, int64_t n, void*) {
+  return rec("lincomb", {out, in[0], n_in > 1 ? in[1] : nullptr}, {n, n_in}, {coef[0], n_in > 1 ? coef[1] : 0.0});
+}
 int wan_axpy_bf16(const wan_bf16* x, const wan_bf16* y, float alpha, wan_bf16* out, int64_t n, void*) { return rec("axpy", {x, y, out}, {n}, {alpha}); }
 // the mixed-precision plan's kernels (csrc/mixed_ops.hip)
 int wan_mx_ln_modulate(const float* x, wan_bf16* out, const wan_bf16* mod, const float* e0, int n_mod, int shift_idx, int scale_idx, int64_t rows,
@@ -148,3 +172,5 @@ int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const fl
   return rec("head", {x, hmod, e, w, bias, tmp, out}, {B, F, Hg, Wg, d, tok0, ntok, token_major, e_rpb, nout});
 }
 int wan_sinusoid_val(float t, bf16_t* out, int dim, void*) { return rec("sinusoid", {out}, {dim}, {t}); }
+int wan_set_f32(float* p, float v, void* stream) { return rec("set_f32", {p, stream}, {}, {v}); }
+extern "C" int wan_sinusoid(const float* t, wan_bf16* out, int n, int dim, void*) { return rec("sinusoid_dev", {t, out}, {n, dim}); }

@@ -36,7 +36,7 @@ def test_ctypes_binding_covers_header(built):
     for s in header_symbols():
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
         assert hasattr(L, s)
-    assert L.wan_version() == 6          # 6: wan_sp_info.mode / a2a_begin / a2a_wait (Ulysses), wan_sp_a2a_begin, wan_permute16; 2: wan_dit_args.t_frames, wan_attention_bounded, wan_gemm_fp8; 3: wan_dit_args grew (n_vace ...), wan_sched_* / wan_vae_* / wan_sp_*; 4: wan_dit_args.nag_* / context_batches, wan_nag_combine; 5: wan_dit_args.perturbation_layers / x_id
+    assert L.wan_version() == 7          # 7: wan_sp_info.a2a_chunks (chunked Ulysses q / o exchanges), wan_permute16_ex, wan_debug_delay; 6: wan_sp_info.mode / a2a_begin / a2a_wait (Ulysses), wan_sp_a2a_begin, wan_permute16; 2: wan_dit_args.t_frames, wan_attention_bounded, wan_gemm_fp8; 3: wan_dit_args grew (n_vace ...), wan_sched_* / wan_vae_* / wan_sp_*; 4: wan_dit_args.nag_* / context_batches, wan_nag_combine; 5: wan_dit_args.perturbation_layers / x_id
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -160,11 +160,18 @@ def test_simulated_cfg_sp_rank_runs_one_stream_and_leaves_the_models_as_they_cam
         c, u = par["cfgp"].guided_pair(m, lat, "ctx", "null")
         assert c is not u and torch.equal(c, u)
         return lat
-    r = bench.simulate_world([2, 3], m, None, one_step, torch.zeros(2), lambda: None, 8.0, {"num_layers": 40}, 75600, par, "cfg-sp")
+    r = bench.simulate_world([2, 3], m, None, one_step, torch.zeros(2), lambda: None, 8.0, {"num_layers": 40}, 75600, par, "cfg-sp", link_GBs=0.0)
     rows = r["ranks"]
     assert rows[0]["layout"] == "cfg2 x sp1" and rows[0]["streams_per_rank"] == 1 and rows[0]["tokens_per_rank"] == 75600
-    assert rows[0]["gathered_bytes_per_block_and_rank"] == 0.0 and "skipped" in rows[1]
+    assert rows[0]["gathered_bytes_per_block_and_rank"] == 0.0 and "skipped" in rows[1] and "rank_step_ms_link" not in rows[0]
     assert calls == [(1, 0)] * 3 and par["cfgp"] is None and m.sp is None
+    # the link model (round 5): the same steps once more with the swap's transfer time behind the copy (19 MB-sized in the bench; here 8 bytes)
+    delays = []
+    monkeypatch.setattr(bench, "_link_delay", lambda nbytes, rate: delays.append((nbytes, rate)))
+    r = bench.simulate_world([2], m, None, one_step, torch.zeros(2), lambda: None, 8.0, {"num_layers": 40}, 75600, par, "cfg-sp", link_GBs=50.0)
+    row = r["ranks"][0]
+    assert r["link_model_GBs_per_peer"] == 50.0 and {"rank_step_ms_link", "link_modelled_efficiency", "exposed_ms_per_block"} <= set(row)
+    assert delays == [(8, 50.0)] * 2 and len(calls) == 3 + 5                 # warm-up + 2 compute-only steps + 2 link-modelled steps
 
 
 class _StrictScheduler:
@@ -211,19 +218,19 @@ def test_blocks_behind_the_timed_region_do_not_depend_on_the_timesteps_it_consum
     lat = torch.zeros(2)
     for i in range(25):                                   # --warmup 5 --steps 20
         lat = one_step(i, lat)
-    r = bench.simulate_world([2, 4, 8], m, m2, one_step, lat, _StrictScheduler, 8.5, {"num_layers": 40}, 75600, par, "both")
+    r = bench.simulate_world([2, 4, 8], m, m2, one_step, lat, _StrictScheduler, 8.5, {"num_layers": 40}, 75600, par, "both", link_GBs=0.0)
     rows = r["ranks"]
     assert [(x["world"], x["layout"]) for x in rows] == [(2, "sp2"), (2, "cfg2 x sp1"), (4, "sp4"), (4, "cfg2 x sp2"), (8, "sp8"), (8, "cfg2 x sp4")]
     assert all("rank_step_ms" in x and "error" not in x and "skipped" not in x for x in rows)
     assert [x["tokens_per_rank"] for x in rows] == [37800, 75600, 18900, 37800, 9450, 18900]
-    assert _StrictScheduler.made == 1 + 6 and main_sched.used == 25
+    assert _StrictScheduler.made == 1 + 2 * 6 and main_sched.used == 25          # per plan: the warm-up's scheduler and the timed run's
     assert m.sp is None and m2.sp is None and par["cfgp"] is None
     # the simulated steps saw their own scheduler, the shard's world and (cfg-sp) the stand-in for the 2-rank swap
     sim = seen[25:]
     assert len(sim) == 18 and not any(s[0] for s in sim)
     assert [s[1] for s in sim[::3]] == [2, 1, 4, 2, 8, 4] and [s[2] for s in sim[::3]] == [False, True] * 3
     # BASELINE configs[3] (161 frames, L = 147,600): the same block at that L with its own rope tables handed through
-    r3 = bench.simulate_world([8], m, m2, one_step, lat, _StrictScheduler, 28.0, {"num_layers": 40}, 147600, par, "both", fr="freqs161")
+    r3 = bench.simulate_world([8], m, m2, one_step, lat, _StrictScheduler, 28.0, {"num_layers": 40}, 147600, par, "both", fr="freqs161", link_GBs=0.0)
     assert [x["tokens_per_rank"] for x in r3["ranks"]] == [18450, 36900] and all(s[3] == "freqs161" for s in seen[43:])
     # all four layouts (the default of the bench line): the Ulysses rows carry the all-to-all exchange, heads must divide by the degree,
     # cfg2 x sp1 has no exchange and therefore no Ulysses twin
@@ -232,10 +239,22 @@ def test_blocks_behind_the_timed_region_do_not_depend_on_the_timesteps_it_consum
     def one_step2(i, lat, sc=None, fr=None):
         modes.append((m.sp.mode, m.sp.world) if m.sp is not None else None)
         return sc.step(None, sc.timesteps[i], lat)[0]
-    r4 = bench.simulate_world([2, 8], m, m2, one_step2, lat, _StrictScheduler, 8.5, {"num_layers": 40, "num_heads": 40}, 75600, par, "all", None, 1)
+    r4 = bench.simulate_world([2, 8], m, m2, one_step2, lat, _StrictScheduler, 8.5, {"num_layers": 40, "num_heads": 40}, 75600, par, "all", None, 1, 0.0)
     assert [x["layout"] for x in r4["ranks"]] == ["sp2", "cfg2 x sp1", "sp2 (ulysses)", "sp8", "cfg2 x sp4", "sp8 (ulysses)", "cfg2 x sp4 (ulysses)"]
-    assert [x["exchange"].split(" ")[0] for x in r4["ranks"]] == ["all-gather", "none", "all-to-all", "all-gather", "all-gather", "all-to-all", "all-to-all"]
+    assert [x["exchange"].split(" ")[0].rstrip(":") for x in r4["ranks"]] == ["all-gather", "none", "all-to-all", "all-gather", "all-gather", "all-to-all", "all-to-all"]
+    assert all("2 head chunks" in x["exchange"] for x in r4["ranks"] if "ulysses" in x["layout"])     # 20 / 5 / 10 heads per rank: the library default
     assert modes[::2] == [("allgather", 2), None, ("ulysses", 2), ("allgather", 8), ("allgather", 4), ("ulysses", 8), ("ulysses", 4)]
+    # the link model on: a Ulysses row runs chunked AND as one exchange per tensor, both with and without the model, and the two must agree bit for bit
+    modes.clear()
+    chunk_seen = []
+
+    def one_step3(i, lat, sc=None, fr=None):
+        chunk_seen.append((m.sp.link_GBs, m.sp.resolved_chunks(40)))
+        return sc.step(None, sc.timesteps[i], lat)[0]
+    r6 = bench.simulate_world([8], m, m2, one_step3, lat, _StrictScheduler, 8.5, {"num_layers": 40, "num_heads": 40}, 75600, par, "cfg-ulysses", None, 1, 50.0)
+    row = r6["ranks"][0]
+    assert chunk_seen == [(0.0, 2), (0.0, 2), (50.0, 2), (0.0, 1), (50.0, 1)]                            # warm-up, then the four figures
+    assert row["one_exchange"]["latents_bit_identical_to_chunked"] is True and "chunking_gain_points" in row and "exposed_ms_per_block" in row
     r5 = bench.simulate_world([8], m, m2, one_step2, lat, _StrictScheduler, 0.4, {"num_layers": 30, "num_heads": 12}, 32760, par, "ulysses")
     assert "12 heads do not divide by 8" in r5["ranks"][0]["skipped"]
 

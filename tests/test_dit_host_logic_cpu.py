@@ -16,7 +16,7 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_uint64, c_void
 import pytest
 
 from oracle import wan_oracle as O
-from wan2gp_amd.lib import DitArgs, DitConfig, GATHER_FN, GATHER_WAIT_FN, POLL_FN, SpInfo
+from wan2gp_amd.lib import DitArgs, DitConfig, GATHER_FN, GATHER_WAIT_FN, POLL_FN, SpInfo, WAN_ABORTED
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -46,6 +46,7 @@ def mock(tmp_path_factory):
     L.wan_dit_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int]
     L.wan_dit_set_weight.argtypes = [c_void_p, c_char_p, c_void_p, c_int, c_int64]
     L.wan_dit_forward_ex.argtypes = [c_void_p, POINTER(DitArgs), c_void_p]
+    L.wan_dit_forward_graph.argtypes = [c_void_p, POINTER(DitArgs), c_void_p, POINTER(c_int)]
     return L
 
 
@@ -74,24 +75,29 @@ class Model:
             assert L.wan_dit_set_weight(self.ctx, k.encode(), c_void_p(a), dt, numel) == 0, L.wan_last_error()
 
     def forward(self, S=2, fhw=(2, 8, 8), should_calc=None, residual=None, nag=None, ctx_batches=None, sp=None, t_frames=None, poll=None,
-                perturb=None, x_id=0):
+                perturb=None, x_id=0, graph=False, t=637.0, x0=0x6000_0000_0000, stream=None):
         L, (F, H, W) = self.L, fhw
         shards = 1 if sp is None else sp.world
         nbytes = L.wan_dit_workspace_bytes(self.ctx, S, F, H, W, shards)
         assert nbytes > 0
-        X = (c_void_p * S)(*[0x6000_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
+        X = (c_void_p * S)(*[x0 + s * 0x1_0000_0000 for s in range(S)])
         C = (c_void_p * S)(*[0x6100_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
         OUT = (c_void_p * S)(*[0x6200_0000_0000 + s * 0x1_0000_0000 for s in range(S)])
         FL = None if should_calc is None else (c_int * S)(*should_calc)
         RP = None if residual is None else (c_void_p * S)(*residual)
         TF = None if t_frames is None else (ctypes.c_float * F)(*t_frames)
-        a = DitArgs(S, X, 637.0, C, None, 0x6300_0000_0000, 0x6310_0000_0000, OUT, F, H, W, WS, nbytes,
+        a = DitArgs(S, X, t, C, None, 0x6300_0000_0000, 0x6310_0000_0000, OUT, F, H, W, WS, nbytes,
                     None if sp is None else ctypes.cast(ctypes.byref(sp), c_void_p), None if poll is None else ctypes.cast(poll, c_void_p), None, FL, RP,
                     None, 1.0, TF, F if t_frames is not None else 0, 0, None, None,
                     *((0.0, 0.0, 0.0, None) if nag is None else (*nag, (c_int * S)(*ctx_batches))),
                     None if not perturb else (c_int * len(perturb))(*perturb), len(perturb or ()), x_id)
         L.mock_reset()
-        rc = L.wan_dit_forward_ex(self.ctx, ctypes.byref(a), None)
+        if graph:
+            how = c_int(-1)
+            rc = L.wan_dit_forward_graph(self.ctx, ctypes.byref(a), stream, ctypes.byref(how))
+            self.how = how.value
+        else:
+            rc = L.wan_dit_forward_ex(self.ctx, ctypes.byref(a), stream)
         calls = [L.mock_get(i).contents for i in range(L.mock_count())]
         return rc, [(c.name.decode(), list(c.p), list(c.i), list(c.f)) for c in calls], nbytes
 
@@ -253,9 +259,22 @@ def test_mixed_precision_plan_launch_order_pointers_and_refusals(mock):
     assert "unpatchify" not in names and names[-1] == "mx_head" and calls[-1][1][6] == 0x6200_0000_0000
     pe = [cl for cl in calls if cl[0] == "mx_patch_embed"][0]
     assert pe[2][6:8] == [Ll // 2, Ll // 2]                                  # this rank's token range
-    # a step-skipping residual buffer: refused (the caches keep bf16 state), with a message that says so
-    rc, _, _ = m.forward(S=2, should_calc=[1, 1], residual=[0x6400_0000_0000, 0x6410_0000_0000])
-    assert rc != 0 and b"mixed-precision" in mock.wan_last_error()
+    # step-skipping caches in the mixed plan (round 5): the residual buffers hold FP32 rows like the stream (model.py:2044-2062 subtracts
+    # two fp32 tensors) -- parked with an fp32-sized copy, re-applied / formed by fp32 linear combinations, never the bf16 add / sub
+    res = [0x6400_0000_0000, 0x6410_0000_0000]
+    sn = Ll * c.dim
+    rc, calls, _ = m.forward(S=2, should_calc=[1, 0], residual=res)
+    assert rc == 0, mock.wan_last_error()
+    names = [cl[0] for cl in calls]
+    assert "add" not in names and "sub" not in names
+    park = [cl for cl in calls if cl[0] == "memcpy" and cl[1][0] == res[0]]
+    assert len(park) == 1 and park[0][1][1] == x32 and park[0][2][0] == sn * 4                 # computing stream: x_before parked as fp32
+    lc = [cl for cl in calls if cl[0] == "lincomb"]
+    assert len(lc) == 2 and all(cl[2][:2] == [sn, 2] for cl in lc)
+    x1 = x32 + sn * 4
+    assert lc[0][1] [:3] == [x1, x1, res[1]] and lc[0][3][:2] == [1.0, 1.0]                     # skipped stream: x += stored residual
+    assert lc[1][1][:3] == [res[0], x32, res[0]] and lc[1][3][:2] == [1.0, -1.0]               # computing stream: residual = x - x_before
+    assert names.index("lincomb") < names.index("mx_ln_modulate") < len(names) - 1 - names[::-1].index("lincomb")
     # an inconsistent registration (fp32 projection, bf16 norm3) is an error, not a silent mix of plans
     bad = Model(mock, mixed=True)
     assert mock.wan_dit_set_weight(bad.ctx, b"blocks.0.norm3.weight", c_void_p(bad.addr["blocks.0.norm3.weight"]), 0, c.dim) == 0
@@ -446,6 +465,94 @@ def test_ulysses_call_order_layouts_and_buffer_lifetimes(mock, S):
     fail = GATHER_FN(lambda user, which, *a: 1 if which == 2 else 0)
     rc, calls, _ = m.forward(S=S, sp=SpInfo(1, world, Ll, Ll, never, GATHER_WAIT_FN(lambda *a: 1), None, SP_ULYSSES, fail, cw))
     assert rc == 3 and b"all-to-all 2" in mock.wan_last_error() and "attention" not in [cl[0] for cl in calls if cl[0] == "attention" and cl[2][6] == world]
+
+
+@pytest.mark.parametrize("S,world,chunks", [(2, 2, 2), (1, 2, 2), (2, 1, 3)], ids=["S2_heads_1+1", "S1_heads_1+1", "S2_one_rank_group_is_plain"])
+def test_ulysses_chunked_exchange_order_offsets_and_overlap(mock, S, world, chunks):
+    """wan_sp_info.a2a_chunks = C > 1 (round 5): k and v^T travel whole but are packed per head chunk, q and o travel per chunk; chunk c's
+    attention launch sits between the wait for ITS q chunk and the begin of ITS o chunk, i.e. with q chunk c + 1 and o chunk c - 1 in
+    flight; the launches see the round-4 layout with H = the chunk's heads at the chunk's offsets; every o chunk is waited for and
+    re-packed before the output projection.  A group of one rank ignores the mode altogether."""
+    from wan2gp_amd.lib import SP_ULYSSES
+    m = Model(mock, name="small")                                            # 4 heads
+    c, (F, H, W) = m.cfg, (2, 8, 8)
+    L_ = F * 16
+    Ll, d, nh = L_ // world, c.dim, c.num_heads
+    Hn, Wd, Lp, rows = nh // world, nh // world * 128, (Ll + 63) // 64 * 64, S * Ll
+    events = []
+
+    def begin(user, which, send, recv, nbytes, stream):
+        events.append(("begin", which, send, recv, nbytes, mock.mock_count()))
+        return 0
+
+    def wait(user, which, stream):
+        events.append(("wait", which, mock.mock_count()))
+        return 0
+    cb, cw = GATHER_FN(begin), GATHER_WAIT_FN(wait)
+    sp = SpInfo(world - 1, world, (world - 1) * Ll, Ll, cb, cw, None, SP_ULYSSES, cb, cw, chunks)
+    rc, calls, nbytes = m.forward(S=S, sp=sp)
+    assert rc == 0, mock.wan_last_error()
+    if world == 1:
+        assert not events and "permute16_ex" not in [cl[0] for cl in calls]
+        return
+    C = min(chunks, Hn)
+    h0 = [cch * Hn // C for cch in range(C + 1)]
+    per_layer = 2 * (2 + 2 * C)
+    assert len(events) == per_layer * c.num_layers
+    for layer in range(c.num_layers):
+        ev = events[per_layer * layer:per_layer * (layer + 1)]
+        want = [("begin", 0), ("begin", 1)] + [("begin", 2 + k) for k in range(C)] + [("wait", 0), ("wait", 1)]
+        for k in range(C):
+            want += [("wait", 2 + k), ("begin", 2 + C + k)]
+        want += [("wait", 2 + C + k) for k in range(C)]
+        assert [(e[0], e[1]) for e in ev] == want
+        bk, bv = ev[0], ev[1]
+        bq = ev[2:2 + C]
+        assert bk[4] == rows * Wd * 2 and bv[4] == S * Wd * Lp * 2
+        packs_k = calls[bk[5] - C:bk[5]]
+        assert [cl[0] for cl in packs_k] == ["permute16_ex"] * C and calls[bk[5] - C - 1][0] == "rmsnorm_rope"
+        att_i = [i for i in range(bk[5], len(calls)) if calls[i][0] == "attention"][:C]
+        for k in range(C):
+            Hc = h0[k + 1] - h0[k]
+            Wc, o0 = Hc * 128, h0[k] * 128
+            # k chunk: columns [o0, o0 + Wc) of every rank's head group of [rows][d] -> [world][chunk][rows][Wc] inside the k send buffer
+            pk = packs_k[k]
+            assert pk[2][:7] == [rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wd * 2] and pk[1][1] == bk[2] + o0 * rows * 2
+            # q chunk: packed, then sent at once -- [chunk][world][rows][Wc]; bytes per peer = the chunk's share
+            assert bq[k][4] == rows * Wc * 2 and bq[k][2] - bq[0][2] == o0 * rows * world * 2 == bq[k][3] - bq[0][3]
+            pq = calls[bq[k][5] - 1]
+            assert pq[0] == "permute16_ex" and pq[2][:7] == [rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2] and pq[1][1] == bq[k][2]
+            wq = [e for e in ev if e[:2] == ("wait", 2 + k)][0]
+            bo = [e for e in ev if e[:2] == ("begin", 2 + C + k)][0]
+            att = calls[att_i[k]]
+            assert wq[2] <= att_i[k] < bo[5]                                                        # launch k between ITS q wait and ITS o begin
+            assert att[2][:10] == [world * S, S, Ll, Ll, Lp, Hc, world, rows * Wd, S * Wd * Lp, 1]
+            assert att[1][0] == bq[k][3] and att[1][1] == bk[3] + o0 * rows * 2 and att[1][2] == bv[3] + o0 * Lp * S * 2
+            assert att[1][3] == bo[2] == bk[2] + o0 * rows * world * 2 and bo[3] == bq[k][2] and bo[4] == rows * Wc * 2
+            if k + 1 < C:                                                                           # overlap: the next q chunk is not waited for yet,
+                nxt = [e for e in ev if e[:2] == ("wait", 2 + k + 1)][0]
+                assert nxt[2] > att_i[k]
+                assert bo[5] <= att_i[k + 1]                                                        # ... and this o chunk is on its way during the next launch
+        if S > 1:
+            packs_v = calls[bv[5] - C:bv[5]]
+            for k, pv in enumerate(packs_v):
+                Wc, o0 = (h0[k + 1] - h0[k]) * 128, h0[k] * 128
+                assert pv[0] == "permute16_ex" and pv[2][:7] == [S, world, Wc * Lp * 2, d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2, S * Wd * Lp * 2]
+                assert pv[1][1] == bv[2] + o0 * Lp * S * 2
+        else:
+            assert calls[bv[5] - 1][0] == "gemm" and calls[bv[5] - 1][1][3] == bv[2]              # S = 1: the epilogue's image already has the layout
+        last_wait = [e for e in ev if e[:2] == ("wait", 2 + 2 * C - 1)][0]
+        back = calls[last_wait[2]]
+        proj = calls[last_wait[2] + 1]
+        assert back[0] == "permute16_ex" and proj[0] == "gemm" and proj[2][5] == 2
+        ups = [cl for cl in calls[[e for e in ev if e[:2] == ("wait", 2 + C)][0][2]:last_wait[2] + 1] if cl[0] == "permute16_ex"]
+        assert len(ups) == C and all(u[1][1] - ups[0][1][1] == h0[k] * 256 for k, u in enumerate(ups)) and ups[0][1][1] == proj[1][0]
+        for k, u in enumerate(ups):
+            Wc = (h0[k + 1] - h0[k]) * 128
+            assert u[2][:7] == [world, rows, Wc * 2, rows * Wc * 2, Wc * 2, Wd * 2, d * 2] and u[1][0] == bq[k][2]
+        for e in ev:
+            if e[0] == "begin":
+                assert in_ws(e[2], nbytes) and in_ws(e[3] + e[4] * world - 1, nbytes)
 
 
 def test_sequence_parallel_failing_gather_hook_stops_the_forward_with_an_error(mock):
@@ -688,3 +795,61 @@ def test_flf2v_clip_context_of_two_images(mock):
     assert rc == 0
     assert not [c for c in fw1 if c[0] == "memcpy" and c[2][0] == 257 * d * 2]
     assert {c[2][3] for c in fw1 if c[0] == "attention"} == {16 * 2, 512, 257} or {c[2][3] for c in fw1 if c[0] == "attention"} >= {512, 257}
+
+
+def test_forward_as_a_replayed_launch_list(mock):
+    """wan_dit_forward_graph: a key's first call runs eagerly (timestep read from device memory), the second is captured on the
+    context's own stream -- the SAME launch list as the eager forward, launch for launch -- and launched once on the caller's stream,
+    every later call is one graph launch behind the one-float timestep kernel; other pointers = another key; calls that cannot be
+    replayed fall through to the eager path; the poll hook is called once in front; registering a weight drops the captured lists."""
+    m = Model(mock)
+    c = m.cfg
+    USER = 0x7777
+    rc, eager, _ = m.forward(S=2)
+    assert rc == 0
+    def strip(calls):       # the launch list without what differs by construction: the timestep's source
+        return [(n, p, i) for n, p, i, f in calls if n not in ("sinusoid", "sinusoid_dev", "set_f32")]
+    # first sight: eager, t through device memory
+    rc, c1, _ = m.forward(S=2, graph=True, t=900.0, stream=USER)
+    assert rc == 0 and m.how == 1, mock.wan_last_error()
+    assert c1[0][0] == "set_f32" and c1[0][3][0] == 900.0 and c1[0][1][1] == USER
+    sd = [cl for cl in c1 if cl[0] == "sinusoid_dev"]
+    assert len(sd) == 1 and sd[0][1][0] == c1[0][1][0] and not [cl for cl in c1 if cl[0] == "sinusoid"]
+    assert strip(c1[1:]) == strip(eager)
+    # second sight: captured (on a stream of the context's own) and launched on the caller's
+    rc, c2, _ = m.forward(S=2, graph=True, t=800.0, stream=USER)
+    assert rc == 0 and m.how == 2
+    names = [cl[0] for cl in c2]
+    assert names[0] == "set_f32" and names[1] == "begin_capture" and names[-2] == "end_capture" and names[-1] == "graph_launch"
+    assert c2[1][1][0] != USER and c2[-1][1][0] == USER
+    assert strip(c2[2:-2]) == strip(eager)                                         # what was captured = the eager launch list
+    span = c2[-1][2][:2]
+    # from then on: the timestep kernel + ONE launch
+    for t in (700.0, 10.0):
+        rc, c3, _ = m.forward(S=2, graph=True, t=t, stream=USER)
+        assert rc == 0 and m.how == 3 and [cl[0] for cl in c3] == ["set_f32", "graph_launch"] and c3[0][3][0] == t
+    # other latents' addresses: another key -> eager again, then its own capture; the first key still replays
+    rc, c4, _ = m.forward(S=2, graph=True, x0=0x6800_0000_0000, stream=USER)
+    assert rc == 0 and m.how == 1
+    rc, _, _ = m.forward(S=2, graph=True, stream=USER)
+    assert rc == 0 and m.how == 3
+    rc, _, _ = m.forward(S=1, graph=True, stream=USER)
+    assert rc == 0 and m.how == 1                                                  # one stream: another key
+    # not replayable: per-frame timesteps, step-skipping, sequence parallelism -> the eager forward, by-value timestep
+    rc, c5, _ = m.forward(S=2, graph=True, t_frames=[0.0, 637.0])
+    assert rc == 0 and m.how == 0 and "set_f32" not in [cl[0] for cl in c5] and "sinusoid" in [cl[0] for cl in c5]
+    rc, _, _ = m.forward(S=2, graph=True, should_calc=[1, 1], residual=[0x6400_0000_0000, 0x6410_0000_0000])
+    assert rc == 0 and m.how == 0
+    # the poll hook: once, in front; a stop request aborts before anything is enqueued
+    seen = []
+    stop = POLL_FN(lambda user, i: seen.append(i) or 1)
+    rc, c6, _ = m.forward(S=2, graph=True, poll=stop, stream=USER)
+    assert rc == WAN_ABORTED and seen == [0] and not c6
+    go = POLL_FN(lambda user, i: seen.append(i) or 0)
+    rc, c7, _ = m.forward(S=2, graph=True, poll=go, stream=USER)
+    assert rc == 0 and m.how == 3 and seen == [0, 0]
+    # a re-registered weight: the captured lists hold the old pointer and are dropped
+    k = "blocks.0.ffn.0.bias"
+    assert mock.wan_dit_set_weight(m.ctx, k.encode(), c_void_p(m.addr[k] + 0x100), 0, c.ffn_dim) == 0
+    rc, _, _ = m.forward(S=2, graph=True, stream=USER)
+    assert rc == 0 and m.how == 1

@@ -52,9 +52,10 @@ class _AsFloat32(Mapping):
         return len(self.base)
 
 
-def _checkpoint_on_gpu(cfg, seed):
+def _checkpoint_on_gpu(cfg, seed, mixed=False):
     """The distribution of O.synth_weights (modulation ~ N(0,1)/sqrt(d), norm weights 1 + 0.02 N, biases 0.01 N, the rest
-    0.02 N; fp32-locked tensors stay fp32), drawn with the device generator."""
+    0.02 N; fp32-locked tensors stay fp32), drawn with the device generator.  mixed: the `mixed_precision_transformer` locks on top
+    (time MLP, time projection, every norm3: bf16-representable values held in fp32, as O.synth_weights(mixed=True) does)."""
     g = torch.Generator(device="cuda").manual_seed(seed)
     W = {}
     for k, shp in O.param_shapes(cfg).items():
@@ -67,19 +68,29 @@ def _checkpoint_on_gpu(cfg, seed):
             w = 0.01 * r
         else:
             w = 0.02 * r
-        W[k] = w if k.startswith(O.FP32_LOCKED) else w.to(BF)
+        if k.startswith(O.FP32_LOCKED):
+            W[k] = w
+        elif O.is_fp32_locked(k, mixed):
+            W[k] = w.to(BF).float()
+        else:
+            W[k] = w.to(BF)
     return W
 
 
-def test_14B_forty_layers_vs_oracle():
+@pytest.mark.parametrize("mixed", [False, True], ids=["bf16_plan", "mixed_precision_plan"])
+def test_14B_forty_layers_vs_oracle(mixed):
+    """mixed (round 5): the reference's `mixed_precision_transformer` plan (model.py:1330-1371: fp32 time MLP / projection / norm3 ->
+    fp32 residual stream, e / e0 and modulation between bf16 Linears; csrc/mixed_ops.hip) at depth 40 and width 5,120 -- the oracle
+    picks the same plan from the fp32 time_projection weight (wan_oracle.dit_forward `adt`), pinned to the reference's own mixed
+    forward by tests/golden/forward_*_mixed.npz.  Same bars; the probed rows are the fp32 stream's."""
     from wan2gp_amd.model import WanModelHIP
     cfg = O.WanConfig(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40)
     f, h, w = 4, 32, 64
     L = f * (h // 2) * (w // 2)
     assert L == 2048
     t0 = time.time()
-    Wg = _checkpoint_on_gpu(cfg, 77)
-    m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers)
+    Wg = _checkpoint_on_gpu(cfg, 77, mixed)
+    m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers, mixed_precision=mixed)
     m.load_state_dict(Wg)
     t_w = time.time() - t0
     lat, ctx, _, _ = O.synth_inputs(cfg, f, h, w, seed=12)
@@ -138,7 +149,7 @@ def test_14B_forty_layers_vs_oracle():
     d = os.path.join(ROOT, "gpurun_out", "parity")
     try:
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "forward14B_40layers_L2048.json"), "w") as fo:
+        with open(os.path.join(d, "forward14B_40layers_L2048%s.json" % ("_mixed" if mixed else "")), "w") as fo:
             json.dump({"layers": table, "output": fin, "probed_rows": len(rows), "block0_gpu_vs_cpu_execution_of_the_oracle": pin,
                        "seconds": {"oracle_bf16_on_gpu": t_bf, "fp32_anchor_on_gpu": t_32, "block0_on_cpu": t_cpu0}}, fo, indent=1)
     except OSError:

@@ -352,6 +352,96 @@ def test_cfg4_world8_rank_dryrun():
     _report("attn_w64q_cfg4_world8_rank", dict(r, workspace_bytes=int(need)))
 
 
+# ---- the layout `bench.py --gpus 8` runs (cfg2 x sp4 / sp8 with the Ulysses all-to-alls), at BASELINE sizes, every rank on one GPU ----
+def _ulysses_world_emulation(S, world, L, chunks, seed, H=40):
+    """A whole Ulysses world's self-attention on one GPU, with the product's kernels and csrc/dit.hip's arguments: every rank j packs
+    its token shard's q / k / v^T with wan_permute16_ex, the all-to-alls are emulated by copying segment i of rank j's send buffer into
+    segment j of rank i's receive buffer, every rank i runs its C attention launches (world x S query batches of L / world rows against
+    S K / V^T batches in `world` segments, H / world heads split in C chunks), the o chunks travel back the same way and every rank
+    un-packs them to [rows][d].  Returns (q, k, v in the natural [S, L, H, 128] layout, o in the same layout = every rank's un-packed
+    rows stacked)."""
+    from wan2gp_amd import ops
+    d = H * 128
+    Hn, Ll = H // world, L // world
+    Wd, Lp, rows = Hn * 128, (Ll + 63) // 64 * 64, S * Ll
+    C = max(1, min(chunks, Hn, 8))
+    h0 = [c * Hn // C for c in range(C + 1)]
+    for c in range(C):                                                          # attention.hip:71 -- the DMA descriptors' 32-bit offsets, per launch
+        assert Ll * (h0[c + 1] - h0[c]) * 256 < 2 ** 32 and Lp * 256 < 2 ** 32
+    assert rows * Wd * 2 * world < 2 ** 40 and world * S <= 65535               # segment strides are 64-bit; grid.z = query batches
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = (torch.randn(S, L, H, 128, device="cuda", generator=g) * ops.attention_qscale()).to(BF)
+    k = torch.randn(S, L, H, 128, device="cuda", generator=g).to(BF)
+    v = torch.randn(S, L, H, 128, device="cuda", generator=g).to(BF)
+    chunks_ = [((h0[c + 1] - h0[c]), (h0[c + 1] - h0[c]) * 128, h0[c] * 128) for c in range(C)]      # (heads, Wc, o0)
+    ks, qs, vs = [], [], []
+    for j in range(world):                                                      # rank j: "my tokens, all heads" -> the send layouts
+        sl = slice(j * Ll, (j + 1) * Ll)
+        kj, qj = k[:, sl].contiguous().view(-1), q[:, sl].contiguous().view(-1)
+        vtj = ops.transpose_v(v[:, sl].contiguous(), Lp).view(-1)               # [S][d][Lp], zero padded: the transposed epilogue's image
+        ksj, qsj = torch.empty(rows * d, dtype=BF, device="cuda"), torch.empty(rows * d, dtype=BF, device="cuda")
+        vsj = vtj if S == 1 else torch.empty(S * d * Lp, dtype=BF, device="cuda")
+        for Hc, Wc, o0 in chunks_:
+            ops.permute16_ex(kj[o0:], ksj[o0 * rows:], rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wd * 2)
+            ops.permute16_ex(qj[o0:], qsj[o0 * rows * world:], rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2)
+            if S > 1:
+                ops.permute16_ex(vtj[o0 * Lp:], vsj[o0 * Lp * S:], S, world, Wc * Lp * 2, d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2, S * Wd * Lp * 2)
+        ks.append(ksj); qs.append(qsj); vs.append(vsj)
+    scratch = torch.zeros(ops.attention_scratch_words(world * S, S, Ll, max(c_[0] for c_ in chunks_)), dtype=torch.float32, device="cuda")
+    o_send = []
+    segk, segv = rows * Wd, S * Wd * Lp
+    for i in range(world):                                                      # rank i: "all tokens, my heads"
+        kr = torch.cat([ks[j][i * segk:(i + 1) * segk] for j in range(world)])
+        vr = torch.cat([vs[j][i * segv:(i + 1) * segv] for j in range(world)])
+        qr = torch.empty(rows * d, dtype=BF, device="cuda")
+        oi = torch.empty(rows * d, dtype=BF, device="cuda")
+        for Hc, Wc, o0 in chunks_:
+            R, seg = o0 * rows * world, rows * Wc
+            for j in range(world):
+                qr[R + j * seg:R + (j + 1) * seg] = qs[j][R + i * seg:R + (i + 1) * seg]
+            ops.attention(qr[R:R + world * seg].view(world * S, Ll, Hc, 128), kr[o0 * rows:], vr[o0 * Lp * S:].view(-1, Lp), Lk=Ll,
+                          out=oi[R:R + world * seg].view(world * S, Ll, Hc, 128), nseg=world, k_seg_stride=segk, vt_seg_stride=segv, Bk=S,
+                          q_prescaled=True, kmax_scratch=scratch)
+        o_send.append(oi)
+        del kr, vr, qr
+    del ks, qs, vs
+    o = torch.empty(S, L, H, 128, dtype=BF, device="cuda")
+    recv, back = torch.empty(rows * d, dtype=BF, device="cuda"), torch.empty(rows * d, dtype=BF, device="cuda")
+    for r in range(world):                                                      # the way back: rank r un-packs what every head owner sent it
+        for Hc, Wc, o0 in chunks_:
+            R, seg = o0 * rows * world, rows * Wc
+            for i in range(world):
+                recv[R + i * seg:R + (i + 1) * seg] = o_send[i][R + r * seg:R + (r + 1) * seg]
+            ops.permute16_ex(recv[R:], back[o0:], world, rows, Wc * 2, rows * Wc * 2, Wc * 2, Wd * 2, d * 2)
+        o[:, r * Ll:(r + 1) * Ll] = back.view(S, Ll, H, 128)
+    torch.cuda.synchronize()
+    return q, k, v, o
+
+
+@pytest.mark.parametrize("S,world,L", [(1, 4, 75600), (2, 8, 75600), (1, 4, 147600), (2, 8, 147600)],
+                         ids=["cfg3_cfg2xsp4_Hn10_Ll18900", "cfg3_sp8_Hn5_Ll9450", "cfg4_cfg2xsp4_Hn10_Ll36900", "cfg4_sp8_Hn5_Ll18450"])
+def test_ulysses_world_rank_dryruns_at_baseline_size(S, world, L):
+    """BASELINE configs[2] / [3] in the layouts `bench.py --gpus 8` runs -- cfg2 x sp4 (ulysses): one stream, 4 ranks, 10 heads each;
+    sp8 (ulysses): both streams, 8 ranks, 5 heads each -- with the q / o exchanges in 2 head chunks (5 + 5, 2 + 3): EVERY rank's
+    re-packs (wan_permute16_ex at [18,900 .. 36,900 x 5,120]), its launches (world x S query batches, `world` segments, the chunk's
+    heads) and the un-pack of the way back, against the fp64 softmax on sampled rows of heads of every owner rank and both chunks;
+    and the chunked result is BIT-IDENTICAL to the one-exchange form (chunks = 1) over the whole tensor."""
+    H = 40
+    Hn = H // world
+    q, k, v, o2 = _ulysses_world_emulation(S, world, L, 2, seed=L + world)
+    assert torch.isfinite(o2.float()).all()
+    vt = v.permute(0, 2, 3, 1).reshape(1, S, H * 128, L)                         # the layout _attn_sampled_check reads: [nseg][B][H*128][ldv]
+    heads = sorted({0, max(Hn // 2 - 1, 0), Hn // 2, Hn - 1, Hn, 2 * Hn + Hn // 2, H - Hn, H - 1})   # both chunks of the first / last owner, a middle one
+    pairs = [(s, hd) for i, hd in enumerate(heads) for s in ([i % S] if S > 1 else [0])]
+    r = _attn_sampled_check(q, k.unsqueeze(0), vt, o2, pairs, 192, what=f"ulysses world {world} S={S} L={L}, 2 head chunks, heads {heads}")
+    del vt
+    q1, k1, v1, o1 = _ulysses_world_emulation(S, world, L, 1, seed=L + world)
+    assert torch.equal(q1, q) and torch.equal(k1, k)
+    same = torch.equal(o1, o2)
+    _report(f"ulysses_world{world}_S{S}_L{L}", dict(r, heads=heads, chunked_equals_unchunked=bool(same), tokens_per_rank=L // world, heads_per_rank=Hn))
+    assert same, f"chunked and one-exchange results differ on {(o1 != o2).float().mean().item():.3e} of the elements"
+
+
 # ---- gemm256k at the Wan shapes ------------------------------------------------------------------------------------------
 def _bf16_close_rows(got, exact, floor, ulps=2, what=""):
     diff = (got.double() - exact).abs()

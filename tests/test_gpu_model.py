@@ -330,3 +330,57 @@ def test_per_frame_timesteps_vs_reference_golden():
     from wan2gp_amd.lib import WanHipError
     with pytest.raises(WanHipError):
         m([lat.cuda()], t=torch.tensor([1, 2, 3]), context=[ctx.cuda()])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "small"])
+def test_forward_as_replayed_launch_list_is_bit_identical(name):
+    """wan_dit_forward_graph (round 5; WanModelHIP.graph): first sight eager, second sight captured, then replayed -- at every stage and
+    for every timestep bit-identical to the eager forward (graph = "off") of the same inputs; the joint pass and a single stream are keys
+    of their own; a callback keeps the per-block contract (eager)."""
+    cfg = O.make_config(name)
+    m, W = build(cfg)
+    f, h, w = (3, 8, 12) if name != "small" else (3, 10, 14)
+    lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
+    cc, cn = ctx.cuda(), ctx_null.cuda()
+    yy = None if y is None else y.cuda()
+    g = torch.Generator().manual_seed(3)
+    hows = []
+    for i, tv in enumerate((900, 637, 412, 55, 999)):
+        x = (lat + 0.1 * i * torch.randn(lat.shape, generator=g)).cuda()
+        t = torch.tensor([tv])
+        m.graph = "off"
+        ref = m([x.clone(), x.clone()], t=t, context=[cc, cn], y=yy)
+        assert m.last_graph_how == 0
+        m.graph = "on"
+        got = m([x.clone(), x.clone()], t=t, context=[cc, cn], y=yy)
+        hows.append(m.last_graph_how)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), (name, i, m.last_graph_how, (a - b).abs().max().item())
+    assert hows == [1, 2, 3, 3, 3], hows
+    one = m([lat.cuda()], t=torch.tensor([500]), context=[cc], y=yy)
+    assert m.last_graph_how == 1                                               # S = 1: its own key
+    m.graph = "off"
+    assert torch.equal(m([lat.cuda()], t=torch.tensor([500]), context=[cc], y=yy)[0], one[0])
+    m.graph = "auto"                                                           # tiny shapes are below graph_max_tokens ...
+    calls = []
+    m([lat.cuda()], t=torch.tensor([500]), context=[cc], y=yy, callback=lambda *a: calls.append(a))
+    assert m.last_graph_how == 0 and len(calls) == cfg.num_layers              # ... but a per-block callback keeps its contract
+    m.graph_max_tokens = 1
+    m([lat.cuda()], t=torch.tensor([500]), context=[cc], y=yy)
+    assert m.last_graph_how == 0
+
+
+def test_generate_with_replayed_forwards_equals_eager_generate():
+    """The sampler loop over replayed forwards (what bench.py's configs[0] block times): same seed, same latents, bit for bit."""
+    from wan2gp_amd.pipeline import WanAny2VHIP
+    cfg = O.make_config("tiny")
+    m, W = build(cfg)
+    _, ctx, ctx_null, _ = O.synth_inputs(cfg, 2, 8, 8)
+    pipe = WanAny2VHIP(m)
+    run = lambda: pipe.generate(context=ctx.cuda(), context_null=ctx_null.cuda(), width=64, height=64, frame_num=5, sampling_steps=6,
+                                guide_scale=3.0, seed=11, return_latents=True)["latents"].cpu()
+    m.graph = "off"
+    base = run()
+    m.graph = "on"
+    fast = run()
+    assert m.last_graph_how == 3 and torch.equal(fast, base)

@@ -683,6 +683,36 @@ def test_permute16_is_a_block_transpose(ops):
         ops.permute16(torch.zeros(3, 5, 4, dtype=BF, device="cuda"), 3, 5)          # 8-byte blocks
 
 
+def test_permute16_ex_pitched_column_ranges(ops):
+    """wan_permute16_ex (round 5, the chunked Ulysses re-packs): a column range of [rows][world][W] rows into a [world][rows][Wc] block of
+    its own and back, a V^T row range [S][world][W][Lp] -> [world][chunk][S][Wc][Lp] -- against torch.as_strided, bit for bit."""
+    g = torch.Generator().manual_seed(5)
+    rows, world, W = 301, 4, 5 * 128
+    d = world * W
+    src = torch.randn(rows * d, generator=g).to(BF).cuda()
+    for o0, Wc in ((0, 2 * 128), (2 * 128, 3 * 128)):
+        dst = torch.zeros(world * rows * Wc, dtype=BF, device="cuda")
+        ops.permute16_ex(src[o0:], dst, rows, world, Wc * 2, d * 2, W * 2, Wc * 2, rows * Wc * 2)
+        want = torch.as_strided(src, (world, rows, Wc), (W, d, 1), o0).contiguous()
+        assert torch.equal(dst.view(world, rows, Wc), want)
+        back = torch.zeros(rows * d, dtype=BF, device="cuda")
+        ops.permute16_ex(dst, back[o0:], world, rows, Wc * 2, rows * Wc * 2, Wc * 2, W * 2, d * 2)
+        assert torch.equal(torch.as_strided(back, (world, rows, Wc), (W, d, 1), o0), want)
+        assert int((back != 0).sum()) <= world * rows * Wc                      # nothing outside the column range was written
+    S, Lp = 2, 128
+    vt = torch.randn(S * d * Lp, generator=g).to(BF).cuda()
+    vs = torch.zeros_like(vt)
+    for o0, Wc in ((0, 2 * 128), (2 * 128, 3 * 128)):
+        ops.permute16_ex(vt[o0 * Lp:], vs[o0 * Lp * S:], S, world, Wc * Lp * 2, d * Lp * 2, W * Lp * 2, Wc * Lp * 2, S * W * Lp * 2)
+    for o0, Wc in ((0, 2 * 128), (2 * 128, 3 * 128)):
+        got = torch.as_strided(vs, (world, S, Wc * Lp), (S * W * Lp, Wc * Lp, 1), o0 * Lp * S)
+        want = torch.as_strided(vt, (world, S, Wc * Lp), (W * Lp, d * Lp, 1), o0 * Lp)
+        assert torch.equal(got, want)
+    from wan2gp_amd.lib import WanHipError
+    with pytest.raises(WanHipError):
+        ops.permute16_ex(src, vs, 2, 2, 24, 48, 96, 24, 48)                       # 24-byte pieces
+
+
 @pytest.mark.parametrize("Lq,Lk,nseg", [(300, 2130, 2), (96, 48, 4)], ids=["long_kv_bounded", "short_kv_tracking"])
 def test_attention_query_batches_share_kv_batches_modulo(ops, Lq, Lk, nseg):
     """The Ulysses launch shape: B = nseg x S query batches (source rank, stream) against Bk = S K / V^T batches held in `nseg`

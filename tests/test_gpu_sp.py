@@ -18,7 +18,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q, backend="gloo", native=False, mode="allgather", fhw=(4, 12, 16)):
+def _worker(rank, world, port, q, backend="gloo", native=False, mode="allgather", fhw=(4, 12, 16), model_kw=None, streams=2, chunks=None,
+            chunk_identity=None):
+    """model_kw: WanConfig fields instead of the `small` config; streams: CFG streams on this group (1 = a cfg-parallel half);
+    chunks: SequenceParallel(chunks=); chunk_identity: also run with that many chunks and demand a BIT-IDENTICAL result."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     import torch.distributed as dist
@@ -32,20 +35,29 @@ def _worker(rank, world, port, q, backend="gloo", native=False, mode="allgather"
         from oracle import wan_oracle as O
         from wan2gp_amd.model import WanModelHIP
         from wan2gp_amd.sp import SequenceParallel
-        cfg = O.make_config("small")
+        cfg = O.make_config("small") if model_kw is None else O.WanConfig(**model_kw)
         W = O.synth_weights(cfg, seed=77)
         m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers)
         m.load_state_dict(W)
+        del W
         f, h, w = fhw                          # default: L = 4*6*8 = 192 tokens -> 96 per rank (not a multiple of 64)
         lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w, seed=9)
         t = torch.tensor([412])
-        ref = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])
-        m.sp = SequenceParallel(rank, world, native=native, mode=mode)
-        got = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])
+        xs = lambda: [lat.cuda() for _ in range(streams)]
+        cs = [ctx.cuda(), ctx_null.cuda()][:streams]
+        ref = m(xs(), t=t, context=cs)
+        m.sp = SequenceParallel(rank, world, native=native, mode=mode, chunks=chunks)
+        got = m(xs(), t=t, context=cs)
         for g, r in zip(got, ref):
             assert g.shape == r.shape
             rel = ((g - r).norm() / r.norm()).item()
             assert rel < 1e-2, f"rank {rank}: SP forward deviates from single-rank forward: rel={rel}"
+        if chunk_identity is not None:
+            m.sp = SequenceParallel(rank, world, native=native, mode=mode, chunks=chunk_identity)
+            assert m.sp.resolved_chunks(cfg.num_heads) != SequenceParallel(rank, world, mode=mode, chunks=chunks).resolved_chunks(cfg.num_heads)
+            again = m(xs(), t=t, context=cs)
+            for g, a in zip(got, again):
+                assert torch.equal(g, a), f"rank {rank}: {chunk_identity} head chunks change the result ({(g != a).float().mean().item():.3e} of the elements)"
         q.put((rank, "ok"))
     except Exception:
         import traceback
@@ -86,6 +98,42 @@ def test_ulysses_forward_ranks_on_one_gpu(world, fhw):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _run_world(world, **kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q), kwargs=kw) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=1200) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+@pytest.mark.parametrize("world,heads,chunks,fhw", [(2, 4, 2, (4, 12, 16)), (2, 6, 2, (9, 32, 32)), (4, 12, 3, (4, 12, 16)), (2, 10, 5, (4, 12, 16))],
+                         ids=["w2_heads_1+1_L192", "w2_heads_1+2_L2304_long_kv", "w4_heads_1+1+1_L192", "w2_heads_5x1_L192"])
+def test_ulysses_chunked_exchange_is_bit_identical_to_one_exchange(world, heads, chunks, fhw):
+    """wan_sp_info.a2a_chunks (round 5): q and o travel in head chunks, chunk c's attention launch between ITS q wait and ITS o begin.
+    Every rank of a world on cuda:0 (gloo-staged exchanges): the chunked forward reproduces the single-rank forward (rel <= 1e-2, the
+    bar of this file) AND is bit-identical to the one-exchange form -- equal and unequal chunks, both CFG streams, short- and long-KV
+    kernels."""
+    _run_world(world, mode="ulysses", fhw=fhw, chunks=chunks, chunk_identity=1,
+               model_kw=dict(dim=128 * heads, ffn_dim=512, num_heads=heads, num_layers=2))
+
+
+@pytest.mark.parametrize("world,streams", [(4, 1), (8, 2)], ids=["cfg2xsp4_half_S1_Hn10_Ll18900", "sp8_S2_Hn5_Ll9450"])
+def test_ulysses_ranks_at_baseline_size_vs_single_gpu_forward(world, streams):
+    """BASELINE configs[2] (720 x 1280 x 81 frames, L = 75,600, d = 5,120, 40 heads) in the layouts `bench.py --gpus 8` runs, EVERY rank
+    a process of its own on cuda:0 with the exchanges staged through gloo: a 2-layer model, each rank's output rows against the
+    single-GPU forward of the same model (rel <= 1e-2).  cfg2 x sp4: one stream on a group of 4 (10 heads per rank, chunks 5 + 5);
+    sp8: both streams on a group of 8 (5 heads per rank, chunks 2 + 3).  A first 8-GPU run must not also be the first correctness
+    run of these re-packs (round-4 verdict)."""
+    _run_world(world, mode="ulysses", fhw=(21, 90, 160), streams=streams, chunks=None,
+               model_kw=dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=2))
 
 
 @pytest.mark.parametrize("native", [False, True], ids=["torch_distributed", "library_communicator"])

@@ -268,6 +268,141 @@ def test_ulysses_exchanges_with_the_forwards_layouts(world, cfg_name):
         assert msg == "ok", f"rank {rank}: {msg}"
 
 
+# ---- the chunked form (round 5, wan_sp_info.a2a_chunks): csrc/dit.hip's per-chunk layouts and offsets restated on oracle arithmetic ---
+def _ulysses_chunked_worker(rank, world, port, q, heads, chunks):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from wan2gp_amd.sp import SequenceParallel, shard_range
+        torch.set_num_threads(2)
+        sp = SequenceParallel(rank, world, mode="ulysses", chunks=chunks)
+        cfg = O.WanConfig(dim=128 * heads, ffn_dim=256, num_heads=heads, num_layers=1)
+        W = O.synth_weights(cfg, dtype=torch.float32)
+        f, h, w = 2, 8, 8
+        S = 2
+        lats = [O.synth_inputs(cfg, f, h, w, seed=42 + s)[0] for s in range(S)]
+        ctx = O.synth_inputs(cfg, f, h, w)[1]
+        grid = (f, h // 2, w // 2)
+        L = f * (h // 2) * (w // 2)
+        tok0, Ll = shard_range(L, rank, world)
+        H, d = cfg.num_heads, cfg.dim
+        Hn, Wd, Lp, rows = H // world, H // world * 128, (Ll + 63) // 64 * 64, S * Ll
+        info = sp.make_info(L, heads=H)
+        C = info.a2a_chunks
+        assert C == min(chunks, Hn) and sp.resolved_chunks(H) == C
+        h0 = [c * Hn // C for c in range(C + 1)]                                # the library's chunk boundaries (dit.hip)
+        cos, sin = O.rope_tables(grid)
+        t = torch.tensor([500])
+        dt = torch.float32
+        e, e0 = O.time_embed(t, W, cfg, dt)
+        cemb = O.text_embed(ctx.float(), W)
+        blkq, blkv = rows * d, S * d * Lp
+        ws = torch.zeros(4 * blkq + 2 * blkv, dtype=torch.float32)
+        sp.bind_workspace(ws.view(torch.uint8))
+        el = 4
+        KS, KR, QS, QR = 0, blkq, 2 * blkq, 3 * blkq                            # element offsets of ks, kr, qs, qr, vs, vr in the workspace
+        VS, VR = 4 * blkq, 4 * blkq + blkv
+
+        def permute_ex(src, src_off, dst_off, A, B, n, sa, sb, da, db):        # wan_permute16_ex, pitches in elements
+            sv = torch.as_strided(src, (A, B, n), (sa, sb, 1), src_off)
+            torch.as_strided(ws, (A, B, n), (da, db, 1), dst_off).copy_(sv)
+
+        def a2a(which, send_off, recv_off, n_per_peer):
+            base = ws.data_ptr()
+            assert sp._a2a_begin_cb(None, which, base + send_off * el, base + recv_off * el, n_per_peer * el, None) == 0
+
+        refs, xs = [], []
+        for s in range(S):
+            full_h, _ = O.patch_embed(lats[s], W, cfg, dt)
+            refs.append(O.block_forward(full_h, e0, cemb, cos, sin, W, 0, cfg, exact=True))
+            xs.append(full_h[:, tok0:tok0 + Ll])
+        p = "blocks.0."
+        sa = p + "self_attn."
+        ee = (W[p + "modulation"] + e0).chunk(6, dim=1)
+        xm = torch.cat([O.layer_norm(x, cfg.eps) * (1 + ee[1]) + ee[0] for x in xs], dim=1)[0]
+        pos = slice(tok0, tok0 + Ll)
+
+        def normed(name, nw):
+            y = O.rms_norm(O._linear(xm, W, sa + name), W[sa + nw], cfg.eps).view(S, Ll, H, 128)
+            return O.rope_apply(y, cos[pos], sin[pos]).reshape(-1).contiguous()
+        kk = normed("k", "norm_k.weight")
+        for c in range(C):                                                      # [rows][world][Hn 128] -> [world][chunk][rows][Wc]
+            Wc, o0 = (h0[c + 1] - h0[c]) * 128, h0[c] * 128
+            permute_ex(kk, o0, KS + o0 * rows, rows, world, Wc, d, Wd, Wc, rows * Wd)
+        a2a(0, KS, KR, rows * Wd)
+        vt = torch.zeros(S, d, Lp)
+        vt[:, :, :Ll] = O._linear(xm, W, sa + "v").view(S, Ll, d).transpose(1, 2)
+        vt = vt.reshape(-1).contiguous()
+        for c in range(C):                                                      # [S][world][Hn 128][Lp] -> [world][chunk][S][Wc][Lp]
+            Wc, o0 = (h0[c + 1] - h0[c]) * 128, h0[c] * 128
+            permute_ex(vt, o0 * Lp, VS + o0 * Lp * S, S, world, Wc * Lp, d * Lp, Wd * Lp, Wc * Lp, S * Wd * Lp)
+        a2a(1, VS, VR, S * Wd * Lp)
+        qq = normed("q", "norm_q.weight")
+        for c in range(C):                                                      # [rows][world][Hn 128] -> [chunk][world][rows][Wc], sent per chunk
+            Wc, o0 = (h0[c + 1] - h0[c]) * 128, h0[c] * 128
+            permute_ex(qq, o0, QS + o0 * rows * world, rows, world, Wc, d, Wd, Wc, rows * Wc)
+            a2a(2 + c, QS + o0 * rows * world, QR + o0 * rows * world, rows * Wc)
+        assert sp._a2a_wait_cb(None, 0, None) == 0 and sp._a2a_wait_cb(None, 1, None) == 0
+        for c in range(C):
+            Hc = h0[c + 1] - h0[c]
+            Wc, o0 = Hc * 128, h0[c] * 128
+            assert sp._a2a_wait_cb(None, 2 + c, None) == 0
+            # the launch of chunk c: the round-4 layout with Hc heads at the chunk's offsets, segment strides of the WHOLE head group
+            Q = ws[QR + o0 * rows * world:QR + (o0 + Wc) * rows * world].view(world, S, Ll, Hc, 128)
+            K = torch.as_strided(ws, (world, S, Ll, Hc, 128), (rows * Wd, Ll * Wc, Wc, 128, 1), KR + o0 * rows)
+            V = torch.as_strided(ws, (world, S, Hc, 128, Lp), (S * Wd * Lp, Wc * Lp, 128 * Lp, Lp, 1), VR + o0 * Lp * S)
+            out = torch.empty(world, S, Ll, Hc, 128)
+            for s in range(S):
+                kf = K[:, s].reshape(1, world * Ll, Hc, 128)
+                vf = V[:, s, :, :, :Ll].permute(0, 3, 1, 2).reshape(1, world * Ll, Hc, 128)
+                for i in range(world):
+                    out[i, s] = O.attention(Q[i, s].unsqueeze(0), kf, vf, exact=True)[0]
+            ws[KS + o0 * rows * world:KS + (o0 + Wc) * rows * world] = out.reshape(-1)        # o over the dead k send buffer ...
+            a2a(2 + C + c, KS + o0 * rows * world, QS + o0 * rows * world, rows * Wc)         # ... received over the dead q send chunk
+        o_rows = torch.zeros(rows * d)
+        for c in range(C):                                                      # [chunk][world][rows][Wc] -> [rows][world][Hn 128]
+            Wc, o0 = (h0[c + 1] - h0[c]) * 128, h0[c] * 128
+            assert sp._a2a_wait_cb(None, 2 + C + c, None) == 0
+            sv = torch.as_strided(ws, (world, rows, Wc), (rows * Wc, Wc, 1), QS + o0 * rows * world)
+            torch.as_strided(o_rows, (world, rows, Wc), (Wd, d, 1), o0).copy_(sv)
+        assert sp.a2a_bytes == (3 * rows * Wd + S * Wd * Lp) * el * (world - 1)      # the same bytes as the unchunked form
+        o_rows = o_rows.view(S, Ll, d)
+        for s in range(S):
+            x = torch.addcmul(xs[s], O._linear(o_rows[s:s + 1], W, sa + "o"), ee[2])
+            y = O.layer_norm(x, cfg.eps, W[p + "norm3.weight"], W[p + "norm3.bias"])
+            x = x + O.cross_attention(y, cemb, W, p + "cross_attn.", cfg, True)
+            y = O.layer_norm(x, cfg.eps) * (1 + ee[4]) + ee[3]
+            y = O._linear(torch.nn.functional.gelu(O._linear(y, W, p + "ffn.0"), approximate="tanh"), W, p + "ffn.2")
+            x = torch.addcmul(x, y, ee[5])
+            assert torch.allclose(x, refs[s][:, tok0:tok0 + Ll], atol=1e-4, rtol=1e-4), (s, (x - refs[s][:, tok0:tok0 + Ll]).abs().max().item())
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,heads,chunks", [(2, 4, 2), (2, 6, 2), (4, 12, 3), (2, 10, 5)],
+                         ids=["w2_heads_1+1", "w2_heads_1+2", "w4_heads_1+1+1", "w2_heads_5x1"])
+def test_ulysses_chunked_exchanges_with_the_forwards_layouts(world, heads, chunks):
+    """The chunked Ulysses block (round 5): k / v^T packed per head chunk and exchanged whole, q / o exchanged per chunk, every chunk's
+    attention on the round-4 layout at the chunk's offsets, the per-chunk un-pack -- with exactly the offsets and pitches csrc/dit.hip
+    passes to wan_permute16_ex / wan_attention_bounded / a2a_begin, through sp.py's callbacks over gloo.  Every rank's block output
+    equals the single-process oracle block on its token shard for both CFG streams; unequal chunks (3 heads as 1 + 2) included."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ulysses_chunked_worker, args=(r, world, port, q, heads, chunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
 def test_sequence_parallel_mode_is_validated():
     from wan2gp_amd.sp import SequenceParallel
     with pytest.raises(ValueError):

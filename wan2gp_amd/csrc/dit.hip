@@ -22,7 +22,7 @@ void wan_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wan_last_error(void) { return g_err; }
-extern "C" int wan_version(void) { return 6; }
+extern "C" int wan_version(void) { return 7; }
 extern "C" int wan_device_cus(void) {
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -37,6 +37,10 @@ int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const fl
                    float* out, int B, int F, int Hg, int Wg, int d, float eps, int64_t tok0, int64_t ntok,
                    int token_major_out, int64_t e_rows_per_batch, int nout, void* stream);
 int wan_sinusoid_val(float t, bf16_t* out, int dim, void* stream);
+int wan_set_f32(float* p, float v, void* stream);
+// wan_dit_forward_graph: the timestep of the forward being enqueued lives in device memory (one float) instead of a launch argument,
+// so that the captured launch list can be replayed for another t (sinusoid_kernel and sinusoid_val_kernel do the same arithmetic)
+static const float* g_t_dev = nullptr;
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ----
 // Off by default.  When enabled, wan_dit_forward brackets the launches of each class with a
@@ -175,6 +179,18 @@ struct wan_ctx {
   bf16_t* clip_ctx = nullptr;   // [257, dim], owned; filled by wan_dit_set_clip
   bf16_t* clip_tmp = nullptr;   // 2 x [257, 1280] scratch, owned
   bool clip_set = false;
+  // wan_dit_forward_graph: captured launch lists (hipGraphExec) keyed by everything a forward's launches depend on except t
+  struct GraphEntry {
+    std::vector<uint8_t> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;   // nullptr: the key has been seen (and run eagerly) once; the next call captures
+    bool bad = false;                // capture or instantiation failed once: this key stays on the eager path
+    uint64_t last_use = 0;
+  };
+  std::vector<GraphEntry> graphs;
+  uint64_t graph_clock = 0;
+  float* t_dev = nullptr;           // owned: the timestep of a replayed forward
+  hipStream_t cap_stream = nullptr; // owned: the stream a launch list is captured on (capture is not allowed on the legacy default stream)
 };
 extern "C" int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out) {
   WAN_REQUIRE(cfg && out, "wan_dit_create: null argument");
@@ -194,6 +210,12 @@ extern "C" void wan_dit_destroy(wan_ctx* ctx) {
   if (ctx) {
     if (ctx->clip_ctx) (void)hipFree(ctx->clip_ctx);
     if (ctx->clip_tmp) (void)hipFree(ctx->clip_tmp);
+    for (auto& e : ctx->graphs) {
+      if (e.exec) (void)hipGraphExecDestroy(e.exec);
+      if (e.graph) (void)hipGraphDestroy(e.graph);
+    }
+    if (ctx->t_dev) (void)hipFree(ctx->t_dev);
+    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   }
   delete ctx;
 }
@@ -204,6 +226,11 @@ extern "C" int wan_dit_set_weight(wan_ctx* ctx, const char* name, const void* pt
   WAN_REQUIRE((((uintptr_t)ptr) & 15) == 0, "wan_dit_set_weight: %s is not 16-byte aligned", name);
   ctx->weights[name] = Tensor{ptr, dtype, numel};
   ctx->resolved = false;
+  for (auto& e : ctx->graphs) {     // captured launch lists hold the old pointers
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.graph) (void)hipGraphDestroy(e.graph);
+  }
+  ctx->graphs.clear();
   return 0;
 }
 
@@ -619,8 +646,10 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     for (int s = 1; s < S && nt > 1; ++s)
       WAN_CHECK_HIP(hipMemcpyAsync(b.mx_e0 + (int64_t)s * nt * 6 * d, b.mx_e0, (size_t)nt * 6 * d * 4, hipMemcpyDeviceToDevice, st));
   }
-  for (int f = 0; f < nt && !mx; ++f)
-    RC(wan_sinusoid_val(t_frames ? t_frames[frame0 + f] : t, b.sinus + (int64_t)f * g.freq_dim, g.freq_dim, stream));
+  for (int f = 0; f < nt && !mx; ++f) {
+    if (g_t_dev != nullptr && t_frames == nullptr) RC(wan_sinusoid(g_t_dev, b.sinus, 1, g.freq_dim, stream));
+    else RC(wan_sinusoid_val(t_frames ? t_frames[frame0 + f] : t, b.sinus + (int64_t)f * g.freq_dim, g.freq_dim, stream));
+  }
   // the time MLP: GEMV for one row of bf16 weights, the tile GEMM otherwise (several rows, or fp8 weights: one tensor)
   auto tlin = [&](const bf16_t* A, const Lin& l, bf16_t* C, int N, int K) -> int {
     if (l.w8 || nt > 1) return linear(A, l, C, nt, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8);
@@ -755,11 +784,82 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       bf16_t *vs = b.vtfull, *vr = b.vtfull + blkv;
       auto a2a = [&](int which, const bf16_t* send, bf16_t* recv, int64_t bytes) -> int {
         if (sp->a2a_begin(sp->user, which, send, recv, bytes, stream)) {
-          wan_set_error("wan_dit_forward: all-to-all %d (0 k, 1 v^T, 2 q, 3 o) failed", which);
+          wan_set_error("wan_dit_forward: all-to-all %d (0 k, 1 v^T, 2.. q chunks, then o chunks) failed", which);
           return 3;
         }
         return 0;
       };
+      auto a2a_wait = [&](int which) -> int {
+        if (sp->a2a_wait(sp->user, which, stream)) {
+          wan_set_error("wan_dit_forward: all-to-all %d failed", which);
+          return 3;
+        }
+        return 0;
+      };
+      // Round 5: the rank's Hn heads in C chunks (wan_sp_info.a2a_chunks; 1 = the round-4 form below).  q and o travel per chunk --
+      // chunk c's attention launch runs while chunk c + 1's q is still arriving and chunk c - 1's o is already on its way back, so of
+      // the two exchanges that nothing could hide (2 x 48 MB per link and block at 8 GPUs) only the first q chunk and the last o
+      // chunk stay exposed.  k and v^T still travel whole (they hide under the V and Q projections) but are LAID OUT per chunk,
+      //   k recv   [world][chunk][S][Ll][Wc]     v^T recv  [world][chunk][S][Wc][Lp]      (chunk c: heads [h0_c, h1_c), Wc = 128 (h1_c - h0_c))
+      //   q recv   [chunk][world][S][Ll][Wc]     o send    [chunk][world][S][Ll][Wc]
+      // so that a chunk's launch sees exactly the round-4 layout with H = h1_c - h0_c heads: the same kernel on the same rows of the
+      // same heads -- the results are bit-identical to C = 1 (tests/test_gpu_sp.py).  Exchange slots: 0 k, 1 v^T, 2 + c q, 2 + C + c o.
+      int C = sp->a2a_chunks < 1 ? 1 : sp->a2a_chunks;
+      if (C > Hn) C = Hn;
+      if (C > WAN_SP_MAX_CHUNKS) C = WAN_SP_MAX_CHUNKS;
+      if (C > 1) {
+        int h0[WAN_SP_MAX_CHUNKS + 1];
+        for (int cch = 0; cch <= C; ++cch) h0[cch] = (int)((int64_t)cch * Hn / C);
+        RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+        RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
+        for (int cch = 0; cch < C; ++cch) {   // [rows][world][Hn 128] -> [world][chunk][rows][Wc]
+          const int64_t Wc = (int64_t)(h0[cch + 1] - h0[cch]) * 128, o0 = (int64_t)h0[cch] * 128;
+          RC(wan_permute16_ex(b.k + o0, ks + o0 * rows, rows, world, Wc * 2, (int64_t)d * 2, Wd * 2, Wc * 2, rows * Wd * 2, stream));
+        }
+        RC(a2a(0, ks, kr, rows * Wd * 2));
+        for (int s = 0; s < S; ++s)
+          RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                    nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr));
+        const bf16_t* vsend = b.vt;       // S = 1: [world][Hn 128][Lp] already IS [world][chunk][Wc][Lp]
+        if (S > 1) {
+          for (int cch = 0; cch < C; ++cch) {   // [S][world][Hn 128][Lp] -> [world][chunk][S][Wc][Lp]
+            const int64_t Wc = (int64_t)(h0[cch + 1] - h0[cch]) * 128, o0 = (int64_t)h0[cch] * 128;
+            RC(wan_permute16_ex(b.vt + o0 * Lp, vs + o0 * Lp * S, S, world, Wc * Lp * 2, (int64_t)d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2,
+                                (int64_t)S * Wd * Lp * 2, stream));
+          }
+          vsend = vs;
+        }
+        RC(a2a(1, vsend, vr, (int64_t)S * Wd * Lp * 2));
+        RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
+                  Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr));
+        RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
+        for (int cch = 0; cch < C; ++cch) {   // [rows][world][Hn 128] -> [chunk][world][rows][Wc]; each chunk leaves as soon as it is packed
+          const int64_t Wc = (int64_t)(h0[cch + 1] - h0[cch]) * 128, o0 = (int64_t)h0[cch] * 128;
+          RC(wan_permute16_ex(b.q + o0, qs + o0 * rows * world, rows, world, Wc * 2, (int64_t)d * 2, Wd * 2, Wc * 2, rows * Wc * 2, stream));
+          RC(a2a(2 + cch, qs + o0 * rows * world, qr + o0 * rows * world, rows * Wc * 2));
+        }
+        RC(a2a_wait(0));
+        RC(a2a_wait(1));
+        for (int cch = 0; cch < C; ++cch) {
+          const int Hc = h0[cch + 1] - h0[cch];
+          const int64_t Wc = (int64_t)Hc * 128, o0 = (int64_t)h0[cch] * 128;
+          RC(a2a_wait(2 + cch));
+          {
+            ProfScope ps(PROF_SELF_ATTN, st);
+            RC(wan_attention_bounded(qr + o0 * rows * world, kr + o0 * rows, vr + o0 * Lp * S, ks + o0 * rows * world, world * S, S, Ll, Ll, Lp, Hc,
+                                     world, rows * Wd, (int64_t)S * Wd * Lp, 1, b.kmax, stream));
+          }
+          if (g_prof_on && g_prof_declined != nullptr && Ll * (int64_t)world > 2048)
+            RC(wan_attention_count_declined(b.kmax, world * S, S, Ll, Hc, g_prof_declined, stream));
+          // o chunk c back over the dead q send buffer (its q chunk was waited for above) while the next chunk's launch runs
+          RC(a2a(2 + C + cch, ks + o0 * rows * world, qs + o0 * rows * world, rows * Wc * 2));
+        }
+        for (int cch = 0; cch < C; ++cch) {   // [chunk][world][rows][Wc] -> [rows][world][Hn 128]
+          const int64_t Wc = (int64_t)(h0[cch + 1] - h0[cch]) * 128, o0 = (int64_t)h0[cch] * 128;
+          RC(a2a_wait(2 + C + cch));
+          RC(wan_permute16_ex(qs + o0 * rows * world, b.q + o0, world, rows, Wc * 2, rows * Wc * 2, Wc * 2, Wd * 2, (int64_t)d * 2, stream));
+        }
+      } else {
       RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
       RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
       RC(wan_permute16(b.k, ks, rows, world, Wd * 2, stream));
@@ -778,11 +878,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
       RC(wan_permute16(b.q, qs, rows, world, Wd * 2, stream));
       RC(a2a(2, qs, qr, rows * Wd * 2));
-      for (int w3 = 0; w3 < 3; ++w3)
-        if (sp->a2a_wait(sp->user, w3, stream)) {
-          wan_set_error("wan_dit_forward: all-to-all %d failed", w3);
-          return 3;
-        }
+      for (int w3 = 0; w3 < 3; ++w3) RC(a2a_wait(w3));
       {
         ProfScope ps(PROF_SELF_ATTN, st);
         RC(wan_attention_bounded(qr, kr, vr, ks, world * S, S, Ll, Ll, Lp, Hn, world, rows * Wd, (int64_t)S * Wd * Lp, 1, b.kmax, stream));
@@ -790,11 +886,9 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       if (g_prof_on && g_prof_declined != nullptr && Ll * (int64_t)world > 2048)
         RC(wan_attention_count_declined(b.kmax, world * S, S, Ll, Hn, g_prof_declined, stream));
       RC(a2a(3, ks, qs, rows * Wd * 2));
-      if (sp->a2a_wait(sp->user, 3, stream)) {
-        wan_set_error("wan_dit_forward: all-to-all 3 (o) failed");
-        return 3;
-      }
+      RC(a2a_wait(3));
       RC(wan_permute16(qs, b.q, world, rows, Wd * 2, stream));
+      }
     } else if (world > 1) {
       // Sequence parallelism: K first (projection, RMSNorm + RoPE), its all-gather started at once; then V^T and its gather; the
       // Q projection / norm and the attention over the rank's OWN K / V^T segment run while both collectives are in flight;
@@ -1055,6 +1149,132 @@ extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* strea
                           many ? a->n_vace : (a->vace_context ? 1 : 0), many ? a->vace_contexts : one_ctx, many ? a->vace_scales : one_scale,
                           nag, a->context_batches, a->n_perturbation_layers > 0 ? a->perturbation_layers : nullptr,
                           a->n_perturbation_layers > 0 ? a->n_perturbation_layers : 0, a->x_id, stream);
+}
+
+// ---- the forward as a replayed launch list ("HIP-graph capture per (shape, expert)") -------------------
+// At small L a forward is launch-bound: ~900 launches of a few microseconds each, enqueued one by one from the host (configs[0], the
+// 1.3B model at L = 3,200: the host needs longer to enqueue a step than the GPU to run it).  wan_dit_forward_graph keys a call by
+// everything its launches depend on EXCEPT the timestep -- shapes, every pointer (streams, contexts, outputs, rope tables, workspace),
+// guidance parameters -- runs an unknown key eagerly once (lazy one-time allocations happen there), captures the SAME host code path
+// into a hipGraph at the key's second appearance, and replays it from then on: one hipGraphLaunch per forward.  The timestep is read
+// from device memory (set by a one-float kernel in front of the launch).  The kernels, their arguments and their order are those of
+// the eager path: outputs are bit-identical (tests/test_gpu_model.py).  Not replayed (the call falls through to the eager forward,
+// *how = 0): sequence parallelism (host hooks between launches), per-frame timesteps, step-skipping caches (flags change per step), the
+// mixed-precision plan, profiling on.  The between-blocks poll of the eager path becomes ONE poll in front of the launch -- a forward
+// this small is shorter than a pause request's latency.  *how: 0 eager (not eligible), 1 eager (first sight of the key), 2 captured
+// and launched, 3 replayed.
+template <typename T>
+static void key_put(std::vector<uint8_t>& k, const T& v) {
+  const uint8_t* p = reinterpret_cast<const uint8_t*>(&v);
+  k.insert(k.end(), p, p + sizeof(T));
+}
+
+extern "C" int wan_dit_forward_graph(wan_ctx* c, const wan_dit_args* a, void* stream, int* how) {
+  WAN_REQUIRE(c && a, "wan_dit_forward_graph: null argument");
+  if (how) *how = 0;
+  RC(resolve(c));
+  const bool world1 = a->sp == nullptr || a->sp->world <= 1;
+  if (!world1 || a->n_t_frames != 0 || a->should_calc != nullptr || a->residual != nullptr || c->mixed || g_prof_on || a->S < 1 || a->S > 8 ||
+      a->n_vace > 8 || a->n_perturbation_layers > 64)
+    return wan_dit_forward_ex(c, a, stream);
+  std::vector<uint8_t> key;
+  key_put(key, a->S); key_put(key, a->F); key_put(key, a->H); key_put(key, a->W);
+  for (int s = 0; s < a->S; ++s) {
+    key_put(key, a->x[s]); key_put(key, a->context[s]); key_put(key, a->outs[s]);
+    key_put(key, a->context_batches ? a->context_batches[s] : 1);
+  }
+  key_put(key, a->y); key_put(key, a->cos); key_put(key, a->sin); key_put(key, a->workspace); key_put(key, a->workspace_bytes);
+  key_put(key, a->vace_context); key_put(key, a->vace_scale); key_put(key, a->n_vace);
+  for (int k = 0; k < a->n_vace; ++k) { key_put(key, a->vace_contexts[k]); key_put(key, a->vace_scales[k]); }
+  key_put(key, a->nag_scale); key_put(key, a->nag_tau); key_put(key, a->nag_alpha);
+  key_put(key, a->n_perturbation_layers);
+  for (int k = 0; k < a->n_perturbation_layers; ++k) key_put(key, a->perturbation_layers[k]);
+  key_put(key, a->x_id); key_put(key, c->clip_set);
+  if (a->poll && a->poll(a->poll_user, 0)) return WAN_ABORTED;
+  hipStream_t st = as_stream(stream);
+  if (c->t_dev == nullptr) WAN_CHECK_HIP(hipMalloc((void**)&c->t_dev, 256));
+  RC(wan_set_f32(c->t_dev, a->t, stream));
+  wan_dit_args b = *a;
+  b.poll = nullptr;
+  wan_ctx::GraphEntry* ent = nullptr;
+  for (auto& e : c->graphs)
+    if (e.key == key) ent = &e;
+  if (ent != nullptr && ent->exec != nullptr) {                 // known: one launch
+    ent->last_use = ++c->graph_clock;
+    WAN_CHECK_HIP(hipGraphLaunch(ent->exec, st));
+    if (how) *how = 3;
+    return 0;
+  }
+  if (ent == nullptr) {                                         // first sight: eagerly, through the same t-from-memory path
+    if (c->graphs.size() >= 8) {                                // a handful of live keys (experts x streams layouts); the oldest goes
+      size_t old = 0;
+      for (size_t i = 1; i < c->graphs.size(); ++i)
+        if (c->graphs[i].last_use < c->graphs[old].last_use) old = i;
+      if (c->graphs[old].exec) (void)hipGraphExecDestroy(c->graphs[old].exec);
+      if (c->graphs[old].graph) (void)hipGraphDestroy(c->graphs[old].graph);
+      c->graphs.erase(c->graphs.begin() + (long)old);
+    }
+    wan_ctx::GraphEntry e;
+    e.key = key;
+    e.last_use = ++c->graph_clock;
+    c->graphs.push_back(e);
+    g_t_dev = c->t_dev;
+    const int rc = wan_dit_forward_ex(c, &b, stream);
+    g_t_dev = nullptr;
+    if (how) *how = 1;
+    return rc;
+  }
+  // second sight: capture the launch list on the context's own stream, instantiate, launch on the caller's.  A runtime that refuses
+  // (capture or instantiation error) costs nothing but the replay: nothing captured has run, the call is enqueued eagerly instead,
+  // the key is marked and *how says 1; wan_last_error() keeps the reason.
+  auto eager = [&]() -> int {
+    g_t_dev = c->t_dev;
+    const int rc2 = wan_dit_forward_ex(c, &b, stream);
+    g_t_dev = nullptr;
+    if (how) *how = 1;
+    return rc2;
+  };
+  if (ent->bad) return eager();
+  if (c->cap_stream == nullptr && hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    c->cap_stream = nullptr;
+    ent->bad = true;
+    return eager();
+  }
+  if (hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+    (void)hipGetLastError();
+    ent->bad = true;
+    wan_set_error("wan_dit_forward_graph: hipStreamBeginCapture failed; the forward stays on the eager path");
+    return eager();
+  }
+  g_t_dev = c->t_dev;
+  const int rc = wan_dit_forward_ex(c, &b, c->cap_stream);
+  g_t_dev = nullptr;
+  hipGraph_t graph = nullptr;
+  const hipError_t ec = hipStreamEndCapture(c->cap_stream, &graph);
+  if (rc != 0) {                                                 // the forward itself refused its arguments: that is the caller's error
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return rc;
+  }
+  hipGraphExec_t exec = nullptr;
+  hipError_t ei = ec;
+  if (ec == hipSuccess && graph != nullptr) ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (ec != hipSuccess || graph == nullptr || ei != hipSuccess || exec == nullptr) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    ent->bad = true;
+    const int rc2 = eager();
+    wan_set_error("wan_dit_forward_graph: capture / instantiation failed (%s); the forward stays on the eager path",
+                  hipGetErrorString(ec != hipSuccess ? ec : ei));
+    return rc2;
+  }
+  ent->graph = graph;
+  ent->exec = exec;
+  ent->last_use = ++c->graph_clock;
+  WAN_CHECK_HIP(hipGraphLaunch(exec, st));
+  if (how) *how = 2;
+  return 0;
 }
 
 extern "C" int wan_dit_set_vace_contexts(wan_ctx* c, int n) {

@@ -723,6 +723,12 @@ extern "C" int wan_sinusoid(const float* t, wan_bf16* out, int n, int dim, void*
   return 0;
 }
 
+__global__ void set_f32_kernel(float* p, float v) { *p = v; }
+int wan_set_f32(float* p, float v, void* stream) {   // (internal: the timestep of a replayed forward, csrc/dit.hip wan_dit_forward_graph)
+  hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(1), 0, as_stream(stream), p, v);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
 int wan_sinusoid_val(float t, bf16_t* out, int dim, void* stream) {
   hipLaunchKernelGGL(sinusoid_val_kernel, dim3((dim / 2 + 255) / 256), dim3(256), 0, as_stream(stream), t, out, dim);
   WAN_LAUNCH_CHECK();
@@ -806,6 +812,30 @@ extern "C" int wan_permute16(const void* src, void* dst, int64_t A, int64_t B, i
   if (total == 0) return 0;
   const int64_t blocks = std::min<int64_t>((total + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(permute16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const uint4*)src, (uint4*)dst, A, B, bytes / 16);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void permute16_ex_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t A, int64_t B, int64_t n16,
+                                                           int64_t sa, int64_t sb, int64_t da, int64_t db) {
+  const int64_t total = A * B * n16, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {  // (b, a, piece) with the piece fastest: 16-byte accesses, coalesced within a piece
+    const int64_t c = i % n16, ba = i / n16;
+    const int64_t a = ba % A, b = ba / A;
+    dst[b * db + a * da + c] = src[a * sa + b * sb + c];
+  }
+}
+extern "C" int wan_permute16_ex(const void* src, void* dst, int64_t A, int64_t B, int64_t bytes, int64_t src_a_pitch, int64_t src_b_pitch,
+                                int64_t dst_a_pitch, int64_t dst_b_pitch, void* stream) {
+  WAN_REQUIRE(src && dst && src != dst, "wan_permute16_ex: null or aliased pointers");
+  WAN_REQUIRE(A >= 0 && B >= 0 && bytes >= 0 && ((bytes | src_a_pitch | src_b_pitch | dst_a_pitch | dst_b_pitch) & 15) == 0,
+              "wan_permute16_ex: bytes=%lld and the pitches must be multiples of 16", (long long)bytes);
+  WAN_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "wan_permute16_ex: pointers must be 16-byte aligned");
+  const int64_t total = A * B * (bytes / 16);
+  if (total == 0) return 0;
+  const int64_t blocks = std::min<int64_t>((total + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(permute16_ex_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (const uint4*)src, (uint4*)dst, A, B, bytes / 16,
+                     src_a_pitch / 16, src_b_pitch / 16, dst_a_pitch / 16, dst_b_pitch / 16);
   WAN_LAUNCH_CHECK();
   return 0;
 }

@@ -57,7 +57,22 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(float* __restrict__ out
       for (int r = 0; r < 16; ++r) s += acc[i][j][r];
   if (s == 12345.678f) out[0] = s;  // keeps the accumulators alive; practically never true
 }
+// one lane spinning on the 100 MHz constant clock (s_memrealtime): occupies a stream for `ticks` x 10 ns and nothing else of the chip
+__global__ void delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 }  // namespace
+
+// Measurement aid (bench.py `simulated_scaling`, the link model): keeps `stream` busy for `microseconds` without using the chip -- the
+// transfer time of an exchange over xGMI (bytes / link rate) behind the device-to-device copy that stands in for it on one GPU.
+extern "C" int wan_debug_delay(double microseconds, void* stream) {
+  WAN_REQUIRE(microseconds >= 0.0 && microseconds <= 5e6, "wan_debug_delay: %g us outside [0, 5 s]", microseconds);
+  if (microseconds == 0.0) return 0;
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, as_stream(stream), (long long)(microseconds * 100.0));
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
 
 // Enqueues `iters` x 64 MFMAs per wave on every CU (iters = 40,000 is ~50 ms); *flop_out = the FLOP the launch performs.
 extern "C" int wan_mfma_sustained_probe(int iters, double* flop_out, void* stream) {

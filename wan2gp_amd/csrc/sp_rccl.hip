@@ -72,7 +72,7 @@ const Api& api() {
     }                                                                                               \
   } while (0)
 
-constexpr int kSlots = 5;   // 0..3: the per-block exchanges (k, v^T, q, o); 4: wan_sp_all_gather
+constexpr int kSlots = 2 + 2 * WAN_SP_MAX_CHUNKS + 1;   // 0, 1: k, v^T; 2 .. 1 + 2 C: the q and o chunks of a block; the last: wan_sp_all_gather
 
 }  // namespace
 

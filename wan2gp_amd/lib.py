@@ -50,7 +50,7 @@ SP_ALLGATHER, SP_ULYSSES = 0, 1
 class SpInfo(ctypes.Structure):
     _fields_ = [("rank", c_int), ("world", c_int), ("tok0", c_int64), ("tok_local", c_int64),
                 ("gather_begin", GATHER_FN), ("gather_wait", GATHER_WAIT_FN), ("user", c_void_p),
-                ("mode", c_int), ("a2a_begin", GATHER_FN), ("a2a_wait", GATHER_WAIT_FN)]
+                ("mode", c_int), ("a2a_begin", GATHER_FN), ("a2a_wait", GATHER_WAIT_FN), ("a2a_chunks", c_int)]
 
 
 # name -> (restype, argtypes); the single source of truth mirrored by tests/test_abi.py
@@ -96,6 +96,7 @@ SIGNATURES = {
     "wan_vae22_dupup_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_dit_set_clip": (c_int, [c_void_p, c_void_p, c_void_p]),
     "wan_dit_forward_ex": (c_int, [c_void_p, POINTER(DitArgs), c_void_p]),
+    "wan_dit_forward_graph": (c_int, [c_void_p, POINTER(DitArgs), c_void_p, POINTER(c_int)]),
     "wan_dit_set_vace_layers": (c_int, [c_void_p, POINTER(c_int), c_int]),
     "wan_dit_set_vace_contexts": (c_int, [c_void_p, c_int]),
     "wan_axpy_bf16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
@@ -125,6 +126,7 @@ SIGNATURES = {
     "wan_sp_gather_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "wan_sp_a2a_begin": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_permute16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "wan_permute16_ex": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "wan_vae_conv3d_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p] + [c_int] * 17 + [c_void_p]),
     "wan_vae_rmsnorm_silu_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "wan_gemm_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
@@ -166,6 +168,7 @@ SIGNATURES = {
     "wan_prof_collect": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(c_int)]),
     "wan_prof_attention_declined": (c_int, [POINTER(c_int64), POINTER(c_int64)]),
     "wan_mfma_sustained_probe": (c_int, [c_int, POINTER(c_double), c_void_p]),
+    "wan_debug_delay": (c_int, [c_double, c_void_p]),
     "wan_attention_count_declined": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "wan_dit_create": (c_int, [POINTER(DitConfig), POINTER(c_void_p)]),
     "wan_dit_destroy": (None, [c_void_p]),

@@ -62,6 +62,14 @@ class WanModelHIP:
             raise NotImplementedError("mixed_precision: the fp32-stream plan serves the t2v / i2v2_2 / ti2v2_2 block chain; VACE context blocks "
                                       "and the Wan2.1 i2v CLIP branch run in the bf16 plan only")
         self.cache = None
+        # the forward as a replayed launch list (wan_dit_forward_graph, csrc/dit.hip): "auto" = when the joint pass holds at most
+        # graph_max_tokens tokens (launch-bound shapes: BASELINE configs[0] is 6,400; 480p x 81 frames is 65,520), "on" / "off";
+        # last_graph_how = what the last forward did (0 eager, 1 eager first sight, 2 captured, 3 replayed)
+        self.graph = "auto"
+        self.graph_max_tokens = 16384
+        self.last_graph_how = 0
+        self._graph_stage = {}
+        self._rope_cache = {}
         self.reference_module = None      # optional: the reference nn.Module to delegate variant calls to
         self.sp = None                    # optional sequence-parallel group (wan2gp_amd.sp.SequenceParallel)
         # normalized attention guidance (NAG_scale, NAG_tau, NAG_alpha), set by generate() (any2video.py:607); None: read
@@ -257,8 +265,12 @@ class WanModelHIP:
         tval = float(tflat[0].item())
         t_frames = (ctypes.c_float * F)(*[float(v) for v in tflat]) if tflat.numel() == F and F > 1 else None
         yy = None if y is None else y.to(device=dev, dtype=torch.float32).contiguous()
-        if freqs is None:
-            freqs = get_rotary_pos_embed((F, H, W))
+        if freqs is None:                                   # (kept per shape: a replayed launch list needs the tables where they were)
+            if (F, H, W) not in self._rope_cache:
+                if len(self._rope_cache) >= 4:
+                    self._rope_cache.clear()
+                self._rope_cache[(F, H, W)] = tuple(f.to(device=dev, dtype=torch.float32).contiguous() for f in get_rotary_pos_embed((F, H, W)))
+            freqs = self._rope_cache[(F, H, W)]
         cos, sin = (f.to(device=dev, dtype=torch.float32).contiguous() for f in freqs)
 
         sp = self.sp if (self.sp is not None and self.sp.world > 1) else None   # a group of one shards nothing: the plain forward
@@ -271,7 +283,7 @@ class WanModelHIP:
         else:
             outs = [torch.empty(1, L // shards, 4 * self.out_dim, dtype=torch.float32, device=dev) for _ in range(S)]
             sp.bind_workspace(ws)
-            sp_struct = ctypes.byref(sp.make_info(L))
+            sp_struct = ctypes.byref(sp.make_info(L, heads=self.num_heads))
 
         def _poll(user, block_idx):
             try:
@@ -319,7 +331,24 @@ class WanModelHIP:
         slg = [int(v) for v in perturbation_layers] if perturbation_layers is not None else []
         if any(v < 0 or v >= self.num_layers for v in slg):
             raise _L.WanHipError(f"perturbation_layers {slg} outside [0, {self.num_layers})")
-        if vace_ts is not None or t_frames is not None or nag is not None or slg:
+        use_graph = (self.graph == "on" or (self.graph == "auto" and S * L <= self.graph_max_tokens)) and sp is None and cache is None \
+            and t_frames is None and not self.mixed_precision and vace_ts is None and callback is None   # (a per-block callback keeps its contract: eager)
+        self.last_graph_how = 0
+        if use_graph:
+            # stable addresses for what changes from step to step (the scheduler hands new latent tensors, the outputs are fresh
+            # allocations): staging copies of a few hundred KB; contexts / y / rope tables are the caller's own long-lived tensors
+            key = (S, C, F, H, W)
+            if key not in self._graph_stage:
+                if len(self._graph_stage) >= 4:
+                    self._graph_stage.clear()
+                self._graph_stage[key] = ([torch.empty(1, C, F, H, W, dtype=torch.float32, device=dev) for _ in range(S)],
+                                          [torch.empty(1, self.out_dim, F, H, W, dtype=torch.float32, device=dev) for _ in range(S)])
+            sx, so = self._graph_stage[key]
+            for a_, b_ in zip(sx, xs):
+                a_.copy_(b_)
+            XP = (c_void_p * S)(*[a_.data_ptr() for a_ in sx])
+            OP = (c_void_p * S)(*[a_.data_ptr() for a_ in so])
+        if use_graph or vace_ts is not None or t_frames is not None or nag is not None or slg:
             nv = 0 if vace_ts is None else len(vace_ts)
             for u in vace_ts or ():
                 if tuple(u.shape) != (self.vace_in_dim, F, H, W):
@@ -331,7 +360,13 @@ class WanModelHIP:
                            None, 1.0, t_frames, F if t_frames is not None else 0, nv, VP, VS,
                            *((0.0, 0.0, 0.0, None) if nag is None else (*nag, (ctypes.c_int * S)(*ctx_batches))),
                            (ctypes.c_int * len(slg))(*slg) if slg else None, len(slg), int(x_id))
-            rc = _L.load().wan_dit_forward_ex(self._ctx, ctypes.byref(a), stream_ptr())
+            if use_graph:
+                how = ctypes.c_int(0)
+                rc = _L.load().wan_dit_forward_graph(self._ctx, ctypes.byref(a), stream_ptr(), ctypes.byref(how))
+                self.last_graph_how = how.value
+                outs = [o.clone() for o in so] if rc == 0 else outs
+            else:
+                rc = _L.load().wan_dit_forward_ex(self._ctx, ctypes.byref(a), stream_ptr())
         elif cache is None:
             rc = _L.load().wan_dit_forward(self._ctx, S, XP, tval, CP, ptr(yy), ptr(cos), ptr(sin), OP, F, H, W, ptr(ws),
                                            ws.numel(), sp_struct, poll, None, stream_ptr())

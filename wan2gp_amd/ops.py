@@ -176,6 +176,17 @@ def permute16(src, A, B):
     return out
 
 
+def permute16_ex(src, dst, A, B, nbytes, src_a_pitch, src_b_pitch, dst_a_pitch, dst_b_pitch):
+    """dst[b * dst_b_pitch + a * dst_a_pitch + i] = src[a * src_a_pitch + b * src_b_pitch + i], a < A, b < B, i < nbytes (all in BYTES,
+    multiples of 16; wan_permute16_ex: the per-head-chunk re-packs of the chunked Ulysses exchange).  src / dst: CUDA tensors whose
+    data pointers are the bases (pass slices for offsets); the caller guarantees the extents."""
+    if not (src.is_cuda and dst.is_cuda):
+        raise _L.WanHipError("permute16_ex: CUDA tensors are required")
+    check(_L.load().wan_permute16_ex(ptr(src), ptr(dst), A, B, nbytes, src_a_pitch, src_b_pitch, dst_a_pitch, dst_b_pitch, stream_ptr()),
+          "wan_permute16_ex")
+    return dst
+
+
 def transpose_v(v, ldv=None):
     """[B,L,H,128] (or [B,L,C]) -> V^T [B, C, ldv] with zero padding."""
     _req(v, BF16, "v")

@@ -39,12 +39,16 @@ class SequenceParallel:
     mode "ulysses": per block four all-to-alls re-shard q, k, v^T from "my tokens, all heads" to "all tokens, my heads" and o back
     (wan_dit_forward with WAN_SP_ULYSSES, csrc/dit.hip): one attention launch at full L for H / world heads; 4 (world - 1) / world
     shard-sized transfers per block and rank instead of 2 (world - 1); needs H % world == 0 (14B: 40 heads -> 2, 4, 8; 1.3B: 12
-    heads -> 2, 4).  Everything outside self-attention is identical in both modes."""
+    heads -> 2, 4).  Everything outside self-attention is identical in both modes.
+    `chunks` (ulysses): head chunks of the q / o exchanges (wan_sp_info.a2a_chunks, csrc/dit.hip): chunk c's attention launch runs
+    while q chunk c + 1 arrives and o chunk c - 1 returns; None = 2 when a rank holds >= 4 heads (14B at 2 / 4 / 8 ranks: 20 / 10 / 5
+    heads -> launches of 10 / 5 / 2-3 heads still fill the chip: DESIGN.md section 6), else 1; results are bit-identical for every value."""
 
-    def __init__(self, rank: int, world: int, group=None, native: bool = False, mode: str = "allgather"):
+    def __init__(self, rank: int, world: int, group=None, native: bool = False, mode: str = "allgather", chunks=None):
         if mode not in ("allgather", "ulysses"):
             raise ValueError(f"SequenceParallel: mode {mode!r} is not 'allgather' or 'ulysses'")
         self.rank, self.world, self.group, self.mode = rank, world, group, mode
+        self.chunks = chunks
         self.a2a_bytes = 0          # bytes this rank SENT to other ranks through the Ulysses exchanges (bench: per block and rank)
         self._ws = None
         self._cb = None
@@ -171,22 +175,32 @@ class SequenceParallel:
             traceback.print_exc()
             return 1
 
-    def make_info(self, L: int) -> SpInfo:
+    def resolved_chunks(self, heads=None) -> int:
+        """Head chunks a Ulysses block of a model with `heads` heads runs with (the library clamps to [1, min(heads / world, 8)])."""
+        if self.mode != "ulysses":
+            return 1
+        hn = (heads // self.world) if heads else None
+        c = self.chunks if self.chunks is not None else (2 if (hn is None or hn >= 4) else 1)
+        c = max(1, min(int(c), 8))
+        return c if hn is None else max(1, min(c, hn))
+
+    def make_info(self, L: int, heads=None) -> SpInfo:
         tok0, n = shard_range(L, self.rank, self.world)
         mode = SP_ULYSSES if self.mode == "ulysses" else SP_ALLGATHER
+        chunks = self.resolved_chunks(heads)
         if self._native is not None:                          # the library's own hooks: no Python in the block loop
             if self._cb is None:
                 self._cb = ctypes.cast(self._lib.wan_sp_gather_begin, GATHER_FN)
                 self._cbw = ctypes.cast(self._lib.wan_sp_gather_wait, GATHER_WAIT_FN)
                 self._cba = ctypes.cast(self._lib.wan_sp_a2a_begin, GATHER_FN)
-            self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, self._native, mode, self._cba, self._cbw)
+            self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, self._native, mode, self._cba, self._cbw, chunks)
             return self._info
         if self._cb is None:
             self._cb = GATHER_FN(self._gather_begin_cb)      # keep the ctypes thunks alive
             self._cbw = GATHER_WAIT_FN(self._gather_wait_cb)
             self._cba = GATHER_FN(self._a2a_begin_cb)
             self._cbaw = GATHER_WAIT_FN(self._a2a_wait_cb)
-        self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, None, mode, self._cba, self._cbaw)
+        self._info = SpInfo(self.rank, self.world, tok0, n, self._cb, self._cbw, None, mode, self._cba, self._cbaw, chunks)
         return self._info
 
     def gather_output(self, tok_major: torch.Tensor, grid):
@@ -214,7 +228,7 @@ class CfgParallel:
 
     `new_group` is collective over ALL ranks and must run in the same order everywhere: every rank creates every group here."""
 
-    def __init__(self, rank: int, world: int, native: bool = False, mode: str = "allgather"):
+    def __init__(self, rank: int, world: int, native: bool = False, mode: str = "allgather", chunks=None):
         if world < 2 or world % 2:
             raise ValueError(f"CFG parallelism splits the world in two halves: world size {world} is not a positive even number")
         self.rank, self.world, self.half = rank, world, world // 2
@@ -223,7 +237,7 @@ class CfgParallel:
         halves = [dist.new_group(list(range(s * self.half, (s + 1) * self.half))) if self.half > 1 else None for s in (0, 1)]
         pairs = [dist.new_group([i, i + self.half]) for i in range(self.half)]
         self.pair = pairs[self.sp_rank]                      # {i, i + k}: group rank 0 = conditional, 1 = unconditional
-        self.sp = SequenceParallel(self.sp_rank, self.half, group=halves[self.stream], native=native, mode=mode) if self.half > 1 else None
+        self.sp = SequenceParallel(self.sp_rank, self.half, group=halves[self.stream], native=native, mode=mode, chunks=chunks) if self.half > 1 else None
 
     def attach(self, *models):
         """The half's sequence-parallel group on every resident expert (None for a world of 2)."""
