@@ -535,10 +535,19 @@ int wan_mx_ln_modulate(const float* x, wan_bf16* out, const wan_bf16* mod, const
                        int64_t rows, int64_t rows_per_batch, int d, float eps, void* stream);
 /* norm3 with its fp32 weight and bias (model.py:664-665; WanLayerNorm.forward :199-212): out = bf16( LN(x) * w + b ). */
 int wan_mx_ln_affine(const float* x, wan_bf16* out, const float* w, const float* b, int64_t rows, int d, float eps, void* stream);
+/* Test hook: on != 0 keeps wan_mx_ln_modulate / wan_mx_ln_affine on the generic row form (the row re-read from L2 for the second and
+ * third pass) at every width; the register-resident form they take at the Wan widths must give the same bits. */
+void wan_mx_debug_generic_rows(int on);
 /* x.addcmul_(y, e[gate_idx]) (model.py:658, :708) on the fp32 stream, y the bf16 result of a Linear: x += y * (float(mod[gate_idx]) +
  * e0[b][gate_idx]) with the product rounded first; gate_idx < 0: x += y (the cross-attention residual, :668; mod, e0 unused). */
 int wan_mx_gated_residual(float* x, const wan_bf16* y, const wan_bf16* mod, const float* e0, int n_mod, int gate_idx, int64_t rows,
                           int64_t rows_per_batch, int d, void* stream);
+/* A bf16 Linear and that update in ONE launch (round 5): x (fp32, in place) += bf16(A W^T + bias) * gate on the accumulators of the
+ * 256 x 256 tile GEMM -- what wan_dit_forward runs for the o projections and ffn.2 of the mixed plan with bf16 weights.  `tmp`
+ * [M, N] bf16 is used only when the shape does not fit that kernel (then: wan_gemm_bf16 into tmp + wan_mx_gated_residual).
+ * Bit-identical to the two-launch form. */
+int wan_gemm_bf16_res32(const wan_bf16* A, int64_t lda, const wan_bf16* W, const wan_bf16* bias, float* x, wan_bf16* tmp, int64_t M, int N,
+                        int K, const wan_bf16* mod, const float* e0, int n_mod, int gate_idx, int64_t rows_per_batch, void* stream);
 /* patch_embedding(x).to(fp32) (model.py:1620-1631; i2v: y concatenated behind x's channels, :1597-1600): the fp32 Conv3d with
  * kernel = stride = (1, 2, 2), result left in fp32.  x [Cin, F, H, W], y [Cy, F, H, W] or NULL, w [d, Cin + Cy, 1, 2, 2], out
  * [ntok, d] = tokens tok0 .. tok0 + ntok of the f-major grid. */

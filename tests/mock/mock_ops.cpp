@@ -132,6 +132,10 @@ int wan_gemv_bf16(const wan_bf16* A, const wan_bf16* W, const wan_bf16* bias, wa
 }
 int wan_add_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void*) { return rec("add", {a, b, out}, {n}); }
 int wan_sub_bf16(const wan_bf16* a, const wan_bf16* b, wan_bf16* out, int64_t n, void*) { return rec("sub", {a, b, out}, {n}); }
+int wan_gemm_bf16_res32(const wan_bf16* A, int64_t lda, const wan_bf16* W, const wan_bf16* bias, float* x, wan_bf16* tmp, int64_t M, int N, int K,
+                        const wan_bf16* mod, const float* e0, int n_mod, int gate_idx, int64_t rpb, void*) {
+  return rec("gemm_res32", {A, W, bias, x, tmp, mod, e0}, {M, N, K, lda, n_mod, gate_idx, rpb});
+}
 int wan_lincomb(float* out, int n_in, const float* const* in, const float* coef, int64_t n, void*) {
   return rec("lincomb", {out, in[0], n_in > 1 ? in[1] : nullptr}, {n, n_in}, {coef[0], n_in > 1 ? coef[1] : 0.0});
 }

@@ -219,9 +219,11 @@ def test_mixed_precision_plan_launch_order_pointers_and_refusals(mock):
     assert [l[1][1] for l in lins] == [m.addr["time_embedding.0.weight"], m.addr["time_embedding.2.weight"], m.addr["time_projection.1.weight"]]
     assert lins[0][1][3] == lins[1][1][0] and lins[1][1][3] == lins[2][1][0]          # sinusoid -> hidden -> e -> e0, chained
     first_block = names.index("mx_ln_modulate")
-    per_layer = ["mx_ln_modulate", "gemm", "gemm", "gemm", "gemm", "rmsnorm_rope", "attention", "gemm", "mx_gated_residual",
-                 "mx_ln_affine", "gemm", "rmsnorm_rope", "gemm", "rmsnorm_rope", "gemm", "gemm", "attention", "gemm", "mx_gated_residual",
-                 "mx_ln_modulate", "gemm", "gemm", "mx_gated_residual"]
+    # (round 5: the three Linears that feed the fp32 stream carry the update in their epilogue -- wan_gemm_bf16_res32 -- instead of a
+    # Linear into xm followed by a separate wan_mx_gated_residual pass; xm stays the buffer of the shape fall-back)
+    per_layer = ["mx_ln_modulate", "gemm", "gemm", "gemm", "gemm", "rmsnorm_rope", "attention", "gemm_res32",
+                 "mx_ln_affine", "gemm", "rmsnorm_rope", "gemm", "rmsnorm_rope", "gemm", "gemm", "attention", "gemm_res32",
+                 "mx_ln_modulate", "gemm", "gemm_res32"]
     body = names[first_block:first_block + len(per_layer) * c.num_layers]
     assert body == per_layer * c.num_layers
     assert names[first_block + len(per_layer) * c.num_layers:] == ["mx_head", "unpatchify", "mx_head", "unpatchify"]
@@ -231,11 +233,13 @@ def test_mixed_precision_plan_launch_order_pointers_and_refusals(mock):
     e0 = blk[0][1][3]
     assert x32 == WS                                                        # the residual stream is the first region of the workspace
     gemms = [cl for cl in blk if cl[0] == "gemm"]
-    assert all(g[2][5] in (0, 1, 3) for g in gemms)                         # no fused residual epilogue (2) in this plan
-    res = [cl for cl in blk if cl[0] == "mx_gated_residual"]
-    assert [r[2][3] for r in res] == [2, -1, 5] and all(r[1][0] == x32 and r[1][1] == xm for r in res)
-    assert [g[1][3] for g in (gemms[4], gemms[9], gemms[11])] == [xm, xm, xm]          # self o, cross o, ffn.2 -> xm
-    assert res[0][1][2] == m.addr["blocks.1.modulation"] and res[0][1][3] == e0 and res[1][1][2] == 0
+    assert all(g[2][5] in (0, 1, 3) for g in gemms)                         # no bf16 fused residual epilogue (2) in this plan
+    res = [cl for cl in blk if cl[0] == "gemm_res32"]
+    assert [r[2][5] for r in res] == [2, -1, 5] and all(r[1][3] == x32 and r[1][4] == xm for r in res)     # gates; x updated in place, xm = fall-back buffer
+    assert [(r[2][0], r[2][1], r[2][2]) for r in res] == [(2 * Ll, c.dim, c.dim), (2 * Ll, c.dim, c.dim), (2 * Ll, c.dim, c.ffn_dim)]
+    assert [r[1][1] for r in res] == [m.addr["blocks.1.self_attn.o.weight"], m.addr["blocks.1.cross_attn.o.weight"], m.addr["blocks.1.ffn.2.weight"]]
+    assert res[0][1][5] == m.addr["blocks.1.modulation"] and res[0][1][6] == e0 and res[1][1][5] == 0 and res[2][1][6] == e0
+    assert not [cl for cl in calls if cl[0] == "mx_gated_residual"]
     aff = [cl for cl in blk if cl[0] == "mx_ln_affine"][0]
     assert aff[1][0] == x32 and aff[1][2] == m.addr["blocks.1.norm3.weight"] and aff[1][3] == m.addr["blocks.1.norm3.bias"]
     mods = [cl for cl in blk if cl[0] == "mx_ln_modulate"]

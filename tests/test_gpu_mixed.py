@@ -56,6 +56,15 @@ def test_mixed_row_kernels(d):
             ref.append(v.to(BF))
         bf16_close(MX.ln_modulate(x.cuda(), mod.cuda(), e0.cuda(), sh, sc), torch.cat(ref), f"mx ln_modulate {sh},{sc}")
     bf16_close(MX.ln_affine(x.cuda(), w.cuda(), b.cuda()), O.layer_norm(x, 1e-6, w, b).to(BF), "mx ln_affine")
+    # round 5: at these widths the row lives in registers (one read instead of three) -- the same bits as the generic re-reading form
+    from wan2gp_amd import lib as L_
+    fast = (MX.ln_modulate(x.cuda(), mod.cuda(), e0.cuda(), 3, 4), MX.ln_affine(x.cuda(), w.cuda(), b.cuda()))
+    L_.load().wan_mx_debug_generic_rows(1)
+    try:
+        slow = (MX.ln_modulate(x.cuda(), mod.cuda(), e0.cuda(), 3, 4), MX.ln_affine(x.cuda(), w.cuda(), b.cuda()))
+    finally:
+        L_.load().wan_mx_debug_generic_rows(0)
+    assert torch.equal(fast[0], slow[0]) and torch.equal(fast[1], slow[1])
     ref = torch.cat([torch.addcmul(x[bi:bi + 1], y[bi:bi + 1].float(), (mod + e0[bi:bi + 1]).chunk(6, dim=1)[2]) for bi in range(B)])
     xx = x.clone().cuda()
     MX.gated_residual_(xx, y.cuda(), mod.cuda(), e0.cuda(), 2)
@@ -63,6 +72,40 @@ def test_mixed_row_kernels(d):
     xx = x.clone().cuda()
     MX.gated_residual_(xx, y.cuda())
     assert torch.equal(xx.cpu(), x + y.float())
+
+
+@pytest.mark.parametrize("M,N,K,gate,batches", [(2 * 18944, 5120, 5120, 2, 2), (2 * 18944, 5120, 5120, -1, 1), (2 * 18900, 5120, 13824, 5, 2),
+                                                (65536, 1536, 8960, 5, 1), (300, 512, 512, 2, 1), (2 * 18900, 5120, 5120, 2, 42)],
+                         ids=["o_gate_14B_two_streams", "cross_o_ungated", "ffn2_14B_ragged_last_tile", "ffn2_1.3B", "fallback_small", "per_frame_batches_of_900_rows"])
+def test_linear_with_fp32_gated_residual_epilogue(M, N, K, gate, batches):
+    """wan_gemm_bf16_res32 (round 5): the mixed plan's Linear + x.addcmul_(y, gate) as the tile GEMM's epilogue -- BIT-IDENTICAL to the
+    two-launch form it replaces (wan_gemm_bf16 NONE into a bf16 tensor, then wan_mx_gated_residual), at the 14B / 1.3B shapes (a batch
+    boundary inside a tile, a ragged last tile), on a shape that takes the fall-back, and with per-frame batches shorter than a tile
+    (fall-back as well); and against an fp64 evaluation on sampled rows."""
+    from wan2gp_amd import mixed_ops as MX, ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + gate)
+    a = torch.randn(M, K, device="cuda", generator=g).to(BF)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(BF)
+    b = (0.1 * torch.randn(N, device="cuda", generator=g)).to(BF)
+    x0 = torch.randn(M, N, device="cuda", generator=g) * 3
+    mod = (torch.randn(1, 6, N, device="cuda", generator=g) / N ** 0.5).to(BF)
+    e0 = 0.5 * torch.randn(batches, 6, N, device="cuda", generator=g)
+    want = x0.clone()
+    y = ops.linear(a, w, b)
+    MX.gated_residual_(want, y, mod if gate >= 0 else None, e0 if gate >= 0 else None, gate)
+    got = x0.clone()
+    MX.linear_gated_residual_(got, a, w, b, mod if gate >= 0 else None, e0 if gate >= 0 else None, gate)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), f"{(got != want).float().mean().item():.3e} of the elements differ, worst {(got - want).abs().max().item()}"
+    rows = torch.cat([torch.arange(0, 4), torch.arange(M - 4, M), torch.arange(M // batches - 2, M // batches + 2) % M,
+                      torch.randperm(M, generator=torch.Generator().manual_seed(1))[:120]]).cuda()
+    acc = a[rows].double() @ w.double().t() + b.double()
+    yb = acc.float().to(BF).double()
+    gt = (mod[0, gate].double() + e0[(rows // (M // batches)).clamp(max=batches - 1), gate].double()) if gate >= 0 else 1.0
+    ref = x0[rows].double() + yb * gt
+    err = (got[rows].double() - ref).abs()
+    tol = (yb.abs() * 2.0 ** -7 * (gt.abs() if gate >= 0 else 1.0) + 1e-5)            # the Linear's bf16 rounding may fall either way by one ulp
+    assert (err <= tol).all(), (err / tol).max().item()
 
 
 @pytest.mark.parametrize("name,fhw", [("tiny", (3, 8, 12)), ("tiny_i2v", (2, 8, 8)), ("tiny_ti2v", (2, 6, 10))])

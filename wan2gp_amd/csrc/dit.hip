@@ -761,6 +761,14 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   }
   auto& b = b2;
   // one WanAttentionBlock (model.py:575-724) on the token streams at b.x, with the weights Lw
+  // mixed-precision plan: a Linear whose bf16 result is added to the fp32 stream -- x += y * gate.  bf16 weights: ONE launch, the update
+  // in the GEMM's epilogue (wan_gemm_bf16_res32; round 5); scaled-fp8 weights: the Linear into xm, then the separate pass
+  auto linear_res32 = [&](const bf16_t* A, const Lin& l, float* xf, bf16_t* tmp, int64_t M, int N, int K, const bf16_t* mod, const float* e0g,
+                          int gate, int64_t rpb_, int nt_) -> int {
+    if (l.w8 == nullptr) return wan_gemm_bf16_res32(A, K, l.w, l.b, xf, tmp, M, N, K, mod, e0g, 6, gate, rpb_, stream);
+    RC(linear(A, l, tmp, M, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, nt_));
+    return wan_mx_gated_residual(xf, tmp, gate >= 0 ? mod : nullptr, gate >= 0 ? e0g : nullptr, 6, gate, M, rpb_, N, stream);
+  };
   auto run_layer = [&](const Layer& Lw) -> int {
     // -- self attention (model.py:632-660) --
     // mixed-precision plan (mx): b.x holds fp32 rows; modulate / norm3 / the gated residuals are the fp32 kernels of mixed_ops.hip, each
@@ -936,8 +944,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     // (attention.hip hands the scratch to the kernels only for long KV -- Lk > 2048: for shorter sequences the flags are never written)
     if (!ulysses && g_prof_on && g_prof_declined != nullptr && b.kmax != nullptr && Ll > 2048) RC(wan_attention_count_declined(b.kmax, S, S, Ll, nh, g_prof_declined, stream));
     if (mx) {
-      RC(linear(b.q, Lw.self.o, b.xm, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
-      RC(wan_mx_gated_residual(xf, b.xm, Lw.mod, e0f, 6, 2, rows, rpb, d, stream));
+      RC(linear_res32(b.q, Lw.self.o, xf, b.xm, rows, d, d, Lw.mod, e0f, 2, rpb, S));
     } else {
       RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb, 0, q8, S));
     }
@@ -1011,8 +1018,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }
     if (mx) {
-      RC(linear(b.q, Lw.cross.o, b.xm, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
-      RC(wan_mx_gated_residual(xf, b.xm, nullptr, nullptr, 6, -1, rows, rpb, d, stream));
+      RC(linear_res32(b.q, Lw.cross.o, xf, b.xm, rows, d, d, nullptr, nullptr, -1, rpb, S));
     } else {
       RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb, 0, q8, S));
     }
@@ -1022,10 +1028,9 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     {
       ProfScope ps(PROF_GEMM, st);  // the two FFN GEMMs: 4*rows*d*ffn FLOP
       RC(linear(b.xm, Lw.f0, b.h, rows, ffn, d, WAN_EPI_GELU_TANH, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
-      if (mx) RC(linear(b.h, Lw.f2, b.xm, rows, d, ffn, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      if (mx) RC(linear_res32(b.h, Lw.f2, xf, b.xm, rows, d, ffn, Lw.mod, e0f, 5, rpb, S));
       else RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb, 0, q8, S));
     }
-    if (mx) RC(wan_mx_gated_residual(xf, b.xm, Lw.mod, e0f, 6, 5, rows, rpb, d, stream));
     return 0;
   };
   for (int i = l0; i < l1; ++i) {

@@ -37,6 +37,11 @@ typedef uint32_t g256m_u4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const g256m_u4 g256m_lds_u4;
 
 constexpr int M_BM = 256, M_BN = 256, M_BK = 64;
+// internal epilogue id (not in the public enum: reached through wan_gemm_bf16_res32): the mixed-precision plan's gated residual --
+// Out is the FP32 residual stream, updated in place: x += bf16(acc + bias) * (mod[gate] + e0[batch][gate]) with an fp32 gate from a
+// bf16 modulation row and an fp32 e0 row (mixed_ops.hip mx_gated_residual_kernel's arithmetic on the accumulators: one pass less
+// over 6 bytes per element, three times per block)
+constexpr int M_EPI_RES32 = 4;
 constexpr int M_UNIT = 256 * M_BK * 2;  // 32 KiB: one operand of one stage (256 rows x 128 B)
 constexpr int M_NU = 5;                  // ring of five units: unit u (Y_S = 2S, X_S = 2S+1) lives in slot u % 5
 
@@ -241,7 +246,83 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
   // Lane (n, g), y tile a, register i: row wy*128 + 16 a + 4 g + i, columns wx*128 + 8 n .. + 7 (one register of each of the eight
   // x tiles).  Stores (and the residual loads of the gated form) go through a buffer descriptor over the tile's rows of Out: rows
   // past the matrix fall outside num_records and are dropped / read as zero by the hardware -- no per-row predicate.
-  {
+  if constexpr (EPI == M_EPI_RES32) {
+    // the fp32 residual stream: a lane's 8 columns are 32 bytes of a row (two 16-byte accesses), read, updated and written back by
+    // the same lane; the next chunk's rows are in flight while this one is converted
+    float* X32 = reinterpret_cast<float*>(Out);
+    const float* e32 = reinterpret_cast<const float*>(e);
+    uint32_t lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const uint32_t ne = lane_e & 15u, ge = lane_e >> 4;
+    const uint32_t colb = (uint32_t)(wx * 128) * 2u + ne * 16u;   // bf16 vectors (bias, modulation)
+    const uint32_t colf = (uint32_t)(wx * 128) * 4u + ne * 32u;   // fp32 rows (x, e0)
+    int64_t rows_valid = YM - y0;
+    if (rows_valid > M_BM) rows_valid = M_BM;
+    const uint32_t onum = (uint32_t)((rows_valid - 1) * ldo * 4 + M_BN * 4);
+    const uint32_t ldo4 = (uint32_t)(ldo * 4);
+    const __amdgpu_buffer_rsrc_t xdesc = __builtin_amdgcn_make_buffer_rsrc((void*)(X32 + y0 * ldo + x0), 0, (int)onum, 0x00020000);
+    const uint32_t row_lane = (uint32_t)(wy * 128) + 4u * ge;
+    const bool col_in = x0 + wx * 128 + 8 * (int64_t)ne + 8 <= XN;
+    const uint32_t lane_off = col_in ? row_lane * ldo4 + colf : 0x80000000u;
+    float bcol[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(bias + x0) + colb), bcol);
+    float gA[8], gB[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gA[j] = gB[j] = 1.f;
+    uint32_t rb = 0xffffffffu;
+    const bool gated = gate_idx >= 0;
+    auto gate_row = [&](int64_t bidx, float* gq) {
+      float mv[8];
+      unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(mod + (int64_t)gate_idx * XN + x0) + colb), mv);
+      const float4* ep = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(e32 + (bidx * n_mod + gate_idx) * XN + x0) + colf);
+      const float4 e0v = ep[0], e1v = ep[1];
+      const float ev[8] = {e0v.x, e0v.y, e0v.z, e0v.w, e1v.x, e1v.y, e1v.z, e1v.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gq[j] = mv[j] + ev[j];    // fp32 gate: bf16 modulation + fp32 e0, no rounding (model.py:658-660 in the mixed plan)
+    };
+    if (gated) {
+      const int64_t b0 = y0 / rows_per_batch;
+      const int64_t yb = (b0 + 1) * rows_per_batch;
+      gate_row(b0, gA);
+      if (yb < y0 + rows_valid) {
+        rb = (uint32_t)(yb - y0);
+        gate_row(b0 + 1, gB);
+      }
+    }
+    typedef unsigned int g256m_st4 __attribute__((__vector_size__(16)));
+    auto xload = [&](int a, int i, int half) -> uint4 {
+      return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xdesc, (int)(lane_off + (uint32_t)(a * 16 + i) * ldo4 + (uint32_t)half * 16u), 0, 0));
+    };
+    uint4 xq[2][4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xq[0][i][0] = xload(0, i, 0); xq[0][i][1] = xload(0, i, 1); }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      if (a + 1 < 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xq[(a + 1) & 1][i][0] = xload(a + 1, i, 0); xq[(a + 1) & 1][i][1] = xload(a + 1, i, 1); }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t rit = (uint32_t)(a * 16 + i);
+        const uint4 lo = xq[a & 1][i][0], hi = xq[a & 1][i][1];
+        float xv[8] = {__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w),
+                       __uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z), __uint_as_float(hi.w)};
+        const bool second = row_lane + rit >= rb;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float y = rbf(acc[a][t][i] * out_scale + bcol[t]);                       // the Linear's bf16 output
+          xv[t] = gated ? __fadd_rn(xv[t], __fmul_rn(y, second ? gB[t] : gA[t])) : xv[t] + y;   // addcmul_: the product rounded first
+        }
+        uint4 wlo, whi;
+        wlo.x = __float_as_uint(xv[0]); wlo.y = __float_as_uint(xv[1]); wlo.z = __float_as_uint(xv[2]); wlo.w = __float_as_uint(xv[3]);
+        whi.x = __float_as_uint(xv[4]); whi.y = __float_as_uint(xv[5]); whi.z = __float_as_uint(xv[6]); whi.w = __float_as_uint(xv[7]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g256m_st4, wlo), xdesc, (int)(lane_off + rit * ldo4), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(g256m_st4, whi), xdesc, (int)(lane_off + rit * ldo4 + 16u), 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
     uint32_t lane_e;  // opaque lane id: derived from threadIdx the epilogue's offsets are hoisted in front of the MFMA loop and spilled
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     const uint32_t ne = lane_e & 15u, ge = lane_e >> 4;
@@ -352,7 +433,11 @@ int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
   if (ldo % 8 != 0 || ((uintptr_t)Out & 15) != 0 || (!BIAS_ROWS && bias != nullptr && ((uintptr_t)bias & 15) != 0)) return -1;  // 16-byte stores / bias loads
   // 32-bit DMA offsets: a tile's 256 rows times the row pitch in bytes, plus the row itself; 31-bit store offsets
   if (256 * ldy * 2 + (int64_t)K * 2 >= ((int64_t)1 << 32) || 256 * ldx * 2 + (int64_t)K * 2 >= ((int64_t)1 << 32)) return -1;
-  if (256 * ldo * 2 + 512 >= ((int64_t)1 << 31)) return -1;
+  if (256 * ldo * (EPI == M_EPI_RES32 ? 4 : 2) + 1024 >= ((int64_t)1 << 31)) return -1;
+  if (EPI == M_EPI_RES32) {  // Out = the fp32 stream, e = the fp32 e0 rows (both behind bf16-typed parameters), mod = bf16 rows
+    if (ldo % 4 != 0 || XN % M_BN != 0) return -1;
+    if (gate_idx >= 0 && (rows_per_batch < M_BM || ((uintptr_t)mod & 15) != 0 || ((uintptr_t)e & 15) != 0)) return -1;
+  }
   if (EPI == WAN_EPI_GATE_RES) {
     if (((uintptr_t)R & 15) != 0) return -1;
     if (gate_idx >= 0 && (rows_per_batch < M_BM || ((uintptr_t)mod & 15) != 0 || ((uintptr_t)e & 15) != 0)) return -1;
@@ -373,6 +458,7 @@ G256M_INST(WAN_EPI_NONE, false)
 G256M_INST(WAN_EPI_GELU_TANH, false)
 G256M_INST(WAN_EPI_GATE_RES, false)
 G256M_INST(WAN_EPI_NONE, true)   // the transposed / V^T form: bias per output row, x = tokens (ragged)
+G256M_INST(M_EPI_RES32, false)   // the mixed-precision plan's gated residual on the fp32 stream (wan_gemm_bf16_res32)
 #undef G256M_INST
 
 #ifdef G256M_TIMING

@@ -287,6 +287,32 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
   return 0;
 }
 
+// The mixed-precision plan's Linear + gated residual in one launch (csrc/gemm256m.hip, epilogue M_EPI_RES32 = 4):
+//   x32[M, N] (fp32, in place) += bf16(A W^T + bias) * (mod[gate_idx] + e0[row / rows_per_batch][gate_idx])        (gate_idx < 0: gate = 1)
+// mod bf16 [n_mod, N], e0 fp32 [batches, n_mod, N] -- wan_gemm_bf16(WAN_EPI_NONE) into `tmp` followed by wan_mx_gated_residual, which
+// is also what runs when the shape does not fit the 256 x 256 tile kernel (few tiles, N % 256 != 0, a batch shorter than a tile).
+// Same operations in the same order on the same values: bit-identical to the two-launch form.
+extern "C" int wan_gemm_bf16_res32(const wan_bf16* A, int64_t lda, const wan_bf16* W, const wan_bf16* bias, float* x32, wan_bf16* tmp,
+                                   int64_t M, int N, int K, const wan_bf16* mod, const float* e0, int n_mod, int gate_idx,
+                                   int64_t rows_per_batch, void* stream) {
+  WAN_REQUIRE(A && W && x32 && tmp, "wan_gemm_bf16_res32: null operand");
+  WAN_REQUIRE(K > 0 && K % BK == 0 && N % 16 == 0, "wan_gemm_bf16_res32: K=%d must be a positive multiple of %d, N=%d of 16", K, BK, N);
+  WAN_REQUIRE(lda % 8 == 0 && (((uintptr_t)A | (uintptr_t)W | (uintptr_t)x32 | (uintptr_t)tmp) & 15) == 0,
+              "wan_gemm_bf16_res32: lda must be a multiple of 8, pointers 16-byte aligned");
+  WAN_REQUIRE(gate_idx < 0 || (mod && e0 && gate_idx < n_mod && rows_per_batch > 0), "wan_gemm_bf16_res32: bad gate arguments");
+  if (M == 0) return 0;
+  hipStream_t st = as_stream(stream);
+#ifndef WAN_GEMM_NO_MI16
+  if (((M + 255) / 256) * (((int64_t)N + 255) / 256) >= 256) {
+    const int rc = wan_gemm256m_try<4, false>(A, lda, M, W, K, N, K, reinterpret_cast<bf16_t*>(x32), N, bias, nullptr, mod,
+                                              reinterpret_cast<const bf16_t*>(e0), n_mod, gate_idx, rows_per_batch > 0 ? rows_per_batch : 1, st, 1.0f);
+    if (rc >= 0) return rc;
+  }
+#endif
+  if (int rc = launch_gemm<WAN_EPI_NONE, false>(A, lda, M, W, K, N, K, tmp, N, bias, nullptr, nullptr, nullptr, 0, -1, 1, st)) return rc;
+  return wan_mx_gated_residual(x32, tmp, mod, e0, n_mod, gate_idx, M, rows_per_batch > 0 ? rows_per_batch : M, N, stream);
+}
+
 // fp16 GEMM for the VAE attention block: C[M,N] (ldc) = scale * A[M,K](lda) @ W[N,K](ldw)^T + bias, or its
 // transpose Ct[N, ldc] (transposed != 0).  K % 64 == 0; N % 16 == 0 unless transposed.
 extern "C" int wan_gemm_f16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,

@@ -17,14 +17,91 @@ namespace {
 
 // 0: modulate -> bf16 (p0 = modulation bf16 [n_mod, d], p1 = e0 fp32 [batches, n_mod, d]);  1: affine -> bf16 (p0 = weight fp32, p1 = bias fp32)
 // 2: modulate -> fp32 (p0 = head.modulation fp32 [2, d], p1 = e fp32 [batches, d]; shift row 0, scale row 1)
-template <int MODE>
-__global__ __launch_bounds__(256) void mx_ln_kernel(const float* __restrict__ x, void* __restrict__ out, const void* __restrict__ p0,
+// NV > 0 (round 5): d == NV * 256 -- the Wan widths -- and the row lives in NV float4 registers per lane: ONE read of the row instead of
+// three (the second and third came out of L2: 8 of the pass's 14 bytes per element), the modulation / e0 vectors in 8- and 16-byte loads.
+// The same operations on the same values in the same order as the generic form (NV = 0): bit-identical results (tests/test_gpu_mixed.py).
+// Wide rows (NV >= 12): three workgroups per CU (168 registers: the row is 80 at d = 5120), each wave with its whole row in flight.
+template <int MODE, int NV = 0>
+__global__ __launch_bounds__(256, (NV >= 12 ? 3 : 4)) void mx_ln_kernel(const float* __restrict__ x, void* __restrict__ out, const void* __restrict__ p0,
                                                     const float* __restrict__ p1, int n_mod, int shift_idx, int scale_idx, int64_t rows,
                                                     int64_t rpb, int d, float eps) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // the wave index as a scalar: row, batch and every row pointer then live in SGPRs and an access is base (SGPR) + lane offset (one VGPR)
+  // + immediate -- per-lane 64-bit addresses for 4 vectors x NV chunks were what spilled at d = 5120
+  const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (row >= rows) return;
   const float* xr = x + row * d;
+  if constexpr (NV > 0) {
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + lane * 4 + i * 256);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + dd * dd);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    const int64_t batch = (int64_t)((uint32_t)row / (uint32_t)rpb);   // rows < 2^31 (launcher)
+    // the per-column vectors of chunk i + 1 are fetched while chunk i is computed; a compiler barrier per chunk keeps the scheduler from
+    // hoisting all NV chunks' loads (and their 64-bit addresses) to the top -- that cost 120 spilled registers at d = 5120
+    struct Vec { uint2 a, b; float4 c, d; };
+    auto fetch = [&](int i) -> Vec {
+      const int c = lane * 4 + i * 256;
+      Vec r = {};
+      if (MODE == 3) {   // p1 = table fp32 [batches][2][d]: row 0 = 1 + (mod + e0)[scale], row 1 = (mod + e0)[shift] (mx_modtab_kernel)
+        r.c = *reinterpret_cast<const float4*>(p1 + batch * (int64_t)2 * d + c);
+        r.d = *reinterpret_cast<const float4*>(p1 + batch * (int64_t)2 * d + d + c);
+      } else if (MODE == 1) {
+        r.c = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p0) + c);
+        r.d = *reinterpret_cast<const float4*>(p1 + c);
+      } else {
+        const float* hm = reinterpret_cast<const float*>(p0);
+        r.c = *reinterpret_cast<const float4*>(hm + c);
+        r.d = *reinterpret_cast<const float4*>(hm + d + c);
+        const float4 ee = *reinterpret_cast<const float4*>(p1 + batch * (int64_t)d + c);
+        r.a.x = __float_as_uint(ee.x); r.a.y = __float_as_uint(ee.y); r.b.x = __float_as_uint(ee.z); r.b.y = __float_as_uint(ee.w);
+      }
+      return r;
+    };
+    Vec cur = fetch(0);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane * 4 + i * 256;
+      Vec nxt = cur;
+      if (i + 1 < NV) nxt = fetch(i + 1);
+      asm volatile("" ::: "memory");
+      const float y[4] = {(v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd};
+      float r[4];
+      if (MODE == 3) {
+        const float scf[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w}, shf[4] = {cur.d.x, cur.d.y, cur.d.z, cur.d.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __fadd_rn(__fmul_rn(y[j], scf[j]), shf[j]);      // `x_mod *= 1 + e[1]; x_mod += e[0]`: two fp32 roundings
+      } else if (MODE == 1) {
+        r[0] = y[0] * cur.c.x + cur.d.x; r[1] = y[1] * cur.c.y + cur.d.y; r[2] = y[2] * cur.c.z + cur.d.z; r[3] = y[3] * cur.c.w + cur.d.w;
+      } else {
+        const float h0f[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w}, h1f[4] = {cur.d.x, cur.d.y, cur.d.z, cur.d.w};
+        const float ef[4] = {__uint_as_float(cur.a.x), __uint_as_float(cur.a.y), __uint_as_float(cur.b.x), __uint_as_float(cur.b.y)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __fadd_rn(__fmul_rn(y[j], 1.0f + (h1f[j] + ef[j])), h0f[j] + ef[j]);
+      }
+      static_assert(NV == 0 || MODE != 0, "the register-resident modulate reads the table form (MODE 3)");
+      if (MODE == 2) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row * d + c) = float4{r[0], r[1], r[2], r[3]};
+      } else {
+        uint2 w2;
+        w2.x = pack2bf(r[0], r[1]);
+        w2.y = pack2bf(r[2], r[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + row * d + c) = w2;
+      }
+      cur = nxt;
+    }
+    return;
+  }
   float s = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xr + c);
@@ -183,6 +260,36 @@ __global__ __launch_bounds__(256) void mx_head_gemm_kernel(const float* __restri
 }
 
 inline hipStream_t mx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// tab[b][0][c] = 1 + (mod[scale][c] + e0[b][scale][c]), tab[b][1][c] = mod[shift][c] + e0[b][shift][c]: the two fp32 vectors the modulate derives
+// for every token row, once per (layer, batch) -- the same fp32 operations, so the modulate's results do not change
+__global__ __launch_bounds__(256) void mx_modtab_kernel(const bf16_t* __restrict__ mod, const float* __restrict__ e0, float* __restrict__ tab, int n_mod,
+                                                        int shift_idx, int scale_idx, int d, int nb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nb * d) return;
+  const int b = i / d, c = i - b * d;
+  const float* e = e0 + (int64_t)b * n_mod * d;
+  tab[(int64_t)b * 2 * d + c] = 1.0f + (bf2f(mod[(int64_t)scale_idx * d + c]) + e[(int64_t)scale_idx * d + c]);
+  tab[(int64_t)b * 2 * d + d + c] = bf2f(mod[(int64_t)shift_idx * d + c]) + e[(int64_t)shift_idx * d + c];
+}
+constexpr size_t MXTAB_SLOT = (size_t)2 << 20;   // 42 batches (21 frames x 2 streams) x 2 x 5120 x 4 B = 1.7 MB is the largest Wan case
+constexpr int MXTAB_NSLOT = 16;
+
+bool g_mx_generic = false;   // test hook (wan_mx_debug_generic_rows): the re-reading form on every width
+// register-resident form for the widths d == NV * 256 it is instantiated for (every Wan width and the test configs'), else the generic one
+#define MX_LN_LAUNCH(MODE_, ...)                                                                                                          \
+  do {                                                                                                                                   \
+    const dim3 grid_((unsigned)((rows + 3) / 4));                                                                                        \
+    const bool fits_ = !g_mx_generic && d % 256 == 0 && rows < ((int64_t)1 << 31) && rows_per_batch_ < ((int64_t)1 << 31);                                \
+    switch (fits_ ? d / 256 : 0) {                                                                                                       \
+      case 1: hipLaunchKernelGGL((mx_ln_kernel<MODE_, 1>), grid_, dim3(256), 0, mx_stream(stream), __VA_ARGS__); break;                  \
+      case 2: hipLaunchKernelGGL((mx_ln_kernel<MODE_, 2>), grid_, dim3(256), 0, mx_stream(stream), __VA_ARGS__); break;                  \
+      case 6: hipLaunchKernelGGL((mx_ln_kernel<MODE_, 6>), grid_, dim3(256), 0, mx_stream(stream), __VA_ARGS__); break;                  \
+      case 12: hipLaunchKernelGGL((mx_ln_kernel<MODE_, 12>), grid_, dim3(256), 0, mx_stream(stream), __VA_ARGS__); break;                \
+      case 20: hipLaunchKernelGGL((mx_ln_kernel<MODE_, 20>), grid_, dim3(256), 0, mx_stream(stream), __VA_ARGS__); break;                \
+      default: hipLaunchKernelGGL((mx_ln_kernel<(MODE_ == 3 ? 1 : MODE_), 0>), grid_, dim3(256), 0, mx_stream(stream), __VA_ARGS__); break; /* (3: never reached, `wide` is checked by the caller) */ \
+    }                                                                                                                                    \
+  } while (0)
+
 inline int mx_blocks(int64_t work, int per_block) {
   int64_t b = (work + per_block - 1) / per_block;
   if (b > 65536) b = 65536;
@@ -191,14 +298,29 @@ inline int mx_blocks(int64_t work, int per_block) {
 
 }  // namespace
 
+extern "C" void wan_mx_debug_generic_rows(int on) { g_mx_generic = on != 0; }
+
 extern "C" int wan_mx_ln_modulate(const float* x, wan_bf16* out, const wan_bf16* mod, const float* e0, int n_mod, int shift_idx, int scale_idx,
                                   int64_t rows, int64_t rows_per_batch, int d, float eps, void* stream) {
   WAN_REQUIRE(x && out && mod && e0, "wan_mx_ln_modulate: null pointer");
   WAN_REQUIRE(d % 4 == 0 && rows >= 0 && rows_per_batch >= 1 && n_mod >= 1 && shift_idx >= 0 && shift_idx < n_mod && scale_idx >= 0 && scale_idx < n_mod,
               "wan_mx_ln_modulate: bad arguments (d=%d n_mod=%d shift=%d scale=%d)", d, n_mod, shift_idx, scale_idx);
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(mx_ln_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, mx_stream(stream), x, (void*)out, (const void*)mod, e0, n_mod,
-                     shift_idx, scale_idx, rows, rows_per_batch, d, eps);
+  const int64_t rows_per_batch_ = rows_per_batch;
+  // the Wan widths: the modulation vectors from a per-(layer, batch) table in the library's scratch ring (16 slots per stream: a table is
+  // dead when its row kernel has run), the row register-resident; other widths, or a table that does not fit: the generic form
+  const int64_t nb = (rows + rows_per_batch - 1) / rows_per_batch;
+  const bool wide = !g_mx_generic && (d == 256 || d == 512 || d == 1536 || d == 3072 || d == 5120) && rows < ((int64_t)1 << 31) &&
+                    rows_per_batch < ((int64_t)1 << 31) && nb * d < ((int64_t)1 << 31);
+  float* tab = wide ? reinterpret_cast<float*>(wan_scratch_ring_slot(/*tag=*/3, MXTAB_SLOT, MXTAB_NSLOT, (size_t)nb * 2 * d * 4, mx_stream(stream))) : nullptr;
+  if (tab != nullptr) {
+    hipLaunchKernelGGL(mx_modtab_kernel, dim3((unsigned)((nb * d + 255) / 256)), dim3(256), 0, mx_stream(stream), mod, e0, tab, n_mod, shift_idx, scale_idx, d, (int)nb);
+    WAN_LAUNCH_CHECK();
+    MX_LN_LAUNCH(3, x, (void*)out, (const void*)nullptr, (const float*)tab, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps);
+  } else {
+    hipLaunchKernelGGL((mx_ln_kernel<0, 0>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, mx_stream(stream), x, (void*)out, (const void*)mod, e0, n_mod,
+                       shift_idx, scale_idx, rows, rows_per_batch, d, eps);
+  }
   WAN_LAUNCH_CHECK();
   return 0;
 }
@@ -207,8 +329,8 @@ extern "C" int wan_mx_ln_affine(const float* x, wan_bf16* out, const float* w, c
   WAN_REQUIRE(x && out && w && b, "wan_mx_ln_affine: null pointer");
   WAN_REQUIRE(d % 4 == 0 && rows >= 0, "wan_mx_ln_affine: bad arguments (d=%d)", d);
   if (rows == 0) return 0;
-  hipLaunchKernelGGL(mx_ln_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, mx_stream(stream), x, (void*)out, (const void*)w, b, 1, 0, 0, rows,
-                     rows, d, eps);
+  const int64_t rows_per_batch_ = rows;
+  MX_LN_LAUNCH(1, x, (void*)out, (const void*)w, b, 1, 0, 0, rows, rows, d, eps);
   WAN_LAUNCH_CHECK();
   return 0;
 }

@@ -145,6 +145,9 @@ SIGNATURES = {
     "wan_mx_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int, c_float, c_void_p]),
     "wan_mx_ln_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "wan_mx_gated_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "wan_mx_debug_generic_rows": (None, [c_int]),
+    "wan_gemm_bf16_res32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                    c_int, c_int, c_int64, c_void_p]),
     "wan_mx_patch_embed": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
     "wan_mx_sinusoid": (c_int, [c_float, c_void_p, c_int, c_void_p]),
     "wan_mx_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

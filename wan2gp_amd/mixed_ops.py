@@ -54,6 +54,23 @@ def gated_residual_(x, y, mod=None, e0=None, gate_idx=-1):
     return x
 
 
+def linear_gated_residual_(x, a, weight, bias, mod=None, e0=None, gate_idx=-1):
+    """x (fp32 [M, N], in place) += bf16(a @ weight.T + bias) * (mod[gate_idx] + e0[b][gate_idx]) in ONE launch (wan_gemm_bf16_res32: the update
+    in the tile GEMM's epilogue; shapes that do not fit it run the Linear + wan_mx_gated_residual pair -- bit-identical either way)."""
+    _req(x, F32, "x"); _req(a, BF16, "a"); _req(weight, BF16, "weight"); _req(bias, BF16, "bias")
+    N, K = weight.shape
+    M = a.numel() // K
+    n_mod, rpb = 1, M
+    if gate_idx >= 0:
+        _req(mod, BF16, "mod"); _req(e0, F32, "e0")
+        n_mod = mod.numel() // N
+        rpb = M // (e0.numel() // (n_mod * N))
+    tmp = torch.empty(M, N, dtype=BF16, device=x.device)
+    check(_L.load().wan_gemm_bf16_res32(ptr(a), K, ptr(weight), ptr(bias), ptr(x), ptr(tmp), M, N, K, ptr(mod) if gate_idx >= 0 else None,
+                                        ptr(e0) if gate_idx >= 0 else None, n_mod, gate_idx, rpb, stream_ptr()), "wan_gemm_bf16_res32")
+    return x
+
+
 def patch_embed(x, w, bias, y=None):
     """x fp32 [Cin, F, H, W] (+ y fp32 [Cy, F, H, W]) -> fp32 [1, L, d] (model.py:1620-1631 with an fp32 modulation dtype)."""
     _req(x, F32, "x"); _req(w, F32, "w"); _req(bias, F32, "bias")
