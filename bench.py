@@ -486,7 +486,7 @@ def main():
             "dtype": ("fp8-e4m3 block Linears (weights + dynamically quantised activations), bf16 elsewhere" if args.fp8 else "bf16") +
                      (" -- mixed_precision_transformer: fp32 residual stream / modulation between the Linears" if args.mixed_precision else ""), "data": "synthetic",
             "config": {"workload": desc, "latent": [16, f, h, w], "tokens": L, "streams": 2, "guide_scale": guide,
-                       "solver": "unipc", "parallelism": (("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) + ((" (ulysses, q / o in %d head chunks)" % attn_chunks if attn_chunks > 1 else " (ulysses)") if sp_mode == "ulysses" else "")) if world > 1 else "single",
+                       "solver": "unipc", "parallelism": (("cfg2 x sp%d" % sp_degree if cfg_sp else "sp%d" % world) + ((" (ulysses, %d head chunks)" % attn_chunks if attn_chunks > 1 else " (ulysses)") if sp_mode == "ulysses" else "")) if world > 1 else "single",
                        **({"parallelism_note": layout_note} if layout_note else {}),
                        "forward_TFLOP": forward_flops(cfg, L) / 1e12},
             "roofline": {"kernel": "attn_w16n_kernel (self-attention: the bounded loop on the 16x16x32 MFMA)", "bound": "mfma", "achieved": achieved,
@@ -982,7 +982,7 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
                    # all-gather form: K + V^T of the other ranks of the group; Ulysses: the (deg - 1) / deg of q, k, v^T, o this rank
                    # sends away (= receives) -- per block, for the streams this rank runs
                    "gathered_bytes_per_block_and_rank": (sp.bytes / (k * layers)) if sp is not None else 0.0,
-                   "exchange": ("all-to-all: k, v^T whole, q / o in %d head chunks" % C if C > 1 else "all-to-all x 4 (q, k, v^T, o)") if uly
+                   "exchange": ("all-to-all: q, k, v^T, o each in %d head chunks" % C if C > 1 else "all-to-all x 4 (q, k, v^T, o)") if uly
                                else ("all-gather x 2 (K, V^T)" if sp is not None else "none"),
                    "tokens_per_rank": L // deg, "streams_per_rank": 1 if cfg_half else 2}
             if link_GBs > 0:

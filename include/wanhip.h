@@ -353,10 +353,10 @@ typedef int (*wan_gather_wait_fn)(void* user, int which, void* stream);
  *   a2a_begin(user, which, send, recv, bytes_per_peer, stream): send = world chunks of bytes_per_peer, chunk j for rank j; recv
  *       = world chunks, chunk i from rank i; which 0 = k, 1 = v^T, 2 = q, 3 = o.  Same ordering contract as gather_begin.
  *   a2a_wait(user, which, stream).
- * Round 5: a2a_chunks = C > 1 splits the rank's H / world heads into C chunks (heads [c Hn / C, (c + 1) Hn / C)): k and v^T still
- * travel whole (laid out per chunk), q and o travel PER CHUNK -- which 2 + c = q chunk c, 2 + C + c = o chunk c -- and chunk c's
- * attention launch runs while q chunk c + 1 arrives and o chunk c - 1 returns: only the first q chunk and the last o chunk are
- * exposed.  Results are bit-identical to C = 1.  C is clamped to [1, min(H / world, WAN_SP_MAX_CHUNKS)]. */
+ * Round 5: a2a_chunks = C > 1 splits the rank's H / world heads into C chunks (heads [c Hn / C, (c + 1) Hn / C)) and every tensor travels
+ * PER CHUNK -- which = c: k chunk c, C + c: v^T, 2 C + c: q, 3 C + c: o (C = 1: the numbering above).  Chunk 0's k, v^T, q leave first (under
+ * the V and Q projections), the other chunks flow under chunk 0's attention launch, chunk c's o returns under chunk c + 1's launch: only
+ * q chunk 0 and the last o chunk are exposed.  Results are bit-identical to C = 1.  C is clamped to [1, min(H / world, WAN_SP_MAX_CHUNKS)]. */
 enum { WAN_SP_ALLGATHER = 0, WAN_SP_ULYSSES = 1 };
 enum { WAN_SP_MAX_CHUNKS = 8 };
 typedef struct {
@@ -385,7 +385,7 @@ void wan_sp_destroy(wan_sp* sp);
 int wan_sp_gather_begin(void* sp, int which, const void* send, void* recv, int64_t bytes, void* stream);
 int wan_sp_gather_wait(void* sp, int which, void* stream);
 /* the all-to-all pair of WAN_SP_ULYSSES on the same communicator and side stream (grouped ncclSend / ncclRecv: `bytes` to and from
- * every peer; the rank's own chunk is a device-to-device copy); which = 0 .. 1 + 2 WAN_SP_MAX_CHUNKS; wait with wan_sp_gather_wait */
+ * every peer; the rank's own chunk is a device-to-device copy); which = 0 .. 4 WAN_SP_MAX_CHUNKS - 1; wait with wan_sp_gather_wait */
 int wan_sp_a2a_begin(void* sp, int which, const void* send, void* recv, int64_t bytes, void* stream);
 int wan_sp_all_gather(wan_sp* sp, const void* send, void* recv, int64_t bytes, void* stream);
 

@@ -473,10 +473,12 @@ def test_ulysses_call_order_layouts_and_buffer_lifetimes(mock, S):
 
 @pytest.mark.parametrize("S,world,chunks", [(2, 2, 2), (1, 2, 2), (2, 1, 3)], ids=["S2_heads_1+1", "S1_heads_1+1", "S2_one_rank_group_is_plain"])
 def test_ulysses_chunked_exchange_order_offsets_and_overlap(mock, S, world, chunks):
-    """wan_sp_info.a2a_chunks = C > 1 (round 5): k and v^T travel whole but are packed per head chunk, q and o travel per chunk; chunk c's
-    attention launch sits between the wait for ITS q chunk and the begin of ITS o chunk, i.e. with q chunk c + 1 and o chunk c - 1 in
-    flight; the launches see the round-4 layout with H = the chunk's heads at the chunk's offsets; every o chunk is waited for and
-    re-packed before the output projection.  A group of one rank ignores the mode altogether."""
+    """wan_sp_info.a2a_chunks = C > 1 (round 5): every tensor is packed chunk-major and travels per head chunk -- slots k_c = c, v_c = C + c,
+    q_c = 2 C + c, o_c = 3 C + c.  Chunk 0's k leaves behind the K pack (under the V projections), its v^T behind the V pack (under the Q
+    projection), its q behind the Q pack, THEN the other chunks' k / v^T / q; chunk c's launch sits between the waits for ITS three
+    tensors and the begin of ITS o chunk -- the later chunks' exchanges and the earlier o chunks in flight meanwhile -- and sees the
+    round-4 layout with H = the chunk's heads; every o chunk is waited for and re-packed before the output projection.  A group of
+    one rank ignores the mode altogether."""
     from wan2gp_amd.lib import SP_ULYSSES
     m = Model(mock, name="small")                                            # 4 heads
     c, (F, H, W) = m.cfg, (2, 8, 8)
@@ -501,59 +503,52 @@ def test_ulysses_chunked_exchange_order_offsets_and_overlap(mock, S, world, chun
         return
     C = min(chunks, Hn)
     h0 = [cch * Hn // C for cch in range(C + 1)]
-    per_layer = 2 * (2 + 2 * C)
+    per_layer = 2 * 4 * C
     assert len(events) == per_layer * c.num_layers
     for layer in range(c.num_layers):
         ev = events[per_layer * layer:per_layer * (layer + 1)]
-        want = [("begin", 0), ("begin", 1)] + [("begin", 2 + k) for k in range(C)] + [("wait", 0), ("wait", 1)]
+        want = [("begin", 0), ("begin", C), ("begin", 2 * C)]
+        for k in range(1, C):
+            want += [("begin", k), ("begin", C + k), ("begin", 2 * C + k)]
         for k in range(C):
-            want += [("wait", 2 + k), ("begin", 2 + C + k)]
-        want += [("wait", 2 + C + k) for k in range(C)]
+            want += [("wait", k), ("wait", C + k), ("wait", 2 * C + k), ("begin", 3 * C + k)]
+        want += [("wait", 3 * C + k) for k in range(C)]
         assert [(e[0], e[1]) for e in ev] == want
-        bk, bv = ev[0], ev[1]
-        bq = ev[2:2 + C]
-        assert bk[4] == rows * Wd * 2 and bv[4] == S * Wd * Lp * 2
-        packs_k = calls[bk[5] - C:bk[5]]
-        assert [cl[0] for cl in packs_k] == ["permute16_ex"] * C and calls[bk[5] - C - 1][0] == "rmsnorm_rope"
-        att_i = [i for i in range(bk[5], len(calls)) if calls[i][0] == "attention"][:C]
+        E = {(e[0], e[1]): e for e in ev}
+        bk0, bv0, bq0 = E[("begin", 0)], E[("begin", C)], E[("begin", 2 * C)]
+        # what sits between the first three begins: the V projections + C v^T packs under k_0; the Q projection, its norm and C q packs under v_0
+        assert [cl[0] for cl in calls[bk0[5] - C:bk0[5]]] == ["permute16_ex"] * C and calls[bk0[5] - C - 1][0] == "rmsnorm_rope"
+        assert [cl[0] for cl in calls[bk0[5]:bv0[5]]] == ["gemm"] * S + ["permute16_ex"] * C
+        assert [cl[0] for cl in calls[bv0[5]:bq0[5]]] == ["gemm", "rmsnorm_rope"] + ["permute16_ex"] * C
+        packs_k, packs_v, packs_q = calls[bk0[5] - C:bk0[5]], calls[bv0[5] - C:bv0[5]], calls[bq0[5] - C:bq0[5]]
+        att_i = [i for i in range(bq0[5], len(calls)) if calls[i][0] == "attention"][:C]
         for k in range(C):
             Hc = h0[k + 1] - h0[k]
             Wc, o0 = Hc * 128, h0[k] * 128
-            # k chunk: columns [o0, o0 + Wc) of every rank's head group of [rows][d] -> [world][chunk][rows][Wc] inside the k send buffer
-            pk = packs_k[k]
-            assert pk[2][:7] == [rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wd * 2] and pk[1][1] == bk[2] + o0 * rows * 2
-            # q chunk: packed, then sent at once -- [chunk][world][rows][Wc]; bytes per peer = the chunk's share
-            assert bq[k][4] == rows * Wc * 2 and bq[k][2] - bq[0][2] == o0 * rows * world * 2 == bq[k][3] - bq[0][3]
-            pq = calls[bq[k][5] - 1]
-            assert pq[0] == "permute16_ex" and pq[2][:7] == [rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2] and pq[1][1] == bq[k][2]
-            wq = [e for e in ev if e[:2] == ("wait", 2 + k)][0]
-            bo = [e for e in ev if e[:2] == ("begin", 2 + C + k)][0]
+            bk, bv, bq, bo = E[("begin", k)], E[("begin", C + k)], E[("begin", 2 * C + k)], E[("begin", 3 * C + k)]
+            # packs: columns [o0, o0 + Wc) of every rank's head group -> a [world][rows][Wc] block of its own at the chunk's offset
+            assert packs_k[k][2][:7] == [rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2] and packs_k[k][1][1] == bk[2] == bk0[2] + o0 * rows * world * 2
+            assert packs_q[k][2][:7] == [rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2] and packs_q[k][1][1] == bq[2] == bq0[2] + o0 * rows * world * 2
+            assert packs_v[k][2][:7] == [S, world, Wc * Lp * 2, d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2, S * Wc * Lp * 2]
+            assert packs_v[k][1][1] == bv[2] == bv0[2] + o0 * Lp * S * world * 2
+            assert bk[4] == bq[4] == bo[4] == rows * Wc * 2 and bv[4] == S * Wc * Lp * 2                       # bytes per PEER: the chunk's share
+            assert bk[3] - bk0[3] == bq[3] - bq0[3] == o0 * rows * world * 2 and bv[3] - bv0[3] == o0 * Lp * S * world * 2
             att = calls[att_i[k]]
-            assert wq[2] <= att_i[k] < bo[5]                                                        # launch k between ITS q wait and ITS o begin
-            assert att[2][:10] == [world * S, S, Ll, Ll, Lp, Hc, world, rows * Wd, S * Wd * Lp, 1]
-            assert att[1][0] == bq[k][3] and att[1][1] == bk[3] + o0 * rows * 2 and att[1][2] == bv[3] + o0 * Lp * S * 2
-            assert att[1][3] == bo[2] == bk[2] + o0 * rows * world * 2 and bo[3] == bq[k][2] and bo[4] == rows * Wc * 2
-            if k + 1 < C:                                                                           # overlap: the next q chunk is not waited for yet,
-                nxt = [e for e in ev if e[:2] == ("wait", 2 + k + 1)][0]
-                assert nxt[2] > att_i[k]
-                assert bo[5] <= att_i[k + 1]                                                        # ... and this o chunk is on its way during the next launch
-        if S > 1:
-            packs_v = calls[bv[5] - C:bv[5]]
-            for k, pv in enumerate(packs_v):
-                Wc, o0 = (h0[k + 1] - h0[k]) * 128, h0[k] * 128
-                assert pv[0] == "permute16_ex" and pv[2][:7] == [S, world, Wc * Lp * 2, d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2, S * Wd * Lp * 2]
-                assert pv[1][1] == bv[2] + o0 * Lp * S * 2
-        else:
-            assert calls[bv[5] - 1][0] == "gemm" and calls[bv[5] - 1][1][3] == bv[2]              # S = 1: the epilogue's image already has the layout
-        last_wait = [e for e in ev if e[:2] == ("wait", 2 + 2 * C - 1)][0]
-        back = calls[last_wait[2]]
-        proj = calls[last_wait[2] + 1]
+            assert max(E[("wait", k)][2], E[("wait", C + k)][2], E[("wait", 2 * C + k)][2]) <= att_i[k] < bo[5]   # between ITS waits and ITS o begin
+            assert att[2][:10] == [world * S, S, Ll, Ll, Lp, Hc, world, rows * Wc, S * Wc * Lp, 1]               # the chunk's segment strides
+            assert (att[1][0], att[1][1], att[1][2]) == (bq[3], bk[3], bv[3])                                  # q / k / v^T chunks as RECEIVED
+            assert att[1][3] == bo[2] == bk[2] and bo[3] == bq[2]                                              # o over the dead k send chunk, back over the dead q send chunk
+            if k + 1 < C:
+                assert E[("begin", 2 * C + k + 1)][5] <= att_i[k] and E[("wait", 2 * C + k + 1)][2] > att_i[k]   # the next chunk's tensors are in flight
+                assert bo[5] <= att_i[k + 1]                                                                   # ... and this o chunk during the next launch
+        last_wait = E[("wait", 4 * C - 1)]
+        back, proj = calls[last_wait[2]], calls[last_wait[2] + 1]
         assert back[0] == "permute16_ex" and proj[0] == "gemm" and proj[2][5] == 2
-        ups = [cl for cl in calls[[e for e in ev if e[:2] == ("wait", 2 + C)][0][2]:last_wait[2] + 1] if cl[0] == "permute16_ex"]
+        ups = [cl for cl in calls[E[("wait", 3 * C)][2]:last_wait[2] + 1] if cl[0] == "permute16_ex"]
         assert len(ups) == C and all(u[1][1] - ups[0][1][1] == h0[k] * 256 for k, u in enumerate(ups)) and ups[0][1][1] == proj[1][0]
         for k, u in enumerate(ups):
             Wc = (h0[k + 1] - h0[k]) * 128
-            assert u[2][:7] == [world, rows, Wc * 2, rows * Wc * 2, Wc * 2, Wd * 2, d * 2] and u[1][0] == bq[k][2]
+            assert u[2][:7] == [world, rows, Wc * 2, rows * Wc * 2, Wc * 2, Wd * 2, d * 2] and u[1][0] == E[("begin", 2 * C + k)][2]
         for e in ev:
             if e[0] == "begin":
                 assert in_ws(e[2], nbytes) and in_ws(e[3] + e[4] * world - 1, nbytes)

@@ -355,8 +355,8 @@ def test_cfg4_world8_rank_dryrun():
 # ---- the layout `bench.py --gpus 8` runs (cfg2 x sp4 / sp8 with the Ulysses all-to-alls), at BASELINE sizes, every rank on one GPU ----
 def _ulysses_world_emulation(S, world, L, chunks, seed, H=40):
     """A whole Ulysses world's self-attention on one GPU, with the product's kernels and csrc/dit.hip's arguments: every rank j packs
-    its token shard's q / k / v^T with wan_permute16_ex, the all-to-alls are emulated by copying segment i of rank j's send buffer into
-    segment j of rank i's receive buffer, every rank i runs its C attention launches (world x S query batches of L / world rows against
+    its token shard's q / k / v^T chunk-major with wan_permute16_ex, the per-chunk all-to-alls are emulated by copying piece i of rank
+    j's send region into piece j of rank i's receive region, every rank i runs its C attention launches (world x S query batches of L / world rows against
     S K / V^T batches in `world` segments, H / world heads split in C chunks), the o chunks travel back the same way and every rank
     un-packs them to [rows][d].  Returns (q, k, v in the natural [S, L, H, 128] layout, o in the same layout = every rank's un-packed
     rows stacked)."""
@@ -375,32 +375,32 @@ def _ulysses_world_emulation(S, world, L, chunks, seed, H=40):
     v = torch.randn(S, L, H, 128, device="cuda", generator=g).to(BF)
     chunks_ = [((h0[c + 1] - h0[c]), (h0[c + 1] - h0[c]) * 128, h0[c] * 128) for c in range(C)]      # (heads, Wc, o0)
     ks, qs, vs = [], [], []
-    for j in range(world):                                                      # rank j: "my tokens, all heads" -> the send layouts
+    for j in range(world):                                                      # rank j: "my tokens, all heads" -> the chunk-major send layouts
         sl = slice(j * Ll, (j + 1) * Ll)
         kj, qj = k[:, sl].contiguous().view(-1), q[:, sl].contiguous().view(-1)
         vtj = ops.transpose_v(v[:, sl].contiguous(), Lp).view(-1)               # [S][d][Lp], zero padded: the transposed epilogue's image
         ksj, qsj = torch.empty(rows * d, dtype=BF, device="cuda"), torch.empty(rows * d, dtype=BF, device="cuda")
-        vsj = vtj if S == 1 else torch.empty(S * d * Lp, dtype=BF, device="cuda")
+        vsj = torch.empty(S * d * Lp, dtype=BF, device="cuda")
         for Hc, Wc, o0 in chunks_:
-            ops.permute16_ex(kj[o0:], ksj[o0 * rows:], rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wd * 2)
+            ops.permute16_ex(kj[o0:], ksj[o0 * rows * world:], rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2)
             ops.permute16_ex(qj[o0:], qsj[o0 * rows * world:], rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2)
-            if S > 1:
-                ops.permute16_ex(vtj[o0 * Lp:], vsj[o0 * Lp * S:], S, world, Wc * Lp * 2, d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2, S * Wd * Lp * 2)
+            ops.permute16_ex(vtj[o0 * Lp:], vsj[o0 * Lp * S * world:], S, world, Wc * Lp * 2, d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2, S * Wc * Lp * 2)
         ks.append(ksj); qs.append(qsj); vs.append(vsj)
     scratch = torch.zeros(ops.attention_scratch_words(world * S, S, Ll, max(c_[0] for c_ in chunks_)), dtype=torch.float32, device="cuda")
     o_send = []
-    segk, segv = rows * Wd, S * Wd * Lp
     for i in range(world):                                                      # rank i: "all tokens, my heads"
-        kr = torch.cat([ks[j][i * segk:(i + 1) * segk] for j in range(world)])
-        vr = torch.cat([vs[j][i * segv:(i + 1) * segv] for j in range(world)])
-        qr = torch.empty(rows * d, dtype=BF, device="cuda")
+        kr, qr = torch.empty(rows * d, dtype=BF, device="cuda"), torch.empty(rows * d, dtype=BF, device="cuda")
+        vr = torch.empty(S * d * Lp, dtype=BF, device="cuda")
         oi = torch.empty(rows * d, dtype=BF, device="cuda")
         for Hc, Wc, o0 in chunks_:
-            R, seg = o0 * rows * world, rows * Wc
-            for j in range(world):
+            R, seg = o0 * rows * world, rows * Wc                               # a chunk's region and one peer's share of it (k, q, o)
+            Rv, segv = o0 * Lp * S * world, S * Wc * Lp                         # ... of v^T
+            for j in range(world):                                              # the three all-to-alls of the chunk: piece i of rank j's send region
+                kr[R + j * seg:R + (j + 1) * seg] = ks[j][R + i * seg:R + (i + 1) * seg]
                 qr[R + j * seg:R + (j + 1) * seg] = qs[j][R + i * seg:R + (i + 1) * seg]
-            ops.attention(qr[R:R + world * seg].view(world * S, Ll, Hc, 128), kr[o0 * rows:], vr[o0 * Lp * S:].view(-1, Lp), Lk=Ll,
-                          out=oi[R:R + world * seg].view(world * S, Ll, Hc, 128), nseg=world, k_seg_stride=segk, vt_seg_stride=segv, Bk=S,
+                vr[Rv + j * segv:Rv + (j + 1) * segv] = vs[j][Rv + i * segv:Rv + (i + 1) * segv]
+            ops.attention(qr[R:R + world * seg].view(world * S, Ll, Hc, 128), kr[R:R + world * seg], vr[Rv:Rv + world * segv].view(-1, Lp), Lk=Ll,
+                          out=oi[R:R + world * seg].view(world * S, Ll, Hc, 128), nseg=world, k_seg_stride=seg, vt_seg_stride=segv, Bk=S,
                           q_prescaled=True, kmax_scratch=scratch)
         o_send.append(oi)
         del kr, vr, qr

@@ -183,7 +183,7 @@ def test_gemm256m_registers_and_stage_instruction_mix(tmp_path_factory):
     whole LDS, and between two barriers of the main loop exactly one stage: 128 MFMAs, 32 ds_read_b128, 16 LDS-DMA pieces and
     NO vector-ALU instruction (a 16-cycle MFMA gap hides two issue slots; an address computation there is a stall)."""
     ks = kernels(asm_of("gemm256m", tmp_path_factory), "gemm256m_kernel")
-    assert len(ks) == 4                                              # NONE / GELU / GATE_RES, and the row-bias (V^T) form
+    assert len(ks) == 5                                              # NONE / GELU / GATE_RES, the row-bias (V^T) form, and the fp32-stream residual (round 5)
     for name, (ops, meta) in ks.items():
         assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256 and meta["LDSByteSize"] == 160 * 1024, (name, meta)
         bars = [i for i, o in enumerate(ops) if o == "s_barrier"]

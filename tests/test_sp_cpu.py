@@ -325,44 +325,47 @@ def _ulysses_chunked_worker(rank, world, port, q, heads, chunks):
         def normed(name, nw):
             y = O.rms_norm(O._linear(xm, W, sa + name), W[sa + nw], cfg.eps).view(S, Ll, H, 128)
             return O.rope_apply(y, cos[pos], sin[pos]).reshape(-1).contiguous()
+        geo = [((h0[c + 1] - h0[c]) * 128, h0[c] * 128) for c in range(C)]        # (Wc, o0) per chunk
         kk = normed("k", "norm_k.weight")
-        for c in range(C):                                                      # [rows][world][Hn 128] -> [world][chunk][rows][Wc]
-            Wc, o0 = (h0[c + 1] - h0[c]) * 128, h0[c] * 128
-            permute_ex(kk, o0, KS + o0 * rows, rows, world, Wc, d, Wd, Wc, rows * Wd)
-        a2a(0, KS, KR, rows * Wd)
+        for Wc, o0 in geo:                                                      # [rows][world][Hn 128] -> [chunk][world][rows][Wc]
+            permute_ex(kk, o0, KS + o0 * rows * world, rows, world, Wc, d, Wd, Wc, rows * Wc)
+        send_k = lambda c: a2a(c, KS + geo[c][1] * rows * world, KR + geo[c][1] * rows * world, rows * geo[c][0])
+        send_k(0)                                                               # chunk 0 first: under the V projection
         vt = torch.zeros(S, d, Lp)
         vt[:, :, :Ll] = O._linear(xm, W, sa + "v").view(S, Ll, d).transpose(1, 2)
         vt = vt.reshape(-1).contiguous()
-        for c in range(C):                                                      # [S][world][Hn 128][Lp] -> [world][chunk][S][Wc][Lp]
-            Wc, o0 = (h0[c + 1] - h0[c]) * 128, h0[c] * 128
-            permute_ex(vt, o0 * Lp, VS + o0 * Lp * S, S, world, Wc * Lp, d * Lp, Wd * Lp, Wc * Lp, S * Wd * Lp)
-        a2a(1, VS, VR, S * Wd * Lp)
+        for Wc, o0 in geo:                                                      # [S][world][Hn 128][Lp] -> [chunk][world][S][Wc][Lp]
+            permute_ex(vt, o0 * Lp, VS + o0 * Lp * S * world, S, world, Wc * Lp, d * Lp, Wd * Lp, Wc * Lp, S * Wc * Lp)
+        send_v = lambda c: a2a(C + c, VS + geo[c][1] * Lp * S * world, VR + geo[c][1] * Lp * S * world, S * geo[c][0] * Lp)
+        send_v(0)
         qq = normed("q", "norm_q.weight")
-        for c in range(C):                                                      # [rows][world][Hn 128] -> [chunk][world][rows][Wc], sent per chunk
-            Wc, o0 = (h0[c + 1] - h0[c]) * 128, h0[c] * 128
+        for Wc, o0 in geo:                                                      # [rows][world][Hn 128] -> [chunk][world][rows][Wc]
             permute_ex(qq, o0, QS + o0 * rows * world, rows, world, Wc, d, Wd, Wc, rows * Wc)
-            a2a(2 + c, QS + o0 * rows * world, QR + o0 * rows * world, rows * Wc)
-        assert sp._a2a_wait_cb(None, 0, None) == 0 and sp._a2a_wait_cb(None, 1, None) == 0
+        send_q = lambda c: a2a(2 * C + c, QS + geo[c][1] * rows * world, QR + geo[c][1] * rows * world, rows * geo[c][0])
+        send_q(0)
+        for c in range(1, C):                                                   # the later chunks, in the order their launches need them
+            send_k(c); send_v(c); send_q(c)
         for c in range(C):
             Hc = h0[c + 1] - h0[c]
-            Wc, o0 = Hc * 128, h0[c] * 128
-            assert sp._a2a_wait_cb(None, 2 + c, None) == 0
-            # the launch of chunk c: the round-4 layout with Hc heads at the chunk's offsets, segment strides of the WHOLE head group
+            Wc, o0 = geo[c]
+            for which in (c, C + c, 2 * C + c):
+                assert sp._a2a_wait_cb(None, which, None) == 0
+            # the launch of chunk c: the round-4 layout with Hc heads, the CHUNK's segment strides
             Q = ws[QR + o0 * rows * world:QR + (o0 + Wc) * rows * world].view(world, S, Ll, Hc, 128)
-            K = torch.as_strided(ws, (world, S, Ll, Hc, 128), (rows * Wd, Ll * Wc, Wc, 128, 1), KR + o0 * rows)
-            V = torch.as_strided(ws, (world, S, Hc, 128, Lp), (S * Wd * Lp, Wc * Lp, 128 * Lp, Lp, 1), VR + o0 * Lp * S)
+            K = ws[KR + o0 * rows * world:KR + (o0 + Wc) * rows * world].view(world, S, Ll, Hc, 128)
+            V = ws[VR + o0 * Lp * S * world:VR + (o0 + Wc) * Lp * S * world].view(world, S, Hc, 128, Lp)
             out = torch.empty(world, S, Ll, Hc, 128)
             for s in range(S):
                 kf = K[:, s].reshape(1, world * Ll, Hc, 128)
                 vf = V[:, s, :, :, :Ll].permute(0, 3, 1, 2).reshape(1, world * Ll, Hc, 128)
                 for i in range(world):
                     out[i, s] = O.attention(Q[i, s].unsqueeze(0), kf, vf, exact=True)[0]
-            ws[KS + o0 * rows * world:KS + (o0 + Wc) * rows * world] = out.reshape(-1)        # o over the dead k send buffer ...
-            a2a(2 + C + c, KS + o0 * rows * world, QS + o0 * rows * world, rows * Wc)         # ... received over the dead q send chunk
+            ws[KS + o0 * rows * world:KS + (o0 + Wc) * rows * world] = out.reshape(-1)        # o over the dead k send chunk ...
+            a2a(3 * C + c, KS + o0 * rows * world, QS + o0 * rows * world, rows * Wc)         # ... received over the dead q send chunk
         o_rows = torch.zeros(rows * d)
         for c in range(C):                                                      # [chunk][world][rows][Wc] -> [rows][world][Hn 128]
             Wc, o0 = (h0[c + 1] - h0[c]) * 128, h0[c] * 128
-            assert sp._a2a_wait_cb(None, 2 + C + c, None) == 0
+            assert sp._a2a_wait_cb(None, 3 * C + c, None) == 0
             sv = torch.as_strided(ws, (world, rows, Wc), (rows * Wc, Wc, 1), QS + o0 * rows * world)
             torch.as_strided(o_rows, (world, rows, Wc), (Wd, d, 1), o0).copy_(sv)
         assert sp.a2a_bytes == (3 * rows * Wd + S * Wd * Lp) * el * (world - 1)      # the same bytes as the unchunked form
@@ -386,8 +389,8 @@ def _ulysses_chunked_worker(rank, world, port, q, heads, chunks):
 @pytest.mark.parametrize("world,heads,chunks", [(2, 4, 2), (2, 6, 2), (4, 12, 3), (2, 10, 5)],
                          ids=["w2_heads_1+1", "w2_heads_1+2", "w4_heads_1+1+1", "w2_heads_5x1"])
 def test_ulysses_chunked_exchanges_with_the_forwards_layouts(world, heads, chunks):
-    """The chunked Ulysses block (round 5): k / v^T packed per head chunk and exchanged whole, q / o exchanged per chunk, every chunk's
-    attention on the round-4 layout at the chunk's offsets, the per-chunk un-pack -- with exactly the offsets and pitches csrc/dit.hip
+    """The chunked Ulysses block (round 5): k / v^T / q / o packed chunk-major and exchanged per head chunk (chunk 0's first), every chunk's
+    attention on the round-4 layout at the chunk's offsets and segment strides, the per-chunk un-pack -- with exactly the offsets and pitches csrc/dit.hip
     passes to wan_permute16_ex / wan_attention_bounded / a2a_begin, through sp.py's callbacks over gloo.  Every rank's block output
     equals the single-process oracle block on its token shard for both CFG streams; unequal chunks (3 heads as 1 + 2) included."""
     ctx = mp.get_context("spawn")

@@ -792,7 +792,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       bf16_t *vs = b.vtfull, *vr = b.vtfull + blkv;
       auto a2a = [&](int which, const bf16_t* send, bf16_t* recv, int64_t bytes) -> int {
         if (sp->a2a_begin(sp->user, which, send, recv, bytes, stream)) {
-          wan_set_error("wan_dit_forward: all-to-all %d (0 k, 1 v^T, 2.. q chunks, then o chunks) failed", which);
+          wan_set_error("wan_dit_forward: all-to-all %d (C head chunks: k 0.., v^T C.., q 2C.., o 3C..) failed", which);
           return 3;
         }
         return 0;
@@ -804,68 +804,67 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
         }
         return 0;
       };
-      // Round 5: the rank's Hn heads in C chunks (wan_sp_info.a2a_chunks; 1 = the round-4 form below).  q and o travel per chunk --
-      // chunk c's attention launch runs while chunk c + 1's q is still arriving and chunk c - 1's o is already on its way back, so of
-      // the two exchanges that nothing could hide (2 x 48 MB per link and block at 8 GPUs) only the first q chunk and the last o
-      // chunk stay exposed.  k and v^T still travel whole (they hide under the V and Q projections) but are LAID OUT per chunk,
-      //   k recv   [world][chunk][S][Ll][Wc]     v^T recv  [world][chunk][S][Wc][Lp]      (chunk c: heads [h0_c, h1_c), Wc = 128 (h1_c - h0_c))
-      //   q recv   [chunk][world][S][Ll][Wc]     o send    [chunk][world][S][Ll][Wc]
-      // so that a chunk's launch sees exactly the round-4 layout with H = h1_c - h0_c heads: the same kernel on the same rows of the
-      // same heads -- the results are bit-identical to C = 1 (tests/test_gpu_sp.py).  Exchange slots: 0 k, 1 v^T, 2 + c q, 2 + C + c o.
+      // Round 5: the rank's Hn heads in C chunks (wan_sp_info.a2a_chunks; 1 = the round-4 form below).  EVERY tensor travels per chunk,
+      // chunk-major --
+      //   k, q recv / o send  [chunk][world][S][Ll][Wc]        v^T recv  [chunk][world][S][Wc][Lp]        (chunk c: heads [h0_c, h1_c), Wc = 128 (h1_c - h0_c))
+      // -- so a chunk's launch sees exactly the round-4 layout with H = h1_c - h0_c heads (segment strides rows Wc / S Wc Lp): the same
+      // kernel on the same rows of the same heads, results bit-identical to C = 1 (tests/test_gpu_sp.py).  What the schedule buys: chunk
+      // 0's k, v^T and q leave FIRST (k_0 under the V projection, v_0 under the Q projection, then q_0), so the first launch waits for
+      // one chunk of q, not for three whole tensors queued on the same links; the other chunks' k / v^T / q flow under chunk 0's launch,
+      // chunk c's o returns under chunk c + 1's launch: exposed are q_0 and the last o chunk.  Slots: k_c = c, v_c = C + c, q_c = 2 C + c,
+      // o_c = 3 C + c (C = 1: the round-4 numbering 0..3).
       int C = sp->a2a_chunks < 1 ? 1 : sp->a2a_chunks;
       if (C > Hn) C = Hn;
       if (C > WAN_SP_MAX_CHUNKS) C = WAN_SP_MAX_CHUNKS;
       if (C > 1) {
         int h0[WAN_SP_MAX_CHUNKS + 1];
         for (int cch = 0; cch <= C; ++cch) h0[cch] = (int)((int64_t)cch * Hn / C);
+        auto wc = [&](int cch) { return (int64_t)(h0[cch + 1] - h0[cch]) * 128; };
+        auto o0 = [&](int cch) { return (int64_t)h0[cch] * 128; };
+        auto send_k = [&](int cch) { return a2a(cch, ks + o0(cch) * rows * world, kr + o0(cch) * rows * world, rows * wc(cch) * 2); };
+        auto send_v = [&](int cch) { return a2a(C + cch, vs + o0(cch) * Lp * S * world, vr + o0(cch) * Lp * S * world, (int64_t)S * wc(cch) * Lp * 2); };
+        auto send_q = [&](int cch) { return a2a(2 * C + cch, qs + o0(cch) * rows * world, qr + o0(cch) * rows * world, rows * wc(cch) * 2); };
         RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
         RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
-        for (int cch = 0; cch < C; ++cch) {   // [rows][world][Hn 128] -> [world][chunk][rows][Wc]
-          const int64_t Wc = (int64_t)(h0[cch + 1] - h0[cch]) * 128, o0 = (int64_t)h0[cch] * 128;
-          RC(wan_permute16_ex(b.k + o0, ks + o0 * rows, rows, world, Wc * 2, (int64_t)d * 2, Wd * 2, Wc * 2, rows * Wd * 2, stream));
-        }
-        RC(a2a(0, ks, kr, rows * Wd * 2));
+        for (int cch = 0; cch < C; ++cch)   // [rows][world][Hn 128] -> [chunk][world][rows][Wc]
+          RC(wan_permute16_ex(b.k + o0(cch), ks + o0(cch) * rows * world, rows, world, wc(cch) * 2, (int64_t)d * 2, Wd * 2, wc(cch) * 2, rows * wc(cch) * 2, stream));
+        RC(send_k(0));
         for (int s = 0; s < S; ++s)
           RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
                     nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr));
-        const bf16_t* vsend = b.vt;       // S = 1: [world][Hn 128][Lp] already IS [world][chunk][Wc][Lp]
-        if (S > 1) {
-          for (int cch = 0; cch < C; ++cch) {   // [S][world][Hn 128][Lp] -> [world][chunk][S][Wc][Lp]
-            const int64_t Wc = (int64_t)(h0[cch + 1] - h0[cch]) * 128, o0 = (int64_t)h0[cch] * 128;
-            RC(wan_permute16_ex(b.vt + o0 * Lp, vs + o0 * Lp * S, S, world, Wc * Lp * 2, (int64_t)d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2,
-                                (int64_t)S * Wd * Lp * 2, stream));
-          }
-          vsend = vs;
-        }
-        RC(a2a(1, vsend, vr, (int64_t)S * Wd * Lp * 2));
+        for (int cch = 0; cch < C; ++cch)   // [S][world][Hn 128][Lp] -> [chunk][world][S][Wc][Lp]
+          RC(wan_permute16_ex(b.vt + o0(cch) * Lp, vs + o0(cch) * Lp * S * world, S, world, wc(cch) * Lp * 2, (int64_t)d * Lp * 2, Wd * Lp * 2,
+                              wc(cch) * Lp * 2, (int64_t)S * wc(cch) * Lp * 2, stream));
+        RC(send_v(0));
         RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
                   Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr));
         RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
-        for (int cch = 0; cch < C; ++cch) {   // [rows][world][Hn 128] -> [chunk][world][rows][Wc]; each chunk leaves as soon as it is packed
-          const int64_t Wc = (int64_t)(h0[cch + 1] - h0[cch]) * 128, o0 = (int64_t)h0[cch] * 128;
-          RC(wan_permute16_ex(b.q + o0, qs + o0 * rows * world, rows, world, Wc * 2, (int64_t)d * 2, Wd * 2, Wc * 2, rows * Wc * 2, stream));
-          RC(a2a(2 + cch, qs + o0 * rows * world, qr + o0 * rows * world, rows * Wc * 2));
+        for (int cch = 0; cch < C; ++cch)   // [rows][world][Hn 128] -> [chunk][world][rows][Wc]
+          RC(wan_permute16_ex(b.q + o0(cch), qs + o0(cch) * rows * world, rows, world, wc(cch) * 2, (int64_t)d * 2, Wd * 2, wc(cch) * 2, rows * wc(cch) * 2, stream));
+        RC(send_q(0));
+        for (int cch = 1; cch < C; ++cch) {   // the later chunks, in the order their launches need them
+          RC(send_k(cch));
+          RC(send_v(cch));
+          RC(send_q(cch));
         }
-        RC(a2a_wait(0));
-        RC(a2a_wait(1));
         for (int cch = 0; cch < C; ++cch) {
           const int Hc = h0[cch + 1] - h0[cch];
-          const int64_t Wc = (int64_t)Hc * 128, o0 = (int64_t)h0[cch] * 128;
-          RC(a2a_wait(2 + cch));
+          RC(a2a_wait(cch));
+          RC(a2a_wait(C + cch));
+          RC(a2a_wait(2 * C + cch));
           {
             ProfScope ps(PROF_SELF_ATTN, st);
-            RC(wan_attention_bounded(qr + o0 * rows * world, kr + o0 * rows, vr + o0 * Lp * S, ks + o0 * rows * world, world * S, S, Ll, Ll, Lp, Hc,
-                                     world, rows * Wd, (int64_t)S * Wd * Lp, 1, b.kmax, stream));
+            RC(wan_attention_bounded(qr + o0(cch) * rows * world, kr + o0(cch) * rows * world, vr + o0(cch) * Lp * S * world, ks + o0(cch) * rows * world,
+                                     world * S, S, Ll, Ll, Lp, Hc, world, rows * wc(cch), (int64_t)S * wc(cch) * Lp, 1, b.kmax, stream));
           }
           if (g_prof_on && g_prof_declined != nullptr && Ll * (int64_t)world > 2048)
             RC(wan_attention_count_declined(b.kmax, world * S, S, Ll, Hc, g_prof_declined, stream));
-          // o chunk c back over the dead q send buffer (its q chunk was waited for above) while the next chunk's launch runs
-          RC(a2a(2 + C + cch, ks + o0 * rows * world, qs + o0 * rows * world, rows * Wc * 2));
+          // o chunk c over the dead k send chunk (its exchange was waited for above), back over the dead q send chunk, while the next launch runs
+          RC(a2a(3 * C + cch, ks + o0(cch) * rows * world, qs + o0(cch) * rows * world, rows * wc(cch) * 2));
         }
         for (int cch = 0; cch < C; ++cch) {   // [chunk][world][rows][Wc] -> [rows][world][Hn 128]
-          const int64_t Wc = (int64_t)(h0[cch + 1] - h0[cch]) * 128, o0 = (int64_t)h0[cch] * 128;
-          RC(a2a_wait(2 + C + cch));
-          RC(wan_permute16_ex(qs + o0 * rows * world, b.q + o0, world, rows, Wc * 2, rows * Wc * 2, Wc * 2, Wd * 2, (int64_t)d * 2, stream));
+          RC(a2a_wait(3 * C + cch));
+          RC(wan_permute16_ex(qs + o0(cch) * rows * world, b.q + o0(cch), world, rows, wc(cch) * 2, rows * wc(cch) * 2, wc(cch) * 2, Wd * 2, (int64_t)d * 2, stream));
         }
       } else {
       RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));

@@ -72,7 +72,7 @@ const Api& api() {
     }                                                                                               \
   } while (0)
 
-constexpr int kSlots = 2 + 2 * WAN_SP_MAX_CHUNKS + 1;   // 0, 1: k, v^T; 2 .. 1 + 2 C: the q and o chunks of a block; the last: wan_sp_all_gather
+constexpr int kSlots = 4 * WAN_SP_MAX_CHUNKS + 1;   // the k, v^T, q and o chunks of a block (C each: k c, v^T C + c, q 2 C + c, o 3 C + c); the last: wan_sp_all_gather
 
 }  // namespace
 

@@ -40,8 +40,8 @@ class SequenceParallel:
     (wan_dit_forward with WAN_SP_ULYSSES, csrc/dit.hip): one attention launch at full L for H / world heads; 4 (world - 1) / world
     shard-sized transfers per block and rank instead of 2 (world - 1); needs H % world == 0 (14B: 40 heads -> 2, 4, 8; 1.3B: 12
     heads -> 2, 4).  Everything outside self-attention is identical in both modes.
-    `chunks` (ulysses): head chunks of the q / o exchanges (wan_sp_info.a2a_chunks, csrc/dit.hip): chunk c's attention launch runs
-    while q chunk c + 1 arrives and o chunk c - 1 returns; None = 2 when a rank holds >= 4 heads (14B at 2 / 4 / 8 ranks: 20 / 10 / 5
+    `chunks` (ulysses): head chunks of the exchanges (wan_sp_info.a2a_chunks, csrc/dit.hip): q, k, v^T and o travel per chunk, chunk 0's
+    first; chunk c's attention launch runs while chunk c + 1's tensors arrive and chunk c - 1's o returns; None = 2 when a rank holds >= 4 heads (14B at 2 / 4 / 8 ranks: 20 / 10 / 5
     heads -> launches of 10 / 5 / 2-3 heads still fill the chip: DESIGN.md section 6), else 1; results are bit-identical for every value."""
 
     def __init__(self, rank: int, world: int, group=None, native: bool = False, mode: str = "allgather", chunks=None):
