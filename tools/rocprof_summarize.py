@@ -10,7 +10,9 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.replace("(anonymous namespace)::", "").replace("void ", "", 1) if name.startswith("void (anonymous") else name
+    name = name.replace("(anonymous namespace)::", "")      # (every kernel of the library lives in one; a name starting with "(" used to
+    if name.startswith("void "):                            #  collapse to "" at the split below: round 5's mixed-plan trace lost its edge kernels)
+        name = name[5:]
     name = name.split("(")[0]
     import re
     m = re.search(r"attn_w64q_kernel<(\d+)>|attn_w64q_kernelILi(\d+)E", name)

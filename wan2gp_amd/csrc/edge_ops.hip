@@ -9,9 +9,11 @@ int wan_ln_modulate_head(const bf16_t* x, bf16_t* out, const float* hmod, const 
 
 #define PE_TOK 32
 // grid.x = ceil(ntok/32), block 256; token t (local) = tok0 + blockIdx.x*32 + i
+// OutT = bf16_t: the bf16 plan (one rounding of the fp32 result); float: the mixed-precision plan's fp32 stream (model.py:1620-1631, no rounding)
+template <typename OutT>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
-                                                          bf16_t* __restrict__ out, int Cin, int Cy, int F, int H, int W,
+                                                          OutT* __restrict__ out, int Cin, int Cy, int F, int H, int W,
                                                           int d, int64_t tok0, int64_t ntok, int64_t out_batch_stride,
                                                           int64_t x_batch_stride) {
   extern __shared__ float patch[];  // [PE_TOK][Kd]
@@ -51,13 +53,17 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 #pragma unroll
     for (int tk = 0; tk < PE_TOK; ++tk) {
       const int64_t tl = t0 + tk;
-      if (tl < ntok) out[(int64_t)b * out_batch_stride + tl * d + n] = f2bf(acc[tk]);
+      if (tl < ntok) {
+        if constexpr (sizeof(OutT) == 4) out[(int64_t)b * out_batch_stride + tl * d + n] = acc[tk];
+        else out[(int64_t)b * out_batch_stride + tl * d + n] = f2bf(acc[tk]);
+      }
     }
   }
 }
 
-int wan_patch_embed_range(const float* x, const float* y, const float* w, const float* bias, bf16_t* out, int B, int Cin,
-                          int Cy, int F, int H, int W, int d, int64_t tok0, int64_t ntok, void* stream) {
+template <typename OutT>
+static int patch_embed_launch(const float* x, const float* y, const float* w, const float* bias, OutT* out, int B, int Cin,
+                              int Cy, int F, int H, int W, int d, int64_t tok0, int64_t ntok, void* stream) {
   WAN_REQUIRE(x && w && bias && out, "wan_patch_embed: null pointer");
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0, "wan_patch_embed: H, W must be even (patch 1x2x2)");
   WAN_REQUIRE(Cy == 0 || y != nullptr, "wan_patch_embed: y missing");
@@ -66,10 +72,19 @@ int wan_patch_embed_range(const float* x, const float* y, const float* w, const 
   WAN_REQUIRE(shm <= 64 * 1024, "wan_patch_embed: too many input channels");
   if (ntok == 0) return 0;
   dim3 grid((unsigned)((ntok + PE_TOK - 1) / PE_TOK), (unsigned)B);
-  hipLaunchKernelGGL(patch_embed_kernel, grid, dim3(256), shm, as_stream(stream), x, y, w, bias, out, Cin, Cy, F, H, W,
+  hipLaunchKernelGGL(patch_embed_kernel<OutT>, grid, dim3(256), shm, as_stream(stream), x, y, w, bias, out, Cin, Cy, F, H, W,
                      d, tok0, ntok, ntok * (int64_t)d, (int64_t)Cin * F * H * W);
   WAN_LAUNCH_CHECK();
   return 0;
+}
+int wan_patch_embed_range(const float* x, const float* y, const float* w, const float* bias, bf16_t* out, int B, int Cin,
+                          int Cy, int F, int H, int W, int d, int64_t tok0, int64_t ntok, void* stream) {
+  return patch_embed_launch<bf16_t>(x, y, w, bias, out, B, Cin, Cy, F, H, W, d, tok0, ntok, stream);
+}
+// the mixed-precision plan's form (csrc/mixed_ops.hip wan_mx_patch_embed): the same tile kernel, fp32 rows out
+int wan_patch_embed_f32_range(const float* x, const float* y, const float* w, const float* bias, float* out, int Cin, int Cy, int F, int H, int W,
+                              int d, int64_t tok0, int64_t ntok, void* stream) {
+  return patch_embed_launch<float>(x, y, w, bias, out, 1, Cin, Cy, F, H, W, d, tok0, ntok, stream);
 }
 
 extern "C" int wan_patch_embed(const float* x, const float* y, const float* w, const float* bias, wan_bf16* out, int B,
@@ -80,7 +95,9 @@ extern "C" int wan_patch_embed(const float* x, const float* y, const float* w, c
 // ---- head GEMM: out[tok][j] = bias[j] + sum_k xm[tok][k] * w[j][k]; 64 tokens x 64 outputs per block, grid.z covers
 // nout = 4 * out_dim outputs in chunks of 64 (64 for the 16-channel latents, 192 for the 48-channel ti2v 5B model) ----
 #define HD_KC 64
-__global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict__ xm, const float* __restrict__ w,
+// InT = bf16_t: the bf16 plan's modulated head input; float: the mixed-precision plan's (unrounded)
+template <typename InT>
+__global__ __launch_bounds__(256) void head_gemm_kernel(const InT* __restrict__ xm, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out, int d,
                                                         int F, int Hg, int Wg, int nout, int64_t tok0, int64_t ntok,
                                                         int64_t rows_per_batch_local, int token_major_out) {
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict
   const int b = blockIdx.y;
   const int j0 = blockIdx.z * 64;
   const int64_t t0 = (int64_t)blockIdx.x * 64;
-  const bf16_t* xb = xm + (int64_t)b * rows_per_batch_local * d;
+  const InT* xb = xm + (int64_t)b * rows_per_batch_local * d;
   float acc[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.f;
@@ -99,7 +116,12 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const bf16_t* __restrict
     for (int i = tid; i < 64 * HD_KC; i += 256) {
       const int r = i / HD_KC, c = i - r * HD_KC;
       const int64_t tl = t0 + r;
-      xs[r][c] = (tl < ntok && k0 + c < d) ? bf2f(xb[tl * d + k0 + c]) : 0.f;
+      float xv0 = 0.f;
+      if (tl < ntok && k0 + c < d) {
+        if constexpr (sizeof(InT) == 4) xv0 = xb[tl * d + k0 + c];
+        else xv0 = bf2f(xb[tl * d + k0 + c]);
+      }
+      xs[r][c] = xv0;
       // w: r -> output j, c -> k
       ws[c][r] = (j0 + r < nout && k0 + c < d) ? w[(int64_t)(j0 + r) * d + k0 + c] : 0.f;
     }
@@ -170,8 +192,16 @@ int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const fl
   if (rc) return rc;
   if (ntok == 0) return 0;
   dim3 grid((unsigned)((ntok + 63) / 64), (unsigned)B, (unsigned)((nout + 63) / 64));
-  hipLaunchKernelGGL(head_gemm_kernel, grid, dim3(256), 0, as_stream(stream), tmp, w, bias, out, d, F, Hg, Wg, nout, tok0,
+  hipLaunchKernelGGL(head_gemm_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)tmp, w, bias, out, d, F, Hg, Wg, nout, tok0,
                      ntok, ntok, token_major_out);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+// the mixed-precision plan's head Linear (csrc/mixed_ops.hip wan_mx_head): fp32 rows in, token-major fp32 [ntok, nout] out
+int wan_head_gemm_f32(const float* xm, const float* w, const float* bias, float* out, int64_t ntok, int d, int nout, void* stream) {
+  if (ntok == 0) return 0;
+  dim3 grid((unsigned)((ntok + 63) / 64), 1u, (unsigned)((nout + 63) / 64));
+  hipLaunchKernelGGL(head_gemm_kernel<float>, grid, dim3(256), 0, as_stream(stream), xm, w, bias, out, d, 1, 1, 1, nout, (int64_t)0, ntok, ntok, 1);
   WAN_LAUNCH_CHECK();
   return 0;
 }

@@ -13,6 +13,12 @@
 //   wan_mx_head           Head.forward on fp32 x         model.py:847-865        token-major fp32 [ntok, nout]
 #include "common.h"
 
+// the edge GEMMs are the bf16 plan's LDS-tiled fp32 kernels instantiated for fp32 rows (csrc/edge_ops.hip; round 5: the plain per-element
+// forms they replace cost 37 ms per forward at 14B-720p -- 0.4 % of a step -- against 5 ms)
+int wan_patch_embed_f32_range(const float* x, const float* y, const float* w, const float* bias, float* out, int Cin, int Cy, int F, int H, int W,
+                              int d, int64_t tok0, int64_t ntok, void* stream);
+int wan_head_gemm_f32(const float* xm, const float* w, const float* bias, float* out, int64_t ntok, int d, int nout, void* stream);
+
 namespace {
 
 // 0: modulate -> bf16 (p0 = modulation bf16 [n_mod, d], p1 = e0 fp32 [batches, n_mod, d]);  1: affine -> bf16 (p0 = weight fp32, p1 = bias fp32)
@@ -181,32 +187,6 @@ __global__ __launch_bounds__(256) void mx_gated_residual_kernel(float* __restric
   }
 }
 
-// out[tok][c] = bias[c] + sum_{ci, ph, pw} in(ci, f, 2 h + ph, 2 w + pw) * w[c][ci][0][ph][pw];  channels >= Cin come from y (i2v: mask + latents)
-__global__ __launch_bounds__(256) void mx_patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ out, int Cin, int Cy, int F,
-                                                             int H, int W, int d, int64_t tok0, int64_t ntok) {
-  const int Hg = H / 2, Wg = W / 2, Ct = Cin + Cy;
-  const int64_t total = ntok * (int64_t)d;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t tl = i / d;
-    const int c = (int)(i - tl * d);
-    const int64_t tok = tok0 + tl;
-    const int f = (int)(tok / ((int64_t)Hg * Wg));
-    const int rem = (int)(tok - (int64_t)f * Hg * Wg);
-    const int hg = rem / Wg, wg = rem - hg * Wg;
-    float acc = 0.f;
-    for (int ci = 0; ci < Ct; ++ci) {
-      const float* src = ci < Cin ? x + (((int64_t)ci * F + f) * H + 2 * hg) * W + 2 * wg : y + (((int64_t)(ci - Cin) * F + f) * H + 2 * hg) * W + 2 * wg;
-      const float* wk = w + ((int64_t)c * Ct + ci) * 4;
-      acc += src[0] * wk[0];
-      acc += src[1] * wk[1];
-      acc += src[W] * wk[2];
-      acc += src[W + 1] * wk[3];
-    }
-    out[i] = acc + bias[c];
-  }
-}
-
 __global__ void mx_sinusoid_kernel(float tval, float* __restrict__ out, int dim) {
   const int half = dim / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,29 +214,6 @@ __global__ __launch_bounds__(256) void mx_linear_f32_kernel(const float* __restr
   }
   s = wave_sum(s);
   if (lane == 0) C[(int64_t)m * N + n] = s + (bias ? bias[n] : 0.f);
-}
-
-// out[tok][j] = bias[j] + sum_c xm[tok][c] * w[j][c]    (xm fp32: the modulated, unrounded head input);  one wave per (tok, 4 outputs)
-__global__ __launch_bounds__(256) void mx_head_gemm_kernel(const float* __restrict__ xm, const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ out, int64_t ntok, int d, int nout) {
-  const int lane = threadIdx.x & 63;
-  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= ntok) return;
-  const float* xr = xm + tok * d;
-  for (int j0 = 0; j0 < nout; j0 += 4) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = lane; c < d; c += 64) {
-      const float v = xr[c];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j0 + j < nout) s[j] += v * w[(int64_t)(j0 + j) * d + c];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float r = wave_sum(s[j]);
-      if (lane == 0 && j0 + j < nout) out[tok * nout + j0 + j] = r + bias[j0 + j];
-    }
-  }
 }
 
 inline hipStream_t mx_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -354,10 +311,7 @@ extern "C" int wan_mx_patch_embed(const float* x, const float* y, const float* w
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && tok0 >= 0 && ntok >= 0 && tok0 + ntok <= (int64_t)F * (H / 2) * (W / 2),
               "wan_mx_patch_embed: H, W must be even and the token range inside the grid");
   if (ntok == 0) return 0;
-  hipLaunchKernelGGL(mx_patch_embed_kernel, dim3(mx_blocks(ntok * (int64_t)d, 256)), dim3(256), 0, mx_stream(stream), x, y, w, bias, out, Cin, Cy, F, H,
-                     W, d, tok0, ntok);
-  WAN_LAUNCH_CHECK();
-  return 0;
+  return wan_patch_embed_f32_range(x, y, w, bias, out, Cin, Cy, F, H, W, d, tok0, ntok, stream);
 }
 
 extern "C" int wan_mx_sinusoid(float t, float* out, int dim, void* stream) {
@@ -384,7 +338,6 @@ extern "C" int wan_mx_head(const float* x, const float* hmod, const float* e, co
   if (ntok == 0) return 0;
   hipLaunchKernelGGL(mx_ln_kernel<2>, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, mx_stream(stream), x, (void*)tmp, (const void*)hmod, e, 2, 0, 1,
                      ntok, e_rows_per_batch, d, eps);
-  hipLaunchKernelGGL(mx_head_gemm_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, mx_stream(stream), (const float*)tmp, w, bias, out, ntok, d, nout);
   WAN_LAUNCH_CHECK();
-  return 0;
+  return wan_head_gemm_f32(tmp, w, bias, out, ntok, d, nout, stream);
 }
