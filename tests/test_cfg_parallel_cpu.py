@@ -107,11 +107,35 @@ def _worker(rank, world, port, q):
         out_i = _generate(pi, image_start=img)
         assert torch.equal(out_i, ref_i), f"i2v under CFG parallelism: max diff {(out_i - ref_i).abs().max().item()}"
         assert not torch.equal(ref_i, ref)
-        # a negative seed means "draw one": rank 0's draw, on every rank
+        # a negative seed means "draw one": rank 0's draw, on every rank -- and the draw leaves this rank's global generator alone
+        gstate = torch.get_rng_state()
         drawn = [pi._replicated_seed(-1)]
+        assert torch.equal(torch.get_rng_state(), gstate)
         allr = [None] * world
         dist.all_gather_object(allr, drawn[0])
         assert len(set(allr)) == 1
+        # two sequence-parallel worlds inside one default group (ranks [0, half) and [half, world)): the latent-sharing group is the
+        # SUB-group, its source a global rank -- each group agrees on its own first member's draw and noise (round-4 advisor: a
+        # broadcast on WORLD from rank 0 hangs or mixes the groups)
+        if half > 1:
+            import types
+            from wan2gp_amd.sp import SequenceParallel
+            groups = [dist.new_group(list(range(s_ * half, (s_ + 1) * half))) for s_ in (0, 1)]
+            mine = rank // half
+            ms = StreamDiT()
+            ms.sp = SequenceParallel(rank % half, half, group=groups[mine])
+            ps = WanAny2VHIP(ms, device="cpu")
+            grp, src = ps._latent_group()
+            assert grp is groups[mine] and src == mine * half
+            sd = ps._replicated_seed(-1)
+            torch.manual_seed(77 + rank)
+            nz = ps._replicated_randn_like(torch.zeros(3, 5))
+            got = [None] * world
+            dist.all_gather_object(got, (sd, nz.tolist()))
+            for g0 in (0, half):
+                assert all(got[r_] == got[g0] for r_ in range(g0, g0 + half)), "a sequence-parallel sub-group disagrees on its draw"
+            assert got[0][1] != got[half][1]                      # different groups, different noise: nothing crossed the group boundary
+        # outside an initialised world nothing is broadcast (cfg_parallel set on a single process: the draw is local)
         # the per-block exchange inside a half can be the Ulysses all-to-alls instead of the all-gathers (bench --parallelism cfg-ulysses)
         cfgu = CfgParallel(rank, world, mode="ulysses")
         assert (cfgu.sp is None) if half == 1 else (cfgu.sp.mode == "ulysses" and cfgu.sp.world == half and cfgu.sp.make_info(64 * half).mode == 1)

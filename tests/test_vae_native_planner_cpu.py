@@ -67,3 +67,17 @@ def test_vae_tile_size_choice_equals_the_references():
             for mixed in (False, True):
                 for hw in ((None, None), (720, 1280), (1088, 1920), (1440, 2560)):
                     assert WanVAEHIP.get_VAE_tile_size(cfg, mem, mixed, *hw) == ns["get_VAE_tile_size"](cfg, mem, mixed, *hw), (cfg, mem, mixed, hw)
+
+
+def test_fp32_plan_is_refused_for_the_wan22_vae_instead_of_building_the_wan21_graph():
+    """`vae_precision` "32" (WanVAEHIP(dtype=torch.float32)) is the Wan2.1 VAE's plan: host graph and key layout are that model's.  The
+    Wan2.2 subclass used to get it silently when constructed with dtype float32 (round-4 advisor); it now refuses in load_state_dict."""
+    import pytest
+    import torch
+    from wan2gp_amd.vae import WanVAEHIP
+    from wan2gp_amd.vae22 import Wan22VAEHIP
+    assert WanVAEHIP.SUPPORTS_F32 and not Wan22VAEHIP.SUPPORTS_F32
+    v = object.__new__(Wan22VAEHIP)
+    v.dtype, v.device = torch.float32, "cpu"
+    with pytest.raises(NotImplementedError, match="Wan2.1 VAE only"):
+        v.load_state_dict({})

@@ -810,8 +810,21 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
     const int fl = (pre ? 6 : 4) | (nseg > 1 ? 64 : 0);
 #ifndef WAN_ATTN_TWO_LAUNCH
     // short KV (cross-attention; attention.hip hands a scratch over from 8 tiles on): one persistent workgroup per CU walks a run of q blocks
+#ifndef WAN_ATTN_NO_MI16   // (the a32 A/B library keeps every call off the 16x16x32 kernel: this branch included)
     if (nseg == 1 && Lk <= 2048 && Lk > 448 && !g_no_persist) {
-      static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+      // the CU count of the device the caller launches on -- per device, like the scratch rings (round-4 advisor: a process-wide static
+      // served the first device's count to every other)
+      static int cus_of[64] = {};
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cus_of[dev] == 0) {
+          int n = 0;
+          cus_of[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        }
+        cus = cus_of[dev];
+      } else {
+        (void)hipGetLastError();
+      }
       const unsigned grid = (unsigned)(total < cus ? total : cus);
 #ifdef W16N_PSTAMPS
       static uint64_t* pst = nullptr;
@@ -819,7 +832,10 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
       raw = reinterpret_cast<float*>(pst);
 #endif
       if (wan_attention_w16n_launch(fl | 128 | 256, grid, stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, (int)nqb, scale_log2e, 1, 0, 0,
-                                    (const float*)kmax_scratch, wg_flags, raw, skip_seg) != 0) return -1;
+                                    (const float*)kmax_scratch, wg_flags, raw, skip_seg) != 0) {
+        wan_set_error("wan_attention: the persistent cross-attention instantiation is missing or its launch failed (flags %d)", fl | 128 | 256);
+        return -1;
+      }
 #ifdef W16N_PSTAMPS
       {
         uint64_t h[12];
@@ -832,6 +848,7 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
       }
 #endif
     } else
+#endif
     if (W16N_TRY(fl | 128, nseg, k_seg_stride, vt_seg_stride, skip_seg)) {
       // ONE bounded launch: the shifted instantiation takes every workgroup (m = 0 inside the plain bound)
     } else

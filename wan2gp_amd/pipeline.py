@@ -12,6 +12,8 @@ callable.  Returns None when interrupted, like the reference.
 """
 from typing import Callable, Optional
 
+import os
+
 import torch
 
 from .rope import get_rotary_pos_embed
@@ -272,15 +274,34 @@ class WanAny2VHIP:
         sp = getattr(self.model, "sp", None)
         return sp is not None and getattr(sp, "world", 1) > 1
 
+    def _latent_group(self):
+        """(process group, global rank of its first member) of the ranks that hold the same latents as this one, or None outside an
+        initialised multi-rank world.  CFG parallelism spans the ranks 0 .. world - 1 of the default group (sp.py CfgParallel builds its
+        halves and pairs from them): the default group, source 0.  Plain sequence parallelism: the group the SequenceParallel object
+        was given (None = the default group) -- which may be a sub-group of a larger world, so the source is translated to a GLOBAL rank
+        (round-4 advisor: a broadcast on WORLD with src 0 hangs for a sub-group whose first member is not global rank 0)."""
+        if not self._ranks_share_latents():
+            return None
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        if getattr(self, "cfg_parallel", None) is not None:
+            return None, 0
+        grp = getattr(self.model.sp, "group", None)
+        return grp, (dist.get_global_rank(grp, 0) if grp is not None else 0)
+
     def _replicated_seed(self, seed):
-        """seed >= 0 as given; a negative seed means "draw one" (torch.seed()) -- in a multi-rank world rank 0's draw, for all."""
+        """seed >= 0 as given; a negative seed means "draw one" -- in a multi-rank world the draw of the latent-sharing group's first
+        rank, for all of them.  Drawn from the OS (not torch.seed(), which would also re-seed this rank's global generator)."""
         if seed >= 0:
             return seed
-        drawn = torch.seed() % (2 ** 31)
-        if self._ranks_share_latents():
+        drawn = int.from_bytes(os.urandom(4), "little") % (2 ** 31)
+        lg = self._latent_group()
+        if lg is not None:
             import torch.distributed as dist
-            t = torch.tensor([drawn], dtype=torch.int64, device=self.device if dist.get_backend() != "gloo" else "cpu")
-            dist.broadcast(t, src=0)
+            grp, src = lg
+            t = torch.tensor([drawn], dtype=torch.int64, device=self.device if dist.get_backend(grp) != "gloo" else "cpu")
+            dist.broadcast(t, src=src, group=grp)
             drawn = int(t.item())
         return drawn
 
@@ -290,15 +311,17 @@ class WanAny2VHIP:
         0 draws and every rank takes its tensor (one broadcast of the prefix's size per step) -- otherwise the conditional and the
         unconditional half of a CFG-parallel world, or the shards of a sequence-parallel one, would denoise different latents."""
         noise = torch.randn_like(ref)
-        if self._ranks_share_latents():
+        lg = self._latent_group()
+        if lg is not None:
             import torch.distributed as dist
-            if dist.get_backend() == "gloo" and noise.is_cuda:
+            grp, src = lg
+            if dist.get_backend(grp) == "gloo" and noise.is_cuda:
                 host = noise.cpu()
-                dist.broadcast(host, src=0)
+                dist.broadcast(host, src=src, group=grp)
                 noise = host.to(ref.device)
             else:
                 noise = noise.contiguous()
-                dist.broadcast(noise, src=0)
+                dist.broadcast(noise, src=src, group=grp)
         return noise
 
     def generate(self, input_prompt=None, n_prompt="", context=None, context_null=None, width=1280, height=720,

@@ -29,6 +29,7 @@ def _pad32(c):
 
 class Wan22VAEHIP(WanVAEHIP):
     NATIVE_GRAPH = False          # this graph (patchify, AvgDown / DupUp shortcuts, 48 latent channels) stays on the host
+    SUPPORTS_F32 = False          # no fp32 plan for this VAE: WanVAEHIP.load_state_dict refuses dtype=float32 instead of building the Wan2.1 graph
     CFG = dict(dim=160, dec_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2, temperal_downsample=[False, True, True])
 
     @staticmethod
