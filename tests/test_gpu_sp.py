@@ -272,15 +272,19 @@ def _native_world1_worker(q):
         spu = SequenceParallel(0, 1, native=True, mode="ulysses")
         iu = spu.make_info(192)
         assert iu.mode == 1 and iu.user
-        recv4 = [torch.zeros(n, dtype=torch.uint8, device="cuda") for _ in range(4)]
-        send4 = [torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda", generator=g) for _ in range(4)]
-        for which in range(4):
+        # ... sixteen slots in flight: the head-chunked exchange of round 5 issues 4 C of them per block (C = 4 here; the library holds 32)
+        ns = 16
+        recv4 = [torch.zeros(n, dtype=torch.uint8, device="cuda") for _ in range(ns)]
+        send4 = [torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda", generator=g) for _ in range(ns)]
+        for which in range(ns):
             assert iu.a2a_begin(iu.user, which, send4[which].data_ptr(), recv4[which].data_ptr(), n, stream_ptr().value) == 0
         assert iu.a2a_begin(iu.user, 2, send4[2].data_ptr(), recv4[2].data_ptr(), n, stream_ptr().value) != 0                # slot busy
-        for which in range(4):
+        assert iu.a2a_begin(iu.user, 33, send4[2].data_ptr(), recv4[2].data_ptr(), n, stream_ptr().value) != 0               # no such slot
+        for which in range(ns):
             assert iu.a2a_wait(iu.user, which, stream_ptr().value) == 0
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(send4, recv4))
+        assert spu.make_info(192, heads=40).a2a_chunks == 2 and SequenceParallel(0, 1, mode="ulysses", chunks=5).make_info(192, heads=40).a2a_chunks == 5
         del sp, spu
         q.put("ok")
     except Exception:

@@ -254,13 +254,19 @@ int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
                      int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                      int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
+#ifndef WAN_GEMM_MIN_TILES_DEFAULT
+#define WAN_GEMM_MIN_TILES_DEFAULT 256
+#endif
 template <int EPI, bool BIAS_ROWS, bool F16 = false>
 static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K,
                        bf16_t* Out, int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod,
                        const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st,
                        float out_scale = 1.0f) {
   const int64_t tx = (XN + BN - 1) / BN;
-  const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= 256;
+  // how many 256 x 256 tiles a problem must have for the one-wave-per-SIMD kernels (a tile per CU: below one wave of tiles the chip is
+  // partly idle for a whole tile time, and the 128-wide kernels balance better).  WAN_GEMM_MIN_TILES overrides for A/B runs.
+  static const int64_t min_tiles = [] { const char* e = getenv("WAN_GEMM_MIN_TILES"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : WAN_GEMM_MIN_TILES_DEFAULT); }();
+  const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= min_tiles;
 #ifndef WAN_GEMM_NO_MI16  // (defined only for the A/B library libwanhip_k.so: gemm256k on every shape)
   if constexpr (!F16 && (!BIAS_ROWS || EPI == WAN_EPI_NONE)) {
     if (many_tiles) {
