@@ -526,7 +526,8 @@ def main():
             log("simulated sequence-parallel ranks: " + args.simulate_world)
             out["simulated_scaling"] = _extra_block(simulate_world, [int(v) for v in args.simulate_world.split(",") if v], model, model2, one_step,
                                                     latents, new_sched, dt / args.steps, cfg, L, par, args.simulate_layout, None,
-                                                    1 if args.simulate_layout == "all" else 2, args.simulate_link_GBs, budget_s=args.extras_budget_s)
+                                                    1 if args.simulate_layout == "all" else 2, args.simulate_link_GBs, args.sp_chunks or None,
+                                                    budget_s=args.extras_budget_s)
         if world == 1 and not args.no_configs3 and args.workload == "14B-720p":
             log("configs3: 14B 720p x 161 frames (L = 147,600), 1 warm-up + 2 timed steps, simulated rank of a world of 8")
             out["configs3"] = _extra_block(configs3_block, model, model2, one_step, new_sched, par, lib, args.simulate_link_GBs, budget_s=args.extras_budget_s)
@@ -834,7 +835,7 @@ def _link_delay(nbytes, link_GBs):
     L_.check(L_.load().wan_debug_delay(nbytes / (link_GBs * 1e3), L_.stream_ptr()), "wan_debug_delay")     # bytes / (GB/s) -> microseconds
 
 
-def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1gpu, cfg, L, par=None, layout="sp", fr=None, k=2, link_GBs=50.0):
+def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1gpu, cfg, L, par=None, layout="sp", fr=None, k=2, link_GBs=50.0, chunks=None):
     """ONE rank (rank 0) of a sequence-parallel world of N on this GPU: its token shard (L / N query rows against N gathered K / V^T
     segments, every token-local kernel at M = S L / N rows), the exchanges replaced by device-to-device copies of what the rank
     would receive, on a side stream like the RCCL path.  `rank_step_ms` / `compute_side_efficiency` are the COMPUTE side of the
@@ -975,8 +976,10 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
                 assert torch.isfinite(lat).all()
                 return dt_, lat
 
+            if sp is not None:
+                sp.chunks = chunks                                            # None: the library default (--sp-chunks overrides)
             C = sp.resolved_chunks(cfg.get("num_heads")) if sp is not None else 1
-            dt, lat_c = timed(0.0, None)
+            dt, lat_c = timed(0.0, chunks)
             row = {"world": n, "layout": name,
                    "rank_step_ms": dt * 1e3, "compute_side_efficiency": step_s_1gpu / (n * dt),
                    # all-gather form: K + V^T of the other ranks of the group; Ulysses: the (deg - 1) / deg of q, k, v^T, o this rank
@@ -986,7 +989,7 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
                                else ("all-gather x 2 (K, V^T)" if sp is not None else "none"),
                    "tokens_per_rank": L // deg, "streams_per_rank": 1 if cfg_half else 2}
             if link_GBs > 0:
-                dl, _ = timed(link_GBs, None)
+                dl, _ = timed(link_GBs, chunks)
                 row.update({"rank_step_ms_link": dl * 1e3, "link_modelled_efficiency": step_s_1gpu / (n * dl),
                             "exposed_ms_per_block": (dl - dt) * 1e3 / layers})
                 if uly and C > 1:
