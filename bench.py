@@ -200,6 +200,31 @@ def cpu_baseline(flops_step_main, sweep=(8, 16, 32, 64, 128), _cfg_name="t2v_1.3
             "extrapolation": f"FLOP ratio {flops_step_main / fl:.0f}x to the main workload (not measured; BASELINE.md section 3)"}
 
 
+def choose_layout(world, parallelism, heads):
+    """-> (cfg_sp, sp_degree, sp_mode): how `world` ranks share a guided step.  cfg_sp: the conditional stream on ranks [0, world/2), the
+    unconditional one on the other half, one swap of the predictions per step; sp_degree: ranks that share one stream's token axis;
+    sp_mode: the per-block exchange inside such a group.  `auto` follows the link-modelled one-GPU tables (runs 02 / 05,
+    25 / 50 / 100 GB/s per peer):
+      * world 2: cfg2 x sp1 -- no per-block exchange at all (0.98);
+      * world 4: cfg2 x sp2 with the K / V^T all-gathers (0.925: one peer, and the gathers hide under a local attention segment half a
+        block long; the Ulysses forms 0.83-0.88);
+      * world >= 8 where the heads divide by it (14B: 40 heads, world 8): the token axis over ALL ranks with the head-chunked Ulysses
+        all-to-alls -- every exchange spreads over 7 links instead of 3, 0.864 / 0.872 / 0.897 at 25 / 50 / 100 GB/s against 0.817 / 0.868 /
+        0.895 for cfg2 x sp4 (ulysses) and 0.59-0.84 for the all-gather forms;
+      * otherwise an even world splits the streams (cfg2 x sp world/2), with the Ulysses exchange from a degree of 4 up where the heads
+        divide by it (1.3B: 12 heads -> cfg2 x sp4 at world 8), else the all-gathers; an odd world is plain sequence parallelism."""
+    if world <= 1:
+        return False, 1, "allgather"
+    if parallelism == "auto":
+        if world >= 8 and heads % world == 0:
+            return False, world, "ulysses"
+        cfg_sp = world % 2 == 0
+        deg = world // 2 if cfg_sp else world
+        return cfg_sp, deg, ("ulysses" if deg >= 4 and heads % deg == 0 else "allgather")
+    cfg_sp = parallelism in ("cfg-sp", "cfg-ulysses") and world % 2 == 0
+    return cfg_sp, (world // 2 if cfg_sp else world), ("ulysses" if parallelism in ("ulysses", "cfg-ulysses") else "allgather")
+
+
 def log(msg):
     """Progress on stderr (stdout carries exactly one JSON line)."""
     if int(os.environ.get("RANK", 0)) == 0:
@@ -235,8 +260,9 @@ def main():
                          "ranks [0, N/2), the unconditional one on [N/2, N), the token axis over the N/2 ranks of a half, one 2-rank swap of "
                          "the predictions per step (wan2gp_amd/sp.py CfgParallel); 'ulysses' / 'cfg-ulysses' = the same two layouts with the "
                          "per-block exchange as four all-to-alls of q, k, v^T, o (heads sharded inside the attention, WAN_SP_ULYSSES; the head "
-                         "count must divide by the sequence-parallel degree) instead of the K / V^T all-gathers; 'auto' = cfg-sp for an even N, "
-                         "sp otherwise (DESIGN.md section 6: the choice and the one-GPU tables behind it)")
+                         "count must divide by the sequence-parallel degree) instead of the K / V^T all-gathers; 'auto' = what the link-modelled "
+                         "one-GPU tables favour (choose_layout: N = 2 cfg-sp, N = 4 cfg-sp with all-gathers, N >= 8 ulysses over all ranks where the "
+                         "heads divide, else cfg-ulysses / cfg-sp; DESIGN.md section 7)")
     ap.add_argument("--extras-budget-s", type=float, default=float(os.environ.get("WAN_BENCH_EXTRAS_BUDGET_S", 900)),
                     help="an OPTIONAL block behind the timed region (secondary workload, simulated ranks, config 5) is skipped -- and says so "
                          "in its place -- when the process is already older than this; the headline measurement, roofline and cpu_baseline never are")
@@ -275,14 +301,7 @@ def main():
     _L = _f * (_h // 2) * (_w // 2)
     if args.parallelism in ("cfg-sp", "cfg-ulysses") and world > 1 and world % 2:
         sys.exit(f"bench.py: --parallelism {args.parallelism} splits the ranks in two halves: {world} is odd")
-    cfg_sp = world > 1 and world % 2 == 0 and args.parallelism in ("auto", "cfg-sp", "cfg-ulysses")
-    sp_degree = world // 2 if cfg_sp else world            # ranks that share one stream's token axis
-    # the per-block exchange: 'auto' takes the Ulysses all-to-alls from a sequence-parallel degree of 4 up, where the heads divide by
-    # it (at a world of 8 a rank computes at 0.93 of linear against 0.92 and exchanges 0.58 GB per block against
-    # 1.16 GB, of which only q and o -- 2 x 48 MB per link -- are exposed), else the K / V^T all-gathers (degree 2: one peer, the same
-    # bytes either way, and the gathers hide under a local attention segment half a block long where q / o exchanges would not)
-    sp_mode = "ulysses" if (args.parallelism in ("ulysses", "cfg-ulysses") or
-                            (args.parallelism == "auto" and sp_degree >= 4 and _cfg["num_heads"] % sp_degree == 0)) else "allgather"
+    cfg_sp, sp_degree, sp_mode = choose_layout(world, args.parallelism, _cfg["num_heads"])
     if _L % sp_degree:
         sys.exit(f"bench.py: the {_L} tokens of workload {args.workload} do not shard over {sp_degree} sequence-parallel ranks "
                  f"(divisors: 2, 4, 8 ...)")

@@ -83,6 +83,23 @@ def test_token_count_that_does_not_shard_is_an_error_before_the_weights_are_buil
     assert "75600" in str(e.value.code) and f"over {degree} sequence-parallel" in str(e.value.code)
 
 
+def test_auto_layout_follows_the_link_modelled_tables():
+    """choose_layout (round 5): N = 2 -> cfg2 x sp1, N = 4 -> cfg2 x sp2 over the all-gathers, N = 8 with 40 heads -> the token axis over all 8
+    ranks with the Ulysses exchange (every all-to-all over 7 links), 12 heads (1.3B) -> cfg2 x sp4 (ulysses), N = 16 -> cfg2 x sp8 (ulysses);
+    an odd world is plain sequence parallelism; explicit modes are taken literally."""
+    b = _bench()
+    assert b.choose_layout(1, "auto", 40) == (False, 1, "allgather")
+    assert b.choose_layout(2, "auto", 40) == (True, 1, "allgather")
+    assert b.choose_layout(4, "auto", 40) == (True, 2, "allgather")
+    assert b.choose_layout(8, "auto", 40) == (False, 8, "ulysses")
+    assert b.choose_layout(8, "auto", 12) == (True, 4, "ulysses")
+    assert b.choose_layout(16, "auto", 40) == (True, 8, "ulysses")
+    assert b.choose_layout(3, "auto", 40) == (False, 3, "allgather")
+    assert b.choose_layout(64, "auto", 40) == (True, 32, "allgather")
+    assert b.choose_layout(8, "cfg-ulysses", 40) == (True, 4, "ulysses") and b.choose_layout(8, "cfg-sp", 40) == (True, 4, "allgather")
+    assert b.choose_layout(8, "sp", 40) == (False, 8, "allgather") and b.choose_layout(8, "ulysses", 40) == (False, 8, "ulysses")
+
+
 def test_cfg_sp_needs_an_even_world(monkeypatch):
     bench = _bench()
     import torch
