@@ -80,8 +80,8 @@ def test_mixed_row_kernels(d):
 def test_linear_with_fp32_gated_residual_epilogue(M, N, K, gate, batches):
     """wan_gemm_bf16_res32 (round 5): the mixed plan's Linear + x.addcmul_(y, gate) as the tile GEMM's epilogue -- BIT-IDENTICAL to the
     two-launch form it replaces (wan_gemm_bf16 NONE into a bf16 tensor, then wan_mx_gated_residual), at the 14B / 1.3B shapes (a batch
-    boundary inside a tile, a ragged last tile), on a shape that takes the fall-back, and with per-frame batches shorter than a tile
-    (fall-back as well); and against an fp64 evaluation on sampled rows."""
+    boundary inside a tile, a ragged last tile, per-frame batches of 900 rows: several gate rows per launch, at most two per tile) and on a
+    shape that takes the fall-back; and against an fp64 evaluation on sampled rows."""
     from wan2gp_amd import mixed_ops as MX, ops
     g = torch.Generator(device="cuda").manual_seed(M + N + K + gate)
     a = torch.randn(M, K, device="cuda", generator=g).to(BF)
