@@ -847,6 +847,11 @@ def test_forward_as_a_replayed_launch_list(mock):
     go = POLL_FN(lambda user, i: seen.append(i) or 0)
     rc, c7, _ = m.forward(S=2, graph=True, poll=go, stream=USER)
     assert rc == 0 and m.how == 3 and seen == [0, 0]
+    # malformed arguments never reach the key (which reads through the arrays): the eager entry reports them
+    bad = DitArgs()
+    bad.S = 2
+    how = c_int(-1)
+    assert mock.wan_dit_forward_graph(m.ctx, ctypes.byref(bad), None, ctypes.byref(how)) != 0 and how.value == 0 and b"null" in mock.wan_last_error()
     # a re-registered weight: the captured lists hold the old pointer and are dropped
     k = "blocks.0.ffn.0.bias"
     assert mock.wan_dit_set_weight(m.ctx, k.encode(), c_void_p(m.addr[k] + 0x100), 0, c.ffn_dim) == 0

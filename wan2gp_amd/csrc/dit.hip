@@ -1178,8 +1178,11 @@ extern "C" int wan_dit_forward_graph(wan_ctx* c, const wan_dit_args* a, void* st
   if (how) *how = 0;
   RC(resolve(c));
   const bool world1 = a->sp == nullptr || a->sp->world <= 1;
-  if (!world1 || a->n_t_frames != 0 || a->should_calc != nullptr || a->residual != nullptr || c->mixed || g_prof_on || a->S < 1 || a->S > 8 ||
-      a->n_vace > 8 || a->n_perturbation_layers > 64)
+  // anything the eager entry would refuse (null arrays, stream counts ...) is ITS error to report: the key below reads through these pointers
+  const bool well_formed = a->x && a->context && a->outs && a->S >= 1 && a->S <= 8 && a->n_vace >= 0 && a->n_vace <= 8 &&
+                           (a->n_vace == 0 || (a->vace_contexts && a->vace_scales)) && a->n_perturbation_layers <= 64 &&
+                           (a->n_perturbation_layers <= 0 || a->perturbation_layers);
+  if (!well_formed || !world1 || a->n_t_frames != 0 || a->should_calc != nullptr || a->residual != nullptr || c->mixed || g_prof_on)
     return wan_dit_forward_ex(c, a, stream);
   std::vector<uint8_t> key;
   key_put(key, a->S); key_put(key, a->F); key_put(key, a->H); key_put(key, a->W);
