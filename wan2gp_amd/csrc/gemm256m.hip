@@ -444,7 +444,9 @@ int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
   }
   const int64_t ty = (YM + M_BM - 1) / M_BM, tx = (XN + M_BN - 1) / M_BN;
   if (ty * tx >= ((int64_t)1 << 31)) return -1;
-  const int group = BIAS_ROWS ? 8 : 4;  // y tiles per group of the tile order (gemm256k.hip)
+  // y tiles per group of the tile order (gemm256k.hip); WAN_GEMM_GROUP overrides the column-bias forms' 4 for A/B runs (round 5, run 07)
+  static const int group_env = [] { const char* e = getenv("WAN_GEMM_GROUP"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const int group = BIAS_ROWS ? 8 : (group_env ? group_env : 4);
   hipLaunchKernelGGL((gemm256m_kernel<EPI, BIAS_ROWS>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R,
                      mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, out_scale, group);
   WAN_LAUNCH_CHECK();
