@@ -36,7 +36,17 @@ def _worker(rank, world, port, q, backend="gloo", native=False, mode="allgather"
         from wan2gp_amd.model import WanModelHIP
         from wan2gp_amd.sp import SequenceParallel
         cfg = O.make_config("small") if model_kw is None else O.WanConfig(**model_kw)
-        W = O.synth_weights(cfg, seed=77)
+        if cfg.dim >= 2048:
+            # model-width checkpoints are drawn on the GPU with the device generator (the same values on every rank: one seed, one
+            # device): a CPU generator needs ~15 s per rank for 0.7 G parameters, eight ranks at once
+            gg = torch.Generator(device="cuda").manual_seed(77)
+            W = {}
+            for k, shp in O.param_shapes(cfg).items():
+                r = torch.randn(shp, generator=gg, device="cuda", dtype=torch.float32)
+                w = r / cfg.dim ** 0.5 if k.endswith("modulation") else (1.0 + 0.02 * r if ("norm" in k and k.endswith("weight")) else (0.01 * r if k.endswith("bias") else 0.02 * r))
+                W[k] = w if k.startswith(O.FP32_LOCKED) else w.to(torch.bfloat16)
+        else:
+            W = O.synth_weights(cfg, seed=77)
         m = WanModelHIP(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers)
         m.load_state_dict(W)
         del W
