@@ -125,6 +125,22 @@ int wan_fp8_quantize(const wan_bf16* x, uint8_t* out, float* ws, int64_t n, void
 int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, const float* w_scale, int w_scale_n,
                  const wan_bf16* bias, wan_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue, const wan_bf16* R,
                  const wan_bf16* mod, const wan_bf16* e, int n_mod, int gate_idx, int64_t rows_per_batch, void* stream);
+/* The abs-max pass of _quantize_activation folded into the kernel that PRODUCES the tensor (round 5): the maximum of |x| is the same
+ * number whoever computes it, so the scale and every fp8 byte are the ones wan_fp8_quantize gives -- but the tensor is not read a second
+ * time for its maximum (3 instead of 5 bytes per element move per quantisation).  Quantisation slots: 64 fp32 words per tensor (a
+ * stream of the joint pass), word 0 = scale_a, word 1 / 2 = abs-max accumulators (float bits, atomicMax) the caller zeroes before the
+ * producer runs.
+ *   wan_ln_modulate_amax / wan_ln_affine_amax: wan_ln_modulate / wan_ln_affine, plus max |out| of every `rows_per_slot` rows into word 1
+ *     of consecutive slots at amax_ws.
+ *   wan_gemm_fp8_amax: wan_gemm_fp8 with WAN_EPI_GELU_TANH (ldc = N), plus max |C| into *amax (ffn.0's output is ffn.2's input).
+ *   wan_fp8_quantize_pre: the quantising half of wan_fp8_quantize, reading the abs-max from ws[amax_word]; ws[0] <- scale_a. */
+int wan_ln_modulate_amax(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod, int shift_idx, int scale_idx,
+                         int64_t rows, int64_t rows_per_batch, int d, float eps, float* amax_ws, int64_t rows_per_slot, void* stream);
+int wan_ln_affine_amax(const wan_bf16* x, wan_bf16* out, const wan_bf16* w, const wan_bf16* b, int64_t rows, int d, float eps, float* amax_ws,
+                       int64_t rows_per_slot, void* stream);
+int wan_gemm_fp8_amax(const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, const float* w_scale, int w_scale_n,
+                      const wan_bf16* bias, wan_bf16* C, int64_t M, int N, int K, float* amax, void* stream);
+int wan_fp8_quantize_pre(const wan_bf16* x, uint8_t* out, float* ws, int64_t n, int amax_word, void* stream);
 
 /* ---- attention ------------------------------------------------------------------------- */
 

@@ -99,6 +99,19 @@ int wan_gemm_bf16(const wan_bf16* A, int64_t lda, const wan_bf16* W, const wan_b
   return rec("gemm", {A, W, bias, C, R, mod, e}, {M, N, K, lda, ldc, epi, gate_idx, rpb});
 }
 int wan_fp8_quantize(const wan_bf16* x, uint8_t* out, float* ws, int64_t n, void*) { return rec("fp8_quantize", {x, out, ws}, {n}); }
+int wan_fp8_quantize_pre(const wan_bf16* x, uint8_t* out, float* ws, int64_t n, int amax_word, void*) { return rec("fp8_quantize_pre", {x, out, ws}, {n, amax_word}); }
+int wan_ln_modulate_amax(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod, int shift_idx, int scale_idx,
+                         int64_t rows, int64_t rows_per_batch, int d, float, float* amax_ws, int64_t rows_per_slot, void*) {
+  return rec("ln_modulate_amax", {x, out, mod, e, amax_ws}, {rows, d, n_mod, shift_idx, scale_idx, rows_per_batch, rows_per_slot});
+}
+int wan_ln_affine_amax(const wan_bf16* x, wan_bf16* out, const wan_bf16* w, const wan_bf16* b, int64_t rows, int d, float, float* amax_ws,
+                       int64_t rows_per_slot, void*) {
+  return rec("ln_affine_amax", {x, out, w, b, amax_ws}, {rows, d, rows_per_slot});
+}
+int wan_gemm_fp8_amax(const uint8_t* A, int64_t lda, const float* sa, const uint8_t* W, const float* wsc, int wn, const wan_bf16* bias, wan_bf16* C,
+                      int64_t M, int N, int K, float* amax, void*) {
+  return rec("gemm_fp8", {A, W, bias, C, nullptr, nullptr, amax, sa}, {M, N, K, lda, N, 1, -1, 1, wn});
+}
 int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* sa, const uint8_t* W, const float* wsc, int wn, const wan_bf16* bias, wan_bf16* C,
                  int64_t ldc, int64_t M, int N, int K, int epi, const wan_bf16* R, const wan_bf16* mod, const wan_bf16* e, int n_mod, int gate_idx,
                  int64_t rpb, void*) {

@@ -112,7 +112,7 @@ def extents(call):
         if p[4]:
             out.append((p[4], M * ldc * 2))
         return out
-    if name == "ln_modulate" or name == "ln_affine":
+    if name in ("ln_modulate", "ln_affine", "ln_modulate_amax", "ln_affine_amax"):
         return [(p[0], i[0] * i[1] * 2), (p[1], i[0] * i[1] * 2)]
     if name == "rmsnorm_rope":
         return [(q, i[0] * i[3] * 2) for q in p[:2] if q]
@@ -129,7 +129,7 @@ def extents(call):
         return [(p[0], i[0])]
     if name == "memcpy":
         return [(p[0], i[0]), (p[1], i[0])]
-    if name == "fp8_quantize":
+    if name in ("fp8_quantize", "fp8_quantize_pre"):
         return [(p[0], i[0] * 2), (p[1], i[0])]
     if name in ("mx_ln_modulate", "mx_ln_affine"):                       # fp32 rows in, bf16 rows out
         return [(p[0], i[0] * i[1] * 4), (p[1], i[0] * i[1] * 2)]
@@ -583,20 +583,48 @@ def test_sequence_parallel_failing_gather_hook_stops_the_forward_with_an_error(m
 
 def test_fp8_checkpoint_quantises_once_per_shared_input(mock):
     """q / k / v share one activation quantisation per stream (the reference quantises per tensor = per stream), the Linears go
-    through the fp8 GEMM with their scales."""
+    through the fp8 GEMM with their scales.  Round 5: four of a block's six quantisations run WITHOUT their abs-max pass -- the
+    LayerNorms in front of q / k / v, cross q and ffn.0 accumulate the abs-max of what they write into word 1 of the streams' slots
+    (zeroed right in front of them), ffn.0's GELU epilogue into word 2 for ffn.2 -- `fp8_quantize_pre`; the attention outputs in front
+    of the two o projections and the text context keep the two-pass form."""
     m = Model(mock, fp8=True)
+    c = m.cfg
     rc, calls, nbytes = m.forward(S=2)
     assert rc == 0, mock.wan_last_error()
     names = [cl[0] for cl in calls]
-    i0 = names.index("ln_modulate")
+    assert "ln_modulate" not in names and "ln_affine" not in names
+    i0 = names.index("ln_modulate_amax")
     i1 = names.index("rmsnorm_rope", i0)
     head = names[i0:i1]
-    assert head.count("fp8_quantize") == 2 and head.count("gemm_fp8") == 2 + 2 + 2       # 2 streams: V^T, q, k
+    assert head.count("fp8_quantize_pre") == 2 and head.count("fp8_quantize") == 0 and head.count("gemm_fp8") == 2 + 2 + 2       # 2 streams: V^T, q, k
+    Ll = 2 * 16
+    per_layer = names[i0:names.index("ln_modulate_amax", names.index("ln_modulate_amax", i0 + 1) + 1)] if c.num_layers > 1 else names[i0:]
+    assert per_layer.count("ln_modulate_amax") == 2 and per_layer.count("ln_affine_amax") == 1
+    assert per_layer.count("fp8_quantize_pre") == 2 + 2 + 2 + 2          # per stream: xm after norm1, norm3, norm2 and the GELU output
+    assert per_layer.count("fp8_quantize") == 2 + 2 + 2                  # per stream: the two attention outputs; the text context (cross k / v)
+    lay = calls[i0:i0 + len(per_layer)]
+    lns = [cl for cl in lay if cl[0] in ("ln_modulate_amax", "ln_affine_amax")]
+    slots = lns[0][1][4]
+    assert all(cl[1][4] == slots and cl[2][6 if cl[0] == "ln_modulate_amax" else 2] == Ll for cl in lns) and in_ws(slots, nbytes)   # rows_per_slot = tokens of a stream
+    for k_, cl in enumerate(lay):
+        if cl[0] in ("ln_modulate_amax", "ln_affine_amax"):
+            z = lay[k_ - 1]
+            assert z[0] == "memset" and z[1][0] == slots and z[2][:2] == [2 * 64 * 4, 0]          # the slots' words zeroed right in front of the producer
+    pre = [cl for cl in lay if cl[0] == "fp8_quantize_pre"]
+    assert [cl[2][1] for cl in pre] == [1, 1, 1, 1, 1, 1, 2, 2]                                   # word 1 x 3 producers x 2 streams, then word 2 (GELU output)
+    assert [cl[1][2] - slots for cl in pre] == [0, 256] * 4                                         # stream s reads slot s
+    gelu = [cl for cl in lay if cl[0] == "gemm_fp8" and cl[2][5] == 1]
+    assert len(gelu) == 2 and [g[1][6] - slots for g in gelu] == [8, 256 + 8]                        # ffn.0 leaves max |h| in word 2 of its stream's slot
     for cl in calls:
         for ptr, n in extents(cl):
             if in_ws(ptr, nbytes):
                 assert ptr + n <= WS + nbytes, (cl[0], hex(ptr - WS), n)
     assert "gemm" in names                                               # time / text embeddings stay bf16
+    # the mixed-precision plan with an fp8 checkpoint keeps the two-pass quantisation (its LayerNorms are the fp32 kernels)
+    mm = Model(mock, fp8=True, mixed=True)
+    rc, calls, _ = mm.forward(S=2)
+    assert rc == 0, mock.wan_last_error()
+    assert "fp8_quantize_pre" not in [cl[0] for cl in calls] and "ln_modulate_amax" not in [cl[0] for cl in calls]
 
 
 def test_interrupt_poll_aborts_between_blocks(mock):

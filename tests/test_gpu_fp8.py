@@ -131,3 +131,56 @@ def test_fp8_checkpoint_forward_vs_reference_golden(tag, per_row):
         dq = ((ob - ref).norm() / ref.norm()).item()
         print(f"[fp8 forward {key}] hip-fp8 vs reference-fp8 {d:.3e}; bf16 checkpoint vs reference-fp8 {dq:.3e}")
         assert torch.isfinite(o).all() and d <= 2.5e-2 and d < dq, (d, dq)
+
+
+@pytest.mark.parametrize("d,rows_per_slot,rows", [(5120, 300, 600), (1536, 37, 111), (256, 5, 60)], ids=["14B_two_streams", "1.3B_three_slots", "row_form_few_rows"])
+def test_absmax_folded_into_the_layernorms_gives_the_same_quantisation(ops, d, rows_per_slot, rows):
+    """Round 5: wan_ln_modulate_amax / wan_ln_affine_amax leave max |out| per stream in the quantisation slots, wan_fp8_quantize_pre reads
+    it -- the rows, the scale and EVERY fp8 byte equal what wan_ln_modulate / wan_ln_affine followed by the two-pass wan_fp8_quantize give
+    (both modulation forms: per-batch table and per-row; three widths; slots shorter than a workgroup's four rows)."""
+    g = torch.Generator(device="cuda").manual_seed(d + rows)
+    x = (torch.randn(rows, d, device="cuda", generator=g) * 2 + 0.3).to(BF)
+    mod = (torch.randn(1, 6, d, device="cuda", generator=g) / d ** 0.5).to(BF)
+    e = (0.5 * torch.randn(1, 6, d, device="cuda", generator=g)).to(BF)
+    w = (1 + 0.05 * torch.randn(d, device="cuda", generator=g)).to(BF)
+    b = (0.02 * torch.randn(d, device="cuda", generator=g)).to(BF)
+    nslot = (rows + rows_per_slot - 1) // rows_per_slot
+    for name, plain, folded in (("modulate", lambda: ops.ln_modulate(x, mod, e, 3, 4), lambda ws: ops.ln_modulate_amax(x, mod, e, 3, 4, ws, rows_per_slot)),
+                                ("affine", lambda: ops.ln_affine(x, w, b), lambda ws: ops.ln_affine_amax(x, w, b, ws, rows_per_slot))):
+        ref = plain()
+        ws = torch.zeros(nslot * 64, dtype=torch.float32, device="cuda")
+        got = folded(ws)
+        assert torch.equal(got, ref), name
+        for sl in range(nslot):
+            part = ref[sl * rows_per_slot:(sl + 1) * rows_per_slot]
+            assert ws[sl * 64 + 1].item() == part.float().abs().max().item(), (name, sl)
+            if part.numel() % 8:
+                continue
+            q_ref, ws_ref = ops.fp8_quantize(part.contiguous())
+            q_pre = ops.fp8_quantize_pre(part.contiguous(), ws[sl * 64:(sl + 1) * 64], 1)
+            assert torch.equal(q_pre.view(torch.uint8), q_ref.view(torch.uint8)) and ws[sl * 64].item() == ws_ref[0].item(), (name, sl)
+
+
+@pytest.mark.parametrize("M,N,K,per_row", [(16384, 4096, 1024, True), (18900, 13824, 5120, False), (512, 256, 256, True)],
+                         ids=["tile_kernel_per_row_scale", "ffn0_14B_ragged_per_tensor", "older_kernel_then_absmax_pass"])
+def test_absmax_folded_into_the_gelu_epilogue(ops, M, N, K, per_row):
+    """wan_gemm_fp8_amax: ffn.0 + GELU on the fp8 MFMA that also leaves max |out| for ffn.2's quantisation -- the same output bits as
+    wan_gemm_fp8, the exact maximum (tile kernel: in the epilogue, ragged last tile included; small shapes: the older kernel + one abs-max
+    pass), and the same fp8 bytes through wan_fp8_quantize_pre as through the two-pass quantiser."""
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda", generator=g).to(BF)
+    wf = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    sc = (wf.abs().amax(dim=1, keepdim=True) / 448.0).clamp_min(1e-12) if per_row else (wf.abs().max() / 448.0).reshape(1, 1)
+    w8 = (wf / sc).clamp(-448, 448).to(torch.float8_e4m3fn)
+    scale = sc.reshape(-1).float().contiguous()
+    bias = (0.1 * torch.randn(N, device="cuda", generator=g)).to(BF)
+    xq = ops.fp8_quantize(x)
+    ref = ops.linear_fp8(x, w8, scale, bias, epilogue=1, x_fp8=xq)
+    slot = torch.zeros(64, dtype=torch.float32, device="cuda")
+    got = ops.linear_fp8_gelu_amax(xq, w8, scale, bias, slot[2:3])
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    assert slot[2].item() == ref.float().abs().max().item()
+    q_ref, ws_ref = ops.fp8_quantize(ref)
+    q_pre = ops.fp8_quantize_pre(ref, slot, 2)
+    assert torch.equal(q_pre.view(torch.uint8), q_ref.view(torch.uint8)) and slot[0].item() == ws_ref[0].item()

@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 // ---- error state ---------------------------------------------------------------------------------
@@ -494,9 +496,13 @@ struct Q8 {
   float* ws = nullptr;
   int64_t slot_bytes = 0;
 };
+// amax_word (round 5): 0 = quantise with the abs-max pass (wan_fp8_quantize); 1 / 2 = the abs-max of every stream's rows already sits in
+// that word of its slot -- left there by the kernel that produced A (the AMAX LayerNorm forms: word 1; ffn.0's GELU epilogue: word 2) -- and
+// only the quantising half runs.  out_amax_word: for a GELU Linear, the word of each stream's slot that receives max |C| for the next one.
 static int linear(const bf16_t* A, const Lin& l, bf16_t* C, int64_t M, int N, int K, int epi, void* st,
                   const bf16_t* R = nullptr, const bf16_t* mod = nullptr, const bf16_t* e = nullptr, int gate = -1,
-                  int64_t rpb = 1, int64_t ldc = 0, const Q8* q8 = nullptr, int nt = 1, int slot0 = 0, bool reuse = false) {
+                  int64_t rpb = 1, int64_t ldc = 0, const Q8* q8 = nullptr, int nt = 1, int slot0 = 0, bool reuse = false, int amax_word = 0,
+                  int out_amax_word = 0) {
   if (l.w8 == nullptr) return wan_gemm_bf16(A, K, l.w, l.b, C, ldc ? ldc : N, M, N, K, epi, R, mod, e, 6, gate, rpb, st);
   WAN_REQUIRE(q8 && q8->xq && M % nt == 0, "fp8 Linear without quantisation scratch (internal)");
   const int64_t Mt = M / nt;
@@ -504,10 +510,16 @@ static int linear(const bf16_t* A, const Lin& l, bf16_t* C, int64_t M, int N, in
   for (int t = 0; t < nt; ++t) {
     uint8_t* xq = q8->xq + (int64_t)(slot0 + t) * q8->slot_bytes;
     float* ws = q8->ws + (int64_t)(slot0 + t) * 64;
-    if (!reuse) RC(wan_fp8_quantize(A + (int64_t)t * Mt * K, xq, ws, Mt * K, st));
+    if (!reuse) {
+      if (amax_word > 0) RC(wan_fp8_quantize_pre(A + (int64_t)t * Mt * K, xq, ws, Mt * K, amax_word, st));
+      else RC(wan_fp8_quantize(A + (int64_t)t * Mt * K, xq, ws, Mt * K, st));
+    }
     const int64_t co = (epi == WAN_EPI_TRANSPOSED) ? 0 : (int64_t)t * Mt * N;
-    RC(wan_gemm_fp8(xq, K, ws, l.w8, l.ws, l.ns, l.b, C + co, ldc ? ldc : N, Mt, N, K, epi, R ? R + co : nullptr, mod, e, 6, gate,
-                    rpb < Mt ? rpb : Mt, st));
+    if (out_amax_word > 0 && epi == WAN_EPI_GELU_TANH && ldc == 0)
+      RC(wan_gemm_fp8_amax(xq, K, ws, l.w8, l.ws, l.ns, l.b, C + co, Mt, N, K, ws + out_amax_word, st));
+    else
+      RC(wan_gemm_fp8(xq, K, ws, l.w8, l.ws, l.ns, l.b, C + co, ldc ? ldc : N, Mt, N, K, epi, R ? R + co : nullptr, mod, e, 6, gate,
+                      rpb < Mt ? rpb : Mt, st));
   }
   return 0;
 }
@@ -774,8 +786,23 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     // mixed-precision plan (mx): b.x holds fp32 rows; modulate / norm3 / the gated residuals are the fp32 kernels of mixed_ops.hip, each
     // Linear that ended in a fused residual epilogue writes its bf16 result to xm (dead at those three points) and a separate pass adds it
     float* const xf = reinterpret_cast<float*>(b.x);
+    // scaled-fp8 checkpoints (round 5): the LayerNorms in front of fp8 Linears (norm1 -> q / k / v, norm3 -> cross q, norm2 -> ffn.0) and
+    // ffn.0's GELU epilogue (-> ffn.2) leave the abs-max of what they write in the streams' quantisation slots, so those four of a block's six
+    // activation quantisations run without their abs-max pass (slot word 1: a LayerNorm's output, word 2: the GELU output; zeroed here, in
+    // front of the producer -- every earlier user of the slots has been enqueued).  `a1` is handed to every consumer: the one that quantises
+    // (reuse == false) takes the short path, the others share its slots as before.
+    static const bool no_fold = [] { const char* e = getenv("WAN_FP8_NO_FOLD"); return e && e[0] == '1'; }();   // A/B runs: the two-pass quantisation everywhere
+    const bool fold = q8 != nullptr && !mx && !no_fold;
+    const int a1 = fold ? 1 : 0;
+    auto zero_slots = [&]() -> int {
+      WAN_CHECK_HIP(hipMemsetAsync(q8->ws, 0, (size_t)S * 64 * sizeof(float), st));
+      return 0;
+    };
     if (mx) RC(wan_mx_ln_modulate(xf, b.xm, Lw.mod, e0f, 6, 0, 1, rows, rpb, d, g.eps, stream));
-    else RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
+    else if (fold) {
+      RC(zero_slots());
+      RC(wan_ln_modulate_amax(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, q8->ws, Ll, stream));
+    } else RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
     if (ulysses) {
       // Ulysses (round 4): re-shard q, k, v from "my tokens, all heads" to "all tokens, my heads" by all-to-all, attend the whole
       // sequence for nh / world heads in ONE launch, bring o back the same way.  Order K, V, Q as below: the k exchange runs under
@@ -824,20 +851,20 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
         auto send_k = [&](int cch) { return a2a(cch, ks + o0(cch) * rows * world, kr + o0(cch) * rows * world, rows * wc(cch) * 2); };
         auto send_v = [&](int cch) { return a2a(C + cch, vs + o0(cch) * Lp * S * world, vr + o0(cch) * Lp * S * world, (int64_t)S * wc(cch) * Lp * 2); };
         auto send_q = [&](int cch) { return a2a(2 * C + cch, qs + o0(cch) * rows * world, qr + o0(cch) * rows * world, rows * wc(cch) * 2); };
-        RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+        RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
         RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
         for (int cch = 0; cch < C; ++cch)   // [rows][world][Hn 128] -> [chunk][world][rows][Wc]
           RC(wan_permute16_ex(b.k + o0(cch), ks + o0(cch) * rows * world, rows, world, wc(cch) * 2, (int64_t)d * 2, Wd * 2, wc(cch) * 2, rows * wc(cch) * 2, stream));
         RC(send_k(0));
         for (int s = 0; s < S; ++s)
           RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                    nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr));
+                    nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
         for (int cch = 0; cch < C; ++cch)   // [S][world][Hn 128][Lp] -> [chunk][world][S][Wc][Lp]
           RC(wan_permute16_ex(b.vt + o0(cch) * Lp, vs + o0(cch) * Lp * S * world, S, world, wc(cch) * Lp * 2, (int64_t)d * Lp * 2, Wd * Lp * 2,
                               wc(cch) * Lp * 2, (int64_t)S * wc(cch) * Lp * 2, stream));
         RC(send_v(0));
         RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
-                  Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr));
+                  Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
         RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
         for (int cch = 0; cch < C; ++cch)   // [rows][world][Hn 128] -> [chunk][world][rows][Wc]
           RC(wan_permute16_ex(b.q + o0(cch), qs + o0(cch) * rows * world, rows, world, wc(cch) * 2, (int64_t)d * 2, Wd * 2, wc(cch) * 2, rows * wc(cch) * 2, stream));
@@ -867,13 +894,13 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
           RC(wan_permute16_ex(qs + o0(cch) * rows * world, b.q + o0(cch), world, rows, wc(cch) * 2, rows * wc(cch) * 2, wc(cch) * 2, Wd * 2, (int64_t)d * 2, stream));
         }
       } else {
-      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
       RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
       RC(wan_permute16(b.k, ks, rows, world, Wd * 2, stream));
       RC(a2a(0, ks, kr, rows * Wd * 2));
       for (int s = 0; s < S; ++s)
         RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr));
+                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
       const bf16_t* vsend = b.vt;
       if (S > 1) {
         RC(wan_permute16(b.vt, vs, S, world, Wd * Lp * 2, stream));
@@ -881,7 +908,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       }
       RC(a2a(1, vsend, vr, (int64_t)S * Wd * Lp * 2));
       RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
-                Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr));
+                Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
       RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
       RC(wan_permute16(b.q, qs, rows, world, Wd * 2, stream));
       RC(a2a(2, qs, qr, rows * Wd * 2));
@@ -900,7 +927,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       // Sequence parallelism: K first (projection, RMSNorm + RoPE), its all-gather started at once; then V^T and its gather; the
       // Q projection / norm and the attention over the rank's OWN K / V^T segment run while both collectives are in flight;
       // only then the waits, and the other ranks' segments on top of the partial sums (wan_attention_sp_local / _remote).
-      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
       RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
       if (sp->gather_begin(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream)) {
         wan_set_error("wan_dit_forward: K all-gather failed");
@@ -908,13 +935,13 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       }
       for (int s = 0; s < S; ++s)
         RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr));
+                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
       if (sp->gather_begin(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
         wan_set_error("wan_dit_forward: V^T all-gather failed");
         return 3;
       }
       RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
-                Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr));
+                Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
       RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
       ProfScope ps(PROF_SELF_ATTN, st);
       RC(wan_attention_sp_local(b.q, b.k, b.vt, S, Ll, Ll, Lp, nh, b.kmax, b.raw, stream));
@@ -927,10 +954,10 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     } else {
       for (int s = 0; s < S; ++s)  // (fp8: this quantises stream s of xm into slot s; q and k below reuse the slots)
         RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                  nullptr, nullptr, -1, 1, Lp, q8, 1, s));
+                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, false, a1));
       const bool vq = Lw.self.v.w8 != nullptr;  // slots hold xm already
-      RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq));
-      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq || Lw.self.q.w8));
+      RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq, a1));
+      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq || Lw.self.q.w8, a1));
       {
         ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
         RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(),
@@ -949,8 +976,11 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     }
     // -- cross attention (model.py:663-668, :245-265) --
     if (mx) RC(wan_mx_ln_affine(xf, b.xm, Lw.n3w32, Lw.n3b32, rows, d, g.eps, stream));
-    else RC(wan_ln_affine(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, stream));
-    RC(linear(b.xm, Lw.cross.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+    else if (fold) {
+      RC(zero_slots());
+      RC(wan_ln_affine_amax(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, q8->ws, Ll, stream));
+    } else RC(wan_ln_affine(b.x, b.xm, Lw.n3w, Lw.n3b, rows, d, g.eps, stream));
+    RC(linear(b.xm, Lw.cross.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
     // norm only; the softmax scale * log2(e) folded into q as for self-attention
     RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.cross.nq, nullptr, nullptr, nullptr, rows, Ll, 0, d, g.eps, wan_attention_qscale(), stream));
     if (any_nag) {
@@ -1023,12 +1053,17 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     }
     // -- FFN (model.py:686-711) --
     if (mx) RC(wan_mx_ln_modulate(xf, b.xm, Lw.mod, e0f, 6, 3, 4, rows, rpb, d, g.eps, stream));
-    else RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 3, 4, rows, rpb, d, g.eps, stream));
+    else if (fold) {
+      RC(zero_slots());
+      RC(wan_ln_modulate_amax(b.x, b.xm, Lw.mod, b.e0, 6, 3, 4, rows, rpb, d, g.eps, q8->ws, Ll, stream));
+    } else RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 3, 4, rows, rpb, d, g.eps, stream));
     {
       ProfScope ps(PROF_GEMM, st);  // the two FFN GEMMs: 4*rows*d*ffn FLOP
-      RC(linear(b.xm, Lw.f0, b.h, rows, ffn, d, WAN_EPI_GELU_TANH, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+      // (ffn.2 reads h's abs-max from word 2 only if ffn.0 IS an fp8 Linear: a bf16 ffn.0 has no such epilogue)
+      const int a2 = (fold && Lw.f0.w8 != nullptr) ? 2 : 0;
+      RC(linear(b.xm, Lw.f0, b.h, rows, ffn, d, WAN_EPI_GELU_TANH, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1, a2));
       if (mx) RC(linear_res32(b.h, Lw.f2, xf, b.xm, rows, d, ffn, Lw.mod, e0f, 5, rpb, S));
-      else RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb, 0, q8, S));
+      else RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb, 0, q8, S, 0, false, a2));
     }
     return 0;
   };

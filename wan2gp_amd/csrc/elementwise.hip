@@ -163,11 +163,15 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? 3 : 1)) void r
 // LayerNorm family.  MODE 0: LN + modulate (norm1/norm2), MODE 1: LN affine (norm3),
 // MODE 2: LN + modulate with fp32 modulation table (head, model.py:856-862)
 // ------------------------------------------------------------------------------------------------
-template <int NCH, int MODE, bool PERSIST = false>
+// AMAX (round 5, scaled-fp8 checkpoints): the kernel also leaves max |out| of every `rows_per_amax` rows (= a stream of the joint pass) in
+// word 1 of that stream's 64-word quantisation slot, amax[(row / rows_per_amax) * 64 + 1], as float bits of the bf16 values by atomicMax
+// (non-negative floats order like unsigned integers; the caller zeroed the words) -- the abs-max pass of the NEXT Linear's activation
+// quantisation (scaled_fp8.py:162-169) folded into the producer of its input: the tensor is not read a second time for its maximum.
+template <int NCH, int MODE, bool PERSIST = false, bool AMAX = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const bf16_t* __restrict__ xin, bf16_t* __restrict__ out, const void* __restrict__ p0,
     const bf16_t* __restrict__ p1, int n_mod, int shift_idx, int scale_idx, int64_t rows,
-    int64_t rows_per_batch, int d, float eps) {
+    int64_t rows_per_batch, int d, float eps, unsigned int* __restrict__ amax = nullptr, int64_t rows_per_amax = 1) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
@@ -176,6 +180,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
   const int nchunk = d >> 3;
 
   uint4 raw[NCH], nxt[NCH];  // rows packed in registers; the PERSIST form exists but is not launched (see above)
+  uint32_t am = 0;
   load_row<NCH>(raw, xin + row * (int64_t)d, lane, nchunk);
   for (;;) {
     const int64_t nrow = row + stride;
@@ -265,8 +270,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
             y[j] = rbf(ln * sc) + sh;
           }
         }
-        *reinterpret_cast<uint4*>(o + c * 8) = pack8(y);
+        const uint4 pk = pack8(y);
+        *reinterpret_cast<uint4*>(o + c * 8) = pk;
+        if (AMAX) {
+          const uint32_t ww[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) am = max(am, max((ww[j] << 16) & 0x7fffffffu, ww[j] & 0x7fff0000u));
+        }
       }
+    }
+    if (AMAX) {
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) am = max(am, (uint32_t)__shfl_xor((int)am, o2, 64));
+      if (lane == 0 && am != 0) atomicMax(amax + (int64_t)((uint32_t)row / (uint32_t)rows_per_amax) * 64 + 1, am);
+      am = 0;
     }
     if (!more) break;
     for (int i = 0; i < NCH; ++i) raw[i] = nxt[i];
@@ -628,17 +645,19 @@ void* wan_scratch_ring_slot(int tag, size_t slot_bytes, int nslot, size_t need_b
   return r->base + (size_t)(r->next++ % (unsigned)r->nslot) * r->slot_bytes;
 }
 
-extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod,
-                               int shift_idx, int scale_idx, int64_t rows, int64_t rows_per_batch, int d, float eps,
-                               void* stream) {
+static int ln_modulate_impl(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod,
+                            int shift_idx, int scale_idx, int64_t rows, int64_t rows_per_batch, int d, float eps,
+                            unsigned int* amax, int64_t rows_per_amax, void* stream) {
   WAN_REQUIRE(x && out && mod && e, "wan_ln_modulate: null pointer");
   WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_ln_modulate: d=%d must be a multiple of 8 and <= 8192", d);
   WAN_REQUIRE(shift_idx >= 0 && shift_idx < n_mod && scale_idx >= 0 && scale_idx < n_mod, "wan_ln_modulate: bad idx");
   WAN_REQUIRE(rows < ((int64_t)1 << 31) && rows_per_batch > 0 && rows_per_batch < ((int64_t)1 << 31),
               "wan_ln_modulate: rows / rows_per_batch must fit 31 bits");
+  WAN_REQUIRE(amax == nullptr || (rows_per_amax > 0 && rows_per_amax < ((int64_t)1 << 31)), "wan_ln_modulate_amax: rows_per_slot must fit 31 bits");
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
   const int64_t nb = (rows + rows_per_batch - 1) / rows_per_batch;
+  const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
   // many rows per batch: derive the two modulation vectors once per batch (a ~2 us kernel) and let the row kernel read them
   bf16_t* tab = (rows >= 64 * nb) ? modtab_slot((size_t)nb * 2 * d * 2, as_stream(stream)) : nullptr;
   if (tab != nullptr) {
@@ -646,27 +665,72 @@ extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16*
     hipLaunchKernelGGL(mod_table_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, as_stream(stream), mod, e, tab, n_mod, shift_idx,
                        scale_idx, d, (int)nb);
     WAN_LAUNCH_CHECK();
-    DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 3>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
-                                         dim3(256), 0, as_stream(stream), x, out, (const void*)nullptr, (const bf16_t*)tab, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps));
+    if (amax != nullptr) {
+      DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 3, false, true>), grid, dim3(256), 0, as_stream(stream), x, out, (const void*)nullptr,
+                                           (const bf16_t*)tab, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps, amax, rows_per_amax));
+    } else {
+      DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 3>), grid, dim3(256), 0, as_stream(stream), x, out, (const void*)nullptr,
+                                           (const bf16_t*)tab, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps, (unsigned int*)nullptr, (int64_t)1));
+    }
     WAN_LAUNCH_CHECK();
     return 0;
   }
-  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 0>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
-                                       dim3(256), 0, as_stream(stream), x, out, (const void*)mod, e, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps));
+  if (amax != nullptr) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 0, false, true>), grid, dim3(256), 0, as_stream(stream), x, out, (const void*)mod, e, n_mod,
+                                         shift_idx, scale_idx, rows, rows_per_batch, d, eps, amax, rows_per_amax));
+  } else {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 0>), grid, dim3(256), 0, as_stream(stream), x, out, (const void*)mod, e, n_mod,
+                                         shift_idx, scale_idx, rows, rows_per_batch, d, eps, (unsigned int*)nullptr, (int64_t)1));
+  }
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod,
+                               int shift_idx, int scale_idx, int64_t rows, int64_t rows_per_batch, int d, float eps,
+                               void* stream) {
+  return ln_modulate_impl(x, out, mod, e, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps, nullptr, 1, stream);
+}
+
+// wan_ln_modulate that also accumulates max |out| per `rows_per_slot` rows into word 1 of consecutive 64-word quantisation slots at
+// `amax_ws` (float bits, atomicMax; the caller zeroed the words): what wan_fp8_quantize_pre(..., amax_word 1) reads (round 5)
+extern "C" int wan_ln_modulate_amax(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod,
+                                    int shift_idx, int scale_idx, int64_t rows, int64_t rows_per_batch, int d, float eps,
+                                    float* amax_ws, int64_t rows_per_slot, void* stream) {
+  WAN_REQUIRE(amax_ws != nullptr, "wan_ln_modulate_amax: null amax words");
+  return ln_modulate_impl(x, out, mod, e, n_mod, shift_idx, scale_idx, rows, rows_per_batch, d, eps, reinterpret_cast<unsigned int*>(amax_ws),
+                          rows_per_slot, stream);
+}
+
+static int ln_affine_impl(const wan_bf16* x, wan_bf16* out, const wan_bf16* w, const wan_bf16* b, int64_t rows, int d, float eps,
+                          unsigned int* amax, int64_t rows_per_amax, void* stream) {
+  WAN_REQUIRE(x && out && w && b, "wan_ln_affine: null pointer");
+  WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_ln_affine: d=%d must be a multiple of 8 and <= 8192", d);
+  WAN_REQUIRE(amax == nullptr || (rows < ((int64_t)1 << 31) && rows_per_amax > 0 && rows_per_amax < ((int64_t)1 << 31)),
+              "wan_ln_affine_amax: rows / rows_per_slot must fit 31 bits");
+  if (rows == 0) return 0;
+  const int nch = pick_nch(d);
+  const dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+  if (amax != nullptr) {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 1, false, true>), grid, dim3(256), 0, as_stream(stream), x, out, (const void*)w, b, 0, 0, 0,
+                                         rows, rows, d, eps, amax, rows_per_amax));
+  } else {
+    DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 1>), grid, dim3(256), 0, as_stream(stream), x, out, (const void*)w, b, 0, 0, 0,
+                                         rows, rows, d, eps, (unsigned int*)nullptr, (int64_t)1));
+  }
   WAN_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int wan_ln_affine(const wan_bf16* x, wan_bf16* out, const wan_bf16* w, const wan_bf16* b, int64_t rows,
                              int d, float eps, void* stream) {
-  WAN_REQUIRE(x && out && w && b, "wan_ln_affine: null pointer");
-  WAN_REQUIRE(d % 8 == 0 && d <= 8192, "wan_ln_affine: d=%d must be a multiple of 8 and <= 8192", d);
-  if (rows == 0) return 0;
-  const int nch = pick_nch(d);
-  DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 1>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
-                                       dim3(256), 0, as_stream(stream), x, out, (const void*)w, b, 0, 0, 0, rows, rows, d, eps));
-  WAN_LAUNCH_CHECK();
-  return 0;
+  return ln_affine_impl(x, out, w, b, rows, d, eps, nullptr, 1, stream);
+}
+
+extern "C" int wan_ln_affine_amax(const wan_bf16* x, wan_bf16* out, const wan_bf16* w, const wan_bf16* b, int64_t rows, int d, float eps,
+                                  float* amax_ws, int64_t rows_per_slot, void* stream) {
+  WAN_REQUIRE(amax_ws != nullptr, "wan_ln_affine_amax: null amax words");
+  return ln_affine_impl(x, out, w, b, rows, d, eps, reinterpret_cast<unsigned int*>(amax_ws), rows_per_slot, stream);
 }
 
 // head LN+modulate (fp32 modulation): exposed to head.hip
@@ -675,7 +739,8 @@ int wan_ln_modulate_head(const bf16_t* x, bf16_t* out, const float* hmod, const 
   if (rows == 0) return 0;
   const int nch = pick_nch(d);
   DISPATCH_NCH(nch, hipLaunchKernelGGL((layernorm_kernel<NCH, 2>), dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)),
-                                       dim3(256), 0, as_stream(stream), x, out, (const void*)hmod, e, 2, 0, 1, rows, rows_per_batch, d, eps));
+                                       dim3(256), 0, as_stream(stream), x, out, (const void*)hmod, e, 2, 0, 1, rows, rows_per_batch, d, eps,
+                                       (unsigned int*)nullptr, (int64_t)1));
   WAN_LAUNCH_CHECK();
   return 0;
 }

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
 // ---- activation quantisation (scaled_fp8.py:162-169) --------------------------------------------------------------------------
 // pass 1: absmax over the tensor (|x| as float bits: non-negative floats order like unsigned integers; NaN bits order above
 // +inf, so a NaN survives -- as it does through torch's .max()).  ws[1] must be zero on entry.
-__global__ __launch_bounds__(256) void fp8_absmax_kernel(const bf16_t* __restrict__ x, int64_t n8, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void fp8_absmax_kernel(const bf16_t* __restrict__ x, int64_t n8, unsigned int* __restrict__ amax) {
   uint32_t m = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const uint4 v = reinterpret_cast<const uint4*>(x)[i];
@@ -346,13 +346,13 @@ __global__ __launch_bounds__(256) void fp8_absmax_kernel(const bf16_t* __restric
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(reinterpret_cast<unsigned int*>(ws + 1), m);
+  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(amax, m);
 }
 // pass 2: scale = absmax / 448 (1 if absmax == 0) -> ws[0]; q = fp8(clamp(bf16(x / bf16(scale)), +-448)).
 // v_cvt_pk_fp8_f32 converts with round-to-nearest-even into OCP e4m3fn on gfx950; the operands are bf16 values, exact in fp32.
 __global__ __launch_bounds__(256) void fp8_quant_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ out, int64_t n8,
-                                                       float* __restrict__ ws) {
-  const float absmax = ws[1];
+                                                       float* __restrict__ ws, const float* __restrict__ amax_src) {
+  const float absmax = *amax_src;
   const float scale = absmax > 0.f ? absmax / 448.0f : 1.0f;
   if (blockIdx.x == 0 && threadIdx.x == 0) ws[0] = scale;
   const float sdiv = rbf(scale);
@@ -380,20 +380,32 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const bf16_t* __restrict
 template <int EPI, bool BIAS_ROWS>
 int wan_gemm_fp8m_try(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                       int64_t ldo, const bf16_t* bias, const float* scale_a, const float* scale_w, bool scale_vec, const bf16_t* R,
-                      const bf16_t* mod, const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st);
+                      const bf16_t* mod, const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st, unsigned int* amax_out);
 namespace {
 
 template <int EPI, bool BIAS_ROWS>
 int launch_fp8(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                int64_t ldo, const bf16_t* bias, const float* scale_a, const float* scale_w, bool scale_vec, const bf16_t* R,
-               const bf16_t* mod, const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st) {
+               const bf16_t* mod, const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st,
+               unsigned int* amax_out = nullptr) {
+  // amax_out (GELU form only, wan_gemm_fp8_amax): the abs-max of the stored tensor -- inside the tile kernel's epilogue, or by the
+  // streaming abs-max pass behind the older kernel (the caller gets its maximum either way)
 #ifndef WAN_FP8_NO_M
   {
     const int rc = wan_gemm_fp8m_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, scale_a, scale_w, scale_vec, R, mod, e, n_mod,
-                                                     gate_idx, rows_per_batch, st);
+                                                     gate_idx, rows_per_batch, st, EPI == WAN_EPI_GELU_TANH ? amax_out : nullptr);
     if (rc >= 0) return rc;
   }
 #endif
+  struct AmaxBehind {   // the older kernel has no amax epilogue: one abs-max pass over its (contiguous, ldo == XN) output when it has run
+    unsigned int* p; const bf16_t* out; int64_t n; hipStream_t st;
+    ~AmaxBehind() {
+      if (p == nullptr) return;
+      const int64_t n8 = n / 8;
+      const int blocks = (int)min((int64_t)4096, (n8 + 255) / 256);
+      hipLaunchKernelGGL(fp8_absmax_kernel, dim3(blocks), dim3(256), 0, st, out, n8, p);
+    }
+  } behind{(amax_out != nullptr && ldo == XN && (YM * XN) % 8 == 0) ? amax_out : nullptr, Out, YM * XN, st};
   WAN_REQUIRE(256 * ldy + (int64_t)K < ((int64_t)1 << 32) && 256 * ldx + (int64_t)K < ((int64_t)1 << 32),
               "wan_gemm_fp8: row pitch exceeds the 32-bit DMA offsets of a tile");
   const int64_t ty = (YM + F_BM - 1) / F_BM, tx = (XN + F_BN - 1) / F_BN;
@@ -419,17 +431,33 @@ extern "C" int wan_fp8_quantize(const wan_bf16* x, uint8_t* out, float* ws, int6
   WAN_CHECK_HIP(hipMemsetAsync(ws + 1, 0, sizeof(float), st));
   const int64_t n8 = n / 8;
   const int blocks = (int)min((int64_t)4096, (n8 + 255) / 256);
-  hipLaunchKernelGGL(fp8_absmax_kernel, dim3(blocks), dim3(256), 0, st, x, n8, ws);
+  hipLaunchKernelGGL(fp8_absmax_kernel, dim3(blocks), dim3(256), 0, st, x, n8, reinterpret_cast<unsigned int*>(ws + 1));
   WAN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(fp8_quant_kernel, dim3(blocks), dim3(256), 0, st, x, out, n8, ws);
+  hipLaunchKernelGGL(fp8_quant_kernel, dim3(blocks), dim3(256), 0, st, x, out, n8, ws, (const float*)(ws + 1));
   WAN_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, const float* w_scale,
+// The second half alone (round 5): ws[amax_word] already holds the tensor's abs-max as float bits -- accumulated with atomicMax by the
+// kernel that PRODUCED x (wan_ln_modulate_amax / wan_ln_affine_amax: word 1 of the stream's slot; wan_gemm_fp8_amax's GELU epilogue: word
+// 2) into a word the caller zeroed before that kernel ran.  The same maximum, hence the same scale and the same bytes as
+// wan_fp8_quantize; 3 instead of 5 bytes per element move.
+extern "C" int wan_fp8_quantize_pre(const wan_bf16* x, uint8_t* out, float* ws, int64_t n, int amax_word, void* stream) {
+  WAN_REQUIRE(x && out && ws, "wan_fp8_quantize_pre: null argument");
+  WAN_REQUIRE(n > 0 && n % 8 == 0 && amax_word >= 1 && amax_word < 64, "wan_fp8_quantize_pre: n=%lld must be a positive multiple of 8, amax_word=%d in [1, 64)",
+              (long long)n, amax_word);
+  WAN_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)out) & 7) == 0, "wan_fp8_quantize_pre: x must be 16-byte, out 8-byte aligned");
+  const int64_t n8 = n / 8;
+  const int blocks = (int)min((int64_t)4096, (n8 + 255) / 256);
+  hipLaunchKernelGGL(fp8_quant_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, out, n8, ws, (const float*)(ws + amax_word));
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int gemm_fp8_entry(const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, const float* w_scale,
                             int w_scale_n, const wan_bf16* bias, wan_bf16* C, int64_t ldc, int64_t M, int N, int K,
                             int epilogue, const wan_bf16* R, const wan_bf16* mod, const wan_bf16* e, int n_mod, int gate_idx,
-                            int64_t rows_per_batch, void* stream) {
+                            int64_t rows_per_batch, void* stream, unsigned int* amax_out) {
   WAN_REQUIRE(A && W && C && scale_a && w_scale, "wan_gemm_fp8: null operand");
   WAN_REQUIRE(K > 0 && K % F_BK == 0, "wan_gemm_fp8: K=%d must be a positive multiple of %d", K, F_BK);
   WAN_REQUIRE(w_scale_n == 1 || w_scale_n == N, "wan_gemm_fp8: weight scale must be a scalar or one value per output row (%d for N=%d)",
@@ -445,7 +473,8 @@ extern "C" int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* scale_a,
       return launch_fp8<WAN_EPI_NONE, false>(A, lda, M, W, K, N, K, C, ldc, bias, scale_a, w_scale, sv, nullptr, nullptr, nullptr, 0, -1, 1, st);
     case WAN_EPI_GELU_TANH:
       WAN_REQUIRE(N % 16 == 0, "wan_gemm_fp8: N=%d must be a multiple of 16", N);
-      return launch_fp8<WAN_EPI_GELU_TANH, false>(A, lda, M, W, K, N, K, C, ldc, bias, scale_a, w_scale, sv, nullptr, nullptr, nullptr, 0, -1, 1, st);
+      return launch_fp8<WAN_EPI_GELU_TANH, false>(A, lda, M, W, K, N, K, C, ldc, bias, scale_a, w_scale, sv, nullptr, nullptr, nullptr, 0, -1, 1, st,
+                                                  amax_out);
     case WAN_EPI_GATE_RES:
       WAN_REQUIRE(N % 16 == 0, "wan_gemm_fp8: N=%d must be a multiple of 16", N);
       WAN_REQUIRE(R != nullptr, "wan_gemm_fp8: GATE_RES needs the residual R");
@@ -458,4 +487,20 @@ extern "C" int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* scale_a,
       WAN_REQUIRE(false, "wan_gemm_fp8: unknown epilogue %d", epilogue);
   }
   return 0;
+}
+
+extern "C" int wan_gemm_fp8(const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, const float* w_scale,
+                            int w_scale_n, const wan_bf16* bias, wan_bf16* C, int64_t ldc, int64_t M, int N, int K,
+                            int epilogue, const wan_bf16* R, const wan_bf16* mod, const wan_bf16* e, int n_mod, int gate_idx,
+                            int64_t rows_per_batch, void* stream) {
+  return gemm_fp8_entry(A, lda, scale_a, W, w_scale, w_scale_n, bias, C, ldc, M, N, K, epilogue, R, mod, e, n_mod, gate_idx, rows_per_batch, stream, nullptr);
+}
+
+// wan_gemm_fp8 with WAN_EPI_GELU_TANH that also leaves max|C| (float bits of the bf16 values, atomicMax) in *amax -- a word the caller
+// zeroed; what the NEXT Linear's wan_fp8_quantize_pre reads (ffn.0 -> ffn.2: the largest tensor of a block is never re-read for its maximum)
+extern "C" int wan_gemm_fp8_amax(const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* W, const float* w_scale, int w_scale_n,
+                                 const wan_bf16* bias, wan_bf16* C, int64_t M, int N, int K, float* amax, void* stream) {
+  WAN_REQUIRE(amax != nullptr, "wan_gemm_fp8_amax: null amax word");
+  return gemm_fp8_entry(A, lda, scale_a, W, w_scale, w_scale_n, bias, C, N, M, N, K, WAN_EPI_GELU_TANH, nullptr, nullptr, nullptr, 0, -1, 1, stream,
+                        reinterpret_cast<unsigned int*>(amax));
 }

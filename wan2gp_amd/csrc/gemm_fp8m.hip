@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void gemm_fp8m_kernel(const uint8_t* __restric
                                                        const float* __restrict__ scale_a, const float* __restrict__ scale_w,
                                                        const bf16_t* __restrict__ R, const bf16_t* __restrict__ mod,
                                                        const bf16_t* __restrict__ e, int n_mod, int gate_idx,
-                                                       int64_t rows_per_batch, int tiles_y, int tiles_x, int group) {
+                                                       int64_t rows_per_batch, int tiles_y, int tiles_x, int group,
+                                                       unsigned int* __restrict__ amax_out) {
   __shared__ __attribute__((aligned(16))) char smem[M_NU * M_UNIT];  // 160 KiB
   f8m_lds_cchar* lds = (f8m_lds_cchar*)smem;
   M_STAMP(0);
@@ -304,6 +305,10 @@ __global__ __launch_bounds__(256) void gemm_fp8m_kernel(const uint8_t* __restric
 #pragma unroll
       for (int i = 0; i < 4; ++i) { rq[0][i] = rload(0, i); rq[1][i] = rload(1, i); }
     }
+    // round 5 (GELU form, amax_out != NULL): |max| of what this tile stores, as float bits of the bf16 values -- the abs-max pass of the
+    // NEXT Linear's activation quantisation (ffn.2 reads this tensor) folded into its producer; rows of a ragged last tile are re-reads of
+    // the last valid row, so they cannot raise the maximum
+    uint32_t amax = 0;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       if (EPI == WAN_EPI_GATE_RES && a + 2 < 8) {
@@ -350,9 +355,20 @@ __global__ __launch_bounds__(256) void gemm_fp8m_kernel(const uint8_t* __restric
         }
         const uint4 w = pack8(v);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(f8m_st4, w), odesc, (int)(lane_off + rit * ldo2), 0, 0);
-        if (EPI == WAN_EPI_GELU_TANH) __builtin_amdgcn_sched_barrier(0);  // 8 GELUs' temporaries at a time
+        if (EPI == WAN_EPI_GELU_TANH) {
+          const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) amax = max(amax, max((ww[j] << 16) & 0x7fffffffu, ww[j] & 0x7fff0000u));
+          __builtin_amdgcn_sched_barrier(0);  // 8 GELUs' temporaries at a time
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (EPI == WAN_EPI_GELU_TANH && amax_out != nullptr) {
+      if (!col_in) amax = 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o, 64));
+      if (lane_e == 0 && amax != 0) atomicMax(amax_out, amax);
     }
   }
   M_STAMP(3);
@@ -364,7 +380,7 @@ __global__ __launch_bounds__(256) void gemm_fp8m_kernel(const uint8_t* __restric
 template <int EPI, bool BIAS_ROWS>
 int wan_gemm_fp8m_try(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                       int64_t ldo, const bf16_t* bias, const float* scale_a, const float* scale_w, bool scale_vec, const bf16_t* R,
-                      const bf16_t* mod, const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st) {
+                      const bf16_t* mod, const bf16_t* e, int n_mod, int gate_idx, int64_t rows_per_batch, hipStream_t st, unsigned int* amax_out) {
   if (K % M_BK != 0 || XN % 8 != 0) return -1;             // a lane stores 8 columns or none
   if (!BIAS_ROWS && XN % M_BN != 0) return -1;             // column bias / scale / gate rows are fetched per lane without an edge form
   if (ldo % 8 != 0 || ((uintptr_t)Out & 15) != 0 || (!BIAS_ROWS && bias != nullptr && ((uintptr_t)bias & 15) != 0)) return -1;
@@ -381,10 +397,10 @@ int wan_gemm_fp8m_try(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* 
   const int group = BIAS_ROWS ? 8 : 4;  // y tiles per group of the tile order (gemm256k.hip)
   if (scale_vec)
     hipLaunchKernelGGL((gemm_fp8m_kernel<EPI, BIAS_ROWS, true>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx, XN, K, Out, ldo,
-                       bias, scale_a, scale_w, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, group);
+                       bias, scale_a, scale_w, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, group, amax_out);
   else
     hipLaunchKernelGGL((gemm_fp8m_kernel<EPI, BIAS_ROWS, false>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx, XN, K, Out, ldo,
-                       bias, scale_a, scale_w, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, group);
+                       bias, scale_a, scale_w, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, group, amax_out);
   WAN_LAUNCH_CHECK();
   return 0;
 }
@@ -392,7 +408,7 @@ int wan_gemm_fp8m_try(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* 
 #define F8M_INST(EPI, BR)                                                                                                            \
   template int wan_gemm_fp8m_try<EPI, BR>(const uint8_t*, int64_t, int64_t, const uint8_t*, int64_t, int64_t, int, bf16_t*, int64_t, \
                                           const bf16_t*, const float*, const float*, bool, const bf16_t*, const bf16_t*, const bf16_t*, \
-                                          int, int, int64_t, hipStream_t);
+                                          int, int, int64_t, hipStream_t, unsigned int*);
 F8M_INST(WAN_EPI_NONE, false)
 F8M_INST(WAN_EPI_GELU_TANH, false)
 F8M_INST(WAN_EPI_GATE_RES, false)

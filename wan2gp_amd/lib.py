@@ -71,6 +71,12 @@ SIGNATURES = {
     "wan_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                               c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "wan_fp8_quantize": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "wan_fp8_quantize_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "wan_ln_modulate_amax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int, c_float, c_void_p,
+                                     c_int64, c_void_p]),
+    "wan_ln_affine_amax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int64, c_void_p]),
+    "wan_gemm_fp8_amax": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p,
+                                  c_void_p]),
     "wan_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int,
                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p]),
     "wan_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_int64,

@@ -79,6 +79,59 @@ def ln_affine(x, w, b, eps=1e-6, out=None):
     return out
 
 
+def ln_modulate_amax(x, mod, e, shift_idx, scale_idx, amax_ws, rows_per_slot, eps=1e-6, out=None):
+    """ln_modulate that also leaves max |out| of every `rows_per_slot` rows in word 1 of consecutive 64-word fp32 slots of `amax_ws` (float
+    bits, atomicMax: zero the words first) -- the abs-max pass of the next fp8 Linear's activation quantisation folded into the producer."""
+    _req(x, BF16, "x"); _req(mod, BF16, "mod"); _req(e, BF16, "e"); _req(amax_ws, torch.float32, "amax_ws")
+    d = x.shape[-1]
+    n_mod = mod.numel() // d
+    rows = x.numel() // d
+    nb = e.numel() // (n_mod * d)
+    if amax_ws.numel() < 64 * ((rows + rows_per_slot - 1) // rows_per_slot):
+        raise _L.WanHipError("ln_modulate_amax: amax_ws holds fewer slots than the rows need")
+    out = torch.empty_like(x) if out is None else out
+    check(_L.load().wan_ln_modulate_amax(ptr(x), ptr(out), ptr(mod), ptr(e), n_mod, shift_idx, scale_idx, rows, rows // nb, d, eps, ptr(amax_ws),
+                                         rows_per_slot, stream_ptr()), "wan_ln_modulate_amax")
+    return out
+
+
+def ln_affine_amax(x, w, b, amax_ws, rows_per_slot, eps=1e-6, out=None):
+    """ln_affine with the same abs-max side output (see ln_modulate_amax)."""
+    for t, n in ((x, "x"), (w, "w"), (b, "b")):
+        _req(t, BF16, n)
+    _req(amax_ws, torch.float32, "amax_ws")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if amax_ws.numel() < 64 * ((rows + rows_per_slot - 1) // rows_per_slot):
+        raise _L.WanHipError("ln_affine_amax: amax_ws holds fewer slots than the rows need")
+    out = torch.empty_like(x) if out is None else out
+    check(_L.load().wan_ln_affine_amax(ptr(x), ptr(out), ptr(w), ptr(b), rows, d, eps, ptr(amax_ws), rows_per_slot, stream_ptr()), "wan_ln_affine_amax")
+    return out
+
+
+def fp8_quantize_pre(x, ws, amax_word):
+    """The quantising half of fp8_quantize: `ws` (64 fp32 words: a quantisation slot) already holds the tensor's abs-max in ws[amax_word]
+    (left there by ln_modulate_amax / ln_affine_amax / linear_fp8_gelu_amax); ws[0] <- scale_a.  Returns the fp8 tensor."""
+    _req(x, BF16, "x"); _req(ws, torch.float32, "ws")
+    out = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    check(_L.load().wan_fp8_quantize_pre(ptr(x), ptr(out), ptr(ws), x.numel(), int(amax_word), stream_ptr()), "wan_fp8_quantize_pre")
+    return out
+
+
+def linear_fp8_gelu_amax(x_fp8, weight_fp8, weight_scale, bias, amax):
+    """linear_fp8(..., epilogue=EPI_GELU_TANH) on an already quantised input (x_fp8 = (fp8 tensor, ws)) that also leaves max |out| in the
+    one-float device tensor `amax` (float bits, atomicMax: zero it first)."""
+    _req(weight_fp8, torch.float8_e4m3fn, "weight_fp8"); _req(weight_scale, torch.float32, "weight_scale"); _req(bias, BF16, "bias")
+    _req(amax, torch.float32, "amax")
+    xq, ws = x_fp8
+    N, K = weight_fp8.shape
+    M = xq.numel() // K
+    out = torch.empty(*xq.shape[:-1], N, dtype=BF16, device=xq.device)
+    check(_L.load().wan_gemm_fp8_amax(ptr(xq), K, ptr(ws), ptr(weight_fp8), ptr(weight_scale), weight_scale.numel(), ptr(bias), ptr(out), M, N, K,
+                                      ptr(amax), stream_ptr()), "wan_gemm_fp8_amax")
+    return out
+
+
 def gated_residual_(x, y, mod=None, e=None, gate_idx=-1):
     """x.addcmul_(y, e[gate]) (model.py:658-660) or x += y when gate_idx < 0."""
     _req(x, BF16, "x"); _req(y, BF16, "y"); _req(mod, BF16, "mod"); _req(e, BF16, "e")
