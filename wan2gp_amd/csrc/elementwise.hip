@@ -282,7 +282,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     if (AMAX) {
 #pragma unroll
       for (int o2 = 32; o2 > 0; o2 >>= 1) am = max(am, (uint32_t)__shfl_xor((int)am, o2, 64));
-      if (lane == 0 && am != 0) atomicMax(amax + (int64_t)((uint32_t)row / (uint32_t)rows_per_amax) * 64 + 1, am);
+      // one atomic per ROW on one address would serialise in the L2 (151,200 of them per call at 14B-720p: run 08 measured the fold's
+      // gain eaten); the running maximum is read first -- after the first few rows almost no row raises it
+      if (lane == 0 && am != 0) {
+        unsigned int* dst = amax + (int64_t)((uint32_t)row / (uint32_t)rows_per_amax) * 64 + 1;
+        if (am > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, am);
+      }
       am = 0;
     }
     if (!more) break;

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void gemm_fp8m_kernel(const uint8_t* __restric
       if (!col_in) amax = 0;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o, 64));
-      if (lane_e == 0 && amax != 0) atomicMax(amax_out, amax);
+      if (lane_e == 0 && amax != 0 && amax > __atomic_load_n(amax_out, __ATOMIC_RELAXED)) atomicMax(amax_out, amax);   // (read first: few tiles raise the running maximum)
     }
   }
   M_STAMP(3);
