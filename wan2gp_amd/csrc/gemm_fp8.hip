@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void fp8_absmax_kernel(const bf16_t* __restric
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(amax, m);
+  if ((threadIdx.x & 63) == 0 && m != 0 && m > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, m);   // (read first: 16k atomics on one address otherwise)
 }
 // pass 2: scale = absmax / 448 (1 if absmax == 0) -> ws[0]; q = fp8(clamp(bf16(x / bf16(scale)), +-448)).
 // v_cvt_pk_fp8_f32 converts with round-to-nearest-even into OCP e4m3fn on gfx950; the operands are bf16 values, exact in fp32.
