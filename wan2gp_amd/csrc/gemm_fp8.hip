@@ -397,15 +397,6 @@ int launch_fp8(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* X, int6
     if (rc >= 0) return rc;
   }
 #endif
-  struct AmaxBehind {   // the older kernel has no amax epilogue: one abs-max pass over its (contiguous, ldo == XN) output when it has run
-    unsigned int* p; const bf16_t* out; int64_t n; hipStream_t st;
-    ~AmaxBehind() {
-      if (p == nullptr) return;
-      const int64_t n8 = n / 8;
-      const int blocks = (int)min((int64_t)4096, (n8 + 255) / 256);
-      hipLaunchKernelGGL(fp8_absmax_kernel, dim3(blocks), dim3(256), 0, st, out, n8, p);
-    }
-  } behind{(amax_out != nullptr && ldo == XN && (YM * XN) % 8 == 0) ? amax_out : nullptr, Out, YM * XN, st};
   WAN_REQUIRE(256 * ldy + (int64_t)K < ((int64_t)1 << 32) && 256 * ldx + (int64_t)K < ((int64_t)1 << 32),
               "wan_gemm_fp8: row pitch exceeds the 32-bit DMA offsets of a tile");
   const int64_t ty = (YM + F_BM - 1) / F_BM, tx = (XN + F_BN - 1) / F_BN;
@@ -418,6 +409,12 @@ int launch_fp8(const uint8_t* Y, int64_t ldy, int64_t YM, const uint8_t* X, int6
     hipLaunchKernelGGL((gemm_fp8_kernel<EPI, BIAS_ROWS, false>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx, XN, K,
                        Out, ldo, bias, scale_a, scale_w, R, mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, group);
   WAN_LAUNCH_CHECK();
+  if (amax_out != nullptr && EPI == WAN_EPI_GELU_TANH) {   // this kernel has no abs-max epilogue: one streaming pass over its (contiguous) output
+    WAN_REQUIRE(ldo == XN && (YM * XN) % 8 == 0, "wan_gemm_fp8_amax: the output must be contiguous rows of a multiple of 8 elements");
+    const int64_t n8 = YM * XN / 8;
+    hipLaunchKernelGGL(fp8_absmax_kernel, dim3((unsigned)min((int64_t)4096, (n8 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)Out, n8, amax_out);
+    WAN_LAUNCH_CHECK();
+  }
   return 0;
 }
 
