@@ -250,7 +250,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 1.3B-480p generate() line")
     ap.add_argument("--fp8", action="store_true", help="scaled-fp8 checkpoint: block Linears on the fp8 MFMA (BASELINE configs[4])")
     ap.add_argument("--mixed-precision", action="store_true", help="the reference's mixed_precision_transformer plan (wgp.py:4039): time MLP, time projection "
-                    "and norm3 in fp32 -> fp32 residual stream and modulation between bf16 Linears (csrc/mixed_ops.hip, DESIGN.md section 3.12); an option of "
+                    "and norm3 in fp32 -> fp32 residual stream and modulation between bf16 Linears (csrc/mixed_ops.hip, DESIGN.md section 4.6); an option of "
                     "the reference, not the headline configuration")
     ap.add_argument("--no-robustness", action="store_true", help="skip the self-attention launches on gain-12 and adversarial inputs (roofline.robustness)")
     ap.add_argument("--no-configs3", action="store_true", help="skip the BASELINE configs[3] block (14B 720p x 161 frames, L = 147,600: 3 steps + a simulated rank of 8)")
