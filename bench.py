@@ -33,6 +33,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -225,6 +226,125 @@ def choose_layout(world, parallelism, heads):
     return cfg_sp, (world // 2 if cfg_sp else world), ("ulysses" if parallelism in ("ulysses", "cfg-ulysses") else "allgather")
 
 
+# ---- first-run hardening of `--gpus N` (round 6) ---------------------------------------------------------------
+# No multi-GPU node was ever available to the builder: the first real run is the driver's.  Three rules make sure it produces a line:
+#   * every layout self-test runs under a wall-clock guard (a collective whose peer never arrives blocks its caller for the backend's
+#     timeout: the bench decides after GUARD_S instead) and the ranks agree on the outcome over a side channel of their own (a gloo group:
+#     a rank that skipped a data collective does not shift its sequence numbers).  Outcome 1 (an error somewhere) demotes the layout on
+#     every rank; outcome 2 (a HANG somewhere) also gives whatever follows fresh process groups -- the old ones hold an unmatched collective;
+#   * if the agreement itself cannot complete, or the basic all-gather fails too, or the whole multi-GPU part is not through its timed
+#     region WORLD_DEADLINE_S after the process started, the world is given up: ranks > 0 exit quietly (status 0: torch.distributed.run
+#     then lets rank 0 finish), rank 0 re-executes itself as a short single-GPU run whose line says what happened (`layout_fell_back_to`);
+#   * init_process_group has a timeout of its own (180 s) instead of the backend's 10 minutes.
+GUARD_S = float(os.environ.get("WAN_BENCH_GUARD_S", 45))
+AGREE_S = float(os.environ.get("WAN_BENCH_AGREE_S", 90))
+WORLD_DEADLINE_S = float(os.environ.get("WAN_BENCH_WORLD_DEADLINE_S", 420))
+_AGREE = {"group": None}
+_TORCHRUN_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                  "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_RUN_ID",
+                  "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE")
+
+
+class WorldLost(RuntimeError):
+    """The ranks can no longer decide anything together: the multi-GPU run is given up (see _leave_world)."""
+
+
+def _guarded(fn, seconds, device=None):
+    """fn() on a thread of its own -> (finished in time, result or the exception it raised).  A thread that does not finish is left
+    behind (daemon): it sits in a collective nobody will complete.  `device`: the HIP device is per thread."""
+    box = {}
+
+    def run():
+        try:
+            if device is not None and str(device) != "cpu":
+                import torch
+                torch.cuda.set_device(device)
+            box["r"] = fn()
+        except BaseException as ex:  # noqa: BLE001 -- handed to the caller
+            box["e"] = ex
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return False, TimeoutError("no answer after %.0f s" % seconds)
+    return True, box.get("e", box.get("r"))
+
+
+def make_agreement_group():
+    """The side channel the ranks decide on (collective over the world, once, right after init_process_group)."""
+    import datetime
+    import torch.distributed as dist
+    try:
+        _AGREE["group"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=AGREE_S + 30))
+    except Exception as ex:                                         # noqa: BLE001 -- the default group then carries the decisions
+        log("no gloo side channel (%r): decisions travel on the default group" % (ex,))
+        _AGREE["group"] = None
+    return _AGREE["group"]
+
+
+def _agree(code, device):
+    """max over all ranks of `code` (0 = fine, 1 = failed, 2 = hung), bounded by AGREE_S; WorldLost if that cannot be had."""
+    import torch
+    import torch.distributed as dist
+    g = _AGREE["group"]
+    on_cpu = g is not None or dist.get_backend() == "gloo"
+    t = torch.tensor([float(code)], device="cpu" if on_cpu else device)
+
+    def run():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=g)
+        return float(t.item())
+    done, r = _guarded(run, AGREE_S, None if on_cpu else (torch.cuda.current_device() if torch.cuda.is_available() else None))
+    if not done or isinstance(r, BaseException):
+        raise WorldLost("the ranks could not agree on a layout: %r" % (r,))
+    return int(r)
+
+
+def _outcome(done, r):
+    """(finished, result) of a guarded self-test -> (code, message)"""
+    if not done:
+        return 2, "hung: %s" % r
+    if isinstance(r, BaseException):
+        return 1, repr(r)
+    return 0, ""
+
+
+def _fresh_groups(world, degree):
+    """New process groups for the world's world / degree runs of `degree` consecutive ranks (collective over ALL ranks, same order
+    everywhere) -> the list; degree == world: one group of everybody."""
+    import torch.distributed as dist
+    return [dist.new_group(list(range(i * degree, (i + 1) * degree))) for i in range(world // degree)]
+
+
+def _leave_world(rank, world, argv_tail, reason):
+    """Give the multi-GPU run up.  Ranks > 0 leave with status 0 (a non-zero exit makes torch.distributed.run kill rank 0 too); rank 0
+    becomes a short single-GPU bench whose line carries `layout_fell_back_to`."""
+    print("[bench rank %d] giving the %d-GPU run up: %s" % (rank, world, reason), file=sys.stderr, flush=True)
+    if rank != 0:
+        os._exit(0)
+    env = {k: v for k, v in os.environ.items() if k not in _TORCHRUN_VARS}
+    env["WAN_BENCH_FELL_BACK"] = json.dumps({"requested_gpus": world, "reason": reason})
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-e2e", "--no-secondary", "--no-robustness", "--no-configs3", "--no-config5",
+           "--no-cpu-baseline", "--simulate-world", ""] + argv_tail
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+class _Deadline(threading.Thread):
+    """One clock for the whole multi-GPU part: not disarmed WORLD_DEADLINE_S after the process started -> _leave_world."""
+
+    def __init__(self, seconds, fire):
+        super().__init__(daemon=True)
+        self.seconds, self.fire, self.done = seconds, fire, threading.Event()
+
+    def run(self):
+        left = self.seconds - (time.perf_counter() - T_PROCESS0)
+        if not self.done.wait(max(left, 1.0)):
+            self.fire("not through the timed region %.0f s after the process started (WAN_BENCH_WORLD_DEADLINE_S)" % self.seconds)
+
+    def disarm(self):
+        self.done.set()
+
+
 def log(msg):
     """Progress on stderr (stdout carries exactly one JSON line)."""
     if int(os.environ.get("RANK", 0)) == 0:
@@ -309,14 +429,34 @@ def main():
         sys.exit(f"bench.py: --parallelism {args.parallelism} shards the {_cfg['num_heads']} heads of workload {args.workload} over "
                  f"{sp_degree} sequence-parallel ranks: not divisible")
     torch.cuda.set_device(local)
+    deadline = None
+    # what a single-GPU re-run of this command keeps of its arguments (_leave_world)
+    argv_tail = ["--workload", args.workload, "--steps", str(min(args.steps, 5)), "--warmup", str(min(args.warmup, 1))] + \
+                (["--fp8"] if args.fp8 else []) + (["--mixed-precision"] if args.mixed_precision else [])
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"          # RCCL sees every rank
-        chk = torch.ones(1, device="cuda")
-        dist.all_reduce(chk)
-        assert int(chk.item()) == world, "RCCL all-reduce did not see every rank"
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        deadline = _Deadline(WORLD_DEADLINE_S + 10.0 * max(args.steps + args.warmup - 25, 0), lambda why: _leave_world(rank, world, argv_tail, why))
+        deadline.start()
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=180))
+            assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl"          # RCCL sees every rank
+            make_agreement_group()
+
+            def first_collective():
+                chk = torch.ones(1, device="cuda")
+                dist.all_reduce(chk)
+                if int(chk.item()) != world:
+                    raise RuntimeError("RCCL all-reduce saw %d of %d ranks" % (int(chk.item()), world))
+            done, r = _guarded(first_collective, GUARD_S, local)
+            if _agree(_outcome(done, r)[0], "cuda") != 0:
+                raise WorldLost("the first RCCL all-reduce %s" % ("hung" if not done else "failed: %r" % (r,)))
+        except WorldLost as ex:
+            _leave_world(rank, world, argv_tail, str(ex))
+        except Exception as ex:                                  # noqa: BLE001 -- init_process_group itself
+            _leave_world(rank, world, argv_tail, "init_process_group / first collective: %r" % (ex,))
 
     from wan2gp_amd import lib as L_
     from wan2gp_amd.model import WanModelHIP
@@ -335,9 +475,12 @@ def main():
     model2 = random_weights(WanModelHIP(**mcfg), cfg, 4321, args.fp8) if two_experts else None
     cfgp, layout_note = None, None
     if world > 1:
-        cfgp, cfg_sp, sp_degree, layout_note = setup_parallel(rank, world, cfg_sp, L, (model, model2), args.parallelism in ("cfg-sp", "cfg-ulysses"),
-                                                              sp_mode=sp_mode, sp_mode_demanded=args.parallelism in ("ulysses", "cfg-ulysses"),
-                                                              chunks=args.sp_chunks or None)
+        try:
+            cfgp, cfg_sp, sp_degree, layout_note = setup_parallel(rank, world, cfg_sp, L, (model, model2), args.parallelism in ("cfg-sp", "cfg-ulysses"),
+                                                                  sp_mode=sp_mode, sp_mode_demanded=args.parallelism in ("ulysses", "cfg-ulysses"),
+                                                                  chunks=args.sp_chunks or None)
+        except WorldLost as ex:
+            _leave_world(rank, world, argv_tail, str(ex))
         eff = cfgp.sp if cfgp is not None else model.sp        # the exchange the run ended up with (the self-test may have fallen back)
         sp_mode = eff.mode if eff is not None else "allgather"
 
@@ -421,6 +564,8 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(lat).all(), "non-finite latents"
+    if deadline is not None:
+        deadline.disarm()
 
     # ---- ... and ends here: causal 3D VAE decode -> uint8 on the host (rank 0; latents are replicated) --------------------------
     log(f"timed region done: {dt / args.steps * 1e3:.1f} ms/step")
@@ -522,6 +667,13 @@ def main():
             "step_TFLOPs": 2 * forward_flops(cfg, L) / (dt / args.steps) / 1e12,
             "forwards_per_s": 2 * args.steps / dt,          # a CFG step is two forwards (SURVEY.md section 8d reports both)
         }
+        # first-run hardening: null = the layout asked for (or chosen by `auto`) ran; else what the run ended up on, and why
+        out["layout_fell_back_to"] = out["config"]["parallelism"] if layout_note else None
+        if os.environ.get("WAN_BENCH_FELL_BACK"):
+            fb = json.loads(os.environ["WAN_BENCH_FELL_BACK"])
+            out["layout_fell_back_to"] = "single GPU (rank 0 of the %d-GPU launch, alone)" % fb["requested_gpus"]
+            out["requested_gpus"] = fb["requested_gpus"]
+            out["fell_back_reason"] = fb["reason"]
         if replayed:
             out["forwards"] = {"mode": "replayed launch lists (wan_dit_forward_graph)" if model.last_graph_how == 3 else "eager",
                                "last_forward_how": int(model.last_graph_how),
@@ -688,56 +840,73 @@ def configs3_block(model, model2, one_step, new_sched, par, lib, link_GBs=50.0):
 def setup_parallel(rank, world, cfg_sp, L, models, cfg_sp_demanded=False, device="cuda", sp_mode="allgather", sp_mode_demanded=False, chunks=None):
     """The multi-GPU layout of this run on the resident experts -> (CfgParallel | None, cfg_sp, sp_degree, note).
 
-    cfg-sp (the default for an even world) is tried first: groups, then a self-test of the 2-rank swap on a tiny tensor.  A rank
-    whose setup or self-test raises says so in an all-reduce; if ANY rank failed, EVERY rank takes plain sequence parallelism over the
-    whole world instead (when the token count shards that way) and the JSON line carries the reason -- a scaling run is worth more
-    than the preferred layout.  With `--parallelism cfg-sp` given explicitly the failure is fatal instead.  (What this cannot help: ONE
-    rank failing inside a collective while its partner waits in it -- that ends at the backend's collective timeout.)  The same
-    agreement in front of the Ulysses exchange (sp_mode "ulysses": _ulysses_self_test), whose fall-back is the all-gather exchange."""
+    cfg-sp (the default for an even world) is tried first: groups, then a self-test of the 2-rank swap on a tiny tensor.  Every self-test
+    runs under a wall-clock guard (_guarded) and the ranks agree on its outcome over the side channel (_agree): if ANY rank failed or
+    hung, EVERY rank takes plain sequence parallelism over the whole world instead (when the token count shards that way) and the JSON
+    line carries the reason -- a scaling run is worth more than the preferred layout.  With `--parallelism cfg-sp` given explicitly the
+    failure is fatal instead.  The same agreement in front of the Ulysses exchange (sp_mode "ulysses": _ulysses_self_test), whose
+    fall-back is the all-gather exchange, and last in front of the all-gather itself (_allgather_self_test) -- if that fails there is no
+    multi-GPU layout left: WorldLost (main: rank 0 alone, one GPU).  After a HANG the layout that follows runs on fresh process groups."""
     import torch
-    import torch.distributed as dist
     from wan2gp_amd.sp import CfgParallel, SequenceParallel
     note = None
+    poisoned = False
+    dev_id = torch.cuda.current_device() if (str(device) != "cpu" and torch.cuda.is_available()) else None
     if cfg_sp:
-        cfgp, err = None, ""
-        try:
-            cfgp = CfgParallel(rank, world, mode=sp_mode, chunks=chunks)
-            mine = torch.full((8,), float(cfgp.stream), device=device)
-            a, b = cfgp.exchange(mine)
+        def st():
+            c = CfgParallel(rank, world, mode=sp_mode, chunks=chunks)
+            mine = torch.full((8,), float(c.stream), device=device)
+            a, b = c.exchange(mine)
             if not (bool((a == 0).all()) and bool((b == 1).all())):
                 raise RuntimeError("the 2-rank swap returned (%r, %r), not (conditional, unconditional)" % (a.tolist(), b.tolist()))
-        except Exception as ex:                                 # noqa: BLE001 -- any failure means: not this layout
-            err = repr(ex)
-        bad = torch.tensor([1.0 if err else 0.0], device=device)
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        if float(bad.item()) == 0.0:
-            note = _ulysses_self_test(cfgp.sp, device, sp_mode_demanded, None)
+            return c
+        done, r = _guarded(st, GUARD_S, dev_id)
+        code, err = _outcome(done, r)
+        verdict = _agree(code, device)
+        if verdict == 0:
+            cfgp = r
+            note = _ulysses_self_test(cfgp.sp, device, sp_mode_demanded, None, world)
+            note = _allgather_self_test(cfgp.sp, device, note)
             cfgp.attach(*models)                                # this rank's stream; the half's sequence-parallel group on the experts
             return cfgp, True, world // 2, note
-        note = "cfg-sp setup failed on %s: %s -- fell back to sequence parallelism over all %d ranks" % (
-            "this rank" if err else "another rank", err or "(see that rank's log)", world)
+        poisoned = verdict == 2
+        note = "cfg-sp setup %s on %s: %s -- fell back to sequence parallelism over all %d ranks" % (
+            "hung" if verdict == 2 else "failed", "this rank" if err else "another rank", err or "(see that rank's log)", world)
         log(note)
         if cfg_sp_demanded or L % world:
             sys.exit("bench.py: " + note + (" refused: --parallelism cfg-sp was asked for" if cfg_sp_demanded else
                                             " impossible: %d tokens do not shard over %d ranks" % (L, world)))
-    sp = SequenceParallel(rank, world, mode=sp_mode, chunks=chunks)
-    note = _ulysses_self_test(sp, device, sp_mode_demanded, note)
+    sp = SequenceParallel(rank, world, group=_fresh_groups(world, world)[0] if poisoned else None, mode=sp_mode, chunks=chunks)
+    note = _ulysses_self_test(sp, device, sp_mode_demanded, note, world)
+    note = _allgather_self_test(sp, device, note)
     for m in models:
         if m is not None:
             m.sp = sp
     return None, False, world, note
 
 
-def _ulysses_self_test(sp, device, demanded, note):
+def _sp_group_index(sp, world):
+    """which of the world's world / sp.world runs of consecutive ranks `sp` shares its token axis with"""
+    import torch.distributed as dist
+    return 0 if sp.world == world else dist.get_rank() // sp.world
+
+
+def _ulysses_self_test(sp, device, demanded, note, world=None):
     """The Ulysses exchange before its first use on this node: one tiny all-to-all on the sequence-parallel group (chunk j must arrive
-    from rank j), every rank reports in one all-reduce; if ANY rank failed EVERY rank keeps the all-gather exchange (sp.mode) and the
-    line says so -- unless the mode was asked for explicitly, then the failure is fatal."""
+    from rank j) under the wall-clock guard, every rank reports over the side channel; if ANY rank failed or hung EVERY rank keeps the
+    all-gather exchange (sp.mode) and the line says so -- unless the mode was asked for explicitly, then the failure is fatal.  After a
+    hang the group gets replaced (its all-to-all will never be matched)."""
     import torch
     import torch.distributed as dist
     if sp is None or sp.mode != "ulysses" or sp.world < 2:
         return note
-    err = ""
-    try:
+    world = world or dist.get_world_size()
+    dev_id = torch.cuda.current_device() if (str(device) != "cpu" and torch.cuda.is_available()) else None
+
+    def st():
+        if int(os.environ.get("WAN_BENCH_INJECT_A2A_HANG_RANK", -1)) == dist.get_rank():     # tests: this rank never enters the exchange
+            time.sleep(float(os.environ.get("WAN_BENCH_INJECT_A2A_HANG_S", 1e9)))
+            raise RuntimeError("injected: woke up after the exchange was given up")
         send = (torch.arange(sp.world * 4, device=device, dtype=torch.float32) // 4) * 0 + float(sp.rank)
         recv = torch.full_like(send, -1.0)
         if dist.get_backend(sp.group) == "gloo":
@@ -749,18 +918,42 @@ def _ulysses_self_test(sp, device, demanded, note):
         want = torch.arange(sp.world, device=device, dtype=torch.float32).repeat_interleave(4)
         if not torch.equal(recv, want):
             raise RuntimeError("all-to-all returned %r" % recv.tolist())
-    except Exception as ex:                                     # noqa: BLE001
-        err = repr(ex)
-    bad = torch.tensor([1.0 if err else 0.0], device=device)
-    dist.all_reduce(bad, op=dist.ReduceOp.MAX)                  # over the WORLD: both halves of a cfg layout decide together
-    if float(bad.item()) != 0.0:
-        msg = "the Ulysses all-to-all self-test failed on %s: %s -- the per-block exchange stays the K / V^T all-gather" % (
-            "this rank" if err else "another rank", err or "(see that rank's log)")
+    done, r = _guarded(st, GUARD_S, dev_id)
+    code, err = _outcome(done, r)
+    verdict = _agree(code, device)                              # over the WORLD: both halves of a cfg layout decide together
+    if verdict != 0:
+        msg = "the Ulysses all-to-all self-test %s on %s: %s -- the per-block exchange stays the K / V^T all-gather" % (
+            "hung" if verdict == 2 else "failed", "this rank" if err else "another rank", err or "(see that rank's log)")
         if demanded:
             sys.exit("bench.py: " + msg + " refused: the mode was asked for")
         log(msg)
         sp.mode = "allgather"
+        if verdict == 2:
+            sp.group = _fresh_groups(world, sp.world)[_sp_group_index(sp, world)]
         note = (note + "; " if note else "") + msg
+    return note
+
+
+def _allgather_self_test(sp, device, note):
+    """What every layout rests on -- one tiny all-gather over the sequence-parallel group, guarded and agreed like the others.  A failure
+    here leaves no multi-GPU layout to fall back to: WorldLost."""
+    import torch
+    import torch.distributed as dist
+    if sp is None or sp.world < 2:
+        return note
+    dev_id = torch.cuda.current_device() if (str(device) != "cpu" and torch.cuda.is_available()) else None
+
+    def st():
+        got = sp.all_gather(torch.full((1, 4), float(sp.rank), device=device))
+        want = torch.arange(sp.world, device=device, dtype=torch.float32).repeat_interleave(4).view(sp.world, 4)
+        if not torch.equal(got, want):
+            raise RuntimeError("all-gather returned %r" % got.tolist())
+    done, r = _guarded(st, GUARD_S, dev_id)
+    code, err = _outcome(done, r)
+    verdict = _agree(code, device)
+    if verdict != 0:
+        raise WorldLost("the all-gather self-test %s on %s: %s" % ("hung" if verdict == 2 else "failed", "this rank" if err else "another rank",
+                                                                   err or "(see that rank's log)"))
     return note
 
 

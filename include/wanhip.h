@@ -653,6 +653,10 @@ int wan_mfma_sustained_probe(int iters, double* flop_out, void* stream);
  * chip -- bench.py's link model puts an exchange's xGMI transfer time behind the device-to-device copy that stands in for it. */
 int wan_debug_delay(double microseconds, void* stream);
 int wan_attention_count_declined(const float* scratch, int B, int Bk, int64_t Lq, int H, uint64_t* acc, void* stream);
+/* Test / A-B hook of the bf16 GEMM dispatch (csrc/gemm_bf16.hip launch_gemm): which problems run on the co-resident small-tile kernel
+ * csrc/gemm16s.hip (round 6).  0 = automatic: problems of fewer than 128 tiles of 256 x 256 (default); 128 / 256 = that tile height on every
+ * problem the kernel accepts, many-tile ones included; -1 = never (the round-5 dispatch).  Returns the old value.  Process-wide. */
+int wan_gemm_debug_force16s(int v);
 
 #ifdef __cplusplus
 }

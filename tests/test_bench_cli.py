@@ -339,3 +339,51 @@ def _check_driver_line(j):
     assert c["kind"] == "port" and str(c["cores"]) in c["thread_sweep"]["dit_3_layers_s"] and len(c["thread_sweep"]["dit_3_layers_s"]) >= 4
     assert min(c["thread_sweep"]["dit_3_layers_s"].values()) == c["thread_sweep"]["dit_3_layers_s"][str(c["cores"])]
     assert j["config5"]["dtype"].startswith("fp8") and j["config5"]["ms_per_step"] < j["ms_per_step"]
+
+
+def test_giving_the_world_up_leaves_rank_0_as_a_single_gpu_run(monkeypatch):
+    """Round 6, first-run hardening: when the ranks cannot run any multi-GPU layout (WorldLost, or the deadline), ranks > 0 exit with
+    status 0 -- a non-zero exit would make torch.distributed.run kill rank 0 -- and rank 0 re-executes itself as a short single-GPU
+    bench, outside the rendezvous, whose JSON line carries what happened."""
+    import json
+    bench = _bench()
+    seen = {}
+    monkeypatch.setattr(bench.os, "_exit", lambda code: (_ for _ in ()).throw(SystemExit(code)))
+    monkeypatch.setattr(bench.os, "execve", lambda exe, cmd, env: seen.update(exe=exe, cmd=cmd, env=env))
+    with pytest.raises(SystemExit) as e:
+        bench._leave_world(3, 8, ["--workload", "14B-720p", "--steps", "5", "--warmup", "1"], "the all-gather self-test hung")
+    assert e.value.code == 0 and not seen
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("MASTER_PORT", "1234"); monkeypatch.setenv("LOCAL_RANK", "0")
+    bench._leave_world(0, 8, ["--workload", "14B-720p", "--steps", "5", "--warmup", "1"], "the all-gather self-test hung")
+    cmd, env = seen["cmd"], seen["env"]
+    assert cmd[0] == sys.executable and cmd[1] == os.path.join(ROOT, "bench.py") and cmd[cmd.index("--gpus") + 1] == "1"
+    assert cmd[cmd.index("--steps") + 1] == "5" and "--no-cpu-baseline" in cmd and cmd[cmd.index("--simulate-world") + 1] == ""
+    assert not any(k in env for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"))
+    fb = json.loads(env["WAN_BENCH_FELL_BACK"])
+    assert fb == {"requested_gpus": 8, "reason": "the all-gather self-test hung"}
+
+
+def test_the_world_deadline_fires_once_and_can_be_disarmed():
+    import time
+    bench = _bench()
+    fired = []
+    d = bench._Deadline(time.perf_counter() - bench.T_PROCESS0 + 1.2, fired.append)
+    d.start()
+    d.join(5)
+    assert len(fired) == 1 and "WAN_BENCH_WORLD_DEADLINE_S" in fired[0]
+    fired2 = []
+    d = bench._Deadline(time.perf_counter() - bench.T_PROCESS0 + 1.2, fired2.append)
+    d.start()
+    d.disarm()
+    d.join(5)
+    assert not fired2
+
+
+def test_guarded_calls_report_hangs_errors_and_results():
+    import time
+    bench = _bench()
+    assert bench._guarded(lambda: 7, 2) == (True, 7)
+    done, r = bench._guarded(lambda: 1 / 0, 2)
+    assert done and isinstance(r, ZeroDivisionError) and bench._outcome(done, r)[0] == 1
+    done, r = bench._guarded(lambda: time.sleep(30), 0.3)
+    assert not done and bench._outcome(done, r)[0] == 2 and "hung" in bench._outcome(done, r)[1]

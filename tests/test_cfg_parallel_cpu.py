@@ -291,3 +291,72 @@ def test_bench_layout_falls_back_to_sequence_parallelism_on_every_rank_together(
                 p.kill()
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _hang_worker(rank, world, port, q, never_wakes):
+    """bench.setup_parallel with ONE rank that never enters the Ulysses all-to-all (round 6, first-run hardening): the others must not
+    sit in the collective for the backend's timeout -- every rank gives the exchange up after the guard, all agree on the all-gather
+    fall-back over the side channel, the fall-back runs on a FRESH group (the old one holds the unmatched all-to-all) and works."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(WAN_BENCH_GUARD_S="2", WAN_BENCH_AGREE_S="6" if never_wakes else "30", WAN_BENCH_INJECT_A2A_HANG_RANK=str(world - 1),
+                      WAN_BENCH_INJECT_A2A_HANG_S="1000" if never_wakes else "4")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib.util
+        import time
+        import types
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        assert bench.GUARD_S == 2.0
+        bench.make_agreement_group()
+        m = types.SimpleNamespace(sp="unset")
+        t0 = time.perf_counter()
+        if never_wakes:
+            # the hung rank never reaches the agreement either: the others cannot decide together -> WorldLost on each of them, inside
+            # guard + agreement time (main() then leaves the world: rank 0 alone on one GPU)
+            if rank == world - 1:
+                q.put((rank, "ok"))
+                time.sleep(20)                      # (stays alive: its sockets stay open, as a hung rank's would)
+                return
+            try:
+                bench.setup_parallel(rank, world, False, 75600, (m,), device="cpu", sp_mode="ulysses")
+                raise AssertionError("must raise WorldLost")
+            except bench.WorldLost as ex:
+                assert "could not agree" in str(ex)
+            assert time.perf_counter() - t0 < 15
+            q.put((rank, "ok"))
+            return
+        cfgp, cfg_sp, degree, note = bench.setup_parallel(rank, world, False, 75600, (m,), device="cpu", sp_mode="ulysses")
+        assert time.perf_counter() - t0 < 25
+        assert cfgp is None and degree == world and m.sp.mode == "allgather" and m.sp.group is not None      # a fresh group
+        assert "hung" in note and ("this rank" in note) == True or "another rank" in note
+        got = m.sp.all_gather(torch.tensor([[float(rank)]]))
+        assert got.flatten().tolist() == [float(r) for r in range(world)]
+        q.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if not never_wakes:
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,never_wakes", [(2, False), (4, False), (4, True)])
+def test_a_rank_hanging_in_the_ulysses_self_test_demotes_the_layout_on_every_rank(world, never_wakes):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hang_worker, args=(r, world, port, q, never_wakes), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=120) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30 if not never_wakes else 1)
+            if p.is_alive():
+                p.kill()
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"

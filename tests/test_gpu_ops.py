@@ -263,6 +263,45 @@ def test_gemm_256x256_kernel_default_path(ops, K):
     assert (vt[:, M:] == 0).all(), "padding columns must stay zero"
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("M,N,K", [(6400, 1536, 1536), (517, 1536, 128), (1024, 5120, 5120), (300, 260, 128), (3200, 1536, 8960), (33, 64, 224)])
+def test_gemm16s_small_tile_kernel(ops, tile, M, N, K):
+    """csrc/gemm16s.hip (round 6: 128 x 128 / 256 x 128 x 32 tiles on the 16x16x32 MFMA, two or three workgroups per CU, the kernel of
+    every problem below one wave of 256 x 256 tiles) forced onto both tile heights: BASELINE configs[0]'s projections (M = 6,400,
+    d = 1,536, ffn 8,960), the 14B text K / V Linears, ragged M and N (N = 260: the last x tile holds 4 columns), K = 4 k-tiles (the
+    prologue + one) ... 280; every epilogue, two batches for the gate, the transposed V^T form.  References: the fp32 matmul rounded
+    once (<= 2 bf16 ulp), as for the other generations; and the automatic dispatch must agree with the forced tile to the same bar."""
+    from wan2gp_amd import lib as L_
+    lib = L_.load()
+    g = torch.Generator().manual_seed(M * 3 + N + K + tile)
+    x = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = (0.1 * torch.randn(N, generator=g)).to(BF)
+    y = _gemm_ref(x, w, b)
+    old = lib.wan_gemm_debug_force16s(tile)
+    try:
+        assert_bf16_close(ops.linear(cu(x), cu(w), cu(b)), y, frac=0.05, what="gemm16s none", floor=0.25)
+        assert_bf16_close(ops.linear(cu(x), cu(w), None), _gemm_ref(x, w, torch.zeros(N)), frac=0.05, what="gemm16s no bias", floor=0.25)
+        assert_bf16_close(ops.linear(cu(x), cu(w), cu(b), epilogue=1), torch.nn.functional.gelu(y, approximate="tanh"), frac=0.05,
+                          ulps=3, what="gemm16s gelu", floor=0.25)
+        r = torch.randn(M, N, generator=g).to(BF)
+        B = 2 if (M % 2 == 0 and M // 2 >= 256) else 1
+        mod = (torch.randn(1, 6, N, generator=g) / N ** 0.5).to(BF); e0 = (0.5 * torch.randn(B, 6, N, generator=g)).to(BF)
+        rpb = M // B
+        ref = torch.cat([torch.addcmul(r[i * rpb:(i + 1) * rpb], y[i * rpb:(i + 1) * rpb], (mod + e0[i:i + 1]).chunk(6, dim=1)[5][0])
+                         for i in range(B)])
+        rr = cu(r.clone())
+        got = ops.linear(cu(x), cu(w), cu(b), epilogue=2, residual=rr, mod=cu(mod), e=cu(e0), gate_idx=5, out=rr)
+        assert_bf16_close(got, ref, frac=0.05, what="gemm16s gate residual (in place)", floor=(r.float().abs() + y.float().abs()))
+        got = ops.linear(cu(x), cu(w), cu(b), epilogue=2, residual=cu(r), gate_idx=-1)
+        assert_bf16_close(got, r + y, frac=0.05, what="gemm16s plain residual", floor=(r.float().abs() + y.float().abs()))
+        vt = ops.linear(cu(x), cu(w), cu(b), epilogue=3)
+        assert_bf16_close(vt[:, :M], y.t(), frac=0.05, what="gemm16s V^T", floor=0.25)
+        assert (vt[:, M:] == 0).all(), "padding columns must stay zero"
+    finally:
+        lib.wan_gemm_debug_force16s(old)
+    assert_bf16_close(ops.linear(cu(x), cu(w), cu(b)), y, frac=0.05, what="automatic dispatch", floor=0.25)
+
+
 def test_gemm_rejects_bad_k(ops):
     from wan2gp_amd.lib import WanHipError
     x = torch.zeros(8, 96, dtype=BF).cuda(); w = torch.zeros(128, 96, dtype=BF).cuda()

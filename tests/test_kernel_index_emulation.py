@@ -1085,3 +1085,123 @@ def test_conv_halo_ring_schedule():
                 if tap == 0:
                     issued += [("P", g + 1)] * 3      # into patch stage (g + 1) & 1: last read in group g - 1
                 assert wstage_owner[q % 3] == q       # the stage this tap reads still holds W(q)
+
+
+# ----------------------------------------------------------------------------------------------
+# gemm16s.hip (round 6: 128 x 128 / 256 x 128 x 32 tiles on the 16x16x32 MFMA, 64-byte LDS rows, X rows staged 4-way interleaved,
+# register-direct 8-byte stores, ring of three stages two tiles ahead)
+# ----------------------------------------------------------------------------------------------
+def _g16s_sw(row):
+    m = (row >> 2) & 3
+    return ((m & 1) << 1) ^ ((m >> 1) * 3)
+
+
+def test_gemm16s_swizzle_is_the_table_and_reads_are_conflict_free():
+    """H = {0, 2, 3, 1} by (row >> 2) & 3; a fragment read (lane (n, g): row 16 tile + n, logical chunk g, physical chunk g ^ H) must give
+    each of ds_read_b128's four 16-lane service groups 16 distinct 16-byte slots of the 256-byte bank sweep."""
+    assert [_g16s_sw(4 * m) for m in range(4)] == [0, 2, 3, 1]
+    for tile in range(8):
+        offs = []
+        for lane in range(64):
+            n, g = lane & 15, lane >> 4
+            offs.append((16 * tile + n) * 64 + ((g ^ _g16s_sw(n)) << 4))
+        assert b128_conflict_free(offs)
+    # the DMA writes a wave's 64 lanes to 1 KB of consecutive LDS bytes: 16 rows x 4 chunks; every (row, logical chunk) exactly once
+    for i in range(4):
+        seen = set()
+        for tid in range(256):
+            q = i * 256 + tid
+            row, pch = q >> 2, q & 3
+            seen.add((row, pch ^ _g16s_sw(row)))
+        assert seen == {(r, c) for r in range(i * 64, i * 64 + 64) for c in range(4)}
+
+
+@pytest.mark.parametrize("WTY", [4, 8])
+def test_gemm16s_layout_end_to_end(WTY):
+    """One workgroup tile with K = 32 (one stage): DMA plan -> LDS images -> fragment addresses -> v_mfma_f32_16x16x32 semantics -> the
+    epilogue's (lane, a, i) -> (row, 4 columns) map.  Every output element exactly once with the right operands; a store instruction
+    writes 4 rows x 128 contiguous bytes."""
+    WTX = 4
+    BM, BN = 32 * WTY, 32 * WTX
+    rng = np.random.default_rng(16 + WTY)
+    Yt = rng.integers(-3, 4, size=(BM, 32)).astype(np.float64)
+    Xt = rng.integers(-3, 4, size=(BN, 32)).astype(np.float64)
+    ylds = np.zeros((BM, 4, 8)); xlds = np.zeros((BN, 4, 8))
+    seen_x = set()
+    for i in range(BM // 64):
+        for tid in range(256):
+            q = i * 256 + tid
+            row, pch = q >> 2, q & 3
+            lch = pch ^ _g16s_sw(row)
+            ylds[row, pch] = Yt[row, lch * 8:lch * 8 + 8]
+    for i in range(BN // 64):
+        for tid in range(256):
+            q = i * 256 + tid
+            row, pch = q >> 2, q & 3
+            lch = pch ^ _g16s_sw(row)
+            slab, t, n = row // (16 * WTX), (row >> 4) % WTX, row & 15
+            xr = slab * 16 * WTX + WTX * n + t
+            seen_x.add(xr)
+            xlds[row, pch] = Xt[xr, lch * 8:lch * 8 + 8]
+    assert seen_x == set(range(BN))
+    out = np.full((BM, BN), np.nan)
+    for wave in range(4):
+        wy, wx = wave >> 1, wave & 1
+        yf = np.zeros((WTY, 64, 8)); xf = np.zeros((WTX, 64, 8))
+        for lane in range(64):
+            n, g = lane & 15, lane >> 4
+            ya = (wy * 16 * WTY + n) * 64 + ((g ^ _g16s_sw(n)) << 4)
+            xa = (wx * 16 * WTX + n) * 64 + ((g ^ _g16s_sw(n)) << 4)
+            for a in range(WTY):
+                addr = a * 1024 + ya
+                yf[a, lane] = ylds[addr // 64, (addr % 64) // 16]
+            for t in range(WTX):
+                addr = t * 1024 + xa
+                xf[t, lane] = xlds[addr // 64, (addr % 64) // 16]
+        for a in range(WTY):
+            accs = [_mfma16(yf[a], xf[t]) for t in range(WTX)]            # [t][lane][i]
+            for i in range(4):
+                rows_of_instr = {}
+                for lane in range(64):
+                    n, g = lane & 15, lane >> 4
+                    row = wy * 16 * WTY + 16 * a + 4 * g + i
+                    col = wx * 16 * WTX + WTX * n
+                    rows_of_instr.setdefault(row, []).append(col * 2)
+                    for t in range(WTX):
+                        assert np.isnan(out[row, col + t])
+                        out[row, col + t] = accs[t][lane, i]
+                assert len(rows_of_instr) == 4
+                for bs in rows_of_instr.values():
+                    assert sorted(bs) == list(range(min(bs), min(bs) + 128, 8))
+    np.testing.assert_array_equal(out, Yt @ Xt.T)
+
+
+def test_gemm16s_ring_schedule():
+    """Tile kt's fragments are read during tile kt - 1 from slot kt % 3; at the top of tile kt (behind the wait + barrier) the DMA of
+    tile kt + 3 goes into slot kt % 3.  No slot is overwritten before every wave's reads of it are behind a barrier, every tile is read
+    from the slot it was fetched into, and with `pieces` DMA instructions per thread and stage the counted waits leave exactly the
+    younger stages in flight."""
+    for nk in (3, 4, 5, 6, 7, 13, 48):
+        slot_holds = {}                     # slot -> k-tile fetched into it (the stream stops at the last tile)
+        kf, pending = 0, []                 # pending: fetches in issue order
+        def stage(s):
+            nonlocal kf
+            slot_holds[s] = kf
+            pending.append(kf)
+            kf = min(kf + 1, nk - 1)
+        stage(0); stage(1); stage(2)
+        landed = set(pending[:-2])          # vmcnt(2 P): all but the two youngest stages
+        assert 0 in landed
+        frag_tile = slot_holds[0]           # load_frags(f0, 0)
+        for kt in range(nk):
+            # wait vmcnt(P): all but the youngest stage landed
+            landed = set(pending[:-1])
+            if kt + 1 < nk:
+                assert kt + 1 in landed
+            assert frag_tile == kt          # the fragments in registers are tile kt's
+            reading_slot = (kt + 1) % 3
+            stage(kt % 3)                   # overwrites the slot whose reads ended before the barrier
+            assert kt % 3 != reading_slot
+            if kt + 1 < nk:
+                assert slot_holds[reading_slot] == kt + 1
+            frag_tile = slot_holds[reading_slot]

@@ -41,8 +41,8 @@ int wan_head_range(const bf16_t* x, const float* hmod, const bf16_t* e, const fl
 int wan_sinusoid_val(float t, bf16_t* out, int dim, void* stream);
 int wan_set_f32(float* p, float v, void* stream);
 // wan_dit_forward_graph: the timestep of the forward being enqueued lives in device memory (one float) instead of a launch argument,
-// so that the captured launch list can be replayed for another t (sinusoid_kernel and sinusoid_val_kernel do the same arithmetic)
-static const float* g_t_dev = nullptr;
+// so that the captured launch list can be replayed for another t (sinusoid_kernel and sinusoid_val_kernel do the same arithmetic).  The
+// pointer travels as dit_forward_impl's `t_dev` argument (round 6: it was a process-wide static, read by whatever forward overlapped).
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline) ----
 // Off by default.  When enabled, wan_dit_forward brackets the launches of each class with a
@@ -208,14 +208,19 @@ extern "C" int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out) {
   *out = c;
   return 0;
 }
+// captured launch lists hold the pointers and the launch order of the state they were captured in: every setter that changes either drops them
+static void drop_graphs(wan_ctx* ctx) {
+  for (auto& e : ctx->graphs) {
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.graph) (void)hipGraphDestroy(e.graph);
+  }
+  ctx->graphs.clear();
+}
 extern "C" void wan_dit_destroy(wan_ctx* ctx) {
   if (ctx) {
     if (ctx->clip_ctx) (void)hipFree(ctx->clip_ctx);
     if (ctx->clip_tmp) (void)hipFree(ctx->clip_tmp);
-    for (auto& e : ctx->graphs) {
-      if (e.exec) (void)hipGraphExecDestroy(e.exec);
-      if (e.graph) (void)hipGraphDestroy(e.graph);
-    }
+    drop_graphs(ctx);
     if (ctx->t_dev) (void)hipFree(ctx->t_dev);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   }
@@ -228,11 +233,7 @@ extern "C" int wan_dit_set_weight(wan_ctx* ctx, const char* name, const void* pt
   WAN_REQUIRE((((uintptr_t)ptr) & 15) == 0, "wan_dit_set_weight: %s is not 16-byte aligned", name);
   ctx->weights[name] = Tensor{ptr, dtype, numel};
   ctx->resolved = false;
-  for (auto& e : ctx->graphs) {     // captured launch lists hold the old pointers
-    if (e.exec) (void)hipGraphExecDestroy(e.exec);
-    if (e.graph) (void)hipGraphDestroy(e.graph);
-  }
-  ctx->graphs.clear();
+  drop_graphs(ctx);
   return 0;
 }
 
@@ -569,7 +570,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
                             int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                             void* poll_user, const int* should_calc, wan_bf16* const* residual, int n_vace,
                             const float* const* vace_contexts, const float* vace_scales, const float* nag, const int* context_batches,
-                            const int* perturb_layers, int n_perturb, int x_id, void* stream) {
+                            const int* perturb_layers, int n_perturb, int x_id, void* stream, const float* t_dev = nullptr) {
   WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
   WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
@@ -659,7 +660,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       WAN_CHECK_HIP(hipMemcpyAsync(b.mx_e0 + (int64_t)s * nt * 6 * d, b.mx_e0, (size_t)nt * 6 * d * 4, hipMemcpyDeviceToDevice, st));
   }
   for (int f = 0; f < nt && !mx; ++f) {
-    if (g_t_dev != nullptr && t_frames == nullptr) RC(wan_sinusoid(g_t_dev, b.sinus, 1, g.freq_dim, stream));
+    if (t_dev != nullptr && t_frames == nullptr) RC(wan_sinusoid(t_dev, b.sinus, 1, g.freq_dim, stream));
     else RC(wan_sinusoid_val(t_frames ? t_frames[frame0 + f] : t, b.sinus + (int64_t)f * g.freq_dim, g.freq_dim, stream));
   }
   // the time MLP: GEMV for one row of bf16 weights, the tile GEMM otherwise (several rows, or fp8 weights: one tensor)
@@ -1171,7 +1172,7 @@ extern "C" int wan_dit_forward_skip(wan_ctx* c, int S, const float* const* x, fl
                           should_calc, residual, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
-extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* stream) {
+static int forward_ex_impl(wan_ctx* c, const wan_dit_args* a, void* stream, const float* t_dev) {
   WAN_REQUIRE(c && a, "wan_dit_forward_ex: null argument");
   WAN_REQUIRE(a->n_t_frames == 0 || (a->t_frames != nullptr && a->n_t_frames == a->F),
               "wan_dit_forward_ex: t_frames must hold one timestep per latent frame (%d given, F = %d)", a->n_t_frames, a->F);
@@ -1187,8 +1188,9 @@ extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* strea
                           a->workspace_bytes, a->sp, a->poll, a->poll_user, a->should_calc, a->residual,
                           many ? a->n_vace : (a->vace_context ? 1 : 0), many ? a->vace_contexts : one_ctx, many ? a->vace_scales : one_scale,
                           nag, a->context_batches, a->n_perturbation_layers > 0 ? a->perturbation_layers : nullptr,
-                          a->n_perturbation_layers > 0 ? a->n_perturbation_layers : 0, a->x_id, stream);
+                          a->n_perturbation_layers > 0 ? a->n_perturbation_layers : 0, a->x_id, stream, t_dev);
 }
+extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* stream) { return forward_ex_impl(c, a, stream, nullptr); }
 
 // ---- the forward as a replayed launch list ("HIP-graph capture per (shape, expert)") -------------------
 // At small L a forward is launch-bound: ~900 launches of a few microseconds each, enqueued one by one from the host (configs[0], the
@@ -1260,9 +1262,7 @@ extern "C" int wan_dit_forward_graph(wan_ctx* c, const wan_dit_args* a, void* st
     e.key = key;
     e.last_use = ++c->graph_clock;
     c->graphs.push_back(e);
-    g_t_dev = c->t_dev;
-    const int rc = wan_dit_forward_ex(c, &b, stream);
-    g_t_dev = nullptr;
+    const int rc = forward_ex_impl(c, &b, stream, c->t_dev);
     if (how) *how = 1;
     return rc;
   }
@@ -1270,9 +1270,7 @@ extern "C" int wan_dit_forward_graph(wan_ctx* c, const wan_dit_args* a, void* st
   // (capture or instantiation error) costs nothing but the replay: nothing captured has run, the call is enqueued eagerly instead,
   // the key is marked and *how says 1; wan_last_error() keeps the reason.
   auto eager = [&]() -> int {
-    g_t_dev = c->t_dev;
-    const int rc2 = wan_dit_forward_ex(c, &b, stream);
-    g_t_dev = nullptr;
+    const int rc2 = forward_ex_impl(c, &b, stream, c->t_dev);
     if (how) *how = 1;
     return rc2;
   };
@@ -1289,9 +1287,7 @@ extern "C" int wan_dit_forward_graph(wan_ctx* c, const wan_dit_args* a, void* st
     wan_set_error("wan_dit_forward_graph: hipStreamBeginCapture failed; the forward stays on the eager path");
     return eager();
   }
-  g_t_dev = c->t_dev;
-  const int rc = wan_dit_forward_ex(c, &b, c->cap_stream);
-  g_t_dev = nullptr;
+  const int rc = forward_ex_impl(c, &b, c->cap_stream, c->t_dev);
   hipGraph_t graph = nullptr;
   const hipError_t ec = hipStreamEndCapture(c->cap_stream, &graph);
   if (rc != 0) {                                                 // the forward itself refused its arguments: that is the caller's error
@@ -1322,6 +1318,7 @@ extern "C" int wan_dit_forward_graph(wan_ctx* c, const wan_dit_args* a, void* st
 extern "C" int wan_dit_set_vace_contexts(wan_ctx* c, int n) {
   WAN_REQUIRE(c && n >= 1 && n <= 8, "wan_dit_set_vace_contexts: 1..8 contexts, got %d", n);
   c->vace_max_ctx = n;
+  drop_graphs(c);     // (the workspace layout moves)
   return 0;
 }
 
@@ -1333,5 +1330,6 @@ extern "C" int wan_dit_set_vace_layers(wan_ctx* c, const int* layers, int n) {
                 "wan_dit_set_vace_layers: layers must start at 0 and increase (model.py:1182)");
   c->vace_layers.assign(layers, layers + n);
   c->resolved = false;
+  drop_graphs(c);
   return 0;
 }

@@ -254,6 +254,19 @@ int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
                      int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                      int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
+// sixth-generation kernel (gemm16s.hip): 128 x 128 / 256 x 128 tiles on the 16x16x32 MFMA, three / two workgroups per CU; bf16
+template <int EPI, bool BIAS_ROWS>
+int wan_gemm16s_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                    int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
+                    int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale, int tile_rows);
+
+static int g_force16s = [] { const char* e = getenv("WAN_GEMM16S"); return e ? atoi(e) : 0; }();
+extern "C" int wan_gemm_debug_force16s(int v) {
+  const int old = g_force16s;
+  g_force16s = (v == 128 || v == 256 || v == -1) ? v : 0;
+  return old;
+}
+
 #ifndef WAN_GEMM_MIN_TILES_DEFAULT
 #define WAN_GEMM_MIN_TILES_DEFAULT 256
 #endif
@@ -267,6 +280,23 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
   // partly idle for a whole tile time, and the 128-wide kernels balance better).  WAN_GEMM_MIN_TILES overrides for A/B runs.
   static const int64_t min_tiles = [] { const char* e = getenv("WAN_GEMM_MIN_TILES"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : WAN_GEMM_MIN_TILES_DEFAULT); }();
   const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= min_tiles;
+  // Round 6: problems of fewer than 128 tiles of 256 x 256 (the text K / V Linears and the text embedding: M = 512 ... 1,024 context rows; UMT5;
+  // the CLIP branch) run on gemm16s.hip's co-resident small tiles -- 256 x 128 from 128 such tiles up, else 128 x 128.  Measured in one
+  // process against the kernels they had (run 03, profiles/r06_ab_gemm16s_run03.log): M = 512, N = K = 4,096: 35 against 70 us; the 14B text
+  // K / V^T: 77 / 54 against 93 / 92 us.  From ~150 tiles up (BASELINE configs[0]: M = 6,400) the small tiles are level with gemm32 and
+  // at many tiles they lose to gemm256m by 1.4-1.8 x (a 128 x 128 x 32 stage is 64 FLOP per byte fetched: 64 B/clk/CU of LDS-DMA at the matrix
+  // pipe's peak -- the vector memory path's whole width; 256 x 256 needs 32), so the rule stops there.  g_force16s (env WAN_GEMM16S at load,
+  // wan_gemm_debug_force16s at run time): -1 = never (the round-5 dispatch), 0 = this rule, 128 / 256 = that tile on EVERY problem it fits.
+  if constexpr (!F16 && (!BIAS_ROWS || EPI == WAN_EPI_NONE)) {
+    const int f16s = g_force16s;
+    const bool small = ((YM + 255) / 256) * ((XN + 255) / 256) < 128 && YM >= 32 && XN >= 32;
+    if (f16s > 0 || (f16s == 0 && small)) {
+      const int64_t t256 = ((YM + 255) / 256) * ((XN + 127) / 128);
+      const int rc = wan_gemm16s_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale,
+                                                     f16s > 0 ? f16s : (t256 >= 128 ? 256 : 128));
+      if (rc >= 0) return rc;
+    }
+  }
 #ifndef WAN_GEMM_NO_MI16  // (defined only for the A/B library libwanhip_k.so: gemm256k on every shape)
   if constexpr (!F16 && (!BIAS_ROWS || EPI == WAN_EPI_NONE)) {
     if (many_tiles) {
