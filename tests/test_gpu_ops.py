@@ -264,11 +264,11 @@ def test_gemm_256x256_kernel_default_path(ops, K):
 
 
 @pytest.mark.parametrize("tile", [128, 256])
-@pytest.mark.parametrize("M,N,K", [(6400, 1536, 1536), (517, 1536, 128), (1024, 5120, 5120), (300, 260, 128), (3200, 1536, 8960), (33, 64, 224)])
+@pytest.mark.parametrize("M,N,K", [(6400, 1536, 1536), (517, 1536, 128), (1024, 5120, 5120), (300, 264, 128), (3200, 1536, 8960), (33, 64, 224)])
 def test_gemm16s_small_tile_kernel(ops, tile, M, N, K):
     """csrc/gemm16s.hip (round 6: 128 x 128 / 256 x 128 x 32 tiles on the 16x16x32 MFMA, two or three workgroups per CU, the kernel of
     every problem below one wave of 256 x 256 tiles) forced onto both tile heights: BASELINE configs[0]'s projections (M = 6,400,
-    d = 1,536, ffn 8,960), the 14B text K / V Linears, ragged M and N (N = 260: the last x tile holds 4 columns), K = 4 k-tiles (the
+    d = 1,536, ffn 8,960), the 14B text K / V Linears, ragged M and N (N = 264: the last x tile holds 8 columns), K = 4 k-tiles (the
     prologue + one) ... 280; every epilogue, two batches for the gate, the transposed V^T form.  References: the fp32 matmul rounded
     once (<= 2 bf16 ulp), as for the other generations; and the automatic dispatch must agree with the forced tile to the same bar."""
     from wan2gp_amd import lib as L_

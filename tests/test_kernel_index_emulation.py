@@ -589,6 +589,49 @@ def test_attention_dma_stream_step_both_forms(Lk, nseg, skip):
     assert last[2] == ((Lk - 1) % KVBLK) * rs2 + 256
 
 
+def seg_table(Lk, nseg, skip, rs2, kseg, vseg):
+    """Transliteration of attention_w16n.hip attn_seg_table_kernel (round 6): one {k offset / 16, v offset / 16, valid K bytes} entry per
+    fetch, the last one repeated for the two fetches past the end."""
+    tps = (Lk + KVBLK - 1) // KVBLK
+    ntile = tps * (nseg - (1 if skip >= 0 else 0))
+    tab = []
+    for f in range(ntile + 3):
+        ff = min(f, ntile - 1)
+        sg, tt = divmod(ff, tps)
+        if skip >= 0 and sg >= skip:
+            sg += 1
+        koff, voff = sg * kseg + tt * KVBLK * rs2, sg * vseg + tt * KVBLK * 2
+        assert koff % 16 == 0 and voff % 16 == 0 and (koff >> 4) < 2 ** 32 and (voff >> 4) < 2 ** 32
+        tab.append((koff >> 4, voff >> 4, (Lk - 1) * rs2 + 256 - tt * KVBLK * rs2))
+    return tab
+
+
+@pytest.mark.parametrize("Lk,nseg,skip", [(9450, 8, 3), (9450, 8, 0), (9450, 8, 7), (9450, 8, -1), (100, 2, 1), (100, 2, 0), (130, 3, -1),
+                                          (37800, 2, -1), (64, 4, 2), (65, 4, 1), (18900, 4, -1), (18450, 8, -1), (18450, 8, 5)])
+def test_attention_segment_table_walk(Lk, nseg, skip):
+    """The table walk of the multi-segment bounded launch (attention_w16n.hip SegTab): entries 0 and 1 are applied by hand in the
+    prologue, the tile loop applies entry t + 2 at the top of tile t (loaded one tile earlier) -- the same (k, v, klen) sequence as
+    the scalar walk it replaces, including the fetches past the end."""
+    rs2, kseg, vseg = 5 * 256, 10 ** 9 + 64, 7 * 10 ** 8 + 128
+    tps = (Lk + KVBLK - 1) // KVBLK
+    ntile = tps * (nseg - (1 if skip >= 0 else 0))
+    tab = seg_table(Lk, nseg, skip, rs2, kseg, vseg)
+    fetched = []
+    i = 0
+    nxt = tab[0]                                                   # prologue
+    fetched.append(nxt)
+    i += 1; nxt = tab[i]
+    fetched.append(nxt)
+    i += 1; nxt = tab[i]
+    for t in range(ntile):                                         # tile t: apply (gaps 0, 1), fetch tile t + 2, load the next entry (gap 2)
+        fetched.append(nxt)
+        i += 1
+        nxt = tab[i]                                               # (the last tile's load, entry ntile + 2, is never applied -- but it is read)
+    assert i == ntile + 2 and len(tab) == ntile + 3
+    ref = dma_stream_reference(Lk, nseg, skip, rs2, kseg, vseg, ntile + 2)
+    assert [(k << 4, v << 4, n) for k, v, n in fetched] == ref
+
+
 def test_bounded_tile_read_plan_register_lifetimes():
     """tile_w64n's LDS read plan (attention_w64q.hip): K(t+1) fragment r (need order: S MFMA i consumes fragment i) is read at gap
     33 + r -- after its register's last reader (S_b's MFMA at gap 32 + r) and >= 15 gaps before the tile ends, so the single

@@ -29,6 +29,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "attn_w64_shared.h"
 
 namespace {
@@ -142,41 +144,38 @@ __device__ __forceinline__ void pv_step16(QH& x, const mfma_bf16x8 (&vf)[8][2], 
 // two in the even gaps 56..62) -- see attention_w64q.hip
 __device__ __forceinline__ constexpr int bk0(int g) { return g - 51 + (g > 56 ? (g - 55) / 2 : 0); }
 
-// dma_advance<true> (attn_w64_shared.h: the step of the segment-walking stream) cut into five parts spread over the three empty gaps behind the
-// barrier (all of it in front of the tile's first DMA piece at gap 3): in one piece its ~50 scalar instructions land in a single MFMA gap (200 cycles in front of one MFMA, every tile)
-struct MultiStep { int adv, sw, stp, hop2; };
-__device__ __forceinline__ void multi_step16(Dma& d, MultiStep& m, int part) {
-  if (part == 0) {
-    m.adv = d.left > 1 ? 1 : 0;
-    d.left -= m.adv;
-    const int last = (d.tt + 1 == d.tps) ? 1 : 0;
-    m.sw = m.adv & last;                                       // move to the next kv segment
-    m.stp = m.adv & (last ^ 1);                                // next tile of the same segment
-    m.hop2 = m.sw & ((d.seg + 1 == d.skip) ? 1 : 0);           // jump over the left-out segment
-  } else if (part == 1) {
-    d.tt = m.sw ? 0 : d.tt + m.stp;
-    d.seg += m.sw ? 1 + m.hop2 : 0;
-    d.klen = m.sw ? d.klen0 : d.klen - (m.stp ? (uint32_t)KVBLK * d.rs2 : 0u);
-  } else if (part == 2) {
-    d.kseg0 = m.sw ? d.kseg0 + (m.hop2 ? 2 * d.kseg : d.kseg) : d.kseg0;
-  } else if (part == 3) {
-    d.vseg0 = m.sw ? d.vseg0 + (m.hop2 ? 2 * d.vseg : d.vseg) : d.vseg0;
-  } else {
-    const char* kstep = d.k + (m.stp ? (int64_t)KVBLK * d.rs2 : (int64_t)0);
-    const char* vstep = d.v + (m.stp ? KVBLK * 2 : 0);
-    d.k = m.sw ? d.kseg0 : kstep;
-    d.v = m.sw ? d.vseg0 : vstep;
-  }
+// The segment-walking stream (sequence parallelism: the all-gather form's segments, the Ulysses rank's `world` source ranks) as a TABLE
+// walk (round 6).  dma_advance<true> (attn_w64_shared.h) tracks tile counter, segment, segment bases and the left-out segment in scalar
+// registers: ~40 scalar instructions per tile more than the single-segment stream, spread over the three empty gaps behind the barrier --
+// and still 2-4 % of a segmented launch against the same work on contiguous K / V^T (profiles/r06_attn_launch_by_layout_run02.log; the
+// rank-of-8 trace r06_rank_world8_kernel_trace_run01.json).  The walk does not depend on the workgroup: the launcher leaves one 16-byte
+// entry per fetch -- {k offset / 16, v offset / 16, valid K bytes} relative to the (batch, head) bases, the last entry repeated for the
+// fetches past the end -- in device memory once per (shape, stream) (seg_table below), and a step is one s_load_dwordx4 issued a
+// whole tile before its result is applied, plus two 64-bit adds: the single-segment stream's cost.
+struct SegTab {
+  const uint4* tab;     // entry f: the f-th tile the stream fetches
+  const char* kb;       // K / V^T of this workgroup's (batch, head), segment 0
+  const char* vb;
+  uint32_t i;           // index of `nxt`
+  uint4 nxt;            // the entry the NEXT step applies (loaded one tile ago)
+};
+__device__ __forceinline__ void segtab_apply_k(Dma& d, const SegTab& g) {
+  d.k = g.kb + ((uint64_t)g.nxt.x << 4);
+  d.klen = g.nxt.z;
+}
+__device__ __forceinline__ void segtab_apply_v(Dma& d, const SegTab& g) { d.v = g.vb + ((uint64_t)g.nxt.y << 4); }
+__device__ __forceinline__ void segtab_load(SegTab& g) {
+  g.i += 1u;
+  g.nxt = g.tab[g.i];
 }
 
 template <int ST, bool MULTI, bool TIMING, bool SHIFT>
 __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4], const int (&vaddr)[2], const mfma_bf16x8 (&qf)[4][4],
                                           const f32x4 (&negm)[4], mfma_bf16x8 (&kf)[4][4], mfma_bf16x8 (&vf)[8][2], QH& a, QH& b, int kv_rem, int lg,
-                                          char* smem_rw, Dma& dma, int& cur_tt, int tps, uint64_t* stamp, bool rec) {
+                                          char* smem_rw, Dma& dma, SegTab& seg, int& cur_tt, int tps, uint64_t* stamp, bool rec) {
   constexpr int VB = ST * IMG, KN = ((ST + 1) % NST) * IMG, DST = (ST + NST - 1) % NST;
   int adv_ = 0;
   uint32_t kb_ = 0;
-  MultiStep ms_ = {};
   // the non-MFMA work of new gap G: g = G >> 1 is attention_w64q.hip's gap; the even sub-gap carries its exp2 (MFMA + transcendental
   // fill its 16 cycles), the odd one the fragment reads, the DMA pieces, the row-sum add of the score exponentiated one gap earlier
   // and the pack of a finished pair
@@ -227,10 +226,10 @@ __device__ __forceinline__ void tile_w16n(lds_cchar* smem, const int (&kaddr)[4]
     if (!MULTI && (G) == 1) { dma.k += kb_; dma.klen -= kb_; }                                                                     \
     if (!MULTI && (G) == 2) { dma.v += adv_ * (KVBLK * 2); }                                                                        \
     if (MULTI && (G) == 4) { const int n_ = cur_tt + 1; cur_tt = n_ == tps ? 0 : n_; }  /* the segment's tile counter (ragged-tail test) */ \
-    /* the segment walk (sequence parallelism), five parts over the three gaps in front of the first piece */                         \
-    if (MULTI && (G) == 0) { multi_step16(dma, ms_, 0); multi_step16(dma, ms_, 1); }                                                 \
-    if (MULTI && (G) == 1) { multi_step16(dma, ms_, 2); multi_step16(dma, ms_, 3); }                                                 \
-    if (MULTI && (G) == 2) multi_step16(dma, ms_, 4);                                                                               \
+    /* the segment walk (sequence parallelism): the table entry loaded a tile ago, then the load of the next one */                   \
+    if (MULTI && (G) == 0) segtab_apply_k(dma, seg);                                                                                \
+    if (MULTI && (G) == 1) segtab_apply_v(dma, seg);                                                                                \
+    if (MULTI && (G) == 2) segtab_load(seg);                                                                                        \
     if (TIMING && rec && ((G) & 7) == 7) stamp[3 + ((G) >> 3)] = __builtin_amdgcn_s_memtime();  /* tuning build: one stamp per 8 gaps */ \
   } while (0)
   if (TIMING && rec) stamp[2] = __builtin_amdgcn_s_memtime();
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
                                                        int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e,
                                                        int nseg, int64_t k_seg_stride, int64_t vt_seg_stride,
                                                        const float* __restrict__ kmax2, int* __restrict__ wg_flags,
-                                                       float* __restrict__ raw, int skip_seg) {
+                                                       float* __restrict__ raw, int skip_seg, const uint32_t* __restrict__ seg_tab) {
   constexpr bool TIMING = (FLAGS & 1) != 0;  // s_memtime stamps of tile 300 of workgroup 0 -> first 160 B of O (tuning build only, -DW64Q_TIMING)
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
   constexpr bool RAW_OUT = (FLAGS & 16) != 0, CARRY_IN = (FLAGS & 32) != 0;
@@ -602,8 +601,25 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   }
 
   PST(4);   // accumulators cleared, stream set up
-  if (!PERSIST) {
-    dma_tile<0, MULTI>(smem, dma);
+  SegTab seg = {};
+  if (MULTI) {   // entries 0 and 1 by hand, entry 2 on its way for the first tile's step
+    seg.tab = reinterpret_cast<const uint4*>(seg_tab);
+    seg.kb = uni(reinterpret_cast<const char*>(kbase));
+    seg.vb = uni(reinterpret_cast<const char*>(vbase));
+    seg.i = 0u;
+    seg.nxt = seg.tab[0];
+    segtab_apply_k(dma, seg);
+    segtab_apply_v(dma, seg);
+#pragma unroll
+    for (int I = 0; I < 8; ++I) dma_piece_i<0>(smem, dma, I);
+    segtab_load(seg);
+    segtab_apply_k(dma, seg);
+    segtab_apply_v(dma, seg);
+#pragma unroll
+    for (int I = 0; I < 8; ++I) dma_piece_i<1>(smem, dma, I);
+    segtab_load(seg);
+  } else if (!PERSIST) {
+    dma_tile<0, false>(smem, dma);
 #pragma unroll
     for (int I = 0; I < 8; ++I) dma_piece_i<1>(smem, dma, I);  // tile 1; the stream steps at the top of every tile of the loop, in front of its pieces
   }
@@ -674,7 +690,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     if (PERSIST && __builtin_expect(qpf_on && t + (J) < 8, 1)) { qpf_piece(2 * (t + (J))); qpf_piece(2 * (t + (J)) + 1); } /* the next block's Q rows */ \
     if (TIMING && rec) stamp[1] = __builtin_amdgcn_s_memtime();                                              \
     const int kv_rem = Lk32 - (MULTI ? cur_tt : t + (J)) * KVBLK;                                            \
-    tile_w16n<J, MULTI, TIMING, SHIFT>(lds, kaddr, vaddr, qf, negm, kf, vf, qa, qb2, kv_rem, lg, smem, dma, cur_tt, tps, stamp, rec); \
+    tile_w16n<J, MULTI, TIMING, SHIFT>(lds, kaddr, vaddr, qf, negm, kf, vf, qa, qb2, kv_rem, lg, smem, dma, seg, cur_tt, tps, stamp, rec); \
     kv_rem_prev = kv_rem;                                                                                    \
   }
   for (int t = 0; t < ntile; t += NST) {
@@ -803,15 +819,114 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
 
 }  // namespace
 
+// ---- the segment table of a multi-segment launch (see SegTab) ----------------------------------------------------------------------
+namespace {
+__global__ void attn_seg_table_kernel(uint4* __restrict__ tab, int n_entries, int ntile, int tps, int skip, int64_t kseg_bytes, int64_t vseg_bytes,
+                                      uint32_t rs2, int Lk) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_entries) return;
+  const int ff = f < ntile ? f : ntile - 1;                 // past the end the stream stays put (later fetches land in a dead stage)
+  int sg = ff / tps;
+  const int tt = ff - sg * tps;
+  if (skip >= 0 && sg >= skip) ++sg;                        // the left-out segment (the rank's own: attended by the local launch)
+  const uint64_t koff = (uint64_t)sg * (uint64_t)kseg_bytes + (uint64_t)tt * KVBLK * rs2;
+  const uint64_t voff = (uint64_t)sg * (uint64_t)vseg_bytes + (uint64_t)tt * (KVBLK * 2);
+  uint4 e;
+  e.x = (uint32_t)(koff >> 4);
+  e.y = (uint32_t)(voff >> 4);
+  e.z = (uint32_t)(Lk - 1) * rs2 + 256u - (uint32_t)tt * KVBLK * rs2;   // valid K bytes from the tile's first row to the segment's last
+  e.w = 0u;
+  tab[f] = e;
+}
+struct SegTabKey {
+  int device;
+  hipStream_t stream;
+  int nseg, skip, Lk;
+  int64_t kseg, vseg;
+  uint32_t rs2;
+  bool operator==(const SegTabKey& o) const {
+    return device == o.device && stream == o.stream && nseg == o.nseg && skip == o.skip && Lk == o.Lk && kseg == o.kseg && vseg == o.vseg && rs2 == o.rs2;
+  }
+};
+struct SegTabEntry {
+  SegTabKey key;
+  uint4* ptr;
+  size_t bytes;
+  uint64_t last_use;
+};
+std::mutex g_segtab_mutex;
+SegTabEntry g_segtabs[32];
+int g_nsegtabs = 0;
+uint64_t g_segtab_clock = 0;
+}  // namespace
+
+// -> device pointer of the table for this walk on this (device, stream), building it (one tiny launch, ordered on `stream` in front of
+// the attention launch that reads it) at the walk's first appearance there; a forward's 40 blocks and a video's steps reuse it.
+// 32 live walks; the least recently used one makes room (hipFree synchronises the device: nothing in flight reads it).
+static int seg_table(const uint32_t** out, int nseg, int skip, int Lk, int64_t kseg_bytes, int64_t vseg_bytes, uint32_t rs2, hipStream_t stream) {
+  WAN_REQUIRE((kseg_bytes & 15) == 0 && (vseg_bytes & 15) == 0 && kseg_bytes >= 0 && vseg_bytes >= 0,
+              "wan_attention: segment strides must be multiples of 16 bytes");
+  const int tps = (Lk + KVBLK - 1) / KVBLK;
+  const int ntile = tps * (nseg - (skip >= 0 ? 1 : 0));
+  WAN_REQUIRE(ntile >= 1, "wan_attention: a segmented launch without a segment to attend");
+  WAN_REQUIRE(((uint64_t)nseg * (uint64_t)kseg_bytes >> 4) < ((uint64_t)1 << 32) && ((uint64_t)nseg * (uint64_t)vseg_bytes >> 4) < ((uint64_t)1 << 32),
+              "wan_attention: K / V^T segments exceed the segment table's 36-bit offsets");
+  const int n_entries = ntile + 3;                        // the stream fetches two tiles past the end, and the last tile still loads the entry behind those
+  SegTabKey key;
+  WAN_CHECK_HIP(hipGetDevice(&key.device));
+  key.stream = stream; key.nseg = nseg; key.skip = skip; key.Lk = Lk; key.kseg = kseg_bytes; key.vseg = vseg_bytes; key.rs2 = rs2;
+  std::lock_guard<std::mutex> lock(g_segtab_mutex);
+  for (int i = 0; i < g_nsegtabs; ++i)
+    if (g_segtabs[i].key == key) {
+      g_segtabs[i].last_use = ++g_segtab_clock;
+      *out = reinterpret_cast<const uint32_t*>(g_segtabs[i].ptr);
+      return 0;
+    }
+  SegTabEntry* e = nullptr;
+  if (g_nsegtabs < 32) {
+    e = &g_segtabs[g_nsegtabs++];
+    e->ptr = nullptr;
+    e->bytes = 0;
+  } else {
+    e = &g_segtabs[0];
+    for (int i = 1; i < 32; ++i)
+      if (g_segtabs[i].last_use < e->last_use) e = &g_segtabs[i];
+  }
+  const size_t need = (size_t)n_entries * sizeof(uint4);
+  if (e->bytes < need) {
+    if (e->ptr) (void)hipFree(e->ptr);
+    e->ptr = nullptr;
+    e->bytes = 0;
+    e->key = SegTabKey{};
+    e->key.device = -1;
+    WAN_CHECK_HIP(hipMalloc((void**)&e->ptr, need));
+    e->bytes = need;
+  } else if (e->key.device >= 0) {
+    WAN_CHECK_HIP(hipDeviceSynchronize());                   // a recycled buffer: its old walk may still be read
+  }
+  hipLaunchKernelGGL(attn_seg_table_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, stream, e->ptr, n_entries, ntile, tps, skip,
+                     kseg_bytes, vseg_bytes, rs2, Lk);
+  WAN_LAUNCH_CHECK();
+  e->key = key;
+  e->last_use = ++g_segtab_clock;
+  *out = reinterpret_cast<const uint32_t*>(e->ptr);
+  return 0;
+}
+
 // The bounded launch of attention_w64q.hip's protocol on this kernel.  fl = that file's FLAGS value (bit 2 set); every other argument as
 // attn_w64q_kernel's.  Returns -1 for a combination this file does not instantiate.
 int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B,
                               int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e, int nseg, int64_t k_seg_stride,
                               int64_t vt_seg_stride, const float* kmax2, int* wg_flags, float* raw, int skip_seg) {
+  const uint32_t* seg_tab = nullptr;
+  if (fl & 64) {   // MULTI: the walk over the segments as a table (its offsets are relative to each workgroup's (batch, head) bases)
+    switch (fl) { case 4 | 64: case 6 | 64: case 2 | 4 | 32 | 64: case 4 | 64 | 128: case 6 | 64 | 128: case 2 | 4 | 32 | 64 | 128: break; default: return -1; }
+    if (int rc = seg_table(&seg_tab, nseg, skip_seg, (int)Lk, k_seg_stride * 2, vt_seg_stride * 2, (uint32_t)(H * 256), stream)) return rc;
+  }
 #define W16N_CASE(FL)                                                                                                              \
   case FL:                                                                                                                         \
     hipLaunchKernelGGL((attn_w16n_kernel<FL>), dim3(total), dim3(256), 0, stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nqb, scale_log2e, \
-                       nseg, k_seg_stride, vt_seg_stride, kmax2, wg_flags, raw, skip_seg);                                         \
+                       nseg, k_seg_stride, vt_seg_stride, kmax2, wg_flags, raw, skip_seg, seg_tab);                                \
     break;
   switch (fl) {
     W16N_CASE(4)
