@@ -374,6 +374,11 @@ def main():
                     "the reference, not the headline configuration")
     ap.add_argument("--no-robustness", action="store_true", help="skip the self-attention launches on gain-12 and adversarial inputs (roofline.robustness)")
     ap.add_argument("--no-configs3", action="store_true", help="skip the BASELINE configs[3] block (14B 720p x 161 frames, L = 147,600: 3 steps + a simulated rank of 8)")
+    ap.add_argument("--e2e-full", action="store_true", help="after the timed region: ONE fully measured video of this workload -- tokenizer + UMT5-XXL "
+                    "text encoding (random weights, the committed tokenizer fixture) of a positive and a negative prompt -> noise -> 30 guided steps -> VAE decode -> "
+                    "uint8 frames on the host, wall clock (e2e_full; ~4.5 minutes at 14B-720p: the builder's run, not the driver's default)")
+    ap.add_argument("--no-s1", action="store_true", help="skip the guidance-1 block (one stream per forward, 4 steps: the regime of the reference's Wan2.2 "
+                    "lightning profiles, profiles/wan_2_2/*.json)")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] block (i2v 14B, scaled-fp8 weights, VAE encode + decode)")
     ap.add_argument("--parallelism", default="auto", choices=["auto", "sp", "cfg-sp", "ulysses", "cfg-ulysses"],
                     help="N > 1: 'sp' = the token axis over all N ranks, both CFG streams on every rank; 'cfg-sp' = the conditional stream on "
@@ -690,6 +695,12 @@ def main():
             if isinstance(rb, dict) and "adversarial_key_all_redone_by_tracking_loop" in rb:
                 out["roofline"]["frac_gain_12"] = rb["gain_12_shifted_loop"]["frac"]
                 out["roofline"]["frac_all_declined"] = rb["adversarial_key_all_redone_by_tracking_loop"]["frac"]
+        if world == 1 and not args.no_s1 and args.workload in TWO_EXPERT_WORKLOADS:
+            log("s1: guidance 1, one stream per forward, 1 warm-up + 4 timed steps")
+            out["s1"] = _extra_block(s1_block, model, model2, latents, ctx, freqs, y, new_sched, e2e, budget_s=args.extras_budget_s)
+        if world == 1 and args.e2e_full and vae is not None:
+            log("e2e_full: tokenizer + UMT5-XXL encode -> %d guided steps -> VAE decode -> uint8 on the host, measured" % VIDEO_STEPS)
+            out["e2e_full"] = _extra_block(e2e_full_block, model, model2, vae, freqs, y, (f, h, w), new_sched, guide, switch_threshold)
         if world == 1 and not args.no_secondary and args.workload in TWO_EXPERT_WORKLOADS:
             log("secondary: 1.3B-480p generate(), 30 steps + VAE decode")
             out["secondary"] = _extra_block(secondary_1p3b, vae, budget_s=args.extras_budget_s)
@@ -1225,6 +1236,90 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
                     "link rate on the side stream (the link model); timed steps per figure: %d" % k,
             "link_model_GBs_per_peer": link_GBs,
             "one_gpu_step_ms": step_s_1gpu * 1e3, "ranks": rows}
+
+
+def s1_block(model, model2, latents, ctx, freqs, y, new_sched, e2e):
+    """Guidance scale 1: ONE stream per forward, no unconditional pass, no combine (any2video.py:1626-1643 with guide_scale 1) -- the
+    regime the reference's Wan2.2 profiles ship (profiles/wan_2_2/*.json: lightning LoRAs, 4 steps, guidance 1, the high-noise expert for
+    the first half).  1 warm-up + 4 timed steps at S = 1 on the resident experts; a 4-step video composed with the VAE decode of this run."""
+    import torch
+    sc = new_sched(4)
+    lat = latents
+
+    def step(i, lat):
+        t = sc.timesteps[i]
+        trans = model2 if (model2 is not None and i >= 2) else model        # two steps per expert
+        pred = trans([lat], t=torch.stack([t]), context=[ctx], freqs=freqs, y=y)[0]
+        return sc.step(pred, t, lat)[0]
+    step(0, lat)                                                            # warm-up: the S = 1 workspace
+    sc = new_sched(4)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(4):
+        lat = step(i, lat)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(lat).all()
+    dec = e2e["vae_decode_to_host_s"] if isinstance(e2e, dict) and "vae_decode_to_host_s" in e2e else None
+    return {"what": "guidance 1: one stream per forward, 4 UniPC steps (two per expert), S = 1", "ms_per_forward": dt / 4 * 1e3, "steps": 4, "warmup": 1,
+            "forwards_per_s": 4 / dt, "sampler_s_per_4_step_video": dt,
+            "composed_s_per_4_step_video_with_vae_decode": (dt + dec) if dec is not None else None}
+
+
+def e2e_full_block(model, model2, vae, freqs, y, fhw, new_sched, guide, switch_threshold):
+    """One video, everything measured: prompt strings -> HuggingfaceTokenizer (the committed fixture tests/golden/tiny_tokenizer; its vocabulary
+    sizes the embedding table) -> UMT5-XXL encoder at full width (24 blocks, d 4096, ffn 10240, 64 heads; random weights) for the positive and
+    the negative prompt (any2video.py:587-593) -> noise -> VIDEO_STEPS guided UniPC steps on the resident experts -> causal 3D VAE decode ->
+    uint8 frames on the host.  Wall clock from the first string to the last frame; the encoder's weights are built before the clock starts
+    (a server holds them resident like the experts)."""
+    import torch
+    from wan2gp_amd.schedulers import cfg_combine
+    from wan2gp_amd.t5 import T5EncoderModelHIP
+    from wan2gp_amd.tokenizers import HuggingfaceTokenizer
+    f, h, w = fhw
+    tok = HuggingfaceTokenizer(os.path.join(ROOT, "tests", "golden", "tiny_tokenizer"), seq_len=512, clean="whitespace")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    vocab = int(max(tok.vocab_size, len(tok.tokenizer)))
+    kw = dict(vocab_size=vocab, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=24, num_buckets=32)
+
+    def rn(*shape, std=0.02):
+        return (torch.randn(*shape, device="cuda", generator=g) * std).to(torch.bfloat16)
+    sd = {"token_embedding.weight": rn(vocab, 4096, std=1.0), "norm.weight": torch.ones(4096, device="cuda", dtype=torch.bfloat16)}
+    for i in range(24):
+        b = "blocks.%d." % i
+        sd.update({b + "norm1.weight": torch.ones(4096, device="cuda", dtype=torch.bfloat16), b + "norm2.weight": torch.ones(4096, device="cuda", dtype=torch.bfloat16),
+                   b + "attn.q.weight": rn(4096, 4096), b + "attn.k.weight": rn(4096, 4096), b + "attn.v.weight": rn(4096, 4096), b + "attn.o.weight": rn(4096, 4096),
+                   b + "ffn.gate.0.weight": rn(10240, 4096), b + "ffn.fc1.weight": rn(10240, 4096), b + "ffn.fc2.weight": rn(4096, 10240),
+                   b + "pos_embedding.embedding.weight": rn(32, 64, std=0.5)})
+    enc = T5EncoderModelHIP(512, tok, state_dict=sd)
+    del sd
+    prompt = "a red fox runs across a snowy field at dawn, cinematic, shallow depth of field"
+    negative = "blurry, low quality, static, watermark"
+    enc([prompt])                                                           # warm-up: relative-position tables, allocator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctxs = enc([prompt, negative])
+    pad = [torch.cat([u, u.new_zeros(512 - u.shape[0], u.shape[1])]).unsqueeze(0) for u in ctxs]        # model.py: context padded to text_len
+    torch.cuda.synchronize()
+    t_enc = time.perf_counter()
+    sc = new_sched()
+    lat = torch.randn(1, 16, f, h, w, device="cuda", generator=g)
+    for i in range(VIDEO_STEPS):
+        t = sc.timesteps[i]
+        trans = model2 if (model2 is not None and int(t) <= switch_threshold) else model
+        cond, uncond = trans([lat, lat], t=torch.stack([t]), context=[pad[0], pad[1]], freqs=freqs, y=y)
+        lat = sc.step(cfg_combine(cond, uncond, guide if trans is model else 3.0), t, lat)[0]
+    torch.cuda.synchronize()
+    t_steps = time.perf_counter()
+    video = vae.decode_to_cpu_uint8([lat[0]], 0)[0]
+    torch.cuda.synchronize()
+    t_end = time.perf_counter()
+    assert video.dtype == torch.uint8 and tuple(video.shape) == (3, (f - 1) * 4 + 1, h * 8, w * 8) and not video.is_cuda
+    return {"unit": "s/video", "measured_s": t_end - t0, "text_encode_s": t_enc - t0, "sampling_s": t_steps - t_enc, "sampling_steps": VIDEO_STEPS,
+            "ms_per_step": (t_steps - t_enc) / VIDEO_STEPS * 1e3, "vae_decode_to_host_s": t_end - t_steps, "video": [3, (f - 1) * 4 + 1, h * 8, w * 8],
+            "prompt_tokens": [int(u.shape[0]) for u in ctxs],
+            "note": "measured, not composed: tokenizer (fixture vocabulary) + UMT5-XXL at full width with random weights, two prompts -> %d guided steps "
+                    "-> VAE decode -> uint8 on the host" % VIDEO_STEPS}
 
 
 def configs0_gpu(vae):

@@ -529,6 +529,14 @@ int wan_vae_rmsnorm_silu(const uint16_t* x, uint16_t* out, const uint16_t* gamma
 int wan_gemm_f16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias,
                  uint16_t* C, int64_t ldc, int64_t M, int64_t N, int K, float scale, int transposed,
                  void* stream);
+/* wan_vae_conv3d with the causal cache as TWO frame pointers (round 6): cache1 = input frame -1, cache0 = input frame -2; cache0 NULL with
+ * cache1 set: frame -2 reads as zeros; both NULL: no cache.  wan_vae_conv3d(x, cache, ...) == wan_vae_conv3d_ex(x, cache, cache + one frame, ...).
+ * The frames may live in the input tensors of two earlier chunks: wan_vae_decode / wan_vae_encode keep those alive and pass pointers where
+ * the reference clones the frames (vae.py:254-273, :149-212). */
+int wan_vae_conv3d_ex(const uint16_t* x, const uint16_t* cache0, const uint16_t* cache1, const uint16_t* w, const uint16_t* bias,
+                      const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int Hin, int Win, int Cin,
+                      int Tout, int Hout, int Wout, int Cout, int KT, int KH, int KW, int st_t, int st_s,
+                      int front, int pad_s, int ups, int interleave, void* stream);
 /* Test hook (not a product entry): force wan_vae_conv3d onto its 64-bit-offset instantiations, which inputs below 2^31
  * elements never reach; returns the previous setting.  Process-wide. */
 int wan_vae_debug_force_big(int on);

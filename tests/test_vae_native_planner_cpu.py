@@ -31,7 +31,9 @@ def test_decode_plan_is_bounded_by_the_chunk_not_the_clip(graph):
 def test_encode_plan(graph):
     a, b = plan(graph, False, 9, 64, 64), plan(graph, False, 17, 64, 64)
     assert 0 < a <= b and (b - a) <= 3 * 8 * 64 * 64 * 32 * 2                          # grows with the packed input frames only (first-fit slack included)
-    assert 2e9 < plan(graph, False, 81, 720, 1280) < 13e9
+    # (round 6: the causal caches point at the previous chunk's input tensors instead of copying their last two frames -- a 4-frame
+    # encoder chunk stays alive where a 2-frame copy did: 14.6 GB against 11-12 GB, of 288)
+    assert 2e9 < plan(graph, False, 81, 720, 1280) < 16e9
 
 
 def test_missing_layers_are_named_and_duplicates_rejected():

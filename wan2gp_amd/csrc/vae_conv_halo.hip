@@ -36,7 +36,8 @@ constexpr int HW0 = 2 * HPATCH;              // weights ring offset
 
 struct HaloP {
   const uint16_t* x;
-  const uint16_t* cache;     // two frames in front of x (or null)
+  const uint16_t* cache0;    // input frame -2 (or null: zeros) and
+  const uint16_t* cache1;    // input frame -1 (or null: no cache) -- separate pointers (round 6: the frames may live in two earlier chunks' tensors)
   const uint16_t* zero16;
   const uint16_t* w;         // [Cout][Kp], K in units of 32 channels, unit = tap * CB + cb (vae_ops.hip's packing)
   const uint16_t* bias;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   auto frame_ptr = [&](int kt) -> const uint16_t* {
     const int ti = to - p.front + kt;
     if (ti >= 0) return ti < p.Tin ? p.x + (int64_t)ti * frame : nullptr;
-    return (p.ncache > 0 && ti >= -p.ncache) ? p.cache + (int64_t)(ti + 2) * frame : nullptr;
+    return (p.ncache > 0 && ti >= -p.ncache) ? (ti == -2 ? p.cache0 : p.cache1) : nullptr;
   };
   const int G = KT * p.CB;  // groups (kt, cb), walked with carried coordinates (a scalar division by CB per tap is a VALU sequence)
   auto issue_patch = [&](int stage, int kt, int cb) {
@@ -248,13 +249,13 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
 
 // Launch for wan_vae_conv3d (vae_ops.hip): the caller has checked KT x 3 x 3 (KT = 3 or 1), stride 1, pad 1, no interleave, 32-bit offsets.
 // H, W: the OUTPUT frame (= the input's, or twice it with ups).
-int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const uint16_t* zero16, const uint16_t* w, const uint16_t* bias,
-                               const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int H, int W, int Cin, int Tout, int Cout,
-                               int front, int Kp, int KT, int ups, hipStream_t stream) {
+int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache0, const uint16_t* cache1, const uint16_t* zero16, const uint16_t* w,
+                               const uint16_t* bias, const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int H, int W, int Cin, int Tout,
+                               int Cout, int front, int Kp, int KT, int ups, hipStream_t stream) {
   HaloP p;
-  p.x = x; p.cache = cache; p.zero16 = zero16; p.w = w; p.bias = bias; p.res = res; p.out = out; p.out_f32 = out_f32;
+  p.x = x; p.cache0 = cache0; p.cache1 = cache1; p.zero16 = zero16; p.w = w; p.bias = bias; p.res = res; p.out = out; p.out_f32 = out_f32;
   p.Tin = Tin; p.H = H; p.W = W; p.Cin = Cin; p.Tout = Tout; p.Cout = Cout; p.CB = Cin / 32; p.Kp = Kp; p.front = front;
-  p.ncache = cache ? 2 : 0;
+  p.ncache = cache1 ? (cache0 ? 2 : 1) : 0;
   // the tile width that pads Cout least: 96 for the 96 / 192 / 384-channel levels (exact), for 160 (192 against 256), for the 32-channel
   // heads and latents; 128 for 128, 256, 640, 1024 ...
   const bool n96 = (Cout + 95) / 96 * 96 < (Cout + 127) / 128 * 128;

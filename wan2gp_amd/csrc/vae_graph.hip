@@ -14,9 +14,9 @@
 #include "common.h"
 
 extern "C" {
-int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const uint16_t* w, const uint16_t* bias, const uint16_t* res,
-                   uint16_t* out, float* out_f32, int Tin, int Hin, int Win, int Cin, int Tout, int Hout, int Wout, int Cout, int KT,
-                   int KH, int KW, int st_t, int st_s, int front, int pad_s, int ups, int interleave, void* stream);
+int wan_vae_conv3d_ex(const uint16_t* x, const uint16_t* cache0, const uint16_t* cache1, const uint16_t* w, const uint16_t* bias, const uint16_t* res,
+                      uint16_t* out, float* out_f32, int Tin, int Hin, int Win, int Cin, int Tout, int Hout, int Wout, int Cout, int KT,
+                      int KH, int KW, int st_t, int st_s, int front, int pad_s, int ups, int interleave, void* stream);
 int wan_vae_rmsnorm_silu(const uint16_t* x, uint16_t* out, const uint16_t* gamma, int64_t npix, int C, int silu, void* stream);
 int wan_gemm_f16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, const uint16_t* bias, uint16_t* C, int64_t ldc,
                  int64_t M, int64_t N, int K, float scale, int transposed, void* stream);
@@ -56,6 +56,7 @@ struct Arena {
   char* base = nullptr;
   int64_t cap = 0, peak = 0;
   std::map<int64_t, int64_t> used;  // offset -> size
+  std::map<int64_t, int> refs;      // offset -> owners: the graph's own handle + the causal caches that point at the tensor's frames (round 6)
   int64_t alloc(int64_t bytes) {
     bytes = (bytes + 255) / 256 * 256;
     int64_t pos = 0;
@@ -64,10 +65,18 @@ struct Arena {
       pos = kv.first + kv.second;
     }
     used[pos] = bytes;
+    refs[pos] = 1;
     if (pos + bytes > peak) peak = pos + bytes;
     return pos;
   }
-  void free(int64_t off) { used.erase(off); }
+  void retain(int64_t off) { ++refs[off]; }
+  bool owned(int64_t off) const { return refs.count(off) != 0; }
+  void free(int64_t off) {          // one owner less; the region returns to the allocator with the last
+    auto it = refs.find(off);
+    if (it != refs.end() && --it->second > 0) return;
+    if (it != refs.end()) refs.erase(it);
+    used.erase(off);
+  }
 };
 
 // a tensor in the arena: fp16 [T,H,W,C] (or fp32 when f32)
@@ -96,13 +105,25 @@ struct wan_vae {
 
 namespace {
 
+// The causal cache of a convolution (vae.py:254-273: `cache_x = x[:, :, -CACHE_T:].clone()`, with the previous chunk's last frame in
+// front when the chunk has one frame) as POINTERS (round 6): frame -1 and frame -2 are frames of the input
+// tensors of this and the previous chunk, kept alive by the slot (Arena::retain) instead of copied -- 2,838 device-to-device copies and
+// 5.2 % of a 720p x 81-frame decode in round 4's trace.  f1 = input frame -1, f0 = frame -2 (invalid: zeros).  `t` holds a copied cache
+// for inputs the arena does not own (views of the latent / video tensor).
+struct FrameRef {
+  Ten owner;          // a tensor of the arena (owner.off is its allocation)
+  int frame = 0;
+  bool valid() const { return owner.valid(); }
+};
 struct CacheSlot {
-  enum Kind { NONE, REP, TENSOR } kind = NONE;
+  enum Kind { NONE, REP, TENSOR, REFS } kind = NONE;
   Ten t;
+  FrameRef f0, f1;
 };
 
 struct ConvOpt {
   const Ten* cache = nullptr;
+  const CacheSlot* slot = nullptr;   // kind REFS: the two frame pointers; kind TENSOR: its two contiguous frames
   const Ten* res = nullptr;
   bool out_f32 = false, ups = false, interleave = false;
   int st_t = 1, st_s = 1, front = -1, pad_s = -1;
@@ -182,10 +203,21 @@ struct Graph {
     else if (o.interleave) out = make(2 * To, Ho, Wo, c->cout / 2);
     else out = make(To, Ho, Wo, c->cout, o.out_f32);
     if (!plan && rc == 0) {
-      const int r = wan_vae_conv3d(h(x), o.cache ? h(*o.cache) : nullptr, c->w, c->b, o.res ? h(*o.res) : nullptr,
-                                   o.out_f32 ? nullptr : h(out), o.out_f32 ? reinterpret_cast<float*>(p(out)) : nullptr, x.T, x.H, x.W,
-                                   x.C, To, Ho, Wo, c->cout, c->kt, c->kh, c->kw, o.st_t, o.st_s, front, pad_s, o.ups ? 1 : 0,
-                                   o.interleave ? 1 : 0, stream);
+      const uint16_t *c0 = nullptr, *c1 = nullptr;
+      if (o.slot != nullptr && o.slot->kind == CacheSlot::REFS) {
+        c1 = h(o.slot->f1.owner, (int64_t)o.slot->f1.frame * o.slot->f1.owner.frame());
+        if (o.slot->f0.valid()) c0 = h(o.slot->f0.owner, (int64_t)o.slot->f0.frame * o.slot->f0.owner.frame());
+      } else if (o.slot != nullptr && o.slot->kind == CacheSlot::TENSOR) {
+        c0 = h(o.slot->t);
+        c1 = h(o.slot->t, o.slot->t.frame());
+      } else if (o.cache != nullptr) {
+        c0 = h(*o.cache);
+        c1 = h(*o.cache, o.cache->frame());
+      }
+      const int r = wan_vae_conv3d_ex(h(x), c0, c1, c->w, c->b, o.res ? h(*o.res) : nullptr,
+                                      o.out_f32 ? nullptr : h(out), o.out_f32 ? reinterpret_cast<float*>(p(out)) : nullptr, x.T, x.H, x.W,
+                                      x.C, To, Ho, Wo, c->cout, c->kt, c->kh, c->kw, o.st_t, o.st_s, front, pad_s, o.ups ? 1 : 0,
+                                      o.interleave ? 1 : 0, stream);
       if (r) rc = r;
     }
     return out;
@@ -202,29 +234,59 @@ struct Graph {
     }
     return out;
   }
-  // cache_x bookkeeping (vae.py:256-263): last 2 frames of [old ; x]
-  Ten cache_update(const Ten& x, const CacheSlot& old) {
-    Ten c = make(2, x.H, x.W, x.C);
-    const int64_t fr = x.frame();
-    if (x.T >= 2) {
-      copy(c, 0, x, (int64_t)(x.T - 2) * fr, 2 * fr);
-    } else if (old.kind != CacheSlot::TENSOR) {
-      zero(c, 0, fr);
-      copy(c, fr, x, (int64_t)(x.T - 1) * fr, fr);
-    } else {
-      copy(c, 0, old.t, fr, fr);
-      copy(c, fr, x, (int64_t)(x.T - 1) * fr, fr);
+  // cache_x bookkeeping (vae.py:256-263): the last 2 frames of [old ; x], as a NEW slot value.  x is a tensor of the arena: the slot
+  // points at its frames and keeps it alive (no copy); x is a view of something else (the latent / video tensor): a copied cache, as before.
+  CacheSlot next_cache(const Ten& x, const CacheSlot& old) {
+    CacheSlot n;
+    if (!ar.owned(x.off)) {
+      n.kind = CacheSlot::TENSOR;
+      n.t = make(2, x.H, x.W, x.C);
+      const int64_t fr = x.frame();
+      if (x.T >= 2) {
+        copy(n.t, 0, x, (int64_t)(x.T - 2) * fr, 2 * fr);
+      } else if (old.kind == CacheSlot::TENSOR) {
+        copy(n.t, 0, old.t, fr, fr);
+        copy(n.t, fr, x, (int64_t)(x.T - 1) * fr, fr);
+      } else if (old.kind == CacheSlot::REFS) {
+        copy(n.t, 0, old.f1.owner, (int64_t)old.f1.frame * fr, fr);
+        copy(n.t, fr, x, (int64_t)(x.T - 1) * fr, fr);
+      } else {
+        zero(n.t, 0, fr);
+        copy(n.t, fr, x, (int64_t)(x.T - 1) * fr, fr);
+      }
+      return n;
     }
-    return c;
+    n.kind = CacheSlot::REFS;
+    n.f1.owner = x; n.f1.frame = x.T - 1;
+    ar.retain(x.off);
+    if (x.T >= 2) {
+      n.f0.owner = x; n.f0.frame = x.T - 2;
+      ar.retain(x.off);
+    } else if (old.kind == CacheSlot::REFS) {
+      n.f0 = old.f1;
+      ar.retain(old.f1.owner.off);
+    } else if (old.kind == CacheSlot::TENSOR) {      // (a slot that changed from copies to pointers mid-stream: frame 1 of the copied pair)
+      n.f0.owner = old.t; n.f0.frame = 1;
+      ar.retain(old.t.off);
+    }                                                 // else: the stream's first chunk -- frame -2 reads as zeros (f0 invalid)
+    return n;
   }
-  void set_cache(CacheSlot& s, Ten t) {
+  void release_cache(CacheSlot& s) {
     if (s.kind == CacheSlot::TENSOR) drop(s.t);
-    s.kind = CacheSlot::TENSOR;
-    s.t = t;
+    if (s.kind == CacheSlot::REFS) {
+      if (s.f0.valid()) ar.free(s.f0.owner.off);
+      if (s.f1.valid()) ar.free(s.f1.owner.off);
+    }
+    s = CacheSlot();
   }
+  void set_cache(CacheSlot& s, const CacheSlot& n) {
+    release_cache(s);
+    s = n;
+  }
+  static const CacheSlot* slot_arg(const CacheSlot& s) { return (s.kind == CacheSlot::TENSOR || s.kind == CacheSlot::REFS) ? &s : nullptr; }
   Ten cached_conv(const Ten& x, const std::string& name, std::vector<CacheSlot>& cache, int& idx, ConvOpt o = ConvOpt()) {
-    Ten cx = cache_update(x, cache[idx]);
-    o.cache = cache[idx].kind == CacheSlot::TENSOR ? &cache[idx].t : nullptr;
+    CacheSlot cx = next_cache(x, cache[idx]);
+    o.slot = slot_arg(cache[idx]);
     Ten y = conv(x, name, o);
     set_cache(cache[idx], cx);
     ++idx;
@@ -240,9 +302,9 @@ struct Graph {
     for (int k = 0; k < 2; ++k) {
       Ten n = norm(y, pfx + "residual." + gi[k] + ".gamma");
       if (y.off != hsc.off && (k == 1 || has_sc)) drop(y);  // y == x is still the shortcut when there is no shortcut conv
-      Ten cx = cache_update(n, cache[idx]);
+      CacheSlot cx = next_cache(n, cache[idx]);
       ConvOpt o;
-      o.cache = cache[idx].kind == CacheSlot::TENSOR ? &cache[idx].t : nullptr;
+      o.slot = slot_arg(cache[idx]);
       if (k == 1) o.res = &hsc;
       y = conv(n, pfx + "residual." + ci[k], o);
       drop(n);
@@ -318,9 +380,9 @@ Ten decoder(Graph& g, const Ten& xin, std::vector<CacheSlot>& cache) {
         if (s.kind == CacheSlot::NONE) {
           s.kind = CacheSlot::REP;
         } else {
-          Ten cx = g.cache_update(x, s);
+          CacheSlot cx = g.next_cache(x, s);
           ConvOpt o;
-          o.cache = s.kind == CacheSlot::TENSOR ? &s.t : nullptr;
+          o.slot = Graph::slot_arg(s);
           o.interleave = true;
           o.pad_s = 0;
           Ten y = g.conv(x, p + "time_conv", o);
@@ -368,24 +430,20 @@ Ten encoder(Graph& g, const Ten& xin, std::vector<CacheSlot>& cache) {
       x = y;
       if (tds[i]) {  // downsample3d (vae.py:195-211): the slot keeps the chunk's last frame
         CacheSlot& s = cache[idx];
-        const int64_t fr = x.frame();
+        // the slot points at the chunk's last frame (x stays alive through the pointer; the time_conv reads it as input frame -1)
+        CacheSlot last;
+        last.kind = CacheSlot::REFS;
+        last.f1.owner = x; last.f1.frame = x.T - 1;
+        g.ar.retain(x.off);
         if (s.kind == CacheSlot::NONE) {
-          Ten last = g.make(1, x.H, x.W, x.C);
-          g.copy(last, 0, x, (int64_t)(x.T - 1) * fr, fr);
           g.set_cache(s, last);
         } else {
-          Ten last = g.make(1, x.H, x.W, x.C);
-          g.copy(last, 0, x, (int64_t)(x.T - 1) * fr, fr);
-          Ten prev2 = g.make(2, x.H, x.W, x.C);  // [zeros ; cached frame]: the kernel reads cache[1] = the last frame
-          g.zero(prev2, 0, fr);
-          g.copy(prev2, fr, s.t, 0, fr);
           ConvOpt t;
-          t.cache = &prev2;
+          t.slot = &s;                           // f0 invalid: frame -2 is never read (front = 1)
           t.st_t = 2;
           t.front = 1;
           t.pad_s = 0;
           Ten z = g.conv(x, p + "time_conv", t);
-          g.drop(prev2);
           g.drop(x);
           x = z;
           g.set_cache(s, last);
@@ -406,8 +464,7 @@ Ten encoder(Graph& g, const Ten& xin, std::vector<CacheSlot>& cache) {
 }
 
 void drop_caches(Graph& g, std::vector<CacheSlot>& cache) {
-  for (auto& s : cache)
-    if (s.kind == CacheSlot::TENSOR) g.drop(s.t);
+  for (auto& s : cache) g.release_cache(s);
 }
 
 // WanVAE_.decode (vae.py:628-662): z [16,t,h,w] fp32 -> uint8 and/or fp32 [3,T,H,W]

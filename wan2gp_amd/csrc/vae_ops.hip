@@ -28,7 +28,8 @@ __device__ __forceinline__ void glds16v(const void* gsrc, void* ldst) { wan_lds_
 
 struct ConvP {
   const uint16_t* x;
-  const uint16_t* cache;
+  const uint16_t* cache0;   // input frame -2 (round 6: the two cached frames are separate pointers -- they may live in two earlier chunks' tensors)
+  const uint16_t* cache1;   // input frame -1
   const uint16_t* zero16;
   const uint16_t* w;
   const uint16_t* bias;
@@ -147,9 +148,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
   for (int i = 0; i < 4; ++i) s_base[i] = (off_t)s_to[i] * fin + ((off_t)s_ho[i] * p.Win + s_wo[i]) * p.Cin + s_coff[i];
   // all four slots of a thread sit in the same unit of a K-step: chunk bit 2 after the swizzle is (tid >> 2 ^ tid >> 6) & 1
   const int my_unit = s_usel[0] != 0 ? 1 : 0;
-  // frames t >= 0 live in x, frames -2 / -1 in the layer's cache: with the cache base shifted by two frames both are
+  // frames t >= 0 live in x, frames -2 / -1 in the layer's cache: with each cached frame's base shifted by its own index both are
   // base + t * frame (32-bit element offsets unless the chunk has 2^31 elements or more)
-  const uint16_t* const cbase = p.cache + 2 * frame_in;
+  const uint16_t* const cbase0 = p.cache0 + 2 * frame_in;
+  const uint16_t* const cbase1 = p.cache1 + frame_in;
   const uint16_t* wbase = p.w;  // first weight of the next k-tile to fetch (wave-uniform)
   __syncthreads();              // utab complete
   uint4 ent = utab[my_unit];    // this thread's unit of K-step 0; the next one is read a step ahead
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
       cur_kt = (int)kt;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        cur[i] = ((((vmask[i] >> (27 + kt)) & 1u) != 0) ? cbase : p.x) + (s_base[i] + (off_t)kt * fin);
+        cur[i] = ((((vmask[i] >> (27 + kt)) & 1u) != 0) ? (s_to[i] + (int)kt == -2 ? cbase0 : cbase1) : p.x) + (s_base[i] + (off_t)kt * fin);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_f16_kernel(ConvP p) {
         const bool in_cache = ((vmask[i] >> (27 + kt)) & 1u) != 0;
         const int hi = (s_ho[i] + (int)((E.z >> 20) & 0xfu)) >> 1, wi = (s_wo[i] + (int)((E.z >> 24) & 0xfu)) >> 1;
         const off_t off = (off_t)(s_to[i] + (int)kt) * fin + ((off_t)hi * p.Win + wi) * p.Cin + (int)E.w + s_coff[i];
-        src = (in_cache ? cbase : p.x) + off;
+        src = (in_cache ? (s_to[i] + (int)kt == -2 ? cbase0 : cbase1) : p.x) + off;
       } else {      // the slot's pointer at this kt + the unit's spatial offset
         src = cur[i] + E.x;
       }
@@ -330,9 +332,9 @@ extern "C" int wan_vae_debug_no_halo(int on) {
   g_no_halo = on ? 1 : 0;
   return old;
 }
-int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache, const uint16_t* zero16, const uint16_t* w, const uint16_t* bias,
-                               const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int H, int W, int Cin, int Tout, int Cout,
-                               int front, int Kp, int KT, int ups, hipStream_t stream);
+int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache0, const uint16_t* cache1, const uint16_t* zero16, const uint16_t* w,
+                               const uint16_t* bias, const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int H, int W, int Cin, int Tout,
+                               int Cout, int front, int Kp, int KT, int ups, hipStream_t stream);
 
 static int g_force_big = 0;
 extern "C" int wan_vae_debug_force_big(int on) {
@@ -341,25 +343,41 @@ extern "C" int wan_vae_debug_force_big(int on) {
   return old;
 }
 
+extern "C" int wan_vae_conv3d_ex(const uint16_t* x, const uint16_t* cache0, const uint16_t* cache1, const uint16_t* w, const uint16_t* bias,
+                                 const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int Hin, int Win, int Cin,
+                                 int Tout, int Hout, int Wout, int Cout, int KT, int KH, int KW, int st_t, int st_s,
+                                 int front, int pad_s, int ups, int interleave, void* stream);
 extern "C" int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const uint16_t* w, const uint16_t* bias,
                               const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int Hin, int Win, int Cin,
                               int Tout, int Hout, int Wout, int Cout, int KT, int KH, int KW, int st_t, int st_s,
                               int front, int pad_s, int ups, int interleave, void* stream) {
+  return wan_vae_conv3d_ex(x, cache, cache ? cache + (int64_t)Hin * Win * Cin : nullptr, w, bias, res, out, out_f32, Tin, Hin, Win, Cin, Tout, Hout, Wout,
+                           Cout, KT, KH, KW, st_t, st_s, front, pad_s, ups, interleave, stream);
+}
+// The causal cache as two frame pointers: cache1 = input frame -1, cache0 = input frame -2 (NULL with a non-NULL cache1: frame -2 reads
+// as zeros, the first chunk of a stream whose chunks hold one frame); both NULL: no cache.  The frames may belong to the input tensors
+// of two earlier chunks -- the layer graph (vae_graph.hip) keeps those alive instead of copying their last frames (vae.py:254-273's clone()s).
+extern "C" int wan_vae_conv3d_ex(const uint16_t* x, const uint16_t* cache0, const uint16_t* cache1, const uint16_t* w, const uint16_t* bias,
+                                 const uint16_t* res, uint16_t* out, float* out_f32, int Tin, int Hin, int Win, int Cin,
+                                 int Tout, int Hout, int Wout, int Cout, int KT, int KH, int KW, int st_t, int st_s,
+                                 int front, int pad_s, int ups, int interleave, void* stream) {
   WAN_REQUIRE(x && w && (out || out_f32), "wan_vae_conv3d: null pointer");
+  WAN_REQUIRE(cache0 == nullptr || cache1 != nullptr, "wan_vae_conv3d: cache frame -2 without frame -1");
+  WAN_REQUIRE((((uintptr_t)(cache0 ? cache0 : x) | (uintptr_t)(cache1 ? cache1 : x)) & 15) == 0, "wan_vae_conv3d: cache frames must be 16-byte aligned");
   WAN_REQUIRE(Cin % 32 == 0, "wan_vae_conv3d: Cin=%d must be a multiple of 32 (pad the activation/weights)", Cin);
   WAN_REQUIRE(!interleave || (Cout % 32 == 0 && res == nullptr && out_f32 == nullptr), "wan_vae_conv3d: bad interleave use");
   WAN_REQUIRE(front <= 2 && front >= 0, "wan_vae_conv3d: front must be 0..2");
   hipStream_t st = as_stream(stream);
   if (int rc = ensure_zero_page(st)) return rc;
   ConvP p;
-  p.x = x; p.cache = cache ? cache : x; p.zero16 = g_zero_page; p.w = w; p.bias = bias; p.res = res; p.out = out;
+  p.x = x; p.cache1 = cache1 ? cache1 : x; p.cache0 = cache0 ? cache0 : p.cache1; p.zero16 = g_zero_page; p.w = w; p.bias = bias; p.res = res; p.out = out;
   p.out_f32 = out_f32;
   p.Tin = Tin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Tout = Tout; p.Hout = Hout; p.Wout = Wout; p.Cout = Cout;
   p.KT = KT; p.KH = KH; p.KW = KW; p.st_t = st_t; p.st_s = st_s; p.front = front; p.pad_s = pad_s; p.ups = ups;
   p.CB = Cin / 32;
   p.U = KT * KH * KW * p.CB;
   p.nk = (p.U + 1) / 2;
-  p.ncache = cache ? 2 : 0;
+  p.ncache = cache1 ? (cache0 ? 2 : 1) : 0;
   p.interleave = interleave;
   p.M = (int64_t)Tout * Hout * Wout;
   if (p.M == 0) return 0;
@@ -368,9 +386,9 @@ extern "C" int wan_vae_conv3d(const uint16_t* x, const uint16_t* cache, const ui
   // frame tap and channel block instead of gathered once per tap (round 4)
   // ... and Resample's Conv2d 3 x 3 behind the nearest-exact 2x up-sampling (KT = 1: the patch pixel (hi, wi) is input pixel (hi >> 1, wi >> 1))
   if (!big && !g_no_halo && (KT == 3 || KT == 1) && KH == 3 && KW == 3 && st_t == 1 && st_s == 1 && pad_s == 1 && !interleave &&
-      Hout == (ups ? 2 * Hin : Hin) && Wout == (ups ? 2 * Win : Win) && (KT == 3 ? !ups : (front == 0 && cache == nullptr)) &&
+      Hout == (ups ? 2 * Hin : Hin) && Wout == (ups ? 2 * Win : Win) && (KT == 3 ? !ups : (front == 0 && cache1 == nullptr)) &&
       (int64_t)Tout * Hout * Wout * Cout < ((int64_t)1 << 31))
-    return wan_vae_conv3d_halo_launch(x, cache, g_zero_page, w, bias, res, out, out_f32, Tin, Hout, Wout, Cin, Tout, Cout, front, p.nk * 64, KT,
+    return wan_vae_conv3d_halo_launch(x, cache0, cache1, g_zero_page, w, bias, res, out, out_f32, Tin, Hout, Wout, Cin, Tout, Cout, front, p.nk * 64, KT,
                                       ups, st);
   p.tiles_y = (int)((p.M + CBM - 1) / CBM);
   p.tiles_x = (Cout + CBN - 1) / CBN;

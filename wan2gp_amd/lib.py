@@ -145,6 +145,7 @@ SIGNATURES = {
     "wan_sched_set_timesteps": (c_int, [c_void_p, c_int, c_double, POINTER(c_double), POINTER(c_float)]),
     "wan_sched_step": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_int64, c_void_p]),
     "wan_vae_conv3d": (c_int, [c_void_p] * 7 + [c_int] * 17 + [c_void_p]),
+    "wan_vae_conv3d_ex": (c_int, [c_void_p] * 8 + [c_int] * 17 + [c_void_p]),
     "wan_vae_debug_force_big": (c_int, [c_int]),
     "wan_vae_debug_no_halo": (c_int, [c_int]),
     "wan_attention_debug_no_persist": (c_int, [c_int]),
@@ -203,7 +204,10 @@ def load():
             f"{LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C wan2gp_amd/csrc). There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    ab_build = os.path.basename(LIB_PATH) != "libwanhip.so"      # tools/*.py --lib <older build>: entry points added since are simply absent
     for name, (res, args) in SIGNATURES.items():
+        if ab_build and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError -> a header symbol is not exported
         fn.restype = res
         fn.argtypes = args
