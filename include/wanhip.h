@@ -459,6 +459,14 @@ typedef struct {
   const int* perturbation_layers;
   int n_perturbation_layers;
   int x_id;
+  /* Text cache (round 6, wan_version() >= 8).  0 = off.  Non-zero: the caller's name for the CONTENTS of `context` -- while it passes the
+   * same value, the same S and the same registered weights, the text embedding (model.py:1856) and every block's cross-attention K / V^T
+   * (model.py:421-433) of this forward are the previous forward's: the library keeps them in buffers of the context's own (two keys; 2 x S x
+   * text_len x dim x 2 bytes per block and tensor) and skips their 3 launches per block + 3 per forward.  Same kernels on the same
+   * inputs: bit-identical to context_key 0.  The caller changes the value when the contents change (wan2gp_amd/model.py: identity +
+   * version counter of the context tensors, which it keeps alive).  Not served (computed as with 0): normalized attention guidance,
+   * skip-layer guidance, a step-skipping call that skips a stream. */
+  uint64_t context_key;
 } wan_dit_args;
 int wan_dit_forward_ex(wan_ctx* ctx, const wan_dit_args* args, void* stream);
 /* The same forward as a REPLAYED launch list: a call is keyed by everything its launches depend on except

@@ -36,7 +36,7 @@ def test_ctypes_binding_covers_header(built):
     for s in header_symbols():
         assert s in lib.SIGNATURES, f"{s} has no ctypes signature"
         assert hasattr(L, s)
-    assert L.wan_version() == 7          # 7: wan_sp_info.a2a_chunks (chunked Ulysses q / o exchanges), wan_permute16_ex, wan_debug_delay; 6: wan_sp_info.mode / a2a_begin / a2a_wait (Ulysses), wan_sp_a2a_begin, wan_permute16; 2: wan_dit_args.t_frames, wan_attention_bounded, wan_gemm_fp8; 3: wan_dit_args grew (n_vace ...), wan_sched_* / wan_vae_* / wan_sp_*; 4: wan_dit_args.nag_* / context_batches, wan_nag_combine; 5: wan_dit_args.perturbation_layers / x_id
+    assert L.wan_version() == 8          # 8: wan_dit_args.context_key (the text cache), wan_vae_conv3d_ex, wan_gemm_debug_force16s; 7: wan_sp_info.a2a_chunks (chunked Ulysses q / o exchanges), wan_permute16_ex, wan_debug_delay; 6: wan_sp_info.mode / a2a_begin / a2a_wait (Ulysses), wan_sp_a2a_begin, wan_permute16; 2: wan_dit_args.t_frames, wan_attention_bounded, wan_gemm_fp8; 3: wan_dit_args grew (n_vace ...), wan_sched_* / wan_vae_* / wan_sp_*; 4: wan_dit_args.nag_* / context_batches, wan_nag_combine; 5: wan_dit_args.perturbation_layers / x_id
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -74,7 +74,7 @@ def _c_class(decl):
     d = decl.strip()
     if "*" in d or any(re.search(r"\b%s\b" % t, d) for t in _FN_PTR_TYPES):
         return "ptr"
-    for pat, cls in ((r"\bint64_t\b", "i64"), (r"\bdouble\b", "f64"), (r"\bfloat\b", "f32"), (r"\bint\b", "i32"), (r"\bvoid\b", "void")):
+    for pat, cls in ((r"\bu?int64_t\b", "i64"), (r"\bdouble\b", "f64"), (r"\bfloat\b", "f32"), (r"\bint\b", "i32"), (r"\bvoid\b", "void")):
         if re.search(pat, d):
             return cls
     raise AssertionError(f"unclassified C declaration: {decl!r}")
@@ -86,7 +86,7 @@ def _ctypes_class(t):
         return "void"
     if t in (ctypes.c_int,):
         return "i32"
-    if t is ctypes.c_int64:
+    if t in (ctypes.c_int64, ctypes.c_uint64):
         return "i64"
     if t is ctypes.c_float:
         return "f32"

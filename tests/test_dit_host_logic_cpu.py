@@ -75,7 +75,7 @@ class Model:
             assert L.wan_dit_set_weight(self.ctx, k.encode(), c_void_p(a), dt, numel) == 0, L.wan_last_error()
 
     def forward(self, S=2, fhw=(2, 8, 8), should_calc=None, residual=None, nag=None, ctx_batches=None, sp=None, t_frames=None, poll=None,
-                perturb=None, x_id=0, graph=False, t=637.0, x0=0x6000_0000_0000, stream=None):
+                perturb=None, x_id=0, graph=False, t=637.0, x0=0x6000_0000_0000, stream=None, context_key=0):
         L, (F, H, W) = self.L, fhw
         shards = 1 if sp is None else sp.world
         nbytes = L.wan_dit_workspace_bytes(self.ctx, S, F, H, W, shards)
@@ -90,7 +90,7 @@ class Model:
                     None if sp is None else ctypes.cast(ctypes.byref(sp), c_void_p), None if poll is None else ctypes.cast(poll, c_void_p), None, FL, RP,
                     None, 1.0, TF, F if t_frames is not None else 0, 0, None, None,
                     *((0.0, 0.0, 0.0, None) if nag is None else (*nag, (c_int * S)(*ctx_batches))),
-                    None if not perturb else (c_int * len(perturb))(*perturb), len(perturb or ()), x_id)
+                    None if not perturb else (c_int * len(perturb))(*perturb), len(perturb or ()), x_id, context_key)
         L.mock_reset()
         if graph:
             how = c_int(-1)
@@ -885,3 +885,80 @@ def test_forward_as_a_replayed_launch_list(mock):
     assert mock.wan_dit_set_weight(m.ctx, k.encode(), c_void_p(m.addr[k] + 0x100), 0, c.ffn_dim) == 0
     rc, _, _ = m.forward(S=2, graph=True, stream=USER)
     assert rc == 0 and m.how == 1
+
+
+def test_text_cache_keeps_cross_attention_k_v_across_forwards(mock):
+    """wan_dit_args.context_key (round 6): a forward with a non-zero key computes the text embedding and every block's cross-attention
+    K / V^T like the plain forward -- but into buffers of the context's own -- and the next forward with that key skips their launches
+    (4 per block + 3 per forward at S = 2: the K Linear, its RMSNorm, one V^T Linear per stream; the text embedding: one first Linear per stream + the second) and reads the same
+    buffers; everything else is launch for launch the plain forward.  Another key, another stream count, a re-registered weight, a
+    stream that skips, NAG and skip-layer guidance recompute."""
+    m = Model(mock)
+    c = m.cfg
+    rc, plain, nbytes = m.forward(S=2)
+    assert rc == 0
+    names = lambda calls: [cl[0] for cl in calls]
+    rc, miss, _ = m.forward(S=2, context_key=11)
+    assert rc == 0 and names(miss) == names(plain), mock.wan_last_error()
+    # the miss: the cross K / V^T of every block land OUTSIDE the workspace, in one buffer pair per block; the cross-attention reads them
+    ck = [cl for cl in miss if cl[0] == "gemm" and cl[2][0] == 2 * TL and cl[2][5] == 0 and cl[2][1] == c.dim and cl[2][2] == c.dim]
+    ck = [cl for cl in ck if not in_ws(cl[1][3], nbytes)]
+    cv = [cl for cl in miss if cl[0] == "gemm" and cl[2][0] == TL and cl[2][5] == 3 and not in_ws(cl[1][3], nbytes)]
+    assert len(ck) == c.num_layers and len(cv) == 2 * c.num_layers
+    assert len({cl[1][3] for cl in ck}) == c.num_layers
+    xatt = [cl for cl in miss if cl[0] == "attention" and cl[2][3] == TL]
+    assert [cl[1][1] for cl in xatt] == [cl[1][3] for cl in ck]
+    assert [cl[1][2] for cl in xatt] == [cv[2 * i][1][3] for i in range(c.num_layers)]
+    # the hit: no text embedding, no cross K / V work; every other launch as before, the cross-attention on the same buffers
+    rc, hit, _ = m.forward(S=2, context_key=11, t=500.0)
+    assert rc == 0
+    gone = [cl for cl in miss if cl not in hit and cl[0] != "sinusoid"]
+    assert len(gone) == 3 + 4 * c.num_layers                     # te0 x 2 streams + te2; per block: ck GEMM + its norm + 2 V^T GEMMs
+    assert sorted(set(names(gone))) == ["gemm", "rmsnorm_rope"]
+    xatt_hit = [cl for cl in hit if cl[0] == "attention" and cl[2][3] == TL]
+    assert [(cl[1][1], cl[1][2]) for cl in xatt_hit] == [(cl[1][1], cl[1][2]) for cl in xatt]
+    strip = lambda calls: [(n, p, i) for n, p, i, f in calls if n != "sinusoid"]
+    assert [x for x in strip(miss) if x not in strip(gone)] == strip(hit)
+    # a second key gets the second slot; the first one still hits; a third evicts the least recently used one
+    rc, m2, _ = m.forward(S=2, context_key=12)
+    assert rc == 0 and names(m2) == names(plain)
+    rc, h1, _ = m.forward(S=2, context_key=11)
+    assert rc == 0 and names(h1) == names(hit)
+    rc, m3, _ = m.forward(S=2, context_key=13)
+    assert rc == 0 and names(m3) == names(plain)
+    rc, h1b, _ = m.forward(S=2, context_key=11)
+    assert rc == 0 and names(h1b) == names(hit)                  # 12 was the older one
+    rc, m2b, _ = m.forward(S=2, context_key=12)
+    assert rc == 0 and names(m2b) == names(plain)
+    # another stream layout under the same key, a re-registered weight: recomputed
+    rc, s1, _ = m.forward(S=1, context_key=11)
+    rc1, p1, _ = m.forward(S=1)
+    assert rc == 0 and rc1 == 0 and names(s1) == names(p1)
+    rc, s1h, _ = m.forward(S=1, context_key=11)
+    assert rc == 0 and len(s1h) == len(p1) - (2 + 3 * c.num_layers)
+    k = "blocks.0.cross_attn.k.bias"
+    assert mock.wan_dit_set_weight(m.ctx, k.encode(), c_void_p(m.addr[k] + 0x100), 0, c.dim) == 0
+    rc, after, _ = m.forward(S=1, context_key=11)
+    assert rc == 0 and names(after) == names(p1)
+    # not served: a skipped stream, skip-layer guidance, NAG -- the plain launch lists, in the workspace
+    rc, sk, _ = m.forward(S=2, context_key=12, should_calc=[1, 0], residual=[0x6400_0000_0000, 0x6410_0000_0000])
+    rc0, sk0, _ = m.forward(S=2, should_calc=[1, 0], residual=[0x6400_0000_0000, 0x6410_0000_0000])
+    assert rc == 0 and rc0 == 0 and strip(sk) == strip(sk0)
+    rc, pl, _ = m.forward(S=2, context_key=12, perturb=[1])
+    rc0, pl0, _ = m.forward(S=2, perturb=[1])
+    assert rc == 0 and rc0 == 0 and strip(pl) == strip(pl0)
+    rc, ng, _ = m.forward(S=2, context_key=12, nag=(2.0, 2.5, 0.25), ctx_batches=[2, 1])
+    rc0, ng0, _ = m.forward(S=2, nag=(2.0, 2.5, 0.25), ctx_batches=[2, 1])
+    assert rc == 0 and rc0 == 0 and strip(ng) == strip(ng0)
+    # the replayed launch list is captured in its hit form only, keyed by the slot
+    m = Model(mock)
+    rc, g0, _ = m.forward(S=2, graph=True, context_key=21, stream=0x7777)
+    assert rc == 0 and m.how == 1 and "set_f32" not in names(g0)                   # a miss: plain eager forward (fills the slot)
+    rc, g1, _ = m.forward(S=2, graph=True, context_key=21, stream=0x7777)
+    assert rc == 0 and m.how == 1 and names(g1)[0] == "set_f32"                    # first sight of the hit form
+    rc, g2, _ = m.forward(S=2, graph=True, context_key=21, stream=0x7777)
+    assert rc == 0 and m.how == 2
+    rc, g3, _ = m.forward(S=2, graph=True, context_key=21, stream=0x7777)
+    assert rc == 0 and m.how == 3 and names(g3) == ["set_f32", "graph_launch"]
+    cap = [cl for cl in g2 if cl[0] == "attention" and cl[2][3] == TL]
+    assert cap and all(not in_ws(cl[1][1], nbytes) for cl in cap)

@@ -384,3 +384,44 @@ def test_generate_with_replayed_forwards_equals_eager_generate():
     m.graph = "on"
     fast = run()
     assert m.last_graph_how == 3 and torch.equal(fast, base)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_i2v21", "tiny_flf2v", "tiny_vace", "small"])
+def test_text_cache_is_bit_identical_and_follows_the_context(name):
+    """The text cache (round 6; wan_dit_args.context_key, WanModelHIP.text_cache): cross-attention K / V^T and the text embedding of an
+    unchanged prompt are kept across forwards.  Same kernels on the same inputs -> every forward equals the text_cache = False forward
+    bit for bit: the filling call, the calls that read the cache (other latents, other timesteps), a call after the context was
+    written IN PLACE (torch's version counter: recomputed), after another context object arrived, and with the two streams swapped."""
+    cfg = O.make_config(name)
+    m, W = build(cfg)
+    f, h, w = (3, 8, 12) if name != "small" else (3, 10, 14)
+    lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
+    yy = None if y is None else y.cuda()
+    clip = O.synth_clip_fea(images=2 if cfg.flf else 1) if cfg.model_type == "i2v" else None
+    kw = {} if clip is None else {"clip_fea": clip.cuda()}
+    vace = O.synth_vace_context(cfg, f, h, w) if cfg.vace_layers is not None else None
+    if vace is not None:
+        kw.update({"vace_context": [vace.cuda()], "vace_context_scale": [0.7]})
+    m.graph = "off"
+    g = torch.Generator().manual_seed(5)
+    cc, cn = ctx.cuda().clone(), ctx_null.cuda().clone()
+
+    def both(x, t, contexts):
+        m.text_cache = False
+        ref = m([x.clone() for _ in contexts], t=t, context=list(contexts), y=yy, **kw)
+        m.text_cache = True
+        got = m([x.clone() for _ in contexts], t=t, context=list(contexts), y=yy, **kw)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), (name, (a - b).abs().max().item())
+    for i, tv in enumerate((900, 637, 55)):                       # fill, then two hits
+        both((lat + 0.1 * i * torch.randn(lat.shape, generator=g)).cuda(), torch.tensor([tv]), (cc, cn))
+    k1 = m._tc_keys[0][2]
+    cc.mul_(0.5)                                                   # the prompt changes in place: a new key, recomputed
+    both(lat.cuda(), torch.tensor([500]), (cc, cn))
+    assert m._tc_keys[0][2] != k1
+    both(lat.cuda(), torch.tensor([400]), (cn, cc))                # the streams swapped: another key
+    both(lat.cuda(), torch.tensor([300]), (cc,))                   # one stream
+    both(lat.cuda(), torch.tensor([300]), (cc,))
+    c3 = (ctx.cuda() * 0.25).contiguous()                          # a third context object: evicts the least recently used key
+    both(lat.cuda(), torch.tensor([200]), (c3, cn))
+    both(lat.cuda(), torch.tensor([100]), (c3, cn))

@@ -24,7 +24,7 @@ void wan_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* wan_last_error(void) { return g_err; }
-extern "C" int wan_version(void) { return 7; }
+extern "C" int wan_version(void) { return 8; }
 extern "C" int wan_device_cus(void) {
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
@@ -193,7 +193,29 @@ struct wan_ctx {
   uint64_t graph_clock = 0;
   float* t_dev = nullptr;           // owned: the timestep of a replayed forward
   hipStream_t cap_stream = nullptr; // owned: the stream a launch list is captured on (capture is not allowed on the legacy default stream)
+  // Text-side tensors kept across forwards (round 6; wan_dit_args.context_key).  The text context does not change during a generation,
+  // and neither do the weights: the text embedding and every block's cross-attention K (Linear + RMSNorm) and V^T are the SAME tensors in
+  // every step -- 3 launches per block and 3 per forward recomputed 2 x 30 times per video by the reference (model.py:1856, :421-433), and
+  // by every rank of a sequence-parallel world (12 ms of a 1,194-ms rank step at 14B-720p, profiles/r06_rank_world8_kernel_trace_run01.json).
+  // With a non-zero context_key the forward leaves them in buffers of the context's own (2 x S x text_len x dim x 2 B per block and tensor:
+  // 1.7 GB per 14B expert, of 288) and a later forward with the same key, stream layout and weights reads them back: same kernels on the
+  // same inputs, so the same bits.  Two keys are kept (the conditional and the unconditional stream of sequential single passes).
+  struct TextCache {
+    uint64_t key = 0;
+    int S = 0, TLx = 0, LDVx = 0;
+    bool valid = false;
+    uint64_t last_use = 0;
+    std::vector<bf16_t*> ck, cvt;    // per block (main blocks, then VACE context blocks): owned
+    size_t elems = 0;                // elements of one ck / cvt buffer
+  };
+  TextCache tcache[2];
+  uint64_t tcache_clock = 0;
 };
+static void text_cache_free(wan_ctx::TextCache& t) {
+  for (auto* p : t.ck) if (p) (void)hipFree(p);
+  for (auto* p : t.cvt) if (p) (void)hipFree(p);
+  t = wan_ctx::TextCache();
+}
 extern "C" int wan_dit_create(const wan_dit_config* cfg, wan_ctx** out) {
   WAN_REQUIRE(cfg && out, "wan_dit_create: null argument");
   WAN_REQUIRE(cfg->dim % cfg->num_heads == 0 && cfg->dim / cfg->num_heads == 128,
@@ -221,6 +243,7 @@ extern "C" void wan_dit_destroy(wan_ctx* ctx) {
     if (ctx->clip_ctx) (void)hipFree(ctx->clip_ctx);
     if (ctx->clip_tmp) (void)hipFree(ctx->clip_tmp);
     drop_graphs(ctx);
+    for (auto& t : ctx->tcache) text_cache_free(t);
     if (ctx->t_dev) (void)hipFree(ctx->t_dev);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
   }
@@ -234,6 +257,7 @@ extern "C" int wan_dit_set_weight(wan_ctx* ctx, const char* name, const void* pt
   ctx->weights[name] = Tensor{ptr, dtype, numel};
   ctx->resolved = false;
   drop_graphs(ctx);
+  for (auto& t : ctx->tcache) t.valid = false;    // (computed with the old weights)
   return 0;
 }
 
@@ -561,6 +585,43 @@ extern "C" int wan_dit_set_clip(wan_ctx* c, const wan_bf16* clip_fea, void* stre
   return 0;
 }
 
+// The text cache slot of (key, stream layout): -> index of a valid slot holding it, or -1
+static int text_cache_find(const wan_ctx* c, uint64_t key, int S, int TLx, int LDVx) {
+  if (key == 0) return -1;
+  for (int i = 0; i < 2; ++i) {
+    const auto& t = c->tcache[i];
+    if (t.valid && t.key == key && t.S == S && t.TLx == TLx && t.LDVx == LDVx) return i;
+  }
+  return -1;
+}
+// a slot to fill for `key`: an invalid one, else the least recently used; buffers for `nblk` blocks of `elems` elements each (kept when
+// they fit).  -1: no memory -- the forward then runs without the cache.  Replayed launch lists hold these pointers: a reallocation drops them.
+static void drop_graphs(wan_ctx* ctx);
+static int text_cache_claim(wan_ctx* c, uint64_t key, int S, int TLx, int LDVx, size_t nblk, size_t elems) {
+  int pick = 0;
+  if (!c->tcache[0].valid) pick = 0;
+  else if (!c->tcache[1].valid) pick = 1;
+  else pick = c->tcache[0].last_use <= c->tcache[1].last_use ? 0 : 1;
+  auto& t = c->tcache[pick];
+  t.valid = false;
+  if (t.ck.size() != nblk || t.elems < elems) {
+    text_cache_free(t);
+    drop_graphs(c);
+    t.ck.assign(nblk, nullptr);
+    t.cvt.assign(nblk, nullptr);
+    for (size_t i = 0; i < nblk; ++i) {
+      if (hipMalloc((void**)&t.ck[i], elems * 2) != hipSuccess || hipMalloc((void**)&t.cvt[i], elems * 2) != hipSuccess) {
+        (void)hipGetLastError();
+        text_cache_free(t);
+        return -1;
+      }
+    }
+    t.elems = elems;
+  }
+  t.key = key; t.S = S; t.TLx = TLx; t.LDVx = LDVx;
+  return pick;
+}
+
 // should_calc / residual: the step-skipping caches of the reference (TeaCache / MagCache, model.py:1914-2064).  Stream s
 // with residual[s] != NULL either runs the block chain and leaves residual[s] = x_after_blocks - x_after_patch_embed
 // (should_calc[s] != 0), or skips the chain and adds the stored residual to its freshly embedded tokens.  The decision is
@@ -570,7 +631,8 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
                             int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
                             void* poll_user, const int* should_calc, wan_bf16* const* residual, int n_vace,
                             const float* const* vace_contexts, const float* vace_scales, const float* nag, const int* context_batches,
-                            const int* perturb_layers, int n_perturb, int x_id, void* stream, const float* t_dev = nullptr) {
+                            const int* perturb_layers, int n_perturb, int x_id, void* stream, const float* t_dev = nullptr,
+                            uint64_t context_key = 0) {
   WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
   WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
   WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
@@ -607,6 +669,25 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     crow[s + 1] = crow[s] + cb[s] * TL;
   }
   WAN_REQUIRE(!any_nag || ffn >= d, "wan_dit_forward: normalized attention guidance parks a result in the FFN buffer (ffn_dim >= dim)");
+  // (flf2v: the text branch's context is [the second image's 257 CLIP tokens ; the text tokens], see below)
+  const int XT = c->has_flf ? CLIP_TOK : 0;
+  const int TLx = TL + XT, LDVx = XT ? ((TLx + 63) / 64) * 64 : TL;
+  // ---- the text cache (wan_ctx::TextCache): served when every stream of the call runs the whole block chain on one prompt each ----
+  wan_ctx::TextCache* tc = nullptr;
+  bool tc_hit = false;
+  {
+    bool all_calc = true;
+    for (int s = 0; should_calc != nullptr && s < S; ++s) all_calc = all_calc && should_calc[s] != 0;
+    if (context_key != 0 && !any_nag && n_perturb == 0 && all_calc) {
+      int slot = text_cache_find(c, context_key, S, TLx, LDVx);
+      tc_hit = slot >= 0;
+      if (slot < 0) slot = text_cache_claim(c, context_key, S, TLx, LDVx, (size_t)g.num_layers + c->vlayers.size(), (size_t)2 * S * TL * d);
+      if (slot >= 0) {
+        tc = &c->tcache[slot];
+        tc->last_use = ++c->tcache_clock;
+      }
+    }
+  }
   Bufs b;
   const bool mx = c->mixed;
   const int64_t need = carve_all(g, S, Ll, world, workspace, &b, c->vace_layers.empty() ? 0 : c->vace_max_ctx, c->any_fp8, F, mx);
@@ -677,11 +758,13 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     for (int s = 1; s < S && nt > 1; ++s)
       WAN_CHECK_HIP(hipMemcpyAsync(b.e0 + (int64_t)s * nt * 6 * d, b.e0, (size_t)nt * 6 * d * 2, hipMemcpyDeviceToDevice, st));
   }
-  for (int s = 0; s < S; ++s) {  // one tensor per stream (fp8: one quantisation per tensor), [cb[s] * TL, text_dim]
+  for (int s = 0; s < S && !tc_hit; ++s) {  // one tensor per stream (fp8: one quantisation per tensor), [cb[s] * TL, text_dim]
     RC(linear(context[s], c->te0, b.ctx_h + (int64_t)crow[s] * d, (int64_t)cb[s] * TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream, nullptr,
               nullptr, nullptr, -1, 1, 0, q8, 1, s));
   }
-  if (!any_nag) {
+  if (tc_hit) {
+    // (the text embedding feeds the blocks' cross-attention K / V Linears only: with those cached it is not needed)
+  } else if (!any_nag) {
     RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
   } else {
     for (int s = 0; s < S; ++s)
@@ -693,11 +776,9 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
   // the context at 257, img_emb produced 514).  Assembled once per forward in ctx_h (dead after the text embedding above): per
   // stream TLx = 257 + text_len rows; the V^T images get a row pitch of TLx rounded up to 64, their pad columns zeroed here (the
   // projection GEMMs of the blocks never write them).
-  const int XT = c->has_flf ? CLIP_TOK : 0;
-  const int TLx = TL + XT, LDVx = XT ? ((TLx + 63) / 64) * 64 : TL;
   if (XT) {
     WAN_REQUIRE(!any_nag, "wan_dit_forward: normalized attention guidance is not served together with the flf2v CLIP context");
-    for (int s = 0; s < S; ++s) {
+    for (int s = 0; s < S && !tc_hit; ++s) {
       bf16_t* dst = b.ctx_h + (int64_t)s * TLx * d;
       WAN_CHECK_HIP(hipMemcpyAsync(dst, c->clip_ctx + (int64_t)CLIP_TOK * d, (size_t)CLIP_TOK * d * 2, hipMemcpyDeviceToDevice, st));
       WAN_CHECK_HIP(hipMemcpyAsync(dst + (int64_t)XT * d, b.ctx_e + (int64_t)s * TL * d, (size_t)TL * d * 2, hipMemcpyDeviceToDevice, st));
@@ -782,7 +863,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     RC(linear(A, l, tmp, M, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, nt_));
     return wan_mx_gated_residual(xf, tmp, gate >= 0 ? mod : nullptr, gate >= 0 ? e0g : nullptr, 6, gate, M, rpb_, N, stream);
   };
-  auto run_layer = [&](const Layer& Lw) -> int {
+  auto run_layer = [&](const Layer& Lw, const int li) -> int {   // li: the block's index in the text cache (main blocks, then VACE context blocks)
     // -- self attention (model.py:632-660) --
     // mixed-precision plan (mx): b.x holds fp32 rows; modulate / norm3 / the gated residuals are the fp32 kernels of mixed_ops.hip, each
     // Linear that ended in a fused residual epilogue writes its bf16 result to xm (dead at those three points) and a separate pass adds it
@@ -1022,18 +1103,24 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
           RC(wan_attention_bounded(qs, ks, vs, dst, 1, 1, Ll, TL, TL, nh, 1, 0, 0, 1, b.kmax, stream));
         }
       }
-    } else {
+    } else if (!tc_hit) {
     // (TLx = text_len, or 257 + text_len under flf2v: b.ctx_e is then the assembled [CLIP tail ; text] context)
-    RC(linear(b.ctx_e, Lw.cross.k, b.ck, (int64_t)S * TLx, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
-    RC(wan_rmsnorm_rope(b.ck, nullptr, Lw.cross.nk, nullptr, nullptr, nullptr, (int64_t)S * TLx, TLx, 0, d, g.eps, stream));
+    // with a text cache: into the block's own buffers, where the next forward with this context finds them
+    if (tc != nullptr && XT) WAN_CHECK_HIP(hipMemsetAsync(tc->cvt[li], 0, (size_t)S * d * LDVx * 2, st));
+    bf16_t* const ckw = tc ? tc->ck[li] : b.ck;
+    bf16_t* const cvtw = tc ? tc->cvt[li] : b.cvt;
+    RC(linear(b.ctx_e, Lw.cross.k, ckw, (int64_t)S * TLx, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+    RC(wan_rmsnorm_rope(ckw, nullptr, Lw.cross.nk, nullptr, nullptr, nullptr, (int64_t)S * TLx, TLx, 0, d, g.eps, stream));
     for (int s = 0; s < S; ++s)
-      RC(linear(b.ctx_e + (int64_t)s * TLx * d, Lw.cross.v, b.cvt + (int64_t)s * d * LDVx, TLx, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+      RC(linear(b.ctx_e + (int64_t)s * TLx * d, Lw.cross.v, cvtw + (int64_t)s * d * LDVx, TLx, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
                 nullptr, nullptr, -1, 1, LDVx, q8, 1, s, Lw.cross.k.w8 != nullptr));
     }
+    const bf16_t* const ck_l = tc ? tc->ck[li] : b.ck;
+    const bf16_t* const cvt_l = tc ? tc->cvt[li] : b.cvt;
     if (!c->has_img) {
       if (!any_nag) {
         ProfScope ps(PROF_CROSS_ATTN, st);
-        RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.q, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, b.kmax, stream));
+        RC(wan_attention_bounded(b.q, ck_l, cvt_l, b.q, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, b.kmax, stream));
       }
     } else {
       // WanI2VCrossAttention (model.py:466-499): the same q attends the text tokens and the 257 CLIP tokens (K_img / V_img
@@ -1043,7 +1130,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(linear(c->clip_ctx, Lw.vimg, b.cvtimg, CLIP_TOK, d, d, WAN_EPI_TRANSPOSED, stream, nullptr, nullptr, nullptr, -1, 1, CLIP_LDV,
                 q8, 1, 0, Lw.kimg.w8 != nullptr));
       ProfScope ps(PROF_CROSS_ATTN, st);
-      if (!any_nag) RC(wan_attention_bounded(b.q, b.ck, b.cvt, b.xm, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, b.kmax, stream));
+      if (!any_nag) RC(wan_attention_bounded(b.q, ck_l, cvt_l, b.xm, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, b.kmax, stream));
       RC(wan_attention_bounded(b.q, b.ckimg, b.cvtimg, b.q, S, 1, Ll, CLIP_TOK, CLIP_LDV, nh, 1, 0, 0, 1, nullptr, stream));
       RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }
@@ -1081,12 +1168,12 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
           bf16_t* t2 = vc[j]; vc[j] = vskip[j]; vskip[j] = t2;
         }
         b.x = vc[j];
-        RC(run_layer(Vw));
+        RC(run_layer(Vw, g.num_layers + n));
         b.x = x_main;
         RC(linear(vc[j], Vw.after, vskip[j], rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));  // c_skip = after_proj(c)
       }
     }
-    RC(run_layer(c->layers[i]));
+    RC(run_layer(c->layers[i], i));
     if (n >= 0)  // x.add_(hint[, alpha=scale]) per context, in context order (:713-719)
       for (int j = 0; j < n_on; ++j) RC(wan_axpy_bf16(b.x, vskip[j], vace_scales[on_k[j]], b.x, rows * (int64_t)d, stream));
   }
@@ -1153,6 +1240,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
                         g.eps, tok0, Ll, world > 1 ? 1 : 0, nt > 1 ? tpf : 0, 4 * g.out_dim, stream));
     }
   }
+  if (tc != nullptr && !tc_hit) tc->valid = true;   // every block's K / V^T is enqueued (an aborted forward returned above: the slot stays invalid)
   return 0;
 }
 
@@ -1188,7 +1276,7 @@ static int forward_ex_impl(wan_ctx* c, const wan_dit_args* a, void* stream, cons
                           a->workspace_bytes, a->sp, a->poll, a->poll_user, a->should_calc, a->residual,
                           many ? a->n_vace : (a->vace_context ? 1 : 0), many ? a->vace_contexts : one_ctx, many ? a->vace_scales : one_scale,
                           nag, a->context_batches, a->n_perturbation_layers > 0 ? a->perturbation_layers : nullptr,
-                          a->n_perturbation_layers > 0 ? a->n_perturbation_layers : 0, a->x_id, stream, t_dev);
+                          a->n_perturbation_layers > 0 ? a->n_perturbation_layers : 0, a->x_id, stream, t_dev, a->context_key);
 }
 extern "C" int wan_dit_forward_ex(wan_ctx* c, const wan_dit_args* a, void* stream) { return forward_ex_impl(c, a, stream, nullptr); }
 
@@ -1234,6 +1322,24 @@ extern "C" int wan_dit_forward_graph(wan_ctx* c, const wan_dit_args* a, void* st
   key_put(key, a->n_perturbation_layers);
   for (int k = 0; k < a->n_perturbation_layers; ++k) key_put(key, a->perturbation_layers[k]);
   key_put(key, a->x_id); key_put(key, c->clip_set);
+  // the text cache (context_key): a launch list is captured in its HIT form only -- a call that misses runs eagerly and fills the slot --
+  // and the slot's index is part of the key (the captured launches read that slot's buffers)
+  if (a->context_key != 0) {
+    bool nagb = false;
+    for (int s = 0; a->context_batches != nullptr && s < a->S; ++s) nagb = nagb || a->context_batches[s] == 2;
+    if (!nagb && a->n_perturbation_layers <= 0) {
+      const int XTg = c->has_flf ? CLIP_TOK : 0;
+      const int TLg = c->cfg.text_len + XTg;
+      const int slot = text_cache_find(c, a->context_key, a->S, TLg, XTg ? ((TLg + 63) / 64) * 64 : c->cfg.text_len);
+      if (slot < 0) {
+        const int rc0 = wan_dit_forward_ex(c, a, stream);
+        if (how) *how = 1;
+        return rc0;
+      }
+      c->tcache[slot].last_use = ++c->tcache_clock;
+      key_put(key, a->context_key); key_put(key, slot);
+    }
+  }
   if (a->poll && a->poll(a->poll_user, 0)) return WAN_ABORTED;
   hipStream_t st = as_stream(stream);
   if (c->t_dev == nullptr) WAN_CHECK_HIP(hipMalloc((void**)&c->t_dev, 256));

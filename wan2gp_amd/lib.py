@@ -39,7 +39,8 @@ class DitArgs(ctypes.Structure):
                 ("vace_context", c_void_p), ("vace_scale", c_float), ("t_frames", POINTER(c_float)), ("n_t_frames", c_int),
                 ("n_vace", c_int), ("vace_contexts", POINTER(c_void_p)), ("vace_scales", POINTER(c_float)),
                 ("nag_scale", c_float), ("nag_tau", c_float), ("nag_alpha", c_float), ("context_batches", POINTER(c_int)),
-                ("perturbation_layers", POINTER(c_int)), ("n_perturbation_layers", c_int), ("x_id", c_int)]
+                ("perturbation_layers", POINTER(c_int)), ("n_perturbation_layers", c_int), ("x_id", c_int),
+                ("context_key", ctypes.c_uint64)]
 GATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p)
 GATHER_WAIT_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, c_void_p)
 
