@@ -673,6 +673,11 @@ int wan_attention_count_declined(const float* scratch, int B, int Bk, int64_t Lq
  * csrc/gemm16s.hip (round 6).  0 = automatic: problems of fewer than 128 tiles of 256 x 256 (default); 128 / 256 = that tile height on every
  * problem the kernel accepts, many-tile ones included; -1 = never (the round-5 dispatch).  Returns the old value.  Process-wide. */
 int wan_gemm_debug_force16s(int v);
+/* Test / A-B hook: the tile height of csrc/gemm256m.hip (round 6: 256, 224, 192 or 160 rows x 256 columns).  0 = automatic -- the height whose
+ * tiles leave the fewest CUs idle (BASELINE configs[0]: 160), 256 unless the gain is at least 8 %; 256 / 224 / 192 / 160 = that height on every
+ * problem the kernel accepts, problems below 128 tiles included; -1 = the round-5 rule (256 rows, problems of 256 tiles and more only).  Returns the
+ * old value.  Process-wide. */
+int wan_gemm_debug_force_tile_rows(int v);
 
 #ifdef __cplusplus
 }

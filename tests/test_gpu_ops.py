@@ -264,11 +264,11 @@ def test_gemm_256x256_kernel_default_path(ops, K):
 
 
 @pytest.mark.parametrize("tile", [128, 256])
-@pytest.mark.parametrize("M,N,K", [(6400, 1536, 1536), (517, 1536, 128), (1024, 5120, 5120), (300, 264, 128), (3200, 1536, 8960), (33, 64, 224)])
+@pytest.mark.parametrize("M,N,K", [(6400, 1536, 1536), (517, 1536, 128), (1024, 5120, 5120), (300, 272, 128), (3200, 1536, 8960), (33, 64, 192)])
 def test_gemm16s_small_tile_kernel(ops, tile, M, N, K):
     """csrc/gemm16s.hip (round 6: 128 x 128 / 256 x 128 x 32 tiles on the 16x16x32 MFMA, two or three workgroups per CU, the kernel of
     every problem below one wave of 256 x 256 tiles) forced onto both tile heights: BASELINE configs[0]'s projections (M = 6,400,
-    d = 1,536, ffn 8,960), the 14B text K / V Linears, ragged M and N (N = 264: the last x tile holds 8 columns), K = 4 k-tiles (the
+    d = 1,536, ffn 8,960), the 14B text K / V Linears, ragged M and N (N = 272: the last x tile holds 16 columns), K = 4 k-tiles (the
     prologue + one) ... 280; every epilogue, two batches for the gate, the transposed V^T form.  References: the fp32 matmul rounded
     once (<= 2 bf16 ulp), as for the other generations; and the automatic dispatch must agree with the forced tile to the same bar."""
     from wan2gp_amd import lib as L_
@@ -300,6 +300,49 @@ def test_gemm16s_small_tile_kernel(ops, tile, M, N, K):
     finally:
         lib.wan_gemm_debug_force16s(old)
     assert_bf16_close(ops.linear(cu(x), cu(w), cu(b)), y, frac=0.05, what="automatic dispatch", floor=0.25)
+
+
+@pytest.mark.parametrize("rows", [160, 192, 224])
+@pytest.mark.parametrize("M,N,K", [(6400, 1536, 1536), (517, 1536, 128), (3200, 1536, 8960), (1000, 512, 448)])
+def test_gemm256m_lower_tile_heights(ops, rows, M, N, K):
+    """csrc/gemm256m.hip with 160 / 192 / 224-row tiles (round 6: template argument TY = 5, 6, 7; the height wan_gemm256m_tile_rows picks
+    when it leaves fewer CUs idle than 256 rows -- BASELINE configs[0]) forced onto configs[0]'s projections and ragged shapes (M = 517:
+    the last y tile holds 37 / 133 / 69 rows; K = 2 ... 140 k-tiles): every epilogue, two batches for the gate, the V^T form; against the
+    fp32 matmul rounded once AND bit for bit against the 256-row tile (same k order per output element)."""
+    from wan2gp_amd import lib as L_
+    lib = L_.load()
+    g = torch.Generator().manual_seed(M * 5 + N + K + rows)
+    x = torch.randn(M, K, generator=g).to(BF); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = (0.1 * torch.randn(N, generator=g)).to(BF)
+    y = _gemm_ref(x, w, b)
+    r = torch.randn(M, N, generator=g).to(BF)
+    B = 2 if (M % 2 == 0 and M // 2 >= 256) else 1
+    mod = (torch.randn(1, 6, N, generator=g) / N ** 0.5).to(BF); e0 = (0.5 * torch.randn(B, 6, N, generator=g)).to(BF)
+    rpb = M // B
+    ref_g = torch.cat([torch.addcmul(r[i * rpb:(i + 1) * rpb], y[i * rpb:(i + 1) * rpb], (mod + e0[i:i + 1]).chunk(6, dim=1)[5][0]) for i in range(B)])
+
+    def run_all():
+        out = {"none": ops.linear(cu(x), cu(w), cu(b)).cpu(), "gelu": ops.linear(cu(x), cu(w), cu(b), epilogue=1).cpu()}
+        rr = cu(r.clone())
+        out["gate"] = ops.linear(cu(x), cu(w), cu(b), epilogue=2, residual=rr, mod=cu(mod), e=cu(e0), gate_idx=5, out=rr).cpu()
+        out["vt"] = ops.linear(cu(x), cu(w), cu(b), epilogue=3).cpu()
+        return out
+    old16 = lib.wan_gemm_debug_force16s(-1)
+    old = lib.wan_gemm_debug_force_tile_rows(rows)
+    try:
+        got = run_all()
+        lib.wan_gemm_debug_force_tile_rows(256)
+        full = run_all()
+    finally:
+        lib.wan_gemm_debug_force_tile_rows(old)
+        lib.wan_gemm_debug_force16s(old16)
+    assert_bf16_close(got["none"], y, frac=0.05, what="none", floor=0.25)
+    assert_bf16_close(got["gelu"], torch.nn.functional.gelu(y, approximate="tanh"), frac=0.05, ulps=3, what="gelu", floor=0.25)
+    assert_bf16_close(got["gate"], ref_g, frac=0.05, what="gate residual", floor=(r.float().abs() + y.float().abs()))
+    assert_bf16_close(got["vt"][:, :M], y.t(), frac=0.05, what="V^T", floor=0.25)
+    assert (got["vt"][:, M:] == 0).all()
+    for k in got:
+        assert torch.equal(got[k], full[k]), f"{k}: the {rows}-row tile differs from the 256-row tile"
 
 
 def test_gemm_rejects_bad_k(ops):

@@ -179,26 +179,28 @@ def test_attention_w16n_tile_instruction_mix(tmp_path_factory):
 
 
 def test_gemm256m_registers_and_stage_instruction_mix(tmp_path_factory):
-    """gemm256m.hip (the product GEMM since round 3, 16x16x32 MFMA): no scratch, 256 accumulators in the accumulator file, the
-    whole LDS, and between two barriers of the main loop exactly one stage: 128 MFMAs, 32 ds_read_b128, 16 LDS-DMA pieces and
-    NO vector-ALU instruction (a 16-cycle MFMA gap hides two issue slots; an address computation there is a stall)."""
+    """gemm256m.hip (the product GEMM since round 3, 16x16x32 MFMA): no scratch, the whole LDS, and between two barriers of the main loop
+    exactly one stage.  The 256-row tile (TY = 8): 256 accumulators in the accumulator file, 128 MFMAs, 32 ds_read_b128, 16 LDS-DMA pieces
+    and NO vector-ALU instruction (a 16-cycle MFMA gap hides two issue slots; an address computation there is a stall).  Round 6: the tile
+    height is a template argument -- TY = 5, 6, 7 (160 / 192 / 224 rows): 32 TY accumulators, 16 TY MFMAs, 2 (TY + 8) fragment reads and
+    TY + 8 pieces per stage, likewise without vector-ALU work."""
     ks = kernels(asm_of("gemm256m", tmp_path_factory), "gemm256m_kernel")
-    assert len(ks) == 5                                              # NONE / GELU / GATE_RES, the row-bias (V^T) form, and the fp32-stream residual (round 5)
+    assert len(ks) == 17                                             # {NONE, GELU, GATE_RES, the row-bias (V^T) form} x TY 5..8, and the fp32-stream residual (TY 8)
+    seen = collections.Counter()
     for name, (ops, meta) in ks.items():
-        assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256 and meta["LDSByteSize"] == 160 * 1024, (name, meta)
+        ty = int(re.search(r"Li(\d)EEEv", name).group(1))
+        seen[ty] += 1
+        assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 32 * ty and meta["LDSByteSize"] == 160 * 1024, (name, meta)
         bars = [i for i, o in enumerate(ops) if o == "s_barrier"]
         stages = [collections.Counter(ops[a:b]) for a, b in zip(bars, bars[1:])]
-        stages = [c for c in stages if c["v_mfma_f32_16x16x32_bf16"] == 128]
+        stages = [c for c in stages if c["v_mfma_f32_16x16x32_bf16"] == 16 * ty]
         assert len(stages) >= 4, name                                # the loop is unrolled by 5: four barrier-to-barrier spans inside it
         for c in stages:
-            assert c["ds_read_b128"] == 32 and c["buffer_load_dwordx4"] == 16, c
+            assert c["ds_read_b128"] == 2 * (ty + 8) and c["buffer_load_dwordx4"] == ty + 8, c
             valu = sum(v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma"))
             assert valu == 0, c
             assert c["s_waitcnt"] <= 20, c
-
-
-
-
+    assert seen == {8: 5, 7: 4, 6: 4, 5: 4}, seen
 
 
 def test_no_kernel_of_the_library_spills_to_scratch(tmp_path_factory):

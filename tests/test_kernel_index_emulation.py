@@ -1248,3 +1248,68 @@ def test_gemm16s_ring_schedule():
             if kt + 1 < nk:
                 assert slot_holds[reading_slot] == kt + 1
             frag_tile = slot_holds[reading_slot]
+
+
+# ----------------------------------------------------------------------------------------------
+# gemm256m.hip with the tile height as a template argument (round 6: TY = 5 .. 8 y tiles of 16 rows per wave)
+# ----------------------------------------------------------------------------------------------
+def _g256m_k1_p(TY):
+    return (8 * TY - 16) // 8
+
+
+def _g256m_k1_piece(TY, m):
+    P = _g256m_k1_p(TY)
+    return (m - 16) % P == 0 and (m - 16) // P < 8
+
+
+def _g256m_k1_load(TY, m):
+    if _g256m_k1_piece(TY, m):
+        return -1
+    if _g256m_k1_p(TY) % 2 == 0:
+        return (m - 17) >> 1 if (m & 1) == 1 and ((m - 17) >> 1) < TY + 8 else -1
+    idx = (m - 16) - sum(1 for q in range(16, m) if _g256m_k1_piece(TY, q))
+    return idx if idx < TY + 8 else -1
+
+
+def _g256m_ord(TY, i):
+    return 1 + i if i < TY - 1 else 9 + (i - (TY - 1)) if i < TY + 6 else 8 if i == TY + 6 else 0
+
+
+@pytest.mark.parametrize("TY", [5, 6, 7, 8])
+def test_gemm256m_stage_schedule_for_every_tile_height(TY):
+    """A stage of the 32 TY x 256 tile: k-step 0 = 8 TY MFMAs carrying the TY pieces of Y_{S+2} (after MFMA 0, 8, ...) and the TY + 8
+    fragments of k-step 1 (after the odd MFMAs); k-step 1 = 16 bare MFMAs, the sync point, then the 8 pieces of X_{S+2} and the next
+    stage's TY + 8 first fragments, never two in one gap, every fragment exactly once in the order y1.., x1.., x0, y0 (what the next
+    k-step's first MFMA needs last); TY = 8 is the round-3 plan slot for slot."""
+    NM, NF = 8 * TY, TY + 8
+    k0_dma = [m for m in range(NM) if (m & 7) == 0]
+    k0_rd = [m for m in range(NM) if (m & 7) != 0 and (m & 1) == 1 and m < 2 * NF]
+    assert [m >> 3 for m in k0_dma] == list(range(TY)) and [m >> 1 for m in k0_rd] == list(range(NF)) and not set(k0_dma) & set(k0_rd)
+    pieces = [m for m in range(16, NM) if _g256m_k1_piece(TY, m)]
+    loads = [(m, _g256m_k1_load(TY, m)) for m in range(16, NM) if _g256m_k1_load(TY, m) >= 0]
+    assert len(pieces) == 8 and [(m - 16) // _g256m_k1_p(TY) for m in pieces] == list(range(8))
+    assert [i for _, i in loads] == list(range(NF)) and not set(pieces) & {m for m, _ in loads}
+    order = [_g256m_ord(TY, i) for i in range(NF)]
+    assert sorted(order) == list(range(TY)) + list(range(8, 16)) and order[-2:] == [8, 0]
+    if TY == 8:
+        assert pieces == list(range(16, 64, 6)) and loads == [(m, (m - 17) >> 1) for m in range(17, 48, 2)]
+        assert order == [1 + i if i < 7 else 2 + i if i < 14 else 8 if i == 14 else 0 for i in range(16)]
+
+
+def test_gemm256m_tile_height_rule():
+    """wan_gemm256m_tile_rows: rounds of tiles x height, 2 % per step below 256, 256 unless the gain is >= 8 % (transliterated)."""
+    def rows(YM, XN, cus=256):
+        tx = (XN + 255) // 256
+        cost = lambda T: ((((YM + 32 * T - 1) // (32 * T)) * tx + cus - 1) // cus) * T * (1.0 + 0.02 * (8 - T))
+        if ((YM + 255) // 256) * tx > 8 * cus:
+            return 256
+        best, cb = 8, cost(8)
+        for T in (7, 6, 5):
+            if cost(T) < cb * 0.92 and cost(T) < cost(best):
+                best = T
+        return 32 * best
+    assert rows(6400, 1536) == 160                 # BASELINE configs[0]: 40 x 6 = 240 tiles on 256 CUs (25 x 6 = 150 at 256 rows)
+    assert rows(6400, 8960) == 224                 # its ffn.0: 29 x 35 = 1,015 tiles = 4 rounds of 7 (875 tiles = 4 rounds of 8)
+    assert rows(65520, 1536) == 256                # 1.3B-480p: 256 x 6 = exactly 6 rounds
+    assert rows(151200, 5120) == 256 and rows(151200, 13824) == 256     # the headline: far beyond eight rounds
+    assert rows(18900, 5120) == 256                # a rank of a world of 8: 5.8 rounds, nothing lower gains 8 %

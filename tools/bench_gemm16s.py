@@ -39,7 +39,8 @@ def main():
     names = list(SETS) if a.set == "all" else a.set.split(",")
     g = torch.Generator(device="cuda").manual_seed(0)
     res = {}
-    variants = (("off", -1), ("t128", 128), ("t256", 256), ("auto", 0))
+    # (16s code, tile-rows code): off = the round-5 dispatch (gemm256m at 256 rows from 256 tiles up, else gemm32 / first generation); h160 .. h256 = gemm256m at that height on every problem
+    variants = (("off", (-1, -1)), ("h256", (-1, 256)), ("t128", (128, 0)), ("t256", (256, 0)), ("h160", (-1, 160)), ("h192", (-1, 192)), ("h224", (-1, 224)), ("auto", (0, 0)))
     for sn in names:
         for name, M, N, K, epi in SETS[sn]:
             x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
@@ -54,7 +55,8 @@ def main():
             reps = 8 if M * N * K < 1e11 else 3
             for i in range(a.rounds + 1):
                 for vn, code in variants:
-                    lib.wan_gemm_debug_force16s(code)
+                    lib.wan_gemm_debug_force16s(code[0])
+                    lib.wan_gemm_debug_force_tile_rows(code[1])
                     ops.linear(x, w, b, epilogue=epi, residual=r, mod=mod, e=e, gate_idx=5 if epi == 2 else -1, out=out)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -67,6 +69,7 @@ def main():
                     elif epi != 2:
                         outs[vn] = out.float().clone()
             lib.wan_gemm_debug_force16s(0)
+            lib.wan_gemm_debug_force_tile_rows(0)
             row = {}
             for vn, _ in variants:
                 t = sorted(ts[vn])

@@ -36,7 +36,7 @@ typedef __attribute__((address_space(3))) const char g256m_lds_cchar;
 typedef uint32_t g256m_u4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const g256m_u4 g256m_lds_u4;
 
-constexpr int M_BM = 256, M_BN = 256, M_BK = 64;
+constexpr int M_BN = 256, M_BK = 64;   // (the tile is 32 TY rows high: 256 for TY = 8)
 // internal epilogue id (not in the public enum: reached through wan_gemm_bf16_res32): the mixed-precision plan's gated residual --
 // Out is the FP32 residual stream, updated in place: x += bf16(acc + bias) * (mod[gate] + e0[batch][gate]) with an fp32 gate from a
 // bf16 modulation row and an fp32 e0 row (mixed_ops.hip mx_gated_residual_kernel's arithmetic on the accumulators: one pass less
@@ -81,7 +81,26 @@ __device__ uint64_t g256m_stamps[16];  // tuning aid: s_memtime stamps of workgr
 #define M_STAMP(I)
 #endif
 
-template <int EPI, bool BIAS_ROWS>
+// the slots of k-step 1 behind the sync point (MFMAs 16 .. 8 TY - 1): the 8 X pieces every P-th gap, the next stage's TY + 8 first fragments in
+// the gaps between them -- for TY = 8 (and 6: P even) the round-3 plan, pieces in even gaps and fragments in the odd ones
+template <int TY> __device__ __forceinline__ constexpr int g256m_k1_p() { return (8 * TY - 16) / 8; }
+template <int TY> __device__ __forceinline__ constexpr bool g256m_k1_piece(int m) { return (m - 16) % g256m_k1_p<TY>() == 0 && (m - 16) / g256m_k1_p<TY>() < 8; }
+template <int TY> __device__ __forceinline__ constexpr int g256m_k1_load(int m) {   // index of the fragment read behind MFMA m, or -1
+  if (g256m_k1_piece<TY>(m)) return -1;
+  if (g256m_k1_p<TY>() % 2 == 0) return ((m & 1) == 1 && ((m - 17) >> 1) < TY + 8) ? ((m - 17) >> 1) : -1;
+  int pieces = 0;
+  for (int q = 16; q < m; ++q) pieces += g256m_k1_piece<TY>(q) ? 1 : 0;
+  const int idx = (m - 16) - pieces;
+  return idx < TY + 8 ? idx : -1;
+}
+// the order a k-step's TY + 8 fragments are read in: y 1 .. TY - 1, x 1 .. 7 (fragment indices 9 .. 15), then x 0 (8) and y 0 (0)
+template <int TY> __device__ __forceinline__ constexpr int g256m_ord(int i) { return i < TY - 1 ? 1 + i : i < TY + 6 ? 9 + (i - (TY - 1)) : i == TY + 6 ? 8 : 0; }
+
+// TY (round 6): y tiles of 16 rows per wave -- the tile is 32 TY rows high (8: the 256 x 256 tile of every many-tile problem; 5, 6, 7: 160,
+// 192, 224 rows for problems of a few hundred tiles, where the height that leaves the fewest CUs idle beats the one with the most reuse:
+// BASELINE configs[0]'s M = 6,400 rows are 25 x 6 tiles of 256 rows on 150 of 256 CUs, but 40 x 6 tiles of 160 rows on 240).  Units, ring,
+// swizzle and sync structure do not change: a Y unit simply holds 32 TY of its 256 rows, a k-step is 8 TY MFMAs.
+template <int EPI, bool BIAS_ROWS, int TY>
 __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict__ Y, int64_t ldy, int64_t YM,
                                                        const bf16_t* __restrict__ X, int64_t ldx, int64_t XN, int K,
                                                        bf16_t* __restrict__ Out, int64_t ldo, const bf16_t* __restrict__ bias,
@@ -107,22 +126,27 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
   const int in_g = wg - gidx * per_group;
   const int ty = first_y + (in_g % gsz);
   const int tx = in_g / gsz;
-  const int64_t y0 = (int64_t)ty * M_BM;
+  constexpr int BMY = 32 * TY;   // rows of the tile (256 for TY = 8)
+  constexpr int NM = 8 * TY;     // MFMAs of a k-step
+  constexpr int NF = TY + 8;     // fragments of a k-step
+  const int64_t y0 = (int64_t)ty * BMY;
   const int64_t x0 = (int64_t)tx * M_BN;
 
   // ---- DMA plan: loop-invariant per-lane byte offsets relative to the tile's first row ---------------------------------------
   // A unit image is 256 rows x 8 chunks of 16 B; piece i (0..7) of wave w fills 16-B slots q = i*256 + w*64 + lane, i.e. rows
   // i*32 + w*8 .. +8, eight lanes per row = the row's whole 128-B line in one instruction; physical chunk p of row r holds
   // logical chunk p ^ ((r >> 1) & 7).  Y rows in place; X image row (slab, t, n) = row slab*128 + 8 n + t of the tile's X panel.
-  uint32_t yofs[8], xofs[8];
+  uint32_t yofs[TY], xofs[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int q = i * 256 + tid;
     const int row = q >> 3, pch = q & 7;
     const int lch = pch ^ ((row >> 1) & 7);
-    int64_t yr = y0 + row;
-    if (yr > YM - 1) yr = YM - 1;  // ragged tile: re-read the last row (its results are never stored)
-    yofs[i] = (uint32_t)((yr - y0) * ldy * 2 + lch * 16);
+    if (i < TY) {
+      int64_t yr = y0 + row;
+      if (yr > YM - 1) yr = YM - 1;  // ragged tile: re-read the last row (its results are never stored)
+      yofs[i] = (uint32_t)((yr - y0) * ldy * 2 + lch * 16);
+    }
     const int slab = row >> 7, t = (row >> 4) & 7, n = row & 15;
     int64_t xr = x0 + slab * 128 + 8 * n + t;
     if (xr > XN - 1) xr = XN - 1;  // ragged x edge (the row-bias / V^T form: x = tokens): re-read the last row, its columns are never stored
@@ -147,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
-      ybw[ks][w] = (uint32_t)((((wy * 128 + l15) * 128 + ((lg ^ sw) << 4)) ^ (ks << 6)) + w * 65536);
+      ybw[ks][w] = (uint32_t)((((wy * (16 * TY) + l15) * 128 + ((lg ^ sw) << 4)) ^ (ks << 6)) + w * 65536);
       xbw[ks][w] = (uint32_t)((((wx * 128 + l15) * 128 + ((lg ^ sw) << 4)) ^ (ks << 6)) + w * 65536);
       asm volatile("" : "+v"(ybw[ks][w]), "+v"(xbw[ks][w]));
     }
@@ -164,20 +188,20 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
 
   // prologue: stages 0 and 1 (units 0..3); Y_2 is issued by stage 0's first k-step like every later Y unit
 #pragma unroll
-  for (int p = 0; p < 8; ++p) y_piece(0, p);
+  for (int p = 0; p < TY; ++p) y_piece(0, p);
   y_advance();
 #pragma unroll
   for (int p = 0; p < 8; ++p) x_piece(1, p);
   x_advance();
 #pragma unroll
-  for (int p = 0; p < 8; ++p) y_piece(2, p);
+  for (int p = 0; p < TY; ++p) y_piece(2, p);
   y_advance();
 #pragma unroll
   for (int p = 0; p < 8; ++p) x_piece(3, p);
   x_advance();
-  f32x4 acc[8][8];  // [y tile][x tile], accumulator file; zeroed while the first stages are in flight (256 writes: ~1k cycles)
+  f32x4 acc[TY][8];  // [y tile][x tile], accumulator file; zeroed while the first stages are in flight (256 writes: ~1k cycles)
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < TY; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
 #pragma unroll
@@ -185,7 +209,11 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
       asm volatile("" : "+a"(acc[a][b]));
     }
 
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // stage 0 landed, stage 1 may be in flight
+  // stage 0 landed, stage 1 (its TY + 8 pieces) may be in flight
+  if (TY == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (TY == 7) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+  else if (TY == 6) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   M_STAMP(1);
@@ -193,9 +221,9 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
   // the order the 16 fragments of a k-step are read in: what its FIRST MFMA needs (y tile 0, x tile 0) LAST -- hipcc then puts one
   // lgkmcnt(0) in front of that MFMA and none behind it (in any other order it counts the reads down with a wait per fragment: 31
   // s_waitcnt per stage, each an issue slot of a 16-cycle gap); every read is issued >= 16 MFMAs before the k-step that uses it
-#define M_ORD(I) ((I) < 7 ? 1 + (I) : (I) < 14 ? 2 + (I) : (I) == 14 ? 8 : 0)
+#define M_ORD(I) g256m_ord<TY>(I)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) load_frag(f0, 0, 1, 0, M_ORD(r));
+  for (int r = 0; r < NF; ++r) load_frag(f0, 0, 1, 0, M_ORD(r));
   // Stage S = 5i + J: Y in slot 2J % 5, X in (2J+1) % 5; 2 k-steps of 64 MFMAs, MFMA m multiplies (y tile m>>3, x tile m&7).
   //   k-step 0 (f0): Y_{S+2} pieces 0..7 -> slot (2J+4) % 5 after MFMA 0,8,..,56; fragments of k-step 1 -> f1 after MFMA 1,3,..,31
   //   k-step 1 (f1): MFMAs 0..15 bare;
@@ -208,23 +236,26 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
     constexpr int J_ = (J);                                                                                     \
     constexpr int SY = (2 * J_) % 5, SX = (2 * J_ + 1) % 5, NY = (2 * J_ + 2) % 5, NX = (2 * J_ + 3) % 5;        \
     constexpr int DY = (2 * J_ + 4) % 5, DX = (2 * J_) % 5;                                                      \
-    _Pragma("unroll") for (int m = 0; m < 64; ++m) {                                                            \
+    _Pragma("unroll") for (int m = 0; m < NM; ++m) {                                                            \
       mfma256m(acc[m >> 3][m & 7], f0.y[m >> 3], f0.x[m & 7]); M_SB();                                           \
       if ((m & 7) == 0) y_piece(DY, m >> 3);                                                                     \
-      else if ((m & 1) == 1 && m < 32) load_frag(f1, SY, SX, 1, M_ORD(m >> 1));                                  \
+      else if ((m & 1) == 1 && m < 2 * NF) load_frag(f1, SY, SX, 1, M_ORD(m >> 1));                              \
       M_SB();                                                                                                   \
     }                                                                                                           \
     y_advance();                                                                                                \
     _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                                            \
       mfma256m(acc[m >> 3][m & 7], f1.y[m >> 3], f1.x[m & 7]); M_SB();                                           \
     }                                                                                                           \
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                                 \
+    if (TY == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                    \
+    else if (TY == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");                               \
+    else if (TY == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                               \
+    else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                                                               \
     asm volatile("" ::: "memory");                                                                              \
-    _Pragma("unroll") for (int m = 16; m < 64; ++m) {                                                           \
+    _Pragma("unroll") for (int m = 16; m < NM; ++m) {                                                           \
       mfma256m(acc[m >> 3][m & 7], f1.y[m >> 3], f1.x[m & 7]); M_SB();                                           \
-      if ((m - 16) % 6 == 0) x_piece(DX, (m - 16) / 6);                                                          \
-      else if ((m & 1) == 1 && m < 48) load_frag(f0, NY, NX, 0, M_ORD((m - 17) >> 1));                           \
+      if (g256m_k1_piece<TY>(m)) x_piece(DX, (m - 16) / g256m_k1_p<TY>());                                       \
+      else if (g256m_k1_load<TY>(m) >= 0) load_frag(f0, NY, NX, 0, M_ORD(g256m_k1_load<TY>(m)));                 \
       M_SB();                                                                                                   \
     }                                                                                                           \
     x_advance();                                                                                                \
@@ -257,11 +288,11 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
     const uint32_t colb = (uint32_t)(wx * 128) * 2u + ne * 16u;   // bf16 vectors (bias, modulation)
     const uint32_t colf = (uint32_t)(wx * 128) * 4u + ne * 32u;   // fp32 rows (x, e0)
     int64_t rows_valid = YM - y0;
-    if (rows_valid > M_BM) rows_valid = M_BM;
+    if (rows_valid > BMY) rows_valid = BMY;
     const uint32_t onum = (uint32_t)((rows_valid - 1) * ldo * 4 + M_BN * 4);
     const uint32_t ldo4 = (uint32_t)(ldo * 4);
     const __amdgpu_buffer_rsrc_t xdesc = __builtin_amdgcn_make_buffer_rsrc((void*)(X32 + y0 * ldo + x0), 0, (int)onum, 0x00020000);
-    const uint32_t row_lane = (uint32_t)(wy * 128) + 4u * ge;
+    const uint32_t row_lane = (uint32_t)(wy * (16 * TY)) + 4u * ge;
     const bool col_in = x0 + wx * 128 + 8 * (int64_t)ne + 8 <= XN;
     const uint32_t lane_off = col_in ? row_lane * ldo4 + colf : 0x80000000u;
     float bcol[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -297,8 +328,8 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) { xq[0][i][0] = xload(0, i, 0); xq[0][i][1] = xload(0, i, 1); }
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      if (a + 1 < 8) {
+    for (int a = 0; a < TY; ++a) {
+      if (a + 1 < TY) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xq[(a + 1) & 1][i][0] = xload(a + 1, i, 0); xq[(a + 1) & 1][i][1] = xload(a + 1, i, 1); }
       }
@@ -328,13 +359,13 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
     const uint32_t ne = lane_e & 15u, ge = lane_e >> 4;
     const uint32_t colb = (uint32_t)(wx * 128) * 2u + ne * 16u;  // byte offset of the lane's 8 columns in the tile row
     int64_t rows_valid = YM - y0;
-    if (rows_valid > M_BM) rows_valid = M_BM;
+    if (rows_valid > BMY) rows_valid = BMY;
     const uint32_t onum = (uint32_t)((rows_valid - 1) * ldo * 2 + M_BN * 2);  // rows >= rows_valid: out of range
     const uint32_t ldo2 = (uint32_t)(ldo * 2);
     const __amdgpu_buffer_rsrc_t odesc = __builtin_amdgcn_make_buffer_rsrc((void*)(Out + y0 * ldo + x0), 0, (int)onum, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdesc =
         __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == WAN_EPI_GATE_RES ? R : Out) + y0 * ldo + x0), 0, (int)onum, 0x00020000);
-    const uint32_t row_lane = (uint32_t)(wy * 128) + 4u * ge;
+    const uint32_t row_lane = (uint32_t)(wy * (16 * TY)) + 4u * ge;
     // a lane's 8 columns are inside the matrix or outside as a whole (the launcher requires XN % 8 == 0); outside: an offset past
     // num_records, the stores are dropped like the rows past the matrix
     const bool col_in = x0 + wx * 128 + 8 * (int64_t)ne + 8 <= XN;
@@ -377,8 +408,8 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
       for (int i = 0; i < 4; ++i) { rq[0][i] = rload(0, i); rq[1][i] = rload(1, i); }
     }
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      if (EPI == WAN_EPI_GATE_RES && a + 2 < 8) {
+    for (int a = 0; a < TY; ++a) {
+      if (EPI == WAN_EPI_GATE_RES && a + 2 < TY) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) rq[(a + 2) % 3][i] = rload(a + 2, i);
       }
@@ -423,11 +454,31 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
 }  // namespace
 
 // Returns -1 when the problem does not fit this kernel (the caller falls back to gemm256k.hip and the generations before it),
-// else the launch status.
+// else the launch status.  tile_rows: 256 (every many-tile problem), or 224 / 192 / 160 (round 6: problems of a few hundred tiles, the
+// height chosen by wan_gemm256m_tile_rows below; not for the fp32-stream epilogue).
+template <int EPI, bool BIAS_ROWS, int TY>
+static int gemm256m_launch(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                           int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
+                           int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale) {
+  constexpr int BMY = 32 * TY;
+  if (EPI == M_EPI_RES32 || EPI == WAN_EPI_GATE_RES) {
+    if (gate_idx >= 0 && rows_per_batch < BMY) return -1;      // a tile touches at most two batches
+  }
+  const int64_t ty = (YM + BMY - 1) / BMY, tx = (XN + M_BN - 1) / M_BN;
+  if (ty * tx >= ((int64_t)1 << 31)) return -1;
+  // y tiles per group of the tile order (gemm256k.hip); WAN_GEMM_GROUP overrides the column-bias forms' 4 for A/B runs (round 5, run 07)
+  static const int group_env = [] { const char* e = getenv("WAN_GEMM_GROUP"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+  const int group = BIAS_ROWS ? 8 : (group_env ? group_env : 4);
+  hipLaunchKernelGGL((gemm256m_kernel<EPI, BIAS_ROWS, TY>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R,
+                     mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, out_scale, group);
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int EPI, bool BIAS_ROWS>
-int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
-                    int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
-                    int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale) {
+int wan_gemm256m_try_h(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                       int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
+                       int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale, int tile_rows) {
   if (K % M_BK != 0 || XN % 8 != 0) return -1;             // a lane stores 8 columns or none
   if (!BIAS_ROWS && XN % M_BN != 0) return -1;             // column bias / gate rows are fetched 16 bytes per lane without an edge form
   if (ldo % 8 != 0 || ((uintptr_t)Out & 15) != 0 || (!BIAS_ROWS && bias != nullptr && ((uintptr_t)bias & 15) != 0)) return -1;  // 16-byte stores / bias loads
@@ -436,26 +487,52 @@ int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
   if (256 * ldo * (EPI == M_EPI_RES32 ? 4 : 2) + 1024 >= ((int64_t)1 << 31)) return -1;
   if (EPI == M_EPI_RES32) {  // Out = the fp32 stream, e = the fp32 e0 rows (both behind bf16-typed parameters), mod = bf16 rows
     if (ldo % 4 != 0 || XN % M_BN != 0) return -1;
-    if (gate_idx >= 0 && (rows_per_batch < M_BM || ((uintptr_t)mod & 15) != 0 || ((uintptr_t)e & 15) != 0)) return -1;
+    if (gate_idx >= 0 && (((uintptr_t)mod & 15) != 0 || ((uintptr_t)e & 15) != 0)) return -1;
   }
   if (EPI == WAN_EPI_GATE_RES) {
     if (((uintptr_t)R & 15) != 0) return -1;
-    if (gate_idx >= 0 && (rows_per_batch < M_BM || ((uintptr_t)mod & 15) != 0 || ((uintptr_t)e & 15) != 0)) return -1;
+    if (gate_idx >= 0 && (((uintptr_t)mod & 15) != 0 || ((uintptr_t)e & 15) != 0)) return -1;
   }
-  const int64_t ty = (YM + M_BM - 1) / M_BM, tx = (XN + M_BN - 1) / M_BN;
-  if (ty * tx >= ((int64_t)1 << 31)) return -1;
-  // y tiles per group of the tile order (gemm256k.hip); WAN_GEMM_GROUP overrides the column-bias forms' 4 for A/B runs (round 5, run 07)
-  static const int group_env = [] { const char* e = getenv("WAN_GEMM_GROUP"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-  const int group = BIAS_ROWS ? 8 : (group_env ? group_env : 4);
-  hipLaunchKernelGGL((gemm256m_kernel<EPI, BIAS_ROWS>), dim3((unsigned)(ty * tx)), dim3(256), 0, st, Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R,
-                     mod, e, n_mod, gate_idx, rows_per_batch, (int)ty, (int)tx, out_scale, group);
-  WAN_LAUNCH_CHECK();
-  return 0;
+#define G256M_GO(T) return gemm256m_launch<EPI, BIAS_ROWS, T>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale)
+  if constexpr (EPI != M_EPI_RES32) {
+    if (tile_rows == 224) G256M_GO(7);
+    if (tile_rows == 192) G256M_GO(6);
+    if (tile_rows == 160) G256M_GO(5);
+  }
+  G256M_GO(8);
+#undef G256M_GO
+}
+template <int EPI, bool BIAS_ROWS>
+int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                    int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
+                    int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale) {
+  return wan_gemm256m_try_h<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale, 256);
+}
+
+// The tile height for a problem of YM x XN outputs on `cus` compute units: the one of {256, 224, 192, 160} whose tiles need the least
+// time -- rounds of tiles x height, with 2 % per step below 256 for the operand reuse a lower tile gives up -- and 256 unless the gain
+// is at least 8 % (and always 256 beyond eight rounds, where the last round's quantisation is noise).
+int wan_gemm256m_tile_rows(int64_t YM, int64_t XN, int cus) {
+  if (cus < 1) cus = 256;
+  const int64_t tx = (XN + M_BN - 1) / M_BN;
+  auto cost = [&](int T) {
+    const int64_t tiles = ((YM + 32 * T - 1) / (32 * T)) * tx;
+    return (double)((tiles + cus - 1) / cus) * T * (1.0 + 0.02 * (8 - T));
+  };
+  const int64_t t8 = ((YM + 255) / 256) * tx;
+  if (t8 > 8 * (int64_t)cus) return 256;
+  int best = 8;
+  double cb = cost(8);
+  for (int T = 7; T >= 5; --T)
+    if (cost(T) < cb * 0.92 && cost(T) < cost(best)) best = T;
+  return 32 * best;
 }
 
 #define G256M_INST(EPI, BR)                                                                                                        \
   template int wan_gemm256m_try<EPI, BR>(const bf16_t*, int64_t, int64_t, const bf16_t*, int64_t, int64_t, int, bf16_t*, int64_t,  \
-                                         const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int64_t, hipStream_t, float);
+                                         const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int64_t, hipStream_t, float); \
+  template int wan_gemm256m_try_h<EPI, BR>(const bf16_t*, int64_t, int64_t, const bf16_t*, int64_t, int64_t, int, bf16_t*, int64_t,  \
+                                           const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, int, int, int64_t, hipStream_t, float, int);
 G256M_INST(WAN_EPI_NONE, false)
 G256M_INST(WAN_EPI_GELU_TANH, false)
 G256M_INST(WAN_EPI_GATE_RES, false)

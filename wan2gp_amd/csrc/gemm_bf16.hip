@@ -254,12 +254,25 @@ int wan_gemm256m_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, 
                      int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                      int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale);
 
+// ... with the tile height as an argument (round 6: 256 / 224 / 192 / 160 rows) and the rule that picks it
+template <int EPI, bool BIAS_ROWS>
+int wan_gemm256m_try_h(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
+                       int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
+                       int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale, int tile_rows);
+int wan_gemm256m_tile_rows(int64_t YM, int64_t XN, int cus);
+
 // sixth-generation kernel (gemm16s.hip): 128 x 128 / 256 x 128 tiles on the 16x16x32 MFMA, three / two workgroups per CU; bf16
 template <int EPI, bool BIAS_ROWS>
 int wan_gemm16s_try(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K, bf16_t* Out,
                     int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod, const bf16_t* e, int n_mod,
                     int gate_idx, int64_t rows_per_batch, hipStream_t st, float out_scale, int tile_rows);
 
+static int g_force_rows = 0;   // test / A-B hook: 0 = wan_gemm256m_tile_rows decides, 256 / 224 / 192 / 160 = that height wherever gemm256m runs, -1 = the round-5 rule (256 rows, many-tile problems only)
+extern "C" int wan_gemm_debug_force_tile_rows(int v) {
+  const int old = g_force_rows;
+  g_force_rows = (v == 256 || v == 224 || v == 192 || v == 160 || v == -1) ? v : 0;
+  return old;
+}
 static int g_force16s = [] { const char* e = getenv("WAN_GEMM16S"); return e ? atoi(e) : 0; }();
 extern "C" int wan_gemm_debug_force16s(int v) {
   const int old = g_force16s;
@@ -280,27 +293,41 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
   // partly idle for a whole tile time, and the 128-wide kernels balance better).  WAN_GEMM_MIN_TILES overrides for A/B runs.
   static const int64_t min_tiles = [] { const char* e = getenv("WAN_GEMM_MIN_TILES"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : WAN_GEMM_MIN_TILES_DEFAULT); }();
   const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= min_tiles;
-  // Round 6: problems of fewer than 128 tiles of 256 x 256 (the text K / V Linears and the text embedding: M = 512 ... 1,024 context rows; UMT5;
-  // the CLIP branch) run on gemm16s.hip's co-resident small tiles -- 256 x 128 from 128 such tiles up, else 128 x 128.  Measured in one
-  // process against the kernels they had (run 03, profiles/r06_ab_gemm16s_run03.log): M = 512, N = K = 4,096: 35 against 70 us; the 14B text
-  // K / V^T: 77 / 54 against 93 / 92 us.  From ~150 tiles up (BASELINE configs[0]: M = 6,400) the small tiles are level with gemm32 and
-  // at many tiles they lose to gemm256m by 1.4-1.8 x (a 128 x 128 x 32 stage is 64 FLOP per byte fetched: 64 B/clk/CU of LDS-DMA at the matrix
-  // pipe's peak -- the vector memory path's whole width; 256 x 256 needs 32), so the rule stops there.  g_force16s (env WAN_GEMM16S at load,
-  // wan_gemm_debug_force16s at run time): -1 = never (the round-5 dispatch), 0 = this rule, 128 / 256 = that tile on EVERY problem it fits.
+  // Round 6 dispatch of the bf16 Linears (run 09 / 10, profiles/r06_ab_gemm_tile_heights_run09.log, r06_ab_gemm_text_shapes_run10.log; one
+  // process, alternating, bit-identical outputs):
+  //   1. gemm256m.hip at the tile HEIGHT that leaves the fewest CUs idle (wan_gemm256m_tile_rows: 256, 224, 192 or 160 rows x 256 columns)
+  //      whenever that gives at least 128 tiles: every many-tile problem as before (256 rows; 224 where a round is saved), and what gemm32
+  //      served until round 5 -- BASELINE configs[0]'s M = 6,400 rows as 40 x 6 tiles of 160 rows on 240 CUs instead of 25 x 6 of 256 on 150:
+  //      q / k / o 46.9 -> 28.0 us, ffn.2 + gate 240.8 -> 128.2 us; the 14B text K Linear (M = 1,024) 93.0 -> 58.9 us;
+  //   2. below that, gemm16s.hip's co-resident small tiles (256 x 128 from 128 such tiles up, else 128 x 128): UMT5's projections at
+  //      M = 512 (70.3 -> 35.0 us), the 1.3B text K / V Linears (28.4 -> 14.6 us), the 14B text V^T (92.3 -> 53.4 us).
+  //      (A 128 x 128 x 32 stage is 64 FLOP per byte fetched = 64 B/clk/CU of LDS-DMA at the matrix pipe's peak, the vector memory path's
+  //      whole width -- 256 x 256 needs 32: at many tiles the small tiles lose by 1.4-1.8 x, which is why they stop here.)
+  // Hooks (tests, in-process A/B): g_force_rows (wan_gemm_debug_force_tile_rows) and g_force16s (env WAN_GEMM16S at load,
+  // wan_gemm_debug_force16s): -1 = the round-5 rule, 0 = this dispatch, a tile size = that tile on every problem it fits.
+#ifndef WAN_GEMM_NO_MI16  // (defined only for the A/B library libwanhip_k.so: gemm256k on every shape)
   if constexpr (!F16 && (!BIAS_ROWS || EPI == WAN_EPI_NONE)) {
+    static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+    if (g_force16s > 0) {   // (forced small tiles come first, many-tile problems included: the A/B tool's t128 / t256 columns)
+      const int rc = wan_gemm16s_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale, g_force16s);
+      if (rc >= 0) return rc;
+    }
+    const int rows = g_force_rows == -1 ? 256 : g_force_rows ? g_force_rows : wan_gemm256m_tile_rows(YM, XN, cus);
+    const int64_t th = ((YM + rows - 1) / rows) * ((XN + 255) / 256);
+    const bool tall = g_force_rows == -1 ? many_tiles : (g_force_rows > 0 || many_tiles || (th >= 128 && min_tiles == WAN_GEMM_MIN_TILES_DEFAULT && g_force16s <= 0));
+    if (tall) {
+      const int rc = wan_gemm256m_try_h<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale, rows);
+      if (rc >= 0) return rc;
+      if (rows != 256 && many_tiles) {   // (a batch shorter than the chosen height, ...: the full-height tile)
+        const int rc2 = wan_gemm256m_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale);
+        if (rc2 >= 0) return rc2;
+      }
+    }
     const int f16s = g_force16s;
-    const bool small = ((YM + 255) / 256) * ((XN + 255) / 256) < 128 && YM >= 32 && XN >= 32;
-    if (f16s > 0 || (f16s == 0 && small)) {
+    if (f16s > 0 || (f16s == 0 && !many_tiles && YM >= 32 && XN >= 32)) {
       const int64_t t256 = ((YM + 255) / 256) * ((XN + 127) / 128);
       const int rc = wan_gemm16s_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale,
                                                      f16s > 0 ? f16s : (t256 >= 128 ? 256 : 128));
-      if (rc >= 0) return rc;
-    }
-  }
-#ifndef WAN_GEMM_NO_MI16  // (defined only for the A/B library libwanhip_k.so: gemm256k on every shape)
-  if constexpr (!F16 && (!BIAS_ROWS || EPI == WAN_EPI_NONE)) {
-    if (many_tiles) {
-      const int rc = wan_gemm256m_try<EPI, BIAS_ROWS>(Y, ldy, YM, X, ldx, XN, K, Out, ldo, bias, R, mod, e, n_mod, gate_idx, rows_per_batch, st, out_scale);
       if (rc >= 0) return rc;
     }
   }
