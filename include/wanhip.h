@@ -552,6 +552,10 @@ int wan_vae_debug_force_big(int on);
  * sum in different orders and agree to fp32 rounding, not bit for bit); returns the old value. */
 int wan_vae_debug_no_halo(int on);
 int wan_attention_debug_no_persist(int on);
+/* Test / A-B hook: 0 = a bounded self-attention call is ONE launch over its q blocks x heads x batches (the form until round 5); 1 (default;
+ * env WAN_ATTN_SPLIT_TAIL=0 at load for the other) = a call whose workgroups do not fill their last round of CUs attends that round's q
+ * blocks as k key-range parts each and finishes them in a third launch (csrc/attention_w64q.hip split_tail).  Returns the old value. */
+int wan_attention_debug_split_tail(int on);
 
 /* ---- the mixed-precision transformer plan (`mixed_precision_transformer`: wgp.py:4039 "mixed_precision" -> any2video.py:190 ->
  * WanModel.lock_layers_dtypes(torch.float32), models/wan/modules/model.py:1330-1371).  The time MLP, the time projection and every

@@ -606,6 +606,66 @@ def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
     assert attn_ok(got2, _prescaled_ref(qs, k2, v))
 
 
+@pytest.mark.parametrize("layout,gain", [("one_segment", 1.0), ("one_segment", 8.0), ("ulysses_segments", 1.0)])
+def test_attention_split_tail_agrees_with_the_one_launch_form_and_fp64(ops, layout, gain):
+    """The split tail of a bounded launch (round 6; csrc/attention_w64q.hip split_tail): 270 workgroups on 256 CUs = one full round + 14
+    q blocks that would run alone for a whole round -- they are attended as 8 key-range parts each (unnormalised sums to the library's
+    scratch) and finished by a third launch.  The bounded softmax's partial sums add exactly up to the order of the fp32 additions:
+    against the fp64 softmax on the tail's rows and a sample of the others, and against the one-launch form (wan_attention_debug_split_tail
+    0) within one bf16 ulp of the output scale.  gain 8: the rows carry a reference shift every part must agree on.  The segmented form is
+    the Ulysses rank's launch (2 x 1 query batches against one K / V^T batch in two segments with ragged tails)."""
+    from wan2gp_amd import lib as L_
+    lib = L_.load()
+    cus = lib.wan_device_cus()
+    if cus != 256:
+        pytest.skip(f"the shape is built for 256 CUs (device has {cus})")
+    g = torch.Generator().manual_seed(int(gain * 10) + len(layout))
+    H = 3
+    if layout == "one_segment":
+        B, Bk, Lq, Lk, nseg = 1, 1, 90 * 256, 8256, 1                      # 90 q blocks x 3 heads = 270 workgroups; 129 tiles, the last one ragged... (8256 = 129 x 64)
+        Lk -= 19                                                           # ... now it is
+        k = (torch.randn(Bk, Lk, H, 128, generator=g) * gain).to(BF); v = torch.randn(Bk, Lk, H, 128, generator=g).to(BF)
+        kk, vv = k, v
+    else:
+        B, Bk, Lq, Lk, nseg = 2, 1, 45 * 256, 4141, 2                      # (source rank, stream) batches; two segments of 65 tiles, ragged tails
+        kseg = (torch.randn(nseg, Bk, Lk, H, 128, generator=g) * gain).to(BF); vseg = torch.randn(nseg, Bk, Lk, H, 128, generator=g).to(BF)
+        kk, vv = torch.cat(list(kseg), dim=1), torch.cat(list(vseg), dim=1)     # [Bk, nseg * Lk, H, 128]: what the rows attend
+    q = torch.randn(B, Lq, H, 128, generator=g)
+    qs = (q * ops.attention_qscale()).to(BF)
+
+    def run():
+        scratch = torch.zeros(ops.attention_scratch_words(B, Bk, Lq, H), device="cuda")
+        if layout == "one_segment":
+            out = ops.attention(cu(qs), cu(k), ops.transpose_v(cu(v)), q_prescaled=True, kmax_scratch=scratch)
+        else:
+            vt = torch.stack([ops.transpose_v(cu(vseg[i])) for i in range(nseg)]).contiguous()
+            out = ops.attention(cu(qs), cu(kseg), vt, Lk=Lk, nseg=nseg, k_seg_stride=Bk * Lk * H * 128, vt_seg_stride=Bk * H * 128 * vt.shape[-1], Bk=Bk,
+                                q_prescaled=True, kmax_scratch=scratch)
+        flags = scratch[Bk * H:Bk * H + (Lq // 256) * H * B].view(torch.int32).cpu()
+        return out.float().cpu(), flags
+    old = lib.wan_attention_debug_split_tail(1)
+    try:
+        split, fl1 = run()
+        lib.wan_attention_debug_split_tail(0)
+        whole, fl0 = run()
+    finally:
+        lib.wan_attention_debug_split_tail(old)
+    assert (fl1 == 0).all() and (fl0 == 0).all()                           # nothing handed to the tracking loop in either form
+    assert torch.isfinite(split).all()
+    # the tail: workgroups 256..269 = the last 14 q blocks of the last (batch, head) pair; plus two q blocks of the full round
+    nqb = Lq // 256
+    for (b, h, qb0, qb1) in ((B - 1, H - 1, nqb - 14, nqb), (0, 0, 3, 5)):
+        rows = slice(qb0 * 256, qb1 * 256)
+        ref = _prescaled_ref(qs[b:b + 1, rows, h:h + 1], kk[:, :, h:h + 1], vv[:, :, h:h + 1])
+        for name, got in (("split", split), ("whole", whole)):
+            part = got[b:b + 1, rows, h:h + 1]
+            err = (part - ref).abs()
+            assert attn_ok(part, ref) and err.mean().item() <= 2e-3, (layout, gain, name, qb0, err.max().item())
+    d = (split - whole).abs()
+    assert d.max().item() <= 2.0 ** -7 * max(1.0, whole.abs().max().item()), d.max().item()
+    assert torch.equal(split[:, :(nqb - 14) * 256] if B == 1 else split[0], whole[:, :(nqb - 14) * 256] if B == 1 else whole[0])   # the full rounds' rows: the same launch form
+
+
 @pytest.mark.parametrize("gain", [6.0, 8.0, 12.0, 30.0])
 def test_attention_shifted_bounded_loop_agrees_with_fp64(ops, gain):
     """Round 4: rows beyond the bound U = |q~| max|k| <= 96 run the bounded loop with a per-row reference shift m = U - 96

@@ -148,7 +148,7 @@ def test_attention_w16n_tile_instruction_mix(tmp_path_factory):
     the DMA stream is spread over the gaps behind the barrier)."""
     asm = asm_of("attention_w16n", tmp_path_factory)
     ks = kernels(asm, "attn_w16n_kernel")
-    assert len(ks) == 14                                             # six plain + their six shifted twins (FLAGS | 128, round 4) + the two persistent short-KV forms (| 256)
+    assert len(ks) == 16                                             # six plain + their six shifted twins (FLAGS | 128, round 4) + the two persistent short-KV forms (| 256) + the split tail's two (round 6: segmented parts, one-segment finish)
     for name, (ops, meta) in ks.items():
         persist = any(t in name for t in ("ILi388E", "ILi390E"))
         assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256, (name, meta)

@@ -323,7 +323,16 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
                                                        int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e,
                                                        int nseg, int64_t k_seg_stride, int64_t vt_seg_stride,
                                                        const float* __restrict__ kmax2, int* __restrict__ wg_flags,
-                                                       float* __restrict__ raw, int skip_seg, const uint32_t* __restrict__ seg_tab) {
+                                                       float* __restrict__ raw, int skip_seg, const uint32_t* __restrict__ seg_tab,
+                                                       int v_base, int kv_split, int carry_n, int part_from) {
+  // v_base / kv_split / carry_n (round 6, the split tail of a launch; 0 / 1 / 1 = a whole launch as before): the launch covers the
+  // workgroups (q blocks) from v_base on.  kv_split = k > 1 (RAW_OUT): k workgroups per q block, part j attends tiles
+  // [j n / k, (j + 1) n / k) of the block's n and leaves its unnormalised sums in raw slot (v - v_base) k + j.  carry_n = k > 1 (CARRY_IN):
+  // the finishing launch -- no tiles of its own, the k parts' sums added (the bounded softmax's partial sums add exactly: one shift m per
+  // row for all parts), normalised, judged and stored like any workgroup's.  part_from (a launch that is neither RAW_OUT nor CARRY_IN):
+  // workgroups [0, part_from) of the grid are whole q blocks 0 .. part_from - 1, the workgroups behind them the kv_split parts of the q
+  // blocks from part_from on -- ONE launch, so that the parts fill the CUs as the last whole round drains (as a launch of their own they
+  // waited for its last workgroup: run 11 measured a third of the predicted gain).
   constexpr bool TIMING = (FLAGS & 1) != 0;  // s_memtime stamps of tile 300 of workgroup 0 -> first 160 B of O (tuning build only, -DW64Q_TIMING)
   constexpr bool PRESCALED = (FLAGS & 2) != 0;
   constexpr bool RAW_OUT = (FLAGS & 16) != 0, CARRY_IN = (FLAGS & 32) != 0;
@@ -378,7 +387,8 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
 #else
 #define PST(I) do { } while (0)
 #endif
-  int v_first, v_end;
+  int v_first, v_end, kv_part = 0;
+  bool is_part = false;
   if (PERSIST) {
     const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     v_first = (int)blockIdx.x * per;
@@ -390,9 +400,22 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   } else {
-    v_first = xcd_remap(blockIdx.x, total);
+    if (!RAW_OUT && !CARRY_IN && kv_split > 1 && (int)blockIdx.x >= part_from) {   // a part behind the whole q blocks of its launch
+      const int u = xcd_remap((int)blockIdx.x - part_from, (int)gridDim.x - part_from);
+      is_part = true;
+      v_base = part_from;
+      v_first = part_from + u / kv_split;
+      kv_part = u - (u / kv_split) * kv_split;
+    } else if (!RAW_OUT && !CARRY_IN && kv_split > 1) {
+      v_first = xcd_remap(blockIdx.x, part_from);
+    } else {
+      const int u = xcd_remap(blockIdx.x, (int)gridDim.x);   // (a whole launch: gridDim.x == total)
+      v_first = v_base + u / kv_split;
+      kv_part = u - (u / kv_split) * kv_split;
+    }
     v_end = v_first + 1;
   }
+  const bool raw_out = RAW_OUT || is_part;   // this workgroup leaves unnormalised sums
   auto qpf_set_next = [&]() {   // the block after the current one
     if (p_qb + 1 < nqb) { qpf_set(p_pair, p_qb + 1, p_b, p_h); return; }
     const int pr = p_pair + 1, bn = pr / H;
@@ -418,11 +441,23 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
 
   const bf16_t* qbase = Q + ((int64_t)b * Lq) * rs + (int64_t)h * 128;
   const bf16_t* kbase = Kg + ((int64_t)bk * Lk) * rs + (int64_t)h * 128;
-  const bf16_t* vbase = Vt + ((int64_t)bk * H * 128 + (int64_t)h * 128) * ldv;
+  const bf16_t* vbase = Vt + ((int64_t)bk * H * 128 + (int64_t)h * 128) * ldv;   // (both move t_lo tiles in for a part of a split tail)
   bf16_t* obase = O + ((int64_t)b * Lq) * rs + (int64_t)h * 128;
 
   const int64_t q0 = (int64_t)qb * 256 + wave * 64;
-  const int Lk32 = (int)Lk;
+  int Lk32 = (int)Lk;
+  // the split tail: part kv_part of kv_split attends the tiles [t_lo, t_hi) of the block's walk
+  const int tps_all = ((int)Lk + KVBLK - 1) / KVBLK;
+  const int ntile_all = tps_all * (nseg - (skip_seg >= 0 ? 1 : 0));
+  const int t_lo = (raw_out && kv_split > 1) ? (int)((int64_t)kv_part * ntile_all / kv_split) : 0;
+  const int t_hi = (raw_out && kv_split > 1) ? (int)((int64_t)(kv_part + 1) * ntile_all / kv_split) : ntile_all;
+  if (!MULTI && raw_out && kv_split > 1) {   // one segment: the part is a K / V^T of its own, t_lo tiles in
+    kbase += (int64_t)t_lo * KVBLK * rs;
+    vbase += (int64_t)t_lo * KVBLK;
+    const int left = (int)Lk - t_lo * KVBLK;
+    const int mine = (t_hi - t_lo) * KVBLK;
+    Lk32 = left < mine ? left : mine;
+  }
   Dma dma;
   if (PERSIST) {  // tiles 0 and 1 first: they travel while the Q fragments are read and the rows are judged
     dma_init(dma, kbase, vbase, 0, 0, Lk32, 1, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, -1, /*k_rows_16x16=*/true);
@@ -520,10 +555,11 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   PST(3);   // votes done
 
   // ---- DMA stream ---------------------------------------------------------------------------------------------------------------
-  const int tps = (Lk32 + KVBLK - 1) / KVBLK;
-  const int ntile = tps * (nseg - (skip_seg >= 0 ? 1 : 0));
+  const int tps = MULTI ? tps_all : (Lk32 + KVBLK - 1) / KVBLK;
+  // (CARRY_IN with carry_n > 1: the finishing launch of a split tail has no tiles of its own)
+  const int ntile = (CARRY_IN && carry_n > 1) ? 0 : (MULTI ? t_hi - t_lo : tps);
   if (!PERSIST) dma_init(dma, kbase, vbase, k_seg_stride * 2, vt_seg_stride * 2, Lk32, nseg, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, skip_seg, /*k_rows_16x16=*/true);
-  int cur_tt = 0;
+  int cur_tt = MULTI ? t_lo % tps_all : 0;   // (a part of a split tail starts t_lo tiles into the walk)
   // valid kv rows from the start of the tile being consumed to the end of its segment: Lk - cur_tt * 64 (cur_tt steps inside the tile)
 
   // ---- LDS fragment addresses: per-lane VGPR + compile-time immediates ------------------------------------------------------------
@@ -543,22 +579,26 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
       for (int r = 0; r < 4; ++r) { qa.accO[dt][qt][r] = 0.f; qb2.accO[dt][qt][r] = 0.f; }
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) { qa.l[qt][0] = qa.l[qt][1] = 0.f; qb2.l[qt][0] = qb2.l[qt][1] = 0.f; }
-  if (CARRY_IN) {  // partial sums of an earlier launch over other kv segments (same grid, same workgroup -> same slots)
-    const float4* src = reinterpret_cast<const float4*>(raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW);
+  // raw slot of this workgroup: a whole launch: v; a split tail: (v - v_base) x parts + part
+  const size_t raw_slot = (size_t)(v - v_base) * (size_t)((raw_out || CARRY_IN) ? kv_split * carry_n : 1) + (size_t)kv_part;
+  if (CARRY_IN) {  // partial sums of an earlier launch over other kv segments (same grid, same workgroup -> same slots); carry_n > 1: of the k parts
+    for (int j = 0; j < carry_n; ++j) {
+      const float4* src = reinterpret_cast<const float4*>(raw + (raw_slot + (size_t)j) * WG_RAW + (size_t)wave * WAVE_RAW);
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
+      for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt)
+        for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          f32x4& acc = hf ? qb2.accO[dt][qt] : qa.accO[dt][qt];
-          const float4 w4 = src[((hf * 8 + dt) * 2 + qt) * 64 + lane];
-          acc[0] = w4.x; acc[1] = w4.y; acc[2] = w4.z; acc[3] = w4.w;
-          asm volatile("" : "+a"(acc));
-        }
-    const float* ls = raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
-    qa.l[0][0] = ls[lane]; qa.l[1][0] = ls[64 + lane];
-    qb2.l[0][0] = ls[128 + lane]; qb2.l[1][0] = ls[192 + lane];
+          for (int qt = 0; qt < 2; ++qt) {
+            f32x4& acc = hf ? qb2.accO[dt][qt] : qa.accO[dt][qt];
+            const float4 w4 = src[((hf * 8 + dt) * 2 + qt) * 64 + lane];
+            acc[0] += w4.x; acc[1] += w4.y; acc[2] += w4.z; acc[3] += w4.w;    // (the accumulators were zeroed above: the first part's sums exactly)
+            asm volatile("" : "+a"(acc));
+          }
+      const float* ls = raw + (raw_slot + (size_t)j) * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
+      qa.l[0][0] += ls[lane]; qa.l[1][0] += ls[64 + lane];
+      qb2.l[0][0] += ls[128 + lane]; qb2.l[1][0] += ls[192 + lane];
+    }
     if (SHIFT) {  // the carried sums were shifted by m(previous maxima) <= m: bring them to this launch's reference
       const float kmp = kmax2[(size_t)Bk * H + (size_t)total + bk * H + h];
       float f[4];
@@ -603,7 +643,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   PST(4);   // accumulators cleared, stream set up
   SegTab seg = {};
   if (MULTI) {   // entries 0 and 1 by hand, entry 2 on its way for the first tile's step
-    seg.tab = reinterpret_cast<const uint4*>(seg_tab);
+    seg.tab = reinterpret_cast<const uint4*>(seg_tab) + t_lo;
     seg.kb = uni(reinterpret_cast<const char*>(kbase));
     seg.vb = uni(reinterpret_cast<const char*>(vbase));
     seg.i = 0u;
@@ -636,7 +676,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     SB();
   }
 
-  if (SAMPLE && Lk32 >= KVBLK && wg_any_shift) {
+  if (SAMPLE && !is_part && Lk32 >= KVBLK && wg_any_shift) {   // (parts must agree on m without seeing each other's tiles: the Cauchy-Schwarz reference only)
     // ---- a LOWER bound of every row's maximum: its scores against the 64 keys of tile 0 (the MFMAs of one S phase, once per workgroup).
     // The row's true maximum lies in [m_s, U].  Where that interval is at most 176 wide, m = U - 96 covers it (nothing can overflow, the
     // maximum cannot underflow below 2^-80): guaranteed.  Where it is wider -- large gains on diffuse rows: U grows like 16 gamma, the
@@ -715,8 +755,8 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // trailing DMA lands before O staging reuses LDS; last PV MFMAs -> accumulator reads
   PST(9);   // drained
   float lsum[4] = {qa.l[0][0] + qa.l[0][1], qa.l[1][0] + qa.l[1][1], qb2.l[0][0] + qb2.l[0][1], qb2.l[1][0] + qb2.l[1][1]};
-  if (RAW_OUT) {  // partial result: accumulators and row-sum shares as they are, lane-major (1-KB stores)
-    float4* dst = reinterpret_cast<float4*>(raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW);
+  if (raw_out) {  // partial result: accumulators and row-sum shares as they are, lane-major (1-KB stores)
+    float4* dst = reinterpret_cast<float4*>(raw + raw_slot * WG_RAW + (size_t)wave * WAVE_RAW);
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -726,7 +766,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
           const f32x4 acc = hf ? qb2.accO[dt][qt] : qa.accO[dt][qt];
           dst[((hf * 8 + dt) * 2 + qt) * 64 + lane] = float4{acc[0], acc[1], acc[2], acc[3]};
         }
-    float* ls = raw + (size_t)v * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
+    float* ls = raw + raw_slot * WG_RAW + (size_t)wave * WAVE_RAW + 2 * 64 * 64;
 #pragma unroll
     for (int c = 0; c < 4; ++c) ls[c * 64 + lane] = lsum[c];
     if (SHIFT && tid == 0) wg_flags[v] = 0;  // partial sums left; underflow is judged on the final row sums (CARRY_IN launch)
@@ -915,18 +955,21 @@ static int seg_table(const uint32_t** out, int nseg, int skip, int Lk, int64_t k
 
 // The bounded launch of attention_w64q.hip's protocol on this kernel.  fl = that file's FLAGS value (bit 2 set); every other argument as
 // attn_w64q_kernel's.  Returns -1 for a combination this file does not instantiate.
+// `total` = the launch's grid (a whole call: q blocks x heads x batches; a piece of a split call: see v_base / kv_split / carry_n at the kernel).
 int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B,
                               int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e, int nseg, int64_t k_seg_stride,
-                              int64_t vt_seg_stride, const float* kmax2, int* wg_flags, float* raw, int skip_seg) {
+                              int64_t vt_seg_stride, const float* kmax2, int* wg_flags, float* raw, int skip_seg, int v_base, int kv_split,
+                              int carry_n, int part_from) {
+  if (part_from < 0) part_from = (int)total;
   const uint32_t* seg_tab = nullptr;
   if (fl & 64) {   // MULTI: the walk over the segments as a table (its offsets are relative to each workgroup's (batch, head) bases)
-    switch (fl) { case 4 | 64: case 6 | 64: case 2 | 4 | 32 | 64: case 4 | 64 | 128: case 6 | 64 | 128: case 2 | 4 | 32 | 64 | 128: break; default: return -1; }
+    switch (fl) { case 4 | 64: case 6 | 64: case 2 | 4 | 32 | 64: case 4 | 64 | 128: case 6 | 64 | 128: case 2 | 4 | 32 | 64 | 128: case 2 | 4 | 16 | 64 | 128: break; default: return -1; }
     if (int rc = seg_table(&seg_tab, nseg, skip_seg, (int)Lk, k_seg_stride * 2, vt_seg_stride * 2, (uint32_t)(H * 256), stream)) return rc;
   }
 #define W16N_CASE(FL)                                                                                                              \
   case FL:                                                                                                                         \
     hipLaunchKernelGGL((attn_w16n_kernel<FL>), dim3(total), dim3(256), 0, stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nqb, scale_log2e, \
-                       nseg, k_seg_stride, vt_seg_stride, kmax2, wg_flags, raw, skip_seg, seg_tab);                                \
+                       nseg, k_seg_stride, vt_seg_stride, kmax2, wg_flags, raw, skip_seg, seg_tab, v_base, kv_split, carry_n, part_from); \
     break;
   switch (fl) {
     W16N_CASE(4)
@@ -941,6 +984,8 @@ int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const 
     W16N_CASE(6 | 64 | 128)
     W16N_CASE(2 | 4 | 16 | 128)
     W16N_CASE(2 | 4 | 32 | 64 | 128)
+    W16N_CASE(2 | 4 | 16 | 64 | 128)   /* the parts of a split tail over segmented K / V^T (round 6) */
+    W16N_CASE(2 | 4 | 32 | 128)        /* ... and the finishing launch of a split tail over one segment */
     W16N_CASE(4 | 128 | 256)
     W16N_CASE(6 | 128 | 256)
 #ifdef W64Q_TIMING

@@ -759,7 +759,8 @@ extern "C" int wan_attention_debug_no_persist(int on) {
 // -DWAN_ATTN_NO_MI16 (the A/B library libwanhip_a32.so)
 int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B,
                               int Bk, int64_t Lq, int64_t Lk, int64_t ldv, int H, int nqb, float scale_log2e, int nseg, int64_t k_seg_stride,
-                              int64_t vt_seg_stride, const float* kmax2, int* wg_flags, float* raw, int skip_seg);
+                              int64_t vt_seg_stride, const float* kmax2, int* wg_flags, float* raw, int skip_seg, int v_base = 0, int kv_split = 1,
+                              int carry_n = 1, int part_from = -1);
 #ifndef WAN_ATTN_NO_MI16
 #define W16N_TRY(FL, NSEG, KS, VS, SKIP)                                                                                         \
   (wan_attention_w16n_launch(FL, (unsigned)total, stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, (int)nqb, scale_log2e, NSEG, KS, VS, \
@@ -767,6 +768,66 @@ int wan_attention_w16n_launch(int fl, unsigned total, hipStream_t stream, const 
 #else
 #define W16N_TRY(FL, NSEG, KS, VS, SKIP) false
 #endif
+
+// ---- the split tail of a bounded launch (round 6) ---------------------------------------------------------------------------------
+// A launch of n workgroups on c CUs runs floor(n / c) full rounds and then t = n mod c workgroups alone, each for a whole round (1.6 ms at
+// L = 75,600): the rank of a world of 8 launches 1,184 and 1,776 workgroups (4.6 and 6.9 rounds), a single GPU 23,680 (92.5).  The bounded
+// softmax's partial sums add exactly -- one reference shift per row, known before the first tile -- so the last round's q blocks are
+// attended as k parts each (behind the whole q blocks in the SAME launch: workgroups [floor(n / c) c, n) x k, part j over tiles [j T / k,
+// (j + 1) T / k), unnormalised sums to a scratch ring of the library's own) and a second launch adds the parts, normalises, judges and stores them like any workgroup: t k / c rounds of
+// 1 / k instead of one whole round.  k = the part count in 2..8 that saves most; taken when it saves at least a fifth of a round.
+// WAN_ATTN_SPLIT_TAIL=0 (A/B runs) or a missing scratch ring: the one-launch form.
+void* wan_scratch_ring_slot(int tag, size_t slot_bytes, int nslot, size_t need_bytes, hipStream_t stream);
+static int g_split_tail = [] { const char* e = getenv("WAN_ATTN_SPLIT_TAIL"); return e ? atoi(e) : 1; }();
+extern "C" int wan_attention_debug_split_tail(int on) {
+  const int old = g_split_tail;
+  g_split_tail = on ? 1 : 0;
+  return old;
+}
+static bool split_tail(int fl, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk, int64_t Lq, int64_t Lk, int64_t ldv,
+                       int H, int nqb, int64_t total, float scale_log2e, int nseg, int64_t k_seg_stride, int64_t vt_seg_stride,
+                       float* kmax_scratch, int* wg_flags, hipStream_t stream) {
+#ifdef WAN_ATTN_NO_MI16
+  return false;
+#else
+  if (!g_split_tail || (fl & 2) == 0) return false;                     // (q pre-scaled: the forward's calls)
+  static int cus_of[64] = {};
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+    if (cus_of[dev] == 0) {
+      int n = 0;
+      cus_of[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    cus = cus_of[dev];
+  } else {
+    (void)hipGetLastError();
+  }
+  const int64_t rounds = total / cus, t = total % cus;
+  const int64_t ntile = ((Lk + 63) / 64) * nseg;
+  if (rounds < 1 || t == 0 || ntile < 128) return false;
+  int best = 1;
+  double cost = 1.0;                                                     // rounds the tail takes
+  for (int kk = 2; kk <= 8; ++kk) {
+    const double ck = (double)((t * kk + cus - 1) / cus) / kk;
+    if (ck < cost - 1e-9) { cost = ck; best = kk; }
+  }
+  if (best == 1 || 1.0 - cost < 0.2) return false;
+  constexpr size_t WG_RAW_BYTES = (size_t)4 * 2 * (64 * 64 + 128) * 4;
+  const size_t need = (size_t)t * best * WG_RAW_BYTES;
+  float* raw = reinterpret_cast<float*>(wan_scratch_ring_slot(/*tag=*/7, (size_t)288 << 20, 2, need, stream));
+  if (raw == nullptr) return false;
+  const int fm = fl | 128;                                               // 6 | 128 (one segment) or 6 | 64 | 128
+  const int multi = fl & 64;
+  // ONE launch: the whole rounds' q blocks, then the last round's q blocks in `best` parts each (dispatched as the whole rounds drain)
+  if (wan_attention_w16n_launch(fm, (unsigned)(rounds * cus + t * best), stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nqb, scale_log2e, nseg, k_seg_stride,
+                                vt_seg_stride, kmax_scratch, wg_flags, raw, -1, 0, best, 1, (int)(rounds * cus)) != 0) return false;
+  // the finishing launch reads "the previous launch's maxima" behind the flags (the sequence-parallel protocol's slot): the same maxima
+  (void)hipMemcpyAsync(kmax_scratch + (size_t)Bk * H + (size_t)total, kmax_scratch, (size_t)Bk * H * 4, hipMemcpyDeviceToDevice, stream);
+  (void)wan_attention_w16n_launch(2 | 4 | 32 | 128 | multi, (unsigned)t, stream, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, nqb, scale_log2e, nseg, k_seg_stride,
+                                  vt_seg_stride, kmax_scratch, wg_flags, raw, -1, (int)(rounds * cus), 1, best);
+  return true;
+#endif
+}
 
 // called from attention.hip's dispatcher.  flags bit1: q is pre-scaled.  kmax_scratch: wan_attention_scratch_words() 4-byte
 // words (the K pre-pass maxima + one flag per workgroup), or NULL (tracking loop only)
@@ -849,6 +910,9 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
 #endif
     } else
 #endif
+    if (split_tail(fl, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, (int)nqb, total, scale_log2e, nseg, k_seg_stride, vt_seg_stride, kmax_scratch, wg_flags, stream)) {
+      // the bounded launch with its last partial round's q blocks as k parts each, and the launch that finishes their sums
+    } else
     if (W16N_TRY(fl | 128, nseg, k_seg_stride, vt_seg_stride, skip_seg)) {
       // ONE bounded launch: the shifted instantiation takes every workgroup (m = 0 inside the plain bound)
     } else

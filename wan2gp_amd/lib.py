@@ -150,6 +150,7 @@ SIGNATURES = {
     "wan_vae_debug_force_big": (c_int, [c_int]),
     "wan_vae_debug_no_halo": (c_int, [c_int]),
     "wan_attention_debug_no_persist": (c_int, [c_int]),
+    "wan_attention_debug_split_tail": (c_int, [c_int]),
     "wan_gemm_debug_force16s": (c_int, [c_int]),
     "wan_gemm_debug_force_tile_rows": (c_int, [c_int]),
     "wan_mx_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int, c_float, c_void_p]),
