@@ -59,6 +59,12 @@ int wan_rmsnorm_rope(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const wan_bf1
 int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const wan_bf16* wk,
                             const float* cos, const float* sin, int64_t rows, int64_t L, int64_t pos0,
                             int d, float eps, float q_scale, void* stream);
+/* wan_rmsnorm_rope_scaled on ONE tensor whose result goes to `pack` in the Ulysses exchange's send layout instead of in place (round 6):
+ * x [rows, d] with d = world x heads_per_rank x 128 is read only; pack [chunk j][world][rows][128 (h0_j+1 - h0_j)], h0_j = j heads_per_rank /
+ * head_chunks, receives what the in-place kernel followed by wan_permute16 (head_chunks 1) / wan_permute16_ex per chunk leaves there --
+ * the same values, bit for bit, without the extra pass (wan_dit_forward, WAN_SP_ULYSSES: the q and k re-packs). */
+int wan_rmsnorm_rope_pack(const wan_bf16* x, wan_bf16* pack, const wan_bf16* w, const float* cos, const float* sin, int64_t rows, int64_t L,
+                          int64_t pos0, int d, float eps, float scale, int world, int heads_per_rank, int head_chunks, void* stream);
 
 /* LayerNorm (no affine) + AdaLN modulate: out = bf16(bf16(LN(x) * bf16(1+scale)) + shift),
  * scale = bf16(mod[scale_idx] + e[b][scale_idx]), shift likewise.

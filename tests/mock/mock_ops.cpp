@@ -84,6 +84,10 @@ int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16* wq, const 
                             int64_t rows, int64_t L, int64_t pos0, int d, float eps, float q_scale, void*) {
   return rec("rmsnorm_rope", {q, k, wq, wk, cos, sin}, {rows, L, pos0, d}, {q_scale});
 }
+int wan_rmsnorm_rope_pack(const wan_bf16* x, wan_bf16* pack, const wan_bf16* w, const float* cos, const float* sin, int64_t rows, int64_t L,
+                          int64_t pos0, int d, float, float scale, int world, int heads_per_rank, int head_chunks, void*) {
+  return rec("rmsnorm_rope_pack", {x, pack, w, cos, sin}, {rows, L, pos0, d, world, heads_per_rank, head_chunks}, {scale});
+}
 int wan_ln_modulate(const wan_bf16* x, wan_bf16* out, const wan_bf16* mod, const wan_bf16* e, int n_mod, int shift_idx, int scale_idx,
                     int64_t rows, int64_t rows_per_batch, int d, float, void*) {
   return rec("ln_modulate", {x, out, mod, e}, {rows, d, n_mod, shift_idx, scale_idx, rows_per_batch});

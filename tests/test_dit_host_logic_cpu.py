@@ -116,6 +116,8 @@ def extents(call):
         return [(p[0], i[0] * i[1] * 2), (p[1], i[0] * i[1] * 2)]
     if name == "rmsnorm_rope":
         return [(q, i[0] * i[3] * 2) for q in p[:2] if q]
+    if name == "rmsnorm_rope_pack":
+        return [(p[0], i[0] * i[3] * 2), (p[1], i[0] * i[3] * 2)]
     if name == "attention":
         B, Bk, Lq, Lk, ldv, H = i[:6]
         return [(p[0], B * Lq * H * 256), (p[1], Bk * Lk * H * 256), (p[2], Bk * H * 128 * ldv * 2), (p[3], B * Lq * H * 256)]
@@ -428,9 +430,9 @@ def test_ulysses_call_order_layouts_and_buffer_lifetimes(mock, S):
         bk, bv, bq, w0, w1, w2, bo, wo = ev
         assert bk[4] == bq[4] == bo[4] == rows * Wd * 2 and bv[4] == S * Wd * Lp * 2              # bytes per PEER
         # in front of the k exchange: K projection, norm + RoPE at the shard's positions, the re-pack into the send buffer
-        pre = calls[bk[5] - 3:bk[5]]
-        assert [cl[0] for cl in pre] == ["gemm", "rmsnorm_rope", "permute16"] and pre[1][2][2] == Ll
-        assert pre[2][2][:3] == [rows, world, Wd * 2] and pre[2][1][1] == bk[2]                    # [rows][world][W] -> [world][rows][W] = what is sent
+        pre = calls[bk[5] - 2:bk[5]]
+        assert [cl[0] for cl in pre] == ["gemm", "rmsnorm_rope_pack"] and pre[1][2][2] == Ll       # (round 6: the norm kernel's stores carry the re-pack)
+        assert pre[1][2][:7] == [rows, Ll, Ll, d, world, Hn, 1] and pre[1][1][0] == pre[0][1][3] and pre[1][1][1] == bk[2]   # [rows][world][W] -> [world][rows][W] = what is sent
         # under the k exchange: the V^T projections (+ the block swap for S = 2); the v^T exchange sends what they left
         under_k = [cl[0] for cl in calls[bk[5]:bv[5]]]
         assert under_k == ["gemm"] * S + (["permute16"] if S > 1 else [])
@@ -440,8 +442,8 @@ def test_ulysses_call_order_layouts_and_buffer_lifetimes(mock, S):
         else:
             assert calls[bv[5] - 1][1][3] == bv[2]                                                    # S = 1: sent straight from the epilogue's image
         under_v = [cl[0] for cl in calls[bv[5]:bq[5]]]
-        assert under_v == ["gemm", "rmsnorm_rope", "permute16"]                                       # Q projection + norm + re-pack under the v^T exchange
-        assert calls[bq[5] - 1][1][1] == bq[2]
+        assert under_v == ["gemm", "rmsnorm_rope_pack"]                                               # Q projection + norm-with-re-pack under the v^T exchange
+        assert calls[bq[5] - 1][1][1] == bq[2] and calls[bq[5] - 1][2][4:7] == [world, Hn, 1]
         assert w0[2] == w1[2] == w2[2] == bq[5]                                                       # nothing between the q exchange and the waits
         att = calls[w2[2]]
         assert att[0] == "attention" and att[2][:10] == [world * S, S, Ll, Ll, Lp, Hn, world, rows * Wd, S * Wd * Lp, 1]
@@ -517,18 +519,21 @@ def test_ulysses_chunked_exchange_order_offsets_and_overlap(mock, S, world, chun
         E = {(e[0], e[1]): e for e in ev}
         bk0, bv0, bq0 = E[("begin", 0)], E[("begin", C)], E[("begin", 2 * C)]
         # what sits between the first three begins: the V projections + C v^T packs under k_0; the Q projection, its norm and C q packs under v_0
-        assert [cl[0] for cl in calls[bk0[5] - C:bk0[5]]] == ["permute16_ex"] * C and calls[bk0[5] - C - 1][0] == "rmsnorm_rope"
+        # (round 6: the K and Q norm kernels write the chunk-major send layout themselves -- one rmsnorm_rope_pack each, no re-pack passes)
+        assert [cl[0] for cl in calls[bk0[5] - 2:bk0[5]]] == ["gemm", "rmsnorm_rope_pack"]
         assert [cl[0] for cl in calls[bk0[5]:bv0[5]]] == ["gemm"] * S + ["permute16_ex"] * C
-        assert [cl[0] for cl in calls[bv0[5]:bq0[5]]] == ["gemm", "rmsnorm_rope"] + ["permute16_ex"] * C
-        packs_k, packs_v, packs_q = calls[bk0[5] - C:bk0[5]], calls[bv0[5] - C:bv0[5]], calls[bq0[5] - C:bq0[5]]
+        assert [cl[0] for cl in calls[bv0[5]:bq0[5]]] == ["gemm", "rmsnorm_rope_pack"]
+        pack_k, pack_q = calls[bk0[5] - 1], calls[bq0[5] - 1]
+        assert pack_k[2][:7] == [rows, Ll, (world - 1) * Ll, d, world, Hn, C] and pack_k[1][1] == bk0[2] and pack_k[3][0] == 1.0
+        assert pack_q[2][:7] == [rows, Ll, (world - 1) * Ll, d, world, Hn, C] and pack_q[1][1] == bq0[2] and pack_q[3][0] != 1.0     # the softmax scale folded into q
+        packs_v = calls[bv0[5] - C:bv0[5]]
         att_i = [i for i in range(bq0[5], len(calls)) if calls[i][0] == "attention"][:C]
         for k in range(C):
             Hc = h0[k + 1] - h0[k]
             Wc, o0 = Hc * 128, h0[k] * 128
             bk, bv, bq, bo = E[("begin", k)], E[("begin", C + k)], E[("begin", 2 * C + k)], E[("begin", 3 * C + k)]
-            # packs: columns [o0, o0 + Wc) of every rank's head group -> a [world][rows][Wc] block of its own at the chunk's offset
-            assert packs_k[k][2][:7] == [rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2] and packs_k[k][1][1] == bk[2] == bk0[2] + o0 * rows * world * 2
-            assert packs_q[k][2][:7] == [rows, world, Wc * 2, d * 2, Wd * 2, Wc * 2, rows * Wc * 2] and packs_q[k][1][1] == bq[2] == bq0[2] + o0 * rows * world * 2
+            # the chunk's [world][rows][Wc] block sits at the chunk's offset of the packed tensor (what the norm kernel's stores address)
+            assert bk[2] == bk0[2] + o0 * rows * world * 2 and bq[2] == bq0[2] + o0 * rows * world * 2
             assert packs_v[k][2][:7] == [S, world, Wc * Lp * 2, d * Lp * 2, Wd * Lp * 2, Wc * Lp * 2, S * Wc * Lp * 2]
             assert packs_v[k][1][1] == bv[2] == bv0[2] + o0 * Lp * S * world * 2
             assert bk[4] == bq[4] == bo[4] == rows * Wc * 2 and bv[4] == S * Wc * Lp * 2                       # bytes per PEER: the chunk's share

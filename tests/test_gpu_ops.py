@@ -77,6 +77,38 @@ def test_rmsnorm_rope_vs_reference_golden(ops):
     assert_bf16_close(q2, torch.from_numpy(gold["rms_bf16"]), what="rms only")
 
 
+@pytest.mark.parametrize("d,H,world,chunks,rope", [(5120, 40, 8, 2, True), (5120, 40, 4, 2, True), (5120, 40, 8, 1, False), (1536, 12, 4, 3, True),
+                                                  (1536, 12, 2, 1, True), (512, 4, 2, 2, True), (5120, 40, 2, 8, True)])
+def test_rmsnorm_rope_pack_equals_norm_then_repack(ops, d, H, world, chunks, rope):
+    """wan_rmsnorm_rope_pack (round 6): the norm kernel writes the Ulysses send layout itself -- bit for bit what the in-place kernel
+    followed by the per-chunk re-packs (wan_permute16_ex, the round-5 path) leaves: [rows][world][Hn 128] -> [chunk][world][rows][Wc].
+    Ragged row counts (not a multiple of the 4 rows per workgroup), both register forms (persistent at d = 5120, one row per wave
+    below), the softmax scale folded into q, positions offset by the shard's first token; the source rows stay untouched."""
+    g = torch.Generator().manual_seed(d + world + chunks)
+    S, Ll = 2, 37 if d == 5120 else 50
+    rows, Hn = S * Ll, H // world
+    x = (torch.randn(S, Ll, d, generator=g) * 1.7).to(BF)
+    w = (1 + 0.05 * torch.randn(d, generator=g)).to(BF)
+    pos0 = 3 * Ll
+    cos, sin = O.rope_tables((8, 4, 7))                       # 224 positions >= pos0 + Ll
+    freqs = (cu(cos), cu(sin)) if rope else None
+    scale = ops.attention_qscale()
+    ref = cu(x.clone())
+    ops.rmsnorm_rope_(ref, None, cu(w), None, freqs, L=Ll, pos0=pos0, q_scale=scale)
+    want = torch.empty(rows * d, dtype=BF, device="cuda")
+    C = min(chunks, Hn)
+    Wd = Hn * 128
+    for j in range(C):
+        h0, h1 = j * Hn // C, (j + 1) * Hn // C
+        wc, o0 = (h1 - h0) * 128, h0 * 128
+        ops.permute16_ex(ref.view(-1)[o0:], want[o0 * rows * world:], rows, world, wc * 2, d * 2, Wd * 2, wc * 2, rows * wc * 2)
+    src = cu(x.clone())
+    keep = src.clone()
+    got = ops.rmsnorm_rope_pack(src, cu(w), world, Hn, C, freqs, L=Ll, pos0=pos0, scale=scale)
+    assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+    assert torch.equal(src, keep)
+
+
 @pytest.mark.parametrize("d,H", [(1536, 12), (5120, 40), (256, 2)])
 def test_rmsnorm_rope_model_widths(ops, d, H):
     g = torch.Generator().manual_seed(d)

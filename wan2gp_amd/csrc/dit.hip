@@ -934,9 +934,9 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
         auto send_v = [&](int cch) { return a2a(C + cch, vs + o0(cch) * Lp * S * world, vr + o0(cch) * Lp * S * world, (int64_t)S * wc(cch) * Lp * 2); };
         auto send_q = [&](int cch) { return a2a(2 * C + cch, qs + o0(cch) * rows * world, qr + o0(cch) * rows * world, rows * wc(cch) * 2); };
         RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
-        RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
-        for (int cch = 0; cch < C; ++cch)   // [rows][world][Hn 128] -> [chunk][world][rows][Wc]
-          RC(wan_permute16_ex(b.k + o0(cch), ks + o0(cch) * rows * world, rows, world, wc(cch) * 2, (int64_t)d * 2, Wd * 2, wc(cch) * 2, rows * wc(cch) * 2, stream));
+        // RMSNorm + RoPE written straight into the send layout [rows][world][Hn 128] -> [chunk][world][rows][Wc] (round 6: the norm kernel's
+        // stores carry the re-pack; until then C wan_permute16_ex passes over the tensor followed it)
+        RC(wan_rmsnorm_rope_pack(b.k, ks, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, world, Hn, C, stream));
         RC(send_k(0));
         for (int s = 0; s < S; ++s)
           RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
@@ -947,9 +947,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
         RC(send_v(0));
         RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
                   Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
-        RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
-        for (int cch = 0; cch < C; ++cch)   // [rows][world][Hn 128] -> [chunk][world][rows][Wc]
-          RC(wan_permute16_ex(b.q + o0(cch), qs + o0(cch) * rows * world, rows, world, wc(cch) * 2, (int64_t)d * 2, Wd * 2, wc(cch) * 2, rows * wc(cch) * 2, stream));
+        RC(wan_rmsnorm_rope_pack(b.q, qs, Lw.self.nq, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), world, Hn, C, stream));
         RC(send_q(0));
         for (int cch = 1; cch < C; ++cch) {   // the later chunks, in the order their launches need them
           RC(send_k(cch));
@@ -977,8 +975,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
         }
       } else {
       RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
-      RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
-      RC(wan_permute16(b.k, ks, rows, world, Wd * 2, stream));
+      RC(wan_rmsnorm_rope_pack(b.k, ks, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, world, Hn, 1, stream));   // norm + RoPE + re-pack in one pass
       RC(a2a(0, ks, kr, rows * Wd * 2));
       for (int s = 0; s < S; ++s)
         RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
@@ -991,8 +988,7 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       RC(a2a(1, vsend, vr, (int64_t)S * Wd * Lp * 2));
       RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
                 Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
-      RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
-      RC(wan_permute16(b.q, qs, rows, world, Wd * 2, stream));
+      RC(wan_rmsnorm_rope_pack(b.q, qs, Lw.self.nq, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), world, Hn, 1, stream));
       RC(a2a(2, qs, qr, rows * Wd * 2));
       for (int w3 = 0; w3 < 3; ++w3) RC(a2a_wait(w3));
       {

@@ -48,18 +48,24 @@ __device__ __forceinline__ wan_f32x2 rope_pair(wan_f32x2 y, float c0, float c1, 
   return p + q;
 }
 
-template <int NCH, bool PERSIST, bool ROPE, bool FULL>
-__global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? 3 : 1)) void rmsnorm_rope_kernel(
+// SCATTER (round 6; the Ulysses exchange's send layout, csrc/dit.hip): the rows are written to `pack` head-group-major instead of in
+// place -- 16-byte chunk c of row r (head c >> 4 = dest rank w, head hl of its `hn`, head chunk j of `nchunk_h` with heads [h0_j, h0_j+1))
+// lands at pack + 16 (A[c] + r B[c]) bytes, A[c] = (128 h0_j rows world + w rows Wc_j + 128 (hl - h0_j)) / 8 + (c & 15), B[c] = Wc_j / 8,
+// Wc_j = 128 (h0_j+1 - h0_j): exactly what wan_permute16_ex leaves from the in-place result ([rows][world][hn 128] -> [chunk][world][rows][Wc]),
+// without the pass over the tensor (4 of a block's 8 re-packs: q and k).  The (A, B) pairs sit in LDS beside the norm weights.
+template <int NCH, bool PERSIST, bool ROPE, bool FULL, bool SCATTER = false>
+__global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? (SCATTER ? 2 : 3) : 1)) void rmsnorm_rope_kernel(   // (SCATTER: two address registers more than three waves per SIMD leave room for)
     bf16_t* __restrict__ q, bf16_t* __restrict__ k, const bf16_t* __restrict__ wq,
     const bf16_t* __restrict__ wk, const float* __restrict__ cosT, const float* __restrict__ sinT,
-    int64_t rows, int64_t L, int64_t pos0, int d, float eps, float q_scale) {
+    int64_t rows, int64_t L, int64_t pos0, int d, float eps, float q_scale, bf16_t* __restrict__ pack = nullptr, int world = 1, int hn = 1,
+    int nchunk_h = 1) {
   // FULL: d == NCH * 512 exactly (every Wan width): no per-chunk bounds test -- each test is an exec-masked branch that also keeps
   // the chunk's 64-bit address in a VGPR pair.  The wave index is made scalar so that the row pointers live in SGPRs and every
   // access is `base(SGPR) + lane * 16 (one VGPR) + immediate`: round 3's kernel spent ~40 VGPRs on addresses at d = 5120.
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
-  if (!PERSIST && row >= rows) return;
+  if (!PERSIST && !SCATTER && row >= rows) return;
   const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
   const float oscale = (blockIdx.y == 0) ? q_scale : 1.0f;  // q only: fp32 scale folded in front of the ONE bf16 rounding
   bf16_t* base = (blockIdx.y == 0 ? q : k);
@@ -74,13 +80,25 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? 3 : 1)) void r
   // share of wlds the live waves read (round 4 returned before the staging: the advisor's finding; tests/test_gpu_ops.py
   // test_rmsnorm_rope_persist_ragged_rows)
   __shared__ uint4 wlds[PERSIST ? NCH * 64 : 1];
+  __shared__ uint2 ptab[SCATTER ? NCH * 64 : 1];
   if (PERSIST) {
     for (int c = threadIdx.x; c < nchunk; c += 256) wlds[c] = *reinterpret_cast<const uint4*>(w + c * 8);
   }
+  if (SCATTER) {
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+      const int head = c >> 4, wr = head / hn, hl = head - wr * hn;
+      int j = 0;
+      while (j + 1 < nchunk_h && (int)((int64_t)(j + 1) * hn / nchunk_h) <= hl) ++j;
+      const int h0 = (int)((int64_t)j * hn / nchunk_h), h1 = (int)((int64_t)(j + 1) * hn / nchunk_h);
+      const int64_t wc = (int64_t)(h1 - h0) * 128;
+      const int64_t A = (int64_t)h0 * 128 * rows * world + (int64_t)wr * rows * wc + (int64_t)(hl - h0) * 128 + (c & 15) * 8;
+      ptab[c] = make_uint2((uint32_t)(A >> 3), (uint32_t)(wc >> 3));
+    }
+  }
   uint4 raw[NCH], nxt[NCH];
-  const bool alive = !PERSIST || row < rows;   // wave-uniform
+  const bool alive = (!PERSIST && !SCATTER) || row < rows;   // wave-uniform
   if (alive) load_row<NCH, FULL>(raw, base + row * (int64_t)d, lane, nchunk);
-  if (PERSIST) {
+  if (PERSIST || SCATTER) {
     __syncthreads();
     if (!alive) return;
   }
@@ -149,7 +167,12 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? 3 : 1)) void r
         }
         uint4 o;
         o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
-        *reinterpret_cast<uint4*>(x + c * 8) = o;
+        if (SCATTER) {
+          const uint2 ab = ptab[c];
+          *reinterpret_cast<uint4*>(pack + ((size_t)(ab.x + (uint32_t)row * ab.y) << 3)) = o;
+        } else {
+          *reinterpret_cast<uint4*>(x + c * 8) = o;
+        }
       }
       if (PERSIST) __builtin_amdgcn_sched_barrier(0);
     }
@@ -578,6 +601,41 @@ extern "C" int wan_rmsnorm_rope_scaled(wan_bf16* q, wan_bf16* k, const wan_bf16*
     else { if (full) RMSROPE_LAUNCH(false, true); else RMSROPE_LAUNCH(false, false); }
   });
 #undef RMSROPE_LAUNCH
+  WAN_LAUNCH_CHECK();
+  return 0;
+}
+
+// RMSNorm (+ RoPE) of ONE tensor written straight into the Ulysses exchange's send layout (see SCATTER at the kernel): x [rows, d] is read,
+// pack receives what wan_rmsnorm_rope_scaled(x) followed by the head-chunk re-packs (wan_permute16 / wan_permute16_ex, csrc/dit.hip) would
+// leave in it; x itself is not written.  d = world x heads_per_rank x 128; head_chunks <= heads_per_rank.
+extern "C" int wan_rmsnorm_rope_pack(const wan_bf16* x, wan_bf16* pack, const wan_bf16* w, const float* cos, const float* sin, int64_t rows,
+                                     int64_t L, int64_t pos0, int d, float eps, float scale, int world, int heads_per_rank, int head_chunks,
+                                     void* stream) {
+  WAN_REQUIRE(x && pack && w, "wan_rmsnorm_rope_pack: null pointer");
+  WAN_REQUIRE(d % 128 == 0 && d <= 8192 && world >= 1 && heads_per_rank >= 1 && (int64_t)world * heads_per_rank * 128 == d,
+              "wan_rmsnorm_rope_pack: d = %d must be world (%d) x heads per rank (%d) x 128", d, world, heads_per_rank);
+  WAN_REQUIRE(head_chunks >= 1 && head_chunks <= heads_per_rank, "wan_rmsnorm_rope_pack: %d head chunks for %d heads", head_chunks, heads_per_rank);
+  WAN_REQUIRE((cos == nullptr) == (sin == nullptr), "wan_rmsnorm_rope_pack: cos/sin must both be set or both null");
+  WAN_REQUIRE(rows < ((int64_t)1 << 31) && L > 0 && L < ((int64_t)1 << 31) && rows * (int64_t)d / 8 < ((int64_t)1 << 32),
+              "wan_rmsnorm_rope_pack: rows / L must fit 31 bits, rows x d / 8 32 bits");
+  WAN_REQUIRE(x != pack, "wan_rmsnorm_rope_pack: the packed rows cannot overwrite their source");
+  if (rows == 0) return 0;
+  const int nch = pick_nch(d);
+  bf16_t* xin = const_cast<bf16_t*>(x);
+#define RMSPACK_LAUNCH(ROPE_, FULL_)                                                                                                        \
+  do {                                                                                                                                      \
+    unsigned gx = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);                                                                 \
+    if (P) gx = persistent_blocks(rmsnorm_rope_kernel<NCH, P, ROPE_, FULL_, true>, rows);                                                    \
+    hipLaunchKernelGGL((rmsnorm_rope_kernel<NCH, P, ROPE_, FULL_, true>), dim3(gx, 1), dim3(256), 0, as_stream(stream), xin, (bf16_t*)nullptr, w, \
+                       (const bf16_t*)nullptr, cos, sin, rows, L, pos0, d, eps, scale, pack, world, heads_per_rank, head_chunks);            \
+  } while (0)
+  DISPATCH_NCH(nch, {
+    constexpr bool P = NCH >= 8;
+    const bool full = d == NCH * 512;
+    if (cos) { if (full) RMSPACK_LAUNCH(true, true); else RMSPACK_LAUNCH(true, false); }
+    else { if (full) RMSPACK_LAUNCH(false, true); else RMSPACK_LAUNCH(false, false); }
+  });
+#undef RMSPACK_LAUNCH
   WAN_LAUNCH_CHECK();
   return 0;
 }

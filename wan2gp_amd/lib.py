@@ -63,6 +63,8 @@ SIGNATURES = {
                                  c_int64, c_int, c_float, c_void_p]),
     "wan_rmsnorm_rope_scaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                         c_int64, c_int, c_float, c_float, c_void_p]),
+    "wan_rmsnorm_rope_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_float, c_float,
+                                      c_int, c_int, c_int, c_void_p]),
     "wan_ln_modulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64,
                                 c_int, c_float, c_void_p]),
     "wan_ln_affine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),

@@ -45,6 +45,24 @@ def rmsnorm_rope_(q, k, wq, wk, freqs=None, eps=1e-6, L=None, pos0=0, q_scale=1.
     return q, k
 
 
+def rmsnorm_rope_pack(x, w, world, heads_per_rank, head_chunks=1, freqs=None, eps=1e-6, L=None, pos0=0, scale=1.0):
+    """WanRMSNorm(x)[, RoPE] of one tensor written in the Ulysses exchange's send layout (wan_rmsnorm_rope_pack): x [B,L,d] bf16 (read only)
+    -> a flat bf16 tensor of x's size holding [chunk j][world][rows][128 (h0_j+1 - h0_j)], h0_j = j * heads_per_rank // head_chunks."""
+    _req(x, BF16, "x"); _req(w, BF16, "w")
+    d = w.numel()
+    rows = x.numel() // d
+    if L is None:
+        L = x.shape[1]
+    cos = sin = None
+    if freqs is not None:
+        cos, sin = freqs
+        _req(cos, torch.float32, "cos"); _req(sin, torch.float32, "sin")
+    out = torch.empty(x.numel(), dtype=BF16, device=x.device)
+    check(_L.load().wan_rmsnorm_rope_pack(ptr(x), ptr(out), ptr(w), ptr(cos), ptr(sin), rows, L, pos0, d, eps, float(scale), world, heads_per_rank,
+                                          head_chunks, stream_ptr()), "wan_rmsnorm_rope_pack")
+    return out
+
+
 def attention_scratch_words(B, Bk, Lq, H):
     """4-byte words of scratch attention(..., kmax_scratch=) needs: Bk*H maxima + one flag per 256-row workgroup."""
     return int(_L.load().wan_attention_scratch_words(B, Bk, Lq, H))
