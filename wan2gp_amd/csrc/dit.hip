@@ -626,424 +626,500 @@ static int text_cache_claim(wan_ctx* c, uint64_t key, int S, int TLx, int LDVx, 
 // with residual[s] != NULL either runs the block chain and leaves residual[s] = x_after_blocks - x_after_patch_embed
 // (should_calc[s] != 0), or skips the chain and adds the stored residual to its freshly embedded tokens.  The decision is
 // host logic (wan2gp_amd/skipcache.py); both arrays NULL = the plain forward.
-static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, const float* t_frames, const wan_bf16* const* context,
-                            const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
-                            int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
-                            void* poll_user, const int* should_calc, wan_bf16* const* residual, int n_vace,
-                            const float* const* vace_contexts, const float* vace_scales, const float* nag, const int* context_batches,
-                            const int* perturb_layers, int n_perturb, int x_id, void* stream, const float* t_dev = nullptr,
-                            uint64_t context_key = 0) {
-  WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
-  WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
-  WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
-  RC(resolve(c));
-  const wan_dit_config& g = c->cfg;
-  const int d = g.dim, ffn = g.ffn_dim, nh = g.num_heads, TL = g.text_len;
-  const int Hg = H / 2, Wg = W / 2;
-  const int64_t L = (int64_t)F * Hg * Wg;
-  const int world = sp ? sp->world : 1;
-  const bool ulysses = sp && world > 1 && sp->mode == WAN_SP_ULYSSES;
-  WAN_REQUIRE(world >= 1 && L % world == 0, "wan_dit_forward: L=%lld not divisible by %d sequence shards",
-              (long long)L, world);
-  const int64_t Ll = L / world;
-  const int64_t tok0 = sp ? sp->tok0 : 0;
-  WAN_REQUIRE(!ulysses || (sp->a2a_begin && sp->a2a_wait && g.num_heads % world == 0),
-              "wan_dit_forward: the Ulysses exchange needs its all-to-all hooks and a head count the world divides (%d heads, world %d)",
-              g.num_heads, world);
-  WAN_REQUIRE(!sp || (sp->tok_local == Ll && sp->tok0 == (int64_t)sp->rank * Ll &&
-                      (world == 1 || ulysses || (sp->gather_begin && sp->gather_wait))),
-              "wan_dit_forward: inconsistent sequence-parallel info");
-  WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
-  WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
-  // Normalized attention guidance (any2video.py:607-608): a stream whose context holds two prompts (positive ; negative) runs its
-  // text cross-attention against both and combines the results (text_cross_attention, model.py:260-292).  crow[s] = first row of
-  // stream s's context in the stacked context buffers, cb[s] = its prompts.
+// ---- WanModel.forward as stages (round 6: the review's item 8) -----------------------------------------------------------------------
+// Until round 5 this was ONE 590-line function whose nested lambdas carried every plan (bf16 / mixed / scaled fp8) x every self-attention
+// form (plain, all-gather, Ulysses one-exchange / chunked) x VACE x NAG x skip-layer guidance x the step-skipping caches.  The same
+// statements, in the same order, now sit in one method per stage of a `Forward` object: prepare (validation, geometry, the text cache,
+// the workspace), embed (patch / time / text embeddings), skip_prologue / skip_epilogue (TeaCache / MagCache residual bookkeeping),
+// vace_embed, run_blocks -> run_layer -> { norm1, self_attention_{plain, allgather, ulysses_chunked, ulysses_one}, o_projection,
+// cross_attention, ffn }, block_chain (skip-layer guidance cuts), head.  A Linear goes through linear() / linear_res32(): the plan is the
+// weight's (bf16 or fp8 bytes) and the context's (fp32 stream or not), not the stage's.  What held the split to 'nothing changes':
+// tools/compare_forward_launch_lists.py replays 122 scenarios (plans x stream counts x text cache x per-frame timesteps x step skipping x
+// skip-layer guidance x NAG x all-gather / Ulysses worlds of 2 and 4 x replayed launch lists) through the function before and after on
+// the recording mock: 10,502 launches and hook calls, argument for argument, 0 differ; tests/test_dit_host_logic_cpu.py asserts the order.
+namespace {
+struct B2 {   // the buffers a run of streams works on: the workspace's scratch from its base, token streams and text context offset to the run
+  bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg;
+  float* kmax;
+  float* raw;
+};
+struct Forward {
+  // ---- the call -----------------------------------------------------------------------------------------------------------------
+  wan_ctx* c; int S; const float* const* x; float t; const float* t_frames; const wan_bf16* const* context; const float* y; const float* cos;
+  const float* sin; float* const* outs; int F, H, W; void* workspace; int64_t workspace_bytes; const wan_sp_info* sp; wan_poll_fn poll;
+  void* poll_user; const int* should_calc; wan_bf16* const* residual; int n_vace; const float* const* vace_contexts; const float* vace_scales;
+  const float* nag; const int* context_batches; const int* perturb_layers; int n_perturb; int x_id; void* stream; const float* t_dev;
+  uint64_t context_key;
+  // ---- geometry, plan, workspace (prepare) -----------------------------------------------------------------------------------------
+  const wan_dit_config& g;
+  int d = 0, ffn = 0, nh = 0, TL = 0, Hg = 0, Wg = 0, world = 1, XT = 0, TLx = 0, LDVx = 0;
+  int64_t L = 0, Ll = 0, tok0 = 0, Lp = 0, sn = 0;
+  bool ulysses = false, any_nag = false, tc_hit = false, mx = false;
   int cb[8], crow[9];
-  bool any_nag = false;
-  crow[0] = 0;
-  for (int s = 0; s < S; ++s) {
-    cb[s] = context_batches ? context_batches[s] : 1;
-    WAN_REQUIRE(cb[s] == 1 || (cb[s] == 2 && nag && nag[0] > 1.f),
-                "wan_dit_forward: context_batches[%d] = %d (1, or 2 together with nag_scale > 1: model.py:260)", s, cb[s]);
-    any_nag = any_nag || cb[s] == 2;
-    crow[s + 1] = crow[s] + cb[s] * TL;
-  }
-  WAN_REQUIRE(!any_nag || ffn >= d, "wan_dit_forward: normalized attention guidance parks a result in the FFN buffer (ffn_dim >= dim)");
-  // (flf2v: the text branch's context is [the second image's 257 CLIP tokens ; the text tokens], see below)
-  const int XT = c->has_flf ? CLIP_TOK : 0;
-  const int TLx = TL + XT, LDVx = XT ? ((TLx + 63) / 64) * 64 : TL;
-  // ---- the text cache (wan_ctx::TextCache): served when every stream of the call runs the whole block chain on one prompt each ----
   wan_ctx::TextCache* tc = nullptr;
-  bool tc_hit = false;
-  {
-    bool all_calc = true;
-    for (int s = 0; should_calc != nullptr && s < S; ++s) all_calc = all_calc && should_calc[s] != 0;
-    if (context_key != 0 && !any_nag && n_perturb == 0 && all_calc) {
-      int slot = text_cache_find(c, context_key, S, TLx, LDVx);
-      tc_hit = slot >= 0;
-      if (slot < 0) slot = text_cache_claim(c, context_key, S, TLx, LDVx, (size_t)g.num_layers + c->vlayers.size(), (size_t)2 * S * TL * d);
-      if (slot >= 0) {
-        tc = &c->tcache[slot];
-        tc->last_use = ++c->tcache_clock;
+  Bufs b;
+  float* x32 = nullptr;
+  hipStream_t st = nullptr;
+  Q8 q8v;
+  const Q8* q8 = nullptr;
+  // ---- embeddings -------------------------------------------------------------------------------------------------------------------
+  int64_t tpf = 0;  // tokens per frame
+  int nt = 1, frame0 = 0;
+  // ---- VACE ---------------------------------------------------------------------------------------------------------------------------
+  int S_all = 0, n_on = 0, on_k[8];
+  bool vace = false;
+  // ---- the run of streams the block chain is on (run_blocks) and the block being enqueued (run_layer) -------------------------------------
+  int Sn = 0, s0 = 0;
+  int64_t rows = 0, rpb = 0;
+  B2 b2;
+  bf16_t* x_main = nullptr;
+  const float* e0f = nullptr;
+  bf16_t *vc[8], *vskip[8];
+  float* xf = nullptr;
+  bool fold = false;
+  int a1 = 0;
+
+  explicit Forward(wan_ctx* c_) : c(c_), g(c_->cfg) {}
+  bool calc(int s) const { return should_calc == nullptr || should_calc[s] != 0; }
+
+  int prepare() {
+    WAN_REQUIRE(c && x && context && cos && sin && outs && workspace, "wan_dit_forward: null argument");
+    WAN_REQUIRE(S >= 1 && S <= 8, "wan_dit_forward: S=%d streams unsupported", S);
+    WAN_REQUIRE(H % 2 == 0 && W % 2 == 0 && F >= 1, "wan_dit_forward: latent H,W must be even");
+    RC(resolve(c));
+    d = g.dim; ffn = g.ffn_dim; nh = g.num_heads; TL = g.text_len;
+    Hg = H / 2; Wg = W / 2;
+    L = (int64_t)F * Hg * Wg;
+    world = sp ? sp->world : 1;
+    ulysses = sp && world > 1 && sp->mode == WAN_SP_ULYSSES;
+    WAN_REQUIRE(world >= 1 && L % world == 0, "wan_dit_forward: L=%lld not divisible by %d sequence shards",
+                (long long)L, world);
+    Ll = L / world;
+    tok0 = sp ? sp->tok0 : 0;
+    WAN_REQUIRE(!ulysses || (sp->a2a_begin && sp->a2a_wait && g.num_heads % world == 0),
+                "wan_dit_forward: the Ulysses exchange needs its all-to-all hooks and a head count the world divides (%d heads, world %d)",
+                g.num_heads, world);
+    WAN_REQUIRE(!sp || (sp->tok_local == Ll && sp->tok0 == (int64_t)sp->rank * Ll &&
+                        (world == 1 || ulysses || (sp->gather_begin && sp->gather_wait))),
+                "wan_dit_forward: inconsistent sequence-parallel info");
+    WAN_REQUIRE((g.in_dim > g.out_dim) == (y != nullptr), "wan_dit_forward: y must be given iff in_dim > out_dim (model.py:1597)");
+    WAN_REQUIRE(!c->has_img || c->clip_set, "wan_dit_forward: this is a Wan2.1 i2v model -- call wan_dit_set_clip first (model.py:1547)");
+    // Normalized attention guidance (any2video.py:607-608): a stream whose context holds two prompts (positive ; negative) runs its
+    // text cross-attention against both and combines the results (text_cross_attention, model.py:260-292).  crow[s] = first row of
+    // stream s's context in the stacked context buffers, cb[s] = its prompts.
+    any_nag = false;
+    crow[0] = 0;
+    for (int s = 0; s < S; ++s) {
+      cb[s] = context_batches ? context_batches[s] : 1;
+      WAN_REQUIRE(cb[s] == 1 || (cb[s] == 2 && nag && nag[0] > 1.f),
+                  "wan_dit_forward: context_batches[%d] = %d (1, or 2 together with nag_scale > 1: model.py:260)", s, cb[s]);
+      any_nag = any_nag || cb[s] == 2;
+      crow[s + 1] = crow[s] + cb[s] * TL;
+    }
+    WAN_REQUIRE(!any_nag || ffn >= d, "wan_dit_forward: normalized attention guidance parks a result in the FFN buffer (ffn_dim >= dim)");
+    // (flf2v: the text branch's context is [the second image's 257 CLIP tokens ; the text tokens], see below)
+    XT = c->has_flf ? CLIP_TOK : 0;
+    TLx = TL + XT; LDVx = XT ? ((TLx + 63) / 64) * 64 : TL;
+    // ---- the text cache (wan_ctx::TextCache): served when every stream of the call runs the whole block chain on one prompt each ----
+    tc = nullptr;
+    tc_hit = false;
+    {
+      bool all_calc = true;
+      for (int s = 0; should_calc != nullptr && s < S; ++s) all_calc = all_calc && should_calc[s] != 0;
+      if (context_key != 0 && !any_nag && n_perturb == 0 && all_calc) {
+        int slot = text_cache_find(c, context_key, S, TLx, LDVx);
+        tc_hit = slot >= 0;
+        if (slot < 0) slot = text_cache_claim(c, context_key, S, TLx, LDVx, (size_t)g.num_layers + c->vlayers.size(), (size_t)2 * S * TL * d);
+        if (slot >= 0) {
+          tc = &c->tcache[slot];
+          tc->last_use = ++c->tcache_clock;
+        }
       }
     }
+    mx = c->mixed;
+    const int64_t need = carve_all(g, S, Ll, world, workspace, &b, c->vace_layers.empty() ? 0 : c->vace_max_ctx, c->any_fp8, F, mx);
+    // the mixed-precision plan serves the block chain of the t2v / i2v2_2 / ti2v models (also under sequence parallelism, NAG, skip-layer
+    // guidance, fp8 Linears); what keeps bf16 state of its own is refused rather than silently run in the other plan
+    bool any_residual = false;
+    for (int s = 0; residual != nullptr && s < S; ++s) any_residual = any_residual || residual[s] != nullptr;
+    (void)any_residual;   // (round 5: the step-skipping caches run in the mixed plan too -- their residual buffers then hold fp32 rows)
+    WAN_REQUIRE(!mx || (n_vace == 0 && c->vace_layers.empty() && !c->has_img),
+                "wan_dit_forward: the mixed-precision plan (fp32 time_projection / norm3 weights) does not serve VACE context blocks or the "
+                "Wan2.1 i2v CLIP branch");
+    x32 = reinterpret_cast<float*>(b.x);
+    WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
+                (long long)workspace_bytes, (long long)need);
+    WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
+    st = as_stream(stream);
+    Lp = b.Lp;
+    q8v.xq = b.xq; q8v.ws = b.qws; q8v.slot_bytes = b.q8_slot;
+    q8 = c->any_fp8 ? &q8v : nullptr;
+    sn = Ll * (int64_t)d;
+    return 0;
   }
-  Bufs b;
-  const bool mx = c->mixed;
-  const int64_t need = carve_all(g, S, Ll, world, workspace, &b, c->vace_layers.empty() ? 0 : c->vace_max_ctx, c->any_fp8, F, mx);
-  // the mixed-precision plan serves the block chain of the t2v / i2v2_2 / ti2v models (also under sequence parallelism, NAG, skip-layer
-  // guidance, fp8 Linears); what keeps bf16 state of its own is refused rather than silently run in the other plan
-  bool any_residual = false;
-  for (int s = 0; residual != nullptr && s < S; ++s) any_residual = any_residual || residual[s] != nullptr;
-  (void)any_residual;   // (round 5: the step-skipping caches run in the mixed plan too -- their residual buffers then hold fp32 rows)
-  WAN_REQUIRE(!mx || (n_vace == 0 && c->vace_layers.empty() && !c->has_img),
-              "wan_dit_forward: the mixed-precision plan (fp32 time_projection / norm3 weights) does not serve VACE context blocks or the "
-              "Wan2.1 i2v CLIP branch");
-  float* const x32 = reinterpret_cast<float*>(b.x);
-  WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
-              (long long)workspace_bytes, (long long)need);
-  WAN_REQUIRE((((uintptr_t)workspace) & 255) == 0, "wan_dit_forward: workspace must be 256-byte aligned");
-  hipStream_t st = as_stream(stream);
-  const int64_t Lp = b.Lp;
-  Q8 q8v;
-  q8v.xq = b.xq; q8v.ws = b.qws; q8v.slot_bytes = b.q8_slot;
-  const Q8* q8 = c->any_fp8 ? &q8v : nullptr;
 
-  // V^T padding columns must be finite for the PV MFMA (P = 0 there)
-  WAN_CHECK_HIP(hipMemsetAsync(b.vt, 0, (size_t)S * d * Lp * 2, st));
-  if (c->has_img) WAN_CHECK_HIP(hipMemsetAsync(b.cvtimg, 0, (size_t)d * CLIP_LDV * 2, st));
-
-  // ---- embeddings (model.py:1631,1731 ; :1815-1818 ; :1856) -----------------------------------------
-  for (int s = 0; s < S; ++s) {
-    if (mx) RC(wan_mx_patch_embed(x[s], y, c->pe_w, c->pe_b, x32 + (int64_t)s * Ll * d, g.out_dim, g.in_dim - g.out_dim, F, H, W, d, tok0, Ll, stream));
-    else RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, g.out_dim, g.in_dim - g.out_dim, F, H, W, d,
-                                  tok0, Ll, stream));
-  }
-  // Timesteps: one scalar, or one per latent frame (t_frames[F], HOST pointer): tokens of frame f are modulated by
-  // e0[f] (model.py:631-638, :856-862).  Under sequence parallelism a rank needs the rows of its own frames only, which
-  // requires shards made of whole frames.
-  const int64_t tpf = (int64_t)Hg * Wg;  // tokens per frame
-  int nt = 1, frame0 = 0;
-  if (t_frames != nullptr) {
-    WAN_REQUIRE(Ll % tpf == 0 && tok0 % tpf == 0, "wan_dit_forward: per-frame timesteps need sequence shards made of whole frames "
-                "(%lld tokens per shard, %lld per frame)", (long long)Ll, (long long)tpf);
-    nt = (int)(Ll / tpf);
-    frame0 = (int)(tok0 / tpf);
-  }
-  if (mx) {
-    // the time MLP and the projection under the fp32 lock (model.py:1815-1818 with an fp32 modulation dtype): e, e0 stay fp32
-    for (int f = 0; f < nt; ++f)
-      RC(wan_mx_sinusoid(t_frames ? t_frames[frame0 + f] : t, b.mx_sin + (int64_t)f * g.freq_dim, g.freq_dim, stream));
-    RC(wan_mx_linear_f32(b.mx_sin, c->mx_tm0w, c->mx_tm0b, b.mx_eh, nt, d, g.freq_dim, 0, stream));
-    RC(wan_mx_linear_f32(b.mx_eh, c->mx_tm2w, c->mx_tm2b, b.mx_e, nt, d, d, 1, stream));          // Linear(SiLU(.))
-    RC(wan_mx_linear_f32(b.mx_e, c->mx_tp1w, c->mx_tp1b, b.mx_e0, nt, 6 * d, d, 1, stream));       // time_projection = SiLU -> Linear
-    for (int s = 1; s < S && nt > 1; ++s)
-      WAN_CHECK_HIP(hipMemcpyAsync(b.mx_e0 + (int64_t)s * nt * 6 * d, b.mx_e0, (size_t)nt * 6 * d * 4, hipMemcpyDeviceToDevice, st));
-  }
-  for (int f = 0; f < nt && !mx; ++f) {
-    if (t_dev != nullptr && t_frames == nullptr) RC(wan_sinusoid(t_dev, b.sinus, 1, g.freq_dim, stream));
-    else RC(wan_sinusoid_val(t_frames ? t_frames[frame0 + f] : t, b.sinus + (int64_t)f * g.freq_dim, g.freq_dim, stream));
-  }
   // the time MLP: GEMV for one row of bf16 weights, the tile GEMM otherwise (several rows, or fp8 weights: one tensor)
-  auto tlin = [&](const bf16_t* A, const Lin& l, bf16_t* C, int N, int K) -> int {
-    if (l.w8 || nt > 1) return linear(A, l, C, nt, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8);
-    return wan_gemv_bf16(A, l.w, l.b, C, 1, N, K, stream);
-  };
-  if (!mx) {
-    RC(tlin(b.sinus, c->tm0, b.e_h, d, g.freq_dim));
-    RC(wan_act_bf16(b.e_h, b.e_h, (int64_t)nt * d, 1, stream));
-    RC(tlin(b.e_h, c->tm2, b.e, d, d));
-    RC(wan_act_bf16(b.e, b.e_s, (int64_t)nt * d, 1, stream));
-    RC(tlin(b.e_s, c->tp1, b.e0, 6 * d, d));
-    for (int s = 1; s < S && nt > 1; ++s)
-      WAN_CHECK_HIP(hipMemcpyAsync(b.e0 + (int64_t)s * nt * 6 * d, b.e0, (size_t)nt * 6 * d * 2, hipMemcpyDeviceToDevice, st));
-  }
-  for (int s = 0; s < S && !tc_hit; ++s) {  // one tensor per stream (fp8: one quantisation per tensor), [cb[s] * TL, text_dim]
-    RC(linear(context[s], c->te0, b.ctx_h + (int64_t)crow[s] * d, (int64_t)cb[s] * TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream, nullptr,
-              nullptr, nullptr, -1, 1, 0, q8, 1, s));
-  }
-  if (tc_hit) {
-    // (the text embedding feeds the blocks' cross-attention K / V Linears only: with those cached it is not needed)
-  } else if (!any_nag) {
-    RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
-  } else {
-    for (int s = 0; s < S; ++s)
-      RC(linear(b.ctx_h + (int64_t)crow[s] * d, c->te2, b.ctx_e + (int64_t)crow[s] * d, (int64_t)cb[s] * TL, d, d, WAN_EPI_NONE, stream,
-                nullptr, nullptr, nullptr, -1, 1, 0, q8, 1, s));
+  int tlin(const bf16_t* A, const Lin& l, bf16_t* C, int N, int K) {
+      if (l.w8 || nt > 1) return linear(A, l, C, nt, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8);
+      return wan_gemv_bf16(A, l.w, l.b, C, 1, N, K, stream);
   }
 
-  // flf2v: the text branch of the cross-attention sees [the second image's 257 CLIP tokens ; the text tokens] (model.py:472-473 splits
-  // the context at 257, img_emb produced 514).  Assembled once per forward in ctx_h (dead after the text embedding above): per
-  // stream TLx = 257 + text_len rows; the V^T images get a row pitch of TLx rounded up to 64, their pad columns zeroed here (the
-  // projection GEMMs of the blocks never write them).
-  if (XT) {
-    WAN_REQUIRE(!any_nag, "wan_dit_forward: normalized attention guidance is not served together with the flf2v CLIP context");
-    for (int s = 0; s < S && !tc_hit; ++s) {
-      bf16_t* dst = b.ctx_h + (int64_t)s * TLx * d;
-      WAN_CHECK_HIP(hipMemcpyAsync(dst, c->clip_ctx + (int64_t)CLIP_TOK * d, (size_t)CLIP_TOK * d * 2, hipMemcpyDeviceToDevice, st));
-      WAN_CHECK_HIP(hipMemcpyAsync(dst + (int64_t)XT * d, b.ctx_e + (int64_t)s * TL * d, (size_t)TL * d * 2, hipMemcpyDeviceToDevice, st));
+  int embed() {
+    // V^T padding columns must be finite for the PV MFMA (P = 0 there)
+    WAN_CHECK_HIP(hipMemsetAsync(b.vt, 0, (size_t)S * d * Lp * 2, st));
+    if (c->has_img) WAN_CHECK_HIP(hipMemsetAsync(b.cvtimg, 0, (size_t)d * CLIP_LDV * 2, st));
+
+    // ---- embeddings (model.py:1631,1731 ; :1815-1818 ; :1856) -----------------------------------------
+    for (int s = 0; s < S; ++s) {
+      if (mx) RC(wan_mx_patch_embed(x[s], y, c->pe_w, c->pe_b, x32 + (int64_t)s * Ll * d, g.out_dim, g.in_dim - g.out_dim, F, H, W, d, tok0, Ll, stream));
+      else RC(wan_patch_embed_range(x[s], y, c->pe_w, c->pe_b, b.x + (int64_t)s * Ll * d, 1, g.out_dim, g.in_dim - g.out_dim, F, H, W, d,
+                                    tok0, Ll, stream));
     }
-    WAN_CHECK_HIP(hipMemsetAsync(b.cvt, 0, (size_t)S * d * LDVx * 2, st));
-  }
-
-  // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups (rpb = rows in run_blocks)
-
-  // Self-attention: softmax scale * log2(e) is folded into q inside the fused RMSNorm+RoPE kernel (in front of q's single
-  // bf16 rounding); the attention kernel's score tiles then come out of the matrix pipe ready for exp2.
-
-  // ---- step-skipping: park x_before in the residual buffer, or add the stored residual and skip (model.py:1967-1990) ----
-  const int64_t sn = Ll * (int64_t)d;
-  auto calc = [&](int s) { return should_calc == nullptr || should_calc[s] != 0; };
-  for (int s = 0; s < S; ++s) {
-    if (residual == nullptr || residual[s] == nullptr) {
-      WAN_REQUIRE(calc(s), "wan_dit_forward: stream %d is skipped but has no residual buffer", s);
-      continue;
+    // Timesteps: one scalar, or one per latent frame (t_frames[F], HOST pointer): tokens of frame f are modulated by
+    // e0[f] (model.py:631-638, :856-862).  Under sequence parallelism a rank needs the rows of its own frames only, which
+    // requires shards made of whole frames.
+    tpf = (int64_t)Hg * Wg;  // tokens per frame
+    nt = 1; frame0 = 0;
+    if (t_frames != nullptr) {
+      WAN_REQUIRE(Ll % tpf == 0 && tok0 % tpf == 0, "wan_dit_forward: per-frame timesteps need sequence shards made of whole frames "
+                  "(%lld tokens per shard, %lld per frame)", (long long)Ll, (long long)tpf);
+      nt = (int)(Ll / tpf);
+      frame0 = (int)(tok0 / tpf);
     }
     if (mx) {
-      // the mixed-precision plan: x is the fp32 stream, so is the reference's previous_residual (torch.sub of two fp32 tensors,
-      // model.py:2044-2062); the caller's buffer holds sn floats.  1 * x + 1 * r is one fma: the fp32 sum, rounded once.
-      float* xs = x32 + s * sn;
-      float* rs = reinterpret_cast<float*>(residual[s]);
-      if (calc(s)) WAN_CHECK_HIP(hipMemcpyAsync(rs, xs, (size_t)sn * 4, hipMemcpyDeviceToDevice, st));
-      else {
-        const float* in2[2] = {xs, rs};
-        const float one2[2] = {1.f, 1.f};
-        RC(wan_lincomb(xs, 2, in2, one2, sn, stream));
+      // the time MLP and the projection under the fp32 lock (model.py:1815-1818 with an fp32 modulation dtype): e, e0 stay fp32
+      for (int f = 0; f < nt; ++f)
+        RC(wan_mx_sinusoid(t_frames ? t_frames[frame0 + f] : t, b.mx_sin + (int64_t)f * g.freq_dim, g.freq_dim, stream));
+      RC(wan_mx_linear_f32(b.mx_sin, c->mx_tm0w, c->mx_tm0b, b.mx_eh, nt, d, g.freq_dim, 0, stream));
+      RC(wan_mx_linear_f32(b.mx_eh, c->mx_tm2w, c->mx_tm2b, b.mx_e, nt, d, d, 1, stream));          // Linear(SiLU(.))
+      RC(wan_mx_linear_f32(b.mx_e, c->mx_tp1w, c->mx_tp1b, b.mx_e0, nt, 6 * d, d, 1, stream));       // time_projection = SiLU -> Linear
+      for (int s = 1; s < S && nt > 1; ++s)
+        WAN_CHECK_HIP(hipMemcpyAsync(b.mx_e0 + (int64_t)s * nt * 6 * d, b.mx_e0, (size_t)nt * 6 * d * 4, hipMemcpyDeviceToDevice, st));
+    }
+    for (int f = 0; f < nt && !mx; ++f) {
+      if (t_dev != nullptr && t_frames == nullptr) RC(wan_sinusoid(t_dev, b.sinus, 1, g.freq_dim, stream));
+      else RC(wan_sinusoid_val(t_frames ? t_frames[frame0 + f] : t, b.sinus + (int64_t)f * g.freq_dim, g.freq_dim, stream));
+    }
+    // the time MLP: GEMV for one row of bf16 weights, the tile GEMM otherwise (several rows, or fp8 weights: one tensor)
+    if (!mx) {
+      RC(tlin(b.sinus, c->tm0, b.e_h, d, g.freq_dim));
+      RC(wan_act_bf16(b.e_h, b.e_h, (int64_t)nt * d, 1, stream));
+      RC(tlin(b.e_h, c->tm2, b.e, d, d));
+      RC(wan_act_bf16(b.e, b.e_s, (int64_t)nt * d, 1, stream));
+      RC(tlin(b.e_s, c->tp1, b.e0, 6 * d, d));
+      for (int s = 1; s < S && nt > 1; ++s)
+        WAN_CHECK_HIP(hipMemcpyAsync(b.e0 + (int64_t)s * nt * 6 * d, b.e0, (size_t)nt * 6 * d * 2, hipMemcpyDeviceToDevice, st));
+    }
+    for (int s = 0; s < S && !tc_hit; ++s) {  // one tensor per stream (fp8: one quantisation per tensor), [cb[s] * TL, text_dim]
+      RC(linear(context[s], c->te0, b.ctx_h + (int64_t)crow[s] * d, (int64_t)cb[s] * TL, d, g.text_dim, WAN_EPI_GELU_TANH, stream, nullptr,
+                nullptr, nullptr, -1, 1, 0, q8, 1, s));
+    }
+    if (tc_hit) {
+      // (the text embedding feeds the blocks' cross-attention K / V Linears only: with those cached it is not needed)
+    } else if (!any_nag) {
+      RC(linear(b.ctx_h, c->te2, b.ctx_e, (int64_t)S * TL, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));
+    } else {
+      for (int s = 0; s < S; ++s)
+        RC(linear(b.ctx_h + (int64_t)crow[s] * d, c->te2, b.ctx_e + (int64_t)crow[s] * d, (int64_t)cb[s] * TL, d, d, WAN_EPI_NONE, stream,
+                  nullptr, nullptr, nullptr, -1, 1, 0, q8, 1, s));
+    }
+
+    // flf2v: the text branch of the cross-attention sees [the second image's 257 CLIP tokens ; the text tokens] (model.py:472-473 splits
+    // the context at 257, img_emb produced 514).  Assembled once per forward in ctx_h (dead after the text embedding above): per
+    // stream TLx = 257 + text_len rows; the V^T images get a row pitch of TLx rounded up to 64, their pad columns zeroed here (the
+    // projection GEMMs of the blocks never write them).
+    if (XT) {
+      WAN_REQUIRE(!any_nag, "wan_dit_forward: normalized attention guidance is not served together with the flf2v CLIP context");
+      for (int s = 0; s < S && !tc_hit; ++s) {
+        bf16_t* dst = b.ctx_h + (int64_t)s * TLx * d;
+        WAN_CHECK_HIP(hipMemcpyAsync(dst, c->clip_ctx + (int64_t)CLIP_TOK * d, (size_t)CLIP_TOK * d * 2, hipMemcpyDeviceToDevice, st));
+        WAN_CHECK_HIP(hipMemcpyAsync(dst + (int64_t)XT * d, b.ctx_e + (int64_t)s * TL * d, (size_t)TL * d * 2, hipMemcpyDeviceToDevice, st));
       }
-      continue;
+      WAN_CHECK_HIP(hipMemsetAsync(b.cvt, 0, (size_t)S * d * LDVx * 2, st));
     }
-    if (calc(s)) WAN_CHECK_HIP(hipMemcpyAsync(residual[s], b.x + s * sn, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
-    else RC(wan_add_bf16(b.x + s * sn, residual[s], b.x + s * sn, sn, stream));
+
+    // every stream of the joint pass shares t, hence e0: one "batch" for the modulation lookups (rpb = rows in run_blocks)
+
+    // Self-attention: softmax scale * log2(e) is folded into q inside the fused RMSNorm+RoPE kernel (in front of q's single
+    // bf16 rounding); the attention kernel's score tiles then come out of the matrix pipe ready for exp2.
+
+    // ---- step-skipping: park x_before in the residual buffer, or add the stored residual and skip (model.py:1967-1990) ----
+    return 0;
   }
 
-  // ---- VACE: c_k = vace_patch_embedding(vace_context[k]) for every context and stream (model.py:1905-1912) -------------------------
-  // Context k with scale 0 is switched off (model.py:622-626): no hint stream, no context block, no add.
-  const int S_all = S;
-  int n_on = 0;
-  int on_k[8];
-  if (n_vace > 0) {
-    WAN_REQUIRE(!c->vace_layers.empty(), "wan_dit_forward: vace_context given but the model has no VACE blocks (wan_dit_set_vace_layers)");
-    WAN_REQUIRE(vace_contexts && vace_scales && n_vace <= c->vace_max_ctx && n_vace <= 8,
-                "wan_dit_forward: %d VACE contexts, the workspace holds %d (wan_dit_set_vace_contexts)", n_vace, c->vace_max_ctx);
-    for (int k = 0; k < n_vace; ++k) {
-      if (vace_scales[k] == 0.f) continue;
-      WAN_REQUIRE(vace_contexts[k] != nullptr, "wan_dit_forward: vace_contexts[%d] is null", k);
-      bf16_t* vck = b.vc + (int64_t)k * S * sn;
-      RC(wan_patch_embed_range(vace_contexts[k], nullptr, c->vpe_w, c->vpe_b, vck, 1, c->vace_in_dim, 0, F, H, W, d, tok0, Ll, stream));
-      for (int s = 1; s < S; ++s)
-        WAN_CHECK_HIP(hipMemcpyAsync(vck + s * sn, vck, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
-      on_k[n_on++] = k;
+  int skip_prologue() {
+    // ---- step-skipping: park x_before in the residual buffer, or add the stored residual and skip (model.py:1967-1990) ----
+    for (int s = 0; s < S; ++s) {
+      if (residual == nullptr || residual[s] == nullptr) {
+        WAN_REQUIRE(calc(s), "wan_dit_forward: stream %d is skipped but has no residual buffer", s);
+        continue;
+      }
+      if (mx) {
+        // the mixed-precision plan: x is the fp32 stream, so is the reference's previous_residual (torch.sub of two fp32 tensors,
+        // model.py:2044-2062); the caller's buffer holds sn floats.  1 * x + 1 * r is one fma: the fp32 sum, rounded once.
+        float* xs = x32 + s * sn;
+        float* rs = reinterpret_cast<float*>(residual[s]);
+        if (calc(s)) WAN_CHECK_HIP(hipMemcpyAsync(rs, xs, (size_t)sn * 4, hipMemcpyDeviceToDevice, st));
+        else {
+          const float* in2[2] = {xs, rs};
+          const float one2[2] = {1.f, 1.f};
+          RC(wan_lincomb(xs, 2, in2, one2, sn, stream));
+        }
+        continue;
+      }
+      if (calc(s)) WAN_CHECK_HIP(hipMemcpyAsync(residual[s], b.x + s * sn, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
+      else RC(wan_add_bf16(b.x + s * sn, residual[s], b.x + s * sn, sn, stream));
     }
+    return 0;
   }
-  const bool vace = n_on > 0;
 
-  // the block chain over streams [s0, s0 + Sn): every scratch buffer is used from its base, only the token stream and the
-  // text context are offset (maximal runs of computing streams; all of them in the plain forward)
-  // layers [l0, l1) of the block chain over streams [s0, s0 + Sn)
-  auto run_blocks = [&](const int s0, const int Sn, const int l0, const int l1) -> int {
-  const int S = Sn;
-  const int64_t rows = (int64_t)Sn * Ll, rpb = nt > 1 ? tpf : rows;
-  struct { bf16_t *x, *xm, *q, *k, *vt, *h, *ck, *cvt, *ctx_e, *e0, *kfull, *vtfull, *ckimg, *cvtimg; float* kmax; float* raw; } b2 = {
-      mx ? reinterpret_cast<bf16_t*>(x32 + s0 * sn) : b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, XT ? b.ctx_h + (int64_t)s0 * TLx * d : b.ctx_e + (int64_t)crow[s0] * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
-  bf16_t* const x_main = mx ? reinterpret_cast<bf16_t*>(x32 + s0 * sn) : b.x + s0 * sn;
-  const float* const e0f = b.mx_e0;   // (the outer Bufs: captured before `b` is shadowed below)
-  // hint streams of this run, per active context; vskip[k] doubles as the swap buffer of before_proj
-  bf16_t *vc[8], *vskip[8];
-  for (int j = 0; j < n_on; ++j) {
-    vc[j] = b.vc + ((int64_t)on_k[j] * S_all + s0) * sn;
-    vskip[j] = b.vskip + ((int64_t)on_k[j] * S_all + s0) * sn;
+  int vace_embed() {
+    // ---- VACE: c_k = vace_patch_embedding(vace_context[k]) for every context and stream (model.py:1905-1912) -------------------------
+    // Context k with scale 0 is switched off (model.py:622-626): no hint stream, no context block, no add.
+    S_all = S;
+    n_on = 0;
+    if (n_vace > 0) {
+      WAN_REQUIRE(!c->vace_layers.empty(), "wan_dit_forward: vace_context given but the model has no VACE blocks (wan_dit_set_vace_layers)");
+      WAN_REQUIRE(vace_contexts && vace_scales && n_vace <= c->vace_max_ctx && n_vace <= 8,
+                  "wan_dit_forward: %d VACE contexts, the workspace holds %d (wan_dit_set_vace_contexts)", n_vace, c->vace_max_ctx);
+      for (int k = 0; k < n_vace; ++k) {
+        if (vace_scales[k] == 0.f) continue;
+        WAN_REQUIRE(vace_contexts[k] != nullptr, "wan_dit_forward: vace_contexts[%d] is null", k);
+        bf16_t* vck = b.vc + (int64_t)k * S * sn;
+        RC(wan_patch_embed_range(vace_contexts[k], nullptr, c->vpe_w, c->vpe_b, vck, 1, c->vace_in_dim, 0, F, H, W, d, tok0, Ll, stream));
+        for (int s = 1; s < S; ++s)
+          WAN_CHECK_HIP(hipMemcpyAsync(vck + s * sn, vck, (size_t)sn * 2, hipMemcpyDeviceToDevice, st));
+        on_k[n_on++] = k;
+      }
+    }
+    vace = n_on > 0;
+    return 0;
   }
-  auto& b = b2;
-  // one WanAttentionBlock (model.py:575-724) on the token streams at b.x, with the weights Lw
-  // mixed-precision plan: a Linear whose bf16 result is added to the fp32 stream -- x += y * gate.  bf16 weights: ONE launch, the update
-  // in the GEMM's epilogue (wan_gemm_bf16_res32; round 5); scaled-fp8 weights: the Linear into xm, then the separate pass
-  auto linear_res32 = [&](const bf16_t* A, const Lin& l, float* xf, bf16_t* tmp, int64_t M, int N, int K, const bf16_t* mod, const float* e0g,
-                          int gate, int64_t rpb_, int nt_) -> int {
-    if (l.w8 == nullptr) return wan_gemm_bf16_res32(A, K, l.w, l.b, xf, tmp, M, N, K, mod, e0g, 6, gate, rpb_, stream);
-    RC(linear(A, l, tmp, M, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, nt_));
-    return wan_mx_gated_residual(xf, tmp, gate >= 0 ? mod : nullptr, gate >= 0 ? e0g : nullptr, 6, gate, M, rpb_, N, stream);
-  };
-  auto run_layer = [&](const Layer& Lw, const int li) -> int {   // li: the block's index in the text cache (main blocks, then VACE context blocks)
+
+    // one WanAttentionBlock (model.py:575-724) on the token streams at b.x, with the weights Lw
+    // mixed-precision plan: a Linear whose bf16 result is added to the fp32 stream -- x += y * gate.  bf16 weights: ONE launch, the update
+    // in the GEMM's epilogue (wan_gemm_bf16_res32; round 5); scaled-fp8 weights: the Linear into xm, then the separate pass
+  int linear_res32(const bf16_t* A, const Lin& l, float* xf_, bf16_t* tmp, int64_t M, int N, int K, const bf16_t* mod, const float* e0g, int gate,
+                   int64_t rpb_, int nt_) {
+      if (l.w8 == nullptr) return wan_gemm_bf16_res32(A, K, l.w, l.b, xf_, tmp, M, N, K, mod, e0g, 6, gate, rpb_, stream);
+      RC(linear(A, l, tmp, M, N, K, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, nt_));
+      return wan_mx_gated_residual(xf_, tmp, gate >= 0 ? mod : nullptr, gate >= 0 ? e0g : nullptr, 6, gate, M, rpb_, N, stream);
+  }
+
+  int zero_slots() {   // (the streams' quantisation slots, in front of the producer that leaves an abs-max there)
+    WAN_CHECK_HIP(hipMemsetAsync(q8->ws, 0, (size_t)Sn * 64 * sizeof(float), st));
+    return 0;
+  }
+
+  int norm1(const Layer& Lw) {
+    auto& b = b2;
     // -- self attention (model.py:632-660) --
     // mixed-precision plan (mx): b.x holds fp32 rows; modulate / norm3 / the gated residuals are the fp32 kernels of mixed_ops.hip, each
     // Linear that ended in a fused residual epilogue writes its bf16 result to xm (dead at those three points) and a separate pass adds it
-    float* const xf = reinterpret_cast<float*>(b.x);
+    xf = reinterpret_cast<float*>(b.x);
     // scaled-fp8 checkpoints (round 5): the LayerNorms in front of fp8 Linears (norm1 -> q / k / v, norm3 -> cross q, norm2 -> ffn.0) and
     // ffn.0's GELU epilogue (-> ffn.2) leave the abs-max of what they write in the streams' quantisation slots, so those four of a block's six
     // activation quantisations run without their abs-max pass (slot word 1: a LayerNorm's output, word 2: the GELU output; zeroed here, in
     // front of the producer -- every earlier user of the slots has been enqueued).  `a1` is handed to every consumer: the one that quantises
     // (reuse == false) takes the short path, the others share its slots as before.
     static const bool no_fold = [] { const char* e = getenv("WAN_FP8_NO_FOLD"); return e && e[0] == '1'; }();   // A/B runs: the two-pass quantisation everywhere
-    const bool fold = q8 != nullptr && !mx && !no_fold;
-    const int a1 = fold ? 1 : 0;
-    auto zero_slots = [&]() -> int {
-      WAN_CHECK_HIP(hipMemsetAsync(q8->ws, 0, (size_t)S * 64 * sizeof(float), st));
-      return 0;
-    };
+    fold = q8 != nullptr && !mx && !no_fold;
+    a1 = fold ? 1 : 0;
     if (mx) RC(wan_mx_ln_modulate(xf, b.xm, Lw.mod, e0f, 6, 0, 1, rows, rpb, d, g.eps, stream));
     else if (fold) {
       RC(zero_slots());
       RC(wan_ln_modulate_amax(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, q8->ws, Ll, stream));
     } else RC(wan_ln_modulate(b.x, b.xm, Lw.mod, b.e0, 6, 0, 1, rows, rpb, d, g.eps, stream));
-    if (ulysses) {
-      // Ulysses (round 4): re-shard q, k, v from "my tokens, all heads" to "all tokens, my heads" by all-to-all, attend the whole
-      // sequence for nh / world heads in ONE launch, bring o back the same way.  Order K, V, Q as below: the k exchange runs under
-      // the V projection, the v exchange under the Q projection + norm; q and o are exposed.  Layouts (W = 128 nh / world):
-      //   send  [world][S][Ll][W]      the projection's [S Ll][d] rows re-packed head-group-major (wan_permute16: one pass)
-      //   recv  [world][S][Ll][W]      = world x S query "batches" of Ll rows for the attention kernel (q batch b attends K / V^T
-      //                                batch b mod S) and world K segments (seg stride S Ll W) -- the all-gather form's layout
-      //   v^T   [world][S][W][Lp]      the transposed epilogue's [S][d][Lp] rows ARE head-group-major per stream: blocks swapped
-      //                                [S][world] -> [world][S] (nothing to do for S = 1); received = world V^T segments
-      //   o     the attention writes [world][S][Ll][W] = the send layout of the way back; received and un-permuted to [S Ll][d]
-      const int Hn = nh / world;
-      const int64_t Wd = (int64_t)Hn * 128, blkq = rows * d, blkv = (int64_t)S * d * Lp;
-      bf16_t *ks = b.kfull, *kr = b.kfull + blkq, *qs = b.kfull + 2 * blkq, *qr = b.kfull + 3 * blkq;
-      bf16_t *vs = b.vtfull, *vr = b.vtfull + blkv;
-      auto a2a = [&](int which, const bf16_t* send, bf16_t* recv, int64_t bytes) -> int {
-        if (sp->a2a_begin(sp->user, which, send, recv, bytes, stream)) {
-          wan_set_error("wan_dit_forward: all-to-all %d (C head chunks: k 0.., v^T C.., q 2C.., o 3C..) failed", which);
-          return 3;
-        }
-        return 0;
-      };
-      auto a2a_wait = [&](int which) -> int {
-        if (sp->a2a_wait(sp->user, which, stream)) {
-          wan_set_error("wan_dit_forward: all-to-all %d failed", which);
-          return 3;
-        }
-        return 0;
-      };
-      // Round 5: the rank's Hn heads in C chunks (wan_sp_info.a2a_chunks; 1 = the round-4 form below).  EVERY tensor travels per chunk,
-      // chunk-major --
-      //   k, q recv / o send  [chunk][world][S][Ll][Wc]        v^T recv  [chunk][world][S][Wc][Lp]        (chunk c: heads [h0_c, h1_c), Wc = 128 (h1_c - h0_c))
-      // -- so a chunk's launch sees exactly the round-4 layout with H = h1_c - h0_c heads (segment strides rows Wc / S Wc Lp): the same
-      // kernel on the same rows of the same heads, results bit-identical to C = 1 (tests/test_gpu_sp.py).  What the schedule buys: chunk
-      // 0's k, v^T and q leave FIRST (k_0 under the V projection, v_0 under the Q projection, then q_0), so the first launch waits for
-      // one chunk of q, not for three whole tensors queued on the same links; the other chunks' k / v^T / q flow under chunk 0's launch,
-      // chunk c's o returns under chunk c + 1's launch: exposed are q_0 and the last o chunk.  Slots: k_c = c, v_c = C + c, q_c = 2 C + c,
-      // o_c = 3 C + c (C = 1: the round-4 numbering 0..3).
-      int C = sp->a2a_chunks < 1 ? 1 : sp->a2a_chunks;
-      if (C > Hn) C = Hn;
-      if (C > WAN_SP_MAX_CHUNKS) C = WAN_SP_MAX_CHUNKS;
-      if (C > 1) {
-        int h0[WAN_SP_MAX_CHUNKS + 1];
-        for (int cch = 0; cch <= C; ++cch) h0[cch] = (int)((int64_t)cch * Hn / C);
-        auto wc = [&](int cch) { return (int64_t)(h0[cch + 1] - h0[cch]) * 128; };
-        auto o0 = [&](int cch) { return (int64_t)h0[cch] * 128; };
-        auto send_k = [&](int cch) { return a2a(cch, ks + o0(cch) * rows * world, kr + o0(cch) * rows * world, rows * wc(cch) * 2); };
-        auto send_v = [&](int cch) { return a2a(C + cch, vs + o0(cch) * Lp * S * world, vr + o0(cch) * Lp * S * world, (int64_t)S * wc(cch) * Lp * 2); };
-        auto send_q = [&](int cch) { return a2a(2 * C + cch, qs + o0(cch) * rows * world, qr + o0(cch) * rows * world, rows * wc(cch) * 2); };
-        RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
-        // RMSNorm + RoPE written straight into the send layout [rows][world][Hn 128] -> [chunk][world][rows][Wc] (round 6: the norm kernel's
-        // stores carry the re-pack; until then C wan_permute16_ex passes over the tensor followed it)
-        RC(wan_rmsnorm_rope_pack(b.k, ks, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, world, Hn, C, stream));
-        RC(send_k(0));
-        for (int s = 0; s < S; ++s)
-          RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                    nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
-        for (int cch = 0; cch < C; ++cch)   // [S][world][Hn 128][Lp] -> [chunk][world][S][Wc][Lp]
-          RC(wan_permute16_ex(b.vt + o0(cch) * Lp, vs + o0(cch) * Lp * S * world, S, world, wc(cch) * Lp * 2, (int64_t)d * Lp * 2, Wd * Lp * 2,
-                              wc(cch) * Lp * 2, (int64_t)S * wc(cch) * Lp * 2, stream));
-        RC(send_v(0));
-        RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
-                  Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
-        RC(wan_rmsnorm_rope_pack(b.q, qs, Lw.self.nq, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), world, Hn, C, stream));
-        RC(send_q(0));
-        for (int cch = 1; cch < C; ++cch) {   // the later chunks, in the order their launches need them
-          RC(send_k(cch));
-          RC(send_v(cch));
-          RC(send_q(cch));
-        }
-        for (int cch = 0; cch < C; ++cch) {
-          const int Hc = h0[cch + 1] - h0[cch];
-          RC(a2a_wait(cch));
-          RC(a2a_wait(C + cch));
-          RC(a2a_wait(2 * C + cch));
-          {
-            ProfScope ps(PROF_SELF_ATTN, st);
-            RC(wan_attention_bounded(qr + o0(cch) * rows * world, kr + o0(cch) * rows * world, vr + o0(cch) * Lp * S * world, ks + o0(cch) * rows * world,
-                                     world * S, S, Ll, Ll, Lp, Hc, world, rows * wc(cch), (int64_t)S * wc(cch) * Lp, 1, b.kmax, stream));
-          }
-          if (g_prof_on && g_prof_declined != nullptr && Ll * (int64_t)world > 2048)
-            RC(wan_attention_count_declined(b.kmax, world * S, S, Ll, Hc, g_prof_declined, stream));
-          // o chunk c over the dead k send chunk (its exchange was waited for above), back over the dead q send chunk, while the next launch runs
-          RC(a2a(3 * C + cch, ks + o0(cch) * rows * world, qs + o0(cch) * rows * world, rows * wc(cch) * 2));
-        }
-        for (int cch = 0; cch < C; ++cch) {   // [chunk][world][rows][Wc] -> [rows][world][Hn 128]
-          RC(a2a_wait(3 * C + cch));
-          RC(wan_permute16_ex(qs + o0(cch) * rows * world, b.q + o0(cch), world, rows, wc(cch) * 2, rows * wc(cch) * 2, wc(cch) * 2, Wd * 2, (int64_t)d * 2, stream));
-        }
-      } else {
-      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
-      RC(wan_rmsnorm_rope_pack(b.k, ks, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, world, Hn, 1, stream));   // norm + RoPE + re-pack in one pass
-      RC(a2a(0, ks, kr, rows * Wd * 2));
-      for (int s = 0; s < S; ++s)
-        RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
-      const bf16_t* vsend = b.vt;
-      if (S > 1) {
-        RC(wan_permute16(b.vt, vs, S, world, Wd * Lp * 2, stream));
-        vsend = vs;
-      }
-      RC(a2a(1, vsend, vr, (int64_t)S * Wd * Lp * 2));
-      RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
-                Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
-      RC(wan_rmsnorm_rope_pack(b.q, qs, Lw.self.nq, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), world, Hn, 1, stream));
-      RC(a2a(2, qs, qr, rows * Wd * 2));
-      for (int w3 = 0; w3 < 3; ++w3) RC(a2a_wait(w3));
+    return 0;
+  }
+
+  int self_attention_ulysses(const Layer& Lw) {
+    const int S = Sn;
+    auto& b = b2;
+    // Ulysses (round 4): re-shard q, k, v from "my tokens, all heads" to "all tokens, my heads" by all-to-all, attend the whole
+    // sequence for nh / world heads in ONE launch, bring o back the same way.  Order K, V, Q as below: the k exchange runs under
+    // the V projection, the v exchange under the Q projection + norm; q and o are exposed.  Layouts (W = 128 nh / world):
+    //   send  [world][S][Ll][W]      the projection's [S Ll][d] rows re-packed head-group-major (wan_permute16: one pass)
+    //   recv  [world][S][Ll][W]      = world x S query "batches" of Ll rows for the attention kernel (q batch b attends K / V^T
+    //                                batch b mod S) and world K segments (seg stride S Ll W) -- the all-gather form's layout
+    //   v^T   [world][S][W][Lp]      the transposed epilogue's [S][d][Lp] rows ARE head-group-major per stream: blocks swapped
+    //                                [S][world] -> [world][S] (nothing to do for S = 1); received = world V^T segments
+    //   o     the attention writes [world][S][Ll][W] = the send layout of the way back; received and un-permuted to [S Ll][d]
+    const int Hn = nh / world;
+    const int64_t Wd = (int64_t)Hn * 128, blkq = rows * d, blkv = (int64_t)S * d * Lp;
+    bf16_t *ks = b.kfull, *kr = b.kfull + blkq, *qs = b.kfull + 2 * blkq, *qr = b.kfull + 3 * blkq;
+    bf16_t *vs = b.vtfull, *vr = b.vtfull + blkv;
+    // Round 5: the rank's Hn heads in C chunks (wan_sp_info.a2a_chunks; 1 = the round-4 form below).  EVERY tensor travels per chunk,
+    // chunk-major --
+    //   k, q recv / o send  [chunk][world][S][Ll][Wc]        v^T recv  [chunk][world][S][Wc][Lp]        (chunk c: heads [h0_c, h1_c), Wc = 128 (h1_c - h0_c))
+    // -- so a chunk's launch sees exactly the round-4 layout with H = h1_c - h0_c heads (segment strides rows Wc / S Wc Lp): the same
+    // kernel on the same rows of the same heads, results bit-identical to C = 1 (tests/test_gpu_sp.py).  What the schedule buys: chunk
+    // 0's k, v^T and q leave FIRST (k_0 under the V projection, v_0 under the Q projection, then q_0), so the first launch waits for
+    // one chunk of q, not for three whole tensors queued on the same links; the other chunks' k / v^T / q flow under chunk 0's launch,
+    // chunk c's o returns under chunk c + 1's launch: exposed are q_0 and the last o chunk.  Slots: k_c = c, v_c = C + c, q_c = 2 C + c,
+    // o_c = 3 C + c (C = 1: the round-4 numbering 0..3).
+    int C = sp->a2a_chunks < 1 ? 1 : sp->a2a_chunks;
+    if (C > Hn) C = Hn;
+    if (C > WAN_SP_MAX_CHUNKS) C = WAN_SP_MAX_CHUNKS;
+    if (C > 1) return ulysses_chunked(Lw, C, Hn, Wd, ks, kr, qs, qr, vs, vr);
+    return ulysses_one(Lw, Hn, Wd, ks, kr, qs, qr, vs, vr);
+  }
+
+  int a2a(int which, const bf16_t* send, bf16_t* recv, int64_t bytes) {
+    if (sp->a2a_begin(sp->user, which, send, recv, bytes, stream)) {
+      wan_set_error("wan_dit_forward: all-to-all %d (C head chunks: k 0.., v^T C.., q 2C.., o 3C..) failed", which);
+      return 3;
+    }
+    return 0;
+  }
+  int a2a_wait(int which) {
+    if (sp->a2a_wait(sp->user, which, stream)) {
+      wan_set_error("wan_dit_forward: all-to-all %d failed", which);
+      return 3;
+    }
+    return 0;
+  }
+
+  int ulysses_chunked(const Layer& Lw, int C, int Hn, int64_t Wd, bf16_t* ks, bf16_t* kr, bf16_t* qs, bf16_t* qr, bf16_t* vs, bf16_t* vr) {
+    const int S = Sn;
+    auto& b = b2;
+    int h0[WAN_SP_MAX_CHUNKS + 1];
+    for (int cch = 0; cch <= C; ++cch) h0[cch] = (int)((int64_t)cch * Hn / C);
+    auto wc = [&](int cch) { return (int64_t)(h0[cch + 1] - h0[cch]) * 128; };
+    auto o0 = [&](int cch) { return (int64_t)h0[cch] * 128; };
+    auto send_k = [&](int cch) { return a2a(cch, ks + o0(cch) * rows * world, kr + o0(cch) * rows * world, rows * wc(cch) * 2); };
+    auto send_v = [&](int cch) { return a2a(C + cch, vs + o0(cch) * Lp * S * world, vr + o0(cch) * Lp * S * world, (int64_t)S * wc(cch) * Lp * 2); };
+    auto send_q = [&](int cch) { return a2a(2 * C + cch, qs + o0(cch) * rows * world, qr + o0(cch) * rows * world, rows * wc(cch) * 2); };
+    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
+    // RMSNorm + RoPE written straight into the send layout [rows][world][Hn 128] -> [chunk][world][rows][Wc] (round 6: the norm kernel's
+    // stores carry the re-pack; until then C wan_permute16_ex passes over the tensor followed it)
+    RC(wan_rmsnorm_rope_pack(b.k, ks, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, world, Hn, C, stream));
+    RC(send_k(0));
+    for (int s = 0; s < S; ++s)
+      RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
+    for (int cch = 0; cch < C; ++cch)   // [S][world][Hn 128][Lp] -> [chunk][world][S][Wc][Lp]
+      RC(wan_permute16_ex(b.vt + o0(cch) * Lp, vs + o0(cch) * Lp * S * world, S, world, wc(cch) * Lp * 2, (int64_t)d * Lp * 2, Wd * Lp * 2,
+                          wc(cch) * Lp * 2, (int64_t)S * wc(cch) * Lp * 2, stream));
+    RC(send_v(0));
+    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
+              Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
+    RC(wan_rmsnorm_rope_pack(b.q, qs, Lw.self.nq, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), world, Hn, C, stream));
+    RC(send_q(0));
+    for (int cch = 1; cch < C; ++cch) {   // the later chunks, in the order their launches need them
+      RC(send_k(cch));
+      RC(send_v(cch));
+      RC(send_q(cch));
+    }
+    for (int cch = 0; cch < C; ++cch) {
+      const int Hc = h0[cch + 1] - h0[cch];
+      RC(a2a_wait(cch));
+      RC(a2a_wait(C + cch));
+      RC(a2a_wait(2 * C + cch));
       {
         ProfScope ps(PROF_SELF_ATTN, st);
-        RC(wan_attention_bounded(qr, kr, vr, ks, world * S, S, Ll, Ll, Lp, Hn, world, rows * Wd, (int64_t)S * Wd * Lp, 1, b.kmax, stream));
+        RC(wan_attention_bounded(qr + o0(cch) * rows * world, kr + o0(cch) * rows * world, vr + o0(cch) * Lp * S * world, ks + o0(cch) * rows * world,
+                                 world * S, S, Ll, Ll, Lp, Hc, world, rows * wc(cch), (int64_t)S * wc(cch) * Lp, 1, b.kmax, stream));
       }
       if (g_prof_on && g_prof_declined != nullptr && Ll * (int64_t)world > 2048)
-        RC(wan_attention_count_declined(b.kmax, world * S, S, Ll, Hn, g_prof_declined, stream));
-      RC(a2a(3, ks, qs, rows * Wd * 2));
-      RC(a2a_wait(3));
-      RC(wan_permute16(qs, b.q, world, rows, Wd * 2, stream));
-      }
-    } else if (world > 1) {
-      // Sequence parallelism: K first (projection, RMSNorm + RoPE), its all-gather started at once; then V^T and its gather; the
-      // Q projection / norm and the attention over the rank's OWN K / V^T segment run while both collectives are in flight;
-      // only then the waits, and the other ranks' segments on top of the partial sums (wan_attention_sp_local / _remote).
-      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
-      RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
-      if (sp->gather_begin(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream)) {
-        wan_set_error("wan_dit_forward: K all-gather failed");
-        return 3;
-      }
-      for (int s = 0; s < S; ++s)
-        RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
-      if (sp->gather_begin(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
-        wan_set_error("wan_dit_forward: V^T all-gather failed");
-        return 3;
-      }
-      RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
-                Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
-      RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
-      ProfScope ps(PROF_SELF_ATTN, st);
-      RC(wan_attention_sp_local(b.q, b.k, b.vt, S, Ll, Ll, Lp, nh, b.kmax, b.raw, stream));
-      if (sp->gather_wait(sp->user, 0, stream) || sp->gather_wait(sp->user, 1, stream)) {
-        wan_set_error("wan_dit_forward: K / V^T all-gather failed");
-        return 3;
-      }
-      RC(wan_attention_sp_remote(b.q, b.kfull, b.vtfull, b.q, S, Ll, Ll, Lp, nh, world, rows * (int64_t)d, (int64_t)S * d * Lp, sp->rank,
-                                 b.kmax, b.raw, stream));
-    } else {
-      for (int s = 0; s < S; ++s)  // (fp8: this quantises stream s of xm into slot s; q and k below reuse the slots)
-        RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
-                  nullptr, nullptr, -1, 1, Lp, q8, 1, s, false, a1));
-      const bool vq = Lw.self.v.w8 != nullptr;  // slots hold xm already
-      RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq, a1));
-      RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq || Lw.self.q.w8, a1));
-      {
-        ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
-        RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(),
-                                   stream));
-      }
-      ProfScope ps(PROF_SELF_ATTN, st);
-      RC(wan_attention_bounded(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, 1, b.kmax, stream));
+        RC(wan_attention_count_declined(b.kmax, world * S, S, Ll, Hc, g_prof_declined, stream));
+      // o chunk c over the dead k send chunk (its exchange was waited for above), back over the dead q send chunk, while the next launch runs
+      RC(a2a(3 * C + cch, ks + o0(cch) * rows * world, qs + o0(cch) * rows * world, rows * wc(cch) * 2));
     }
+    for (int cch = 0; cch < C; ++cch) {   // [chunk][world][rows][Wc] -> [rows][world][Hn 128]
+      RC(a2a_wait(3 * C + cch));
+      RC(wan_permute16_ex(qs + o0(cch) * rows * world, b.q + o0(cch), world, rows, wc(cch) * 2, rows * wc(cch) * 2, wc(cch) * 2, Wd * 2, (int64_t)d * 2, stream));
+    }
+    return 0;
+  }
+
+  int ulysses_one(const Layer& Lw, int Hn, int64_t Wd, bf16_t* ks, bf16_t* kr, bf16_t* qs, bf16_t* qr, bf16_t* vs, bf16_t* vr) {
+    const int S = Sn;
+    auto& b = b2;
+    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
+    RC(wan_rmsnorm_rope_pack(b.k, ks, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, world, Hn, 1, stream));   // norm + RoPE + re-pack in one pass
+    RC(a2a(0, ks, kr, rows * Wd * 2));
+    for (int s = 0; s < S; ++s)
+      RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
+    const bf16_t* vsend = b.vt;
+    if (S > 1) {
+      RC(wan_permute16(b.vt, vs, S, world, Wd * Lp * 2, stream));
+      vsend = vs;
+    }
+    RC(a2a(1, vsend, vr, (int64_t)S * Wd * Lp * 2));
+    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
+              Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
+    RC(wan_rmsnorm_rope_pack(b.q, qs, Lw.self.nq, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), world, Hn, 1, stream));
+    RC(a2a(2, qs, qr, rows * Wd * 2));
+    for (int w3 = 0; w3 < 3; ++w3) RC(a2a_wait(w3));
+    {
+      ProfScope ps(PROF_SELF_ATTN, st);
+      RC(wan_attention_bounded(qr, kr, vr, ks, world * S, S, Ll, Ll, Lp, Hn, world, rows * Wd, (int64_t)S * Wd * Lp, 1, b.kmax, stream));
+    }
+    if (g_prof_on && g_prof_declined != nullptr && Ll * (int64_t)world > 2048)
+      RC(wan_attention_count_declined(b.kmax, world * S, S, Ll, Hn, g_prof_declined, stream));
+    RC(a2a(3, ks, qs, rows * Wd * 2));
+    RC(a2a_wait(3));
+    RC(wan_permute16(qs, b.q, world, rows, Wd * 2, stream));
+    return 0;
+  }
+
+  int self_attention_allgather(const Layer& Lw) {
+    const int S = Sn;
+    auto& b = b2;
+    // Sequence parallelism: K first (projection, RMSNorm + RoPE), its all-gather started at once; then V^T and its gather; the
+    // Q projection / norm and the attention over the rank's OWN K / V^T segment run while both collectives are in flight;
+    // only then the waits, and the other ranks' segments on top of the partial sums (wan_attention_sp_local / _remote).
+    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, false, a1));
+    RC(wan_rmsnorm_rope_scaled(b.k, nullptr, Lw.self.nk, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, 1.0f, stream));
+    if (sp->gather_begin(sp->user, 0, b.k, b.kfull, rows * (int64_t)d * 2, stream)) {
+      wan_set_error("wan_dit_forward: K all-gather failed");
+      return 3;
+    }
+    for (int s = 0; s < S; ++s)
+      RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                nullptr, nullptr, -1, 1, Lp, q8, 1, s, Lw.self.k.w8 != nullptr, a1));
+    if (sp->gather_begin(sp->user, 1, b.vt, b.vtfull, (int64_t)S * d * Lp * 2, stream)) {
+      wan_set_error("wan_dit_forward: V^T all-gather failed");
+      return 3;
+    }
+    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0,
+              Lw.self.k.w8 != nullptr || Lw.self.v.w8 != nullptr, a1));
+    RC(wan_rmsnorm_rope_scaled(b.q, nullptr, Lw.self.nq, nullptr, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(), stream));
+    ProfScope ps(PROF_SELF_ATTN, st);
+    RC(wan_attention_sp_local(b.q, b.k, b.vt, S, Ll, Ll, Lp, nh, b.kmax, b.raw, stream));
+    if (sp->gather_wait(sp->user, 0, stream) || sp->gather_wait(sp->user, 1, stream)) {
+      wan_set_error("wan_dit_forward: K / V^T all-gather failed");
+      return 3;
+    }
+    RC(wan_attention_sp_remote(b.q, b.kfull, b.vtfull, b.q, S, Ll, Ll, Lp, nh, world, rows * (int64_t)d, (int64_t)S * d * Lp, sp->rank,
+                               b.kmax, b.raw, stream));
+    return 0;
+  }
+
+  int self_attention_plain(const Layer& Lw) {
+    const int S = Sn;
+    auto& b = b2;
+    for (int s = 0; s < S; ++s)  // (fp8: this quantises stream s of xm into slot s; q and k below reuse the slots)
+      RC(linear(b.xm + (int64_t)s * Ll * d, Lw.self.v, b.vt + (int64_t)s * d * Lp, Ll, d, d, WAN_EPI_TRANSPOSED, stream, nullptr,
+                nullptr, nullptr, -1, 1, Lp, q8, 1, s, false, a1));
+    const bool vq = Lw.self.v.w8 != nullptr;  // slots hold xm already
+    RC(linear(b.xm, Lw.self.q, b.q, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq, a1));
+    RC(linear(b.xm, Lw.self.k, b.k, rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S, 0, vq || Lw.self.q.w8, a1));
+    {
+      ProfScope ps(PROF_ROWOPS, st);  // fused RMSNorm(q,k)+RoPE: 4*rows*d*2 B
+      RC(wan_rmsnorm_rope_scaled(b.q, b.k, Lw.self.nq, Lw.self.nk, cos, sin, rows, Ll, tok0, d, g.eps, wan_attention_qscale(),
+                                 stream));
+    }
+    ProfScope ps(PROF_SELF_ATTN, st);
+    RC(wan_attention_bounded(b.q, b.k, b.vt, b.q, S, S, Ll, Ll, Lp, nh, 1, 0, 0, 1, b.kmax, stream));
+    return 0;
+  }
+
+  int o_projection(const Layer& Lw) {
+    const int S = Sn;
+    auto& b = b2;
     // outside the timed bracket: which share of the launch's workgroups failed the score bound and ran the tracking loop
     // (attention.hip hands the scratch to the kernels only for long KV -- Lk > 2048: for shorter sequences the flags are never written)
     if (!ulysses && g_prof_on && g_prof_declined != nullptr && b.kmax != nullptr && Ll > 2048) RC(wan_attention_count_declined(b.kmax, S, S, Ll, nh, g_prof_declined, stream));
@@ -1052,6 +1128,12 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     } else {
       RC(linear(b.q, Lw.self.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 2, rpb, 0, q8, S));
     }
+    return 0;
+  }
+
+  int cross_attention(const Layer& Lw, const int li) {
+    const int S = Sn;
+    auto& b = b2;
     // -- cross attention (model.py:663-668, :245-265) --
     if (mx) RC(wan_mx_ln_affine(xf, b.xm, Lw.n3w32, Lw.n3b32, rows, d, g.eps, stream));
     else if (fold) {
@@ -1135,6 +1217,12 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
     } else {
       RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb, 0, q8, S));
     }
+    return 0;
+  }
+
+  int ffn_block(const Layer& Lw) {
+    const int S = Sn;
+    auto& b = b2;
     // -- FFN (model.py:686-711) --
     if (mx) RC(wan_mx_ln_modulate(xf, b.xm, Lw.mod, e0f, 6, 3, 4, rows, rpb, d, g.eps, stream));
     else if (fold) {
@@ -1150,33 +1238,65 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       else RC(linear(b.h, Lw.f2, b.x, rows, d, ffn, WAN_EPI_GATE_RES, stream, b.x, Lw.mod, b.e0, 5, rpb, 0, q8, S, 0, false, a2));
     }
     return 0;
-  };
-  for (int i = l0; i < l1; ++i) {
-    if (poll && poll(poll_user, i)) return WAN_ABORTED;  // model.py:1995-1998
-    const int n = vace ? c->vace_at[i] : -1;
-    if (n >= 0) {
-      // VaceWanAttentionBlock.forward (model.py:816-828), called at the top of main block i (:617-629) once per active context:
-      // the context block runs the same layer code on that context's hint streams, with the main streams' e0 / text context / RoPE.
-      const Layer& Vw = c->vlayers[n];
-      for (int j = 0; j < n_on; ++j) {
-        if (n == 0) {  // c = before_proj(c) + x
-          RC(linear(vc[j], Vw.before, vskip[j], rows, d, d, WAN_EPI_GATE_RES, stream, x_main, nullptr, nullptr, -1, rpb, 0, q8, S));
-          bf16_t* t2 = vc[j]; vc[j] = vskip[j]; vskip[j] = t2;
-        }
-        b.x = vc[j];
-        RC(run_layer(Vw, g.num_layers + n));
-        b.x = x_main;
-        RC(linear(vc[j], Vw.after, vskip[j], rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));  // c_skip = after_proj(c)
-      }
-    }
-    RC(run_layer(c->layers[i], i));
-    if (n >= 0)  // x.add_(hint[, alpha=scale]) per context, in context order (:713-719)
-      for (int j = 0; j < n_on; ++j) RC(wan_axpy_bf16(b.x, vskip[j], vace_scales[on_k[j]], b.x, rows * (int64_t)d, stream));
   }
-  return 0;
-  };
+
+  // one WanAttentionBlock (model.py:575-724) on the token streams at b2.x, with the weights Lw; li: the block's index in the text cache
+  // (main blocks, then VACE context blocks)
+  int run_layer(const Layer& Lw, const int li) {
+    RC(norm1(Lw));
+    if (ulysses) RC(self_attention_ulysses(Lw));
+    else if (world > 1) RC(self_attention_allgather(Lw));
+    else RC(self_attention_plain(Lw));
+    RC(o_projection(Lw));
+    RC(cross_attention(Lw, li));
+    return ffn_block(Lw);
+  }
+
+    // the block chain over streams [s0, s0 + Sn): every scratch buffer is used from its base, only the token stream and the
+    // text context are offset (maximal runs of computing streams; all of them in the plain forward)
+    // layers [l0, l1) of the block chain over streams [s0, s0 + Sn)
+  int run_blocks(const int s0_, const int Sn_, const int l0, const int l1) {
+    s0 = s0_;
+    Sn = Sn_;
+    const int S = Sn;
+    rows = (int64_t)Sn * Ll; rpb = nt > 1 ? tpf : rows;
+    b2 = B2{
+        mx ? reinterpret_cast<bf16_t*>(x32 + s0 * sn) : b.x + s0 * sn, b.xm, b.q, b.k, b.vt, b.h, b.ck, b.cvt, XT ? b.ctx_h + (int64_t)s0 * TLx * d : b.ctx_e + (int64_t)crow[s0] * d, b.e0, b.kfull, b.vtfull, b.ckimg, b.cvtimg, b.kmax, b.raw};
+    x_main = mx ? reinterpret_cast<bf16_t*>(x32 + s0 * sn) : b.x + s0 * sn;
+    e0f = b.mx_e0;   // (the outer Bufs: captured before `b` is shadowed below)
+    // hint streams of this run, per active context; vskip[k] doubles as the swap buffer of before_proj
+    for (int j = 0; j < n_on; ++j) {
+      vc[j] = b.vc + ((int64_t)on_k[j] * S_all + s0) * sn;
+      vskip[j] = b.vskip + ((int64_t)on_k[j] * S_all + s0) * sn;
+    }
+    auto& b = b2;
+    for (int i = l0; i < l1; ++i) {
+      if (poll && poll(poll_user, i)) return WAN_ABORTED;  // model.py:1995-1998
+      const int n = vace ? c->vace_at[i] : -1;
+      if (n >= 0) {
+        // VaceWanAttentionBlock.forward (model.py:816-828), called at the top of main block i (:617-629) once per active context:
+        // the context block runs the same layer code on that context's hint streams, with the main streams' e0 / text context / RoPE.
+        const Layer& Vw = c->vlayers[n];
+        for (int j = 0; j < n_on; ++j) {
+          if (n == 0) {  // c = before_proj(c) + x
+            RC(linear(vc[j], Vw.before, vskip[j], rows, d, d, WAN_EPI_GATE_RES, stream, x_main, nullptr, nullptr, -1, rpb, 0, q8, S));
+            bf16_t* t2 = vc[j]; vc[j] = vskip[j]; vskip[j] = t2;
+          }
+          b.x = vc[j];
+          RC(run_layer(Vw, g.num_layers + n));
+          b.x = x_main;
+          RC(linear(vc[j], Vw.after, vskip[j], rows, d, d, WAN_EPI_NONE, stream, nullptr, nullptr, nullptr, -1, 1, 0, q8, S));  // c_skip = after_proj(c)
+        }
+      }
+      RC(run_layer(c->layers[i], i));
+      if (n >= 0)  // x.add_(hint[, alpha=scale]) per context, in context order (:713-719)
+        for (int j = 0; j < n_on; ++j) RC(wan_axpy_bf16(b.x, vskip[j], vace_scales[on_k[j]], b.x, rows * (int64_t)d, stream));
+    }
+    return 0;
+  }
+
   // maximal runs of computing streams through layers [l0, l1)
-  auto run_streams = [&](const int l0, const int l1) -> int {
+  int run_streams(const int l0, const int l1) {
     for (int s0 = 0; s0 < S;) {
       if (!calc(s0)) { ++s0; continue; }
       int Sn = 1;
@@ -1185,59 +1305,98 @@ static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, c
       s0 += Sn;
     }
     return 0;
-  };
-  if (n_perturb == 0) {
-    RC(run_streams(0, g.num_layers));
-  } else {
-    // Skip-layer guidance (any2video.py:1502; model.py:2025-2028): a block listed in perturbation_layers runs for the FIRST stream
-    // of the call only -- and only in the call that carries the conditional stream (x_id 0) -- every other stream passes through
-    // it unchanged.  The chain is cut at those blocks: [unlisted blocks: every computing stream] [listed block: stream 0] ...
-    WAN_REQUIRE(perturb_layers != nullptr && !vace, "wan_dit_forward: perturbation_layers %s",
-                vace ? "together with VACE context blocks is not implemented (the hint streams' state spans the chain)" : "is null");
-    auto listed = [&](int i) {
-      for (int k = 0; k < n_perturb; ++k)
-        if (perturb_layers[k] == i) return true;
-      return false;
-    };
-    for (int l = 0; l < g.num_layers;) {
-      if (listed(l)) {
-        if (x_id == 0 && calc(0)) RC(run_blocks(0, 1, l, l + 1));
-        ++l;
-        continue;
-      }
-      int e = l;
-      while (e < g.num_layers && !listed(e)) ++e;
-      RC(run_streams(l, e));
-      l = e;
-    }
   }
-  for (int s = 0; s < S; ++s)
-    if (residual != nullptr && residual[s] != nullptr && calc(s)) {
-      if (mx) {
-        float* rs = reinterpret_cast<float*>(residual[s]);
-        const float* in2[2] = {x32 + s * sn, rs};
-        const float pm[2] = {1.f, -1.f};
-        RC(wan_lincomb(rs, 2, in2, pm, sn, stream));                          // fp32 x - ori, one rounding
-      } else {
-        RC(wan_sub_bf16(b.x + s * sn, residual[s], residual[s], sn, stream));  // previous_residual = x - ori (model.py:2044-2062)
-      }
-    }
 
-  // ---- head + unpatchify (model.py:2068-2097) -------------------------------------------------------
-  for (int s = 0; s < S; ++s) {
-    if (mx) {
-      // Head.forward on the fp32 stream (model.py:847-865): token-major result; one rank unpatchifies here, a sequence-parallel rank
-      // hands its shard's rows to the host's gather like the bf16 plan does
-      RC(wan_mx_head(x32 + (int64_t)s * Ll * d, c->head_mod, b.mx_e, c->head_w, c->head_b, b.mx_tmp, world > 1 ? outs[s] : b.mx_tok, Ll, d, g.eps,
-                     nt > 1 ? tpf : Ll, 4 * g.out_dim, stream));
-      if (world == 1) RC(wan_unpatchify_n(b.mx_tok, outs[s], 1, F, Hg, Wg, 4 * g.out_dim, stream));
+  int block_chain() {
+    if (n_perturb == 0) {
+      RC(run_streams(0, g.num_layers));
     } else {
-      RC(wan_head_range(b.x + (int64_t)s * Ll * d, c->head_mod, b.e, c->head_w, c->head_b, b.xm, outs[s], 1, F, Hg, Wg, d,
-                        g.eps, tok0, Ll, world > 1 ? 1 : 0, nt > 1 ? tpf : 0, 4 * g.out_dim, stream));
+      // Skip-layer guidance (any2video.py:1502; model.py:2025-2028): a block listed in perturbation_layers runs for the FIRST stream
+      // of the call only -- and only in the call that carries the conditional stream (x_id 0) -- every other stream passes through
+      // it unchanged.  The chain is cut at those blocks: [unlisted blocks: every computing stream] [listed block: stream 0] ...
+      WAN_REQUIRE(perturb_layers != nullptr && !vace, "wan_dit_forward: perturbation_layers %s",
+                  vace ? "together with VACE context blocks is not implemented (the hint streams' state spans the chain)" : "is null");
+      auto listed = [&](int i) {
+        for (int k = 0; k < n_perturb; ++k)
+          if (perturb_layers[k] == i) return true;
+        return false;
+      };
+      for (int l = 0; l < g.num_layers;) {
+        if (listed(l)) {
+          if (x_id == 0 && calc(0)) RC(run_blocks(0, 1, l, l + 1));
+          ++l;
+          continue;
+        }
+        int e = l;
+        while (e < g.num_layers && !listed(e)) ++e;
+        RC(run_streams(l, e));
+        l = e;
+      }
     }
+    return 0;
   }
-  if (tc != nullptr && !tc_hit) tc->valid = true;   // every block's K / V^T is enqueued (an aborted forward returned above: the slot stays invalid)
-  return 0;
+
+  int skip_epilogue() {
+    for (int s = 0; s < S; ++s)
+      if (residual != nullptr && residual[s] != nullptr && calc(s)) {
+        if (mx) {
+          float* rs = reinterpret_cast<float*>(residual[s]);
+          const float* in2[2] = {x32 + s * sn, rs};
+          const float pm[2] = {1.f, -1.f};
+          RC(wan_lincomb(rs, 2, in2, pm, sn, stream));                          // fp32 x - ori, one rounding
+        } else {
+          RC(wan_sub_bf16(b.x + s * sn, residual[s], residual[s], sn, stream));  // previous_residual = x - ori (model.py:2044-2062)
+        }
+      }
+    return 0;
+  }
+
+  int head() {
+    // ---- head + unpatchify (model.py:2068-2097) -------------------------------------------------------
+    for (int s = 0; s < S; ++s) {
+      if (mx) {
+        // Head.forward on the fp32 stream (model.py:847-865): token-major result; one rank unpatchifies here, a sequence-parallel rank
+        // hands its shard's rows to the host's gather like the bf16 plan does
+        RC(wan_mx_head(x32 + (int64_t)s * Ll * d, c->head_mod, b.mx_e, c->head_w, c->head_b, b.mx_tmp, world > 1 ? outs[s] : b.mx_tok, Ll, d, g.eps,
+                       nt > 1 ? tpf : Ll, 4 * g.out_dim, stream));
+        if (world == 1) RC(wan_unpatchify_n(b.mx_tok, outs[s], 1, F, Hg, Wg, 4 * g.out_dim, stream));
+      } else {
+        RC(wan_head_range(b.x + (int64_t)s * Ll * d, c->head_mod, b.e, c->head_w, c->head_b, b.xm, outs[s], 1, F, Hg, Wg, d,
+                          g.eps, tok0, Ll, world > 1 ? 1 : 0, nt > 1 ? tpf : 0, 4 * g.out_dim, stream));
+      }
+    }
+    return 0;
+  }
+
+  int run() {
+    RC(prepare());
+    RC(embed());
+    RC(skip_prologue());
+    RC(vace_embed());
+    RC(block_chain());
+    RC(skip_epilogue());
+    RC(head());
+    if (tc != nullptr && !tc_hit) tc->valid = true;   // every block's K / V^T is enqueued (an aborted forward returned above: the slot stays invalid)
+    return 0;
+  }
+};
+}  // namespace
+
+static int dit_forward_impl(wan_ctx* c, int S, const float* const* x, float t, const float* t_frames, const wan_bf16* const* context,
+                            const float* y, const float* cos, const float* sin, float* const* outs, int F, int H,
+                            int W, void* workspace, int64_t workspace_bytes, const wan_sp_info* sp, wan_poll_fn poll,
+                            void* poll_user, const int* should_calc, wan_bf16* const* residual, int n_vace,
+                            const float* const* vace_contexts, const float* vace_scales, const float* nag, const int* context_batches,
+                            const int* perturb_layers, int n_perturb, int x_id, void* stream, const float* t_dev = nullptr,
+                            uint64_t context_key = 0) {
+  WAN_REQUIRE(c != nullptr, "wan_dit_forward: null argument");
+  Forward f(c);
+  f.S = S; f.x = x; f.t = t; f.t_frames = t_frames; f.context = context; f.y = y; f.cos = cos; f.sin = sin; f.outs = outs; f.F = F; f.H = H; f.W = W;
+  f.workspace = workspace; f.workspace_bytes = workspace_bytes; f.sp = sp; f.poll = poll; f.poll_user = poll_user; f.should_calc = should_calc;
+  f.residual = residual; f.n_vace = n_vace; f.vace_contexts = vace_contexts; f.vace_scales = vace_scales; f.nag = nag;
+  f.context_batches = context_batches; f.perturb_layers = perturb_layers; f.n_perturb = n_perturb; f.x_id = x_id; f.stream = stream;
+  f.t_dev = t_dev; f.context_key = context_key;
+  return f.run();
 }
 
 extern "C" int wan_dit_forward(wan_ctx* c, int S, const float* const* x, float t, const wan_bf16* const* context,
