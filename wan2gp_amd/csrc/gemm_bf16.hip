@@ -283,6 +283,12 @@ extern "C" int wan_gemm_debug_force16s(int v) {
 #ifndef WAN_GEMM_MIN_TILES_DEFAULT
 #define WAN_GEMM_MIN_TILES_DEFAULT 256
 #endif
+// how many 256 x 256 tiles make a "many-tile" problem (WAN_GEMM_MIN_TILES overrides for A/B runs): ONE value for launch_gemm and for the
+// fp32-stream form below (round-5 advisor: wan_gemm_bf16_res32 hard-coded 256 while launch_gemm read the variable)
+static int64_t gemm_min_tiles() {
+  static const int64_t v = [] { const char* e = getenv("WAN_GEMM_MIN_TILES"); const long n = e ? atol(e) : 0; return (int64_t)(n > 0 ? n : WAN_GEMM_MIN_TILES_DEFAULT); }();
+  return v;
+}
 template <int EPI, bool BIAS_ROWS, bool F16 = false>
 static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X, int64_t ldx, int64_t XN, int K,
                        bf16_t* Out, int64_t ldo, const bf16_t* bias, const bf16_t* R, const bf16_t* mod,
@@ -291,7 +297,7 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
   const int64_t tx = (XN + BN - 1) / BN;
   // how many 256 x 256 tiles a problem must have for the one-wave-per-SIMD kernels (a tile per CU: below one wave of tiles the chip is
   // partly idle for a whole tile time, and the 128-wide kernels balance better).  WAN_GEMM_MIN_TILES overrides for A/B runs.
-  static const int64_t min_tiles = [] { const char* e = getenv("WAN_GEMM_MIN_TILES"); const long v = e ? atol(e) : 0; return (int64_t)(v > 0 ? v : WAN_GEMM_MIN_TILES_DEFAULT); }();
+  const int64_t min_tiles = gemm_min_tiles();
   const bool many_tiles = ((YM + 255) / 256) * ((XN + 255) / 256) >= min_tiles;
   // Round 6 dispatch of the bf16 Linears (run 09 / 10, profiles/r06_ab_gemm_tile_heights_run09.log, r06_ab_gemm_text_shapes_run10.log; one
   // process, alternating, bit-identical outputs):
@@ -301,8 +307,9 @@ static int launch_gemm(const bf16_t* Y, int64_t ldy, int64_t YM, const bf16_t* X
   //      q / k / o 46.9 -> 28.0 us, ffn.2 + gate 240.8 -> 128.2 us; the 14B text K Linear (M = 1,024) 93.0 -> 58.9 us;
   //   2. below that, gemm16s.hip's co-resident small tiles (256 x 128 from 128 such tiles up, else 128 x 128): UMT5's projections at
   //      M = 512 (70.3 -> 35.0 us), the 1.3B text K / V Linears (28.4 -> 14.6 us), the 14B text V^T (92.3 -> 53.4 us).
-  //      (A 128 x 128 x 32 stage is 64 FLOP per byte fetched = 64 B/clk/CU of LDS-DMA at the matrix pipe's peak, the vector memory path's
-  //      whole width -- 256 x 256 needs 32: at many tiles the small tiles lose by 1.4-1.8 x, which is why they stop here.)
+  //      (A 128 x 128 x 32 stage fetches a byte per 64 FLOP, a 256 x 128 one per 85, the 256 x 256 tile per 128: 64 / 48 / 32 B/clk/CU of
+  //      LDS-DMA at the matrix pipe's peak.  Measured at many tiles, same shapes, one process: 0.30 / 0.40 / 0.58 of peak -- the fetch path,
+  //      not the matrix pipe, bounds the small tiles; they lose by 1.4-1.8 x there, which is why they stop here.)
   // Hooks (tests, in-process A/B): g_force_rows (wan_gemm_debug_force_tile_rows) and g_force16s (env WAN_GEMM16S at load,
   // wan_gemm_debug_force16s): -1 = the round-5 rule, 0 = this dispatch, a tile size = that tile on every problem it fits.
 #ifndef WAN_GEMM_NO_MI16  // (defined only for the A/B library libwanhip_k.so: gemm256k on every shape)
@@ -366,7 +373,7 @@ extern "C" int wan_gemm_bf16_res32(const wan_bf16* A, int64_t lda, const wan_bf1
   if (M == 0) return 0;
   hipStream_t st = as_stream(stream);
 #ifndef WAN_GEMM_NO_MI16
-  if (((M + 255) / 256) * (((int64_t)N + 255) / 256) >= 256) {
+  if (((M + 255) / 256) * (((int64_t)N + 255) / 256) >= gemm_min_tiles()) {
     const int rc = wan_gemm256m_try<4, false>(A, lda, M, W, K, N, K, reinterpret_cast<bf16_t*>(x32), N, bias, nullptr, mod,
                                               reinterpret_cast<const bf16_t*>(e0), n_mod, gate_idx, rows_per_batch > 0 ? rows_per_batch : 1, st, 1.0f);
     if (rc >= 0) return rc;
