@@ -1218,12 +1218,17 @@ def simulate_world(worlds, model, model2, one_step, latents, new_sched, step_s_1
                 if uly and C > 1:
                     d1, lat_1 = timed(0.0, 1)
                     d1l, _ = timed(link_GBs, 1)
+                    # bit-identical while every launch is one launch; with the split tail (round 6) the q blocks of a launch's last partial
+                    # round are summed as key-range parts, and WHICH blocks those are depends on the launch's size: a few fp32 additions
+                    # in another order on those rows (tests/test_gpu_baseline_configs.py pins both statements)
                     same = bool(torch.equal(lat_1, lat_c))
+                    dmax = float((lat_1.float() - lat_c.float()).abs().max())
+                    scale = max(1.0, float(lat_c.float().abs().max()))
                     row["one_exchange"] = {"rank_step_ms": d1 * 1e3, "compute_side_efficiency": step_s_1gpu / (n * d1), "rank_step_ms_link": d1l * 1e3,
                                            "link_modelled_efficiency": step_s_1gpu / (n * d1l), "exposed_ms_per_block": (d1l - d1) * 1e3 / layers,
-                                           "latents_bit_identical_to_chunked": same}
+                                           "latents_bit_identical_to_chunked": same, "latents_max_abs_diff_to_chunked": dmax}
                     row["chunking_gain_points"] = 100.0 * (row["link_modelled_efficiency"] - row["one_exchange"]["link_modelled_efficiency"])
-                    assert same, "the chunked and the one-exchange Ulysses runs of the simulated rank differ"
+                    assert dmax <= 2.0 ** -6 * scale, "the chunked and the one-exchange Ulysses runs of the simulated rank differ by %g (scale %g)" % (dmax, scale)
             rows.append(row)
         finally:                                                              # whatever happened: the models leave as they came
             model.sp = None

@@ -271,7 +271,8 @@ def test_blocks_behind_the_timed_region_do_not_depend_on_the_timesteps_it_consum
     r6 = bench.simulate_world([8], m, m2, one_step3, lat, _StrictScheduler, 8.5, {"num_layers": 40, "num_heads": 40}, 75600, par, "cfg-ulysses", None, 1, 50.0)
     row = r6["ranks"][0]
     assert chunk_seen == [(0.0, 2), (0.0, 2), (50.0, 2), (0.0, 1), (50.0, 1)]                            # warm-up, then the four figures
-    assert row["one_exchange"]["latents_bit_identical_to_chunked"] is True and "chunking_gain_points" in row and "exposed_ms_per_block" in row
+    assert row["one_exchange"]["latents_bit_identical_to_chunked"] is True and row["one_exchange"]["latents_max_abs_diff_to_chunked"] == 0.0
+    assert "chunking_gain_points" in row and "exposed_ms_per_block" in row
     r5 = bench.simulate_world([8], m, m2, one_step2, lat, _StrictScheduler, 0.4, {"num_layers": 30, "num_heads": 12}, 32760, par, "ulysses")
     assert "12 heads do not divide by 8" in r5["ranks"][0]["skipped"]
 

@@ -638,13 +638,15 @@ def test_attention_bound_exceeded_falls_back_per_workgroup(ops):
     assert attn_ok(got2, _prescaled_ref(qs, k2, v))
 
 
-@pytest.mark.parametrize("layout,gain", [("one_segment", 1.0), ("one_segment", 8.0), ("ulysses_segments", 1.0)])
+@pytest.mark.parametrize("layout,gain", [("one_segment", 1.0), ("one_segment", 8.0), ("ulysses_segments", 1.0), ("one_segment", 12.0), ("ulysses_segments", 12.0)])
 def test_attention_split_tail_agrees_with_the_one_launch_form_and_fp64(ops, layout, gain):
     """The split tail of a bounded launch (round 6; csrc/attention_w64q.hip split_tail): 270 workgroups on 256 CUs = one full round + 14
     q blocks that would run alone for a whole round -- they are attended as 8 key-range parts each (unnormalised sums to the library's
     scratch) and finished by a third launch.  The bounded softmax's partial sums add exactly up to the order of the fp32 additions:
     against the fp64 softmax on the tail's rows and a sample of the others, and against the one-launch form (wan_attention_debug_split_tail
-    0) within one bf16 ulp of the output scale.  gain 8: the rows carry a reference shift every part must agree on.  The segmented form is
+    0) within one bf16 ulp of the output scale.  gains 8 / 12: the rows carry a reference shift -- such a q block does not split (its parts could
+    not use the sample of tile 0 and would hand diffuse rows to the tracking loop: the closing run of round 6 caught exactly that at gain 12):
+    part 0 attends it whole, flag 3, which the finishing launch clears -- no flag survives, nothing is redone.  The segmented form is
     the Ulysses rank's launch (2 x 1 query batches against one K / V^T batch in two segments with ragged tails)."""
     from wan2gp_amd import lib as L_
     lib = L_.load()

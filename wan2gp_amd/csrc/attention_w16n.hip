@@ -415,7 +415,6 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     }
     v_end = v_first + 1;
   }
-  const bool raw_out = RAW_OUT || is_part;   // this workgroup leaves unnormalised sums
   auto qpf_set_next = [&]() {   // the block after the current one
     if (p_qb + 1 < nqb) { qpf_set(p_pair, p_qb + 1, p_b, p_h); return; }
     const int pr = p_pair + 1, bn = pr / H;
@@ -432,7 +431,16 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   if (SHIFT) { if (wg_flags[v] != 2) return; }  // only what the plain launch handed over
   else if (CARRY_IN && wg_flags[v] != 0) return;  // an earlier partial launch already gave this workgroup up
 #else
-  if (CARRY_IN && wg_flags[v] != 0) return;       // an earlier partial launch already gave this workgroup up
+  if (CARRY_IN) {                                 // an earlier partial launch already gave this workgroup up (1), or finished it whole (3: a split tail's shifted block)
+    const int fv = wg_flags[v];
+    if (fv != 0) {
+      if (fv == 3) {
+        __syncthreads();                          // (every thread has read the 3)
+        if (tid == 0) wg_flags[v] = 0;
+      }
+      return;
+    }
+  }
 #endif
   const int pair = PERSIST ? p_pair : v / nqb;
   const int qb = PERSIST ? p_qb : v - pair * nqb;
@@ -446,18 +454,6 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
 
   const int64_t q0 = (int64_t)qb * 256 + wave * 64;
   int Lk32 = (int)Lk;
-  // the split tail: part kv_part of kv_split attends the tiles [t_lo, t_hi) of the block's walk
-  const int tps_all = ((int)Lk + KVBLK - 1) / KVBLK;
-  const int ntile_all = tps_all * (nseg - (skip_seg >= 0 ? 1 : 0));
-  const int t_lo = (raw_out && kv_split > 1) ? (int)((int64_t)kv_part * ntile_all / kv_split) : 0;
-  const int t_hi = (raw_out && kv_split > 1) ? (int)((int64_t)(kv_part + 1) * ntile_all / kv_split) : ntile_all;
-  if (!MULTI && raw_out && kv_split > 1) {   // one segment: the part is a K / V^T of its own, t_lo tiles in
-    kbase += (int64_t)t_lo * KVBLK * rs;
-    vbase += (int64_t)t_lo * KVBLK;
-    const int left = (int)Lk - t_lo * KVBLK;
-    const int mine = (t_hi - t_lo) * KVBLK;
-    Lk32 = left < mine ? left : mine;
-  }
   Dma dma;
   if (PERSIST) {  // tiles 0 and 1 first: they travel while the Q fragments are read and the rows are judged
     dma_init(dma, kbase, vbase, 0, 0, Lk32, 1, (uint32_t)(rs * 2), (uint32_t)(ldv * 2), tid, wave, -1, /*k_rows_16x16=*/true);
@@ -554,6 +550,29 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
   if (qpf_on) qpf_set_next();
   PST(3);   // votes done
 
+  // A part of a split tail whose q block carries a reference shift (gains beyond the plain bound) does not split: the parts would have to agree
+  // on m without the sample of tile 0 (the Cauchy-Schwarz reference alone underflows diffuse rows, and the tracking launch would redo the
+  // block).  Part 0 attends the whole block like any workgroup and leaves flag 3 -- "done, nothing to finish" -- which the finishing launch
+  // turns back into 0; the other parts leave.  (wg_any_shift is a function of the block's Q rows and the head's max |k|: the same in every part.)
+  bool whole_by_part0 = false;
+  if (SHIFT && !RAW_OUT && !CARRY_IN && is_part && wg_any_shift) {
+    if (kv_part != 0) return;
+    is_part = false;
+    whole_by_part0 = true;
+  }
+  const bool raw_out = RAW_OUT || is_part;   // this workgroup leaves unnormalised sums
+  // the split tail: part kv_part of kv_split attends the tiles [t_lo, t_hi) of the block's walk
+  const int tps_all = ((int)Lk + KVBLK - 1) / KVBLK;
+  const int ntile_all = tps_all * (nseg - (skip_seg >= 0 ? 1 : 0));
+  const int t_lo = (raw_out && kv_split > 1) ? (int)((int64_t)kv_part * ntile_all / kv_split) : 0;
+  const int t_hi = (raw_out && kv_split > 1) ? (int)((int64_t)(kv_part + 1) * ntile_all / kv_split) : ntile_all;
+  if (!MULTI && raw_out && kv_split > 1) {   // one segment: the part is a K / V^T of its own, t_lo tiles in
+    kbase += (int64_t)t_lo * KVBLK * rs;
+    vbase += (int64_t)t_lo * KVBLK;
+    const int left = (int)Lk - t_lo * KVBLK;
+    const int mine = (t_hi - t_lo) * KVBLK;
+    Lk32 = left < mine ? left : mine;
+  }
   // ---- DMA stream ---------------------------------------------------------------------------------------------------------------
   const int tps = MULTI ? tps_all : (Lk32 + KVBLK - 1) / KVBLK;
   // (CARRY_IN with carry_n > 1: the finishing launch of a split tail has no tiles of its own)
@@ -798,7 +817,7 @@ __global__ __launch_bounds__(256) void attn_w16n_kernel(const bf16_t* __restrict
     } else {
       any_bad = __syncthreads_or(bad ? 1 : 0);
     }
-    if (tid == 0) wg_flags[v] = any_bad ? 1 : 0;
+    if (tid == 0) wg_flags[v] = any_bad ? 1 : (whole_by_part0 ? 3 : 0);
     // a handed-over workgroup stores nothing: wan_dit_forward attends IN PLACE (o = q), and the tracking launch that redoes the workgroup
     // reads its Q rows again
     if (any_bad) { if (PERSIST) continue; return; }
