@@ -65,7 +65,10 @@ class WanModelHIP:
         # the forward as a replayed launch list (wan_dit_forward_graph, csrc/dit.hip): "auto" = when the joint pass holds at most
         # graph_max_tokens tokens (launch-bound shapes: BASELINE configs[0] is 6,400; 480p x 81 frames is 65,520), "on" / "off";
         # last_graph_how = what the last forward did (0 eager, 1 eager first sight, 2 captured, 3 replayed)
-        self.graph = "auto"
+        # Default "off" (round 6, advisor): the replay measured a null on the one launch-bound BASELINE shape twice (configs[0]: 34.4 ms replayed /
+        # 34.2 eager in round 5, 25.93 / 25.91 in run 14 -- the step is GPU-bound) while every replayed forward pays a staging copy, an output
+        # clone and, per key, a capture with scratch rings of its own.  "auto" / "on" remain for hosts whose CPU is slower than the bench box's.
+        self.graph = "off"
         self.graph_max_tokens = 16384
         self.last_graph_how = 0
         # the text cache (wan_dit_args.context_key): cross-attention K / V^T and the text embedding of an unchanged prompt are kept across
