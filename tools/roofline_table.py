@@ -31,6 +31,11 @@ def main():
     if not n_self:                                              # one bounded launch per call since the second half of round 4: the shifted twin alone
         n_self, _ = tot("attn_w16n_kernel<shifted")
     forwards = n_self / w["layers"] if n_self else 0            # forward passes in the trace (one joint CFG pass each)
+    # round 6: a self-attention call whose workgroups do not fill their last round of CUs is TWO launches of that name (the split tail's
+    # finishing launch); the persistent cross-attention kernel is launched exactly once per block and forward
+    n_cross, _ = tot("attn_w16n_kernel<persistent")
+    if n_cross:
+        forwards = n_cross / w["layers"]
     lines = {}
 
     def line(name, prefix, work_per_forward, unit, peak, note=""):
@@ -45,6 +50,7 @@ def main():
     line("self-attention", SELF_ALL, w["layers"] * 4.0 * S * L * L * d, "TFLOP/s", 2500.0, "4 S L^2 d per block; plain + shifted launch of every call")
     if "self-attention" in lines:
         lines["self-attention"]["launches"] = n_self
+        lines["self-attention"]["calls"] = int(round(forwards * w["layers"]))
     line("cross-attention (Lk=512)", ("attn_w16n_kernel<persistent", "attn_w64q_kernel<tracking"), w["layers"] * 4.0 * S * L * text * d, "TFLOP/s", 2500.0,
          "4 S L 512 d per block; the persistent bounded walk (round 4) + every tracking launch of the trace (the hand-over passes behind self- and cross-attention: zero work)")
     big = w["layers"] * 2.0 * M * (6.0 * d * d + 2.0 * d * ffn)          # q,k,v,o, cross q,o, ffn1, ffn2 per block
