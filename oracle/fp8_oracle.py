@@ -83,11 +83,13 @@ def linear_fallback(x: torch.Tensor, w_fp8: torch.Tensor, scale: torch.Tensor, b
     return out
 
 
-def quantize_weight(w: torch.Tensor, per_row: bool = True):
+def quantize_weight(w: torch.Tensor, per_row: bool = True, fp8_dtype=None):
     """Synthetic fp8 checkpoint tensors from a bf16/fp32 weight (the reference ships no quantiser for this format -- the
     files come pre-quantised): absmax scaling per output row (or per tensor) onto the e4m3 range."""
     w = w.float()
+    fp8_dtype = FP8 if fp8_dtype is None else fp8_dtype                # (float8_e5m2: the `scaled_float8_e5m2` qtype, scaled_fp8.py:17,34-49)
+    fmax = float(torch.finfo(fp8_dtype).max)
     amax = w.abs().amax(dim=1, keepdim=True) if per_row else w.abs().max().reshape(1, 1)
-    scale = (amax / FP8_MAX).clamp_min(1e-12)
-    q = (w / scale).clamp(-FP8_MAX, FP8_MAX).to(FP8)
+    scale = (amax / fmax).clamp_min(1e-12)
+    q = (w / scale).clamp(-fmax, fmax).to(fp8_dtype)
     return q, (scale.reshape(-1) if per_row else scale.reshape(()))

@@ -272,13 +272,16 @@ def _linear(x, W, prefix):
     if w.dtype == torch.float8_e4m3fn:                       # scaled-fp8 checkpoint: QLinearScaledFP8 (shared/qtypes/scaled_fp8.py)
         from . import fp8_oracle
         return fp8_oracle.linear_scaled(x, w, W[prefix + ".scale_weight"], W[prefix + ".bias"])
+    if w.dtype == torch.float8_e5m2:                         # scaled_float8_e5m2: torch._scaled_mm takes no e5m2 x e5m2 product (the probe at
+        from . import fp8_oracle                             # scaled_fp8.py:197-221 fails), every such Linear runs _linear_fallback (:306-322)
+        return fp8_oracle.linear_fallback(x, w, W[prefix + ".scale_weight"], W[prefix + ".bias"], dtype=x.dtype)
     return F.linear(x, w, W[prefix + ".bias"])
 
 
 FP8_BLOCK_LINEARS = tuple(f"{a}.{l}" for a in ("self_attn", "cross_attn") for l in "qkvo") + ("ffn.0", "ffn.2")
 
 
-def quantize_checkpoint_fp8(W, per_row: bool = True):
+def quantize_checkpoint_fp8(W, per_row: bool = True, fp8_dtype=None):
     """A scaled-fp8 checkpoint from a bf16 one: the ten Linears of every block become float8_e4m3fn `.weight` + fp32
     `.scale_weight` (the layout QLinearScaledFP8._load_from_state_dict reads, scaled_fp8.py:563-637); everything else
     (embeddings, norms, modulation, head, biases) stays as it is."""
@@ -286,7 +289,7 @@ def quantize_checkpoint_fp8(W, per_row: bool = True):
     out = dict(W)
     for k in list(W):
         if k.startswith(("blocks.", "vace_blocks.")) and k.endswith(".weight") and k[:-7].split(".", 2)[2] in FP8_BLOCK_LINEARS:
-            q, s_ = fp8_oracle.quantize_weight(W[k].float(), per_row=per_row)
+            q, s_ = fp8_oracle.quantize_weight(W[k].float(), per_row=per_row, fp8_dtype=fp8_dtype)
             out[k] = q
             out[k[:-7] + ".scale_weight"] = s_.float()
     return out

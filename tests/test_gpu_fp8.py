@@ -133,6 +133,44 @@ def test_fp8_checkpoint_forward_vs_reference_golden(tag, per_row):
         assert torch.isfinite(o).all() and d <= 2.5e-2 and d < dq, (d, dq)
 
 
+@pytest.mark.parametrize("per_row", [True, False], ids=["row", "tensor"])
+def test_e5m2_checkpoint_runs_the_reference_fallback(per_row):
+    """`scaled_float8_e5m2` checkpoints (shared/qtypes/scaled_fp8.py:17,34-49; refused until round 6): torch._scaled_mm multiplies no two
+    e5m2 matrices, so the reference's probe (:197-221) sends every such Linear through `_linear_fallback` (:306-322) -- weights.to(bf16) *=
+    scale.to(bf16), a bf16 matmul.  WanModelHIP forms that product once at load (model.dequantize_scaled_fp8: the reference's values, bit
+    for bit) and runs bf16 Linears: the forward equals the same model loaded with the dequantised checkpoint exactly, and sits at the bf16
+    plan's distance from the oracle's CPU forward of the e5m2 checkpoint."""
+    from oracle import wan_oracle as O, fp8_oracle as F8
+    from wan2gp_amd.model import WanModelHIP, dequantize_scaled_fp8
+    cfg = O.make_config("tiny")
+    Wb = O.synth_weights(cfg)
+    W5 = O.quantize_checkpoint_fp8(Wb, per_row=per_row, fp8_dtype=torch.float8_e5m2)
+    assert sum(v.dtype == torch.float8_e5m2 for v in W5.values()) == 10 * cfg.num_layers
+    Wd = {}
+    for k, v in W5.items():
+        if v.dtype == torch.float8_e5m2:
+            Wd[k] = F8.dequantize(v, W5[k[:-7] + ".scale_weight"])
+            assert torch.equal(Wd[k], dequantize_scaled_fp8(v, W5[k[:-7] + ".scale_weight"]))
+        elif not k.endswith(".scale_weight"):
+            Wd[k] = v
+    f, h, w = 3, 8, 8
+    lat, ctx, ctx_null, _ = O.synth_inputs(cfg, f, h, w)
+    t = torch.tensor([637])
+    kw = dict(dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers)
+    m5 = WanModelHIP(**kw).load_state_dict({("model.diffusion_model." + k): v for k, v in reversed(list(W5.items()))})   # scales in front of their weights, prefixed keys
+    md = WanModelHIP(**kw).load_state_dict(Wd)
+    o5 = [o.cpu() for o in m5([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])]
+    od = [o.cpu() for o in md([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()])]
+    ref = O.dit_forward([lat, lat], t, [ctx, ctx_null], W5, cfg)
+    refb = O.dit_forward([lat, lat], t, [ctx, ctx_null], Wd, cfg)
+    for a, b, r, rb in zip(o5, od, ref, refb):
+        assert torch.equal(a, b)
+        d = ((a - r.float()).norm() / r.float().norm()).item()
+        db = ((b - rb.float()).norm() / rb.float().norm()).item()
+        print(f"[e5m2 forward] hip vs oracle (fallback Linears) {d:.3e}; dequantised bf16 checkpoint hip vs oracle {db:.3e}")
+        assert torch.isfinite(a).all() and d <= 2e-2 and d <= 2.0 * db + 1e-3, (d, db)
+
+
 @pytest.mark.parametrize("d,rows_per_slot,rows", [(5120, 300, 600), (1536, 37, 111), (256, 5, 60)], ids=["14B_two_streams", "1.3B_three_slots", "row_form_few_rows"])
 def test_absmax_folded_into_the_layernorms_gives_the_same_quantisation(ops, d, rows_per_slot, rows):
     """Round 5: wan_ln_modulate_amax / wan_ln_affine_amax leave max |out| per stream in the quantisation slots, wan_fp8_quantize_pre reads

@@ -26,6 +26,21 @@ FP32_PREFIXES = ("patch_embedding.", "head.")
 MIXED_FP32_PREFIXES = ("time_embedding.", "time_projection.")
 
 
+def dequantize_scaled_fp8(weight, scale=None, dtype=torch.bfloat16):
+    """ScaledFP8WeightTensor._linear_fallback's weight (shared/qtypes/scaled_fp8.py:318-335): `weights.to(dtype)`, then IN PLACE
+    `*= scale.to(dtype)` reshaped to [N, 1, ...] when it has one entry per output row (_reshape_scale, :135-142) -- every product rounded to
+    `dtype` once.  scale None: ScaledFP8WeightTensor.create's default of 1 (:229-230)."""
+    out = weight.to(dtype)
+    if scale is None:
+        return out
+    sc = scale.to(device=out.device, dtype=dtype)
+    if sc.numel() == 1:
+        return out.mul_(sc.reshape(()))
+    if sc.numel() != out.shape[0]:
+        raise ValueError(f"scale of {sc.numel()} entries for a weight of {out.shape[0]} rows")
+    return out.mul_(sc.reshape(out.shape[0], *([1] * (out.dim() - 1))))
+
+
 def _wants_fp32(key: str, mixed: bool) -> bool:
     return key.startswith(FP32_PREFIXES) or (mixed and (key.startswith(MIXED_FP32_PREFIXES) or (key.startswith("blocks.") and ".norm3." in key)))
 
@@ -110,6 +125,7 @@ class WanModelHIP:
         'model.diffusion_model.' prefix is stripped, model.py:913-941).  Tensors are moved to
         HBM once and stay resident: bf16 everywhere except patch_embedding/head (fp32)."""
         lib = _L.load()
+        pending_e5m2 = {}
         for k, v in sd.items():
             if k.startswith("model.diffusion_model."):
                 k = k[len("model.diffusion_model."):]
@@ -131,7 +147,12 @@ class WanModelHIP:
                 check(lib.wan_dit_set_weight(self._ctx, k.encode(), ptr(t), 2, t.numel()), f"wan_dit_set_weight({k})")
                 continue
             if v.dtype == torch.float8_e5m2:
-                raise NotImplementedError(f"{k}: float8_e5m2 weights (scaled_float8_e5m2) are not implemented; e4m3fn is")
+                # scaled_float8_e5m2 (shared/qtypes/scaled_fp8.py:17,34-49): torch._scaled_mm takes no e5m2 x e5m2 product, so the reference's
+                # probe (:197-221) leaves _FP8_MM_SUPPORT[e5m2] False and every such Linear runs _linear_fallback (:318-335) -- weights.to(bf16)
+                # *= scale.to(bf16), then a bf16 matmul.  The weights never change: that product is formed once, below, when every key has
+                # been seen (the scale may follow its weight), and the Linear is a bf16 Linear from then on.
+                pending_e5m2[k] = v
+                continue
             want = torch.float32 if _wants_fp32(k, self.mixed_precision) else torch.bfloat16
             if k.startswith("vace_patch_embedding."):
                 # a bf16 Conv3d in the reference (lock_layers_dtypes, model.py:1351-1355); the fp32 patch-embed kernel gets
@@ -144,6 +165,12 @@ class WanModelHIP:
             self._weights[k] = t
             check(lib.wan_dit_set_weight(self._ctx, k.encode(), ptr(t), 1 if want == torch.float32 else 0, t.numel()),
                   f"wan_dit_set_weight({k})")
+        for k, v in pending_e5m2.items():
+            want = torch.float32 if _wants_fp32(k, self.mixed_precision) else torch.bfloat16
+            t = dequantize_scaled_fp8(v.detach().to(device=self.device), self._weights.get(k[: k.rindex(".")] + ".scale_weight") if k.endswith(".weight") else None)
+            t = t.to(want).contiguous()
+            self._weights[k] = t
+            check(lib.wan_dit_set_weight(self._ctx, k.encode(), ptr(t), 1 if want == torch.float32 else 0, t.numel()), f"wan_dit_set_weight({k})")
         return self
 
     # ---- step-skipping caches (model.py:1373-1482) --------------------------------------------------------
