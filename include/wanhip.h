@@ -261,6 +261,11 @@ int wan_vae22_to_video(const float* y, uint8_t* u8, float* f32, int Ti, int h, i
 int wan_vae22_avgdown_add(const uint16_t* x, uint16_t* io, int T, int H, int W, int C, int Co, int ft, int fs, void* stream);
 int wan_vae22_dupup_add(const uint16_t* x, uint16_t* io, int T, int H, int W, int C, int Co, int ft, int fs, int first_chunk,
                         void* stream);
+/* The same four in the fp32 plan (`vae_precision` "32", wgp.py:4038 -> Wan2_2_VAE(dtype=torch.float32), vae2_2.py:1144-1160): fp32 channels-last
+ * activations, no 16-bit rounding point (wan_vae22_to_video reads fp32 in both plans). */
+int wan_vae22_patchify_f32(const float* video, float* out, int T, int H, int W, int Cp, void* stream);
+int wan_vae22_avgdown_add_f32(const float* x, float* io, int T, int H, int W, int C, int Co, int ft, int fs, void* stream);
+int wan_vae22_dupup_add_f32(const float* x, float* io, int T, int H, int W, int C, int Co, int ft, int fs, int first_chunk, void* stream);
 
 /* ---- UMT5 text encoder (models/wan/modules/t5.py) ------------------------------ */
 /* T5Attention core (t5.py:109-131) for head_dim 64: out = softmax_fp32(bf16(q k^T) + pos_bias, masked) v.

@@ -124,6 +124,64 @@ def test_encode_vs_reference_golden(vae):
     assert err <= 1e-2 * ref.abs().max().item() + 1e-3
 
 
+# ---- the fp32 plan (`vae_precision` "32", wgp.py:4038; round 6) -------------------------------------------------------------------------
+def cl32(x):
+    return x[0].permute(1, 2, 3, 0).contiguous().float().cuda()
+
+
+@pytest.mark.parametrize("C,Co,ft,fs,T", [(32, 64, 2, 2, 4), (32, 64, 2, 2, 1), (64, 128, 1, 2, 3), (32, 64, 2, 2, 3)])
+def test_avgdown_add_f32(lib, C, Co, ft, fs, T):
+    from wan2gp_amd.lib import check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(1, C, T, 6, 8, generator=g)
+    sc = V2.avg_down3d(x, Co, ft, fs)
+    main = torch.randn(sc.shape, generator=g)
+    io = cl32(main)
+    check(lib.load().wan_vae22_avgdown_add_f32(ptr(cl32(x)), ptr(io), T, 6, 8, C, Co, ft, fs, stream_ptr()), "avgdown f32")
+    assert (uncl(io) - (main + sc)).abs().max().item() <= 1e-6 * max(1.0, (main + sc).abs().max().item())   # (fp32 sum order only)
+
+
+@pytest.mark.parametrize("C,Co,ft,fs,T,first", [(64, 32, 2, 2, 2, False), (64, 32, 2, 2, 1, True), (128, 64, 1, 2, 3, False)])
+def test_dupup_add_and_patchify_f32(lib, C, Co, ft, fs, T, first):
+    from wan2gp_amd.lib import check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(1, C, T, 3, 5, generator=g)
+    sc = V2.dup_up3d(x, Co, ft, fs, first)
+    main = torch.randn(sc.shape, generator=g)
+    io = cl32(main)
+    check(lib.load().wan_vae22_dupup_add_f32(ptr(cl32(x)), ptr(io), T, 3, 5, C, Co, ft, fs, 1 if first else 0, stream_ptr()), "dupup f32")
+    assert torch.equal(uncl(io), main + sc)
+    v = torch.randn(3, 2, 8, 12, generator=g)
+    a = torch.empty(2, 4, 6, 32, dtype=torch.float32, device="cuda"); b = torch.empty(2, 4, 6, 32, dtype=F16, device="cuda")
+    check(lib.load().wan_vae22_patchify_f32(ptr(v.cuda()), ptr(a), 2, 8, 12, 32, stream_ptr()), "patchify f32")
+    check(lib.load().wan_vae22_patchify(ptr(v.to(F16).float().cuda()), ptr(b), 2, 8, 12, 32, stream_ptr()), "patchify")
+    assert torch.equal(a.cpu()[..., :12], V2.patchify(v.unsqueeze(0), 2)[0].permute(1, 2, 3, 0)) and (a.cpu()[..., 12:] == 0).all()
+    assert torch.equal(a.cpu().to(F16)[..., :12], V2.patchify(v.unsqueeze(0), 2)[0].permute(1, 2, 3, 0).to(F16)) and b.shape == a.shape
+
+
+def test_fp32_plan_equals_the_references_own_cpu_run():
+    """Wan22VAEHIP(dtype=torch.float32) -- refused until round 6 -- against tests/golden/vae22_small.npz = the reference's own vae2_2.py
+    modules executed in fp32 on the CPU: decoded float frames to 1e-4, uint8 frames >= 99.9 % identical with at most 1 LSB anywhere (only the
+    summation order differs), encoded latents to 1e-4 of their scale.  (The fp16 plan above: 1.5e-2 / >= 90 % / 1e-2.)"""
+    from wan2gp_amd.vae22 import Wan22VAEHIP
+    cfg = V2.SMALL
+    vae32 = Wan22VAEHIP(z_dim=cfg["z_dim"], c_dim=cfg["dim"], dec_dim=cfg["dec_dim"], state_dict=V2.synth_vae22_weights(cfg=cfg), device="cuda",
+                        dtype=torch.float32)
+    z, vid = _inputs()
+    dec = vae32.decode([z[0]], 0)[0].cpu()
+    refd = torch.from_numpy(G["dec"])[0].clamp(-1, 1)
+    e_dec = (dec - refd).abs().max().item()
+    u8 = vae32.decode_to_cpu_uint8([z[0]], 0)[0]
+    d = (u8.int() - torch.from_numpy(G["dec_u8"])[0].int()).abs()
+    same = (d == 0).float().mean().item()
+    mu = vae32.encode([vid[0]])[0].cpu()
+    ref = torch.from_numpy(G["enc"])[0]
+    e_enc = (mu - ref).abs().max().item()
+    print(f"VAE2.2 fp32 plan: decode float err {e_dec:.2e}, uint8 identical {same * 100:.3f}% max delta {int(d.max())}, encode err {e_enc:.2e}")
+    assert e_dec <= 1e-4 and same >= 0.999 and int(d.max()) <= 1, (e_dec, same, int(d.max()))
+    assert e_enc <= 1e-4 * max(1.0, ref.abs().max().item()), e_enc
+
+
 @pytest.fixture(scope="module")
 def full_vae():
     from wan2gp_amd.vae22 import Wan22VAEHIP

@@ -71,15 +71,19 @@ def test_vae_tile_size_choice_equals_the_references():
                     assert WanVAEHIP.get_VAE_tile_size(cfg, mem, mixed, *hw) == ns["get_VAE_tile_size"](cfg, mem, mixed, *hw), (cfg, mem, mixed, hw)
 
 
-def test_fp32_plan_is_refused_for_the_wan22_vae_instead_of_building_the_wan21_graph():
-    """`vae_precision` "32" (WanVAEHIP(dtype=torch.float32)) is the Wan2.1 VAE's plan: host graph and key layout are that model's.  The
-    Wan2.2 subclass used to get it silently when constructed with dtype float32 (round-4 advisor); it now refuses in load_state_dict."""
+def test_fp32_plan_is_refused_by_a_subclass_that_does_not_declare_it():
+    """`vae_precision` "32" (dtype=torch.float32): a subclass gets the fp32 host graph only if it says SUPPORTS_F32 -- the Wan2.2 subclass
+    used to get the Wan2.1 fp32 graph silently (round-4 advisor), refused it in rounds 4-5, and runs its own graph in fp32 since round 6
+    (vae22.py `_op22`, csrc/vae22_ops.hip `_f32` forms; tests/test_gpu_vae22.py).  A subclass that declares nothing stays refused."""
     import pytest
     import torch
     from wan2gp_amd.vae import WanVAEHIP
     from wan2gp_amd.vae22 import Wan22VAEHIP
-    assert WanVAEHIP.SUPPORTS_F32 and not Wan22VAEHIP.SUPPORTS_F32
-    v = object.__new__(Wan22VAEHIP)
+    assert WanVAEHIP.SUPPORTS_F32 and Wan22VAEHIP.SUPPORTS_F32
+
+    class Other(WanVAEHIP):
+        SUPPORTS_F32 = False
+    v = object.__new__(Other)
     v.dtype, v.device = torch.float32, "cpu"
-    with pytest.raises(NotImplementedError, match="Wan2.1 VAE only"):
+    with pytest.raises(NotImplementedError, match="fp32 plan"):
         v.load_state_dict({})

@@ -10,9 +10,38 @@
 //                          C*ft*fs*fs/Co consecutive folded channels averaged.  mean in fp32, rounded to fp16, added, rounded.
 //   wan_vae22_dupup_add    io += DupUp3D(x, first_chunk) (:409-431; Up_ResidualBlock.forward :508-516).
 // All four are pure gathers bound by HBM; one thread per 8 output channels (16-byte stores).
+// Round 6: every piece also in fp32 (`vae_precision` "32", wgp.py:4038 -> Wan2_2_VAE(dtype=torch.float32)): the same gathers on fp32
+// channels-last activations, no 16-bit rounding point (wan_vae22_*_f32; the layer graph runs on csrc/vae_f32.hip's kernels).
 #include "common.h"
 
-__global__ void vae22_patchify_kernel(const float* __restrict__ v, uint16_t* __restrict__ out, int T, int H, int W, int Cp) {
+template <bool F32> struct V22El { using type = uint16_t; };
+template <> struct V22El<true> { using type = float; };
+template <bool F32>
+__device__ __forceinline__ void v22_load8(const typename V22El<F32>::type* p, float (&f)[8]) {
+  if constexpr (F32) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    unpack8t<true>(*reinterpret_cast<const uint4*>(p), f);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ void v22_store8(typename V22El<F32>::type* p, const float (&f)[8]) {
+  if constexpr (F32) {
+    *reinterpret_cast<float4*>(p) = float4{f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<float4*>(p + 4) = float4{f[4], f[5], f[6], f[7]};
+  } else {
+    *reinterpret_cast<uint4*>(p) = pack8t<true>(f);
+  }
+}
+template <bool F32>
+__device__ __forceinline__ float v22_ld(const typename V22El<F32>::type* p) {
+  if constexpr (F32) return *p;
+  else return h2f(*p);
+}
+
+template <bool F32>
+__global__ void vae22_patchify_kernel(const float* __restrict__ v, typename V22El<F32>::type* __restrict__ out, int T, int H, int W, int Cp) {
   const int h2 = H >> 1, w2 = W >> 1;
   const int64_t npix = (int64_t)T * h2 * w2;
   const int cpp = Cp >> 3;  // 8-channel groups per pixel
@@ -33,7 +62,7 @@ __global__ void vae22_patchify_kernel(const float* __restrict__ v, uint16_t* __r
       }
       f[j] = val;
     }
-    *reinterpret_cast<uint4*>(out + pix * Cp + cg * 8) = pack8t<true>(f);
+    v22_store8<F32>(out + pix * Cp + cg * 8, f);
   }
 }
 
@@ -58,7 +87,8 @@ __global__ void vae22_to_video_kernel(const float* __restrict__ y, uint8_t* __re
   }
 }
 
-__global__ void vae22_avgdown_add_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ io, int T, int H, int W, int C,
+template <bool F32>
+__global__ void vae22_avgdown_add_kernel(const typename V22El<F32>::type* __restrict__ x, typename V22El<F32>::type* __restrict__ io, int T, int H, int W, int C,
                                          int Co, int ft, int fs) {
   const int pad_t = (ft - T % ft) % ft;
   const int To = (T + pad_t) / ft, Ho = H / fs, Wo = W / fs;
@@ -73,8 +103,8 @@ __global__ void vae22_avgdown_add_kernel(const uint16_t* __restrict__ x, uint16_
     const int rem = (int)(pix - (int64_t)to * Ho * Wo);
     const int ho = rem / Wo, wo = rem - ho * Wo;
     float cur[8];
-    uint16_t* dst = io + pix * Co + cg * 8;
-    unpack8t<true>(*reinterpret_cast<const uint4*>(dst), cur);
+    typename V22El<F32>::type* dst = io + pix * Co + cg * 8;
+    v22_load8<F32>(dst, cur);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int o = cg * 8 + j;
@@ -84,15 +114,16 @@ __global__ void vae22_avgdown_add_kernel(const uint16_t* __restrict__ x, uint16_
         const int c = cf / factor, blk = cf - c * factor;
         const int it = blk / (fs * fs), ih = (blk / fs) % fs, iw = blk % fs;
         const int t = to * ft + it - pad_t;
-        if (t >= 0) sum += h2f(x[(((int64_t)t * H + ho * fs + ih) * W + wo * fs + iw) * C + c]);
+        if (t >= 0) sum += v22_ld<F32>(x + (((int64_t)t * H + ho * fs + ih) * W + wo * fs + iw) * C + c);
       }
-      cur[j] = cur[j] + rnd16<true>(sum / (float)g);
+      cur[j] = cur[j] + (F32 ? sum / (float)g : rnd16<true>(sum / (float)g));
     }
-    *reinterpret_cast<uint4*>(dst) = pack8t<true>(cur);
+    v22_store8<F32>(dst, cur);
   }
 }
 
-__global__ void vae22_dupup_add_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ io, int T, int H, int W, int C,
+template <bool F32>
+__global__ void vae22_dupup_add_kernel(const typename V22El<F32>::type* __restrict__ x, typename V22El<F32>::type* __restrict__ io, int T, int H, int W, int C,
                                        int Co, int ft, int fs, int drop) {
   const int To = T * ft - drop, Ho = H * fs, Wo = W * fs;
   const int factor = ft * fs * fs;
@@ -108,16 +139,16 @@ __global__ void vae22_dupup_add_kernel(const uint16_t* __restrict__ x, uint16_t*
     const int tf = to + drop;  // frame index before the first-chunk trim
     const int t = tf / ft, it = tf - t * ft;
     const int hh = ho / fs, ih = ho - hh * fs, ww = wo / fs, iw = wo - ww * fs;
-    const uint16_t* src = x + (((int64_t)t * H + hh) * W + ww) * C;
+    const typename V22El<F32>::type* src = x + (((int64_t)t * H + hh) * W + ww) * C;
     float cur[8];
-    uint16_t* dst = io + pix * Co + cg * 8;
-    unpack8t<true>(*reinterpret_cast<const uint4*>(dst), cur);
+    typename V22El<F32>::type* dst = io + pix * Co + cg * 8;
+    v22_load8<F32>(dst, cur);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int o = cg * 8 + j;
-      cur[j] += h2f(src[(o * factor + it * fs * fs + ih * fs + iw) / rep]);
+      cur[j] += v22_ld<F32>(src + (o * factor + it * fs * fs + ih * fs + iw) / rep);
     }
-    *reinterpret_cast<uint4*>(dst) = pack8t<true>(cur);
+    v22_store8<F32>(dst, cur);
   }
 }
 
@@ -126,14 +157,21 @@ static inline int v22_blocks(int64_t n) {
   return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
-extern "C" int wan_vae22_patchify(const float* video, uint16_t* out, int T, int H, int W, int Cp, void* stream) {
+template <bool F32>
+static int v22_patchify(const float* video, typename V22El<F32>::type* out, int T, int H, int W, int Cp, void* stream) {
   WAN_REQUIRE(video && out, "wan_vae22_patchify: null pointer");
   WAN_REQUIRE(T >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && Cp >= 16 && Cp % 8 == 0,
               "wan_vae22_patchify: bad shape T=%d H=%d W=%d Cp=%d (even H, W; Cp >= 16, multiple of 8)", T, H, W, Cp);
   const int64_t n = (int64_t)T * (H / 2) * (W / 2) * (Cp / 8);
-  hipLaunchKernelGGL(vae22_patchify_kernel, dim3(v22_blocks(n)), dim3(256), 0, as_stream(stream), video, out, T, H, W, Cp);
+  hipLaunchKernelGGL(vae22_patchify_kernel<F32>, dim3(v22_blocks(n)), dim3(256), 0, as_stream(stream), video, out, T, H, W, Cp);
   WAN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int wan_vae22_patchify(const float* video, uint16_t* out, int T, int H, int W, int Cp, void* stream) {
+  return v22_patchify<false>(video, out, T, H, W, Cp, stream);
+}
+extern "C" int wan_vae22_patchify_f32(const float* video, float* out, int T, int H, int W, int Cp, void* stream) {
+  return v22_patchify<true>(video, out, T, H, W, Cp, stream);
 }
 
 extern "C" int wan_vae22_to_video(const float* y, uint8_t* u8, float* f32, int Ti, int h, int w, int Ttot, int t0, void* stream) {
@@ -146,27 +184,40 @@ extern "C" int wan_vae22_to_video(const float* y, uint8_t* u8, float* f32, int T
   return 0;
 }
 
-extern "C" int wan_vae22_avgdown_add(const uint16_t* x, uint16_t* io, int T, int H, int W, int C, int Co, int ft, int fs,
-                                     void* stream) {
+template <bool F32>
+static int v22_avgdown_add(const typename V22El<F32>::type* x, typename V22El<F32>::type* io, int T, int H, int W, int C, int Co, int ft, int fs, void* stream) {
   WAN_REQUIRE(x && io, "wan_vae22_avgdown_add: null pointer");
   WAN_REQUIRE(T >= 1 && (ft == 1 || ft == 2) && (fs == 1 || fs == 2) && H % fs == 0 && W % fs == 0 && Co % 8 == 0 &&
                   (C * ft * fs * fs) % Co == 0,
               "wan_vae22_avgdown_add: bad shape T=%d H=%d W=%d C=%d Co=%d ft=%d fs=%d", T, H, W, C, Co, ft, fs);
   const int To = (T + (ft - T % ft) % ft) / ft;
   const int64_t n = (int64_t)To * (H / fs) * (W / fs) * (Co / 8);
-  hipLaunchKernelGGL(vae22_avgdown_add_kernel, dim3(v22_blocks(n)), dim3(256), 0, as_stream(stream), x, io, T, H, W, C, Co, ft, fs);
+  hipLaunchKernelGGL(vae22_avgdown_add_kernel<F32>, dim3(v22_blocks(n)), dim3(256), 0, as_stream(stream), x, io, T, H, W, C, Co, ft, fs);
   WAN_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int wan_vae22_avgdown_add(const uint16_t* x, uint16_t* io, int T, int H, int W, int C, int Co, int ft, int fs, void* stream) {
+  return v22_avgdown_add<false>(x, io, T, H, W, C, Co, ft, fs, stream);
+}
+extern "C" int wan_vae22_avgdown_add_f32(const float* x, float* io, int T, int H, int W, int C, int Co, int ft, int fs, void* stream) {
+  return v22_avgdown_add<true>(x, io, T, H, W, C, Co, ft, fs, stream);
+}
 
-extern "C" int wan_vae22_dupup_add(const uint16_t* x, uint16_t* io, int T, int H, int W, int C, int Co, int ft, int fs,
-                                   int first_chunk, void* stream) {
+template <bool F32>
+static int v22_dupup_add(const typename V22El<F32>::type* x, typename V22El<F32>::type* io, int T, int H, int W, int C, int Co, int ft, int fs, int first_chunk,
+                         void* stream) {
   WAN_REQUIRE(x && io, "wan_vae22_dupup_add: null pointer");
   WAN_REQUIRE(T >= 1 && (ft == 1 || ft == 2) && (fs == 1 || fs == 2) && Co % 8 == 0 && (Co * ft * fs * fs) % C == 0,
               "wan_vae22_dupup_add: bad shape T=%d C=%d Co=%d ft=%d fs=%d", T, C, Co, ft, fs);
   const int drop = first_chunk ? ft - 1 : 0;
   const int64_t n = (int64_t)(T * ft - drop) * (H * fs) * (W * fs) * (Co / 8);
-  hipLaunchKernelGGL(vae22_dupup_add_kernel, dim3(v22_blocks(n)), dim3(256), 0, as_stream(stream), x, io, T, H, W, C, Co, ft, fs, drop);
+  hipLaunchKernelGGL(vae22_dupup_add_kernel<F32>, dim3(v22_blocks(n)), dim3(256), 0, as_stream(stream), x, io, T, H, W, C, Co, ft, fs, drop);
   WAN_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int wan_vae22_dupup_add(const uint16_t* x, uint16_t* io, int T, int H, int W, int C, int Co, int ft, int fs, int first_chunk, void* stream) {
+  return v22_dupup_add<false>(x, io, T, H, W, C, Co, ft, fs, first_chunk, stream);
+}
+extern "C" int wan_vae22_dupup_add_f32(const float* x, float* io, int T, int H, int W, int C, int Co, int ft, int fs, int first_chunk, void* stream) {
+  return v22_dupup_add<true>(x, io, T, H, W, C, Co, ft, fs, first_chunk, stream);
 }

@@ -103,6 +103,9 @@ SIGNATURES = {
     "wan_vae22_to_video": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_vae22_avgdown_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_vae22_dupup_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_vae22_patchify_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_vae22_avgdown_add_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wan_vae22_dupup_add_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wan_dit_set_clip": (c_int, [c_void_p, c_void_p, c_void_p]),
     "wan_dit_forward_ex": (c_int, [c_void_p, POINTER(DitArgs), c_void_p]),
     "wan_dit_forward_graph": (c_int, [c_void_p, POINTER(DitArgs), c_void_p, POINTER(c_int)]),

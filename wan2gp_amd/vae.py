@@ -386,13 +386,13 @@ class WanVAEHIP:
             self.load_state_dict(load_file(vae_pth))
 
     NATIVE_GRAPH = True                                    # run encode / decode through wan_vae_* (the Wan2.2 subclass keeps the host graph)
-    SUPPORTS_F32 = True                                    # the fp32 plan's host graph / key layout is the Wan2.1 VAE's (the 2.2 subclass says False)
+    SUPPORTS_F32 = True                                    # a subclass with a graph of its own must bring its own fp32 pieces (vae22.py does) or say False
 
     def load_state_dict(self, sd):
         if self.dtype == torch.float32:                    # `vae_precision` "32" (wgp.py:4038): the fp32 plan, on the host graph below
             if not self.SUPPORTS_F32:                      # (round-4 advisor: a subclass silently got the Wan2.1 fp32 graph)
-                raise NotImplementedError(f"{type(self).__name__}: the fp32 plan (vae_precision '32') is implemented for the Wan2.1 VAE only; "
-                                          "construct this VAE with dtype=torch.float16")
+                raise NotImplementedError(f"{type(self).__name__}: the fp32 plan (vae_precision '32') is not implemented for this VAE; "
+                                          "construct it with dtype=torch.float16")
             self.net = _VaeNetF32(sd, self.device)
             self.native = None
             return self

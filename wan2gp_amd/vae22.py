@@ -6,7 +6,8 @@ the Wan2.1 one plus (vae2_2.py): 2x2 patchify in front of the encoder and unpatc
 :879), `Down_ResidualBlock` / `Up_ResidualBlock` with parameter-free AvgDown3D / DupUp3D shortcuts around each
 resolution level (:335-516), an upsample Conv2d that keeps its channel count (:108-117).  Convolutions, RMS_norm+SiLU and
 the attention block are the vae_ops.hip kernels through `_VaeNet`; the four new pieces are vae22_ops.hip.  tile_size is
-accepted and ignored (288 GB: the tile_size == 0 path, :971-975).
+accepted and ignored (288 GB: the tile_size == 0 path, :971-975).  dtype=torch.float32 (`vae_precision` "32", wgp.py:4038) runs the same
+graph in fp32 throughout (`_VaeNetF32` + the `_f32` forms of the four pieces), like the Wan2.1 VAE's fp32 plan.
 """
 import torch
 
@@ -29,7 +30,7 @@ def _pad32(c):
 
 class Wan22VAEHIP(WanVAEHIP):
     NATIVE_GRAPH = False          # this graph (patchify, AvgDown / DupUp shortcuts, 48 latent channels) stays on the host
-    SUPPORTS_F32 = False          # no fp32 plan for this VAE: WanVAEHIP.load_state_dict refuses dtype=float32 instead of building the Wan2.1 graph
+    SUPPORTS_F32 = True           # round 6: `vae_precision` "32" -- this graph on _VaeNetF32 (csrc/vae_f32.hip) and the wan_vae22_*_f32 pieces
     CFG = dict(dim=160, dec_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2, temperal_downsample=[False, True, True])
 
     @staticmethod
@@ -47,6 +48,10 @@ class Wan22VAEHIP(WanVAEHIP):
         self.mean = torch.tensor(MEAN22[:z_dim], dtype=torch.float32, device=self.device)
         self.std = torch.tensor(STD22[:z_dim], dtype=torch.float32, device=self.device)
         self.scale = [self.mean, 1.0 / self.std]
+
+    def _op22(self, name):
+        """wan_vae22_<name> of the plan in use."""
+        return getattr(self.net.lib, f"wan_vae22_{name}_f32" if self.dtype == torch.float32 else f"wan_vae22_{name}")
 
     # ---- Down_ResidualBlock / Up_ResidualBlock (vae2_2.py:434-516) --------------------------------------------------------
     def _down_block(self, x, pre, cout, t_down, down, cache, idx):
@@ -68,7 +73,7 @@ class Wan22VAEHIP(WanVAEHIP):
                     cache[j] = cx
                 idx[0] += 1
         T, H, W, C = x0.shape
-        check(n.lib.wan_vae22_avgdown_add(ptr(x0), ptr(x), T, H, W, C, cout, 2 if t_down else 1, 2 if down else 1, stream_ptr()),
+        check(self._op22("avgdown_add")(ptr(x0), ptr(x), T, H, W, C, cout, 2 if t_down else 1, 2 if down else 1, stream_ptr()),
               "wan_vae22_avgdown_add")
         return x
 
@@ -92,8 +97,8 @@ class Wan22VAEHIP(WanVAEHIP):
             idx[0] += 1
         xm = n.conv(xm, p + "resample.1", ups=True)                      # nearest-exact 2x + Conv2d dim -> dim (:108-111)
         T, H, W, C = x.shape
-        check(n.lib.wan_vae22_dupup_add(ptr(x), ptr(xm), T, H, W, C, cout, 2 if t_up else 1, 2, 1 if first_chunk else 0,
-                                        stream_ptr()), "wan_vae22_dupup_add")
+        check(self._op22("dupup_add")(ptr(x), ptr(xm), T, H, W, C, cout, 2 if t_up else 1, 2, 1 if first_chunk else 0,
+                                      stream_ptr()), "wan_vae22_dupup_add")
         return xm
 
     def _decoder(self, x, cache, idx, first_chunk=False):
@@ -133,10 +138,9 @@ class Wan22VAEHIP(WanVAEHIP):
         z = z.to(device=self.device, dtype=torch.float32).contiguous()          # [z_dim, t, h, w]
         C, t, h, w = z.shape
         Cp = _pad32(C)
-        zp = torch.empty(t, h, w, Cp, dtype=F16, device=self.device)
+        zp = torch.empty(t, h, w, Cp, dtype=self._adt, device=self.device)
         inv_std = (1.0 / self.scale[1]).contiguous()                             # z / scale[1] + scale[0]
-        check(lib.wan_vae_pack(ptr(z), ptr(zp), ptr(inv_std), ptr(self.scale[0].contiguous()), C, Cp, t * h * w, stream_ptr()),
-              "wan_vae_pack")
+        self._pack(z, zp, inv_std, self.scale[0].contiguous(), C, Cp, t * h * w)
         x = self.net.conv(zp, "conv2")                                           # 1x1x1, z -> z (padded to a multiple of 32)
         T_out = (t - 1) * 4 + 1
         H, W = h * 16, w * 16
@@ -162,8 +166,8 @@ class Wan22VAEHIP(WanVAEHIP):
         for v in videos:
             v = v.to(device=self.device, dtype=torch.float32).contiguous()       # [3, T, H, W]
             C, T, H, W = v.shape
-            vp = torch.empty(T, H // 2, W // 2, 32, dtype=F16, device=self.device)
-            check(lib.wan_vae22_patchify(ptr(v), ptr(vp), T, H, W, 32, stream_ptr()), "wan_vae22_patchify")
+            vp = torch.empty(T, H // 2, W // 2, 32, dtype=self._adt, device=self.device)
+            check(self._op22("patchify")(ptr(v), ptr(vp), T, H, W, 32, stream_ptr()), "wan_vae22_patchify")
             cache = [None] * self._n_cached("encoder.")
             chunks = []
             for i in range(1 + (T - 1) // 4):
@@ -173,7 +177,6 @@ class Wan22VAEHIP(WanVAEHIP):
             mu = self.net.conv(enc, "conv1")                                     # 1x1x1 2z -> 2z; mu = first z channels
             t, h, w, Cs = mu.shape
             out = torch.empty(zd, t, h, w, dtype=torch.float32, device=self.device)
-            check(lib.wan_vae_unpack(ptr(mu), ptr(out), ptr(self.scale[0].contiguous()), ptr(self.scale[1].contiguous()),
-                                     zd, Cs, t * h * w, stream_ptr()), "wan_vae_unpack")
+            self._unpack(mu, out, self.scale[0].contiguous(), self.scale[1].contiguous(), zd, Cs, t * h * w)
             outs.append(out)
         return outs

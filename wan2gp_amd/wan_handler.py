@@ -296,9 +296,10 @@ class family_handler():
         else:
             vae_path = _locate("Wan2.2_VAE.safetensors" if wan_5B else "Wan2.1_VAE.safetensors", checkpoint_dir)
         vae = None
-        # VAE_dtype: wgp.py:4038 passes torch.float16 for `vae_precision` "16" (its default) and torch.float for "32".  The Wan2.1 VAE
-        # serves both plans (fp32: csrc/vae_f32.hip, a slow exact option); any other dtype, and the Wan2.2 VAE, run the fp16 plan
-        vae_kw = {"dtype": torch.float32} if (VAE_dtype == torch.float32 and not wan_5B) else {}
+        # VAE_dtype: wgp.py:4038 passes torch.float16 for `vae_precision` "16" (its default) and torch.float for "32".  Both VAEs serve
+        # both plans (fp32: csrc/vae_f32.hip + the `_f32` pieces of vae22_ops.hip since round 6, a slow exact option); any other dtype runs
+        # the fp16 plan
+        vae_kw = {"dtype": torch.float32} if VAE_dtype == torch.float32 else {}
         if vae_state_dict is not None:
             vae = VAE(state_dict=vae_state_dict, device=device, **vae_kw)
         elif os.path.isfile(vae_path):
