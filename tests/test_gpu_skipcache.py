@@ -100,6 +100,51 @@ def test_teacache_joint_pass_vs_reference(model):
         model.cache = None
 
 
+def test_teacache_with_per_frame_timesteps(model):
+    """Per-frame timesteps (t of shape [1, F]: model.py:1812-1818) together with TeaCache -- refused until round 6.  The reference's decision
+    reads e = time_embedding(sinusoidal(t.flatten())): F rows, the relative L1 a mean over all of them (model.py:1954).  (a) F equal
+    timesteps: decisions, skip count and outputs of the scalar-t run (the rows are copies of its one row); (b) frame 0 held at t = 0 (the
+    ti2v image-conditioning pattern, any2video.py:1496-1499): decisions equal a host-side restatement on the stacked embeddings."""
+    from wan2gp_amd import skipcache
+    lats, ts, ctx, ctx_null = inputs(CFG)
+    F = lats[0].shape[-3]
+    assert F > 1
+    runs = {}
+    for name in ("scalar", "equal_frames", "frame0_clean"):
+        c = model.cache = mk("tea")
+        try:
+            model.compute_teacache_threshold(c.start_step, ts, c.multiplier)
+            flags, outs_all, prev, acc, want = [], [], None, 0.0, []
+            for i in range(STEPS):
+                tf = ts[i].reshape(1).repeat(F)
+                if name == "frame0_clean":
+                    tf[0] = 0
+                t = torch.stack([ts[i]]) if name == "scalar" else tf.reshape(1, F)
+                if name == "frame0_clean":                                                     # model.py:1947-1962 restated on the F-row embedding
+                    e = torch.cat([model.time_embedding(float(v)) for v in tf], 0)
+                    if i <= c.start_step or i == c.num_steps - 1 or prev is None:
+                        w, acc = True, 0.0
+                    else:
+                        acc += abs(np.poly1d(c.coefficients)(skipcache._rel_l1(e, prev)))
+                        w = not (acc < c.rel_l1_thresh)
+                        acc = 0.0 if w else acc
+                    prev = e
+                    want.append(int(w))
+                outs = model([lats[i].cuda(), lats[i].cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()], real_step_no=i, current_step_no=i)
+                flags.append(int(c.should_calc))
+                outs_all.append([o.cpu() for o in outs])
+            runs[name] = (flags, c.skipped_steps, outs_all)
+            if name == "frame0_clean":
+                assert flags == want, (flags, want)
+                assert all(torch.isfinite(o).all() for step in outs_all for o in step)
+        finally:
+            model.cache = None
+    assert runs["equal_frames"][0] == runs["scalar"][0] == G["teaj_flags"].tolist() and runs["equal_frames"][1] == runs["scalar"][1]
+    worst = max(rel(a, b) for sa, sb in zip(runs["equal_frames"][2], runs["scalar"][2]) for a, b in zip(sa, sb))
+    print(f"TeaCache + per-frame t: flags {runs['equal_frames'][0]} (scalar-t run's), per-frame vs scalar outputs {worst:.2e}; frame-0-clean flags {runs['frame0_clean'][0]}")
+    assert worst <= 1e-2
+
+
 def test_skip_reapplies_the_stored_residual(model):
     """Same inputs computed, then skipped: patch_embed(x) + (x_after - x_before) must give the computed output back up to
     the two bf16 roundings of the residual round trip; a skipped stream without a stored residual is an error."""

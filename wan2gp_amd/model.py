@@ -337,12 +337,13 @@ class WanModelHIP:
         FL = RP = None
         if cache is not None:
             # TeaCache / MagCache (model.py:1914-2064): host decision, residual bookkeeping inside the forward
-            if t_frames is not None and cache.cache_type == "tea":
-                # TeaCache decides on the time embedding of ONE timestep; the reference's handler switches it off for the model that
-                # uses per-frame timesteps (wan_handler.py: tea_cache is False for the 5B ti2v model, mag_cache stays on)
-                raise NotImplementedError("per-frame timesteps together with TeaCache (MagCache works)")
             from . import skipcache
-            e = self.time_embedding(tval) if (cache.cache_type == "tea" and x_id == 0) else None
+            e = None
+            if cache.cache_type == "tea" and x_id == 0:
+                # TeaCache decides on e = time_embedding(sinusoidal(t.flatten())) (model.py:1812-1817, :1954): one row per timestep, i.e. F rows
+                # under per-frame timesteps (the relative L1 is a mean over whatever e holds).  The reference's handler switches TeaCache
+                # off for the one model that uses per-frame timesteps (the 5B ti2v class; MagCache stays on) -- the forward serves it anyway
+                e = self.time_embedding(tval) if t_frames is None else torch.cat([self.time_embedding(float(v)) for v in tflat], 0)
             flags = skipcache.decide(cache, S, x_id, real_step_no, e)
             if getattr(cache, "previous_residual", None) is None:
                 cache.previous_residual = [None] * S
