@@ -146,17 +146,9 @@ def _worker(rank, world, port, q):
         a = p1.generate(context=torch.zeros(1, 512, 4096, dtype=torch.bfloat16), width=64, height=64, frame_num=9, sampling_steps=3,
                         guide_scale=1.0, seed=3, return_latents=True)["latents"]
         assert torch.isfinite(a).all() and all(n == 1 and x_id == 0 for n, x_id, _ in m1.calls)
-        # a step-skipping cache needs both streams in one process: refused
-        import types
-        m2 = StreamDiT()
-        m2.cache = types.SimpleNamespace(cache_type="mag")
-        p2 = WanAny2VHIP(m2, device="cpu")
-        p2.cfg_parallel = cfgp
-        try:
-            _generate(p2)
-            raise AssertionError("a cache under CFG parallelism must be refused")
-        except NotImplementedError:
-            pass
+        # (a step-skipping cache under CFG parallelism -- refused until round 6 -- is served by the unconditional rank making the conditional
+        # stream's decision itself: test_step_skipping_decisions_of_the_unconditional_rank_equal_the_single_process_sequence below,
+        # tests/test_gpu_skipcache.py::test_cache_on_the_unconditional_rank_of_cfg_parallelism)
         dist.barrier()
         q.put((rank, "ok"))
     except Exception:  # noqa
@@ -360,3 +352,40 @@ def test_a_rank_hanging_in_the_ulysses_self_test_demotes_the_layout_on_every_ran
                 p.kill()
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+@pytest.mark.parametrize("kind,x_count", [("tea", 2), ("mag", 2), ("mag", 3)])
+def test_step_skipping_decisions_of_the_unconditional_rank_equal_the_single_process_sequence(kind, x_count):
+    """A step-skipping cache under CFG parallelism (refused until round 6).  In one process the reference decides for the conditional pass
+    (x_id 0) and the unconditional pass (x_id 1) of a step in turn; TeaCache's x_id-1 pass and MagCache's one_for_all form (x_count > 2) read
+    the x_id-0 verdict (model.py:1921-1923, :1945-1946).  That verdict depends on the timestep's embedding and the cache's counters only:
+    the rank that runs stream 1 makes it itself first (WanModelHIP.forward, cfg_parallel_stream) -- same flags for both streams as the
+    single-process order, for every step, with nothing exchanged."""
+    import numpy as np
+    import torch
+    from wan2gp_amd import skipcache as SC
+    steps = 12
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(1, 64, generator=g)
+    es = [base * (1 + 0.05 * i) for i in range(steps)]            # relative L1 between neighbours ~ 0.04: three skips, then a computed step
+
+    def mk():
+        c = SC.SkipStepsCache(cache_type=kind, multiplier=2.0, start_step=1, num_steps=steps, skipped_steps=0, previous_residual=None,
+                              previous_modulated_input=None)
+        if kind == "mag":
+            c.update({"magcache_thresh": 0.08, "magcache_K": 3, "mag_ratios": np.concatenate([[1.0, 1.0], 1.0 - 0.02 * np.arange(1, 2 * steps - 1) / steps])})
+        else:
+            c.update({"coefficients": [1.0, 0.0], "rel_l1_thresh": 0.15, "accumulated_rel_l1_distance": 0})
+        SC.reset_for_generation(c, x_count)
+        return c
+    one, r0, r1 = mk(), mk(), mk()
+    want, got = [], []
+    for i in range(steps):
+        e = es[i] if kind == "tea" else None
+        want.append((SC.decide(one, 1, 0, i, e)[0], SC.decide(one, 1, 1, i, None)[0]))
+        f0 = SC.decide(r0, 1, 0, i, e)[0]                       # the conditional rank: its own pass
+        SC.decide(r1, 1, 0, i, e)                               # the unconditional rank: stream 0's decision first ...
+        got.append((f0, SC.decide(r1, 1, 1, i, None)[0]))       # ... then its own pass
+    assert got == want
+    assert any(not a for a, _ in want) and any(a for a, _ in want[2:])      # the scenario skips some steps and computes others
+    assert r1.skipped_steps == one.skipped_steps == r0.skipped_steps

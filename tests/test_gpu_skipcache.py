@@ -145,6 +145,43 @@ def test_teacache_with_per_frame_timesteps(model):
     assert worst <= 1e-2
 
 
+@pytest.mark.parametrize("kind", ["mag", "tea"])
+def test_cache_on_the_unconditional_rank_of_cfg_parallelism(model, kind):
+    """A step-skipping cache together with CFG parallelism (refused until round 6): the rank that runs only the unconditional stream
+    (`cfg_parallel_stream` 1, set by sp.CfgParallel.attach) makes the conditional stream's decision itself before its own pass.  One GPU plays
+    that rank -- x_id-1 passes only, a cache of its own -- against the single-process order (x_id 0 then 1 per step): the same decisions at
+    every step and the same outputs (MagCache also against the reference's own single passes in the golden file)."""
+    lats, ts, ctx, ctx_null = inputs(CFG)
+
+    def setup():
+        c = model.cache = mk(kind)
+        (model.compute_magcache_threshold if kind == "mag" else model.compute_teacache_threshold)(c.start_step, ts, c.multiplier)
+        return c
+    try:
+        c = setup()
+        want_flags, want = [], []
+        for i in range(STEPS):
+            for x_id, cc in enumerate((ctx, ctx_null)):
+                out = model([lats[i].cuda()], t=torch.stack([ts[i]]), context=[cc.cuda()], real_step_no=i, current_step_no=i, x_id=x_id)[0]
+                if x_id == 1:
+                    want.append(out.cpu())
+                    want_flags.append(int(c.accumulated_steps[1] == 0) if kind == "mag" else int(c.should_calc))
+        skipped = c.skipped_steps
+        c = setup()
+        model.cfg_parallel_stream = 1
+        got_flags, worst = [], 0.0
+        for i in range(STEPS):
+            out = model([lats[i].cuda()], t=torch.stack([ts[i]]), context=[ctx_null.cuda()], real_step_no=i, current_step_no=i, x_id=1)[0]
+            got_flags.append(int(c.accumulated_steps[1] == 0) if kind == "mag" else int(c.should_calc))
+            assert torch.equal(out.cpu(), want[i]), (kind, i)
+            if kind == "mag":
+                worst = max(worst, rel(out, G[f"mags_{i}_1"]))
+        assert got_flags == want_flags and c.skipped_steps == skipped and 0 in got_flags[2:] and worst <= 2.5e-2, (got_flags, want_flags, worst)
+    finally:
+        model.cache = None
+        model.cfg_parallel_stream = None
+
+
 def test_skip_reapplies_the_stored_residual(model):
     """Same inputs computed, then skipped: patch_embed(x) + (x_after - x_before) must give the computed output back up to
     the two bf16 roundings of the residual round trip; a skipped stream without a stored residual is an error."""

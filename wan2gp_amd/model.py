@@ -187,6 +187,10 @@ class WanModelHIP:
         h = ops.silu(ops.gemv(s, w["time_embedding.0.weight"], w["time_embedding.0.bias"]))
         return ops.gemv(h, w["time_embedding.2.weight"], w["time_embedding.2.bias"])
 
+    def _tea_e(self, tval, t_frames, tflat):
+        """TeaCache's e (model.py:1812-1817, :1954): one row per timestep the call carries."""
+        return self.time_embedding(tval) if t_frames is None else torch.cat([self.time_embedding(float(v)) for v in tflat], 0)
+
     def compute_teacache_threshold(self, start_step, timesteps=None, speed_factor=0):
         from . import skipcache
         return skipcache.compute_teacache_threshold(self.cache, start_step, [self.time_embedding(float(t)) for t in timesteps], speed_factor)
@@ -338,12 +342,18 @@ class WanModelHIP:
         if cache is not None:
             # TeaCache / MagCache (model.py:1914-2064): host decision, residual bookkeeping inside the forward
             from . import skipcache
+            # CFG parallelism (sp.CfgParallel): the conditional stream runs in another process, but what the reference's x_id-1 pass reads
+            # from the x_id-0 pass of the same step -- TeaCache's should_calc, MagCache's one_for_all verdict (model.py:1921-1923, :1945-1946)
+            # -- depends on the timestep, the weights and the cache's own counters only, never on the latents: the unconditional rank
+            # makes the conditional stream's decision itself first (same state, same arithmetic, nothing exchanged)
+            if getattr(self, "cfg_parallel_stream", None) == 1 and x_id == 1 and S == 1:
+                skipcache.decide(cache, 1, 0, real_step_no, self._tea_e(tval, t_frames, tflat) if cache.cache_type == "tea" else None)
             e = None
             if cache.cache_type == "tea" and x_id == 0:
                 # TeaCache decides on e = time_embedding(sinusoidal(t.flatten())) (model.py:1812-1817, :1954): one row per timestep, i.e. F rows
                 # under per-frame timesteps (the relative L1 is a mean over whatever e holds).  The reference's handler switches TeaCache
                 # off for the one model that uses per-frame timesteps (the 5B ti2v class; MagCache stays on) -- the forward serves it anyway
-                e = self.time_embedding(tval) if t_frames is None else torch.cat([self.time_embedding(float(v)) for v in tflat], 0)
+                e = self._tea_e(tval, t_frames, tflat)
             flags = skipcache.decide(cache, S, x_id, real_step_no, e)
             if getattr(cache, "previous_residual", None) is None:
                 cache.previous_residual = [None] * S

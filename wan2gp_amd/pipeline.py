@@ -544,12 +544,10 @@ class WanAny2VHIP:
                 m.cache = c
             return None
         # multi-GPU: `self.cfg_parallel` (sp.CfgParallel) puts the conditional and the unconditional stream of every guided step on the
-        # two halves of the world.  A step-skipping cache decides for the unconditional stream from what it saw of the conditional
-        # one in the same process (skipcache.decide, x_id 0 then 1): with the streams in different processes that state is missing.
+        # two halves of the world.  A step-skipping cache decides for the unconditional stream from the conditional stream's decision of
+        # the same step (skipcache.decide, x_id 0 then 1); that decision never reads latents, so the unconditional rank makes it itself
+        # (WanModelHIP.forward, cfg_parallel_stream) -- refused until round 6.
         cfg_parallel = getattr(self, "cfg_parallel", None)
-        if cfg_parallel is not None and any(getattr(m, "cache", None) is not None for m in (self.model, self.model2) if m is not None):
-            raise NotImplementedError("WanAny2VHIP.generate: a step-skipping cache (TeaCache / MagCache) together with CFG parallelism -- "
-                                      "use sequence parallelism over the whole world (model.sp) with a cache")
         # step-skipping caches (any2video.py:1398-1408): reset, then pick the threshold that meets cache.multiplier
         # The reference configures only self.model.cache (any2video.py:1396-1406; wgp.py hands the SAME object to both
         # experts): one reset, threshold from model's time embedding.  A distinct cache object on model2 gets its own setup.

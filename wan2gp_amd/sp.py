@@ -244,6 +244,7 @@ class CfgParallel:
         for m in models:
             if m is not None:
                 m.sp = self.sp
+                m.cfg_parallel_stream = self.stream          # (a step-skipping cache on stream 1 makes stream 0's decision itself: model.py forward)
         return self
 
     def exchange(self, mine: torch.Tensor):
