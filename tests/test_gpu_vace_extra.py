@@ -97,9 +97,3 @@ def test_per_frame_timesteps_with_magcache_vs_reference():
             worst = max(worst, rel(outs[k], G[f"tfmag_{i}_{k}"]))
     print(f"per-frame t + MagCache: skipped {c.skipped_steps}/{STEPS}, worst rel err {worst:.4f}")
     assert c.skipped_steps == 4 and worst <= 2.5e-2
-    c2 = SkipStepsCache(cache_type="tea", multiplier=2.0, start_step=1, num_steps=STEPS, skipped_steps=0, previous_residual=None,
-                        previous_modulated_input=None)
-    c2.update({"coefficients": [0.04, 0.001], "rel_l1_thresh": 0.1, "accumulated_rel_l1_distance": 0})
-    m.cache = c2
-    with pytest.raises(NotImplementedError, match="TeaCache"):
-        m([lats[0].cuda()], t=torch.stack([torch.zeros(()), ts[0]]), context=[ctx.cuda()])
