@@ -754,8 +754,10 @@ def test_attention_shifted_rows_that_leave_the_exponent_range_are_redone_by_the_
 
 
 def _no_persist(on):
+    """wan_attention_debug_no_persist: 0 the product dispatch, 1 / True one q block per workgroup, 2 the persistent walk also where the
+    K / V^T-stationary kernel (attention_xkv.hip) would serve the call; returns the old value"""
     from wan2gp_amd import lib as L
-    return L.load().wan_attention_debug_no_persist(1 if on else 0)
+    return L.load().wan_attention_debug_no_persist(int(on))
 
 
 @pytest.mark.parametrize("B,Lq,Lk,H,Bk,gain", [(2, 3405, 512, 12, 2, 1.0), (2, 3405, 512, 12, 2, 8.0), (1, 700, 512, 3, 1, 1.0), (3, 1100, 500, 5, 1, 6.0),
@@ -776,13 +778,17 @@ def test_cross_attention_persistent_workgroups_agree_with_fp64_and_with_one_bloc
     ref = _prescaled_ref(qs, k.expand(B, -1, -1, -1) if Bk == 1 else k, v.expand(B, -1, -1, -1) if Bk == 1 else v)
     scratch = torch.zeros(ops.attention_scratch_words(B, Bk, Lq, H), device="cuda")
     vt = ops.transpose_v(cu(v))
-    got = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch, Bk=Bk)
+    old = _no_persist(2)      # (round 6: at 512 keys the product dispatch is attention_xkv.hip -- its own test below; 2 = this walk everywhere)
+    try:
+        got = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch, Bk=Bk)
+    finally:
+        _no_persist(old)
     nflag = ((Lq + 255) // 256) * H * B
     flags = scratch[Bk * H:Bk * H + nflag].view(torch.int32)
     assert int((flags != 0).sum()) == 0, flags.cpu().tolist()
     err = (got.float().cpu() - ref).abs()
     assert attn_ok(got, ref) and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
-    old = _no_persist(True)
+    old = _no_persist(1)
     try:
         one = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch, Bk=Bk)
     finally:
@@ -811,7 +817,11 @@ def test_cross_attention_persistent_handover_keeps_q_intact_in_place(ops):
     ref = _prescaled_ref(qs, k, v)
     scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
     vt = ops.transpose_v(cu(v))
-    out = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch)
+    old = _no_persist(2)      # (the persistent walk: out of place the product dispatch is attention_xkv.hip at 512 keys)
+    try:
+        out = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch)
+    finally:
+        _no_persist(old)
     nqb = (Lq + 255) // 256
     flags = scratch[B * H:B * H + nqb * H * B].view(torch.int32).view(B * H, nqb).cpu()
     assert flags[0].tolist() == [1] * nqb and flags[3].tolist() == [1] * nqb          # head 0: handed over after the loop
@@ -821,6 +831,71 @@ def test_cross_attention_persistent_handover_keeps_q_intact_in_place(ops):
     qio = cu(qs).clone()
     same = ops.attention(qio, cu(k), vt, q_prescaled=True, kmax_scratch=scratch, out=qio)
     assert same.data_ptr() == qio.data_ptr() and torch.equal(same, out)
+
+
+@pytest.mark.parametrize("B,Lq,H,Bk", [(2, 3405, 12, 2), (1, 700, 3, 1), (3, 1100, 5, 1), (1, 16, 1, 1), (2, 4096 + 17, 40, 2), (1, 75600, 3, 1)],
+                         ids=["two_runs_per_cu", "fewer_blocks_than_cus", "shared_kv_ragged_tile", "one_tile", "40_heads_ragged_row", "full_length_rows"])
+def test_cross_attention_kv_stationary_agrees_with_fp64_and_with_the_persistent_walk(ops, B, Lq, H, Bk):
+    """Round 6: text cross-attention (512 keys, q pre-scaled, out of place) keeps a head's K / V^T in the registers of one workgroup and streams
+    the Q rows past them (attention_xkv.hip): a wave attends 128 keys, the four partial O^T and row sums are added through LDS (the bounded
+    softmax's partial sums add exactly).  Against the fp64 softmax at the file's attention tolerance, and against the persistent walk it
+    replaces (debug hook 2) within two bf16 ulp: the same P = 2^s, summed in another order.  Shapes: runs that cross (batch, head) pairs,
+    fewer blocks than CUs, shared K / V^T with a ragged last tile (1100 = 68 x 16 + 12), a single tile, the model's 40 heads with a
+    one-row last tile, the BASELINE row count."""
+    g = torch.Generator().manual_seed(Lq + H)
+    q = torch.randn(B, Lq, H, 128, generator=g).to(BF); k = torch.randn(Bk, 512, H, 128, generator=g).to(BF)
+    v = torch.randn(Bk, 512, H, 128, generator=g).to(BF)
+    qs = (q.float() * ops.attention_qscale()).to(BF)
+    scratch = torch.zeros(ops.attention_scratch_words(B, Bk, Lq, H), device="cuda")
+    vt = ops.transpose_v(cu(v))
+    got = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch, Bk=Bk)
+    nflag = ((Lq + 255) // 256) * H * B
+    flags = scratch[Bk * H:Bk * H + nflag].view(torch.int32)
+    assert int((flags != 0).sum()) == 0, flags.cpu().tolist()
+    old = _no_persist(2)
+    try:
+        walk = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch, Bk=Bk)
+    finally:
+        _no_persist(old)
+    d = (got.float() - walk.float()).abs()
+    assert bool((d <= torch.clamp(walk.float().abs() * 2.0 ** -7, min=2e-3)).all()), d.max().item()
+    assert not torch.equal(got, walk) or Lq <= 16       # (it IS another kernel: identical outputs would mean the hook did not switch)
+    if Lq <= 5000:
+        ref = _prescaled_ref(qs, k, v)
+        err = (got.float().cpu() - ref).abs()
+        assert attn_ok(got, ref) and err.mean().item() <= 2e-3, (err.max().item(), err.mean().item())
+
+
+def test_cross_attention_kv_stationary_hands_unsound_rows_over(ops):
+    """attention_xkv.hip has no running maximum and no reference shift: a row whose sum leaves [2^-80, 2^100] (a score beyond ~100 in log2
+    units, or every score far below) flags its 256-row block and the tracking launch behind every bounded launch redoes the block.  Head 0 of
+    batch 0 carries a key that overflows rows of every block; rows 300..399 of head 1 have all their scores near -200 (underflow: block 1 only);
+    head 2 is ordinary.  Flags exactly there, result == fp64 everywhere; an in-place call (o = q) never takes this kernel and agrees."""
+    g = torch.Generator().manual_seed(9)
+    B, Lq, H = 2, 1500, 3
+    q = torch.randn(B, Lq, H, 128, generator=g); k = torch.randn(B, 512, H, 128, generator=g)
+    v = torch.randn(B, 512, H, 128, generator=g).to(BF)
+    q[0, :, 0, 0] += 6.0
+    k[0, 300, 0] = 0.0
+    k[0, 300, 0, 0] = 400.0
+    q[:, 300:400, 1] = 0.0
+    q[:, 300:400, 1, 5] = -40.0
+    k[:, :, 1, 5] = k[:, :, 1, 5].abs() + 40.0
+    k = k.to(BF)
+    qs = (q * ops.attention_qscale()).to(BF)
+    ref = _prescaled_ref(qs, k, v)
+    scratch = torch.zeros(ops.attention_scratch_words(B, B, Lq, H), device="cuda")
+    vt = ops.transpose_v(cu(v))
+    out = ops.attention(cu(qs), cu(k), vt, q_prescaled=True, kmax_scratch=scratch)
+    nqb = (Lq + 255) // 256
+    flags = scratch[B * H:B * H + nqb * H * B].view(torch.int32).view(B * H, nqb).cpu()
+    assert flags[0].tolist() == [1] * nqb, flags.tolist()
+    assert flags[1].tolist() == [0, 1] + [0] * (nqb - 2) and flags[4].tolist() == flags[1].tolist(), flags.tolist()
+    assert flags[2].tolist() == [0] * nqb and flags[3].tolist() == [0] * nqb and flags[5].tolist() == [0] * nqb, flags.tolist()
+    assert attn_ok(out, ref)
+    qio = cu(qs).clone()
+    same = ops.attention(qio, cu(k), vt, q_prescaled=True, kmax_scratch=scratch, out=qio)
+    assert same.data_ptr() == qio.data_ptr() and attn_ok(same, ref)
 
 
 @pytest.mark.parametrize("gains", [(1.0, 8.0), (6.0, 8.0), (8.0, 2.0)], ids=["plain_then_shifted", "shifted_then_larger_shift", "shifted_then_same"])

@@ -5,6 +5,7 @@ Interleaved rounds of the kernel's entry points in one process (cdna guide secti
   tracking   the same kernel without a pre-pass: lazy-max loop
   generic    wan_attention on unscaled q (long KV: the 4x64 kernel with its pre-scaling pass; short KV: attn_pp<0,0,4>)
   oneblock   (short KV, --Lk 449..2048) `bounded` is then the persistent walk of round 4; this is the same loop, one q block per workgroup
+  persist    (--Lk 512) `bounded` is then the K / V^T-stationary kernel of round 6 (attention_xkv.hip); this is round 4's persistent walk
 """
 import argparse
 import json
@@ -25,10 +26,11 @@ if "--stamps" in sys.argv:
 from wan2gp_amd import ops  # noqa: E402
 
 
-def _one_block(fn):
-    """short KV (--Lk 449..2048): `bounded` is the persistent walk; this is the same loop launched one q block per workgroup"""
+def _one_block(fn, mode=1):
+    """short KV (--Lk 449..2048): `bounded` is the persistent walk (512 keys: the K / V^T-stationary kernel); mode 1 = the same loop launched one
+    q block per workgroup, mode 2 = the persistent walk"""
     from wan2gp_amd import lib as L
-    old = L.load().wan_attention_debug_no_persist(1)
+    old = L.load().wan_attention_debug_no_persist(mode)
     try:
         return fn()
     finally:
@@ -59,6 +61,7 @@ def main():
     run = {"bounded": lambda: ops.attention(qs, k, vt, q_prescaled=True, kmax_scratch=scratch),
            "tracking": lambda: ops.attention(qs, k, vt, q_prescaled=True, kmax_scratch=False),
            "oneblock": lambda: _one_block(lambda: ops.attention(qs, k, vt, q_prescaled=True, kmax_scratch=scratch)),
+           "persist": lambda: _one_block(lambda: ops.attention(qs, k, vt, q_prescaled=True, kmax_scratch=scratch), 2),
            "generic": lambda: ops.attention(q, k, vt)}
     modes = a.modes.split(",")
     if a.stamps:

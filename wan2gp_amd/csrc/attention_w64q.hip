@@ -747,13 +747,17 @@ __global__ __launch_bounds__(256) void attn_kmax_kernel(const bf16_t* __restrict
 
 }  // namespace
 
-// Test / A-B hook: short KV with a scratch takes the bounded loop as ordinary (one q block per workgroup) launches instead of the persistent form
+// Test / A-B hook: 1 = short KV with a scratch takes the bounded loop as ordinary (one q block per workgroup) launches instead of the persistent
+// form; 2 = the persistent walk also where the K / V^T-stationary kernel (attention_xkv.hip) would serve the call; 0 = the product dispatch
 static int g_no_persist = 0;
 extern "C" int wan_attention_debug_no_persist(int on) {
   const int old = g_no_persist;
-  g_no_persist = on ? 1 : 0;
+  g_no_persist = on == 2 ? 2 : (on ? 1 : 0);
   return old;
 }
+// text cross-attention with K / V^T stationary in registers (attention_xkv.hip): 512 keys, q pre-scaled, out of place
+int wan_attention_xkv_launch(unsigned grid, hipStream_t stream, const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int B, int Bk, int64_t Lq,
+                             int64_t ldv, int H, int nqb, int* wg_flags);
 
 // the bounded loop on the 16x16x32 MFMA (attention_w16n.hip): takes the bounded launches below unless the library is built
 // -DWAN_ATTN_NO_MI16 (the A/B library libwanhip_a32.so)
@@ -842,11 +846,21 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
   float* raw = nullptr;
   const int skip_seg = -1;
   int* wg_flags = nullptr;
+  // Text cross-attention as the call sites in csrc/dit.hip make it (512 keys in one segment, q pre-scaled, o != q): K / V^T stationary in
+  // registers, Q streamed (attention_xkv.hip).  It judges rows by their row sums, not by max |k|: no K pre-pass.  In-place calls keep the
+  // persistent walk -- a block handed over to the tracking launch must still hold its Q rows.
+#if defined(WAN_ATTN_TWO_LAUNCH) || defined(WAN_ATTN_NO_MI16) || defined(W16N_PSTAMPS) || defined(W64Q_TIMING)
+  const bool xkv = false;
+#else
+  const bool xkv = kmax_scratch != nullptr && nseg == 1 && Lk == 512 && ldv >= 512 && (flags & 2) != 0 && q != o && g_no_persist == 0;
+#endif
   if (kmax_scratch != nullptr) {
     // pre-pass: max over the kv rows (all segments) of |k_h|^2 per (batch, head) -> the bounded-softmax test of the kernel;
     // the workgroup flags follow the maxima in the scratch
     wg_flags = reinterpret_cast<int*>(kmax_scratch + (size_t)Bk * H);
     WAN_CHECK_HIP(hipMemsetAsync(kmax_scratch, 0, ((size_t)Bk * H + (size_t)total) * 4, stream));
+  }
+  if (kmax_scratch != nullptr && !xkv) {
     const int rblocks = (int)((Lk + KMAX_ROWS - 1) / KMAX_ROWS);
     hipLaunchKernelGGL(attn_kmax_kernel, dim3((unsigned)rblocks, (unsigned)(Bk * H), (unsigned)nseg), dim3(256), 0, stream, k,
                        kmax_scratch, Bk, Lk, H, k_seg_stride);
@@ -872,7 +886,7 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
 #ifndef WAN_ATTN_TWO_LAUNCH
     // short KV (cross-attention; attention.hip hands a scratch over from 8 tiles on): one persistent workgroup per CU walks a run of q blocks
 #ifndef WAN_ATTN_NO_MI16   // (the a32 A/B library keeps every call off the 16x16x32 kernel: this branch included)
-    if (nseg == 1 && Lk <= 2048 && Lk > 448 && !g_no_persist) {
+    if (nseg == 1 && Lk <= 2048 && Lk > 448 && g_no_persist != 1) {
       // the CU count of the device the caller launches on -- per device, like the scratch rings (round-4 advisor: a process-wide static
       // served the first device's count to every other)
       static int cus_of[64] = {};
@@ -887,6 +901,9 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
         (void)hipGetLastError();
       }
       const unsigned grid = (unsigned)(total < cus ? total : cus);
+      if (xkv) {
+        if (int rc = wan_attention_xkv_launch(grid, stream, q, k, vt, o, B, Bk, Lq, ldv, H, (int)nqb, wg_flags)) return rc;
+      } else {
 #ifdef W16N_PSTAMPS
       static uint64_t* pst = nullptr;
       if (!pst) WAN_CHECK_HIP(hipMalloc((void**)&pst, 32 * 8));
@@ -908,6 +925,7 @@ int wan_attention_w64q_launch(int flags, const bf16_t* q, const bf16_t* k, const
         raw = nullptr;
       }
 #endif
+      }
     } else
 #endif
     if (split_tail(fl, q, k, vt, o, B, Bk, Lq, Lk, ldv, H, (int)nqb, total, scale_log2e, nseg, k_seg_stride, vt_seg_stride, kmax_scratch, wg_flags, stream)) {

@@ -1195,10 +1195,15 @@ struct Forward {
     }
     const bf16_t* const ck_l = tc ? tc->ck[li] : b.ck;
     const bf16_t* const cvt_l = tc ? tc->cvt[li] : b.cvt;
+    // the attention's result: where the o projection reads its input.  The plain text branch attends OUT OF PLACE into the self-attention K
+    // buffer (dead since the block's self-attention): 512 keys then take the K / V^T-stationary kernel (attention_xkv.hip, round 6), which
+    // serves out-of-place calls only.  Every other branch ends in b.q as before.
+    const bf16_t* co = b.q;
     if (!c->has_img) {
       if (!any_nag) {
         ProfScope ps(PROF_CROSS_ATTN, st);
-        RC(wan_attention_bounded(b.q, ck_l, cvt_l, b.q, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, b.kmax, stream));
+        RC(wan_attention_bounded(b.q, ck_l, cvt_l, b.k, S, S, Ll, TLx, LDVx, nh, 1, 0, 0, 1, b.kmax, stream));
+        co = b.k;
       }
     } else {
       // WanI2VCrossAttention (model.py:466-499): the same q attends the text tokens and the 257 CLIP tokens (K_img / V_img
@@ -1213,9 +1218,9 @@ struct Forward {
       RC(wan_add_bf16(b.xm, b.q, b.q, rows * (int64_t)d, stream));
     }
     if (mx) {
-      RC(linear_res32(b.q, Lw.cross.o, xf, b.xm, rows, d, d, nullptr, nullptr, -1, rpb, S));
+      RC(linear_res32(co, Lw.cross.o, xf, b.xm, rows, d, d, nullptr, nullptr, -1, rpb, S));
     } else {
-      RC(linear(b.q, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb, 0, q8, S));
+      RC(linear(co, Lw.cross.o, b.x, rows, d, d, WAN_EPI_GATE_RES, stream, b.x, nullptr, nullptr, -1, rpb, 0, q8, S));
     }
     return 0;
   }
