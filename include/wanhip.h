@@ -184,9 +184,14 @@ int wan_attention_prescaled(const wan_bf16* q, const wan_bf16* k, const wan_bf16
  * q already holds q * wan_attention_qscale().
  * Short KV (one segment, 449 <= Lk <= 2048: text cross-attention, model.py:410-445) with a scratch takes the same bounded loop as ONE
  * persistent workgroup per CU that walks a run of q blocks and fetches the next block's Q rows while it works (round 4); without a
- * scratch, and below 449 keys, the lazy-max loop as before.  o may alias q (wan_dit_forward attends in place): a workgroup that
- * hands itself over to the lazy-max launch stores nothing.
- * wan_attention_debug_no_persist(1): test / A-B hook, short KV with a scratch runs as ordinary one-block workgroups; returns the old value. */
+ * scratch, and below 449 keys, the lazy-max loop as before.  o may alias q: a workgroup that hands itself over to the lazy-max launch
+ * stores nothing.
+ * Exactly 512 keys in one segment, q pre-scaled, a scratch and o != q (round 6; what wan_dit_forward's text branch passes): the head's K and
+ * V^T stay in the registers of one workgroup per CU and the Q rows stream past them (csrc/attention_xkv.hip).  No K pre-pass: a row is sound
+ * when its row sum lies in [2^-80, 2^100]; a 256-row block with an unsound row is flagged in the scratch and the lazy-max launch redoes it
+ * from its Q rows -- hence out of place only (o == q keeps the persistent walk).
+ * wan_attention_debug_no_persist(n): test / A-B hook, returns the old value.  1: short KV with a scratch runs as ordinary one-block
+ * workgroups; 2: the persistent walk also where the K / V^T-stationary kernel would serve the call; 0: the product dispatch. */
 int64_t wan_attention_scratch_words(int B, int Bk, int64_t Lq, int H);
 int wan_attention_bounded(const wan_bf16* q, const wan_bf16* k, const wan_bf16* vt, wan_bf16* o, int B, int Bk,
                           int64_t Lq, int64_t Lk, int64_t ldv, int H, int nseg, int64_t k_seg_stride,

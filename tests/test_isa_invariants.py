@@ -203,6 +203,42 @@ def test_gemm256m_registers_and_stage_instruction_mix(tmp_path_factory):
     assert seen == {8: 5, 7: 4, 6: 4, 5: 4}, seen
 
 
+def test_attention_xkv_stream_has_no_valu_write_in_front_of_an_mfma_that_reads_it(tmp_path_factory):
+    """attention_xkv.hip's MFMAs are inline asm: hipcc pads no hazard around them.  The one it can create by itself is a register copy (v_mov /
+    v_accvgpr) placed straight in front of an MFMA that reads the copy -- it did, when an accumulator's old value was kept alive across the
+    next tile's first MFMA (registers 2, 3 of every O^T tile came out stale on hardware).  Asserted on the ISA: one kernel, 64 MFMAs per
+    iteration, K / V^T in all 256 accumulator registers, no scratch, 32 v_exp_f32, and no MFMA whose previous instruction writes one of its
+    source registers."""
+    asm = asm_of("attention_xkv", tmp_path_factory)
+    ks = kernels(asm, "attn_xkv_kernel")
+    assert len(ks) == 1
+    (name, (ops, meta)), = ks.items()
+    assert meta["ScratchSize"] == 0 and meta["NumAgprs"] == 256, meta
+    assert ops.count("v_mfma_f32_16x16x32_bf16") == 64 and ops.count("v_exp_f32_e32") == 32 and ops.count("s_barrier") == 3, collections.Counter(ops).most_common(12)
+    assert not [o for o in ops if o.startswith(("v_accvgpr", "scratch_", "flat_load", "flat_store"))]
+    body = asm[asm.index(name + ":"):]
+    lines = [l.strip() for l in body[:body.index(".Lfunc_end")].split("\n") if l.strip() and not l.strip().startswith((";", "."))]
+
+    def regs(tok):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
+    bad = []
+    for prev, cur in zip(lines, lines[1:]):
+        if not cur.startswith("v_mfma") or not prev.startswith("v_") or prev.startswith("v_mfma"):
+            continue
+        written = regs(prev.split(None, 1)[1].split(",")[0].strip())
+        srcs = set()
+        for tok in cur.split(None, 1)[1].split(",")[1:]:
+            srcs |= regs(tok.strip())
+        if written & srcs:
+            bad.append((prev, cur))
+    assert not bad, bad[:4]
+
+
 def test_no_kernel_of_the_library_spills_to_scratch(tmp_path_factory):
     """Every kernel of every translation unit: ScratchSize 0 (a spill inside a tile loop is a performance cliff, and the hot kernels
     run at the edge of the 512-register file).  No exceptions: round 2's one (the scaled-fp8 GEMM with GELU and a per-row weight

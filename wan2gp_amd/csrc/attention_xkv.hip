@@ -6,34 +6,45 @@
 // 256-row q block: 16.4k matrix cycles per block inside ~36k -- 43.5 % matrix-pipe busy at 1.89 GHz, 0.34 of peak -- because one workgroup per
 // CU has nobody to run while it judges rows, stores O and restarts its ring (docs/history section 3.1).  With 512 keys the
 // roles can be swapped: a head's K and V^T are 256 KB = exactly the 4 x 64 lanes x 256 accumulator-file registers of a workgroup.  Here
-//   * wave w keeps keys 128 w .. 128 w + 127 of the head: K as 8 x 4 A-fragments (S^T = K Q^T), V^T as 8 x 4 A-fragments (O^T = V^T P^T), loaded
-//     ONCE per (batch, head) run of the workgroup's walk, pinned to the accumulator file;
+//   * wave w keeps K of keys 128 w .. 128 w + 127 (8 x 4 A-fragments: S^T = K Q^T over its keys) and V^T of channels d = 32 w .. 32 w + 31 over
+//     ALL 512 keys (2 x 16 A-fragments: O^T = V^T P^T for its channels), loaded ONCE per (batch, head) run of the workgroup's walk and pinned
+//     to the accumulator file;
 //   * Q rows stream through a 16-deep LDS-DMA ring in tiles of 16 rows (4 KB; one 1-KB piece per wave per tile, 15 tiles ahead);
-//   * per tile a wave issues 32 MFMAs of S^T (its 128 keys), 32 exp2, 32 MFMAs of O^T (partial over its keys), then the four partial O^T
-//     (and row sums) are added through LDS: wave w ends up with d = 32 w .. 32 w + 31 of the tile's 16 rows, normalises and stores them;
-//   * everything is ONE software-pipelined stream -- S of tile t, O^T of tile t - 1, the sum / store of tile t - 2 in one iteration of 64 MFMA
-//     slots -- so a q block has no prologue, no verdict stage and no epilogue of its own; the only serial work left is the K / V^T load of a run
-//     (once or twice per workgroup) and two pipeline-fill iterations per run.
-// The bounded softmax has no running maximum (P = 2^s, as attention_w16n.hip's plain loop): its partial sums over disjoint keys add exactly.
-// A row is sound when its row sum lies in [2^-80, 2^100] (no score overflowed, the sum did not underflow; attention_w16n.hip's verdict with
-// m = 0); a tile with an unsound row flags its 256-row block 1 in wg_flags and the tracking launch that follows every bounded launch redoes
-// that block -- which re-reads its Q rows, so this kernel serves OUT-OF-PLACE calls only (o != q; the launcher sends in-place calls to the
-// persistent walk).
+//   * per tile a wave issues 32 MFMAs of S^T, 32 exp2, packs its four P^T fragments (bf16, 16 q x 128 keys = 4 KB) into LDS, and -- behind
+//     one barrier -- multiplies ALL sixteen P^T fragments of the tile (its own and the other waves': plain lane-linear ds_read_b128) with its
+//     V^T: 32 MFMAs that end in the finished O[16 rows][32 channels] of the wave, normalised by the row sums (exchanged the same way) and
+//     stored.  What crosses LDS is P in bf16 -- half the bytes of the first form of this kernel (run 21), which exchanged fp32 partial O^T
+//     and was bound by the LDS store path -- and nothing is added outside the matrix pipe;
+//   * everything is ONE software-pipelined stream: S^T of tile t, three quarters of O^T of tile t - 1, the last quarter and the store of tile
+//     t - 2 in one iteration of 64 MFMA slots -- a q block has no prologue, no verdict stage and no epilogue of its own; the only serial work
+//     left is the K / V^T load of a run (once or twice per workgroup) and two pipeline-fill iterations per run.
+// The bounded softmax has no running maximum (P = 2^s, as attention_w16n.hip's plain loop).  A row is sound when its row sum lies in
+// [2^-80, 2^100] (no score overflowed, the sum did not underflow; attention_w16n.hip's verdict with m = 0); a tile with an unsound row flags its
+// 256-row block 1 in wg_flags and the tracking launch that follows every bounded launch redoes that block -- which re-reads its Q rows, so
+// this kernel serves OUT-OF-PLACE calls only (o != q; the launcher sends in-place calls to the persistent walk).
 //
 // Fragment layout (v_mfma_f32_16x16x32_bf16; lane: n = lane & 15, g = lane >> 4): attention_w16n.hip's.
 //   S^T tile kt (16 key slots x 16 q): A = K fragment: lane (n, g) holds key slot 16 kt + n, d = 32 ks + 8 g .. + 7; B = Q fragment: q row n, the
 //   same d.  Register i of lane (n, g) = score of q row n against slot 16 kt + 4 g + i.  Slot (kt, m) holds key 32 (kt >> 1) + 8 (m >> 2) +
-//   4 (kt & 1) + (m & 3) of the wave's 128, so that registers 0..3 of tiles 2 c, 2 c + 1 are the 8 CONSECUTIVE keys 32 c + 8 g .. + 7: the P^T
-//   B-fragment of k-step c without moving anything between lanes, against a V^T A-fragment read straight from memory.
-//   O^T tile dt: register i of lane (n, g) = O[q row n][d = 16 dt + 4 g + i].
+//   4 (kt & 1) + (m & 3) of the wave's 128, so that registers 0..3 of tiles 2 p, 2 p + 1 are the 8 CONSECUTIVE keys 32 p + 8 g .. + 7 of q row n:
+//   the lane's 16 bytes of the P^T B-fragment of global k-step C = 4 wave + p -- LDS slot [C][lane], read back by every wave at [C][lane].
+//   O^T tile j of wave w: register i of lane (n, g) = O[q row n][d = 32 w + 16 j + 4 g + i]; A = V^T fragment (j, C): channel 32 w + 16 j + n,
+//   keys 32 C + 8 g .. + 7, straight from memory.
 //
-// One iteration = 64 slots of one MFMA + its fillers, four groups of [8 x S^T (tile pair p = keys 32 p ..) | 8 x O^T (k-step c = p)]:
-//   exp2 of pair p's 8 scores in slots 16 p + 10 .. 17 (>= 3 MFMAs behind the tile's last MFMA: asm MFMAs are not padded by hipcc), in place;
-//   the pack of P^T fragment p in slots 16 p + 18 .. 21 (its previous value was last read by slot 16 p + 15);
-//   pair 3's tail (2 exp2, 4 packs) in slots 0 .. 5 of the next iteration;
-//   slots 3 .. 11: the finished partial O^T of the previous tile (last written by slot 56 + dt) -> LDS, slot 24: barrier, slots 26 .. 37: the
-//   other waves' partials of this wave's quarter, slots 38 .. 55: sums, 1 / l, bf16, two 8-byte stores per lane;
-//   slots 50 .. 56: the next tile's Q fragments (Q fragment ks is last read by slot 49 + 2 ks).
+// One iteration I = 64 slots of one MFMA + its fillers, four blocks of 16.  MFMAs of block p: even slots: S^T of tile I, key tiles 2 p, 2 p + 1
+// (k-step major); odd slots: O^T, four k-steps x two channel tiles -- blocks 2, 3: tile I - 1, k-steps 0-3, 4-7; blocks 0, 1: tile I - 2,
+// k-steps 8-11, 12-15.  Two MFMAs on one accumulator are four slots apart.  Fillers -- the transcendental in EVERY even slot (MFMA + v_exp_f32
+// fill a slot's 16 matrix cycles by themselves, attention_w16n.hip), the rest in odd slots:
+//   exp2 of score r = 0..7 of pair p in slot 16 p + 16 + 2 r (>= 3 MFMAs behind the tile's last MFMA: asm MFMAs are not padded by hipcc), in
+//   place; its row-sum add THREE slots behind (one behind, hipcc pads the transcendental's result with an s_nop: an issue slot -- and this
+//   stream is bound by its instruction count: 4 cycles per instruction of one wave per SIMD, run 30's counters); pair 3 ends in slots 0 .. 17
+//   of the next iteration;
+//   the pack of word w of pair p in slot 16 p + 21 + 4 w, its 16 bytes -> LDS in slot 16 p + 35 (pairs 2, 3: slots 3, 19 of the next iteration);
+//   slot 21: the row-sum shares of tile I - 1 -> LDS; slot 23: the Q piece of tile I + 15; slot 27: vmcnt / lgkmcnt + the iteration's barrier;
+//   P^T fragment reads behind the last use of their register (1, 5 .. 17 | 29 .. 35 | 37 .. 49 | 53 .. 61);
+//   slots 32, 34: tile I - 2 normalised and packed in front of the next tile's first O^T MFMAs (33, 35); slot 36: one 16-byte store per lane;
+//   slots 39 .. 59: the four waves' row-sum shares of tile I - 1, their sum over waves and lane groups, 1 / l and the verdict;
+//   slots 51 .. 63: the next tile's Q fragments.
 #include <stdlib.h>
 
 #include <utility>
@@ -45,13 +56,13 @@ namespace {
 constexpr int XR = 16;                          // Q ring depth (tiles)
 constexpr int XQT = 4096;                       // bytes per Q tile (16 rows x 256 B)
 constexpr int XQ_BYTES = XR * XQT;              // 64 KB
-constexpr int XP_O = 4 * 8 * 1024;              // partial O^T of one tile: [wave][d tile][lane] x 16 B
-constexpr int XP_BUF = XP_O + 4 * 256;          // + row-sum shares [wave][lane] x 4 B
+constexpr int XP_P = 16 * 1024;                 // P^T of one tile: [k-step 0..15][lane] x 16 B
+constexpr int XP_BUF = XP_P + 4 * 256;          // + row-sum shares [wave][lane] x 4 B
 constexpr float X_MIN_ROWSUM = 8.271806125530277e-25f;   // 2^-80
 constexpr float X_MAX_ROWSUM = 1.2676506002282294e30f;   // 2^100
 
 typedef uint32_t xkv_u4 __attribute__((ext_vector_type(4)));
-typedef unsigned int xkv_st2 __attribute__((__vector_size__(8)));
+typedef unsigned int xkv_st4 __attribute__((__vector_size__(16)));
 
 __device__ __forceinline__ void xs0(f32x4& d, const mfma_bf16x8& k, const mfma_bf16x8& q) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(d) : "a"(k), "v"(q));
@@ -60,42 +71,64 @@ __device__ __forceinline__ void xs1(f32x4& d, const mfma_bf16x8& k, const mfma_b
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(k), "v"(q));
 }
 
+// -DXKV_ABL=bits (make xabl; diagnostics, outputs are garbage): 1 = every MFMA without its accumulate dependency, 2 = no exp2 / row sums / packs,
+// 4 = no P^T / row-sum exchange through LDS, 8 = no barrier and no counted waits, 16 = no stores
+#ifndef XKV_ABL
+#define XKV_ABL 0
+#endif
 struct XState {
   mfma_bf16x8 qf[4];   // Q fragments of the tile whose S^T runs in this iteration
   f32x4 s[8];          // S^T tiles, then P in place
-  xkv_u4 pk[4];        // P^T fragments of the tile whose O^T runs in this iteration
-  f32x4 o[8];          // partial O^T (this wave's 128 keys)
-  float lacc, lh, lw;  // this lane's share of the row sums: being summed / of the tile in O^T / of the tile being added up
+  xkv_u4 pk;           // the pair being packed
+  mfma_bf16x8 pf[4];   // P^T fragments of the O^T group in flight
+  f32x4 o[2];          // O^T of this wave's 32 channels
+  float lacc, lh;      // this lane's share of the row sums: being summed / complete (tile I - 1)
+  float inv;           // 1 / l of tile I - 2
 };
 
-// MFMA of slot i
-__device__ __forceinline__ void xkv_mfma(XState& x, const mfma_bf16x8 (&kf)[8][4], const mfma_bf16x8 (&vf)[8][4], int i) {
-  const int p = i >> 4, w = i & 15;
-  if (w < 8) {
-    const int kt = 2 * p + (w & 1), ks = w >> 1;
-    if (ks == 0) xs0(x.s[kt], kf[kt][0], x.qf[0]);
+// MFMA of slot i.  Block p = i >> 4: S^T of pair p in its even slots, O^T k-steps in its odd slots -- two MFMAs on the SAME accumulator are four
+// slots apart (with fillers between them a dependent MFMA two slots behind its producer waits for the write-back: measured 31 cycles per
+// slot against 20 in this form, run 26 / 27).
+__device__ __forceinline__ void xkv_mfma(XState& x, const mfma_bf16x8 (&kf)[8][4], const mfma_bf16x8 (&vf)[2][16], int i) {
+  const int p = i >> 4, m = (i & 15) >> 1;
+  if ((i & 1) == 0) {
+    const int kt = 2 * p + (m & 1), ks = m >> 1;
+    if (ks == 0 || (XKV_ABL & 1)) xs0(x.s[kt], kf[kt][ks], x.qf[ks]);
     else xs1(x.s[kt], kf[kt][ks], x.qf[ks]);
   } else {
-    const int dt = w - 8;
-    if (p == 0) xs0(x.o[dt], vf[dt][0], __builtin_bit_cast(mfma_bf16x8, x.pk[0]));
-    else xs1(x.o[dt], vf[dt][p], __builtin_bit_cast(mfma_bf16x8, x.pk[p]));
+    const int j = m >> 1, d = m & 1;
+    const int C = ((p + 2) & 3) * 4 + j;
+    if (C == 0 || (XKV_ABL & 1)) xs0(x.o[d], vf[d][C], x.pf[j]);
+    else xs1(x.o[d], vf[d][C], x.pf[j]);
   }
 }
-__device__ __forceinline__ void xkv_exp(XState& x, int e) {   // e = 0..63: position in the exp2 stream of a tile (pair e >> 4, its scores 0..7 at e & 15 < 8)
-  const int p = e >> 4, r = e & 15;
-  if (r >= 8) return;
+// The exp2 stream of a tile: score r = 0..7 of pair p in the EVEN slot 16 p + 16 + 2 r (pair 3: 0 .. 14 of the next iteration), its row-sum add
+// in the odd slot behind it, in place.
+__device__ __forceinline__ constexpr int xkv_exp_pair(int i) { return i >= 16 ? (i - 16) >> 4 : 3; }
+__device__ __forceinline__ constexpr int xkv_exp_reg(int i) { return (i & 15) >> 1; }
+__device__ __forceinline__ void xkv_exp(XState& x, int i) {   // i: an even slot
+  if (XKV_ABL & 2) return;
+  const int p = xkv_exp_pair(i), r = xkv_exp_reg(i);
   float v = __builtin_amdgcn_exp2f(x.s[2 * p + (r >> 2)][r & 3]);
   asm volatile("" : "+v"(v));
   x.s[2 * p + (r >> 2)][r & 3] = v;
-  x.lacc += v;
+}
+__device__ __forceinline__ void xkv_sum(XState& x, int i) {   // i: the odd slot THREE behind an exp2 (one behind, hipcc pads the transcendental's
+  if (XKV_ABL & 2) return;                                    // result with an s_nop -- an issue slot; this stream is bound by its instruction count)
+  const int e = (i + 61) & 63;
+  const int p = xkv_exp_pair(e), r = xkv_exp_reg(e);
+  x.lacc += x.s[2 * p + (r >> 2)][r & 3];
   asm volatile("" : "+v"(x.lacc));
 }
-__device__ __forceinline__ void xkv_pack(XState& x, int k) {  // k = 0..63: pair k >> 4, word k & 15 < 4 of its fragment
-  const int p = k >> 4, r = k & 15;
-  if (r >= 4) return;
-  const f32x4& t = x.s[2 * p + (r >> 1)];
-  x.pk[p][r] = cvt_pk(t[2 * (r & 1)], t[2 * (r & 1) + 1]);
-  asm volatile("" : "+v"(x.pk[p]));
+// pack word w of pair p: odd slot 16 p + 21 + 4 w, three behind its second exp2 (pair 3: 5, 9, 13, 17 of the next iteration)
+__device__ __forceinline__ void xkv_pack(XState& x, int i) {
+  if (XKV_ABL & 2) return;
+  const int k = i >= 21 ? i - 21 : i + 43;
+  const int p = k >> 4, w = (k & 15) >> 2;
+  if ((k & 3) != 0) return;
+  const f32x4& t = x.s[2 * p + (w >> 1)];
+  x.pk[w] = cvt_pk(t[2 * (w & 1)], t[2 * (w & 1) + 1]);
+  asm volatile("" : "+v"(x.pk));
 }
 
 #ifdef XKV_STAMPS
@@ -120,15 +153,12 @@ struct XLane {         // loop-invariant per-lane addresses
   char* smem;
   lds_cchar* lds;
   uint32_t q[4], pw, pr, lw, lr, st;
-  int tid;
 };
 struct XIter {         // one iteration's values
-  uint32_t pbuf, qoff;
-  bool live;
+  uint32_t pb1, pb2, qoff;   // LDS offsets: the P buffer of tile I - 1 (= of tile I + 1), of tile I - 2 (= of tile I); the next tile's Q ring slot
   __amdgpu_buffer_rsrc_t odesc;
-  int* flag;
-  f32x4 rd[4][2], acc0, acc1;
   float lsrc[4], lt, inv;
+  uint32_t ow[4];
   int bad;
 #ifdef XKV_STAMPS
   bool rec;
@@ -137,71 +167,84 @@ struct XIter {         // one iteration's values
 };
 // slot I of an iteration: its MFMA, then its fillers
 template <int I>
-__device__ __forceinline__ void xkv_slot(XState& x, const mfma_bf16x8 (&kf)[8][4], const mfma_bf16x8 (&vf)[8][4], XIter& c, const XLane& L, XQ& q) {
+__device__ __forceinline__ void xkv_slot(XState& x, const mfma_bf16x8 (&kf)[8][4], const mfma_bf16x8 (&vf)[2][16], XIter& c, const XLane& L, XQ& q) {
   constexpr int i = I;
   XST(i);
   xkv_mfma(x, kf, vf, i);
   SB();
-  xkv_exp(x, i >= 10 ? i - 10 : i + 54);
-  if (i == 2) { x.lw = x.lh; x.lh = x.lacc; x.lacc = 0.f; asm volatile("" : "+v"(x.lw), "+v"(x.lh), "+v"(x.lacc)); }
-  xkv_pack(x, i >= 18 ? i - 18 : i + 46);
-  if (i >= 3 && i <= 10) {   // the finished partial O^T tile dt = i - 3 (last written by slot 56 + dt of the previous iteration; rewritten by slot 8 + dt)
-    constexpr int dt = (i - 3) & 7;
-    *reinterpret_cast<f32x4*>(L.smem + c.pbuf + L.pw + dt * 1024) = x.o[dt];
-  }
-  if (i == 11) *reinterpret_cast<float*>(L.smem + c.pbuf + L.lw) = x.lw;
-  if (i == 22) xkv_q_issue(q);
-  if (i == 24) {
-    asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");   // this wave's piece of tile it + 1 landed; its partials are written
-    XST(64);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    XST(65);
-  }
-  if (i >= 26 && i <= 33) {   // the four waves' partials of this wave's d tiles 2 wave, 2 wave + 1
-    constexpr int r = (i - 26) & 7, src = r >> 1, j = r & 1;
-    c.rd[src][j] = *reinterpret_cast<const f32x4*>(L.smem + c.pbuf + L.pr + src * 8192 + j * 1024);
-  }
-  if (i >= 34 && i <= 37) c.lsrc[(i - 34) & 3] = *reinterpret_cast<const float*>(L.smem + c.pbuf + L.lr + ((i - 34) & 3) * 256);
-  if (i == 38) { c.acc0 = c.rd[0][0] + c.rd[1][0]; c.acc1 = c.rd[0][1] + c.rd[1][1]; asm volatile("" : "+v"(c.acc0), "+v"(c.acc1)); }
-  if (i == 39) { c.acc0 += c.rd[2][0]; c.acc1 += c.rd[2][1]; asm volatile("" : "+v"(c.acc0), "+v"(c.acc1)); }
-  if (i == 40) { c.acc0 += c.rd[3][0]; c.acc1 += c.rd[3][1]; asm volatile("" : "+v"(c.acc0), "+v"(c.acc1)); }
-  if (i == 41) c.lt = (c.lsrc[0] + c.lsrc[1]) + (c.lsrc[2] + c.lsrc[3]);
-  // the row's sum over the four lane groups: v_permlane16_swap / v_permlane32_swap (VALU; a ds_bpermute's round trip would sit in the stream twice)
-  if (i == 42) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c.lt), __float_as_uint(c.lt), false, false);
-    c.lt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  if (i == 43) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c.lt), __float_as_uint(c.lt), false, false);
-    c.lt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  if (i == 44) {
-    c.inv = __builtin_amdgcn_rcpf(c.lt);
-    asm volatile("" : "+v"(c.inv));
-    // (no branch inside the stream: a block boundary lets the code sinker pull the sums above down to their first use)
-    c.bad = !(c.lt >= X_MIN_ROWSUM && c.lt <= X_MAX_ROWSUM) ? 1 : 0;
-  }
-  if (i == 48) {
-    xkv_st2 w0;
-    w0[0] = cvt_pk(c.acc0[0] * c.inv, c.acc0[1] * c.inv);
-    w0[1] = cvt_pk(c.acc0[2] * c.inv, c.acc0[3] * c.inv);
-    __builtin_amdgcn_raw_buffer_store_b64(w0, c.odesc, (int)L.st, 0, 0);
-  }
-  if (i == 49) {
-    xkv_st2 w1;
-    w1[0] = cvt_pk(c.acc1[0] * c.inv, c.acc1[1] * c.inv);
-    w1[1] = cvt_pk(c.acc1[2] * c.inv, c.acc1[3] * c.inv);
-    __builtin_amdgcn_raw_buffer_store_b64(w1, c.odesc, (int)(L.st + 32u), 0, 0);
-  }
-  if (i == 50 || i == 52 || i == 54 || i == 56) {   // the next tile's Q fragment ks (last read by slot 49 + 2 ks)
-    constexpr int ks = ((i - 50) >> 1) & 3;
-    x.qf[ks] = *(lds_frag*)(L.lds + c.qoff + L.q[ks]);
+  if ((i & 1) == 0) {
+    xkv_exp(x, i);
+    // tile I - 2's finished O^T tile d (last MFMA: slot 29 + 2 d) normalised, packed, stored -- in front of the next tile's first MFMA on that
+    // accumulator (slot 33 + 2 d): a value kept across it lives in other registers, and hipcc then returns the loop-carried accumulator to
+    // its own with v_movs straight in front of an asm MFMA that reads it -- two wait states short, silently (run 27: registers 2, 3 stale)
+    if (i == 32 || i == 34) {
+      constexpr int d = ((i - 32) >> 1) & 1;
+      const f32x4 t = x.o[d];
+      c.ow[2 * d] = cvt_pk(t[0] * x.inv, t[1] * x.inv);
+      c.ow[2 * d + 1] = cvt_pk(t[2] * x.inv, t[3] * x.inv);
+    }
+    // ... as ONE 16-byte store per lane: lane group g holds channels 4 g .. + 3 of tile 0 (ow 0, 1) and of tile 1 (ow 2, 3); v_permlane16_swap
+    // (vdst = tile 0's word, vsrc = tile 1's: vdst's odd rows <-> vsrc's even rows) leaves an even group with tile 0's channels 4 g .. 4 g + 7
+    // and the odd group behind it with tile 1's 4 (g - 1) .. + 7 -- 8 consecutive channels.  (Two 8-byte stores per lane cost the stream
+    // 0.2 ms of a 1.8-ms call: run 28's ablation -- a wave's store instruction is priced by the rows it touches, not by its bytes.)
+    if (i == 36) {
+      const auto r0 = __builtin_amdgcn_permlane16_swap(c.ow[0], c.ow[2], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(c.ow[1], c.ow[3], false, false);
+      xkv_u4 w = {r0[0], r1[0], r0[1], r1[1]};
+      if (!(XKV_ABL & 16)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xkv_st4, w), c.odesc, (int)L.st, 0, 0);
+      else asm volatile("" :: "v"(w));
+    }
+  } else {
+    if (i == 27 && !(XKV_ABL & 8)) {   // the iteration's barrier, in front of the slot's other fillers
+      asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");   // this wave's piece of tile I + 1 landed; its P^T and row sums of tile I - 1 are written
+      XST(64);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      XST(65);
+    }
+    xkv_sum(x, i);
+    if (i == 17) { x.lh = (XKV_ABL & 2) ? 1.f : x.lacc; x.lacc = 0.f; asm volatile("" : "+v"(x.lh), "+v"(x.lacc)); }   // (behind the add of the tail's last exp2, slot 14; slot 19 adds the new tile's first)
+    xkv_pack(x, i);
+    // the packed pair -> LDS slot [4 wave + pair][lane]: pairs 0, 1 of tile I (its buffer = tile I - 2's), pairs 2, 3 of tile I - 1
+    if (!(XKV_ABL & 4)) if (i == 35) *reinterpret_cast<xkv_u4*>(L.smem + c.pb2 + L.pw + 0 * 1024) = x.pk;
+    if (!(XKV_ABL & 4)) if (i == 51) *reinterpret_cast<xkv_u4*>(L.smem + c.pb2 + L.pw + 1 * 1024) = x.pk;
+    if (!(XKV_ABL & 4)) if (i == 3) *reinterpret_cast<xkv_u4*>(L.smem + c.pb1 + L.pw + 2 * 1024) = x.pk;
+    if (!(XKV_ABL & 4)) if (i == 19) *reinterpret_cast<xkv_u4*>(L.smem + c.pb1 + L.pw + 3 * 1024) = x.pk;
+    if (!(XKV_ABL & 4)) if (i == 21) *reinterpret_cast<float*>(L.smem + c.pb1 + L.lw) = x.lh;
+    if (i == 23) xkv_q_issue(q);
+    // P^T fragment reads: register j behind its last use (slot 16 p + 4 j + 3 of the block in flight), 6 to 12 slots ahead of its next
+    if (!(XKV_ABL & 4) && (i == 5 || i == 9 || i == 13 || i == 17)) { constexpr int j = ((i - 5) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb2 + L.pr + (12 + j) * 1024); }    // tile I - 2, k-steps 12..15
+    if (!(XKV_ABL & 4) && (i == 29 || i == 31 || i == 33 || i == 35)) { constexpr int j = ((i - 29) >> 1) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb1 + L.pr + (0 + j) * 1024); }  // tile I - 1, k-steps 0..3 (behind the barrier)
+    if (!(XKV_ABL & 4) && (i == 37 || i == 41 || i == 45 || i == 49)) { constexpr int j = ((i - 37) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb1 + L.pr + (4 + j) * 1024); }  // k-steps 4..7
+    if (!(XKV_ABL & 4) && (i == 53 || i == 57 || i == 61)) { constexpr int j = ((i - 53) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb1 + L.pr + (8 + j) * 1024); }             // k-steps 8..10 (the next iteration's block 0)
+    if (!(XKV_ABL & 4) && i == 1) x.pf[3] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb2 + L.pr + 11 * 1024);                                                                                  // tile I - 2, k-step 11
+    // the row sums of tile I - 1: four waves' shares, the four lane groups (v_permlane16_swap / v_permlane32_swap: VALU, no LDS round trip)
+    if (!(XKV_ABL & 4) && i == 39) { c.lsrc[0] = *reinterpret_cast<const float*>(L.smem + c.pb1 + L.lr); c.lsrc[1] = *reinterpret_cast<const float*>(L.smem + c.pb1 + L.lr + 256); }
+    if (!(XKV_ABL & 4) && i == 43) { c.lsrc[2] = *reinterpret_cast<const float*>(L.smem + c.pb1 + L.lr + 512); c.lsrc[3] = *reinterpret_cast<const float*>(L.smem + c.pb1 + L.lr + 768); }
+    if (i == 47) c.lt = (c.lsrc[0] + c.lsrc[1]) + (c.lsrc[2] + c.lsrc[3]);
+    if (i == 51) {
+      const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c.lt), __float_as_uint(c.lt), false, false);
+      c.lt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if (i == 55) {
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c.lt), __float_as_uint(c.lt), false, false);
+      c.lt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if (i == 59) {
+      c.inv = __builtin_amdgcn_rcpf(c.lt);
+      asm volatile("" : "+v"(c.inv));
+      // (no branch inside the stream: a block boundary lets the code sinker pull values down to their first use)
+      c.bad = !(c.lt >= X_MIN_ROWSUM && c.lt <= X_MAX_ROWSUM) ? 1 : 0;
+    }
+    if (i == 51 || i == 55 || i == 59 || i == 63) {   // the next tile's Q fragment ks (last read by slot 50 + 4 ks)
+      constexpr int ks = ((i - 51) >> 2) & 3;
+      x.qf[ks] = *(lds_frag*)(L.lds + c.qoff + L.q[ks]);
+    }
   }
   SB();
 }
 template <int... I>
-__device__ __forceinline__ void xkv_iter(XState& x, const mfma_bf16x8 (&kf)[8][4], const mfma_bf16x8 (&vf)[8][4], XIter& c, const XLane& L, XQ& q,
+__device__ __forceinline__ void xkv_iter(XState& x, const mfma_bf16x8 (&kf)[8][4], const mfma_bf16x8 (&vf)[2][16], XIter& c, const XLane& L, XQ& q,
                                          std::integer_sequence<int, I...>) {
   (xkv_slot<I>(x, kf, vf, c, L, q), ...);
 }
@@ -233,22 +276,28 @@ __global__ __launch_bounds__(256) void attn_xkv_kernel(const bf16_t* __restrict_
   uint32_t qlane[4];   // Q fragment ks inside a ring slot: row n, chunk 4 ks + g
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qlane[ks] = (uint32_t)(n * 256 + (((ks * 4 + g) ^ n) << 4));
-  const uint32_t pw_lane = (uint32_t)(XQ_BYTES + (wave * 512 + lane) * 16);        // partial write: [wave][dt][lane]
-  const uint32_t pr_lane = (uint32_t)(XQ_BYTES + (2 * wave * 64 + lane) * 16);      // partial read: [src][2 wave + j][lane]
-  const uint32_t lw_lane = (uint32_t)(XQ_BYTES + XP_O + (wave * 64 + lane) * 4);
-  const uint32_t lr_lane = (uint32_t)(XQ_BYTES + XP_O + lane * 4);
-  const uint32_t st_lane = (uint32_t)n * rs2 + (uint32_t)(wave * 64 + g * 8);       // O store: row n, d = 32 wave + 4 g (+ 16)
+  const uint32_t pw_lane = (uint32_t)(XQ_BYTES + (4 * wave * 64 + lane) * 16);      // P^T write: [4 wave + pair][lane]
+  const uint32_t pr_lane = (uint32_t)(XQ_BYTES + lane * 16);                        // P^T read: [k-step][lane]
+  const uint32_t lw_lane = (uint32_t)(XQ_BYTES + XP_P + (wave * 64 + lane) * 4);
+  const uint32_t lr_lane = (uint32_t)(XQ_BYTES + XP_P + lane * 4);
+  const uint32_t st_lane = (uint32_t)n * rs2 + (uint32_t)(wave * 64 + (g & 1) * 32 + (g >> 1) * 16);   // O store: row n, channels 32 wave + 16 (g & 1) + 8 (g >> 1) .. + 7
 
   XLane L;
-  L.smem = smem; L.lds = lds; L.pw = pw_lane; L.pr = pr_lane; L.lw = lw_lane; L.lr = lr_lane; L.st = st_lane; L.tid = tid;
+  L.smem = smem; L.lds = lds; L.pw = pw_lane; L.pr = pr_lane; L.lw = lw_lane; L.lr = lr_lane; L.st = st_lane;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) L.q[ks] = qlane[ks];
+#ifdef XKV_STAMPS
+  const uint64_t t_start = __builtin_amdgcn_s_memtime();
+  int n_iter = 0;
+#endif
   XState x;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { x.s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; x.o[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < 8; ++i) x.s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  x.o[0] = x.o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  x.pk = xkv_u4{0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) x.pk[i] = xkv_u4{0u, 0u, 0u, 0u};
-  x.lacc = x.lh = x.lw = 0.f;
+  for (int i = 0; i < 4; ++i) x.pf[i] = __builtin_bit_cast(mfma_bf16x8, xkv_u4{0u, 0u, 0u, 0u});
+  x.lacc = x.lh = x.inv = 0.f;
 
   while (v < v_end) {
     // ---- a run: the blocks of ONE (batch, head) pair ------------------------------------------------------------------------------
@@ -263,10 +312,10 @@ __global__ __launch_bounds__(256) void attn_xkv_kernel(const bf16_t* __restrict_
     const int n_tiles = uni((run_rows + 15) >> 4);
 
     // K / V^T of this wave's 128 keys -> the accumulator file
-    mfma_bf16x8 kf[8][4], vf[8][4];
+    mfma_bf16x8 kf[8][4], vf[2][16];
     {
       const bf16_t* kb = Kg + ((int64_t)bk * Lk + wave * 128) * rs + (int64_t)h * 128 + g * 8;
-      const bf16_t* vb = Vt + ((int64_t)bk * H * 128 + (int64_t)h * 128 + n) * ldv + wave * 128 + g * 8;
+      const bf16_t* vb = Vt + ((int64_t)bk * H * 128 + (int64_t)h * 128 + 32 * wave + n) * ldv + g * 8;
 #pragma unroll
       for (int kt = 0; kt < 8; ++kt) {
         const int row = 32 * (kt >> 1) + 8 * (n >> 2) + 4 * (kt & 1) + (n & 3);
@@ -274,13 +323,17 @@ __global__ __launch_bounds__(256) void attn_xkv_kernel(const bf16_t* __restrict_
         for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *reinterpret_cast<const mfma_bf16x8*>(kb + (int64_t)row * rs + ks * 32);
       }
 #pragma unroll
-      for (int dt = 0; dt < 8; ++dt)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) vf[dt][c] = *reinterpret_cast<const mfma_bf16x8*>(vb + (int64_t)(16 * dt) * ldv + 32 * c);
+        for (int C = 0; C < 16; ++C) vf[j][C] = *reinterpret_cast<const mfma_bf16x8*>(vb + (int64_t)(16 * j) * ldv + 32 * C);
 #pragma unroll
       for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { asm volatile("" : "+a"(kf[a][c])); asm volatile("" : "+a"(vf[a][c])); }
+        for (int c = 0; c < 4; ++c) asm volatile("" : "+a"(kf[a][c]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int C = 0; C < 16; ++C) asm volatile("" : "+a"(vf[j][C]));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -297,19 +350,19 @@ __global__ __launch_bounds__(256) void attn_xkv_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) x.qf[ks] = *(lds_frag*)(lds + qlane[ks]);
 
-    // ---- iterations: S^T of tile it, O^T of tile it - 1, sum / store of tile it - 2 ------------------------------------------------------
-    int o_left = run_rows + 32;   // rows from tile it - 2's first to the run's last (<= 0 or > run_rows: no such tile)
+    // ---- iterations: S^T of tile it, O^T of tile it - 1 (k-steps 0..11), O^T k-steps 12..15 and the store of tile it - 2 --------------------
+    int o_left = run_rows + 32;   // rows from tile it - 2's first to the run's last
     for (int it = 0; it < n_tiles + 2; ++it) {
-      const uint32_t pbuf = (uint32_t)((it & 1) * XP_BUF);
-      const uint32_t qoff = (uint32_t)(((it + 1) & (XR - 1)) * XQT);
-      const bool live = it >= 2;                                     // (it - 2 < n_tiles by the loop bound)
-      int valid = o_left > 16 ? 16 : o_left;
-      if (!live) valid = 0;
-      const uint32_t onum = valid > 0 ? (uint32_t)(valid - 1) * rs2 + 256u : 0u;
-      const __amdgpu_buffer_rsrc_t odesc = __builtin_amdgcn_make_buffer_rsrc((void*)(obase + (int64_t)(it - 2) * 16 * (int64_t)rs2), 0, (int)onum, 0x00020000);
       XIter c;
-      c.pbuf = pbuf; c.qoff = qoff; c.live = live; c.odesc = odesc; c.flag = wg_flags + v + ((it - 2) >> 4);
+      c.pb1 = (uint32_t)(((it + 1) & 1) * XP_BUF);
+      c.pb2 = (uint32_t)((it & 1) * XP_BUF);
+      c.qoff = (uint32_t)(((it + 1) & (XR - 1)) * XQT);
+      int valid = o_left > 16 ? 16 : o_left;
+      if (it < 2) valid = 0;                                          // (it - 2 < n_tiles by the loop bound)
+      const uint32_t onum = valid > 0 ? (uint32_t)(valid - 1) * rs2 + 256u : 0u;
+      c.odesc = __builtin_amdgcn_make_buffer_rsrc((void*)(obase + (int64_t)(it - 2) * 16 * (int64_t)rs2), 0, (int)onum, 0x00020000);
       c.lt = 0.f; c.inv = 0.f; c.bad = 0;
+      c.lsrc[0] = c.lsrc[1] = c.lsrc[2] = c.lsrc[3] = 1.f;
 #ifdef XKV_STAMPS
       c.rec = blockIdx.x == 0 && it == 200;
 #endif
@@ -321,8 +374,13 @@ __global__ __launch_bounds__(256) void attn_xkv_kernel(const bf16_t* __restrict_
         xkv_stamps[wave][66] = t1;
       }
 #endif
-      if (__builtin_expect(live && __builtin_amdgcn_ballot_w64(c.bad != 0) != 0, 0)) {   // (every wave holds the same sums: thread 0 speaks)
-        if (tid == 0) *c.flag = 1;
+#ifdef XKV_STAMPS
+      n_iter += 1;
+#endif
+      x.inv = c.inv;
+      // the verdict of tile it - 1 (every wave holds the same sums: thread 0 speaks)
+      if (__builtin_expect(it >= 1 && it <= n_tiles && __builtin_amdgcn_ballot_w64(c.bad != 0) != 0, 0)) {
+        if (tid == 0) wg_flags[v + ((it - 1) >> 4)] = 1;
       }
       o_left -= 16;
     }
@@ -331,6 +389,9 @@ __global__ __launch_bounds__(256) void attn_xkv_kernel(const bf16_t* __restrict_
     asm volatile("" ::: "memory");
     v += nblk;
   }
+#ifdef XKV_STAMPS
+  if (blockIdx.x == 0 && lane == 0) { xkv_stamps[wave][67] = __builtin_amdgcn_s_memtime() - t_start; xkv_stamps[wave][68] = (uint64_t)n_iter; }
+#endif
 }
 
 }  // namespace
@@ -352,7 +413,7 @@ int wan_attention_xkv_launch(unsigned grid, hipStream_t stream, const bf16_t* q,
         fprintf(stderr, "xkv stamps wave %d: iteration %lld; wait+barrier at 24: %lld + %lld; per 8 slots:", w, (long long)(h[w][66] - h[w][0]),
                 (long long)(h[w][64] - h[w][24]), (long long)(h[w][65] - h[w][64]));
         for (int i = 0; i < 64; i += 8) fprintf(stderr, " %lld", (long long)((i < 56 ? h[w][i + 8] : h[w][66]) - h[w][i]));
-        fprintf(stderr, "\n");
+        fprintf(stderr, "; kernel %lld ticks, %lld iterations\n", (long long)h[w][67], (long long)h[w][68]);
       }
   }
 #endif
