@@ -1,5 +1,5 @@
 # full GPU suite, smoke, default bench.py, rocprofv3 kernel trace of a short bench (+ summary and per-kernel roofline table)
-TAG=${TAG:-run}; ROUND=${ROUND:-r05}
+TAG=${TAG:-run}; ROUND=${ROUND:-r06}
 cd $GRAFT_REPO_ROOT; R=$GRAFT_REPO_ROOT; O=gpurun_out/$TAG; mkdir -p $O; export TMPDIR=/tmp
 timeout 180 python -c "import torch; print(torch.zeros(4).cuda().sum().item())" || { echo "GPU init failed"; exit 0; }
 ( time timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider ) > $O/${ROUND}_pytest_gpu_all_$TAG.log 2>&1; echo "rc=$?" >> $O/${ROUND}_pytest_gpu_all_$TAG.log; tail -6 $O/${ROUND}_pytest_gpu_all_$TAG.log

@@ -13,7 +13,7 @@ from rocprof_summarize import short  # noqa: E402
 
 CLASSES = (("self-attention", ("attn_w16n_kernel<shifted", "attn_w16n_kernel<bounded", "attn_w64q_kernel<bounded")),
            ("attention K pre-pass", ("attn_kmax_kernel",)),
-           ("cross-attention + hand-over", ("attn_w16n_kernel<persistent", "attn_w64q_kernel<tracking")),
+           ("cross-attention + hand-over", ("attn_xkv_kernel", "attn_w16n_kernel<persistent", "attn_w64q_kernel<tracking")),
            ("GEMM tile kernels", ("gemm256m_kernel", "gemm256k_kernel", "gemm_fp8m_kernel")),
            ("GEMM small (gemm32 / first generation / gemv)", ("gemm32_kernel", "gemm_bf16_kernel", "gemv_kernel", "gemm_fp8_kernel", "gemm128")),
            ("RMSNorm + RoPE", ("rmsnorm_rope",)),

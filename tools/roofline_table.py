@@ -33,7 +33,9 @@ def main():
     forwards = n_self / w["layers"] if n_self else 0            # forward passes in the trace (one joint CFG pass each)
     # round 6: a self-attention call whose workgroups do not fill their last round of CUs is TWO launches of that name (the split tail's
     # finishing launch); the persistent cross-attention kernel is launched exactly once per block and forward
-    n_cross, _ = tot("attn_w16n_kernel<persistent")
+    n_cross, _ = tot("attn_xkv_kernel")              # round 6: the K / V^T-stationary kernel serves the text branch
+    if not n_cross:
+        n_cross, _ = tot("attn_w16n_kernel<persistent")
     if n_cross:
         forwards = n_cross / w["layers"]
     lines = {}
@@ -51,8 +53,8 @@ def main():
     if "self-attention" in lines:
         lines["self-attention"]["launches"] = n_self
         lines["self-attention"]["calls"] = int(round(forwards * w["layers"]))
-    line("cross-attention (Lk=512)", ("attn_w16n_kernel<persistent", "attn_w64q_kernel<tracking"), w["layers"] * 4.0 * S * L * text * d, "TFLOP/s", 2500.0,
-         "4 S L 512 d per block; the persistent bounded walk (round 4) + every tracking launch of the trace (the hand-over passes behind self- and cross-attention: zero work)")
+    line("cross-attention (Lk=512)", ("attn_xkv_kernel", "attn_w16n_kernel<persistent", "attn_w64q_kernel<tracking"), w["layers"] * 4.0 * S * L * text * d, "TFLOP/s", 2500.0,
+         "4 S L 512 d per block; the K / V^T-stationary kernel (round 6; the persistent bounded walk of round 4 where a trace still has it) + every tracking launch of the trace (the hand-over passes behind self- and cross-attention: zero work)")
     big = w["layers"] * 2.0 * M * (6.0 * d * d + 2.0 * d * ffn)          # q,k,v,o, cross q,o, ffn1, ffn2 per block
     if fp8:
         line("GEMM (scaled fp8)", ("gemm_fp8m_kernel", "gemm_fp8_kernel"), big, "TFLOP/s", 5000.0, "2 M (6 d^2 + 2 d ffn) per block")
