@@ -31,20 +31,20 @@
 //   O^T tile j of wave w: register i of lane (n, g) = O[q row n][d = 32 w + 16 j + 4 g + i]; A = V^T fragment (j, C): channel 32 w + 16 j + n,
 //   keys 32 C + 8 g .. + 7, straight from memory.
 //
-// One iteration I = 64 slots of one MFMA + its fillers.  MFMAs: even slots: S^T of tile I -- slots 0-30: key tiles 0..3, slots 32-62: 4..7, k-step
-// major; odd slots: O^T, four k-steps x two channel tiles per block of 16 -- block 3: tile I - 1, k-steps 0-3; blocks 0, 1, 2: tile I - 2,
-// k-steps 4-7, 8-11, 12-15 (even and odd k-steps in accumulators of their own).  Two MFMAs on one accumulator are EIGHT slots apart.
-// Fillers -- the transcendental in EVERY even slot (MFMA + v_exp_f32 fill a slot's 16 matrix cycles by themselves, attention_w16n.hip), the rest
-// in odd slots:
-//   exp2 of score r = 0..7 of pair p (key tiles 2 p, 2 p + 1) in slot 28 + 16 p + 2 r (mod 64; >= 3 MFMAs behind the tile's last MFMA: asm MFMAs
-//   are not padded by hipcc), in place; its row-sum add THREE slots behind (one behind, hipcc pads the transcendental's result with an s_nop);
-//   the pack of word w of pair p in slot 33 + 16 p + 4 w, its 16 bytes -> LDS in slot 47 + 16 p (pairs 2, 3: slots 15, 31 of the next iteration);
-//   slot 33: the row-sum shares of tile I - 1 -> LDS; slot 35: the Q piece of tile I + 15; slot 37: vmcnt / lgkmcnt + the iteration's barrier;
-//   P^T fragment reads two slots behind the last use of their register, twelve ahead of its next (37 .. 49 | 53 .. 1 | 5 .. 17 | 21 .. 33);
-//   slots 39 .. 61: the four waves' row-sum shares of tile I - 1, their sum over waves and lane groups, 1 / l and the verdict;
-//   slots 48, 50: tile I - 2's two parities added, normalised and packed in front of the next tile's first O^T MFMAs (49, 51); slot 52: one
-//   16-byte store per lane;
-//   slots 39 .. 63: the next tile's Q fragments (fragment ks is last read by slot 38 + 8 ks).
+// One iteration I = 64 slots of one MFMA + its fillers, four blocks of 16.  MFMAs of block p: even slots: S^T of tile I, key tiles 2 p, 2 p + 1
+// (k-step major); odd slots: O^T, four k-steps x two channel tiles -- blocks 2, 3: tile I - 1, k-steps 0-3, 4-7; blocks 0, 1: tile I - 2,
+// k-steps 8-11, 12-15.  Two MFMAs on one accumulator are four slots apart.  Fillers -- the transcendental in EVERY even slot (MFMA + v_exp_f32
+// fill a slot's 16 matrix cycles by themselves, attention_w16n.hip), the rest in odd slots:
+//   exp2 of score r = 0..7 of pair p in slot 16 p + 16 + 2 r (>= 3 MFMAs behind the tile's last MFMA: asm MFMAs are not padded by hipcc), in
+//   place; its row-sum add THREE slots behind (one behind, hipcc pads the transcendental's result with an s_nop: an issue slot -- and this
+//   stream is bound by its instruction count: 4 cycles per instruction of one wave per SIMD, run 30's counters); pair 3 ends in slots 0 .. 17
+//   of the next iteration;
+//   the pack of word w of pair p in slot 16 p + 21 + 4 w, its 16 bytes -> LDS in slot 16 p + 35 (pairs 2, 3: slots 3, 19 of the next iteration);
+//   slot 21: the row-sum shares of tile I - 1 -> LDS; slot 23: the Q piece of tile I + 15; slot 27: vmcnt / lgkmcnt + the iteration's barrier;
+//   P^T fragment reads behind the last use of their register (1, 5 .. 17 | 29 .. 35 | 37 .. 49 | 53 .. 61);
+//   slots 32, 34: tile I - 2 normalised and packed in front of the next tile's first O^T MFMAs (33, 35); slot 36: one 16-byte store per lane;
+//   slots 39 .. 59: the four waves' row-sum shares of tile I - 1, their sum over waves and lane groups, 1 / l and the verdict;
+//   slots 51 .. 63: the next tile's Q fragments.
 #include <stdlib.h>
 
 #include <utility>
@@ -81,33 +81,31 @@ struct XState {
   f32x4 s[8];          // S^T tiles, then P in place
   xkv_u4 pk;           // the pair being packed
   mfma_bf16x8 pf[4];   // P^T fragments of the O^T group in flight
-  f32x4 o[2][2];       // O^T of this wave's 32 channels [channel tile][k-step parity]: an accumulator is revisited every eight slots
+  f32x4 o[2];          // O^T of this wave's 32 channels
   float lacc, lh;      // this lane's share of the row sums: being summed / complete (tile I - 1)
   float inv;           // 1 / l of tile I - 2
 };
 
-// MFMA of slot i.  Even slots: S^T of tile I -- super-block q = i >> 5 holds key tiles 4 q .. 4 q + 3, k-step major, so a tile's accumulator is
-// revisited every eight slots; odd slots: O^T -- block b = i >> 4 holds four k-steps x two channel tiles, even and odd k-steps in accumulators
-// of their own (added at the store): eight slots again.  With fillers between them a dependent MFMA closer than that waits for the
-// write-back (run 28's ablation: 0.12 ms of a 1.76-ms call at four slots).
+// MFMA of slot i.  Block p = i >> 4: S^T of pair p in its even slots, O^T k-steps in its odd slots -- two MFMAs on the SAME accumulator are four
+// slots apart (with fillers between them a dependent MFMA two slots behind its producer waits for the write-back: measured 31 cycles per
+// slot against 20 in this form, run 26 / 27).
 __device__ __forceinline__ void xkv_mfma(XState& x, const mfma_bf16x8 (&kf)[8][4], const mfma_bf16x8 (&vf)[2][16], int i) {
+  const int p = i >> 4, m = (i & 15) >> 1;
   if ((i & 1) == 0) {
-    const int q = i >> 5, m = (i & 31) >> 1;
-    const int kt = 4 * q + (m & 3), ks = m >> 2;
+    const int kt = 2 * p + (m & 1), ks = m >> 1;
     if (ks == 0 || (XKV_ABL & 1)) xs0(x.s[kt], kf[kt][ks], x.qf[ks]);
     else xs1(x.s[kt], kf[kt][ks], x.qf[ks]);
   } else {
-    const int b = i >> 4, m = (i & 15) >> 1;
     const int j = m >> 1, d = m & 1;
-    const int C = ((b + 1) & 3) * 4 + j;      // block 3: k-steps 0..3 of tile I - 1; blocks 0, 1, 2: 4..7, 8..11, 12..15 of tile I - 2
-    if (C < 2 || (XKV_ABL & 1)) xs0(x.o[d][C & 1], vf[d][C], x.pf[j]);
-    else xs1(x.o[d][C & 1], vf[d][C], x.pf[j]);
+    const int C = ((p + 2) & 3) * 4 + j;
+    if (C == 0 || (XKV_ABL & 1)) xs0(x.o[d], vf[d][C], x.pf[j]);
+    else xs1(x.o[d], vf[d][C], x.pf[j]);
   }
 }
-// The exp2 stream of a tile, one transcendental in EVERY even slot: pair p (key tiles 2 p, 2 p + 1; complete at slots 26, 30, 58, 62) from slot
-// 28 + 16 p on, score r = 0..7 in slot 28 + 16 p + 2 r (mod 64: pair 2 ends, pair 3 runs in the next iteration), in place.
-__device__ __forceinline__ constexpr int xkv_exp_pair(int i) { return ((i + 36) & 63) >> 4; }
-__device__ __forceinline__ constexpr int xkv_exp_reg(int i) { return (((i + 36) & 63) & 15) >> 1; }
+// The exp2 stream of a tile: score r = 0..7 of pair p in the EVEN slot 16 p + 16 + 2 r (pair 3: 0 .. 14 of the next iteration), its row-sum add
+// in the odd slot behind it, in place.
+__device__ __forceinline__ constexpr int xkv_exp_pair(int i) { return i >= 16 ? (i - 16) >> 4 : 3; }
+__device__ __forceinline__ constexpr int xkv_exp_reg(int i) { return (i & 15) >> 1; }
 __device__ __forceinline__ void xkv_exp(XState& x, int i) {   // i: an even slot
   if (XKV_ABL & 2) return;
   const int p = xkv_exp_pair(i), r = xkv_exp_reg(i);
@@ -115,17 +113,17 @@ __device__ __forceinline__ void xkv_exp(XState& x, int i) {   // i: an even slot
   asm volatile("" : "+v"(v));
   x.s[2 * p + (r >> 2)][r & 3] = v;
 }
-__device__ __forceinline__ void xkv_sum(XState& x, int i) {   // i: the odd slot THREE behind an exp2 (one behind, hipcc pads the transcendental's result with an s_nop)
-  if (XKV_ABL & 2) return;
+__device__ __forceinline__ void xkv_sum(XState& x, int i) {   // i: the odd slot THREE behind an exp2 (one behind, hipcc pads the transcendental's
+  if (XKV_ABL & 2) return;                                    // result with an s_nop -- an issue slot; this stream is bound by its instruction count)
   const int e = (i + 61) & 63;
   const int p = xkv_exp_pair(e), r = xkv_exp_reg(e);
   x.lacc += x.s[2 * p + (r >> 2)][r & 3];
   asm volatile("" : "+v"(x.lacc));
 }
-// pack word w of pair p: odd slot 33 + 16 p + 4 w (mod 64), three behind its second exp2
+// pack word w of pair p: odd slot 16 p + 21 + 4 w, three behind its second exp2 (pair 3: 5, 9, 13, 17 of the next iteration)
 __device__ __forceinline__ void xkv_pack(XState& x, int i) {
   if (XKV_ABL & 2) return;
-  const int k = (i + 31) & 63;
+  const int k = i >= 21 ? i - 21 : i + 43;
   const int p = k >> 4, w = (k & 15) >> 2;
   if ((k & 3) != 0) return;
   const f32x4& t = x.s[2 * p + (w >> 1)];
@@ -176,13 +174,12 @@ __device__ __forceinline__ void xkv_slot(XState& x, const mfma_bf16x8 (&kf)[8][4
   SB();
   if ((i & 1) == 0) {
     xkv_exp(x, i);
-    // tile I - 2's finished O^T tile d (last MFMAs: slots 41 + 2 d, 45 + 2 d) -- its two k-step parities added, normalised, packed -- in front of
-    // the next tile's first MFMA on those accumulators (slot 49 + 2 d): a value kept across it lives in other registers, and hipcc then returns
-    // the loop-carried accumulator to its own with v_movs straight in front of an asm MFMA that reads it -- two wait states short, silently
-    // (run 27: registers 2, 3 stale)
-    if (i == 48 || i == 50) {
-      constexpr int d = ((i - 48) >> 1) & 1;
-      const f32x4 t = x.o[d][0] + x.o[d][1];
+    // tile I - 2's finished O^T tile d (last MFMA: slot 29 + 2 d) normalised, packed, stored -- in front of the next tile's first MFMA on that
+    // accumulator (slot 33 + 2 d): a value kept across it lives in other registers, and hipcc then returns the loop-carried accumulator to
+    // its own with v_movs straight in front of an asm MFMA that reads it -- two wait states short, silently (run 27: registers 2, 3 stale)
+    if (i == 32 || i == 34) {
+      constexpr int d = ((i - 32) >> 1) & 1;
+      const f32x4 t = x.o[d];
       c.ow[2 * d] = cvt_pk(t[0] * x.inv, t[1] * x.inv);
       c.ow[2 * d + 1] = cvt_pk(t[2] * x.inv, t[3] * x.inv);
     }
@@ -190,7 +187,7 @@ __device__ __forceinline__ void xkv_slot(XState& x, const mfma_bf16x8 (&kf)[8][4
     // (vdst = tile 0's word, vsrc = tile 1's: vdst's odd rows <-> vsrc's even rows) leaves an even group with tile 0's channels 4 g .. 4 g + 7
     // and the odd group behind it with tile 1's 4 (g - 1) .. + 7 -- 8 consecutive channels.  (Two 8-byte stores per lane cost the stream
     // 0.2 ms of a 1.8-ms call: run 28's ablation -- a wave's store instruction is priced by the rows it touches, not by its bytes.)
-    if (i == 52) {
+    if (i == 36) {
       const auto r0 = __builtin_amdgcn_permlane16_swap(c.ow[0], c.ow[2], false, false);
       const auto r1 = __builtin_amdgcn_permlane16_swap(c.ow[1], c.ow[3], false, false);
       xkv_u4 w = {r0[0], r1[0], r0[1], r1[1]};
@@ -198,7 +195,7 @@ __device__ __forceinline__ void xkv_slot(XState& x, const mfma_bf16x8 (&kf)[8][4
       else asm volatile("" :: "v"(w));
     }
   } else {
-    if (i == 37 && !(XKV_ABL & 8)) {   // the iteration's barrier, in front of the slot's other fillers
+    if (i == 27 && !(XKV_ABL & 8)) {   // the iteration's barrier, in front of the slot's other fillers
       asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");   // this wave's piece of tile I + 1 landed; its P^T and row sums of tile I - 1 are written
       XST(64);
       __builtin_amdgcn_s_barrier();
@@ -206,41 +203,41 @@ __device__ __forceinline__ void xkv_slot(XState& x, const mfma_bf16x8 (&kf)[8][4
       XST(65);
     }
     xkv_sum(x, i);
-    if (i == 29) { x.lh = (XKV_ABL & 2) ? 1.f : x.lacc; x.lacc = 0.f; asm volatile("" : "+v"(x.lh), "+v"(x.lacc)); }   // (behind the add of tile I - 1's last exp2, slot 26; slot 31 adds tile I's first)
+    if (i == 17) { x.lh = (XKV_ABL & 2) ? 1.f : x.lacc; x.lacc = 0.f; asm volatile("" : "+v"(x.lh), "+v"(x.lacc)); }   // (behind the add of the tail's last exp2, slot 14; slot 19 adds the new tile's first)
     xkv_pack(x, i);
     // the packed pair -> LDS slot [4 wave + pair][lane]: pairs 0, 1 of tile I (its buffer = tile I - 2's), pairs 2, 3 of tile I - 1
-    if (!(XKV_ABL & 4)) if (i == 47) *reinterpret_cast<xkv_u4*>(L.smem + c.pb2 + L.pw + 0 * 1024) = x.pk;
-    if (!(XKV_ABL & 4)) if (i == 63) *reinterpret_cast<xkv_u4*>(L.smem + c.pb2 + L.pw + 1 * 1024) = x.pk;
-    if (!(XKV_ABL & 4)) if (i == 15) *reinterpret_cast<xkv_u4*>(L.smem + c.pb1 + L.pw + 2 * 1024) = x.pk;
-    if (!(XKV_ABL & 4)) if (i == 31) *reinterpret_cast<xkv_u4*>(L.smem + c.pb1 + L.pw + 3 * 1024) = x.pk;
-    if (!(XKV_ABL & 4)) if (i == 33) *reinterpret_cast<float*>(L.smem + c.pb1 + L.lw) = x.lh;
-    if (i == 35) xkv_q_issue(q);
-    // P^T fragment reads: register j behind its last use (slot 16 b + 4 j + 3 of the block in flight), twelve slots ahead of its next
-    if (!(XKV_ABL & 4) && (i == 37 || i == 41 || i == 45 || i == 49)) { constexpr int j = ((i - 37) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb1 + L.pr + (0 + j) * 1024); }  // tile I - 1, k-steps 0..3 (behind the barrier)
-    if (!(XKV_ABL & 4) && (i == 53 || i == 57 || i == 61)) { constexpr int j = ((i - 53) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb1 + L.pr + (4 + j) * 1024); }             // k-steps 4..6 (the next iteration's block 0)
-    if (!(XKV_ABL & 4) && i == 1) x.pf[3] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb2 + L.pr + 7 * 1024);                                                                                 // tile I - 2, k-step 7
-    if (!(XKV_ABL & 4) && (i == 5 || i == 9 || i == 13 || i == 17)) { constexpr int j = ((i - 5) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb2 + L.pr + (8 + j) * 1024); }     // tile I - 2, k-steps 8..11
-    if (!(XKV_ABL & 4) && (i == 21 || i == 25 || i == 29 || i == 33)) { constexpr int j = ((i - 21) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb2 + L.pr + (12 + j) * 1024); } // tile I - 2, k-steps 12..15
+    if (!(XKV_ABL & 4)) if (i == 35) *reinterpret_cast<xkv_u4*>(L.smem + c.pb2 + L.pw + 0 * 1024) = x.pk;
+    if (!(XKV_ABL & 4)) if (i == 51) *reinterpret_cast<xkv_u4*>(L.smem + c.pb2 + L.pw + 1 * 1024) = x.pk;
+    if (!(XKV_ABL & 4)) if (i == 3) *reinterpret_cast<xkv_u4*>(L.smem + c.pb1 + L.pw + 2 * 1024) = x.pk;
+    if (!(XKV_ABL & 4)) if (i == 19) *reinterpret_cast<xkv_u4*>(L.smem + c.pb1 + L.pw + 3 * 1024) = x.pk;
+    if (!(XKV_ABL & 4)) if (i == 21) *reinterpret_cast<float*>(L.smem + c.pb1 + L.lw) = x.lh;
+    if (i == 23) xkv_q_issue(q);
+    // P^T fragment reads: register j behind its last use (slot 16 p + 4 j + 3 of the block in flight), 6 to 12 slots ahead of its next
+    if (!(XKV_ABL & 4) && (i == 5 || i == 9 || i == 13 || i == 17)) { constexpr int j = ((i - 5) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb2 + L.pr + (12 + j) * 1024); }    // tile I - 2, k-steps 12..15
+    if (!(XKV_ABL & 4) && (i == 29 || i == 31 || i == 33 || i == 35)) { constexpr int j = ((i - 29) >> 1) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb1 + L.pr + (0 + j) * 1024); }  // tile I - 1, k-steps 0..3 (behind the barrier)
+    if (!(XKV_ABL & 4) && (i == 37 || i == 41 || i == 45 || i == 49)) { constexpr int j = ((i - 37) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb1 + L.pr + (4 + j) * 1024); }  // k-steps 4..7
+    if (!(XKV_ABL & 4) && (i == 53 || i == 57 || i == 61)) { constexpr int j = ((i - 53) >> 2) & 3; x.pf[j] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb1 + L.pr + (8 + j) * 1024); }             // k-steps 8..10 (the next iteration's block 0)
+    if (!(XKV_ABL & 4) && i == 1) x.pf[3] = *reinterpret_cast<const mfma_bf16x8*>(L.smem + c.pb2 + L.pr + 11 * 1024);                                                                                  // tile I - 2, k-step 11
     // the row sums of tile I - 1: four waves' shares, the four lane groups (v_permlane16_swap / v_permlane32_swap: VALU, no LDS round trip)
     if (!(XKV_ABL & 4) && i == 39) { c.lsrc[0] = *reinterpret_cast<const float*>(L.smem + c.pb1 + L.lr); c.lsrc[1] = *reinterpret_cast<const float*>(L.smem + c.pb1 + L.lr + 256); }
     if (!(XKV_ABL & 4) && i == 43) { c.lsrc[2] = *reinterpret_cast<const float*>(L.smem + c.pb1 + L.lr + 512); c.lsrc[3] = *reinterpret_cast<const float*>(L.smem + c.pb1 + L.lr + 768); }
-    if (i == 51) c.lt = (c.lsrc[0] + c.lsrc[1]) + (c.lsrc[2] + c.lsrc[3]);
-    if (i == 53) {
+    if (i == 47) c.lt = (c.lsrc[0] + c.lsrc[1]) + (c.lsrc[2] + c.lsrc[3]);
+    if (i == 51) {
       const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(c.lt), __float_as_uint(c.lt), false, false);
       c.lt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
-    if (i == 57) {
+    if (i == 55) {
       const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c.lt), __float_as_uint(c.lt), false, false);
       c.lt = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
-    if (i == 61) {
+    if (i == 59) {
       c.inv = __builtin_amdgcn_rcpf(c.lt);
       asm volatile("" : "+v"(c.inv));
       // (no branch inside the stream: a block boundary lets the code sinker pull values down to their first use)
       c.bad = !(c.lt >= X_MIN_ROWSUM && c.lt <= X_MAX_ROWSUM) ? 1 : 0;
     }
-    if (i == 39 || i == 47 || i == 55 || i == 63) {   // the next tile's Q fragment ks (last read by slot 38 + 8 ks)
-      constexpr int ks = ((i - 39) >> 3) & 3;
+    if (i == 51 || i == 55 || i == 59 || i == 63) {   // the next tile's Q fragment ks (last read by slot 50 + 4 ks)
+      constexpr int ks = ((i - 51) >> 2) & 3;
       x.qf[ks] = *(lds_frag*)(L.lds + c.qoff + L.q[ks]);
     }
   }
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_xkv_kernel(const bf16_t* __restrict_
   XState x;
 #pragma unroll
   for (int i = 0; i < 8; ++i) x.s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  x.o[0][0] = x.o[0][1] = x.o[1][0] = x.o[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  x.o[0] = x.o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
   x.pk = xkv_u4{0u, 0u, 0u, 0u};
 #pragma unroll
   for (int i = 0; i < 4; ++i) x.pf[i] = __builtin_bit_cast(mfma_bf16x8, xkv_u4{0u, 0u, 0u, 0u});
