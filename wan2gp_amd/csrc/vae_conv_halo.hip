@@ -60,7 +60,11 @@ __device__ __forceinline__ const char* huni(const char* p) {
   return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
-template <int KT, bool UPS, int NB>  // NB: 16-channel tiles per wave -- 4: 128 output channels per workgroup; 3: 96 (Cout a multiple of 96: the 96- / 192- /
+template <int KT, bool UPS, int NB, int WCX = 2>  // WCX: waves across the output channels -- 2: wave (wr = wave >> 1, wc = wave & 1) owns 4 pixel rows x NB channel tiles
+                                     // (the forms above); 1 (round 6, NB = 1): a convolution of at most 16 output channels -- the decoder's head, 96 -> 3 --
+                                     // gives every wave 2 pixel rows x ONE channel tile: the 96-wide tile spent 32 MFMAs on 3 channels (5 % of a
+                                     // 720p decode's matrix time); same K order per output element, so the same bits.
+                                     // NB: 16-channel tiles per wave -- 4: 128 output channels per workgroup; 3: 96 (Cout a multiple of 96: the 96- / 192- /
                                      // 384-channel levels -- a 128-wide tile would spend a quarter of its MFMAs on channels that do not exist).  KT = 3: the causal 3 x 3 x 3 convolution; KT = 1: Resample's Conv2d 3 x 3 -- UPS: on the nearest-exact 2x up-sampled input (vae.py:105-111,
                              // :124-141), i.e. patch pixel (hi, wi) of the up-sampled frame is input pixel (hi >> 1, wi >> 1); p.H / p.W are the OUTPUT sizes
 __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
@@ -68,7 +72,8 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  constexpr int RT = 16 / (8 / WCX);        // pixel rows (MFMA tiles) per wave: 4 with two waves across the channels, 2 with one
+  const int wr = WCX == 2 ? wave >> 1 : wave, wc = WCX == 2 ? (wave & 1) : 0;
   const int n = lane & 15, lg = lane >> 4;
 
   const int nwg = p.Tout * p.tiles_h * p.tiles_w * p.tiles_x;
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   const int th = wg % p.tiles_h;
   const int to = wg / p.tiles_h;
   constexpr int NW = NB * 16;            // output channels per wave
-  const int h0 = th * HT, w0 = tw * HT, x0 = tx * (2 * NW);
+  const int h0 = th * HT, w0 = tw * HT, x0 = tx * (WCX * NW);
   const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;   // the stored input frame
   const int64_t frame = (int64_t)Hs * Ws * p.Cin;
 
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
   }
   // ---- weight piece: 16 rows x 64 B of a stage per wave (NB = 3: six pieces, waves 6 and 7 repeat pieces 0 and 1)
   uint32_t wvoff;
-  const int wpiece = __builtin_amdgcn_readfirstlane(wave % (2 * NB));
+  const int wpiece = __builtin_amdgcn_readfirstlane(wave % (WCX * NB));
   {
     const int R = wpiece * 16 + (lane >> 2), slot = lane & 3;
     const int c = slot ^ ((R >> 1) & 2);
@@ -132,15 +137,15 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
     hglds_s(wvoff, huni(reinterpret_cast<const char*>(p.w) + (int64_t)u * 64), lds0 + HW0 + stage * HWST + wpiece * 1024);
   };
 
-  f32x4 acc[4][NB];
+  f32x4 acc[RT][NB];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int ybase[4];
+  int ybase[RT];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) ybase[a] = ((4 * wr + a) * HP + n) * HPITCH + lg * 16;   // before the swizzle (it depends on the tap: bit 2 of the patch pixel)
+  for (int a = 0; a < RT; ++a) ybase[a] = ((RT * wr + a) * HP + n) * HPITCH + lg * 16;   // before the swizzle (it depends on the tap: bit 2 of the patch pixel)
   const int xbase = HW0 + (wc * NW + n) * 64 + ((lg ^ ((n >> 1) & 2)) << 4);   // (NW is a multiple of 16: bit 2 of the row is bit 2 of n)
 
   int kt = 0, cb = 0;                                   // group g
@@ -166,13 +171,15 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
     issue_w((TAP) + 2 < 9 ? ub + ((TAP) + 2) * p.CB : ub1 + ((TAP) + 2 - 9) * p.CB, ((TAP) + 2) % 3);                               \
     if ((TAP) == 0) issue_patch((g + 1) & 1, kt1, cb1);                                                                            \
     constexpr int dy = (TAP) / 3, dx = (TAP) % 3;                                                                                  \
-    halo_f16x8 yf[4], xf[NB];                                                                                                      \
+    halo_f16x8 yf[RT], xf[NB];                                                                                                     \
     _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                                                \
-      const int ya = ybase[t] + (poff + (dy * HP + dx) * HPITCH);                                                                  \
-      yf[t] = *reinterpret_cast<const halo_f16x8*>(smem + (ya ^ ((ya >> 3) & 32)));   /* chunk slot ^= 2 where bit 2 of the pixel is set (poff is a multiple of 512) */ \
-      if (t < NB) xf[t] = *reinterpret_cast<const halo_f16x8*>(smem + xbase + ((TAP) % 3) * HWST + t * 1024);                      \
+      if (t < RT) {                                                                                                                \
+        const int ya = ybase[t < RT ? t : 0] + (poff + (dy * HP + dx) * HPITCH);                                                   \
+        yf[t < RT ? t : 0] = *reinterpret_cast<const halo_f16x8*>(smem + (ya ^ ((ya >> 3) & 32)));   /* chunk slot ^= 2 where bit 2 of the pixel is set (poff is a multiple of 512) */ \
+      }                                                                                                                            \
+      if (t < NB) xf[t < NB ? t : 0] = *reinterpret_cast<const halo_f16x8*>(smem + xbase + ((TAP) % 3) * HWST + t * 1024);         \
     }                                                                                                                              \
-    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < RT; ++a)                                                                                 \
       _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                               \
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[b], yf[a], acc[a][b], 0, 0, 0);                                      \
   }
@@ -199,8 +206,8 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
       if (xb + j < p.Cout) bcol[j] = h2f(p.bias[xb + j]);
   }
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int h = h0 + 4 * wr + a, w = w0 + n2;
+  for (int a = 0; a < RT; ++a) {
+    const int h = h0 + RT * wr + a, w = w0 + n2;
     if (h >= p.H || w >= p.W) continue;
     const int64_t pp = ((int64_t)to * p.H + h) * p.W + w;
     float v[NV];
@@ -259,12 +266,14 @@ int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache0, const 
   // the tile width that pads Cout least: 96 for the 96 / 192 / 384-channel levels (exact), for 160 (192 against 256), for the 32-channel
   // heads and latents; 128 for 128, 256, 640, 1024 ...
   const bool n96 = (Cout + 95) / 96 * 96 < (Cout + 127) / 128 * 128;
-  p.tiles_h = (H + HT - 1) / HT; p.tiles_w = (W + HT - 1) / HT; p.tiles_x = n96 ? (Cout + 95) / 96 : (Cout + 127) / 128;
+  const bool n16 = Cout <= 16 && KT == 3 && !ups;   // the decoder's head (96 -> 3): one 16-channel tile, every wave on pixels
+  p.tiles_h = (H + HT - 1) / HT; p.tiles_w = (W + HT - 1) / HT; p.tiles_x = n16 ? 1 : (n96 ? (Cout + 95) / 96 : (Cout + 127) / 128);
   const int64_t nwg = (int64_t)Tout * p.tiles_h * p.tiles_w * p.tiles_x;
   if (nwg == 0) return 0;
   WAN_REQUIRE(nwg < ((int64_t)1 << 31), "wan_vae_conv3d: grid too large");
 #define HALO_GO(K, U, N) hipLaunchKernelGGL((conv3d_halo_kernel<K, U, N>), dim3((unsigned)nwg), dim3(512), 0, stream, p)
-  if (KT == 3) { if (n96) HALO_GO(3, false, 3); else HALO_GO(3, false, 4); }
+  if (n16) hipLaunchKernelGGL((conv3d_halo_kernel<3, false, 1, 1>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
+  else if (KT == 3) { if (n96) HALO_GO(3, false, 3); else HALO_GO(3, false, 4); }
   else if (ups) { if (n96) HALO_GO(1, true, 3); else HALO_GO(1, true, 4); }
   else { if (n96) HALO_GO(1, false, 3); else HALO_GO(1, false, 4); }
 #undef HALO_GO
