@@ -142,8 +142,12 @@ def gen_forward_mixed(ns, name, f, h, w, tval):
     m = build_ref_model(ns, cfg, W, dtype, mixed=True)
     assert m.time_projection[1].weight.dtype == torch.float32 and m.blocks[0].norm3.weight.dtype == torch.float32
     assert m.blocks[0].self_attn.q.weight.dtype == dtype and m.text_embedding[0].weight.dtype == dtype
-    r = ref_forward(ns, m, [lat, lat], t, [ctx.to(dtype), ctx_null.to(dtype)], y=y)
+    # Wan2.1 i2v / flf2v: the CLIP tokens (img_emb, k_img / v_img stay in the checkpoint's dtype: no lock names them, model.py:1330-1371)
+    clip = O.synth_clip_fea(images=2 if cfg.flf else 1) if cfg.model_type == "i2v" else None
+    r = ref_forward(ns, m, [lat, lat], t, [ctx.to(dtype), ctx_null.to(dtype)], y=y, clip_fea=clip)
     out["cond_mixed"], out["uncond_mixed"] = f32(r[0]), f32(r[1])
+    if clip is not None:
+        assert m.img_emb.proj[1].weight.dtype == dtype and m.blocks[0].cross_attn.k_img.weight.dtype == dtype
     if name == "tiny_ti2v":                                     # per-frame timesteps
         tf = torch.full((f,), tval, dtype=torch.int64)
         tf[:1] = 0
@@ -279,6 +283,9 @@ def main():
         gen_forward_mixed(ns, "tiny_i2v", 2, 8, 8, 912)      # i2v2_2: y (mask + latents) concatenated in front of the patch embedding
         gen_forward_mixed(ns, "tiny_ti2v", 2, 6, 10, 455)    # + per-frame timesteps: e0 [frames, 6, dim] in fp32
         gen_forward_mixed(ns, "small", 3, 10, 14, 412)
+    if "mixed_clip" in which:                                # round 6: the mixed plan with the Wan2.1 i2v CLIP branch (one image, and flf2v's two)
+        gen_forward_mixed(ns, "tiny_i2v21", 2, 8, 8, 731)
+        gen_forward_mixed(ns, "tiny_flf2v", 2, 8, 8, 644)
     if "sched" in which:
         gen_sched(ns)
     if "sched2" in which:

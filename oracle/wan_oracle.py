@@ -527,8 +527,8 @@ def dit_forward(x_list: List[torch.Tensor], t: torch.Tensor, context_list: List[
     # mixed-precision locks (synth_weights(mixed=True)) -- then the residual stream runs in fp32 between bf16 Linears (block_forward `adt`)
     mdt = W["time_projection.1.weight"].dtype
     adt = dtype if mdt != dtype else None
-    if adt is not None and (vace_context is not None or clip_fea is not None):
-        raise NotImplementedError("wan_oracle: the mixed-precision plan is restated for the t2v / i2v2_2 / ti2v block chain only")
+    if adt is not None and vace_context is not None:
+        raise NotImplementedError("wan_oracle: the mixed-precision plan is restated for the t2v / i2v2_2 / ti2v / i2v (CLIP) block chain, not for VACE")
     for x in x_list:
         if y is not None:                                   # model.py:1597-1600
             yy = y.unsqueeze(0)

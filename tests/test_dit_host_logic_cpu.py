@@ -774,6 +774,29 @@ def _clip_forward(L, m, S, nag=None, ctx_batches=None):
     return rc, [(c.name.decode(), list(c.p), list(c.i), list(c.f)) for c in (L.mock_get(i).contents for i in range(L.mock_count()))]
 
 
+def test_mixed_precision_plan_serves_the_clip_branch(mock):
+    """Round 6: a Wan2.1 i2v model under the mixed-precision plan (no lock of model.py:1330-1371 names img_emb or k_img / v_img).  The CLIP
+    branch is the bf16 plan's own -- text attention into xm, the 257 CLIP tokens attended in place, the two results added -- between the fp32
+    norm3 in front of the q Linear and the fp32-stream o projection behind it; nothing of the bf16 plan's row kernels runs."""
+    L = mock
+    L.wan_dit_set_clip.argtypes = [c_void_p, c_void_p, c_void_p]
+    m = Model(L, "tiny_i2v21", mixed=True)
+    assert L.wan_dit_set_clip(m.ctx, c_void_p(0x6700_0000_0000), None) == 0, L.wan_last_error()
+    rc, calls = _clip_forward(L, m, 2)
+    assert rc == 0, L.wan_last_error()
+    names = [cl[0] for cl in calls]
+    assert not {"ln_modulate", "ln_affine", "head", "patch_embed"} & set(names)
+    i0 = names.index("mx_ln_affine")                                        # block 0's norm3
+    j0 = i0 + 1 + names[i0 + 1:].index("gemm_res32")                         # ... its cross-attention o projection into the fp32 stream
+    seg = names[i0:j0 + 1]
+    assert seg.count("attention") == 2 and seg.count("add") == 1 and seg.index("add") > max(k for k, n in enumerate(seg) if n == "attention")
+    att = [cl for cl in calls[i0:j0] if cl[0] == "attention"]
+    add = [cl for cl in calls[i0:j0] if cl[0] == "add"][0]
+    assert att[0][1][0] == att[1][1][0] == att[1][1][3] and att[0][1][3] != att[0][1][0]        # same q; text result elsewhere (xm), CLIP result in place
+    assert add[1][:3] == [att[0][1][3], att[1][1][3], att[1][1][3]]                               # q <- text + image
+    assert calls[j0][1][0] == att[1][1][3]                                                       # the o projection reads the sum
+
+
 def test_flf2v_clip_context_of_two_images(mock):
     """flf2v_720p (model.py:878-887, :472-473): img_emb adds its position embedding to the 2 x 257 CLIP tokens and projects 514; the
     blocks' image branch takes the first 257 of them, the text branch [the other 257 ; the 512 text tokens] -- assembled once per

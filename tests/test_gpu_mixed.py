@@ -146,7 +146,7 @@ def build(cfg, seed=1234):
     return m, W
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "small"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "small", "tiny_i2v21", "tiny_flf2v"])
 def test_mixed_forward_vs_reference_golden(name):
     g = load(f"forward_{name}_mixed.npz")
     f, h, w = [int(v) for v in g["shape"]]
@@ -156,9 +156,13 @@ def test_mixed_forward_vs_reference_golden(name):
     assert m._weights["blocks.0.self_attn.q.weight"].dtype == BF
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
     t = torch.tensor([int(g["t"][0])], dtype=torch.int64)
-    outs = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()], y=None if y is None else y.cuda())
+    # (round 6: Wan2.1 i2v / flf2v -- the CLIP branch inside the plan; the reference's own run with the locks: oracle/make_golden.py mixed_clip)
+    clip = O.synth_clip_fea(images=2 if cfg.flf else 1) if cfg.model_type == "i2v" else None
+    kw = {} if clip is None else {"clip_fea": clip.cuda()}
+    outs = m([lat.cuda(), lat.cuda()], t=t, context=[ctx.cuda(), ctx_null.cuda()], y=None if y is None else y.cuda(), **kw)
     W32 = O.synth_weights(cfg, dtype=torch.float32)
-    anchor = O.dit_forward([lat, lat], t, [ctx.float(), ctx_null.float()], W32, cfg, y=y, dtype=torch.float32, exact=True)
+    anchor = O.dit_forward([lat, lat], t, [ctx.float(), ctx_null.float()], W32, cfg, y=y, dtype=torch.float32, exact=True,
+                           clip_fea=None if clip is None else clip.float())
     gb = load(f"forward_{name}.npz")
     for o, key, a in zip(outs, ("cond", "uncond"), anchor):
         assert o.dtype == torch.float32 and tuple(o.shape) == (1, cfg.out_dim, f, h, w)
@@ -181,8 +185,6 @@ def test_mixed_forward_vs_reference_golden(name):
 
 def test_mixed_plan_refuses_what_it_does_not_serve():
     from wan2gp_amd.model import WanModelHIP
-    with pytest.raises(NotImplementedError):
-        WanModelHIP(model_type="i2v", dim=256, ffn_dim=512, num_heads=2, num_layers=2, mixed_precision=True)
     with pytest.raises(NotImplementedError):
         WanModelHIP(dim=256, ffn_dim=512, num_heads=2, num_layers=2, vace_layers=[0], mixed_precision=True)
 

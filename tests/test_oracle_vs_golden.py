@@ -116,7 +116,7 @@ def test_forward_matches_reference(name, tag, dtype):
         assert rel < 1e-2, rel
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "small"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_i2v", "tiny_ti2v", "small", "tiny_i2v21", "tiny_flf2v"])
 def test_forward_mixed_precision_plan_matches_reference(name):
     """`mixed_precision_transformer` (wgp.py:4039 -> any2video.py:190 -> lock_layers_dtypes(torch.float32), model.py:1330-1371): the time
     MLP, the time projection and every norm3 hold their bf16-valued weights in fp32, and by type promotion the residual stream, e / e0 and
@@ -134,7 +134,9 @@ def test_forward_mixed_precision_plan_matches_reference(name):
     assert all(torch.equal(W[k].float(), Wb[k].float()) for k in W)          # the same values: the upcast of a bf16 checkpoint is exact
     lat, ctx, ctx_null, y = O.synth_inputs(cfg, f, h, w)
     tt = torch.tensor([int(g["t"][0])], dtype=torch.int64)
-    cond, uncond = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, y=y, dtype=dtype)
+    # (round 6: the Wan2.1 i2v / flf2v CLIP branch under the plan -- no lock names img_emb or k_img / v_img: they stay bf16)
+    clip = O.synth_clip_fea(images=2 if cfg.flf else 1) if cfg.model_type == "i2v" else None
+    cond, uncond = O.dit_forward([lat, lat], tt, [ctx.to(dtype), ctx_null.to(dtype)], W, cfg, y=y, dtype=dtype, clip_fea=clip)
     assert torch.equal(cond, t(g["cond_mixed"])) and torch.equal(uncond, t(g["uncond_mixed"]))
     gb = load(f"forward_{name}.npz")
     rel = ((cond - t(gb["cond_bf16"])).norm() / t(gb["cond_bf16"]).norm()).item()

@@ -738,14 +738,15 @@ struct Forward {
     }
     mx = c->mixed;
     const int64_t need = carve_all(g, S, Ll, world, workspace, &b, c->vace_layers.empty() ? 0 : c->vace_max_ctx, c->any_fp8, F, mx);
-    // the mixed-precision plan serves the block chain of the t2v / i2v2_2 / ti2v models (also under sequence parallelism, NAG, skip-layer
-    // guidance, fp8 Linears); what keeps bf16 state of its own is refused rather than silently run in the other plan
+    // the mixed-precision plan serves the block chain of the t2v / i2v2_2 / ti2v / i2v (CLIP) models (also under sequence parallelism, NAG,
+    // skip-layer guidance, fp8 Linears); what keeps bf16 state of its own is refused rather than silently run in the other plan
     bool any_residual = false;
     for (int s = 0; residual != nullptr && s < S; ++s) any_residual = any_residual || residual[s] != nullptr;
     (void)any_residual;   // (round 5: the step-skipping caches run in the mixed plan too -- their residual buffers then hold fp32 rows)
-    WAN_REQUIRE(!mx || (n_vace == 0 && c->vace_layers.empty() && !c->has_img),
-                "wan_dit_forward: the mixed-precision plan (fp32 time_projection / norm3 weights) does not serve VACE context blocks or the "
-                "Wan2.1 i2v CLIP branch");
+    // (round 6: the Wan2.1 i2v / flf2v CLIP branch runs in the plan -- no lock of model.py:1330-1371 names img_emb or k_img / v_img, so the
+    // branch is the bf16 plan's own between the fp32 norm3 in front of the q Linear and the fp32-stream o projection behind it)
+    WAN_REQUIRE(!mx || (n_vace == 0 && c->vace_layers.empty()),
+                "wan_dit_forward: the mixed-precision plan (fp32 time_projection / norm3 weights) does not serve VACE context blocks");
     x32 = reinterpret_cast<float*>(b.x);
     WAN_REQUIRE(workspace_bytes >= need, "wan_dit_forward: workspace %lld < required %lld bytes",
                 (long long)workspace_bytes, (long long)need);

@@ -73,9 +73,9 @@ class WanModelHIP:
         self.patch_size = tuple(patch_size)
         self.device = torch.device(device)
         self.mixed_precision = bool(mixed_precision)
-        if self.mixed_precision and (vace_layers is not None or model_type == "i2v"):
-            raise NotImplementedError("mixed_precision: the fp32-stream plan serves the t2v / i2v2_2 / ti2v2_2 block chain; VACE context blocks "
-                                      "and the Wan2.1 i2v CLIP branch run in the bf16 plan only")
+        if self.mixed_precision and vace_layers is not None:
+            raise NotImplementedError("mixed_precision: the fp32-stream plan serves the t2v / i2v2_2 / ti2v2_2 / i2v (CLIP) block chains; VACE "
+                                      "context blocks run in the bf16 plan only")
         self.cache = None
         # the forward as a replayed launch list (wan_dit_forward_graph, csrc/dit.hip): "auto" = when the joint pass holds at most
         # graph_max_tokens tokens (launch-bound shapes: BASELINE configs[0] is 6,400; 480p x 81 frames is 65,520), "on" / "off";

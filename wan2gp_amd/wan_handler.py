@@ -277,8 +277,9 @@ class family_handler():
             raise ValueError("load_model: no checkpoint given")
         # mixed_precision_transformer (wgp.py:4039 server setting "mixed_precision" -> any2video.py:190 lock_layers_dtypes(torch.float32)):
         # the time MLP, the time projection and every norm3 are registered in fp32 and the library runs its fp32-stream plan (csrc/mixed_ops.hip;
-        # tests/test_gpu_mixed.py against the reference's own forward under those locks).  Served for the t2v / i2v2_2 / ti2v2_2 block chain;
-        # WanModelHIP refuses the combination with VACE blocks or the Wan2.1 CLIP branch; TeaCache / MagCache run in the plan (fp32 residual, round 5).
+        # tests/test_gpu_mixed.py against the reference's own forward under those locks).  Served for the t2v / i2v2_2 / ti2v2_2 block chain
+        # and (round 6) the Wan2.1 i2v / flf2v CLIP branch; WanModelHIP refuses the combination with VACE blocks; TeaCache / MagCache run in the plan
+        # (fp32 residual, round 5).
         models = [WanModelHIP(device=device, mixed_precision=bool(mixed_precision_transformer), **arch).load_state_dict(sd) for sd in sds[:2]]
         # any2video.py:137-163: VAE_URLs of the model definition (a path, or a list whose first entry the host's file locator resolves),
         # else the family's default file, resolved by the host application's locator (its checkpoint folders are configurable) or, outside
