@@ -272,3 +272,41 @@ def test_any_end_frame_vs_reference_golden(vae):
     assert err <= 1e-2 * refe.abs().max().item() + 1e-3
     body = vae.encode([vid[0][:, :9]])[0].cpu()                        # the first nine frames are the ordinary causal chain
     assert torch.equal(mu[:, :3], body)
+
+
+# ---- a convolution's result must not depend on what else the GPU is doing ----------------------------------------------------------------
+def _conv_repeat_worker(tag, iters, q):
+    try:
+        from wan2gp_amd.vae import WanVAEHIP, random_vae_state_dict
+        n = WanVAEHIP(state_dict=random_vae_state_dict()).net
+        g = torch.Generator().manual_seed(3)
+        bad = {}
+        for name, f32 in (("decoder.head.2", True), ("decoder.middle.0.residual.2", False)):
+            c = n.convs[name]
+            x = (torch.randn(4, 64, 64, c.cin, generator=g) * 0.5).to(torch.float16).cuda()
+            ref = n.conv(x, name, out_f32=f32).clone()
+            bad[name] = sum(int(not torch.equal(n.conv(x, name, out_f32=f32), ref)) for _ in range(iters))
+        q.put((tag, bad))
+    except Exception:
+        import traceback
+        q.put((tag, traceback.format_exc()))
+
+
+def test_halo_convolution_is_reproducible_beside_another_process():
+    """Round 6 (runs 42-47): the halo convolution's weight ring is three stages deep and a stage is refilled one barrier after it was read.  The
+    reads were only ISSUED in front of that barrier -- hipcc parks the consuming MFMA, and with it the lgkmcnt wait, behind it -- so with
+    the LDS queue backed up by another process on the same GPU the refill could land first: a wave's tile of garbage in 1 of 400 launches of
+    the 96-wide tiles, 1 in 6 of the decoder head's 16-channel tile.  Two processes launch the same two convolutions 300 times side by side;
+    every launch must return the first launch's bits."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_conv_repeat_worker, args=(t, 300, q)) for t in ("A", "B")]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for tag, bad in res:
+        assert isinstance(bad, dict), f"{tag}: {bad}"
+        assert all(v == 0 for v in bad.values()), (tag, bad)

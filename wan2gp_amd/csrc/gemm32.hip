@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(const bf16_t* __restrict
     constexpr int J0 = (J); (void)J0;                                                        \
     G32_STAMP(0)                                                                             \
     if (kt + (J) > 0) {                                                                      \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* tile kt+J+1 landed (issued a tile ago) */ \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); /* tile kt+J+1 landed (issued a tile ago); this wave's fragment reads returned (round 6: vae_conv_halo.hip's race) */ \
       G32_STAMP(1)                                                                           \
       __builtin_amdgcn_s_barrier();                                                          \
       asm volatile("" ::: "memory");                                                         \
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void gemm32_kernel(const bf16_t* __restrict
     // tile kt has landed once at most the younger tile's 6 pieces per lane are still in flight
 #define G32_STEP2(J)                                                                         \
   if (__builtin_expect(kt + (J) < nk, 1)) {                                                  \
-    if (kt + (J) + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                  \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+    if (kt + (J) + 1 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");       \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                         \
     __builtin_amdgcn_s_barrier();                                                            \
     asm volatile("" ::: "memory");                                                           \
     if (kt + (J) + 2 < nk) stage(((J) + 2) % 3); /* slot of tile kt+J-1: every wave is past it */ \

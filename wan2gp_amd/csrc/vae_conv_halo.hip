@@ -20,6 +20,8 @@
 //      4 chunks conflict-free from ANY starting row -- the patch windows start anywhere.  The first version (80-byte pixels, no swizzle)
 //      spent half of its LDS cycles in bank conflicts (profiles/r04_vae_conv_pmc_lds_run24.json).
 // MFMA: acc[a][b] += W frag(b) x P frag(a), v_mfma_f32_16x16x32_f16, one k-step per (tap, cb).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) _Float16 halo_f16x8;
@@ -163,8 +165,13 @@ __global__ __launch_bounds__(512, 4) void conv3d_halo_kernel(HaloP p) {
 #define HALO_TAP(TAP)                                                                                                              \
   {                                                                                                                                \
     if ((TAP) > 0 || g > 0) {                                                                                                      \
-      if ((TAP) == 1 || (TAP) == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); /* W(q) landed; W(q+1) and the next patch's three pieces may be out */ \
-      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                                                        \
+      /* lgkmcnt(0): THIS wave's fragment reads of the previous tap have RETURNED before the barrier lets any wave overwrite their ring stage.    */ \
+      /* The MFMAs are builtins: hipcc software-pipelines the loop and parks the consuming MFMA (with its lgkmcnt wait) BELOW the next tap's     */ \
+      /* barrier and DMA issue -- the read was then merely issued when the stage's next weights were on their way.  Beside another process on    */ \
+      /* the same GPU (LDS queue backed up, L2-warm weights back in ~300 cycles) the DMA won: a wave's tile of garbage in 1 of 400 launches of   */ \
+      /* the 96-wide tiles, 1 in 6 of the 16-channel head tile (runs 42-46: tools/probes/vae_conv_determinism.py).                                */ \
+      if ((TAP) == 1 || (TAP) == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); /* W(q) landed; W(q+1) and the next patch's three pieces may be out */ \
+      else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                                                             \
       __builtin_amdgcn_s_barrier();                                                                                                \
       asm volatile("" ::: "memory");                                                                                               \
     }                                                                                                                              \
@@ -266,7 +273,8 @@ int wan_vae_conv3d_halo_launch(const uint16_t* x, const uint16_t* cache0, const 
   // the tile width that pads Cout least: 96 for the 96 / 192 / 384-channel levels (exact), for 160 (192 against 256), for the 32-channel
   // heads and latents; 128 for 128, 256, 640, 1024 ...
   const bool n96 = (Cout + 95) / 96 * 96 < (Cout + 127) / 128 * 128;
-  const bool n16 = Cout <= 16 && KT == 3 && !ups;   // the decoder's head (96 -> 3): one 16-channel tile, every wave on pixels
+  static const bool no16 = [] { const char* e = getenv("WAN_VAE_NO_HEAD16"); return e && e[0] == '1'; }();   // (A/B and bisecting: the 96-wide tile for the head)
+  const bool n16 = Cout <= 16 && KT == 3 && !ups && !no16;   // the decoder's head (96 -> 3): one 16-channel tile, every wave on pixels
   p.tiles_h = (H + HT - 1) / HT; p.tiles_w = (W + HT - 1) / HT; p.tiles_x = n16 ? 1 : (n96 ? (Cout + 95) / 96 : (Cout + 127) / 128);
   const int64_t nwg = (int64_t)Tout * p.tiles_h * p.tiles_w * p.tiles_x;
   if (nwg == 0) return 0;
