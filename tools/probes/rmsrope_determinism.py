@@ -2,6 +2,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if "--lib" in sys.argv:
+    from wan2gp_amd import lib as _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), sys.argv[sys.argv.index("--lib") + 1])
 from wan2gp_amd import ops
 from oracle import wan_oracle as O
 tag, iters = sys.argv[1], int(sys.argv[2])
