@@ -230,9 +230,6 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
   //   P_S: vmcnt(8) (X_{S+1} and everything older landed; Y_{S+2} may fly), lgkmcnt(0) (stage S fully read) + barrier
   //                  MFMAs 16..63: X_{S+2} pieces 0..7 -> slot 2J % 5 (= Y_S, dead now) after MFMA 16,22,..,58; stage S+1's
   //                  k-step-0 fragments -> f0 after MFMA 17,19,..,47
-#ifndef G256M_PROBE
-#define G256M_PROBE 0
-#endif
 #define M_SB() __builtin_amdgcn_sched_barrier(0)
 #define M_STEP(J)                                                                                               \
   if (__builtin_expect(kt + (J) < nk, 1)) {                                                                     \
@@ -249,14 +246,12 @@ __global__ __launch_bounds__(256) void gemm256m_kernel(const bf16_t* __restrict_
     _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                                            \
       mfma256m(acc[m >> 3][m & 7], f1.y[m >> 3], f1.x[m & 7]); M_SB();                                           \
     }                                                                                                           \
-    if (G256M_PROBE == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                           \
-    else if (TY == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                               \
+    if (TY == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                                    \
     else if (TY == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");                               \
     else if (TY == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                               \
     else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");                                            \
     __builtin_amdgcn_s_barrier();                                                                               \
     asm volatile("" ::: "memory");                                                                              \
-    if (G256M_PROBE == 2) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); \
     _Pragma("unroll") for (int m = 16; m < NM; ++m) {                                                           \
       mfma256m(acc[m >> 3][m & 7], f1.y[m >> 3], f1.x[m & 7]); M_SB();                                           \
       if (g256m_k1_piece<TY>(m)) x_piece(DX, (m - 16) / g256m_k1_p<TY>());                                       \
