@@ -1020,3 +1020,76 @@ def test_attention_sp_bound_exceeded_is_recomputed_by_the_tracking_loop(ops):
     got, scratch = ops.attention_sp(cu(qs), cu(k[own]), vt[own].contiguous(), cu(k), vt, own)
     assert (scratch[B * H:-B * H].view(torch.int32) == 1).all()
     assert attn_ok(got, ref), (got.float().cpu() - ref).abs().max().item()
+
+
+# ---- the narrow in-place RMSNorm + RoPE kernel beside processes that come and go on the same GPU (round 6, runs 65-77) ---------------------
+def _rr_victim(seconds, q):
+    try:
+        import time
+        from wan2gp_amd import ops as OPS
+        g = torch.Generator().manual_seed(6)
+        d, grid = 1536, (9, 30, 52)
+        Lt = grid[0] * grid[1] * grid[2]
+        q0 = torch.randn(2, Lt, d, generator=g).to(BF).cuda()
+        wq = (1 + 0.1 * torch.randn(d, generator=g)).to(BF).cuda()
+        cos, sin = [t.cuda() for t in O.rope_tables(grid)]
+
+        def f():
+            x = q0.clone()
+            OPS.rmsnorm_rope_(x, None, wq, wq, freqs=(cos, sin), L=Lt, q_scale=OPS.attention_qscale())
+            return x
+        ref = f().clone()
+        q.put(("ready", 0, 0))
+        bad = n = 0
+        t_end = time.time() + seconds
+        while time.time() < t_end:
+            bad += int(not torch.equal(f(), ref))
+            n += 1
+        q.put(("done", bad, n))
+    except Exception:
+        import traceback
+        q.put(("error", traceback.format_exc(), 0))
+
+
+def _rr_neighbour(q):
+    try:                                                                          # what the reproducer's neighbour did (tools/probes/dit_determinism.py):
+        from wan2gp_amd.model import WanModelHIP                                  # a 2-layer model at the 1.3B widths built, loaded, run, and gone again
+        cfg = O.make_config("t2v_1.3B")
+        cfg.num_layers = 2
+        m = WanModelHIP(model_type=cfg.model_type, dim=cfg.dim, ffn_dim=cfg.ffn_dim, num_heads=cfg.num_heads, num_layers=cfg.num_layers,
+                        in_dim=cfg.in_dim, out_dim=cfg.out_dim).load_state_dict(O.synth_weights(cfg, seed=7))
+        lat, ctx, ctx_null, _ = O.synth_inputs(cfg, 9, 60, 104, seed=3)
+        x, c0, c1 = lat.cuda(), ctx.cuda(), ctx_null.cuda()
+        for _ in range(12):
+            m([x, x], t=torch.tensor([500]), context=[c0, c1])
+        torch.cuda.synchronize()
+        q.put("gone")
+    except Exception:
+        import traceback
+        q.put(traceback.format_exc())
+
+
+def test_rmsnorm_rope_narrow_form_is_reproducible_while_processes_come_and_go():
+    """The narrow in-place form of rmsnorm_rope_kernel (one row per wave: d < 4096) was the one kernel of the library that did not return its bits
+    beside another process: in ~10-ms windows of a neighbour's start-up or exit every tenth launch left ~1 % of its rows with a few wrong
+    16-byte chunks -- the 1.3B forward differed in 10-25 % of its calls when two processes shared the GPU.  It had no LDS
+    and no barrier; with one LDS word per wave and one barrier it returned its bits in 333,066 of 333,066 launches (run 77).  Here: one process
+    launches it in place on fresh copies of fixed rows while two others, one after the other, build a 2-layer model at the 1.3B widths, run it and exit."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, qn = ctx.Queue(), ctx.Queue()
+    victim = ctx.Process(target=_rr_victim, args=(75.0, q))
+    victim.start()
+    msg = q.get(timeout=300)
+    assert msg[0] == "ready", msg
+    for _ in range(2):
+        nb = ctx.Process(target=_rr_neighbour, args=(qn,))
+        nb.start()
+        r = qn.get(timeout=300)
+        assert r == "gone", r
+        nb.join(timeout=60)
+    msg = q.get(timeout=300)
+    victim.join(timeout=60)
+    assert msg[0] == "done", msg
+    print(f"rmsnorm_rope (narrow, in place): {msg[1]} of {msg[2]} launches differ")
+    assert msg[1] == 0 and msg[2] > 1000, msg

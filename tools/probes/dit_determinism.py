@@ -19,7 +19,8 @@ if mode.startswith("force"): L.load().wan_gemm_debug_force_tile_rows(int(mode[5:
 if mode.startswith("L1"): os.environ["_L1"] = "1"
 shapes = (("small", (5, 32, 48)),) if mode != "product" else (("small", (5, 32, 48)), ("t2v_1.3B", (3, 24, 40)))
 if mode.startswith("bigL"): os.environ["_BL"] = mode[4:5]; shapes = (("t2v_1.3B", (9, 60, 104)),)
-if mode == "big": shapes = (("t2v_1.3B", (9, 60, 104)),)          # 14,040 tokens per stream: every Linear a many-tile problem (gemm256m at 256 rows)
+if mode == "big": shapes = (("t2v_1.3B", (9, 60, 104)),)
+if mode == "big14": shapes = (("t2v_14B", (9, 60, 104)),); os.environ["_BL"] = "2"        # the 14B widths (d = 5120: the persistent row kernels), two layers          # 14,040 tokens per stream: every Linear a many-tile problem (gemm256m at 256 rows)
 for name, fhw in shapes:
     cfg = O.make_config(name)
     if name == "t2v_1.3B":

@@ -65,6 +65,19 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? (SCATTER ? 2 :
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+  // The narrow in-place form (one row per wave, no weights in LDS, no address table) had NO LDS and NO barrier -- and was the one kernel of the
+  // library that did not return its bits beside another process on the same GPU: in ~10-ms windows of the neighbour's start-up / exit every
+  // tenth launch left ~1 % of its rows with a few wrong 16-byte chunks (runs 65-76: tools/probes/rmsrope_twice.py, inplace_determinism.py;
+  // the 1.3B forward differed in 10-25 % of its calls, the 14B widths -- the persistent form below, which has both -- never).  The same
+  // arithmetic out of place (SCATTER: LDS table + barrier) was clean in the same loop.  With one LDS word per wave and one barrier in front
+  // of the first load: 0 of 400 forwards against 41 of 200, A-B-A in one call (run 76).  Why a workgroup that shares nothing needs to be a
+  // workgroup is not understood; the barrier costs nothing measurable.
+  if (!PERSIST && !SCATTER) {
+    __shared__ int wg_word[ROWS_PER_BLOCK];
+    if (lane == 0) wg_word[wave] = wave;
+    __syncthreads();
+    asm volatile("" :: "v"(wg_word[wave ^ 1]));
+  }
   if (!PERSIST && !SCATTER && row >= rows) return;
   const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
   const float oscale = (blockIdx.y == 0) ? q_scale : 1.0f;  // q only: fp32 scale folded in front of the ONE bf16 rounding
