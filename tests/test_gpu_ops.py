@@ -1073,7 +1073,9 @@ def test_rmsnorm_rope_narrow_form_is_reproducible_while_processes_come_and_go():
     """The narrow in-place form of rmsnorm_rope_kernel (one row per wave: d < 4096) was the one kernel of the library that did not return its bits
     beside another process: in ~10-ms windows of a neighbour's start-up or exit every tenth launch left ~1 % of its rows with a few wrong
     16-byte chunks -- the 1.3B forward differed in 10-25 % of its calls when two processes shared the GPU.  It had no LDS
-    and no barrier; with one LDS word per wave and one barrier it returned its bits in 333,066 of 333,066 launches (run 77).  Here: one process
+    and no barrier; with one LDS word per wave and one barrier it returned its bits in 333,066 of 333,066 launches (run 77).  Runs 80-84 found what was
+    wrong -- the low result of `v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (RoPE's crosswise products) zero in lanes 48-63 -- and the rotation
+    now works on aligned register pairs (tests/test_isa_invariants.py holds the instruction out of the row kernels).  Here: one process
     launches it in place on fresh copies of fixed rows while two others, one after the other, build a 2-layer model at the 1.3B widths, run it and exit."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")

@@ -263,3 +263,35 @@ def test_no_kernel_of_the_library_spills_to_scratch(tmp_path_factory):
                 offenders.append((unit, m.group(1), int(meta.group(1))))
     assert seen >= 100 and not offenders, offenders
     assert "gemm256m" in asms and asms["gemm256m"].count("gemm256m_kernel") >= 4
+
+
+def test_row_kernels_hold_no_packed_instruction_that_reads_a_register_pair_crosswise(tmp_path_factory):
+    """Round 6, runs 80-85: `v_pk_mul_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]` -- what hipcc's SLP vectoriser made of RoPE's
+    (-x1 sin0, x0 sin1) -- returned a LOW result of zero in lanes 48-63 of a few waves while another process on the same GPU started or exited:
+    every wrong element of the narrow in-place RMSNorm + RoPE launch was x0 cos0 without its - x1 sin0.  The rotation now works on aligned pairs
+    (E = x0 of two pairs, O = x1 of two pairs) and the modulation sums are plain adds, so no kernel of elementwise.hip / mixed_ops.hip holds a
+    packed instruction whose low lane selects a HIGH source register (an op_sel bit) -- except the three timestep-sinusoid kernels, whose sin / cos
+    come from the device library (one launch of a few hundred lanes per forward).  The build of rounds 3-5 (ROPE_FORM 0) is the control."""
+    cross = re.compile(r"^\s*(v_pk_\w+) .*op_sel:\[(?:1,[01]|0,1)\]", re.M)
+
+    def per_kernel(asm):
+        found = collections.Counter()
+        for m in re.finditer(r"^(_Z\S+):", asm, re.M):
+            end = asm.find(".Lfunc_end", m.end())
+            if end > 0:
+                n = len(cross.findall(asm[m.end():end]))
+                if n:
+                    found[m.group(1)] = n
+        return found
+
+    new = per_kernel(asm_of("elementwise", tmp_path_factory))
+    mixed = per_kernel(asm_of("mixed_ops", tmp_path_factory))
+    offenders = {k: n for k, n in {**new, **mixed}.items() if "sinusoid" not in k}
+    assert not offenders, offenders
+    asm = asm_of("elementwise", tmp_path_factory)
+    rope = [m.group(1) for m in re.finditer(r"^(_Z19rmsnorm_rope_kernel\S+):", asm, re.M)]
+    assert len(rope) >= 20
+    body = asm[asm.index(rope[0] + ":"):]
+    assert body[:body.index(".Lfunc_end")].count("v_pk_mul_f32") >= 8          # the packed design is still there, on aligned pairs
+    old = per_kernel(asm_of("elementwise", tmp_path_factory, defines=("-DROPE_FORM=0",)))
+    assert sum(n for k, n in old.items() if "rmsnorm_rope_kernel" in k) >= 500   # the control: the pair-wise form does produce the instruction

@@ -45,6 +45,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f
 // round a float through bf16 (value of the bf16 the reference would have stored)
 __device__ __forceinline__ float rbf(float f) { return __uint_as_float(pack2bf(f, 0.f) << 16); }
 
+// ---- fp32 products / sums hipcc must NOT fuse into a packed instruction that reads a register pair crosswise ------------------------
+// Round 6, runs 80-83: `v_pk_mul_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]` (low result = a.lo * b.HI, high result = a.hi * b.LO -- what the
+// SLP vectoriser makes of RoPE's (-x1 sin0, x0 sin1)) returned a low result of ZERO in lanes 48-63 of a few waves while another process on
+// the same GPU started or exited: every wrong element of the narrow in-place RMSNorm + RoPE launch was exactly x0 cos0 without its
+// - x1 sin0 (2,533 of 2,533 in a dump; odd elements, other lanes: never).  With the two products as plain v_mul_f32 the same LDS-less kernel
+// returned its bits in 385,549 of 385,549 launches; onto another register pair the packed form still failed.  So the library contains no
+// packed-f32 instruction whose LOW lane selects a HIGH source register or the reverse (tests/test_isa_invariants.py); same IEEE operations, same bits.
+__device__ __forceinline__ float wan_mul_f32(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float wan_add_f32(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // ---- fp16 <-> f32 (VAE path) ---------------------------------------------------------------------
 __device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }

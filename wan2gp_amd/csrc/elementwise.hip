@@ -16,6 +16,12 @@
 
 #define ROWS_PER_BLOCK 4  // 4 waves of 64 lanes
 
+#ifndef RMSROPE_WG
+#define RMSROPE_WG 3
+#endif
+#ifndef ROPE_FORM
+#define ROPE_FORM 1
+#endif
 // ------------------------------------------------------------------------------------------------
 // RMSNorm(q,k) + RoPE  -- model.py:160-175, posemb_layers.py:251-269
 // ------------------------------------------------------------------------------------------------
@@ -37,14 +43,19 @@ __device__ __forceinline__ void load_row(uint4 (&r)[NCH], const bf16_t* x, int l
 }
 
 // x0' = x0*cos0 - x1*sin0 ; x1' = x1*cos1 + x0*sin1 -- fp32, the four products rounded SEPARATELY (posemb_layers.py:251-267: no fused
-// multiply-add), one bf16 rounding by the caller.  Written on pairs so that hipcc emits two v_pk_mul_f32 and one v_pk_add_f32.
+// multiply-add), one bf16 rounding by the caller.  The pair-wise form of rounds 3-5: only diagnostics builds (ROPE_FORM 0 / 2) call it.
 __device__ __forceinline__ wan_f32x2 rope_pair(wan_f32x2 y, float c0, float c1, float s0, float s1) {
 #pragma clang fp contract(off)
   const wan_f32x2 cc = {c0, c1};
   const wan_f32x2 ss = {-s0, s1};
-  const wan_f32x2 ys = {y.y, y.x};
   const wan_f32x2 p = y * cc;
+#if ROPE_FORM == 2     // diagnostics: the packed crosswise multiply, but never onto its own source pair
+  wan_f32x2 q;
+  asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=&v"(q) : "v"(ss), "v"(y));
+#else                  // hipcc fuses this into v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0]
+  const wan_f32x2 ys = {y.y, y.x};
   const wan_f32x2 q = ys * ss;      // (-x1*sin0, x0*sin1): the sign flip of a product is exact
+#endif
   return p + q;
 }
 
@@ -67,16 +78,18 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? (SCATTER ? 2 :
   int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
   // The narrow in-place form (one row per wave, no weights in LDS, no address table) had NO LDS and NO barrier -- and was the one kernel of the
   // library that did not return its bits beside another process on the same GPU: in ~10-ms windows of the neighbour's start-up / exit every
-  // tenth launch left ~1 % of its rows with a few wrong 16-byte chunks (runs 65-76: tools/probes/rmsrope_twice.py, inplace_determinism.py;
-  // the 1.3B forward differed in 10-25 % of its calls, the 14B widths -- the persistent form below, which has both -- never).  The same
-  // arithmetic out of place (SCATTER: LDS table + barrier) was clean in the same loop.  With one LDS word per wave and one barrier in front
-  // of the first load: 0 of 400 forwards against 41 of 200, A-B-A in one call (run 76).  Why a workgroup that shares nothing needs to be a
-  // workgroup is not understood; the barrier costs nothing measurable.
-  if (!PERSIST && !SCATTER) {
-    __shared__ int wg_word[ROWS_PER_BLOCK];
-    if (lane == 0) wg_word[wave] = wave;
-    __syncthreads();
-    asm volatile("" :: "v"(wg_word[wave ^ 1]));
+  // tenth launch left ~1 % of its rows with a few wrong 16-byte chunks (runs 65-85; the 1.3B forward differed in 10-25 % of its calls, the 14B
+  // widths -- the persistent form below -- never).  What was wrong (run 82): in lanes 48-63 the EVEN element of a rotation pair came out as
+  // x0 cos0 without its - x1 sin0 -- the low result of the packed crosswise multiply (common.h), which the rotation no longer contains (run 84:
+  // 0 of 316,187 launches without the LDS word, 58 of 310,685 with the old rotation).  Found first, and kept: one LDS word per wave (the word
+  // cures the old rotation by itself, the barrier alone does not: run 80) -- why a workgroup's LDS allocation shields that instruction is not
+  // understood; it costs nothing measurable.
+  // (RMSROPE_WG, diagnostics only -- `make rrwg`: 1 = the LDS word without the barrier, 2 = the barrier without LDS, 0 = neither, the form of rounds 3-5)
+  if (!PERSIST && !SCATTER && RMSROPE_WG) {
+    __shared__ int wg_word[(RMSROPE_WG & 1) ? ROWS_PER_BLOCK : 1];
+    if ((RMSROPE_WG & 1) && lane == 0) wg_word[wave] = wave;
+    if (RMSROPE_WG & 2) __syncthreads();
+    if (RMSROPE_WG & 1) asm volatile("" :: "v"(wg_word[wave ^ 1]));
   }
   if (!PERSIST && !SCATTER && row >= rows) return;
   const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
@@ -165,6 +178,36 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? (SCATTER ? 2 :
         const uint32_t ww[4] = {wraw.x, wraw.y, wraw.z, wraw.w};
         const uint32_t vw[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
         uint32_t ow[4];
+#if ROPE_FORM == 1
+        // Two words (= two rotation pairs A, B) at a time, as E = (x0 of A, x0 of B) and O = (x1 of A, x1 of B): every multiply and add of the
+        // row is then a packed-f32 instruction on ALIGNED register pairs -- x0' = E C0 + O (-S0), x1' = O C1 + E S1 -- where the pair-wise form
+        // (rounds 3-5, below) needed (-x1 sin0, x0 sin1): v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0], the instruction that lost its low product
+        // beside a neighbour process (common.h).  Same operations per element, same roundings: identical bytes (tools/rows_hash.py).
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma clang fp contract(off)
+          const uint32_t va = vw[2 * h], vb = vw[2 * h + 1], wa = ww[2 * h], wb = ww[2 * h + 1];
+          wan_f32x2 E = {__uint_as_float(va << 16), __uint_as_float(vb << 16)};
+          wan_f32x2 O = {__uint_as_float(va & 0xffff0000u), __uint_as_float(vb & 0xffff0000u)};
+          const wan_f32x2 WE = {__uint_as_float(wa << 16), __uint_as_float(wb << 16)};
+          const wan_f32x2 WO = {__uint_as_float(wa & 0xffff0000u), __uint_as_float(wb & 0xffff0000u)};
+          E = E * r; O = O * r;                                        // x *= rsqrt
+          uint32_t ua = pack2bf(E.x, O.x), ub = pack2bf(E.y, O.y);     // bf16 rounding
+          E = wan_f32x2{__uint_as_float(ua << 16), __uint_as_float(ub << 16)} * WE;   // x *= weight
+          O = wan_f32x2{__uint_as_float(ua & 0xffff0000u), __uint_as_float(ub & 0xffff0000u)} * WO;
+          ua = pack2bf(E.x, O.x); ub = pack2bf(E.y, O.y);
+          E = wan_f32x2{__uint_as_float(ua << 16), __uint_as_float(ub << 16)};
+          O = wan_f32x2{__uint_as_float(ua & 0xffff0000u), __uint_as_float(ub & 0xffff0000u)};
+          if (ROPE) {
+            const wan_f32x2 C0 = {cs[4 * h], cs[4 * h + 2]}, C1 = {cs[4 * h + 1], cs[4 * h + 3]};
+            const wan_f32x2 NS0 = {-sn[4 * h], -sn[4 * h + 2]}, S1 = {sn[4 * h + 1], sn[4 * h + 3]};   // the sign flip of a product is exact
+            const wan_f32x2 pe = E * C0, qe = O * NS0, po = O * C1, qo = E * S1;   // four products rounded separately (posemb_layers.py:251-267)
+            E = pe + qe; O = po + qo;
+          }
+          E = E * oscale; O = O * oscale;                              // (x * 1.0f is x: no select on a launch constant inside the row)
+          ow[2 * h] = pack2bf(E.x, O.x); ow[2 * h + 1] = pack2bf(E.y, O.y);
+        }
+#else   // ROPE_FORM 0 / 2: the pair-wise form of rounds 3-5 (diagnostics, `make rrwg`)
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq) {
           wan_f32x2 v2 = {__uint_as_float(vw[pq] << 16), __uint_as_float(vw[pq] & 0xffff0000u)};
@@ -178,6 +221,7 @@ __global__ __launch_bounds__(256, (PERSIST && FULL && NCH <= 10 ? (SCATTER ? 2 :
           y2 = y2 * oscale;                                            // (x * 1.0f is x: no select on a launch constant inside the row)
           ow[pq] = pack2bf(y2.x, y2.y);
         }
+#endif
         uint4 o;
         o.x = ow[0]; o.y = ow[1]; o.z = ow[2]; o.w = ow[3];
         if (SCATTER) {
@@ -276,8 +320,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float ln = rbf((v[j] - mean) * rstd);           // F.layer_norm -> bf16
-            const float sc = rbf(1.0f + rbf(msc[j] + esc[j]));    // 1 + e[scale]    (bf16 ops)
-            const float sh = rbf(msh[j] + esh[j]);                // e[shift]
+            const float sc = rbf(1.0f + rbf(wan_add_f32(msc[j], esc[j])));    // 1 + e[scale]    (bf16 ops; plain adds: common.h)
+            const float sh = rbf(wan_add_f32(msh[j], esh[j]));                // e[shift]
             y[j] = rbf(ln * sc) + sh;                             // x *= 1+scale ; x += shift
           }
         } else if (MODE == 3) {
@@ -354,7 +398,7 @@ __global__ __launch_bounds__(256) void gated_residual_kernel(
       unpack8(*reinterpret_cast<const uint4*>(mod + (int64_t)gate_idx * d + c * 8), m);
       unpack8(*reinterpret_cast<const uint4*>(e + (b * n_mod + gate_idx) * (int64_t)d + c * 8), ev);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g[j] = rbf(m[j] + ev[j]);
+      for (int j = 0; j < 8; ++j) g[j] = rbf(wan_add_f32(m[j], ev[j]));   // (a plain add: common.h)
 #pragma unroll
       for (int j = 0; j < 8; ++j) xv[j] = xv[j] + yv[j] * g[j];
     } else {
@@ -669,8 +713,8 @@ __global__ __launch_bounds__(256) void mod_table_kernel(const bf16_t* __restrict
   unpack8(*reinterpret_cast<const uint4*>(eb + (int64_t)scale_idx * d + c * 8), esc);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sc[j] = rbf(1.0f + rbf(msc[j] + esc[j]));
-    sh[j] = rbf(msh[j] + esh[j]);
+    sc[j] = rbf(1.0f + rbf(wan_add_f32(msc[j], esc[j])));   // (plain adds: common.h)
+    sh[j] = rbf(wan_add_f32(msh[j], esh[j]));
   }
   *reinterpret_cast<uint4*>(tab + (int64_t)b * 2 * d + c * 8) = pack8(sc);
   *reinterpret_cast<uint4*>(tab + (int64_t)b * 2 * d + d + c * 8) = pack8(sh);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, (NV >= 12 ? 3 : 4)) void mx_ln_kernel(const fl
     for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + lane * 4 + i * 256);
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    for (int i = 0; i < NV; ++i) s += wan_add_f32(wan_add_f32(v[i].x, v[i].y), wan_add_f32(v[i].z, v[i].w));   // (plain adds: common.h)
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, (NV >= 12 ? 3 : 4)) void mx_ln_kernel(const fl
   float s = 0.f;
   for (int c = lane * 4; c < d; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xr + c);
-    s += (v.x + v.y) + (v.z + v.w);
+    s += wan_add_f32(wan_add_f32(v.x, v.y), wan_add_f32(v.z, v.w));
   }
   const float mean = wave_sum(s) / (float)d;
   float q = 0.f;
