@@ -18,7 +18,17 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 
 
+_ASM = {}
+
+
 def asm_of(name, tmp_path_factory, defines=()):
+    key = (name, tuple(defines))
+    if key not in _ASM:
+        _ASM[key] = _asm_of(name, tmp_path_factory, defines)
+    return _ASM[key]
+
+
+def _asm_of(name, tmp_path_factory, defines=()):
     out = tmp_path_factory.mktemp("isa") / (name + ".s")
     src = os.path.join(ROOT, "wan2gp_amd", "csrc", name + ".hip")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-ffp-contract=on", *defines,
@@ -266,32 +276,41 @@ def test_no_kernel_of_the_library_spills_to_scratch(tmp_path_factory):
 
 
 def test_row_kernels_hold_no_packed_instruction_that_reads_a_register_pair_crosswise(tmp_path_factory):
-    """Round 6, runs 80-85: `v_pk_mul_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]` -- what hipcc's SLP vectoriser made of RoPE's
+    """Round 6, runs 80-86: `v_pk_mul_f32 d, a, b op_sel:[0,1] op_sel_hi:[1,0]` -- what hipcc's SLP vectoriser made of RoPE's
     (-x1 sin0, x0 sin1) -- returned a LOW result of zero in lanes 48-63 of a few waves while another process on the same GPU started or exited:
-    every wrong element of the narrow in-place RMSNorm + RoPE launch was x0 cos0 without its - x1 sin0.  The rotation now works on aligned pairs
-    (E = x0 of two pairs, O = x1 of two pairs) and the modulation sums are plain adds, so no kernel of elementwise.hip / mixed_ops.hip holds a
-    packed instruction whose low lane selects a HIGH source register (an op_sel bit) -- except the three timestep-sinusoid kernels, whose sin / cos
-    come from the device library (one launch of a few hundred lanes per forward).  The build of rounds 3-5 (ROPE_FORM 0) is the control."""
-    cross = re.compile(r"^\s*(v_pk_\w+) .*op_sel:\[(?:1,[01]|0,1)\]", re.M)
+    every wrong element of the narrow in-place RMSNorm + RoPE launch was x0 cos0 without its - x1 sin0.  One LDS word per wave shielded it (not
+    understood); the rotation now works on aligned pairs (E = x0 of two pairs, O = x1 of two pairs) and the modulation sums are plain adds.  Held here:
+    (1) no kernel of elementwise.hip / mixed_ops.hip holds a packed instruction whose LOW lane selects a HIGH source register (an op_sel bit), except
+    the three timestep-sinusoid kernels (the device library's sin / cos), which hold an LDS word; (2) in the whole library every kernel that holds
+    such an instruction is an LDS-holding workgroup; (3) the control: the build of rounds 3-5 (ROPE_FORM 0) does compile to the instruction."""
+    import concurrent.futures as cf
+    import glob
+    cross = re.compile(r"^\s*(v_pk_\w+) .*op_sel:\[[01,]*1[01,]*\]", re.M)
 
     def per_kernel(asm):
-        found = collections.Counter()
+        found = {}
         for m in re.finditer(r"^(_Z\S+):", asm, re.M):
             end = asm.find(".Lfunc_end", m.end())
             if end > 0:
                 n = len(cross.findall(asm[m.end():end]))
                 if n:
-                    found[m.group(1)] = n
+                    found[m.group(1)] = (n, int(re.search(r"; LDSByteSize: (\d+)", asm[end:end + 6000]).group(1)))
         return found
 
-    new = per_kernel(asm_of("elementwise", tmp_path_factory))
-    mixed = per_kernel(asm_of("mixed_ops", tmp_path_factory))
-    offenders = {k: n for k, n in {**new, **mixed}.items() if "sinusoid" not in k}
-    assert not offenders, offenders
-    asm = asm_of("elementwise", tmp_path_factory)
+    srcs = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(ROOT, "wan2gp_amd", "csrc", "*.hip")))
+    with cf.ThreadPoolExecutor(max_workers=8) as ex:
+        asms = dict(zip(srcs, ex.map(lambda n: asm_of(n, tmp_path_factory), srcs)))
+    found = {unit: per_kernel(asm) for unit, asm in asms.items()}
+    rows = {k: v for unit in ("elementwise", "mixed_ops") for k, v in found[unit].items()}
+    assert sorted(k for k in rows if "sinusoid" not in k) == [], rows                                   # (1)
+    assert len(rows) == 3 and all(lds > 0 for _, lds in rows.values()), rows
+    without_lds = {(unit, k): v for unit, ks in found.items() for k, v in ks.items() if v[1] == 0}
+    assert not without_lds, without_lds                                                                 # (2)
+    assert sum(len(ks) for ks in found.values()) >= 10                                                  # (the pattern still finds the GEMM / VAE ones)
+    asm = asms["elementwise"]
     rope = [m.group(1) for m in re.finditer(r"^(_Z19rmsnorm_rope_kernel\S+):", asm, re.M)]
     assert len(rope) >= 20
     body = asm[asm.index(rope[0] + ":"):]
     assert body[:body.index(".Lfunc_end")].count("v_pk_mul_f32") >= 8          # the packed design is still there, on aligned pairs
     old = per_kernel(asm_of("elementwise", tmp_path_factory, defines=("-DROPE_FORM=0",)))
-    assert sum(n for k, n in old.items() if "rmsnorm_rope_kernel" in k) >= 500   # the control: the pair-wise form does produce the instruction
+    assert sum(n for k, (n, _) in old.items() if "rmsnorm_rope_kernel" in k) >= 500                      # (3)

@@ -54,6 +54,14 @@ __device__ __forceinline__ float rbf(float f) { return __uint_as_float(pack2bf(f
 // packed-f32 instruction whose LOW lane selects a HIGH source register or the reverse (tests/test_isa_invariants.py); same IEEE operations, same bits.
 __device__ __forceinline__ float wan_mul_f32(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float wan_add_f32(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// Where such an instruction cannot be written away (the device library's sin / cos in the timestep-sinusoid kernels) the kernel holds one LDS word:
+// the allocation alone shielded the old rotation (run 80: 0 of 379,910 launches with the word and no barrier, 119 of 383,085 without).  Call it
+// first, in front of any return; every other kernel of the library that holds one is an LDS-holding workgroup already (tests/test_isa_invariants.py).
+__device__ __forceinline__ void wan_hold_lds_word() {
+  __shared__ int wan_lds_word;
+  if (threadIdx.x == 0) wan_lds_word = 0;
+  asm volatile("" :: "v"(wan_lds_word));
+}
 
 // ---- fp16 <-> f32 (VAE path) ---------------------------------------------------------------------
 __device__ __forceinline__ float h2f(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }

@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256) void nag_combine_kernel(const bf16_t* x_pos, c
 // ------------------------------------------------------------------------------------------------
 __global__ void sinusoid_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int n, int dim) {
   // cat([cos(t * 10000^(-i/half)), sin(...)])   model.py:32-42
+  wan_hold_lds_word();   // (common.h: cosf / sinf hold packed instructions that read a register pair crosswise)
   const int half = dim / 2;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * half) return;
@@ -478,6 +479,7 @@ __global__ void sinusoid_kernel(const float* __restrict__ t, bf16_t* __restrict_
 }
 
 __global__ void sinusoid_val_kernel(float tval, bf16_t* __restrict__ out, int dim) {
+  wan_hold_lds_word();
   const int half = dim / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= half) return;

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void mx_gated_residual_kernel(float* __restric
 }
 
 __global__ void mx_sinusoid_kernel(float tval, float* __restrict__ out, int dim) {
+  wan_hold_lds_word();   // (common.h)
   const int half = dim / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= half) return;
